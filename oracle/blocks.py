@@ -1,0 +1,168 @@
+"""Oracle building blocks: functional restatements over a flat parameter dict `P` and a key prefix.
+
+Channel-major tensors [B, C, T] throughout.  Reference citations are relative to
+/root/reference/src/stylish_tts/train/models/.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def wn_weight(P, name):
+    """weight_norm effective weight w = g * v / ||v|| (norm over all dims but 0).
+
+    torch.nn.utils.parametrizations.weight_norm as applied at ada_norm.py:17-84, decoder.py:37-49.
+    """
+    g = P[name + ".parametrizations.weight.original0"]
+    v = P[name + ".parametrizations.weight.original1"]
+    n = v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+    return g * v / n
+
+
+def sn_weight(P, name):
+    """old-hook spectral_norm in eval mode: weight_orig / (u . W v)  (mel_style_encoder.py:18-39,87-93)."""
+    w = P[name + ".weight_orig"]
+    u, v = P[name + ".weight_u"], P[name + ".weight_v"]
+    sigma = torch.dot(u, torch.mv(w.flatten(1), v))
+    return w / sigma
+
+
+def style_affine(P, name, style):
+    """fc(style) -> (gamma, beta), each [B, C]   (ada_norm.py:135-138, 204-207)."""
+    h = F.linear(style, P[name + ".fc.weight"], P[name + ".fc.bias"])
+    return torch.chunk(h, 2, dim=1)
+
+
+def adain(P, name, x, style, eps=1e-5):
+    """AdaptiveInstance: (1+gamma) * InstanceNorm1d(x) + beta, biased var over T (ada_norm.py:129-140)."""
+    gamma, beta = style_affine(P, name, style)
+    mean = x.mean(dim=2, keepdim=True)
+    var = x.var(dim=2, keepdim=True, unbiased=False)
+    xn = (x - mean) / torch.sqrt(var + eps)
+    return (1 + gamma[:, :, None]) * xn + beta[:, :, None]
+
+
+def adaln(P, name, x, style, eps=1e-5):
+    """AdaptiveLayerNorm on [B,C,T]: layer_norm over C (no affine) then style affine (ada_norm.py:195-211)."""
+    gamma, beta = style_affine(P, name, style)
+    xn = F.layer_norm(x.transpose(1, 2), (x.shape[1],), eps=eps).transpose(1, 2)
+    return (1 + gamma[:, :, None]) * xn + beta[:, :, None]
+
+
+def chan_layer_norm(x, w, b, eps):
+    """nn.LayerNorm(C) applied over the channel axis of [B,C,T] (generator.py:756-758,770-773,776-778,886-887)."""
+    return F.layer_norm(x.transpose(1, 2), (x.shape[1],), w, b, eps).transpose(1, 2)
+
+
+def snake(x, alpha):
+    """x + sin^2(alpha x) / alpha with alpha broadcast over channels (conv_next.py:78, ada_norm.py:114)."""
+    return x + (1.0 / alpha) * torch.sin(alpha * x) ** 2
+
+
+def grn_scale(h, gamma, eps=1e-6):
+    """GRN over *time*: s[b,c] = 1 + gamma[c] * gx/(mean_c gx + eps), gx = ||h[b,c,:]||_2 (conv_next.py:15-18).
+
+    GRN(h) = gamma*(h*nx) + beta + h = h * s + beta.
+    """
+    gx = h.norm(p=2, dim=2)  # [B, 4C]
+    nx = gx / (gx.mean(dim=1, keepdim=True) + eps)
+    return 1 + gamma.view(1, -1) * nx
+
+
+def convnext_block(P, p, x, style, want=None):
+    """GeneratorConvNeXtBlock on [B,C,T] (conv_next.py:80-93)."""
+    C = x.shape[1]
+    h = F.conv1d(x, P[p + ".dwconv.weight"], P[p + ".dwconv.bias"], padding=3, groups=C)
+    h = adaln(P, p + ".norm", h, style, eps=1e-6)
+    h = F.conv1d(h, P[p + ".pwconv1.weight"][:, :, None], P[p + ".pwconv1.bias"])
+    h = snake(h, P[p + ".snake"].view(1, -1, 1))
+    s = grn_scale(h, P[p + ".grn.gamma"])
+    if want is not None:
+        want[p + ".grn_scale"] = s
+    h = h * s[:, :, None] + P[p + ".grn.beta"].view(1, -1, 1)
+    h = F.conv1d(h, P[p + ".pwconv2.weight"][:, :, None], P[p + ".pwconv2.bias"])
+    return x + h
+
+
+def gen_resblock(P, p, x, style):
+    """AdaptiveGeneratorBlock(k=11, dil 1/3/5) (ada_norm.py:109-120)."""
+    for i, d in enumerate((1, 3, 5)):
+        xt = adain(P, f"{p}.adain1.{i}", x, style)
+        xt = snake(xt, P[f"{p}.alpha1.{i}"])
+        xt = F.conv1d(xt, wn_weight(P, f"{p}.convs1.{i}"), P[f"{p}.convs1.{i}.bias"], padding=5 * d, dilation=d)
+        xt = adain(P, f"{p}.adain2.{i}", xt, style)
+        xt = snake(xt, P[f"{p}.alpha2.{i}"])
+        xt = F.conv1d(xt, wn_weight(P, f"{p}.convs2.{i}"), P[f"{p}.convs2.{i}.bias"], padding=5)
+        x = xt + x
+    return x
+
+
+def decoder_block(P, p, x, style):
+    """AdaptiveDecoderBlock: AdaIN -> LeakyReLU(0.2) -> wn conv k3, twice; learned 1x1 shortcut; /sqrt2
+    (ada_norm.py:172-192)."""
+    h = adain(P, p + ".norm1", x, style)
+    h = F.leaky_relu(h, 0.2)
+    h = F.conv1d(h, wn_weight(P, p + ".conv1"), P[p + ".conv1.bias"], padding=1)
+    h = adain(P, p + ".norm2", h, style)
+    h = F.leaky_relu(h, 0.2)
+    h = F.conv1d(h, wn_weight(P, p + ".conv2"), P[p + ".conv2.bias"], padding=1)
+    sc = x
+    if (p + ".conv1x1.parametrizations.weight.original0") in P:
+        sc = F.conv1d(x, wn_weight(P, p + ".conv1x1"))
+    return (h + sc) / math.sqrt(2)
+
+
+def decoder(P, p, asr, f0_curve, energy, style, voiced):
+    """Decoder.forward in eval mode (decoder.py:77-90; the train-mode random smoothing :53-75 is off)."""
+    f0 = F.conv1d(f0_curve[:, None], wn_weight(P, p + ".F0_conv"), P[p + ".F0_conv.bias"], padding=1)
+    n = F.conv1d(energy[:, None], wn_weight(P, p + ".N_conv"), P[p + ".N_conv.bias"], padding=1)
+    v = F.conv1d(voiced[:, None], wn_weight(P, p + ".voiced_conv"), P[p + ".voiced_conv.bias"], padding=1)
+    x = torch.cat([asr, f0, n, v], dim=1)
+    x = decoder_block(P, p + ".encode", x, style)
+    res = F.conv1d(asr, wn_weight(P, p + ".asr_res.0"), P[p + ".asr_res.0.bias"])
+    for i in range(4):
+        x = torch.cat([x, res, f0, n, v], dim=1)
+        x = decoder_block(P, f"{p}.decode.{i}", x, style)
+    return x
+
+
+def conformer_block(P, p, x, style, bn_eps=1e-5):
+    """ConformerBlock on [B,C,T] in eval mode (conformer.py:242-250, 111-144, 176-193)."""
+    C = x.shape[1]
+
+    def ff(name, z):
+        z = adaln(P, f"{p}.{name}.fn.norm", z, style)
+        z = F.conv1d(z, P[f"{p}.{name}.fn.fn.net.0.weight"][:, :, None], P[f"{p}.{name}.fn.fn.net.0.bias"])
+        z = z * torch.sigmoid(z)
+        return F.conv1d(z, P[f"{p}.{name}.fn.fn.net.3.weight"][:, :, None], P[f"{p}.{name}.fn.fn.net.3.bias"])
+
+    x_ff1 = 0.5 * ff("ff1", x) + x
+    # attention is applied to x (not x_ff1), conformer.py:243-246
+    z = adaln(P, p + ".attn.norm", x, style)
+    q = F.conv1d(z, P[p + ".attn.fn.to_q.weight"][:, :, None])
+    kv = F.conv1d(z, P[p + ".attn.fn.to_kv.weight"][:, :, None])
+    k, v = kv.chunk(2, dim=1)
+    B, _, T = q.shape
+    heads, dh = 8, 64
+    qh = q.view(B, heads, dh, T).transpose(2, 3)
+    kh = k.view(B, heads, dh, T).transpose(2, 3)
+    vh = v.view(B, heads, dh, T).transpose(2, 3)
+    att = torch.softmax(qh @ kh.transpose(2, 3) * dh ** -0.5, dim=-1)
+    o = (att @ vh).transpose(2, 3).reshape(B, heads * dh, T)
+    o = F.conv1d(o, P[p + ".attn.fn.to_out.weight"][:, :, None], P[p + ".attn.fn.to_out.bias"])
+    x = o + x_ff1
+    # conv module
+    z = adaln(P, p + ".conv.norm", x, style)
+    z = F.conv1d(z, P[p + ".conv.net.1.weight"], P[p + ".conv.net.1.bias"])
+    a, gate = z.chunk(2, dim=1)
+    z = a * torch.sigmoid(gate)
+    z = F.conv1d(F.pad(z, (15, 15)), P[p + ".conv.net.3.conv.weight"], P[p + ".conv.net.3.conv.bias"], groups=z.shape[1])
+    z = (z - P[p + ".conv.net.4.running_mean"][None, :, None]) / torch.sqrt(
+        P[p + ".conv.net.4.running_var"][None, :, None] + bn_eps
+    ) * P[p + ".conv.net.4.weight"][None, :, None] + P[p + ".conv.net.4.bias"][None, :, None]
+    z = z * torch.sigmoid(z)
+    z = F.conv1d(z, P[p + ".conv.net.6.weight"], P[p + ".conv.net.6.bias"])
+    x = z + x
+    x = 0.5 * ff("ff2", x) + x
+    return adaln(P, p + ".post_norm", x, style)
