@@ -1,0 +1,140 @@
+/* libstylish_hip.so -- C ABI of the MI355X (gfx950) acoustic hot path of stylish-tts.
+ *
+ * The reference has no FFI: its boundary is torch.nn.Module forward() signatures plus state_dict key
+ * names.  This ABI sits directly underneath those modules: a model object is
+ * created per reference module, its parameters are bound BY THE REFERENCE'S state_dict KEY, and one entry
+ * point per reference forward() runs the whole module on the caller's HIP stream.  Plain pointers and
+ * sizes only; no torch types.  All activations are fp32, contiguous, channel-major [B, C, T].
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative sty_status; sty_last_error() gives the text.
+ *   - all pointers are DEVICE pointers unless the name ends in _host.
+ *   - every entry point is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - the caller owns inputs, outputs and the workspace; the library owns only the prepared (repacked)
+ *     weight arena of each model, allocated once in sty_model_finalize().
+ *   - there is NO CPU fallback: without a HIP device every compute entry point returns STY_EHIP.
+ */
+#ifndef STYLISH_HIP_H
+#define STYLISH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  STY_OK = 0,
+  STY_EINVAL = -1, /* bad argument / unknown key */
+  STY_ESHAPE = -2, /* tensor shape does not match the module's manifest */
+  STY_EHIP = -3,   /* HIP runtime error (incl. no device) */
+  STY_ENOMEM = -4, /* workspace too small */
+  STY_ESTATE = -5  /* call order violated (e.g. forward before finalize) */
+} sty_status;
+
+typedef struct sty_model sty_model;
+
+int sty_version(void);
+const char *sty_last_error(void);
+
+/* ---- model objects -------------------------------------------------------------------------------
+ * kind: "speech_predictor"   = train/models/speech_predictor.py:10-73 (text_encoder + decoder + generator)
+ *       "mel_style_encoder"  = train/models/mel_style_encoder.py:121-152
+ * Dimensions are taken from the bound tensors' shapes (train/config/model.yml defaults are checked).   */
+int sty_model_create(const char *kind, sty_model **out);
+void sty_model_destroy(sty_model *m);
+/* Bind one state_dict entry by its reference key, e.g.
+ *   "generator.basegen.phase_convnext.3.pwconv1.weight"  (SURVEY.md Appendix B).
+ * The pointer must stay valid and may be updated in place by the optimiser between calls.            */
+int sty_model_bind(sty_model *m, const char *key, const float *ptr, int ndim, const int64_t *shape);
+/* Check that every key of the module's manifest is bound, allocate the prepared-weight arena.        */
+int sty_model_finalize(sty_model *m);
+/* Number of keys the manifest expects / i-th key (for binding loops and for tests).                  */
+int sty_model_num_keys(const sty_model *m);
+const char *sty_model_key(const sty_model *m, int i);
+/* Re-derive effective weights (weight_norm g*v/|v|, spectral_norm W/sigma, MFMA operand packing, folded
+ * GRN beta) from the bound parameters.  Call after every optimiser step; once for inference.          */
+int sty_model_prepare(sty_model *m, void *stream);
+
+/* ---- vocoder: MultiGenerator.forward (train/models/generator.py:884-901) -------------------------
+ * mel [B,128,T], style [B,64], pitch [B,T], voiced [B,T]  ->  audio [B,1,300*T].
+ * noise [B,300*T,9] is SineGen's randn draw (generator.py:440-442), explicit for parity; if NULL a
+ *   counter-based generator seeded with `seed` is used instead.
+ * prior_override [B,300*T] (optional) replaces the harmonic source output (generator.py:722).        */
+typedef struct {
+  int B, T;
+  const float *mel, *style, *pitch, *voiced, *noise, *prior_override;
+  uint64_t seed;
+  float *audio;
+  /* optional taps for parity tests (NULL = not written) */
+  float *tap_conformer_out; /* [B,256,T]   */
+  float *tap_prior;         /* [B,300T]    */
+  float *tap_har_spec;      /* [B,32,75T]  */
+  float *tap_har_phase;     /* [B,32,75T]  */
+  float *tap_logamp_prior;  /* [B,32,75T]  */
+  float *tap_phase_prior;   /* [B,32,75T]  */
+  float *tap_trunk;         /* [B,32,75T]  */
+  float *tap_logamp;        /* [B,32,75T]  */
+} sty_vocoder_io;
+int sty_vocoder_workspace_bytes(const sty_model *m, int B, int T, size_t *bytes);
+int sty_vocoder_fwd(sty_model *m, const sty_vocoder_io *io, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- SpeechPredictor.forward (train/models/speech_predictor.py:47-73) ----------------------------
+ * texts [B,L] int64, text_lengths [B] int64, alignment [B,L,T], pitch/energy/voiced [B,T], style [B,64].
+ * denormal_pitch [B,T] feeds the harmonic source (speech_predictor.py:69).                           */
+typedef struct {
+  int B, L, T;
+  const int64_t *texts, *text_lengths;
+  const float *alignment, *pitch, *energy, *voiced, *style, *denormal_pitch, *noise, *prior_override;
+  uint64_t seed;
+  float *audio;
+  float *tap_text_encoding; /* [B,128,L] */
+  float *tap_decoder_out;   /* [B,128,T] */
+  sty_vocoder_io voc_taps;  /* only the tap_* fields are read */
+} sty_speech_io;
+int sty_speech_workspace_bytes(const sty_model *m, int B, int L, int T, size_t *bytes);
+int sty_speech_fwd(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- MelStyleEncoder.forward (train/models/mel_style_encoder.py:147-152) -------------------------
+ * mel [B,1,80,T] -> style [B,64]                                                                      */
+int sty_style_workspace_bytes(const sty_model *m, int B, int T, size_t *bytes);
+int sty_style_fwd(sty_model *m, int B, int T, const float *mel, float *style, void *workspace, size_t ws_bytes,
+                  void *stream);
+
+/* ---- front end: calculate_mel (train/utils.py:825-834) + log energy (utils.py:73-85) --------------
+ * audio [B,N] -> mel [B,80,frames] with frames = even(N/hop + 1); energy [B,frames] (optional).       */
+int sty_mel_workspace_bytes(int B, int N, int n_fft, int hop, size_t *bytes);
+int sty_mel_fwd(int B, int N, const float *audio, int n_fft, int win_length, int hop, float mean, float std,
+                float *mel, float *energy, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- soft alignment: DurationProcessor.duration_to_alignment (train/utils.py:752-791) ------------
+ * durations [B,L] -> alignment [B,L,T] (softmax over L)                                               */
+int sty_alignment_fwd(int B, int L, int T, const float *durations, float *alignment, void *stream);
+
+/* ---- fine-grained entry points for unit parity (each = one reference sub-module) ------------------ */
+/* GeneratorConvNeXtBlock (conv_next.py:80-93) of channel count C on [B,C,T]; prefix e.g.
+ * "generator.basegen.phase_convnext.0".                                                              */
+int sty_convnext_fwd(sty_model *m, const char *prefix, int B, int C, int T, const float *x, const float *style,
+                     float *y, void *workspace, size_t ws_bytes, void *stream);
+/* AdaptiveGeneratorBlock (ada_norm.py:109-120), 32 channels, k=11, dil 1/3/5.                         */
+int sty_resblock_fwd(sty_model *m, const char *prefix, int B, int T, const float *x, const float *style, float *y,
+                     void *workspace, size_t ws_bytes, void *stream);
+/* STFT(64, hop 4).transform -> (mag, atan2(y,x)) bins 0..31, last frame dropped (generator.py:724-729);
+ * wave [B,N] -> spec, phase [B,32,N/4].                                                               */
+int sty_stft64_fwd(int B, int N, const float *wave, float *spec, float *phase, void *stream);
+/* synthesis head: exp/atan2-free cos,sin + conv-transpose iSTFT + tanh (generator.py:782-799,896);
+ * logamp, real, imag [B,32,F] -> audio [B,1,4F].                                                      */
+int sty_istft64_fwd(int B, int F, const float *logamp, const float *real, const float *imag, float *audio,
+                    void *stream);
+/* harmonic source (generator.py:720-723, 415-447, 496-510): pitch, voiced [B,T], noise [B,300T,9] or
+ * NULL -> prior [B,300T].  lin_w [9], lin_b [1] = m_source.l_linear.                                  */
+int sty_source_fwd(int B, int T, const float *pitch, const float *voiced, const float *noise, uint64_t seed,
+                   const float *lin_w, const float *lin_b, float *prior, void *workspace, size_t ws_bytes,
+                   void *stream);
+int sty_source_workspace_bytes(int B, int T, size_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

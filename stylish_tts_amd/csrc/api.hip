@@ -1,0 +1,1217 @@
+// C ABI of libstylish_hip.so: model objects bound by reference state_dict keys, weight preparation,
+// and the forward plans that sequence the HIP kernels on the caller's stream.  See include/stylish_hip.h.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "model.h"
+
+namespace sty {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  return STY_EHIP;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// parameter lookup
+// ---------------------------------------------------------------------------------------------------
+struct Builder {
+  sty_model* m;
+  bool dry;  // first pass: only measure the arena and collect the key list
+  bool ok = true;
+
+  const Param* get(const std::string& key, std::initializer_list<int64_t> shape = {}) {
+    if (dry) m->requested.push_back(key);
+    auto it = m->params.find(key);
+    if (it == m->params.end()) {
+      if (ok) m->missing = key;
+      ok = false;
+      return nullptr;
+    }
+    if (shape.size()) {
+      std::vector<int64_t> want(shape);
+      if (want != it->second.shape) {
+        if (ok) m->missing = key + " (shape mismatch)";
+        ok = false;
+        return nullptr;
+      }
+    }
+    return &it->second;
+  }
+  const float* ptr(const std::string& key, std::initializer_list<int64_t> shape = {}) {
+    const Param* p = get(key, shape);
+    return p ? p->p : nullptr;
+  }
+  bool has(const std::string& key) const { return m->params.count(key) != 0; }
+
+  // dense conv / linear -> PackedConv (+ pack job).  wn: weight_norm parametrization.  glu: GLU channel order.
+  PackedConv conv(const std::string& name, bool wn = false, bool bias = true, bool glu = false,
+                  const float* bias_override_src = nullptr) {
+    PackedConv pc;
+    const Param* w = wn ? get(name + ".parametrizations.weight.original1") : get(name + ".weight");
+    const Param* g = wn ? get(name + ".parametrizations.weight.original0") : nullptr;
+    const float* b = bias ? ptr(name + ".bias") : nullptr;
+    if (!w || (wn && !g)) return pc;
+    const auto& s = w->shape;
+    pc.Cout = (int)s[0];
+    pc.Cin = (int)s[1];
+    pc.K = s.size() > 2 ? (int)s[2] : 1;
+    pc.CinP = (int)align_up(pc.Cin, CI_CHUNK);
+    pc.CoutP = glu ? (int)align_up(pc.Cout, 64) : (int)align_up(pc.Cout, 32);
+    float* wp = m->ab.take<float>((size_t)pc.K * pc.CinP * pc.CoutP);
+    float* bp = m->ab.take<float>(pc.CoutP);
+    pc.wp = wp;
+    pc.bias = (bias || bias_override_src) ? bp : nullptr;
+    if (!dry) {
+      PackJob j;
+      j.kind = glu ? PK_CONV_GLU : (wn ? PK_CONV_WN : PK_CONV);
+      j.w = wn ? nullptr : w->p;
+      j.g = g ? g->p : nullptr;
+      j.v = wn ? w->p : nullptr;
+      j.bias = b;
+      j.Cout = pc.Cout;
+      j.Cin = pc.Cin;
+      j.K = pc.K;
+      j.CinP = pc.CinP;
+      j.CoutP = pc.CoutP;
+      j.wp = wp;
+      j.bp = bp;
+      m->jobs.push_back(j);
+    }
+    return pc;
+  }
+
+  AdaFc fc(const std::string& name, int C) {
+    AdaFc a;
+    a.C = C;
+    const float* W = ptr(name + ".fc.weight", {2 * C, m->style_dim});
+    const float* b = ptr(name + ".fc.bias", {2 * C});
+    a.off = m->gb_floats_per_batch;
+    m->gb_floats_per_batch += 2 * C;
+    if (!dry) {
+      a.idx = (int)m->fcs.size();
+      StyleFcDesc d;
+      d.W = W;
+      d.b = b;
+      d.off = a.off;
+      d.n = 2 * C;
+      d.pad = 0;
+      m->fcs.push_back(d);
+    }
+    return a;
+  }
+
+  ConvNeXt convnext(const std::string& p, int C) {
+    ConvNeXt c;
+    c.C = C;
+    c.dw_w = ptr(p + ".dwconv.weight", {C, 1, 7});
+    c.dw_b = ptr(p + ".dwconv.bias", {C});
+    c.norm = fc(p + ".norm", C);
+    c.alpha = ptr(p + ".snake", {1, 1, 4 * C});
+    c.grn_gamma = ptr(p + ".grn.gamma", {1, 1, 4 * C});
+    const float* grn_beta = ptr(p + ".grn.beta", {1, 1, 4 * C});
+    c.b1 = ptr(p + ".pwconv1.bias", {4 * C});
+    const float* w2 = ptr(p + ".pwconv2.weight", {C, 4 * C});
+    const float* b2 = ptr(p + ".pwconv2.bias", {C});
+    c.pw1 = conv(p + ".pwconv1");
+    c.w1p = c.pw1.wp;
+    // pw2: packed conv with bias := b2eff (written by the W2A job)
+    PackedConv pc;
+    pc.Cout = C;
+    pc.Cin = 4 * C;
+    pc.K = 1;
+    pc.CinP = 4 * C;
+    pc.CoutP = (int)align_up(C, 32);
+    float* wp = m->ab.take<float>((size_t)pc.CinP * pc.CoutP);
+    float* bp = m->ab.take<float>(pc.CoutP);
+    float* w2a = m->ab.take<float>((size_t)4 * C * C);
+    pc.wp = wp;
+    pc.bias = bp;
+    c.pw2 = pc;
+    c.w2a = w2a;
+    if (!dry && w2) {
+      PackJob j;
+      j.kind = PK_CONV;
+      j.w = w2;
+      j.bias = nullptr;
+      j.Cout = C;
+      j.Cin = 4 * C;
+      j.K = 1;
+      j.CinP = pc.CinP;
+      j.CoutP = pc.CoutP;
+      j.wp = wp;
+      j.bp = nullptr;
+      m->jobs.push_back(j);
+      PackJob k;
+      k.kind = PK_W2A;
+      k.w = w2;
+      k.bias = b2;
+      k.extra = grn_beta;
+      k.Cout = C;
+      k.wp = w2a;
+      k.bp = bp;
+      m->jobs.push_back(k);
+    }
+    return c;
+  }
+
+  ResBlock32 resblock(const std::string& p) {
+    ResBlock32 r;
+    for (int i = 0; i < 3; ++i) {
+      const std::string si = std::to_string(i);
+      r.c1[i] = conv(p + ".convs1." + si, true);
+      r.c2[i] = conv(p + ".convs2." + si, true);
+      r.n1[i] = fc(p + ".adain1." + si, 32);
+      r.n2[i] = fc(p + ".adain2." + si, 32);
+      r.a1[i] = ptr(p + ".alpha1." + si, {1, 32, 1});
+      r.a2[i] = ptr(p + ".alpha2." + si, {1, 32, 1});
+    }
+    return r;
+  }
+
+  void vocoder(const std::string& g) {
+    VocoderPlan& v = m->voc;
+    v.amp_input_conv = conv(g + "amp_input_conv");
+    const int hd = v.amp_input_conv.Cout ? v.amp_input_conv.Cout : 256;
+    v.hidden = hd;
+    v.amp_norm_w = ptr(g + "amp_norm.weight", {hd});
+    v.amp_norm_b = ptr(g + "amp_norm.bias", {hd});
+    const std::string c = g + "amp_conformer.layers.0.";
+    Conformer& cf = v.conf;
+    cf.ff1n = fc(c + "ff1.fn.norm", hd);
+    cf.ff1a = conv(c + "ff1.fn.fn.net.0");
+    cf.ff1b = conv(c + "ff1.fn.fn.net.3");
+    cf.attn_n = fc(c + "attn.norm", hd);
+    cf.to_q = conv(c + "attn.fn.to_q", false, false);
+    cf.to_kv = conv(c + "attn.fn.to_kv", false, false);
+    cf.to_out = conv(c + "attn.fn.to_out");
+    cf.conv_n = fc(c + "conv.norm", hd);
+    cf.pw1 = conv(c + "conv.net.1", false, true, true);
+    cf.dw_w = ptr(c + "conv.net.3.conv.weight", {2 * hd, 1, 31});
+    cf.dw_b = ptr(c + "conv.net.3.conv.bias", {2 * hd});
+    cf.bn_w = ptr(c + "conv.net.4.weight", {2 * hd});
+    cf.bn_b = ptr(c + "conv.net.4.bias", {2 * hd});
+    cf.bn_rm = ptr(c + "conv.net.4.running_mean", {2 * hd});
+    cf.bn_rv = ptr(c + "conv.net.4.running_var", {2 * hd});
+    cf.pw2 = conv(c + "conv.net.6");
+    cf.ff2n = fc(c + "ff2.fn.norm", hd);
+    cf.ff2a = conv(c + "ff2.fn.fn.net.0");
+    cf.ff2b = conv(c + "ff2.fn.fn.net.3");
+    cf.post_n = fc(c + "post_norm", hd);
+    const std::string b = g + "basegen.";
+    v.amp_convnext.clear();
+    for (int i = 0; has(b + "amp_convnext." + std::to_string(i) + ".dwconv.weight"); ++i)
+      v.amp_convnext.push_back(convnext(b + "amp_convnext." + std::to_string(i), hd));
+    int after = hd;
+    for (int i = 0; i < 3; ++i) {
+      after /= 2;
+      v.upconv[i] = conv(b + "upconvs." + std::to_string(i));
+      v.upblock[i] = convnext(b + "upblocks." + std::to_string(i), after);
+    }
+    v.lin_w = ptr(b + "m_source.l_linear.weight", {1, 9});
+    v.lin_b = ptr(b + "m_source.l_linear.bias", {1});
+    // STFT bases are deterministic buffers; use the bound ones when present, else the built-in table
+    v.stft_fr = has(b + "stft.weight_forward_real") ? ptr(b + "stft.weight_forward_real", {33, 1, 64}) : m->stft_default;
+    v.stft_fi = has(b + "stft.weight_forward_imag") ? ptr(b + "stft.weight_forward_imag", {33, 1, 64})
+                                                     : m->stft_default + 33 * 64;
+    v.stft_br = has(b + "stft.weight_backward_real") ? ptr(b + "stft.weight_backward_real", {33, 1, 64})
+                                                      : m->stft_default + 2 * 33 * 64;
+    v.stft_bi = has(b + "stft.weight_backward_imag") ? ptr(b + "stft.weight_backward_imag", {33, 1, 64})
+                                                      : m->stft_default + 3 * 33 * 64;
+    v.amp_prior_conv = conv(b + "amp_prior_conv");
+    v.phase_prior_conv = conv(b + "phase_prior_conv");
+    v.amp_prior_block = resblock(b + "amp_prior_block");
+    v.phase_prior_block = resblock(b + "phase_prior_block");
+    v.phase_input_conv = conv(b + "phase_input_conv");
+    v.amp_output_conv = conv(b + "amp_output_conv");
+    v.real_conv = conv(b + "phase_output_real_conv");
+    v.imag_conv = conv(b + "phase_output_imag_conv");
+    v.phase_norm_w = ptr(b + "phase_norm.weight", {32});
+    v.phase_norm_b = ptr(b + "phase_norm.bias", {32});
+    v.amp_fln_w = ptr(b + "amp_final_layer_norm.weight", {32});
+    v.amp_fln_b = ptr(b + "amp_final_layer_norm.bias", {32});
+    v.phase_fln_w = ptr(b + "phase_final_layer_norm.weight", {32});
+    v.phase_fln_b = ptr(b + "phase_final_layer_norm.bias", {32});
+    v.phase_convnext.clear();
+    for (int i = 0; has(b + "phase_convnext." + std::to_string(i) + ".dwconv.weight"); ++i)
+      v.phase_convnext.push_back(convnext(b + "phase_convnext." + std::to_string(i), 32));
+    if (ok && (v.amp_convnext.empty() || v.phase_convnext.empty())) {
+      m->missing = b + "amp_convnext.0 / phase_convnext.0";
+      ok = false;
+    }
+  }
+
+  void text_encoder(const std::string& p) {
+    TextEncPlan& t = m->te;
+    const Param* e = get(p + "emb.weight");
+    if (!e) return;
+    t.emb = e->p;
+    t.tokens = (int)e->shape[0];
+    t.H = (int)e->shape[1];
+    for (int i = 0; i < 3; ++i) {
+      const std::string si = std::to_string(i);
+      t.pre[i] = conv(p + "prenet.conv_layers." + si);
+      t.pre_g[i] = ptr(p + "prenet.norm_layers." + si + ".gamma", {t.H});
+      t.pre_b[i] = ptr(p + "prenet.norm_layers." + si + ".beta", {t.H});
+    }
+    t.proj = conv(p + "prenet.proj");
+    t.layers.clear();
+    for (int i = 0; has(p + "encoder.attn_layers." + std::to_string(i) + ".conv_q.weight"); ++i) {
+      const std::string si = std::to_string(i);
+      TextEncLayer l;
+      l.q = conv(p + "encoder.attn_layers." + si + ".conv_q");
+      l.k = conv(p + "encoder.attn_layers." + si + ".conv_k");
+      l.v = conv(p + "encoder.attn_layers." + si + ".conv_v");
+      l.o = conv(p + "encoder.attn_layers." + si + ".conv_o");
+      l.n1g = ptr(p + "encoder.norm_layers_1." + si + ".gamma", {t.H});
+      l.n1b = ptr(p + "encoder.norm_layers_1." + si + ".beta", {t.H});
+      l.f1 = conv(p + "encoder.ffn_layers." + si + ".conv_1");
+      l.f2 = conv(p + "encoder.ffn_layers." + si + ".conv_2");
+      l.n2g = ptr(p + "encoder.norm_layers_2." + si + ".gamma", {t.H});
+      l.n2b = ptr(p + "encoder.norm_layers_2." + si + ".beta", {t.H});
+      t.layers.push_back(l);
+    }
+    t.proj_m = conv(p + "proj_m");
+    for (int i = 0; i < 4; ++i) t.theta[i] = 1.0f / powf(10000.0f, (float)(2 * i) / 8.0f);
+  }
+
+  DecBlock dec_block(const std::string& p) {
+    DecBlock d;
+    d.c1 = conv(p + ".conv1", true);
+    d.c2 = conv(p + ".conv2", true);
+    d.Cin = d.c1.Cin;
+    d.Cout = d.c1.Cout;
+    d.n1 = fc(p + ".norm1", d.Cin);
+    d.n2 = fc(p + ".norm2", d.Cout);
+    d.has_sc = has(p + ".conv1x1.parametrizations.weight.original0");
+    if (d.has_sc) d.sc = conv(p + ".conv1x1", true, false);
+    return d;
+  }
+
+  void decoder(const std::string& p) {
+    DecoderPlan& d = m->dec;
+    d.encode = dec_block(p + "encode");
+    for (int i = 0; i < 4; ++i) d.decode[i] = dec_block(p + "decode." + std::to_string(i));
+    d.asr_res = conv(p + "asr_res.0", true);
+    d.f0_g = ptr(p + "F0_conv.parametrizations.weight.original0", {1, 1, 1});
+    d.f0_v = ptr(p + "F0_conv.parametrizations.weight.original1", {1, 1, 3});
+    d.f0_b = ptr(p + "F0_conv.bias", {1});
+    d.n_g = ptr(p + "N_conv.parametrizations.weight.original0", {1, 1, 1});
+    d.n_v = ptr(p + "N_conv.parametrizations.weight.original1", {1, 1, 3});
+    d.n_b = ptr(p + "N_conv.bias", {1});
+    d.v_g = ptr(p + "voiced_conv.parametrizations.weight.original0", {1, 1, 1});
+    d.v_v = ptr(p + "voiced_conv.parametrizations.weight.original1", {1, 1, 3});
+    d.v_b = ptr(p + "voiced_conv.bias", {1});
+    d.fnv_w = m->ab.take<float>(12);
+  }
+
+  void build() {
+    m->gb_floats_per_batch = 0;
+    if (m->kind == "speech_predictor") {
+      text_encoder("text_encoder.");
+      decoder("decoder.");
+      vocoder("generator.");
+    } else if (m->kind == "vocoder") {
+      vocoder("");
+    }
+  }
+};
+
+static hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------------------
+// forward plans
+// ---------------------------------------------------------------------------------------------------
+struct Run {
+  sty_model* m;
+  Bump ws;
+  hipStream_t st;
+  int B;
+  float* gb = nullptr;  // style fc outputs
+  int rc = STY_OK;
+
+  const float* gbp(const AdaFc& a) const { return gb ? gb + a.off * B : nullptr; }
+  void chk(int r) {
+    if (rc == STY_OK && r != STY_OK) rc = r;
+  }
+  bool live() const { return ws.base != nullptr && rc == STY_OK; }
+
+  void conv(const ConvArgs& a) {
+    if (live()) chk(launch_conv1d(a, st));
+  }
+  ConvArgs base(const PackedConv& w, const float* x, int T, float* y) {
+    ConvArgs a;
+    a.x[0] = x;
+    a.xc[0] = w.Cin;
+    a.nsrc = 1;
+    a.B = B;
+    a.T = T;
+    a.w = w;
+    a.pad = (w.K - 1) / 2;
+    a.y = y;
+    return a;
+  }
+
+  // AdaIN fold of tensor x [B][C][T] -> per-(b,c) affine (a, s)
+  void adain(const float* x, int C, int T, const AdaFc& fc, float* a, float* s, double* part) {
+    if (!live()) return;
+    chk(launch_row_stats(x, B * C, T, part, st));
+    chk(launch_adain_finalize(part, row_stats_nseg(T), gbp(fc), B, C, T, 1e-5f, a, s, st));
+  }
+
+  size_t peak = 0;
+  void note_peak() { peak = ws.off > peak ? ws.off : peak; }
+  struct Scope {  // temporaries taken inside a scope are released (bump pointer rewound) at its end
+    Run& r;
+    size_t off;
+    explicit Scope(Run& run) : r(run), off(run.ws.off) {}
+    ~Scope() {
+      r.note_peak();
+      r.ws.off = off;
+    }
+  };
+
+  // GeneratorConvNeXtBlock in place on x [B][C][T]
+  void convnext(const ConvNeXt& c, float* x, int T) {
+    const int C = c.C;
+    Scope sc(*this);
+    if (C == 32) {
+      const int nt = convnext32_ntiles(T);
+      double* part = ws.take<double>((size_t)B * 128 * nt * 2);
+      float* scale = ws.take<float>((size_t)B * 128);
+      if (live()) {
+        Cnx32Args a;
+        a.x = x;
+        a.dw_w = c.dw_w;
+        a.dw_b = c.dw_b;
+        a.gb = gbp(c.norm);
+        a.w1p = c.w1p;
+        a.b1 = c.b1;
+        a.alpha = c.alpha;
+        a.w2a = c.w2a;
+        a.b2eff = c.pw2.bias;
+        a.scale = scale;
+        a.part = part;
+        a.y = x;
+        a.T = T;
+        a.ntiles = nt;
+        chk(launch_convnext32(a, B, 1, st));
+        chk(launch_grn_finalize(part, nt, c.grn_gamma, B, 128, scale, st));
+        chk(launch_convnext32(a, B, 2, st));
+      }
+      return;
+    }
+    float* u = ws.take<float>((size_t)B * C * T);
+    float* h = ws.take<float>((size_t)B * 4 * C * T);
+    const int nseg = row_stats_nseg(T);
+    double* part = ws.take<double>((size_t)B * 4 * C * nseg * 2);
+    float* scale = ws.take<float>((size_t)B * 4 * C);
+    if (live()) {
+      chk(launch_dwconv_adaln(x, c.dw_w, c.dw_b, B, C, T, 7, 1e-6f, gbp(c.norm), u, st));
+      ConvArgs a = base(c.pw1, u, T, h);
+      a.act = ACT_SNAKE;
+      a.act_alpha = c.alpha;
+      conv(a);
+      chk(launch_row_stats(h, B * 4 * C, T, part, st));
+      chk(launch_grn_finalize(part, nseg, c.grn_gamma, B, 4 * C, scale, st));
+      ConvArgs b2 = base(c.pw2, h, T, x);
+      b2.pro = PRO_SCALE;
+      b2.pa = scale;
+      b2.residual = x;
+      conv(b2);
+    }
+  }
+
+  // AdaptiveGeneratorBlock in place on x [B][32][T]
+  void resblock(const ResBlock32& r, float* x, int T) {
+    Scope sc_(*this);
+    float* xt = ws.take<float>((size_t)B * 32 * T);
+    double* part = ws.take<double>((size_t)B * 32 * row_stats_nseg(T) * 2);
+    float* a = ws.take<float>(B * 32);
+    float* s = ws.take<float>(B * 32);
+    const int dil[3] = {1, 3, 5};
+    for (int i = 0; i < 3 && live(); ++i) {
+      adain(x, 32, T, r.n1[i], a, s, part);
+      ConvArgs c1 = base(r.c1[i], x, T, xt);
+      c1.dil = dil[i];
+      c1.pad = 5 * dil[i];
+      c1.pro = PRO_AFFINE_SNAKE;
+      c1.pa = a;
+      c1.ps = s;
+      c1.palpha = r.a1[i];
+      conv(c1);
+      adain(xt, 32, T, r.n2[i], a, s, part);
+      ConvArgs c2 = base(r.c2[i], xt, T, x);
+      c2.pro = PRO_AFFINE_SNAKE;
+      c2.pa = a;
+      c2.ps = s;
+      c2.palpha = r.a2[i];
+      c2.residual = x;
+      conv(c2);
+    }
+  }
+
+  void layernorm_ada(const float* x, float* y, int C, int T, const AdaFc& fc) {
+    if (live()) chk(launch_chan_layernorm(x, y, B, C, T, 1e-5f, 1, nullptr, nullptr, gbp(fc), 0, nullptr, st));
+  }
+
+  // ConformerBlock on x [B][C][T] -> out (conformer.py:242-250)
+  void conformer(const Conformer& c, const float* x, float* out, int C, int T) {
+    Scope sc_(*this);
+    const size_t n = (size_t)B * C * T;
+    float* z = ws.take<float>(n);
+    float* big = ws.take<float>(4 * n);
+    float* xff1 = ws.take<float>(n);
+    float* q = ws.take<float>(2 * n);
+    float* kv = ws.take<float>(4 * n);
+    float* o = ws.take<float>(2 * n);
+    float* x2 = ws.take<float>(n);
+    float* g = ws.take<float>(2 * n);
+    float* d = ws.take<float>(2 * n);
+    float* x3 = ws.take<float>(n);
+    float* x4 = ws.take<float>(n);
+    if (live()) {
+      auto ff = [&](const AdaFc& nrm, const PackedConv& w0, const PackedConv& w3, const float* in, float* res) {
+        layernorm_ada(in, z, C, T, nrm);
+        ConvArgs a = base(w0, z, T, big);
+        a.act = ACT_SWISH;
+        conv(a);
+        ConvArgs b2 = base(w3, big, T, res);
+        b2.out_scale = 0.5f;
+        b2.residual = in;
+        conv(b2);
+      };
+      ff(c.ff1n, c.ff1a, c.ff1b, x, xff1);
+      layernorm_ada(x, z, C, T, c.attn_n);
+      conv(base(c.to_q, z, T, q));
+      conv(base(c.to_kv, z, T, kv));
+      AttnArgs at;
+      const int inner = c.to_q.Cout;  // 512 = 8 x 64
+      at.q = q;
+      at.k = kv;
+      at.v = kv + (size_t)inner * T;
+      at.o = o;
+      at.qbs = (size_t)inner * T;
+      at.kbs = at.vbs = (size_t)2 * inner * T;
+      at.obs = (size_t)inner * T;
+      at.T = T;
+      at.H = 8;
+      at.scale = 1.0f / sqrtf((float)(inner / 8));
+      at.lengths = nullptr;
+      chk(launch_attention(at, B, inner / 8, st));
+      ConvArgs ao = base(c.to_out, o, T, x2);
+      ao.residual = xff1;
+      conv(ao);
+      layernorm_ada(x2, z, C, T, c.conv_n);
+      ConvArgs p1 = base(c.pw1, z, T, g);
+      p1.act = ACT_GLU;
+      conv(p1);
+      chk(launch_dwconv_bn_swish(g, c.dw_w, c.dw_b, c.bn_w, c.bn_b, c.bn_rm, c.bn_rv, 1e-5f, B, 2 * C, T, 31, d, st));
+      ConvArgs p2 = base(c.pw2, d, T, x3);
+      p2.residual = x2;
+      conv(p2);
+      ff(c.ff2n, c.ff2a, c.ff2b, x3, x4);
+      layernorm_ada(x4, out, C, T, c.post_n);
+    }
+  }
+
+  // MultiGenerator.forward
+  void vocoder(const sty_vocoder_io& io) {
+    const VocoderPlan& v = m->voc;
+    const int T = io.T, Tu = 75 * T, N = 300 * T, C = v.hidden;
+    // ---- harmonic source branch (no grad in the reference) ----
+    float* prior = ws.take<float>((size_t)B * N);
+    float* srcws = ws.take<float>(source_workspace_floats(B, T));
+    float* lap = ws.take<float>((size_t)B * 32 * Tu);
+    float* pp = ws.take<float>((size_t)B * 32 * Tu);
+    float* hs = ws.take<float>((size_t)B * 32 * Tu);
+    float* hp = ws.take<float>((size_t)B * 32 * Tu);
+    const float* prior_used = prior;
+    if (live()) {
+      if (io.prior_override)
+        prior_used = io.prior_override;
+      else
+        chk(launch_source(B, T, io.pitch, io.voiced, io.noise, io.seed, v.lin_w, v.lin_b, prior, srcws, st));
+      chk(launch_stft64(B, N, prior_used, v.stft_fr, v.stft_fi, hs, hp, st));
+      conv(base(v.amp_prior_conv, hs, Tu, lap));
+      conv(base(v.phase_prior_conv, hp, Tu, pp));
+    }
+    resblock(v.amp_prior_block, lap, Tu);
+    resblock(v.phase_prior_block, pp, Tu);
+    if (live()) {
+      tap(io.tap_prior, prior_used, (size_t)B * N);
+      tap(io.tap_har_spec, hs, (size_t)B * 32 * Tu);
+      tap(io.tap_har_phase, hp, (size_t)B * 32 * Tu);
+      tap(io.tap_logamp_prior, lap, (size_t)B * 32 * Tu);
+      tap(io.tap_phase_prior, pp, (size_t)B * 32 * Tu);
+    }
+    // hs / hp are dead from here on: reuse them
+    // ---- stage A @T ----
+    const size_t mark = ws.off;
+    float* x0 = ws.take<float>((size_t)B * C * T);
+    float* x1 = ws.take<float>((size_t)B * C * T);
+    float* xc = ws.take<float>((size_t)B * C * T);
+    if (live()) {
+      conv(base(v.amp_input_conv, io.mel, T, x0));
+      chk(launch_chan_layernorm(x0, x1, B, C, T, 1e-6f, 0, v.amp_norm_w, v.amp_norm_b, nullptr, 0, nullptr, st));
+    }
+    conformer(v.conf, x1, xc, C, T);
+    if (live()) tap(io.tap_conformer_out, xc, (size_t)B * C * T);
+    // ---- stage B: ConvNeXt trunk with pixel-shuffle upsampling ----
+    for (const ConvNeXt& c : v.amp_convnext) convnext(c, xc, T);
+    float* cur = xc;
+    int Tc = T, Cc = C;
+    const int rates[3] = {3, 5, 5};
+    float* trunk = nullptr;
+    for (int i = 0; i < 3; ++i) {
+      const int s = rates[i];
+      float* nx = (i == 2) ? hs : ws.take<float>((size_t)B * (Cc / 2) * Tc * s);
+      if (live()) {
+        ConvArgs a = base(v.upconv[i], cur, Tc, nx);
+        a.shuffle = s;
+        conv(a);
+      }
+      Tc *= s;
+      Cc /= 2;
+      convnext(v.upblock[i], nx, Tc);
+      cur = nx;
+    }
+    trunk = cur;  // [B][32][Tu] (lives in hs)
+    if (live()) tap(io.tap_trunk, trunk, (size_t)B * 32 * Tu);
+    note_peak();
+    ws.off = mark;
+    // ---- heads @75T ----
+    float* logamp = ws.take<float>((size_t)B * 32 * Tu);
+    float* ph = hp;
+    float* real = ws.take<float>((size_t)B * 32 * Tu);
+    float* imag = ws.take<float>((size_t)B * 32 * Tu);
+    if (live()) {
+      ConvArgs a = base(v.amp_output_conv, trunk, Tu, logamp);
+      a.pro = PRO_LN_AFFINE;
+      a.palpha = v.amp_fln_w;
+      a.pbeta = v.amp_fln_b;
+      a.ln_eps = 1e-6f;
+      conv(a);
+      tap(io.tap_logamp, logamp, (size_t)B * 32 * Tu);
+      ConvArgs p = base(v.phase_input_conv, trunk, Tu, ph);
+      p.nsrc = 3;
+      p.x[1] = lap;
+      p.x[2] = pp;
+      p.xc[0] = p.xc[1] = p.xc[2] = 32;
+      p.ln_out = 1;
+      p.ln_w = v.phase_norm_w;
+      p.ln_b = v.phase_norm_b;
+      p.ln_eps = 1e-6f;
+      conv(p);
+    }
+    for (const ConvNeXt& c : v.phase_convnext) convnext(c, ph, Tu);
+    if (live()) {
+      ConvArgs r = base(v.real_conv, ph, Tu, real);
+      r.pro = PRO_LN_AFFINE;
+      r.palpha = v.phase_fln_w;
+      r.pbeta = v.phase_fln_b;
+      r.ln_eps = 1e-6f;
+      conv(r);
+      r.w = v.imag_conv;
+      r.y = imag;
+      conv(r);
+      chk(launch_istft64(B, Tu, logamp, real, imag, v.stft_br, v.stft_bi, io.audio, st));
+    }
+    note_peak();
+  }
+
+  void tap(float* dst, const float* src, size_t n) {
+    if (dst && src && rc == STY_OK) {
+      hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "tap copy");
+    }
+  }
+
+  // TextEncoder.forward -> mu [B][inter][L]
+  void text_encoder(const int64_t* tokens, const int64_t* lengths, int L, float* mu) {
+    const TextEncPlan& t = m->te;
+    const int H = t.H;
+    Scope sc_(*this);
+    const size_t n = (size_t)B * H * L;
+    float* mask = ws.take<float>((size_t)B * L);
+    float* x = ws.take<float>(n);
+    float* h1 = ws.take<float>(n);
+    float* h2 = ws.take<float>(n);
+    float* q = ws.take<float>(n);
+    float* k = ws.take<float>(n);
+    float* vv = ws.take<float>(n);
+    float* o = ws.take<float>(n);
+    float* f = ws.take<float>((size_t)B * (t.layers.empty() ? H : t.layers[0].f1.Cout) * L);
+    if (live()) {
+      chk(launch_length_mask(lengths, B, L, mask, st));
+      chk(launch_embedding(tokens, t.emb, B, L, H, t.tokens, sqrtf((float)H), x, st));
+      const float* hin = x;
+      for (int i = 0; i < 3; ++i) {
+        ConvArgs a = base(t.pre[i], hin, L, h1);
+        a.pro = PRO_MASK;
+        a.mask = mask;
+        conv(a);
+        chk(launch_chan_layernorm(h1, h2, B, H, L, 1e-4f, 0, t.pre_g[i], t.pre_b[i], nullptr, 1, nullptr, st));
+        hin = h2;
+      }
+      // hin holds relu(LN(...)) of layer 3; x = (x + proj(hin)) * mask
+      ConvArgs pj = base(t.proj, hin, L, x);
+      pj.residual = x;
+      pj.out_mask = mask;
+      pj.out_mask_post = 1;
+      conv(pj);
+      for (const TextEncLayer& l : t.layers) {
+        ConvArgs aq = base(l.q, x, L, q);
+        aq.pro = PRO_MASK;
+        aq.mask = mask;
+        conv(aq);
+        aq.w = l.k;
+        aq.y = k;
+        conv(aq);
+        aq.w = l.v;
+        aq.y = vv;
+        conv(aq);
+        chk(launch_rope(q, k, B, 8, H / 8, L, 8, t.theta, st));
+        AttnArgs at;
+        at.q = q;
+        at.k = k;
+        at.v = vv;
+        at.o = o;
+        at.qbs = at.kbs = at.vbs = at.obs = (size_t)H * L;
+        at.T = L;
+        at.H = 8;
+        at.scale = 1.0f / sqrtf((float)(H / 8));
+        at.lengths = lengths;
+        chk(launch_attention(at, B, H / 8, st));
+        // x is masked already (prenet output / previous LN2 output are written masked)
+        ConvArgs ao = base(l.o, o, L, h1);
+        ao.residual = x;
+        conv(ao);
+        chk(launch_chan_layernorm(h1, x, B, H, L, 1e-4f, 0, l.n1g, l.n1b, nullptr, 0, nullptr, st));
+        ConvArgs f1 = base(l.f1, x, L, f);
+        f1.pro = PRO_MASK;
+        f1.mask = mask;
+        f1.act = ACT_RELU;
+        conv(f1);
+        ConvArgs f2 = base(l.f2, f, L, h1);
+        f2.pro = PRO_MASK;
+        f2.mask = mask;
+        f2.out_mask = mask;
+        f2.residual = x;
+        conv(f2);
+        chk(launch_chan_layernorm(h1, x, B, H, L, 1e-4f, 0, l.n2g, l.n2b, nullptr, 0, mask, st));
+      }
+      ConvArgs pm = base(t.proj_m, x, L, mu);
+      pm.out_mask = mask;
+      pm.out_mask_post = 1;
+      conv(pm);
+    }
+  }
+
+  // AdaptiveDecoderBlock (ada_norm.py:180-192): xcat [B][Cin][T] -> out [B][Cout][T]
+  void dec_block(const DecBlock& d, const float* xcat, float* out, int T) {
+    Scope sc_(*this);
+    float* h = ws.take<float>((size_t)B * d.Cout * T);
+    float* sc = ws.take<float>((size_t)B * d.Cout * T);
+    const int cmax = d.Cin > d.Cout ? d.Cin : d.Cout;
+    double* part = ws.take<double>((size_t)B * cmax * row_stats_nseg(T) * 2);
+    float* a = ws.take<float>((size_t)B * cmax);
+    float* s = ws.take<float>((size_t)B * cmax);
+    if (live()) {
+      const float r2 = 0.70710678118654752f;
+      const float* res = xcat;
+      if (d.has_sc) {
+        ConvArgs c = base(d.sc, xcat, T, sc);
+        c.out_scale = r2;
+        conv(c);
+        res = sc;
+      }
+      adain(xcat, d.Cin, T, d.n1, a, s, part);
+      ConvArgs c1 = base(d.c1, xcat, T, h);
+      c1.pro = PRO_AFFINE_LRELU;
+      c1.pa = a;
+      c1.ps = s;
+      conv(c1);
+      adain(h, d.Cout, T, d.n2, a, s, part);
+      ConvArgs c2 = base(d.c2, h, T, out);
+      c2.pro = PRO_AFFINE_LRELU;
+      c2.pa = a;
+      c2.ps = s;
+      c2.out_scale = r2;
+      c2.residual = res;
+      conv(c2);
+      if (!d.has_sc) set_error("decoder block without learned shortcut is not built");
+      if (!d.has_sc) rc = STY_EINVAL;
+    }
+  }
+
+  // Decoder.forward eval mode (decoder.py:77-90): asr [B][128][T] -> mel [B][128][T]
+  void decoder(const float* asr, const float* pitch, const float* energy, const float* voiced, int T, float* out) {
+    const DecoderPlan& d = m->dec;
+    Scope sc_(*this);
+    const int din = d.asr_res.Cin, dr = d.asr_res.Cout, dh = d.encode.Cout;
+    float* fnv = ws.take<float>((size_t)B * 3 * T);
+    float* cat = ws.take<float>((size_t)B * (dh + dr + 3) * T);
+    float* x = ws.take<float>((size_t)B * dh * T);
+    float* res = ws.take<float>((size_t)B * dr * T);
+    if (live()) {
+      chk(launch_fnv(pitch, energy, voiced, d.fnv_w, B, T, fnv, st));
+      const float* s1[2] = {asr, fnv};
+      const int c1[2] = {din, 3};
+      chk(launch_concat(s1, c1, 2, B, T, cat, st));
+    }
+    dec_block(d.encode, cat, x, T);
+    if (live()) conv(base(d.asr_res, asr, T, res));
+    for (int i = 0; i < 4; ++i) {
+      if (live()) {
+        const float* s2[3] = {x, res, fnv};
+        const int c2[3] = {dh, dr, 3};
+        chk(launch_concat(s2, c2, 3, B, T, cat, st));
+      }
+      dec_block(d.decode[i], cat, i == 3 ? out : x, T);
+    }
+  }
+};
+
+static int model_ready(const sty_model* m, const char* kind_a, const char* kind_b = nullptr) {
+  if (!m) {
+    set_error("null model");
+    return STY_EINVAL;
+  }
+  if (m->kind != kind_a && (!kind_b || m->kind != kind_b)) {
+    set_error("model kind '%s' does not provide this entry point", m->kind.c_str());
+    return STY_EINVAL;
+  }
+  if (!m->finalized) {
+    set_error("model not finalized");
+    return STY_ESTATE;
+  }
+  return STY_OK;
+}
+
+static int run_style_fc(Run& r, const float* style) {
+  sty_model* m = r.m;
+  r.gb = r.ws.take<float>(m->gb_floats_per_batch * r.B);
+  if (r.live() && !m->fcs.empty())
+    r.chk(launch_style_fc(m->fcs_dev, (int)m->fcs.size(), r.B, m->style_dim, style, r.gb, r.st));
+  return r.rc;
+}
+
+}  // namespace sty
+
+using namespace sty;
+
+extern "C" {
+
+int sty_version(void) { return 1; }
+const char* sty_last_error(void) { return g_err; }
+
+int sty_model_create(const char* kind, sty_model** out) {
+  if (!kind || !out) {
+    set_error("sty_model_create: null argument");
+    return STY_EINVAL;
+  }
+  std::string k(kind);
+  if (k != "speech_predictor" && k != "vocoder" && k != "mel_style_encoder") {
+    set_error("unknown model kind '%s'", kind);
+    return STY_EINVAL;
+  }
+  *out = new sty_model();
+  (*out)->kind = k;
+  return STY_OK;
+}
+
+void sty_model_destroy(sty_model* m) {
+  if (!m) return;
+  if (m->arena) (void)hipFree(m->arena);
+  if (m->fcs_dev) (void)hipFree(m->fcs_dev);
+  if (m->stft_default) (void)hipFree(m->stft_default);
+  delete m;
+}
+
+int sty_model_bind(sty_model* m, const char* key, const float* ptr, int ndim, const int64_t* shape) {
+  if (!m || !key || !ptr || ndim < 0 || (ndim > 0 && !shape)) {
+    set_error("sty_model_bind: bad argument");
+    return STY_EINVAL;
+  }
+  Param p;
+  p.p = ptr;
+  p.shape.assign(shape, shape + ndim);
+  m->params[key] = p;
+  m->finalized = false;
+  return STY_OK;
+}
+
+int sty_model_finalize(sty_model* m) {
+  if (!m) {
+    set_error("null model");
+    return STY_EINVAL;
+  }
+  if (m->arena) {
+    (void)hipFree(m->arena);
+    m->arena = nullptr;
+  }
+  if (!m->stft_default) {
+    float host[4 * 33 * 64];
+    build_stft64_bases(host);
+    STY_HIP(hipMalloc((void**)&m->stft_default, sizeof(host)));
+    STY_HIP(hipMemcpy(m->stft_default, host, sizeof(host), hipMemcpyHostToDevice));
+  }
+  m->requested.clear();
+  m->jobs.clear();
+  m->fcs.clear();
+  m->missing.clear();
+  m->ab = Bump();
+  Builder dry{m, true};
+  dry.build();
+  if (!dry.ok) {
+    set_error("state_dict key missing or wrong shape: %s", m->missing.c_str());
+    return m->missing.find("shape") != std::string::npos ? STY_ESHAPE : STY_EINVAL;
+  }
+  m->arena_bytes = align_up(m->ab.off, 256) + 256;
+  STY_HIP(hipMalloc((void**)&m->arena, m->arena_bytes));
+  STY_HIP(hipMemset(m->arena, 0, m->arena_bytes));
+  m->ab = Bump();
+  m->ab.base = m->arena;
+  m->ab.cap = m->arena_bytes;
+  Builder real{m, false};
+  real.build();
+  if (!real.ok || m->ab.overflow) {
+    set_error("internal: arena plan mismatch");
+    return STY_EINVAL;
+  }
+  if (m->fcs_dev) {
+    (void)hipFree(m->fcs_dev);
+    m->fcs_dev = nullptr;
+  }
+  if (!m->fcs.empty()) {
+    STY_HIP(hipMalloc((void**)&m->fcs_dev, m->fcs.size() * sizeof(StyleFcDesc)));
+    STY_HIP(hipMemcpy(m->fcs_dev, m->fcs.data(), m->fcs.size() * sizeof(StyleFcDesc), hipMemcpyHostToDevice));
+  }
+  m->finalized = true;
+  m->prepared = false;
+  return STY_OK;
+}
+
+int sty_model_num_keys(const sty_model* m) { return m ? (int)m->requested.size() : 0; }
+const char* sty_model_key(const sty_model* m, int i) {
+  if (!m || i < 0 || i >= (int)m->requested.size()) return nullptr;
+  return m->requested[i].c_str();
+}
+
+int sty_model_prepare(sty_model* m, void* stream) {
+  if (!m || !m->finalized) {
+    set_error("sty_model_prepare: model not finalized");
+    return STY_ESTATE;
+  }
+  hipStream_t st = S(stream);
+  for (const PackJob& j : m->jobs) {
+    int r = STY_OK;
+    switch (j.kind) {
+      case PK_CONV:
+      case PK_CONV_WN:
+        r = launch_pack_conv(j.w, j.g, j.v, j.bias, j.Cout, j.Cin, j.K, j.wp, j.bp, j.CinP, j.CoutP, st);
+        break;
+      case PK_CONV_GLU:
+        r = launch_pack_conv_glu(j.w, j.bias, j.Cout, j.Cin, j.K, j.wp, j.bp, j.CinP, j.CoutP, st);
+        break;
+      case PK_W2A:
+        r = launch_pack_w2a(j.w, j.bias, j.extra, j.Cout, j.wp, j.bp, st);
+        break;
+    }
+    if (r != STY_OK) return r;
+  }
+  if (m->kind == "speech_predictor") {
+    const DecoderPlan& d = m->dec;
+    int r = launch_prep_fnv(d.f0_g, d.f0_v, d.f0_b, d.n_g, d.n_v, d.n_b, d.v_g, d.v_v, d.v_b, d.fnv_w, st);
+    if (r != STY_OK) return r;
+  }
+  m->prepared = true;
+  return STY_OK;
+}
+
+static int vocoder_run(sty_model* m, const sty_vocoder_io* io, void* ws, size_t ws_bytes, void* stream, size_t* need) {
+  Run r;
+  r.m = m;
+  r.st = S(stream);
+  r.B = io->B;
+  r.ws.base = (char*)ws;
+  r.ws.cap = ws_bytes;
+  run_style_fc(r, io->style);
+  r.vocoder(*io);
+  if (need) *need = align_up(r.peak > r.ws.off ? r.peak : r.ws.off, 256) + 256;
+  if (ws && (r.ws.overflow || r.peak > ws_bytes)) {
+    set_error("workspace too small: need %zu bytes, have %zu", r.peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return r.rc;
+}
+
+int sty_vocoder_workspace_bytes(const sty_model* m, int B, int T, size_t* bytes) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!bytes || B <= 0 || T <= 1) {
+    set_error("sty_vocoder_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  sty_vocoder_io io;
+  memset(&io, 0, sizeof(io));
+  io.B = B;
+  io.T = T;
+  return vocoder_run(const_cast<sty_model*>(m), &io, nullptr, 0, nullptr, bytes);
+}
+
+int sty_vocoder_fwd(sty_model* m, const sty_vocoder_io* io, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!io || !workspace || !io->mel || !io->style || !io->audio || io->B <= 0 || io->T <= 1 ||
+      (!io->prior_override && (!io->pitch || !io->voiced))) {
+    set_error("sty_vocoder_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (!m->prepared) {
+    rc = sty_model_prepare(m, stream);
+    if (rc) return rc;
+  }
+  return vocoder_run(m, io, workspace, ws_bytes, stream, nullptr);
+}
+
+static int speech_run(sty_model* m, const sty_speech_io* io, void* ws, size_t ws_bytes, void* stream, size_t* need) {
+  Run r;
+  r.m = m;
+  r.st = S(stream);
+  r.B = io->B;
+  r.ws.base = (char*)ws;
+  r.ws.cap = ws_bytes;
+  run_style_fc(r, io->style);
+  const int B = io->B, L = io->L, T = io->T;
+  const int inter = m->te.proj_m.Cout ? m->te.proj_m.Cout : 128;
+  float* enc = r.ws.take<float>((size_t)B * inter * L);
+  float* asr = r.ws.take<float>((size_t)B * inter * T);
+  float* mel = r.ws.take<float>((size_t)B * m->dec.encode.Cout * T);
+  r.text_encoder(io->texts, io->text_lengths, L, enc);
+  if (r.live()) {
+    r.tap(io->tap_text_encoding, enc, (size_t)B * inter * L);
+    r.chk(launch_bmm_ct(enc, io->alignment, B, inter, L, T, asr, r.st));
+  }
+  r.decoder(asr, io->pitch, io->energy, io->voiced, T, mel);
+  if (r.live()) r.tap(io->tap_decoder_out, mel, (size_t)B * m->dec.encode.Cout * T);
+  sty_vocoder_io v = io->voc_taps;
+  v.B = B;
+  v.T = T;
+  v.mel = mel;
+  v.style = io->style;
+  v.pitch = io->denormal_pitch;
+  v.voiced = io->voiced;
+  v.noise = io->noise;
+  v.prior_override = io->prior_override;
+  v.seed = io->seed;
+  v.audio = io->audio;
+  r.vocoder(v);
+  if (need) *need = align_up(r.peak > r.ws.off ? r.peak : r.ws.off, 256) + 256;
+  if (ws && (r.ws.overflow || r.peak > ws_bytes)) {
+    set_error("workspace too small: need %zu bytes, have %zu", r.peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return r.rc;
+}
+
+int sty_speech_workspace_bytes(const sty_model* m, int B, int L, int T, size_t* bytes) {
+  int rc = model_ready(m, "speech_predictor");
+  if (rc) return rc;
+  if (!bytes || B <= 0 || L <= 0 || T <= 1) {
+    set_error("sty_speech_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  sty_speech_io io;
+  memset(&io, 0, sizeof(io));
+  io.B = B;
+  io.L = L;
+  io.T = T;
+  return speech_run(const_cast<sty_model*>(m), &io, nullptr, 0, nullptr, bytes);
+}
+
+int sty_speech_fwd(sty_model* m, const sty_speech_io* io, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "speech_predictor");
+  if (rc) return rc;
+  if (!io || !workspace || !io->texts || !io->text_lengths || !io->alignment || !io->pitch || !io->energy ||
+      !io->voiced || !io->style || !io->denormal_pitch || !io->audio || io->B <= 0 || io->L <= 0 || io->T <= 1) {
+    set_error("sty_speech_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (!m->prepared) {
+    rc = sty_model_prepare(m, stream);
+    if (rc) return rc;
+  }
+  return speech_run(m, io, workspace, ws_bytes, stream, nullptr);
+}
+
+// ---- fine-grained entry points ----
+int sty_convnext_fwd(sty_model* m, const char* prefix, int B, int C, int T, const float* x, const float* style,
+                     float* y, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!prefix || !x || !style || !y || !workspace) {
+    set_error("sty_convnext_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
+  // locate the block by its first requested key
+  const ConvNeXt* blk = nullptr;
+  const std::string want = std::string(prefix) + ".dwconv.weight";
+  auto it = m->params.find(want);
+  if (it == m->params.end()) {
+    set_error("no such block: %s", prefix);
+    return STY_EINVAL;
+  }
+  auto match = [&](const ConvNeXt& c) { return c.dw_w == it->second.p; };
+  for (const ConvNeXt& c : m->voc.amp_convnext)
+    if (match(c)) blk = &c;
+  for (const ConvNeXt& c : m->voc.phase_convnext)
+    if (match(c)) blk = &c;
+  for (int i = 0; i < 3; ++i)
+    if (match(m->voc.upblock[i])) blk = &m->voc.upblock[i];
+  if (!blk || blk->C != C) {
+    set_error("block %s not found or channel mismatch", prefix);
+    return STY_EINVAL;
+  }
+  Run r;
+  r.m = m;
+  r.st = S(stream);
+  r.B = B;
+  r.ws.base = (char*)workspace;
+  r.ws.cap = ws_bytes;
+  run_style_fc(r, style);
+  if (y != x) STY_HIP(hipMemcpyAsync(y, x, (size_t)B * C * T * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+  r.convnext(*blk, y, T);
+  if (r.ws.overflow || r.peak > ws_bytes) {
+    set_error("workspace too small: need %zu bytes", r.peak);
+    return STY_ENOMEM;
+  }
+  return r.rc;
+}
+
+int sty_resblock_fwd(sty_model* m, const char* prefix, int B, int T, const float* x, const float* style, float* y,
+                     void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!prefix || !x || !style || !y || !workspace) {
+    set_error("sty_resblock_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
+  const std::string p(prefix);
+  const ResBlock32* blk = nullptr;
+  if (p.size() >= 15 && p.compare(p.size() - 15, 15, "amp_prior_block") == 0) blk = &m->voc.amp_prior_block;
+  if (p.size() >= 17 && p.compare(p.size() - 17, 17, "phase_prior_block") == 0) blk = &m->voc.phase_prior_block;
+  if (!blk) {
+    set_error("no such resblock: %s", prefix);
+    return STY_EINVAL;
+  }
+  Run r;
+  r.m = m;
+  r.st = S(stream);
+  r.B = B;
+  r.ws.base = (char*)workspace;
+  r.ws.cap = ws_bytes;
+  run_style_fc(r, style);
+  if (y != x) STY_HIP(hipMemcpyAsync(y, x, (size_t)B * 32 * T * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+  r.resblock(*blk, y, T);
+  if (r.ws.overflow || r.peak > ws_bytes) {
+    set_error("workspace too small: need %zu bytes", r.peak);
+    return STY_ENOMEM;
+  }
+  return r.rc;
+}
+
+static float* g_bases = nullptr;  // default STFT(64) bases for the model-free entry points
+static int ensure_bases() {
+  if (g_bases) return STY_OK;
+  float host[4 * 33 * 64];
+  build_stft64_bases(host);
+  STY_HIP(hipMalloc((void**)&g_bases, sizeof(host)));
+  STY_HIP(hipMemcpy(g_bases, host, sizeof(host), hipMemcpyHostToDevice));
+  return STY_OK;
+}
+
+void sty_stft64_bases_host(float* out) { build_stft64_bases(out); }
+
+int sty_stft64_fwd(int B, int N, const float* wave, float* spec, float* phase, void* stream) {
+  if (!wave || !spec || !phase || B <= 0 || N < 64 || N % 4) {
+    set_error("sty_stft64_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  int rc = ensure_bases();
+  if (rc) return rc;
+  return launch_stft64(B, N, wave, g_bases, g_bases + 33 * 64, spec, phase, S(stream));
+}
+
+int sty_istft64_fwd(int B, int F, const float* logamp, const float* real, const float* imag, float* audio,
+                    void* stream) {
+  if (!logamp || !real || !imag || !audio || B <= 0 || F <= 0) {
+    set_error("sty_istft64_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  int rc = ensure_bases();
+  if (rc) return rc;
+  return launch_istft64(B, F, logamp, real, imag, g_bases + 2 * 33 * 64, g_bases + 3 * 33 * 64, audio, S(stream));
+}
+
+int sty_source_workspace_bytes(int B, int T, size_t* bytes) {
+  if (!bytes || B <= 0 || T <= 1) {
+    set_error("sty_source_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  *bytes = (size_t)source_workspace_floats(B, T) * sizeof(float);
+  return STY_OK;
+}
+
+int sty_source_fwd(int B, int T, const float* pitch, const float* voiced, const float* noise, uint64_t seed,
+                   const float* lin_w, const float* lin_b, float* prior, void* workspace, size_t ws_bytes,
+                   void* stream) {
+  if (!pitch || !voiced || !lin_w || !lin_b || !prior || !workspace || B <= 0 || T <= 1) {
+    set_error("sty_source_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (ws_bytes < (size_t)source_workspace_floats(B, T) * sizeof(float)) {
+    set_error("sty_source_fwd: workspace too small");
+    return STY_ENOMEM;
+  }
+  return launch_source(B, T, pitch, voiced, noise, seed, lin_w, lin_b, prior, (float*)workspace, S(stream));
+}
+
+int sty_alignment_fwd(int B, int L, int T, const float* durations, float* alignment, void* stream) {
+  if (!durations || !alignment || B <= 0 || L <= 0 || T <= 0) {
+    set_error("sty_alignment_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  return launch_alignment(durations, B, L, T, alignment, S(stream));
+}
+
+// not built yet: declared in the header so bindings can probe for them; they fail loudly.
+int sty_style_workspace_bytes(const sty_model*, int, int, size_t*) {
+  set_error("mel_style_encoder: HIP path not built in this revision");
+  return STY_ESTATE;
+}
+int sty_style_fwd(sty_model*, int, int, const float*, float*, void*, size_t, void*) {
+  set_error("mel_style_encoder: HIP path not built in this revision");
+  return STY_ESTATE;
+}
+int sty_mel_workspace_bytes(int, int, int, int, size_t*) {
+  set_error("mel front end: HIP path not built in this revision");
+  return STY_ESTATE;
+}
+int sty_mel_fwd(int, int, const float*, int, int, int, float, float, float*, float*, void*, size_t, void*) {
+  set_error("mel front end: HIP path not built in this revision");
+  return STY_ESTATE;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// Fused softmax attention on channel-major tensors with the fp32 matrix cores.
+//   vocoder conformer: 8 heads x 64, no mask, no positional encoding (conformer.py:111-144)
+//   text encoder:      8 heads x 16, additive -1e4 mask, partial RoPE on 8 dims (text_encoder.py:234-280)
+// q/k/v/o are [B, H*DH, T] (what the 1x1-conv projections produce and consume), so
+//   S^T[j][i] = sum_d K[d][j] Q[d][i]   A = K tile (LDS), B = Q fragment (registers, lanes along queries)
+//   O^T[d][i] = sum_j V[d][j] P^T[j][i] A = V tile (LDS, lanes along d), B = P^T straight from the S^T accumulator
+// with queries along lanes: every softmax statistic is lane-local (+ one exchange with lane^32), the P fragment
+// never leaves registers, and O^T stores are 128-B coalesced along time.
+#include "sty_common.h"
+
+namespace sty {
+
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  constexpr int DP = DH < 32 ? 32 : DH;  // V rows padded to a multiple of 32
+  constexpr int LS = 33;
+  __shared__ float ks[DH * LS];
+  __shared__ float vs[DP * LS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, T = a.T;
+  const int i0 = blockIdx.x * 128 + wave * 32;
+  const int qi = i0 + l31;
+  const float* qb = a.q + (size_t)b * a.qbs + (size_t)h * DH * T;
+  const float* kb = a.k + (size_t)b * a.kbs + (size_t)h * DH * T;
+  const float* vb = a.v + (size_t)b * a.vbs + (size_t)h * DH * T;
+  int len = T;
+  if (a.lengths) len = (int)a.lengths[b];
+
+  float qreg[DH / 2];
+#pragma unroll
+  for (int c2 = 0; c2 < DH / 2; ++c2) qreg[c2] = qi < T ? qb[(size_t)(2 * c2 + hi) * T + qi] * a.scale : 0.f;
+
+  f32x16 oacc[DP / 32];
+#pragma unroll
+  for (int d = 0; d < DP / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -3.0e38f, l_run = 0.f;
+  const bool q_pad = a.lengths && qi >= len;
+
+  for (int j0 = 0; j0 < T; j0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < DH * 32; e += 256) {
+      const int d = e >> 5, jj = e & 31;
+      const int j = j0 + jj;
+      ks[d * LS + jj] = j < T ? kb[(size_t)d * T + j] : 0.f;
+      vs[d * LS + jj] = j < T ? vb[(size_t)d * T + j] : 0.f;
+    }
+    if (DP > DH)
+      for (int e = tid; e < (DP - DH) * 32; e += 256) vs[(DH + (e >> 5)) * LS + (e & 31)] = 0.f;
+    __syncthreads();
+
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < DH / 2; ++c2)
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[(2 * c2 + hi) * LS + l31], qreg[c2], s, 0, 0, 0);
+
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float x = s[r];
+      if (a.lengths && (q_pad || j >= len)) x += -1e4f;
+      if (j >= T) x = -INFINITY;
+      s[r] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(s[r] - m_new);
+      s[r] = p;
+      rs += p;
+    }
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DP / 32; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float av = vs[(d * 32 + l31) * LS + (q & 3) + 8 * (q >> 2) + 4 * hi];
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[q], oacc[d], 0, 0, 0);
+      }
+    }
+  }
+  if (qi < T) {
+    const float inv = 1.0f / l_run;
+    float* ob = a.o + (size_t)b * a.obs + (size_t)h * DH * T;
+#pragma unroll
+    for (int d = 0; d < DP / 32; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dd = d * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (dd < DH) ob[(size_t)dd * T + qi] = oacc[d][r] * inv;
+      }
+  }
+}
+
+int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st) {
+  dim3 grid(cdiv(a.T, 128), a.H, B);
+  if (DH == 64)
+    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), 0, st, a);
+  else if (DH == 16)
+    hipLaunchKernelGGL(attn_kernel<16>, grid, dim3(256), 0, st, a);
+  else {
+    set_error("attention: head dim %d not built (16, 64)", DH);
+    return STY_EINVAL;
+  }
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// partial RoPE in place on q and k [B][H*DH][L]: first `d` dims of every head (text_encoder.py:146-168)
+__global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, int H, int DH, int L, int d, float t0,
+                            float t1, float t2, float t3) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (pos >= L) return;
+  const float theta[4] = {t0, t1, t2, t3};
+  const int half = d / 2;
+  float* ptr[2] = {q, k};
+  for (int w = 0; w < 2; ++w) {
+    float* base = ptr[w] + ((size_t)b * H + h) * DH * L + pos;
+    float x[8];
+    for (int i = 0; i < d; ++i) x[i] = base[(size_t)i * L];
+    for (int i = 0; i < d; ++i) {
+      const float ang = (float)pos * theta[i % half];
+      const float rot = i < half ? -x[i + half] : x[i - half];
+      base[(size_t)i * L] = x[i] * cosf(ang) + rot * sinf(ang);
+    }
+  }
+}
+
+int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st) {
+  if (d != 8) {
+    set_error("rope: only d == 8 built");
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d, theta4[0], theta4[1],
+                     theta4[2], theta4[3]);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

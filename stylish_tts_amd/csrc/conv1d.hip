@@ -1,0 +1,327 @@
+// Dense 1-D convolution as an implicit GEMM on the fp32 matrix cores of gfx950.
+//
+//   y[b][co][t] = epilogue( sum_{k,ci} Wp[k][ci][co] * prologue(x)[b][ci][t - pad + k*dil] + bias[co] )
+//
+// Covers every dense conv / Linear of the hot path (reference call sites: generator.py:731-780,
+// ada_norm.py:109-120,180-192, conformer.py:85-91,111-144,176-187, text_encoder.py:79-86,214-223,325-330).
+// Design (MI355X):
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 157 TF peak = the fp32 vector peak,
+//     but reached from one wave per SIMD with the VALU left free for the fused prologue / epilogue.
+//   * M = output channels (A operand = packed weights, 128-B coalesced rows straight from L2),
+//     N = time (B operand = input tile in LDS, lanes along time: conflict-free ds_read_b32),
+//     so the D fragment has time along lanes -> 128-B coalesced stores into the [B,C,T] layout.
+//   * the input tile (CI_CHUNK channels x (tile + receptive-field halo)) is staged ONCE per chunk with the
+//     normalisation / activation prologue applied during staging (once per element, not per tap).
+#include "sty_common.h"
+
+namespace sty {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  constexpr int CO_BLK = 32 * MT * WM;
+  constexpr int TT_BLK = 32 * NT * WN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * TT_BLK;
+  const int co0 = blockIdx.y * CO_BLK + wm * (32 * MT);
+  const int T = a.T;
+  const int K = a.w.K, CinP = a.w.CinP, CoutP = a.w.CoutP, Cin = a.w.Cin;
+  const int halo = (K - 1) * a.dil;
+  const int LW = TT_BLK + halo;
+  const int tw = wn * (32 * NT);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  for (int ci0 = 0; ci0 < CinP; ci0 += CI_CHUNK) {
+    __syncthreads();
+    // ---- stage CI_CHUNK x LW input tile with the prologue applied ----
+    for (int c = wave; c < CI_CHUNK; c += 4) {
+      const int ci = ci0 + c;
+      float* row = xs + c * LW;
+      if (ci >= Cin) {
+        for (int j = lane; j < LW; j += 64) row[j] = 0.f;
+        continue;
+      }
+      const float* src;
+      int cl = ci, csz;
+      if (cl < a.xc[0]) {
+        src = a.x[0];
+        csz = a.xc[0];
+      } else if (cl < a.xc[0] + a.xc[1]) {
+        src = a.x[1];
+        cl -= a.xc[0];
+        csz = a.xc[1];
+      } else {
+        src = a.x[2];
+        cl -= a.xc[0] + a.xc[1];
+        csz = a.xc[2];
+      }
+      src += ((size_t)b * csz + cl) * T;
+      float pa = 1.f, ps = 0.f, alpha = 1.f;
+      const int pro = a.pro;
+      if (pro == PRO_AFFINE || pro == PRO_AFFINE_SNAKE || pro == PRO_AFFINE_LRELU || pro == PRO_SCALE) {
+        pa = a.pa[(size_t)b * Cin + ci];
+        if (pro != PRO_SCALE) ps = a.ps[(size_t)b * Cin + ci];
+      }
+      if (pro == PRO_AFFINE_SNAKE) alpha = a.palpha[ci];
+      for (int j = lane; j < LW; j += 64) {
+        const int t = t0 - a.pad + j;
+        float v = 0.f;
+        if (t >= 0 && t < T) {
+          v = src[t];
+          if (pro == PRO_AFFINE || pro == PRO_SCALE) {
+            v = v * pa + ps;
+          } else if (pro == PRO_AFFINE_SNAKE) {
+            v = v * pa + ps;
+            float sn = sinf(alpha * v);
+            v = v + (1.0f / alpha) * (sn * sn);
+          } else if (pro == PRO_AFFINE_LRELU) {
+            v = v * pa + ps;
+            v = v > 0.f ? v : 0.2f * v;
+          } else if (pro == PRO_MASK) {
+            v *= a.mask[(size_t)b * T + t];
+          }
+        }
+        row[j] = v;
+      }
+    }
+    if (a.pro == PRO_LN_AFFINE) {
+      // LayerNorm over the Cin (<= 32, single chunk) channels of every in-range column, then affine.
+      __syncthreads();
+      for (int j = tid; j < LW; j += 256) {
+        const int t = t0 - a.pad + j;
+        if (t < 0 || t >= T) continue;
+        float mean = 0.f;
+        for (int c = 0; c < Cin; ++c) mean += xs[c * LW + j];
+        mean /= (float)Cin;
+        float var = 0.f;
+        for (int c = 0; c < Cin; ++c) {
+          float d = xs[c * LW + j] - mean;
+          var += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(var / (float)Cin + a.ln_eps);
+        for (int c = 0; c < Cin; ++c) xs[c * LW + j] = (xs[c * LW + j] - mean) * rstd * a.palpha[c] + a.pbeta[c];
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over taps x channel pairs ----
+    for (int k = 0; k < K; ++k) {
+      const float* wrow = a.w.wp + ((size_t)k * CinP + ci0 + hi) * CoutP + co0 + l31;
+      const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
+#pragma unroll
+      for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) {
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[n] = xrow[(2 * c2) * LW + n * 32];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  const int Cout = a.w.Cout;
+  if (a.act == ACT_GLU) {
+    // packed channel order: 32-blocks alternate (value block, gate block); MT == 2 pairs them per wave.
+    if constexpr (MT == 2) {
+      const int Ch = Cout / 2;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int t = t0 + tw + n * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int cp = co0 + row;                      // packed index of the value channel
+          const int ch = (cp >> 6) * 32 + (cp & 31);     // logical half-channel
+          if (t < T && ch < Ch) {
+            float va = acc[0][n][r] + a.w.bias[cp];
+            float vg = acc[1][n][r] + a.w.bias[cp + 32];
+            a.y[((size_t)b * Ch + ch) * T + t] = va * sigmoidf_(vg);
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma clang loop unroll(full)
+  for (int m = 0; m < MT; ++m) {
+#pragma clang loop unroll(full)
+    for (int n = 0; n < NT; ++n) {
+      const int t = t0 + tw + n * 32 + l31;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float x = acc[m][n][r];
+        if (a.w.bias) x += a.w.bias[co];
+        if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
+        else if (a.act == ACT_SWISH) x = x * sigmoidf_(x);
+        else if (a.act == ACT_SNAKE) {
+          const float al = a.act_alpha[co < Cout ? co : 0];
+          float sn = sinf(al * x);
+          x = x + (1.0f / al) * (sn * sn);
+        }
+        x *= a.out_scale;
+        if (a.out_mask && !a.out_mask_post && t < T) x *= a.out_mask[(size_t)b * T + t];
+        if (a.residual && co < Cout && t < T) x += a.residual[((size_t)b * Cout + co) * T + t];
+        v[r] = x;
+      }
+      if (a.ln_out) {  // LayerNorm over the 32 output channels of this column (Cout == 32, MT == 1)
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[r];
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / 32.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float d = v[r] - mean;
+          q += d * d;
+        }
+        q += __shfl_xor(q, 32);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 32.0f) + a.ln_eps);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          v[r] = (v[r] - mean) * rstd * a.ln_w[co] + a.ln_b[co];
+        }
+      }
+      if (t < T) {
+        const float om = (a.out_mask && a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (co < Cout) {
+            const float o = v[r] * om;
+            if (a.shuffle == 1) {
+              a.y[((size_t)b * Cout + co) * T + t] = o;
+            } else {
+              const int s = a.shuffle;
+              a.y[((size_t)b * (Cout / s) + co / s) * ((size_t)T * s) + (size_t)t * s + co % s] = o;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int MT, int NT>
+static int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  constexpr int CO_BLK = 32 * MT * WM;
+  constexpr int TT_BLK = 32 * NT * WN;
+  const int halo = (a.w.K - 1) * a.dil;
+  const size_t lds = (size_t)CI_CHUNK * (TT_BLK + halo) * sizeof(float);
+  if (lds > 64 * 1024) {
+    set_error("conv1d: LDS tile %zu B exceeds 64 KiB (K=%d dil=%d)", lds, a.w.K, a.dil);
+    return STY_EINVAL;
+  }
+  if (a.w.CoutP % CO_BLK != 0) {
+    set_error("conv1d: CoutP %d not a multiple of block tile %d", a.w.CoutP, CO_BLK);
+    return STY_EINVAL;
+  }
+  dim3 grid(cdiv(a.T, TT_BLK), a.w.CoutP / CO_BLK, a.B);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT>), grid, dim3(256), lds, st, a);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+int launch_conv1d(const ConvArgs& a, hipStream_t st) {
+  int cin = 0;
+  for (int i = 0; i < a.nsrc; ++i) cin += a.xc[i];
+  if (cin != a.w.Cin) {
+    set_error("conv1d: input channels %d != weight Cin %d", cin, a.w.Cin);
+    return STY_ESHAPE;
+  }
+  if (a.pro == PRO_LN_AFFINE && a.w.CinP != CI_CHUNK) {
+    set_error("conv1d: LN prologue needs Cin <= %d", CI_CHUNK);
+    return STY_EINVAL;
+  }
+  if (a.ln_out && a.w.Cout != 32) {
+    set_error("conv1d: LN epilogue needs Cout == 32");
+    return STY_EINVAL;
+  }
+  if (a.act == ACT_GLU) {
+    if (a.w.CoutP % 128 == 0 && a.T <= 4096) return launch_cfg<2, 2, 2, 2>(a, st);
+    return launch_cfg<1, 4, 2, 2>(a, st);
+  }
+  if (a.w.CoutP % 128 == 0) return launch_cfg<2, 2, 2, 2>(a, st);
+  if (a.w.CoutP % 64 == 0) return launch_cfg<1, 4, 2, 2>(a, st);
+  return launch_cfg<1, 4, 1, 2>(a, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing (+ weight_norm): one block per output channel.
+//   w: [Cout][Cin][K] plain weight, or nullptr with (g [Cout], v [Cout][Cin][K]) for weight_norm
+//   glu != 0: output-channel order is interleaved in 32-blocks (value block, gate block) for ACT_GLU.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ g,
+                                                        const float* __restrict__ v, const float* __restrict__ bias,
+                                                        int Cout, int Cin, int K, float* __restrict__ wp,
+                                                        float* __restrict__ bp, int CinP, int CoutP, int glu) {
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  const int n = Cin * K;
+  int cp = co;
+  if (glu) {
+    const int Ch = Cout / 2;
+    const int half = co >= Ch, c = half ? co - Ch : co;
+    cp = (c >> 5) * 64 + half * 32 + (c & 31);
+  }
+  float scale = 1.f;
+  const float* src = w;
+  if (!w) {
+    src = v;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      float x = v[(size_t)co * n + i];
+      s += x * x;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    scale = g[co] / sqrtf(red[0]);
+  }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / K, k = i % K;
+    wp[((size_t)k * CinP + ci) * CoutP + cp] = src[(size_t)co * n + i] * scale;
+  }
+  if (threadIdx.x == 0 && bp) bp[cp] = bias ? bias[co] : 0.f;
+}
+
+int launch_pack_conv(const float* w, const float* g, const float* v, const float* bias, int Cout, int Cin, int K,
+                     float* wp, float* bp, int CinP, int CoutP, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(Cout), dim3(256), 0, st, w, g, v, bias, Cout, Cin, K, wp, bp, CinP, CoutP, 0);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+int launch_pack_conv_glu(const float* w, const float* bias, int Cout, int Cin, int K, float* wp, float* bp, int CinP,
+                         int CoutP, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(Cout), dim3(256), 0, st, w, (const float*)nullptr, (const float*)nullptr,
+                     bias, Cout, Cin, K, wp, bp, CinP, CoutP, 1);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

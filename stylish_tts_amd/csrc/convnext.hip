@@ -1,0 +1,193 @@
+// Fused GeneratorConvNeXtBlock for C = 32 channels at the 75T frame rate (conv_next.py:80-93):
+//   dwconv k7 -> AdaLN(eps 1e-6) -> Linear 32->128 -> Snake -> GRN(over time) -> Linear 128->32 -> + x
+// Nine of these run on [B,32,75T] and carry most of the vocoder's activation traffic.
+// GRN needs sum_t h^2 per (b, channel) over the WHOLE utterance, so the block is two launches:
+//   pass 1 recomputes h = snake(pw1(adaln(dw(x)))) tile by tile and writes per-tile sum-of-squares;
+//   pass 2 recomputes h, scales it by the GRN factor and feeds it STRAIGHT from the MFMA accumulator
+//          registers into the second GEMM (the D fragment of GEMM-1 is already a legal B fragment of
+//          GEMM-2 when the reduction index is enumerated as (q, hi) -> row (q&3)+8(q>>2)+4hi),
+// so x is read twice and y written once: the 4C intermediate never touches HBM or even LDS.
+#include "sty_common.h"
+
+namespace sty {
+
+constexpr int CNX_TT = 256;  // time positions per block (4 waves x 2 MFMA column tiles)
+
+
+template <bool PASS2>
+__global__ __launch_bounds__(256) void convnext32_kernel(Cnx32Args a) {
+  constexpr int LW = CNX_TT + 6;
+  __shared__ __attribute__((aligned(16))) float xs[32 * LW];
+  __shared__ float red[4][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.y, t0 = blockIdx.x * CNX_TT, T = a.T;
+  const float* xb = a.x + (size_t)b * 32 * T;
+
+  // stage raw x tile with 3-sample halo, zero outside [0,T)
+  for (int c = wave; c < 32; c += 4) {
+    const float* src = xb + (size_t)c * T;
+    for (int j = lane; j < LW; j += 64) {
+      const int t = t0 - 3 + j;
+      xs[c * LW + j] = (t >= 0 && t < T) ? src[t] : 0.f;
+    }
+  }
+  __syncthreads();
+  // depthwise k7 + AdaLN over channels: one thread per time column, 32 channels in registers
+  {
+    float u[32];
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      float acc = a.dw_b[c];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc = fmaf(a.dw_w[c * 7 + k], xs[c * LW + tid + k], acc);
+      u[c] = acc;
+      mean += acc;
+    }
+    mean *= (1.0f / 32.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float d = u[c] - mean;
+      var += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 32.0f) + 1e-6f);
+    __syncthreads();  // all taps read before the tile is overwritten in place
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float g = 1.f + a.gb[b * 64 + c], be = a.gb[b * 64 + 32 + c];
+      xs[c * LW + 3 + tid] = (u[c] - mean) * rstd * g + be;
+    }
+  }
+  __syncthreads();
+
+  const int tw = wave * 64;
+  f32x16 acc2[2];
+  if (PASS2) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+  }
+  const float* xrow = xs + hi * LW + 3 + tw + l31;
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {
+    f32x16 h[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[n][r] = 0.f;
+    const float* wrow = a.w1p + hi * 128 + j * 32 + l31;
+#pragma unroll
+    for (int c2 = 0; c2 < 16; ++c2) {
+      const float av = wrow[(2 * c2) * 128];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        h[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xrow[(2 * c2) * LW + n * 32], h[n], 0, 0, 0);
+    }
+    float sq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float bias = a.b1[ch], al = a.alpha[ch];
+      const float ral = 1.0f / al;
+      float sc = 1.f;
+      if (PASS2) sc = a.scale[b * 128 + ch];
+      float s2 = 0.f;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        float v = h[n][r] + bias;
+        const float sn = sinf(al * v);
+        v = v + ral * (sn * sn);
+        if (PASS2) {
+          h[n][r] = v * sc;
+        } else {
+          const int t = t0 + tw + n * 32 + l31;
+          if (t < T) s2 += v * v;
+        }
+      }
+      sq[r] = s2;
+    }
+    if (PASS2) {
+      const float* w2 = a.w2a + ((j * 16) * 2 + hi) * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float av = w2[q * 64];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, h[n][q], acc2[n], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = sq[r];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        if (l31 == 0) red[wave][j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = v;
+      }
+    }
+  }
+  if (PASS2) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int t = t0 + tw + n * 32 + l31;
+      if (t < T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const size_t o = ((size_t)b * 32 + co) * T + t;
+          a.y[o] = acc2[n][r] + a.b2eff[co] + a.x[o];
+        }
+      }
+    }
+  } else {
+    __syncthreads();
+    if (tid < 128) {
+      const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+      a.part[(((size_t)b * 128 + tid) * a.ntiles + blockIdx.x) * 2 + 1] = s;
+    }
+  }
+}
+
+int convnext32_ntiles(int T) { return cdiv(T, CNX_TT); }
+
+int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st) {
+  dim3 grid(a.ntiles, B);
+  if (pass == 1)
+    hipLaunchKernelGGL(convnext32_kernel<false>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(convnext32_kernel<true>, grid, dim3(256), 0, st, a);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// pwconv2 [C][4C] -> A fragments of the chained GEMM: w2a[j][q][hi][co] = W2[co][32j + (q&3)+8(q>>2) + 4hi]
+// and b2eff[co] = b2[co] + sum_ch W2[co][ch] * grn_beta[ch].
+__global__ void pack_w2a_kernel(const float* __restrict__ w2, const float* __restrict__ b2,
+                                const float* __restrict__ grn_beta, int C, float* __restrict__ w2a,
+                                float* __restrict__ b2eff) {
+  const int C4 = 4 * C;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C4 * C) {
+    const int co = i % C, rest = i / C;
+    const int hi = rest & 1, q = (rest >> 1) & 15, j = rest >> 5;
+    const int ch = 32 * j + (q & 3) + 8 * (q >> 2) + 4 * hi;
+    w2a[i] = w2[(size_t)co * C4 + ch];
+  }
+  if (i < C) {
+    float acc = b2[i];
+    for (int ch = 0; ch < C4; ++ch) acc = fmaf(w2[(size_t)i * C4 + ch], grn_beta[ch], acc);
+    b2eff[i] = acc;
+  }
+}
+
+int launch_pack_w2a(const float* w2, const float* b2, const float* grn_beta, int C, float* w2a, float* b2eff,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(pack_w2a_kernel, dim3(cdiv(4 * C * C, 256)), dim3(256), 0, st, w2, b2, grn_beta, C, w2a, b2eff);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

@@ -1,0 +1,177 @@
+// Small data-movement / glue kernels of the text-encoder and decoder paths.
+#include "sty_common.h"
+
+namespace sty {
+
+// emb(tokens) * sqrt(H), transposed to channel-major [B][H][L] (text_encoder.py:453-454)
+__global__ void embedding_kernel(const int64_t* __restrict__ tok, const float* __restrict__ emb, int L, int H, int ntok,
+                                 float scale, float* __restrict__ y) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (l >= L) return;
+  int64_t t = tok[(size_t)b * L + l];
+  if (t < 0 || t >= ntok) t = 0;
+  y[((size_t)b * H + c) * L + l] = emb[(size_t)t * H + c] * scale;
+}
+int launch_embedding(const int64_t* tokens, const float* emb, int B, int L, int H, int ntok, float scale, float* y,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(embedding_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, tokens, emb, L, H, ntok, scale, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// sequence_mask (train/utils.py:54-58) as float [B][L]
+__global__ void length_mask_kernel(const int64_t* __restrict__ len, int L, float* __restrict__ mask) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (l < L) mask[(size_t)b * L + l] = (int64_t)l < len[b] ? 1.f : 0.f;
+}
+int launch_length_mask(const int64_t* lengths, int B, int L, float* mask, hipStream_t st) {
+  hipLaunchKernelGGL(length_mask_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, st, lengths, L, mask);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// text_encoding @ alignment (speech_predictor.py:60): y[b][c][t] = sum_l enc[b][c][l] * ali[b][l][t]
+__global__ __launch_bounds__(256) void bmm_ct_kernel(const float* __restrict__ enc, const float* __restrict__ ali,
+                                                     int C, int L, int T, float* __restrict__ y) {
+  extern __shared__ float es[];  // enc rows of this block's 4 channels: [4][L]
+  const int b = blockIdx.z, c0 = blockIdx.y * 4;
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63), cw = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * L; i += 256) {
+    const int cc = i / L, l = i % L;
+    es[i] = (c0 + cc < C) ? enc[((size_t)b * C + c0 + cc) * L + l] : 0.f;
+  }
+  __syncthreads();
+  if (t >= T || c0 + cw >= C) return;
+  const float* a = ali + (size_t)b * L * T + t;
+  float acc = 0.f;
+  for (int l = 0; l < L; ++l) acc = fmaf(es[cw * L + l], a[(size_t)l * T], acc);
+  y[((size_t)b * C + c0 + cw) * T + t] = acc;
+}
+int launch_bmm_ct(const float* enc, const float* ali, int B, int C, int L, int T, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(bmm_ct_kernel, dim3(cdiv(T, 64), cdiv(C, 4), B), dim3(256), 4 * L * sizeof(float), st, enc, ali,
+                     C, L, T, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+struct ConcatArgs {
+  const float* src[4];
+  int ch[4];
+  int nsrc, Ctot, T;
+};
+__global__ void concat_kernel(ConcatArgs a, float* __restrict__ y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= a.T) return;
+  int cl = c, s = 0;
+  while (s < a.nsrc - 1 && cl >= a.ch[s]) {
+    cl -= a.ch[s];
+    ++s;
+  }
+  y[((size_t)b * a.Ctot + c) * a.T + t] = a.src[s][((size_t)b * a.ch[s] + cl) * a.T + t];
+}
+int launch_concat(const float* const* src, const int* ch, int nsrc, int B, int T, float* y, hipStream_t st) {
+  ConcatArgs a;
+  a.nsrc = nsrc;
+  a.T = T;
+  a.Ctot = 0;
+  for (int i = 0; i < 4; ++i) {
+    a.src[i] = i < nsrc ? src[i] : nullptr;
+    a.ch[i] = i < nsrc ? ch[i] : 0;
+    a.Ctot += a.ch[i];
+  }
+  hipLaunchKernelGGL(concat_kernel, dim3(cdiv(T, 256), a.Ctot, B), dim3(256), 0, st, a, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// decoder.py:77-79: weight-normed 1->1 k3 convs on F0 / energy / voiced
+__global__ void prep_fnv_kernel(const float* g0, const float* v0, const float* b0, const float* g1, const float* v1,
+                                const float* b1, const float* g2, const float* v2, const float* b2, float* w34) {
+  const float* g[3] = {g0, g1, g2};
+  const float* v[3] = {v0, v1, v2};
+  const float* bb[3] = {b0, b1, b2};
+  const int i = threadIdx.x;
+  if (i < 3) {
+    const float n = sqrtf(v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2]);
+    for (int k = 0; k < 3; ++k) w34[i * 4 + k] = g[i][0] * v[i][k] / n;
+    w34[i * 4 + 3] = bb[i][0];
+  }
+}
+int launch_prep_fnv(const float* g0, const float* v0, const float* b0, const float* g1, const float* v1,
+                    const float* b1, const float* g2, const float* v2, const float* b2, float* w34, hipStream_t st) {
+  hipLaunchKernelGGL(prep_fnv_kernel, dim3(1), dim3(64), 0, st, g0, v0, b0, g1, v1, b1, g2, v2, b2, w34);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+__global__ void fnv_kernel(const float* __restrict__ p, const float* __restrict__ e, const float* __restrict__ v,
+                           const float* __restrict__ w34, int T, float* __restrict__ y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* src = (i == 0 ? p : (i == 1 ? e : v)) + (size_t)b * T;
+  const float x0 = t > 0 ? src[t - 1] : 0.f, x1 = src[t], x2 = t < T - 1 ? src[t + 1] : 0.f;
+  y[((size_t)b * 3 + i) * T + t] = w34[i * 4 + 0] * x0 + w34[i * 4 + 1] * x1 + w34[i * 4 + 2] * x2 + w34[i * 4 + 3];
+}
+int launch_fnv(const float* pitch, const float* energy, const float* voiced, const float* w34, int B, int T, float* y,
+               hipStream_t st) {
+  hipLaunchKernelGGL(fnv_kernel, dim3(cdiv(T, 256), 3, B), dim3(256), 0, st, pitch, energy, voiced, w34, T, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// DurationProcessor.duration_to_alignment (train/utils.py:752-791): one block per (b, t) column, softmax over L.
+__global__ __launch_bounds__(256) void alignment_kernel(const float* __restrict__ dur, int L, int T,
+                                                        float* __restrict__ ali) {
+  extern __shared__ float sm[];  // a[L]
+  __shared__ float red[256];
+  const int t = blockIdx.x, b = blockIdx.y;
+  // inclusive cumsum of durations is needed per l: recompute serially per thread chunk (L <= 512)
+  float mx = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    float upper = 0.f;
+    for (int i = 0; i <= l; ++i) upper += dur[(size_t)b * L + i];
+    const float d = dur[(size_t)b * L + l];
+    const float lower = upper - d;
+    const float mean = (lower + upper) / 2.f;
+    const float x = (float)t - mean;
+    const float q = x * 2.f / (d + 6.f);
+    float a = 1.f - q * q;
+    const bool in = ((float)t > lower - 3.f) && ((float)t < upper + 3.f);
+    a = in ? a : 0.f;
+    a = fmaxf(a, 0.f);
+    sm[l] = a;
+    mx = fmaxf(mx, a);
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float s = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const float e = expf(sm[l] - mx);
+    sm[l] = e;
+    s += e;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float inv = 1.f / red[0];
+  for (int l = threadIdx.x; l < L; l += 256) ali[((size_t)b * L + l) * T + t] = sm[l] * inv;
+}
+int launch_alignment(const float* dur, int B, int L, int T, float* ali, hipStream_t st) {
+  hipLaunchKernelGGL(alignment_kernel, dim3(T, B), dim3(256), L * sizeof(float), st, dur, L, T, ali);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

@@ -1,0 +1,145 @@
+// Host-side model object: parameters bound by reference state_dict key, prepared-weight arena, forward plans.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "sty_common.h"
+
+namespace sty {
+
+struct Param {
+  const float* p = nullptr;
+  std::vector<int64_t> shape;
+};
+
+int convnext32_ntiles(int T);
+int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st);
+int launch_pack_w2a(const float* w2, const float* b2, const float* grn_beta, int C, float* w2a, float* b2eff,
+                    hipStream_t st);
+int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st);
+int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st);
+int source_workspace_floats(int B, int T);
+int launch_source(int B, int T, const float* pitch, const float* voiced, const float* noise, uint64_t seed,
+                  const float* lin_w, const float* lin_b, float* prior, float* ws, hipStream_t st);
+int launch_stft64(int B, int N, const float* wave, const float* br, const float* bi, float* spec, float* phase,
+                  hipStream_t st);
+int launch_istft64(int B, int F, const float* logamp, const float* real, const float* imag, const float* bbr,
+                   const float* bbi, float* audio, hipStream_t st);
+void build_stft64_bases(float* out);
+
+// bump allocator over a caller-provided workspace (or a dry run that only measures)
+struct Bump {
+  char* base = nullptr;
+  size_t off = 0, cap = 0;
+  bool overflow = false;
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    if (base && off > cap) overflow = true;
+    return p;
+  }
+};
+
+enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A };
+struct PackJob {
+  PackKind kind;
+  const float *w = nullptr, *g = nullptr, *v = nullptr, *bias = nullptr, *extra = nullptr;
+  int Cout = 0, Cin = 0, K = 1, CinP = 0, CoutP = 0;
+  float* wp = nullptr;
+  float* bp = nullptr;
+};
+
+struct AdaFc {      // one AdaIN / AdaLN style projection
+  int idx = -1;     // index in the module's fc table
+  int C = 0;        // channels (fc produces 2C)
+  size_t off = 0;   // its [B][2C] output sits at gb_base + off*B
+};
+
+struct ConvNeXt {
+  int C = 0;
+  const float *dw_w = nullptr, *dw_b = nullptr, *b1 = nullptr, *alpha = nullptr, *grn_gamma = nullptr;
+  AdaFc norm;
+  PackedConv pw1, pw2;     // pw2.bias = b2eff (b2 + W2 . grn_beta)
+  const float* w2a = nullptr;  // C == 32 only: chained-GEMM fragments
+  const float* w1p = nullptr;
+};
+
+struct ResBlock32 {
+  PackedConv c1[3], c2[3];
+  AdaFc n1[3], n2[3];
+  const float *a1[3], *a2[3];
+};
+
+struct Conformer {
+  AdaFc ff1n, ff2n, attn_n, conv_n, post_n;
+  PackedConv ff1a, ff1b, ff2a, ff2b, to_q, to_kv, to_out, pw1, pw2;
+  const float *dw_w, *dw_b, *bn_w, *bn_b, *bn_rm, *bn_rv;
+};
+
+struct VocoderPlan {
+  PackedConv amp_input_conv;
+  const float *amp_norm_w, *amp_norm_b;
+  Conformer conf;
+  std::vector<ConvNeXt> amp_convnext;   // 5 x C=256
+  PackedConv upconv[3];
+  ConvNeXt upblock[3];                  // C = 128, 64, 32
+  const float *lin_w, *lin_b;           // m_source.l_linear
+  const float *stft_fr, *stft_fi, *stft_br, *stft_bi;
+  PackedConv amp_prior_conv, phase_prior_conv, phase_input_conv, amp_output_conv, real_conv, imag_conv;
+  ResBlock32 amp_prior_block, phase_prior_block;
+  const float *phase_norm_w, *phase_norm_b, *amp_fln_w, *amp_fln_b, *phase_fln_w, *phase_fln_b;
+  std::vector<ConvNeXt> phase_convnext;  // 8 x C=32
+  int hidden = 256;
+};
+
+struct TextEncLayer {
+  PackedConv q, k, v, o, f1, f2;
+  const float *n1g, *n1b, *n2g, *n2b;
+};
+struct TextEncPlan {
+  const float* emb = nullptr;
+  int tokens = 0, H = 0;
+  PackedConv pre[3], proj, proj_m;
+  const float *pre_g[3], *pre_b[3];
+  std::vector<TextEncLayer> layers;
+  float theta[4];
+};
+
+struct DecBlock {
+  int Cin = 0, Cout = 0;
+  PackedConv c1, c2, sc;
+  bool has_sc = false;
+  AdaFc n1, n2;
+};
+struct DecoderPlan {
+  DecBlock encode, decode[4];
+  PackedConv asr_res;
+  float* fnv_w = nullptr;  // [3][4]: effective k3 weights + bias of F0_conv, N_conv, voiced_conv (prepared)
+  const float *f0_g, *f0_v, *f0_b, *n_g, *n_v, *n_b, *v_g, *v_v, *v_b;
+};
+
+}  // namespace sty
+
+struct sty_model {
+  std::string kind;
+  std::unordered_map<std::string, sty::Param> params;
+  std::vector<std::string> requested;
+  bool finalized = false, prepared = false;
+  int style_dim = 64;
+  // prepared-weight arena
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  sty::Bump ab;
+  std::vector<sty::PackJob> jobs;
+  std::vector<sty::StyleFcDesc> fcs;  // host copy; out = offset encoded as pointer, patched per call
+  sty::StyleFcDesc* fcs_dev = nullptr;
+  size_t gb_floats_per_batch = 0;
+  std::string missing;
+  sty::VocoderPlan voc;
+  sty::TextEncPlan te;
+  sty::DecoderPlan dec;
+  float* stft_default = nullptr;  // device [4][33][64]
+};

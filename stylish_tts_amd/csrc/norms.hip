@@ -1,0 +1,273 @@
+// Normalisation / statistics kernels: style fc (AdaIN / AdaLN affine), per-row statistics over time
+// (InstanceNorm, GRN), channel LayerNorm, depthwise convolutions.  All HBM-bound streaming kernels:
+// lanes run along time (coalesced), reductions over time use fp64 partial sums written per segment
+// (deterministic two-stage reduction, no atomics).
+#include "sty_common.h"
+
+namespace sty {
+
+// ---- fc(style) for every AdaIN/AdaLN layer of a module in one launch (ada_norm.py:135-138,204-207) ----
+__global__ __launch_bounds__(256) void style_fc_kernel(const StyleFcDesc* __restrict__ descs, int style_dim,
+                                                       const float* __restrict__ style, float* __restrict__ gb_base,
+                                                       int B) {
+  __shared__ float s[256];
+  const StyleFcDesc d = descs[blockIdx.x];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < style_dim; i += 256) s[i] = style[(size_t)b * style_dim + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < d.n; j += 256) {
+    const float* w = d.W + (size_t)j * style_dim;
+    float acc = 0.f;
+    for (int k = 0; k < style_dim; ++k) acc = fmaf(s[k], w[k], acc);
+    gb_base[d.off * B + (size_t)b * d.n + j] = acc + d.b[j];
+  }
+}
+
+int launch_style_fc(const StyleFcDesc* descs_dev, int nlayers, int B, int style_dim, const float* style,
+                    float* gb_base, hipStream_t st) {
+  if (style_dim > 256) {
+    set_error("style_fc: style_dim %d > 256", style_dim);
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(style_fc_kernel, dim3(nlayers, B), dim3(256), 0, st, descs_dev, style_dim, style, gb_base, B);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- per-row partial sums over time ----
+constexpr int SEG = 4096;
+int row_stats_nseg(int T) { return cdiv(T, SEG); }
+
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int T, int nseg,
+                                                        double* __restrict__ part) {
+  __shared__ double rs[8], rq[8];
+  const int seg = blockIdx.x, row = blockIdx.y;
+  const float* p = x + (size_t)row * T;
+  const int beg = seg * SEG, end = min(beg + SEG, T);
+  double s = 0.0, q = 0.0;
+  for (int i = beg + threadIdx.x; i < end; i += 256) {
+    const double v = (double)p[i];
+    s += v;
+    q += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    rs[wave] = s;
+    rq[wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = rs[0] + rs[1] + rs[2] + rs[3], tq = rq[0] + rq[1] + rq[2] + rq[3];
+    part[((size_t)row * nseg + seg) * 2 + 0] = ts;
+    part[((size_t)row * nseg + seg) * 2 + 1] = tq;
+  }
+}
+
+int launch_row_stats(const float* x, int rows, int T, double* part, hipStream_t st) {
+  const int nseg = row_stats_nseg(T);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(nseg, rows), dim3(256), 0, st, x, T, nseg, part);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// AdaptiveInstance folded to a per-(b,c) affine (ada_norm.py:129-140): InstanceNorm1d biased var, eps 1e-5
+__global__ void adain_finalize_kernel(const double* __restrict__ part, int nseg, const float* __restrict__ gb, int B,
+                                      int C, int T, float eps, float* __restrict__ a, float* __restrict__ s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  double sum = 0.0, sq = 0.0;
+  for (int k = 0; k < nseg; ++k) {
+    sum += part[((size_t)i * nseg + k) * 2];
+    sq += part[((size_t)i * nseg + k) * 2 + 1];
+  }
+  const double mean = sum / T;
+  double var = sq / T - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = 1.f + gb[(size_t)b * 2 * C + c], be = gb[(size_t)b * 2 * C + C + c];
+  const float av = g * rstd;
+  a[i] = av;
+  s[i] = be - av * (float)mean;
+}
+
+int launch_adain_finalize(const double* part, int nseg, const float* gb, int B, int C, int T, float eps, float* a,
+                          float* s, hipStream_t st) {
+  hipLaunchKernelGGL(adain_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, part, nseg, gb, B, C, T, eps, a, s);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// GRN over time (conv_next.py:15-18): one block per batch row
+__global__ __launch_bounds__(256) void grn_finalize_kernel(const double* __restrict__ part, int nseg,
+                                                           const float* __restrict__ gamma, int C4,
+                                                           float* __restrict__ scale) {
+  __shared__ float red[256];
+  __shared__ float gxs[1024];
+  const int b = blockIdx.x;
+  float loc = 0.f;
+  for (int c = threadIdx.x; c < C4; c += 256) {
+    double sq = 0.0;
+    for (int k = 0; k < nseg; ++k) sq += part[(((size_t)b * C4 + c) * nseg + k) * 2 + 1];
+    const float gx = (float)sqrt(sq);
+    gxs[c] = gx;
+    loc += gx;
+  }
+  red[threadIdx.x] = loc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float mean = red[0] / (float)C4;
+  for (int c = threadIdx.x; c < C4; c += 256) scale[(size_t)b * C4 + c] = 1.f + gamma[c] * (gxs[c] / (mean + 1e-6f));
+}
+
+int launch_grn_finalize(const double* part, int nseg, const float* gamma, int B, int C4, float* scale,
+                        hipStream_t st) {
+  if (C4 > 1024) {
+    set_error("grn_finalize: 4C = %d > 1024", C4);
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, st, part, nseg, gamma, C4, scale);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- LayerNorm over channels, one thread per time column (generator.py:886-887; ada_norm.py:203-211) ----
+__global__ __launch_bounds__(64) void chan_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                            int T, float eps, int ada, const float* __restrict__ w,
+                                                            const float* __restrict__ bvec,
+                                                            const float* __restrict__ gb, int relu,
+                                                            const float* __restrict__ out_mask) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const float* p = x + (size_t)b * C * T + t;
+  float mean = 0.f;
+  for (int c = 0; c < C; ++c) mean += p[(size_t)c * T];
+  mean /= (float)C;
+  float var = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = p[(size_t)c * T] - mean;
+    var += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(var / (float)C + eps);
+  float* q = y + (size_t)b * C * T + t;
+  for (int c = 0; c < C; ++c) {
+    const float n = (p[(size_t)c * T] - mean) * rstd;
+    float sc, sh;
+    if (ada) {
+      sc = 1.f + gb[(size_t)b * 2 * C + c];
+      sh = gb[(size_t)b * 2 * C + C + c];
+    } else {
+      sc = w[c];
+      sh = bvec[c];
+    }
+    float o = n * sc + sh;
+    if (relu) o = fmaxf(o, 0.f);
+    if (out_mask) o *= out_mask[(size_t)b * T + t];
+    q[(size_t)c * T] = o;
+  }
+}
+
+int launch_chan_layernorm(const float* x, float* y, int B, int C, int T, float eps, int ada, const float* w,
+                          const float* bvec, const float* gb, int relu, const float* out_mask, hipStream_t st) {
+  hipLaunchKernelGGL(chan_layernorm_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, st, x, y, C, T, eps, ada, w, bvec, gb,
+                     relu, out_mask);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- depthwise conv k (zero 'same' padding) fused with AdaLN over channels (conv_next.py:82-84) ----
+// block = 64 time columns x all C channels; u tile in LDS, stats per column, normalised write-out.
+__global__ __launch_bounds__(256) void dwconv_adaln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int C, int T, int K,
+                                                           float eps, const float* __restrict__ gb,
+                                                           float* __restrict__ y, int TT) {
+  extern __shared__ __attribute__((aligned(16))) float u[];  // [C][TT] then stats [2][TT]
+  float* smean = u + (size_t)C * TT;
+  float* srstd = smean + TT;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  const int pad = K / 2;
+  const int tid = threadIdx.x;
+  const int lane = tid % TT, grp = tid / TT, ngrp = 256 / TT;
+  const int t = t0 + lane;
+  for (int c = grp; c < C; c += ngrp) {
+    const float* p = x + ((size_t)b * C + c) * T;
+    float acc = bias[c];
+    for (int k = 0; k < K; ++k) {
+      const int tt = t - pad + k;
+      if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+    }
+    u[c * TT + lane] = acc;
+  }
+  __syncthreads();
+  if (tid < TT) {
+    float mean = 0.f;
+    for (int c = 0; c < C; ++c) mean += u[c * TT + tid];
+    mean /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = u[c * TT + tid] - mean;
+      var += d * d;
+    }
+    smean[tid] = mean;
+    srstd[tid] = 1.0f / sqrtf(var / (float)C + eps);
+  }
+  __syncthreads();
+  if (t < T) {
+    const float mean = smean[lane], rstd = srstd[lane];
+    for (int c = grp; c < C; c += ngrp) {
+      const float g = 1.f + gb[(size_t)b * 2 * C + c], be = gb[(size_t)b * 2 * C + C + c];
+      y[((size_t)b * C + c) * T + t] = (u[c * TT + lane] - mean) * rstd * g + be;
+    }
+  }
+}
+
+int launch_dwconv_adaln(const float* x, const float* w, const float* bias, int B, int C, int T, int K, float eps,
+                        const float* gb, float* y, hipStream_t st) {
+  const int TT = C > 128 ? 32 : 64;
+  const size_t lds = ((size_t)C * TT + 2 * TT) * sizeof(float);
+  hipLaunchKernelGGL(dwconv_adaln_kernel, dim3(cdiv(T, TT), B), dim3(256), lds, st, x, w, bias, C, T, K, eps, gb, y, TT);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- conformer conv module: depthwise k31 (pad 15,15) -> BatchNorm1d(eval) -> Swish (conformer.py:180-184) ----
+__global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ bn_w,
+                                                              const float* __restrict__ bn_b,
+                                                              const float* __restrict__ bn_rm,
+                                                              const float* __restrict__ bn_rv, float bn_eps, int C,
+                                                              int T, int K, float* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* p = x + ((size_t)b * C + c) * T;
+  const int pad = K / 2;
+  float acc = bias[c];
+  for (int k = 0; k < K; ++k) {
+    const int tt = t - pad + k;
+    if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+  }
+  float v = (acc - bn_rm[c]) / sqrtf(bn_rv[c] + bn_eps) * bn_w[c] + bn_b[c];
+  v = v * (1.0f / (1.0f + expf(-v)));
+  y[((size_t)b * C + c) * T + t] = v;
+}
+
+int launch_dwconv_bn_swish(const float* x, const float* w, const float* bias, const float* bn_w, const float* bn_b,
+                           const float* bn_rm, const float* bn_rv, float bn_eps, int B, int C, int T, int K, float* y,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(dwconv_bn_swish_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, x, w, bias, bn_w, bn_b, bn_rm,
+                     bn_rv, bn_eps, C, T, K, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

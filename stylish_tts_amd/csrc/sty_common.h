@@ -1,0 +1,167 @@
+// Shared declarations for libstylish_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/stylish_hip.h"
+
+namespace sty {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define STY_HIP(expr)                                      \
+  do {                                                     \
+    hipError_t _e = (expr);                                \
+    if (_e != hipSuccess) return sty::hip_fail(_e, #expr); \
+  } while (0)
+
+#define STY_LAUNCH_CHECK() STY_HIP(hipGetLastError())
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// Packed weights.  A dense conv weight [Cout][Cin][K] (torch layout) is repacked once per optimiser
+// step into the MFMA A-operand order  Wp[k][ci][co]  (co fastest, Cin padded to CinP = even multiple
+// of CI_CHUNK, Cout padded to CoutP = multiple of 32; padding is zero).  For v_mfma_f32_32x32x2_f32 lane l
+// needs A[i = l&31][kk = l>>5]: two 128-B rows of Wp per instruction, fully coalesced.
+// ---------------------------------------------------------------------------------------------
+struct PackedConv {
+  const float* wp = nullptr;    // [K][CinP][CoutP]
+  const float* bias = nullptr;  // [CoutP] (zero padded) or nullptr
+  int Cin = 0, Cout = 0, K = 1, CinP = 0, CoutP = 0;
+};
+
+constexpr int CI_CHUNK = 32;  // channels staged in LDS per reduction chunk
+
+// prologue applied to the conv INPUT while it is staged into LDS (zero padding is applied AFTER it)
+enum ConvPro : int {
+  PRO_NONE = 0,
+  PRO_AFFINE = 1,        // x*a[b,c] + s[b,c]
+  PRO_AFFINE_SNAKE = 2,  // AdaIN folded into (a,s), then x + sin^2(alpha x)/alpha
+  PRO_AFFINE_LRELU = 3,  // AdaIN folded, then LeakyReLU(0.2)
+  PRO_LN_AFFINE = 4,     // LayerNorm over the (<=32) input channels, then * w[c] + b[c]
+  PRO_MASK = 5,          // x * mask[b,t]
+  PRO_SCALE = 6,         // x * a[b,c]   (GRN scale)
+};
+// epilogue activation applied to (acc + bias)
+enum ConvAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2, ACT_SNAKE = 3, ACT_GLU = 4 };
+
+struct ConvArgs {
+  // input: up to 3 channel-concatenated sources
+  const float* x[3] = {nullptr, nullptr, nullptr};
+  int xc[3] = {0, 0, 0};
+  int nsrc = 1;
+  int B = 0, T = 0;
+  int dil = 1, pad = 0;
+  PackedConv w;
+  int pro = PRO_NONE;
+  const float* pa = nullptr;     // [B][Cin] scale
+  const float* ps = nullptr;     // [B][Cin] shift
+  const float* palpha = nullptr; // [Cin] snake alpha / LN weight
+  const float* pbeta = nullptr;  // [Cin] LN bias
+  float ln_eps = 1e-6f;
+  const float* mask = nullptr;   // [B][T]
+  int act = ACT_NONE;
+  const float* act_alpha = nullptr;  // [Cout] snake alpha for ACT_SNAKE
+  float out_scale = 1.f;             // y = out_scale * act(acc + bias) + residual
+  const float* residual = nullptr;   // [B][Cout][T]
+  const float* out_mask = nullptr;   // [B][T]: applied before the residual add, or after everything if out_mask_post
+  int out_mask_post = 0;
+  int shuffle = 1;                   // pixel shuffle factor s: y[b][co/s][t*s + co%s]
+  int ln_out = 0;                    // LayerNorm over the 32 output channels (Cout == 32 only)
+  const float* ln_w = nullptr;
+  const float* ln_b = nullptr;
+  float* y = nullptr;
+  double* stats = nullptr;  // optional [B][Cout][2] (sum, sumsq) accumulated with atomics (pre-zeroed)
+};
+
+int launch_conv1d(const ConvArgs& a, hipStream_t st);
+
+// weight preparation
+int launch_pack_conv(const float* w, const float* g, const float* v, const float* bias, int Cout, int Cin, int K,
+                     float* wp, float* bp, int CinP, int CoutP, hipStream_t st);
+
+}  // namespace sty
+
+namespace sty {
+int launch_pack_conv_glu(const float* w, const float* bias, int Cout, int Cin, int K, float* wp, float* bp, int CinP,
+                         int CoutP, hipStream_t st);
+
+// ---- norms.hip ------------------------------------------------------------------------------
+struct StyleFcDesc {
+  const float* W;  // [n][style_dim]
+  const float* b;  // [n]
+  size_t off;      // output = gb_base + off*B, laid out [B][n]
+  int n;
+  int pad;
+};
+int launch_style_fc(const StyleFcDesc* descs_dev, int nlayers, int B, int style_dim, const float* style,
+                    float* gb_base, hipStream_t st);
+// per-row (b,c) partial sums over time: part[row][nseg][2] doubles; nseg = row_stats_nseg(T)
+int row_stats_nseg(int T);
+int launch_row_stats(const float* x, int rows, int T, double* part, hipStream_t st);
+// AdaIN fold: gb = fc(style) [B][2C] -> a = (1+gamma)*rstd, s = beta - a*mean
+int launch_adain_finalize(const double* part, int nseg, const float* gb, int B, int C, int T, float eps, float* a,
+                          float* s, hipStream_t st);
+// GRN: part holds sum of h^2 per (b,ch) -> scale[b][ch] = 1 + gamma[ch]*gx/(mean_ch gx + 1e-6)
+int launch_grn_finalize(const double* part, int nseg, const float* gamma, int B, int C4, float* scale, hipStream_t st);
+// LayerNorm over channels of [B,C,T]; ada=0: y = LN(x)*w[c]+b[c];  ada=1: y = LN(x)*(1+gb[b][c]) + gb[b][C+c]
+int launch_chan_layernorm(const float* x, float* y, int B, int C, int T, float eps, int ada, const float* w,
+                          const float* bvec, const float* gb, int relu, const float* out_mask, hipStream_t st);
+// ---- misc.hip ----
+int launch_embedding(const int64_t* tokens, const float* emb, int B, int L, int H, int ntok, float scale, float* y,
+                     hipStream_t st);
+int launch_length_mask(const int64_t* lengths, int B, int L, float* mask, hipStream_t st);
+int launch_bmm_ct(const float* enc, const float* ali, int B, int C, int L, int T, float* y, hipStream_t st);
+int launch_concat(const float* const* src, const int* ch, int nsrc, int B, int T, float* y, hipStream_t st);
+// three 1->1 k3 convs (weights prepared as [3][4] = w0,w1,w2,bias) on pitch/energy/voiced -> fnv [B][3][T]
+int launch_fnv(const float* pitch, const float* energy, const float* voiced, const float* w34, int B, int T, float* y,
+               hipStream_t st);
+int launch_prep_fnv(const float* g0, const float* v0, const float* b0, const float* g1, const float* v1,
+                    const float* b1, const float* g2, const float* v2, const float* b2, float* w34, hipStream_t st);
+int launch_alignment(const float* dur, int B, int L, int T, float* ali, hipStream_t st);
+// depthwise conv (k taps, 'same' zero padding pad_l) [+ AdaLN over channels]  (ConvNeXt front half)
+int launch_dwconv_adaln(const float* x, const float* w, const float* bias, int B, int C, int T, int K, float eps,
+                        const float* gb, float* y, hipStream_t st);
+// conformer conv module middle: depthwise k31 (pad 15/15) + BatchNorm(eval) + Swish
+int launch_dwconv_bn_swish(const float* x, const float* w, const float* bias, const float* bn_w, const float* bn_b,
+                           const float* bn_rm, const float* bn_rv, float bn_eps, int B, int C, int T, int K,
+                           float* y, hipStream_t st);
+}  // namespace sty
+
+namespace sty {
+struct Cnx32Args {
+  const float* x;       // [B][32][T]
+  const float* dw_w;    // [32][7]
+  const float* dw_b;    // [32]
+  const float* gb;      // [B][64] AdaLN fc(style): gamma | beta
+  const float* w1p;     // packed pwconv1: [32 ci][128 ch]
+  const float* b1;      // [128]
+  const float* alpha;   // [128] snake
+  const float* w2a;     // packed pwconv2 A-fragments: [4 j][16 q][2 hi][32 co]
+  const float* b2eff;   // [32] = b2 + W2 . grn_beta
+  const float* scale;   // [B][128] GRN scale (pass 2)
+  double* part;         // [B][128][ntiles][2] (pass 1; slot 1 = sum of squares)
+  float* y;             // [B][32][T] (pass 2)
+  int T, ntiles;
+};
+
+struct AttnArgs {
+  const float* q;  // [B][H*DH][T]   (batch stride qbs floats)
+  const float* k;
+  const float* v;
+  float* o;        // [B][H*DH][T]
+  size_t qbs, kbs, vbs, obs;
+  int T, H;
+  float scale;
+  const int64_t* lengths;  // optional [B]: additive -1e4 where query or key index >= length
+};
+}  // namespace sty

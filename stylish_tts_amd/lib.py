@@ -1,0 +1,85 @@
+"""ctypes binding of libstylish_hip.so (include/stylish_hip.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstylish_hip.so")
+
+
+class StyError(RuntimeError):
+    pass
+
+
+class VocoderIO(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int)] + [
+        (n, C.c_void_p) for n in ("mel", "style", "pitch", "voiced", "noise", "prior_override")
+    ] + [("seed", C.c_uint64), ("audio", C.c_void_p)] + [
+        (n, C.c_void_p) for n in ("tap_conformer_out", "tap_prior", "tap_har_spec", "tap_har_phase",
+                                  "tap_logamp_prior", "tap_phase_prior", "tap_trunk", "tap_logamp")
+    ]
+
+
+class SpeechIO(C.Structure):
+    _fields_ = [("B", C.c_int), ("L", C.c_int), ("T", C.c_int)] + [
+        (n, C.c_void_p) for n in ("texts", "text_lengths", "alignment", "pitch", "energy", "voiced", "style",
+                                  "denormal_pitch", "noise", "prior_override")
+    ] + [("seed", C.c_uint64), ("audio", C.c_void_p), ("tap_text_encoding", C.c_void_p),
+         ("tap_decoder_out", C.c_void_p), ("voc_taps", VocoderIO)]
+
+
+# every symbol include/stylish_hip.h declares: name -> (restype, argtypes)
+_P, _I, _SZP = C.c_void_p, C.c_int, C.POINTER(C.c_size_t)
+SYMBOLS = {
+    "sty_version": (C.c_int, []),
+    "sty_last_error": (C.c_char_p, []),
+    "sty_model_create": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "sty_model_destroy": (None, [_P]),
+    "sty_model_bind": (C.c_int, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64)]),
+    "sty_model_finalize": (C.c_int, [_P]),
+    "sty_model_num_keys": (C.c_int, [_P]),
+    "sty_model_key": (C.c_char_p, [_P, _I]),
+    "sty_model_prepare": (C.c_int, [_P, _P]),
+    "sty_vocoder_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
+    "sty_vocoder_fwd": (C.c_int, [_P, C.POINTER(VocoderIO), _P, C.c_size_t, _P]),
+    "sty_speech_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
+    "sty_speech_fwd": (C.c_int, [_P, C.POINTER(SpeechIO), _P, C.c_size_t, _P]),
+    "sty_style_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
+    "sty_style_fwd": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
+    "sty_mel_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _SZP]),
+    "sty_mel_fwd": (C.c_int, [_I, _I, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _P]),
+    "sty_alignment_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P]),
+    "sty_convnext_fwd": (C.c_int, [_P, C.c_char_p, _I, _I, _I, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_resblock_fwd": (C.c_int, [_P, C.c_char_p, _I, _I, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_stft64_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P]),
+    "sty_istft64_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P]),
+    "sty_source_fwd": (C.c_int, [_I, _I, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_source_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
+}
+
+LIB = None
+
+
+def load():
+    """Load the in-tree shared library (built by `python -m stylish_tts_amd.build` / __graft_entry__.build())."""
+    global LIB
+    if LIB is not None:
+        return LIB
+    if not os.path.exists(LIB_PATH):
+        raise StyError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+                       "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise StyError(f"libstylish_hip: status {rc}: {LIB.sty_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

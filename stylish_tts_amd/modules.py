@@ -1,0 +1,280 @@
+"""nn.Module shells with the reference's constructor arguments, forward signatures and state_dict keys,
+whose forward runs libstylish_hip.so (hand-written gfx950 kernels) on the current HIP stream.
+
+Reference interfaces mirrored here (paths under the reference tree, src/stylish_tts/train/models/):
+  SpeechPredictor(model_config).forward(texts, text_lengths, alignment, pitch, energy, voiced, style,
+      denormal_pitch) -> DecoderPrediction            speech_predictor.py:10-73
+  MultiGenerator(style_dim=, n_fft=, win_length=, hop_length=, sample_rate=, config=)
+      .forward(*, mel, style, pitch, energy, voiced) -> DecoderPrediction     generator.py:802-901
+  MelStyleEncoder(dim_in, style_dim, max_conv_dim, skip_downsamples).forward(x) -> [B, style_dim]
+      mel_style_encoder.py:121-152
+Forward only in this revision: calling with autograd enabled raises (no silent PyTorch fallback).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .manifest import DEFAULT_CFG, speech_predictor_manifest, style_encoder_manifest
+
+
+class DecoderPrediction:  # train/utils.py:643-653
+    def __init__(self, *, audio, magnitude, phase):
+        self.audio = audio
+        self.magnitude = magnitude
+        self.phase = phase
+
+
+_BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked", "weight_u", "weight_v")
+
+
+class _Node(torch.nn.Module):
+    """Anonymous container so that dotted state_dict keys come out identical to the reference's."""
+
+
+def _register(root, key, tensor, as_buffer):
+    parts = key.split(".")
+    node = root
+    for p in parts[:-1]:
+        if not hasattr(node, p):
+            node.add_module(p, _Node())
+        node = getattr(node, p)
+    if as_buffer:
+        node.register_buffer(parts[-1], tensor)
+    else:
+        node.register_parameter(parts[-1], torch.nn.Parameter(tensor))
+
+
+def _init_value(key, shape):
+    """Reference-like initialisation (generator.py:705-708, common.py:5-8, conv_next.py:12-13,73)."""
+    last = key.rsplit(".", 1)[-1]
+    t = torch.zeros(shape)
+    if last == "num_batches_tracked":
+        return torch.zeros((), dtype=torch.int64)
+    if last in ("running_var", "snake", "original0", "gamma") or key.count(".alpha") or \
+            (last == "weight" and len(shape) == 1):
+        if key.endswith("grn.gamma"):
+            return t
+        return torch.ones(shape)
+    if last in ("weight", "weight_orig", "original1") and len(shape) >= 2:
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        return torch.nn.init.trunc_normal_(t, std=min(0.02, fan_in ** -0.5) if "basegen" in key else fan_in ** -0.5)
+    if last in ("weight_u", "weight_v"):
+        return torch.nn.functional.normalize(torch.randn(shape), dim=0)
+    return t
+
+
+class _HipModule(torch.nn.Module):
+    KIND = None
+
+    def _build(self, manifest, stft_buffers=None):
+        for key, shape in manifest.items():
+            last = key.rsplit(".", 1)[-1]
+            if ".stft." in key:
+                _register(self, key, stft_buffers[key.rsplit("stft.", 1)[1]].clone(), True)
+            else:
+                _register(self, key, _init_value(key, tuple(shape)), last in _BUFFER_SUFFIXES)
+        self._manifest = dict(manifest)
+        self._handle = None
+        self._bound = None
+        self._ws = None
+
+    # ---- C-ABI plumbing ----
+    def _ensure(self, device):
+        lib = L.load()
+        sd = {k: v for k, v in self.state_dict(keep_vars=True).items()}
+        ptrs = {}
+        for k, v in sd.items():
+            if not v.is_floating_point():
+                continue
+            if v.device != device or v.dtype != torch.float32 or not v.is_contiguous():
+                raise L.StyError(f"{k}: parameters must be contiguous fp32 on {device} (got {v.dtype}, {v.device})")
+            ptrs[k] = v.data_ptr()
+        if self._handle is None:
+            h = C.c_void_p()
+            L.check(lib.sty_model_create(self.KIND.encode(), C.byref(h)))
+            self._handle = h
+        if self._bound != ptrs:
+            for k, v in sd.items():
+                if k not in ptrs:
+                    continue
+                shp = (C.c_int64 * v.dim())(*v.shape)
+                L.check(lib.sty_model_bind(self._handle, k.encode(), C.c_void_p(ptrs[k]), v.dim(), shp))
+            L.check(lib.sty_model_finalize(self._handle))
+            self._bound = ptrs
+        return lib
+
+    def requested_keys(self):
+        lib = L.load()
+        return [lib.sty_model_key(self._handle, i).decode() for i in range(lib.sty_model_num_keys(self._handle))]
+
+    def prepare(self):
+        """Re-derive packed / normalised weights after an optimiser step (sty_model_prepare)."""
+        lib = L.load()
+        L.check(lib.sty_model_prepare(self._handle, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None and L.LIB is not None:
+                L.LIB.sty_model_destroy(self._handle)
+        except Exception:
+            pass
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _no_autograd(what):
+    if torch.is_grad_enabled():
+        raise L.StyError(f"{what}: backward kernels are not built in this revision; call under torch.no_grad()")
+
+
+def _stft_buffers():
+    """STFT(64, hop 4) bases as the reference registers them (stft.py:39-96): built by the library's host code."""
+    import numpy as np
+
+    n_fft = 64
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float32)
+    w = win.numpy()  # fp32 window; products below are taken in float64 and rounded once, as numpy does there
+    ang = 2.0 * np.pi * np.outer(np.arange(n_fft // 2 + 1), np.arange(n_fft)) / n_fft
+    f32 = lambda a: torch.from_numpy(a).float().unsqueeze(1)
+    inv = w * (1.0 / n_fft)
+    return {"window": win, "weight_forward_real": f32(np.cos(ang) * w), "weight_forward_imag": f32(-np.sin(ang) * w),
+            "weight_backward_real": f32(np.cos(ang) * inv), "weight_backward_imag": f32(np.sin(ang) * inv)}
+
+
+def _cfg_from_model_config(mc):
+    g, te, se = mc.generator, mc.text_encoder, mc.style_encoder
+    return dict(sample_rate=mc.sample_rate, n_mels=mc.n_mels, n_fft=mc.n_fft, win_length=mc.win_length,
+                hop_length=mc.hop_length, style_dim=mc.style_dim, inter_dim=mc.inter_dim,
+                dec_hidden=mc.decoder.hidden_dim, dec_residual=mc.decoder.residual_dim,
+                gen_input_dim=g.input_dim, io_kernel=g.io_conv_kernel_size, conformer_layers=g.conformer_layers,
+                conv_layers=g.conv_layers, tokens=te.tokens, te_hidden=te.hidden_dim, te_filter=te.filter_channels,
+                te_heads=te.heads, te_layers=te.layers, te_kernel=te.kernel_size, se_n_mels=se.n_mels,
+                se_max_channels=se.max_channels, se_skip_downsample=se.skip_downsample)
+
+
+class SpeechPredictor(_HipModule):
+    KIND = "speech_predictor"
+
+    def __init__(self, model_config=None):
+        super().__init__()
+        cfg = dict(DEFAULT_CFG) if model_config is None else _cfg_from_model_config(model_config)
+        self.cfg = cfg
+        self._build(speech_predictor_manifest(cfg), _stft_buffers())
+
+    def forward(self, texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, *, noise=None,
+                seed=0, prior_override=None, taps=None):
+        """Same positional signature as the reference.  Extra keyword-only arguments make the reference's
+        implicit RNG explicit: `noise` [B,300T,9] = SineGen's randn draw (generator.py:440-442); without it a
+        counter-based generator seeded with `seed` is used.  `taps`: dict name -> preallocated tensor."""
+        _no_autograd("SpeechPredictor.forward")
+        dev = style.device
+        lib = self._ensure(dev)
+        B, Lt = texts.shape
+        T = pitch.shape[1]
+        io = L.SpeechIO()
+        io.B, io.L, io.T = B, Lt, T
+        keep = [texts.to(dev, torch.int64).contiguous(), text_lengths.to(dev, torch.int64).contiguous()]
+        io.texts, io.text_lengths = keep[0].data_ptr(), keep[1].data_ptr()
+        for name, t in (("alignment", alignment), ("pitch", pitch), ("energy", energy), ("voiced", voiced),
+                        ("style", style), ("denormal_pitch", denormal_pitch), ("noise", noise),
+                        ("prior_override", prior_override)):
+            if t is not None:
+                t = _f32(t, dev)
+                keep.append(t)
+                setattr(io, name, t.data_ptr())
+        io.seed = int(seed)
+        audio = torch.empty(B, 1, 300 * T, dtype=torch.float32, device=dev)
+        io.audio = audio.data_ptr()
+        for k, t in (taps or {}).items():
+            if k in ("tap_text_encoding", "tap_decoder_out"):
+                setattr(io, k, t.data_ptr())
+            else:
+                setattr(io.voc_taps, k, t.data_ptr())
+        need = C.c_size_t()
+        L.check(lib.sty_speech_workspace_bytes(self._handle, B, Lt, T, C.byref(need)))
+        ws = self._workspace(need.value, dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_speech_fwd(self._handle, C.byref(io), C.c_void_p(ws.data_ptr()), ws.numel(), st))
+        return DecoderPrediction(audio=audio, magnitude=None, phase=None)
+
+    def vocoder_forward(self, *, mel, style, pitch, energy=None, voiced, noise=None, seed=0, prior_override=None,
+                        taps=None):
+        """MultiGenerator.forward on this predictor's `generator.*` weights (generator.py:884-901)."""
+        _no_autograd("MultiGenerator.forward")
+        dev = style.device
+        lib = self._ensure(dev)
+        B, _, T = mel.shape
+        io = L.VocoderIO()
+        io.B, io.T = B, T
+        keep = []
+        for name, t in (("mel", mel), ("style", style), ("pitch", pitch), ("voiced", voiced), ("noise", noise),
+                        ("prior_override", prior_override)):
+            if t is not None:
+                t = _f32(t, dev)
+                keep.append(t)
+                setattr(io, name, t.data_ptr())
+        io.seed = int(seed)
+        audio = torch.empty(B, 1, 300 * T, dtype=torch.float32, device=dev)
+        io.audio = audio.data_ptr()
+        for k, t in (taps or {}).items():
+            setattr(io, k, t.data_ptr())
+        need = C.c_size_t()
+        L.check(lib.sty_vocoder_workspace_bytes(self._handle, B, T, C.byref(need)))
+        ws = self._workspace(need.value, dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_vocoder_fwd(self._handle, C.byref(io), C.c_void_p(ws.data_ptr()), ws.numel(), st))
+        return DecoderPrediction(audio=audio, magnitude=None, phase=None)
+
+
+class MultiGenerator(SpeechPredictor):
+    """Vocoder-only view with the reference's keyword constructor (generator.py:803-805).  Holds the same
+    `generator.*`-free key layout as the reference MultiGenerator by prefix-stripping is NOT done here: use
+    SpeechPredictor.vocoder_forward for checkpoints of the whole predictor."""
+
+    def __init__(self, *, style_dim=64, n_fft=512, win_length=512, hop_length=300, sample_rate=24000, config=None):
+        cfg = dict(style_dim=style_dim, n_fft=n_fft, win_length=win_length, hop_length=hop_length,
+                   sample_rate=sample_rate)
+        if config is not None:
+            cfg.update(gen_input_dim=config.input_dim, io_kernel=config.io_conv_kernel_size,
+                       conformer_layers=config.conformer_layers, conv_layers=config.conv_layers)
+        torch.nn.Module.__init__(self)
+        self.cfg = dict(DEFAULT_CFG, **cfg)
+        self._build(speech_predictor_manifest(self.cfg), _stft_buffers())
+
+    def forward(self, *, mel, style, pitch, energy, voiced, **kw):
+        return self.vocoder_forward(mel=mel, style=style, pitch=pitch, energy=energy, voiced=voiced, **kw)
+
+
+class MelStyleEncoder(_HipModule):
+    KIND = "mel_style_encoder"
+
+    def __init__(self, dim_in=80, style_dim=64, max_conv_dim=384, skip_downsamples=True):
+        super().__init__()
+        self.cfg = dict(DEFAULT_CFG, se_n_mels=dim_in, style_dim=style_dim, se_max_channels=max_conv_dim,
+                        se_skip_downsample=skip_downsamples)
+        self._build(style_encoder_manifest(self.cfg))
+
+    def forward(self, x):
+        _no_autograd("MelStyleEncoder.forward")
+        dev = x.device
+        lib = self._ensure(dev)
+        B, _, _, T = x.shape
+        x = _f32(x, dev)
+        out = torch.empty(B, self.cfg["style_dim"], dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_style_workspace_bytes(self._handle, B, T, C.byref(need)))
+        ws = self._workspace(need.value, dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_style_fwd(self._handle, B, T, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), st))
+        return out

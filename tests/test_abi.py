@@ -1,0 +1,75 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/stylish_hip.h declares,
+and the nn.Module shells reproduce the reference's state_dict layout.  No compute calls (no GPU here)."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from stylish_tts_amd import lib as L
+    return L.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "stylish_hip.h")).read()
+    declared = set(re.findall(r"\b(sty_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sty_status"}
+    from stylish_tts_amd import lib as L
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sty_version() >= 1
+
+
+def test_error_paths_without_gpu(lib):
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.sty_model_create(b"no_such_kind", C.byref(h)) == -1
+    assert b"unknown model kind" in lib.sty_last_error()
+    assert lib.sty_model_create(b"speech_predictor", C.byref(h)) == 0
+    # forward before finalize -> STY_ESTATE, never a silent fallback
+    need = C.c_size_t()
+    assert lib.sty_vocoder_workspace_bytes(h, 2, 80, C.byref(need)) == -5
+    lib.sty_model_destroy(h)
+
+
+def test_module_shells_have_reference_state_dict_layout():
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    G = os.path.join(ROOT, "tests", "golden")
+    sp = S.SpeechPredictor()
+    ref = json.load(open(os.path.join(G, "manifest_speech_predictor.json")))
+    assert {k: list(v.shape) for k, v in sp.state_dict().items()} == ref
+    se = S.MelStyleEncoder()
+    ref = json.load(open(os.path.join(G, "manifest_style_encoder.json")))
+    assert {k: list(v.shape) for k, v in se.state_dict().items()} == ref
+    # STFT bases registered by the shell are bit-identical to the reference's buffers
+    bufs = load_file(os.path.join(G, "stft_buffers.safetensors"))
+    for k, v in bufs.items():
+        assert torch.equal(sp.state_dict()["generator.basegen.stft." + k], v), k
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "stylish_tts_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_forward_refuses_autograd_and_cpu():
+    import stylish_tts_amd as S
+    sp = S.SpeechPredictor()
+    x = torch.zeros(1, 128, 8)
+    with pytest.raises(S.StyError):
+        sp.vocoder_forward(mel=x, style=torch.zeros(1, 64), pitch=torch.zeros(1, 8), voiced=torch.zeros(1, 8))
