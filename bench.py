@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Benchmark of the stylish-tts acoustic hot path on MI355X (see DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c5]
+
+A step is one pass of the hot path over one synthetic batch already resident in HBM:
+  c2 (default; BASELINE.json configs[1]): sample_dataset shape, B=16 utterances of T=160 mel frames (2.0 s),
+      L=37 phoneme tokens, fp32 -- the acoustic step's forward (text encoder -> alignment expand -> decoder ->
+      vocoder).  The metric's backward half is NOT built yet: `config.pass` says so and DESIGN.md lists it as open.
+  c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
+N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
+collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "c2": dict(B=16, T=160, L=37, what="speech_predictor"),
+    "c5": dict(B=8, T=800, L=0, what="vocoder"),
+}
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    B, T, L = w["B"], w["T"], w["L"]
+    pitch = torch.rand(B, T, generator=g) * 200 + 80
+    unv = (torch.rand(B, (T + 9) // 10, generator=g) < 0.3).repeat_interleave(10, dim=1)[:, :T]
+    pitch[unv] = 0
+    d = dict(pitch=pitch, voiced=(pitch > 20).float(), energy=torch.randn(B, T, generator=g),
+             style=torch.randn(B, 64, generator=g))
+    if w["what"] == "vocoder":
+        d["mel"] = torch.randn(B, 128, T, generator=g)
+    else:
+        d["texts"] = torch.randint(1, 178, (B, L), generator=g)
+        d["text_lengths"] = torch.full((B,), L, dtype=torch.int64)
+        # integer durations >= 1 summing to T (multinomial split), as the alignment cache holds them
+        dur = torch.ones(B, L)
+        extra = torch.multinomial(torch.ones(L), T - L, replacement=True, generator=g) if T > L else torch.zeros(0)
+        for b in range(B):
+            idx = torch.multinomial(torch.ones(L), T - L, replacement=True, generator=g)
+            dur[b] += torch.bincount(idx, minlength=L).float()
+        d["durations"] = dur
+    return {k: v.to(device) for k, v in d.items()}
+
+
+def build_model(device):
+    import stylish_tts_amd as S
+    from oracle.manifest import speech_predictor_manifest   # deterministic random-init weights (test infra fill)
+    from oracle.weights import fill_state_dict
+    P = fill_state_dict(speech_predictor_manifest(), 0)
+    m = S.SpeechPredictor()
+    m.load_state_dict(P, strict=False)
+    return m.to(device), P
+
+
+def cpu_baseline(P, w, budget_s=12.0):
+    """The CPU oracle (plain PyTorch restatement, kind 'port') on this box's host cores, bounded sample."""
+    from oracle import frontend, speech_predictor as osp, vocoder as ov
+    Bs = 2
+    ws = dict(w, B=Bs)
+    inp = make_inputs(ws, 99, "cpu")
+    T = w["T"]
+    noise = torch.randn(Bs, 300 * T, 9)
+
+    def once():
+        t0 = time.perf_counter()
+        if w["what"] == "vocoder":
+            ov.multi_generator(P, "generator", inp["mel"], inp["style"], inp["pitch"], inp["voiced"], noise)
+        else:
+            ali = frontend.duration_to_alignment(inp["durations"])
+            osp.speech_predictor(P, inp["texts"], inp["text_lengths"], ali, inp["pitch"], inp["energy"],
+                                 inp["voiced"], inp["style"], inp["pitch"], noise)
+        return time.perf_counter() - t0
+
+    # ATen's CPU kernels on this op mix (tiny-channel convs, elementwise) slow down badly when every host core
+    # joins the OpenMP team; pick the fastest of a few team sizes and report the one used.
+    ncpu = os.cpu_count() or 1
+    t_all = time.perf_counter()
+    best, best_thr, n_timed = None, None, 0
+    with torch.no_grad():
+        for thr in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+            torch.set_num_threads(thr)
+            once()  # warm-up at this team size
+            for _ in range(2):
+                dt = once()
+                n_timed += 1
+                if best is None or dt < best:
+                    best, best_thr = dt, thr
+            if time.perf_counter() - t_all > budget_s:
+                break
+    return dict(value=Bs * T / best, unit="frames/s", cores=best_thr, kind="port", host_cores=ncpu,
+                sample=f"oracle forward, B={Bs}, T={T}; best of {n_timed} timed iterations over OpenMP team sizes "
+                       f"8/16/32/64 (1 warm-up each), {time.perf_counter() - t_all:.1f} s of CPU work")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU product path"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    w = WORKLOADS[args.workload]
+    model, P = build_model(device)
+    inp = make_inputs(w, 1000 + rank, device)
+    B, T = w["B"], w["T"]
+
+    def step(i):
+        with torch.no_grad():
+            if w["what"] == "vocoder":
+                return model.vocoder_forward(mel=inp["mel"], style=inp["style"], pitch=inp["pitch"],
+                                             voiced=inp["voiced"], seed=i).audio
+            ali = torch.empty(B, w["L"], T, device=device)
+            L.check(lib.sty_alignment_fwd(B, w["L"], T, L.ptr(inp["durations"]), L.ptr(ali),
+                                          torch.cuda.current_stream().cuda_stream))
+            return model(inp["texts"], inp["text_lengths"], ali, inp["pitch"], inp["energy"], inp["voiced"],
+                         inp["style"], inp["pitch"], seed=i).audio
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    barrier()
+    lib.sty_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.sty_prof_enable(0)
+    prof = L.prof_report() if rank == 0 else []
+    assert bool(torch.isfinite(out).all())
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    if rank != 0:
+        return
+    frames = world * B * T * args.steps
+    rec = {
+        "metric": "audio frames/sec/GPU (24 kHz) forward+backward; DDP scaling 1/2/4/8 MI355X",
+        "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {w['what']} B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
+                   "pass": "forward only -- backward kernels are not built yet, so this is NOT yet the "
+                           "forward+backward metric (DESIGN.md, open items)",
+                   "x_realtime": frames / dt / 80.0},
+    }
+    if prof:
+        dom = max(prof, key=lambda r: r["ms"])
+        per = dom["ms"] / dom["launches"] * 1e-3
+        tf = dom["flops"] / dom["launches"] / per / 1e12
+        gbs = dom["bytes"] / dom["launches"] / per / 1e9
+        rec["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                           "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
+                           "avg_launch_us": per * 1e6, "launches": dom["launches"],
+                           "hbm_GBps_algorithmic": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
+                           "share_of_step_time": dom["ms"] / (1e3 * dt)}
+        rec["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / args.steps,
+                           "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
+                           "GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
+                          for r in sorted(prof, key=lambda r: -r["ms"])]
+    if not args.no_cpu_baseline and world == 1:
+        rec["cpu_baseline"] = cpu_baseline(P, w)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,21 @@ int sty_source_fwd(int B, int T, const float *pitch, const float *voiced, const 
                    void *stream);
 int sty_source_workspace_bytes(int B, int T, size_t *bytes);
 
+/* ---- in-situ kernel timing (used by bench.py for the roofline object) --------------------------------
+ * When enabled, every launch of the instrumented kernel families is bracketed by HIP events on the launch
+ * stream.  sty_prof_report synchronises the device, sums the event times per family and writes up to `cap`
+ * rows; it returns the number of families.  flops/bytes are ALGORITHMIC counts computed from the launch shapes
+ * (DESIGN.md section "roofline accounting"), not counter readings.                                       */
+typedef struct {
+  char name[48];
+  uint64_t launches;
+  double ms;    /* summed launch durations */
+  double flops; /* summed algorithmic flops */
+  double bytes; /* summed algorithmic HBM bytes (each operand tensor read once, each result written once) */
+} sty_prof_row;
+int sty_prof_enable(int on);
+int sty_prof_report(sty_prof_row *rows, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,39 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// in-situ kernel timing
+// ---------------------------------------------------------------------------------------------------
+struct ProfEntry {
+  const char* family;
+  double flops, bytes;
+  hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfEntry> g_prof;
+static std::vector<hipEvent_t> g_evpool;
+static hipEvent_t prof_event() {
+  if (!g_evpool.empty()) {
+    hipEvent_t e = g_evpool.back();
+    g_evpool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+ProfScope::ProfScope(const char* family, double flops, double bytes, hipStream_t s) : st(s) {
+  if (!g_prof_on) return;
+  ProfEntry e{family, flops, bytes, prof_event(), prof_event()};
+  if (!e.a || !e.b) return;
+  (void)hipEventRecord(e.a, st);
+  slot = (int)g_prof.size();
+  g_prof.push_back(e);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // parameter lookup
 // ---------------------------------------------------------------------------------------------------
 struct Builder {
@@ -379,11 +412,17 @@ struct Run {
     }
   };
 
-  // GeneratorConvNeXtBlock in place on x [B][C][T]
-  void convnext(const ConvNeXt& c, float* x, int T) {
+  // GeneratorConvNeXtBlock: x [B][C][T] -> y.  The fused C == 32 kernel reads a 3-sample halo of x, so it must
+  // run out of place (y != x); the generic path is in place when y == x (its last conv is 1x1).
+  void convnext(const ConvNeXt& c, const float* x, float* y, int T) {
     const int C = c.C;
     Scope sc(*this);
     if (C == 32) {
+      if (live() && x == y) {
+        set_error("internal: fused ConvNeXt32 needs distinct input and output buffers");
+        rc = STY_EINVAL;
+        return;
+      }
       const int nt = convnext32_ntiles(T);
       double* part = ws.take<double>((size_t)B * 128 * nt * 2);
       float* scale = ws.take<float>((size_t)B * 128);
@@ -400,7 +439,7 @@ struct Run {
         a.b2eff = c.pw2.bias;
         a.scale = scale;
         a.part = part;
-        a.y = x;
+        a.y = y;
         a.T = T;
         a.ntiles = nt;
         chk(launch_convnext32(a, B, 1, st));
@@ -422,7 +461,7 @@ struct Run {
       conv(a);
       chk(launch_row_stats(h, B * 4 * C, T, part, st));
       chk(launch_grn_finalize(part, nseg, c.grn_gamma, B, 4 * C, scale, st));
-      ConvArgs b2 = base(c.pw2, h, T, x);
+      ConvArgs b2 = base(c.pw2, h, T, y);
       b2.pro = PRO_SCALE;
       b2.pa = scale;
       b2.residual = x;
@@ -566,7 +605,7 @@ struct Run {
     conformer(v.conf, x1, xc, C, T);
     if (live()) tap(io.tap_conformer_out, xc, (size_t)B * C * T);
     // ---- stage B: ConvNeXt trunk with pixel-shuffle upsampling ----
-    for (const ConvNeXt& c : v.amp_convnext) convnext(c, xc, T);
+    for (const ConvNeXt& c : v.amp_convnext) convnext(c, xc, xc, T);
     float* cur = xc;
     int Tc = T, Cc = C;
     const int rates[3] = {3, 5, 5};
@@ -581,16 +620,22 @@ struct Run {
       }
       Tc *= s;
       Cc /= 2;
-      convnext(v.upblock[i], nx, Tc);
+      if (i == 2) {  // C == 32: fused block, out of place hs -> hp (har_phase is dead by now)
+        convnext(v.upblock[i], nx, hp, Tc);
+        nx = hp;
+      } else {
+        convnext(v.upblock[i], nx, nx, Tc);
+      }
       cur = nx;
     }
-    trunk = cur;  // [B][32][Tu] (lives in hs)
+    trunk = cur;  // [B][32][Tu] (lives in hp)
     if (live()) tap(io.tap_trunk, trunk, (size_t)B * 32 * Tu);
     note_peak();
     ws.off = mark;
     // ---- heads @75T ----
     float* logamp = ws.take<float>((size_t)B * 32 * Tu);
-    float* ph = hp;
+    float* ph = hs;
+    float* ph_alt = ws.take<float>((size_t)B * 32 * Tu);
     float* real = ws.take<float>((size_t)B * 32 * Tu);
     float* imag = ws.take<float>((size_t)B * 32 * Tu);
     if (live()) {
@@ -612,7 +657,12 @@ struct Run {
       p.ln_eps = 1e-6f;
       conv(p);
     }
-    for (const ConvNeXt& c : v.phase_convnext) convnext(c, ph, Tu);
+    for (const ConvNeXt& c : v.phase_convnext) {  // ping-pong: the fused block is out of place
+      convnext(c, ph, ph_alt, Tu);
+      float* t = ph;
+      ph = ph_alt;
+      ph_alt = t;
+    }
     if (live()) {
       ConvArgs r = base(v.real_conv, ph, Tu, real);
       r.pro = PRO_LN_AFFINE;
@@ -810,6 +860,38 @@ static int run_style_fc(Run& r, const float* style) {
 using namespace sty;
 
 extern "C" {
+
+int sty_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return STY_OK;
+}
+int sty_prof_report(sty_prof_row* rows, int cap) {
+  STY_HIP(hipDeviceSynchronize());
+  std::vector<sty_prof_row> agg;
+  for (ProfEntry& e : g_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) ms = 0.f;
+    g_evpool.push_back(e.a);
+    g_evpool.push_back(e.b);
+    sty_prof_row* r = nullptr;
+    for (auto& x : agg)
+      if (!strcmp(x.name, e.family)) r = &x;
+    if (!r) {
+      sty_prof_row n;
+      memset(&n, 0, sizeof(n));
+      strncpy(n.name, e.family, sizeof(n.name) - 1);
+      agg.push_back(n);
+      r = &agg.back();
+    }
+    r->launches += 1;
+    r->ms += ms;
+    r->flops += e.flops;
+    r->bytes += e.bytes;
+  }
+  g_prof.clear();
+  for (int i = 0; i < (int)agg.size() && i < cap && rows; ++i) rows[i] = agg[i];
+  return (int)agg.size();
+}
 
 int sty_version(void) { return 1; }
 const char* sty_last_error(void) { return g_err; }
@@ -1090,8 +1172,11 @@ int sty_convnext_fwd(sty_model* m, const char* prefix, int B, int C, int T, cons
   r.ws.base = (char*)workspace;
   r.ws.cap = ws_bytes;
   run_style_fc(r, style);
-  if (y != x) STY_HIP(hipMemcpyAsync(y, x, (size_t)B * C * T * sizeof(float), hipMemcpyDeviceToDevice, r.st));
-  r.convnext(*blk, y, T);
+  if (x == y && C == 32) {
+    set_error("sty_convnext_fwd: C == 32 runs out of place, y must differ from x");
+    return STY_EINVAL;
+  }
+  r.convnext(*blk, x, y, T);
   if (r.ws.overflow || r.peak > ws_bytes) {
     set_error("workspace too small: need %zu bytes", r.peak);
     return STY_ENOMEM;

@@ -238,6 +238,13 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     return STY_EINVAL;
   }
   dim3 grid(cdiv(a.T, TT_BLK), a.w.CoutP / CO_BLK, a.B);
+  // algorithmic work: 2*Cin*K flops per output element; input + output (+ residual) once, weights once
+  const double outs = (double)a.B * a.w.Cout * a.T;
+  const double flops = 2.0 * a.w.Cin * a.w.K * outs;
+  const double bytes = 4.0 * ((double)a.B * a.w.Cin * a.T + outs * (a.residual ? 2.0 : 1.0) +
+                              (double)a.w.Cout * a.w.Cin * a.w.K);
+  const char* fam = CO_BLK == 32 ? "conv1d_mfma<co32>" : (CO_BLK == 64 ? "conv1d_mfma<co64>" : "conv1d_mfma<co128>");
+  ProfScope prof(fam, flops, bytes, st);
   hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT>), grid, dim3(256), lds, st, a);
   STY_LAUNCH_CHECK();
   return STY_OK;

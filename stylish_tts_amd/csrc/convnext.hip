@@ -155,6 +155,12 @@ int convnext32_ntiles(int T) { return cdiv(T, CNX_TT); }
 
 int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st) {
   dim3 grid(a.ntiles, B);
+  // per position: dw 2*7*32, pw1 2*32*128, pw2 2*128*32 (pass 2 only); x read once (+ once more as residual in
+  // pass 2, an L2 hit counted as HBM here), y written once
+  const double pos = (double)B * a.T;
+  const double flops = pos * (448.0 + 8192.0 + (pass == 2 ? 8192.0 : 0.0));
+  const double bytes = pos * 32 * 4.0 * (pass == 2 ? 2.0 : 1.0);
+  ProfScope prof(pass == 1 ? "convnext32<pass1>" : "convnext32<pass2>", flops, bytes, st);
   if (pass == 1)
     hipLaunchKernelGGL(convnext32_kernel<false>, grid, dim3(256), 0, st, a);
   else

@@ -19,6 +19,14 @@ int hip_fail(hipError_t e, const char* what);
 
 #define STY_LAUNCH_CHECK() STY_HIP(hipGetLastError())
 
+// in-situ timing of kernel families (api.hip); no-ops unless sty_prof_enable(1)
+struct ProfScope {
+  int slot = -1;
+  hipStream_t st;
+  ProfScope(const char* family, double flops, double bytes, hipStream_t s);
+  ~ProfScope();
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -54,7 +54,24 @@ SYMBOLS = {
     "sty_istft64_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P]),
     "sty_source_fwd": (C.c_int, [_I, _I, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_source_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
+    "sty_prof_enable": (C.c_int, [_I]),
+    "sty_prof_report": (C.c_int, [_P, _I]),
 }
+
+
+class ProfRow(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+def prof_report(cap=64):
+    """Drain the in-situ kernel timers: list of dicts (name, launches, ms, flops, bytes)."""
+    rows = (ProfRow * cap)()
+    n = LIB.sty_prof_report(C.cast(rows, C.c_void_p), cap)
+    if n < 0:
+        check(n)
+    return [dict(name=r.name.decode(), launches=int(r.launches), ms=r.ms, flops=r.flops, bytes=r.bytes)
+            for r in rows[:min(n, cap)]]
 
 LIB = None
 

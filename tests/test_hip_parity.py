@@ -102,7 +102,8 @@ def test_stft64_and_istft64(env):
     ref = torch.tanh(stft_inverse(torch.cat([la.exp(), z], 1), torch.cat([php.cos(), z + 1], 1) * 1.0,
                                   torch.cat([php.sin(), z], 1), bases))
     audio = torch.empty(3, 1, 4 * F, device=DEV)
-    L.check(lib.sty_istft64_fwd(3, F, L.ptr(dev(logamp)), L.ptr(dev(real)), L.ptr(dev(imag)), L.ptr(audio), None))
+    d_la, d_re, d_im = dev(logamp), dev(real), dev(imag)  # keep alive: temporaries would be recycled mid-call
+    L.check(lib.sty_istft64_fwd(3, F, L.ptr(d_la), L.ptr(d_re), L.ptr(d_im), L.ptr(audio), None))
     rep.add("istft64.audio", audio, ref, 1e-5)
     rep.done()
 
@@ -121,7 +122,8 @@ def test_harmonic_source(env):
     ws = torch.empty(need.value, dtype=torch.uint8, device=DEV)
     out = torch.empty(B, 300 * T, device=DEV)
     lw, lb = dev(P["generator.basegen.m_source.l_linear.weight"]), dev(P["generator.basegen.m_source.l_linear.bias"])
-    L.check(lib.sty_source_fwd(B, T, L.ptr(dev(cs["pitch"])), L.ptr(dev(env["voiced"])), L.ptr(dev(cs["noise"])), 0,
+    d_p, d_v, d_n = dev(cs["pitch"]), dev(env["voiced"]), dev(cs["noise"])
+    L.check(lib.sty_source_fwd(B, T, L.ptr(d_p), L.ptr(d_v), L.ptr(d_n), 0,
                                L.ptr(lw), L.ptr(lb), L.ptr(out), L.ptr(ws), ws.numel(), None))
     err = (out.cpu() - ref).abs()
     print(f"\n  source: max|err| {err.max().item():.3e}  mean|err| {err.mean().item():.3e}  "
@@ -130,7 +132,7 @@ def test_harmonic_source(env):
     assert err.max().item() <= 2e-3 and err.mean().item() <= 2e-5
     # internal RNG path: finite, bounded, unvoiced regions look like noise
     out2 = torch.empty_like(out)
-    L.check(lib.sty_source_fwd(B, T, L.ptr(dev(cs["pitch"])), L.ptr(dev(env["voiced"])), None, 7, L.ptr(lw), L.ptr(lb),
+    L.check(lib.sty_source_fwd(B, T, L.ptr(d_p), L.ptr(d_v), None, 7, L.ptr(lw), L.ptr(lb),
                                L.ptr(out2), L.ptr(ws), ws.numel(), None))
     assert bool(torch.isfinite(out2).all()) and out2.abs().max().item() <= 1.0 and out2.std().item() > 1e-3
 
@@ -159,7 +161,8 @@ def test_convnext_block(env, prefix, C, T):
     y = torch.empty(2, C, T, device=DEV)
     ws = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
     st = C_void(torch.cuda.current_stream().cuda_stream)
-    L.check(lib.sty_convnext_fwd(m._handle, prefix.encode(), 2, C, T, L.ptr(dev(x)), L.ptr(dev(style)), L.ptr(y),
+    d_x, d_s = dev(x), dev(style)
+    L.check(lib.sty_convnext_fwd(m._handle, prefix.encode(), 2, C, T, L.ptr(d_x), L.ptr(d_s), L.ptr(y),
                                  L.ptr(ws), ws.numel(), st))
     torch.cuda.synchronize()
     rep = Report()
@@ -183,7 +186,8 @@ def test_adain_resblock(env, prefix):
         ref = blocks.gen_resblock(P, prefix, x, style)
     y = torch.empty(2, 32, 700, device=DEV)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
-    L.check(lib.sty_resblock_fwd(m._handle, prefix.encode(), 2, 700, L.ptr(dev(x)), L.ptr(dev(style)), L.ptr(y),
+    d_x, d_s = dev(x), dev(style)
+    L.check(lib.sty_resblock_fwd(m._handle, prefix.encode(), 2, 700, L.ptr(d_x), L.ptr(d_s), L.ptr(y),
                                  L.ptr(ws), ws.numel(), C_void(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     rep = Report()
@@ -200,7 +204,8 @@ def test_alignment(env):
     B, Lt = dur.shape
     T = ref.shape[2]
     out = torch.empty(B, Lt, T, device=DEV)
-    L.check(lib.sty_alignment_fwd(B, Lt, T, L.ptr(dev(dur)), L.ptr(out), None))
+    d_dur = dev(dur)
+    L.check(lib.sty_alignment_fwd(B, Lt, T, L.ptr(d_dur), L.ptr(out), None))
     rep = Report()
     rep.add("alignment", out, ref, 1e-6)
     rep.done()
