@@ -64,13 +64,26 @@ def build_model(device):
     return m.to(device), P
 
 
-def cpu_baseline(P, w, budget_s=12.0):
-    """The CPU oracle (plain PyTorch restatement, kind 'port') on this box's host cores, bounded sample."""
+def _usable_cpus():
+    """cores this process may actually use: affinity mask intersected with the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def _cpu_baseline_worker(w, q, budget_s):
+    """Runs in a child process: the CPU oracle (plain PyTorch restatement, kind 'port'), bounded sample."""
     from oracle import frontend, speech_predictor as osp, vocoder as ov
-    Bs = 2
-    ws = dict(w, B=Bs)
-    inp = make_inputs(ws, 99, "cpu")
-    T = w["T"]
+    from oracle.manifest import speech_predictor_manifest
+    from oracle.weights import fill_state_dict
+    P = fill_state_dict(speech_predictor_manifest(), 0)
+    Bs, T = 2, w["T"]
+    inp = make_inputs(dict(w, B=Bs), 99, "cpu")
     noise = torch.randn(Bs, 300 * T, 9)
 
     def once():
@@ -83,25 +96,46 @@ def cpu_baseline(P, w, budget_s=12.0):
                                  inp["voiced"], inp["style"], inp["pitch"], noise)
         return time.perf_counter() - t0
 
-    # ATen's CPU kernels on this op mix (tiny-channel convs, elementwise) slow down badly when every host core
-    # joins the OpenMP team; pick the fastest of a few team sizes and report the one used.
-    ncpu = os.cpu_count() or 1
+    usable = _usable_cpus()
     t_all = time.perf_counter()
     best, best_thr, n_timed = None, None, 0
     with torch.no_grad():
-        for thr in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        # ATen's CPU kernels on this op mix (tiny-channel convs, elementwise) get slower when the OpenMP team is
+        # larger than the cores actually granted; try a few team sizes and report the one used.
+        for thr in sorted({min(usable, t) for t in (8, 16, 32, 64)}):
             torch.set_num_threads(thr)
-            once()  # warm-up at this team size
+            once()
             for _ in range(2):
                 dt = once()
                 n_timed += 1
                 if best is None or dt < best:
                     best, best_thr = dt, thr
+                q.put(dict(value=Bs * T / best, unit="frames/s", cores=best_thr, kind="port",
+                           host_cores=os.cpu_count(), usable_cores=usable,
+                           sample=f"oracle forward, B={Bs}, T={T}; best of {n_timed} timed iterations "
+                                  f"(1 warm-up per OpenMP team size), {time.perf_counter() - t_all:.1f} s of CPU work"))
             if time.perf_counter() - t_all > budget_s:
                 break
-    return dict(value=Bs * T / best, unit="frames/s", cores=best_thr, kind="port", host_cores=ncpu,
-                sample=f"oracle forward, B={Bs}, T={T}; best of {n_timed} timed iterations over OpenMP team sizes "
-                       f"8/16/32/64 (1 warm-up each), {time.perf_counter() - t_all:.1f} s of CPU work")
+
+
+def cpu_baseline(w, budget_s=15.0, hard_timeout_s=120.0):
+    """CPU baseline in a child process with a hard wall-clock limit, so the bench can never hang on it."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_cpu_baseline_worker, args=(w, q, budget_s), daemon=True)
+    p.start()
+    p.join(hard_timeout_s)
+    if p.is_alive():
+        p.kill()
+        p.join()
+    last = None
+    while not q.empty():
+        last = q.get()
+    if last is None:
+        return dict(value=None, unit="frames/s", cores=_usable_cpus(), kind="port",
+                    sample=f"oracle forward did not finish one timed iteration within {hard_timeout_s:.0f} s")
+    return last
 
 
 def main():
@@ -193,7 +227,7 @@ def main():
                            "GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
                           for r in sorted(prof, key=lambda r: -r["ms"])]
     if not args.no_cpu_baseline and world == 1:
-        rec["cpu_baseline"] = cpu_baseline(P, w)
+        rec["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(rec))
 
 
