@@ -12,17 +12,116 @@
 //     so the D fragment has time along lanes -> 128-B coalesced stores into the [B,C,T] layout.
 //   * the input tile (CI_CHUNK channels x (tile + receptive-field halo)) is staged ONCE per chunk with the
 //     normalisation / activation prologue applied during staging (once per element, not per tap).
+#include <stdlib.h>
+
 #include "sty_common.h"
 
 namespace sty {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// ---- prologue applied while the input tile is staged (one instantiation per mode keeps the code small: the
+//      first version branched on the mode per element inside fully unrolled loops and produced 95-180 KB
+//      kernels that thrashed the instruction cache) ----
+template <int PRO>
+__device__ __forceinline__ float pro_apply(float v, float pa, float ps, float alpha, float ralpha, float mk) {
+  if constexpr (PRO == PRO_AFFINE || PRO == PRO_SCALE) return v * pa + ps;
+  if constexpr (PRO == PRO_AFFINE_SNAKE) return sty_snake(v * pa + ps, alpha, ralpha);
+  if constexpr (PRO == PRO_AFFINE_LRELU) {
+    const float z = v * pa + ps;
+    return z > 0.f ? z : 0.2f * z;
+  }
+  if constexpr (PRO == PRO_MASK) return v * mk;
+  return v;
+}
+
+// Stage CI_CHUNK x LW input samples of channels [ci0, ci0+32) into LDS with the prologue applied.  Each wave owns
+// rows wave, wave+NW, ...; two rows x MAXJ column chunks are loaded into registers first so that 2*MAXJ global
+// loads are in flight per lane before any dependent math / LDS store.  Zero padding is applied AFTER the prologue.
+template <int PRO, int NW, int MAXJ>
+__device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int t0, int LW,
+                                            int wave, int lane) {
+  const int T = a.T, Cin = a.w.Cin;
+  for (int c = wave; c < CI_CHUNK; c += 2 * NW) {
+    const float* src[2];
+    float pa[2], ps[2], alpha[2], ralpha[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ci = ci0 + c + NW * u;
+      live[u] = ci < Cin;
+      pa[u] = 1.f;
+      ps[u] = 0.f;
+      alpha[u] = ralpha[u] = 1.f;
+      src[u] = a.x[0];
+      if (live[u]) {
+        int cl = ci, csz;
+        const float* sp;
+        if (cl < a.xc[0]) {
+          sp = a.x[0];
+          csz = a.xc[0];
+        } else if (cl < a.xc[0] + a.xc[1]) {
+          sp = a.x[1];
+          cl -= a.xc[0];
+          csz = a.xc[1];
+        } else {
+          sp = a.x[2];
+          cl -= a.xc[0] + a.xc[1];
+          csz = a.xc[2];
+        }
+        src[u] = sp + ((size_t)b * csz + cl) * T;
+        if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+          pa[u] = a.pa[(size_t)b * Cin + ci];
+          if constexpr (PRO != PRO_SCALE) ps[u] = a.ps[(size_t)b * Cin + ci];
+        }
+        if constexpr (PRO == PRO_AFFINE_SNAKE) {
+          alpha[u] = a.palpha[ci];
+          ralpha[u] = 1.0f / alpha[u];
+        }
+      }
+    }
+    float vv[2][MAXJ], mk[MAXJ];
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) {
+      const int j = lane + 64 * q;
+      const int t = t0 - a.pad + j;
+      const bool in = j < LW && t >= 0 && t < T;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) vv[u][q] = (in && live[u]) ? src[u][t] : 0.f;
+      mk[q] = 1.f;
+      if constexpr (PRO == PRO_MASK) mk[q] = in ? a.mask[(size_t)b * T + t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float* row = xs + (c + NW * u) * LW;
+#pragma unroll
+      for (int q = 0; q < MAXJ; ++q) {
+        const int j = lane + 64 * q;
+        const int t = t0 - a.pad + j;
+        float v = 0.f;
+        if (live[u] && t >= 0 && t < T) v = pro_apply<PRO>(vv[u][q], pa[u], ps[u], alpha[u], ralpha[u], mk[q]);
+        if (j < LW) row[j] = v;
+      }
+    }
+  }
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_apply(float x, float alpha) {
+  if constexpr (ACT == ACT_RELU) return fmaxf(x, 0.f);
+  if constexpr (ACT == ACT_SWISH) return x * sigmoidf_(x);
+  if constexpr (ACT == ACT_SNAKE) return sty_snake(x, alpha, 1.0f / alpha);
+  return x;
+}
+
 template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_mfma_kernel(ConvArgs a) {
+  constexpr int NW = WM * WN;  // waves per workgroup (4 or 8)
+  constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float xs[];
   constexpr int CO_BLK = 32 * MT * WM;
   constexpr int TT_BLK = 32 * NT * WN;
+  constexpr int MAXJ = (TT_BLK + 128 + 63) / 64;  // launch_cfg guarantees halo <= 128
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -47,61 +146,18 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
 
   for (int ci0 = 0; ci0 < CinP; ci0 += CI_CHUNK) {
     __syncthreads();
-    // ---- stage CI_CHUNK x LW input tile with the prologue applied ----
-    for (int c = wave; c < CI_CHUNK; c += 4) {
-      const int ci = ci0 + c;
-      float* row = xs + c * LW;
-      if (ci >= Cin) {
-        for (int j = lane; j < LW; j += 64) row[j] = 0.f;
-        continue;
-      }
-      const float* src;
-      int cl = ci, csz;
-      if (cl < a.xc[0]) {
-        src = a.x[0];
-        csz = a.xc[0];
-      } else if (cl < a.xc[0] + a.xc[1]) {
-        src = a.x[1];
-        cl -= a.xc[0];
-        csz = a.xc[1];
-      } else {
-        src = a.x[2];
-        cl -= a.xc[0] + a.xc[1];
-        csz = a.xc[2];
-      }
-      src += ((size_t)b * csz + cl) * T;
-      float pa = 1.f, ps = 0.f, alpha = 1.f;
-      const int pro = a.pro;
-      if (pro == PRO_AFFINE || pro == PRO_AFFINE_SNAKE || pro == PRO_AFFINE_LRELU || pro == PRO_SCALE) {
-        pa = a.pa[(size_t)b * Cin + ci];
-        if (pro != PRO_SCALE) ps = a.ps[(size_t)b * Cin + ci];
-      }
-      if (pro == PRO_AFFINE_SNAKE) alpha = a.palpha[ci];
-      for (int j = lane; j < LW; j += 64) {
-        const int t = t0 - a.pad + j;
-        float v = 0.f;
-        if (t >= 0 && t < T) {
-          v = src[t];
-          if (pro == PRO_AFFINE || pro == PRO_SCALE) {
-            v = v * pa + ps;
-          } else if (pro == PRO_AFFINE_SNAKE) {
-            v = v * pa + ps;
-            float sn = sinf(alpha * v);
-            v = v + (1.0f / alpha) * (sn * sn);
-          } else if (pro == PRO_AFFINE_LRELU) {
-            v = v * pa + ps;
-            v = v > 0.f ? v : 0.2f * v;
-          } else if (pro == PRO_MASK) {
-            v *= a.mask[(size_t)b * T + t];
-          }
-        }
-        row[j] = v;
-      }
+    switch (a.pro) {
+      case PRO_AFFINE: stage_chunk<PRO_AFFINE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
+      case PRO_SCALE: stage_chunk<PRO_SCALE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
+      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
+      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
+      case PRO_MASK: stage_chunk<PRO_MASK, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
+      default: stage_chunk<PRO_NONE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
     }
     if (a.pro == PRO_LN_AFFINE) {
       // LayerNorm over the Cin (<= 32, single chunk) channels of every in-range column, then affine.
       __syncthreads();
-      for (int j = tid; j < LW; j += 256) {
+      for (int j = tid; j < LW; j += NTHR) {
         const int t = t0 - a.pad + j;
         if (t < 0 || t >= T) continue;
         float mean = 0.f;
@@ -118,20 +174,68 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
     }
     __syncthreads();
     // ---- MFMA over taps x channel pairs ----
-    for (int k = 0; k < K; ++k) {
-      const float* wrow = a.w.wp + ((size_t)k * CinP + ci0 + hi) * CoutP + co0 + l31;
-      const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
+    // All B fragments of a tap are read from LDS before its first MFMA (hipcc otherwise recycles one register pair:
+    // ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs); 4-wave configurations also fetch the A fragments (packed
+    // weights, L2-resident) of tap k+1 while tap k's MFMAs issue.
+    if constexpr (NW == 4) {
+      float a_nxt[CI_CHUNK / 2][MT];
+      {
+        const float* wrow = a.w.wp + ((size_t)ci0 + hi) * CoutP + co0 + l31;
 #pragma unroll
-      for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) {
-        float av[MT], bv[NT];
+        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) av[m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+          for (int m = 0; m < MT; ++m) a_nxt[c2][m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+      }
+      for (int k = 0; k < K; ++k) {
+        float a_cur[CI_CHUNK / 2][MT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bv[n] = xrow[(2 * c2) * LW + n * 32];
+        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m) a_cur[c2][m] = a_nxt[c2][m];
+        if (k + 1 < K) {
+          const float* wrow = a.w.wp + ((size_t)(k + 1) * CinP + ci0 + hi) * CoutP + co0 + l31;
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+          for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_nxt[c2][m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+        }
+        const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
+        float bv[CI_CHUNK / 2][NT];
+#pragma unroll
+        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bv[c2][n] = xrow[(2 * c2) * LW + n * 32];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c2][m], bv[c2][n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const float* wrow = a.w.wp + ((size_t)k * CinP + ci0 + hi) * CoutP + co0 + l31;
+        const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
+        float av[CI_CHUNK / 2][MT], bv[CI_CHUNK / 2][NT];
+#pragma unroll
+        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[c2][m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bv[c2][n] = xrow[(2 * c2) * LW + n * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2][m], bv[c2][n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -148,8 +252,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const int cp = co0 + row;                      // packed index of the value channel
-          const int ch = (cp >> 6) * 32 + (cp & 31);     // logical half-channel
+          const int cp = co0 + row;                   // packed index of the value channel
+          const int ch = (cp >> 6) * 32 + (cp & 31);  // logical half-channel
           if (t < T && ch < Ch) {
             float va = acc[0][n][r] + a.w.bias[cp];
             float vg = acc[1][n][r] + a.w.bias[cp + 32];
@@ -160,27 +264,38 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
     }
     return;
   }
+  // E1: bias + activation + scale, one small instantiation per activation (switch outside the unrolled loops)
+#define STY_EPI_ACT(ACT)                                                                 \
+  _Pragma("clang loop unroll(full)") for (int m = 0; m < MT; ++m)                        \
+  _Pragma("clang loop unroll(full)") for (int n = 0; n < NT; ++n)                        \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
+    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                       \
+    float x = acc[m][n][r] + (a.w.bias ? a.w.bias[co] : 0.f);                            \
+    float al = 1.f;                                                                      \
+    if constexpr (ACT == ACT_SNAKE) al = a.act_alpha[co < Cout ? co : 0];                \
+    acc[m][n][r] = act_apply<ACT>(x, al) * a.out_scale;                                  \
+  }
+  switch (a.act) {
+    case ACT_RELU: { STY_EPI_ACT(ACT_RELU) } break;
+    case ACT_SWISH: { STY_EPI_ACT(ACT_SWISH) } break;
+    case ACT_SNAKE: { STY_EPI_ACT(ACT_SNAKE) } break;
+    default: { STY_EPI_ACT(ACT_NONE) } break;
+  }
+#undef STY_EPI_ACT
+  // E2: masks, residual, optional LayerNorm over the 32 output channels, store (optionally pixel-shuffled)
 #pragma clang loop unroll(full)
   for (int m = 0; m < MT; ++m) {
 #pragma clang loop unroll(full)
     for (int n = 0; n < NT; ++n) {
       const int t = t0 + tw + n * 32 + l31;
+      const bool tin = t < T;
       float v[16];
+      const float om_pre = (a.out_mask && !a.out_mask_post && tin) ? a.out_mask[(size_t)b * T + t] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float x = acc[m][n][r];
-        if (a.w.bias) x += a.w.bias[co];
-        if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
-        else if (a.act == ACT_SWISH) x = x * sigmoidf_(x);
-        else if (a.act == ACT_SNAKE) {
-          const float al = a.act_alpha[co < Cout ? co : 0];
-          float sn = sinf(al * x);
-          x = x + (1.0f / al) * (sn * sn);
-        }
-        x *= a.out_scale;
-        if (a.out_mask && !a.out_mask_post && t < T) x *= a.out_mask[(size_t)b * T + t];
-        if (a.residual && co < Cout && t < T) x += a.residual[((size_t)b * Cout + co) * T + t];
+        float x = acc[m][n][r] * om_pre;
+        if (a.residual && co < Cout && tin) x += a.residual[((size_t)b * Cout + co) * T + t];
         v[r] = x;
       }
       if (a.ln_out) {  // LayerNorm over the 32 output channels of this column (Cout == 32, MT == 1)
@@ -203,19 +318,21 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
           v[r] = (v[r] - mean) * rstd * a.ln_w[co] + a.ln_b[co];
         }
       }
-      if (t < T) {
+      if (tin) {
         const float om = (a.out_mask && a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
+        if (a.shuffle == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (co < Cout) {
-            const float o = v[r] * om;
-            if (a.shuffle == 1) {
-              a.y[((size_t)b * Cout + co) * T + t] = o;
-            } else {
-              const int s = a.shuffle;
-              a.y[((size_t)b * (Cout / s) + co / s) * ((size_t)T * s) + (size_t)t * s + co % s] = o;
-            }
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout) a.y[((size_t)b * Cout + co) * T + t] = v[r] * om;
+          }
+        } else {
+          const int s = a.shuffle;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout)
+              a.y[((size_t)b * (Cout / s) + co / s) * ((size_t)T * s) + (size_t)t * s + co % s] = v[r] * om;
           }
         }
       }
@@ -229,9 +346,22 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   constexpr int TT_BLK = 32 * NT * WN;
   const int halo = (a.w.K - 1) * a.dil;
   const size_t lds = (size_t)CI_CHUNK * (TT_BLK + halo) * sizeof(float);
-  if (lds > 64 * 1024) {
-    set_error("conv1d: LDS tile %zu B exceeds 64 KiB (K=%d dil=%d)", lds, a.w.K, a.dil);
+  if (halo > 128) {
+    set_error("conv1d: receptive-field halo %d > 128 not built", halo);
     return STY_EINVAL;
+  }
+  if (lds > 64 * 1024) {
+    // more than the default dynamic-LDS allowance: opt in (160 KiB per CU on gfx950)
+    static bool raised = false;
+    if (!raised) {
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, MT, NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      raised = true;
+    }
+    if (lds > 80 * 1024) {
+      set_error("conv1d: LDS tile %zu B exceeds 80 KiB (K=%d dil=%d)", lds, a.w.K, a.dil);
+      return STY_EINVAL;
+    }
   }
   if (a.w.CoutP % CO_BLK != 0) {
     set_error("conv1d: CoutP %d not a multiple of block tile %d", a.w.CoutP, CO_BLK);
@@ -244,8 +374,11 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const double bytes = 4.0 * ((double)a.B * a.w.Cin * a.T + outs * (a.residual ? 2.0 : 1.0) +
                               (double)a.w.Cout * a.w.Cin * a.w.K);
   const char* fam = CO_BLK == 32 ? "conv1d_mfma<co32>" : (CO_BLK == 64 ? "conv1d_mfma<co64>" : "conv1d_mfma<co128>");
+  if (CO_BLK == 32 && TT_BLK == 512) fam = "conv1d_mfma<co32,t512>";
+  if (CO_BLK == 64 && TT_BLK == 64) fam = "conv1d_mfma<co64,t64>";
+  if (CO_BLK == 64 && TT_BLK == 128) fam = "conv1d_mfma<co64,t128,glu>";
   ProfScope prof(fam, flops, bytes, st);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), lds, st, a);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -265,12 +398,23 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     set_error("conv1d: LN epilogue needs Cout == 32");
     return STY_EINVAL;
   }
+  // Tile choice: the biggest output tile that still gives the chip >= ~2 workgroups per CU; the 256-channel stage
+  // runs at T <= 800 frames, where 128x128 tiles would launch ~100 workgroups on 256 CUs.
+  const long tiles128 = (long)cdiv(a.T, 128) * (a.w.CoutP / 128) * a.B;
   if (a.act == ACT_GLU) {
-    if (a.w.CoutP % 128 == 0 && a.T <= 4096) return launch_cfg<2, 2, 2, 2>(a, st);
-    return launch_cfg<1, 4, 2, 2>(a, st);
+    if (a.w.CoutP % 128 == 0 && tiles128 >= 512) return launch_cfg<2, 2, 2, 2>(a, st);
+    return launch_cfg<1, 4, 2, 1>(a, st);  // 64 packed couts (value+gate) x 128 time
   }
-  if (a.w.CoutP % 128 == 0) return launch_cfg<2, 2, 2, 2>(a, st);
-  if (a.w.CoutP % 64 == 0) return launch_cfg<1, 4, 2, 2>(a, st);
+  if (a.w.CoutP % 128 == 0 && tiles128 >= 512) return launch_cfg<2, 2, 2, 2>(a, st);
+  if (a.w.CoutP % 64 == 0) {
+    const long tiles64 = (long)cdiv(a.T, 256) * (a.w.CoutP / 64) * a.B;
+    if (tiles64 >= 512) return launch_cfg<1, 4, 2, 2>(a, st);
+    return launch_cfg<2, 2, 1, 1>(a, st);  // 64 couts x 64 time
+  }
+  // 32-cout blocks: at the 75T frame rate use 8 waves on a 512-sample tile (2 workgroups = 16 waves per CU, halo
+  // overhead halved); short sequences keep the 4-wave 256-sample tile for grid size.
+  static const bool w8 = getenv("STY_CO32_W4") == nullptr;  // A/B switch; 8 waves measured 73 vs 69 TF on config c5
+  if (w8 && (long)cdiv(a.T, 512) * (a.w.CoutP / 32) * a.B >= 512) return launch_cfg<1, 8, 1, 2>(a, st);
   return launch_cfg<1, 4, 1, 2>(a, st);
 }
 

@@ -15,7 +15,7 @@ constexpr int CNX_TT = 256;  // time positions per block (4 waves x 2 MFMA colum
 
 
 template <bool PASS2>
-__global__ __launch_bounds__(256) void convnext32_kernel(Cnx32Args a) {
+__global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
   constexpr int LW = CNX_TT + 6;
   __shared__ __attribute__((aligned(16))) float xs[32 * LW];
   __shared__ float red[4][128];
@@ -24,12 +24,27 @@ __global__ __launch_bounds__(256) void convnext32_kernel(Cnx32Args a) {
   const float* xb = a.x + (size_t)b * 32 * T;
 
   // stage raw x tile with 3-sample halo, zero outside [0,T)
-  for (int c = wave; c < 32; c += 4) {
-    const float* src = xb + (size_t)c * T;
-    for (int j = lane; j < LW; j += 64) {
-      const int t = t0 - 3 + j;
-      xs[c * LW + j] = (t >= 0 && t < T) ? src[t] : 0.f;
+  // (each wave: 8 rows x 5 column chunks; 4 rows = 20 loads are put in flight before the first LDS store)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float v[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* src = xb + (size_t)(wave + 4 * (half * 4 + i)) * T;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int j = lane + 64 * q;
+        const int t = t0 - 3 + j;
+        v[i][q] = (j < LW && t >= 0 && t < T) ? src[t] : 0.f;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int j = lane + 64 * q;
+        if (j < LW) xs[(wave + 4 * (half * 4 + i)) * LW + j] = v[i][q];
+      }
   }
   __syncthreads();
   // depthwise k7 + AdaLN over channels: one thread per time column, 32 channels in registers
@@ -69,7 +84,14 @@ __global__ __launch_bounds__(256) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
   }
+  // B fragments of GEMM-1 (the normalised tile, 32 channels x this wave's 64 columns) do not depend on the
+  // output-channel chunk j: read them from LDS once (32 VGPRs) and reuse them for all four chunks.
   const float* xrow = xs + hi * LW + 3 + tw + l31;
+  float bx[16][2];
+#pragma unroll
+  for (int c2 = 0; c2 < 16; ++c2)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) bx[c2][n] = xrow[(2 * c2) * LW + n * 32];
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {
     f32x16 h[2];
@@ -78,27 +100,40 @@ __global__ __launch_bounds__(256) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[n][r] = 0.f;
     const float* wrow = a.w1p + hi * 128 + j * 32 + l31;
+    float av[16];
 #pragma unroll
-    for (int c2 = 0; c2 < 16; ++c2) {
-      const float av = wrow[(2 * c2) * 128];
+    for (int c2 = 0; c2 < 16; ++c2) av[c2] = wrow[(2 * c2) * 128];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-        h[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xrow[(2 * c2) * LW + n * 32], h[n], 0, 0, 0);
-    }
+    for (int c2 = 0; c2 < 16; ++c2)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) h[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2], bx[c2][n], h[n], 0, 0, 0);
     float sq[16];
+    // Snake argument range check once per 32-element group (wave-uniform branch) instead of per element
+    float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const float bias = a.b1[ch], al = a.alpha[ch];
-      const float ral = 1.0f / al;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        h[n][r] += bias;
+        amax = fmaxf(amax, fabsf(al * h[n][r]));
+      }
+    }
+    const bool slow = __any(amax > 8192.0f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float al = a.alpha[ch];
+      const float ral = __builtin_amdgcn_rcpf(al);
       float sc = 1.f;
       if (PASS2) sc = a.scale[b * 128 + ch];
       float s2 = 0.f;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        float v = h[n][r] + bias;
-        const float sn = sinf(al * v);
-        v = v + ral * (sn * sn);
+        const float z = h[n][r];
+        float v = fmaf(ral, slow ? sty_sin2(al * z) : sty_sin2_fast(al * z), z);
         if (PASS2) {
           h[n][r] = v * sc;
         } else {
@@ -110,12 +145,14 @@ __global__ __launch_bounds__(256) void convnext32_kernel(Cnx32Args a) {
     }
     if (PASS2) {
       const float* w2 = a.w2a + ((j * 16) * 2 + hi) * 32 + l31;
+      float aw[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float av = w2[q * 64];
+      for (int q = 0; q < 16; ++q) aw[q] = w2[q * 64];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, h[n][q], acc2[n], 0, 0, 0);
-      }
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q], h[n][q], acc2[n], 0, 0, 0);
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -102,20 +102,36 @@ int launch_adain_finalize(const double* part, int nseg, const float* gb, int B, 
   return STY_OK;
 }
 
-// GRN over time (conv_next.py:15-18): one block per batch row
+// GRN over time (conv_next.py:15-18): one block per batch row; the per-segment partials of one channel are summed
+// by 256/C4 threads in parallel (fixed order -> deterministic), then combined through LDS.
 __global__ __launch_bounds__(256) void grn_finalize_kernel(const double* __restrict__ part, int nseg,
                                                            const float* __restrict__ gamma, int C4,
                                                            float* __restrict__ scale) {
   __shared__ float red[256];
   __shared__ float gxs[1024];
+  __shared__ double psum[256];
   const int b = blockIdx.x;
+  const int cw = C4 < 256 ? C4 : 256;  // channels handled concurrently
+  const int ngr = 256 / cw;            // threads cooperating on one channel
+  const int cl = threadIdx.x % cw, g = threadIdx.x / cw;
   float loc = 0.f;
-  for (int c = threadIdx.x; c < C4; c += 256) {
+  for (int c0 = 0; c0 < C4; c0 += cw) {
+    const int c = c0 + cl;
     double sq = 0.0;
-    for (int k = 0; k < nseg; ++k) sq += part[(((size_t)b * C4 + c) * nseg + k) * 2 + 1];
-    const float gx = (float)sqrt(sq);
-    gxs[c] = gx;
-    loc += gx;
+    if (g < ngr && c < C4) {
+      const double* p = part + ((size_t)b * C4 + c) * nseg * 2 + 1;
+      for (int k = g; k < nseg; k += ngr) sq += p[(size_t)k * 2];
+    }
+    psum[threadIdx.x] = sq;
+    __syncthreads();
+    if (g == 0 && c < C4) {
+      double t = 0.0;
+      for (int i = 0; i < ngr; ++i) t += psum[i * cw + cl];
+      const float gx = (float)sqrt(t);
+      gxs[c] = gx;
+      loc += gx;
+    }
+    __syncthreads();
   }
   red[threadIdx.x] = loc;
   __syncthreads();
@@ -175,10 +191,80 @@ __global__ __launch_bounds__(64) void chan_layernorm_kernel(const float* __restr
   }
 }
 
+// Fast path: 64 time columns x 4 waves; every thread keeps its C/4 channel values in registers (all loads in
+// flight at once), the column sums are combined across the 4 waves through LDS.  Two-pass (mean, then centred
+// second moment) like the reference's layer_norm; one global read and one write per element.
+template <int CPT>
+__global__ __launch_bounds__(256) void chan_layernorm_reg_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 int T, float eps, int ada,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bvec,
+                                                                 const float* __restrict__ gb, int relu,
+                                                                 const float* __restrict__ out_mask) {
+  constexpr int C = 4 * CPT;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane, b = blockIdx.y;
+  const bool in = t < T;
+  const float* p = x + (size_t)b * C * T + t;
+  float v[CPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    v[i] = in ? p[(size_t)(wave + 4 * i) * T] : 0.f;
+    s += v[i];
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * (1.0f / C);
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  red[wave][lane] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * (1.0f / C) + eps);
+  if (!in) return;
+  const float om = out_mask ? out_mask[(size_t)b * T + t] : 1.f;
+  float* o = y + (size_t)b * C * T + t;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = wave + 4 * i;
+    float sc, sh;
+    if (ada) {
+      sc = 1.f + gb[(size_t)b * 2 * C + c];
+      sh = gb[(size_t)b * 2 * C + C + c];
+    } else {
+      sc = w[c];
+      sh = bvec[c];
+    }
+    float r = (v[i] - mean) * rstd * sc + sh;
+    if (relu) r = fmaxf(r, 0.f);
+    o[(size_t)c * T] = r * om;
+  }
+}
+
 int launch_chan_layernorm(const float* x, float* y, int B, int C, int T, float eps, int ada, const float* w,
                           const float* bvec, const float* gb, int relu, const float* out_mask, hipStream_t st) {
-  hipLaunchKernelGGL(chan_layernorm_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, st, x, y, C, T, eps, ada, w, bvec, gb,
-                     relu, out_mask);
+  const dim3 grid(cdiv(T, 64), B);
+#define STY_LN_CASE(CPT)                                                                                          \
+  case 4 * CPT:                                                                                                    \
+    hipLaunchKernelGGL(chan_layernorm_reg_kernel<CPT>, grid, dim3(256), 0, st, x, y, T, eps, ada, w, bvec, gb, relu, \
+                       out_mask);                                                                                  \
+    break;
+  switch (C) {
+    STY_LN_CASE(8)
+    STY_LN_CASE(16)
+    STY_LN_CASE(32)
+    STY_LN_CASE(64)
+    default:
+      hipLaunchKernelGGL(chan_layernorm_kernel, grid, dim3(64), 0, st, x, y, C, T, eps, ada, w, bvec, gb, relu,
+                         out_mask);
+  }
+#undef STY_LN_CASE
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

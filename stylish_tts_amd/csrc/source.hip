@@ -31,24 +31,38 @@ __device__ __forceinline__ float up300(const float* __restrict__ p, int T, int n
   return __fmaf_rn(l0, p[i0], __fmul_rn(l1, p[i1]));
 }
 
-// frame-rate phase: one thread per (b, harmonic), sequential fp64 cumsum over T frames
-__global__ void source_phase_kernel(const float* __restrict__ pitch, const float* __restrict__ voiced, int B, int T,
-                                    float* __restrict__ pv, float* __restrict__ phase) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= B * NH) return;
-  const int b = id / NH, h = id % NH;
+// frame-rate phase: one wave per (b, harmonic) row; rad is computed in parallel, the cumsum is a wave-level
+// inclusive scan in fp64 (ATen's CPU cumsum accumulates fp32 in double and rounds each element; a different
+// association of the double sum changes the rounded fp32 value only on exact ties).
+__global__ __launch_bounds__(64) void source_phase_kernel(const float* __restrict__ pitch,
+                                                          const float* __restrict__ voiced, int B, int T,
+                                                          float* __restrict__ pv, float* __restrict__ phase) {
+  const int row = blockIdx.x;
+  const int b = row / NH, h = row % NH, lane = threadIdx.x;
   const float* p = pv + (size_t)b * T;
   const float mult = (float)(h + 1);
-  double c = 0.0;
   float* out = phase + ((size_t)b * NH + h) * T;
-  for (int i = 0; i < T; ++i) {
-    const float f0a = up300(p, T, HOP * i + 149), f0b = up300(p, T, HOP * i + 150);
-    const float ra = fmodf(__fdiv_rn(__fmul_rn(f0a, mult), SR), 1.0f);
-    const float rb = fmodf(__fdiv_rn(__fmul_rn(f0b, mult), SR), 1.0f);
-    const float rad = __fadd_rn(__fmul_rn(0.5f, ra), __fmul_rn(0.5f, rb));
-    c += (double)rad;
-    const float cf = (float)c;
-    out[i] = __fmul_rn(__fmul_rn(__fmul_rn(cf, 2.0f), 3.14159274101257324f), 300.0f);
+  double carry = 0.0;
+  for (int i0 = 0; i0 < T; i0 += 64) {
+    const int i = i0 + lane;
+    double v = 0.0;
+    if (i < T) {
+      const float f0a = up300(p, T, HOP * i + 149), f0b = up300(p, T, HOP * i + 150);
+      const float ra = fmodf(__fdiv_rn(__fmul_rn(f0a, mult), SR), 1.0f);
+      const float rb = fmodf(__fdiv_rn(__fmul_rn(f0b, mult), SR), 1.0f);
+      v = (double)__fadd_rn(__fmul_rn(0.5f, ra), __fmul_rn(0.5f, rb));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double u = __shfl_up(v, o);
+      if (lane >= o) v += u;
+    }
+    const double c = carry + v;
+    if (i < T) {
+      const float cf = (float)c;
+      out[i] = __fmul_rn(__fmul_rn(__fmul_rn(cf, 2.0f), 3.14159274101257324f), 300.0f);
+    }
+    carry += __shfl(v, 63);
   }
 }
 
@@ -100,7 +114,7 @@ int launch_source(int B, int T, const float* pitch, const float* voiced, const f
   float* pv = ws;
   float* phase = ws + (size_t)B * T;
   hipLaunchKernelGGL(mul_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, st, pitch, voiced, pv, B * T);
-  hipLaunchKernelGGL(source_phase_kernel, dim3(cdiv(B * NH, 64)), dim3(64), 0, st, pitch, voiced, B, T, pv, phase);
+  hipLaunchKernelGGL(source_phase_kernel, dim3(B * NH), dim3(64), 0, st, pitch, voiced, B, T, pv, phase);
   hipLaunchKernelGGL(source_prior_kernel, dim3(cdiv(T * HOP, 256), B), dim3(256), 0, st, pv, phase, noise, seed, lin_w,
                      lin_b, T, prior);
   STY_LAUNCH_CHECK();

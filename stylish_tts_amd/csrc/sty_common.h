@@ -173,3 +173,54 @@ struct AttnArgs {
   const int64_t* lengths;  // optional [B]: additive -1e4 where query or key index >= length
 };
 }  // namespace sty
+
+#ifdef __HIPCC__
+namespace sty {
+// sin(x) to ~1 ulp for |x| <= 8192 (3-constant Cody-Waite reduction by pi/2 + cephes minimax polynomials, ~20 VALU);
+// beyond that the library sinf (Payne-Hanek).  The Snake activations evaluate this 256x per 75T-rate position
+// per ConvNeXt block, where ocml's sinf with its huge-argument path costs about 3x more.
+static __device__ __attribute__((noinline)) float sty_sinf_slow(float x) { return sinf(x); }
+__device__ __forceinline__ float sty_sinf(float x) {
+  if (__builtin_expect(fabsf(x) > 8192.0f, 0)) return sty_sinf_slow(x);  // out-of-line: keeps call sites small
+  const float kf = rintf(x * 0.636619772f);
+  const int k = (int)kf;
+  float r = fmaf(-kf, 1.57079637050628662109375f, x);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  r = fmaf(-kf, -1.71512449e-15f, r);
+  const float r2 = r * r;
+  const float ps = fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+  const float s = fmaf(r * r2, ps, r);
+  const float pc = fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+  const float c = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  const float res = (k & 1) ? c : s;
+  return (k & 2) ? -res : res;
+}
+// sin^2(x) directly (max abs error 1.1e-7 for |x| <= 8192): reduce by pi/2, sin^2 r = z(1 - z/3 + 2z^2/45 - ...)
+// with z = r^2 on |r| <= pi/4, odd quadrants take 1 - sin^2 r.  ~14 VALU instead of ~28 for sin() then square:
+// the fused ConvNeXt kernel is VALU-issue bound on exactly this (256 Snake evaluations per position per block).
+__device__ __forceinline__ float sty_sin2_fast(float x) {  // caller guarantees |x| <= 8192
+  const float kf = rintf(x * 0.636619772f);
+  float r = fmaf(-kf, 1.57079637050628662109375f, x);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  const float z = r * r;
+  float p = fmaf(z, -4.27556050e-6f, 1.41093474e-4f);
+  p = fmaf(p, z, -3.17460317e-3f);
+  p = fmaf(p, z, 4.44444444e-2f);
+  p = fmaf(p, z, -3.33333333e-1f);
+  p = fmaf(p, z, 1.0f);
+  const float s2 = z * p;
+  return ((int)kf & 1) ? 1.0f - s2 : s2;
+}
+__device__ __forceinline__ float sty_sin2(float x) {
+  if (__builtin_expect(fabsf(x) > 8192.0f, 0)) {
+    const float s = sty_sinf_slow(x);
+    return s * s;
+  }
+  return sty_sin2_fast(x);
+}
+// Snake: v + sin^2(alpha v) / alpha   (conv_next.py:78, ada_norm.py:114)
+__device__ __forceinline__ float sty_snake(float v, float alpha, float ralpha) {
+  return fmaf(ralpha, sty_sin2(alpha * v), v);
+}
+}  // namespace sty
+#endif
