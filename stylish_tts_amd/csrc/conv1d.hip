@@ -32,6 +32,7 @@ __device__ __forceinline__ float pro_apply(float v, float pa, float ps, float al
     return z > 0.f ? z : 0.2f * z;
   }
   if constexpr (PRO == PRO_MASK) return v * mk;
+  if constexpr (PRO == PRO_LRELU) return v > 0.f ? v : 0.2f * v;
   return v;
 }
 
@@ -39,9 +40,9 @@ __device__ __forceinline__ float pro_apply(float v, float pa, float ps, float al
 // rows wave, wave+NW, ...; two rows x MAXJ column chunks are loaded into registers first so that 2*MAXJ global
 // loads are in flight per lane before any dependent math / LDS store.  Zero padding is applied AFTER the prologue.
 template <int PRO, int NW, int MAXJ>
-__device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int t0, int LW,
-                                            int wave, int lane) {
-  const int T = a.T, Cin = a.w.Cin;
+__device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
+                                            int LW, int wave, int lane) {
+  const int T = a.Tin ? a.Tin : a.T, Cin = a.w.Cin;
   for (int c = wave; c < CI_CHUNK; c += 2 * NW) {
     const float* src[2];
     float pa[2], ps[2], alpha[2], ralpha[2];
@@ -54,7 +55,12 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict
       ps[u] = 0.f;
       alpha[u] = ralpha[u] = 1.f;
       src[u] = a.x[0];
-      if (live[u]) {
+      if (live[u] && a.H) {  // 2-D mode: reduction index = (kh, ci)
+        const int kh = ci / a.Cin2d, cc = ci - kh * a.Cin2d;
+        const int hin = h + kh - a.hpad;
+        live[u] = hin >= 0 && hin < a.Hin;
+        src[u] = a.x[0] + (((size_t)b * a.Cin2d + cc) * a.Hin + (live[u] ? hin : 0)) * T;
+      } else if (live[u]) {
         int cl = ci, csz;
         const float* sp;
         if (cl < a.xc[0]) {
@@ -127,7 +133,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z;
+  const int b = a.H ? blockIdx.z / a.H : blockIdx.z;
+  const int h = a.H ? blockIdx.z % a.H : 0;
+  const int HM = a.H ? a.H : 1;  // rows per (b, channel) plane of the output
   const int t0 = blockIdx.x * TT_BLK;
   const int co0 = blockIdx.y * CO_BLK + wm * (32 * MT);
   const int T = a.T;
@@ -147,12 +155,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
   for (int ci0 = 0; ci0 < CinP; ci0 += CI_CHUNK) {
     __syncthreads();
     switch (a.pro) {
-      case PRO_AFFINE: stage_chunk<PRO_AFFINE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
-      case PRO_SCALE: stage_chunk<PRO_SCALE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
-      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
-      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
-      case PRO_MASK: stage_chunk<PRO_MASK, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
-      default: stage_chunk<PRO_NONE, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane); break;
+      case PRO_AFFINE: stage_chunk<PRO_AFFINE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      case PRO_SCALE: stage_chunk<PRO_SCALE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      case PRO_MASK: stage_chunk<PRO_MASK, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      case PRO_LRELU: stage_chunk<PRO_LRELU, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      default: stage_chunk<PRO_NONE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
     }
     if (a.pro == PRO_LN_AFFINE) {
       // LayerNorm over the Cin (<= 32, single chunk) channels of every in-range column, then affine.
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         float x = acc[m][n][r] * om_pre;
-        if (a.residual && co < Cout && tin) x += a.residual[((size_t)b * Cout + co) * T + t];
+        if (a.residual && co < Cout && tin) x += a.residual[(((size_t)b * Cout + co) * HM + h) * T + t];
         v[r] = x;
       }
       if (a.ln_out) {  // LayerNorm over the 32 output channels of this column (Cout == 32, MT == 1)
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (co < Cout) a.y[((size_t)b * Cout + co) * T + t] = v[r] * om;
+            if (co < Cout) a.y[(((size_t)b * Cout + co) * HM + h) * T + t] = v[r] * om;
           }
         } else {
           const int s = a.shuffle;
@@ -367,12 +376,13 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     set_error("conv1d: CoutP %d not a multiple of block tile %d", a.w.CoutP, CO_BLK);
     return STY_EINVAL;
   }
-  dim3 grid(cdiv(a.T, TT_BLK), a.w.CoutP / CO_BLK, a.B);
+  const int HM = a.H ? a.H : 1;
+  dim3 grid(cdiv(a.T, TT_BLK), a.w.CoutP / CO_BLK, a.B * HM);
   // algorithmic work: 2*Cin*K flops per output element; input + output (+ residual) once, weights once
-  const double outs = (double)a.B * a.w.Cout * a.T;
+  const double outs = (double)a.B * a.w.Cout * a.T * HM;
   const double flops = 2.0 * a.w.Cin * a.w.K * outs;
-  const double bytes = 4.0 * ((double)a.B * a.w.Cin * a.T + outs * (a.residual ? 2.0 : 1.0) +
-                              (double)a.w.Cout * a.w.Cin * a.w.K);
+  const double in_elems = a.H ? (double)a.B * a.Cin2d * a.Hin * (a.Tin ? a.Tin : a.T) : (double)a.B * a.w.Cin * a.T;
+  const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
   const char* fam = CO_BLK == 32 ? "conv1d_mfma<co32>" : (CO_BLK == 64 ? "conv1d_mfma<co64>" : "conv1d_mfma<co128>");
   if (CO_BLK == 32 && TT_BLK == 512) fam = "conv1d_mfma<co32,t512>";
   if (CO_BLK == 64 && TT_BLK == 64) fam = "conv1d_mfma<co64,t64>";
@@ -386,6 +396,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   int cin = 0;
   for (int i = 0; i < a.nsrc; ++i) cin += a.xc[i];
+  if (a.H) cin = a.w.Cin;  // 2-D mode: Cin of the packed weight = kh * Cin2d, checked by the caller
   if (cin != a.w.Cin) {
     set_error("conv1d: input channels %d != weight Cin %d", cin, a.w.Cin);
     return STY_ESHAPE;

@@ -174,4 +174,15 @@ int launch_alignment(const float* dur, int B, int L, int T, float* ali, hipStrea
   return STY_OK;
 }
 
+// y += a * x
+__global__ void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = fmaf(a, x[i], y[i]);
+}
+int launch_axpy(const float* x, float a, float* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, a, y, n);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 }  // namespace sty

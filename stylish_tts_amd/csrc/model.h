@@ -43,13 +43,23 @@ struct Bump {
   }
 };
 
-enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A };
+enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A, PK_CONV2D_SN, PK_DW2D_SN };
+int launch_pack_conv2d_sn(const float* w, const float* u, const float* v, const float* bias, int Cout, int Cin, int KH,
+                          int KW, float* wp, float* bp, int CinP, int CoutP, float* tscratch, hipStream_t st);
+int launch_pack_dw2d_sn(const float* w, const float* u, const float* v, int C, float* w9, float* tscratch,
+                        hipStream_t st);
+int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B, int C, int H, int W, float* y,
+                       hipStream_t st);
+int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st);
+int launch_pool_fc(const float* x, int B, int C, int HW, const float* W, const float* bvec, int S, float* out,
+                   hipStream_t st);
 struct PackJob {
   PackKind kind;
   const float *w = nullptr, *g = nullptr, *v = nullptr, *bias = nullptr, *extra = nullptr;
-  int Cout = 0, Cin = 0, K = 1, CinP = 0, CoutP = 0;
+  int Cout = 0, Cin = 0, K = 1, CinP = 0, CoutP = 0, KH = 1;
   float* wp = nullptr;
   float* bp = nullptr;
+  float* scratch = nullptr;
 };
 
 struct AdaFc {      // one AdaIN / AdaLN style projection
@@ -121,6 +131,21 @@ struct DecoderPlan {
   const float *f0_g, *f0_v, *f0_b, *n_g, *n_v, *n_b, *v_g, *v_v, *v_b;
 };
 
+struct StyleResBlk {  // mel_style_encoder.py:69-118
+  int Cin = 0, Cout = 0;
+  bool down = false, has_sc = false;
+  PackedConv c1, c2, sc;      // 3x3, 3x3, 1x1 (2-D mode: Cin = KH * Cin2d)
+  const float* dw_w9 = nullptr;  // prepared depthwise stride-2 weights [Cin][9]
+  const float* dw_b = nullptr;
+};
+struct StylePlan {
+  int n_mels = 80, style_dim = 64;
+  PackedConv stem;            // 3x3, 1 -> n_mels
+  StyleResBlk blk[4];
+  PackedConv head;            // 5x5 valid
+  const float *fc_w = nullptr, *fc_b = nullptr;
+};
+
 }  // namespace sty
 
 struct sty_model {
@@ -141,5 +166,6 @@ struct sty_model {
   sty::VocoderPlan voc;
   sty::TextEncPlan te;
   sty::DecoderPlan dec;
+  sty::StylePlan sty_enc;
   float* stft_default = nullptr;  // device [4][33][64]
 };

@@ -58,6 +58,7 @@ enum ConvPro : int {
   PRO_LN_AFFINE = 4,     // LayerNorm over the (<=32) input channels, then * w[c] + b[c]
   PRO_MASK = 5,          // x * mask[b,t]
   PRO_SCALE = 6,         // x * a[b,c]   (GRN scale)
+  PRO_LRELU = 7,         // LeakyReLU(0.2) (style-encoder ResBlk, mel_style_encoder.py:106-113)
 };
 // epilogue activation applied to (acc + bias)
 enum ConvAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2, ACT_SNAKE = 3, ACT_GLU = 4 };
@@ -67,8 +68,12 @@ struct ConvArgs {
   const float* x[3] = {nullptr, nullptr, nullptr};
   int xc[3] = {0, 0, 0};
   int nsrc = 1;
-  int B = 0, T = 0;
+  int B = 0, T = 0;       // T = output length (time / image width)
+  int Tin = 0;            // input length; 0 = same as T ('same' padding)
   int dil = 1, pad = 0;
+  // 2-D mode (Conv2d on [B,C,H,W] as one 1-D conv per output row): the packed reduction "channel" index is
+  // (kh, ci) with ci fastest, input row = h + kh - hpad; grid z = B * H.  Single source only.
+  int H = 0, Hin = 0, hpad = 0, Cin2d = 0;
   PackedConv w;
   int pro = PRO_NONE;
   const float* pa = nullptr;     // [B][Cin] scale
@@ -136,6 +141,7 @@ int launch_fnv(const float* pitch, const float* energy, const float* voiced, con
 int launch_prep_fnv(const float* g0, const float* v0, const float* b0, const float* g1, const float* v1,
                     const float* b1, const float* g2, const float* v2, const float* b2, float* w34, hipStream_t st);
 int launch_alignment(const float* dur, int B, int L, int T, float* ali, hipStream_t st);
+int launch_axpy(const float* x, float a, float* y, size_t n, hipStream_t st);
 // depthwise conv (k taps, 'same' zero padding pad_l) [+ AdaLN over channels]  (ConvNeXt front half)
 int launch_dwconv_adaln(const float* x, const float* w, const float* bias, int B, int C, int T, int K, float eps,
                         const float* gb, float* y, hipStream_t st);

@@ -297,3 +297,31 @@ def test_vocoder_properties_full_size(env):
     assert torch.equal(a, b), "forward is not deterministic"
     # utterances are independent: rows 2..4 alone give the same audio except for the per-(b,n) noise stream
     assert a[2:5].std().item() > 1e-3 and c.std().item() > 1e-3
+
+
+@pytest.mark.parametrize("T", [80, 161, 222])
+def test_mel_style_encoder(T):
+    """A2: MelStyleEncoder (conv2d stack) vs the oracle, and vs the reference's golden vector at T=80."""
+    import stylish_tts_amd as S
+    from oracle import style_encoder as ose
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from safetensors.torch import load_file
+    from tests.cases import make_case
+    P = fill_state_dict(style_encoder_manifest(), 0)
+    m = S.MelStyleEncoder()
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    if T == 80:
+        x = make_case("se_small")["mel"]
+    else:
+        x = torch.randn(3, 1, 80, T, generator=torch.Generator().manual_seed(T))
+    with torch.no_grad():
+        ref = ose.mel_style_encoder(P, "", x)
+        out = m(dev(x))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add(f"style T={T} vs oracle", out, ref, 1e-5)
+    if T == 80:
+        rep.add("style vs reference golden", out, load_file(os.path.join(G, "se_small.safetensors"))["style"], 1e-5)
+    rep.done()
