@@ -5,8 +5,8 @@
 
 A step is one pass of the hot path over one synthetic batch already resident in HBM:
   c2 (default; BASELINE.json configs[1]): sample_dataset shape, B=16 utterances of T=160 mel frames (2.0 s),
-      L=37 phoneme tokens, fp32 -- the acoustic step's forward (text encoder -> alignment expand -> decoder ->
-      vocoder).  The metric's backward half is NOT built yet: `config.pass` says so and DESIGN.md lists it as open.
+      L=37 phoneme tokens, fp32 -- the AcousticStep forward (mel x2 + energy, alignment, style encoder, text encoder,
+      alignment expand, decoder, vocoder, 3-resolution STFT features of target and prediction).  The metric's backward half is NOT built yet: `config.pass` says so and DESIGN.md lists it as open.
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
@@ -42,6 +42,11 @@ def make_inputs(w, seed, device):
     if w["what"] == "vocoder":
         d["mel"] = torch.randn(B, 128, T, generator=g)
     else:
+        # synthetic sample_dataset-like audio: harmonics of a slowly varying f0 + noise
+        t = torch.arange(300 * T) / 24000.0
+        f0 = 110.0 + 100.0 * torch.rand(B, 1, generator=g)
+        d["audio_gt"] = sum(torch.sin(2 * torch.pi * f0 * (h + 1) * t) / (h + 1) for h in range(8)) * 0.15 \
+            + 0.01 * torch.randn(B, 300 * T, generator=g)
         d["texts"] = torch.randint(1, 178, (B, L), generator=g)
         d["text_lengths"] = torch.full((B,), L, dtype=torch.int64)
         # integer durations >= 1 summing to T (multinomial split), as the alignment cache holds them
@@ -61,7 +66,10 @@ def build_model(device):
     P = fill_state_dict(speech_predictor_manifest(), 0)
     m = S.SpeechPredictor()
     m.load_state_dict(P, strict=False)
-    return m.to(device), P
+    from oracle.manifest import style_encoder_manifest
+    se = S.MelStyleEncoder()
+    se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+    return m.to(device), se.to(device), P
 
 
 def _usable_cpus():
@@ -81,7 +89,9 @@ def _cpu_baseline_worker(w, q, budget_s):
     from oracle import frontend, speech_predictor as osp, vocoder as ov
     from oracle.manifest import speech_predictor_manifest
     from oracle.weights import fill_state_dict
+    from oracle.manifest import style_encoder_manifest
     P = fill_state_dict(speech_predictor_manifest(), 0)
+    Pse = fill_state_dict(style_encoder_manifest(), 0)
     Bs, T = 2, w["T"]
     inp = make_inputs(dict(w, B=Bs), 99, "cpu")
     noise = torch.randn(Bs, 300 * T, 9)
@@ -91,9 +101,11 @@ def _cpu_baseline_worker(w, q, budget_s):
         if w["what"] == "vocoder":
             ov.multi_generator(P, "generator", inp["mel"], inp["style"], inp["pitch"], inp["voiced"], noise)
         else:
-            ali = frontend.duration_to_alignment(inp["durations"])
-            osp.speech_predictor(P, inp["texts"], inp["text_lengths"], ali, inp["pitch"], inp["energy"],
-                                 inp["voiced"], inp["style"], inp["pitch"], noise)
+            a = osp.acoustic_forward(P, Pse, inp["audio_gt"], inp["texts"], inp["text_lengths"], inp["pitch"],
+                                     inp["durations"], noise)
+            for fft, hop, win in frontend.RESOLUTIONS:
+                frontend.multi_spectrogram_single(a.squeeze(1), fft, hop, win)
+                frontend.multi_spectrogram_single(inp["audio_gt"], fft, hop, win)
         return time.perf_counter() - t0
 
     usable = _usable_cpus()
@@ -163,7 +175,10 @@ def main():
     from stylish_tts_amd import lib as L
     lib = L.load()
     w = WORKLOADS[args.workload]
-    model, P = build_model(device)
+    model, style_enc, P = build_model(device)
+    from stylish_tts_amd.acoustic import acoustic_forward
+    from stylish_tts_amd.frontend import MultiSpectrogram
+    mspec = MultiSpectrogram(sample_rate=24000)
     inp = make_inputs(w, 1000 + rank, device)
     B, T = w["B"], w["T"]
 
@@ -172,11 +187,11 @@ def main():
             if w["what"] == "vocoder":
                 return model.vocoder_forward(mel=inp["mel"], style=inp["style"], pitch=inp["pitch"],
                                              voiced=inp["voiced"], seed=i).audio
-            ali = torch.empty(B, w["L"], T, device=device)
-            L.check(lib.sty_alignment_fwd(B, w["L"], T, L.ptr(inp["durations"]), L.ptr(ali),
-                                          torch.cuda.current_stream().cuda_stream))
-            return model(inp["texts"], inp["text_lengths"], ali, inp["pitch"], inp["energy"], inp["voiced"],
-                         inp["style"], inp["pitch"], seed=i).audio
+            # the whole AcousticStep forward: mel x2 + energy, alignment, style encoder, predictor, 3-res STFT features
+            o = acoustic_forward(model, style_enc, audio_gt=inp["audio_gt"], texts=inp["texts"],
+                                 text_lengths=inp["text_lengths"], pitch=inp["pitch"], durations=inp["durations"],
+                                 T=T, seed=i, multi_spectrogram=mspec)
+            return o.pred.audio
 
     def barrier():
         if world > 1:

@@ -103,10 +103,19 @@ int sty_style_fwd(sty_model *m, int B, int T, const float *mel, float *style, vo
                   void *stream);
 
 /* ---- front end: calculate_mel (train/utils.py:825-834) + log energy (utils.py:73-85) --------------
- * audio [B,N] -> mel [B,80,frames] with frames = even(N/hop + 1); energy [B,frames] (optional).       */
+ * audio [B,N] -> mel [B,80,frames] with frames = even(N/hop + 1); energy [B,frames] (optional).
+ * 80 HTK mel bins at 24 kHz (train/config/model.yml), window = periodic hann(win_length) centred in n_fft.  */
 int sty_mel_workspace_bytes(int B, int N, int n_fft, int hop, size_t *bytes);
 int sty_mel_fwd(int B, int N, const float *audio, int n_fft, int win_length, int hop, float mean, float std,
                 float *mel, float *energy, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- MultiSpectrogram.calculate_single x3 (train/multi_spectrogram.py:40-55), resolutions (fft,hop) =
+ * (512,128), (1024,256), (2048,512), win = fft.  audio [B,N] -> for each resolution i (frames = N/hop+1):
+ *   mag[i]     [B,128,frames] = log1p(mel128(|X|))      phase[i] [B,F,frames] = (|X| > 1e-3) * angle(X) (optional)
+ *   fft_mag[i] [B,F,frames]   = |X|,  F = fft/2+1                                                          */
+int sty_multispec_workspace_bytes(int B, int N, size_t *bytes);
+int sty_multispec_fwd(int B, int N, const float *audio, float *const *mag, float *const *phase,
+                      float *const *fft_mag, void *workspace, size_t ws_bytes, void *stream);
 
 /* ---- soft alignment: DurationProcessor.duration_to_alignment (train/utils.py:752-791) ------------
  * durations [B,L] -> alignment [B,L,T] (softmax over L)                                               */

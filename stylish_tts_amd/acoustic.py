@@ -1,0 +1,52 @@
+"""AcousticStep tensor flow (train/stage_type.py:61-180, use_predicted_pe=False, predict_audio=True) on the HIP path.
+
+    step = acoustic_forward(speech_predictor, speech_style_encoder, batch, mean, std)
+
+mirrors: mel/style_mel = calculate_mel(audio_gt, to_mel / to_style_mel); energy = log(||exp(mel*std+mean)||_2 + 1e-9);
+alignment = duration_to_alignment(durations); speech_style = speech_style_encoder(style_mel[:, None]);
+voiced = (pitch > 20); pred = speech_predictor(text, text_length, alignment, pitch, energy, voiced, style, pitch);
+six lists = multi_spectrogram(target=audio_gt, pred=pred.audio.squeeze(1)).   Forward only.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .frontend import MelSpec, MultiSpectrogram, calculate_mel
+
+TO_MEL = MelSpec(512, 512, 300)          # train_context.py:155-161 with model.yml n_fft/win/hop
+TO_STYLE_MEL = MelSpec(2048, 1200, 300)  # train_context.py:162-169 with model.yml style_encoder settings
+
+
+class AcousticOut:
+    pass
+
+
+def duration_to_alignment(durations, T):
+    """DurationProcessor.duration_to_alignment (train/utils.py:752-791); T = round(max_b sum d) is taken on the host
+    by the caller (the reference does the same .item() sync at utils.py:759)."""
+    lib = L.load()
+    d = durations.to(torch.float32).contiguous()
+    B, Lt = d.shape
+    out = torch.empty(B, Lt, T, device=d.device)
+    L.check(lib.sty_alignment_fwd(B, Lt, T, L.ptr(d), L.ptr(out),
+                                  C.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)))
+    return out
+
+
+def acoustic_forward(speech_predictor, style_encoder, *, audio_gt, texts, text_lengths, pitch, durations, T=None,
+                     mean=-4.0, std=4.0, noise=None, seed=0, multi_spectrogram=None, prior_override=None):
+    o = AcousticOut()
+    with torch.no_grad():
+        o.mel, _, o.energy = calculate_mel(audio_gt, TO_MEL, mean, std, want_energy=True)
+        o.style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, mean, std)
+        T = o.mel.shape[2] if T is None else T
+        o.alignment = duration_to_alignment(durations, T)
+        o.speech_style = style_encoder(o.style_mel.unsqueeze(1))
+        o.voiced = (pitch > 20).float()
+        o.pred = speech_predictor(texts, text_lengths, o.alignment, pitch, o.energy, o.voiced, o.speech_style, pitch,
+                                  noise=noise, seed=seed, prior_override=prior_override)
+        if multi_spectrogram is not None:
+            (o.target_spec, o.pred_spec, o.target_phase, o.pred_phase, o.target_fft, o.pred_fft) = multi_spectrogram(
+                target=audio_gt, pred=o.pred.audio.squeeze(1))
+    return o

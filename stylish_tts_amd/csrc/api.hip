@@ -1499,14 +1499,61 @@ int sty_style_fwd(sty_model* m, int B, int T, const float* mel, float* style, vo
   if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
   return style_entry(m, B, T, mel, style, workspace, ws_bytes, stream, nullptr);
 }
-// not built yet: declared in the header so bindings can probe for them; they fail loudly.
-int sty_mel_workspace_bytes(int, int, int, int, size_t*) {
-  set_error("mel front end: HIP path not built in this revision");
-  return STY_ESTATE;
+int sty_mel_workspace_bytes(int B, int N, int n_fft, int hop, size_t* bytes) {
+  if (!bytes || B <= 0 || N <= n_fft / 2 || n_fft <= 0 || hop <= 0) {
+    set_error("sty_mel_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  *bytes = mel_workspace_floats(B, N, n_fft, hop, 80) * sizeof(float);
+  return STY_OK;
 }
-int sty_mel_fwd(int, int, const float*, int, int, int, float, float, float*, float*, void*, size_t, void*) {
-  set_error("mel front end: HIP path not built in this revision");
-  return STY_ESTATE;
+int sty_mel_fwd(int B, int N, const float* audio, int n_fft, int win_length, int hop, float mean, float std_,
+                float* mel, float* energy, void* workspace, size_t ws_bytes, void* stream) {
+  if (!audio || !mel || !workspace || B <= 0 || N <= n_fft / 2 || win_length > n_fft || hop <= 0 || std_ == 0.f) {
+    set_error("sty_mel_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (ws_bytes < mel_workspace_floats(B, N, n_fft, hop, 80) * sizeof(float)) {
+    set_error("sty_mel_fwd: workspace too small");
+    return STY_ENOMEM;
+  }
+  return launch_mel(B, N, audio, n_fft, win_length, hop, 80, 24000, mean, std_, mel, energy, (float*)workspace,
+                    S(stream));
+}
+int sty_multispec_workspace_bytes(int B, int N, size_t* bytes) {
+  if (!bytes || B <= 0 || N <= 1024) {
+    set_error("sty_multispec_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  size_t mx = 0;
+  const int res[3][2] = {{512, 128}, {1024, 256}, {2048, 512}};
+  for (auto& r : res) {
+    const size_t n = multispec_workspace_floats(B, N, r[0], r[1]);
+    mx = n > mx ? n : mx;
+  }
+  *bytes = mx * sizeof(float);
+  return STY_OK;
+}
+int sty_multispec_fwd(int B, int N, const float* audio, float* const* mag, float* const* phase, float* const* fft_mag,
+                      void* workspace, size_t ws_bytes, void* stream) {
+  if (!audio || !mag || !fft_mag || !workspace || B <= 0 || N <= 1024) {
+    set_error("sty_multispec_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  size_t need = 0;
+  int rc = sty_multispec_workspace_bytes(B, N, &need);
+  if (rc) return rc;
+  if (ws_bytes < need) {
+    set_error("sty_multispec_fwd: workspace too small");
+    return STY_ENOMEM;
+  }
+  const int res[3][2] = {{512, 128}, {1024, 256}, {2048, 512}};  // multi_spectrogram.py:13-20
+  for (int i = 0; i < 3; ++i) {
+    rc = launch_multispec_single(B, N, audio, res[i][0], res[i][1], 24000, mag[i], phase ? phase[i] : nullptr,
+                                 fft_mag[i], (float*)workspace, S(stream));
+    if (rc) return rc;
+  }
+  return STY_OK;
 }
 
 }  // extern "C"

@@ -27,6 +27,12 @@ int launch_stft64(int B, int N, const float* wave, const float* br, const float*
 int launch_istft64(int B, int F, const float* logamp, const float* real, const float* imag, const float* bbr,
                    const float* bbi, float* audio, hipStream_t st);
 void build_stft64_bases(float* out);
+size_t mel_workspace_floats(int B, int N, int n_fft, int hop, int n_mels);
+int launch_mel(int B, int N, const float* audio, int n_fft, int win, int hop, int n_mels, int sample_rate, float mean,
+               float std_, float* mel, float* energy, float* ws, hipStream_t st);
+size_t multispec_workspace_floats(int B, int N, int n_fft, int hop);
+int launch_multispec_single(int B, int N, const float* audio, int n_fft, int hop, int sample_rate, float* mag,
+                            float* phase, float* fft_mag, float* ws, hipStream_t st);
 
 // bump allocator over a caller-provided workspace (or a dry run that only measures)
 struct Bump {

@@ -47,6 +47,8 @@ SYMBOLS = {
     "sty_style_fwd": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "sty_mel_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _SZP]),
     "sty_mel_fwd": (C.c_int, [_I, _I, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _P]),
+    "sty_multispec_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
+    "sty_multispec_fwd": (C.c_int, [_I, _I, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t, _P]),
     "sty_alignment_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P]),
     "sty_convnext_fwd": (C.c_int, [_P, C.c_char_p, _I, _I, _I, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_resblock_fwd": (C.c_int, [_P, C.c_char_p, _I, _I, _P, _P, _P, _P, C.c_size_t, _P]),

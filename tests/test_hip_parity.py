@@ -325,3 +325,95 @@ def test_mel_style_encoder(T):
     if T == 80:
         rep.add("style vs reference golden", out, load_file(os.path.join(G, "se_small.safetensors"))["style"], 1e-5)
     rep.done()
+
+
+def _test_audio(B, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(N) / 24000.0
+    f0 = 110.0 + 60.0 * torch.rand(B, 1, generator=g)
+    x = sum(torch.sin(2 * torch.pi * f0 * (h + 1) * t) / (h + 1) for h in range(6)) * 0.2
+    return x + 0.01 * torch.randn(B, N, generator=g)
+
+
+@pytest.mark.parametrize("n_fft,win", [(512, 512), (2048, 1200)])
+def test_mel_front_end(n_fft, win):
+    """A1: calculate_mel + log energy vs the oracle restatement (torchaudio boundary: parity unpinned)."""
+    from oracle import frontend as ofe
+    from stylish_tts_amd.frontend import MelSpec, calculate_mel
+    audio = _test_audio(3, 24000 + 300 * 7, n_fft)
+    ref = ofe.calculate_mel(audio, n_fft, win, 300)
+    ref_e = ofe.log_energy(ref)
+    mel, length, energy = calculate_mel(dev(audio), MelSpec(n_fft, win, 300), -4.0, 4.0, want_energy=True)
+    torch.cuda.synchronize()
+    assert mel.shape == ref.shape and int(length[0]) == ref.shape[2]
+    l1 = (mel.cpu() - ref).abs().mean().item()
+    print(f"\n  mel n_fft={n_fft}: L1 {l1:.3e}  max {(mel.cpu() - ref).abs().max().item():.3e}")
+    assert l1 <= 1e-3  # north-star gate
+    rep = Report()
+    rep.add(f"mel n_fft={n_fft}", mel, ref, 1e-4)
+    rep.add("energy", energy, ref_e, 1e-4)
+    rep.done()
+
+
+def test_multi_spectrogram():
+    """A10: three-resolution STFT features vs the oracle (torch.stft + restated MelScale)."""
+    from oracle import frontend as ofe
+    from stylish_tts_amd.frontend import MultiSpectrogram
+    audio = _test_audio(2, 24000, 5)
+    ms = MultiSpectrogram(sample_rate=24000)
+    with torch.no_grad():
+        mags, phases, ffts = ms.calculate(dev(audio))
+    torch.cuda.synchronize()
+    rep = Report()
+    for i, (fft, hop, win) in enumerate(ofe.RESOLUTIONS):
+        r_mag, r_phase, r_fft = ofe.multi_spectrogram_single(audio, fft, hop, win)
+        rep.add(f"fft_mag {fft}", ffts[i], r_fft, 1e-5)
+        rep.add(f"log1p mel128 {fft}", mags[i], r_mag, 1e-5)
+        # phase: compare where both sides are gated on and away from the +-pi wrap
+        gate = (r_fft[:, 0] > 2e-3)
+        d = torch.remainder(phases[i].cpu() - r_phase + torch.pi, 2 * torch.pi) - torch.pi
+        err = (d.abs() * gate).max().item()
+        rep.rows.append(f"  phase {fft:5d} (gated)              max wrapped err {err:9.3e}")
+        if err > 5e-3:
+            rep.bad.append(f"phase {fft}")
+    rep.done()
+
+
+def test_acoustic_step_forward(env):
+    """A0: the AcousticStep tensor flow end to end (mel -> style encoder -> predictor -> multi-spectrogram)."""
+    import stylish_tts_amd as S
+    from oracle import frontend as ofe, speech_predictor as osp
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from stylish_tts_amd.acoustic import acoustic_forward
+    from stylish_tts_amd.frontend import MultiSpectrogram
+    cs = env["cs"]
+    B, T = cs["pitch"].shape
+    audio_gt = _test_audio(B, 300 * T, 21)
+    Pse = fill_state_dict(style_encoder_manifest(), 0)
+    se = S.MelStyleEncoder()
+    se.load_state_dict(Pse)
+    se = se.to(DEV)
+    want = {}
+    with torch.no_grad():
+        ref = osp.acoustic_forward(env["P"], Pse, audio_gt, cs["texts"], cs["text_lengths"], cs["pitch"],
+                                   cs["durations"], cs["noise"], want)
+    out = acoustic_forward(env["m"], se, audio_gt=dev(audio_gt), texts=dev(cs["texts"]),
+                           text_lengths=dev(cs["text_lengths"]), pitch=dev(cs["pitch"]), durations=dev(cs["durations"]),
+                           noise=dev(cs["noise"]), prior_override=dev(want["prior"]),
+                           multi_spectrogram=MultiSpectrogram(sample_rate=24000))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("mel", out.mel, want["mel"], 1e-4)
+    rep.add("style_mel", out.style_mel, want["style_mel"], 1e-4)
+    rep.add("energy", out.energy, want["energy"], 1e-4)
+    rep.add("alignment", out.alignment, want["alignment"], 1e-6)
+    rep.add("speech_style", out.speech_style, want["style"], 1e-4)
+    err = (out.pred.audio.cpu() - ref).abs()
+    mse = (err ** 2).mean().item()
+    print(f"\n  acoustic audio: max|err| {err.max().item():.3e} mse {mse:.3e} mel-L1 {_mel_l1(out.pred.audio.cpu(), ref):.3e}")
+    r_mag, _, r_fft = ofe.multi_spectrogram_single(ref.squeeze(1), 1024, 256, 1024)
+    rep.add("pred_fft[1]", out.pred_fft[1], r_fft, 1e-3)
+    rep.add("pred_spec[1]", out.pred_spec[1], r_mag, 1e-3)
+    rep.done()
+    assert mse <= 1e-7 and _mel_l1(out.pred.audio.cpu(), ref) <= 1e-3
