@@ -159,13 +159,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from stylish_tts_amd import dist as D
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    rank, world = D.init("nccl")  # RCCL; one process per GPU (torchrun environment)
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU product path"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -210,10 +206,7 @@ def main():
     lib.sty_prof_enable(0)
     prof = L.prof_report() if rank == 0 else []
     assert bool(torch.isfinite(out).all())
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = tt.item()
+    dt = D.max_over_ranks(dt, device)
     if rank != 0:
         return
     frames = world * B * T * args.steps

@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size-2 gloo processes.  Checks (i) utterance sharding + max-over-ranks timing,
+(ii) bucketed gradient all-reduce: the 2-rank mean gradient equals the 1-rank gradient on the concatenated batch.
+The compute under test here is the oracle's autograd (this file tests the collective plumbing, not the HIP kernels)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _loss_and_params():
+    from oracle import blocks
+    from oracle import manifest as M
+    from oracle.weights import fill_tensor
+    m = {}
+    M._convnext(m, "cnx", 32, 64)
+    M._gen_block(m, "res", 32, 64)
+    P = {k: fill_tensor(k, s, 0).requires_grad_(True) for k, s in m.items()}
+
+    def loss(x, style):
+        # per-utterance mean so that the batch loss is an average over utterances (what DDP averaging assumes)
+        y = blocks.gen_resblock(P, "res", blocks.convnext_block(P, "cnx", x, style), style)
+        return y.abs().mean(dim=(1, 2)).mean()
+    return P, loss
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from stylish_tts_amd import dist as D
+    r, w = D.init("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    X, S = torch.randn(4, 32, 300, generator=g), torch.randn(4, 64, generator=g)
+    idx = list(D.shard(4, rank, world))
+    P, loss = _loss_and_params()
+    buckets = D.GradBuckets(list(P.values()), bucket_bytes=64 << 10)
+    assert len(buckets.buckets) > 1
+    buckets.attach()
+    loss(X[idx], S[idx]).backward()
+    buckets.reduce_all()
+    buckets.finish()
+    t = D.max_over_ranks(1.0 + rank)
+    q.put((rank, idx, t, {k: v.grad.numpy().copy() for k, v in P.items()}))  # by value (no shm handles)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_mean_equals_single_rank_batch():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    assert res[0][1] == [0, 1] and res[1][1] == [2, 3]
+    assert res[0][2] == 2.0 and res[1][2] == 2.0          # max over ranks of (1.0, 2.0)
+    # single-rank reference on the concatenated batch
+    g = torch.Generator().manual_seed(0)
+    X, S = torch.randn(4, 32, 300, generator=g), torch.randn(4, 64, generator=g)
+    P, loss = _loss_and_params()
+    loss(X, S).backward()
+    for k, v in P.items():
+        for r in res:
+            d = (torch.from_numpy(r[3][k]) - v.grad).abs().max().item()
+            assert d <= 1e-5 * (v.grad.abs().max().item() + 1e-6) + 1e-8, (k, d)
