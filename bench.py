@@ -161,9 +161,9 @@ def main():
 
     from stylish_tts_amd import dist as D
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    rank, world = D.init("nccl")  # RCCL; one process per GPU (torchrun environment)
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU product path"
     torch.cuda.set_device(local)
+    rank, world = D.init("nccl")  # RCCL; one process per GPU (torchrun environment)
     device = torch.device("cuda", local)
 
     import __graft_entry__ as ge
