@@ -143,6 +143,19 @@ int sty_source_fwd(int B, int T, const float *pitch, const float *voiced, const 
                    void *stream);
 int sty_source_workspace_bytes(int B, int T, size_t *bytes);
 
+/* ---- training (backward, K15): vocoder first ---------------------------------------------------------
+ * sty_model_bind_grad: where the gradient of a bound parameter is ACCUMULATED (zero it yourself, e.g.
+ * optimizer.zero_grad).  Call it (or sty_model_enable_training) before sty_model_finalize.
+ * sty_vocoder_fwd_train runs MultiGenerator.forward in its training graph (eval-mode statistics: BatchNorm
+ * running stats, no dropout) keeping what the backward needs in `workspace`, which must stay untouched until
+ * sty_vocoder_bwd returns.  sty_vocoder_bwd takes d loss / d audio [B,1,300T] and writes d loss / d mel
+ * [B,128,T] and d loss / d style [B,64] (each optional) and adds the parameter gradients.                  */
+int sty_model_enable_training(sty_model *m);
+int sty_model_bind_grad(sty_model *m, const char *key, float *grad);
+int sty_vocoder_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
+int sty_vocoder_fwd_train(sty_model *m, const sty_vocoder_io *io, void *workspace, size_t ws_bytes, void *stream);
+int sty_vocoder_bwd(sty_model *m, const float *d_audio, float *d_mel, float *d_style, void *stream);
+
 /* ---- in-situ kernel timing (used by bench.py for the roofline object) --------------------------------
  * When enabled, every launch of the instrumented kernel families is bracketed by HIP events on the launch
  * stream.  sty_prof_report synchronises the device, sums the event times per family and writes up to `cap`

@@ -119,7 +119,59 @@ struct Builder {
       j.bp = bp;
       m->jobs.push_back(j);
     }
+    if (m->train_enabled) {
+      if (glu) {  // the training graph runs GLU as a separate op: it needs the plain channel order
+        PackedConv pl = pc;
+        pl.CoutP = (int)align_up(pc.Cout, 32);
+        float* wp2 = m->ab.take<float>((size_t)pc.K * pc.CinP * pl.CoutP);
+        float* bp2 = m->ab.take<float>(pl.CoutP);
+        pl.wp = wp2;
+        pl.bias = bias ? bp2 : nullptr;
+        if (!dry) {
+          PackJob j;
+          j.kind = PK_CONV;
+          j.w = w->p;
+          j.bias = b;
+          j.Cout = pc.Cout;
+          j.Cin = pc.Cin;
+          j.K = pc.K;
+          j.CinP = pc.CinP;
+          j.CoutP = pl.CoutP;
+          j.wp = wp2;
+          j.bp = bp2;
+          m->jobs.push_back(j);
+          m->plain_of[wp] = pl;
+        }
+        add_dgrad(pl);
+      } else {
+        add_dgrad(pc);
+      }
+    }
     return pc;
+  }
+
+  // input-gradient weights Wd[k'][co][ci] = Wp[K-1-k'][ci][co] of a packed conv (prepared after the pack jobs)
+  void add_dgrad(const PackedConv& pc) {
+    PackedConv d;
+    d.Cin = pc.Cout;
+    d.CinP = pc.CoutP;
+    d.Cout = pc.Cin;
+    d.CoutP = pc.CinP;
+    d.K = pc.K;
+    float* wd = m->ab.take<float>((size_t)pc.K * pc.CinP * pc.CoutP);
+    d.wp = wd;
+    d.bias = nullptr;
+    if (!dry) {
+      PackJob j;
+      j.kind = PK_DGRAD;
+      j.w = pc.wp;
+      j.K = pc.K;
+      j.CinP = pc.CinP;
+      j.CoutP = pc.CoutP;
+      j.wp = wd;
+      m->jobs.push_back(j);
+      m->dgrad[pc.wp] = d;
+    }
   }
 
   AdaFc fc(const std::string& name, int C) {
@@ -193,6 +245,7 @@ struct Builder {
       k.bp = bp;
       m->jobs.push_back(k);
     }
+    if (m->train_enabled) add_dgrad(pc);
     return c;
   }
 
@@ -1091,6 +1144,9 @@ void sty_model_destroy(sty_model* m) {
   if (m->arena) (void)hipFree(m->arena);
   if (m->fcs_dev) (void)hipFree(m->fcs_dev);
   if (m->stft_default) (void)hipFree(m->stft_default);
+  if (m->garena) (void)hipFree(m->garena);
+  if (m->fcs_bwd_dev) (void)hipFree(m->fcs_bwd_dev);
+  if (m->trainer) trainer_destroy(m->trainer);
   delete m;
 }
 
@@ -1153,9 +1209,132 @@ int sty_model_finalize(sty_model* m) {
     STY_HIP(hipMalloc((void**)&m->fcs_dev, m->fcs.size() * sizeof(StyleFcDesc)));
     STY_HIP(hipMemcpy(m->fcs_dev, m->fcs.data(), m->fcs.size() * sizeof(StyleFcDesc), hipMemcpyHostToDevice));
   }
+  if (m->garena) {
+    (void)hipFree(m->garena);
+    m->garena = nullptr;
+  }
+  if (m->train_enabled) {
+    STY_HIP(hipMalloc((void**)&m->garena, m->arena_bytes));
+    STY_HIP(hipMemset(m->garena, 0, m->arena_bytes));
+    m->pgrad.clear();
+    for (auto& kv : m->pgrad_by_key) {
+      auto it = m->params.find(kv.first);
+      if (it == m->params.end()) {
+        set_error("sty_model_bind_grad: '%s' is not a bound parameter", kv.first.c_str());
+        return STY_EINVAL;
+      }
+      m->pgrad[it->second.p] = kv.second;
+    }
+  }
   m->finalized = true;
   m->prepared = false;
   return STY_OK;
+}
+
+int sty_model_enable_training(sty_model* m) {
+  if (!m) {
+    set_error("null model");
+    return STY_EINVAL;
+  }
+  m->train_enabled = true;
+  m->finalized = false;
+  return STY_OK;
+}
+
+int sty_model_bind_grad(sty_model* m, const char* key, float* grad) {
+  if (!m || !key || !grad) {
+    set_error("sty_model_bind_grad: bad argument");
+    return STY_EINVAL;
+  }
+  m->pgrad_by_key[key] = grad;
+  m->train_enabled = true;
+  m->finalized = false;
+  return STY_OK;
+}
+
+// packed gradients -> the caller's parameter gradients (+=)
+static int unpack_grads(sty_model* m, hipStream_t st) {
+  auto PG = [&](const float* p) -> float* {
+    auto it = m->pgrad.find(p);
+    return it == m->pgrad.end() ? nullptr : it->second;
+  };
+  auto GA = [&](const float* packed) -> float* {
+    return reinterpret_cast<float*>(m->garena + (reinterpret_cast<const char*>(packed) - m->arena));
+  };
+  for (const PackJob& j : m->jobs) {
+    if (j.kind == PK_CONV || j.kind == PK_CONV_WN) {
+      // GLU-ordered jobs are never used by the training graph; their plain-ordered twins are PK_CONV
+      float* dW = j.w ? PG(j.w) : nullptr;
+      float* dg = j.g ? PG(j.g) : nullptr;
+      float* dv = j.v ? PG(j.v) : nullptr;
+      if (j.kind == PK_CONV && dW) {
+        int r = launch_unpack_grad(GA(j.wp), nullptr, nullptr, j.Cout, j.Cin, j.K, j.CinP, j.CoutP, 0, dW, nullptr,
+                                   nullptr, st);
+        if (r) return r;
+      }
+      if (j.kind == PK_CONV_WN && dg && dv) {
+        int r = launch_unpack_grad(GA(j.wp), j.g, j.v, j.Cout, j.Cin, j.K, j.CinP, j.CoutP, 0, nullptr, dg, dv, st);
+        if (r) return r;
+      }
+      float* db = (j.bias && j.bp) ? PG(j.bias) : nullptr;
+      if (db) {
+        int r = launch_axpy(GA(j.bp), 1.0f, db, (size_t)j.Cout, st);
+        if (r) return r;
+      }
+    } else if (j.kind == PK_W2A) {
+      // b2eff = b2 + W2 . grn_beta:  db2 += g, dbeta += W2^T g, dW2 += g beta^T   (g = gradient of b2eff)
+      float* db2 = PG(j.bias);
+      float* dbeta = PG(j.extra);
+      float* dW2 = PG(j.w);
+      int r = launch_b2eff_bwd(GA(j.bp), j.w, j.extra, j.Cout, db2, dbeta, dW2, st);
+      if (r) return r;
+    }
+  }
+  return STY_OK;
+}
+
+int sty_vocoder_train_workspace_bytes(sty_model* m, int B, int T, size_t* bytes) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!m->train_enabled || !bytes || B <= 0 || T <= 1) {
+    set_error("sty_vocoder_train_workspace_bytes: bad argument or training not enabled");
+    return STY_EINVAL;
+  }
+  if (!m->trainer) m->trainer = trainer_create(m);
+  sty_vocoder_io io;
+  memset(&io, 0, sizeof(io));
+  io.B = B;
+  io.T = T;
+  return trainer_vocoder_forward(m->trainer, &io, nullptr, 0, nullptr, bytes);
+}
+
+int sty_vocoder_fwd_train(sty_model* m, const sty_vocoder_io* io, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  if (!io || !workspace || !io->mel || !io->style || !io->audio || io->B <= 0 || io->T <= 1 ||
+      (!io->prior_override && (!io->pitch || !io->voiced))) {
+    set_error("sty_vocoder_fwd_train: bad argument");
+    return STY_EINVAL;
+  }
+  if ((rc = sty_model_prepare(m, stream))) return rc;  // parameters change every step
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_vocoder_forward(m->trainer, io, workspace, ws_bytes, S(stream), nullptr);
+}
+
+int sty_vocoder_bwd(sty_model* m, const float* d_audio, float* d_mel, float* d_style, void* stream) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!m->trainer || !d_audio) {
+    set_error("sty_vocoder_bwd: no forward recorded or null gradient");
+    return STY_ESTATE;
+  }
+  rc = trainer_vocoder_backward(m->trainer, d_audio, d_mel, d_style, S(stream));
+  if (rc) return rc;
+  return unpack_grads(m, S(stream));
 }
 
 int sty_model_num_keys(const sty_model* m) { return m ? (int)m->requested.size() : 0; }
@@ -1173,6 +1352,8 @@ int sty_model_prepare(sty_model* m, void* stream) {
   for (const PackJob& j : m->jobs) {
     int r = STY_OK;
     switch (j.kind) {
+      case PK_DGRAD:
+        break;  // second pass below
       case PK_CONV:
       case PK_CONV_WN:
         r = launch_pack_conv(j.w, j.g, j.v, j.bias, j.Cout, j.Cin, j.K, j.wp, j.bp, j.CinP, j.CoutP, st);
@@ -1193,6 +1374,11 @@ int sty_model_prepare(sty_model* m, void* stream) {
     }
     if (r != STY_OK) return r;
   }
+  for (const PackJob& j : m->jobs)
+    if (j.kind == PK_DGRAD) {
+      int r = launch_pack_dgrad(j.w, j.K, j.CinP, j.CoutP, j.wp, st);
+      if (r != STY_OK) return r;
+    }
   if (m->kind == "speech_predictor") {
     const DecoderPlan& d = m->dec;
     int r = launch_prep_fnv(d.f0_g, d.f0_v, d.f0_b, d.n_g, d.n_v, d.n_b, d.v_g, d.v_v, d.v_b, d.fnv_w, st);

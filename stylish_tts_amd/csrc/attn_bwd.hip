@@ -1,0 +1,158 @@
+// Attention backward (conformer.py:111-144, text_encoder.py:234-280), channel-major q/k/v/o [B][H*DH][T].
+// First version: three straightforward VALU kernels with lanes along the query (A, C) or key (B) index, so that the
+// other operand is wave-uniform (scalar loads).  O(T^2 DH) at the T frame rate only; the MFMA formulation of the
+// forward kernel is the planned replacement.
+//   A: lse_i = logsumexp_j s_ij,  delta_i = sum_d dO[d][i] O[d][i]
+//   B: dV[d][j] = sum_i p_ij dO[d][i],   dK[d][j] = scale * sum_i ds_ij q[d][i]
+//   C: dQ[d][i] = scale * sum_j ds_ij k[d][j],   with p_ij = exp(s_ij - lse_i), ds_ij = p_ij (dp_ij - delta_i),
+//      dp_ij = sum_d v[d][j] dO[d][i],  s_ij = scale q_i.k_j (+ -1e4 where i or j >= length).
+#include "sty_common.h"
+
+namespace sty {
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_bwd_a_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
+                                                        float* __restrict__ lse, float* __restrict__ delta) {
+  const int T = a.T, b = blockIdx.z, h = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= T) return;
+  const float* qb = a.q + (size_t)b * a.qbs + (size_t)h * DH * T;
+  const float* kb = a.k + (size_t)b * a.kbs + (size_t)h * DH * T;
+  const float* ob = a.o + (size_t)b * a.obs + (size_t)h * DH * T;
+  const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  float q[DH];
+  float dl = 0.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    q[d] = qb[(size_t)d * T + i] * a.scale;
+    dl = fmaf(gb[(size_t)d * T + i], ob[(size_t)d * T + i], dl);
+  }
+  float m = -3.0e38f, l = 0.f;
+  const bool qpad = a.lengths && i >= len;
+  for (int j = 0; j < T; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) s = fmaf(q[d], kb[(size_t)d * T + j], s);
+    if (a.lengths && (qpad || j >= len)) s += -1e4f;
+    const float mn = fmaxf(m, s);
+    l = l * expf(m - mn) + expf(s - mn);
+    m = mn;
+  }
+  const size_t o = ((size_t)b * a.H + h) * T + i;
+  lse[o] = m + logf(l);
+  delta[o] = dl;
+}
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_bwd_c_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
+                                                        const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        float* __restrict__ dQ, size_t dqbs) {
+  const int T = a.T, b = blockIdx.z, h = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= T) return;
+  const float* qb = a.q + (size_t)b * a.qbs + (size_t)h * DH * T;
+  const float* kb = a.k + (size_t)b * a.kbs + (size_t)h * DH * T;
+  const float* vb = a.v + (size_t)b * a.vbs + (size_t)h * DH * T;
+  const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  const size_t oi = ((size_t)b * a.H + h) * T + i;
+  const float L = lse[oi], dl = delta[oi];
+  float q[DH], g[DH], acc[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    q[d] = qb[(size_t)d * T + i] * a.scale;
+    g[d] = gb[(size_t)d * T + i];
+    acc[d] = 0.f;
+  }
+  const bool qpad = a.lengths && i >= len;
+  for (int j = 0; j < T; ++j) {
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      s = fmaf(q[d], kb[(size_t)d * T + j], s);
+      dp = fmaf(g[d], vb[(size_t)d * T + j], dp);
+    }
+    if (a.lengths && (qpad || j >= len)) s += -1e4f;
+    const float ds = expf(s - L) * (dp - dl);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = fmaf(ds, kb[(size_t)d * T + j], acc[d]);
+  }
+  float* dq = dQ + (size_t)b * dqbs + (size_t)h * DH * T;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) dq[(size_t)d * T + i] += acc[d] * a.scale;
+}
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_bwd_b_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
+                                                        const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        float* __restrict__ dK, size_t dkbs, float* __restrict__ dV,
+                                                        size_t dvbs) {
+  __shared__ float ks[DH * 65], vs[DH * 65];
+  const int T = a.T, b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * 64, lane = threadIdx.x;
+  const int j = j0 + lane;
+  const float* qb = a.q + (size_t)b * a.qbs + (size_t)h * DH * T;
+  const float* kb = a.k + (size_t)b * a.kbs + (size_t)h * DH * T;
+  const float* vb = a.v + (size_t)b * a.vbs + (size_t)h * DH * T;
+  const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  for (int d = 0; d < DH; ++d) {
+    ks[d * 65 + lane] = j < T ? kb[(size_t)d * T + j] : 0.f;
+    vs[d * 65 + lane] = j < T ? vb[(size_t)d * T + j] : 0.f;
+  }
+  float ak[DH], av[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) ak[d] = av[d] = 0.f;
+  const float* Lb = lse + ((size_t)b * a.H + h) * T;
+  const float* Db = delta + ((size_t)b * a.H + h) * T;
+  for (int i = 0; i < T; ++i) {
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      s = fmaf(qb[(size_t)d * T + i], ks[d * 65 + lane], s);
+      dp = fmaf(gb[(size_t)d * T + i], vs[d * 65 + lane], dp);
+    }
+    s *= a.scale;
+    if (a.lengths && (i >= len || j >= len)) s += -1e4f;
+    const float p = j < T ? expf(s - Lb[i]) : 0.f;
+    const float ds = p * (dp - Db[i]);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      av[d] = fmaf(p, gb[(size_t)d * T + i], av[d]);
+      ak[d] = fmaf(ds, qb[(size_t)d * T + i], ak[d]);
+    }
+  }
+  if (j < T) {
+    float* dk = dK + (size_t)b * dkbs + (size_t)h * DH * T;
+    float* dv = dV + (size_t)b * dvbs + (size_t)h * DH * T;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      dk[(size_t)d * T + j] += ak[d] * a.scale;
+      dv[(size_t)d * T + j] += av[d];
+    }
+  }
+}
+
+size_t attention_bwd_ws_floats(int B, int H, int T) { return (size_t)2 * B * H * T; }
+
+// gradients are ACCUMULATED into dQ / dK / dV
+int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* dK, float* dV, size_t dqbs, size_t dkbs,
+                         size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st) {
+  float* lse = ws;
+  float* delta = ws + (size_t)B * a.H * a.T;
+  dim3 grid(cdiv(a.T, 64), a.H, B);
+  if (DH == 64) {
+    hipLaunchKernelGGL(attn_bwd_a_kernel<64>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta);
+    hipLaunchKernelGGL(attn_bwd_b_kernel<64>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dK, dkbs, dV, dvbs);
+    hipLaunchKernelGGL(attn_bwd_c_kernel<64>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dQ, dqbs);
+  } else if (DH == 16) {
+    hipLaunchKernelGGL(attn_bwd_a_kernel<16>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta);
+    hipLaunchKernelGGL(attn_bwd_b_kernel<16>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dK, dkbs, dV, dvbs);
+    hipLaunchKernelGGL(attn_bwd_c_kernel<16>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dQ, dqbs);
+  } else {
+    set_error("attention_bwd: head dim %d not built", DH);
+    return STY_EINVAL;
+  }
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

@@ -1,0 +1,657 @@
+// Backward kernels of the acoustic path (K15).  Same data layout as the forward: fp32 [B][C][T], lanes along time.
+// Row reductions (per (b,c) sums over time) are done one workgroup per row with fp32 lane partials and an fp64
+// combine; parameter gradients that sum over the batch are accumulated with one atomicAdd per row.
+//
+// Math (x: conv input before its fused prologue, z = a x + s the AdaIN-folded value, u = d loss / d prologue(x)):
+//   Snake   f(z) = z + sin^2(alpha z)/alpha      f' = 1 + sin(2 alpha z)     df/dalpha = (z sin(2 alpha z) - sin^2(alpha z)/alpha)/alpha
+//   LReLU   f' = z > 0 ? 1 : 0.2
+//   AdaIN fold  a = (1+gamma) r, s = beta - a mu  ->  dgamma = r (da - mu ds), dbeta = ds,
+//               dmu = -a ds, dr = (1+gamma)(da - mu ds), and dx += dmu/T - dr r^3 (x - mu)/T
+#include "sty_common.h"
+
+namespace sty {
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum of up to 4 doubles per thread (256 threads); result valid on thread 0
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double (*red)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    v[i] = wave_sum(v[i]);
+    if (lane == 0) red[i][wave] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = red[i][0] + red[i][1] + red[i][2] + red[i][3];
+  }
+}
+
+// ---- fused-prologue backward: u = d/d(prologue(x)) -> dx (+=), row sums for da, ds, dalpha ----
+// mode = ConvPro.  One workgroup per (b, c) row.  u is [B][Cu][T] with this tensor's channels starting at cu0
+// (the dgrad conv of a channel-concatenated input produces one tensor for all sources).
+__global__ __launch_bounds__(256) void pro_bwd_kernel(int mode, const float* __restrict__ u, int Cu, int cu0,
+                                                      const float* __restrict__ x, int C, int T,
+                                                      const float* __restrict__ pa, const float* __restrict__ ps,
+                                                      int pC, int pc0, const float* __restrict__ alpha,
+                                                      const float* __restrict__ mask, float* __restrict__ dx,
+                                                      int accumulate, float* __restrict__ dpa,
+                                                      float* __restrict__ dps, float* __restrict__ dalpha) {
+  __shared__ double red[3][4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* ur = u + ((size_t)b * Cu + cu0 + c) * T;
+  const float* xr = x + ((size_t)b * C + c) * T;
+  float* dr = dx + ((size_t)b * C + c) * T;
+  float a = 1.f, s = 0.f, al = 1.f;
+  if (mode == PRO_AFFINE || mode == PRO_AFFINE_SNAKE || mode == PRO_AFFINE_LRELU || mode == PRO_SCALE) {
+    a = pa[(size_t)b * pC + pc0 + c];
+    if (mode != PRO_SCALE) s = ps[(size_t)b * pC + pc0 + c];
+  }
+  if (mode == PRO_AFFINE_SNAKE) al = alpha[pc0 + c];
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float uv = ur[t], xv = xr[t];
+    float g;  // d loss / d z
+    float dal = 0.f;
+    if (mode == PRO_AFFINE_SNAKE) {
+      const float z = a * xv + s;
+      const float s2 = sty_sin2(al * z), s2a = sty_sinf(2.f * al * z);
+      g = uv * (1.f + s2a);
+      dal = uv * (z * s2a - s2 / al) / al;
+    } else if (mode == PRO_AFFINE_LRELU) {
+      const float z = a * xv + s;
+      g = z > 0.f ? uv : 0.2f * uv;
+    } else if (mode == PRO_LRELU) {
+      g = xv > 0.f ? uv : 0.2f * uv;
+    } else if (mode == PRO_MASK) {
+      g = uv * mask[(size_t)b * T + t];
+    } else {
+      g = uv;
+    }
+    const float d = g * a;
+    dr[t] = accumulate ? dr[t] + d : d;
+    acc[0] += (double)g * xv;
+    acc[1] += (double)g;
+    acc[2] += (double)dal;
+  }
+  block_sum<3>(acc, red);
+  if (threadIdx.x == 0) {
+    if (dpa) dpa[(size_t)b * pC + pc0 + c] = (float)acc[0];
+    if (dps) dps[(size_t)b * pC + pc0 + c] = (float)acc[1];
+    if (dalpha && mode == PRO_AFFINE_SNAKE) atomicAdd(&dalpha[pc0 + c], (float)acc[2]);
+  }
+}
+
+int launch_pro_bwd(int mode, const float* u, int Cu, int cu0, const float* x, int B, int C, int T, const float* pa,
+                   const float* ps, int pC, int pc0, const float* alpha, const float* mask, float* dx, int accumulate,
+                   float* dpa, float* dps, float* dalpha, hipStream_t st) {
+  hipLaunchKernelGGL(pro_bwd_kernel, dim3(C, B), dim3(256), 0, st, mode, u, Cu, cu0, x, C, T, pa, ps, pC, pc0, alpha,
+                     mask, dx, accumulate, dpa, dps, dalpha);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- AdaIN fold backward: (da, ds, mean, rstd, gb) -> dgb (+=), row coefficients c0, c1 with dx += c0 + c1 x ----
+__global__ void adain_fold_bwd_kernel(const float* __restrict__ da, const float* __restrict__ ds,
+                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                      const float* __restrict__ gb, int B, int C, int T, float* __restrict__ dgb,
+                                      float* __restrict__ c0, float* __restrict__ c1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  const float mu = mean[i], r = rstd[i], g1 = 1.f + gb[(size_t)b * 2 * C + c];
+  const float dA = da[i], dS = ds[i];
+  const float a = g1 * r;
+  dgb[(size_t)b * 2 * C + c] += r * (dA - mu * dS);
+  dgb[(size_t)b * 2 * C + C + c] += dS;
+  const float dmu = -a * dS, dr = g1 * (dA - mu * dS);
+  const float k1 = -dr * r * r * r / (float)T;
+  c1[i] = k1;
+  c0[i] = dmu / (float)T - k1 * mu;
+}
+int launch_adain_fold_bwd(const float* da, const float* ds, const float* mean, const float* rstd, const float* gb, int B,
+                          int C, int T, float* dgb, float* c0, float* c1, hipStream_t st) {
+  hipLaunchKernelGGL(adain_fold_bwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, da, ds, mean, rstd, gb, B, C, T,
+                     dgb, c0, c1);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// dx[b,c,t] += c0[b,c] + c1[b,c] * x[b,c,t]
+__global__ void row_axpb_kernel(const float* __restrict__ x, const float* __restrict__ c0,
+                                const float* __restrict__ c1, int T, float* __restrict__ dx) {
+  const int t = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+  if (t >= T) return;
+  const size_t o = (size_t)row * T + t;
+  dx[o] += c0[row] + c1[row] * x[o];
+}
+int launch_row_axpb(const float* x, const float* c0, const float* c1, int rows, int T, float* dx, hipStream_t st) {
+  hipLaunchKernelGGL(row_axpb_kernel, dim3(cdiv(T, 256), rows), dim3(256), 0, st, x, c0, c1, T, dx);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- per-row mean / rstd (InstanceNorm statistics kept for the backward) ----
+__global__ void adain_stats_kernel(const double* __restrict__ part, int nseg, int rows, int T, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  double sum = 0.0, sq = 0.0;
+  for (int k = 0; k < nseg; ++k) {
+    sum += part[((size_t)i * nseg + k) * 2];
+    sq += part[((size_t)i * nseg + k) * 2 + 1];
+  }
+  const double m = sum / T;
+  double var = sq / T - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+int launch_adain_stats(const double* part, int nseg, int rows, int T, float eps, float* mean, float* rstd,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(adain_stats_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, part, nseg, rows, T, eps, mean, rstd);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- LayerNorm over channels, backward.  dx per column; parameter sums per row. ----
+// y = xhat * A + Bv,  A = w[c] (ada = 0) or 1 + gb[b][c] (ada = 1);  relu / out_mask as in the forward.
+__global__ __launch_bounds__(64) void chan_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ y, int C, int T, float eps,
+                                                            int ada, const float* __restrict__ w,
+                                                            const float* __restrict__ gb, int relu,
+                                                            const float* __restrict__ out_mask,
+                                                            float* __restrict__ dx, int accumulate,
+                                                            float* __restrict__ mu_out, float* __restrict__ r_out) {
+  const int t = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const size_t base = (size_t)b * C * T + t;
+  float mean = 0.f;
+  for (int c = 0; c < C; ++c) mean += x[base + (size_t)c * T];
+  mean /= (float)C;
+  float var = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = x[base + (size_t)c * T] - mean;
+    var += d * d;
+  }
+  const float r = 1.0f / sqrtf(var / (float)C + eps);
+  const float om = out_mask ? out_mask[(size_t)b * T + t] : 1.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const size_t o = base + (size_t)c * T;
+    float g = dy[o] * om;
+    if (relu && !(y[o] > 0.f)) g = 0.f;
+    const float A = ada ? 1.f + gb[(size_t)b * 2 * C + c] : w[c];
+    const float dxh = g * A, xh = (x[o] - mean) * r;
+    s1 += dxh;
+    s2 += dxh * xh;
+  }
+  s1 /= (float)C;
+  s2 /= (float)C;
+  for (int c = 0; c < C; ++c) {
+    const size_t o = base + (size_t)c * T;
+    float g = dy[o] * om;
+    if (relu && !(y[o] > 0.f)) g = 0.f;
+    const float A = ada ? 1.f + gb[(size_t)b * 2 * C + c] : w[c];
+    const float xh = (x[o] - mean) * r;
+    const float d = r * (g * A - s1 - xh * s2);
+    dx[o] = accumulate ? dx[o] + d : d;
+  }
+  mu_out[(size_t)b * T + t] = mean;
+  r_out[(size_t)b * T + t] = r;
+}
+// per (b,c) row: dA = sum_t g xhat, dB = sum_t g  ->  dgb (ada) or atomics into dw/db (affine)
+__global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dy,
+                                                                const float* __restrict__ y,
+                                                                const float* __restrict__ mu,
+                                                                const float* __restrict__ r, int C, int T, int ada,
+                                                                int relu, const float* __restrict__ out_mask,
+                                                                float* __restrict__ dgb, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+  __shared__ double red[2][4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const size_t row = ((size_t)b * C + c) * T;
+  double acc[2] = {0.0, 0.0};
+  for (int t = threadIdx.x; t < T; t += 256) {
+    float g = dy[row + t];
+    if (out_mask) g *= out_mask[(size_t)b * T + t];
+    if (relu && !(y[row + t] > 0.f)) g = 0.f;
+    const float xh = (x[row + t] - mu[(size_t)b * T + t]) * r[(size_t)b * T + t];
+    acc[0] += (double)g * xh;
+    acc[1] += (double)g;
+  }
+  block_sum<2>(acc, red);
+  if (threadIdx.x == 0) {
+    if (ada) {
+      dgb[(size_t)b * 2 * C + c] += (float)acc[0];
+      dgb[(size_t)b * 2 * C + C + c] += (float)acc[1];
+    } else {
+      atomicAdd(&dw[c], (float)acc[0]);
+      atomicAdd(&db[c], (float)acc[1]);
+    }
+  }
+}
+int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,
+                       const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
+                       float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st) {
+  hipLaunchKernelGGL(chan_ln_bwd_dx_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, st, x, dy, y, C, T, eps, ada, w, gb, relu,
+                     out_mask, dx, accumulate, mu_tmp, r_tmp);
+  hipLaunchKernelGGL(chan_ln_bwd_param_kernel, dim3(C, B), dim3(256), 0, st, x, dy, y, mu_tmp, r_tmp, C, T, ada, relu,
+                     out_mask, dgb, dw, db);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- GRN backward (conv_next.py:15-18).  Forward: gx = ||h||_2 over time, nx = gx/(mean_c gx + eps),
+// s = 1 + gamma nx, out = h s (+ beta, folded into the next conv's bias).  Input ds[b][c] = d loss / d s. ----
+// One workgroup per batch row -> coef[b][c] = dgx/gx (so that dh += coef * h), dgamma += sum_b ds nx.
+__global__ __launch_bounds__(256) void grn_bwd_kernel(const double* __restrict__ part, int nseg,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ ds, int C4,
+                                                      float* __restrict__ coef, float* __restrict__ dgamma) {
+  __shared__ float gxs[1024];
+  __shared__ double red[2][4];
+  const int b = blockIdx.x;
+  double acc[1] = {0.0};
+  for (int c = threadIdx.x; c < C4; c += 256) {
+    double sq = 0.0;
+    for (int k = 0; k < nseg; ++k) sq += part[(((size_t)b * C4 + c) * nseg + k) * 2 + 1];
+    const float gx = (float)sqrt(sq);
+    gxs[c] = gx;
+    acc[0] += gx;
+  }
+  __shared__ float mean_s, dot_s;
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) mean_s = (float)(acc[0] / C4);
+  __syncthreads();
+  const float m = mean_s + 1e-6f;
+  double d2[1] = {0.0};
+  for (int c = threadIdx.x; c < C4; c += 256) {
+    const float dnx = ds[(size_t)b * C4 + c] * gamma[c];
+    d2[0] += (double)dnx * gxs[c];
+    atomicAdd(&dgamma[c], ds[(size_t)b * C4 + c] * (gxs[c] / m));
+  }
+  __syncthreads();
+  block_sum<1>(d2, red);
+  if (threadIdx.x == 0) dot_s = (float)d2[0];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C4; c += 256) {
+    const float dnx = ds[(size_t)b * C4 + c] * gamma[c];
+    const float dgx = dnx / m - dot_s / (m * m) / (float)C4;
+    coef[(size_t)b * C4 + c] = gxs[c] > 0.f ? dgx / gxs[c] : 0.f;
+  }
+}
+int launch_grn_bwd(const double* part, int nseg, const float* gamma, const float* ds, int B, int C4, float* coef,
+                   float* dgamma, hipStream_t st) {
+  if (C4 > 1024) {
+    set_error("grn_bwd: 4C > 1024");
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(grn_bwd_kernel, dim3(B), dim3(256), 0, st, part, nseg, gamma, ds, C4, coef, dgamma);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- pointwise activations, forward (training graph keeps the pre-activation) and backward ----
+// kind: ACT_RELU / ACT_SWISH / ACT_SNAKE (alpha per channel) / ACT_GLU (x [B][2C][T] -> y [B][C][T]) / 100 = tanh
+__global__ void act_fwd_kernel(int kind, const float* __restrict__ x, const float* __restrict__ alpha, int C, int T,
+                               float* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  if (kind == ACT_GLU) {
+    const float a = x[((size_t)b * 2 * C + c) * T + t], g = x[((size_t)b * 2 * C + C + c) * T + t];
+    y[((size_t)b * C + c) * T + t] = a / (1.f + expf(-g));
+    return;
+  }
+  const size_t o = ((size_t)b * C + c) * T + t;
+  const float v = x[o];
+  float r = v;
+  if (kind == ACT_RELU) r = fmaxf(v, 0.f);
+  else if (kind == ACT_SWISH) r = v / (1.f + expf(-v));
+  else if (kind == ACT_SNAKE) r = sty_snake(v, alpha[c], 1.f / alpha[c]);
+  else if (kind == 100) r = tanhf(v);
+  y[o] = r;
+}
+int launch_act_fwd(int kind, const float* x, const float* alpha, int B, int C, int T, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, kind, x, alpha, C, T, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// one workgroup per (b,c) row: dx (write / accumulate) and the snake alpha gradient
+__global__ __launch_bounds__(256) void act_bwd_kernel(int kind, const float* __restrict__ x,
+                                                      const float* __restrict__ dy, const float* __restrict__ alpha,
+                                                      int C, int T, float* __restrict__ dx, int accumulate,
+                                                      float* __restrict__ dalpha) {
+  __shared__ double red[1][4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  double acc[1] = {0.0};
+  if (kind == ACT_GLU) {
+    const size_t ra = ((size_t)b * 2 * C + c) * T, rg = ((size_t)b * 2 * C + C + c) * T, ro = ((size_t)b * C + c) * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float a = x[ra + t], g = x[rg + t], d = dy[ro + t];
+      const float sg = 1.f / (1.f + expf(-g));
+      const float da = d * sg, dg = d * a * sg * (1.f - sg);
+      dx[ra + t] = accumulate ? dx[ra + t] + da : da;
+      dx[rg + t] = accumulate ? dx[rg + t] + dg : dg;
+    }
+    return;
+  }
+  const size_t row = ((size_t)b * C + c) * T;
+  const float al = kind == ACT_SNAKE ? alpha[c] : 1.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float v = x[row + t], d = dy[row + t];
+    float g = d;
+    if (kind == ACT_RELU) g = v > 0.f ? d : 0.f;
+    else if (kind == ACT_SWISH) {
+      const float sg = 1.f / (1.f + expf(-v));
+      g = d * (sg + v * sg * (1.f - sg));
+    } else if (kind == ACT_SNAKE) {
+      const float s2 = sty_sin2(al * v), s2a = sty_sinf(2.f * al * v);
+      g = d * (1.f + s2a);
+      acc[0] += (double)(d * (v * s2a - s2 / al) / al);
+    } else if (kind == 100) {
+      const float th = tanhf(v);
+      g = d * (1.f - th * th);
+    }
+    dx[row + t] = accumulate ? dx[row + t] + g : g;
+  }
+  if (kind == ACT_SNAKE && dalpha) {
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&dalpha[c], (float)acc[0]);
+  }
+}
+int launch_act_bwd(int kind, const float* x, const float* dy, const float* alpha, int B, int C, int T, float* dx,
+                   int accumulate, float* dalpha, hipStream_t st) {
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(C, B), dim3(256), 0, st, kind, x, dy, alpha, C, T, dx, accumulate, dalpha);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// dh[b,c,t] (+)= coef[b,c] * h[b,c,t]   (GRN), or plain scaled add with coef == nullptr: dst += src * k
+__global__ void row_scale_add_kernel(const float* __restrict__ src, const float* __restrict__ coef, float k, int T,
+                                     float* __restrict__ dst) {
+  const int t = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+  if (t >= T) return;
+  const size_t o = (size_t)row * T + t;
+  dst[o] += src[o] * (coef ? coef[row] : k);
+}
+int launch_row_scale_add(const float* src, const float* coef, float k, int rows, int T, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(row_scale_add_kernel, dim3(cdiv(T, 256), rows), dim3(256), 0, st, src, coef, k, T, dst);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- depthwise conv: plain forward (training graph), input gradient, weight/bias gradient ----
+__global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ bias, int C, int T, int K, int pad,
+                                  float* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* p = x + ((size_t)b * C + c) * T;
+  float acc = bias ? bias[c] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int tt = t - pad + k;
+    if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+  }
+  y[((size_t)b * C + c) * T + t] = acc;
+}
+int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad, float* y,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, x, w, bias, C, T, K, pad, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+__global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C, int T, int K,
+                                     int pad, float* __restrict__ dx, int accumulate) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* p = dy + ((size_t)b * C + c) * T;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {  // y[t'] uses x[t' - pad + k]  ->  x[t] feeds y[t + pad - k]
+    const int tt = t + pad - k;
+    if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+  }
+  const size_t o = ((size_t)b * C + c) * T + t;
+  dx[o] = accumulate ? dx[o] + acc : acc;
+}
+// one workgroup per channel: dw[c][k] += sum_{b,t} dy[t] x[t - pad + k], db[c] += sum dy
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           int B, int C, int T, int K, int pad,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double red[1][4];
+  const int c = blockIdx.x;
+  for (int k = 0; k <= K; ++k) {  // k == K: bias
+    double acc[1] = {0.0};
+    for (int b = 0; b < B; ++b) {
+      const float* xr = x + ((size_t)b * C + c) * T;
+      const float* gr = dy + ((size_t)b * C + c) * T;
+      for (int t = threadIdx.x; t < T; t += 256) {
+        if (k == K) {
+          acc[0] += gr[t];
+        } else {
+          const int tt = t - pad + k;
+          if (tt >= 0 && tt < T) acc[0] += (double)gr[t] * xr[tt];
+        }
+      }
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) {
+      if (k == K) {
+        if (db) db[c] += (float)acc[0];
+      } else {
+        dw[c * K + k] += (float)acc[0];
+      }
+    }
+    __syncthreads();
+  }
+}
+int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
+                      int accumulate, float* dw, float* db, hipStream_t st) {
+  if (dx)
+    hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
+                       accumulate);
+  if (dw) hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(C), dim3(256), 0, st, x, dy, B, C, T, K, pad, dw, db);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// per-channel affine y = x * sc[c] + sh[c] (BatchNorm in eval mode), forward / backward
+__global__ void chan_affine_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                   const float* __restrict__ bvec, const float* __restrict__ rm,
+                                   const float* __restrict__ rv, float eps, int C, int T, float* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const size_t o = ((size_t)b * C + c) * T + t;
+  y[o] = (x[o] - rm[c]) / sqrtf(rv[c] + eps) * w[c] + bvec[c];
+}
+int launch_bn_eval_fwd(const float* x, const float* w, const float* b, const float* rm, const float* rv, float eps,
+                       int B, int C, int T, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(chan_affine_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, x, w, b, rm, rv, eps, C, T, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+__global__ __launch_bounds__(256) void bn_eval_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ w, const float* __restrict__ rm,
+                                                          const float* __restrict__ rv, float eps, int B, int C, int T,
+                                                          float* __restrict__ dx, float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+  __shared__ double red[2][4];
+  const int c = blockIdx.x;
+  const float inv = 1.0f / sqrtf(rv[c] + eps);
+  double acc[2] = {0.0, 0.0};
+  for (int b = 0; b < B; ++b) {
+    const size_t row = ((size_t)b * C + c) * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float g = dy[row + t];
+      dx[row + t] = g * w[c] * inv;
+      acc[0] += (double)g * ((x[row + t] - rm[c]) * inv);
+      acc[1] += g;
+    }
+  }
+  block_sum<2>(acc, red);
+  if (threadIdx.x == 0) {
+    dw[c] += (float)acc[0];
+    db[c] += (float)acc[1];
+  }
+}
+int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const float* rm, const float* rv, float eps,
+                       int B, int C, int T, float* dx, float* dw, float* db, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(C), dim3(256), 0, st, x, dy, w, rm, rv, eps, B, C, T, dx, dw, db);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- bias gradient of a dense conv: db[co] += scale * sum_{b,t} g[b][co][t] (* mask) ----
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                        int B, int C, int T, int shuffle, float scale,
+                                                        float* __restrict__ db) {
+  __shared__ double red[1][4];
+  const int co = blockIdx.x;
+  double acc[1] = {0.0};
+  for (int b = 0; b < B; ++b) {
+    for (int t = threadIdx.x; t < T; t += 256) {
+      float v;
+      if (shuffle > 1)
+        v = g[((size_t)b * (C / shuffle) + co / shuffle) * ((size_t)T * shuffle) + (size_t)t * shuffle + co % shuffle];
+      else
+        v = g[((size_t)b * C + co) * T + t];
+      if (mask) v *= mask[(size_t)b * T + t];
+      acc[0] += v;
+    }
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) db[co] += (float)acc[0] * scale;
+}
+int launch_bias_grad(const float* g, const float* mask, int B, int C, int T, int shuffle, float scale, float* db,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, st, g, mask, B, C, T, shuffle, scale, db);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- fc(style) backward for every AdaIN/AdaLN layer: dW += dgb^T style, db += sum_b dgb, dstyle += dgb W ----
+__global__ __launch_bounds__(256) void style_fc_bwd_kernel(const StyleFcBwdDesc* __restrict__ descs, int style_dim,
+                                                           const float* __restrict__ style,
+                                                           const float* __restrict__ dgb_base, int B,
+                                                           float* __restrict__ dstyle) {
+  const StyleFcBwdDesc d = descs[blockIdx.x];
+  const float* dgb = dgb_base + d.off * B;
+  // parameter grads: thread per (j, k)
+  for (int i = threadIdx.x; i < d.n * style_dim; i += 256) {
+    const int j = i / style_dim, k = i % style_dim;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(dgb[(size_t)b * d.n + j], style[(size_t)b * style_dim + k], acc);
+    if (d.dW) d.dW[i] += acc;
+  }
+  for (int j = threadIdx.x; j < d.n; j += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += dgb[(size_t)b * d.n + j];
+    if (d.db) d.db[j] += acc;
+  }
+  if (dstyle) {
+    for (int i = threadIdx.x; i < B * style_dim; i += 256) {
+      const int b = i / style_dim, k = i % style_dim;
+      float acc = 0.f;
+      for (int j = 0; j < d.n; ++j) acc = fmaf(dgb[(size_t)b * d.n + j], d.W[(size_t)j * style_dim + k], acc);
+      atomicAdd(&dstyle[i], acc);
+    }
+  }
+}
+int launch_style_fc_bwd(const void* descs_dev, int nlayers, int B, int style_dim, const float* style,
+                        const float* dgb_base, float* dstyle, hipStream_t st) {
+  hipLaunchKernelGGL(style_fc_bwd_kernel, dim3(nlayers), dim3(256), 0, st, (const StyleFcBwdDesc*)descs_dev, style_dim,
+                     style, dgb_base, B, dstyle);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- synthesis head backward (generator.py:782-799,896; stft.py:138-187) ----
+// audio = tanh(v), v = OLA(frames), frame f = Br^T (mag cos) - Bi^T (mag sin); frame F is the replicate of F-1.
+// One workgroup = 128 frames: gather dv windows into LDS, 32x64 GEMM per 32 frames on the matrix cores, then the
+// exp/atan2/cos/sin chain rule.  Frame F's contribution is added to frame F-1 with atomics (one column per batch).
+__global__ __launch_bounds__(256) void istft64_bwd_kernel(const float* __restrict__ audio,
+                                                          const float* __restrict__ daudio,
+                                                          const float* __restrict__ logamp,
+                                                          const float* __restrict__ real,
+                                                          const float* __restrict__ imag, const float* __restrict__ bbr,
+                                                          const float* __restrict__ bbi, int F,
+                                                          float* __restrict__ dlogamp, float* __restrict__ dreal,
+                                                          float* __restrict__ dimag) {
+  __shared__ float xs[4 * 128 + 64];
+  __shared__ float bsr[64 * 32], bsi[64 * 32];  // transposed backward bases [m][bin]
+  const int tid = threadIdx.x, lane = tid & 63, wave_id = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.y, f0 = blockIdx.x * 128;
+  const int N = 4 * F;
+  for (int j = tid; j < 4 * 128 + 64; j += 256) {
+    const int n = 4 * f0 - 32 + j;  // trimmed output index of untrimmed position 4 f + m
+    float v = 0.f;
+    if (n >= 0 && n < N) {
+      const float a = audio[(size_t)b * N + n];
+      v = daudio[(size_t)b * N + n] * (1.f - a * a);
+    }
+    xs[j] = v;
+  }
+  for (int e = tid; e < 64 * 32; e += 256) {
+    const int m = e >> 5, bin = e & 31;
+    bsr[e] = bbr[bin * 64 + m];
+    bsi[e] = bbi[bin * 64 + m];
+  }
+  __syncthreads();
+  f32x16 dc, dsn;  // d loss / d (mag cos), d loss / d (mag sin)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dc[r] = dsn[r] = 0.f;
+  const float* xb = xs + 4 * (wave_id * 32 + l31) + hi;
+#pragma unroll
+  for (int c2 = 0; c2 < 32; ++c2) {
+    const float xv = xb[2 * c2];
+    dc = __builtin_amdgcn_mfma_f32_32x32x2f32(bsr[(2 * c2 + hi) * 32 + l31], xv, dc, 0, 0, 0);
+    dsn = __builtin_amdgcn_mfma_f32_32x32x2f32(bsi[(2 * c2 + hi) * 32 + l31], xv, dsn, 0, 0, 0);
+  }
+  const int f = f0 + wave_id * 32 + l31;
+  if (f <= F) {
+    const int fs = f < F ? f : F - 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int bin = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const size_t o = ((size_t)b * 32 + bin) * F + fs;
+      const float re = real[o], im = imag[o];
+      const float ph = atan2f(im, re), mag = expf(logamp[o]);
+      const float c = cosf(ph), s = sinf(ph);
+      const float gc = dc[r], gs = -dsn[r];
+      const float dla = (gc * c + gs * s) * mag;
+      const float dph = mag * (-gc * s + gs * c);
+      const float h2 = re * re + im * im;
+      const float dre = h2 > 0.f ? dph * (-im / h2) : 0.f, dim_ = h2 > 0.f ? dph * (re / h2) : 0.f;
+      if (f < F) {
+        // frame F-1 also receives frame F's share: accumulate, buffers are pre-zeroed by the caller
+        atomicAdd(&dlogamp[o], dla);
+        atomicAdd(&dreal[o], dre);
+        atomicAdd(&dimag[o], dim_);
+      } else {
+        atomicAdd(&dlogamp[o], dla);
+        atomicAdd(&dreal[o], dre);
+        atomicAdd(&dimag[o], dim_);
+      }
+    }
+  }
+}
+int launch_istft64_bwd(int B, int F, const float* audio, const float* daudio, const float* logamp, const float* real,
+                       const float* imag, const float* bbr, const float* bbi, float* dlogamp, float* dreal,
+                       float* dimag, hipStream_t st) {
+  const size_t n = (size_t)B * 32 * F * sizeof(float);
+  STY_HIP(hipMemsetAsync(dlogamp, 0, n, st));
+  STY_HIP(hipMemsetAsync(dreal, 0, n, st));
+  STY_HIP(hipMemsetAsync(dimag, 0, n, st));
+  hipLaunchKernelGGL(istft64_bwd_kernel, dim3(cdiv(F + 1, 128), B), dim3(256), 0, st, audio, daudio, logamp, real, imag,
+                     bbr, bbi, F, dlogamp, dreal, dimag);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

@@ -20,97 +20,11 @@ namespace sty {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// ---- prologue applied while the input tile is staged (one instantiation per mode keeps the code small: the
-//      first version branched on the mode per element inside fully unrolled loops and produced 95-180 KB
-//      kernels that thrashed the instruction cache) ----
-template <int PRO>
-__device__ __forceinline__ float pro_apply(float v, float pa, float ps, float alpha, float ralpha, float mk) {
-  if constexpr (PRO == PRO_AFFINE || PRO == PRO_SCALE) return v * pa + ps;
-  if constexpr (PRO == PRO_AFFINE_SNAKE) return sty_snake(v * pa + ps, alpha, ralpha);
-  if constexpr (PRO == PRO_AFFINE_LRELU) {
-    const float z = v * pa + ps;
-    return z > 0.f ? z : 0.2f * z;
-  }
-  if constexpr (PRO == PRO_MASK) return v * mk;
-  if constexpr (PRO == PRO_LRELU) return v > 0.f ? v : 0.2f * v;
-  return v;
-}
+}  // namespace sty
 
-// Stage CI_CHUNK x LW input samples of channels [ci0, ci0+32) into LDS with the prologue applied.  Each wave owns
-// rows wave, wave+NW, ...; two rows x MAXJ column chunks are loaded into registers first so that 2*MAXJ global
-// loads are in flight per lane before any dependent math / LDS store.  Zero padding is applied AFTER the prologue.
-template <int PRO, int NW, int MAXJ>
-__device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
-                                            int LW, int wave, int lane) {
-  const int T = a.Tin ? a.Tin : a.T, Cin = a.w.Cin;
-  for (int c = wave; c < CI_CHUNK; c += 2 * NW) {
-    const float* src[2];
-    float pa[2], ps[2], alpha[2], ralpha[2];
-    bool live[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int ci = ci0 + c + NW * u;
-      live[u] = ci < Cin;
-      pa[u] = 1.f;
-      ps[u] = 0.f;
-      alpha[u] = ralpha[u] = 1.f;
-      src[u] = a.x[0];
-      if (live[u] && a.H) {  // 2-D mode: reduction index = (kh, ci)
-        const int kh = ci / a.Cin2d, cc = ci - kh * a.Cin2d;
-        const int hin = h + kh - a.hpad;
-        live[u] = hin >= 0 && hin < a.Hin;
-        src[u] = a.x[0] + (((size_t)b * a.Cin2d + cc) * a.Hin + (live[u] ? hin : 0)) * T;
-      } else if (live[u]) {
-        int cl = ci, csz;
-        const float* sp;
-        if (cl < a.xc[0]) {
-          sp = a.x[0];
-          csz = a.xc[0];
-        } else if (cl < a.xc[0] + a.xc[1]) {
-          sp = a.x[1];
-          cl -= a.xc[0];
-          csz = a.xc[1];
-        } else {
-          sp = a.x[2];
-          cl -= a.xc[0] + a.xc[1];
-          csz = a.xc[2];
-        }
-        src[u] = sp + ((size_t)b * csz + cl) * T;
-        if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
-          pa[u] = a.pa[(size_t)b * Cin + ci];
-          if constexpr (PRO != PRO_SCALE) ps[u] = a.ps[(size_t)b * Cin + ci];
-        }
-        if constexpr (PRO == PRO_AFFINE_SNAKE) {
-          alpha[u] = a.palpha[ci];
-          ralpha[u] = 1.0f / alpha[u];
-        }
-      }
-    }
-    float vv[2][MAXJ], mk[MAXJ];
-#pragma unroll
-    for (int q = 0; q < MAXJ; ++q) {
-      const int j = lane + 64 * q;
-      const int t = t0 - a.pad + j;
-      const bool in = j < LW && t >= 0 && t < T;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) vv[u][q] = (in && live[u]) ? src[u][t] : 0.f;
-      mk[q] = 1.f;
-      if constexpr (PRO == PRO_MASK) mk[q] = in ? a.mask[(size_t)b * T + t] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float* row = xs + (c + NW * u) * LW;
-#pragma unroll
-      for (int q = 0; q < MAXJ; ++q) {
-        const int j = lane + 64 * q;
-        const int t = t0 - a.pad + j;
-        float v = 0.f;
-        if (live[u] && t >= 0 && t < T) v = pro_apply<PRO>(vv[u][q], pa[u], ps[u], alpha[u], ralpha[u], mk[q]);
-        if (j < LW) row[j] = v;
-      }
-    }
-  }
-}
+#include "conv_stage.h"
+
+namespace sty {
 
 template <int ACT>
 __device__ __forceinline__ float act_apply(float x, float alpha) {

@@ -49,7 +49,7 @@ struct Bump {
   }
 };
 
-enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A, PK_CONV2D_SN, PK_DW2D_SN };
+enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A, PK_CONV2D_SN, PK_DW2D_SN, PK_DGRAD };
 int launch_pack_conv2d_sn(const float* w, const float* u, const float* v, const float* bias, int Cout, int Cin, int KH,
                           int KW, float* wp, float* bp, int CinP, int CoutP, float* tscratch, hipStream_t st);
 int launch_pack_dw2d_sn(const float* w, const float* u, const float* v, int C, float* w9, float* tscratch,
@@ -137,6 +137,7 @@ struct DecoderPlan {
   const float *f0_g, *f0_v, *f0_b, *n_g, *n_v, *n_b, *v_g, *v_v, *v_b;
 };
 
+struct Trainer;
 struct StyleResBlk {  // mel_style_encoder.py:69-118
   int Cin = 0, Cout = 0;
   bool down = false, has_sc = false;
@@ -174,4 +175,68 @@ struct sty_model {
   sty::DecoderPlan dec;
   sty::StylePlan sty_enc;
   float* stft_default = nullptr;  // device [4][33][64]
+  // ---- training ----
+  bool train_enabled = false;
+  char* garena = nullptr;  // gradients of the prepared (packed) weights, same layout/offsets as `arena`
+  std::unordered_map<const float*, float*> pgrad;               // bound parameter -> caller's gradient buffer
+  std::unordered_map<std::string, float*> pgrad_by_key;
+  std::unordered_map<const float*, sty::PackedConv> dgrad;      // forward packed weights -> input-gradient weights
+  std::unordered_map<const float*, sty::PackedConv> plain_of;   // GLU-ordered packed conv -> plain-ordered copy
+  void* fcs_bwd_dev = nullptr;
+  struct sty::Trainer* trainer = nullptr;
 };
+
+// ---- backward launchers (bwd.hip, wgrad.hip) and training-mode state ----
+#include <functional>
+#include <unordered_set>
+namespace sty {
+int launch_pro_bwd(int mode, const float* u, int Cu, int cu0, const float* x, int B, int C, int T, const float* pa,
+                   const float* ps, int pC, int pc0, const float* alpha, const float* mask, float* dx, int accumulate,
+                   float* dpa, float* dps, float* dalpha, hipStream_t st);
+int launch_adain_fold_bwd(const float* da, const float* ds, const float* mean, const float* rstd, const float* gb, int B,
+                          int C, int T, float* dgb, float* c0, float* c1, hipStream_t st);
+int launch_row_axpb(const float* x, const float* c0, const float* c1, int rows, int T, float* dx, hipStream_t st);
+int launch_adain_stats(const double* part, int nseg, int rows, int T, float eps, float* mean, float* rstd,
+                       hipStream_t st);
+int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,
+                       const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
+                       float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st);
+int launch_grn_bwd(const double* part, int nseg, const float* gamma, const float* ds, int B, int C4, float* coef,
+                   float* dgamma, hipStream_t st);
+int launch_act_fwd(int kind, const float* x, const float* alpha, int B, int C, int T, float* y, hipStream_t st);
+int launch_act_bwd(int kind, const float* x, const float* dy, const float* alpha, int B, int C, int T, float* dx,
+                   int accumulate, float* dalpha, hipStream_t st);
+int launch_row_scale_add(const float* src, const float* coef, float k, int rows, int T, float* dst, hipStream_t st);
+int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad, float* y,
+                      hipStream_t st);
+int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
+                      int accumulate, float* dw, float* db, hipStream_t st);
+int launch_bn_eval_fwd(const float* x, const float* w, const float* b, const float* rm, const float* rv, float eps,
+                       int B, int C, int T, float* y, hipStream_t st);
+int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const float* rm, const float* rv, float eps,
+                       int B, int C, int T, float* dx, float* dw, float* db, hipStream_t st);
+int launch_bias_grad(const float* g, const float* mask, int B, int C, int T, int shuffle, float scale, float* db,
+                     hipStream_t st);
+int launch_style_fc_bwd(const void* descs_dev, int nlayers, int B, int style_dim, const float* style,
+                        const float* dgb_base, float* dstyle, hipStream_t st);
+int launch_istft64_bwd(int B, int F, const float* audio, const float* daudio, const float* logamp, const float* real,
+                       const float* imag, const float* bbr, const float* bbi, float* dlogamp, float* dreal,
+                       float* dimag, hipStream_t st);
+size_t wgrad_partial_floats(const PackedConv& w, int B, int T);
+int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask, float scale, float* gwp,
+                        float* partial, hipStream_t st);
+int launch_pack_dgrad(const float* wp, int K, int CinP, int CoutP, float* wd, hipStream_t st);
+int launch_b2eff_bwd(const float* g, const float* w2, const float* beta, int C, float* db2, float* dbeta, float* dW2,
+                     hipStream_t st);
+int launch_unpack_grad(const float* gwp, const float* g, const float* v, int Cout, int Cin, int K, int CinP, int CoutP,
+                       int glu, float* dW, float* dg, float* dv, hipStream_t st);
+int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* dK, float* dV, size_t dqbs, size_t dkbs,
+                         size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st);
+size_t attention_bwd_ws_floats(int B, int H, int T);
+struct Trainer;
+Trainer* trainer_create(sty_model* m);
+void trainer_destroy(Trainer* t);
+int trainer_vocoder_forward(Trainer* t, const sty_vocoder_io* io, void* ws, size_t ws_bytes, hipStream_t st,
+                            size_t* need);
+int trainer_vocoder_backward(Trainer* t, const float* d_audio, float* d_mel, float* d_style, hipStream_t st);
+}  // namespace sty

@@ -74,6 +74,7 @@ struct ConvArgs {
   // 2-D mode (Conv2d on [B,C,H,W] as one 1-D conv per output row): the packed reduction "channel" index is
   // (kh, ci) with ci fastest, input row = h + kh - hpad; grid z = B * H.  Single source only.
   int H = 0, Hin = 0, hpad = 0, Cin2d = 0;
+  int in_shuffle = 0;     // > 1: source 0 is stored pixel-shuffled [B][C/s][T*s] (backward of a shuffled store)
   PackedConv w;
   int pro = PRO_NONE;
   const float* pa = nullptr;     // [B][Cin] scale
@@ -118,6 +119,14 @@ struct StyleFcDesc {
 };
 int launch_style_fc(const StyleFcDesc* descs_dev, int nlayers, int B, int style_dim, const float* style,
                     float* gb_base, hipStream_t st);
+struct StyleFcBwdDesc {
+  const float* W;
+  float* dW;
+  float* db;
+  size_t off;
+  int n;
+  int pad;
+};
 // per-row (b,c) partial sums over time: part[row][nseg][2] doubles; nseg = row_stats_nseg(T)
 int row_stats_nseg(int T);
 int launch_row_stats(const float* x, int rows, int T, double* part, hipStream_t st);

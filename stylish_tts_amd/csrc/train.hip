@@ -1,0 +1,585 @@
+// Training-mode graph of the vocoder (MultiGenerator, generator.py:884-901 / 710-799) with a tape of backward steps.
+//
+// The forward here is the UNFUSED-epilogue form of the inference plan in api.hip: convs keep their fused input
+// prologues (AdaIN+Snake, GRN scale, ...) but activations / LayerNorms that the backward needs the inputs of are
+// separate ops, nothing is computed in place, and no workspace is recycled, so that every backward step finds its
+// operands.  Each forward op pushes one closure; backward runs them in reverse.  Gradient buffers are zero-filled
+// when first requested and every backward kernel accumulates, which makes fan-out (residual streams) trivial.
+// Eval-mode semantics (BatchNorm running statistics, no dropout), matching the golden gradients of the oracle.
+#include <string.h>
+
+#include <unordered_map>
+
+#include "model.h"
+
+namespace sty {
+
+struct Trainer {
+  sty_model* m = nullptr;
+  hipStream_t st = nullptr;
+  int B = 0, T = 0;
+  Bump ws;
+  int rc = STY_OK;
+  float* gb = nullptr;   // fc(style) outputs of every AdaIN/AdaLN layer
+  float* dgb = nullptr;  // their gradients
+  const float* style = nullptr;
+  float* audio = nullptr;
+  std::vector<std::function<void()>> tape;
+  std::unordered_map<const float*, float*> gmap;
+  std::unordered_set<const float*> nograd;
+  float* scratch_param = nullptr;  // sink for gradients of parameters nobody bound a gradient for
+  size_t scratch_param_n = 0;
+  const float* mel_in = nullptr;
+  size_t peak = 0;
+
+  bool dry = false;  // sizing pass: fake base pointer, allocations are tracked but nothing is launched
+  bool live() const { return !dry && ws.base != nullptr && rc == STY_OK; }
+  void chk(int r) {
+    if (rc == STY_OK && r != STY_OK) rc = r;
+  }
+  const float* gbp(const AdaFc& a) const { return gb ? gb + a.off * B : nullptr; }
+  float* dgbp(const AdaFc& a) const { return dgb ? dgb + a.off * B : nullptr; }
+
+  template <typename Tp>
+  Tp* take(size_t n) {
+    Tp* p = ws.take<Tp>(n);
+    peak = ws.off > peak ? ws.off : peak;
+    return p;
+  }
+  // gradient buffer of an activation (zero-filled on first request)
+  float* G(const float* act, size_t n) {
+    auto it = gmap.find(act);
+    if (it != gmap.end()) return it->second;
+    float* g = take<float>(n);
+    if (live()) {
+      hipError_t e = hipMemsetAsync(g, 0, n * sizeof(float), st);
+      if (e != hipSuccess) rc = hip_fail(e, "grad memset");
+    }
+    gmap[act] = g;
+    return g;
+  }
+  bool wants(const float* act) const { return !nograd.count(act); }
+  // parameter gradient pointer: packed (inside the grad arena) or bound by the caller
+  float* PGpacked(const float* packed) const {
+    if (!packed || !m->garena) return nullptr;
+    return reinterpret_cast<float*>(m->garena + (reinterpret_cast<const char*>(packed) - m->arena));
+  }
+  float* PG(const float* param, size_t n) {
+    auto it = m->pgrad.find(param);
+    if (it != m->pgrad.end()) return it->second;
+    if (n > scratch_param_n) return nullptr;
+    return scratch_param;
+  }
+
+  ConvArgs base(const PackedConv& w, const float* x, int Tt, float* y) {
+    ConvArgs a;
+    a.x[0] = x;
+    a.xc[0] = w.Cin;
+    a.nsrc = 1;
+    a.B = B;
+    a.T = Tt;
+    a.w = w;
+    a.pad = (w.K - 1) / 2;
+    a.y = y;
+    return a;
+  }
+
+  // ---------------- ops ----------------
+  void conv(const ConvArgs& a) {
+    if (live()) chk(launch_conv1d(a, st));
+    ConvArgs f = a;
+    tape.push_back([this, f]() { conv_bwd(f); });
+  }
+  void conv_bwd(const ConvArgs& f) {
+    const PackedConv& w = f.w;
+    const int Tt = f.T;
+    const size_t ny = (size_t)B * w.Cout * Tt;
+    // resolve every persistent gradient buffer BEFORE the temporaries (which are released at the end)
+    float* gY = G(f.y, ny);
+    float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
+    float* gX[3] = {nullptr, nullptr, nullptr};
+    bool any = false;
+    for (int i = 0; i < f.nsrc; ++i)
+      if (wants(f.x[i])) {
+        gX[i] = G(f.x[i], (size_t)B * f.xc[i] * Tt);
+        any = true;
+      }
+    float* dpa = nullptr;
+    float* dps = nullptr;
+    float* dal = nullptr;
+    if (any) {
+      if (f.pro == PRO_AFFINE_SNAKE || f.pro == PRO_AFFINE_LRELU || f.pro == PRO_AFFINE) {
+        dpa = G(f.pa, (size_t)B * w.Cin);
+        dps = G(f.ps, (size_t)B * w.Cin);
+      } else if (f.pro == PRO_SCALE) {
+        dpa = G(f.pa, (size_t)B * w.Cin);
+      }
+      if (f.pro == PRO_AFFINE_SNAKE) dal = PG(f.palpha, w.Cin);
+    }
+    const size_t mark = ws.off;
+    if (gR && live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, B * w.Cout, Tt, gR, st));
+    if (w.bias && live()) chk(launch_bias_grad(gY, nullptr, B, w.Cout, Tt, f.shuffle, f.out_scale, PGpacked(w.bias), st));
+    float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
+    if (live()) chk(launch_conv1d_wgrad(f, gY, nullptr, f.out_scale, PGpacked(w.wp), partial, st));
+    if (any) {
+      auto it = m->dgrad.find(w.wp);
+      if (it == m->dgrad.end()) {
+        set_error("training: no input-gradient weights for a conv (model not finalized for training?)");
+        rc = STY_ESTATE;
+        return;
+      }
+      float* U = take<float>((size_t)B * w.Cin * Tt);
+      ConvArgs d;
+      d.x[0] = gY;
+      d.xc[0] = w.Cout;
+      d.nsrc = 1;
+      d.B = B;
+      d.T = Tt;
+      d.w = it->second;
+      d.dil = f.dil;
+      d.pad = (w.K - 1) * f.dil - f.pad;
+      d.out_scale = f.out_scale;
+      d.in_shuffle = f.shuffle > 1 ? f.shuffle : 0;
+      d.y = U;
+      if (live()) chk(launch_conv1d(d, st));
+      int c0 = 0;
+      for (int i = 0; i < f.nsrc; ++i) {
+        if (gX[i] && live())
+          chk(launch_pro_bwd(f.pro, U, w.Cin, c0, f.x[i], B, f.xc[i], Tt, f.pa, f.ps, w.Cin, c0, f.palpha, f.mask, gX[i],
+                             1, dpa, dps, dal, st));
+        c0 += f.xc[i];
+      }
+    }
+    ws.off = mark;
+  }
+
+  // pointwise activation y = act(x)
+  float* act(int kind, const float* x, const float* alpha, int C, int Tt) {
+    float* y = take<float>((size_t)B * C * Tt);
+    if (live()) chk(launch_act_fwd(kind, x, alpha, B, C, Tt, y, st));
+    tape.push_back([=]() {
+      const int Cin = kind == ACT_GLU ? 2 * C : C;
+      float* gY = G(y, (size_t)B * C * Tt);
+      float* gX = G(x, (size_t)B * Cin * Tt);
+      float* dal = kind == ACT_SNAKE ? PG(alpha, C) : nullptr;
+      if (live()) chk(launch_act_bwd(kind, x, gY, alpha, B, C, Tt, gX, 1, dal, st));
+    });
+    return y;
+  }
+
+  // LayerNorm over channels; ada: (1+gamma, beta) from fc(style) [fc], else affine (w, bvec)
+  float* layernorm(const float* x, int C, int Tt, float eps, const AdaFc* fc, const float* w, const float* bvec) {
+    float* y = take<float>((size_t)B * C * Tt);
+    const float* gbl = fc ? gbp(*fc) : nullptr;
+    float* dgl = fc ? dgbp(*fc) : nullptr;
+    if (live()) chk(launch_chan_layernorm(x, y, B, C, Tt, eps, fc ? 1 : 0, w, bvec, gbl, 0, nullptr, st));
+    tape.push_back([=]() {
+      float* gY = G(y, (size_t)B * C * Tt);
+      float* gX = G(x, (size_t)B * C * Tt);
+      const size_t mark = ws.off;
+      float* mu = take<float>((size_t)B * Tt);
+      float* r = take<float>((size_t)B * Tt);
+      float* dw = fc ? nullptr : PG(w, C);
+      float* db = fc ? nullptr : PG(bvec, C);
+      if (live())
+        chk(launch_chan_ln_bwd(x, gY, nullptr, B, C, Tt, eps, fc ? 1 : 0, w, gbl, 0, nullptr, gX, 1, mu, r, dgl, dw, db,
+                               st));
+      ws.off = mark;
+    });
+    return y;
+  }
+
+  // AdaIN folded to a per-(b,c) affine (a, s) consumed by the next conv's prologue
+  void adain(const float* x, int C, int Tt, const AdaFc& fc, float*& a, float*& s) {
+    a = take<float>((size_t)B * C);
+    s = take<float>((size_t)B * C);
+    float* mean = take<float>((size_t)B * C);
+    float* rstd = take<float>((size_t)B * C);
+    const int nseg = row_stats_nseg(Tt);
+    double* part = take<double>((size_t)B * C * nseg * 2);
+    if (live()) {
+      chk(launch_row_stats(x, B * C, Tt, part, st));
+      chk(launch_adain_finalize(part, nseg, gbp(fc), B, C, Tt, 1e-5f, a, s, st));
+      chk(launch_adain_stats(part, nseg, B * C, Tt, 1e-5f, mean, rstd, st));
+    }
+    const float* gbl = gbp(fc);
+    float* dgl = dgbp(fc);
+    float* aa = a;
+    float* ss = s;
+    tape.push_back([=]() {
+      float* da = G(aa, (size_t)B * C);
+      float* ds = G(ss, (size_t)B * C);
+      float* gX = G(x, (size_t)B * C * Tt);
+      const size_t mark = ws.off;
+      float* c0 = take<float>((size_t)B * C);
+      float* c1 = take<float>((size_t)B * C);
+      if (live()) {
+        chk(launch_adain_fold_bwd(da, ds, mean, rstd, gbl, B, C, Tt, dgl, c0, c1, st));
+        chk(launch_row_axpb(x, c0, c1, B * C, Tt, gX, st));
+      }
+      ws.off = mark;
+    });
+  }
+
+  float* dwconv(const float* x, const float* w, const float* bias, int C, int Tt, int K, int pad) {
+    float* y = take<float>((size_t)B * C * Tt);
+    if (live()) chk(launch_dwconv_fwd(x, w, bias, B, C, Tt, K, pad, y, st));
+    tape.push_back([=]() {
+      float* gY = G(y, (size_t)B * C * Tt);
+      float* gX = wants(x) ? G(x, (size_t)B * C * Tt) : nullptr;
+      if (live()) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, 1, PG(w, (size_t)C * K), PG(bias, C), st));
+    });
+    return y;
+  }
+
+  // GeneratorConvNeXtBlock (conv_next.py:80-93), any channel count
+  float* convnext(const ConvNeXt& c, const float* x, int Tt) {
+    const int C = c.C;
+    float* u = dwconv(x, c.dw_w, c.dw_b, C, Tt, 7, 3);
+    float* xn = layernorm(u, C, Tt, 1e-6f, &c.norm, nullptr, nullptr);
+    float* h0 = take<float>((size_t)B * 4 * C * Tt);
+    conv(base(c.pw1, xn, Tt, h0));
+    float* h = act(ACT_SNAKE, h0, c.alpha, 4 * C, Tt);
+    // GRN scale
+    const int nseg = row_stats_nseg(Tt);
+    double* part = take<double>((size_t)B * 4 * C * nseg * 2);
+    float* scale = take<float>((size_t)B * 4 * C);
+    if (live()) {
+      chk(launch_row_stats(h, B * 4 * C, Tt, part, st));
+      chk(launch_grn_finalize(part, nseg, c.grn_gamma, B, 4 * C, scale, st));
+    }
+    const float* gamma = c.grn_gamma;
+    tape.push_back([=]() {
+      float* dsc = G(scale, (size_t)B * 4 * C);
+      float* gH = G(h, (size_t)B * 4 * C * Tt);
+      const size_t mark = ws.off;
+      float* coef = take<float>((size_t)B * 4 * C);
+      if (live()) {
+        chk(launch_grn_bwd(part, nseg, gamma, dsc, B, 4 * C, coef, PG(gamma, 4 * C), st));
+        chk(launch_row_scale_add(h, coef, 0.f, B * 4 * C, Tt, gH, st));
+      }
+      ws.off = mark;
+    });
+    float* y = take<float>((size_t)B * C * Tt);
+    ConvArgs b2 = base(c.pw2, h, Tt, y);
+    b2.pro = PRO_SCALE;
+    b2.pa = scale;
+    b2.residual = x;
+    conv(b2);
+    return y;
+  }
+
+  // AdaptiveGeneratorBlock (ada_norm.py:109-120)
+  float* resblock(const ResBlock32& r, float* x, int Tt) {
+    const int dil[3] = {1, 3, 5};
+    for (int i = 0; i < 3; ++i) {
+      float *a, *s;
+      adain(x, 32, Tt, r.n1[i], a, s);
+      float* xt = take<float>((size_t)B * 32 * Tt);
+      ConvArgs c1 = base(r.c1[i], x, Tt, xt);
+      c1.dil = dil[i];
+      c1.pad = 5 * dil[i];
+      c1.pro = PRO_AFFINE_SNAKE;
+      c1.pa = a;
+      c1.ps = s;
+      c1.palpha = r.a1[i];
+      conv(c1);
+      adain(xt, 32, Tt, r.n2[i], a, s);
+      float* xn = take<float>((size_t)B * 32 * Tt);
+      ConvArgs c2 = base(r.c2[i], xt, Tt, xn);
+      c2.pro = PRO_AFFINE_SNAKE;
+      c2.pa = a;
+      c2.ps = s;
+      c2.palpha = r.a2[i];
+      c2.residual = x;
+      conv(c2);
+      x = xn;
+    }
+    return x;
+  }
+
+  float* attention(const float* q, const float* kv, int inner, int Tt) {
+    float* o = take<float>((size_t)B * inner * Tt);
+    AttnArgs at;
+    at.q = q;
+    at.k = kv;
+    at.v = kv + (size_t)inner * Tt;
+    at.o = o;
+    at.qbs = (size_t)inner * Tt;
+    at.kbs = at.vbs = (size_t)2 * inner * Tt;
+    at.obs = (size_t)inner * Tt;
+    at.T = Tt;
+    at.H = 8;
+    at.scale = 1.0f / sqrtf((float)(inner / 8));
+    at.lengths = nullptr;
+    if (live()) chk(launch_attention(at, B, inner / 8, st));
+    tape.push_back([=]() {
+      float* gO = G(o, (size_t)B * inner * Tt);
+      float* gQ = G(q, (size_t)B * inner * Tt);
+      float* gKV = G(kv, (size_t)B * 2 * inner * Tt);
+      const size_t mark = ws.off;
+      float* w2 = take<float>(attention_bwd_ws_floats(B, 8, Tt));
+      if (live())
+        chk(launch_attention_bwd(at, gO, gQ, gKV, gKV + (size_t)inner * Tt, at.qbs, at.kbs, at.vbs, at.obs, B, inner / 8,
+                                 w2, st));
+      ws.off = mark;
+    });
+    return o;
+  }
+
+  float* conformer(const Conformer& c, const float* x, int C, int Tt) {
+    auto ff = [&](const AdaFc& nrm, const PackedConv& w0, const PackedConv& w3, const float* in) {
+      float* z = layernorm(in, C, Tt, 1e-5f, &nrm, nullptr, nullptr);
+      float* h0 = take<float>((size_t)B * 4 * C * Tt);
+      conv(base(w0, z, Tt, h0));
+      float* h = act(ACT_SWISH, h0, nullptr, 4 * C, Tt);
+      float* out = take<float>((size_t)B * C * Tt);
+      ConvArgs b2 = base(w3, h, Tt, out);
+      b2.out_scale = 0.5f;
+      b2.residual = in;
+      conv(b2);
+      return out;
+    };
+    float* xff1 = ff(c.ff1n, c.ff1a, c.ff1b, x);
+    float* z = layernorm(x, C, Tt, 1e-5f, &c.attn_n, nullptr, nullptr);
+    const int inner = c.to_q.Cout;
+    float* q = take<float>((size_t)B * inner * Tt);
+    float* kv = take<float>((size_t)B * 2 * inner * Tt);
+    conv(base(c.to_q, z, Tt, q));
+    conv(base(c.to_kv, z, Tt, kv));
+    float* o = attention(q, kv, inner, Tt);
+    float* x2 = take<float>((size_t)B * C * Tt);
+    ConvArgs ao = base(c.to_out, o, Tt, x2);
+    ao.residual = xff1;
+    conv(ao);
+    float* z2 = layernorm(x2, C, Tt, 1e-5f, &c.conv_n, nullptr, nullptr);
+    auto pit = m->plain_of.find(c.pw1.wp);
+    if (pit == m->plain_of.end()) {
+      set_error("training: GLU conv has no plain-packed copy");
+      rc = STY_ESTATE;
+      return nullptr;
+    }
+    float* g0 = take<float>((size_t)B * 4 * C * Tt);
+    conv(base(pit->second, z2, Tt, g0));
+    float* g = act(ACT_GLU, g0, nullptr, 2 * C, Tt);
+    float* d0 = dwconv(g, c.dw_w, c.dw_b, 2 * C, Tt, 31, 15);
+    float* d1 = take<float>((size_t)B * 2 * C * Tt);
+    if (live()) chk(launch_bn_eval_fwd(d0, c.bn_w, c.bn_b, c.bn_rm, c.bn_rv, 1e-5f, B, 2 * C, Tt, d1, st));
+    {
+      const float *bw = c.bn_w, *bb = c.bn_b, *rm = c.bn_rm, *rv = c.bn_rv;
+      tape.push_back([=]() {
+        float* gY = G(d1, (size_t)B * 2 * C * Tt);
+        float* gX = G(d0, (size_t)B * 2 * C * Tt);
+        const size_t mark = ws.off;
+        float* tmp = take<float>((size_t)B * 2 * C * Tt);
+        if (live()) {
+          chk(launch_bn_eval_bwd(d0, gY, bw, rm, rv, 1e-5f, B, 2 * C, Tt, tmp, PG(bw, 2 * C), PG(bb, 2 * C), st));
+          chk(launch_row_scale_add(tmp, nullptr, 1.0f, B * 2 * C, Tt, gX, st));
+        }
+        ws.off = mark;
+      });
+    }
+    float* d = act(ACT_SWISH, d1, nullptr, 2 * C, Tt);
+    float* x3 = take<float>((size_t)B * C * Tt);
+    ConvArgs p2 = base(c.pw2, d, Tt, x3);
+    p2.residual = x2;
+    conv(p2);
+    float* x4 = ff(c.ff2n, c.ff2a, c.ff2b, x3);
+    return layernorm(x4, C, Tt, 1e-5f, &c.post_n, nullptr, nullptr);
+  }
+
+  void forward(const sty_vocoder_io& io) {
+    const VocoderPlan& v = m->voc;
+    T = io.T;
+    const int Tt = io.T, Tu = 75 * Tt, N = 300 * Tt, C = v.hidden;
+    style = io.style;
+    mel_in = io.mel;
+    tape.clear();
+    gmap.clear();
+    nograd.clear();
+    scratch_param_n = 1 << 20;
+    scratch_param = take<float>(scratch_param_n);
+    gb = take<float>(m->gb_floats_per_batch * B);
+    dgb = take<float>(m->gb_floats_per_batch * B);
+    if (live()) {
+      if (!m->fcs.empty()) chk(launch_style_fc(m->fcs_dev, (int)m->fcs.size(), B, m->style_dim, style, gb, st));
+      hipError_t e = hipMemsetAsync(dgb, 0, m->gb_floats_per_batch * B * sizeof(float), st);
+      if (e != hipSuccess) rc = hip_fail(e, "dgb memset");
+      if (m->garena) {
+        e = hipMemsetAsync(m->garena, 0, m->arena_bytes, st);
+        if (e != hipSuccess) rc = hip_fail(e, "grad arena memset");
+      }
+    }
+    // harmonic source branch: no gradient (torch.no_grad in the reference, generator.py:711-729)
+    float* prior = take<float>((size_t)B * N);
+    float* srcws = take<float>(source_workspace_floats(B, Tt));
+    float* hs = take<float>((size_t)B * 32 * Tu);
+    float* hp = take<float>((size_t)B * 32 * Tu);
+    const float* prior_used = io.prior_override ? io.prior_override : prior;
+    if (live()) {
+      if (!io.prior_override)
+        chk(launch_source(B, Tt, io.pitch, io.voiced, io.noise, io.seed, v.lin_w, v.lin_b, prior, srcws, st));
+      chk(launch_stft64(B, N, prior_used, v.stft_fr, v.stft_fi, hs, hp, st));
+    }
+    nograd.insert(hs);
+    nograd.insert(hp);
+    float* lap0 = take<float>((size_t)B * 32 * Tu);
+    float* pp0 = take<float>((size_t)B * 32 * Tu);
+    conv(base(v.amp_prior_conv, hs, Tu, lap0));
+    conv(base(v.phase_prior_conv, hp, Tu, pp0));
+    float* lap = resblock(v.amp_prior_block, lap0, Tu);
+    float* pp = resblock(v.phase_prior_block, pp0, Tu);
+    // stage A
+    float* x0 = take<float>((size_t)B * C * Tt);
+    conv(base(v.amp_input_conv, io.mel, Tt, x0));
+    float* x1 = layernorm(x0, C, Tt, 1e-6f, nullptr, v.amp_norm_w, v.amp_norm_b);
+    float* x = conformer(v.conf, x1, C, Tt);
+    if (!x) return;
+    for (const ConvNeXt& c : v.amp_convnext) x = convnext(c, x, Tt);
+    int Tc = Tt, Cc = C;
+    const int rates[3] = {3, 5, 5};
+    for (int i = 0; i < 3; ++i) {
+      const int s = rates[i];
+      float* nx = take<float>((size_t)B * (Cc / 2) * Tc * s);
+      ConvArgs a = base(v.upconv[i], x, Tc, nx);
+      a.shuffle = s;
+      conv(a);
+      Tc *= s;
+      Cc /= 2;
+      x = convnext(v.upblock[i], nx, Tc);
+    }
+    float* trunk = x;
+    float* lnA = layernorm(trunk, 32, Tu, 1e-6f, nullptr, v.amp_fln_w, v.amp_fln_b);
+    float* logamp = take<float>((size_t)B * 32 * Tu);
+    conv(base(v.amp_output_conv, lnA, Tu, logamp));
+    float* ph0 = take<float>((size_t)B * 32 * Tu);
+    ConvArgs p = base(v.phase_input_conv, trunk, Tu, ph0);
+    p.nsrc = 3;
+    p.x[1] = lap;
+    p.x[2] = pp;
+    p.xc[0] = p.xc[1] = p.xc[2] = 32;
+    conv(p);
+    float* ph = layernorm(ph0, 32, Tu, 1e-6f, nullptr, v.phase_norm_w, v.phase_norm_b);
+    for (const ConvNeXt& c : v.phase_convnext) ph = convnext(c, ph, Tu);
+    float* lnP = layernorm(ph, 32, Tu, 1e-6f, nullptr, v.phase_fln_w, v.phase_fln_b);
+    float* real = take<float>((size_t)B * 32 * Tu);
+    float* imag = take<float>((size_t)B * 32 * Tu);
+    conv(base(v.real_conv, lnP, Tu, real));
+    conv(base(v.imag_conv, lnP, Tu, imag));
+    audio = io.audio;
+    if (live()) chk(launch_istft64(B, Tu, logamp, real, imag, v.stft_br, v.stft_bi, io.audio, st));
+    const float *bbr = v.stft_br, *bbi = v.stft_bi;
+    float* au = io.audio;
+    tape.push_back([=]() {
+      float* gA = G(au, (size_t)B * 4 * Tu);
+      float* gl = G(logamp, (size_t)B * 32 * Tu);
+      float* gr = G(real, (size_t)B * 32 * Tu);
+      float* gi = G(imag, (size_t)B * 32 * Tu);
+      const size_t mark = ws.off;
+      float* t1 = take<float>((size_t)B * 32 * Tu);
+      float* t2 = take<float>((size_t)B * 32 * Tu);
+      float* t3 = take<float>((size_t)B * 32 * Tu);
+      if (live()) {
+        chk(launch_istft64_bwd(B, Tu, au, gA, logamp, real, imag, bbr, bbi, t1, t2, t3, st));
+        chk(launch_row_scale_add(t1, nullptr, 1.0f, B * 32, Tu, gl, st));
+        chk(launch_row_scale_add(t2, nullptr, 1.0f, B * 32, Tu, gr, st));
+        chk(launch_row_scale_add(t3, nullptr, 1.0f, B * 32, Tu, gi, st));
+      }
+      ws.off = mark;
+    });
+  }
+
+  void backward(const float* d_audio, float* d_mel, float* d_style) {
+    // seed: gradient of the audio
+    const size_t na = (size_t)B * 300 * T;
+    float* gA = G(audio, na);
+    if (live() && d_audio) {
+      hipError_t e = hipMemcpyAsync(gA, d_audio, na * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "seed copy");
+    }
+    if (!d_mel) nograd.insert(mel_in);
+    for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
+      (*it)();
+      if (rc != STY_OK) return;
+    }
+    // fc(style) backward for every AdaIN / AdaLN layer
+    if (live() && !m->fcs.empty()) {
+      if (d_style) {
+        hipError_t e = hipMemsetAsync(d_style, 0, (size_t)B * m->style_dim * sizeof(float), st);
+        if (e != hipSuccess) rc = hip_fail(e, "d_style memset");
+      }
+      std::vector<StyleFcBwdDesc> hb(m->fcs.size());
+      for (size_t i = 0; i < m->fcs.size(); ++i) {
+        hb[i].W = m->fcs[i].W;
+        hb[i].dW = PG(m->fcs[i].W, (size_t)m->fcs[i].n * m->style_dim);
+        hb[i].db = PG(m->fcs[i].b, m->fcs[i].n);
+        hb[i].off = m->fcs[i].off;
+        hb[i].n = m->fcs[i].n;
+        hb[i].pad = 0;
+      }
+      if (!m->fcs_bwd_dev) {
+        hipError_t e = hipMalloc((void**)&m->fcs_bwd_dev, hb.size() * sizeof(StyleFcBwdDesc));
+        if (e != hipSuccess) rc = hip_fail(e, "fc bwd table");
+      }
+      if (rc == STY_OK) {
+        hipError_t e = hipMemcpyAsync(m->fcs_bwd_dev, hb.data(), hb.size() * sizeof(StyleFcBwdDesc),
+                                      hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) rc = hip_fail(e, "fc bwd table copy");
+        // the host vector must outlive the async copy
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = hip_fail(e, "sync");
+        chk(launch_style_fc_bwd(m->fcs_bwd_dev, (int)hb.size(), B, m->style_dim, style, dgb, d_style, st));
+      }
+    }
+    if (live() && d_mel) {
+      float* gm = G(mel_in, (size_t)B * m->voc.amp_input_conv.Cin * T);
+      hipError_t e = hipMemcpyAsync(d_mel, gm, (size_t)B * m->voc.amp_input_conv.Cin * T * sizeof(float),
+                                    hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "d_mel copy");
+    }
+  }
+};
+
+Trainer* trainer_create(sty_model* m) {
+  Trainer* t = new Trainer();
+  t->m = m;
+  return t;
+}
+void trainer_destroy(Trainer* t) { delete t; }
+
+int trainer_vocoder_forward(Trainer* t, const sty_vocoder_io* io, void* ws, size_t ws_bytes, hipStream_t st,
+                            size_t* need) {
+  t->st = st;
+  t->B = io->B;
+  t->rc = STY_OK;
+  t->ws = Bump();
+  t->dry = need != nullptr;
+  t->ws.base = need ? reinterpret_cast<char*>(size_t(1) << 30) : (char*)ws;  // dry: fake base, never dereferenced
+  t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
+  t->peak = 0;
+  t->forward(*io);
+  if (need) {
+    // dry run: also run the backward allocations to size the workspace
+    t->backward(nullptr, reinterpret_cast<float*>(1), nullptr);
+    *need = align_up(t->peak, 256) + (64 << 20);
+    t->tape.clear();
+    return t->rc;
+  }
+  if (t->ws.overflow) {
+    set_error("training workspace too small: need %zu bytes, have %zu", t->peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_vocoder_backward(Trainer* t, const float* d_audio, float* d_mel, float* d_style, hipStream_t st) {
+  t->st = st;
+  t->backward(d_audio, d_mel, d_style);
+  if (t->ws.overflow) {
+    set_error("training workspace too small in backward: need %zu bytes", t->peak);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+}  // namespace sty

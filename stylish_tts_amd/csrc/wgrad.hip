@@ -1,0 +1,289 @@
+// Weight gradient of the dense conv, input-gradient weight packing, and gradient un-packing.
+//
+//   dW[co][ci][k] = sum_{b,t} G[b][co][t] * prologue(x)[b][ci][t - pad + k*dil]
+// as a GEMM on the fp32 matrix cores: M = 32 output channels, N = 32 input channels (one tile pair per workgroup
+// column), reduction over (batch, time).  Both operands are staged in LDS with lanes along the CHANNEL index, so
+// rows get an odd stride (bank-conflict-free column reads); the G fragments of a 128-sample chunk are held in
+// registers (64 VGPRs) and reused for every tap.  The four waves of a workgroup split the taps (k mod 4), or the
+// time chunk when K == 1.  Each workgroup walks its share of the (b, chunk) list keeping the accumulators in
+// registers and writes ONE partial result; a second kernel sums the partials in a fixed order (deterministic, no
+// float atomics) into the packed gradient.
+#include "conv_stage.h"
+
+namespace sty {
+
+constexpr int WG_TW = 128;  // time samples per chunk
+
+template <int KT>  // taps per wave (K <= 4*KT), KT == 0: K == 1, waves split the chunk in time
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
+                                                           float* __restrict__ partial) {
+  // ax: the forward conv's input side (sources, prologue, pad, dil, weight dims); ag: the output-gradient side
+  //     (x[0] = G, optional mask / in_shuffle), K = 1, pad = 0.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int K = ax.w.K, dil = ax.dil;
+  const int halo = (K - 1) * dil;
+  const int LWx = (WG_TW + halo) | 1, LWg = WG_TW + 1;  // odd row strides
+  float* xs = lds;
+  float* gs = lds + CI_CHUNK * LWx;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, split = blockIdx.z;
+  constexpr int NACC = KT == 0 ? 1 : KT;
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const int total = ax.B * chunks_per_b;
+  constexpr int MAXJ = (WG_TW + 128 + 1 + 63) / 64;
+  for (int ch = split; ch < total; ch += nsplit) {
+    const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
+    __syncthreads();
+    switch (ax.pro) {
+      case PRO_AFFINE: stage_chunk<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+      case PRO_SCALE: stage_chunk<PRO_SCALE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+      case PRO_MASK: stage_chunk<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+      case PRO_LRELU: stage_chunk<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+      default: stage_chunk<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+    }
+    if (ag.pro == PRO_MASK)
+      stage_chunk<PRO_MASK, 4, MAXJ>(ag, gs, co0, b, 0, t0, LWg, wave, lane);
+    else
+      stage_chunk<PRO_NONE, 4, MAXJ>(ag, gs, co0, b, 0, t0, LWg, wave, lane);
+    __syncthreads();
+    if constexpr (KT == 0) {
+      // K == 1: each wave reduces its quarter of the chunk
+      const int q0 = wave * (WG_TW / 8);
+#pragma unroll
+      for (int q = 0; q < WG_TW / 8; ++q) {
+        const float av = gs[l31 * LWg + 2 * (q0 + q) + hi];
+        const float bv = xs[l31 * LWx + 2 * (q0 + q) + hi];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
+      }
+    } else {
+      float af[WG_TW / 2];
+#pragma unroll
+      for (int q = 0; q < WG_TW / 2; ++q) af[q] = gs[l31 * LWg + 2 * q + hi];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int k = wave + 4 * kt;
+        if (k < K) {
+          const float* xr = xs + l31 * LWx + hi + k * dil;
+#pragma unroll
+          for (int q = 0; q < WG_TW / 2; ++q)
+            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[kt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial layout: [slice][k][ci (CinP)][co (CoutP)], slice = split (K > 1) or split*4 + wave (K == 1)
+  const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;
+  const size_t plane = (size_t)K * CinP * CoutP;
+  if constexpr (KT == 0) {
+    float* p = partial + ((size_t)split * 4 + wave) * plane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      p[(size_t)(ci0 + l31) * CoutP + co] = acc[0][r];
+    }
+  } else {
+    float* p = partial + (size_t)split * plane;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int k = wave + 4 * kt;
+      if (k < K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          p[((size_t)k * CinP + ci0 + l31) * CoutP + co] = acc[kt][r];
+        }
+      }
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nslices, size_t plane, float scale,
+                                    float* __restrict__ gwp) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= plane) return;
+  float s = 0.f;
+  for (int k = 0; k < nslices; ++k) s += partial[(size_t)k * plane + i];
+  gwp[i] += s * scale;
+}
+
+size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {
+  const int tiles = (w.CinP / 32) * (w.CoutP / 32);
+  const int chunks = B * cdiv(T, WG_TW);
+  int nsplit = 512 / tiles;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > chunks) nsplit = chunks;
+  const int slices = w.K == 1 ? nsplit * 4 : nsplit;
+  return (size_t)slices * w.K * w.CinP * w.CoutP;
+}
+
+// ax: forward ConvArgs (sources, prologue, dil, pad, w); g: output gradient [B][Cout][T] (shuffled when ax.shuffle > 1);
+// gmask: optional [B][T] multiplier of g; scale: constant factor (the forward out_scale); gwp += result.
+int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask, float scale, float* gwp,
+                        float* partial, hipStream_t st) {
+  if (fwd.H) {
+    set_error("wgrad: 2-D mode not built");
+    return STY_EINVAL;
+  }
+  const PackedConv& w = fwd.w;
+  ConvArgs ax = fwd;
+  ax.pad = fwd.pad;  // staging start t0 - pad
+  ConvArgs ag;
+  ag.x[0] = g;
+  ag.xc[0] = w.Cout;
+  ag.nsrc = 1;
+  ag.B = fwd.B;
+  ag.T = fwd.T;
+  ag.pad = 0;
+  ag.w.Cin = w.Cout;
+  ag.w.CinP = w.CoutP;
+  ag.w.K = 1;
+  ag.in_shuffle = fwd.shuffle > 1 ? fwd.shuffle : 0;
+  ag.pro = gmask ? PRO_MASK : PRO_NONE;
+  ag.mask = gmask;
+  const int tiles = (w.CinP / 32) * (w.CoutP / 32);
+  const int chunks_per_b = cdiv(fwd.T, WG_TW);
+  const int chunks = fwd.B * chunks_per_b;
+  int nsplit = 512 / tiles;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > chunks) nsplit = chunks;
+  const int halo = (w.K - 1) * fwd.dil;
+  if (halo > 128) {
+    set_error("wgrad: halo %d > 128", halo);
+    return STY_EINVAL;
+  }
+  const size_t lds = ((size_t)CI_CHUNK * ((WG_TW + halo) | 1) + (size_t)CI_CHUNK * (WG_TW + 1)) * sizeof(float);
+  dim3 grid(w.CinP / 32, w.CoutP / 32, nsplit);
+  const double flops = 2.0 * w.Cin * w.K * (double)fwd.B * w.Cout * fwd.T;
+  const double bytes = 4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T);
+  ProfScope prof("conv1d_wgrad", flops, bytes, st);
+  const int KT = w.K == 1 ? 0 : cdiv(w.K, 4);
+#define STY_WG(KTV)                                                                                              \
+  hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, partial)
+  switch (KT) {
+    case 0: STY_WG(0); break;
+    case 1: STY_WG(1); break;
+    case 2: STY_WG(2); break;
+    case 3: STY_WG(3); break;
+    case 6: STY_WG(6); break;
+    default:
+      if (KT <= 6) {
+        STY_WG(6);
+      } else {
+        set_error("wgrad: kernel size %d not built", w.K);
+        return STY_EINVAL;
+      }
+  }
+#undef STY_WG
+  const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
+  const int slices = w.K == 1 ? nsplit * 4 : nsplit;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, partial, slices,
+                     plane, scale, gwp);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- input-gradient weights: Wd[k'][co][ci] = Wp[K-1-k'][ci][co] ----
+__global__ void pack_dgrad_kernel(const float* __restrict__ wp, int K, int CinP, int CoutP, float* __restrict__ wd) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)K * CinP * CoutP;
+  if (i >= n) return;
+  const int ci = (int)(i % CinP);
+  const int co = (int)((i / CinP) % CoutP);
+  const int kd = (int)(i / ((size_t)CinP * CoutP));
+  wd[i] = wp[((size_t)(K - 1 - kd) * CinP + ci) * CoutP + co];
+}
+int launch_pack_dgrad(const float* wp, int K, int CinP, int CoutP, float* wd, hipStream_t st) {
+  const size_t n = (size_t)K * CinP * CoutP;
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wp, K, CinP, CoutP, wd);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- packed gradient -> parameter gradients (+=); one workgroup per output channel ----
+//   plain:        dW[co][ci][k] += gwp[k][ci][cp]
+//   weight_norm:  w = g v/|v|:  dg[co] += <gw, v>/|v|,  dv += g/|v| (gw - v <gw, v>/|v|^2)
+//   glu != 0: packed output order (value/gate 32-blocks), as in pack_conv_kernel
+__global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restrict__ gwp, const float* __restrict__ gv,
+                                                          const float* __restrict__ vv, int Cout, int Cin, int K,
+                                                          int CinP, int CoutP, int glu, float* __restrict__ dW,
+                                                          float* __restrict__ dg, float* __restrict__ dv) {
+  __shared__ float r1[256], r2[256];
+  const int co = blockIdx.x;
+  const int n = Cin * K;
+  int cp = co;
+  if (glu) {
+    const int Ch = Cout / 2;
+    const int half = co >= Ch, c = half ? co - Ch : co;
+    cp = (c >> 5) * 64 + half * 32 + (c & 31);
+  }
+  if (!vv) {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int ci = i / K, k = i % K;
+      dW[(size_t)co * n + i] += gwp[((size_t)k * CinP + ci) * CoutP + cp];
+    }
+    return;
+  }
+  float dot = 0.f, nn = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / K, k = i % K;
+    const float v = vv[(size_t)co * n + i];
+    dot = fmaf(gwp[((size_t)k * CinP + ci) * CoutP + cp], v, dot);
+    nn = fmaf(v, v, nn);
+  }
+  r1[threadIdx.x] = dot;
+  r2[threadIdx.x] = nn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      r1[threadIdx.x] += r1[threadIdx.x + o];
+      r2[threadIdx.x] += r2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const float norm = sqrtf(r2[0]), d = r1[0], gg = gv[co];
+  if (threadIdx.x == 0) dg[co] += d / norm;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / K, k = i % K;
+    const float v = vv[(size_t)co * n + i];
+    dv[(size_t)co * n + i] += gg / norm * (gwp[((size_t)k * CinP + ci) * CoutP + cp] - v * d / (norm * norm));
+  }
+}
+int launch_unpack_grad(const float* gwp, const float* g, const float* v, int Cout, int Cin, int K, int CinP, int CoutP,
+                       int glu, float* dW, float* dg, float* dv, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_grad_kernel, dim3(Cout), dim3(256), 0, st, gwp, g, v, Cout, Cin, K, CinP, CoutP, glu, dW,
+                     dg, dv);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ConvNeXt pwconv2 bias folding b2eff = b2 + W2 . beta (convnext.hip): g = d loss / d b2eff [C]
+__global__ void b2eff_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w2,
+                                 const float* __restrict__ beta, int C, float* __restrict__ db2,
+                                 float* __restrict__ dbeta, float* __restrict__ dW2) {
+  const int C4 = 4 * C;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C && db2) db2[i] += g[i];
+  if (i < C4 && dbeta) {
+    float acc = 0.f;
+    for (int co = 0; co < C; ++co) acc = fmaf(w2[(size_t)co * C4 + i], g[co], acc);
+    dbeta[i] += acc;
+  }
+  if (i < C * C4 && dW2) {
+    const int co = i / C4, ch = i % C4;
+    dW2[i] += g[co] * beta[ch];
+  }
+}
+int launch_b2eff_bwd(const float* g, const float* w2, const float* beta, int C, float* db2, float* dbeta, float* dW2,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(b2eff_bwd_kernel, dim3(cdiv(4 * C * C, 256)), dim3(256), 0, st, g, w2, beta, C, db2, dbeta, dW2);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

@@ -56,6 +56,11 @@ SYMBOLS = {
     "sty_istft64_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P]),
     "sty_source_fwd": (C.c_int, [_I, _I, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_source_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
+    "sty_model_enable_training": (C.c_int, [_P]),
+    "sty_model_bind_grad": (C.c_int, [_P, C.c_char_p, _P]),
+    "sty_vocoder_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
+    "sty_vocoder_fwd_train": (C.c_int, [_P, C.POINTER(VocoderIO), _P, C.c_size_t, _P]),
+    "sty_vocoder_bwd": (C.c_int, [_P, _P, _P, _P, _P]),
     "sty_prof_enable": (C.c_int, [_I]),
     "sty_prof_report": (C.c_int, [_P, _I]),
 }

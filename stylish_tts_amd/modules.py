@@ -96,15 +96,28 @@ class _HipModule(torch.nn.Module):
             h = C.c_void_p()
             L.check(lib.sty_model_create(self.KIND.encode(), C.byref(h)))
             self._handle = h
-        if self._bound != ptrs:
+        gptrs = {}
+        if getattr(self, "_train", False):
+            for k, p in self.named_parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                gptrs[k] = p.grad.data_ptr()
+        if self._bound != (ptrs, gptrs):
             for k, v in sd.items():
                 if k not in ptrs:
                     continue
                 shp = (C.c_int64 * v.dim())(*v.shape)
                 L.check(lib.sty_model_bind(self._handle, k.encode(), C.c_void_p(ptrs[k]), v.dim(), shp))
+            for k, g in gptrs.items():
+                L.check(lib.sty_model_bind_grad(self._handle, k.encode(), C.c_void_p(g)))
             L.check(lib.sty_model_finalize(self._handle))
-            self._bound = ptrs
+            self._bound = (ptrs, gptrs)
         return lib
+
+    def enable_training(self):
+        """Gradients of every parameter are accumulated into `param.grad` by the *_backward calls (K15)."""
+        self._train = True
+        return self
 
     def requested_keys(self):
         lib = L.load()
@@ -234,6 +247,47 @@ class SpeechPredictor(_HipModule):
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         L.check(lib.sty_vocoder_fwd(self._handle, C.byref(io), C.c_void_p(ws.data_ptr()), ws.numel(), st))
         return DecoderPrediction(audio=audio, magnitude=None, phase=None)
+
+
+    # ---- training (vocoder first): forward in the training graph, then backward from d loss / d audio ----
+    def vocoder_forward_train(self, *, mel, style, pitch, voiced, noise=None, seed=0, prior_override=None):
+        dev = style.device
+        self._train = True
+        lib = self._ensure(dev)
+        B, _, T = mel.shape
+        io = L.VocoderIO()
+        io.B, io.T = B, T
+        keep = []
+        for name, t in (("mel", mel), ("style", style), ("pitch", pitch), ("voiced", voiced), ("noise", noise),
+                        ("prior_override", prior_override)):
+            if t is not None:
+                t = _f32(t.detach(), dev)
+                keep.append(t)
+                setattr(io, name, t.data_ptr())
+        io.seed = int(seed)
+        audio = torch.empty(B, 1, 300 * T, dtype=torch.float32, device=dev)
+        io.audio = audio.data_ptr()
+        need = C.c_size_t()
+        L.check(lib.sty_vocoder_train_workspace_bytes(self._handle, B, T, C.byref(need)))
+        self._train_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self._train_keep = keep
+        self._train_shape = (B, T)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_vocoder_fwd_train(self._handle, C.byref(io), C.c_void_p(self._train_ws.data_ptr()),
+                                          self._train_ws.numel(), st))
+        return audio
+
+    def vocoder_backward(self, d_audio, want_mel=True, want_style=True):
+        """d loss / d audio [B,1,300T] -> (d_mel [B,128,T], d_style [B,64]); parameter grads go to param.grad."""
+        lib = L.load()
+        dev = d_audio.device
+        B, T = self._train_shape
+        d_audio = _f32(d_audio, dev)
+        d_mel = torch.zeros(B, self.cfg["gen_input_dim"], T, device=dev) if want_mel else None
+        d_style = torch.zeros(B, self.cfg["style_dim"], device=dev) if want_style else None
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_vocoder_bwd(self._handle, L.ptr(d_audio), L.ptr(d_mel), L.ptr(d_style), st))
+        return d_mel, d_style
 
 
 class MultiGenerator(SpeechPredictor):

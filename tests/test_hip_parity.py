@@ -417,3 +417,61 @@ def test_acoustic_step_forward(env):
     rep.add("pred_spec[1]", out.pred_spec[1], r_mag, 1e-3)
     rep.done()
     assert mse <= 1e-7 and _mel_l1(out.pred.audio.cpu(), ref) <= 1e-3
+
+
+def test_vocoder_backward(env):
+    """K15 (vocoder): gradients of mean|audio| w.r.t. mel, style and parameters vs the oracle's autograd."""
+    import stylish_tts_amd as S
+    from oracle import vocoder as ov
+    cs, want = env["cs"], env["want"]
+    P = {k: v.clone() for k, v in env["P"].items()}
+    m = S.SpeechPredictor()
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).enable_training()
+    mel = want["decoder_out"].clone()
+    audio = m.vocoder_forward_train(mel=dev(mel), style=dev(cs["style"]), pitch=dev(cs["pitch"]), voiced=dev(env["voiced"]),
+                                    noise=dev(cs["noise"]), prior_override=dev(want["prior"]))
+    torch.cuda.synchronize()
+    ref_fwd = env["ref_audio"]
+    mse = ((audio.cpu() - ref_fwd) ** 2).mean().item()
+    print(f"\n  training-graph forward: max|err| {(audio.cpu() - ref_fwd).abs().max().item():.3e} mse {mse:.3e}")
+    assert mse <= 1e-8
+    d_audio = torch.sign(audio) / audio.numel()
+    d_mel, d_style = m.vocoder_backward(d_audio)
+    torch.cuda.synchronize()
+    # oracle gradients
+    keys = [
+        "generator.basegen.phase_output_real_conv.weight", "generator.basegen.phase_output_real_conv.bias",
+        "generator.basegen.phase_final_layer_norm.weight",
+        "generator.basegen.phase_convnext.7.pwconv2.weight", "generator.basegen.phase_convnext.7.pwconv2.bias",
+        "generator.basegen.phase_convnext.7.grn.gamma", "generator.basegen.phase_convnext.7.grn.beta",
+        "generator.basegen.phase_convnext.7.snake", "generator.basegen.phase_convnext.7.pwconv1.weight",
+        "generator.basegen.phase_convnext.7.norm.fc.weight", "generator.basegen.phase_convnext.7.dwconv.weight",
+        "generator.basegen.phase_convnext.0.dwconv.bias", "generator.basegen.phase_input_conv.weight",
+        "generator.basegen.amp_output_conv.weight", "generator.basegen.amp_final_layer_norm.bias",
+        "generator.basegen.amp_prior_block.convs1.1.parametrizations.weight.original1",
+        "generator.basegen.amp_prior_block.convs1.1.parametrizations.weight.original0",
+        "generator.basegen.amp_prior_block.alpha1.1", "generator.basegen.amp_prior_block.adain2.2.fc.weight",
+        "generator.basegen.phase_prior_conv.weight",
+        "generator.basegen.upconvs.2.weight", "generator.basegen.upconvs.0.bias",
+        "generator.basegen.upblocks.1.pwconv1.weight", "generator.basegen.amp_convnext.3.pwconv2.weight",
+        "generator.amp_conformer.layers.0.attn.fn.to_q.weight", "generator.amp_conformer.layers.0.attn.fn.to_kv.weight",
+        "generator.amp_conformer.layers.0.attn.fn.to_out.bias", "generator.amp_conformer.layers.0.ff1.fn.fn.net.0.weight",
+        "generator.amp_conformer.layers.0.conv.net.1.weight", "generator.amp_conformer.layers.0.conv.net.3.conv.weight",
+        "generator.amp_conformer.layers.0.conv.net.4.weight", "generator.amp_conformer.layers.0.post_norm.fc.bias",
+        "generator.amp_norm.weight", "generator.amp_input_conv.weight",
+    ]
+    for k in keys:
+        P[k].requires_grad_(True)
+    mel_r = mel.clone().requires_grad_(True)
+    style_r = cs["style"].clone().requires_grad_(True)
+    ref = ov.multi_generator(P, "generator", mel_r, style_r, cs["pitch"], env["voiced"], cs["noise"], prior=want["prior"])
+    ref.abs().mean().backward()
+    rep = Report()
+    # conditioning: see tests/test_oracle_golden.py::test_backward_vs_reference (fp64 vs fp32 differ by ~1e-2 on row 1)
+    rep.add("d_mel", d_mel, mel_r.grad, 3e-2)
+    rep.add("d_style", d_style, style_r.grad, 3e-2)
+    named = dict(m.named_parameters())
+    for k in keys:
+        rep.add("d " + k.replace("generator.", "")[-44:], named[k].grad, P[k].grad, 3e-2)
+    rep.done()
