@@ -155,6 +155,11 @@ int sty_model_bind_grad(sty_model *m, const char *key, float *grad);
 int sty_vocoder_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
 int sty_vocoder_fwd_train(sty_model *m, const sty_vocoder_io *io, void *workspace, size_t ws_bytes, void *stream);
 int sty_vocoder_bwd(sty_model *m, const float *d_audio, float *d_mel, float *d_style, void *stream);
+/* Same for SpeechPredictor.forward (text encoder -> alignment expand -> decoder -> vocoder): gradients of every
+ * parameter of the predictor, plus d loss / d style [B,64] and d loss / d energy [B,T] (each optional).      */
+int sty_speech_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);
+int sty_speech_fwd_train(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
+int sty_speech_bwd(sty_model *m, const float *d_audio, float *d_style, float *d_energy, void *stream);
 
 /* ---- in-situ kernel timing (used by bench.py for the roofline object) --------------------------------
  * When enabled, every launch of the instrumented kernel families is bracketed by HIP events on the launch

@@ -1290,7 +1290,58 @@ static int unpack_grads(sty_model* m, hipStream_t st) {
       if (r) return r;
     }
   }
+  if (m->kind == "speech_predictor" && m->dec.fnv_w) {
+    const DecoderPlan& d = m->dec;
+    int r = launch_fnv_unpack(GA(d.fnv_w), d.f0_g, d.f0_v, d.n_g, d.n_v, d.v_g, d.v_v, PG(d.f0_g), PG(d.f0_v),
+                              PG(d.f0_b), PG(d.n_g), PG(d.n_v), PG(d.n_b), PG(d.v_g), PG(d.v_v), PG(d.v_b), st);
+    if (r) return r;
+  }
   return STY_OK;
+}
+
+int sty_speech_train_workspace_bytes(sty_model* m, int B, int L, int T, size_t* bytes) {
+  int rc = model_ready(m, "speech_predictor");
+  if (rc) return rc;
+  if (!m->train_enabled || !bytes || B <= 0 || L <= 0 || T <= 1) {
+    set_error("sty_speech_train_workspace_bytes: bad argument or training not enabled");
+    return STY_EINVAL;
+  }
+  if (!m->trainer) m->trainer = trainer_create(m);
+  sty_speech_io io;
+  memset(&io, 0, sizeof(io));
+  io.B = B;
+  io.L = L;
+  io.T = T;
+  return trainer_speech_forward(m->trainer, &io, nullptr, 0, nullptr, bytes);
+}
+
+int sty_speech_fwd_train(sty_model* m, const sty_speech_io* io, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "speech_predictor");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  if (!io || !workspace || !io->texts || !io->text_lengths || !io->alignment || !io->pitch || !io->energy ||
+      !io->voiced || !io->style || !io->denormal_pitch || !io->audio || io->B <= 0 || io->L <= 0 || io->T <= 1) {
+    set_error("sty_speech_fwd_train: bad argument");
+    return STY_EINVAL;
+  }
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_speech_forward(m->trainer, io, workspace, ws_bytes, S(stream), nullptr);
+}
+
+int sty_speech_bwd(sty_model* m, const float* d_audio, float* d_style, float* d_energy, void* stream) {
+  int rc = model_ready(m, "speech_predictor");
+  if (rc) return rc;
+  if (!m->trainer || !d_audio) {
+    set_error("sty_speech_bwd: no forward recorded or null gradient");
+    return STY_ESTATE;
+  }
+  rc = trainer_speech_backward(m->trainer, d_audio, d_style, d_energy, S(stream));
+  if (rc) return rc;
+  return unpack_grads(m, S(stream));
 }
 
 int sty_vocoder_train_workspace_bytes(sty_model* m, int B, int T, size_t* bytes) {

@@ -121,7 +121,7 @@ int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st) {
 
 // partial RoPE in place on q and k [B][H*DH][L]: first `d` dims of every head (text_encoder.py:146-168)
 __global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, int H, int DH, int L, int d, float t0,
-                            float t1, float t2, float t3) {
+                            float t1, float t2, float t3, float sgn) {
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   if (pos >= L) return;
@@ -135,18 +135,33 @@ __global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, int H,
     for (int i = 0; i < d; ++i) {
       const float ang = (float)pos * theta[i % half];
       const float rot = i < half ? -x[i + half] : x[i - half];
-      base[(size_t)i * L] = x[i] * cosf(ang) + rot * sinf(ang);
+      base[(size_t)i * L] = x[i] * cosf(ang) + rot * (sgn * sinf(ang));
     }
   }
 }
 
-int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st) {
+// sgn = +1: forward rotation; sgn = -1: its transpose (= the backward of the forward rotation)
+int launch_rope_signed(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, float sgn,
+                       hipStream_t st) {
   if (d != 8) {
     set_error("rope: only d == 8 built");
     return STY_EINVAL;
   }
   hipLaunchKernelGGL(rope_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d, theta4[0], theta4[1],
-                     theta4[2], theta4[3]);
+                     theta4[2], theta4[3], sgn);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st) {
+  return launch_rope_signed(q, k, B, H, DH, L, d, theta4, 1.0f, st);
+}
+int launch_rope_unused(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st) {
+  if (d != 8) {
+    set_error("rope: only d == 8 built");
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d, theta4[0], theta4[1],
+                     theta4[2], theta4[3], 1.0f);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

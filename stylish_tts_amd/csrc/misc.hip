@@ -174,6 +174,123 @@ int launch_alignment(const float* dur, int B, int L, int T, float* ali, hipStrea
   return STY_OK;
 }
 
+// ---- backward of the glue ops ----
+// embedding: demb[tok][c] += scale * g[b][c][l]
+__global__ void embedding_bwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ g, int L, int H,
+                                     int ntok, float scale, float* __restrict__ demb) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (l >= L) return;
+  int64_t t = tok[(size_t)b * L + l];
+  if (t < 0 || t >= ntok) t = 0;
+  atomicAdd(&demb[(size_t)t * H + c], g[((size_t)b * H + c) * L + l] * scale);
+}
+int launch_embedding_bwd(const int64_t* tokens, const float* g, int B, int L, int H, int ntok, float scale, float* demb,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, tokens, g, L, H, ntok, scale, demb);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// y = enc @ ali  ->  denc[b][c][l] += sum_t g[b][c][t] * ali[b][l][t]
+__global__ __launch_bounds__(64) void bmm_ct_bwd_kernel(const float* __restrict__ g, const float* __restrict__ ali, int C,
+                                                        int L, int T, float* __restrict__ denc) {
+  const int l = blockIdx.x, c = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  const float* gr = g + ((size_t)b * C + c) * T;
+  const float* ar = ali + ((size_t)b * L + l) * T;
+  float acc = 0.f;
+  for (int t = lane; t < T; t += 64) acc = fmaf(gr[t], ar[t], acc);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) denc[((size_t)b * C + c) * L + l] += acc;
+}
+int launch_bmm_ct_bwd(const float* g, const float* ali, int B, int C, int L, int T, float* denc, hipStream_t st) {
+  hipLaunchKernelGGL(bmm_ct_bwd_kernel, dim3(L, C, B), dim3(64), 0, st, g, ali, C, L, T, denc);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// dst[b][c][t] += src[b][c0 + c][t]   (backward of a channel concat)
+__global__ void slice_add_kernel(const float* __restrict__ src, int Csrc, int c0, int C, int T,
+                                 float* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  dst[((size_t)b * C + c) * T + t] += src[((size_t)b * Csrc + c0 + c) * T + t];
+}
+int launch_slice_add(const float* src, int Csrc, int c0, int B, int C, int T, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(slice_add_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, src, Csrc, c0, C, T, dst);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// fnv (three weight-normed 1->1 k3 convs): gradients of the inputs and of the effective weights w34 [3][4]
+__global__ __launch_bounds__(256) void fnv_bwd_kernel(const float* __restrict__ p, const float* __restrict__ e,
+                                                      const float* __restrict__ v, const float* __restrict__ w34,
+                                                      const float* __restrict__ g, int B, int T,
+                                                      float* __restrict__ dw34, float* __restrict__ dp,
+                                                      float* __restrict__ de, float* __restrict__ dv) {
+  __shared__ float red[4][256];
+  const int i = blockIdx.x;  // which conv
+  const float* src = i == 0 ? p : (i == 1 ? e : v);
+  float* dsrc = i == 0 ? dp : (i == 1 ? de : dv);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int idx = threadIdx.x; idx < B * T; idx += 256) {
+    const int b = idx / T, t = idx % T;
+    const float* gr = g + ((size_t)b * 3 + i) * T;
+    const float* xr = src + (size_t)b * T;
+    const float gy = gr[t];
+    acc[0] += gy * (t > 0 ? xr[t - 1] : 0.f);
+    acc[1] += gy * xr[t];
+    acc[2] += gy * (t < T - 1 ? xr[t + 1] : 0.f);
+    acc[3] += gy;
+    if (dsrc) {
+      // y[t'] = w0 x[t'-1] + w1 x[t'] + w2 x[t'+1]  ->  dx[t] = w0 g[t+1] + w1 g[t] + w2 g[t-1]
+      float d = w34[i * 4 + 1] * gy;
+      if (t + 1 < T) d += w34[i * 4 + 0] * gr[t + 1];
+      if (t > 0) d += w34[i * 4 + 2] * gr[t - 1];
+      dsrc[(size_t)b * T + t] += d;
+    }
+  }
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) dw34[i * 4 + threadIdx.x] += red[threadIdx.x][0];
+}
+int launch_fnv_bwd(const float* pitch, const float* energy, const float* voiced, const float* w34, const float* g, int B,
+                   int T, float* dw34, float* dp, float* de, float* dv, hipStream_t st) {
+  hipLaunchKernelGGL(fnv_bwd_kernel, dim3(3), dim3(256), 0, st, pitch, energy, voiced, w34, g, B, T, dw34, dp, de, dv);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// dw34 -> weight-norm parameters of the three convs: w = g v/|v|
+__global__ void fnv_unpack_kernel(const float* dw34, const float* g0, const float* v0, const float* g1, const float* v1,
+                                  const float* g2, const float* v2, float* dg0, float* dv0, float* db0, float* dg1,
+                                  float* dv1, float* db1, float* dg2, float* dv2, float* db2) {
+  const float* g[3] = {g0, g1, g2};
+  const float* v[3] = {v0, v1, v2};
+  float* dg[3] = {dg0, dg1, dg2};
+  float* dv[3] = {dv0, dv1, dv2};
+  float* db[3] = {db0, db1, db2};
+  const int i = threadIdx.x;
+  if (i >= 3) return;
+  const float n2 = v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2], n = sqrtf(n2);
+  float dot = 0.f;
+  for (int k = 0; k < 3; ++k) dot += dw34[i * 4 + k] * v[i][k];
+  if (dg[i]) dg[i][0] += dot / n;
+  if (dv[i])
+    for (int k = 0; k < 3; ++k) dv[i][k] += g[i][0] / n * (dw34[i * 4 + k] - v[i][k] * dot / n2);
+  if (db[i]) db[i][0] += dw34[i * 4 + 3];
+}
+int launch_fnv_unpack(const float* dw34, const float* g0, const float* v0, const float* g1, const float* v1,
+                      const float* g2, const float* v2, float* dg0, float* dv0, float* db0, float* dg1, float* dv1,
+                      float* db1, float* dg2, float* dv2, float* db2, hipStream_t st) {
+  hipLaunchKernelGGL(fnv_unpack_kernel, dim3(1), dim3(64), 0, st, dw34, g0, v0, g1, v1, g2, v2, dg0, dv0, db0, dg1, dv1,
+                     db1, dg2, dv2, db2);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // y += a * x
 __global__ void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

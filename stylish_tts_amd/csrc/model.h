@@ -233,8 +233,22 @@ int launch_unpack_grad(const float* gwp, const float* g, const float* v, int Cou
 int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* dK, float* dV, size_t dqbs, size_t dkbs,
                          size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st);
 size_t attention_bwd_ws_floats(int B, int H, int T);
+int launch_rope_signed(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, float sgn,
+                       hipStream_t st);
+int launch_embedding_bwd(const int64_t* tokens, const float* g, int B, int L, int H, int ntok, float scale, float* demb,
+                         hipStream_t st);
+int launch_bmm_ct_bwd(const float* g, const float* ali, int B, int C, int L, int T, float* denc, hipStream_t st);
+int launch_slice_add(const float* src, int Csrc, int c0, int B, int C, int T, float* dst, hipStream_t st);
+int launch_fnv_bwd(const float* pitch, const float* energy, const float* voiced, const float* w34, const float* g, int B,
+                   int T, float* dw34, float* dp, float* de, float* dv, hipStream_t st);
+int launch_fnv_unpack(const float* dw34, const float* g0, const float* v0, const float* g1, const float* v1,
+                      const float* g2, const float* v2, float* dg0, float* dv0, float* db0, float* dg1, float* dv1,
+                      float* db1, float* dg2, float* dv2, float* db2, hipStream_t st);
 struct Trainer;
 Trainer* trainer_create(sty_model* m);
+int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t ws_bytes, hipStream_t st,
+                           size_t* need);
+int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st);
 void trainer_destroy(Trainer* t);
 int trainer_vocoder_forward(Trainer* t, const sty_vocoder_io* io, void* ws, size_t ws_bytes, hipStream_t st,
                             size_t* need);

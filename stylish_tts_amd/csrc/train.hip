@@ -117,10 +117,18 @@ struct Trainer {
       if (f.pro == PRO_AFFINE_SNAKE) dal = PG(f.palpha, w.Cin);
     }
     const size_t mark = ws.off;
-    if (gR && live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, B * w.Cout, Tt, gR, st));
-    if (w.bias && live()) chk(launch_bias_grad(gY, nullptr, B, w.Cout, Tt, f.shuffle, f.out_scale, PGpacked(w.bias), st));
+    // y = ((acc + bias) * out_scale * mask_pre + residual) * mask_post: the conv core always sees gY * mask
+    const float* gmask = f.out_mask;
+    if (gR && live()) {
+      if (f.out_mask && f.out_mask_post)
+        chk(launch_pro_bwd(PRO_MASK, gY, w.Cout, 0, gY, B, w.Cout, Tt, nullptr, nullptr, w.Cout, 0, nullptr, f.out_mask,
+                           gR, 1, nullptr, nullptr, nullptr, st));
+      else
+        chk(launch_row_scale_add(gY, nullptr, 1.0f, B * w.Cout, Tt, gR, st));
+    }
+    if (w.bias && live()) chk(launch_bias_grad(gY, gmask, B, w.Cout, Tt, f.shuffle, f.out_scale, PGpacked(w.bias), st));
     float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
-    if (live()) chk(launch_conv1d_wgrad(f, gY, nullptr, f.out_scale, PGpacked(w.wp), partial, st));
+    if (live()) chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, st));
     if (any) {
       auto it = m->dgrad.find(w.wp);
       if (it == m->dgrad.end()) {
@@ -140,6 +148,10 @@ struct Trainer {
       d.pad = (w.K - 1) * f.dil - f.pad;
       d.out_scale = f.out_scale;
       d.in_shuffle = f.shuffle > 1 ? f.shuffle : 0;
+      if (gmask) {
+        d.pro = PRO_MASK;
+        d.mask = gmask;
+      }
       d.y = U;
       if (live()) chk(launch_conv1d(d, st));
       int c0 = 0;
@@ -168,11 +180,12 @@ struct Trainer {
   }
 
   // LayerNorm over channels; ada: (1+gamma, beta) from fc(style) [fc], else affine (w, bvec)
-  float* layernorm(const float* x, int C, int Tt, float eps, const AdaFc* fc, const float* w, const float* bvec) {
+  float* layernorm(const float* x, int C, int Tt, float eps, const AdaFc* fc, const float* w, const float* bvec,
+                   int relu = 0, const float* omask = nullptr) {
     float* y = take<float>((size_t)B * C * Tt);
     const float* gbl = fc ? gbp(*fc) : nullptr;
     float* dgl = fc ? dgbp(*fc) : nullptr;
-    if (live()) chk(launch_chan_layernorm(x, y, B, C, Tt, eps, fc ? 1 : 0, w, bvec, gbl, 0, nullptr, st));
+    if (live()) chk(launch_chan_layernorm(x, y, B, C, Tt, eps, fc ? 1 : 0, w, bvec, gbl, relu, omask, st));
     tape.push_back([=]() {
       float* gY = G(y, (size_t)B * C * Tt);
       float* gX = G(x, (size_t)B * C * Tt);
@@ -182,8 +195,7 @@ struct Trainer {
       float* dw = fc ? nullptr : PG(w, C);
       float* db = fc ? nullptr : PG(bvec, C);
       if (live())
-        chk(launch_chan_ln_bwd(x, gY, nullptr, B, C, Tt, eps, fc ? 1 : 0, w, gbl, 0, nullptr, gX, 1, mu, r, dgl, dw, db,
-                               st));
+        chk(launch_chan_ln_bwd(x, gY, y, B, C, Tt, eps, fc ? 1 : 0, w, gbl, relu, omask, gX, 1, mu, r, dgl, dw, db, st));
       ws.off = mark;
     });
     return y;
@@ -326,6 +338,240 @@ struct Trainer {
     });
     return o;
   }
+  // separate q / k / v tensors [B][H*DH][L] with an optional length mask (text encoder)
+  float* attention3(const float* q, const float* k, const float* v, int Hd, int L, const int64_t* lengths) {
+    const size_t n = (size_t)B * Hd * L;
+    float* o = take<float>(n);
+    AttnArgs at;
+    at.q = q;
+    at.k = k;
+    at.v = v;
+    at.o = o;
+    at.qbs = at.kbs = at.vbs = at.obs = (size_t)Hd * L;
+    at.T = L;
+    at.H = 8;
+    at.scale = 1.0f / sqrtf((float)(Hd / 8));
+    at.lengths = lengths;
+    if (live()) chk(launch_attention(at, B, Hd / 8, st));
+    tape.push_back([=]() {
+      float* gO = G(o, n);
+      float* gQ = G(q, n);
+      float* gK = G(k, n);
+      float* gV = G(v, n);
+      const size_t mark = ws.off;
+      float* w2 = take<float>(attention_bwd_ws_floats(B, 8, L));
+      if (live()) chk(launch_attention_bwd(at, gO, gQ, gK, gV, at.qbs, at.kbs, at.vbs, at.obs, B, Hd / 8, w2, st));
+      ws.off = mark;
+    });
+    return o;
+  }
+
+  // TextEncoder.forward (text_encoder.py:434-463), eval mode -> mu [B][inter][L]
+  float* text_encoder(const int64_t* tokens, const int64_t* lengths, int L) {
+    const TextEncPlan& t = m->te;
+    const int H = t.H;
+    const size_t n = (size_t)B * H * L;
+    float* mask = take<float>((size_t)B * L);
+    float* x0 = take<float>(n);
+    const float esc = sqrtf((float)H);
+    if (live()) {
+      chk(launch_length_mask(lengths, B, L, mask, st));
+      chk(launch_embedding(tokens, t.emb, B, L, H, t.tokens, esc, x0, st));
+    }
+    nograd.insert(mask);
+    {
+      const float* emb = t.emb;
+      const int ntok = t.tokens;
+      tape.push_back([=]() {
+        float* g = G(x0, n);
+        if (live()) chk(launch_embedding_bwd(tokens, g, B, L, H, ntok, esc, PG(emb, (size_t)ntok * H), st));
+      });
+    }
+    const float* h = x0;
+    for (int i = 0; i < 3; ++i) {
+      float* h1 = take<float>(n);
+      ConvArgs a = base(t.pre[i], h, L, h1);
+      a.pro = PRO_MASK;
+      a.mask = mask;
+      conv(a);
+      h = layernorm(h1, H, L, 1e-4f, nullptr, t.pre_g[i], t.pre_b[i], 1, nullptr);
+    }
+    float* x = take<float>(n);
+    ConvArgs pj = base(t.proj, h, L, x);
+    pj.residual = x0;
+    pj.out_mask = mask;
+    pj.out_mask_post = 1;
+    conv(pj);
+    for (const TextEncLayer& l : t.layers) {
+      float* q = take<float>(n);
+      float* k = take<float>(n);
+      float* v = take<float>(n);
+      ConvArgs aq = base(l.q, x, L, q);
+      aq.pro = PRO_MASK;
+      aq.mask = mask;
+      conv(aq);
+      aq.w = l.k;
+      aq.y = k;
+      conv(aq);
+      aq.w = l.v;
+      aq.y = v;
+      conv(aq);
+      // partial RoPE (out of place for the tape)
+      float* qr = take<float>(n);
+      float* kr = take<float>(n);
+      if (live()) {
+        hipError_t e = hipMemcpyAsync(qr, q, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(kr, k, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) rc = hip_fail(e, "rope copy");
+        chk(launch_rope(qr, kr, B, 8, H / 8, L, 8, t.theta, st));
+      }
+      {
+        const float* th = t.theta;
+        tape.push_back([=]() {
+          float* gqr = G(qr, n);
+          float* gkr = G(kr, n);
+          float* gq = G(q, n);
+          float* gk = G(k, n);
+          if (live()) {
+            // transpose rotation in place on the (dead afterwards) rotated-tensor gradients, then accumulate
+            chk(launch_rope_signed(gqr, gkr, B, 8, H / 8, L, 8, th, -1.0f, st));
+            chk(launch_row_scale_add(gqr, nullptr, 1.0f, B * H, L, gq, st));
+            chk(launch_row_scale_add(gkr, nullptr, 1.0f, B * H, L, gk, st));
+          }
+        });
+      }
+      float* o = attention3(qr, kr, v, H, L, lengths);
+      float* h1 = take<float>(n);
+      ConvArgs ao = base(l.o, o, L, h1);
+      ao.residual = x;
+      conv(ao);
+      float* x1 = layernorm(h1, H, L, 1e-4f, nullptr, l.n1g, l.n1b);
+      const int Fc = l.f1.Cout;
+      float* f0 = take<float>((size_t)B * Fc * L);
+      ConvArgs f1 = base(l.f1, x1, L, f0);
+      f1.pro = PRO_MASK;
+      f1.mask = mask;
+      conv(f1);
+      float* fr = act(ACT_RELU, f0, nullptr, Fc, L);
+      float* h2 = take<float>(n);
+      ConvArgs f2 = base(l.f2, fr, L, h2);
+      f2.pro = PRO_MASK;
+      f2.mask = mask;
+      f2.out_mask = mask;
+      f2.residual = x1;
+      conv(f2);
+      x = layernorm(h2, H, L, 1e-4f, nullptr, l.n2g, l.n2b, 0, mask);
+    }
+    float* mu = take<float>((size_t)B * t.proj_m.Cout * L);
+    ConvArgs pm = base(t.proj_m, x, L, mu);
+    pm.out_mask = mask;
+    pm.out_mask_post = 1;
+    conv(pm);
+    return mu;
+  }
+
+  float* concat(const float* const* src, const int* ch, int nsrc, int Tt) {
+    int Ctot = 0;
+    for (int i = 0; i < nsrc; ++i) Ctot += ch[i];
+    float* y = take<float>((size_t)B * Ctot * Tt);
+    if (live()) chk(launch_concat(src, ch, nsrc, B, Tt, y, st));
+    std::vector<const float*> sv(src, src + nsrc);
+    std::vector<int> cv(ch, ch + nsrc);
+    tape.push_back([=]() {
+      float* gY = G(y, (size_t)B * Ctot * Tt);
+      int c0 = 0;
+      for (int i = 0; i < nsrc; ++i) {
+        if (wants(sv[i])) {
+          float* gs = G(sv[i], (size_t)B * cv[i] * Tt);
+          if (live()) chk(launch_slice_add(gY, Ctot, c0, B, cv[i], Tt, gs, st));
+        }
+        c0 += cv[i];
+      }
+    });
+    return y;
+  }
+
+  // AdaptiveDecoderBlock (ada_norm.py:180-192)
+  float* dec_block(const DecBlock& d, const float* xcat, int Tt) {
+    const float r2 = 0.70710678118654752f;
+    if (!d.has_sc) {
+      set_error("decoder block without learned shortcut is not built");
+      rc = STY_EINVAL;
+      return nullptr;
+    }
+    float* sc = take<float>((size_t)B * d.Cout * Tt);
+    ConvArgs cs = base(d.sc, xcat, Tt, sc);
+    cs.out_scale = r2;
+    conv(cs);
+    float *a, *s;
+    adain(xcat, d.Cin, Tt, d.n1, a, s);
+    float* h = take<float>((size_t)B * d.Cout * Tt);
+    ConvArgs c1 = base(d.c1, xcat, Tt, h);
+    c1.pro = PRO_AFFINE_LRELU;
+    c1.pa = a;
+    c1.ps = s;
+    conv(c1);
+    adain(h, d.Cout, Tt, d.n2, a, s);
+    float* out = take<float>((size_t)B * d.Cout * Tt);
+    ConvArgs c2 = base(d.c2, h, Tt, out);
+    c2.pro = PRO_AFFINE_LRELU;
+    c2.pa = a;
+    c2.ps = s;
+    c2.out_scale = r2;
+    c2.residual = sc;
+    conv(c2);
+    return out;
+  }
+
+  const float *in_pitch = nullptr, *in_energy = nullptr, *in_voiced = nullptr;
+  // Decoder.forward, eval mode (decoder.py:77-90)
+  float* decoder(const float* asr, const float* pitch, const float* energy, const float* voiced, int Tt) {
+    const DecoderPlan& d = m->dec;
+    const int din = d.asr_res.Cin, dr = d.asr_res.Cout, dh = d.encode.Cout;
+    float* fnv = take<float>((size_t)B * 3 * Tt);
+    if (live()) chk(launch_fnv(pitch, energy, voiced, d.fnv_w, B, Tt, fnv, st));
+    in_pitch = pitch;
+    in_energy = energy;
+    in_voiced = voiced;
+    nograd.insert(pitch);
+    nograd.insert(voiced);
+    {
+      const float* w34 = d.fnv_w;
+      tape.push_back([=]() {
+        float* g = G(fnv, (size_t)B * 3 * Tt);
+        float* de = wants(energy) ? G(energy, (size_t)B * Tt) : nullptr;
+        if (live()) chk(launch_fnv_bwd(pitch, energy, voiced, w34, g, B, Tt, PGpacked(w34), nullptr, de, nullptr, st));
+      });
+    }
+    const float* s1[2] = {asr, fnv};
+    const int c1[2] = {din, 3};
+    float* cat = concat(s1, c1, 2, Tt);
+    float* x = dec_block(d.encode, cat, Tt);
+    if (!x) return nullptr;
+    float* res = take<float>((size_t)B * dr * Tt);
+    conv(base(d.asr_res, asr, Tt, res));
+    for (int i = 0; i < 4; ++i) {
+      const float* s2[3] = {x, res, fnv};
+      const int c2[3] = {dh, dr, 3};
+      float* cat2 = concat(s2, c2, 3, Tt);
+      x = dec_block(d.decode[i], cat2, Tt);
+      if (!x) return nullptr;
+    }
+    return x;
+  }
+
+  // text_encoding @ alignment (speech_predictor.py:60)
+  float* expand(const float* enc, const float* ali, int C, int L, int Tt) {
+    float* asr = take<float>((size_t)B * C * Tt);
+    if (live()) chk(launch_bmm_ct(enc, ali, B, C, L, Tt, asr, st));
+    nograd.insert(ali);
+    tape.push_back([=]() {
+      float* g = G(asr, (size_t)B * C * Tt);
+      float* ge = G(enc, (size_t)B * C * L);
+      if (live()) chk(launch_bmm_ct_bwd(g, ali, B, C, L, Tt, ge, st));
+    });
+    return asr;
+  }
 
   float* conformer(const Conformer& c, const float* x, int C, int Tt) {
     auto ff = [&](const AdaFc& nrm, const PackedConv& w0, const PackedConv& w3, const float* in) {
@@ -388,12 +634,8 @@ struct Trainer {
     return layernorm(x4, C, Tt, 1e-5f, &c.post_n, nullptr, nullptr);
   }
 
-  void forward(const sty_vocoder_io& io) {
-    const VocoderPlan& v = m->voc;
-    T = io.T;
-    const int Tt = io.T, Tu = 75 * Tt, N = 300 * Tt, C = v.hidden;
-    style = io.style;
-    mel_in = io.mel;
+  void begin(const float* style_in) {
+    style = style_in;
     tape.clear();
     gmap.clear();
     nograd.clear();
@@ -410,6 +652,14 @@ struct Trainer {
         if (e != hipSuccess) rc = hip_fail(e, "grad arena memset");
       }
     }
+  }
+
+  void forward(const sty_vocoder_io& io, bool fresh = true) {
+    const VocoderPlan& v = m->voc;
+    T = io.T;
+    const int Tt = io.T, Tu = 75 * Tt, N = 300 * Tt, C = v.hidden;
+    if (fresh) begin(io.style);
+    mel_in = io.mel;
     // harmonic source branch: no gradient (torch.no_grad in the reference, generator.py:711-729)
     float* prior = take<float>((size_t)B * N);
     float* srcws = take<float>(source_workspace_floats(B, Tt));
@@ -498,6 +748,7 @@ struct Trainer {
       if (e != hipSuccess) rc = hip_fail(e, "seed copy");
     }
     if (!d_mel) nograd.insert(mel_in);
+    if (d_mel == reinterpret_cast<float*>(2)) d_mel = nullptr;  // speech graph: mel is an internal activation
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
       (*it)();
       if (rc != STY_OK) return;
@@ -539,6 +790,64 @@ struct Trainer {
     }
   }
 };
+
+int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t ws_bytes, hipStream_t st,
+                           size_t* need) {
+  t->st = st;
+  t->B = io->B;
+  t->rc = STY_OK;
+  t->ws = Bump();
+  t->dry = need != nullptr;
+  t->ws.base = need ? reinterpret_cast<char*>(size_t(1) << 30) : (char*)ws;
+  t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
+  t->peak = 0;
+  t->begin(io->style);
+  const int inter = t->m->te.proj_m.Cout ? t->m->te.proj_m.Cout : 128;
+  float* mu = t->text_encoder(io->texts, io->text_lengths, io->L);
+  float* asr = t->expand(mu, io->alignment, inter, io->L, io->T);
+  float* mel = t->decoder(asr, io->pitch, io->energy, io->voiced, io->T);
+  if (mel) {
+    sty_vocoder_io v = io->voc_taps;
+    v.B = io->B;
+    v.T = io->T;
+    v.mel = mel;
+    v.style = io->style;
+    v.pitch = io->denormal_pitch;
+    v.voiced = io->voiced;
+    v.noise = io->noise;
+    v.prior_override = io->prior_override;
+    v.seed = io->seed;
+    v.audio = io->audio;
+    t->forward(v, false);
+  }
+  if (need) {
+    t->backward(nullptr, reinterpret_cast<float*>(2), nullptr);
+    *need = align_up(t->peak, 256) + (64 << 20);
+    t->tape.clear();
+    return t->rc;
+  }
+  if (t->ws.overflow) {
+    set_error("training workspace too small: need %zu bytes, have %zu", t->peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st) {
+  t->st = st;
+  if (!d_energy && t->in_energy) t->nograd.insert(t->in_energy);
+  t->backward(d_audio, reinterpret_cast<float*>(2), d_style);
+  if (t->rc == STY_OK && d_energy && t->in_energy && t->live()) {
+    float* g = t->G(t->in_energy, (size_t)t->B * t->T);
+    hipError_t e = hipMemcpyAsync(d_energy, g, (size_t)t->B * t->T * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "d_energy copy");
+  }
+  if (t->ws.overflow) {
+    set_error("training workspace too small in backward: need %zu bytes", t->peak);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
 
 Trainer* trainer_create(sty_model* m) {
   Trainer* t = new Trainer();

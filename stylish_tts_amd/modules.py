@@ -290,6 +290,52 @@ class SpeechPredictor(_HipModule):
         return d_mel, d_style
 
 
+    def forward_train(self, texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, *, noise=None,
+                      seed=0, prior_override=None):
+        """SpeechPredictor.forward in the training graph (eval-mode statistics); follow with backward(d_audio)."""
+        dev = style.device
+        self._train = True
+        lib = self._ensure(dev)
+        B, Lt = texts.shape
+        T = pitch.shape[1]
+        io = L.SpeechIO()
+        io.B, io.L, io.T = B, Lt, T
+        keep = [texts.to(dev, torch.int64).contiguous(), text_lengths.to(dev, torch.int64).contiguous()]
+        io.texts, io.text_lengths = keep[0].data_ptr(), keep[1].data_ptr()
+        for name, t in (("alignment", alignment), ("pitch", pitch), ("energy", energy), ("voiced", voiced),
+                        ("style", style), ("denormal_pitch", denormal_pitch), ("noise", noise),
+                        ("prior_override", prior_override)):
+            if t is not None:
+                t = _f32(t.detach(), dev)
+                keep.append(t)
+                setattr(io, name, t.data_ptr())
+        io.seed = int(seed)
+        audio = torch.empty(B, 1, 300 * T, dtype=torch.float32, device=dev)
+        io.audio = audio.data_ptr()
+        need = C.c_size_t()
+        L.check(lib.sty_speech_train_workspace_bytes(self._handle, B, Lt, T, C.byref(need)))
+        if getattr(self, "_train_ws", None) is None or self._train_ws.numel() < need.value:
+            self._train_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self._train_keep = keep
+        self._train_shape = (B, T)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_speech_fwd_train(self._handle, C.byref(io), C.c_void_p(self._train_ws.data_ptr()),
+                                         self._train_ws.numel(), st))
+        return audio
+
+    def backward(self, d_audio, want_style=True, want_energy=True):
+        """d loss / d audio -> (d_style [B,64], d_energy [B,T]); parameter gradients are added to param.grad."""
+        lib = L.load()
+        dev = d_audio.device
+        B, T = self._train_shape
+        d_audio = _f32(d_audio, dev)
+        d_style = torch.zeros(B, self.cfg["style_dim"], device=dev) if want_style else None
+        d_energy = torch.zeros(B, T, device=dev) if want_energy else None
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_speech_bwd(self._handle, L.ptr(d_audio), L.ptr(d_style), L.ptr(d_energy), st))
+        return d_style, d_energy
+
+
 class MultiGenerator(SpeechPredictor):
     """Vocoder-only view with the reference's keyword constructor (generator.py:803-805).  Holds the same
     `generator.*`-free key layout as the reference MultiGenerator by prefix-stripping is NOT done here: use

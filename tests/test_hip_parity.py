@@ -475,3 +475,51 @@ def test_vocoder_backward(env):
     for k in keys:
         rep.add("d " + k.replace("generator.", "")[-44:], named[k].grad, P[k].grad, 3e-2)
     rep.done()
+
+
+def test_speech_predictor_backward_vs_oracle_and_reference_golden(env):
+    """K15: SpeechPredictor backward (text encoder, alignment expand, decoder, vocoder) vs the oracle's autograd and
+    vs the gradients the REFERENCE produced (tests/golden/sp_small_grads.safetensors)."""
+    import stylish_tts_amd as S
+    from oracle import speech_predictor as osp
+    from safetensors.torch import load_file
+    cs, want, ali = env["cs"], env["want"], env["ali"]
+    P = {k: v.clone() for k, v in env["P"].items()}
+    m = S.SpeechPredictor()
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).enable_training()
+    audio = m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(ali), dev(cs["pitch"]), dev(cs["energy"]),
+                            dev(env["voiced"]), dev(cs["style"]), dev(cs["pitch"]), noise=dev(cs["noise"]),
+                            prior_override=dev(want["prior"]))
+    torch.cuda.synchronize()
+    mse = ((audio.cpu() - env["ref_audio"]) ** 2).mean().item()
+    print(f"\n  training-graph forward: mse {mse:.3e}")
+    assert mse <= 1e-8
+    d_style, d_energy = m.backward(torch.sign(audio) / audio.numel())
+    torch.cuda.synchronize()
+    gold = load_file(os.path.join(G, "sp_small_grads.safetensors"))
+    keys = [k[len("grad."):] for k in gold if k not in ("grad.style", "grad.energy")]
+    extra = ["text_encoder.prenet.conv_layers.1.weight", "text_encoder.prenet.norm_layers.2.gamma",
+             "text_encoder.encoder.ffn_layers.3.conv_2.weight", "text_encoder.encoder.norm_layers_2.7.beta",
+             "text_encoder.encoder.attn_layers.0.conv_k.bias", "text_encoder.proj_m.weight",
+             "decoder.encode.conv1x1.parametrizations.weight.original1", "decoder.decode.0.norm1.fc.weight",
+             "decoder.N_conv.parametrizations.weight.original1", "decoder.N_conv.parametrizations.weight.original0",
+             "decoder.F0_conv.bias", "decoder.asr_res.0.parametrizations.weight.original1"]
+    for k in keys + extra:
+        P[k].requires_grad_(True)
+    style_r = cs["style"].clone().requires_grad_(True)
+    energy_r = cs["energy"].clone().requires_grad_(True)
+    ref = osp.speech_predictor(P, cs["texts"], cs["text_lengths"], ali, cs["pitch"], energy_r, env["voiced"], style_r,
+                               cs["pitch"], cs["noise"], prior=want["prior"])
+    ref.abs().mean().backward()
+    rep = Report()
+    named = dict(m.named_parameters())
+    rep.add("d_style vs oracle", d_style, style_r.grad, 3e-2)
+    rep.add("d_energy vs oracle", d_energy, energy_r.grad, 3e-2)
+    rep.add("d_style vs REFERENCE", d_style, gold["grad.style"], 3e-2)
+    rep.add("d_energy vs REFERENCE", d_energy, gold["grad.energy"], 3e-2)
+    for k in keys:
+        rep.add("REF d " + k[-40:], named[k].grad, gold["grad." + k], 3e-2)
+    for k in keys + extra:
+        rep.add("d " + k[-44:], named[k].grad, P[k].grad, 3e-2)
+    rep.done()
