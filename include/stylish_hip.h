@@ -161,6 +161,15 @@ int sty_speech_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *
 int sty_speech_fwd_train(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
 int sty_speech_bwd(sty_model *m, const float *d_audio, float *d_style, float *d_energy, void *stream);
 
+/* ---- acoustic-stage losses without third-party models, forward + backward in one call ---------------
+ * mel  = MultiResolutionSTFTLoss (train/losses.py:17-38) on log1p(mel128|X|); multi_phase = losses.py:41-91;
+ * seed = w_mel*mel/(mel.detach()+1e-9) + w_phase*multi_phase/(multi_phase.detach()+1e-9)  (loss_log.py:82-94).
+ * audio_gt, audio_pred [B,N] -> losses[2] (device: mel, multi_phase), d_audio_pred [B,N] = d seed / d audio_pred. */
+int sty_acoustic_loss_workspace_bytes(int B, int N, size_t *bytes);
+int sty_acoustic_loss_fwd_bwd(int B, int N, const float *audio_gt, const float *audio_pred, float w_mel,
+                              float w_phase, float *losses, float *d_audio_pred, void *workspace, size_t ws_bytes,
+                              void *stream);
+
 /* ---- in-situ kernel timing (used by bench.py for the roofline object) --------------------------------
  * When enabled, every launch of the instrumented kernel families is bracketed by HIP events on the launch
  * stream.  sty_prof_report synchronises the device, sums the event times per family and writes up to `cap`

@@ -1793,4 +1793,26 @@ int sty_multispec_fwd(int B, int N, const float* audio, float* const* mag, float
   return STY_OK;
 }
 
+int sty_acoustic_loss_workspace_bytes(int B, int N, size_t* bytes) {
+  if (!bytes || B <= 0 || N <= 1024) {
+    set_error("sty_acoustic_loss_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  *bytes = acoustic_loss_workspace_floats(B, N) * sizeof(float);
+  return STY_OK;
+}
+int sty_acoustic_loss_fwd_bwd(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
+                              float* losses, float* d_audio_pred, void* workspace, size_t ws_bytes, void* stream) {
+  if (!audio_gt || !audio_pred || !losses || !d_audio_pred || !workspace || B <= 0 || N <= 1024) {
+    set_error("sty_acoustic_loss_fwd_bwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (ws_bytes < acoustic_loss_workspace_floats(B, N) * sizeof(float)) {
+    set_error("sty_acoustic_loss_fwd_bwd: workspace too small");
+    return STY_ENOMEM;
+  }
+  return launch_acoustic_loss(B, N, audio_gt, audio_pred, w_mel, w_phase, losses, d_audio_pred, (float*)workspace,
+                              S(stream));
+}
+
 }  // extern "C"

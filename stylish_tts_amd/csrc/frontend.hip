@@ -21,8 +21,17 @@ struct FrontTables {
   float* window = nullptr;  // [n_fft] (hann(win) zero-padded centred)
   PackedConv dft;           // [n_fft] -> [re_0..re_F-1, im_0..im_F-1]
   PackedConv fb;            // [F] -> [n_mels]
+  PackedConv dftT;          // backward: [2F] -> [n_fft]   (transposed basis)
+  PackedConv fbT;           // backward: [n_mels] -> [F]    (transposed filter bank)
   int n_fft = 0, F = 0, n_mels = 0;
 };
+
+// wt[r][c] = w[c][r] for packed [rows][colsP] -> [cols][rowsP]
+__global__ void transpose_pack_kernel(const float* __restrict__ w, int rows, int cols, int colsP, int rowsP,
+                                      float* __restrict__ wt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < cols) wt[(size_t)c * rowsP + r] = w[(size_t)r * colsP + c];
+}
 
 __global__ void window_kernel(float* __restrict__ w, int n_fft, int win) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,6 +108,30 @@ static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream
   t.window = w;
   t.dft.wp = d;
   t.fb.wp = f;
+  // transposed copies for the backward pass
+  t.dftT.Cin = 2 * F;
+  t.dftT.CinP = (int)align_up(2 * F, CI_CHUNK);
+  t.dftT.Cout = n_fft;
+  t.dftT.CoutP = (int)align_up(n_fft, 128);
+  t.dftT.K = 1;
+  t.fbT.Cin = n_mels;
+  t.fbT.CinP = (int)align_up(n_mels, CI_CHUNK);
+  t.fbT.Cout = F;
+  t.fbT.CoutP = (int)align_up(F, 32);
+  t.fbT.K = 1;
+  float *dt, *ft;
+  const size_t dtn = (size_t)t.dftT.CinP * t.dftT.CoutP, ftn = (size_t)t.fbT.CinP * t.fbT.CoutP;
+  STY_HIP(hipMalloc((void**)&dt, dtn * sizeof(float)));
+  STY_HIP(hipMalloc((void**)&ft, ftn * sizeof(float)));
+  STY_HIP(hipMemsetAsync(dt, 0, dtn * sizeof(float), st));
+  STY_HIP(hipMemsetAsync(ft, 0, ftn * sizeof(float), st));
+  hipLaunchKernelGGL(transpose_pack_kernel, dim3(cdiv(2 * F, 256), n_fft), dim3(256), 0, st, d, n_fft, 2 * F,
+                     t.dft.CoutP, t.dftT.CoutP, dt);
+  hipLaunchKernelGGL(transpose_pack_kernel, dim3(cdiv(n_mels, 64), F), dim3(64), 0, st, f, F, n_mels, t.fb.CoutP,
+                     t.fbT.CoutP, ft);
+  STY_LAUNCH_CHECK();
+  t.dftT.wp = dt;
+  t.fbT.wp = ft;
   auto ins = g_tables.emplace(key, t);
   *out = &ins.first->second;
   return STY_OK;
@@ -227,6 +260,262 @@ int launch_multispec_single(int B, int N, const float* audio, int n_fft, int hop
   if (rc) return rc;
   const size_t n = (size_t)B * 128 * frames;
   hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, n);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// =====================================================================================================
+// Acoustic-stage losses on the three-resolution features and their gradient w.r.t. the predicted waveform.
+//   mel          = mean_r ||T_r - P_r||_1 / (||T_r||_1 + 1e-6)           on log1p(mel128(|X|))   (losses.py:17-38)
+//   multi_phase  = mean_r [ mean aw(dP)W + mean aw(diff_f dP)W[:-1] + mean aw(diff_t dP)W ]       (losses.py:41-91)
+//                  aw(x) = |x - 2 pi round(x / 2 pi)|,  W[f] = 2.5^(f / (F//2)),  phase = (|X| > 1e-3) angle(X)
+//   backward seed = w_mel * mel / (mel.detach() + 1e-9) + w_phase * multi_phase / (multi_phase.detach() + 1e-9)
+//                                                                                       (loss_log.py:82-94)
+// =====================================================================================================
+struct ResBufs {  // per resolution, all [B][.][frames]
+  float *t_mag, *t_phase, *p_mag, *p_phase, *p_fft, *p_y;  // p_y = predicted re/im [B][2F][frames]
+  float *d_mag, *d_phase;
+  int n_fft, hop, F, frames;
+};
+
+__device__ __forceinline__ float aw_res(float x) { return x - 6.28318530717958647692f * rintf(x / 6.28318530717958647692f); }
+
+// sums[r*5 + {0: sum|T-P|, 1: sum|T|, 2: sum aw0 W, 3: sum aw1 W, 4: sum aw2 W}]  (double atomics)
+__global__ __launch_bounds__(256) void loss_sums_kernel(ResBufs rb, int r, int B, double* __restrict__ sums) {
+  __shared__ double red[5][4];
+  const int F = rb.F, fr = rb.frames;
+  const size_t nph = (size_t)B * F * fr, nmag = (size_t)B * 128 * fr;
+  const double lb = log(2.5) / (double)(F / 2);
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nmag; i += (size_t)gridDim.x * 256) {
+    acc[0] += fabsf(rb.t_mag[i] - rb.p_mag[i]);
+    acc[1] += fabsf(rb.t_mag[i]);
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nph; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % fr), f = (int)((i / fr) % F);
+    const float w = (float)exp(lb * f);
+    const float d0 = rb.p_phase[i] - rb.t_phase[i];
+    acc[2] += fabsf(aw_res(d0)) * w;
+    if (f + 1 < F) {
+      const float d1 = (rb.p_phase[i + fr] - rb.t_phase[i + fr]) - d0;
+      acc[3] += fabsf(aw_res(d1)) * w;
+    }
+    if (t + 1 < fr) {
+      const float d2 = (rb.p_phase[i + 1] - rb.t_phase[i + 1]) - d0;
+      acc[4] += fabsf(aw_res(d2)) * w;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 5; ++k) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[k][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) atomicAdd(&sums[r * 5 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] +
+                                                                 red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// losses[0] = mel, losses[1] = multi_phase (device scalars)
+__global__ void loss_finalize_kernel(const double* __restrict__ sums, const int* __restrict__ dims, int B,
+                                     float* __restrict__ losses) {
+  double mel = 0.0, ph = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    const int F = dims[2 * r], fr = dims[2 * r + 1];
+    mel += sums[r * 5] / (sums[r * 5 + 1] + 1e-6);
+    ph += sums[r * 5 + 2] / ((double)B * F * fr) + sums[r * 5 + 3] / ((double)B * (F - 1) * fr) +
+          sums[r * 5 + 4] / ((double)B * F * (fr - 1));
+  }
+  losses[0] = (float)(mel / 3.0);
+  losses[1] = (float)(ph / 3.0);
+}
+
+__device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// gradients of the backward seed w.r.t. P_mag and P_phase
+__global__ void loss_grad_kernel(ResBufs rb, int r, int B, const double* __restrict__ sums,
+                                 const float* __restrict__ losses, float w_mel, float w_phase) {
+  const int F = rb.F, fr = rb.frames;
+  const size_t nph = (size_t)B * F * fr, nmag = (size_t)B * 128 * fr;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const float kmel = w_mel / (losses[0] + 1e-9f) / 3.0f / (float)(sums[r * 5 + 1] + 1e-6);
+  const float kph = w_phase / (losses[1] + 1e-9f) / 3.0f;
+  if (i < nmag) rb.d_mag[i] = -kmel * sgnf(rb.t_mag[i] - rb.p_mag[i]);
+  if (i < nph) {
+    const int t = (int)(i % fr), f = (int)((i / fr) % F);
+    const double lb = log(2.5) / (double)(F / 2);
+    const float w = (float)exp(lb * f), wm = f > 0 ? (float)exp(lb * (f - 1)) : 0.f;
+    const float n0 = 1.0f / ((float)B * F * fr), n1 = 1.0f / ((float)B * (F - 1) * fr),
+                n2 = 1.0f / ((float)B * F * (fr - 1));
+    auto D = [&](size_t j) { return rb.p_phase[j] - rb.t_phase[j]; };
+    const float d0 = D(i);
+    float g = w * sgnf(aw_res(d0)) * n0;
+    if (f + 1 < F) g -= w * sgnf(aw_res(D(i + fr) - d0)) * n1;
+    if (f > 0) g += wm * sgnf(aw_res(d0 - D(i - fr))) * n1;
+    if (t + 1 < fr) g -= w * sgnf(aw_res(D(i + 1) - d0)) * n2;
+    if (t > 0) g += w * sgnf(aw_res(d0 - D(i - 1))) * n2;
+    rb.d_phase[i] = kph * g;
+  }
+}
+
+// d_mel = d_mag / (1 + mel) = d_mag * exp(-mag)   (in place on d_mag)
+__global__ void log1p_bwd_kernel(float* __restrict__ d, const float* __restrict__ mag, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] *= expf(-mag[i]);
+}
+
+// dY[b][f / F+f][fr] from d|X| and d phase
+__global__ void magphase_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dabs,
+                                    const float* __restrict__ dphase, int F, int frames, float* __restrict__ dy) {
+  const int fr = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y, b = blockIdx.z;
+  if (fr >= frames) return;
+  const size_t ore = ((size_t)b * 2 * F + f) * frames + fr, oim = ((size_t)b * 2 * F + F + f) * frames + fr;
+  const float re = y[ore], im = y[oim];
+  const float m = hypotf(re, im);
+  const size_t o = ((size_t)b * F + f) * frames + fr;
+  float gre = 0.f, gim = 0.f;
+  if (m > 0.f) {
+    gre = dabs[o] * re / m;
+    gim = dabs[o] * im / m;
+    if (m > 1e-3f) {
+      const float h2 = m * m;
+      gre += dphase[o] * (-im / h2);
+      gim += dphase[o] * (re / h2);
+    }
+  }
+  dy[ore] = gre;
+  dy[oim] = gim;
+}
+
+// d audio[b][i] += sum over frames / reflections of w[n] * dxt[b][n][fr]   (gather, no atomics)
+__global__ void frame_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ w, int N, int n_fft, int hop,
+                                 int frames, float* __restrict__ daudio) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= N) return;
+  const int half = n_fft / 2;
+  float acc = 0.f;
+  // padded positions p (p = i + half in padded coordinates) that read sample i: i itself, its left mirror, its right mirror
+  int ps[3];
+  int np = 0;
+  ps[np++] = i;
+  if (i >= 1 && i <= half) ps[np++] = -i;
+  if (i <= N - 2 && i >= N - 1 - half) ps[np++] = 2 * (N - 1) - i;
+  for (int k = 0; k < np; ++k) {
+    const int q = ps[k] + half;  // index into the padded signal, frame fr covers [fr*hop, fr*hop + n_fft)
+    int f_hi = q / hop;
+    if (f_hi > frames - 1) f_hi = frames - 1;
+    int f_lo = (q - n_fft + hop) / hop;
+    if (q - n_fft + 1 <= 0) f_lo = 0;
+    if (f_lo < 0) f_lo = 0;
+    for (int fr = f_lo; fr <= f_hi; ++fr) {
+      const int n = q - fr * hop;
+      if (n >= 0 && n < n_fft) acc = fmaf(w[n], dxt[((size_t)b * n_fft + n) * frames + fr], acc);
+    }
+  }
+  daudio[(size_t)b * N + i] += acc;
+}
+
+size_t acoustic_loss_workspace_floats(int B, int N) {
+  size_t tot = 64;
+  const int res[3][2] = {{512, 128}, {1024, 256}, {2048, 512}};
+  size_t tmp = 0;
+  for (auto& r : res) {
+    const size_t frames = N / r[1] + 1, F = r[0] / 2 + 1;
+    tot += (size_t)B * frames * (128 * 3 + F * 4 + 2 * F + 16);   // persistent per-resolution tensors
+    const size_t t = (size_t)B * frames * ((size_t)r[0] + 2 * F + F) + 1024;  // frames + y/dy + d|X|
+    tmp = t > tmp ? t : tmp;
+  }
+  return tot + tmp + 4096;
+}
+
+// losses_out: device [2] (mel, multi_phase); d_pred [B][N] is OVERWRITTEN with d seed / d audio_pred
+int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
+                         float* losses_out, float* d_pred, float* ws, hipStream_t st) {
+  const int res[3][2] = {{512, 128}, {1024, 256}, {2048, 512}};
+  ResBufs rb[3];
+  float* p = ws;
+  auto take = [&](size_t n) {
+    float* q = p;
+    p += (n + 63) / 64 * 64;
+    return q;
+  };
+  double* sums = reinterpret_cast<double*>(take(32));
+  int* dims = reinterpret_cast<int*>(take(16));
+  int hdims[6];
+  for (int r = 0; r < 3; ++r) {
+    const int frames = N / res[r][1] + 1, F = res[r][0] / 2 + 1;
+    rb[r].n_fft = res[r][0];
+    rb[r].hop = res[r][1];
+    rb[r].F = F;
+    rb[r].frames = frames;
+    rb[r].t_mag = take((size_t)B * 128 * frames);
+    rb[r].p_mag = take((size_t)B * 128 * frames);
+    rb[r].d_mag = take((size_t)B * 128 * frames);
+    rb[r].t_phase = take((size_t)B * F * frames);
+    rb[r].p_phase = take((size_t)B * F * frames);
+    rb[r].d_phase = take((size_t)B * F * frames);
+    rb[r].p_fft = take((size_t)B * F * frames);
+    rb[r].p_y = take((size_t)B * 2 * F * frames);
+    hdims[2 * r] = F;
+    hdims[2 * r + 1] = frames;
+  }
+  float* tmp = p;
+  STY_HIP(hipMemsetAsync(sums, 0, 16 * sizeof(double), st));
+  STY_HIP(hipMemcpyAsync(dims, hdims, sizeof(hdims), hipMemcpyHostToDevice, st));
+  STY_HIP(hipMemsetAsync(d_pred, 0, (size_t)B * N * sizeof(float), st));
+  // features: target (scratch y), prediction (kept y)
+  for (int r = 0; r < 3; ++r) {
+    const FrontTables* t;
+    int rc = get_tables(rb[r].n_fft, rb[r].n_fft, 128, 24000, st, &t);
+    if (rc) return rc;
+    const int frames = rb[r].frames, F = rb[r].F, n_fft = rb[r].n_fft;
+    float* xt = tmp;
+    float* y = xt + (size_t)B * n_fft * frames;
+    float* tfft = y + (size_t)B * 2 * F * frames;
+    for (int side = 0; side < 2; ++side) {
+      const float* audio = side == 0 ? audio_gt : audio_pred;
+      float* yy = side == 0 ? y : rb[r].p_y;
+      float* fm = side == 0 ? tfft : rb[r].p_fft;
+      float* mg = side == 0 ? rb[r].t_mag : rb[r].p_mag;
+      float* ph = side == 0 ? rb[r].t_phase : rb[r].p_phase;
+      hipLaunchKernelGGL(frame_kernel, dim3(cdiv(frames, 256), n_fft, B), dim3(256), 0, st, audio, t->window, N, n_fft,
+                         rb[r].hop, frames, xt);
+      rc = dense(t->dft, xt, B, frames, yy, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, yy, F, frames, fm, ph);
+      rc = dense(t->fb, fm, B, frames, mg, st);
+      if (rc) return rc;
+      const size_t n = (size_t)B * 128 * frames;
+      hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mg, n);
+    }
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(256), dim3(256), 0, st, rb[r], r, B, sums);
+  }
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, sums, dims, B, losses_out);
+  // backward
+  for (int r = 0; r < 3; ++r) {
+    const FrontTables* t;
+    int rc = get_tables(rb[r].n_fft, rb[r].n_fft, 128, 24000, st, &t);
+    if (rc) return rc;
+    const int frames = rb[r].frames, F = rb[r].F, n_fft = rb[r].n_fft;
+    const size_t nph = (size_t)B * F * frames, nmag = (size_t)B * 128 * frames;
+    const size_t nmax = nph > nmag ? nph : nmag;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, st, rb[r], r, B, sums,
+                       losses_out, w_mel, w_phase);
+    hipLaunchKernelGGL(log1p_bwd_kernel, dim3((unsigned)((nmag + 255) / 256)), dim3(256), 0, st, rb[r].d_mag,
+                       rb[r].p_mag, nmag);
+    float* dabs = tmp;                                   // [B][F][frames]
+    float* dy = dabs + (size_t)B * F * frames;           // [B][2F][frames]
+    float* dxt = dy + (size_t)B * 2 * F * frames;        // [B][n_fft][frames]
+    rc = dense(t->fbT, rb[r].d_mag, B, frames, dabs, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(magphase_bwd_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, rb[r].p_y, dabs,
+                       rb[r].d_phase, F, frames, dy);
+    rc = dense(t->dftT, dy, B, frames, dxt, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(frame_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, dxt, t->window, N, n_fft, rb[r].hop,
+                       frames, d_pred);
+  }
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

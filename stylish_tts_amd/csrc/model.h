@@ -31,6 +31,9 @@ size_t mel_workspace_floats(int B, int N, int n_fft, int hop, int n_mels);
 int launch_mel(int B, int N, const float* audio, int n_fft, int win, int hop, int n_mels, int sample_rate, float mean,
                float std_, float* mel, float* energy, float* ws, hipStream_t st);
 size_t multispec_workspace_floats(int B, int N, int n_fft, int hop);
+size_t acoustic_loss_workspace_floats(int B, int N);
+int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
+                         float* losses_out, float* d_pred, float* ws, hipStream_t st);
 int launch_multispec_single(int B, int N, const float* audio, int n_fft, int hop, int sample_rate, float* mag,
                             float* phase, float* fft_mag, float* ws, hipStream_t st);
 

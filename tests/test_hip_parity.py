@@ -523,3 +523,27 @@ def test_speech_predictor_backward_vs_oracle_and_reference_golden(env):
     for k in keys + extra:
         rep.add("d " + k[-44:], named[k].grad, P[k].grad, 3e-2)
     rep.done()
+
+
+def test_acoustic_losses_forward_backward():
+    """N1 + A10 backward: mel / multi-phase losses and d seed / d audio_pred vs the oracle's autograd."""
+    from oracle import losses as ol
+    from stylish_tts_amd.losses import acoustic_loss
+    gt = _test_audio(2, 24000, 3)
+    g = torch.Generator().manual_seed(4)
+    pred = (0.8 * gt + 0.05 * torch.randn(2, 24000, generator=g)).requires_grad_(True)
+    mel, mph, tot = ol.acoustic_losses(gt, pred)
+    tot.backward()
+    losses, d = acoustic_loss(dev(gt), dev(pred.detach()))
+    torch.cuda.synchronize()
+    print(f"\n  mel {losses[0].item():.6f} vs {mel.item():.6f}   multi_phase {losses[1].item():.6f} vs {mph.item():.6f}")
+    assert abs(losses[0].item() - mel.item()) <= 1e-5 * abs(mel.item()) + 1e-7
+    assert abs(losses[1].item() - mph.item()) <= 1e-4 * abs(mph.item())
+    # the loss is piecewise linear (|.| and the wrap): elements within rounding of a kink flip their sign, so
+    # compare the gradients in aggregate
+    ref = pred.grad
+    err = (d.cpu() - ref)
+    rel = err.norm().item() / ref.norm().item()
+    cos = torch.nn.functional.cosine_similarity(d.cpu().flatten(), ref.flatten(), dim=0).item()
+    print(f"  d_audio: relative L2 error {rel:.3e}, cosine {cos:.6f}, max|ref| {ref.abs().max().item():.3e}")
+    assert rel <= 2e-2 and cos >= 0.9995
