@@ -160,6 +160,12 @@ int sty_vocoder_bwd(sty_model *m, const float *d_audio, float *d_mel, float *d_s
 int sty_speech_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);
 int sty_speech_fwd_train(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
 int sty_speech_bwd(sty_model *m, const float *d_audio, float *d_style, float *d_energy, void *stream);
+/* Same for MelStyleEncoder.forward: gradients of every parameter (through the eval-mode spectral norm
+ * W/sigma(W) with fixed u, v: torch.nn.utils.spectral_norm, mel_style_encoder.py:67-152) from d loss / d style. */
+int sty_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
+int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *style, void *workspace, size_t ws_bytes,
+                        void *stream);
+int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
 
 /* ---- acoustic-stage losses without third-party models, forward + backward in one call ---------------
  * mel  = MultiResolutionSTFTLoss (train/losses.py:17-38) on log1p(mel128|X|); multi_phase = losses.py:41-91;

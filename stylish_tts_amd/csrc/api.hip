@@ -436,6 +436,31 @@ struct Builder {
       j.scratch = ts;
       m->jobs.push_back(j);
     }
+    if (m->train_enabled) {  // input-gradient weights: rows (kh', co), columns ci, taps flipped in both directions
+      PackedConv d;
+      d.Cin = KH * Cout;
+      d.CinP = (int)align_up(d.Cin, CI_CHUNK);
+      d.Cout = Cin;
+      d.CoutP = (int)align_up(Cin, 32);
+      d.K = KW;
+      float* wd = m->ab.take<float>((size_t)KW * d.CinP * d.CoutP);
+      d.wp = wd;
+      d.bias = nullptr;
+      if (!dry) {
+        PackJob j;
+        j.kind = PK_DGRAD2D;
+        j.w = wp;
+        j.Cout = Cout;
+        j.Cin = Cin;
+        j.K = KW;
+        j.KH = KH;
+        j.CinP = pc.CinP;
+        j.CoutP = pc.CoutP;
+        j.wp = wd;
+        m->jobs.push_back(j);
+        m->dgrad[wp] = d;
+      }
+    }
     return pc;
   }
 
@@ -1281,6 +1306,24 @@ static int unpack_grads(sty_model* m, hipStream_t st) {
         int r = launch_axpy(GA(j.bp), 1.0f, db, (size_t)j.Cout, st);
         if (r) return r;
       }
+    } else if (j.kind == PK_CONV2D_SN) {
+      float* dW = PG(j.w);
+      if (dW) {  // the gradient-arena twin of the sigma scratch holds the <G, W> row sums
+        int r = launch_sn_unpack(GA(j.wp), j.w, j.g, j.v, j.scratch, j.Cout, j.Cin, j.KH, j.K, j.CinP, j.CoutP,
+                                 GA(j.scratch), dW, st);
+        if (r) return r;
+      }
+      float* db = (j.bias && j.bp) ? PG(j.bias) : nullptr;
+      if (db) {
+        int r = launch_axpy(GA(j.bp), 1.0f, db, (size_t)j.Cout, st);
+        if (r) return r;
+      }
+    } else if (j.kind == PK_DW2D_SN) {
+      float* dW = PG(j.w);
+      if (dW) {
+        int r = launch_dw2d_sn_unpack(GA(j.wp), j.w, j.g, j.v, j.scratch, j.Cout, dW, st);
+        if (r) return r;
+      }
     } else if (j.kind == PK_W2A) {
       // b2eff = b2 + W2 . grn_beta:  db2 += g, dbeta += W2^T g, dW2 += g beta^T   (g = gradient of b2eff)
       float* db2 = PG(j.bias);
@@ -1404,6 +1447,7 @@ int sty_model_prepare(sty_model* m, void* stream) {
     int r = STY_OK;
     switch (j.kind) {
       case PK_DGRAD:
+      case PK_DGRAD2D:
         break;  // second pass below
       case PK_CONV:
       case PK_CONV_WN:
@@ -1425,11 +1469,14 @@ int sty_model_prepare(sty_model* m, void* stream) {
     }
     if (r != STY_OK) return r;
   }
-  for (const PackJob& j : m->jobs)
-    if (j.kind == PK_DGRAD) {
-      int r = launch_pack_dgrad(j.w, j.K, j.CinP, j.CoutP, j.wp, st);
-      if (r != STY_OK) return r;
-    }
+  for (const PackJob& j : m->jobs) {
+    int r = STY_OK;
+    if (j.kind == PK_DGRAD) r = launch_pack_dgrad(j.w, j.K, j.CinP, j.CoutP, j.wp, st);
+    if (j.kind == PK_DGRAD2D)
+      r = launch_pack_dgrad2d(j.w, j.K, j.KH, j.Cin, j.Cout, j.CinP, j.CoutP, (int)align_up(j.KH * j.Cout, CI_CHUNK),
+                              (int)align_up(j.Cin, 32), j.wp, st);
+    if (r != STY_OK) return r;
+  }
   if (m->kind == "speech_predictor") {
     const DecoderPlan& d = m->dec;
     int r = launch_prep_fnv(d.f0_g, d.f0_v, d.f0_b, d.n_g, d.n_v, d.n_b, d.v_g, d.v_v, d.v_b, d.fnv_w, st);
@@ -1735,6 +1782,44 @@ int sty_style_fwd(sty_model* m, int B, int T, const float* mel, float* style, vo
   }
   if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
   return style_entry(m, B, T, mel, style, workspace, ws_bytes, stream, nullptr);
+}
+int sty_style_train_workspace_bytes(sty_model* m, int B, int T, size_t* bytes) {
+  int rc = model_ready(m, "mel_style_encoder");
+  if (rc) return rc;
+  if (!m->train_enabled || !bytes || B <= 0 || T < 40) {
+    set_error("sty_style_train_workspace_bytes: bad argument or training not enabled");
+    return STY_EINVAL;
+  }
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_style_forward(m->trainer, B, T, nullptr, nullptr, nullptr, 0, nullptr, bytes);
+}
+int sty_style_fwd_train(sty_model* m, int B, int T, const float* mel, float* style, void* workspace, size_t ws_bytes,
+                        void* stream) {
+  int rc = model_ready(m, "mel_style_encoder");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  if (!mel || !style || !workspace || B <= 0 || T < 40) {
+    set_error("sty_style_fwd_train: bad argument (T >= 40 frames)");
+    return STY_EINVAL;
+  }
+  // weights change between steps: re-derive the prepared (spectral-normalised, packed) form every call
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_style_forward(m->trainer, B, T, mel, style, workspace, ws_bytes, S(stream), nullptr);
+}
+int sty_style_bwd(sty_model* m, const float* d_style, void* stream) {
+  int rc = model_ready(m, "mel_style_encoder");
+  if (rc) return rc;
+  if (!m->trainer || !d_style) {
+    set_error("sty_style_bwd: no recorded forward or null gradient");
+    return STY_ESTATE;
+  }
+  rc = trainer_style_backward(m->trainer, d_style, S(stream));
+  if (rc) return rc;
+  return unpack_grads(m, S(stream));
 }
 int sty_mel_workspace_bytes(int B, int N, int n_fft, int hop, size_t* bytes) {
   if (!bytes || B <= 0 || N <= n_fft / 2 || n_fft <= 0 || hop <= 0) {

@@ -149,4 +149,151 @@ int launch_pool_fc(const float* x, int B, int C, int HW, const float* W, const f
   return STY_OK;
 }
 
+// ---- backward ----
+// depthwise 3x3 stride 2 pad 1: dx (+=), dw9 (+=, w.r.t. the EFFECTIVE weights), db (+=)
+__global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __restrict__ gy,
+                                                                 const float* __restrict__ w9, int C, int H, int W,
+                                                                 int Ho, int Wo, float* __restrict__ dx) {
+  const int wi = blockIdx.x * 256 + threadIdx.x;
+  const int hi = blockIdx.y, bc = blockIdx.z, c = bc % C;
+  if (wi >= W) return;
+  const float* g = gy + (size_t)bc * Ho * Wo;
+  float acc = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hn = hi + 1 - kh;  // 2 ho = hi + 1 - kh
+    if (hn < 0 || (hn & 1)) continue;
+    const int ho = hn >> 1;
+    if (ho >= Ho) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wn = wi + 1 - kw;
+      if (wn < 0 || (wn & 1)) continue;
+      const int wo = wn >> 1;
+      if (wo < Wo) acc = fmaf(w9[c * 9 + kh * 3 + kw], g[(size_t)ho * Wo + wo], acc);
+    }
+  }
+  dx[((size_t)bc * H + hi) * W + wi] += acc;
+}
+__global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gy, int B, int C, int H,
+                                                                int W, int Ho, int Wo, float* __restrict__ dw9,
+                                                                float* __restrict__ db) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  for (int k = 0; k <= 9; ++k) {
+    const int kh = k / 3, kw = k % 3;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float* p = x + ((size_t)b * C + c) * H * W;
+      const float* g = gy + ((size_t)b * C + c) * Ho * Wo;
+      for (int i = threadIdx.x; i < Ho * Wo; i += 256) {
+        const int ho = i / Wo, wo = i % Wo;
+        if (k == 9) {
+          acc += g[i];
+        } else {
+          const int hi = 2 * ho + kh - 1, wi = 2 * wo + kw - 1;
+          if (hi >= 0 && hi < H && wi >= 0 && wi < W) acc = fmaf(g[i], p[(size_t)hi * W + wi], acc);
+        }
+      }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (k == 9) {
+        if (db) db[c] += red[0];
+      } else {
+        dw9[c * 9 + k] += red[0];
+      }
+    }
+    __syncthreads();
+  }
+}
+int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int B, int C, int H, int W, float* dx,
+                           float* dw9, float* db, hipStream_t st) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_dx_kernel, dim3(cdiv(W, 256), H, B * C), dim3(256), 0, st, gy, w9, C, H, W, Ho, Wo,
+                     dx);
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_kernel, dim3(C), dim3(256), 0, st, x, gy, B, C, H, W, Ho, Wo, dw9, db);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// depthwise spectral norm: dW[c][k] += g9[c][k]/sigma - (<g9, W>/sigma^2) u[c] v[k]; t from sn_rowdot (sigma = sum t)
+__global__ void dw2d_sn_unpack_kernel(const float* __restrict__ g9, const float* __restrict__ w,
+                                      const float* __restrict__ u, const float* __restrict__ v,
+                                      const float* __restrict__ t, int C, float* __restrict__ dW) {
+  float sig = 0.f, dot = 0.f;
+  for (int i = 0; i < C; ++i) sig += t[i];
+  for (int i = 0; i < C * 9; ++i) dot = fmaf(g9[i], w[i], dot);
+  const float inv = 1.0f / sig, k = dot * inv * inv;
+  for (int i = threadIdx.x; i < C * 9; i += blockDim.x) dW[i] += g9[i] * inv - k * u[i / 9] * v[i % 9];
+}
+int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const float* v, const float* t, int C,
+                          float* dW, hipStream_t st) {
+  hipLaunchKernelGGL(dw2d_sn_unpack_kernel, dim3(1), dim3(256), 0, st, g9, w, u, v, t, C, dW);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gy, int H, int W, int Ho, int Wo,
+                                                           float scale, float* __restrict__ dx) {
+  const int wi = blockIdx.x * 256 + threadIdx.x;
+  const int hi = blockIdx.y, bc = blockIdx.z;
+  if (wi >= W) return;
+  const int ho = hi >> 1;
+  const int wo = wi >> 1;
+  float g = gy[((size_t)bc * Ho + ho) * Wo + wo];
+  // odd W: the last column was replicated, so it is read twice by the last output column
+  const float mult = (W & 1) && wi == W - 1 ? 2.f : 1.f;
+  dx[((size_t)bc * H + hi) * W + wi] += g * 0.25f * scale * mult;
+}
+int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, hipStream_t st) {
+  const int Ho = H / 2, Wo = (W + 1) / 2;
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cdiv(W, 256), H, BC), dim3(256), 0, st, gy, H, W, Ho, Wo, scale, dx);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// pool + LeakyReLU + Linear backward: gs [B][S] -> dW (+=), db (+=), dx[b][c][:] += (W^T gs)[c] lrelu'(mean)/HW
+__global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restrict__ x, int B, int C, int HW,
+                                                          const float* __restrict__ W, int S,
+                                                          const float* __restrict__ gs, float* __restrict__ dW,
+                                                          float* __restrict__ db, float* __restrict__ dx) {
+  extern __shared__ float sh[];  // pooled[C] (pre-activation mean), gp[C]
+  float* pooled = sh;
+  float* gp = sh + C;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < C; c += 4) {
+    const float* p = x + ((size_t)b * C + c) * HW;
+    float s = 0.f;
+    for (int i = lane; i < HW; i += 64) s += p[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) pooled[c] = s / (float)HW;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < S; ++j) acc = fmaf(W[(size_t)j * C + c], gs[(size_t)b * S + j], acc);
+    gp[c] = acc * (pooled[c] > 0.f ? 1.f : 0.2f) / (float)HW;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * HW; i += 256) dx[(size_t)b * C * HW + i] += gp[i / HW];
+  for (int i = threadIdx.x; i < S * C; i += 256) {
+    const int j = i / C, c = i % C;
+    const float a = pooled[c] > 0.f ? pooled[c] : 0.2f * pooled[c];
+    atomicAdd(&dW[i], gs[(size_t)b * S + j] * a);
+  }
+  for (int j = threadIdx.x; j < S; j += 256) atomicAdd(&db[j], gs[(size_t)b * S + j]);
+}
+int launch_pool_fc_bwd(const float* x, int B, int C, int HW, const float* W, int S, const float* gs, float* dW,
+                       float* db, float* dx, hipStream_t st) {
+  hipLaunchKernelGGL(pool_fc_bwd_kernel, dim3(B), dim3(256), 2 * C * sizeof(float), st, x, B, C, HW, W, S, gs, dW, db,
+                     dx);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 }  // namespace sty

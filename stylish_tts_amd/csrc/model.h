@@ -52,7 +52,7 @@ struct Bump {
   }
 };
 
-enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A, PK_CONV2D_SN, PK_DW2D_SN, PK_DGRAD };
+enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A, PK_CONV2D_SN, PK_DW2D_SN, PK_DGRAD, PK_DGRAD2D };
 int launch_pack_conv2d_sn(const float* w, const float* u, const float* v, const float* bias, int Cout, int Cin, int KH,
                           int KW, float* wp, float* bp, int CinP, int CoutP, float* tscratch, hipStream_t st);
 int launch_pack_dw2d_sn(const float* w, const float* u, const float* v, int C, float* w9, float* tscratch,
@@ -247,6 +247,20 @@ int launch_fnv_bwd(const float* pitch, const float* energy, const float* voiced,
 int launch_fnv_unpack(const float* dw34, const float* g0, const float* v0, const float* g1, const float* v1,
                       const float* g2, const float* v2, float* dg0, float* dv0, float* db0, float* dg1, float* dv1,
                       float* db1, float* dg2, float* dv2, float* db2, hipStream_t st);
+int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int CinP, int CoutP, int CinPd, int CoutPd,
+                        float* wd, hipStream_t st);
+int launch_sn_unpack(const float* gwp, const float* w, const float* u, const float* v, const float* t, int Cout,
+                     int Cin, int KH, int KW, int CinP, int CoutP, float* gw_scratch, float* dW, hipStream_t st);
+int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int B, int C, int H, int W, float* dx,
+                           float* dw9, float* db, hipStream_t st);
+int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const float* v, const float* t, int C,
+                          float* dW, hipStream_t st);
+int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, hipStream_t st);
+int launch_pool_fc_bwd(const float* x, int B, int C, int HW, const float* W, int S, const float* gs, float* dW,
+                       float* db, float* dx, hipStream_t st);
+int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
+                          hipStream_t st, size_t* need);
+int trainer_style_backward(struct Trainer* t, const float* d_style, hipStream_t st);
 struct Trainer;
 Trainer* trainer_create(sty_model* m);
 int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t ws_bytes, hipStream_t st,

@@ -634,6 +634,182 @@ struct Trainer {
     return layernorm(x4, C, Tt, 1e-5f, &c.post_n, nullptr, nullptr);
   }
 
+  // ---------------- MelStyleEncoder (mel_style_encoder.py:9-152), 2-D convs on the same MFMA kernels ----------------
+  void conv2d(const PackedConv& w, const float* x, int Cin2d, int Hin, int Win, float* y, int Hout, int Wout, int hpad,
+              int pad, int pro, float out_scale, const float* residual) {
+    ConvArgs a;
+    a.x[0] = x;
+    a.xc[0] = w.Cin;
+    a.nsrc = 1;
+    a.B = B;
+    a.T = Wout;
+    a.Tin = Win;
+    a.pad = pad;
+    a.w = w;
+    a.H = Hout;
+    a.Hin = Hin;
+    a.hpad = hpad;
+    a.Cin2d = Cin2d;
+    a.pro = pro;
+    a.out_scale = out_scale;
+    a.residual = residual;
+    a.y = y;
+    if (live()) chk(launch_conv1d(a, st));
+    tape.push_back([this, a]() { conv2d_bwd(a); });
+  }
+  void conv2d_bwd(const ConvArgs& f) {
+    const PackedConv& w = f.w;
+    const int KH = w.Cin / f.Cin2d;
+    const size_t ny = (size_t)B * w.Cout * f.H * f.T, nx = (size_t)B * f.Cin2d * f.Hin * f.Tin;
+    float* gY = G(f.y, ny);
+    float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
+    float* gX = wants(f.x[0]) ? G(f.x[0], nx) : nullptr;
+    const size_t mark = ws.off;
+    if (gR && live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, 1, (int)ny, gR, st));
+    if (w.bias && live())
+      chk(launch_bias_grad(gY, nullptr, B, w.Cout, f.H * f.T, 0, f.out_scale, PGpacked(w.bias), st));
+    float* partial = take<float>(wgrad_partial_floats(w, B * f.H, f.T));
+    if (live()) chk(launch_conv1d_wgrad(f, gY, nullptr, f.out_scale, PGpacked(w.wp), partial, st));
+    if (gX) {
+      auto it = m->dgrad.find(w.wp);
+      if (it == m->dgrad.end()) {
+        set_error("training: no input-gradient weights for a 2-D conv");
+        rc = STY_ESTATE;
+        return;
+      }
+      float* U = take<float>(nx);
+      ConvArgs d;
+      d.x[0] = gY;
+      d.xc[0] = it->second.Cin;
+      d.nsrc = 1;
+      d.B = B;
+      d.T = f.Tin;   // output width = forward input width
+      d.Tin = f.T;
+      d.pad = (w.K - 1) - f.pad;
+      d.w = it->second;
+      d.H = f.Hin;
+      d.Hin = f.H;
+      d.hpad = (KH - 1) - f.hpad;
+      d.Cin2d = w.Cout;
+      d.out_scale = f.out_scale;
+      d.y = U;
+      if (live()) {
+        chk(launch_conv1d(d, st));
+        chk(launch_pro_bwd(f.pro, U, f.Cin2d, 0, f.x[0], B, f.Cin2d, f.Hin * f.Tin, nullptr, nullptr, f.Cin2d, 0,
+                           nullptr, nullptr, gX, 1, nullptr, nullptr, nullptr, st));
+      }
+    }
+    ws.off = mark;
+  }
+
+  float* style_out = nullptr;
+  void style_forward(const float* mel, int Tt, float* style_dst) {
+    const StylePlan& sp = m->sty_enc;
+    tape.clear();
+    gmap.clear();
+    nograd.clear();
+    scratch_param_n = 1 << 16;
+    scratch_param = take<float>(scratch_param_n);
+    if (live() && m->garena) {
+      hipError_t e = hipMemsetAsync(m->garena, 0, m->arena_bytes, st);
+      if (e != hipSuccess) rc = hip_fail(e, "grad arena memset");
+    }
+    nograd.insert(mel);
+    const float r2 = 0.70710678118654752f;
+    int H = sp.n_mels, W = Tt, C = sp.n_mels;
+    float* x = take<float>((size_t)B * C * H * W);
+    conv2d(sp.stem, mel, 1, H, W, x, H, W, 1, 1, PRO_NONE, 1.f, nullptr);
+    for (int i = 0; i < 4; ++i) {
+      const StyleResBlk& k = sp.blk[i];
+      const int Ho = k.down ? H / 2 : H, Wo = k.down ? (W + 1) / 2 : W;
+      const int Hc = H, Wc = W;
+      const float* xin = x;
+      const float* sc_src = xin;
+      if (k.has_sc) {
+        float* sc_full = take<float>((size_t)B * k.Cout * H * W);
+        conv2d(k.sc, xin, k.Cin, H, W, sc_full, H, W, 0, 0, PRO_NONE, r2, nullptr);
+        sc_src = sc_full;
+      }
+      const float* res = nullptr;
+      if (k.down) {
+        float* sc = take<float>((size_t)B * k.Cout * Ho * Wo);
+        const float scale = k.has_sc ? 1.f : r2;
+        if (live()) chk(launch_avgpool2(sc_src, B * k.Cout, H, W, scale, sc, st));
+        const int BC = B * k.Cout;
+        tape.push_back([=]() {
+          float* g = G(sc, (size_t)BC * Ho * Wo);
+          float* gs = G(sc_src, (size_t)BC * Hc * Wc);
+          if (live()) chk(launch_avgpool2_bwd(g, BC, Hc, Wc, scale, gs, st));
+        });
+        res = sc;
+      } else if (k.has_sc) {
+        res = sc_src;
+      }
+      float* h1 = take<float>((size_t)B * k.Cin * H * W);
+      conv2d(k.c1, xin, k.Cin, H, W, h1, H, W, 1, 1, PRO_LRELU, 1.f, nullptr);
+      const float* h = h1;
+      if (k.down) {
+        float* h2 = take<float>((size_t)B * k.Cin * Ho * Wo);
+        if (live()) chk(launch_dwconv2d_s2(h1, k.dw_w9, k.dw_b, B, k.Cin, H, W, h2, st));
+        const float* w9 = k.dw_w9;
+        const float* dwb = k.dw_b;
+        const int Cc = k.Cin;
+        tape.push_back([=]() {
+          float* g = G(h2, (size_t)B * Cc * Ho * Wo);
+          float* gx = G(h1, (size_t)B * Cc * Hc * Wc);
+          if (live()) chk(launch_dwconv2d_s2_bwd(h1, g, w9, B, Cc, Hc, Wc, gx, PGpacked(w9), PG(dwb, Cc), st));
+        });
+        h = h2;
+      }
+      float* y = take<float>((size_t)B * k.Cout * Ho * Wo);
+      conv2d(k.c2, h, k.Cin, Ho, Wo, y, Ho, Wo, 1, 1, PRO_LRELU, r2, res);
+      if (!res) {  // identity shortcut: y += x / sqrt2
+        const size_t n = (size_t)B * k.Cout * Ho * Wo;
+        if (live()) chk(launch_axpy(xin, r2, y, n, st));
+        tape.push_back([=]() {
+          float* g = G(y, n);
+          float* gx = G(xin, n);
+          if (live()) chk(launch_axpy(g, r2, gx, n, st));
+        });
+      }
+      x = y;
+      H = Ho;
+      W = Wo;
+      C = k.Cout;
+    }
+    const int KH = 5;
+    const int Hh = H - KH + 1, Wh = W - sp.head.K + 1;
+    if (Hh < 1 || Wh < 1) {
+      set_error("style encoder: input too short (need T >= 40 frames)");
+      rc = STY_ESHAPE;
+      return;
+    }
+    float* hd = take<float>((size_t)B * C * Hh * Wh);
+    conv2d(sp.head, x, C, H, W, hd, Hh, Wh, 0, 0, PRO_LRELU, 1.f, nullptr);
+    style_out = style_dst;
+    if (live()) chk(launch_pool_fc(hd, B, C, Hh * Wh, sp.fc_w, sp.fc_b, sp.style_dim, style_dst, st));
+    const float* fw = sp.fc_w;
+    const float* fb = sp.fc_b;
+    const int S = sp.style_dim, HW = Hh * Wh, Cc = C;
+    tape.push_back([=]() {
+      float* gs = G(style_dst, (size_t)B * S);
+      float* gx = G(hd, (size_t)B * Cc * HW);
+      if (live()) chk(launch_pool_fc_bwd(hd, B, Cc, HW, fw, S, gs, PG(fw, (size_t)S * Cc), PG(fb, S), gx, st));
+    });
+  }
+  void style_backward(const float* d_style) {
+    const size_t n = (size_t)B * m->sty_enc.style_dim;
+    float* g = G(style_out, n);
+    if (live() && d_style) {
+      hipError_t e = hipMemcpyAsync(g, d_style, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "seed copy");
+    }
+    for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
+      (*it)();
+      if (rc != STY_OK) return;
+    }
+  }
+
   void begin(const float* style_in) {
     style = style_in;
     tape.clear();
@@ -842,6 +1018,41 @@ int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, fl
     hipError_t e = hipMemcpyAsync(d_energy, g, (size_t)t->B * t->T * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) t->rc = hip_fail(e, "d_energy copy");
   }
+  if (t->ws.overflow) {
+    set_error("training workspace too small in backward: need %zu bytes", t->peak);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_style_forward(Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
+                          hipStream_t st, size_t* need) {
+  t->st = st;
+  t->B = B;
+  t->T = T;
+  t->rc = STY_OK;
+  t->ws = Bump();
+  t->dry = need != nullptr;
+  t->ws.base = need ? reinterpret_cast<char*>(size_t(1) << 30) : (char*)ws;
+  t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
+  t->peak = 0;
+  t->style_forward(need ? reinterpret_cast<const float*>(8) : mel, T, need ? reinterpret_cast<float*>(16) : style);
+  if (need) {
+    if (t->rc == STY_OK) t->style_backward(nullptr);
+    *need = align_up(t->peak, 256) + (16 << 20);
+    t->tape.clear();
+    return t->rc;
+  }
+  if (t->ws.overflow) {
+    set_error("training workspace too small: need %zu bytes, have %zu", t->peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_style_backward(Trainer* t, const float* d_style, hipStream_t st) {
+  t->st = st;
+  t->style_backward(d_style);
   if (t->ws.overflow) {
     set_error("training workspace too small in backward: need %zu bytes", t->peak);
     return STY_ENOMEM;

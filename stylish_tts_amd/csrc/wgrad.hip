@@ -33,24 +33,26 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   for (int i = 0; i < NACC; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const int total = ax.B * chunks_per_b;
+  const int HM = ax.H ? ax.H : 1;  // 2-D mode: one chunk list per (b, output row h)
+  const int total = ax.B * HM * chunks_per_b;
   constexpr int MAXJ = (WG_TW + 128 + 1 + 63) / 64;
   for (int ch = split; ch < total; ch += nsplit) {
-    const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
+    const int bh = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
+    const int b = bh / HM, h = bh % HM;
     __syncthreads();
     switch (ax.pro) {
-      case PRO_AFFINE: stage_chunk<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
-      case PRO_SCALE: stage_chunk<PRO_SCALE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
-      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
-      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
-      case PRO_MASK: stage_chunk<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
-      case PRO_LRELU: stage_chunk<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
-      default: stage_chunk<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, 0, t0, LWx, wave, lane); break;
+      case PRO_AFFINE: stage_chunk<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
+      case PRO_SCALE: stage_chunk<PRO_SCALE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
+      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
+      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
+      case PRO_MASK: stage_chunk<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
+      case PRO_LRELU: stage_chunk<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
+      default: stage_chunk<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
     }
     if (ag.pro == PRO_MASK)
-      stage_chunk<PRO_MASK, 4, MAXJ>(ag, gs, co0, b, 0, t0, LWg, wave, lane);
+      stage_chunk<PRO_MASK, 4, MAXJ>(ag, gs, co0, b, h, t0, LWg, wave, lane);
     else
-      stage_chunk<PRO_NONE, 4, MAXJ>(ag, gs, co0, b, 0, t0, LWg, wave, lane);
+      stage_chunk<PRO_NONE, 4, MAXJ>(ag, gs, co0, b, h, t0, LWg, wave, lane);
     __syncthreads();
     if constexpr (KT == 0) {
       // K == 1: each wave reduces its quarter of the chunk
@@ -112,7 +114,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nslic
   gwp[i] += s * scale;
 }
 
-size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {
+size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x output rows in 2-D mode
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks = B * cdiv(T, WG_TW);
   int nsplit = 512 / tiles;
@@ -126,10 +128,6 @@ size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {
 // gmask: optional [B][T] multiplier of g; scale: constant factor (the forward out_scale); gwp += result.
 int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask, float scale, float* gwp,
                         float* partial, hipStream_t st) {
-  if (fwd.H) {
-    set_error("wgrad: 2-D mode not built");
-    return STY_EINVAL;
-  }
   const PackedConv& w = fwd.w;
   ConvArgs ax = fwd;
   ax.pad = fwd.pad;  // staging start t0 - pad
@@ -146,9 +144,16 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   ag.in_shuffle = fwd.shuffle > 1 ? fwd.shuffle : 0;
   ag.pro = gmask ? PRO_MASK : PRO_NONE;
   ag.mask = gmask;
+  if (fwd.H) {  // 2-D mode: G is [B][Cout][H][T]
+    ag.H = fwd.H;
+    ag.Hin = fwd.H;
+    ag.hpad = 0;
+    ag.Cin2d = w.Cout;
+  }
+  const int HM = fwd.H ? fwd.H : 1;
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks_per_b = cdiv(fwd.T, WG_TW);
-  const int chunks = fwd.B * chunks_per_b;
+  const int chunks = fwd.B * HM * chunks_per_b;
   int nsplit = 512 / tiles;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > chunks) nsplit = chunks;
@@ -258,6 +263,82 @@ int launch_unpack_grad(const float* gwp, const float* g, const float* v, int Cou
                        int glu, float* dW, float* dg, float* dv, hipStream_t st) {
   hipLaunchKernelGGL(unpack_grad_kernel, dim3(Cout), dim3(256), 0, st, gwp, g, v, Cout, Cin, K, CinP, CoutP, glu, dW,
                      dg, dv);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// 2-D: Wd[kw'][kh'*Cout + co][ci] = Wp[KW-1-kw'][(KH-1-kh')*Cin + ci][co]
+__global__ void pack_dgrad2d_kernel(const float* __restrict__ wp, int KW, int KH, int Cin, int Cout, int CinP,
+                                    int CoutP, int CinPd, int CoutPd, float* __restrict__ wd) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)KW * KH * Cout * Cin;
+  if (i >= n) return;
+  const int ci = (int)(i % Cin);
+  const int co = (int)((i / Cin) % Cout);
+  const int kh = (int)((i / ((size_t)Cin * Cout)) % KH);
+  const int kw = (int)(i / ((size_t)Cin * Cout * KH));
+  wd[((size_t)kw * CinPd + kh * Cout + co) * CoutPd + ci] =
+      wp[((size_t)(KW - 1 - kw) * CinP + (KH - 1 - kh) * Cin + ci) * CoutP + co];
+}
+int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int CinP, int CoutP, int CinPd, int CoutPd,
+                        float* wd, hipStream_t st) {
+  const size_t n = (size_t)KW * KH * Cout * Cin;
+  hipLaunchKernelGGL(pack_dgrad2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wp, KW, KH, Cin, Cout,
+                     CinP, CoutP, CinPd, CoutPd, wd);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// spectral norm (eval mode, fixed u, v): W_eff = W / sigma, sigma = u^T W v
+//   dW[co][i] += G[co][i]/sigma - (<G, W>/sigma^2) u[co] v[i],   G taken from the packed gradient.
+// t[co] = u[co] <W[co,:], v> (sn_rowdot_kernel) gives sigma = sum t.  Two kernels: <G,W> per row, then apply.
+__global__ __launch_bounds__(256) void sn_gw_rowdot_kernel(const float* __restrict__ gwp, const float* __restrict__ w,
+                                                           int Cin, int KH, int KW, int CinP, int CoutP,
+                                                           float* __restrict__ gw) {
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  const int n = Cin * KH * KW;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int kw = i % KW, kh = (i / KW) % KH, ci = i / (KW * KH);
+    s = fmaf(gwp[((size_t)kw * CinP + kh * Cin + ci) * CoutP + co], w[(size_t)co * n + i], s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gw[co] = red[0];
+}
+__global__ __launch_bounds__(256) void sn_unpack_kernel(const float* __restrict__ gwp, const float* __restrict__ t,
+                                                        const float* __restrict__ gw, const float* __restrict__ u,
+                                                        const float* __restrict__ v, int Cout, int Cin, int KH, int KW,
+                                                        int CinP, int CoutP, float* __restrict__ dW) {
+  __shared__ float sig, dot;
+  const int co = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float s = 0.f, d = 0.f;
+    for (int i = 0; i < Cout; ++i) {
+      s += t[i];
+      d += gw[i];
+    }
+    sig = s;
+    dot = d;
+  }
+  __syncthreads();
+  const int n = Cin * KH * KW;
+  const float inv = 1.0f / sig, k = dot * inv * inv;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int kw = i % KW, kh = (i / KW) % KH, ci = i / (KW * KH);
+    dW[(size_t)co * n + i] += gwp[((size_t)kw * CinP + kh * Cin + ci) * CoutP + co] * inv - k * u[co] * v[i];
+  }
+}
+int launch_sn_unpack(const float* gwp, const float* w, const float* u, const float* v, const float* t, int Cout,
+                     int Cin, int KH, int KW, int CinP, int CoutP, float* gw_scratch, float* dW, hipStream_t st) {
+  hipLaunchKernelGGL(sn_gw_rowdot_kernel, dim3(Cout), dim3(256), 0, st, gwp, w, Cin, KH, KW, CinP, CoutP, gw_scratch);
+  hipLaunchKernelGGL(sn_unpack_kernel, dim3(Cout), dim3(256), 0, st, gwp, t, gw_scratch, u, v, Cout, Cin, KH, KW, CinP,
+                     CoutP, dW);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -64,6 +64,9 @@ SYMBOLS = {
     "sty_speech_train_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
     "sty_speech_fwd_train": (C.c_int, [_P, C.POINTER(SpeechIO), _P, C.c_size_t, _P]),
     "sty_speech_bwd": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sty_style_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
+    "sty_style_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
+    "sty_style_bwd": (C.c_int, [_P, _P, _P]),
     "sty_acoustic_loss_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
     "sty_acoustic_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "sty_prof_enable": (C.c_int, [_I]),

@@ -378,3 +378,28 @@ class MelStyleEncoder(_HipModule):
         L.check(lib.sty_style_fwd(self._handle, B, T, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
                                   C.c_void_p(ws.data_ptr()), ws.numel(), st))
         return out
+
+    def forward_train(self, x):
+        """MelStyleEncoder.forward in the training graph; follow with backward(d_style)."""
+        dev = x.device
+        self._train = True
+        lib = self._ensure(dev)
+        B, _, _, T = x.shape
+        x = _f32(x.detach(), dev)
+        out = torch.empty(B, self.cfg["style_dim"], dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_style_train_workspace_bytes(self._handle, B, T, C.byref(need)))
+        if getattr(self, "_train_ws", None) is None or self._train_ws.numel() < need.value:
+            self._train_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self._train_keep = [x]
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_style_fwd_train(self._handle, B, T, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(self._train_ws.data_ptr()), self._train_ws.numel(), st))
+        return out
+
+    def backward(self, d_style):
+        """d loss / d style [B,64]; parameter gradients are added to param.grad."""
+        lib = L.load()
+        d_style = _f32(d_style, d_style.device)
+        st = C.c_void_p(torch.cuda.current_stream(d_style.device).cuda_stream)
+        L.check(lib.sty_style_bwd(self._handle, L.ptr(d_style), st))

@@ -547,3 +547,35 @@ def test_acoustic_losses_forward_backward():
     cos = torch.nn.functional.cosine_similarity(d.cpu().flatten(), ref.flatten(), dim=0).item()
     print(f"  d_audio: relative L2 error {rel:.3e}, cosine {cos:.6f}, max|ref| {ref.abs().max().item():.3e}")
     assert rel <= 2e-2 and cos >= 0.9995
+
+
+@pytest.mark.parametrize("T", [80, 161])
+def test_mel_style_encoder_backward(T):
+    """A2 backward: gradients of every MelStyleEncoder parameter (through the eval-mode spectral norm) vs the
+    oracle's autograd.  T=161 exercises the odd-width column replication of the average-pool shortcut."""
+    import stylish_tts_amd as S
+    from oracle import style_encoder as ose
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    P = fill_state_dict(style_encoder_manifest(), 0)
+    m = S.MelStyleEncoder()
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).enable_training()
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(2, 1, 80, T, generator=g) * 0.8 - 0.3
+    cot = torch.randn(2, 64, generator=g)
+    out = m.forward_train(dev(x))
+    m.backward(dev(cot))
+    torch.cuda.synchronize()
+    Pr = {k: v.clone() for k, v in P.items()}
+    names = [k for k, _ in m.named_parameters()]
+    for k in names:
+        Pr[k].requires_grad_(True)
+    ref = ose.mel_style_encoder(Pr, "", x)
+    (ref * cot).sum().backward()
+    rep = Report()
+    rep.add("style (training graph)", out, ref.detach(), 1e-5)
+    named = dict(m.named_parameters())
+    for k in names:
+        rep.add("d " + k[-44:], named[k].grad, Pr[k].grad, 2e-3)
+    rep.done()
