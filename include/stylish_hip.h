@@ -167,6 +167,11 @@ int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *sty
                         void *stream);
 int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
 
+/* ---- optimizer: torch.optim.AdamW (train/optimizers.py:110-118) over one flat fp32 bucket ------------------
+ * p, g, m, v: n floats each, 16-byte aligned, identically laid out; step = 1, 2, ... (bias correction).          */
+int sty_adamw_step(size_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, void *stream);
+
 /* ---- acoustic-stage losses without third-party models, forward + backward in one call ---------------
  * mel  = MultiResolutionSTFTLoss (train/losses.py:17-38) on log1p(mel128|X|); multi_phase = losses.py:41-91;
  * seed = w_mel*mel/(mel.detach()+1e-9) + w_phase*multi_phase/(multi_phase.detach()+1e-9)  (loss_log.py:82-94).

@@ -50,3 +50,52 @@ def acoustic_forward(speech_predictor, style_encoder, *, audio_gt, texts, text_l
             (o.target_spec, o.pred_spec, o.target_phase, o.pred_phase, o.target_fft, o.pred_fft) = multi_spectrogram(
                 target=audio_gt, pred=o.pred.audio.squeeze(1))
     return o
+
+
+class AcousticTrainer:
+    """train_acoustic + optimizer_step (train/stage_type.py:346-373, train/stage.py:104-124) for the two acoustic
+    losses that need no third-party model (mel spectral convergence + multi-phase; GAN / WavLM terms are off):
+
+        zero_grad -> AcousticStep forward -> LossLog.backwards_loss() seed -> backward through the predictor and the
+        style encoder -> gradient mean over ranks -> AdamW step of both models.
+
+    Eval-mode statistics (BatchNorm running stats, no dropout / F0 smoothing, fixed spectral-norm u, v).
+    One process per GPU: every rank runs this on its own utterances; the only exchange is the bucketed gradient
+    all-reduce, started for the predictor's buckets before the style encoder's backward runs."""
+
+    def __init__(self, speech_predictor, style_encoder, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4,
+                 w_mel=5.0, w_phase=8.0, mean=-4.0, std=4.0, bucket_bytes=25 << 20):
+        from .optim import FlatAdamW
+        self.sp, self.se = speech_predictor.enable_training(), style_encoder.enable_training()
+        self.w_mel, self.w_phase, self.mean, self.std = w_mel, w_phase, mean, std
+        kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, bucket_bytes=bucket_bytes)
+        # one optimizer per model key, as train/optimizers.py:106-118 builds them
+        self.opt = {"speech_predictor": FlatAdamW(list(self.sp.parameters()), **kw),
+                    "speech_style_encoder": FlatAdamW(list(self.se.parameters()), **kw)}
+
+    def train_batch(self, *, audio_gt, texts, text_lengths, pitch, durations, noise=None, seed=0,
+                    prior_override=None):
+        """One optimizer step; returns the (mel, multi_phase) loss values as a device tensor [2]."""
+        from .losses import acoustic_loss
+        for o in self.opt.values():
+            o.zero_grad()
+        mel, _, energy = calculate_mel(audio_gt, TO_MEL, self.mean, self.std, want_energy=True)
+        style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)
+        T = mel.shape[2]
+        alignment = duration_to_alignment(durations, T)
+        style = self.se.forward_train(style_mel.unsqueeze(1))
+        voiced = (pitch > 20).float()
+        audio = self.sp.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, pitch,
+                                      noise=noise, seed=seed, prior_override=prior_override)
+        losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase)
+        d_style, _ = self.sp.backward(d_audio, want_style=True, want_energy=False)
+        gp, gs = self.opt["speech_predictor"].grads, self.opt["speech_style_encoder"].grads
+        gp.reduce_all()                 # overlaps the style encoder's backward
+        self.se.backward(d_style)
+        gs.reduce_all()
+        gp.finish()
+        gs.finish()
+        for o in self.opt.values():
+            o.step()
+        self.audio = audio
+        return losses

@@ -1,0 +1,72 @@
+// AdamW over a flat fp32 bucket (parameters, gradients and both moments are contiguous and equally laid out), the
+// arithmetic order of torch.optim.AdamW's single-tensor path (torch/optim/adamw.py -> adam.py _single_tensor_adam):
+//   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2*v + (1-b2)*g*g;
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// as used by the reference (train/optimizers.py:110-118: AdamW, eps 1e-9, betas (0.85, 0.99), weight decay 1e-4).
+// One pass: 4 reads + 3 writes per element, HBM-bound (28 B/element).
+#include "sty_common.h"
+
+namespace sty {
+
+__global__ __launch_bounds__(256) void adamw_kernel(size_t n4, size_t n, float4* __restrict__ p,
+                                                    const float4* __restrict__ g, float4* __restrict__ m,
+                                                    float4* __restrict__ v, float decay, float w1, float b2, float w2,
+                                                    float step_size, float bc2s, float eps) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    pp *= decay;
+    mm = mm + w1 * (gg - mm);
+    vv = vv * b2 + w2 * gg * gg;
+    const float denom = sqrtf(vv) / bc2s + eps;
+    pp = pp - step_size * (mm / denom);
+  };
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 pv = p[i], mv = m[i], vv = v[i];
+    const float4 gv = g[i];
+    upd(pv.x, gv.x, mv.x, vv.x);
+    upd(pv.y, gv.y, mv.y, vv.y);
+    upd(pv.z, gv.z, mv.z, vv.z);
+    upd(pv.w, gv.w, mv.w, vv.w);
+    p[i] = pv;
+    m[i] = mv;
+    v[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0) {
+    float* ps = reinterpret_cast<float*>(p);
+    const float* gs = reinterpret_cast<const float*>(g);
+    float* ms = reinterpret_cast<float*>(m);
+    float* vs = reinterpret_cast<float*>(v);
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) upd(ps[i], gs[i], ms[i], vs[i]);
+  }
+}
+
+int launch_adamw(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, hipStream_t st) {
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2s = (float)sqrt(bc2);
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  ProfScope prof("adamw", 12.0 * n, 28.0 * n, st);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n4, n, reinterpret_cast<float4*>(p),
+                     reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v),
+                     1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2s, eps);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty
+
+extern "C" int sty_adamw_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, void* stream) {
+  using namespace sty;
+  if (!p || !g || !m || !v || step < 1 || ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) {
+    set_error("sty_adamw_step: null / unaligned (16 B) buffer or step < 1");
+    return STY_EINVAL;
+  }
+  if (n == 0) return STY_OK;
+  return launch_adamw(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, reinterpret_cast<hipStream_t>(stream));
+}

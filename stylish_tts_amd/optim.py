@@ -1,0 +1,41 @@
+"""AdamW on flat buckets (train/optimizers.py:110-118: AdamW(lr, weight_decay=1e-4, betas=(0.85, 0.99), eps=1e-9)).
+
+Parameters, gradients and both moments of a bucket are contiguous and identically laid out (`dist.GradBuckets`), so
+the optimizer step is ONE HBM-bound kernel per bucket (sty_adamw_step) instead of a few kernels per parameter tensor.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .dist import GradBuckets
+
+
+class FlatAdamW:
+    def __init__(self, params, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4, bucket_bytes=25 << 20):
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.grads = GradBuckets(params, bucket_bytes)
+        self.grads.attach()
+        self.flat_p, self.m, self.v = [], [], []
+        for gflat, items in self.grads.buckets:
+            pflat = torch.empty_like(gflat)
+            for p, off, n in items:  # move the parameter storage into the bucket
+                pflat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = pflat[off:off + n].view_as(p)
+            self.flat_p.append(pflat)
+            self.m.append(torch.zeros_like(gflat))
+            self.v.append(torch.zeros_like(gflat))
+        self.t = 0
+
+    def zero_grad(self):
+        self.grads.zero()
+
+    def step(self):
+        lib = L.load()
+        self.t += 1
+        for (gflat, _), p, m, v in zip(self.grads.buckets, self.flat_p, self.m, self.v):
+            if not gflat.is_cuda:
+                raise L.StyError("FlatAdamW.step: parameters must live on the GPU (there is no CPU path)")
+            st = C.c_void_p(torch.cuda.current_stream(gflat.device).cuda_stream)
+            L.check(lib.sty_adamw_step(gflat.numel(), L.ptr(p), L.ptr(gflat), L.ptr(m), L.ptr(v), self.lr,
+                                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, st))

@@ -579,3 +579,97 @@ def test_mel_style_encoder_backward(T):
     for k in names:
         rep.add("d " + k[-44:], named[k].grad, Pr[k].grad, 2e-3)
     rep.done()
+
+
+def test_adamw_matches_torch():
+    """sty_adamw_step on a flat bucket vs torch.optim.AdamW (the reference's optimizer, optimizers.py:110-118)."""
+    from stylish_tts_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(33, 7), (129,), (4, 5, 3), (1,), (1000,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=1e-3, weight_decay=1e-4, betas=(0.85, 0.99), eps=1e-9)
+    opt = FlatAdamW(hip_p, lr=1e-3, weight_decay=1e-4, betas=(0.85, 0.99), eps=1e-9, bucket_bytes=4096)
+    assert len(opt.grads.buckets) > 1
+    for it in range(4):
+        for pr, ph in zip(ref_p, hip_p):
+            gr = torch.randn(pr.shape, generator=g) * (10.0 ** (it - 2))
+            pr.grad = gr.clone()
+            ph.grad.copy_(gr)
+        ref.step()
+        opt.step()
+    torch.cuda.synchronize()
+    for pr, ph in zip(ref_p, hip_p):
+        err = (ph.detach().cpu() - pr.detach()).abs().max().item()
+        assert err <= 2e-6, err
+
+
+def _train_setup(env, lr):
+    import stylish_tts_amd as S
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from stylish_tts_amd.acoustic import AcousticTrainer
+    P = {k: v.clone() for k, v in env["P"].items()}
+    Pse = fill_state_dict(style_encoder_manifest(), 0)
+    sp = S.SpeechPredictor()
+    sp.load_state_dict(P, strict=False)
+    se = S.MelStyleEncoder()
+    se.load_state_dict(Pse)
+    tr = AcousticTrainer(sp.to(DEV), se.to(DEV), lr=lr)
+    return tr, P, Pse
+
+
+def test_acoustic_train_step_gradients(env):
+    """A0 forward+backward assembled (mel -> style encoder -> predictor -> losses -> backward of both models):
+    losses and parameter gradients of ONE train_acoustic step (lr = 0) vs the oracle's autograd."""
+    from oracle import losses as ol, speech_predictor as osp
+    cs = env["cs"]
+    B, T = cs["pitch"].shape
+    audio_gt = _test_audio(B, 300 * T, 21)
+    tr, P, Pse = _train_setup(env, 0.0)
+    want = {}
+    sp_keys = ["generator.amp_output_conv.weight", "generator.phase_output_real_conv.bias",
+               "decoder.decode.0.norm1.fc.weight", "text_encoder.proj_m.weight", "text_encoder.emb.weight",
+               "generator.conformer.ff1.1.weight" if "generator.conformer.ff1.1.weight" in P else None]
+    sp_keys = [k for k in sp_keys if k and k in P and P[k].is_floating_point()]
+    se_keys = ["shared.0.weight_orig", "shared.2.conv1.weight_orig", "shared.4.conv2.bias", "unshared.weight"]
+    for k in sp_keys:
+        P[k].requires_grad_(True)
+    for k in se_keys:
+        Pse[k].requires_grad_(True)
+    ref = osp.acoustic_forward(P, Pse, audio_gt, cs["texts"], cs["text_lengths"], cs["pitch"], cs["durations"],
+                               cs["noise"], want)
+    mel, mph, tot = ol.acoustic_losses(audio_gt, ref.squeeze(1))
+    tot.backward()
+    losses = tr.train_batch(audio_gt=dev(audio_gt), texts=dev(cs["texts"]), text_lengths=dev(cs["text_lengths"]),
+                            pitch=dev(cs["pitch"]), durations=dev(cs["durations"]), noise=dev(cs["noise"]),
+                            prior_override=dev(want["prior"]))
+    torch.cuda.synchronize()
+    print(f"\n  mel {losses[0].item():.6f} vs {mel.item():.6f}   multi_phase {losses[1].item():.6f} vs {mph.item():.6f}")
+    assert abs(losses[0].item() - mel.item()) <= 1e-4 * abs(mel.item())
+    assert abs(losses[1].item() - mph.item()) <= 1e-3 * abs(mph.item())
+    rep = Report()
+    nsp, nse = dict(tr.sp.named_parameters()), dict(tr.se.named_parameters())
+    for k in sp_keys:
+        rep.add("d " + k[-44:], nsp[k].grad, P[k].grad, 5e-2)
+        rep.add("p " + k[-44:], nsp[k], P[k].detach(), 1e-7)  # lr = 0: parameters untouched
+    for k in se_keys:
+        rep.add("d se." + k[-40:], nse[k].grad, Pse[k].grad, 5e-2)
+    rep.done()
+
+
+def test_acoustic_training_reduces_loss(env):
+    """A few optimizer steps on one fixed batch lower both losses (forward, backward, AdamW and the weight
+    re-preparation between steps all act on the same parameters)."""
+    cs = env["cs"]
+    B, T = cs["pitch"].shape
+    audio_gt = _test_audio(B, 300 * T, 21)
+    tr, _, _ = _train_setup(env, 2e-4)
+    hist = []
+    for it in range(6):
+        losses = tr.train_batch(audio_gt=dev(audio_gt), texts=dev(cs["texts"]), text_lengths=dev(cs["text_lengths"]),
+                                pitch=dev(cs["pitch"]), durations=dev(cs["durations"]), noise=dev(cs["noise"]))
+        hist.append(losses.cpu().tolist())
+    print("\n  (mel, multi_phase) per step: " + "  ".join(f"({a:.4f},{b:.4f})" for a, b in hist))
+    assert all(torch.isfinite(torch.tensor(hist)).flatten().tolist())
+    assert hist[-1][0] < hist[0][0]
