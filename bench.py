@@ -5,8 +5,13 @@
 
 A step is one pass of the hot path over one synthetic batch already resident in HBM:
   c2 (default; BASELINE.json configs[1]): sample_dataset shape, B=16 utterances of T=160 mel frames (2.0 s),
-      L=37 phoneme tokens, fp32 -- the AcousticStep forward (mel x2 + energy, alignment, style encoder, text encoder,
-      alignment expand, decoder, vocoder, 3-resolution STFT features of target and prediction).  The metric's backward half is NOT built yet: `config.pass` says so and DESIGN.md lists it as open.
+      L=37 phoneme tokens, fp32 -- one train_acoustic step (train/stage_type.py:346-373 + stage.py:124):
+      AcousticStep forward (mel x2 + energy, alignment, style encoder, text encoder, alignment expand, decoder,
+      vocoder), mel + multi-phase losses through the 3-resolution STFT features, backward through the predictor and
+      the style encoder, gradient all-reduce (N > 1) and the AdamW step of both models.  GAN / WavLM loss terms are
+      off (third-party models); eval-mode normalisation statistics.
+  c2-fwd: the forward half only (AcousticStep forward + the six multi-spectrogram lists).
+  c3-fp32: LJSpeech shape, B=32, T=520, L=100, the same training step in fp32 (the bf16 variant is not built).
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
@@ -24,8 +29,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    "c2": dict(B=16, T=160, L=37, what="speech_predictor"),
+    "c2": dict(B=16, T=160, L=37, what="train"),
+    "c2-fwd": dict(B=16, T=160, L=37, what="forward"),
+    "c3-fp32": dict(B=32, T=520, L=100, what="train"),
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
+}
+PASS = {
+    "train": "forward + backward + AdamW (mel + multi-phase losses; GAN/WavLM terms off; eval-mode statistics)",
+    "forward": "forward only (AcousticStep forward + multi-spectrogram features)",
+    "vocoder": "vocoder forward only (inference)",
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
@@ -96,25 +108,42 @@ def _cpu_baseline_worker(w, q, budget_s):
     inp = make_inputs(dict(w, B=Bs), 99, "cpu")
     noise = torch.randn(Bs, 300 * T, 9)
 
+    if w["what"] == "train":
+        from oracle import losses as ol
+        for d in (P, Pse):
+            for v in d.values():
+                if v.is_floating_point():
+                    v.requires_grad_(True)
+        params = [v for d in (P, Pse) for v in d.values() if v.requires_grad]
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, betas=(0.85, 0.99), eps=1e-9)
+
     def once():
         t0 = time.perf_counter()
         if w["what"] == "vocoder":
-            ov.multi_generator(P, "generator", inp["mel"], inp["style"], inp["pitch"], inp["voiced"], noise)
-        else:
+            with torch.no_grad():
+                ov.multi_generator(P, "generator", inp["mel"], inp["style"], inp["pitch"], inp["voiced"], noise)
+        elif w["what"] == "train":
+            opt.zero_grad()
             a = osp.acoustic_forward(P, Pse, inp["audio_gt"], inp["texts"], inp["text_lengths"], inp["pitch"],
                                      inp["durations"], noise)
-            for fft, hop, win in frontend.RESOLUTIONS:
-                frontend.multi_spectrogram_single(a.squeeze(1), fft, hop, win)
-                frontend.multi_spectrogram_single(inp["audio_gt"], fft, hop, win)
+            ol.acoustic_losses(inp["audio_gt"], a.squeeze(1))[2].backward()
+            opt.step()
+        else:
+            with torch.no_grad():
+                a = osp.acoustic_forward(P, Pse, inp["audio_gt"], inp["texts"], inp["text_lengths"], inp["pitch"],
+                                         inp["durations"], noise)
+                for fft, hop, win in frontend.RESOLUTIONS:
+                    frontend.multi_spectrogram_single(a.squeeze(1), fft, hop, win)
+                    frontend.multi_spectrogram_single(inp["audio_gt"], fft, hop, win)
         return time.perf_counter() - t0
 
     usable = _usable_cpus()
     t_all = time.perf_counter()
     best, best_thr, n_timed = None, None, 0
-    with torch.no_grad():
+    if True:
         # ATen's CPU kernels on this op mix (tiny-channel convs, elementwise) get slower when the OpenMP team is
         # larger than the cores actually granted; try a few team sizes and report the one used.
-        for thr in sorted({min(usable, t) for t in (8, 16, 32, 64)}):
+        for thr in sorted({min(usable, t) for t in ((16, 32) if w["what"] == "train" else (8, 16, 32, 64))}):
             torch.set_num_threads(thr)
             once()
             for _ in range(2):
@@ -124,7 +153,7 @@ def _cpu_baseline_worker(w, q, budget_s):
                     best, best_thr = dt, thr
                 q.put(dict(value=Bs * T / best, unit="frames/s", cores=best_thr, kind="port",
                            host_cores=os.cpu_count(), usable_cores=usable,
-                           sample=f"oracle forward, B={Bs}, T={T}; best of {n_timed} timed iterations "
+                           sample=f"oracle {PASS[w['what']].split(' (')[0]}, B={Bs}, T={T}; best of {n_timed} timed iterations "
                                   f"(1 warm-up per OpenMP team size), {time.perf_counter() - t_all:.1f} s of CPU work"))
             if time.perf_counter() - t_all > budget_s:
                 break
@@ -172,18 +201,22 @@ def main():
     lib = L.load()
     w = WORKLOADS[args.workload]
     model, style_enc, P = build_model(device)
-    from stylish_tts_amd.acoustic import acoustic_forward
+    from stylish_tts_amd.acoustic import AcousticTrainer, acoustic_forward
     from stylish_tts_amd.frontend import MultiSpectrogram
     mspec = MultiSpectrogram(sample_rate=24000)
     inp = make_inputs(w, 1000 + rank, device)
     B, T = w["B"], w["T"]
+    trainer = AcousticTrainer(model, style_enc, lr=1e-4) if w["what"] == "train" else None
 
     def step(i):
+        if w["what"] == "train":
+            # one train_acoustic step incl. gradient all-reduce and optimizer; returns the loss values
+            return trainer.train_batch(audio_gt=inp["audio_gt"], texts=inp["texts"], text_lengths=inp["text_lengths"],
+                                       pitch=inp["pitch"], durations=inp["durations"], seed=i)
         with torch.no_grad():
             if w["what"] == "vocoder":
                 return model.vocoder_forward(mel=inp["mel"], style=inp["style"], pitch=inp["pitch"],
                                              voiced=inp["voiced"], seed=i).audio
-            # the whole AcousticStep forward: mel x2 + energy, alignment, style encoder, predictor, 3-res STFT features
             o = acoustic_forward(model, style_enc, audio_gt=inp["audio_gt"], texts=inp["texts"],
                                  text_lengths=inp["text_lengths"], pitch=inp["pitch"], durations=inp["durations"],
                                  T=T, seed=i, multi_spectrogram=mspec)
@@ -204,7 +237,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     lib.sty_prof_enable(0)
-    prof = L.prof_report() if rank == 0 else []
+    prof = L.prof_report(2048) if rank == 0 else []
     assert bool(torch.isfinite(out).all())
     dt = D.max_over_ranks(dt, device)
     if rank != 0:
@@ -215,9 +248,8 @@ def main():
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {w['what']} B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
-                   "pass": "forward only -- backward kernels are not built yet, so this is NOT yet the "
-                           "forward+backward metric (DESIGN.md, open items)",
+        "config": {"workload": f"{args.workload}: B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
+                   "pass": PASS[w["what"]],
                    "x_realtime": frames / dt / 80.0},
     }
     if prof:

@@ -24,7 +24,7 @@ int hip_fail(hipError_t e, const char* what) {
 // in-situ kernel timing
 // ---------------------------------------------------------------------------------------------------
 struct ProfEntry {
-  const char* family;
+  std::string family;
   double flops, bytes;
   hipEvent_t a, b;
 };
@@ -41,9 +41,13 @@ static hipEvent_t prof_event() {
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
 }
-ProfScope::ProfScope(const char* family, double flops, double bytes, hipStream_t s) : st(s) {
+// STY_PROF_SHAPES=1: one row per (kernel family, problem shape) instead of one per family
+static const bool g_prof_shapes = getenv("STY_PROF_SHAPES") != nullptr;
+ProfScope::ProfScope(const char* family, double flops, double bytes, hipStream_t s, const char* detail) : st(s) {
   if (!g_prof_on) return;
-  ProfEntry e{family, flops, bytes, prof_event(), prof_event()};
+  std::string name(family);
+  if (g_prof_shapes && detail) name = name + " " + detail;
+  ProfEntry e{name, flops, bytes, prof_event(), prof_event()};
   if (!e.a || !e.b) return;
   (void)hipEventRecord(e.a, st);
   slot = (int)g_prof.size();
@@ -996,91 +1000,95 @@ struct Run {
 
 // MelStyleEncoder.forward (mel_style_encoder.py:147-152): mel [B][1][n_mels][T] -> style [B][style_dim]
 static void style_run(Run& r, const float* mel, int T, float* style) {
+  // padded-flat image layout (conv2d.hip): every activation is [B][C][H][W+1] with a zero last column
   const StylePlan& sp = r.m->sty_enc;
   const int B = r.B;
-  auto conv2d = [&](const PackedConv& w, const float* x, int Cin2d, int Hin, int Win, float* y, int Hout, int Wout,
-                    int hpad, int pad, int pro, float out_scale, const float* residual) {
+  auto conv2d = [&](const PackedConv& w, const float* x, int Cin2d, int n, int Wp, float* y, int hpad, int pad, int pro,
+                    float out_scale, const float* residual, const float* mask) {
     if (!r.live()) return;
     ConvArgs a;
     a.x[0] = x;
     a.xc[0] = w.Cin;
     a.nsrc = 1;
     a.B = B;
-    a.T = Wout;
-    a.Tin = Win;
+    a.T = n;
     a.pad = pad;
     a.w = w;
-    a.H = Hout;
-    a.Hin = Hin;
+    a.flatW = Wp;
     a.hpad = hpad;
     a.Cin2d = Cin2d;
     a.pro = pro;
     a.out_scale = out_scale;
     a.residual = residual;
+    a.out_mask = mask;
+    a.out_mask_post = 1;
     a.y = y;
     r.chk(launch_conv1d(a, r.st));
   };
+  auto mask_for = [&](int Hh, int Ww, int Hv, int Wv) {
+    float* mk = r.ws.take<float>((size_t)B * Hh * (Ww + 1));
+    if (r.live()) r.chk(launch_flat_mask(B, Hh, Ww + 1, Hv, Wv, mk, r.st));
+    return mk;
+  };
   const float r2 = 0.70710678118654752f;
   int H = sp.n_mels, W = T, C = sp.n_mels;
-  float* x = r.ws.take<float>((size_t)B * C * H * W);
-  conv2d(sp.stem, mel, 1, H, W, x, H, W, 1, 1, PRO_NONE, 1.f, nullptr);
+  float* melp = r.ws.take<float>((size_t)B * H * (W + 1));
+  if (r.live()) r.chk(launch_pad_cols(mel, (size_t)B * H, W, melp, r.st));
+  const float* mk = mask_for(H, W, H, W);
+  float* x = r.ws.take<float>((size_t)B * C * H * (W + 1));
+  conv2d(sp.stem, melp, 1, H * (W + 1), W + 1, x, 1, 1, PRO_NONE, 1.f, nullptr, mk);
   for (int i = 0; i < 4; ++i) {
     const StyleResBlk& k = sp.blk[i];
     const int Ho = k.down ? H / 2 : H, Wo = k.down ? (W + 1) / 2 : W;
-    float* sc_full = r.ws.take<float>((size_t)B * k.Cout * H * W);
-    float* sc = r.ws.take<float>((size_t)B * k.Cout * Ho * Wo);
-    float* h1 = r.ws.take<float>((size_t)B * k.Cin * H * W);
-    float* h2 = r.ws.take<float>((size_t)B * k.Cin * Ho * Wo);
-    float* y = r.ws.take<float>((size_t)B * k.Cout * Ho * Wo);
+    const int n = H * (W + 1), no = Ho * (Wo + 1);
+    const float* mko = k.down ? mask_for(Ho, Wo, Ho, Wo) : mk;
+    float* sc_full = r.ws.take<float>((size_t)B * k.Cout * n);
+    float* sc = r.ws.take<float>((size_t)B * k.Cout * no);
+    float* h1 = r.ws.take<float>((size_t)B * k.Cin * n);
+    float* h2 = r.ws.take<float>((size_t)B * k.Cin * no);
+    float* y = r.ws.take<float>((size_t)B * k.Cout * no);
     // shortcut (scaled by 1/sqrt2 up front: pooling is linear)
     const float* sc_src = x;
     if (k.has_sc) {
-      conv2d(k.sc, x, k.Cin, H, W, sc_full, H, W, 0, 0, PRO_NONE, r2, nullptr);
+      conv2d(k.sc, x, k.Cin, n, W + 1, sc_full, 0, 0, PRO_NONE, r2, nullptr, mk);
       sc_src = sc_full;
     }
-    const float* res;
+    const float* res = nullptr;
     if (k.down) {
       if (r.live()) r.chk(launch_avgpool2(sc_src, B * k.Cout, H, W, k.has_sc ? 1.f : r2, sc, r.st));
       res = sc;
     } else if (k.has_sc) {
       res = sc_full;
-    } else {
-      // identity shortcut without pooling: scale by 1/sqrt2 via a pooling-free path is not needed by the
-      // reference configuration (last block: 384 -> 384, no downsample) -- handled through out_scale below
-      res = nullptr;
     }
     // residual branch
-    conv2d(k.c1, x, k.Cin, H, W, h1, H, W, 1, 1, PRO_LRELU, 1.f, nullptr);
+    conv2d(k.c1, x, k.Cin, n, W + 1, h1, 1, 1, PRO_LRELU, 1.f, nullptr, mk);
     const float* h = h1;
     if (k.down) {
       if (r.live()) r.chk(launch_dwconv2d_s2(h1, k.dw_w9, k.dw_b, B, k.Cin, H, W, h2, r.st));
       h = h2;
     }
-    if (res) {
-      conv2d(k.c2, h, k.Cin, Ho, Wo, y, Ho, Wo, 1, 1, PRO_LRELU, r2, res);
-    } else {
-      // out = (x + conv2(h)) / sqrt2 with identity shortcut: y = conv2 * r2, then add x * r2
-      conv2d(k.c2, h, k.Cin, Ho, Wo, y, Ho, Wo, 1, 1, PRO_LRELU, r2, nullptr);
-      if (r.live()) r.chk(launch_axpy(x, r2, y, (size_t)B * k.Cout * Ho * Wo, r.st));
-    }
+    conv2d(k.c2, h, k.Cin, no, Wo + 1, y, 1, 1, PRO_LRELU, r2, res, mko);
+    // identity shortcut (last block: 384 -> 384, no downsample): out = (x + conv2(h)) / sqrt2
+    if (!res && r.live()) r.chk(launch_axpy(x, r2, y, (size_t)B * k.Cout * no, r.st));
     x = y;
     H = Ho;
     W = Wo;
     C = k.Cout;
+    mk = mko;
   }
   // LeakyReLU -> 5x5 valid conv -> global mean -> LeakyReLU -> Linear
   const int KH = 5;
   const int Hh = H - KH + 1, Wh = W - sp.head.K + 1;
-  float* hd = r.ws.take<float>((size_t)B * C * (Hh > 0 ? Hh : 1) * (Wh > 0 ? Wh : 1));
-  if (r.live()) {
-    if (Hh < 1 || Wh < 1) {
-      set_error("style encoder: input too short (need T >= 40 frames)");
-      r.rc = STY_ESHAPE;
-      return;
-    }
+  const int n = H * (W + 1);
+  if (r.live() && (Hh < 1 || Wh < 1)) {
+    set_error("style encoder: input too short (need T >= 40 frames)");
+    r.rc = STY_ESHAPE;
+    return;
   }
-  conv2d(sp.head, x, C, H, W, hd, Hh, Wh, 0, 0, PRO_LRELU, 1.f, nullptr);
-  if (r.live()) r.chk(launch_pool_fc(hd, B, C, Hh * Wh, sp.fc_w, sp.fc_b, sp.style_dim, style, r.st));
+  const float* mkh = mask_for(H, W, Hh > 0 ? Hh : 0, Wh > 0 ? Wh : 0);
+  float* hd = r.ws.take<float>((size_t)B * C * n);
+  conv2d(sp.head, x, C, n, W + 1, hd, 0, 0, PRO_LRELU, 1.f, nullptr, mkh);
+  if (r.live()) r.chk(launch_pool_fc(hd, B, C, n, Hh * Wh, sp.fc_w, sp.fc_b, sp.style_dim, style, r.st));
   r.note_peak();
 }
 
@@ -1128,11 +1136,11 @@ int sty_prof_report(sty_prof_row* rows, int cap) {
     g_evpool.push_back(e.b);
     sty_prof_row* r = nullptr;
     for (auto& x : agg)
-      if (!strcmp(x.name, e.family)) r = &x;
+      if (!strncmp(x.name, e.family.c_str(), sizeof(x.name) - 1)) r = &x;
     if (!r) {
       sty_prof_row n;
       memset(&n, 0, sizeof(n));
-      strncpy(n.name, e.family, sizeof(n.name) - 1);
+      strncpy(n.name, e.family.c_str(), sizeof(n.name) - 1);
       agg.push_back(n);
       r = &agg.back();
     }

@@ -161,39 +161,69 @@ int launch_adain_stats(const double* part, int nseg, int rows, int T, float eps,
 
 // ---- LayerNorm over channels, backward.  dx per column; parameter sums per row. ----
 // y = xhat * A + Bv,  A = w[c] (ada = 0) or 1 + gb[b][c] (ada = 1);  relu / out_mask as in the forward.
-__global__ __launch_bounds__(64) void chan_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            const float* __restrict__ y, int C, int T, float eps,
-                                                            int ada, const float* __restrict__ w,
-                                                            const float* __restrict__ gb, int relu,
-                                                            const float* __restrict__ out_mask,
-                                                            float* __restrict__ dx, int accumulate,
-                                                            float* __restrict__ mu_out, float* __restrict__ r_out) {
-  const int t = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
-  if (t >= T) return;
-  const size_t base = (size_t)b * C * T + t;
-  float mean = 0.f;
-  for (int c = 0; c < C; ++c) mean += x[base + (size_t)c * T];
+// TC time columns x (256/TC) channel groups per workgroup; the per-column sums are combined through LDS in a fixed
+// order.  TC = 16 keeps >= 160 workgroups in flight for the short tensors (stage A: T = 160; text encoder: L ~ 40);
+// the first version ran one THREAD per column over all channels and left most of the chip idle there.
+template <int TC>
+__global__ __launch_bounds__(256) void chan_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ y, int C, int T, float eps,
+                                                             int ada, const float* __restrict__ w,
+                                                             const float* __restrict__ gb, int relu,
+                                                             const float* __restrict__ out_mask,
+                                                             float* __restrict__ dx, int accumulate,
+                                                             float* __restrict__ mu_out, float* __restrict__ r_out) {
+  constexpr int CG = 256 / TC;
+  __shared__ float red[2][CG][TC];
+  const int col = threadIdx.x % TC, cg = threadIdx.x / TC;
+  const int t = blockIdx.x * TC + col, b = blockIdx.y;
+  const bool in = t < T;
+  const size_t base = (size_t)b * C * T + (in ? t : 0);
+  auto combine = [&](float a, float bb, float& ra, float& rb) {
+    red[0][cg][col] = a;
+    red[1][cg][col] = bb;
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CG; ++k) {
+      s0 += red[0][k][col];
+      s1 += red[1][k][col];
+    }
+    __syncthreads();
+    ra = s0;
+    rb = s1;
+  };
+  float p0 = 0.f, p1 = 0.f, mean, dummy;
+  if (in)
+    for (int c = cg; c < C; c += CG) p0 += x[base + (size_t)c * T];
+  combine(p0, 0.f, mean, dummy);
   mean /= (float)C;
-  float var = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float d = x[base + (size_t)c * T] - mean;
-    var += d * d;
-  }
+  p0 = 0.f;
+  if (in)
+    for (int c = cg; c < C; c += CG) {
+      const float d = x[base + (size_t)c * T] - mean;
+      p0 += d * d;
+    }
+  float var;
+  combine(p0, 0.f, var, dummy);
   const float r = 1.0f / sqrtf(var / (float)C + eps);
-  const float om = out_mask ? out_mask[(size_t)b * T + t] : 1.f;
-  float s1 = 0.f, s2 = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const size_t o = base + (size_t)c * T;
-    float g = dy[o] * om;
-    if (relu && !(y[o] > 0.f)) g = 0.f;
-    const float A = ada ? 1.f + gb[(size_t)b * 2 * C + c] : w[c];
-    const float dxh = g * A, xh = (x[o] - mean) * r;
-    s1 += dxh;
-    s2 += dxh * xh;
-  }
+  const float om = (in && out_mask) ? out_mask[(size_t)b * T + t] : 1.f;
+  p0 = p1 = 0.f;
+  if (in)
+    for (int c = cg; c < C; c += CG) {
+      const size_t o = base + (size_t)c * T;
+      float g = dy[o] * om;
+      if (relu && !(y[o] > 0.f)) g = 0.f;
+      const float A = ada ? 1.f + gb[(size_t)b * 2 * C + c] : w[c];
+      const float dxh = g * A, xh = (x[o] - mean) * r;
+      p0 += dxh;
+      p1 += dxh * xh;
+    }
+  float s1, s2;
+  combine(p0, p1, s1, s2);
   s1 /= (float)C;
   s2 /= (float)C;
-  for (int c = 0; c < C; ++c) {
+  if (!in) return;
+  for (int c = cg; c < C; c += CG) {
     const size_t o = base + (size_t)c * T;
     float g = dy[o] * om;
     if (relu && !(y[o] > 0.f)) g = 0.f;
@@ -202,8 +232,10 @@ __global__ __launch_bounds__(64) void chan_ln_bwd_dx_kernel(const float* __restr
     const float d = r * (g * A - s1 - xh * s2);
     dx[o] = accumulate ? dx[o] + d : d;
   }
-  mu_out[(size_t)b * T + t] = mean;
-  r_out[(size_t)b * T + t] = r;
+  if (cg == 0) {
+    mu_out[(size_t)b * T + t] = mean;
+    r_out[(size_t)b * T + t] = r;
+  }
 }
 // per (b,c) row: dA = sum_t g xhat, dB = sum_t g  ->  dgb (ada) or atomics into dw/db (affine)
 __global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __restrict__ x,
@@ -240,8 +272,12 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __r
 int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,
                        const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
                        float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st) {
-  hipLaunchKernelGGL(chan_ln_bwd_dx_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, st, x, dy, y, C, T, eps, ada, w, gb, relu,
-                     out_mask, dx, accumulate, mu_tmp, r_tmp);
+  if ((size_t)B * T >= 65536)
+    hipLaunchKernelGGL(chan_ln_bwd_dx_kernel<64>, dim3(cdiv(T, 64), B), dim3(256), 0, st, x, dy, y, C, T, eps, ada, w, gb,
+                       relu, out_mask, dx, accumulate, mu_tmp, r_tmp);
+  else
+    hipLaunchKernelGGL(chan_ln_bwd_dx_kernel<16>, dim3(cdiv(T, 16), B), dim3(256), 0, st, x, dy, y, C, T, eps, ada, w, gb,
+                       relu, out_mask, dx, accumulate, mu_tmp, r_tmp);
   hipLaunchKernelGGL(chan_ln_bwd_param_kernel, dim3(C, B), dim3(256), 0, st, x, dy, y, mu_tmp, r_tmp, C, T, ada, relu,
                      out_mask, dgb, dw, db);
   STY_LAUNCH_CHECK();
@@ -420,43 +456,78 @@ __global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* 
   const size_t o = ((size_t)b * C + c) * T + t;
   dx[o] = accumulate ? dx[o] + acc : acc;
 }
-// one workgroup per channel: dw[c][k] += sum_{b,t} dy[t] x[t - pad + k], db[c] += sum dy
-__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           int B, int C, int T, int K, int pad,
-                                                           float* __restrict__ dw, float* __restrict__ db) {
-  __shared__ double red[1][4];
-  const int c = blockIdx.x;
-  for (int k = 0; k <= K; ++k) {  // k == K: bias
-    double acc[1] = {0.0};
-    for (int b = 0; b < B; ++b) {
-      const float* xr = x + ((size_t)b * C + c) * T;
-      const float* gr = dy + ((size_t)b * C + c) * T;
-      for (int t = threadIdx.x; t < T; t += 256) {
-        if (k == K) {
-          acc[0] += gr[t];
-        } else {
-          const int tt = t - pad + k;
-          if (tt >= 0 && tt < T) acc[0] += (double)gr[t] * xr[tt];
-        }
-      }
+// dw[c][k] += sum_{b,t} dy[t] x[t - pad + k], db[c] += sum dy.  Two deterministic stages: one workgroup per
+// (channel, batch row, 4096-sample segment) writes K+1 partial sums, a second kernel adds them in a fixed order.
+// (The first version used one workgroup per channel looping over the whole batch: 1.1 ms per call at C = 32.)
+constexpr int DW_SEG = 4096;
+template <int MAXK>
+__global__ __launch_bounds__(256) void dwconv_bwd_w_part_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dy, int C, int T, int K,
+                                                                int pad, int nseg, float* __restrict__ part) {
+  __shared__ double red[4];
+  const int seg = blockIdx.x % nseg, b = blockIdx.x / nseg, c = blockIdx.y;
+  const float* xr = x + ((size_t)b * C + c) * T;
+  const float* gr = dy + ((size_t)b * C + c) * T;
+  float acc[MAXK + 1];
+#pragma unroll
+  for (int k = 0; k <= MAXK; ++k) acc[k] = 0.f;
+  const int t1 = min(T, (seg + 1) * DW_SEG);
+  for (int t = seg * DW_SEG + threadIdx.x; t < t1; t += 256) {
+    const float g = gr[t];
+    acc[MAXK] += g;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int tt = t - pad + k;
+      if (k < K && tt >= 0 && tt < T) acc[k] = fmaf(g, xr[tt], acc[k]);
     }
-    block_sum<1>(acc, red);
-    if (threadIdx.x == 0) {
-      if (k == K) {
-        if (db) db[c] += (float)acc[0];
-      } else {
-        dw[c * K + k] += (float)acc[0];
-      }
+  }
+  float* out = part + ((size_t)c * gridDim.x + blockIdx.x) * (K + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k <= MAXK; ++k) {
+    if (k < K || k == MAXK) {
+      const double v = wave_sum((double)acc[k]);
+      if (lane == 0) red[wave] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) out[k == MAXK ? K : k] = (float)(red[0] + red[1] + red[2] + red[3]);
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
+__global__ void dwconv_bwd_w_sum_kernel(const float* __restrict__ part, int C, int K, int nblk, float* __restrict__ dw,
+                                        float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * (K + 1)) return;
+  const int c = i / (K + 1), k = i % (K + 1);
+  double s = 0.0;
+  for (int j = 0; j < nblk; ++j) s += part[((size_t)c * nblk + j) * (K + 1) + k];
+  if (k == K) {
+    if (db) db[c] += (float)s;
+  } else {
+    dw[c * K + k] += (float)s;
+  }
+}
+size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K) { return (size_t)C * B * cdiv(T, DW_SEG) * (K + 1); }
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
-                      int accumulate, float* dw, float* db, hipStream_t st) {
+                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st) {
   if (dx)
     hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
                        accumulate);
-  if (dw) hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(C), dim3(256), 0, st, x, dy, B, C, T, K, pad, dw, db);
+  if (dw) {
+    const int nseg = cdiv(T, DW_SEG);
+    if (K <= 7)
+      hipLaunchKernelGGL(dwconv_bwd_w_part_kernel<7>, dim3(nseg * B, C), dim3(256), 0, st, x, dy, C, T, K, pad, nseg,
+                         scratch);
+    else if (K <= 31)
+      hipLaunchKernelGGL(dwconv_bwd_w_part_kernel<31>, dim3(nseg * B, C), dim3(256), 0, st, x, dy, C, T, K, pad, nseg,
+                         scratch);
+    else {
+      set_error("dwconv_bwd: kernel size %d > 31", K);
+      return STY_EINVAL;
+    }
+    hipLaunchKernelGGL(dwconv_bwd_w_sum_kernel, dim3(cdiv(C * (K + 1), 64)), dim3(64), 0, st, scratch, C, K, nseg * B,
+                       dw, db);
+  }
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -508,29 +579,47 @@ int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const fl
 }
 
 // ---- bias gradient of a dense conv: db[co] += scale * sum_{b,t} g[b][co][t] (* mask) ----
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, const float* __restrict__ mask,
-                                                        int B, int C, int T, int shuffle, float scale,
-                                                        float* __restrict__ db) {
+// two deterministic stages like the depthwise weight gradient: (channel, batch row, segment) partials, then a sum
+__global__ __launch_bounds__(256) void bias_grad_part_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                             int C, int T, int shuffle, int nseg,
+                                                             float* __restrict__ part) {
   __shared__ double red[1][4];
-  const int co = blockIdx.x;
-  double acc[1] = {0.0};
-  for (int b = 0; b < B; ++b) {
-    for (int t = threadIdx.x; t < T; t += 256) {
-      float v;
-      if (shuffle > 1)
-        v = g[((size_t)b * (C / shuffle) + co / shuffle) * ((size_t)T * shuffle) + (size_t)t * shuffle + co % shuffle];
-      else
-        v = g[((size_t)b * C + co) * T + t];
+  const int seg = blockIdx.x % nseg, b = blockIdx.x / nseg, co = blockIdx.y;
+  const int t1 = min(T, (seg + 1) * DW_SEG);
+  float a = 0.f;
+  if (shuffle > 1) {
+    const float* gr = g + ((size_t)b * (C / shuffle) + co / shuffle) * ((size_t)T * shuffle) + co % shuffle;
+    for (int t = seg * DW_SEG + threadIdx.x; t < t1; t += 256) {
+      float v = gr[(size_t)t * shuffle];
       if (mask) v *= mask[(size_t)b * T + t];
-      acc[0] += v;
+      a += v;
+    }
+  } else {
+    const float* gr = g + ((size_t)b * C + co) * T;
+    for (int t = seg * DW_SEG + threadIdx.x; t < t1; t += 256) {
+      float v = gr[t];
+      if (mask) v *= mask[(size_t)b * T + t];
+      a += v;
     }
   }
+  double acc[1] = {(double)a};
   block_sum<1>(acc, red);
-  if (threadIdx.x == 0) db[co] += (float)acc[0] * scale;
+  if (threadIdx.x == 0) part[(size_t)co * gridDim.x + blockIdx.x] = (float)acc[0];
 }
+__global__ void bias_grad_sum_kernel(const float* __restrict__ part, int C, int nblk, float scale,
+                                     float* __restrict__ db) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= C) return;
+  double s = 0.0;
+  for (int j = 0; j < nblk; ++j) s += part[(size_t)co * nblk + j];
+  db[co] += (float)s * scale;
+}
+size_t bias_grad_scratch_floats(int B, int C, int T) { return (size_t)C * B * cdiv(T, DW_SEG); }
 int launch_bias_grad(const float* g, const float* mask, int B, int C, int T, int shuffle, float scale, float* db,
-                     hipStream_t st) {
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, st, g, mask, B, C, T, shuffle, scale, db);
+                     float* scratch, hipStream_t st) {
+  const int nseg = cdiv(T, DW_SEG);
+  hipLaunchKernelGGL(bias_grad_part_kernel, dim3(nseg * B, C), dim3(256), 0, st, g, mask, C, T, shuffle, nseg, scratch);
+  hipLaunchKernelGGL(bias_grad_sum_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, scratch, C, nseg * B, scale, db);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

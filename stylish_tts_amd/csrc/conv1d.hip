@@ -73,9 +73,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
       case PRO_SCALE: stage_chunk<PRO_SCALE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
       case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
       case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
-      case PRO_MASK: stage_chunk<PRO_MASK, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
-      case PRO_LRELU: stage_chunk<PRO_LRELU, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
-      default: stage_chunk<PRO_NONE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      case PRO_MASK:
+        if (a.flatW)
+          stage_chunk<PRO_MASK, NW, MAXJ, true>(a, xs, ci0, b, h, t0, LW, wave, lane);
+        else
+          stage_chunk<PRO_MASK, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane);
+        break;
+      case PRO_LRELU:
+        if (a.flatW)
+          stage_chunk<PRO_LRELU, NW, MAXJ, true>(a, xs, ci0, b, h, t0, LW, wave, lane);
+        else
+          stage_chunk<PRO_LRELU, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane);
+        break;
+      default:
+        if (a.flatW)
+          stage_chunk<PRO_NONE, NW, MAXJ, true>(a, xs, ci0, b, h, t0, LW, wave, lane);
+        else
+          stage_chunk<PRO_NONE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane);
+        break;
     }
     if (a.pro == PRO_LN_AFFINE) {
       // LayerNorm over the Cin (<= 32, single chunk) channels of every in-range column, then affine.
@@ -295,13 +310,16 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   // algorithmic work: 2*Cin*K flops per output element; input + output (+ residual) once, weights once
   const double outs = (double)a.B * a.w.Cout * a.T * HM;
   const double flops = 2.0 * a.w.Cin * a.w.K * outs;
-  const double in_elems = a.H ? (double)a.B * a.Cin2d * a.Hin * (a.Tin ? a.Tin : a.T) : (double)a.B * a.w.Cin * a.T;
+  const double in_elems = a.H ? (double)a.B * a.Cin2d * a.Hin * (a.Tin ? a.Tin : a.T)
+                                : (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
   const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
   const char* fam = CO_BLK == 32 ? "conv1d_mfma<co32>" : (CO_BLK == 64 ? "conv1d_mfma<co64>" : "conv1d_mfma<co128>");
   if (CO_BLK == 32 && TT_BLK == 512) fam = "conv1d_mfma<co32,t512>";
   if (CO_BLK == 64 && TT_BLK == 64) fam = "conv1d_mfma<co64,t64>";
   if (CO_BLK == 64 && TT_BLK == 128) fam = "conv1d_mfma<co64,t128,glu>";
-  ProfScope prof(fam, flops, bytes, st);
+  char detail[40];
+  snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
+  ProfScope prof(fam, flops, bytes, st, detail);
   hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), lds, st, a);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -310,7 +328,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   int cin = 0;
   for (int i = 0; i < a.nsrc; ++i) cin += a.xc[i];
-  if (a.H) cin = a.w.Cin;  // 2-D mode: Cin of the packed weight = kh * Cin2d, checked by the caller
+  if (a.H || a.flatW) cin = a.w.Cin;  // 2-D mode: Cin of the packed weight = kh * Cin2d, checked by the caller
   if (cin != a.w.Cin) {
     set_error("conv1d: input channels %d != weight Cin %d", cin, a.w.Cin);
     return STY_ESHAPE;

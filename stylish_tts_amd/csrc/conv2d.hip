@@ -68,15 +68,59 @@ int launch_pack_dw2d_sn(const float* w, const float* u, const float* v, int C, f
   return STY_OK;
 }
 
-// LearnedDownSample 'half': depthwise 3x3, stride 2, pad 1 (mel_style_encoder.py:28-38) on [B][C][H][W]
+// ---------------------------------------------------------------------------------------------------
+// Padded-flat image layout of the style encoder.  An activation [B][C][H][W] is stored with ONE zero column
+// appended to every row: [B][C][H][Wp], Wp = W + 1.  A 'same' 3x3 convolution is then a 1-D convolution over the
+// flattened H*Wp axis: tap (kh, kw) is the constant shift (kh-1)*Wp + (kw-1), the zero column supplies the left
+// and right padding (index -1 of a row IS the pad column of the row above) and the array bounds supply the top
+// and bottom padding.  conv1d_mfma_kernel runs it with flatW = Wp: N tiles of 64 flattened positions are full
+// even when W is 20 (the row-per-workgroup form used 20 of 64 lanes), at the price of Wp/W extra columns that a
+// [B][H*Wp] 0/1 mask zeroes in the epilogue.
+// ---------------------------------------------------------------------------------------------------
+// [rows][W] -> [rows][W+1] with a zero last column
+__global__ void pad_cols_kernel(const float* __restrict__ x, size_t rows, int W, float* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = rows * (W + 1);
+  if (i >= n) return;
+  const size_t r = i / (W + 1);
+  const int w = (int)(i % (W + 1));
+  y[i] = w < W ? x[r * W + w] : 0.f;
+}
+int launch_pad_cols(const float* x, size_t rows, int W, float* y, hipStream_t st) {
+  const size_t n = rows * (W + 1);
+  hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, W, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// mask[b][h*Wp + w] = (h < Hv && w < Wv)
+__global__ void flat_mask_kernel(int B, int H, int Wp, int Hv, int Wv, float* __restrict__ m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * H * Wp) return;
+  const int t = i % (H * Wp);
+  m[i] = (t / Wp < Hv && t % Wp < Wv) ? 1.f : 0.f;
+}
+int launch_flat_mask(int B, int H, int Wp, int Hv, int Wv, float* m, hipStream_t st) {
+  hipLaunchKernelGGL(flat_mask_kernel, dim3(cdiv(B * H * Wp, 256)), dim3(256), 0, st, B, H, Wp, Hv, Wv, m);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// LearnedDownSample 'half': depthwise 3x3, stride 2, pad 1 (mel_style_encoder.py:28-38); rows of x have stride
+// W + 1, rows of y stride Wo + 1 (the pad column is written as zero)
 __global__ __launch_bounds__(256) void dwconv2d_s2_kernel(const float* __restrict__ x, const float* __restrict__ w9,
                                                           const float* __restrict__ bias, int C, int H, int W, int Ho,
                                                           int Wo, float* __restrict__ y) {
   const int wo = blockIdx.x * 256 + threadIdx.x;
   const int ho = blockIdx.y;
   const int bc = blockIdx.z, c = bc % C;
-  if (wo >= Wo) return;
-  const float* p = x + (size_t)bc * H * W;
+  if (wo > Wo) return;
+  const int ldi = W + 1, ldo = Wo + 1;
+  float* out = y + ((size_t)bc * Ho + ho) * ldo + wo;
+  if (wo == Wo) {
+    *out = 0.f;
+    return;
+  }
+  const float* p = x + (size_t)bc * H * ldi;
   float acc = bias[c];
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
@@ -85,16 +129,16 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_kernel(const float* __restric
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int wi = 2 * wo + kw - 1;
-      if (wi >= 0 && wi < W) acc = fmaf(w9[c * 9 + kh * 3 + kw], p[(size_t)hi * W + wi], acc);
+      if (wi >= 0 && wi < W) acc = fmaf(w9[c * 9 + kh * 3 + kw], p[(size_t)hi * ldi + wi], acc);
     }
   }
-  y[((size_t)bc * Ho + ho) * Wo + wo] = acc;
+  *out = acc;
 }
 int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B, int C, int H, int W, float* y,
                        hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(dwconv2d_s2_kernel, dim3(cdiv(Wo, 256), Ho, B * C), dim3(256), 0, st, x, w9, bias, C, H, W, Ho, Wo,
-                     y);
+  hipLaunchKernelGGL(dwconv2d_s2_kernel, dim3(cdiv(Wo + 1, 256), Ho, B * C), dim3(256), 0, st, x, w9, bias, C, H, W, Ho,
+                     Wo, y);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -104,34 +148,41 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__
                                                        float scale, float* __restrict__ y) {
   const int wo = blockIdx.x * 256 + threadIdx.x;
   const int ho = blockIdx.y, bc = blockIdx.z;
-  if (wo >= Wo) return;
-  const float* p = x + (size_t)bc * H * W;
+  if (wo > Wo) return;
+  const int ldi = W + 1, ldo = Wo + 1;
+  float* out = y + ((size_t)bc * Ho + ho) * ldo + wo;
+  if (wo == Wo) {
+    *out = 0.f;
+    return;
+  }
+  const float* p = x + (size_t)bc * H * ldi;
   const int w0 = 2 * wo, w1 = min(2 * wo + 1, W - 1);
-  const float s = p[(size_t)(2 * ho) * W + w0] + p[(size_t)(2 * ho) * W + w1] + p[(size_t)(2 * ho + 1) * W + w0] +
-                  p[(size_t)(2 * ho + 1) * W + w1];
-  y[((size_t)bc * Ho + ho) * Wo + wo] = s * 0.25f * scale;
+  const float s = p[(size_t)(2 * ho) * ldi + w0] + p[(size_t)(2 * ho) * ldi + w1] +
+                  p[(size_t)(2 * ho + 1) * ldi + w0] + p[(size_t)(2 * ho + 1) * ldi + w1];
+  *out = s * 0.25f * scale;
 }
 int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st) {
   const int Ho = H / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(Wo, 256), Ho, BC), dim3(256), 0, st, x, H, W, Ho, Wo, scale, y);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(Wo + 1, 256), Ho, BC), dim3(256), 0, st, x, H, W, Ho, Wo, scale, y);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
 
-// AdaptiveAvgPool2d(1) -> LeakyReLU(0.2) -> Linear (mel_style_encoder.py:140-152): x [B][C][H][W] -> s [B][S]
-__global__ __launch_bounds__(256) void pool_fc_kernel(const float* __restrict__ x, int C, int HW,
+// AdaptiveAvgPool2d(1) -> LeakyReLU(0.2) -> Linear (mel_style_encoder.py:140-152): x [B][C][n] (positions outside the
+// valid region are zero) -> s [B][S]; the mean divides by `count` valid positions
+__global__ __launch_bounds__(256) void pool_fc_kernel(const float* __restrict__ x, int C, int n, float inv_count,
                                                       const float* __restrict__ W, const float* __restrict__ bvec,
                                                       int S, float* __restrict__ out) {
   extern __shared__ float pooled[];  // [C]
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = wave; c < C; c += 4) {
-    const float* p = x + ((size_t)b * C + c) * HW;
+    const float* p = x + ((size_t)b * C + c) * n;
     float s = 0.f;
-    for (int i = lane; i < HW; i += 64) s += p[i];
+    for (int i = lane; i < n; i += 64) s += p[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) {
-      const float m = s / (float)HW;
+      const float m = s * inv_count;
       pooled[c] = m > 0.f ? m : 0.2f * m;
     }
   }
@@ -142,9 +193,10 @@ __global__ __launch_bounds__(256) void pool_fc_kernel(const float* __restrict__ 
     out[(size_t)b * S + j] = acc;
   }
 }
-int launch_pool_fc(const float* x, int B, int C, int HW, const float* W, const float* bvec, int S, float* out,
+int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* W, const float* bvec, int S, float* out,
                    hipStream_t st) {
-  hipLaunchKernelGGL(pool_fc_kernel, dim3(B), dim3(256), C * sizeof(float), st, x, C, HW, W, bvec, S, out);
+  hipLaunchKernelGGL(pool_fc_kernel, dim3(B), dim3(256), C * sizeof(float), st, x, C, n, 1.0f / (float)count, W, bvec, S,
+                     out);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -157,7 +209,8 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __
   const int wi = blockIdx.x * 256 + threadIdx.x;
   const int hi = blockIdx.y, bc = blockIdx.z, c = bc % C;
   if (wi >= W) return;
-  const float* g = gy + (size_t)bc * Ho * Wo;
+  const int ldi = W + 1, ldo = Wo + 1;
+  const float* g = gy + (size_t)bc * Ho * ldo;
   float acc = 0.f;
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
@@ -170,55 +223,65 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __
       const int wn = wi + 1 - kw;
       if (wn < 0 || (wn & 1)) continue;
       const int wo = wn >> 1;
-      if (wo < Wo) acc = fmaf(w9[c * 9 + kh * 3 + kw], g[(size_t)ho * Wo + wo], acc);
+      if (wo < Wo) acc = fmaf(w9[c * 9 + kh * 3 + kw], g[(size_t)ho * ldo + wo], acc);
     }
   }
-  dx[((size_t)bc * H + hi) * W + wi] += acc;
+  dx[((size_t)bc * H + hi) * ldi + wi] += acc;
 }
-__global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ gy, int B, int C, int H,
-                                                                int W, int Ho, int Wo, float* __restrict__ dw9,
-                                                                float* __restrict__ db) {
-  __shared__ float red[256];
-  const int c = blockIdx.x;
-  for (int k = 0; k <= 9; ++k) {
-    const int kh = k / 3, kw = k % 3;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float* p = x + ((size_t)b * C + c) * H * W;
-      const float* g = gy + ((size_t)b * C + c) * Ho * Wo;
-      for (int i = threadIdx.x; i < Ho * Wo; i += 256) {
-        const int ho = i / Wo, wo = i % Wo;
-        if (k == 9) {
-          acc += g[i];
-        } else {
-          const int hi = 2 * ho + kh - 1, wi = 2 * wo + kw - 1;
-          if (hi >= 0 && hi < H && wi >= 0 && wi < W) acc = fmaf(g[i], p[(size_t)hi * W + wi], acc);
-        }
-      }
+// one workgroup per (channel, batch row): 10 partial sums; summed over the batch in a fixed order afterwards
+__global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_part_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ gy, int C, int H, int W,
+                                                                     int Ho, int Wo, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int ldi = W + 1, ldo = Wo + 1;
+  const float* p = x + ((size_t)b * C + c) * H * ldi;
+  const float* g = gy + ((size_t)b * C + c) * Ho * ldo;
+  float acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  for (int i = threadIdx.x; i < Ho * Wo; i += 256) {
+    const int ho = i / Wo, wo = i % Wo;
+    const float gv = g[(size_t)ho * ldo + wo];
+    acc[9] += gv;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int hi = 2 * ho + k / 3 - 1, wi = 2 * wo + k % 3 - 1;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) acc[k] = fmaf(gv, p[(size_t)hi * ldi + wi], acc[k]);
     }
-    red[threadIdx.x] = acc;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    float v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wave] = v;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      if (k == 9) {
-        if (db) db[c] += red[0];
-      } else {
-        dw9[c * 9 + k] += red[0];
-      }
-    }
+    if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * 10 + k] = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
   }
 }
+__global__ void dwconv2d_s2_bwd_w_sum_kernel(const float* __restrict__ part, int C, int B, float* __restrict__ dw9,
+                                             float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 10) return;
+  const int c = i / 10, k = i % 10;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[((size_t)c * B + b) * 10 + k];
+  if (k == 9) {
+    if (db) db[c] += s;
+  } else {
+    dw9[c * 9 + k] += s;
+  }
+}
+size_t dwconv2d_s2_bwd_scratch_floats(int B, int C) { return (size_t)B * C * 10; }
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int B, int C, int H, int W, float* dx,
-                           float* dw9, float* db, hipStream_t st) {
+                           float* dw9, float* db, float* scratch, hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   hipLaunchKernelGGL(dwconv2d_s2_bwd_dx_kernel, dim3(cdiv(W, 256), H, B * C), dim3(256), 0, st, gy, w9, C, H, W, Ho, Wo,
                      dx);
-  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_kernel, dim3(C), dim3(256), 0, st, x, gy, B, C, H, W, Ho, Wo, dw9, db);
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_part_kernel, dim3(C, B), dim3(256), 0, st, x, gy, C, H, W, Ho, Wo, scratch);
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_sum_kernel, dim3(cdiv(C * 10, 64)), dim3(64), 0, st, scratch, C, B, dw9, db);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -226,11 +289,22 @@ int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int
 __global__ void dw2d_sn_unpack_kernel(const float* __restrict__ g9, const float* __restrict__ w,
                                       const float* __restrict__ u, const float* __restrict__ v,
                                       const float* __restrict__ t, int C, float* __restrict__ dW) {
+  __shared__ float red[2][256];
   float sig = 0.f, dot = 0.f;
-  for (int i = 0; i < C; ++i) sig += t[i];
-  for (int i = 0; i < C * 9; ++i) dot = fmaf(g9[i], w[i], dot);
-  const float inv = 1.0f / sig, k = dot * inv * inv;
-  for (int i = threadIdx.x; i < C * 9; i += blockDim.x) dW[i] += g9[i] * inv - k * u[i / 9] * v[i % 9];
+  for (int i = threadIdx.x; i < C; i += 256) sig += t[i];
+  for (int i = threadIdx.x; i < C * 9; i += 256) dot = fmaf(g9[i], w[i], dot);
+  red[0][threadIdx.x] = sig;
+  red[1][threadIdx.x] = dot;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const float inv = 1.0f / red[0][0], k = red[1][0] * inv * inv;
+  for (int i = threadIdx.x; i < C * 9; i += 256) dW[i] += g9[i] * inv - k * u[i / 9] * v[i % 9];
 }
 int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const float* v, const float* t, int C,
                           float* dW, hipStream_t st) {
@@ -245,10 +319,10 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
   if (wi >= W) return;
   const int ho = hi >> 1;
   const int wo = wi >> 1;
-  float g = gy[((size_t)bc * Ho + ho) * Wo + wo];
+  float g = gy[((size_t)bc * Ho + ho) * (Wo + 1) + wo];
   // odd W: the last column was replicated, so it is read twice by the last output column
   const float mult = (W & 1) && wi == W - 1 ? 2.f : 1.f;
-  dx[((size_t)bc * H + hi) * W + wi] += g * 0.25f * scale * mult;
+  dx[((size_t)bc * H + hi) * (W + 1) + wi] += g * 0.25f * scale * mult;
 }
 int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, hipStream_t st) {
   const int Ho = H / 2, Wo = (W + 1) / 2;
@@ -256,9 +330,10 @@ int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, floa
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
-// pool + LeakyReLU + Linear backward: gs [B][S] -> dW (+=), db (+=), dx[b][c][:] += (W^T gs)[c] lrelu'(mean)/HW
-__global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restrict__ x, int B, int C, int HW,
-                                                          const float* __restrict__ W, int S,
+// pool + LeakyReLU + Linear backward: gs [B][S] -> dW (+=), db (+=), dx[b][c][:] += (W^T gs)[c] lrelu'(mean)/count
+// (every position: the head conv's backward masks its output gradient to the valid region)
+__global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restrict__ x, int B, int C, int n,
+                                                          float inv_count, const float* __restrict__ W, int S,
                                                           const float* __restrict__ gs, float* __restrict__ dW,
                                                           float* __restrict__ db, float* __restrict__ dx) {
   extern __shared__ float sh[];  // pooled[C] (pre-activation mean), gp[C]
@@ -267,20 +342,20 @@ __global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restric
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = wave; c < C; c += 4) {
-    const float* p = x + ((size_t)b * C + c) * HW;
+    const float* p = x + ((size_t)b * C + c) * n;
     float s = 0.f;
-    for (int i = lane; i < HW; i += 64) s += p[i];
+    for (int i = lane; i < n; i += 64) s += p[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) pooled[c] = s / (float)HW;
+    if (lane == 0) pooled[c] = s * inv_count;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float acc = 0.f;
     for (int j = 0; j < S; ++j) acc = fmaf(W[(size_t)j * C + c], gs[(size_t)b * S + j], acc);
-    gp[c] = acc * (pooled[c] > 0.f ? 1.f : 0.2f) / (float)HW;
+    gp[c] = acc * (pooled[c] > 0.f ? 1.f : 0.2f) * inv_count;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * HW; i += 256) dx[(size_t)b * C * HW + i] += gp[i / HW];
+  for (int i = threadIdx.x; i < C * n; i += 256) dx[(size_t)b * C * n + i] += gp[i / n];
   for (int i = threadIdx.x; i < S * C; i += 256) {
     const int j = i / C, c = i % C;
     const float a = pooled[c] > 0.f ? pooled[c] : 0.2f * pooled[c];
@@ -288,10 +363,10 @@ __global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restric
   }
   for (int j = threadIdx.x; j < S; j += 256) atomicAdd(&db[j], gs[(size_t)b * S + j]);
 }
-int launch_pool_fc_bwd(const float* x, int B, int C, int HW, const float* W, int S, const float* gs, float* dW,
-                       float* db, float* dx, hipStream_t st) {
-  hipLaunchKernelGGL(pool_fc_bwd_kernel, dim3(B), dim3(256), 2 * C * sizeof(float), st, x, B, C, HW, W, S, gs, dW, db,
-                     dx);
+int launch_pool_fc_bwd(const float* x, int B, int C, int n, int count, const float* W, int S, const float* gs,
+                       float* dW, float* db, float* dx, hipStream_t st) {
+  hipLaunchKernelGGL(pool_fc_bwd_kernel, dim3(B), dim3(256), 2 * C * sizeof(float), st, x, B, C, n,
+                     1.0f / (float)count, W, S, gs, dW, db, dx);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -24,7 +24,7 @@ __device__ __forceinline__ float pro_apply(float v, float pa, float ps, float al
 // Stage CI_CHUNK x LW input samples of channels [ci0, ci0+32) into LDS with the prologue applied.  Each wave owns
 // rows wave, wave+NW, ...; two rows x MAXJ column chunks are loaded into registers first so that 2*MAXJ global
 // loads are in flight per lane before any dependent math / LDS store.  Zero padding is applied AFTER the prologue.
-template <int PRO, int NW, int MAXJ>
+template <int PRO, int NW, int MAXJ, bool FLAT = false>
 __device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
                                             int LW, int wave, int lane) {
   const int T = a.Tin ? a.Tin : a.T, Cin = a.w.Cin;
@@ -33,6 +33,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict
     const float* src[2];
     float pa[2], ps[2], alpha[2], ralpha[2];
     bool live[2];
+    int tsh[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ci = ci0 + c + NW * u;
@@ -41,7 +42,13 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict
       ps[u] = 0.f;
       alpha[u] = ralpha[u] = 1.f;
       src[u] = a.x[0];
-      if (live[u] && a.H) {  // 2-D mode: reduction index = (kh, ci)
+      if constexpr (FLAT) {  // flat 2-D mode: reduction index (kh, ci) = the same image shifted by whole rows
+        if (live[u]) {
+          const int kh = ci / a.Cin2d, cc = ci - kh * a.Cin2d;
+          tsh[u] = (kh - a.hpad) * a.flatW;
+          src[u] = a.x[0] + ((size_t)b * a.Cin2d + cc) * T;
+        }
+      } else if (live[u] && a.H) {  // 2-D mode: reduction index = (kh, ci)
         const int kh = ci / a.Cin2d, cc = ci - kh * a.Cin2d;
         const int hin = h + kh - a.hpad;
         live[u] = hin >= 0 && hin < a.Hin;
@@ -75,16 +82,20 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict
         }
       }
     }
-    float vv[2][MAXJ], mk[MAXJ];
+    float vv[2][MAXJ], mk[FLAT ? 2 : 1][MAXJ];
 #pragma unroll
     for (int q = 0; q < MAXJ; ++q) {
       const int j = lane + 64 * q;
-      const int t = t0 - a.pad + j;
-      const bool in = j < LW && t >= 0 && t < T;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) vv[u][q] = (in && live[u]) ? src[u][(size_t)t * es] : 0.f;
-      mk[q] = 1.f;
-      if constexpr (PRO == PRO_MASK) mk[q] = in ? a.mask[(size_t)b * T + t] : 0.f;
+      for (int u = 0; u < 2; ++u) {
+        const int t = t0 - a.pad + j + tsh[u];
+        const bool in = j < LW && t >= 0 && t < T;
+        vv[u][q] = (in && live[u]) ? src[u][(size_t)t * es] : 0.f;
+        if (u == 0 || FLAT) {
+          mk[FLAT ? u : 0][q] = 1.f;
+          if constexpr (PRO == PRO_MASK) mk[FLAT ? u : 0][q] = in ? a.mask[(size_t)b * T + t] : 0.f;
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -92,9 +103,10 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict
 #pragma unroll
       for (int q = 0; q < MAXJ; ++q) {
         const int j = lane + 64 * q;
-        const int t = t0 - a.pad + j;
+        const int t = t0 - a.pad + j + tsh[u];
         float v = 0.f;
-        if (live[u] && t >= 0 && t < T) v = pro_apply<PRO>(vv[u][q], pa[u], ps[u], alpha[u], ralpha[u], mk[q]);
+        if (live[u] && t >= 0 && t < T)
+          v = pro_apply<PRO>(vv[u][q], pa[u], ps[u], alpha[u], ralpha[u], mk[FLAT ? u : 0][q]);
         if (j < LW) row[j] = v;
       }
     }

@@ -60,8 +60,8 @@ int launch_pack_dw2d_sn(const float* w, const float* u, const float* v, int C, f
 int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B, int C, int H, int W, float* y,
                        hipStream_t st);
 int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st);
-int launch_pool_fc(const float* x, int B, int C, int HW, const float* W, const float* bvec, int S, float* out,
-                   hipStream_t st);
+int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* W, const float* bvec, int S,
+                   float* out, hipStream_t st);
 struct PackJob {
   PackKind kind;
   const float *w = nullptr, *g = nullptr, *v = nullptr, *bias = nullptr, *extra = nullptr;
@@ -212,14 +212,16 @@ int launch_act_bwd(int kind, const float* x, const float* dy, const float* alpha
 int launch_row_scale_add(const float* src, const float* coef, float k, int rows, int T, float* dst, hipStream_t st);
 int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad, float* y,
                       hipStream_t st);
+size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K);
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
-                      int accumulate, float* dw, float* db, hipStream_t st);
+                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st);
 int launch_bn_eval_fwd(const float* x, const float* w, const float* b, const float* rm, const float* rv, float eps,
                        int B, int C, int T, float* y, hipStream_t st);
 int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const float* rm, const float* rv, float eps,
                        int B, int C, int T, float* dx, float* dw, float* db, hipStream_t st);
+size_t bias_grad_scratch_floats(int B, int C, int T);
 int launch_bias_grad(const float* g, const float* mask, int B, int C, int T, int shuffle, float scale, float* db,
-                     hipStream_t st);
+                     float* scratch, hipStream_t st);
 int launch_style_fc_bwd(const void* descs_dev, int nlayers, int B, int style_dim, const float* style,
                         const float* dgb_base, float* dstyle, hipStream_t st);
 int launch_istft64_bwd(int B, int F, const float* audio, const float* daudio, const float* logamp, const float* real,
@@ -251,13 +253,16 @@ int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int 
                         float* wd, hipStream_t st);
 int launch_sn_unpack(const float* gwp, const float* w, const float* u, const float* v, const float* t, int Cout,
                      int Cin, int KH, int KW, int CinP, int CoutP, float* gw_scratch, float* dW, hipStream_t st);
+size_t dwconv2d_s2_bwd_scratch_floats(int B, int C);
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int B, int C, int H, int W, float* dx,
-                           float* dw9, float* db, hipStream_t st);
+                           float* dw9, float* db, float* scratch, hipStream_t st);
+int launch_pad_cols(const float* x, size_t rows, int W, float* y, hipStream_t st);
+int launch_flat_mask(int B, int H, int Wp, int Hv, int Wv, float* m, hipStream_t st);
 int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const float* v, const float* t, int C,
                           float* dW, hipStream_t st);
 int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, hipStream_t st);
-int launch_pool_fc_bwd(const float* x, int B, int C, int HW, const float* W, int S, const float* gs, float* dW,
-                       float* db, float* dx, hipStream_t st);
+int launch_pool_fc_bwd(const float* x, int B, int C, int n, int count, const float* W, int S, const float* gs,
+                       float* dW, float* db, float* dx, hipStream_t st);
 int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
                           hipStream_t st, size_t* need);
 int trainer_style_backward(struct Trainer* t, const float* d_style, hipStream_t st);

@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char* what);
 struct ProfScope {
   int slot = -1;
   hipStream_t st;
-  ProfScope(const char* family, double flops, double bytes, hipStream_t s);
+  ProfScope(const char* family, double flops, double bytes, hipStream_t s, const char* detail = nullptr);
   ~ProfScope();
 };
 
@@ -74,6 +74,9 @@ struct ConvArgs {
   // 2-D mode (Conv2d on [B,C,H,W] as one 1-D conv per output row): the packed reduction "channel" index is
   // (kh, ci) with ci fastest, input row = h + kh - hpad; grid z = B * H.  Single source only.
   int H = 0, Hin = 0, hpad = 0, Cin2d = 0;
+  // flat 2-D mode (conv2d.hip, "padded-flat image layout"): x and y are [B][C][T] with T = H*flatW flattened image
+  // positions; reduction index (kh, ci) reads x shifted by (kh - hpad)*flatW.  H stays 0 (grid z = B).
+  int flatW = 0;
   int in_shuffle = 0;     // > 1: source 0 is stored pixel-shuffled [B][C/s][T*s] (backward of a shuffled store)
   PackedConv w;
   int pro = PRO_NONE;

@@ -126,7 +126,10 @@ struct Trainer {
       else
         chk(launch_row_scale_add(gY, nullptr, 1.0f, B * w.Cout, Tt, gR, st));
     }
-    if (w.bias && live()) chk(launch_bias_grad(gY, gmask, B, w.Cout, Tt, f.shuffle, f.out_scale, PGpacked(w.bias), st));
+    if (w.bias) {
+      float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, Tt));
+      if (live()) chk(launch_bias_grad(gY, gmask, B, w.Cout, Tt, f.shuffle, f.out_scale, PGpacked(w.bias), bs, st));
+    }
     float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
     if (live()) chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, st));
     if (any) {
@@ -239,7 +242,10 @@ struct Trainer {
     tape.push_back([=]() {
       float* gY = G(y, (size_t)B * C * Tt);
       float* gX = wants(x) ? G(x, (size_t)B * C * Tt) : nullptr;
-      if (live()) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, 1, PG(w, (size_t)C * K), PG(bias, C), st));
+      const size_t mark = ws.off;
+      float* sc = take<float>(dwconv_bwd_scratch_floats(B, C, Tt, K));
+      if (live()) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, 1, PG(w, (size_t)C * K), PG(bias, C), sc, st));
+      ws.off = mark;
     });
     return y;
   }
@@ -634,42 +640,49 @@ struct Trainer {
     return layernorm(x4, C, Tt, 1e-5f, &c.post_n, nullptr, nullptr);
   }
 
-  // ---------------- MelStyleEncoder (mel_style_encoder.py:9-152), 2-D convs on the same MFMA kernels ----------------
-  void conv2d(const PackedConv& w, const float* x, int Cin2d, int Hin, int Win, float* y, int Hout, int Wout, int hpad,
-              int pad, int pro, float out_scale, const float* residual) {
+  // ---------------- MelStyleEncoder (mel_style_encoder.py:9-152) in the padded-flat image layout (conv2d.hip) -------
+  // every activation is [B][C][H][W+1] with a zero last column; n = H*(W+1) flattened positions
+  void conv2d(const PackedConv& w, const float* x, int Cin2d, int n, int Wp, float* y, int hpad, int pad, int pro,
+              float out_scale, const float* residual, const float* mask) {
     ConvArgs a;
     a.x[0] = x;
     a.xc[0] = w.Cin;
     a.nsrc = 1;
     a.B = B;
-    a.T = Wout;
-    a.Tin = Win;
+    a.T = n;
     a.pad = pad;
     a.w = w;
-    a.H = Hout;
-    a.Hin = Hin;
+    a.flatW = Wp;
     a.hpad = hpad;
     a.Cin2d = Cin2d;
     a.pro = pro;
     a.out_scale = out_scale;
     a.residual = residual;
+    a.out_mask = mask;
+    a.out_mask_post = 1;
     a.y = y;
     if (live()) chk(launch_conv1d(a, st));
     tape.push_back([this, a]() { conv2d_bwd(a); });
   }
   void conv2d_bwd(const ConvArgs& f) {
     const PackedConv& w = f.w;
-    const int KH = w.Cin / f.Cin2d;
-    const size_t ny = (size_t)B * w.Cout * f.H * f.T, nx = (size_t)B * f.Cin2d * f.Hin * f.Tin;
+    const int KH = w.Cin / f.Cin2d, n = f.T;
+    const size_t ny = (size_t)B * w.Cout * n, nx = (size_t)B * f.Cin2d * n;
     float* gY = G(f.y, ny);
     float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
     float* gX = wants(f.x[0]) ? G(f.x[0], nx) : nullptr;
     const size_t mark = ws.off;
-    if (gR && live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, 1, (int)ny, gR, st));
-    if (w.bias && live())
-      chk(launch_bias_grad(gY, nullptr, B, w.Cout, f.H * f.T, 0, f.out_scale, PGpacked(w.bias), st));
-    float* partial = take<float>(wgrad_partial_floats(w, B * f.H, f.T));
-    if (live()) chk(launch_conv1d_wgrad(f, gY, nullptr, f.out_scale, PGpacked(w.wp), partial, st));
+    // gY may carry values in the pad columns (written by element-wise backward steps): everything below sees
+    // gY * mask, exactly as the forward stored y * mask
+    if (gR && live())
+      chk(launch_pro_bwd(PRO_MASK, gY, w.Cout, 0, gY, B, w.Cout, n, nullptr, nullptr, w.Cout, 0, nullptr, f.out_mask,
+                         gR, 1, nullptr, nullptr, nullptr, st));
+    if (w.bias) {
+      float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, n));
+      if (live()) chk(launch_bias_grad(gY, f.out_mask, B, w.Cout, n, 0, f.out_scale, PGpacked(w.bias), bs, st));
+    }
+    float* partial = take<float>(wgrad_partial_floats(w, B, n));
+    if (live()) chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, PGpacked(w.wp), partial, st));
     if (gX) {
       auto it = m->dgrad.find(w.wp);
       if (it == m->dgrad.end()) {
@@ -683,20 +696,20 @@ struct Trainer {
       d.xc[0] = it->second.Cin;
       d.nsrc = 1;
       d.B = B;
-      d.T = f.Tin;   // output width = forward input width
-      d.Tin = f.T;
+      d.T = n;
       d.pad = (w.K - 1) - f.pad;
       d.w = it->second;
-      d.H = f.Hin;
-      d.Hin = f.H;
+      d.flatW = f.flatW;
       d.hpad = (KH - 1) - f.hpad;
       d.Cin2d = w.Cout;
+      d.pro = PRO_MASK;
+      d.mask = f.out_mask;
       d.out_scale = f.out_scale;
       d.y = U;
       if (live()) {
         chk(launch_conv1d(d, st));
-        chk(launch_pro_bwd(f.pro, U, f.Cin2d, 0, f.x[0], B, f.Cin2d, f.Hin * f.Tin, nullptr, nullptr, f.Cin2d, 0,
-                           nullptr, nullptr, gX, 1, nullptr, nullptr, nullptr, st));
+        chk(launch_pro_bwd(f.pro, U, f.Cin2d, 0, f.x[0], B, f.Cin2d, n, nullptr, nullptr, f.Cin2d, 0, nullptr, nullptr,
+                           gX, 1, nullptr, nullptr, nullptr, st));
       }
     }
     ws.off = mark;
@@ -714,68 +727,82 @@ struct Trainer {
       hipError_t e = hipMemsetAsync(m->garena, 0, m->arena_bytes, st);
       if (e != hipSuccess) rc = hip_fail(e, "grad arena memset");
     }
-    nograd.insert(mel);
     const float r2 = 0.70710678118654752f;
     int H = sp.n_mels, W = Tt, C = sp.n_mels;
-    float* x = take<float>((size_t)B * C * H * W);
-    conv2d(sp.stem, mel, 1, H, W, x, H, W, 1, 1, PRO_NONE, 1.f, nullptr);
+    auto mask_for = [&](int Hh, int Ww, int Hv, int Wv) {
+      float* mk = take<float>((size_t)B * Hh * (Ww + 1));
+      if (live()) chk(launch_flat_mask(B, Hh, Ww + 1, Hv, Wv, mk, st));
+      return mk;
+    };
+    float* melp = take<float>((size_t)B * H * (W + 1));
+    if (live()) chk(launch_pad_cols(mel, (size_t)B * H, W, melp, st));
+    nograd.insert(melp);
+    const float* mk = mask_for(H, W, H, W);
+    float* x = take<float>((size_t)B * C * H * (W + 1));
+    conv2d(sp.stem, melp, 1, H * (W + 1), W + 1, x, 1, 1, PRO_NONE, 1.f, nullptr, mk);
     for (int i = 0; i < 4; ++i) {
       const StyleResBlk& k = sp.blk[i];
       const int Ho = k.down ? H / 2 : H, Wo = k.down ? (W + 1) / 2 : W;
       const int Hc = H, Wc = W;
+      const int n = H * (W + 1), no = Ho * (Wo + 1);
+      const float* mko = k.down ? mask_for(Ho, Wo, Ho, Wo) : mk;
       const float* xin = x;
       const float* sc_src = xin;
       if (k.has_sc) {
-        float* sc_full = take<float>((size_t)B * k.Cout * H * W);
-        conv2d(k.sc, xin, k.Cin, H, W, sc_full, H, W, 0, 0, PRO_NONE, r2, nullptr);
+        float* sc_full = take<float>((size_t)B * k.Cout * n);
+        conv2d(k.sc, xin, k.Cin, n, W + 1, sc_full, 0, 0, PRO_NONE, r2, nullptr, mk);
         sc_src = sc_full;
       }
       const float* res = nullptr;
       if (k.down) {
-        float* sc = take<float>((size_t)B * k.Cout * Ho * Wo);
+        float* sc = take<float>((size_t)B * k.Cout * no);
         const float scale = k.has_sc ? 1.f : r2;
         if (live()) chk(launch_avgpool2(sc_src, B * k.Cout, H, W, scale, sc, st));
         const int BC = B * k.Cout;
         tape.push_back([=]() {
-          float* g = G(sc, (size_t)BC * Ho * Wo);
-          float* gs = G(sc_src, (size_t)BC * Hc * Wc);
+          float* g = G(sc, (size_t)BC * no);
+          float* gs = G(sc_src, (size_t)BC * n);
           if (live()) chk(launch_avgpool2_bwd(g, BC, Hc, Wc, scale, gs, st));
         });
         res = sc;
       } else if (k.has_sc) {
         res = sc_src;
       }
-      float* h1 = take<float>((size_t)B * k.Cin * H * W);
-      conv2d(k.c1, xin, k.Cin, H, W, h1, H, W, 1, 1, PRO_LRELU, 1.f, nullptr);
+      float* h1 = take<float>((size_t)B * k.Cin * n);
+      conv2d(k.c1, xin, k.Cin, n, W + 1, h1, 1, 1, PRO_LRELU, 1.f, nullptr, mk);
       const float* h = h1;
       if (k.down) {
-        float* h2 = take<float>((size_t)B * k.Cin * Ho * Wo);
+        float* h2 = take<float>((size_t)B * k.Cin * no);
         if (live()) chk(launch_dwconv2d_s2(h1, k.dw_w9, k.dw_b, B, k.Cin, H, W, h2, st));
         const float* w9 = k.dw_w9;
         const float* dwb = k.dw_b;
         const int Cc = k.Cin;
         tape.push_back([=]() {
-          float* g = G(h2, (size_t)B * Cc * Ho * Wo);
-          float* gx = G(h1, (size_t)B * Cc * Hc * Wc);
-          if (live()) chk(launch_dwconv2d_s2_bwd(h1, g, w9, B, Cc, Hc, Wc, gx, PGpacked(w9), PG(dwb, Cc), st));
+          float* g = G(h2, (size_t)B * Cc * no);
+          float* gx = G(h1, (size_t)B * Cc * n);
+          const size_t mark = ws.off;
+          float* sc = take<float>(dwconv2d_s2_bwd_scratch_floats(B, Cc));
+          if (live()) chk(launch_dwconv2d_s2_bwd(h1, g, w9, B, Cc, Hc, Wc, gx, PGpacked(w9), PG(dwb, Cc), sc, st));
+          ws.off = mark;
         });
         h = h2;
       }
-      float* y = take<float>((size_t)B * k.Cout * Ho * Wo);
-      conv2d(k.c2, h, k.Cin, Ho, Wo, y, Ho, Wo, 1, 1, PRO_LRELU, r2, res);
+      float* y = take<float>((size_t)B * k.Cout * no);
+      conv2d(k.c2, h, k.Cin, no, Wo + 1, y, 1, 1, PRO_LRELU, r2, res, mko);
       if (!res) {  // identity shortcut: y += x / sqrt2
-        const size_t n = (size_t)B * k.Cout * Ho * Wo;
-        if (live()) chk(launch_axpy(xin, r2, y, n, st));
+        const size_t ne = (size_t)B * k.Cout * no;
+        if (live()) chk(launch_axpy(xin, r2, y, ne, st));
         tape.push_back([=]() {
-          float* g = G(y, n);
-          float* gx = G(xin, n);
-          if (live()) chk(launch_axpy(g, r2, gx, n, st));
+          float* g = G(y, ne);
+          float* gx = G(xin, ne);
+          if (live()) chk(launch_axpy(g, r2, gx, ne, st));
         });
       }
       x = y;
       H = Ho;
       W = Wo;
       C = k.Cout;
+      mk = mko;
     }
     const int KH = 5;
     const int Hh = H - KH + 1, Wh = W - sp.head.K + 1;
@@ -784,17 +811,20 @@ struct Trainer {
       rc = STY_ESHAPE;
       return;
     }
-    float* hd = take<float>((size_t)B * C * Hh * Wh);
-    conv2d(sp.head, x, C, H, W, hd, Hh, Wh, 0, 0, PRO_LRELU, 1.f, nullptr);
+    // 5x5 valid conv: computed at every flattened position, kept (mask) where the window fits
+    const int n = H * (W + 1);
+    const float* mkh = mask_for(H, W, Hh, Wh);
+    float* hd = take<float>((size_t)B * C * n);
+    conv2d(sp.head, x, C, n, W + 1, hd, 0, 0, PRO_LRELU, 1.f, nullptr, mkh);
     style_out = style_dst;
-    if (live()) chk(launch_pool_fc(hd, B, C, Hh * Wh, sp.fc_w, sp.fc_b, sp.style_dim, style_dst, st));
+    if (live()) chk(launch_pool_fc(hd, B, C, n, Hh * Wh, sp.fc_w, sp.fc_b, sp.style_dim, style_dst, st));
     const float* fw = sp.fc_w;
     const float* fb = sp.fc_b;
-    const int S = sp.style_dim, HW = Hh * Wh, Cc = C;
+    const int S = sp.style_dim, cnt = Hh * Wh, Cc = C;
     tape.push_back([=]() {
       float* gs = G(style_dst, (size_t)B * S);
-      float* gx = G(hd, (size_t)B * Cc * HW);
-      if (live()) chk(launch_pool_fc_bwd(hd, B, Cc, HW, fw, S, gs, PG(fw, (size_t)S * Cc), PG(fb, S), gx, st));
+      float* gx = G(hd, (size_t)B * Cc * n);
+      if (live()) chk(launch_pool_fc_bwd(hd, B, Cc, n, cnt, fw, S, gs, PG(fw, (size_t)S * Cc), PG(fb, S), gx, st));
     });
   }
   void style_backward(const float* d_style) {

@@ -46,8 +46,18 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
       case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
       case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
       case PRO_MASK: stage_chunk<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
-      case PRO_LRELU: stage_chunk<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
-      default: stage_chunk<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
+      case PRO_LRELU:
+        if (ax.flatW)
+          stage_chunk<PRO_LRELU, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
+        else
+          stage_chunk<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
+        break;
+      default:
+        if (ax.flatW)
+          stage_chunk<PRO_NONE, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
+        else
+          stage_chunk<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
+        break;
     }
     if (ag.pro == PRO_MASK)
       stage_chunk<PRO_MASK, 4, MAXJ>(ag, gs, co0, b, h, t0, LWg, wave, lane);
@@ -105,13 +115,31 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nslices, size_t plane, float scale,
-                                    float* __restrict__ gwp) {
+__global__ void wgrad_reduce_small_kernel(const float* __restrict__ partial, int nslices, size_t plane, float scale,
+                                          float* __restrict__ gwp) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= plane) return;
   float s = 0.f;
   for (int k = 0; k < nslices; ++k) s += partial[(size_t)k * plane + i];
   gwp[i] += s * scale;
+}
+// 16 plane elements x 16 slice groups per workgroup, combined through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nslices, size_t plane,
+                                                           float scale, float* __restrict__ gwp) {
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + e;
+  float s = 0.f;
+  if (i < plane)
+    for (int k = sg; k < nslices; k += 16) s += partial[(size_t)k * plane + i];
+  red[sg][e] = s;
+  __syncthreads();
+  if (sg == 0 && i < plane) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][e];
+    gwp[i] += t * scale;
+  }
 }
 
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x output rows in 2-D mode
@@ -166,7 +194,9 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   dim3 grid(w.CinP / 32, w.CoutP / 32, nsplit);
   const double flops = 2.0 * w.Cin * w.K * (double)fwd.B * w.Cout * fwd.T;
   const double bytes = 4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T);
-  ProfScope prof("conv1d_wgrad", flops, bytes, st);
+  char detail[40];
+  snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
+  ProfScope prof("wgrad", flops * HM, bytes * HM, st, detail);
   const int KT = w.K == 1 ? 0 : cdiv(w.K, 4);
 #define STY_WG(KTV)                                                                                              \
   hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, partial)
@@ -187,8 +217,12 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
 #undef STY_WG
   const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
   const int slices = w.K == 1 ? nsplit * 4 : nsplit;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, partial, slices,
-                     plane, scale, gwp);
+  if (slices >= 16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((plane + 15) / 16)), dim3(256), 0, st, partial, slices,
+                       plane, scale, gwp);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, partial,
+                       slices, plane, scale, gwp);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
