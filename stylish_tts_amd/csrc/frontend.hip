@@ -138,15 +138,20 @@ static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream
 }
 
 // frames (centre, reflect pad), windowed, channel-major: xt[b][n][fr] = w[n] * audio[reflect(fr*hop + n - n_fft/2)]
+// Element (b, c, fr) of every intermediate below lives at b*sb + c*sc + fr.  Plain layout [B][C][frames]: sb = C*frames,
+// sc = frames.  Batch-folded layout [C][B*frames] (sb = frames, sc = B*frames): the DFT / filter-bank GEMMs then see
+// ONE problem with B*frames columns instead of B problems with ~100 columns each (full MFMA tiles, and the 16 MB
+// DFT basis is streamed once per column tile instead of once per batch item).
 __global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ audio, const float* __restrict__ w, int N,
-                                                    int n_fft, int hop, int frames, float* __restrict__ xt) {
+                                                    int n_fft, int hop, int frames, size_t sb, size_t sc,
+                                                    float* __restrict__ xt) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
   int i = fr * hop + n - n_fft / 2;
   if (i < 0) i = -i;
   if (i >= N) i = 2 * (N - 1) - i;
-  xt[((size_t)b * n_fft + n) * frames + fr] = w[n] * audio[(size_t)b * N + i];
+  xt[b * sb + n * sc + fr] = w[n] * audio[(size_t)b * N + i];
 }
 
 // y [B][2F][frames] -> power [B][F][frames]
@@ -159,14 +164,15 @@ __global__ void power_kernel(const float* __restrict__ y, int F, int frames, flo
 }
 
 // y [B][2F][frames] -> |X| and (|X| > 1e-3) * angle(X)  (multi_spectrogram.py:48-49)
-__global__ void magphase_kernel(const float* __restrict__ y, int F, int frames, float* __restrict__ mag,
-                                float* __restrict__ phase) {
+// strides: y is (sb2, sc) with 2F channels, mag / phase are (sb1, sc) with F channels
+__global__ void magphase_kernel(const float* __restrict__ y, int F, int frames, size_t sb2, size_t sb1, size_t sc,
+                                float* __restrict__ mag, float* __restrict__ phase) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int f = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
-  const float re = y[((size_t)b * 2 * F + f) * frames + fr], im = y[((size_t)b * 2 * F + F + f) * frames + fr];
+  const float re = y[b * sb2 + f * sc + fr], im = y[b * sb2 + (size_t)(F + f) * sc + fr];
   const float m = hypotf(re, im);
-  const size_t o = ((size_t)b * F + f) * frames + fr;
+  const size_t o = b * sb1 + f * sc + fr;
   mag[o] = m;
   if (phase) phase[o] = m > 1e-3f ? atan2f(im, re) : 0.f;
 }
@@ -224,7 +230,7 @@ int launch_mel(int B, int N, const float* audio, int n_fft, int win, int hop, in
   float* p = y + (size_t)B * 2 * F * frames;
   float* mp = p + (size_t)B * F * frames;
   hipLaunchKernelGGL(frame_kernel, dim3(cdiv(frames, 256), n_fft, B), dim3(256), 0, st, audio, t->window, N, n_fft, hop,
-                     frames, xt);
+                     frames, (size_t)n_fft * frames, (size_t)frames, xt);
   rc = dense(t->dft, xt, B, frames, y, st);
   if (rc) return rc;
   hipLaunchKernelGGL(power_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, p);
@@ -252,10 +258,11 @@ int launch_multispec_single(int B, int N, const float* audio, int n_fft, int hop
   float* xt = ws;
   float* y = xt + (size_t)B * n_fft * frames;
   hipLaunchKernelGGL(frame_kernel, dim3(cdiv(frames, 256), n_fft, B), dim3(256), 0, st, audio, t->window, N, n_fft, hop,
-                     frames, xt);
+                     frames, (size_t)n_fft * frames, (size_t)frames, xt);
   rc = dense(t->dft, xt, B, frames, y, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, fft_mag, phase);
+  hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames,
+                     (size_t)2 * F * frames, (size_t)F * frames, (size_t)frames, fft_mag, phase);
   rc = dense(t->fb, fft_mag, B, frames, mag, st);
   if (rc) return rc;
   const size_t n = (size_t)B * 128 * frames;
@@ -291,13 +298,14 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(ResBufs rb, int r, int B
     acc[0] += fabsf(rb.t_mag[i] - rb.p_mag[i]);
     acc[1] += fabsf(rb.t_mag[i]);
   }
+  const size_t fs = (size_t)B * fr;  // batch-folded layout [F][B][frames]: frequency stride
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nph; i += (size_t)gridDim.x * 256) {
-    const int t = (int)(i % fr), f = (int)((i / fr) % F);
+    const int t = (int)(i % fr), f = (int)(i / fs);
     const float w = (float)exp(lb * f);
     const float d0 = rb.p_phase[i] - rb.t_phase[i];
     acc[2] += fabsf(aw_res(d0)) * w;
     if (f + 1 < F) {
-      const float d1 = (rb.p_phase[i + fr] - rb.t_phase[i + fr]) - d0;
+      const float d1 = (rb.p_phase[i + fs] - rb.t_phase[i + fs]) - d0;
       acc[3] += fabsf(aw_res(d1)) * w;
     }
     if (t + 1 < fr) {
@@ -342,7 +350,8 @@ __global__ void loss_grad_kernel(ResBufs rb, int r, int B, const double* __restr
   const float kph = w_phase / (losses[1] + 1e-9f) / 3.0f;
   if (i < nmag) rb.d_mag[i] = -kmel * sgnf(rb.t_mag[i] - rb.p_mag[i]);
   if (i < nph) {
-    const int t = (int)(i % fr), f = (int)((i / fr) % F);
+    const size_t fs = (size_t)B * fr;
+    const int t = (int)(i % fr), f = (int)(i / fs);
     const double lb = log(2.5) / (double)(F / 2);
     const float w = (float)exp(lb * f), wm = f > 0 ? (float)exp(lb * (f - 1)) : 0.f;
     const float n0 = 1.0f / ((float)B * F * fr), n1 = 1.0f / ((float)B * (F - 1) * fr),
@@ -350,8 +359,8 @@ __global__ void loss_grad_kernel(ResBufs rb, int r, int B, const double* __restr
     auto D = [&](size_t j) { return rb.p_phase[j] - rb.t_phase[j]; };
     const float d0 = D(i);
     float g = w * sgnf(aw_res(d0)) * n0;
-    if (f + 1 < F) g -= w * sgnf(aw_res(D(i + fr) - d0)) * n1;
-    if (f > 0) g += wm * sgnf(aw_res(d0 - D(i - fr))) * n1;
+    if (f + 1 < F) g -= w * sgnf(aw_res(D(i + fs) - d0)) * n1;
+    if (f > 0) g += wm * sgnf(aw_res(d0 - D(i - fs))) * n1;
     if (t + 1 < fr) g -= w * sgnf(aw_res(D(i + 1) - d0)) * n2;
     if (t > 0) g += w * sgnf(aw_res(d0 - D(i - 1))) * n2;
     rb.d_phase[i] = kph * g;
@@ -366,14 +375,15 @@ __global__ void log1p_bwd_kernel(float* __restrict__ d, const float* __restrict_
 
 // dY[b][f / F+f][fr] from d|X| and d phase
 __global__ void magphase_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dabs,
-                                    const float* __restrict__ dphase, int F, int frames, float* __restrict__ dy) {
+                                    const float* __restrict__ dphase, int F, int frames, size_t sb2, size_t sb1,
+                                    size_t sc, float* __restrict__ dy) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int f = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
-  const size_t ore = ((size_t)b * 2 * F + f) * frames + fr, oim = ((size_t)b * 2 * F + F + f) * frames + fr;
+  const size_t ore = b * sb2 + f * sc + fr, oim = b * sb2 + (size_t)(F + f) * sc + fr;
   const float re = y[ore], im = y[oim];
   const float m = hypotf(re, im);
-  const size_t o = ((size_t)b * F + f) * frames + fr;
+  const size_t o = b * sb1 + f * sc + fr;
   float gre = 0.f, gim = 0.f;
   if (m > 0.f) {
     gre = dabs[o] * re / m;
@@ -390,7 +400,7 @@ __global__ void magphase_bwd_kernel(const float* __restrict__ y, const float* __
 
 // d audio[b][i] += sum over frames / reflections of w[n] * dxt[b][n][fr]   (gather, no atomics)
 __global__ void frame_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ w, int N, int n_fft, int hop,
-                                 int frames, float* __restrict__ daudio) {
+                                 int frames, size_t sb, size_t sc, float* __restrict__ daudio) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= N) return;
   const int half = n_fft / 2;
@@ -410,7 +420,7 @@ __global__ void frame_bwd_kernel(const float* __restrict__ dxt, const float* __r
     if (f_lo < 0) f_lo = 0;
     for (int fr = f_lo; fr <= f_hi; ++fr) {
       const int n = q - fr * hop;
-      if (n >= 0 && n < n_fft) acc = fmaf(w[n], dxt[((size_t)b * n_fft + n) * frames + fr], acc);
+      if (n >= 0 && n < n_fft) acc = fmaf(w[n], dxt[b * sb + n * sc + fr], acc);
     }
   }
   daudio[(size_t)b * N + i] += acc;
@@ -479,12 +489,14 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
       float* fm = side == 0 ? tfft : rb[r].p_fft;
       float* mg = side == 0 ? rb[r].t_mag : rb[r].p_mag;
       float* ph = side == 0 ? rb[r].t_phase : rb[r].p_phase;
+      // batch-folded layout: (sb, sc) = (frames, B*frames) for every tensor, GEMMs over B*frames columns
       hipLaunchKernelGGL(frame_kernel, dim3(cdiv(frames, 256), n_fft, B), dim3(256), 0, st, audio, t->window, N, n_fft,
-                         rb[r].hop, frames, xt);
-      rc = dense(t->dft, xt, B, frames, yy, st);
+                         rb[r].hop, frames, (size_t)frames, (size_t)B * frames, xt);
+      rc = dense(t->dft, xt, 1, B * frames, yy, st);
       if (rc) return rc;
-      hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, yy, F, frames, fm, ph);
-      rc = dense(t->fb, fm, B, frames, mg, st);
+      hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, yy, F, frames,
+                         (size_t)frames, (size_t)frames, (size_t)B * frames, fm, ph);
+      rc = dense(t->fb, fm, 1, B * frames, mg, st);
       if (rc) return rc;
       const size_t n = (size_t)B * 128 * frames;
       hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mg, n);
@@ -507,14 +519,14 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
     float* dabs = tmp;                                   // [B][F][frames]
     float* dy = dabs + (size_t)B * F * frames;           // [B][2F][frames]
     float* dxt = dy + (size_t)B * 2 * F * frames;        // [B][n_fft][frames]
-    rc = dense(t->fbT, rb[r].d_mag, B, frames, dabs, st);
+    rc = dense(t->fbT, rb[r].d_mag, 1, B * frames, dabs, st);
     if (rc) return rc;
     hipLaunchKernelGGL(magphase_bwd_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, rb[r].p_y, dabs,
-                       rb[r].d_phase, F, frames, dy);
-    rc = dense(t->dftT, dy, B, frames, dxt, st);
+                       rb[r].d_phase, F, frames, (size_t)frames, (size_t)frames, (size_t)B * frames, dy);
+    rc = dense(t->dftT, dy, 1, B * frames, dxt, st);
     if (rc) return rc;
     hipLaunchKernelGGL(frame_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, dxt, t->window, N, n_fft, rb[r].hop,
-                       frames, d_pred);
+                       frames, (size_t)frames, (size_t)B * frames, d_pred);
   }
   STY_LAUNCH_CHECK();
   return STY_OK;

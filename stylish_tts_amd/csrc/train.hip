@@ -58,6 +58,19 @@ struct Trainer {
     gmap[act] = g;
     return g;
   }
+  // same, for a producer that can either overwrite or accumulate: the first writer of a buffer overwrites it
+  // (acc = 0) and no zero-fill is issued; later writers accumulate
+  float* Gw(const float* act, size_t n, int& acc) {
+    auto it = gmap.find(act);
+    if (it != gmap.end()) {
+      acc = 1;
+      return it->second;
+    }
+    float* g = take<float>(n);
+    gmap[act] = g;
+    acc = 0;
+    return g;
+  }
   bool wants(const float* act) const { return !nograd.count(act); }
   // parameter gradient pointer: packed (inside the grad arena) or bound by the caller
   float* PGpacked(const float* packed) const {
@@ -98,12 +111,16 @@ struct Trainer {
     float* gY = G(f.y, ny);
     float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
     float* gX[3] = {nullptr, nullptr, nullptr};
+    int accX[3] = {1, 1, 1};
     bool any = false;
     for (int i = 0; i < f.nsrc; ++i)
       if (wants(f.x[i])) {
-        gX[i] = G(f.x[i], (size_t)B * f.xc[i] * Tt);
+        gX[i] = Gw(f.x[i], (size_t)B * f.xc[i] * Tt, accX[i]);
         any = true;
       }
+    for (int i = 1; i < f.nsrc; ++i)
+      for (int j = 0; j < i; ++j)
+        if (gX[i] && gX[i] == gX[j]) accX[i] = 1;
     float* dpa = nullptr;
     float* dps = nullptr;
     float* dal = nullptr;
@@ -161,7 +178,7 @@ struct Trainer {
       for (int i = 0; i < f.nsrc; ++i) {
         if (gX[i] && live())
           chk(launch_pro_bwd(f.pro, U, w.Cin, c0, f.x[i], B, f.xc[i], Tt, f.pa, f.ps, w.Cin, c0, f.palpha, f.mask, gX[i],
-                             1, dpa, dps, dal, st));
+                             accX[i], dpa, dps, dal, st));
         c0 += f.xc[i];
       }
     }
@@ -175,9 +192,10 @@ struct Trainer {
     tape.push_back([=]() {
       const int Cin = kind == ACT_GLU ? 2 * C : C;
       float* gY = G(y, (size_t)B * C * Tt);
-      float* gX = G(x, (size_t)B * Cin * Tt);
+      int acc = 1;
+      float* gX = Gw(x, (size_t)B * Cin * Tt, acc);
       float* dal = kind == ACT_SNAKE ? PG(alpha, C) : nullptr;
-      if (live()) chk(launch_act_bwd(kind, x, gY, alpha, B, C, Tt, gX, 1, dal, st));
+      if (live()) chk(launch_act_bwd(kind, x, gY, alpha, B, C, Tt, gX, acc, dal, st));
     });
     return y;
   }
@@ -191,14 +209,15 @@ struct Trainer {
     if (live()) chk(launch_chan_layernorm(x, y, B, C, Tt, eps, fc ? 1 : 0, w, bvec, gbl, relu, omask, st));
     tape.push_back([=]() {
       float* gY = G(y, (size_t)B * C * Tt);
-      float* gX = G(x, (size_t)B * C * Tt);
+      int acc = 1;
+      float* gX = Gw(x, (size_t)B * C * Tt, acc);
       const size_t mark = ws.off;
       float* mu = take<float>((size_t)B * Tt);
       float* r = take<float>((size_t)B * Tt);
       float* dw = fc ? nullptr : PG(w, C);
       float* db = fc ? nullptr : PG(bvec, C);
       if (live())
-        chk(launch_chan_ln_bwd(x, gY, y, B, C, Tt, eps, fc ? 1 : 0, w, gbl, relu, omask, gX, 1, mu, r, dgl, dw, db, st));
+        chk(launch_chan_ln_bwd(x, gY, y, B, C, Tt, eps, fc ? 1 : 0, w, gbl, relu, omask, gX, acc, mu, r, dgl, dw, db, st));
       ws.off = mark;
     });
     return y;
@@ -241,10 +260,11 @@ struct Trainer {
     if (live()) chk(launch_dwconv_fwd(x, w, bias, B, C, Tt, K, pad, y, st));
     tape.push_back([=]() {
       float* gY = G(y, (size_t)B * C * Tt);
-      float* gX = wants(x) ? G(x, (size_t)B * C * Tt) : nullptr;
+      int acc = 1;
+      float* gX = wants(x) ? Gw(x, (size_t)B * C * Tt, acc) : nullptr;
       const size_t mark = ws.off;
       float* sc = take<float>(dwconv_bwd_scratch_floats(B, C, Tt, K));
-      if (live()) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, 1, PG(w, (size_t)C * K), PG(bias, C), sc, st));
+      if (live()) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, acc, PG(w, (size_t)C * K), PG(bias, C), sc, st));
       ws.off = mark;
     });
     return y;
@@ -670,7 +690,8 @@ struct Trainer {
     const size_t ny = (size_t)B * w.Cout * n, nx = (size_t)B * f.Cin2d * n;
     float* gY = G(f.y, ny);
     float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
-    float* gX = wants(f.x[0]) ? G(f.x[0], nx) : nullptr;
+    int accX = 1;
+    float* gX = wants(f.x[0]) ? Gw(f.x[0], nx, accX) : nullptr;
     const size_t mark = ws.off;
     // gY may carry values in the pad columns (written by element-wise backward steps): everything below sees
     // gY * mask, exactly as the forward stored y * mask
@@ -709,7 +730,7 @@ struct Trainer {
       if (live()) {
         chk(launch_conv1d(d, st));
         chk(launch_pro_bwd(f.pro, U, f.Cin2d, 0, f.x[0], B, f.Cin2d, n, nullptr, nullptr, f.Cin2d, 0, nullptr, nullptr,
-                           gX, 1, nullptr, nullptr, nullptr, st));
+                           gX, accX, nullptr, nullptr, nullptr, st));
       }
     }
     ws.off = mark;
