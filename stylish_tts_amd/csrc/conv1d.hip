@@ -34,8 +34,14 @@ __device__ __forceinline__ float act_apply(float x, float alpha) {
   return x;
 }
 
+#ifndef STY_PIPE
+#define STY_PIPE 0
+#endif
+#ifndef STY_MINW
+#define STY_MINW 2
+#endif
 template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void conv1d_mfma_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;  // waves per workgroup (4 or 8)
   constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
   constexpr int MAXJ = (TT_BLK + 128 + 63) / 64;  // launch_cfg guarantees halo <= 128
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: descriptors stay in SGPRs
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
   const int b = a.H ? blockIdx.z / a.H : blockIdx.z;
@@ -66,32 +72,58 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w.wp), 0, K * CinP * CoutP * 4, 0x00020000);
+  const int wv = (hi * CoutP + co0 + l31) * 4;
+  // Optional software pipeline (STY_PIPE=1, 4-wave configurations): the global loads of chunk c+1 are issued before
+  // the last tap's MFMAs of chunk c.  Measured on MI355X it LOSES (c2 step 71.9 -> 88.6 ms, c5 12.3 -> 14.4 ms):
+  // the in-order vmcnt makes the next A-fragment wait also wait for the tile loads, and the tile registers stay
+  // live across the barrier.  Default: load -> prologue -> LDS -> compute, overlap comes from 2-4 workgroups per CU.
+  constexpr bool PIPE = NW == 4 && STY_PIPE;
+  StageRegs<NW, PIPE ? MAXJ : 1> R;
+  auto do_load = [&](int ci0) {
+    if constexpr (PIPE) {
+      if (a.flatW)
+        stage_load<NW, MAXJ, true>(a, ci0, b, h, t0, LW, wave, lane, R);
+      else
+        stage_load<NW, MAXJ, false>(a, ci0, b, h, t0, LW, wave, lane, R);
+    }
+  };
+#define STY_STAGE(PRO, FLAT)                                                       \
+  do {                                                                             \
+    if constexpr (PIPE)                                                            \
+      stage_store<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, R);   \
+    else                                                                           \
+      stage_chunk<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane);      \
+  } while (0)
+  do_load(0);
   for (int ci0 = 0; ci0 < CinP; ci0 += CI_CHUNK) {
     __syncthreads();
     switch (a.pro) {
-      case PRO_AFFINE: stage_chunk<PRO_AFFINE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
-      case PRO_SCALE: stage_chunk<PRO_SCALE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
-      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
-      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane); break;
+      case PRO_AFFINE: STY_STAGE(PRO_AFFINE, false); break;
+      case PRO_SCALE: STY_STAGE(PRO_SCALE, false); break;
+      case PRO_AFFINE_SNAKE: STY_STAGE(PRO_AFFINE_SNAKE, false); break;
+      case PRO_AFFINE_LRELU: STY_STAGE(PRO_AFFINE_LRELU, false); break;
       case PRO_MASK:
         if (a.flatW)
-          stage_chunk<PRO_MASK, NW, MAXJ, true>(a, xs, ci0, b, h, t0, LW, wave, lane);
+          STY_STAGE(PRO_MASK, true);
         else
-          stage_chunk<PRO_MASK, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane);
+          STY_STAGE(PRO_MASK, false);
         break;
       case PRO_LRELU:
         if (a.flatW)
-          stage_chunk<PRO_LRELU, NW, MAXJ, true>(a, xs, ci0, b, h, t0, LW, wave, lane);
+          STY_STAGE(PRO_LRELU, true);
         else
-          stage_chunk<PRO_LRELU, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane);
+          STY_STAGE(PRO_LRELU, false);
         break;
       default:
         if (a.flatW)
-          stage_chunk<PRO_NONE, NW, MAXJ, true>(a, xs, ci0, b, h, t0, LW, wave, lane);
+          STY_STAGE(PRO_NONE, true);
         else
-          stage_chunk<PRO_NONE, NW, MAXJ>(a, xs, ci0, b, h, t0, LW, wave, lane);
+          STY_STAGE(PRO_NONE, false);
         break;
     }
+#undef STY_STAGE
     if (a.pro == PRO_LN_AFFINE) {
       // LayerNorm over the Cin (<= 32, single chunk) channels of every in-range column, then affine.
       __syncthreads();
@@ -115,14 +147,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
     // All B fragments of a tap are read from LDS before its first MFMA (hipcc otherwise recycles one register pair:
     // ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs); 4-wave configurations also fetch the A fragments (packed
     // weights, L2-resident) of tap k+1 while tap k's MFMAs issue.
+    // packed weights through one buffer descriptor: per-lane byte offset wv (fixed for the whole kernel), the
+    // (tap, channel pair) part of the address is a scalar soffset
     if constexpr (NW == 4) {
       float a_nxt[CI_CHUNK / 2][MT];
       {
-        const float* wrow = a.w.wp + ((size_t)ci0 + hi) * CoutP + co0 + l31;
+        const int srow = ci0 * CoutP * 4;
 #pragma unroll
         for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a_nxt[c2][m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+          for (int m = 0; m < MT; ++m)
+            a_nxt[c2][m] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
       }
       for (int k = 0; k < K; ++k) {
         float a_cur[CI_CHUNK / 2][MT];
@@ -131,12 +167,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
 #pragma unroll
           for (int m = 0; m < MT; ++m) a_cur[c2][m] = a_nxt[c2][m];
         if (k + 1 < K) {
-          const float* wrow = a.w.wp + ((size_t)(k + 1) * CinP + ci0 + hi) * CoutP + co0 + l31;
+          const int srow = ((k + 1) * CinP + ci0) * CoutP * 4;
 #pragma unroll
           for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a_nxt[c2][m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+            for (int m = 0; m < MT; ++m)
+              a_nxt[c2][m] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
         }
+        if (k == K - 1 && ci0 + CI_CHUNK < CinP) do_load(ci0 + CI_CHUNK);  // next chunk's tile, in flight below
         const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
         float bv[CI_CHUNK / 2][NT];
 #pragma unroll
@@ -155,13 +194,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 1)) void conv1d_m
       }
     } else {
       for (int k = 0; k < K; ++k) {
-        const float* wrow = a.w.wp + ((size_t)k * CinP + ci0 + hi) * CoutP + co0 + l31;
+        const int srow = (k * CinP + ci0) * CoutP * 4;
         const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
         float av[CI_CHUNK / 2][MT], bv[CI_CHUNK / 2][NT];
 #pragma unroll
         for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) av[c2][m] = wrow[(size_t)(2 * c2) * CoutP + m * 32];
+          for (int m = 0; m < MT; ++m)
+            av[c2][m] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
 #pragma unroll
           for (int n = 0; n < NT; ++n) bv[c2][n] = xrow[(2 * c2) * LW + n * 32];
         }

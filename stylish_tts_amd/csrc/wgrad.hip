@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   // ax: the forward conv's input side (sources, prologue, pad, dil, weight dims); ag: the output-gradient side
   //     (x[0] = G, optional mask / in_shuffle), K = 1, pad = 0.
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
+            hi = lane >> 5;
   const int K = ax.w.K, dil = ax.dil;
   const int halo = (K - 1) * dil;
   const int LWx = (WG_TW + halo) | 1, LWg = WG_TW + 1;  // odd row strides

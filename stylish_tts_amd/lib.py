@@ -4,6 +4,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstylish_hip.so")
+if os.environ.get("STY_LIB_VARIANT"):  # kernel-tuning aid (tools/build_variant.sh): same ABI, different build flags
+    LIB_PATH = os.path.join(HERE, f"libstylish_hip_{os.environ['STY_LIB_VARIANT']}.so")
 
 
 class StyError(RuntimeError):
