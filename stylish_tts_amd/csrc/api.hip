@@ -1179,6 +1179,10 @@ void sty_model_destroy(sty_model* m) {
   if (m->stft_default) (void)hipFree(m->stft_default);
   if (m->garena) (void)hipFree(m->garena);
   if (m->fcs_bwd_dev) (void)hipFree(m->fcs_bwd_dev);
+  for (int i = 0; i < 3; ++i) {
+    if (m->mj_dev[i]) (void)hipFree(m->mj_dev[i]);
+    if (m->mj_blk_dev[i]) (void)hipFree(m->mj_blk_dev[i]);
+  }
   if (m->trainer) trainer_destroy(m->trainer);
   delete m;
 }
@@ -1213,6 +1217,7 @@ int sty_model_finalize(sty_model* m) {
   }
   m->requested.clear();
   m->jobs.clear();
+  m->mj_ready = false;
   m->fcs.clear();
   m->missing.clear();
   m->ab = Bump();
@@ -1285,6 +1290,7 @@ int sty_model_bind_grad(sty_model* m, const char* key, float* grad) {
   return STY_OK;
 }
 
+static int build_multi_tables(sty_model* m);
 // packed gradients -> the caller's parameter gradients (+=)
 static int unpack_grads(sty_model* m, hipStream_t st) {
   auto PG = [&](const float* p) -> float* {
@@ -1294,26 +1300,17 @@ static int unpack_grads(sty_model* m, hipStream_t st) {
   auto GA = [&](const float* packed) -> float* {
     return reinterpret_cast<float*>(m->garena + (reinterpret_cast<const char*>(packed) - m->arena));
   };
+  if (!m->mj_ready) {
+    int r = build_multi_tables(m);
+    if (r != STY_OK) return r;
+  }
+  {  // every plain / weight-norm conv (weights and biases) in one launch
+    int r = launch_multi(2, m->mj_dev[2], m->mj_blk_dev[2], m->mj_nblk[2], st);
+    if (r != STY_OK) return r;
+  }
   for (const PackJob& j : m->jobs) {
     if (j.kind == PK_CONV || j.kind == PK_CONV_WN) {
-      // GLU-ordered jobs are never used by the training graph; their plain-ordered twins are PK_CONV
-      float* dW = j.w ? PG(j.w) : nullptr;
-      float* dg = j.g ? PG(j.g) : nullptr;
-      float* dv = j.v ? PG(j.v) : nullptr;
-      if (j.kind == PK_CONV && dW) {
-        int r = launch_unpack_grad(GA(j.wp), nullptr, nullptr, j.Cout, j.Cin, j.K, j.CinP, j.CoutP, 0, dW, nullptr,
-                                   nullptr, st);
-        if (r) return r;
-      }
-      if (j.kind == PK_CONV_WN && dg && dv) {
-        int r = launch_unpack_grad(GA(j.wp), j.g, j.v, j.Cout, j.Cin, j.K, j.CinP, j.CoutP, 0, nullptr, dg, dv, st);
-        if (r) return r;
-      }
-      float* db = (j.bias && j.bp) ? PG(j.bias) : nullptr;
-      if (db) {
-        int r = launch_axpy(GA(j.bp), 1.0f, db, (size_t)j.Cout, st);
-        if (r) return r;
-      }
+      // batched above
     } else if (j.kind == PK_CONV2D_SN) {
       float* dW = PG(j.w);
       if (dW) {  // the gradient-arena twin of the sigma scratch holds the <G, W> row sums
@@ -1445,12 +1442,96 @@ const char* sty_model_key(const sty_model* m, int i) {
   return m->requested[i].c_str();
 }
 
+// device tables for the batched pack / input-gradient pack / gradient un-pack launches
+static int build_multi_tables(sty_model* m) {
+  std::vector<MultiJob> jobs[3];
+  std::vector<int> blk[3];
+  auto PG = [&](const float* p) -> float* {
+    auto it = p ? m->pgrad.find(p) : m->pgrad.end();
+    return it == m->pgrad.end() ? nullptr : it->second;
+  };
+  auto GA = [&](const float* packed) -> float* {
+    return (packed && m->garena) ? reinterpret_cast<float*>(m->garena + (reinterpret_cast<const char*>(packed) - m->arena))
+                                 : nullptr;
+  };
+  auto add = [&](int which, MultiJob j, int nblocks) {
+    j.blk0 = (int)blk[which].size();
+    for (int i = 0; i < nblocks; ++i) blk[which].push_back((int)jobs[which].size());
+    jobs[which].push_back(j);
+  };
+  for (const PackJob& j : m->jobs) {
+    if (j.kind == PK_CONV || j.kind == PK_CONV_WN || j.kind == PK_CONV_GLU) {
+      MultiJob a;
+      a.p0 = j.w;
+      a.p1 = j.g;
+      a.p2 = j.v;
+      a.p3 = j.bias;
+      a.q0 = j.wp;
+      a.q1 = j.bp;
+      a.Cout = j.Cout;
+      a.Cin = j.Cin;
+      a.K = j.K;
+      a.CinP = j.CinP;
+      a.CoutP = j.CoutP;
+      a.glu = j.kind == PK_CONV_GLU;
+      add(0, a, j.Cout);
+      if (m->garena && j.kind != PK_CONV_GLU) {  // GLU-ordered packs are not used by the training graph
+        MultiJob u;
+        u.p0 = GA(j.wp);
+        u.p1 = j.g;
+        u.p2 = j.kind == PK_CONV_WN ? j.v : nullptr;
+        u.p3 = (j.bias && j.bp) ? GA(j.bp) : nullptr;
+        u.q0 = j.kind == PK_CONV ? PG(j.w) : nullptr;
+        u.q1 = j.kind == PK_CONV_WN ? PG(j.g) : nullptr;
+        u.q2 = j.kind == PK_CONV_WN ? PG(j.v) : nullptr;
+        u.q3 = (j.bias && j.bp) ? PG(j.bias) : nullptr;
+        u.Cout = j.Cout;
+        u.Cin = j.Cin;
+        u.K = j.K;
+        u.CinP = j.CinP;
+        u.CoutP = j.CoutP;
+        if (u.q0 || (u.q1 && u.q2) || u.q3) add(2, u, j.Cout);
+      }
+    } else if (j.kind == PK_DGRAD) {
+      MultiJob a;
+      a.p0 = j.w;
+      a.q0 = j.wp;
+      a.K = j.K;
+      a.CinP = j.CinP;
+      a.CoutP = j.CoutP;
+      add(1, a, (int)(((size_t)j.K * j.CinP * j.CoutP + 255) / 256));
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (m->mj_dev[i]) (void)hipFree(m->mj_dev[i]);
+    if (m->mj_blk_dev[i]) (void)hipFree(m->mj_blk_dev[i]);
+    m->mj_dev[i] = nullptr;
+    m->mj_blk_dev[i] = nullptr;
+    m->mj_nblk[i] = (int)blk[i].size();
+    if (blk[i].empty()) continue;
+    STY_HIP(hipMalloc((void**)&m->mj_dev[i], jobs[i].size() * sizeof(MultiJob)));
+    STY_HIP(hipMalloc((void**)&m->mj_blk_dev[i], blk[i].size() * sizeof(int)));
+    STY_HIP(hipMemcpy(m->mj_dev[i], jobs[i].data(), jobs[i].size() * sizeof(MultiJob), hipMemcpyHostToDevice));
+    STY_HIP(hipMemcpy(m->mj_blk_dev[i], blk[i].data(), blk[i].size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  m->mj_ready = true;
+  return STY_OK;
+}
+
 int sty_model_prepare(sty_model* m, void* stream) {
   if (!m || !m->finalized) {
     set_error("sty_model_prepare: model not finalized");
     return STY_ESTATE;
   }
   hipStream_t st = S(stream);
+  if (!m->mj_ready) {
+    int r = build_multi_tables(m);
+    if (r != STY_OK) return r;
+  }
+  {  // every plain / weight-norm / GLU conv pack in one launch
+    int r = launch_multi(0, m->mj_dev[0], m->mj_blk_dev[0], m->mj_nblk[0], st);
+    if (r != STY_OK) return r;
+  }
   for (const PackJob& j : m->jobs) {
     int r = STY_OK;
     switch (j.kind) {
@@ -1459,11 +1540,8 @@ int sty_model_prepare(sty_model* m, void* stream) {
         break;  // second pass below
       case PK_CONV:
       case PK_CONV_WN:
-        r = launch_pack_conv(j.w, j.g, j.v, j.bias, j.Cout, j.Cin, j.K, j.wp, j.bp, j.CinP, j.CoutP, st);
-        break;
       case PK_CONV_GLU:
-        r = launch_pack_conv_glu(j.w, j.bias, j.Cout, j.Cin, j.K, j.wp, j.bp, j.CinP, j.CoutP, st);
-        break;
+        break;  // batched above
       case PK_W2A:
         r = launch_pack_w2a(j.w, j.bias, j.extra, j.Cout, j.wp, j.bp, st);
         break;
@@ -1477,9 +1555,12 @@ int sty_model_prepare(sty_model* m, void* stream) {
     }
     if (r != STY_OK) return r;
   }
+  {
+    int r = launch_multi(1, m->mj_dev[1], m->mj_blk_dev[1], m->mj_nblk[1], st);
+    if (r != STY_OK) return r;
+  }
   for (const PackJob& j : m->jobs) {
     int r = STY_OK;
-    if (j.kind == PK_DGRAD) r = launch_pack_dgrad(j.w, j.K, j.CinP, j.CoutP, j.wp, st);
     if (j.kind == PK_DGRAD2D)
       r = launch_pack_dgrad2d(j.w, j.K, j.KH, j.Cin, j.Cout, j.CinP, j.CoutP, (int)align_up(j.KH * j.Cout, CI_CHUNK),
                               (int)align_up(j.Cin, 32), j.wp, st);

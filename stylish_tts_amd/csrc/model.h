@@ -186,6 +186,11 @@ struct sty_model {
   std::unordered_map<const float*, sty::PackedConv> dgrad;      // forward packed weights -> input-gradient weights
   std::unordered_map<const float*, sty::PackedConv> plain_of;   // GLU-ordered packed conv -> plain-ordered copy
   void* fcs_bwd_dev = nullptr;
+  // batched weight-side launches: device tables [0] pack, [1] input-gradient pack, [2] gradient un-pack
+  sty::MultiJob* mj_dev[3] = {nullptr, nullptr, nullptr};
+  int* mj_blk_dev[3] = {nullptr, nullptr, nullptr};
+  int mj_nblk[3] = {0, 0, 0};
+  bool mj_ready = false;
   struct sty::Trainer* trainer = nullptr;
 };
 

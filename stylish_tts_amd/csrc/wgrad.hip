@@ -302,6 +302,111 @@ int launch_unpack_grad(const float* gwp, const float* g, const float* v, int Cou
   return STY_OK;
 }
 
+// ---- the same three weight-side steps for MANY convs in one launch (the speech predictor has ~130 dense convs:
+//      ~400 launches of 4-5 us each per optimizer step when issued one by one) ----
+// job_of_block[blockIdx.x] selects the job, blockIdx.x - job.blk0 is the block index inside it.
+__global__ __launch_bounds__(256) void pack_conv_multi_kernel(const MultiJob* __restrict__ jobs,
+                                                              const int* __restrict__ job_of_block) {
+  __shared__ float red[256];
+  const MultiJob j = jobs[job_of_block[blockIdx.x]];
+  const int co = blockIdx.x - j.blk0;
+  const int n = j.Cin * j.K;
+  int cp = co;
+  if (j.glu) {
+    const int Ch = j.Cout / 2;
+    const int half = co >= Ch, c = half ? co - Ch : co;
+    cp = (c >> 5) * 64 + half * 32 + (c & 31);
+  }
+  float scale = 1.f;
+  const float* src = j.p0;  // plain weight, or (p1 = g, p2 = v) of weight norm
+  if (!src) {
+    src = j.p2;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float x = src[(size_t)co * n + i];
+      s += x * x;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    scale = j.p1[co] / sqrtf(red[0]);
+  }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / j.K, k = i % j.K;
+    j.q0[((size_t)k * j.CinP + ci) * j.CoutP + cp] = src[(size_t)co * n + i] * scale;
+  }
+  if (threadIdx.x == 0 && j.q1) j.q1[cp] = j.p3 ? j.p3[co] : 0.f;
+}
+__global__ __launch_bounds__(256) void pack_dgrad_multi_kernel(const MultiJob* __restrict__ jobs,
+                                                               const int* __restrict__ job_of_block) {
+  const MultiJob j = jobs[job_of_block[blockIdx.x]];
+  const size_t i = (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x;
+  const size_t n = (size_t)j.K * j.CinP * j.CoutP;
+  if (i >= n) return;
+  const int ci = (int)(i % j.CinP);
+  const int co = (int)((i / j.CinP) % j.CoutP);
+  const int kd = (int)(i / ((size_t)j.CinP * j.CoutP));
+  j.q0[i] = j.p0[((size_t)(j.K - 1 - kd) * j.CinP + ci) * j.CoutP + co];
+}
+// p0 = packed weight gradient, p1 = g, p2 = v (weight norm) or null, p3 = packed bias gradient or null;
+// q0 = dW, q1 = dg, q2 = dv, q3 = db
+__global__ __launch_bounds__(256) void unpack_grad_multi_kernel(const MultiJob* __restrict__ jobs,
+                                                                const int* __restrict__ job_of_block) {
+  __shared__ float r1[256], r2[256];
+  const MultiJob j = jobs[job_of_block[blockIdx.x]];
+  const int co = blockIdx.x - j.blk0;
+  const int n = j.Cin * j.K;
+  const int cp = co;
+  if (threadIdx.x == 0 && j.q3 && j.p3) j.q3[co] += j.p3[cp];
+  if (!j.p2) {
+    if (!j.q0) return;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int ci = i / j.K, k = i % j.K;
+      j.q0[(size_t)co * n + i] += j.p0[((size_t)k * j.CinP + ci) * j.CoutP + cp];
+    }
+    return;
+  }
+  if (!j.q1 || !j.q2) return;
+  float dot = 0.f, nn = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / j.K, k = i % j.K;
+    const float v = j.p2[(size_t)co * n + i];
+    dot = fmaf(j.p0[((size_t)k * j.CinP + ci) * j.CoutP + cp], v, dot);
+    nn = fmaf(v, v, nn);
+  }
+  r1[threadIdx.x] = dot;
+  r2[threadIdx.x] = nn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      r1[threadIdx.x] += r1[threadIdx.x + o];
+      r2[threadIdx.x] += r2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const float norm = sqrtf(r2[0]), d = r1[0], gg = j.p1[co];
+  if (threadIdx.x == 0) j.q1[co] += d / norm;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ci = i / j.K, k = i % j.K;
+    const float v = j.p2[(size_t)co * n + i];
+    j.q2[(size_t)co * n + i] += gg / norm * (j.p0[((size_t)k * j.CinP + ci) * j.CoutP + cp] - v * d / (norm * norm));
+  }
+}
+int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st) {
+  if (nblocks <= 0) return STY_OK;
+  if (which == 0)
+    hipLaunchKernelGGL(pack_conv_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
+  else if (which == 1)
+    hipLaunchKernelGGL(pack_dgrad_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
+  else
+    hipLaunchKernelGGL(unpack_grad_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // 2-D: Wd[kw'][kh'*Cout + co][ci] = Wp[KW-1-kw'][(KH-1-kh')*Cin + ci][co]
 __global__ void pack_dgrad2d_kernel(const float* __restrict__ wp, int KW, int KH, int Cin, int Cout, int CinP,
                                     int CoutP, int CinPd, int CoutPd, float* __restrict__ wd) {
