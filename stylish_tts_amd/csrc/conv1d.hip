@@ -97,6 +97,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
       stage_chunk<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane);      \
   } while (0)
   do_load(0);
+  // A fragments (packed weights) of the NEXT (chunk, tap), requested one step ahead so that their latency -- and in
+  // the pipelined build the next input tile's -- overlaps the current step's MFMAs
+  float a_nxt[NW == 4 ? CI_CHUNK / 2 : 1][MT];
+  if constexpr (NW == 4) {
+#pragma unroll
+    for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        a_nxt[c2][m] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, 2 * c2 * CoutP * 4, 0));
+  }
   for (int ci0 = 0; ci0 < CinP; ci0 += CI_CHUNK) {
     __syncthreads();
     switch (a.pro) {
@@ -150,24 +161,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
     // packed weights through one buffer descriptor: per-lane byte offset wv (fixed for the whole kernel), the
     // (tap, channel pair) part of the address is a scalar soffset
     if constexpr (NW == 4) {
-      float a_nxt[CI_CHUNK / 2][MT];
-      {
-        const int srow = ci0 * CoutP * 4;
-#pragma unroll
-        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            a_nxt[c2][m] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
-      }
+      const bool more = ci0 + CI_CHUNK < CinP;
       for (int k = 0; k < K; ++k) {
         float a_cur[CI_CHUNK / 2][MT];
 #pragma unroll
         for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
           for (int m = 0; m < MT; ++m) a_cur[c2][m] = a_nxt[c2][m];
-        if (k + 1 < K) {
-          const int srow = ((k + 1) * CinP + ci0) * CoutP * 4;
+        if (k + 1 < K || more) {  // (chunk, tap + 1), or tap 0 of the next chunk
+          const int srow = (k + 1 < K ? (k + 1) * CinP + ci0 : ci0 + CI_CHUNK) * CoutP * 4;
 #pragma unroll
           for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
               a_nxt[c2][m] = __builtin_bit_cast(
                   float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
         }
-        if (k == K - 1 && ci0 + CI_CHUNK < CinP) do_load(ci0 + CI_CHUNK);  // next chunk's tile, in flight below
+        if (k == K - 1 && more) do_load(ci0 + CI_CHUNK);  // pipelined build: next chunk's tile, in flight below
         const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
         float bv[CI_CHUNK / 2][NT];
 #pragma unroll

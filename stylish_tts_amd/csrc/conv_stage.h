@@ -94,8 +94,8 @@ struct StageRegs {
 // Phase 1: issue the global loads of channels [ci0, ci0+32) x LW columns (nothing waits on them here).
 // `wave` must be wave-uniform for the compiler (readfirstlane), or every load is wrapped in a waterfall loop.
 template <int NW, int MAXJ, bool FLAT>
-__device__ __forceinline__ void stage_load_it(const ConvArgs& a, int ci0, int b, int h, int t0, int wave, int lane,
-                                              int it, float (&vv)[2][MAXJ]) {
+__device__ __forceinline__ void stage_load_it(const ConvArgs& a, int ci0, int b, int h, int t0, int LW, int wave,
+                                              int lane, int it, float (&vv)[2][MAXJ]) {
   const int T = a.Tin ? a.Tin : a.T;
   const int es = a.in_shuffle > 1 ? a.in_shuffle : 1;  // element stride of a pixel-shuffled source
   const int voff = (t0 - a.pad + lane) * 4 * es;        // byte offset of column j = lane inside a row
@@ -107,7 +107,8 @@ __device__ __forceinline__ void stage_load_it(const ConvArgs& a, int ci0, int b,
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.src), 0, (int)r.bytes, 0x00020000);
     const int vrow = FLAT ? voff + r.tsh * 4 : voff;
 #pragma unroll
-    for (int q = 0; q < MAXJ; ++q) vv[u][q] = buf_load(rs, vrow + 256 * es * q);
+    for (int q = 0; q < MAXJ; ++q)
+      if (64 * q < LW) vv[u][q] = buf_load(rs, vrow + 256 * es * q);  // MAXJ covers the largest halo; skip the rest
   }
 }
 template <int NW, int MAXJ, bool FLAT = false>
@@ -115,14 +116,15 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, int ci0, int b, in
                                            StageRegs<NW, MAXJ>& R) {
 #pragma unroll
   for (int it = 0; it < StageRegs<NW, MAXJ>::ITER; ++it)
-    stage_load_it<NW, MAXJ, FLAT>(a, ci0, b, h, t0, wave, lane, it, R.vv[it]);
+    stage_load_it<NW, MAXJ, FLAT>(a, ci0, b, h, t0, LW, wave, lane, it, R.vv[it]);
 }
 
 // Phase 2: prologue + LDS stores.  Zero padding is applied AFTER the prologue.  (The mask of PRO_MASK is read
 // here, not prefetched: it is shared by all rows and stays in L1.)
 template <int PRO, int NW, int MAXJ, bool FLAT>
 __device__ __forceinline__ void stage_store_it(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
-                                               int LW, int wave, int lane, int it, const float (&vv)[2][MAXJ]) {
+                                               int LW, int wave, int lane, int it, const float (&vv)[2][MAXJ],
+                                               const float* mkpre = nullptr) {
   const int T = a.Tin ? a.Tin : a.T, Cin = a.w.Cin;
   const int es = a.in_shuffle > 1 ? a.in_shuffle : 1;
   const int c = wave + 2 * NW * it;
@@ -149,7 +151,7 @@ __device__ __forceinline__ void stage_store_it(const ConvArgs& a, float* __restr
       float v = 0.f;
       if (r.live && t >= 0 && t < T) {
         float mk = 1.f;
-        if constexpr (PRO == PRO_MASK) mk = j < LW ? a.mask[(size_t)b * T + t] : 0.f;
+        if constexpr (PRO == PRO_MASK) mk = mkpre ? mkpre[q] : (j < LW ? a.mask[(size_t)b * T + t] : 0.f);
         v = pro_apply<PRO>(vv[u][q], pa, ps, alpha, ralpha, mk);
       }
       if (j < LW) row[j] = v;
@@ -158,20 +160,30 @@ __device__ __forceinline__ void stage_store_it(const ConvArgs& a, float* __restr
 }
 template <int PRO, int NW, int MAXJ, bool FLAT = false>
 __device__ __forceinline__ void stage_store(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
-                                            int LW, int wave, int lane, const StageRegs<NW, MAXJ>& R) {
+                                            int LW, int wave, int lane, const StageRegs<NW, MAXJ>& R,
+                                            const float* mkpre = nullptr) {
 #pragma unroll
   for (int it = 0; it < StageRegs<NW, MAXJ>::ITER; ++it)
-    stage_store_it<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, it, R.vv[it]);
+    stage_store_it<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, it, R.vv[it], mkpre);
 }
 
 // Both phases, two rows at a time (weight-gradient kernel, non-pipelined conv configurations): 2*MAXJ loads in
 // flight per lane, 2*MAXJ staging registers.
+#ifndef STY_STAGE_ALL
+#define STY_STAGE_ALL 1
+#endif
 template <int PRO, int NW, int MAXJ, bool FLAT = false>
 __device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
                                             int LW, int wave, int lane) {
+  if constexpr (STY_STAGE_ALL && NW == 4 && MAXJ <= 4) {  // every row of the chunk in flight at once
+    StageRegs<NW, MAXJ> R;
+    stage_load<NW, MAXJ, FLAT>(a, ci0, b, h, t0, LW, wave, lane, R);
+    stage_store<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, R);
+    return;
+  }
   for (int it = 0; it < CI_CHUNK / (2 * NW); ++it) {
     float vv[2][MAXJ];
-    stage_load_it<NW, MAXJ, FLAT>(a, ci0, b, h, t0, wave, lane, it, vv);
+    stage_load_it<NW, MAXJ, FLAT>(a, ci0, b, h, t0, LW, wave, lane, it, vv);
     stage_store_it<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, it, vv);
   }
 }

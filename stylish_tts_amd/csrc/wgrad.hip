@@ -12,7 +12,8 @@
 
 namespace sty {
 
-constexpr int WG_TW = 128;  // time samples per chunk
+constexpr int WG_TW = 128;      // time samples per chunk
+constexpr int WG_TARGET = 1024;  // workgroups per launch aimed at (4 per CU): the (batch, time) list is split to get there
 
 template <int KT>  // taps per wave (K <= 4*KT), KT == 0: K == 1, waves split the chunk in time
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
@@ -40,6 +41,51 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   for (int ch = split; ch < total; ch += nsplit) {
     const int bh = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
     const int b = bh / HM, h = bh % HM;
+    if constexpr (KT <= 3) {
+      // both tiles (and the mask row) are requested before anything waits: one memory round trip per chunk instead
+      // of eight (the two-rows-at-a-time order below left the kernel latency-bound at ~13 us per chunk)
+      constexpr int MAXJG = (WG_TW + 1 + 63) / 64;
+      StageRegs<4, MAXJ> Rx;
+      StageRegs<4, MAXJG> Rg;
+      float mk[MAXJG];
+      if (ax.flatW)
+        stage_load<4, MAXJ, true>(ax, ci0, b, h, t0, LWx, wave, lane, Rx);
+      else
+        stage_load<4, MAXJ, false>(ax, ci0, b, h, t0, LWx, wave, lane, Rx);
+      stage_load<4, MAXJG, false>(ag, co0, b, h, t0, LWg, wave, lane, Rg);
+      if (ag.pro == PRO_MASK) {
+#pragma unroll
+        for (int q = 0; q < MAXJG; ++q) {
+          const int t = t0 + lane + 64 * q;
+          mk[q] = (t < ag.T && lane + 64 * q < LWg) ? ag.mask[(size_t)b * ag.T + t] : 0.f;
+        }
+      }
+      __syncthreads();
+      switch (ax.pro) {
+        case PRO_AFFINE: stage_store<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
+        case PRO_SCALE: stage_store<PRO_SCALE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
+        case PRO_AFFINE_SNAKE: stage_store<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
+        case PRO_AFFINE_LRELU: stage_store<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
+        case PRO_MASK: stage_store<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
+        case PRO_LRELU:
+          if (ax.flatW)
+            stage_store<PRO_LRELU, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
+          else
+            stage_store<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
+          break;
+        default:
+          if (ax.flatW)
+            stage_store<PRO_NONE, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
+          else
+            stage_store<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
+          break;
+      }
+      if (ag.pro == PRO_MASK)
+        stage_store<PRO_MASK, 4, MAXJG>(ag, gs, co0, b, h, t0, LWg, wave, lane, Rg, mk);
+      else
+        stage_store<PRO_NONE, 4, MAXJG>(ag, gs, co0, b, h, t0, LWg, wave, lane, Rg);
+      __syncthreads();
+    } else {
     __syncthreads();
     switch (ax.pro) {
       case PRO_AFFINE: stage_chunk<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
@@ -65,6 +111,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
     else
       stage_chunk<PRO_NONE, 4, MAXJ>(ag, gs, co0, b, h, t0, LWg, wave, lane);
     __syncthreads();
+    }
     if constexpr (KT == 0) {
       // K == 1: each wave reduces its quarter of the chunk
       const int q0 = wave * (WG_TW / 8);
@@ -116,6 +163,137 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   }
 }
 
+// ---- K == 1 (Linear / 1x1 conv) weight gradient: dW[co][ci] = sum_{b,t} G[co][t] x[ci][t] ----
+// The general kernel above gives each workgroup ONE 32x32 output tile, so for K == 1 a wave issues 16 MFMAs per pair
+// of staged tiles and the kernel is staging-bound (10-15 TFLOP/s).  Here a workgroup owns a (32 WI MI) x (32 WO MO)
+// block of dW: the staged rows are reused by WI*WO waves x MI*MO tiles (128x128: 8x more MFMAs per staged byte).
+constexpr int W1_TW = 64;  // time samples per chunk
+template <int PRO, int ROWS>
+__device__ __forceinline__ void w1_store(const ConvArgs& a, float* __restrict__ ls, int c0, int b, int t0, int wave,
+                                         int lane, const float (&v)[ROWS / 4], float mk) {
+  const int T = a.T, Cin = a.w.Cin;
+  const int t = t0 + lane;
+#pragma unroll
+  for (int i = 0; i < ROWS / 4; ++i) {
+    const int row = wave + 4 * i, ci = c0 + row;
+    float pa = 1.f, ps = 0.f, alpha = 1.f, ralpha = 1.f;
+    if (ci < Cin) {
+      if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+        pa = a.pa[(size_t)b * Cin + ci];
+        if constexpr (PRO != PRO_SCALE) ps = a.ps[(size_t)b * Cin + ci];
+      }
+      if constexpr (PRO == PRO_AFFINE_SNAKE) {
+        alpha = a.palpha[ci];
+        ralpha = 1.0f / alpha;
+      }
+    }
+    float x = 0.f;
+    if (ci < Cin && t < T) x = pro_apply<PRO>(v[i], pa, ps, alpha, ralpha, mk);
+    ls[row * (W1_TW + 1) + lane] = x;
+  }
+}
+template <int WI, int WO, int MI, int MO>
+__global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
+                                                       float* __restrict__ partial) {
+  constexpr int TI = 32 * WI * MI, TO = 32 * WO * MO, LW = W1_TW + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;
+  float* gs = lds + TI * LW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
+            hi = lane >> 5;
+  const int wi = wave / WO, wo = wave % WO;
+  const int ci0 = blockIdx.x * TI, co0 = blockIdx.y * TO, split = blockIdx.z;
+  const int T = ax.T;
+  const int es = ax.in_shuffle > 1 ? ax.in_shuffle : 1, esg = ag.in_shuffle > 1 ? ag.in_shuffle : 1;
+  f32x16 acc[MI][MO];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][mo][r] = 0.f;
+  const int total = ax.B * chunks_per_b;
+  for (int ch = split; ch < total; ch += nsplit) {
+    const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * W1_TW;
+    float vx[TI / 4], vg[TO / 4];
+#pragma unroll
+    for (int i = 0; i < TI / 4; ++i) {
+      const StageRow r = stage_row<false>(ax, ci0 + wave + 4 * i, b, 0, T, es);
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.src), 0, (int)r.bytes, 0x00020000);
+      vx[i] = buf_load(rs, (t0 + lane) * 4 * es);
+    }
+#pragma unroll
+    for (int i = 0; i < TO / 4; ++i) {
+      const StageRow r = stage_row<false>(ag, co0 + wave + 4 * i, b, 0, T, esg);
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.src), 0, (int)r.bytes, 0x00020000);
+      vg[i] = buf_load(rs, (t0 + lane) * 4 * esg);
+    }
+    float mk = 1.f, mkx = 1.f;
+    if (ag.pro == PRO_MASK) mk = t0 + lane < T ? ag.mask[(size_t)b * T + t0 + lane] : 0.f;
+    if (ax.pro == PRO_MASK) mkx = t0 + lane < T ? ax.mask[(size_t)b * T + t0 + lane] : 0.f;
+    __syncthreads();
+    switch (ax.pro) {
+      case PRO_AFFINE: w1_store<PRO_AFFINE, TI>(ax, xs, ci0, b, t0, wave, lane, vx, 1.f); break;
+      case PRO_SCALE: w1_store<PRO_SCALE, TI>(ax, xs, ci0, b, t0, wave, lane, vx, 1.f); break;
+      case PRO_AFFINE_SNAKE: w1_store<PRO_AFFINE_SNAKE, TI>(ax, xs, ci0, b, t0, wave, lane, vx, 1.f); break;
+      case PRO_AFFINE_LRELU: w1_store<PRO_AFFINE_LRELU, TI>(ax, xs, ci0, b, t0, wave, lane, vx, 1.f); break;
+      case PRO_MASK: w1_store<PRO_MASK, TI>(ax, xs, ci0, b, t0, wave, lane, vx, mkx); break;
+      case PRO_LRELU: w1_store<PRO_LRELU, TI>(ax, xs, ci0, b, t0, wave, lane, vx, 1.f); break;
+      default: w1_store<PRO_NONE, TI>(ax, xs, ci0, b, t0, wave, lane, vx, 1.f); break;
+    }
+    w1_store<PRO_MASK, TO>(ag, gs, co0, b, t0, wave, lane, vg, mk);
+    __syncthreads();
+    const float* gr = gs + (wo * MO * 32 + l31) * LW + hi;
+    const float* xr = xs + (wi * MI * 32 + l31) * LW + hi;
+#pragma unroll 8
+    for (int q = 0; q < W1_TW / 2; ++q) {
+      float av[MO], bv[MI];
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) av[mo] = gr[mo * 32 * LW + 2 * q];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) bv[mi] = xr[mi * 32 * LW + 2 * q];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+          acc[mi][mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mo], bv[mi], acc[mi][mo], 0, 0, 0);
+    }
+  }
+  const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;
+  float* p = partial + (size_t)split * CinP * CoutP;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int ci = ci0 + (wi * MI + mi) * 32 + l31;
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wo * MO + mo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (ci < CinP && co < CoutP) p[(size_t)ci * CoutP + co] = acc[mi][mo][r];
+      }
+  }
+}
+
+struct W1Cfg {
+  int TI, TO;
+};
+static W1Cfg w1_cfg(const PackedConv& w, int B, int T) {
+  // 128x128 blocks need a long (batch, time) list to fill the chip; short ones get 4x more, smaller blocks
+  if (w.CinP >= 128 && w.CoutP >= 128 && (long)B * T >= 16384) return {128, 128};
+  if (w.CinP <= 32) return {32, 128};
+  if (w.CoutP <= 32) return {128, 32};
+  return {64, 64};
+}
+static int w1_nsplit(const PackedConv& w, int B, int T, W1Cfg c) {
+  const int tiles = cdiv(w.CinP, c.TI) * cdiv(w.CoutP, c.TO);
+  const int chunks = B * cdiv(T, W1_TW);
+  int nsplit = cdiv(WG_TARGET, tiles);
+  if (nsplit > chunks) nsplit = chunks;
+  return nsplit;
+}
+
 __global__ void wgrad_reduce_small_kernel(const float* __restrict__ partial, int nslices, size_t plane, float scale,
                                           float* __restrict__ gwp) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -144,10 +322,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x output rows in 2-D mode
+  if (w.K == 1) return (size_t)w1_nsplit(w, B, T, w1_cfg(w, B, T)) * w.CinP * w.CoutP;
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks = B * cdiv(T, WG_TW);
-  int nsplit = 512 / tiles;
-  if (nsplit < 1) nsplit = 1;
+  int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);  // few tiles: keep the partial planes small
   if (nsplit > chunks) nsplit = chunks;
   const int slices = w.K == 1 ? nsplit * 4 : nsplit;
   return (size_t)slices * w.K * w.CinP * w.CoutP;
@@ -180,11 +358,47 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     ag.Cin2d = w.Cout;
   }
   const int HM = fwd.H ? fwd.H : 1;
+  if (w.K == 1 && !fwd.H) {
+    const W1Cfg c = w1_cfg(w, fwd.B, fwd.T);
+    const int nsplit = w1_nsplit(w, fwd.B, fwd.T, c);
+    const int cpb = cdiv(fwd.T, W1_TW);
+    ag.pad = 0;
+    ConvArgs ax1 = fwd;
+    ax1.flatW = 0;  // KH == KW == 1: the flat image is a plain [B][C][T] tensor
+    dim3 grid(cdiv(w.CinP, c.TI), cdiv(w.CoutP, c.TO), nsplit);
+    const size_t lds = (size_t)(c.TI + c.TO) * (W1_TW + 1) * sizeof(float);
+    char detail[40];
+    snprintf(detail, sizeof(detail), "ci%d co%d k1 T%d W%d", w.Cin, w.Cout, fwd.T, fwd.flatW);
+    ProfScope prof("wgrad", 2.0 * w.Cin * (double)fwd.B * w.Cout * fwd.T,
+                   4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T), st, detail);
+    static bool raised = false;
+    if (!raised) {
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<2, 2, 2, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      raised = true;
+    }
+    if (c.TI == 128 && c.TO == 128)
+      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 2, 2>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+    else if (c.TI == 32)
+      hipLaunchKernelGGL((wgrad_k1_kernel<1, 4, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+    else if (c.TO == 32)
+      hipLaunchKernelGGL((wgrad_k1_kernel<4, 1, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+    else
+      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+    const size_t plane = (size_t)w.CinP * w.CoutP;
+    if (nsplit >= 16)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((plane + 15) / 16)), dim3(256), 0, st, partial, nsplit,
+                         plane, scale, gwp);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, partial,
+                         nsplit, plane, scale, gwp);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks_per_b = cdiv(fwd.T, WG_TW);
   const int chunks = fwd.B * HM * chunks_per_b;
-  int nsplit = 512 / tiles;
-  if (nsplit < 1) nsplit = 1;
+  int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
   if (nsplit > chunks) nsplit = chunks;
   const int halo = (w.K - 1) * fwd.dil;
   if (halo > 128) {
