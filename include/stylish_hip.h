@@ -167,6 +167,13 @@ int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *sty
                         void *stream);
 int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
 
+/* ---- one dense Conv1d ('same' padding, torch.nn.functional.conv1d semantics) on the MFMA implicit-GEMM kernel every
+ * conv / Linear of the path runs on; for unit parity tests and kernel tuning.  x [B,Cin,T], w [Cout,Cin,K],
+ * bias [Cout] or NULL -> y [B,Cout,T].  (K-1)*dil <= 128.                                                     */
+int sty_conv1d_workspace_bytes(int Cout, int Cin, int K, size_t *bytes);
+int sty_conv1d_fwd(int B, int Cin, int Cout, int K, int dil, int T, const float *x, const float *w, const float *bias,
+                   float *y, void *workspace, size_t ws_bytes, void *stream);
+
 /* ---- optimizer: torch.optim.AdamW (train/optimizers.py:110-118) over one flat fp32 bucket ------------------
  * p, g, m, v: n floats each, 16-byte aligned, identically laid out; step = 1, 2, ... (bias correction).          */
 int sty_adamw_step(size_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,

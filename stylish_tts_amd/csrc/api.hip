@@ -1910,6 +1910,49 @@ int sty_style_bwd(sty_model* m, const float* d_style, void* stream) {
   if (rc) return rc;
   return unpack_grads(m, S(stream));
 }
+// ---- one dense Conv1d ('same' padding) on the MFMA conv kernel: unit parity and kernel tuning ----
+int sty_conv1d_workspace_bytes(int Cout, int Cin, int K, size_t* bytes) {
+  if (!bytes || Cout <= 0 || Cin <= 0 || K <= 0) {
+    set_error("sty_conv1d_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  *bytes = ((size_t)K * align_up(Cin, CI_CHUNK) * align_up(Cout, 128) + align_up(Cout, 128)) * sizeof(float) + 512;
+  return STY_OK;
+}
+int sty_conv1d_fwd(int B, int Cin, int Cout, int K, int dil, int T, const float* x, const float* w, const float* bias,
+                   float* y, void* workspace, size_t ws_bytes, void* stream) {
+  size_t need = 0;
+  int rc = sty_conv1d_workspace_bytes(Cout, Cin, K, &need);
+  if (rc) return rc;
+  if (!x || !w || !y || !workspace || B <= 0 || T <= 0 || dil <= 0 || (K - 1) * dil > 128 || ws_bytes < need) {
+    set_error("sty_conv1d_fwd: bad argument, halo > 128 or workspace too small");
+    return STY_EINVAL;
+  }
+  PackedConv pc;
+  pc.Cin = Cin;
+  pc.Cout = Cout;
+  pc.K = K;
+  pc.CinP = (int)align_up(Cin, CI_CHUNK);
+  pc.CoutP = (int)align_up(Cout, 128);
+  float* wp = reinterpret_cast<float*>(align_up(reinterpret_cast<size_t>(workspace), 256));
+  float* bp = wp + (size_t)K * pc.CinP * pc.CoutP;
+  STY_HIP(hipMemsetAsync(wp, 0, ((size_t)K * pc.CinP * pc.CoutP + pc.CoutP) * sizeof(float), S(stream)));
+  rc = launch_pack_conv(w, nullptr, nullptr, bias, Cout, Cin, K, wp, bp, pc.CinP, pc.CoutP, S(stream));
+  if (rc) return rc;
+  pc.wp = wp;
+  pc.bias = bias ? bp : nullptr;
+  ConvArgs a;
+  a.x[0] = x;
+  a.xc[0] = Cin;
+  a.nsrc = 1;
+  a.B = B;
+  a.T = T;
+  a.w = pc;
+  a.dil = dil;
+  a.pad = (K - 1) * dil / 2;
+  a.y = y;
+  return launch_conv1d(a, S(stream));
+}
 int sty_mel_workspace_bytes(int B, int N, int n_fft, int hop, size_t* bytes) {
   if (!bytes || B <= 0 || N <= n_fft / 2 || n_fft <= 0 || hop <= 0) {
     set_error("sty_mel_workspace_bytes: bad argument");

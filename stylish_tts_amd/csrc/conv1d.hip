@@ -34,9 +34,6 @@ __device__ __forceinline__ float act_apply(float x, float alpha) {
   return x;
 }
 
-#ifndef STY_PIPE
-#define STY_PIPE 0
-#endif
 #ifndef STY_MINW
 #define STY_MINW 2
 #endif
@@ -75,30 +72,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w.wp), 0, K * CinP * CoutP * 4, 0x00020000);
   const int wv = (hi * CoutP + co0 + l31) * 4;
-  // Optional software pipeline (STY_PIPE=1, 4-wave configurations): the global loads of chunk c+1 are issued before
-  // the last tap's MFMAs of chunk c.  Measured on MI355X it LOSES (c2 step 71.9 -> 88.6 ms, c5 12.3 -> 14.4 ms):
-  // the in-order vmcnt makes the next A-fragment wait also wait for the tile loads, and the tile registers stay
-  // live across the barrier.  Default: load -> prologue -> LDS -> compute, overlap comes from 2-4 workgroups per CU.
-  constexpr bool PIPE = NW == 4 && STY_PIPE;
-  StageRegs<NW, PIPE ? MAXJ : 1> R;
-  auto do_load = [&](int ci0) {
-    if constexpr (PIPE) {
-      if (a.flatW)
-        stage_load<NW, MAXJ, true>(a, ci0, b, h, t0, LW, wave, lane, R);
-      else
-        stage_load<NW, MAXJ, false>(a, ci0, b, h, t0, LW, wave, lane, R);
-    }
-  };
-#define STY_STAGE(PRO, FLAT)                                                       \
-  do {                                                                             \
-    if constexpr (PIPE)                                                            \
-      stage_store<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, R);   \
-    else                                                                           \
-      stage_chunk<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane);      \
-  } while (0)
-  do_load(0);
-  // A fragments (packed weights) of the NEXT (chunk, tap), requested one step ahead so that their latency -- and in
-  // the pipelined build the next input tile's -- overlaps the current step's MFMAs
+  // Staging order: load every row of the chunk -> prologue -> LDS -> compute; overlap comes from 2-4 workgroups per
+  // CU.  (A register-staged software pipeline -- next chunk's tile requested before the last tap's MFMAs -- was
+  // measured on MI355X and LOST: c2 step 71.9 -> 88.6 ms, c5 12.3 -> 14.4 ms; the tile registers stay live across
+  // the barrier and the in-order vmcnt couples the A-fragment waits to the tile loads.)
+  const int smode = stage_mode(a);
+  const float* xb = stage_base(a, b);
+  // A fragments (packed weights) of the NEXT (chunk, tap), requested one step ahead so that their latency overlaps
+  // the current step's MFMAs
   float a_nxt[NW == 4 ? CI_CHUNK / 2 : 1][MT];
   if constexpr (NW == 4) {
 #pragma unroll
@@ -108,33 +89,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
         a_nxt[c2][m] =
             __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, 2 * c2 * CoutP * 4, 0));
   }
+#define STY_ST(PRO, MODE) stage_chunk<PRO, NW, MAXJ, MODE, TT_BLK, NW == 4>(a, xb, xs, ci0, b, h, t0, LW, wave, lane)
+#define STY_ST2(PRO)              \
+  if (smode == ST_SIMPLE)         \
+    STY_ST(PRO, ST_SIMPLE);       \
+  else                            \
+    STY_ST(PRO, ST_GENERIC)
+#define STY_ST3(PRO)              \
+  if (smode == ST_SIMPLE)         \
+    STY_ST(PRO, ST_SIMPLE);       \
+  else if (smode == ST_FLAT)      \
+    STY_ST(PRO, ST_FLAT);         \
+  else                            \
+    STY_ST(PRO, ST_GENERIC)
   for (int ci0 = 0; ci0 < CinP; ci0 += CI_CHUNK) {
     __syncthreads();
     switch (a.pro) {
-      case PRO_AFFINE: STY_STAGE(PRO_AFFINE, false); break;
-      case PRO_SCALE: STY_STAGE(PRO_SCALE, false); break;
-      case PRO_AFFINE_SNAKE: STY_STAGE(PRO_AFFINE_SNAKE, false); break;
-      case PRO_AFFINE_LRELU: STY_STAGE(PRO_AFFINE_LRELU, false); break;
-      case PRO_MASK:
-        if (a.flatW)
-          STY_STAGE(PRO_MASK, true);
-        else
-          STY_STAGE(PRO_MASK, false);
-        break;
-      case PRO_LRELU:
-        if (a.flatW)
-          STY_STAGE(PRO_LRELU, true);
-        else
-          STY_STAGE(PRO_LRELU, false);
-        break;
-      default:
-        if (a.flatW)
-          STY_STAGE(PRO_NONE, true);
-        else
-          STY_STAGE(PRO_NONE, false);
-        break;
+      case PRO_AFFINE: STY_ST2(PRO_AFFINE); break;
+      case PRO_SCALE: STY_ST2(PRO_SCALE); break;
+      case PRO_AFFINE_SNAKE: STY_ST2(PRO_AFFINE_SNAKE); break;
+      case PRO_AFFINE_LRELU: STY_ST2(PRO_AFFINE_LRELU); break;
+      case PRO_MASK: STY_ST3(PRO_MASK); break;
+      case PRO_LRELU: STY_ST3(PRO_LRELU); break;
+      default: STY_ST3(PRO_NONE); break;
     }
-#undef STY_STAGE
+#undef STY_ST3
+#undef STY_ST2
+#undef STY_ST
     if (a.pro == PRO_LN_AFFINE) {
       // LayerNorm over the Cin (<= 32, single chunk) channels of every in-range column, then affine.
       __syncthreads();
@@ -177,7 +158,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
               a_nxt[c2][m] = __builtin_bit_cast(
                   float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
         }
-        if (k == K - 1 && more) do_load(ci0 + CI_CHUNK);  // pipelined build: next chunk's tile, in flight below
         const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
         float bv[CI_CHUNK / 2][NT];
 #pragma unroll
@@ -383,6 +363,15 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   if (a.ln_out && a.w.Cout != 32) {
     set_error("conv1d: LN epilogue needs Cout == 32");
     return STY_EINVAL;
+  }
+  // tuning aid: STY_CONV_CFG=0..5 forces one tile configuration (when the shape allows it)
+  static const int forced = getenv("STY_CONV_CFG") ? atoi(getenv("STY_CONV_CFG")) : -1;
+  if (forced >= 0 && a.act != ACT_GLU) {
+    if (forced == 0 && a.w.CoutP % 128 == 0) return launch_cfg<2, 2, 2, 2>(a, st);
+    if (forced == 1 && a.w.CoutP % 64 == 0) return launch_cfg<1, 4, 2, 2>(a, st);
+    if (forced == 2 && a.w.CoutP % 64 == 0) return launch_cfg<2, 2, 1, 1>(a, st);
+    if (forced == 3) return launch_cfg<1, 8, 1, 2>(a, st);
+    if (forced == 4) return launch_cfg<1, 4, 1, 2>(a, st);
   }
   // Tile choice: the biggest output tile that still gives the chip >= ~2 workgroups per CU; the 256-channel stage
   // runs at T <= 800 frames, where 128x128 tiles would launch ~100 workgroups on 256 CUs.

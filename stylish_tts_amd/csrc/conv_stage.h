@@ -26,6 +26,15 @@ __device__ __forceinline__ float pro_apply(float v, float pa, float ps, float al
 // same for every row of the tile, and the hardware bounds check returns 0 for t < 0 (offset wraps), t >= T and for
 // rows past Cin (length 0) -- no per-element predicates and no 64-bit per-lane addresses (the flat-load version
 // needed 170-256 VGPRs, i.e. one workgroup per CU).
+//
+// Addressing modes (MODE template parameter; the scalar address arithmetic per row is what the small-grid GEMMs
+// of the text encoder / stage A are bound by -- PMC: 500 SALU instructions per 32-channel chunk in the first
+// version, most of them the generic source selection):
+//   ST_SIMPLE  one plain source [B][Cin][T]                      row = xb + ci*T
+//   ST_FLAT    flat 2-D image, reduction row (kh, ci)            row = xb + cc*T shifted by (kh - hpad)*flatW
+//   ST_GENERIC up to 3 concatenated sources, pixel-shuffled source, row-mode 2-D
+enum StageMode : int { ST_SIMPLE = 0, ST_FLAT = 1, ST_GENERIC = 2 };
+
 struct StageRow {
   const float* src;
   unsigned bytes;  // valid bytes from src (0: dead row)
@@ -33,21 +42,26 @@ struct StageRow {
   bool live;
 };
 
-template <bool FLAT>
-__device__ __forceinline__ StageRow stage_row(const ConvArgs& a, int ci, int b, int h, int T, int es) {
+// xb: batch base of source 0 (x[0] + b * C * T), hoisted out of the chunk loop by the caller
+template <int MODE>
+__device__ __forceinline__ StageRow stage_row(const ConvArgs& a, const float* xb, int ci, int b, int h, int T, int es) {
   StageRow r;
   r.live = ci < a.w.Cin;
-  r.src = a.x[0];
+  r.src = xb;
   r.tsh = 0;
   r.bytes = 0;
-  if constexpr (FLAT) {  // flat 2-D mode: reduction index (kh, ci) = the same image shifted by whole rows
-    if (r.live) {
-      const int kh = ci / a.Cin2d, cc = ci - kh * a.Cin2d;
-      r.tsh = (kh - a.hpad) * a.flatW;
-      r.src = a.x[0] + ((size_t)b * a.Cin2d + cc) * T;
-      r.bytes = (unsigned)T * 4u;
-    }
-  } else if (r.live && a.H) {  // 2-D mode: reduction index = (kh, ci)
+  if constexpr (MODE == ST_SIMPLE) {
+    r.src = xb + (unsigned)(ci * T);
+    r.bytes = r.live ? (unsigned)T * 4u : 0u;
+  } else if constexpr (MODE == ST_FLAT) {
+    // kh = ci / Cin2d without the emulated division (KH <= 5)
+    const int c2 = a.Cin2d;
+    const int kh = (ci >= c2) + (ci >= 2 * c2) + (ci >= 3 * c2) + (ci >= 4 * c2);
+    const int cc = ci - kh * c2;
+    r.tsh = (kh - a.hpad) * a.flatW;
+    r.src = xb + (unsigned)(cc * T);
+    r.bytes = r.live ? (unsigned)T * 4u : 0u;
+  } else if (r.live && a.H) {  // 2-D row mode: reduction index = (kh, ci)
     const int kh = ci / a.Cin2d, cc = ci - kh * a.Cin2d;
     const int hin = h + kh - a.hpad;
     r.live = hin >= 0 && hin < a.Hin;
@@ -78,62 +92,77 @@ __device__ __forceinline__ StageRow stage_row(const ConvArgs& a, int ci, int b, 
   }
   return r;
 }
+__device__ __forceinline__ int stage_mode(const ConvArgs& a) {
+  if (a.flatW) return ST_FLAT;
+  if (a.nsrc == 1 && a.in_shuffle <= 1 && !a.H) return ST_SIMPLE;
+  return ST_GENERIC;
+}
+__device__ __forceinline__ const float* stage_base(const ConvArgs& a, int b) {
+  const int T = a.Tin ? a.Tin : a.T;
+  return a.x[0] + (size_t)b * (a.flatW ? a.Cin2d : a.xc[0]) * T;
+}
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, int byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
 }
 
 // Registers holding one CI_CHUNK x LW tile in flight between the global loads and the LDS stores: each wave owns
-// rows wave, wave+NW, ...; ITER = CI_CHUNK/(2 NW) passes of two rows x MAXJ column chunks.
+// rows wave, wave+NW, ...; ITER = CI_CHUNK/(2 NW) passes of two rows x MAXJ column chunks.  live / tsh of every
+// row are kept from the load phase so that the store phase does not redo the address arithmetic.
 template <int NW, int MAXJ>
 struct StageRegs {
   static constexpr int ITER = CI_CHUNK / (2 * NW);
   float vv[ITER][2][MAXJ];
+  int tsh[ITER][2];
+  bool live[ITER][2];
 };
 
 // Phase 1: issue the global loads of channels [ci0, ci0+32) x LW columns (nothing waits on them here).
 // `wave` must be wave-uniform for the compiler (readfirstlane), or every load is wrapped in a waterfall loop.
-template <int NW, int MAXJ, bool FLAT>
-__device__ __forceinline__ void stage_load_it(const ConvArgs& a, int ci0, int b, int h, int t0, int LW, int wave,
-                                              int lane, int it, float (&vv)[2][MAXJ]) {
+// The first TBASE/64 column groups always exist; only the halo groups are guarded (MAXJ covers a 128-sample halo).
+template <int NW, int MAXJ, int MODE, int TBASE>
+__device__ __forceinline__ void stage_load_it(const ConvArgs& a, const float* xb, int ci0, int b, int h, int t0, int LW,
+                                              int wave, int lane, int it, float (&vv)[2][MAXJ], int (&tsh)[2],
+                                              bool (&live)[2]) {
   const int T = a.Tin ? a.Tin : a.T;
-  const int es = a.in_shuffle > 1 ? a.in_shuffle : 1;  // element stride of a pixel-shuffled source
-  const int voff = (t0 - a.pad + lane) * 4 * es;        // byte offset of column j = lane inside a row
+  const int es = MODE == ST_GENERIC ? (a.in_shuffle > 1 ? a.in_shuffle : 1) : 1;  // pixel-shuffled source stride
+  const int voff = (t0 - a.pad + lane) * 4 * es;  // byte offset of column j = lane inside a row
   const int c = wave + 2 * NW * it;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const StageRow r = stage_row<FLAT>(a, ci0 + c + NW * u, b, h, T, es);
+    const StageRow r = stage_row<MODE>(a, xb, ci0 + c + NW * u, b, h, T, es);
+    tsh[u] = r.tsh;
+    live[u] = r.live;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.src), 0, (int)r.bytes, 0x00020000);
-    const int vrow = FLAT ? voff + r.tsh * 4 : voff;
+    const int vrow = MODE == ST_FLAT ? voff + r.tsh * 4 : voff;
 #pragma unroll
     for (int q = 0; q < MAXJ; ++q)
-      if (64 * q < LW) vv[u][q] = buf_load(rs, vrow + 256 * es * q);  // MAXJ covers the largest halo; skip the rest
+      if (q < TBASE / 64 || 64 * q < LW) vv[u][q] = buf_load(rs, vrow + 256 * es * q);
   }
 }
-template <int NW, int MAXJ, bool FLAT = false>
-__device__ __forceinline__ void stage_load(const ConvArgs& a, int ci0, int b, int h, int t0, int LW, int wave, int lane,
-                                           StageRegs<NW, MAXJ>& R) {
+template <int NW, int MAXJ, int MODE, int TBASE>
+__device__ __forceinline__ void stage_load(const ConvArgs& a, const float* xb, int ci0, int b, int h, int t0, int LW,
+                                           int wave, int lane, StageRegs<NW, MAXJ>& R) {
 #pragma unroll
   for (int it = 0; it < StageRegs<NW, MAXJ>::ITER; ++it)
-    stage_load_it<NW, MAXJ, FLAT>(a, ci0, b, h, t0, LW, wave, lane, it, R.vv[it]);
+    stage_load_it<NW, MAXJ, MODE, TBASE>(a, xb, ci0, b, h, t0, LW, wave, lane, it, R.vv[it], R.tsh[it], R.live[it]);
 }
 
 // Phase 2: prologue + LDS stores.  Zero padding is applied AFTER the prologue.  (The mask of PRO_MASK is read
-// here, not prefetched: it is shared by all rows and stays in L1.)
-template <int PRO, int NW, int MAXJ, bool FLAT>
-__device__ __forceinline__ void stage_store_it(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
+// here unless the caller prefetched it: it is shared by all rows and stays in L1.)
+template <int PRO, int NW, int MAXJ>
+__device__ __forceinline__ void stage_store_it(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int t0,
                                                int LW, int wave, int lane, int it, const float (&vv)[2][MAXJ],
+                                               const int (&tsh)[2], const bool (&live)[2],
                                                const float* mkpre = nullptr) {
   const int T = a.Tin ? a.Tin : a.T, Cin = a.w.Cin;
-  const int es = a.in_shuffle > 1 ? a.in_shuffle : 1;
   const int c = wave + 2 * NW * it;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int ci = ci0 + c + NW * u;
-    const StageRow r = stage_row<FLAT>(a, ci, b, h, T, es);
     float pa = 1.f, ps = 0.f, alpha = 1.f, ralpha = 1.f;
-    if (r.live) {
+    if (live[u]) {
       if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
         pa = a.pa[(size_t)b * Cin + ci];
         if constexpr (PRO != PRO_SCALE) ps = a.ps[(size_t)b * Cin + ci];
@@ -147,9 +176,9 @@ __device__ __forceinline__ void stage_store_it(const ConvArgs& a, float* __restr
 #pragma unroll
     for (int q = 0; q < MAXJ; ++q) {
       const int j = lane + 64 * q;
-      const int t = t0 - a.pad + j + r.tsh;
+      const int t = t0 - a.pad + j + tsh[u];
       float v = 0.f;
-      if (r.live && t >= 0 && t < T) {
+      if (live[u] && t >= 0 && t < T) {
         float mk = 1.f;
         if constexpr (PRO == PRO_MASK) mk = mkpre ? mkpre[q] : (j < LW ? a.mask[(size_t)b * T + t] : 0.f);
         v = pro_apply<PRO>(vv[u][q], pa, ps, alpha, ralpha, mk);
@@ -158,34 +187,45 @@ __device__ __forceinline__ void stage_store_it(const ConvArgs& a, float* __restr
     }
   }
 }
-template <int PRO, int NW, int MAXJ, bool FLAT = false>
-__device__ __forceinline__ void stage_store(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
-                                            int LW, int wave, int lane, const StageRegs<NW, MAXJ>& R,
+template <int PRO, int NW, int MAXJ>
+__device__ __forceinline__ void stage_store(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int t0, int LW,
+                                            int wave, int lane, const StageRegs<NW, MAXJ>& R,
                                             const float* mkpre = nullptr) {
 #pragma unroll
   for (int it = 0; it < StageRegs<NW, MAXJ>::ITER; ++it)
-    stage_store_it<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, it, R.vv[it], mkpre);
+    stage_store_it<PRO, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane, it, R.vv[it], R.tsh[it], R.live[it], mkpre);
 }
 
-// Both phases, two rows at a time (weight-gradient kernel, non-pipelined conv configurations): 2*MAXJ loads in
-// flight per lane, 2*MAXJ staging registers.
-#ifndef STY_STAGE_ALL
-#define STY_STAGE_ALL 1
-#endif
-template <int PRO, int NW, int MAXJ, bool FLAT = false>
-__device__ __forceinline__ void stage_chunk(const ConvArgs& a, float* __restrict__ xs, int ci0, int b, int h, int t0,
-                                            int LW, int wave, int lane) {
-  if constexpr (STY_STAGE_ALL && NW == 4 && MAXJ <= 4) {  // every row of the chunk in flight at once
+// Both phases of one chunk.  ALL: every row in flight at once (one memory round trip per chunk; 4-wave
+// configurations); otherwise two rows at a time (2*MAXJ staging registers; 8-wave configurations, register budget 128).
+template <int PRO, int NW, int MAXJ, int MODE, int TBASE, bool ALL>
+__device__ __forceinline__ void stage_chunk(const ConvArgs& a, const float* xb, float* __restrict__ xs, int ci0, int b,
+                                            int h, int t0, int LW, int wave, int lane) {
+  if constexpr (ALL) {
     StageRegs<NW, MAXJ> R;
-    stage_load<NW, MAXJ, FLAT>(a, ci0, b, h, t0, LW, wave, lane, R);
-    stage_store<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, R);
-    return;
-  }
-  for (int it = 0; it < CI_CHUNK / (2 * NW); ++it) {
-    float vv[2][MAXJ];
-    stage_load_it<NW, MAXJ, FLAT>(a, ci0, b, h, t0, LW, wave, lane, it, vv);
-    stage_store_it<PRO, NW, MAXJ, FLAT>(a, xs, ci0, b, h, t0, LW, wave, lane, it, vv);
+    stage_load<NW, MAXJ, MODE, TBASE>(a, xb, ci0, b, h, t0, LW, wave, lane, R);
+    stage_store<PRO, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane, R);
+  } else {
+    for (int it = 0; it < CI_CHUNK / (2 * NW); ++it) {
+      float vv[2][MAXJ];
+      int tsh[2];
+      bool live[2];
+      stage_load_it<NW, MAXJ, MODE, TBASE>(a, xb, ci0, b, h, t0, LW, wave, lane, it, vv, tsh, live);
+      stage_store_it<PRO, NW, MAXJ>(a, xs, ci0, b, t0, LW, wave, lane, it, vv, tsh, live);
+    }
   }
 }
+
+// run-time mode -> compile-time MODE
+#define STY_STAGE_DISPATCH(mode, CALL)            \
+  do {                                            \
+    if ((mode) == ST_SIMPLE) {                    \
+      CALL(ST_SIMPLE);                            \
+    } else if ((mode) == ST_FLAT) {               \
+      CALL(ST_FLAT);                              \
+    } else {                                      \
+      CALL(ST_GENERIC);                           \
+    }                                             \
+  } while (0)
 
 }  // namespace sty

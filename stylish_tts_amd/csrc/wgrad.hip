@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   for (int ch = split; ch < total; ch += nsplit) {
     const int bh = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
     const int b = bh / HM, h = bh % HM;
+    const int xmode = stage_mode(ax), gmode = stage_mode(ag);
+    const float* xb = stage_base(ax, b);
+    const float* gb = stage_base(ag, b);
     if constexpr (KT <= 3) {
       // both tiles (and the mask row) are requested before anything waits: one memory round trip per chunk instead
       // of eight (the two-rows-at-a-time order below left the kernel latency-bound at ~13 us per chunk)
@@ -48,11 +51,15 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
       StageRegs<4, MAXJ> Rx;
       StageRegs<4, MAXJG> Rg;
       float mk[MAXJG];
-      if (ax.flatW)
-        stage_load<4, MAXJ, true>(ax, ci0, b, h, t0, LWx, wave, lane, Rx);
+#define STY_LX(MODE) stage_load<4, MAXJ, MODE, WG_TW>(ax, xb, ci0, b, h, t0, LWx, wave, lane, Rx)
+      STY_STAGE_DISPATCH(xmode, STY_LX);
+#undef STY_LX
+#define STY_LG(MODE) stage_load<4, MAXJG, MODE, WG_TW>(ag, gb, co0, b, h, t0, LWg, wave, lane, Rg)
+      if (gmode == ST_SIMPLE)
+        STY_LG(ST_SIMPLE);
       else
-        stage_load<4, MAXJ, false>(ax, ci0, b, h, t0, LWx, wave, lane, Rx);
-      stage_load<4, MAXJG, false>(ag, co0, b, h, t0, LWg, wave, lane, Rg);
+        STY_LG(ST_GENERIC);
+#undef STY_LG
       if (ag.pro == PRO_MASK) {
 #pragma unroll
         for (int q = 0; q < MAXJG; ++q) {
@@ -62,55 +69,43 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
       }
       __syncthreads();
       switch (ax.pro) {
-        case PRO_AFFINE: stage_store<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
-        case PRO_SCALE: stage_store<PRO_SCALE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
-        case PRO_AFFINE_SNAKE: stage_store<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
-        case PRO_AFFINE_LRELU: stage_store<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
-        case PRO_MASK: stage_store<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx); break;
-        case PRO_LRELU:
-          if (ax.flatW)
-            stage_store<PRO_LRELU, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
-          else
-            stage_store<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
-          break;
-        default:
-          if (ax.flatW)
-            stage_store<PRO_NONE, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
-          else
-            stage_store<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane, Rx);
-          break;
+        case PRO_AFFINE: stage_store<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_SCALE: stage_store<PRO_SCALE, 4, MAXJ>(ax, xs, ci0, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_AFFINE_SNAKE: stage_store<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_AFFINE_LRELU: stage_store<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_MASK: stage_store<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_LRELU: stage_store<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, t0, LWx, wave, lane, Rx); break;
+        default: stage_store<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, t0, LWx, wave, lane, Rx); break;
       }
       if (ag.pro == PRO_MASK)
-        stage_store<PRO_MASK, 4, MAXJG>(ag, gs, co0, b, h, t0, LWg, wave, lane, Rg, mk);
+        stage_store<PRO_MASK, 4, MAXJG>(ag, gs, co0, b, t0, LWg, wave, lane, Rg, mk);
       else
-        stage_store<PRO_NONE, 4, MAXJG>(ag, gs, co0, b, h, t0, LWg, wave, lane, Rg);
+        stage_store<PRO_NONE, 4, MAXJG>(ag, gs, co0, b, t0, LWg, wave, lane, Rg);
       __syncthreads();
     } else {
-    __syncthreads();
-    switch (ax.pro) {
-      case PRO_AFFINE: stage_chunk<PRO_AFFINE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
-      case PRO_SCALE: stage_chunk<PRO_SCALE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
-      case PRO_AFFINE_SNAKE: stage_chunk<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
-      case PRO_AFFINE_LRELU: stage_chunk<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
-      case PRO_MASK: stage_chunk<PRO_MASK, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane); break;
-      case PRO_LRELU:
-        if (ax.flatW)
-          stage_chunk<PRO_LRELU, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
-        else
-          stage_chunk<PRO_LRELU, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
-        break;
-      default:
-        if (ax.flatW)
-          stage_chunk<PRO_NONE, 4, MAXJ, true>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
-        else
-          stage_chunk<PRO_NONE, 4, MAXJ>(ax, xs, ci0, b, h, t0, LWx, wave, lane);
-        break;
-    }
-    if (ag.pro == PRO_MASK)
-      stage_chunk<PRO_MASK, 4, MAXJ>(ag, gs, co0, b, h, t0, LWg, wave, lane);
-    else
-      stage_chunk<PRO_NONE, 4, MAXJ>(ag, gs, co0, b, h, t0, LWg, wave, lane);
-    __syncthreads();
+      __syncthreads();
+#define STY_SX(PRO, MODE) stage_chunk<PRO, 4, MAXJ, MODE, WG_TW, false>(ax, xb, xs, ci0, b, h, t0, LWx, wave, lane)
+#define STY_SX2(PRO)         \
+  if (xmode == ST_SIMPLE)    \
+    STY_SX(PRO, ST_SIMPLE);  \
+  else                       \
+    STY_SX(PRO, ST_GENERIC)
+      switch (ax.pro) {
+        case PRO_AFFINE: STY_SX2(PRO_AFFINE); break;
+        case PRO_SCALE: STY_SX2(PRO_SCALE); break;
+        case PRO_AFFINE_SNAKE: STY_SX2(PRO_AFFINE_SNAKE); break;
+        case PRO_AFFINE_LRELU: STY_SX2(PRO_AFFINE_LRELU); break;
+        case PRO_MASK: STY_SX2(PRO_MASK); break;
+        case PRO_LRELU: STY_SX2(PRO_LRELU); break;
+        default: STY_SX2(PRO_NONE); break;
+      }
+#undef STY_SX2
+#undef STY_SX
+      if (ag.pro == PRO_MASK)
+        stage_chunk<PRO_MASK, 4, MAXJ, ST_GENERIC, WG_TW, false>(ag, gb, gs, co0, b, h, t0, LWg, wave, lane);
+      else
+        stage_chunk<PRO_NONE, 4, MAXJ, ST_GENERIC, WG_TW, false>(ag, gb, gs, co0, b, h, t0, LWg, wave, lane);
+      __syncthreads();
     }
     if constexpr (KT == 0) {
       // K == 1: each wave reduces its quarter of the chunk
@@ -218,14 +213,14 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     float vx[TI / 4], vg[TO / 4];
 #pragma unroll
     for (int i = 0; i < TI / 4; ++i) {
-      const StageRow r = stage_row<false>(ax, ci0 + wave + 4 * i, b, 0, T, es);
+      const StageRow r = stage_row<ST_GENERIC>(ax, ax.x[0], ci0 + wave + 4 * i, b, 0, T, es);
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.src), 0, (int)r.bytes, 0x00020000);
       vx[i] = buf_load(rs, (t0 + lane) * 4 * es);
     }
 #pragma unroll
     for (int i = 0; i < TO / 4; ++i) {
-      const StageRow r = stage_row<false>(ag, co0 + wave + 4 * i, b, 0, T, esg);
+      const StageRow r = stage_row<ST_GENERIC>(ag, ag.x[0], co0 + wave + 4 * i, b, 0, T, esg);
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.src), 0, (int)r.bytes, 0x00020000);
       vg[i] = buf_load(rs, (t0 + lane) * 4 * esg);
@@ -413,6 +408,10 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
   ProfScope prof("wgrad", flops * HM, bytes * HM, st, detail);
   const int KT = w.K == 1 ? 0 : cdiv(w.K, 4);
+  if (fwd.flatW && KT > 3) {
+    set_error("wgrad: flat 2-D mode is built for K <= 12");
+    return STY_EINVAL;
+  }
 #define STY_WG(KTV)                                                                                              \
   hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, partial)
   switch (KT) {

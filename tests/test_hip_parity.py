@@ -673,3 +673,27 @@ def test_acoustic_training_reduces_loss(env):
     print("\n  (mel, multi_phase) per step: " + "  ".join(f"({a:.4f},{b:.4f})" for a, b in hist))
     assert all(torch.isfinite(torch.tensor(hist)).flatten().tolist())
     assert hist[-1][0] < hist[0][0]
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 80, 5, 2, 203), (3, 128, 130, 1, 1, 64), (1, 33, 32, 21, 1, 1500),
+                                   (2, 512, 64, 3, 1, 37)])
+def test_dense_conv1d_vs_torch(shape):
+    """The MFMA implicit-GEMM conv every dense layer runs on vs torch.nn.functional.conv1d (fp32)."""
+    import ctypes as C
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    B, Ci, Co, K, d, T = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x, w, b = torch.randn(B, Ci, T, generator=g), torch.randn(Co, Ci, K, generator=g) / (Ci * K) ** 0.5, torch.randn(Co, generator=g)
+    ref = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), padding=(K - 1) * d // 2, dilation=d).float()
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.empty(B, Co, T, device=DEV)
+    need = C.c_size_t()
+    L.check(lib.sty_conv1d_workspace_bytes(Co, Ci, K, C.byref(need)))
+    ws = torch.empty(need.value, dtype=torch.uint8, device=DEV)
+    L.check(lib.sty_conv1d_fwd(B, Ci, Co, K, d, T, L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(y), L.ptr(ws), ws.numel(),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    err = (y.cpu() - ref).abs().max().item()
+    print(f"\n  conv1d {shape}: max|err| {err:.3e}")
+    assert err <= 2e-5
