@@ -1,0 +1,39 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; csv output).
+
+MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B as rocprofv3 reports them;
+on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, so reads are doubled.  Writes are left uncorrected
+(uncalibrated in the guide).  Output: JSON {kernel: {launches, fetch_bytes_per_launch, write_bytes_per_launch}}."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def collect(d, name):
+    tot, n = collections.Counter(), collections.Counter()
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != name:
+                continue
+            k = r["Kernel_Name"]
+            tot[k] += float(r["Counter_Value"])
+            n[k] += 1
+    return tot, n
+
+
+def main(fetch_dir, write_dir):
+    ft, fn = collect(fetch_dir, "FETCH_SIZE")
+    wt, wn = collect(write_dir, "WRITE_SIZE")
+    out = {}
+    for k in ft:
+        if "sty::" not in k:
+            continue
+        out[k] = {"launches": fn[k], "fetch_bytes_per_launch": 2.0 * 1024.0 * ft[k] / fn[k],
+                  "write_bytes_per_launch": 1024.0 * wt.get(k, 0.0) / max(1, wn.get(k, 0)),
+                  "note": "FETCH_SIZE x2 (gfx950 correction) x1024; WRITE_SIZE x1024 uncorrected"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
