@@ -84,6 +84,24 @@ def build_model(device):
     return m.to(device), se.to(device), P
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel from the committed PMC passes of this same command (tools/profile_round.sh ->
+    profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  Counters cannot be
+    read from inside the process, so this is the recorded figure, or None when no record matches."""
+    import glob
+    import re
+    key = re.sub(r"\s+", "", family)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c2_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if key in re.sub(r"\s+", "", k):
+                return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def _usable_cpus():
     """cores this process may actually use: affinity mask intersected with the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -254,11 +272,14 @@ def main():
     }
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
+        traffic, traffic_src = pmc_traffic(dom["name"])
         per = dom["ms"] / dom["launches"] * 1e-3
         tf = dom["flops"] / dom["launches"] / per / 1e12
         gbs = dom["bytes"] / dom["launches"] / per / 1e9
         rec["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
-                           "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
+                           "traffic_source": traffic_src,
+                           "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                            "avg_launch_us": per * 1e6, "launches": dom["launches"],
                            "hbm_GBps_algorithmic": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                            "share_of_step_time": dom["ms"] / (1e3 * dt)}

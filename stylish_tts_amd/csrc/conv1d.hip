@@ -336,10 +336,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const double in_elems = a.H ? (double)a.B * a.Cin2d * a.Hin * (a.Tin ? a.Tin : a.T)
                                 : (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
   const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
-  const char* fam = CO_BLK == 32 ? "conv1d_mfma<co32>" : (CO_BLK == 64 ? "conv1d_mfma<co64>" : "conv1d_mfma<co128>");
-  if (CO_BLK == 32 && TT_BLK == 512) fam = "conv1d_mfma<co32,t512>";
-  if (CO_BLK == 64 && TT_BLK == 64) fam = "conv1d_mfma<co64,t64>";
-  if (CO_BLK == 64 && TT_BLK == 128) fam = "conv1d_mfma<co64,t128,glu>";
+  char fam[48];  // the kernel's own name, as rocprofv3 prints it (minus spaces)
+  snprintf(fam, sizeof(fam), "conv1d_mfma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
   ProfScope prof(fam, flops, bytes, st, detail);

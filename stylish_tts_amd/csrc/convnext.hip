@@ -197,7 +197,7 @@ int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st) {
   const double pos = (double)B * a.T;
   const double flops = pos * (448.0 + 8192.0 + (pass == 2 ? 8192.0 : 0.0));
   const double bytes = pos * 32 * 4.0 * (pass == 2 ? 2.0 : 1.0);
-  ProfScope prof(pass == 1 ? "convnext32<pass1>" : "convnext32<pass2>", flops, bytes, st);
+  ProfScope prof(pass == 1 ? "convnext32_pass1_kernel" : "convnext32_pass2_kernel", flops, bytes, st);
   if (pass == 1)
     hipLaunchKernelGGL(convnext32_kernel<false>, grid, dim3(256), 0, st, a);
   else

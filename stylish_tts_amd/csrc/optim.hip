@@ -50,7 +50,7 @@ int launch_adamw(size_t n, float* p, const float* g, float* m, float* v, float l
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
-  ProfScope prof("adamw", 12.0 * n, 28.0 * n, st);
+  ProfScope prof("adamw_kernel", 12.0 * n, 28.0 * n, st);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n4, n, reinterpret_cast<float4*>(p),
                      reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v),
                      1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2s, eps);

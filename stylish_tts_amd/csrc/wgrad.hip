@@ -364,7 +364,11 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     const size_t lds = (size_t)(c.TI + c.TO) * (W1_TW + 1) * sizeof(float);
     char detail[40];
     snprintf(detail, sizeof(detail), "ci%d co%d k1 T%d W%d", w.Cin, w.Cout, fwd.T, fwd.flatW);
-    ProfScope prof("wgrad", 2.0 * w.Cin * (double)fwd.B * w.Cout * fwd.T,
+    char fam[48];
+    snprintf(fam, sizeof(fam), "wgrad_k1_kernel<%d,%d,%d,%d>", c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 1 : (c.TO == 32 ? 4 : 2)),
+             c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 4 : (c.TO == 32 ? 1 : 2)), c.TI == 128 && c.TO == 128 ? 2 : 1,
+             c.TI == 128 && c.TO == 128 ? 2 : 1);
+    ProfScope prof(fam, 2.0 * w.Cin * (double)fwd.B * w.Cout * fwd.T,
                    4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T), st, detail);
     static bool raised = false;
     if (!raised) {
@@ -406,7 +410,9 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   const double bytes = 4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
-  ProfScope prof("wgrad", flops * HM, bytes * HM, st, detail);
+  char fam[48];
+  snprintf(fam, sizeof(fam), "conv1d_wgrad_kernel<%d>", w.K == 1 ? 0 : (cdiv(w.K, 4) <= 3 ? cdiv(w.K, 4) : 6));
+  ProfScope prof(fam, flops * HM, bytes * HM, st, detail);
   const int KT = w.K == 1 ? 0 : cdiv(w.K, 4);
   if (fwd.flatW && KT > 3) {
     set_error("wgrad: flat 2-D mode is built for K <= 12");
