@@ -109,7 +109,15 @@ struct Trainer {
     const size_t ny = (size_t)B * w.Cout * Tt;
     // resolve every persistent gradient buffer BEFORE the temporaries (which are released at the end)
     float* gY = G(f.y, ny);
-    float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
+    // y = conv + residual: d residual = gY.  When nobody has written the residual's gradient yet and no mask is
+    // applied after the add, gY itself BECOMES that buffer (this conv is its last reader), no copy, no zero-fill.
+    float* gR = nullptr;
+    if (f.residual && wants(f.residual)) {
+      if (!gmap.count(f.residual) && !(f.out_mask && f.out_mask_post) && f.shuffle <= 1)
+        gmap[f.residual] = gY;
+      else
+        gR = G(f.residual, ny);
+    }
     float* gX[3] = {nullptr, nullptr, nullptr};
     int accX[3] = {1, 1, 1};
     bool any = false;
@@ -173,6 +181,19 @@ struct Trainer {
         d.mask = gmask;
       }
       d.y = U;
+      if (f.nsrc == 1 && (f.pro == PRO_NONE || f.pro == PRO_MASK) && gX[0] != gY) {
+        // no prologue derivative to apply: the input-gradient conv writes (or accumulates, through its residual
+        // operand) straight into the gradient buffer; the forward's input mask becomes an output mask
+        d.y = gX[0];
+        d.residual = accX[0] ? gX[0] : nullptr;
+        if (f.pro == PRO_MASK) {
+          d.out_mask = f.mask;
+          d.out_mask_post = 0;
+        }
+        if (live()) chk(launch_conv1d(d, st));
+        ws.off = mark;
+        return;
+      }
       if (live()) chk(launch_conv1d(d, st));
       int c0 = 0;
       for (int i = 0; i < f.nsrc; ++i) {

@@ -703,17 +703,28 @@ int launch_sn_unpack(const float* gwp, const float* w, const float* u, const flo
 }
 
 // ConvNeXt pwconv2 bias folding b2eff = b2 + W2 . beta (convnext.hip): g = d loss / d b2eff [C]
-__global__ void b2eff_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w2,
-                                 const float* __restrict__ beta, int C, float* __restrict__ db2,
-                                 float* __restrict__ dbeta, float* __restrict__ dW2) {
+// grid: x = 64-channel slice of the 4C axis (dbeta, one wave-quarter of the co loop each, summed through LDS),
+// plus C*4C/256 blocks for the rank-1 dW2 update
+__global__ __launch_bounds__(256) void b2eff_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w2,
+                                                        const float* __restrict__ beta, int C, int nbeta_blocks,
+                                                        float* __restrict__ db2, float* __restrict__ dbeta,
+                                                        float* __restrict__ dW2) {
+  __shared__ float red[4][64];
   const int C4 = 4 * C;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < C && db2) db2[i] += g[i];
-  if (i < C4 && dbeta) {
+  if ((int)blockIdx.x < nbeta_blocks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + lane;
     float acc = 0.f;
-    for (int co = 0; co < C; ++co) acc = fmaf(w2[(size_t)co * C4 + i], g[co], acc);
-    dbeta[i] += acc;
+    if (ch < C4)
+      for (int co = wave; co < C; co += 4) acc = fmaf(w2[(size_t)co * C4 + ch], g[co], acc);
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && ch < C4 && dbeta) dbeta[ch] += red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (blockIdx.x == 0 && db2)
+      for (int i = threadIdx.x; i < C; i += 256) db2[i] += g[i];
+    return;
   }
+  const int i = (blockIdx.x - nbeta_blocks) * 256 + threadIdx.x;
   if (i < C * C4 && dW2) {
     const int co = i / C4, ch = i % C4;
     dW2[i] += g[co] * beta[ch];
@@ -721,7 +732,9 @@ __global__ void b2eff_bwd_kernel(const float* __restrict__ g, const float* __res
 }
 int launch_b2eff_bwd(const float* g, const float* w2, const float* beta, int C, float* db2, float* dbeta, float* dW2,
                      hipStream_t st) {
-  hipLaunchKernelGGL(b2eff_bwd_kernel, dim3(cdiv(4 * C * C, 256)), dim3(256), 0, st, g, w2, beta, C, db2, dbeta, dW2);
+  const int nb = cdiv(4 * C, 64);
+  hipLaunchKernelGGL(b2eff_bwd_kernel, dim3(nb + cdiv(4 * C * C, 256)), dim3(256), 0, st, g, w2, beta, C, nb, db2, dbeta,
+                     dW2);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
