@@ -20,10 +20,28 @@ def wn_weight(P, name):
     return g * v / n
 
 
+# Train-mode switches (the reference's module.train() behaviour on this path), all off = eval mode:
+#   bn_batch  BatchNorm1d of the conformer conv module uses batch statistics and updates its running buffers
+#             (conformer.py:183; momentum 0.1, unbiased running variance)
+#   sn_iter   spectral_norm does one power iteration per forward and stores the new u, v (torch.nn.utils.spectral_norm,
+#             n_power_iterations=1, eps 1e-12; mel_style_encoder.py:18-39)
+#   f0_down / n_down   widths of the Decoder's random box smoothing of F0 / energy (decoder.py:53-75: 0, 7, 15 / 31)
+# Buffer updates are written back into the parameter dict P (callers pass a copy).  Dropout is not modelled.
+TRAIN = {"bn_batch": False, "sn_iter": False, "f0_down": 0, "n_down": 0}
+
+
 def sn_weight(P, name):
-    """old-hook spectral_norm in eval mode: weight_orig / (u . W v)  (mel_style_encoder.py:18-39,87-93)."""
+    """old-hook spectral_norm: weight_orig / (u . W v)  (mel_style_encoder.py:18-39,87-93); eval mode uses the stored
+    u, v, train mode (TRAIN['sn_iter']) refreshes them first with one power iteration, as
+    torch.nn.utils.spectral_norm.SpectralNorm.compute_weight does."""
     w = P[name + ".weight_orig"]
     u, v = P[name + ".weight_u"], P[name + ".weight_v"]
+    if TRAIN["sn_iter"]:
+        with torch.no_grad():
+            wm = w.detach().flatten(1)
+            v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+        P[name + ".weight_u"], P[name + ".weight_v"] = u, v
     sigma = torch.dot(u, torch.mv(w.flatten(1), v))
     return w / sigma
 
@@ -113,8 +131,18 @@ def decoder_block(P, p, x, style):
     return (h + sc) / math.sqrt(2)
 
 
+def _box(x, width):
+    """decoder.py:58-75: conv1d with a ones kernel, zero padding width//2, divided by the width."""
+    if not width:
+        return x
+    return F.conv1d(x[:, None], torch.ones(1, 1, width, dtype=x.dtype), padding=width // 2)[:, 0] / width
+
+
 def decoder(P, p, asr, f0_curve, energy, style, voiced):
-    """Decoder.forward in eval mode (decoder.py:77-90; the train-mode random smoothing :53-75 is off)."""
+    """Decoder.forward (decoder.py:52-90); the train-mode box smoothing of F0 / energy (:53-75) uses the widths in
+    TRAIN (0 = off, the eval-mode behaviour)."""
+    f0_curve = _box(f0_curve, TRAIN["f0_down"])
+    energy = _box(energy, TRAIN["n_down"])
     f0 = F.conv1d(f0_curve[:, None], wn_weight(P, p + ".F0_conv"), P[p + ".F0_conv.bias"], padding=1)
     n = F.conv1d(energy[:, None], wn_weight(P, p + ".N_conv"), P[p + ".N_conv.bias"], padding=1)
     v = F.conv1d(voiced[:, None], wn_weight(P, p + ".voiced_conv"), P[p + ".voiced_conv.bias"], padding=1)
@@ -158,9 +186,14 @@ def conformer_block(P, p, x, style, bn_eps=1e-5):
     a, gate = z.chunk(2, dim=1)
     z = a * torch.sigmoid(gate)
     z = F.conv1d(F.pad(z, (15, 15)), P[p + ".conv.net.3.conv.weight"], P[p + ".conv.net.3.conv.bias"], groups=z.shape[1])
-    z = (z - P[p + ".conv.net.4.running_mean"][None, :, None]) / torch.sqrt(
-        P[p + ".conv.net.4.running_var"][None, :, None] + bn_eps
-    ) * P[p + ".conv.net.4.weight"][None, :, None] + P[p + ".conv.net.4.bias"][None, :, None]
+    if TRAIN["bn_batch"]:  # nn.BatchNorm1d in training mode: batch statistics + running-buffer update
+        rm, rv = P[p + ".conv.net.4.running_mean"].clone(), P[p + ".conv.net.4.running_var"].clone()
+        z = F.batch_norm(z, rm, rv, P[p + ".conv.net.4.weight"], P[p + ".conv.net.4.bias"], True, 0.1, bn_eps)
+        P[p + ".conv.net.4.running_mean"], P[p + ".conv.net.4.running_var"] = rm, rv
+    else:
+        z = (z - P[p + ".conv.net.4.running_mean"][None, :, None]) / torch.sqrt(
+            P[p + ".conv.net.4.running_var"][None, :, None] + bn_eps
+        ) * P[p + ".conv.net.4.weight"][None, :, None] + P[p + ".conv.net.4.bias"][None, :, None]
     z = z * torch.sigmoid(z)
     z = F.conv1d(z, P[p + ".conv.net.6.weight"], P[p + ".conv.net.6.bias"])
     x = z + x
