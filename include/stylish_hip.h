@@ -151,6 +151,19 @@ int sty_source_workspace_bytes(int B, int T, size_t *bytes);
  * sty_vocoder_bwd returns.  sty_vocoder_bwd takes d loss / d audio [B,1,300T] and writes d loss / d mel
  * [B,128,T] and d loss / d style [B,64] (each optional) and adds the parameter gradients.                  */
 int sty_model_enable_training(sty_model *m);
+/* module.train() behaviour of the *_fwd_train entry points (all zero = eval-mode statistics, the default).
+ * Dropout is not implemented: run the reference's Dropout modules at p = 0 for parity.                        */
+typedef struct {
+  int bn_batch_stats;  /* conformer BatchNorm1d (conformer.py:183): batch statistics, running_mean / running_var of the
+                          bound state_dict buffers are updated in place                                          */
+  int sn_power_iter;   /* spectral_norm (mel_style_encoder.py:18-39): one power iteration per forward, weight_u /
+                          weight_v of the bound state_dict buffers are updated in place                          */
+  int f0_smooth;       /* Decoder box-smoothing width of F0 (decoder.py:53-75): 0, 7 or 15; the reference draws it
+                          per step with random.randint, here the caller does                                      */
+  int energy_smooth;   /* of the energy: 0, 7, 15 or 31                                                          */
+  float bn_momentum;   /* 0.1 (nn.BatchNorm1d default)                                                           */
+} sty_train_opts;
+int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
 int sty_model_bind_grad(sty_model *m, const char *key, float *grad);
 int sty_vocoder_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
 int sty_vocoder_fwd_train(sty_model *m, const sty_vocoder_io *io, void *workspace, size_t ws_bytes, void *stream);

@@ -420,6 +420,7 @@ struct Builder {
     float* wp = m->ab.take<float>((size_t)KW * pc.CinP * pc.CoutP);
     float* bp = m->ab.take<float>(pc.CoutP);
     float* ts = m->ab.take<float>(Cout);
+    float* ts2 = m->train_enabled ? m->ab.take<float>((size_t)Cin * KH * KW + Cout) : nullptr;
     pc.wp = wp;
     pc.bias = bias ? bp : nullptr;
     if (!dry) {
@@ -438,6 +439,7 @@ struct Builder {
       j.wp = wp;
       j.bp = bp;
       j.scratch = ts;
+      j.scratch2 = ts2;
       m->jobs.push_back(j);
     }
     if (m->train_enabled) {  // input-gradient weights: rows (kh', co), columns ci, taps flipped in both directions
@@ -490,6 +492,7 @@ struct Builder {
         r.dw_b = ptr(d + ".bias", {r.Cin});
         float* w9 = m->ab.take<float>((size_t)r.Cin * 9);
         float* ts = m->ab.take<float>(r.Cin);
+        float* ts2 = m->train_enabled ? m->ab.take<float>((size_t)9 + r.Cin) : nullptr;
         r.dw_w9 = w9;
         if (!dry) {
           PackJob j;
@@ -500,6 +503,7 @@ struct Builder {
           j.Cout = r.Cin;
           j.wp = w9;
           j.scratch = ts;
+          j.scratch2 = ts2;
           m->jobs.push_back(j);
         }
       }
@@ -1279,6 +1283,16 @@ int sty_model_enable_training(sty_model* m) {
   return STY_OK;
 }
 
+int sty_model_set_train_opts(sty_model* m, const sty_train_opts* o) {
+  if (!m || !o || (o->f0_smooth && !(o->f0_smooth & 1)) || (o->energy_smooth && !(o->energy_smooth & 1)) ||
+      o->f0_smooth < 0 || o->energy_smooth < 0 || o->f0_smooth > 63 || o->energy_smooth > 63) {
+    set_error("sty_model_set_train_opts: null argument or smoothing width not an odd number in [0, 63]");
+    return STY_EINVAL;
+  }
+  m->topts = *o;
+  return STY_OK;
+}
+
 int sty_model_bind_grad(sty_model* m, const char* key, float* grad) {
   if (!m || !key || !grad) {
     set_error("sty_model_bind_grad: bad argument");
@@ -1893,6 +1907,14 @@ int sty_style_fwd_train(sty_model* m, int B, int T, const float* mel, float* sty
   if (!mel || !style || !workspace || B <= 0 || T < 40) {
     set_error("sty_style_fwd_train: bad argument (T >= 40 frames)");
     return STY_EINVAL;
+  }
+  if (m->topts.sn_power_iter) {  // training-mode spectral norm: refresh u, v (in the caller's buffers) first
+    for (const PackJob& j : m->jobs) {
+      if (j.kind != PK_CONV2D_SN && j.kind != PK_DW2D_SN) continue;
+      const int n = j.kind == PK_CONV2D_SN ? j.Cin * j.KH * j.K : 9;
+      rc = launch_sn_power_iter(j.w, const_cast<float*>(j.g), const_cast<float*>(j.v), j.Cout, n, j.scratch2, S(stream));
+      if (rc) return rc;
+    }
   }
   // weights change between steps: re-derive the prepared (spectral-normalised, packed) form every call
   if ((rc = sty_model_prepare(m, stream))) return rc;

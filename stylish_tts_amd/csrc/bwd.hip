@@ -578,6 +578,113 @@ int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const fl
   return STY_OK;
 }
 
+// ---- BatchNorm1d in TRAINING mode (conformer.py:183): batch statistics over (B, T), running-buffer update ----
+// part: per-(b,c) row sums from row_stats_kernel ([B*C][nseg][2] doubles).  One thread per channel.
+__global__ void bn_train_finalize_kernel(const double* __restrict__ part, int nseg, int B, int C, int T, float eps,
+                                         float momentum, float* __restrict__ rm, float* __restrict__ rv,
+                                         float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < nseg; ++k) {
+      s += part[(((size_t)b * C + c) * nseg + k) * 2];
+      q += part[(((size_t)b * C + c) * nseg + k) * 2 + 1];
+    }
+  const double n = (double)B * T;
+  const double mu = s / n;
+  double var = q / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mu;
+  rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * n / (n - 1.0));  // unbiased, as torch does
+}
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bvec,
+                                const float* __restrict__ mean, const float* __restrict__ rstd, int C, int T,
+                                float* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const size_t o = ((size_t)b * C + c) * T + t;
+  y[o] = (x[o] - mean[c]) * rstd[c] * w[c] + bvec[c];
+}
+int launch_bn_train_fwd(const float* x, const float* w, const float* b, float* rm, float* rv, float eps, float momentum,
+                        int B, int C, int T, float* y, float* mean, float* rstd, double* part, hipStream_t st) {
+  int r = launch_row_stats(x, B * C, T, part, st);
+  if (r) return r;
+  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, part, row_stats_nseg(T), B, C, T, eps,
+                     momentum, rm, rv, mean, rstd);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, x, w, b, mean, rstd, C, T, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// sums[c] = (sum dy, sum dy xhat) over (B, T); parameter gradients accumulate
+__global__ __launch_bounds__(256) void bn_train_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, int B, int C, int T,
+                                                                float* __restrict__ sums, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+  __shared__ double red[2][4];
+  const int c = blockIdx.x;
+  double acc[2] = {0.0, 0.0};
+  for (int b = 0; b < B; ++b) {
+    const size_t row = ((size_t)b * C + c) * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float g = dy[row + t];
+      acc[0] += g;
+      acc[1] += (double)g * ((x[row + t] - mean[c]) * rstd[c]);
+    }
+  }
+  block_sum<2>(acc, red);
+  if (threadIdx.x == 0) {
+    sums[2 * c] = (float)acc[0];
+    sums[2 * c + 1] = (float)acc[1];
+    if (db) db[c] += (float)acc[0];
+    if (dw) dw[c] += (float)acc[1];
+  }
+}
+__global__ void bn_train_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                       const float* __restrict__ w, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const float* __restrict__ sums, int B, int C,
+                                       int T, float* __restrict__ dx, int accumulate) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const size_t o = ((size_t)b * C + c) * T + t;
+  const float inv_n = 1.0f / ((float)B * (float)T);
+  const float xh = (x[o] - mean[c]) * rstd[c];
+  const float d = w[c] * rstd[c] * (dy[o] - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+  dx[o] = accumulate ? dx[o] + d : d;
+}
+int launch_bn_train_bwd(const float* x, const float* dy, const float* w, const float* mean, const float* rstd, int B,
+                        int C, int T, float* dx, int accumulate, float* dw, float* db, float* sums, hipStream_t st) {
+  hipLaunchKernelGGL(bn_train_bwd_sums_kernel, dim3(C), dim3(256), 0, st, x, dy, mean, rstd, B, C, T, sums, dw, db);
+  hipLaunchKernelGGL(bn_train_bwd_dx_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, x, dy, w, mean, rstd, sums, B,
+                     C, T, dx, accumulate);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- Decoder train-mode smoothing (decoder.py:58-75): y = conv1d(x, ones(width), zero padding width/2) / width ----
+// (odd width: the operator is symmetric, so the same kernel is its own transpose in the backward)
+__global__ void box_smooth_kernel(const float* __restrict__ x, int T, int width, float* __restrict__ y,
+                                  int accumulate) {
+  const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const int h = width / 2;
+  float s = 0.f;
+  for (int k = -h; k <= h; ++k) {
+    const int u = t + k;
+    if (u >= 0 && u < T) s += x[(size_t)b * T + u];
+  }
+  const float v = s / (float)width;
+  y[(size_t)b * T + t] = accumulate ? y[(size_t)b * T + t] + v : v;
+}
+int launch_box_smooth(const float* x, int B, int T, int width, float* y, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(box_smooth_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, x, T, width, y, accumulate);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // ---- bias gradient of a dense conv: db[co] += scale * sum_{b,t} g[b][co][t] (* mask) ----
 // two deterministic stages like the depthwise weight gradient: (channel, batch row, segment) partials, then a sum
 __global__ __launch_bounds__(256) void bias_grad_part_kernel(const float* __restrict__ g, const float* __restrict__ mask,

@@ -21,6 +21,55 @@ __global__ __launch_bounds__(256) void sn_rowdot_kernel(const float* __restrict_
   if (threadIdx.x == 0) t[co] = u[co] * red[0];
 }
 
+// One power iteration of torch.nn.utils.spectral_norm in training mode (n_power_iterations = 1, eps 1e-12):
+//   v = normalize(W^T u), u = normalize(W v), written back into the module's weight_u / weight_v buffers.
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, int Cout,
+                                                      int n, float* __restrict__ vraw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int co = 0; co < Cout; ++co) s = fmaf(w[(size_t)co * n + i], u[co], s);
+  vraw[i] = s;
+}
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ raw, int n, float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)raw[i] * raw[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float nrm = fmaxf((float)sqrt(red[0]), 1e-12f);
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = raw[i] / nrm;
+}
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, int n,
+                                                     float* __restrict__ uraw) {
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s = fmaf(w[(size_t)co * n + i], v[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) uraw[co] = red[0];
+}
+// scratch: n + Cout floats
+int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st) {
+  float* vraw = scratch;
+  float* uraw = scratch + n;
+  hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, u, Cout, n, vraw);
+  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, n, v);
+  hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, w, v, n, uraw);
+  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, uraw, Cout, u);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // W[co][ci][kh][kw] / sigma  ->  Wp[kw][(kh*Cin + ci)][co]   (+ bias copy); one block per output channel
 __global__ __launch_bounds__(256) void pack_conv2d_sn_kernel(const float* __restrict__ w, const float* __restrict__ t,
                                                              const float* __restrict__ bias, int Cout, int Cin, int KH,

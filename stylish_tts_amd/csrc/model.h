@@ -69,6 +69,7 @@ struct PackJob {
   float* wp = nullptr;
   float* bp = nullptr;
   float* scratch = nullptr;
+  float* scratch2 = nullptr;  // spectral norm, training: n + Cout floats for the power iteration
 };
 
 struct AdaFc {      // one AdaIN / AdaLN style projection
@@ -191,6 +192,7 @@ struct sty_model {
   int* mj_blk_dev[3] = {nullptr, nullptr, nullptr};
   int mj_nblk[3] = {0, 0, 0};
   bool mj_ready = false;
+  sty_train_opts topts = {0, 0, 0, 0, 0.1f};  // train-mode behaviour of the *_fwd_train entry points
   struct sty::Trainer* trainer = nullptr;
 };
 
@@ -268,6 +270,12 @@ int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const
 int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, hipStream_t st);
 int launch_pool_fc_bwd(const float* x, int B, int C, int n, int count, const float* W, int S, const float* gs,
                        float* dW, float* db, float* dx, hipStream_t st);
+int launch_bn_train_fwd(const float* x, const float* w, const float* b, float* rm, float* rv, float eps, float momentum,
+                        int B, int C, int T, float* y, float* mean, float* rstd, double* part, hipStream_t st);
+int launch_bn_train_bwd(const float* x, const float* dy, const float* w, const float* mean, const float* rstd, int B,
+                        int C, int T, float* dx, int accumulate, float* dw, float* db, float* sums, hipStream_t st);
+int launch_box_smooth(const float* x, int B, int T, int width, float* y, int accumulate, hipStream_t st);
+int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st);
 int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
                           hipStream_t st, size_t* need);
 int trainer_style_backward(struct Trainer* t, const float* d_style, hipStream_t st);

@@ -575,11 +575,32 @@ struct Trainer {
   float* decoder(const float* asr, const float* pitch, const float* energy, const float* voiced, int Tt) {
     const DecoderPlan& d = m->dec;
     const int din = d.asr_res.Cin, dr = d.asr_res.Cout, dh = d.encode.Cout;
-    float* fnv = take<float>((size_t)B * 3 * Tt);
-    if (live()) chk(launch_fnv(pitch, energy, voiced, d.fnv_w, B, Tt, fnv, st));
     in_pitch = pitch;
     in_energy = energy;
     in_voiced = voiced;
+    // train-mode box smoothing of the F0 curve and the energy (decoder.py:53-75); the widths are the caller's draw
+    if (m->topts.f0_smooth > 1) {
+      float* ps = take<float>((size_t)B * Tt);
+      if (live()) chk(launch_box_smooth(pitch, B, Tt, m->topts.f0_smooth, ps, 0, st));
+      pitch = ps;
+    }
+    if (m->topts.energy_smooth > 1) {
+      float* es = take<float>((size_t)B * Tt);
+      const int wdt = m->topts.energy_smooth;
+      if (live()) chk(launch_box_smooth(energy, B, Tt, wdt, es, 0, st));
+      const float* e0 = energy;
+      tape.push_back([=]() {
+        if (!wants(e0)) return;
+        float* g = G(es, (size_t)B * Tt);
+        int acc = 1;
+        float* g0 = Gw(e0, (size_t)B * Tt, acc);
+        if (live()) chk(launch_box_smooth(g, B, Tt, wdt, g0, acc, st));  // symmetric operator = its own transpose
+      });
+      if (!wants(e0)) nograd.insert(es);
+      energy = es;
+    }
+    float* fnv = take<float>((size_t)B * 3 * Tt);
+    if (live()) chk(launch_fnv(pitch, energy, voiced, d.fnv_w, B, Tt, fnv, st));
     nograd.insert(pitch);
     nograd.insert(voiced);
     {
@@ -657,8 +678,28 @@ struct Trainer {
     float* g = act(ACT_GLU, g0, nullptr, 2 * C, Tt);
     float* d0 = dwconv(g, c.dw_w, c.dw_b, 2 * C, Tt, 31, 15);
     float* d1 = take<float>((size_t)B * 2 * C * Tt);
-    if (live()) chk(launch_bn_eval_fwd(d0, c.bn_w, c.bn_b, c.bn_rm, c.bn_rv, 1e-5f, B, 2 * C, Tt, d1, st));
-    {
+    if (m->topts.bn_batch_stats) {
+      // training-mode BatchNorm: batch statistics, running buffers of the bound state_dict updated in place
+      const int Cb = 2 * C;
+      float* mean = take<float>(Cb);
+      float* rstd = take<float>(Cb);
+      double* part = take<double>((size_t)B * Cb * row_stats_nseg(Tt) * 2);
+      if (live())
+        chk(launch_bn_train_fwd(d0, c.bn_w, c.bn_b, const_cast<float*>(c.bn_rm), const_cast<float*>(c.bn_rv), 1e-5f,
+                                m->topts.bn_momentum, B, Cb, Tt, d1, mean, rstd, part, st));
+      const float *bw = c.bn_w, *bb = c.bn_b;
+      tape.push_back([=]() {
+        float* gY = G(d1, (size_t)B * Cb * Tt);
+        int acc = 1;
+        float* gX = Gw(d0, (size_t)B * Cb * Tt, acc);
+        const size_t mark = ws.off;
+        float* sums = take<float>(2 * Cb);
+        if (live())
+          chk(launch_bn_train_bwd(d0, gY, bw, mean, rstd, B, Cb, Tt, gX, acc, PG(bw, Cb), PG(bb, Cb), sums, st));
+        ws.off = mark;
+      });
+    } else {
+      if (live()) chk(launch_bn_eval_fwd(d0, c.bn_w, c.bn_b, c.bn_rm, c.bn_rv, 1e-5f, B, 2 * C, Tt, d1, st));
       const float *bw = c.bn_w, *bb = c.bn_b, *rm = c.bn_rm, *rv = c.bn_rv;
       tape.push_back([=]() {
         float* gY = G(d1, (size_t)B * 2 * C * Tt);

@@ -29,6 +29,11 @@ class SpeechIO(C.Structure):
          ("tap_decoder_out", C.c_void_p), ("voc_taps", VocoderIO)]
 
 
+class TrainOpts(C.Structure):
+    _fields_ = [("bn_batch_stats", C.c_int), ("sn_power_iter", C.c_int), ("f0_smooth", C.c_int),
+                ("energy_smooth", C.c_int), ("bn_momentum", C.c_float)]
+
+
 # every symbol include/stylish_hip.h declares: name -> (restype, argtypes)
 _P, _I, _SZP = C.c_void_p, C.c_int, C.POINTER(C.c_size_t)
 SYMBOLS = {
@@ -60,6 +65,7 @@ SYMBOLS = {
     "sty_source_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
     "sty_model_enable_training": (C.c_int, [_P]),
     "sty_model_bind_grad": (C.c_int, [_P, C.c_char_p, _P]),
+    "sty_model_set_train_opts": (C.c_int, [_P, C.POINTER(TrainOpts)]),
     "sty_vocoder_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_vocoder_fwd_train": (C.c_int, [_P, C.POINTER(VocoderIO), _P, C.c_size_t, _P]),
     "sty_vocoder_bwd": (C.c_int, [_P, _P, _P, _P, _P]),

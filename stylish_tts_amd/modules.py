@@ -112,11 +112,23 @@ class _HipModule(torch.nn.Module):
                 L.check(lib.sty_model_bind_grad(self._handle, k.encode(), C.c_void_p(g)))
             L.check(lib.sty_model_finalize(self._handle))
             self._bound = (ptrs, gptrs)
+        if getattr(self, "_train_opts", None) is not None:
+            L.check(lib.sty_model_set_train_opts(self._handle, C.byref(self._train_opts)))
         return lib
 
     def enable_training(self):
         """Gradients of every parameter are accumulated into `param.grad` by the *_backward calls (K15)."""
         self._train = True
+        return self
+
+    def set_train_opts(self, *, bn_batch_stats=False, sn_power_iter=False, f0_smooth=0, energy_smooth=0,
+                       bn_momentum=0.1):
+        """module.train() behaviour of forward_train (sty_train_opts): BatchNorm batch statistics, spectral-norm
+        power iteration, Decoder smoothing widths (decoder.py:53-75; the caller draws them per step)."""
+        self._train_opts = L.TrainOpts(int(bn_batch_stats), int(sn_power_iter), int(f0_smooth), int(energy_smooth),
+                                       float(bn_momentum))
+        if self._handle is not None:
+            L.check(L.load().sty_model_set_train_opts(self._handle, C.byref(self._train_opts)))
         return self
 
     def requested_keys(self):

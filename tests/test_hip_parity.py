@@ -604,7 +604,7 @@ def test_adamw_matches_torch():
         assert err <= 2e-6, err
 
 
-def _train_setup(env, lr):
+def _train_setup(env, lr, train_mode=False):
     import stylish_tts_amd as S
     from oracle.manifest import style_encoder_manifest
     from oracle.weights import fill_state_dict
@@ -615,7 +615,7 @@ def _train_setup(env, lr):
     sp.load_state_dict(P, strict=False)
     se = S.MelStyleEncoder()
     se.load_state_dict(Pse)
-    tr = AcousticTrainer(sp.to(DEV), se.to(DEV), lr=lr)
+    tr = AcousticTrainer(sp.to(DEV), se.to(DEV), lr=lr, train_mode=train_mode)
     return tr, P, Pse
 
 
@@ -664,7 +664,7 @@ def test_acoustic_training_reduces_loss(env):
     cs = env["cs"]
     B, T = cs["pitch"].shape
     audio_gt = _test_audio(B, 300 * T, 21)
-    tr, _, _ = _train_setup(env, 2e-4)
+    tr, _, _ = _train_setup(env, 2e-4, train_mode=True)
     hist = []
     for it in range(6):
         losses = tr.train_batch(audio_gt=dev(audio_gt), texts=dev(cs["texts"]), text_lengths=dev(cs["text_lengths"]),
@@ -697,3 +697,66 @@ def test_dense_conv1d_vs_torch(shape):
     err = (y.cpu() - ref).abs().max().item()
     print(f"\n  conv1d {shape}: max|err| {err:.3e}")
     assert err <= 2e-5
+
+
+def _sub(t, stride=97):
+    t = t.detach().flatten()
+    return t[::stride] if t.numel() > 4096 else t
+
+
+def test_speech_predictor_train_mode_vs_reference_golden(env):
+    """module.train() behaviour on the HIP path: BatchNorm batch statistics + running-buffer update, Decoder box
+    smoothing (widths 7 / 15) and the gradients through both vs what the REFERENCE produced in .train() with dropout
+    off (tests/golden/sp_train_small.safetensors, tools/gen_golden_train.py)."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    gold = load_file(os.path.join(G, "sp_train_small.safetensors"))
+    cs, ali = env["cs"], env["ali"]
+    P = {k: v.clone() for k, v in env["P"].items()}
+    m = S.SpeechPredictor()
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).enable_training().set_train_opts(bn_batch_stats=True, f0_smooth=7, energy_smooth=15)
+    audio = m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(ali), dev(cs["pitch"]), dev(cs["energy"]),
+                            dev(env["voiced"]), dev(cs["style"]), dev(cs["pitch"]), noise=dev(cs["noise"]))
+    d_style, d_energy = m.backward(torch.sign(audio) / audio.numel())
+    torch.cuda.synchronize()
+    mse = ((audio.cpu() - gold["audio"]) ** 2).mean().item()
+    print(f"\n  train-mode forward vs reference: mse {mse:.3e}")
+    assert mse <= 1e-8
+    rep = Report()
+    sd = m.state_dict()
+    bn = "generator.amp_conformer.layers.0.conv.net.4."
+    rep.add("BN running_mean", sd[bn + "running_mean"], gold["bn.running_mean"], 1e-5)
+    rep.add("BN running_var", sd[bn + "running_var"], gold["bn.running_var"], 1e-5)
+    rep.add("d_style", d_style, gold["grad.style"], 3e-2)
+    rep.add("d_energy (through the smoothing)", d_energy, gold["grad.energy"], 3e-2)
+    named = dict(m.named_parameters())
+    for k in [k[len("grad."):] for k in gold if k.startswith("grad.") and k not in ("grad.style", "grad.energy")]:
+        rep.add("d " + k[-44:], _sub(named[k].grad), gold["grad." + k], 3e-2)
+    rep.done()
+
+
+def test_style_encoder_train_mode_vs_reference_golden():
+    """Spectral-norm power iteration on the HIP path (u, v buffers refreshed in place once per training forward) and the
+    gradients through W / sigma vs the REFERENCE in .train() (tests/golden/se_train_small.safetensors)."""
+    import stylish_tts_amd as S
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from safetensors.torch import load_file
+    from tests.cases import make_case
+    gold = load_file(os.path.join(G, "se_train_small.safetensors"))
+    se = S.MelStyleEncoder()
+    se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+    se = se.to(DEV).enable_training().set_train_opts(sn_power_iter=True)
+    out = se.forward_train(dev(make_case("se_small")["mel"]))
+    se.backward(dev(gold["cotangent"]))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("style", out, gold["style"], 1e-5)
+    sd = se.state_dict()
+    named = dict(se.named_parameters())
+    for k in ("shared.0", "shared.2.conv1", "shared.2.downsample_res.conv", "shared.6"):
+        rep.add(k + ".weight_u", sd[k + ".weight_u"], gold[k + ".weight_u"], 1e-5)
+        rep.add(k + ".weight_v", sd[k + ".weight_v"], gold[k + ".weight_v"], 1e-5)
+        rep.add("d " + k + ".weight_orig", _sub(named[k + ".weight_orig"].grad), gold["grad." + k + ".weight_orig"], 1e-3)
+    rep.done()
