@@ -27,7 +27,43 @@ def wn_weight(P, name):
 #             n_power_iterations=1, eps 1e-12; mel_style_encoder.py:18-39)
 #   f0_down / n_down   widths of the Decoder's random box smoothing of F0 / energy (decoder.py:53-75: 0, 7, 15 / 31)
 # Buffer updates are written back into the parameter dict P (callers pass a copy).  Dropout is not modelled.
-TRAIN = {"bn_batch": False, "sn_iter": False, "f0_down": 0, "n_down": 0}
+#   dropout_seed  != 0: Dropout / attention-probability dropout are active.  torch draws its masks from the global
+#             Philox stream, which no other implementation can reproduce; the path's masks are instead a pure function
+#             keep = u(seed, site, element) >= p of a counter-based hash (below), `site` numbering the dropout calls in
+#             execution order and `element` the linear index in the [B, C, T] (attention: [B, H, Tq, Tk]) layout.
+#             tools/gen_golden_train.py runs the reference with F.dropout / SDPA patched to the same function.
+TRAIN = {"bn_batch": False, "sn_iter": False, "f0_down": 0, "n_down": 0, "dropout_seed": 0, "_site": 0}
+_M32 = 0xFFFFFFFF
+
+
+def hash_uniform(seed, site, n):
+    """u in [0, 1) with 24 bits: lowbias32(idx * 0x9E3779B1 + site * 0x85EBCA77 + seed * 0xC2B2AE3D) >> 8."""
+    x = (torch.arange(n, dtype=torch.int64) * 0x9E3779B1 + site * 0x85EBCA77 + seed * 0xC2B2AE3D) & _M32
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return (x >> 8).to(torch.float32) / 16777216.0
+
+
+def keep_mask(shape, p):
+    """next dropout site: 0 / 1/(1-p) multiplier of the given (canonical-layout) shape, or None when dropout is off"""
+    if not TRAIN["dropout_seed"] or p <= 0.0:
+        return None
+    site = TRAIN["_site"]
+    TRAIN["_site"] = site + 1
+    n = 1
+    for d in shape:
+        n *= int(d)
+    u = hash_uniform(TRAIN["dropout_seed"], site, n).view(*shape)
+    return (u >= p).to(torch.float32) / (1.0 - p)
+
+
+def drop(x, p):
+    """nn.Dropout(p) in training mode with the hash mask; x is in the canonical [B, C, T] layout"""
+    m = keep_mask(x.shape, p)
+    return x if m is None else x * m
 
 
 def sn_weight(P, name):
@@ -158,6 +194,9 @@ def decoder(P, p, asr, f0_curve, energy, style, voiced):
 def conformer_block(P, p, x, style, bn_eps=1e-5):
     """ConformerBlock on [B,C,T] in eval mode (conformer.py:242-250, 111-144, 176-193)."""
     C = x.shape[1]
+
+    # MultiGenerator asks for attn/ff/conv dropout 0.2 (generator.py:821-826) but Conformer.__init__ never forwards
+    # those arguments to its ConformerBlocks (conformer.py:278-290), so every Dropout in here has p = 0: no dropout.
 
     def ff(name, z):
         z = adaln(P, f"{p}.{name}.fn.norm", z, style)

@@ -1,8 +1,10 @@
-"""Oracle: TextEncoder (train/models/text_encoder.py), eval mode (dropouts off)."""
+"""Oracle: TextEncoder (train/models/text_encoder.py); dropouts through oracle.blocks.drop (off in eval mode)."""
 import math
 
 import torch
 import torch.nn.functional as F
+
+from . import blocks as OB
 
 
 def sequence_mask(lengths, max_len):
@@ -32,7 +34,7 @@ def rope(x, d=8, base=10000.0):
     return torch.cat([xr * cos + rot * sin, xp], dim=-1)
 
 
-def mha(P, p, x, attn_mask, n_heads=8):
+def mha(P, p, x, attn_mask, n_heads=8, p_drop=0.0):
     """MultiHeadAttention.forward/attention with SDPA and additive -1e4 mask (text_encoder.py:214-280)."""
     Bn, C, L = x.shape
     dh = C // n_heads
@@ -43,6 +45,7 @@ def mha(P, p, x, attn_mask, n_heads=8):
     q, k, v = rope(heads(q), dh // 2), rope(heads(k), dh // 2), heads(v)
     add = torch.zeros_like(attn_mask, dtype=x.dtype).masked_fill(attn_mask == 0, -1e4)  # [B,1,L,L]
     att = torch.softmax(q @ k.transpose(2, 3) / math.sqrt(dh) + add, dim=-1)
+    att = OB.drop(att, p_drop)  # SDPA dropout_p on the attention probabilities (text_encoder.py:270-276)
     o = (att @ v).transpose(2, 3).reshape(Bn, C, L)
     return F.conv1d(o, P[p + ".conv_o.weight"], P[p + ".conv_o.bias"])
 
@@ -58,22 +61,23 @@ def text_encoder(P, p, tokens, lengths, want=None):
     for i in range(3):
         h = F.conv1d(h * mask, P[f"{p}.prenet.conv_layers.{i}.weight"], P[f"{p}.prenet.conv_layers.{i}.bias"], padding=2)
         h = chan_ln(h, P[f"{p}.prenet.norm_layers.{i}.gamma"], P[f"{p}.prenet.norm_layers.{i}.beta"])
-        h = torch.relu(h)
+        h = OB.drop(torch.relu(h), 0.5)  # ConvReluNorm p_dropout (text_encoder.py:418)
     x = (x + F.conv1d(h, P[p + ".prenet.proj.weight"], P[p + ".prenet.proj.bias"])) * mask
     if want is not None:
         want["te.prenet"] = x
     # encoder (text_encoder.py:378-394)
     attn_mask = mask.unsqueeze(2) * mask.unsqueeze(-1)  # [B,1,L,L]
+    pd = OB.TRAIN.get("text_dropout", 0.2)  # model.yml text_encoder.dropout
     i = 0
     while f"{p}.encoder.attn_layers.{i}.conv_q.weight" in P:
         x = x * mask
-        y = mha(P, f"{p}.encoder.attn_layers.{i}", x, attn_mask)
+        y = OB.drop(mha(P, f"{p}.encoder.attn_layers.{i}", x, attn_mask, p_drop=pd), pd)
         x = chan_ln(x + y, P[f"{p}.encoder.norm_layers_1.{i}.gamma"], P[f"{p}.encoder.norm_layers_1.{i}.beta"])
         f = f"{p}.encoder.ffn_layers.{i}"
         kpad = P[f + ".conv_1.weight"].shape[2] // 2
         y = F.conv1d(x * mask, P[f + ".conv_1.weight"], P[f + ".conv_1.bias"], padding=kpad)
-        y = torch.relu(y)
-        y = F.conv1d(y * mask, P[f + ".conv_2.weight"], P[f + ".conv_2.bias"], padding=kpad) * mask
+        y = OB.drop(torch.relu(y), pd)
+        y = OB.drop(F.conv1d(y * mask, P[f + ".conv_2.weight"], P[f + ".conv_2.bias"], padding=kpad) * mask, pd)
         x = chan_ln(x + y, P[f"{p}.encoder.norm_layers_2.{i}.gamma"], P[f"{p}.encoder.norm_layers_2.{i}.beta"])
         if want is not None:
             want[f"te.layer{i}"] = x
