@@ -10,7 +10,7 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       vocoder), mel + multi-phase losses through the 3-resolution STFT features, backward through the predictor and
       the style encoder, gradient all-reduce (N > 1) and the AdamW step of both models.  GAN / WavLM loss terms are
       off (third-party models); module.train() behaviour (BatchNorm batch statistics, spectral-norm
-      power iteration, random Decoder smoothing) except dropout, which is not built.
+      power iteration, random Decoder smoothing, TextEncoder dropout).
   c2-fwd: the forward half only (AcousticStep forward + the six multi-spectrogram lists).
   c3-fp32: LJSpeech shape, B=32, T=520, L=100, the same training step in fp32 (the bf16 variant is not built).
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
@@ -36,7 +36,7 @@ WORKLOADS = {
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
 }
 PASS = {
-    "train": "forward + backward + AdamW (mel + multi-phase losses; GAN/WavLM terms off; train mode without dropout)",
+    "train": "forward + backward + AdamW (mel + multi-phase losses; GAN/WavLM terms off; train mode)",
     "forward": "forward only (AcousticStep forward + multi-spectrogram features)",
     "vocoder": "vocoder forward only (inference)",
 }

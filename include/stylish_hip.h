@@ -152,7 +152,8 @@ int sty_source_workspace_bytes(int B, int T, size_t *bytes);
  * [B,128,T] and d loss / d style [B,64] (each optional) and adds the parameter gradients.                  */
 int sty_model_enable_training(sty_model *m);
 /* module.train() behaviour of the *_fwd_train entry points (all zero = eval-mode statistics, the default).
- * Dropout is not implemented: run the reference's Dropout modules at p = 0 for parity.                        */
+ * Dropout masks are a counter-based hash of (dropout_seed, call site, element), not torch's Philox stream: parity with
+ * the reference holds when its F.dropout / SDPA are patched to the same function (tools/gen_golden_train.py).   */
 typedef struct {
   int bn_batch_stats;  /* conformer BatchNorm1d (conformer.py:183): batch statistics, running_mean / running_var of the
                           bound state_dict buffers are updated in place                                          */
@@ -162,6 +163,11 @@ typedef struct {
                           per step with random.randint, here the caller does                                      */
   int energy_smooth;   /* of the energy: 0, 7, 15 or 31                                                          */
   float bn_momentum;   /* 0.1 (nn.BatchNorm1d default)                                                           */
+  unsigned dropout_seed; /* != 0: TextEncoder dropout is active (text_encoder.py: prenet 0.5 after every ReLU :63,:418;
+                          encoder: attention probabilities :274, after attention :387, inside the FFN :328, after the
+                          FFN :391).  Draw a new seed every step.  The conformer's dropouts are dead in the reference
+                          (conformer.py:278-290 never forwards the rates).                                        */
+  float text_dropout;  /* model.yml text_encoder.dropout (0.2)                                                    */
 } sty_train_opts;
 int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
 int sty_model_bind_grad(sty_model *m, const char *key, float *grad);

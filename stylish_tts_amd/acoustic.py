@@ -59,17 +59,20 @@ class AcousticTrainer:
         zero_grad -> AcousticStep forward -> LossLog.backwards_loss() seed -> backward through the predictor and the
         style encoder -> gradient mean over ranks -> AdamW step of both models.
 
-    train_mode=True runs the reference's module.train() behaviour except dropout (BatchNorm batch statistics and
-    running-buffer updates, random Decoder F0 / energy smoothing, one spectral-norm power iteration per step);
+    train_mode=True runs the reference's module.train() behaviour (BatchNorm batch statistics and running-buffer
+    updates, random Decoder F0 / energy smoothing, one spectral-norm power iteration per step, TextEncoder dropout with
+    counter-based masks);
     train_mode=False is the eval-mode graph of the golden gradient fixtures.
     One process per GPU: every rank runs this on its own utterances; the only exchange is the bucketed gradient
     all-reduce, started for the predictor's buckets before the style encoder's backward runs."""
 
     def __init__(self, speech_predictor, style_encoder, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4,
-                 w_mel=5.0, w_phase=8.0, mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0):
+                 w_mel=5.0, w_phase=8.0, mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0,
+                 text_dropout=0.2):
         import random
         from .optim import FlatAdamW
         self.train_mode = train_mode
+        self.text_dropout = text_dropout  # model.yml text_encoder.dropout
         self._rng = random.Random(seed)  # the Decoder's smoothing draws (decoder.py:55-57)
         self.sp, self.se = speech_predictor.enable_training(), style_encoder.enable_training()
         self.w_mel, self.w_phase, self.mean, self.std = w_mel, w_phase, mean, std
@@ -87,7 +90,8 @@ class AcousticTrainer:
         if self.train_mode:
             # module.train(): BatchNorm batch statistics, spectral-norm power iteration, random F0 / energy smoothing
             self.sp.set_train_opts(bn_batch_stats=True, f0_smooth=(0, 7, 15)[self._rng.randint(0, 2)],
-                                   energy_smooth=(0, 7, 15, 31)[self._rng.randint(0, 3)])
+                                   energy_smooth=(0, 7, 15, 31)[self._rng.randint(0, 3)],
+                                   dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.text_dropout)
             self.se.set_train_opts(sn_power_iter=True)
         mel, _, energy = calculate_mel(audio_gt, TO_MEL, self.mean, self.std, want_energy=True)
         style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)

@@ -81,6 +81,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     rs += __shfl_xor(rs, 32);
     l_run = l_run * alpha + rs;
     m_run = m_new;
+    if (a.drop_p > 0.f) {  // dropout acts on the normalised probabilities: the row sum above stays unmasked
+      const float ks_ = 1.0f / (1.0f - a.drop_p);
+      const unsigned rowi = ((unsigned)(b * a.H + h) * (unsigned)T + (unsigned)qi) * (unsigned)T;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        s[r] = sty_hash_u(a.drop_seed, a.drop_site, rowi + (unsigned)j) >= a.drop_p ? s[r] * ks_ : 0.f;
+      }
+    }
 #pragma unroll
     for (int d = 0; d < DP / 32; ++d) {
 #pragma unroll

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(64) void attn_bwd_c_kernel(AttnArgs a, const float*
       dp = fmaf(g[d], vb[(size_t)d * T + j], dp);
     }
     if (a.lengths && (qpad || j >= len)) s += -1e4f;
+    if (a.drop_p > 0.f) {
+      const unsigned idx = ((unsigned)(b * a.H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j;
+      dp = sty_hash_u(a.drop_seed, a.drop_site, idx) >= a.drop_p ? dp / (1.0f - a.drop_p) : 0.f;
+    }
     const float ds = expf(s - L) * (dp - dl);
 #pragma unroll
     for (int d = 0; d < DH; ++d) acc[d] = fmaf(ds, kb[(size_t)d * T + j], acc[d]);
@@ -120,10 +124,17 @@ __global__ __launch_bounds__(256) void attn_bwd_b_kernel(AttnArgs a, const float
     s *= a.scale;
     if (a.lengths && (i >= len || j >= len)) s += -1e4f;
     const float p = j < T ? expf(s - Lb[i]) : 0.f;
+    float pm = p;  // dropped / rescaled probability that multiplied V in the forward
+    if (a.drop_p > 0.f) {
+      const unsigned idx = ((unsigned)(b * a.H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j;
+      const float mf = sty_hash_u(a.drop_seed, a.drop_site, idx) >= a.drop_p ? 1.0f / (1.0f - a.drop_p) : 0.f;
+      pm = p * mf;
+      dp *= mf;
+    }
     const float ds = p * (dp - Db[i]);
 #pragma unroll
     for (int d = 0; d < DH; ++d) {
-      av[d] = fmaf(p, gb[(size_t)d * T + i], av[d]);
+      av[d] = fmaf(pm, gb[(size_t)d * T + i], av[d]);
       ak[d] = fmaf(ds, qb[(size_t)d * T + i], ak[d]);
     }
   }

@@ -578,6 +578,24 @@ int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const fl
   return STY_OK;
 }
 
+// ---- nn.Dropout with the counter-based hash mask: y = keep(seed, site, i) ? x / (1-p) : 0 (+ residual) ----
+// The backward is the same kernel on the output gradient (residual = nullptr, accumulate as needed).
+__global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ res, size_t n, float p,
+                               unsigned seed, unsigned site, float* __restrict__ y, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = sty_hash_u(seed, site, (unsigned)i) >= p ? x[i] / (1.0f - p) : 0.f;
+  if (res) v += res[i];
+  y[i] = accumulate ? y[i] + v : v;
+}
+int launch_dropout(const float* x, const float* res, size_t n, float p, unsigned seed, unsigned site, float* y,
+                   int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, res, n, p, seed, site, y,
+                     accumulate);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // ---- BatchNorm1d in TRAINING mode (conformer.py:183): batch statistics over (B, T), running-buffer update ----
 // part: per-(b,c) row sums from row_stats_kernel ([B*C][nseg][2] doubles).  One thread per channel.
 __global__ void bn_train_finalize_kernel(const double* __restrict__ part, int nseg, int B, int C, int T, float eps,

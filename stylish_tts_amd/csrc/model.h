@@ -192,7 +192,7 @@ struct sty_model {
   int* mj_blk_dev[3] = {nullptr, nullptr, nullptr};
   int mj_nblk[3] = {0, 0, 0};
   bool mj_ready = false;
-  sty_train_opts topts = {0, 0, 0, 0, 0.1f};  // train-mode behaviour of the *_fwd_train entry points
+  sty_train_opts topts = {0, 0, 0, 0, 0.1f, 0u, 0.2f};  // train-mode behaviour of the *_fwd_train entry points
   struct sty::Trainer* trainer = nullptr;
 };
 
@@ -274,6 +274,8 @@ int launch_bn_train_fwd(const float* x, const float* w, const float* b, float* r
                         int B, int C, int T, float* y, float* mean, float* rstd, double* part, hipStream_t st);
 int launch_bn_train_bwd(const float* x, const float* dy, const float* w, const float* mean, const float* rstd, int B,
                         int C, int T, float* dx, int accumulate, float* dw, float* db, float* sums, hipStream_t st);
+int launch_dropout(const float* x, const float* res, size_t n, float p, unsigned seed, unsigned site, float* y,
+                   int accumulate, hipStream_t st);
 int launch_box_smooth(const float* x, int B, int T, int width, float* y, int accumulate, hipStream_t st);
 int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st);
 int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,

@@ -197,11 +197,26 @@ struct AttnArgs {
   int T, H;
   float scale;
   const int64_t* lengths;  // optional [B]: additive -1e4 where query or key index >= length
+  // dropout on the attention probabilities (SDPA dropout_p, text_encoder.py:270-276): keep = hash_u(seed, site,
+  // ((b*H + h)*T + i)*T + j) >= p, kept entries scaled by 1/(1-p); p = 0: off
+  float drop_p = 0.f;
+  unsigned drop_seed = 0, drop_site = 0;
 };
 }  // namespace sty
 
 #ifdef __HIPCC__
 namespace sty {
+// Counter-based uniform in [0,1) with 24 bits for dropout masks (oracle/blocks.py hash_uniform is the same function):
+// lowbias32(idx * 0x9E3779B1 + site * 0x85EBCA77 + seed * 0xC2B2AE3D) >> 8.  Forward and backward recompute it.
+__device__ __forceinline__ float sty_hash_u(unsigned seed, unsigned site, unsigned idx) {
+  unsigned x = idx * 0x9E3779B1u + site * 0x85EBCA77u + seed * 0xC2B2AE3Du;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
 // sin(x) to ~1 ulp for |x| <= 8192 (3-constant Cody-Waite reduction by pi/2 + cephes minimax polynomials, ~20 VALU);
 // beyond that the library sinf (Payne-Hanek).  The Snake activations evaluate this 256x per 75T-rate position
 // per ConvNeXt block, where ocml's sinf with its huge-argument path costs about 3x more.

@@ -221,6 +221,37 @@ struct Trainer {
     return y;
   }
 
+  // nn.Dropout(p) with the counter-based hash mask (sty_hash_u), optionally fused with a residual add:
+  // y = drop(x) (+ residual).  Sites are numbered in execution order; the backward recomputes the mask.
+  unsigned drop_site = 0;
+  bool dropout_on() const { return m->topts.dropout_seed != 0; }
+  float* dropout(const float* x, float p, int C, int Tt, const float* residual) {
+    const size_t n = (size_t)B * C * Tt;
+    float* y = take<float>(n);
+    const unsigned seed = m->topts.dropout_seed, site = drop_site++;
+    if (live()) chk(launch_dropout(x, residual, n, p, seed, site, y, 0, st));
+    tape.push_back([=]() {
+      float* gY = G(y, n);
+      if (residual && wants(residual)) {
+        if (!gmap.count(residual)) {
+          gmap[residual] = gY;  // first writer: the output gradient becomes the residual's gradient buffer
+        } else {
+          float* gR = G(residual, n);
+          if (live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, 1, (int)n, gR, st));
+        }
+      }
+      int acc = 1;
+      float* gX = Gw(x, n, acc);
+      if (gX == gY) {  // cannot happen (x != residual), kept as a guard against in-place masking of a shared buffer
+        set_error("dropout backward: aliased gradient buffers");
+        rc = STY_ESTATE;
+        return;
+      }
+      if (live()) chk(launch_dropout(gY, nullptr, n, p, seed, site, gX, acc, st));
+    });
+    return y;
+  }
+
   // LayerNorm over channels; ada: (1+gamma, beta) from fc(style) [fc], else affine (w, bvec)
   float* layernorm(const float* x, int C, int Tt, float eps, const AdaFc* fc, const float* w, const float* bvec,
                    int relu = 0, const float* omask = nullptr) {
@@ -399,6 +430,11 @@ struct Trainer {
     at.H = 8;
     at.scale = 1.0f / sqrtf((float)(Hd / 8));
     at.lengths = lengths;
+    if (dropout_on() && m->topts.text_dropout > 0.f) {  // SDPA dropout_p on the attention probabilities
+      at.drop_p = m->topts.text_dropout;
+      at.drop_seed = m->topts.dropout_seed;
+      at.drop_site = drop_site++;
+    }
     if (live()) chk(launch_attention(at, B, Hd / 8, st));
     tape.push_back([=]() {
       float* gO = G(o, n);
@@ -442,6 +478,7 @@ struct Trainer {
       a.mask = mask;
       conv(a);
       h = layernorm(h1, H, L, 1e-4f, nullptr, t.pre_g[i], t.pre_b[i], 1, nullptr);
+      if (dropout_on()) h = dropout(h, 0.5f, H, L, nullptr);  // ConvReluNorm p_dropout (text_encoder.py:63, :418)
     }
     float* x = take<float>(n);
     ConvArgs pj = base(t.proj, h, L, x);
@@ -488,10 +525,17 @@ struct Trainer {
         });
       }
       float* o = attention3(qr, kr, v, H, L, lengths);
+      const float pd = m->topts.text_dropout;
+      const bool dr = dropout_on() && pd > 0.f;
       float* h1 = take<float>(n);
       ConvArgs ao = base(l.o, o, L, h1);
-      ao.residual = x;
-      conv(ao);
+      if (dr) {  // x + drop(conv_o(o))  (text_encoder.py:386-388)
+        conv(ao);
+        h1 = dropout(h1, pd, H, L, x);
+      } else {
+        ao.residual = x;
+        conv(ao);
+      }
       float* x1 = layernorm(h1, H, L, 1e-4f, nullptr, l.n1g, l.n1b);
       const int Fc = l.f1.Cout;
       float* f0 = take<float>((size_t)B * Fc * L);
@@ -500,13 +544,19 @@ struct Trainer {
       f1.mask = mask;
       conv(f1);
       float* fr = act(ACT_RELU, f0, nullptr, Fc, L);
+      if (dr) fr = dropout(fr, pd, Fc, L, nullptr);  // FFN.drop after the ReLU (text_encoder.py:326-328)
       float* h2 = take<float>(n);
       ConvArgs f2 = base(l.f2, fr, L, h2);
       f2.pro = PRO_MASK;
       f2.mask = mask;
       f2.out_mask = mask;
-      f2.residual = x1;
-      conv(f2);
+      if (dr) {  // x1 + drop(conv_2(.) * mask)  (text_encoder.py:389-392)
+        conv(f2);
+        h2 = dropout(h2, pd, H, L, x1);
+      } else {
+        f2.residual = x1;
+        conv(f2);
+      }
       x = layernorm(h2, H, L, 1e-4f, nullptr, l.n2g, l.n2b, 0, mask);
     }
     float* mu = take<float>((size_t)B * t.proj_m.Cout * L);
@@ -925,6 +975,7 @@ struct Trainer {
 
   void begin(const float* style_in) {
     style = style_in;
+    drop_site = 0;
     tape.clear();
     gmap.clear();
     nograd.clear();

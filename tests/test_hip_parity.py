@@ -760,3 +760,31 @@ def test_style_encoder_train_mode_vs_reference_golden():
         rep.add(k + ".weight_v", sd[k + ".weight_v"], gold[k + ".weight_v"], 1e-5)
         rep.add("d " + k + ".weight_orig", _sub(named[k + ".weight_orig"].grad), gold["grad." + k + ".weight_orig"], 1e-3)
     rep.done()
+
+
+def test_speech_predictor_dropout_vs_patched_reference_golden(env):
+    """Dropout on the HIP path (counter-based hash masks in the TextEncoder: prenet, attention probabilities inside the
+    MFMA attention kernel and its backward, post-attention, FFN) vs the REFERENCE run in .train() with F.dropout / SDPA
+    patched to the same mask function (tests/golden/sp_train_dropout_small.safetensors)."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    gold = load_file(os.path.join(G, "sp_train_dropout_small.safetensors"))
+    cs, ali = env["cs"], env["ali"]
+    P = {k: v.clone() for k, v in env["P"].items()}
+    m = S.SpeechPredictor()
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).enable_training().set_train_opts(bn_batch_stats=True, f0_smooth=15, energy_smooth=0,
+                                                   dropout_seed=1234, text_dropout=0.2)
+    audio = m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(ali), dev(cs["pitch"]), dev(cs["energy"]),
+                            dev(env["voiced"]), dev(cs["style"]), dev(cs["pitch"]), noise=dev(cs["noise"]))
+    d_style, _ = m.backward(torch.sign(audio) / audio.numel(), want_energy=False)
+    torch.cuda.synchronize()
+    mse = ((audio.cpu() - gold["audio"]) ** 2).mean().item()
+    print(f"\n  dropout forward vs patched reference: mse {mse:.3e}")
+    assert mse <= 1e-8
+    rep = Report()
+    rep.add("d_style", d_style, gold["grad.style"], 3e-2)
+    named = dict(m.named_parameters())
+    for k in [k[len("grad."):] for k in gold if k.startswith("grad.") and k != "grad.style"]:
+        rep.add("d " + k[-44:], _sub(named[k].grad), gold["grad." + k], 3e-2)
+    rep.done()
