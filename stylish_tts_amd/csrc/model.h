@@ -236,7 +236,7 @@ int launch_istft64_bwd(int B, int F, const float* audio, const float* daudio, co
                        float* dimag, hipStream_t st);
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T);
 int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask, float scale, float* gwp,
-                        float* partial, hipStream_t st);
+                        float* partial, float* gbias, bool* bias_done, hipStream_t st);
 int launch_pack_dgrad(const float* wp, int K, int CinP, int CoutP, float* wd, hipStream_t st);
 int launch_b2eff_bwd(const float* g, const float* w2, const float* beta, int C, float* db2, float* dbeta, float* dW2,
                      hipStream_t st);

@@ -134,10 +134,12 @@ struct Trainer {
     float* dal = nullptr;
     if (any) {
       if (f.pro == PRO_AFFINE_SNAKE || f.pro == PRO_AFFINE_LRELU || f.pro == PRO_AFFINE) {
-        dpa = G(f.pa, (size_t)B * w.Cin);
-        dps = G(f.ps, (size_t)B * w.Cin);
+        int dummy;  // pro_bwd OVERWRITES these per-(b,c) sums (each folded affine feeds exactly one conv): no zero-fill
+        dpa = Gw(f.pa, (size_t)B * w.Cin, dummy);
+        dps = Gw(f.ps, (size_t)B * w.Cin, dummy);
       } else if (f.pro == PRO_SCALE) {
-        dpa = G(f.pa, (size_t)B * w.Cin);
+        int dummy;
+        dpa = Gw(f.pa, (size_t)B * w.Cin, dummy);
       }
       if (f.pro == PRO_AFFINE_SNAKE) dal = PG(f.palpha, w.Cin);
     }
@@ -151,12 +153,16 @@ struct Trainer {
       else
         chk(launch_row_scale_add(gY, nullptr, 1.0f, B * w.Cout, Tt, gR, st));
     }
-    if (w.bias) {
+    // weight gradient; the bias gradient is a by-product of the same pass over gY for K <= 12
+    float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
+    bool bias_done = false;
+    if (live())
+      chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, w.bias ? PGpacked(w.bias) : nullptr,
+                              &bias_done, st));
+    if (w.bias && !bias_done) {
       float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, Tt));
       if (live()) chk(launch_bias_grad(gY, gmask, B, w.Cout, Tt, f.shuffle, f.out_scale, PGpacked(w.bias), bs, st));
     }
-    float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
-    if (live()) chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, st));
     if (any) {
       auto it = m->dgrad.find(w.wp);
       if (it == m->dgrad.end()) {
@@ -810,12 +816,15 @@ struct Trainer {
     if (gR && live())
       chk(launch_pro_bwd(PRO_MASK, gY, w.Cout, 0, gY, B, w.Cout, n, nullptr, nullptr, w.Cout, 0, nullptr, f.out_mask,
                          gR, 1, nullptr, nullptr, nullptr, st));
-    if (w.bias) {
+    float* partial = take<float>(wgrad_partial_floats(w, B, n));
+    bool bias_done = false;
+    if (live())
+      chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, PGpacked(w.wp), partial,
+                              w.bias ? PGpacked(w.bias) : nullptr, &bias_done, st));
+    if (w.bias && !bias_done) {
       float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, n));
       if (live()) chk(launch_bias_grad(gY, f.out_mask, B, w.Cout, n, 0, f.out_scale, PGpacked(w.bias), bs, st));
     }
-    float* partial = take<float>(wgrad_partial_floats(w, B, n));
-    if (live()) chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, PGpacked(w.wp), partial, st));
     if (gX) {
       auto it = m->dgrad.find(w.wp);
       if (it == m->dgrad.end()) {

@@ -17,7 +17,7 @@ constexpr int WG_TARGET = 1024;  // workgroups per launch aimed at (4 per CU): t
 
 template <int KT>  // taps per wave (K <= 4*KT), KT == 0: K == 1, waves split the chunk in time
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, int want_bias) {
   // ax: the forward conv's input side (sources, prologue, pad, dil, weight dims); ag: the output-gradient side
   //     (x[0] = G, optional mask / in_shuffle), K = 1, pad = 0.
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   for (int i = 0; i < NACC; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // fused bias gradient (KT <= 3 staging keeps the G rows in registers): ci-tile-0 workgroups sum them over time
+  const bool do_bias = want_bias && blockIdx.x == 0 && KT >= 1 && KT <= 3;
+  float bsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   const int HM = ax.H ? ax.H : 1;  // 2-D mode: one chunk list per (b, output row h)
   const int total = ax.B * HM * chunks_per_b;
   constexpr int MAXJ = (WG_TW + 128 + 1 + 63) / 64;
@@ -81,6 +84,15 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
         stage_store<PRO_MASK, 4, MAXJG>(ag, gs, co0, b, t0, LWg, wave, lane, Rg, mk);
       else
         stage_store<PRO_NONE, 4, MAXJG>(ag, gs, co0, b, t0, LWg, wave, lane, Rg);
+      if (do_bias) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < MAXJG; ++q)
+              if (lane + 64 * q < WG_TW) bsum[it][u] = fmaf(Rg.vv[it][u][q], ag.pro == PRO_MASK ? mk[q] : 1.f, bsum[it][u]);
+      }
       __syncthreads();
     } else {
       __syncthreads();
@@ -135,15 +147,28 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   // partial layout: [slice][k][ci (CinP)][co (CoutP)], slice = split (K > 1) or split*4 + wave (K == 1)
   const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;
   const size_t plane = (size_t)K * CinP * CoutP;
+  const size_t stride = plane + CoutP;
+  if (do_bias) {
+    float* pb = partial + (size_t)split * stride + plane;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float v = bsum[it][u];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const int co = co0 + wave + 8 * it + 4 * u;  // staged row of this wave (conv_stage.h)
+        if (lane == 0 && co < CoutP) pb[co] = v;
+      }
+  }
   if constexpr (KT == 0) {
-    float* p = partial + ((size_t)split * 4 + wave) * plane;
+    float* p = partial + ((size_t)split * 4 + wave) * stride;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       p[(size_t)(ci0 + l31) * CoutP + co] = acc[0][r];
     }
   } else {
-    float* p = partial + (size_t)split * plane;
+    float* p = partial + (size_t)split * stride;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       const int k = wave + 4 * kt;
@@ -189,7 +214,7 @@ __device__ __forceinline__ void w1_store(const ConvArgs& a, float* __restrict__ 
 }
 template <int WI, int WO, int MI, int MO>
 __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, int want_bias) {
   constexpr int TI = 32 * WI * MI, TO = 32 * WO * MO, LW = W1_TW + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;
@@ -207,6 +232,11 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][mo][r] = 0.f;
+  // fused bias gradient: the ci-tile-0 workgroups also sum their G rows over time (rows wave, wave+4, ... per wave)
+  const bool do_bias = want_bias && blockIdx.x == 0;
+  float bsum[TO / 4];
+#pragma unroll
+  for (int i = 0; i < TO / 4; ++i) bsum[i] = 0.f;
   const int total = ax.B * chunks_per_b;
   for (int ch = split; ch < total; ch += nsplit) {
     const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * W1_TW;
@@ -228,6 +258,10 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     float mk = 1.f, mkx = 1.f;
     if (ag.pro == PRO_MASK) mk = t0 + lane < T ? ag.mask[(size_t)b * T + t0 + lane] : 0.f;
     if (ax.pro == PRO_MASK) mkx = t0 + lane < T ? ax.mask[(size_t)b * T + t0 + lane] : 0.f;
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < TO / 4; ++i) bsum[i] = fmaf(vg[i], mk, bsum[i]);  // rows past Cout / columns past T load 0
+    }
     __syncthreads();
     switch (ax.pro) {
       case PRO_AFFINE: w1_store<PRO_AFFINE, TI>(ax, xs, ci0, b, t0, wave, lane, vx, 1.f); break;
@@ -257,7 +291,18 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     }
   }
   const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;
-  float* p = partial + (size_t)split * CinP * CoutP;
+  const size_t stride = (size_t)CinP * CoutP + CoutP;
+  float* p = partial + (size_t)split * stride;
+  if (do_bias) {
+    float* pb = p + (size_t)CinP * CoutP;
+#pragma unroll
+    for (int i = 0; i < TO / 4; ++i) {
+      float v = bsum[i];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      const int co = co0 + wave + 4 * i;
+      if (lane == 0 && co < CoutP) pb[co] = v;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int ci = ci0 + (wi * MI + mi) * 32 + l31;
@@ -289,47 +334,70 @@ static int w1_nsplit(const PackedConv& w, int B, int T, W1Cfg c) {
   return nsplit;
 }
 
-__global__ void wgrad_reduce_small_kernel(const float* __restrict__ partial, int nslices, size_t plane, float scale,
-                                          float* __restrict__ gwp) {
+// Slices are `stride` floats apart: [plane weight partials][nb bias partials (fused bias gradient, or unused)].
+// Element i < plane accumulates into gwp, plane <= i < plane + nb into gbias.
+__global__ void wgrad_reduce_small_kernel(const float* __restrict__ partial, int nslices, size_t plane, size_t stride,
+                                          int nb, float scale, float* __restrict__ gwp, float* __restrict__ gbias) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= plane) return;
+  if (i >= plane + nb) return;
   float s = 0.f;
-  for (int k = 0; k < nslices; ++k) s += partial[(size_t)k * plane + i];
-  gwp[i] += s * scale;
+  for (int k = 0; k < nslices; ++k) s += partial[(size_t)k * stride + i];
+  if (i < plane)
+    gwp[i] += s * scale;
+  else
+    gbias[i - plane] += s * scale;
 }
 // 16 plane elements x 16 slice groups per workgroup, combined through LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nslices, size_t plane,
-                                                           float scale, float* __restrict__ gwp) {
+                                                           size_t stride, int nb, float scale, float* __restrict__ gwp,
+                                                           float* __restrict__ gbias) {
   __shared__ float red[16][17];
   const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
   const size_t i = (size_t)blockIdx.x * 16 + e;
+  const size_t n = plane + nb;
   float s = 0.f;
-  if (i < plane)
-    for (int k = sg; k < nslices; k += 16) s += partial[(size_t)k * plane + i];
+  if (i < n)
+    for (int k = sg; k < nslices; k += 16) s += partial[(size_t)k * stride + i];
   red[sg][e] = s;
   __syncthreads();
-  if (sg == 0 && i < plane) {
+  if (sg == 0 && i < n) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][e];
-    gwp[i] += t * scale;
+    if (i < plane)
+      gwp[i] += t * scale;
+    else
+      gbias[i - plane] += t * scale;
   }
+}
+static void launch_wgrad_reduce(const float* partial, int nslices, size_t plane, size_t stride, int nb, float scale,
+                                float* gwp, float* gbias, hipStream_t st) {
+  const size_t n = plane + nb;
+  if (nslices >= 16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, partial, nslices, plane,
+                       stride, nb, scale, gwp, gbias);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, nslices,
+                       plane, stride, nb, scale, gwp, gbias);
 }
 
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x output rows in 2-D mode
-  if (w.K == 1) return (size_t)w1_nsplit(w, B, T, w1_cfg(w, B, T)) * w.CinP * w.CoutP;
+  if (w.K == 1) return (size_t)w1_nsplit(w, B, T, w1_cfg(w, B, T)) * ((size_t)w.CinP * w.CoutP + w.CoutP);
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks = B * cdiv(T, WG_TW);
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);  // few tiles: keep the partial planes small
   if (nsplit > chunks) nsplit = chunks;
   const int slices = w.K == 1 ? nsplit * 4 : nsplit;
-  return (size_t)slices * w.K * w.CinP * w.CoutP;
+  return (size_t)slices * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
 }
 
 // ax: forward ConvArgs (sources, prologue, dil, pad, w); g: output gradient [B][Cout][T] (shuffled when ax.shuffle > 1);
 // gmask: optional [B][T] multiplier of g; scale: constant factor (the forward out_scale); gwp += result.
+// gbias: packed bias gradient (+=) or nullptr; *bias_done tells the caller whether this launch produced it (K == 1 and
+// K <= 12 do; the others need launch_bias_grad)
 int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask, float scale, float* gwp,
-                        float* partial, hipStream_t st) {
+                        float* partial, float* gbias, bool* bias_done, hipStream_t st) {
+  if (bias_done) *bias_done = false;
   const PackedConv& w = fwd.w;
   ConvArgs ax = fwd;
   ax.pad = fwd.pad;  // staging start t0 - pad
@@ -376,21 +444,18 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       raised = true;
     }
+    const int wb = gbias != nullptr;
     if (c.TI == 128 && c.TO == 128)
-      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 2, 2>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 2, 2>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
     else if (c.TI == 32)
-      hipLaunchKernelGGL((wgrad_k1_kernel<1, 4, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+      hipLaunchKernelGGL((wgrad_k1_kernel<1, 4, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
     else if (c.TO == 32)
-      hipLaunchKernelGGL((wgrad_k1_kernel<4, 1, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+      hipLaunchKernelGGL((wgrad_k1_kernel<4, 1, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
     else
-      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial);
+      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
     const size_t plane = (size_t)w.CinP * w.CoutP;
-    if (nsplit >= 16)
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((plane + 15) / 16)), dim3(256), 0, st, partial, nsplit,
-                         plane, scale, gwp);
-    else
-      hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, partial,
-                         nsplit, plane, scale, gwp);
+    launch_wgrad_reduce(partial, nsplit, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+    if (bias_done) *bias_done = wb != 0;
     STY_LAUNCH_CHECK();
     return STY_OK;
   }
@@ -414,12 +479,13 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   snprintf(fam, sizeof(fam), "conv1d_wgrad_kernel<%d>", w.K == 1 ? 0 : (cdiv(w.K, 4) <= 3 ? cdiv(w.K, 4) : 6));
   ProfScope prof(fam, flops * HM, bytes * HM, st, detail);
   const int KT = w.K == 1 ? 0 : cdiv(w.K, 4);
+  const int wb = (gbias != nullptr && KT >= 1 && KT <= 3 && !fwd.H) ? 1 : 0;
   if (fwd.flatW && KT > 3) {
     set_error("wgrad: flat 2-D mode is built for K <= 12");
     return STY_EINVAL;
   }
 #define STY_WG(KTV)                                                                                              \
-  hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, partial)
+  hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, partial, wb)
   switch (KT) {
     case 0: STY_WG(0); break;
     case 1: STY_WG(1); break;
@@ -437,12 +503,8 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
 #undef STY_WG
   const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
   const int slices = w.K == 1 ? nsplit * 4 : nsplit;
-  if (slices >= 16)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((plane + 15) / 16)), dim3(256), 0, st, partial, slices,
-                       plane, scale, gwp);
-  else
-    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, partial,
-                       slices, plane, scale, gwp);
+  launch_wgrad_reduce(partial, slices, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+  if (bias_done) *bias_done = wb != 0;
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
