@@ -76,6 +76,7 @@ class AcousticTrainer:
         self._rng = random.Random(seed)  # the Decoder's smoothing draws (decoder.py:55-57)
         self.sp, self.se = speech_predictor.enable_training(), style_encoder.enable_training()
         self.w_mel, self.w_phase, self.mean, self.std = w_mel, w_phase, mean, std
+        self.base_lr = lr
         kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, bucket_bytes=bucket_bytes)
         # one optimizer per model key, as train/optimizers.py:106-118 builds them
         self.opt = {"speech_predictor": FlatAdamW(list(self.sp.parameters()), **kw),
@@ -113,3 +114,9 @@ class AcousticTrainer:
             o.step()
         self.audio = audio
         return losses
+
+    def schedule(self, step, step_limit):
+        """Stage.steps / MultiOptimizer.scheduler (train/optimizers.py:96-104): cosine schedule with a 90 % plateau."""
+        from .optim import scheduled_lr
+        for o in self.opt.values():
+            o.lr = scheduled_lr(self.base_lr, step, step_limit)

@@ -39,3 +39,17 @@ class FlatAdamW:
             st = C.c_void_p(torch.cuda.current_stream(gflat.device).cuda_stream)
             L.check(lib.sty_adamw_step(gflat.numel(), L.ptr(p), L.ptr(gflat), L.ptr(m), L.ptr(v), self.lr,
                                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, st))
+
+
+LOGICAL_STEP_LIMIT = 10000  # train/optimizers.py:11
+
+
+def scheduled_lr(base_lr, step, step_limit, plateau=0.9):
+    """MultiOptimizer.scheduler (train/optimizers.py:96-104) around transformers.get_cosine_schedule_with_warmup with
+    no warm-up and 10 000 logical steps (optimizers.py:119-123): the stage's progress is mapped to a logical step that
+    saturates at 90 %; the reference sets scheduler.last_epoch = logical and then calls scheduler.step(), which advances
+    to logical + 1 before the cosine is evaluated: lr = base * max(0, 0.5 (1 + cos(pi * (logical + 1) / 10000)))."""
+    import math
+    logical = min(step * LOGICAL_STEP_LIMIT // step_limit, LOGICAL_STEP_LIMIT * plateau) + 1
+    progress = float(logical) / float(max(1, LOGICAL_STEP_LIMIT))
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))

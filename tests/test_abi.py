@@ -73,3 +73,21 @@ def test_forward_refuses_autograd_and_cpu():
     x = torch.zeros(1, 128, 8)
     with pytest.raises(S.StyError):
         sp.vocoder_forward(mel=x, style=torch.zeros(1, 64), pitch=torch.zeros(1, 8), voiced=torch.zeros(1, 8))
+
+
+def test_lr_schedule_matches_transformers_cosine():
+    """optim.scheduled_lr vs the reference's scheduler: transformers.get_cosine_schedule_with_warmup(opt, 0, 10000) with
+    last_epoch set to the logical step (train/optimizers.py:96-104, 119-123)."""
+    import torch
+    import transformers
+    from stylish_tts_amd.optim import scheduled_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=3e-4)
+    sch = transformers.get_cosine_schedule_with_warmup(opt, num_warmup_steps=0, num_training_steps=10000)
+    step_limit = 777
+    for step in (0, 1, 100, 388, 700, 776, 777, 5000):
+        logical = min(step * 10000 // step_limit, 10000 * 0.9)
+        sch.last_epoch = logical
+        sch.step()  # as MultiOptimizer.scheduler does: sets last_epoch, then steps
+        want = opt.param_groups[0]["lr"]
+        assert abs(scheduled_lr(3e-4, step, step_limit) - want) <= 1e-12, (step, want)
