@@ -5,6 +5,7 @@ end-to-end audio: the north-star gates (waveform MSE <= 1e-8, mel-L1 <= 1e-3) pl
 """
 import ctypes as C
 import os
+import sys
 
 import pytest
 import torch
@@ -788,3 +789,30 @@ def test_speech_predictor_dropout_vs_patched_reference_golden(env):
     for k in [k[len("grad."):] for k in gold if k.startswith("grad.") and k != "grad.style"]:
         rep.add("d " + k[-44:], _sub(named[k].grad), gold["grad." + k], 3e-2)
     rep.done()
+
+
+def test_training_from_sample_dataset_files(tmp_path, env):
+    """N2 + A0: a dataset in the reference's sample_dataset layout (wav-dir, training-list, pitch / alignment safetensors)
+    goes through the loader counterparts (stylish_tts_amd.data) into train_acoustic steps on the HIP path."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_sample_dataset import make
+    from stylish_tts_amd import data as D
+    root = str(tmp_path)
+    make(root, 12, 7)
+    lines = open(os.path.join(root, "training-list.txt"), encoding="utf-8").read().splitlines()
+    ds = D.SampleDataset(data_list=lines, root_path=os.path.join(root, "wav-dir"),
+                         pitch_path=os.path.join(root, "pitch.safetensors"),
+                         alignment_path=os.path.join(root, "alignment.safetensors"))
+    bins, _ = ds.time_bins()
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=D.LengthBinSampler(bins, lambda k: 4),
+                                         collate_fn=D.Collater(stage="acoustic", hop_length=300))
+    tr, _, _ = _train_setup(env, 1e-4, train_mode=True)
+    seen = 0
+    for batch in loader:
+        kw = D.to_step_inputs(batch, DEV)
+        losses = tr.train_batch(**kw)
+        assert bool(torch.isfinite(losses).all()), losses
+        assert tr.audio.shape == (kw["audio_gt"].shape[0], 1, kw["audio_gt"].shape[1])
+        seen += kw["audio_gt"].shape[0]
+    torch.cuda.synchronize()
+    assert seen == len(lines)
