@@ -164,15 +164,4 @@ int launch_rope_signed(float* q, float* k, int B, int H, int DH, int L, int d, c
 int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st) {
   return launch_rope_signed(q, k, B, H, DH, L, d, theta4, 1.0f, st);
 }
-int launch_rope_unused(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st) {
-  if (d != 8) {
-    set_error("rope: only d == 8 built");
-    return STY_EINVAL;
-  }
-  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d, theta4[0], theta4[1],
-                     theta4[2], theta4[3], 1.0f);
-  STY_LAUNCH_CHECK();
-  return STY_OK;
-}
-
 }  // namespace sty

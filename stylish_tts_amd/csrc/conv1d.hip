@@ -50,9 +50,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: descriptors stay in SGPRs
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = a.H ? blockIdx.z / a.H : blockIdx.z;
-  const int h = a.H ? blockIdx.z % a.H : 0;
-  const int HM = a.H ? a.H : 1;  // rows per (b, channel) plane of the output
+  const int b = blockIdx.z;
+  const int h = 0;
   const int t0 = blockIdx.x * TT_BLK;
   const int co0 = blockIdx.y * CO_BLK + wm * (32 * MT);
   const int T = a.T;
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         float x = acc[m][n][r] * om_pre;
-        if (a.residual && co < Cout && tin) x += a.residual[(((size_t)b * Cout + co) * HM + h) * T + t];
+        if (a.residual && co < Cout && tin) x += a.residual[((size_t)b * Cout + co) * T + t];
         v[r] = x;
       }
       if (a.ln_out) {  // LayerNorm over the 32 output channels of this column (Cout == 32, MT == 1)
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (co < Cout) a.y[(((size_t)b * Cout + co) * HM + h) * T + t] = v[r] * om;
+            if (co < Cout) a.y[((size_t)b * Cout + co) * T + t] = v[r] * om;
           }
         } else {
           const int s = a.shuffle;
@@ -328,13 +327,11 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     set_error("conv1d: CoutP %d not a multiple of block tile %d", a.w.CoutP, CO_BLK);
     return STY_EINVAL;
   }
-  const int HM = a.H ? a.H : 1;
-  dim3 grid(cdiv(a.T, TT_BLK), a.w.CoutP / CO_BLK, a.B * HM);
+  dim3 grid(cdiv(a.T, TT_BLK), a.w.CoutP / CO_BLK, a.B);
   // algorithmic work: 2*Cin*K flops per output element; input + output (+ residual) once, weights once
-  const double outs = (double)a.B * a.w.Cout * a.T * HM;
+  const double outs = (double)a.B * a.w.Cout * a.T;
   const double flops = 2.0 * a.w.Cin * a.w.K * outs;
-  const double in_elems = a.H ? (double)a.B * a.Cin2d * a.Hin * (a.Tin ? a.Tin : a.T)
-                                : (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
+  const double in_elems = (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
   const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
   char fam[48];  // the kernel's own name, as rocprofv3 prints it (minus spaces)
   snprintf(fam, sizeof(fam), "conv1d_mfma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
@@ -349,7 +346,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   int cin = 0;
   for (int i = 0; i < a.nsrc; ++i) cin += a.xc[i];
-  if (a.H || a.flatW) cin = a.w.Cin;  // 2-D mode: Cin of the packed weight = kh * Cin2d, checked by the caller
+  if (a.flatW) cin = a.w.Cin;  // 2-D mode: Cin of the packed weight = kh * Cin2d, checked by the caller
   if (cin != a.w.Cin) {
     set_error("conv1d: input channels %d != weight Cin %d", cin, a.w.Cin);
     return STY_ESHAPE;

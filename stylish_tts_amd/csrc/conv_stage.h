@@ -32,7 +32,7 @@ __device__ __forceinline__ float pro_apply(float v, float pa, float ps, float al
 // version, most of them the generic source selection):
 //   ST_SIMPLE  one plain source [B][Cin][T]                      row = xb + ci*T
 //   ST_FLAT    flat 2-D image, reduction row (kh, ci)            row = xb + cc*T shifted by (kh - hpad)*flatW
-//   ST_GENERIC up to 3 concatenated sources, pixel-shuffled source, row-mode 2-D
+//   ST_GENERIC up to 3 concatenated sources, pixel-shuffled source
 enum StageMode : int { ST_SIMPLE = 0, ST_FLAT = 1, ST_GENERIC = 2 };
 
 struct StageRow {
@@ -61,12 +61,6 @@ __device__ __forceinline__ StageRow stage_row(const ConvArgs& a, const float* xb
     r.tsh = (kh - a.hpad) * a.flatW;
     r.src = xb + (unsigned)(cc * T);
     r.bytes = r.live ? (unsigned)T * 4u : 0u;
-  } else if (r.live && a.H) {  // 2-D row mode: reduction index = (kh, ci)
-    const int kh = ci / a.Cin2d, cc = ci - kh * a.Cin2d;
-    const int hin = h + kh - a.hpad;
-    r.live = hin >= 0 && hin < a.Hin;
-    r.src = a.x[0] + (((size_t)b * a.Cin2d + cc) * a.Hin + (r.live ? hin : 0)) * T;
-    r.bytes = r.live ? (unsigned)T * 4u : 0u;
   } else if (r.live) {
     int cl = ci, csz;
     const float* sp;
@@ -94,7 +88,7 @@ __device__ __forceinline__ StageRow stage_row(const ConvArgs& a, const float* xb
 }
 __device__ __forceinline__ int stage_mode(const ConvArgs& a) {
   if (a.flatW) return ST_FLAT;
-  if (a.nsrc == 1 && a.in_shuffle <= 1 && !a.H) return ST_SIMPLE;
+  if (a.nsrc == 1 && a.in_shuffle <= 1) return ST_SIMPLE;
   return ST_GENERIC;
 }
 __device__ __forceinline__ const float* stage_base(const ConvArgs& a, int b) {

@@ -71,11 +71,10 @@ struct ConvArgs {
   int B = 0, T = 0;       // T = output length (time / image width)
   int Tin = 0;            // input length; 0 = same as T ('same' padding)
   int dil = 1, pad = 0;
-  // 2-D mode (Conv2d on [B,C,H,W] as one 1-D conv per output row): the packed reduction "channel" index is
-  // (kh, ci) with ci fastest, input row = h + kh - hpad; grid z = B * H.  Single source only.
-  int H = 0, Hin = 0, hpad = 0, Cin2d = 0;
-  // flat 2-D mode (conv2d.hip, "padded-flat image layout"): x and y are [B][C][T] with T = H*flatW flattened image
-  // positions; reduction index (kh, ci) reads x shifted by (kh - hpad)*flatW.  H stays 0 (grid z = B).
+  // 2-D convs run in the flat mode (conv2d.hip, "padded-flat image layout"): x and y are [B][C][T] with T = H*flatW
+  // flattened image positions, the packed reduction "channel" index is (kh, ci) with ci fastest (Cin2d real channels),
+  // and row kh reads x shifted by (kh - hpad)*flatW.  flatW == 0: plain 1-D conv.
+  int hpad = 0, Cin2d = 0;
   int flatW = 0;
   int in_shuffle = 0;     // > 1: source 0 is stored pixel-shuffled [B][C/s][T*s] (backward of a shuffled store)
   PackedConv w;

@@ -15,7 +15,7 @@ namespace sty {
 constexpr int WG_TW = 128;      // time samples per chunk
 constexpr int WG_TARGET = 1024;  // workgroups per launch aimed at (4 per CU): the (batch, time) list is split to get there
 
-template <int KT>  // taps per wave (K <= 4*KT), KT == 0: K == 1, waves split the chunk in time
+template <int KT>  // taps per wave (K <= 4*KT); K == 1 runs on wgrad_k1_kernel below
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                            float* __restrict__ partial, int want_bias) {
   // ax: the forward conv's input side (sources, prologue, pad, dil, weight dims); ag: the output-gradient side
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   float* xs = lds;
   float* gs = lds + CI_CHUNK * LWx;
   const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, split = blockIdx.z;
-  constexpr int NACC = KT == 0 ? 1 : KT;
+  constexpr int NACC = KT;
   f32x16 acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i)
@@ -38,12 +38,10 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   // fused bias gradient (KT <= 3 staging keeps the G rows in registers): ci-tile-0 workgroups sum them over time
   const bool do_bias = want_bias && blockIdx.x == 0 && KT >= 1 && KT <= 3;
   float bsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-  const int HM = ax.H ? ax.H : 1;  // 2-D mode: one chunk list per (b, output row h)
-  const int total = ax.B * HM * chunks_per_b;
+  const int total = ax.B * chunks_per_b;
   constexpr int MAXJ = (WG_TW + 128 + 1 + 63) / 64;
   for (int ch = split; ch < total; ch += nsplit) {
-    const int bh = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
-    const int b = bh / HM, h = bh % HM;
+    const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW, h = 0;
     const int xmode = stage_mode(ax), gmode = stage_mode(ag);
     const float* xb = stage_base(ax, b);
     const float* gb = stage_base(ag, b);
@@ -119,16 +117,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
         stage_chunk<PRO_NONE, 4, MAXJ, ST_GENERIC, WG_TW, false>(ag, gb, gs, co0, b, h, t0, LWg, wave, lane);
       __syncthreads();
     }
-    if constexpr (KT == 0) {
-      // K == 1: each wave reduces its quarter of the chunk
-      const int q0 = wave * (WG_TW / 8);
-#pragma unroll
-      for (int q = 0; q < WG_TW / 8; ++q) {
-        const float av = gs[l31 * LWg + 2 * (q0 + q) + hi];
-        const float bv = xs[l31 * LWx + 2 * (q0 + q) + hi];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
-      }
-    } else {
+    {
       float af[WG_TW / 2];
 #pragma unroll
       for (int q = 0; q < WG_TW / 2; ++q) af[q] = gs[l31 * LWg + 2 * q + hi];
@@ -144,7 +133,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
       }
     }
   }
-  // partial layout: [slice][k][ci (CinP)][co (CoutP)], slice = split (K > 1) or split*4 + wave (K == 1)
+  // partial layout: [split][k][ci (CinP)][co (CoutP)] (+ CoutP bias partials)
   const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;
   const size_t plane = (size_t)K * CinP * CoutP;
   const size_t stride = plane + CoutP;
@@ -160,14 +149,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
         if (lane == 0 && co < CoutP) pb[co] = v;
       }
   }
-  if constexpr (KT == 0) {
-    float* p = partial + ((size_t)split * 4 + wave) * stride;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      p[(size_t)(ci0 + l31) * CoutP + co] = acc[0][r];
-    }
-  } else {
+  {
     float* p = partial + (size_t)split * stride;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -387,8 +369,7 @@ size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x
   const int chunks = B * cdiv(T, WG_TW);
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);  // few tiles: keep the partial planes small
   if (nsplit > chunks) nsplit = chunks;
-  const int slices = w.K == 1 ? nsplit * 4 : nsplit;
-  return (size_t)slices * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
+  return (size_t)nsplit * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
 }
 
 // ax: forward ConvArgs (sources, prologue, dil, pad, w); g: output gradient [B][Cout][T] (shuffled when ax.shuffle > 1);
@@ -414,14 +395,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   ag.in_shuffle = fwd.shuffle > 1 ? fwd.shuffle : 0;
   ag.pro = gmask ? PRO_MASK : PRO_NONE;
   ag.mask = gmask;
-  if (fwd.H) {  // 2-D mode: G is [B][Cout][H][T]
-    ag.H = fwd.H;
-    ag.Hin = fwd.H;
-    ag.hpad = 0;
-    ag.Cin2d = w.Cout;
-  }
-  const int HM = fwd.H ? fwd.H : 1;
-  if (w.K == 1 && !fwd.H) {
+  if (w.K == 1) {
     const W1Cfg c = w1_cfg(w, fwd.B, fwd.T);
     const int nsplit = w1_nsplit(w, fwd.B, fwd.T, c);
     const int cpb = cdiv(fwd.T, W1_TW);
@@ -461,7 +435,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   }
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks_per_b = cdiv(fwd.T, WG_TW);
-  const int chunks = fwd.B * HM * chunks_per_b;
+  const int chunks = fwd.B * chunks_per_b;
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
   if (nsplit > chunks) nsplit = chunks;
   const int halo = (w.K - 1) * fwd.dil;
@@ -476,10 +450,10 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
   char fam[48];
-  snprintf(fam, sizeof(fam), "conv1d_wgrad_kernel<%d>", w.K == 1 ? 0 : (cdiv(w.K, 4) <= 3 ? cdiv(w.K, 4) : 6));
-  ProfScope prof(fam, flops * HM, bytes * HM, st, detail);
-  const int KT = w.K == 1 ? 0 : cdiv(w.K, 4);
-  const int wb = (gbias != nullptr && KT >= 1 && KT <= 3 && !fwd.H) ? 1 : 0;
+  snprintf(fam, sizeof(fam), "conv1d_wgrad_kernel<%d>", cdiv(w.K, 4) <= 3 ? cdiv(w.K, 4) : 6);
+  ProfScope prof(fam, flops, bytes, st, detail);
+  const int KT = cdiv(w.K, 4);
+  const int wb = (gbias != nullptr && KT >= 1 && KT <= 3) ? 1 : 0;
   if (fwd.flatW && KT > 3) {
     set_error("wgrad: flat 2-D mode is built for K <= 12");
     return STY_EINVAL;
@@ -487,7 +461,6 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
 #define STY_WG(KTV)                                                                                              \
   hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, partial, wb)
   switch (KT) {
-    case 0: STY_WG(0); break;
     case 1: STY_WG(1); break;
     case 2: STY_WG(2); break;
     case 3: STY_WG(3); break;
@@ -502,8 +475,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   }
 #undef STY_WG
   const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
-  const int slices = w.K == 1 ? nsplit * 4 : nsplit;
-  launch_wgrad_reduce(partial, slices, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+  launch_wgrad_reduce(partial, nsplit, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
   if (bias_done) *bias_done = wb != 0;
   STY_LAUNCH_CHECK();
   return STY_OK;
