@@ -210,8 +210,12 @@ def main():
     from stylish_tts_amd import dist as D
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU product path"
+    # STY_BENCH_SHARE_DEVICE=1 (test aid): all ranks share device 0 and exchange gradients over gloo, so the N > 1 code
+    # path can be exercised on a 1-GPU box; the numbers of such a run mean nothing
+    share = os.environ.get("STY_BENCH_SHARE_DEVICE") == "1"
+    local = 0 if share else local
     torch.cuda.set_device(local)
-    rank, world = D.init("nccl")  # RCCL; one process per GPU (torchrun environment)
+    rank, world = D.init("gloo" if share else "nccl")  # "nccl" = RCCL; one process per GPU (torchrun environment)
     device = torch.device("cuda", local)
 
     import __graft_entry__ as ge

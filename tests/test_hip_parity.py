@@ -816,3 +816,22 @@ def test_training_from_sample_dataset_files(tmp_path, env):
         seen += kw["audio_gt"].shape[0]
     torch.cuda.synchronize()
     assert seen == len(lines)
+
+
+def test_bench_two_ranks_on_one_device():
+    """The N > 1 path of bench.py end to end (torchrun, utterance sharding, bucketed gradient all-reduce, max-over-ranks
+    timing, one JSON line on rank 0) with both ranks on device 0 and gloo as the transport (STY_BENCH_SHARE_DEVICE=1)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STY_BENCH_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert "roofline" in rec and rec["config"]["workload"].startswith("c2")
