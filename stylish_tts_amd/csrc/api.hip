@@ -420,7 +420,7 @@ struct Builder {
     float* wp = m->ab.take<float>((size_t)KW * pc.CinP * pc.CoutP);
     float* bp = m->ab.take<float>(pc.CoutP);
     float* ts = m->ab.take<float>(Cout);
-    float* ts2 = m->train_enabled ? m->ab.take<float>((size_t)Cin * KH * KW + Cout) : nullptr;
+    float* ts2 = m->train_enabled ? m->ab.take<float>(sn_power_iter_scratch_floats(Cout, Cin * KH * KW)) : nullptr;
     pc.wp = wp;
     pc.bias = bias ? bp : nullptr;
     if (!dry) {
@@ -492,7 +492,7 @@ struct Builder {
         r.dw_b = ptr(d + ".bias", {r.Cin});
         float* w9 = m->ab.take<float>((size_t)r.Cin * 9);
         float* ts = m->ab.take<float>(r.Cin);
-        float* ts2 = m->train_enabled ? m->ab.take<float>((size_t)9 + r.Cin) : nullptr;
+        float* ts2 = m->train_enabled ? m->ab.take<float>(sn_power_iter_scratch_floats(r.Cin, 9)) : nullptr;
         r.dw_w9 = w9;
         if (!dry) {
           PackJob j;

@@ -11,7 +11,7 @@
 namespace sty {
 
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   constexpr int DP = DH < 32 ? 32 : DH;  // V rows padded to a multiple of 32
   constexpr int LS = 33;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     rs += __shfl_xor(rs, 32);
     l_run = l_run * alpha + rs;
     m_run = m_new;
-    if (a.drop_p > 0.f) {  // dropout acts on the normalised probabilities: the row sum above stays unmasked
+    if constexpr (DROP) {  // dropout acts on the normalised probabilities: the row sum above stays unmasked
       const float ks_ = 1.0f / (1.0f - a.drop_p);
       const unsigned rowi = ((unsigned)(b * a.H + h) * (unsigned)T + (unsigned)qi) * (unsigned)T;
 #pragma unroll
@@ -116,12 +116,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
 int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st) {
   dim3 grid(cdiv(a.T, 128), a.H, B);
-  if (DH == 64)
-    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), 0, st, a);
+  const bool drop = a.drop_p > 0.f;
+  if (DH == 64 && !drop)
+    hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, st, a);
+  else if (DH == 16 && !drop)
+    hipLaunchKernelGGL((attn_kernel<16, false>), grid, dim3(256), 0, st, a);
   else if (DH == 16)
-    hipLaunchKernelGGL(attn_kernel<16>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_kernel<16, true>), grid, dim3(256), 0, st, a);
   else {
-    set_error("attention: head dim %d not built (16, 64)", DH);
+    set_error("attention: head dim %d%s not built (16, 64; dropout: 16)", DH, drop ? " with dropout" : "");
     return STY_EINVAL;
   }
   STY_LAUNCH_CHECK();

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void attn_bwd_a_kernel(AttnArgs a, const float*
   delta[o] = dl;
 }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_c_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
                                                         const float* __restrict__ lse, const float* __restrict__ delta,
                                                         float* __restrict__ dQ, size_t dqbs) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void attn_bwd_c_kernel(AttnArgs a, const float*
       dp = fmaf(g[d], vb[(size_t)d * T + j], dp);
     }
     if (a.lengths && (qpad || j >= len)) s += -1e4f;
-    if (a.drop_p > 0.f) {
+    if constexpr (DROP) {
       const unsigned idx = ((unsigned)(b * a.H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j;
       dp = sty_hash_u(a.drop_seed, a.drop_site, idx) >= a.drop_p ? dp / (1.0f - a.drop_p) : 0.f;
     }
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void attn_bwd_c_kernel(AttnArgs a, const float*
 // 4 waves per workgroup share one 64-key tile and split the query range; their partial dK / dV are summed through
 // LDS in a fixed order (wave 0 + 1 + 2 + 3).  (One wave per tile took 2.6 ms for the conformer's 8 x 64 heads at
 // T = 160: 384 waves on 1024 SIMDs.)
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_b_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          float* __restrict__ dK, size_t dkbs, float* __restrict__ dV,
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_bwd_b_kernel(AttnArgs a, const float
     if (a.lengths && (i >= len || j >= len)) s += -1e4f;
     const float p = j < T ? expf(s - Lb[i]) : 0.f;
     float pm = p;  // dropped / rescaled probability that multiplied V in the forward
-    if (a.drop_p > 0.f) {
+    if constexpr (DROP) {
       const unsigned idx = ((unsigned)(b * a.H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j;
       const float mf = sty_hash_u(a.drop_seed, a.drop_site, idx) >= a.drop_p ? 1.0f / (1.0f - a.drop_p) : 0.f;
       pm = p * mf;
@@ -176,18 +176,22 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
   float* lse = ws;
   float* delta = ws + (size_t)B * a.H * a.T;
   dim3 grid(cdiv(a.T, 64), a.H, B);
-  if (DH == 64) {
-    hipLaunchKernelGGL(attn_bwd_a_kernel<64>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta);
-    hipLaunchKernelGGL(attn_bwd_b_kernel<64>, grid, dim3(256), 0, st, a, dO, dobs, lse, delta, dK, dkbs, dV, dvbs);
-    hipLaunchKernelGGL(attn_bwd_c_kernel<64>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dQ, dqbs);
+  const bool drop = a.drop_p > 0.f;
+#define STY_ABWD(DHV, DR)                                                                                            \
+  hipLaunchKernelGGL(attn_bwd_a_kernel<DHV>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta);                        \
+  hipLaunchKernelGGL((attn_bwd_b_kernel<DHV, DR>), grid, dim3(256), 0, st, a, dO, dobs, lse, delta, dK, dkbs, dV, dvbs); \
+  hipLaunchKernelGGL((attn_bwd_c_kernel<DHV, DR>), grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dQ, dqbs)
+  if (DH == 64 && !drop) {
+    STY_ABWD(64, false);
+  } else if (DH == 16 && !drop) {
+    STY_ABWD(16, false);
   } else if (DH == 16) {
-    hipLaunchKernelGGL(attn_bwd_a_kernel<16>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta);
-    hipLaunchKernelGGL(attn_bwd_b_kernel<16>, grid, dim3(256), 0, st, a, dO, dobs, lse, delta, dK, dkbs, dV, dvbs);
-    hipLaunchKernelGGL(attn_bwd_c_kernel<16>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dQ, dqbs);
+    STY_ABWD(16, true);
   } else {
-    set_error("attention_bwd: head dim %d not built", DH);
+    set_error("attention_bwd: head dim %d%s not built", DH, drop ? " with dropout" : "");
     return STY_EINVAL;
   }
+#undef STY_ABWD
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

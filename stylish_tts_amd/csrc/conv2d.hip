@@ -23,18 +23,27 @@ __global__ __launch_bounds__(256) void sn_rowdot_kernel(const float* __restrict_
 
 // One power iteration of torch.nn.utils.spectral_norm in training mode (n_power_iterations = 1, eps 1e-12):
 //   v = normalize(W^T u), u = normalize(W v), written back into the module's weight_u / weight_v buffers.
+// vraw[s][i] = sum over the s-th slice of co of W[co][i] u[co]   (grid: (n/256, SN_SLICES))
+constexpr int SN_SLICES = 8;
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, int Cout,
                                                       int n, float* __restrict__ vraw) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int co = 0; co < Cout; ++co) s = fmaf(w[(size_t)co * n + i], u[co], s);
-  vraw[i] = s;
+  for (int co = blockIdx.y; co < Cout; co += SN_SLICES) s = fmaf(w[(size_t)co * n + i], u[co], s);
+  vraw[(size_t)blockIdx.y * n + i] = s;
 }
-__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ raw, int n, float* __restrict__ out) {
+// out = normalize(sum of `slices` partial vectors raw[s][.]) (slices summed in a fixed order)
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ raw, int n, int slices,
+                                                           float* __restrict__ out) {
   __shared__ double red[256];
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += (double)raw[i] * raw[i];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v = 0.f;
+    for (int k = 0; k < slices; ++k) v += raw[(size_t)k * n + i];
+    out[i] = v;  // un-normalised sum, scaled below
+    s += (double)v * v;
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -42,7 +51,7 @@ __global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restri
     __syncthreads();
   }
   const float nrm = fmaxf((float)sqrt(red[0]), 1e-12f);
-  for (int i = threadIdx.x; i < n; i += 256) out[i] = raw[i] / nrm;
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = out[i] / nrm;
 }
 __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, int n,
                                                      float* __restrict__ uraw) {
@@ -58,14 +67,15 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ w
   }
   if (threadIdx.x == 0) uraw[co] = red[0];
 }
-// scratch: n + Cout floats
+// scratch: SN_SLICES * n + Cout floats
+size_t sn_power_iter_scratch_floats(int Cout, int n) { return (size_t)SN_SLICES * n + Cout; }
 int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st) {
   float* vraw = scratch;
-  float* uraw = scratch + n;
-  hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, u, Cout, n, vraw);
-  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, n, v);
+  float* uraw = scratch + (size_t)SN_SLICES * n;
+  hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(n, 256), SN_SLICES), dim3(256), 0, st, w, u, Cout, n, vraw);
+  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, n, SN_SLICES, v);
   hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, w, v, n, uraw);
-  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, uraw, Cout, u);
+  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, uraw, Cout, 1, u);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

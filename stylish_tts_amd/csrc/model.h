@@ -277,6 +277,7 @@ int launch_bn_train_bwd(const float* x, const float* dy, const float* w, const f
 int launch_dropout(const float* x, const float* res, size_t n, float p, unsigned seed, unsigned site, float* y,
                    int accumulate, hipStream_t st);
 int launch_box_smooth(const float* x, int B, int T, int width, float* y, int accumulate, hipStream_t st);
+size_t sn_power_iter_scratch_floats(int Cout, int n);
 int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st);
 int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
                           hipStream_t st, size_t* need);
