@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
   }
   if (qi < T) {
+    if (a.lse && hi == 0) a.lse[((size_t)b * a.H + h) * T + qi] = m_run + logf(l_run);
     const float inv = 1.0f / l_run;
     float* ob = a.o + (size_t)b * a.obs + (size_t)h * DH * T;
 #pragma unroll

@@ -168,6 +168,177 @@ __global__ __launch_bounds__(256) void attn_bwd_b_kernel(AttnArgs a, const float
   }
 }
 
+// =====================================================================================================
+// MFMA backward (no mask, no dropout: the vocoder conformer, 8 heads x 64, T up to a few thousand frames).
+// The VALU kernels above cost 25 ms per c3 step (T = 520); these do the same five T x T x DH contractions on the fp32
+// matrix cores with the chained-fragment idiom of the forward kernel: a 32x32 accumulator fragment (rows in
+// registers, columns across lanes) is a legal B operand of the next MFMA when the reduction runs over its ROW index.
+//   kv kernel (one 32-key tile per wave, loop over 32-query tiles):
+//     S[i][j]  = sum_d Q[d][i] K[d][j]      A = Q tile (LDS), B = K fragment (registers)   -> rows i, cols j
+//     dP[i][j] = sum_d dO[d][i] V[d][j]     A = dO tile,      B = V fragment
+//     P = exp(scale S - lse_i), dS = P (dP - delta_i)
+//     dV[d][j] += sum_i dO[d][i] P[i][j]    A = dO tile read with the fragment row map, B = P fragment
+//     dK[d][j] += scale sum_i Q[d][i] dS[i][j]
+//   q kernel (one 32-query tile per wave, loop over 32-key tiles): S^T, dP^T with rows j, cols i, then
+//     dQ[d][i] += scale sum_j K[d][j] dS^T[j][i]
+// lse comes from the forward kernel, delta_i = sum_d dO[d][i] O[d][i] from attn_delta_kernel.
+// =====================================================================================================
+__global__ void attn_delta_kernel(const float* __restrict__ o, size_t obs, const float* __restrict__ dO, size_t dobs,
+                                  int H, int DH, int T, float* __restrict__ delta) {
+  const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+  if (i >= T) return;
+  const float* ob = o + (size_t)b * obs + (size_t)h * DH * T;
+  const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
+  float s = 0.f;
+  for (int d = 0; d < DH; ++d) s = fmaf(gb[(size_t)d * T + i], ob[(size_t)d * T + i], s);
+  delta[((size_t)b * H + h) * T + i] = s;
+}
+
+__device__ __forceinline__ int frag_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               float* __restrict__ dK, size_t dkbs,
+                                                               float* __restrict__ dV, size_t dvbs) {
+  constexpr int LS = 33, NB = DH / 32;
+  __shared__ float qs[DH * LS], gs[DH * LS], lse_s[32], del_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, T = a.T;
+  const int j = blockIdx.x * 128 + wave * 32 + l31;
+  const float* qb = a.q + (size_t)b * a.qbs + (size_t)h * DH * T;
+  const float* kb = a.k + (size_t)b * a.kbs + (size_t)h * DH * T;
+  const float* vb = a.v + (size_t)b * a.vbs + (size_t)h * DH * T;
+  const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
+  const float* Lb = lse + ((size_t)b * a.H + h) * T;
+  const float* Db = delta + ((size_t)b * a.H + h) * T;
+  float kreg[DH / 2], vreg[DH / 2];
+#pragma unroll
+  for (int c2 = 0; c2 < DH / 2; ++c2) {
+    kreg[c2] = j < T ? kb[(size_t)(2 * c2 + hi) * T + j] : 0.f;
+    vreg[c2] = j < T ? vb[(size_t)(2 * c2 + hi) * T + j] : 0.f;
+  }
+  f32x16 dv[NB], dk[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[n][r] = dk[n][r] = 0.f;
+  for (int i0 = 0; i0 < T; i0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < DH * 32; e += 256) {
+      const int d = e >> 5, ii = e & 31, i = i0 + ii;
+      qs[d * LS + ii] = i < T ? qb[(size_t)d * T + i] : 0.f;
+      gs[d * LS + ii] = i < T ? gb[(size_t)d * T + i] : 0.f;
+    }
+    if (tid < 32) {
+      lse_s[tid] = i0 + tid < T ? Lb[i0 + tid] : 0.f;
+      del_s[tid] = i0 + tid < T ? Db[i0 + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < DH / 2; ++c2) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(qs[(2 * c2 + hi) * LS + l31], kreg[c2], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[(2 * c2 + hi) * LS + l31], vreg[c2], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ii = frag_row(r, hi);
+      const bool ok = i0 + ii < T && j < T;
+      const float p = ok ? expf(s[r] * a.scale - lse_s[ii]) : 0.f;
+      s[r] = p;
+      dp[r] = p * (dp[r] - del_s[ii]);
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ii = frag_row(q, hi);
+        dv[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[(n * 32 + l31) * LS + ii], s[q], dv[n], 0, 0, 0);
+        dk[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(qs[(n * 32 + l31) * LS + ii], dp[q], dk[n], 0, 0, 0);
+      }
+  }
+  if (j < T) {
+    float* dkb = dK + (size_t)b * dkbs + (size_t)h * DH * T;
+    float* dvb = dV + (size_t)b * dvbs + (size_t)h * DH * T;
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = n * 32 + frag_row(r, hi);
+        dkb[(size_t)d * T + j] += dk[n][r] * a.scale;
+        dvb[(size_t)d * T + j] += dv[n][r];
+      }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta,
+                                                              float* __restrict__ dQ, size_t dqbs) {
+  constexpr int LS = 33, NB = DH / 32;
+  __shared__ float ks[DH * LS], vs[DH * LS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, T = a.T;
+  const int i = blockIdx.x * 128 + wave * 32 + l31;
+  const float* qb = a.q + (size_t)b * a.qbs + (size_t)h * DH * T;
+  const float* kb = a.k + (size_t)b * a.kbs + (size_t)h * DH * T;
+  const float* vb = a.v + (size_t)b * a.vbs + (size_t)h * DH * T;
+  const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
+  const float L = i < T ? lse[((size_t)b * a.H + h) * T + i] : 0.f;
+  const float dl = i < T ? delta[((size_t)b * a.H + h) * T + i] : 0.f;
+  float qreg[DH / 2], greg[DH / 2];
+#pragma unroll
+  for (int c2 = 0; c2 < DH / 2; ++c2) {
+    qreg[c2] = i < T ? qb[(size_t)(2 * c2 + hi) * T + i] : 0.f;
+    greg[c2] = i < T ? gb[(size_t)(2 * c2 + hi) * T + i] : 0.f;
+  }
+  f32x16 dq[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[n][r] = 0.f;
+  for (int j0 = 0; j0 < T; j0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < DH * 32; e += 256) {
+      const int d = e >> 5, jj = e & 31, jx = j0 + jj;
+      ks[d * LS + jj] = jx < T ? kb[(size_t)d * T + jx] : 0.f;
+      vs[d * LS + jj] = jx < T ? vb[(size_t)d * T + jx] : 0.f;
+    }
+    __syncthreads();
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < DH / 2; ++c2) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[(2 * c2 + hi) * LS + l31], qreg[c2], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(2 * c2 + hi) * LS + l31], greg[c2], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = j0 + frag_row(r, hi) < T && i < T;
+      const float p = ok ? expf(s[r] * a.scale - L) : 0.f;
+      dp[r] = p * (dp[r] - dl);
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        dq[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[(n * 32 + l31) * LS + frag_row(q, hi)], dp[q], dq[n], 0, 0, 0);
+  }
+  if (i < T) {
+    float* dqb = dQ + (size_t)b * dqbs + (size_t)h * DH * T;
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqb[(size_t)(n * 32 + frag_row(r, hi)) * T + i] += dq[n][r] * a.scale;
+  }
+}
+
 size_t attention_bwd_ws_floats(int B, int H, int T) { return (size_t)2 * B * H * T; }
 
 // gradients are ACCUMULATED into dQ / dK / dV
@@ -175,6 +346,15 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
                          size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st) {
   float* lse = ws;
   float* delta = ws + (size_t)B * a.H * a.T;
+  if (DH == 64 && a.lse && !a.lengths && a.drop_p <= 0.f) {  // matrix-core path; lse kept by the forward kernel
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a.T, 256), a.H, B), dim3(256), 0, st, a.o, a.obs, dO, dobs, a.H, DH,
+                       a.T, delta);
+    dim3 g2(cdiv(a.T, 128), a.H, B);
+    hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel<64>, g2, dim3(256), 0, st, a, dO, dobs, a.lse, delta, dK, dkbs, dV, dvbs);
+    hipLaunchKernelGGL(attn_bwd_q_mfma_kernel<64>, g2, dim3(256), 0, st, a, dO, dobs, a.lse, delta, dQ, dqbs);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   dim3 grid(cdiv(a.T, 64), a.H, B);
   const bool drop = a.drop_p > 0.f;
 #define STY_ABWD(DHV, DR)                                                                                            \

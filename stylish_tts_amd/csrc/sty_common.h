@@ -200,6 +200,7 @@ struct AttnArgs {
   // ((b*H + h)*T + i)*T + j) >= p, kept entries scaled by 1/(1-p); p = 0: off
   float drop_p = 0.f;
   unsigned drop_seed = 0, drop_site = 0;
+  float* lse = nullptr;  // optional [B][H][T]: log-sum-exp of every score row, kept for the MFMA backward
 };
 }  // namespace sty
 

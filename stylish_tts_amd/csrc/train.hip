@@ -408,6 +408,7 @@ struct Trainer {
     at.H = 8;
     at.scale = 1.0f / sqrtf((float)(inner / 8));
     at.lengths = nullptr;
+    at.lse = take<float>((size_t)B * 8 * Tt);  // row log-sum-exp, kept for the MFMA backward
     if (live()) chk(launch_attention(at, B, inner / 8, st));
     tape.push_back([=]() {
       float* gO = G(o, (size_t)B * inner * Tt);
