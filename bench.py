@@ -85,14 +85,14 @@ def build_model(device):
     return m.to(device), se.to(device), P
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, workload):
     """HBM bytes per launch of a kernel from the committed PMC passes of this same command (tools/profile_round.sh ->
     profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  Counters cannot be
-    read from inside the process, so this is the recorded figure, or None when no record matches."""
+    read from inside the process, so this is the recorded figure of the SAME workload, or None when there is none."""
     import glob
     import re
     key = re.sub(r"\s+", "", family)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c2_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
@@ -277,7 +277,7 @@ def main():
     }
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
-        traffic, traffic_src = pmc_traffic(dom["name"])
+        traffic, traffic_src = pmc_traffic(dom["name"], args.workload)
         per = dom["ms"] / dom["launches"] * 1e-3
         tf = dom["flops"] / dom["launches"] / per / 1e12
         gbs = dom["bytes"] / dom["launches"] / per / 1e9
