@@ -37,17 +37,24 @@ __device__ __forceinline__ float act_apply(float x, float alpha) {
 #ifndef STY_MINW
 #define STY_MINW 2
 #endif
-template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void conv1d_mfma_kernel(ConvArgs a) {
-  constexpr int NW = WM * WN;  // waves per workgroup (4 or 8)
-  constexpr int NTHR = 64 * NW;
-  extern __shared__ __attribute__((aligned(16))) float xs[];
+// KS > 1: split-K INSIDE the workgroup.  KS groups of WM*WN waves work on the same output tile, group g takes the
+// reduction chunks g, g+KS, ... into its own LDS tile and accumulators; the partial tiles are summed through LDS in a
+// fixed order before the epilogue.  For the small-grid GEMMs (stage A at T = 160, the text encoder, the deep layers of
+// the style encoder: fewer workgroups than CUs, 30-60 chunks each) this doubles the waves per SIMD that hide each
+// other's memory latency and halves the length of the serial chunk loop.
+template <int WM, int WN, int MT, int NT, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MINW)) void conv1d_mfma_kernel(ConvArgs a) {
+  constexpr int NW = WM * WN;  // waves per reduction group (4 or 8)
+  constexpr int NTHR = 64 * NW * KS;
+  extern __shared__ __attribute__((aligned(16))) float xs_all[];
   constexpr int CO_BLK = 32 * MT * WM;
   constexpr int TT_BLK = 32 * NT * WN;
   constexpr int MAXJ = (TT_BLK + 128 + 63) / 64;  // launch_cfg guarantees halo <= 128
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: descriptors stay in SGPRs
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: descriptors stay in SGPRs
+  const int kg = KS > 1 ? wave_all / NW : 0;                      // reduction group of this wave
+  const int wave = KS > 1 ? wave_all % NW : wave_all;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z;
@@ -59,6 +66,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
   const int halo = (K - 1) * a.dil;
   const int LW = TT_BLK + halo;
   const int tw = wn * (32 * NT);
+  float* xs = xs_all + kg * (CI_CHUNK * LW);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -81,12 +89,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
   // the current step's MFMAs
   float a_nxt[NW == 4 ? CI_CHUNK / 2 : 1][MT];
   if constexpr (NW == 4) {
+    const int srow0 = kg * CI_CHUNK * CoutP * 4;  // first chunk of this reduction group (in range: CinP >= 32*KS)
 #pragma unroll
     for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        a_nxt[c2][m] =
-            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, 2 * c2 * CoutP * 4, 0));
+        a_nxt[c2][m] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow0 + 2 * c2 * CoutP * 4, 0));
   }
 #define STY_ST(PRO, MODE) stage_chunk<PRO, NW, MAXJ, MODE, TT_BLK, NW == 4>(a, xb, xs, ci0, b, h, t0, LW, wave, lane)
 #define STY_ST2(PRO)              \
@@ -101,9 +110,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
     STY_ST(PRO, ST_FLAT);         \
   else                            \
     STY_ST(PRO, ST_GENERIC)
-  for (int ci0 = 0; ci0 < CinP; ci0 += CI_CHUNK) {
+  const int nchunks = CinP / CI_CHUNK;
+  for (int itc = 0; itc < (nchunks + KS - 1) / KS; ++itc) {
+    const int ci0 = (itc * KS + kg) * CI_CHUNK;
+    const bool active = KS == 1 || ci0 < CinP;  // the last round of an odd chunk count idles one group (barriers only)
     __syncthreads();
-    switch (a.pro) {
+    if (active) switch (a.pro) {
       case PRO_AFFINE: STY_ST2(PRO_AFFINE); break;
       case PRO_SCALE: STY_ST2(PRO_SCALE); break;
       case PRO_AFFINE_SNAKE: STY_ST2(PRO_AFFINE_SNAKE); break;
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
 #undef STY_ST3
 #undef STY_ST2
 #undef STY_ST
-    if (a.pro == PRO_LN_AFFINE) {
+    if (KS == 1 && a.pro == PRO_LN_AFFINE) {
       // LayerNorm over the Cin (<= 32, single chunk) channels of every in-range column, then affine.
       __syncthreads();
       for (int j = tid; j < LW; j += NTHR) {
@@ -140,8 +152,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
     // weights, L2-resident) of tap k+1 while tap k's MFMAs issue.
     // packed weights through one buffer descriptor: per-lane byte offset wv (fixed for the whole kernel), the
     // (tap, channel pair) part of the address is a scalar soffset
+    if (!active) continue;
     if constexpr (NW == 4) {
-      const bool more = ci0 + CI_CHUNK < CinP;
+      const bool more = ci0 + CI_CHUNK * KS < CinP;
       for (int k = 0; k < K; ++k) {
         float a_cur[CI_CHUNK / 2][MT];
 #pragma unroll
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
 #pragma unroll
           for (int m = 0; m < MT; ++m) a_cur[c2][m] = a_nxt[c2][m];
         if (k + 1 < K || more) {  // (chunk, tap + 1), or tap 0 of the next chunk
-          const int srow = (k + 1 < K ? (k + 1) * CinP + ci0 : ci0 + CI_CHUNK) * CoutP * 4;
+          const int srow = (k + 1 < K ? (k + 1) * CinP + ci0 : ci0 + CI_CHUNK * KS) * CoutP * 4;
 #pragma unroll
           for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
@@ -200,6 +213,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
     }
   }
 
+  if constexpr (KS > 1) {
+    // ordered sum of the groups' partial tiles through LDS (layout [fragment element][thread of a group])
+    float* red = xs_all;
+    constexpr int GT = 64 * NW;
+    for (int g = 1; g < KS; ++g) {
+      __syncthreads();
+      if (kg == g) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((m * NT + n) * 16 + r) * GT + wave * 64 + lane] = acc[m][n][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] += red[((m * NT + n) * 16 + r) * GT + wave * 64 + lane];
+      }
+    }
+    if (kg != 0) return;
+  }
   // ---- epilogue ----
   const int Cout = a.w.Cout;
   if (a.act == ACT_GLU) {
@@ -300,12 +339,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : STY_MINW)) void c
   }
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int KS = 1>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   constexpr int CO_BLK = 32 * MT * WM;
   constexpr int TT_BLK = 32 * NT * WN;
   const int halo = (a.w.K - 1) * a.dil;
-  const size_t lds = (size_t)CI_CHUNK * (TT_BLK + halo) * sizeof(float);
+  size_t lds = (size_t)KS * CI_CHUNK * (TT_BLK + halo) * sizeof(float);
+  if (KS > 1 && lds < (size_t)MT * NT * 16 * 64 * WM * WN * sizeof(float)) lds = (size_t)MT * NT * 16 * 64 * WM * WN * sizeof(float);
   if (halo > 128) {
     set_error("conv1d: receptive-field halo %d > 128 not built", halo);
     return STY_EINVAL;
@@ -314,7 +354,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     // more than the default dynamic-LDS allowance: opt in (160 KiB per CU on gfx950)
     static bool raised = false;
     if (!raised) {
-      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, MT, NT>),
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, MT, NT, KS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       raised = true;
     }
@@ -334,11 +374,11 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const double in_elems = (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
   const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
   char fam[48];  // the kernel's own name, as rocprofv3 prints it (minus spaces)
-  snprintf(fam, sizeof(fam), "conv1d_mfma_kernel<%d,%d,%d,%d>", WM, WN, MT, NT);
+  snprintf(fam, sizeof(fam), "conv1d_mfma_kernel<%d,%d,%d,%d,%d>", WM, WN, MT, NT, KS);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
   ProfScope prof(fam, flops, bytes, st, detail);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT, KS>), grid, dim3(64 * WM * WN * KS), lds, st, a);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -379,7 +419,11 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   if (a.w.CoutP % 64 == 0) {
     const long tiles64 = (long)cdiv(a.T, 256) * (a.w.CoutP / 64) * a.B;
     if (tiles64 >= 512) return launch_cfg<1, 4, 2, 2>(a, st);
-    return launch_cfg<2, 2, 1, 1>(a, st);  // 64 couts x 64 time
+    // 64 couts x 64 time; with few workgroups and a long reduction, two wave groups split the reduction
+    static const bool ks_on = getenv("STY_NO_KSPLIT") == nullptr;
+    const long wgs = (long)cdiv(a.T, 64) * (a.w.CoutP / 64) * a.B;
+    if (ks_on && wgs <= 768 && a.w.CinP >= 8 * CI_CHUNK && a.pro != PRO_LN_AFFINE) return launch_cfg<2, 2, 1, 1, 2>(a, st);
+    return launch_cfg<2, 2, 1, 1>(a, st);
   }
   // 32-cout blocks: at the 75T frame rate use 8 waves on a 512-sample tile (2 workgroups = 16 waves per CU, halo
   // overhead halved); short sequences keep the 4-wave 256-sample tile for grid size.
