@@ -422,7 +422,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     // 64 couts x 64 time; with few workgroups and a long reduction, two wave groups split the reduction
     static const bool ks_on = getenv("STY_NO_KSPLIT") == nullptr;
     const long wgs = (long)cdiv(a.T, 64) * (a.w.CoutP / 64) * a.B;
-    if (ks_on && wgs <= 768 && a.w.CinP >= 8 * CI_CHUNK && a.pro != PRO_LN_AFFINE) return launch_cfg<2, 2, 1, 1, 2>(a, st);
+    if (ks_on && wgs <= 768 && a.w.CinP >= 4 * CI_CHUNK && a.pro != PRO_LN_AFFINE) return launch_cfg<2, 2, 1, 1, 2>(a, st);
     return launch_cfg<2, 2, 1, 1>(a, st);
   }
   // 32-cout blocks: at the 75T frame rate use 8 waves on a 512-sample tile (2 workgroups = 16 waves per CU, halo
