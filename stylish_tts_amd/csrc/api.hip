@@ -212,6 +212,8 @@ struct Builder {
     const float* b2 = ptr(p + ".pwconv2.bias", {C});
     c.pw1 = conv(p + ".pwconv1");
     c.w1p = c.pw1.wp;
+    c.w1_raw = ptr(p + ".pwconv1.weight", {4 * C, C});
+    c.w2_raw = w2;
     // pw2: packed conv with bias := b2eff (written by the W2A job)
     PackedConv pc;
     pc.Cout = C;

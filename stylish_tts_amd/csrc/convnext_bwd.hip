@@ -1,0 +1,285 @@
+// Backward of the fused GeneratorConvNeXtBlock at C = 32 (conv_next.py:80-93), recompute-based:
+//   forward   u = dw7(x), xh = LN(u), xn = (1+g) xh + b, h0 = W1 xn + b1, h = snake(h0; alpha),
+//             s = GRN scale(sum_t h^2), y = W2 (h s) + b2eff + x
+// The training graph used to keep u, xn, h0, h (4C channels!) and ran ~20 kernels per block over them; at the 75T
+// frame rate the nine C = 32 blocks were the largest single cost of a c3 step (~65 of 216 ms).  Here the forward is
+// the fused two-pass inference kernel (nothing but x and the per-(b, channel) GRN scale is kept) and the backward
+// recomputes the block tile by tile on the matrix cores:
+//   pass 1   U = W2^T gY (per tile), ds[b,ch] partial = sum_t U h            (GRN needs it over the whole utterance)
+//   -> grn_bwd: coef[b,ch], d gamma
+//   pass 2   gH = U s + coef h, gH0 = gH snake'(h0); chained GEMM gXn = W1^T gH0 (accumulator fragment as B operand);
+//            LayerNorm backward per column in registers -> gU; writes gU, xn, h s and gH0 (the operands of the two
+//            weight-gradient GEMMs, which run on wgrad_k1_kernel) and per-tile partials of d alpha, d(gamma,beta)_AdaLN.
+// The depthwise-conv backward runs on the existing kernels from gU.  HBM traffic per time column: ~1 100 floats for
+// forward + backward against ~3 300 before.
+#include "sty_common.h"
+
+namespace sty {
+
+constexpr int CB_TT = 256;
+
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) {
+  constexpr int LW = CB_TT + 6, LG = CB_TT + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                 // [32][LW]  x tile, then x-hat
+  float* gys = xs + 32 * LW;       // [32][LG]  gY tile
+  float* rstd_s = gys + 32 * LG;   // [256]
+  float* red = rstd_s + 256;       // [4][128]
+  float* red2 = red + 4 * 128;     // [4][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.y, t0 = blockIdx.x * CB_TT, T = a.T;
+  const float* xb = a.x + (size_t)b * 32 * T;
+  const float* gb_ = a.gy + (size_t)b * 32 * T;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float v[4][5], g[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 4 * (half * 4 + i);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int j = lane + 64 * q, t = t0 - 3 + j;
+        v[i][q] = (j < LW && t >= 0 && t < T) ? xb[(size_t)row * T + t] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = t0 + lane + 64 * q;
+        g[i][q] = t < T ? gb_[(size_t)row * T + t] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 4 * (half * 4 + i);
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+        if (lane + 64 * q < LW) xs[row * LW + lane + 64 * q] = v[i][q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gys[row * LG + lane + 64 * q] = g[i][q];
+    }
+  }
+  __syncthreads();
+  {  // depthwise k7 + LayerNorm statistics: one thread per time column
+    float u[32];
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      float acc = a.dw_b[c];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc = fmaf(a.dw_w[c * 7 + k], xs[c * LW + tid + k], acc);
+      u[c] = acc;
+      mean += acc;
+    }
+    mean *= (1.0f / 32.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float d = u[c] - mean;
+      var += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 32.0f) + 1e-6f);
+    __syncthreads();
+    rstd_s[tid] = rstd;
+    const int t = t0 + tid;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float xh = (u[c] - mean) * rstd;
+      xs[c * LW + 3 + tid] = xh;
+      if (PASS == 2 && t < T) a.xn[((size_t)b * 32 + c) * T + t] = xh * (1.f + a.gb[b * 64 + c]) + a.gb[b * 64 + 32 + c];
+    }
+  }
+  __syncthreads();
+  const int tw = wave * 64;
+  // This wave's 64 columns are processed as two independent 32-column passes (n): with both in flight the kernel
+  // needed 256 VGPRs + 672 B of scratch per lane; one at a time it fits with room to spare, at the price of reading
+  // the (L1-resident, 48 KB) weight fragments twice.
+  if (tid < 128) {
+    red[tid] = red[128 + tid] = red[256 + tid] = red[384 + tid] = 0.f;
+  }
+  if (PASS == 2 && tid < 64) red2[tid] = red2[64 + tid] = red2[128 + tid] = red2[192 + tid] = 0.f;
+  __syncthreads();
+#pragma unroll 1
+  for (int n = 0; n < 2; ++n) {
+    const int tl = tw + n * 32 + l31, t = t0 + tl;
+    const bool ok = t < T;
+    // B fragments: normalised input (AdaLN affine applied on the way) and the output gradient
+    float bx[16], by[16];
+#pragma unroll
+    for (int c2 = 0; c2 < 16; ++c2) {
+      const int c = 2 * c2 + hi;
+      bx[c2] = fmaf(xs[c * LW + 3 + tl], 1.f + a.gb[b * 64 + c], a.gb[b * 64 + 32 + c]);
+      by[c2] = gys[c * LG + tl];
+    }
+    f32x16 gxn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gxn[r] = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+      f32x16 h, uu;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[r] = uu[r] = 0.f;
+      {
+        const float* w1row = a.w1p + hi * 128 + j * 32 + l31;  // [ci][ch]
+        const float* w2row = a.w2 + hi * 128 + j * 32 + l31;   // raw pwconv2.weight [co][ch]
+        float av[16], a2[16];
+#pragma unroll
+        for (int c2 = 0; c2 < 16; ++c2) {
+          av[c2] = w1row[(2 * c2) * 128];
+          a2[c2] = w2row[(2 * c2) * 128];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < 16; ++c2) {
+          h = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2], bx[c2], h, 0, 0, 0);
+          uu = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[c2], by[c2], uu, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float bias = a.b1[ch], al = a.alpha[ch], ral = 1.0f / al;
+        const float sc = a.scale[b * 128 + ch];
+        const float z = h[r] + bias;
+        const float s2 = sty_sin2(al * z);
+        const float hv = fmaf(ral, s2, z);
+        float rsum;
+        if (PASS == 1) {
+          rsum = ok ? uu[r] * hv : 0.f;
+        } else {
+          const float cf = a.coef[b * 128 + ch];
+          const float gH = ok ? fmaf(uu[r], sc, cf * hv) : 0.f;
+          const float s2a = sty_sinf(2.f * al * z);
+          const float g0 = gH * (1.f + s2a);
+          rsum = gH * (z * s2a - s2 * ral) * ral;
+          if (ok) {
+            const size_t o = ((size_t)b * 128 + ch) * T + t;
+            a.hs[o] = hv * sc;
+            a.gh0[o] = g0;
+          }
+          h[r] = g0;
+        }
+        rsum += __shfl_xor(rsum, 1);
+        rsum += __shfl_xor(rsum, 2);
+        rsum += __shfl_xor(rsum, 4);
+        rsum += __shfl_xor(rsum, 8);
+        rsum += __shfl_xor(rsum, 16);
+        if (l31 == 0) red[wave * 128 + ch] += rsum;  // the same lane owns this slot in both passes
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the per-channel loads / store addresses of later
+                                                              // rows from being hoisted (that cost 106 spilled VGPRs)
+      }
+      if (PASS == 2) {  // gXn[ci][t] += sum_ch W1[ch][ci] gH0[ch][t]: the gH0 fragment is the B operand
+        float aw[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) aw[q] = a.w1[(size_t)(j * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * 32 + l31];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gxn = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q], h[q], gxn, 0, 0, 0);
+      }
+    }
+    if (PASS == 2) {
+      // LayerNorm backward over the 32 channels of this column (fragment rows: 16 registers x 2 half-waves)
+      float gxh[16], xh[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        xh[r] = xs[c * LW + 3 + tl];
+        gxh[r] = gxn[r] * (1.f + a.gb[b * 64 + c]);
+        s1 += gxh[r];
+        s2 = fmaf(gxh[r], xh[r], s2);
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      s1 *= (1.0f / 32.0f);
+      s2 *= (1.0f / 32.0f);
+      const float rs = rstd_s[tl];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (ok) a.gu[((size_t)b * 32 + c) * T + t] = rs * (gxh[r] - s1 - xh[r] * s2);
+        float v = ok ? gxn[r] * xh[r] : 0.f, w = ok ? gxn[r] : 0.f;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          v += __shfl_xor(v, o);
+          w += __shfl_xor(w, o);
+        }
+        if (l31 == 0) {
+          red2[wave * 64 + c] += v;
+          red2[wave * 64 + 32 + c] += w;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const double s = (double)red[tid] + (double)red[128 + tid] + (double)red[256 + tid] + (double)red[384 + tid];
+    // pass 1: ds partial; pass 2: d alpha partial
+    a.part[((size_t)b * 128 + tid) * a.ntiles + blockIdx.x] = s;
+  }
+  if (PASS == 2) {
+    __syncthreads();
+    if (tid < 64)
+      a.part_gb[((size_t)b * 64 + tid) * a.ntiles + blockIdx.x] =
+          (double)red2[tid] + (double)red2[64 + tid] + (double)red2[128 + tid] + (double)red2[192 + tid];
+  }
+}
+
+// sum the per-tile partials in a fixed order
+//  mode 0: out[b][ch] = sum_tiles part          (ds of the GRN scale)
+//  mode 1: out[ch] += sum_b sum_tiles part      (d alpha)
+//  mode 2: out[b][ch] += sum_tiles part         (d (gamma | beta) of the AdaLN projection output)
+// one wave per output element: lanes stride over the partials (coalesced), fp64 shuffle reduction (fixed order)
+__global__ __launch_bounds__(64) void cnx_partial_sum_kernel(const double* __restrict__ part, int B, int C, int ntiles,
+                                                             int mode, float* __restrict__ out) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  if (mode == 1) {
+    for (int b = 0; b < B; ++b) {
+      const double* p = part + ((size_t)b * C + i) * ntiles;
+      for (int k = lane; k < ntiles; k += 64) s += p[k];
+    }
+  } else {
+    const double* p = part + (size_t)i * ntiles;
+    for (int k = lane; k < ntiles; k += 64) s += p[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    if (mode == 0)
+      out[i] = (float)s;
+    else
+      out[i] += (float)s;
+  }
+}
+
+int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mode, float* out, hipStream_t st) {
+  const int n = mode == 1 ? C : B * C;
+  hipLaunchKernelGGL(cnx_partial_sum_kernel, dim3(n), dim3(64), 0, st, part, B, C, ntiles, mode, out);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st) {
+  constexpr size_t lds = (32 * (CB_TT + 6) + 32 * (CB_TT + 1) + 256 + 4 * 128 + 4 * 64) * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = true;
+  }
+  dim3 grid(a.ntiles, B);
+  const double pos = (double)B * a.T;
+  // per position: dw 448, GEMM-1 8192, U 8192 (+ gXn 8192 in pass 2); pass 1 reads x, gY; pass 2 also writes
+  // h s, gH0 (128 each), xn, gU (32 each)
+  const double flops = pos * (448.0 + 16384.0 + (pass == 2 ? 8192.0 : 0.0));
+  const double bytes = pos * 4.0 * (64.0 + (pass == 2 ? 320.0 : 0.0));
+  ProfScope prof(pass == 1 ? "convnext32_bwd_kernel<1>" : "convnext32_bwd_kernel<2>", flops, bytes, st);
+  if (pass == 1)
+    hipLaunchKernelGGL(convnext32_bwd_kernel<1>, grid, dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(convnext32_bwd_kernel<2>, grid, dim3(256), lds, st, a);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

@@ -85,6 +85,7 @@ struct ConvNeXt {
   PackedConv pw1, pw2;     // pw2.bias = b2eff (b2 + W2 . grn_beta)
   const float* w2a = nullptr;  // C == 32 only: chained-GEMM fragments
   const float* w1p = nullptr;
+  const float *w1_raw = nullptr, *w2_raw = nullptr;  // pwconv1.weight [4C][C], pwconv2.weight [C][4C] as bound
 };
 
 struct ResBlock32 {

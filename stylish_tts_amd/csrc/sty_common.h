@@ -187,6 +187,26 @@ struct Cnx32Args {
   int T, ntiles;
 };
 
+struct Cnx32BwdArgs {       // convnext_bwd.hip
+  const float* x;           // [B][32][T] block input
+  const float* gy;          // [B][32][T] gradient of the block output
+  const float *dw_w, *dw_b; // [32][7], [32]
+  const float* gb;          // [B][64] AdaLN fc(style): gamma | beta
+  const float* w1p;         // packed pwconv1 [32 ci][128 ch]
+  const float* w1;          // raw pwconv1.weight [128][32]
+  const float* w2;          // raw pwconv2.weight [32][128]
+  const float *b1, *alpha;  // [128]
+  const float* scale;       // [B][128] GRN scale of the forward
+  const float* coef;        // [B][128] (pass 2) d loss / d(sum_t h^2) folded: gH += coef h
+  double* part;             // [B][128][ntiles]  pass 1: ds partials, pass 2: d alpha partials
+  double* part_gb;          // [B][64][ntiles]   pass 2: d(gamma | beta) partials
+  float *hs, *gh0;          // [B][128][T] (pass 2) h*s and gH0: operands of the weight-gradient GEMMs
+  float *xn, *gu;           // [B][32][T]  (pass 2) normalised input, gradient of the depthwise-conv output
+  int T, ntiles;
+};
+int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st);
+int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mode, float* out, hipStream_t st);
+
 struct AttnArgs {
   const float* q;  // [B][H*DH][T]   (batch stride qbs floats)
   const float* k;

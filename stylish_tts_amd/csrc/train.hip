@@ -6,6 +6,7 @@
 // operands.  Each forward op pushes one closure; backward runs them in reverse.  Gradient buffers are zero-filled
 // when first requested and every backward kernel accumulates, which makes fan-out (residual streams) trivial.
 // Eval-mode semantics (BatchNorm running statistics, no dropout), matching the golden gradients of the oracle.
+#include <stdlib.h>
 #include <string.h>
 
 #include <unordered_map>
@@ -328,9 +329,106 @@ struct Trainer {
     return y;
   }
 
+  // GeneratorConvNeXtBlock at C = 32 (the nine blocks at the 75T frame rate): fused two-pass forward, recompute-based
+  // fused backward (convnext_bwd.hip); only x and the GRN statistics are kept between the two
+  float* convnext32_fused(const ConvNeXt& c, const float* x, int Tt) {
+    const int nt = convnext32_ntiles(Tt);
+    const size_t n32 = (size_t)B * 32 * Tt, n128 = (size_t)B * 128 * Tt;
+    double* part = take<double>((size_t)B * 128 * nt * 2);
+    float* scale = take<float>((size_t)B * 128);
+    float* y = take<float>(n32);
+    if (live()) {
+      Cnx32Args a;
+      a.x = x;
+      a.dw_w = c.dw_w;
+      a.dw_b = c.dw_b;
+      a.gb = gbp(c.norm);
+      a.w1p = c.w1p;
+      a.b1 = c.b1;
+      a.alpha = c.alpha;
+      a.w2a = c.w2a;
+      a.b2eff = c.pw2.bias;
+      a.scale = scale;
+      a.part = part;
+      a.y = y;
+      a.T = Tt;
+      a.ntiles = nt;
+      chk(launch_convnext32(a, B, 1, st));
+      chk(launch_grn_finalize(part, nt, c.grn_gamma, B, 128, scale, st));
+      chk(launch_convnext32(a, B, 2, st));
+    }
+    const float* gbl = gbp(c.norm);
+    float* dgl = dgbp(c.norm);
+    tape.push_back([=]() {
+      float* gY = G(y, n32);
+      // y = ... + x: the output gradient becomes (or is added to) the input's gradient
+      float* gX;
+      if (!gmap.count(x)) {
+        gmap[x] = gY;
+        gX = gY;
+      } else {
+        gX = G(x, n32);
+        if (live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, 1, (int)n32, gX, st));
+      }
+      const size_t mark = ws.off;
+      double* pds = take<double>((size_t)B * 128 * nt);
+      double* pgb = take<double>((size_t)B * 64 * nt);
+      float* ds = take<float>((size_t)B * 128);
+      float* coef = take<float>((size_t)B * 128);
+      float* hs = take<float>(n128);
+      float* gh0 = take<float>(n128);
+      float* xn = take<float>(n32);
+      float* gu = take<float>(n32);
+      Cnx32BwdArgs a;
+      a.x = x;
+      a.gy = gY;
+      a.dw_w = c.dw_w;
+      a.dw_b = c.dw_b;
+      a.gb = gbl;
+      a.w1p = c.w1p;
+      a.w1 = c.w1_raw;
+      a.w2 = c.w2_raw;
+      a.b1 = c.b1;
+      a.alpha = c.alpha;
+      a.scale = scale;
+      a.coef = coef;
+      a.part = pds;
+      a.part_gb = pgb;
+      a.hs = hs;
+      a.gh0 = gh0;
+      a.xn = xn;
+      a.gu = gu;
+      a.T = Tt;
+      a.ntiles = nt;
+      // weight gradients run on the K = 1 weight-gradient kernel: pw2 from (h s, gY), pw1 from (xn, gH0)
+      ConvArgs f2 = base(c.pw2, hs, Tt, nullptr);
+      ConvArgs f1 = base(c.pw1, xn, Tt, nullptr);
+      float* p2 = take<float>(wgrad_partial_floats(c.pw2, B, Tt));
+      float* p1 = take<float>(wgrad_partial_floats(c.pw1, B, Tt));
+      float* dsc = take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7));
+      if (live()) {
+        bool done = false;
+        chk(launch_convnext32_bwd(a, B, 1, st));
+        chk(launch_cnx_partial_sum(pds, B, 128, nt, 0, ds, st));
+        chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
+        chk(launch_convnext32_bwd(a, B, 2, st));
+        chk(launch_cnx_partial_sum(pds, B, 128, nt, 1, PG(c.alpha, 128), st));
+        chk(launch_cnx_partial_sum(pgb, B, 64, nt, 2, dgl, st));
+        chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, PGpacked(c.pw2.wp), p2, PGpacked(c.pw2.bias), &done, st));
+        chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, PGpacked(c.pw1.wp), p1, PGpacked(c.pw1.bias), &done, st));
+        // depthwise conv backward from gU; note gX may alias gY, which every kernel above has finished reading
+        chk(launch_dwconv_bwd(x, gu, c.dw_w, B, 32, Tt, 7, 3, gX, 1, PG(c.dw_w, 32 * 7), PG(c.dw_b, 32), dsc, st));
+      }
+      ws.off = mark;
+    });
+    return y;
+  }
+
   // GeneratorConvNeXtBlock (conv_next.py:80-93), any channel count
   float* convnext(const ConvNeXt& c, const float* x, int Tt) {
     const int C = c.C;
+    static const bool fuse32 = getenv("STY_NO_CNX_FUSED") == nullptr;
+    if (C == 32 && fuse32 && c.w2a && c.w1_raw && c.w2_raw) return convnext32_fused(c, x, Tt);
     float* u = dwconv(x, c.dw_w, c.dw_b, C, Tt, 7, 3);
     float* xn = layernorm(u, C, Tt, 1e-6f, &c.norm, nullptr, nullptr);
     float* h0 = take<float>((size_t)B * 4 * C * Tt);
