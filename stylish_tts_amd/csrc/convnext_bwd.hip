@@ -27,10 +27,34 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
   float* rstd_s = gys + 32 * LG;   // [256]
   float* red = rstd_s + 256;       // [4][128]
   float* red2 = red + 4 * 128;     // [4][64]
+  float* prm = red2 + 4 * 64;      // [4][128] b1, alpha, GRN scale, coef of this batch row (read as LDS broadcasts:
+                                   // as global loads inside the element loops they were 55 % of the wave cycles)
+  float* gbs = prm + 4 * 128;      // [64] 1 + gamma | beta of the AdaLN
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.y, t0 = blockIdx.x * CB_TT, T = a.T;
   const float* xb = a.x + (size_t)b * 32 * T;
   const float* gb_ = a.gy + (size_t)b * 32 * T;
+  // pass-2 outputs go through buffer descriptors of this batch row (32-bit offsets: the 64-bit per-row store
+  // addresses of the flat form cost ~80 spilled VGPRs)
+  __amdgpu_buffer_rsrc_t r_hs, r_g0, r_xn, r_gu;
+  if (PASS == 2) {
+    r_hs = __builtin_amdgcn_make_buffer_rsrc(a.hs + (size_t)b * 128 * T, 0, 128 * T * 4, 0x00020000);
+    r_g0 = __builtin_amdgcn_make_buffer_rsrc(a.gh0 + (size_t)b * 128 * T, 0, 128 * T * 4, 0x00020000);
+    r_xn = __builtin_amdgcn_make_buffer_rsrc(a.xn + (size_t)b * 32 * T, 0, 32 * T * 4, 0x00020000);
+    r_gu = __builtin_amdgcn_make_buffer_rsrc(a.gu + (size_t)b * 32 * T, 0, 32 * T * 4, 0x00020000);
+  }
+  auto bst = [](__amdgpu_buffer_rsrc_t rs, float v, int off) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
+  };
+  if (tid < 128) {
+    prm[tid] = a.b1[tid];
+    prm[128 + tid] = a.alpha[tid];
+    prm[256 + tid] = a.scale[b * 128 + tid];
+    prm[384 + tid] = PASS == 2 ? a.coef[b * 128 + tid] : 0.f;
+  } else if (tid < 192) {
+    const int c = tid - 128;
+    gbs[c] = c < 32 ? 1.f + a.gb[b * 64 + c] : a.gb[b * 64 + c];
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     float v[4][5], g[4][4];
@@ -85,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     for (int c = 0; c < 32; ++c) {
       const float xh = (u[c] - mean) * rstd;
       xs[c * LW + 3 + tid] = xh;
-      if (PASS == 2 && t < T) a.xn[((size_t)b * 32 + c) * T + t] = xh * (1.f + a.gb[b * 64 + c]) + a.gb[b * 64 + 32 + c];
+      if (PASS == 2 && t < T) bst(r_xn, fmaf(xh, gbs[c], gbs[32 + c]), (c * T + t) * 4);
     }
   }
   __syncthreads();
@@ -107,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
     for (int c2 = 0; c2 < 16; ++c2) {
       const int c = 2 * c2 + hi;
-      bx[c2] = fmaf(xs[c * LW + 3 + tl], 1.f + a.gb[b * 64 + c], a.gb[b * 64 + 32 + c]);
+      bx[c2] = fmaf(xs[c * LW + 3 + tl], gbs[c], gbs[32 + c]);
       by[c2] = gys[c * LG + tl];
     }
     f32x16 gxn;
@@ -137,24 +161,30 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float bias = a.b1[ch], al = a.alpha[ch], ral = 1.0f / al;
-        const float sc = a.scale[b * 128 + ch];
+        const float bias = prm[ch], al = prm[128 + ch], ral = 1.0f / al;
+        const float sc = prm[256 + ch];
         const float z = h[r] + bias;
-        const float s2 = sty_sin2(al * z);
+        float s2, s2a = 0.f;
+        if (PASS == 1) {
+          s2 = sty_sin2(al * z);
+        } else {  // sin^2 and sin(2 a z) = 2 sin cos from one range reduction
+          float sn, cs;
+          sty_sincos(al * z, sn, cs);
+          s2 = sn * sn;
+          s2a = 2.f * sn * cs;
+        }
         const float hv = fmaf(ral, s2, z);
         float rsum;
         if (PASS == 1) {
           rsum = ok ? uu[r] * hv : 0.f;
         } else {
-          const float cf = a.coef[b * 128 + ch];
+          const float cf = prm[384 + ch];
           const float gH = ok ? fmaf(uu[r], sc, cf * hv) : 0.f;
-          const float s2a = sty_sinf(2.f * al * z);
           const float g0 = gH * (1.f + s2a);
           rsum = gH * (z * s2a - s2 * ral) * ral;
           if (ok) {
-            const size_t o = ((size_t)b * 128 + ch) * T + t;
-            a.hs[o] = hv * sc;
-            a.gh0[o] = g0;
+            bst(r_hs, hv * sc, (ch * T + t) * 4);
+            bst(r_g0, g0, (ch * T + t) * 4);
           }
           h[r] = g0;
         }
@@ -183,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
         xh[r] = xs[c * LW + 3 + tl];
-        gxh[r] = gxn[r] * (1.f + a.gb[b * 64 + c]);
+        gxh[r] = gxn[r] * gbs[c];
         s1 += gxh[r];
         s2 = fmaf(gxh[r], xh[r], s2);
       }
@@ -195,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (ok) a.gu[((size_t)b * 32 + c) * T + t] = rs * (gxh[r] - s1 - xh[r] * s2);
+        if (ok) bst(r_gu, rs * (gxh[r] - s1 - xh[r] * s2), (c * T + t) * 4);
         float v = ok ? gxn[r] * xh[r] : 0.f, w = ok ? gxn[r] : 0.f;
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
@@ -258,7 +288,7 @@ int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mod
 }
 
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st) {
-  constexpr size_t lds = (32 * (CB_TT + 6) + 32 * (CB_TT + 1) + 256 + 4 * 128 + 4 * 64) * sizeof(float);
+  constexpr size_t lds = (32 * (CB_TT + 6) + 32 * (CB_TT + 1) + 256 + 4 * 128 + 4 * 64 + 4 * 128 + 64) * sizeof(float);
   static bool raised = false;
   if (!raised) {
     STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<1>),

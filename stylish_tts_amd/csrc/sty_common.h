@@ -279,6 +279,30 @@ __device__ __forceinline__ float sty_sin2(float x) {
   }
   return sty_sin2_fast(x);
 }
+// sin(x) and cos(x) from ONE range reduction (the Snake backward needs sin^2(a z) and sin(2 a z) = 2 sin cos)
+static __device__ __attribute__((noinline)) void sty_sincos_slow(float x, float& s, float& c) {
+  s = sinf(x);
+  c = cosf(x);
+}
+__device__ __forceinline__ void sty_sincos(float x, float& s, float& c) {
+  if (__builtin_expect(fabsf(x) > 8192.0f, 0)) {
+    sty_sincos_slow(x, s, c);
+    return;
+  }
+  const float kf = rintf(x * 0.636619772f);
+  const int k = (int)kf;
+  float r = fmaf(-kf, 1.57079637050628662109375f, x);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  r = fmaf(-kf, -1.71512449e-15f, r);
+  const float r2 = r * r;
+  const float ps = fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+  const float sr = fmaf(r * r2, ps, r);
+  const float pc = fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+  const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  const float sv = (k & 1) ? cr : sr, cv = (k & 1) ? sr : cr;
+  s = (k & 2) ? -sv : sv;
+  c = ((k + 1) & 2) ? -cv : cv;
+}
 // Snake: v + sin^2(alpha v) / alpha   (conv_next.py:78, ada_norm.py:114)
 __device__ __forceinline__ float sty_snake(float v, float alpha, float ralpha) {
   return fmaf(ralpha, sty_sin2(alpha * v), v);
