@@ -19,9 +19,20 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
   constexpr int LW = CNX_TT + 6;
   __shared__ __attribute__((aligned(16))) float xs[32 * LW];
   __shared__ float red[4][128];
+  __shared__ float prm[3][128];  // b1, alpha, GRN scale of this batch row: LDS broadcasts instead of global loads in
+                                 // the element loops
+  __shared__ float gbs[64];      // 1 + gamma | beta of the AdaLN
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.y, t0 = blockIdx.x * CNX_TT, T = a.T;
   const float* xb = a.x + (size_t)b * 32 * T;
+  if (tid < 128) {
+    prm[0][tid] = a.b1[tid];
+    prm[1][tid] = a.alpha[tid];
+    prm[2][tid] = PASS2 ? a.scale[b * 128 + tid] : 1.f;
+  } else if (tid < 192) {
+    const int c = tid - 128;
+    gbs[c] = c < 32 ? 1.f + a.gb[b * 64 + c] : a.gb[b * 64 + c];
+  }
 
   // stage raw x tile with 3-sample halo, zero outside [0,T)
   // (each wave: 8 rows x 5 column chunks; 4 rows = 20 loads are put in flight before the first LDS store)
@@ -70,8 +81,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
     __syncthreads();  // all taps read before the tile is overwritten in place
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
-      const float g = 1.f + a.gb[b * 64 + c], be = a.gb[b * 64 + 32 + c];
-      xs[c * LW + 3 + tid] = (u[c] - mean) * rstd * g + be;
+      xs[c * LW + 3 + tid] = (u[c] - mean) * rstd * gbs[c] + gbs[32 + c];
     }
   }
   __syncthreads();
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float bias = a.b1[ch], al = a.alpha[ch];
+      const float bias = prm[0][ch], al = prm[1][ch];
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         h[n][r] += bias;
@@ -125,10 +135,9 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float al = a.alpha[ch];
+      const float al = prm[1][ch];
       const float ral = __builtin_amdgcn_rcpf(al);
-      float sc = 1.f;
-      if (PASS2) sc = a.scale[b * 128 + ch];
+      const float sc = prm[2][ch];
       float s2 = 0.f;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
