@@ -38,6 +38,85 @@ struct Trainer {
   void chk(int r) {
     if (rc == STY_OK && r != STY_OK) rc = r;
   }
+
+  // ---- side stream for the weight gradients ----
+  // A weight gradient is a leaf of the backward graph: it reads (x, gY) and nothing reads it before the optimizer.
+  // On the sample_dataset shapes the input-gradient chain is a sequence of kernels too small to fill 256 CUs, so the
+  // weight-gradient kernels (512-1024 workgroups each) run on a second, lower-priority stream and take the idle CUs.
+  // Ordering: the side stream waits for the main stream's position before every launch (gY complete); the main
+  // stream waits for a side-stream reader only when it is about to write a buffer that reader uses, which happens
+  // when a gradient buffer is shared through the residual aliasing below (G / Gw check side_reads on every lookup
+  // of an existing buffer); backward() joins the two streams after the tape.  The side stream has its own partial-sum
+  // buffer (side_partial, sized in the forward for the largest conv) since the main stream recycles its temporaries.
+  hipStream_t st2 = nullptr;
+  bool side_on = getenv("STY_NO_SIDE_STREAM") == nullptr;
+  std::vector<hipEvent_t> evs;
+  size_t ev_used = 0;
+  std::unordered_map<const float*, size_t> side_reads;  // buffer -> event recorded after its last side-stream reader
+  bool side_dirty = false;
+  size_t side_need = 0;  // floats
+  float* side_partial = nullptr;
+  ~Trainer() {
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (st2) (void)hipStreamDestroy(st2);
+  }
+  hipEvent_t next_event() {
+    if (ev_used == evs.size()) {
+      hipEvent_t e = nullptr;
+      hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      if (r != hipSuccess) rc = hip_fail(r, "event");
+      evs.push_back(e);
+    }
+    return evs[ev_used++];
+  }
+  void side_begin() {
+    ev_used = 0;
+    side_reads.clear();
+    side_dirty = false;
+    side_partial = side_on && side_need ? take<float>(side_need) : nullptr;
+    if (side_on && !st2 && live()) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      hipError_t r = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, least);
+      if (r != hipSuccess) rc = hip_fail(r, "side stream");
+    }
+  }
+  // stream for a weight-gradient launch that reads the current state of the main stream
+  hipStream_t side_fork() {
+    if (!side_on || !st2 || !live()) return st;
+    hipEvent_t e = next_event();
+    if (rc != STY_OK) return st;
+    hipError_t r = hipEventRecord(e, st);
+    if (r == hipSuccess) r = hipStreamWaitEvent(st2, e, 0);
+    if (r != hipSuccess) rc = hip_fail(r, "side fork");
+    return st2;
+  }
+  void side_done(hipStream_t s, const float* gbuf) {
+    if (s == st || !live()) return;
+    hipEvent_t e = next_event();
+    if (rc != STY_OK) return;
+    hipError_t r = hipEventRecord(e, st2);
+    if (r != hipSuccess) rc = hip_fail(r, "side record");
+    side_reads[gbuf] = ev_used - 1;
+    side_dirty = true;
+  }
+  void side_wait(const float* gbuf) {
+    if (side_reads.empty()) return;
+    auto it = side_reads.find(gbuf);
+    if (it == side_reads.end()) return;
+    hipError_t r = hipStreamWaitEvent(st, evs[it->second], 0);
+    if (r != hipSuccess) rc = hip_fail(r, "side wait");
+    side_reads.erase(it);
+  }
+  void side_join() {
+    if (!side_dirty || !st2) return;
+    hipEvent_t e = next_event();
+    hipError_t r = hipEventRecord(e, st2);
+    if (r == hipSuccess) r = hipStreamWaitEvent(st, e, 0);
+    if (r != hipSuccess) rc = hip_fail(r, "side join");
+    side_reads.clear();
+    side_dirty = false;
+  }
   const float* gbp(const AdaFc& a) const { return gb ? gb + a.off * B : nullptr; }
   float* dgbp(const AdaFc& a) const { return dgb ? dgb + a.off * B : nullptr; }
 
@@ -50,7 +129,10 @@ struct Trainer {
   // gradient buffer of an activation (zero-filled on first request)
   float* G(const float* act, size_t n) {
     auto it = gmap.find(act);
-    if (it != gmap.end()) return it->second;
+    if (it != gmap.end()) {
+      side_wait(it->second);
+      return it->second;
+    }
     float* g = take<float>(n);
     if (live()) {
       hipError_t e = hipMemsetAsync(g, 0, n * sizeof(float), st);
@@ -65,6 +147,7 @@ struct Trainer {
     auto it = gmap.find(act);
     if (it != gmap.end()) {
       acc = 1;
+      side_wait(it->second);
       return it->second;
     }
     float* g = take<float>(n);
@@ -100,6 +183,8 @@ struct Trainer {
 
   // ---------------- ops ----------------
   void conv(const ConvArgs& a) {
+    const size_t pn = wgrad_partial_floats(a.w, B, a.T);
+    side_need = pn > side_need ? pn : side_need;
     if (live()) chk(launch_conv1d(a, st));
     ConvArgs f = a;
     tape.push_back([this, f]() { conv_bwd(f); });
@@ -155,11 +240,16 @@ struct Trainer {
         chk(launch_row_scale_add(gY, nullptr, 1.0f, B * w.Cout, Tt, gR, st));
     }
     // weight gradient; the bias gradient is a by-product of the same pass over gY for K <= 12
-    float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
+    float* partial = side_partial ? side_partial : take<float>(wgrad_partial_floats(w, B, Tt));
     bool bias_done = false;
-    if (live())
+    if (live()) {
+      hipStream_t sw = side_partial ? side_fork() : st;
       chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, w.bias ? PGpacked(w.bias) : nullptr,
-                              &bias_done, st));
+                              &bias_done, sw));
+      side_done(sw, gY);
+      for (int i = 0; i < f.nsrc; ++i)
+        if (gX[i] == gY) side_wait(gY);  // y = conv(x) + x with the shared buffer: the input gradient lands in gY
+    }
     if (w.bias && !bias_done) {
       float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, Tt));
       if (live()) chk(launch_bias_grad(gY, gmask, B, w.Cout, Tt, f.shuffle, f.out_scale, PGpacked(w.bias), bs, st));
@@ -898,6 +988,8 @@ struct Trainer {
     a.out_mask = mask;
     a.out_mask_post = 1;
     a.y = y;
+    const size_t pn = wgrad_partial_floats(w, B, n);
+    side_need = pn > side_need ? pn : side_need;
     if (live()) chk(launch_conv1d(a, st));
     tape.push_back([this, a]() { conv2d_bwd(a); });
   }
@@ -915,11 +1007,15 @@ struct Trainer {
     if (gR && live())
       chk(launch_pro_bwd(PRO_MASK, gY, w.Cout, 0, gY, B, w.Cout, n, nullptr, nullptr, w.Cout, 0, nullptr, f.out_mask,
                          gR, 1, nullptr, nullptr, nullptr, st));
-    float* partial = take<float>(wgrad_partial_floats(w, B, n));
+    float* partial = side_partial ? side_partial : take<float>(wgrad_partial_floats(w, B, n));
     bool bias_done = false;
-    if (live())
+    if (live()) {
+      hipStream_t sw = side_partial ? side_fork() : st;
       chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, PGpacked(w.wp), partial,
-                              w.bias ? PGpacked(w.bias) : nullptr, &bias_done, st));
+                              w.bias ? PGpacked(w.bias) : nullptr, &bias_done, sw));
+      side_done(sw, gY);
+      if (gX == gY) side_wait(gY);
+    }
     if (w.bias && !bias_done) {
       float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, n));
       if (live()) chk(launch_bias_grad(gY, f.out_mask, B, w.Cout, n, 0, f.out_scale, PGpacked(w.bias), bs, st));
@@ -1070,6 +1166,7 @@ struct Trainer {
   }
   void style_backward(const float* d_style) {
     const size_t n = (size_t)B * m->sty_enc.style_dim;
+    side_begin();
     float* g = G(style_out, n);
     if (live() && d_style) {
       hipError_t e = hipMemcpyAsync(g, d_style, n * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1077,12 +1174,14 @@ struct Trainer {
     }
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
       (*it)();
-      if (rc != STY_OK) return;
+      if (rc != STY_OK) break;
     }
+    side_join();
   }
 
   void begin(const float* style_in) {
     style = style_in;
+    side_need = 0;
     drop_site = 0;
     tape.clear();
     gmap.clear();
@@ -1190,6 +1289,7 @@ struct Trainer {
   void backward(const float* d_audio, float* d_mel, float* d_style) {
     // seed: gradient of the audio
     const size_t na = (size_t)B * 300 * T;
+    side_begin();
     float* gA = G(audio, na);
     if (live() && d_audio) {
       hipError_t e = hipMemcpyAsync(gA, d_audio, na * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1199,8 +1299,10 @@ struct Trainer {
     if (d_mel == reinterpret_cast<float*>(2)) d_mel = nullptr;  // speech graph: mel is an internal activation
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
       (*it)();
-      if (rc != STY_OK) return;
+      if (rc != STY_OK) break;
     }
+    side_join();
+    if (rc != STY_OK) return;
     // fc(style) backward for every AdaIN / AdaLN layer
     if (live() && !m->fcs.empty()) {
       if (d_style) {
@@ -1308,6 +1410,7 @@ int trainer_style_forward(Trainer* t, int B, int T, const float* mel, float* sty
   t->ws.base = need ? reinterpret_cast<char*>(size_t(1) << 30) : (char*)ws;
   t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
   t->peak = 0;
+  t->side_need = 0;
   t->style_forward(need ? reinterpret_cast<const float*>(8) : mel, T, need ? reinterpret_cast<float*>(16) : style);
   if (need) {
     if (t->rc == STY_OK) t->style_backward(nullptr);

@@ -8,6 +8,8 @@
 // time chunk when K == 1.  Each workgroup walks its share of the (b, chunk) list keeping the accumulators in
 // registers and writes ONE partial result; a second kernel sums the partials in a fixed order (deterministic, no
 // float atomics) into the packed gradient.
+#include <stdlib.h>
+
 #include "conv_stage.h"
 
 namespace sty {
@@ -163,6 +165,147 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
       }
     }
   }
+}
+
+// ---- 2 <= K <= KN taps, Cin and Cout >= 64: a workgroup owns a 64 (ci) x 64 (co) block of dW for ALL taps ----
+// The general kernel above gives a workgroup one 32x32 tile and splits the taps over its waves: for K = 3 one wave idles
+// and each staged pair of 32-row tiles feeds 64 MFMAs per wave (34-49 TFLOP/s on the style encoder's 3x3 convs).
+// Here the four waves form a 2x2 grid over the block, every wave runs all K taps on its 32x32 tile against G fragments
+// held in registers: K x 64 MFMAs per wave and chunk from 2x the staged rows.
+template <int KN>
+__global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
+                                                               float* __restrict__ partial, int want_bias) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
+            hi = lane >> 5;
+  const int wi = wave >> 1, wo = wave & 1;
+  const int K = ax.w.K, dil = ax.dil;
+  const int halo = (K - 1) * dil;
+  const int LWx = (WG_TW + halo) | 1, LWg = WG_TW + 1;
+  float* xs = lds;                 // [64][LWx]
+  float* gs = lds + 64 * LWx;      // [64][LWg]
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+  f32x16 acc[KN];
+#pragma unroll
+  for (int i = 0; i < KN; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const bool do_bias = want_bias && blockIdx.x == 0;
+  float bsum[2][4][2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) bsum[hh][it][0] = bsum[hh][it][1] = 0.f;
+  const int total = ax.B * chunks_per_b;
+  constexpr int MAXJ = (WG_TW + 64 + 1 + 63) / 64;  // halo <= 64 (checked by the launcher)
+  constexpr int MAXJG = (WG_TW + 1 + 63) / 64;
+  const int xmode = stage_mode(ax), gmode = stage_mode(ag);
+  for (int ch = split; ch < total; ch += nsplit) {
+    const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
+    const float* xb = stage_base(ax, b);
+    const float* gb = stage_base(ag, b);
+    float mk[MAXJG];
+    if (ag.pro == PRO_MASK) {
+#pragma unroll
+      for (int q = 0; q < MAXJG; ++q) {
+        const int t = t0 + lane + 64 * q;
+        mk[q] = (t < ag.T && lane + 64 * q < LWg) ? ag.mask[(size_t)b * ag.T + t] : 0.f;
+      }
+    }
+    __syncthreads();  // previous chunk's MFMAs are done with the tiles
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {  // two 32-row halves of each tile, all rows of a half in flight at once
+      StageRegs<4, MAXJ> Rx;
+      StageRegs<4, MAXJG> Rg;
+#define STY_LX(MODE) stage_load<4, MAXJ, MODE, WG_TW>(ax, xb, ci0 + 32 * hh, b, 0, t0, LWx, wave, lane, Rx)
+      STY_STAGE_DISPATCH(xmode, STY_LX);
+#undef STY_LX
+      if (gmode == ST_SIMPLE)
+        stage_load<4, MAXJG, ST_SIMPLE, WG_TW>(ag, gb, co0 + 32 * hh, b, 0, t0, LWg, wave, lane, Rg);
+      else
+        stage_load<4, MAXJG, ST_GENERIC, WG_TW>(ag, gb, co0 + 32 * hh, b, 0, t0, LWg, wave, lane, Rg);
+      float* xh = xs + hh * 32 * LWx;
+      float* gh = gs + hh * 32 * LWg;
+      switch (ax.pro) {
+        case PRO_AFFINE: stage_store<PRO_AFFINE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_SCALE: stage_store<PRO_SCALE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_AFFINE_SNAKE: stage_store<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_AFFINE_LRELU: stage_store<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_MASK: stage_store<PRO_MASK, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
+        case PRO_LRELU: stage_store<PRO_LRELU, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
+        default: stage_store<PRO_NONE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
+      }
+      if (ag.pro == PRO_MASK)
+        stage_store<PRO_MASK, 4, MAXJG>(ag, gh, co0 + 32 * hh, b, t0, LWg, wave, lane, Rg, mk);
+      else
+        stage_store<PRO_NONE, 4, MAXJG>(ag, gh, co0 + 32 * hh, b, t0, LWg, wave, lane, Rg);
+      if (do_bias) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < MAXJG; ++q)
+              if (lane + 64 * q < WG_TW)
+                bsum[hh][it][u] = fmaf(Rg.vv[it][u][q], ag.pro == PRO_MASK ? mk[q] : 1.f, bsum[hh][it][u]);
+      }
+    }
+    __syncthreads();
+    float af[WG_TW / 2];
+    const float* gr = gs + (wo * 32 + l31) * LWg + hi;
+#pragma unroll
+    for (int q = 0; q < WG_TW / 2; ++q) af[q] = gr[2 * q];
+    const float* xr0 = xs + (wi * 32 + l31) * LWx + hi;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      if (k < K) {
+        const float* xr = xr0 + k * dil;
+#pragma unroll
+        for (int q = 0; q < WG_TW / 2; ++q)
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[k], 0, 0, 0);
+      }
+    }
+  }
+  const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;
+  const size_t plane = (size_t)K * CinP * CoutP;
+  const size_t stride = plane + CoutP;
+  if (do_bias) {
+    float* pb = partial + (size_t)split * stride + plane;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float v = bsum[hh][it][u];
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          const int co = co0 + 32 * hh + wave + 8 * it + 4 * u;
+          if (lane == 0 && co < CoutP) pb[co] = v;
+        }
+  }
+  float* p = partial + (size_t)split * stride;
+  const int ci = ci0 + wi * 32 + l31;
+#pragma unroll
+  for (int k = 0; k < KN; ++k) {
+    if (k < K && ci < CinP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co < CoutP) p[((size_t)k * CinP + ci) * CoutP + co] = acc[k][r];
+      }
+    }
+  }
+}
+static bool wgrad64_ok(const PackedConv& w, int dil) {
+  static const bool on = getenv("STY_NO_WGRAD64") == nullptr;
+  return on && w.K >= 2 && w.K <= 5 && w.CinP >= 64 && w.CoutP >= 64 && (w.K - 1) * dil <= 64;
+}
+static int wgrad64_nsplit(const PackedConv& w, int B, int T) {
+  const int tiles = cdiv(w.CinP, 64) * cdiv(w.CoutP, 64);
+  const int chunks = B * cdiv(T, WG_TW);
+  int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
+  if (nsplit > chunks) nsplit = chunks;
+  return nsplit;
 }
 
 // ---- K == 1 (Linear / 1x1 conv) weight gradient: dW[co][ci] = sum_{b,t} G[co][t] x[ci][t] ----
@@ -365,11 +508,14 @@ static void launch_wgrad_reduce(const float* partial, int nslices, size_t plane,
 
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x output rows in 2-D mode
   if (w.K == 1) return (size_t)w1_nsplit(w, B, T, w1_cfg(w, B, T)) * ((size_t)w.CinP * w.CoutP + w.CoutP);
+  size_t n64 = 0;
+  if (wgrad64_ok(w, 1)) n64 = (size_t)wgrad64_nsplit(w, B, T) * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks = B * cdiv(T, WG_TW);
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);  // few tiles: keep the partial planes small
   if (nsplit > chunks) nsplit = chunks;
-  return (size_t)nsplit * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
+  const size_t n32 = (size_t)nsplit * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
+  return n32 > n64 ? n32 : n64;
 }
 
 // ax: forward ConvArgs (sources, prologue, dil, pad, w); g: output gradient [B][Cout][T] (shuffled when ax.shuffle > 1);
@@ -428,6 +574,36 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     else
       hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
     const size_t plane = (size_t)w.CinP * w.CoutP;
+    launch_wgrad_reduce(partial, nsplit, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+    if (bias_done) *bias_done = wb != 0;
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
+  if (wgrad64_ok(w, fwd.dil)) {
+    const int nsplit = wgrad64_nsplit(w, fwd.B, fwd.T);
+    const int cpb = cdiv(fwd.T, WG_TW);
+    const int halo = (w.K - 1) * fwd.dil;
+    const size_t lds = ((size_t)64 * ((WG_TW + halo) | 1) + (size_t)64 * (WG_TW + 1)) * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_wgrad64_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_wgrad64_kernel<5>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+      raised = true;
+    }
+    dim3 grid(cdiv(w.CinP, 64), cdiv(w.CoutP, 64), nsplit);
+    char detail[40], fam[48];
+    snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
+    snprintf(fam, sizeof(fam), "conv1d_wgrad64_kernel<%d>", w.K <= 3 ? 3 : 5);
+    ProfScope prof(fam, 2.0 * w.Cin * w.K * (double)fwd.B * w.Cout * fwd.T,
+                   4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T), st, detail);
+    const int wb = gbias != nullptr;
+    if (w.K <= 3)
+      hipLaunchKernelGGL((conv1d_wgrad64_kernel<3>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
+    else
+      hipLaunchKernelGGL((conv1d_wgrad64_kernel<5>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
+    const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
     launch_wgrad_reduce(partial, nsplit, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
     if (bias_done) *bias_done = wb != 0;
     STY_LAUNCH_CHECK();
