@@ -236,6 +236,8 @@ int launch_istft64_bwd(int B, int F, const float* audio, const float* daudio, co
                        const float* imag, const float* bbr, const float* bbi, float* dlogamp, float* dreal,
                        float* dimag, hipStream_t st);
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T);
+// whether launch_conv1d_wgrad produces the bias gradient as a by-product (every kernel for K <= 12 does)
+inline bool wgrad_fuses_bias(const PackedConv& w) { return w.K <= 12; }
 int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask, float scale, float* gwp,
                         float* partial, float* gbias, bool* bias_done, hipStream_t st);
 int launch_pack_dgrad(const float* wp, int K, int CinP, int CoutP, float* wd, hipStream_t st);

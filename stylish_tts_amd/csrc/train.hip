@@ -43,16 +43,21 @@ struct Trainer {
   // A weight gradient is a leaf of the backward graph: it reads (x, gY) and nothing reads it before the optimizer.
   // On the sample_dataset shapes the input-gradient chain is a sequence of kernels too small to fill 256 CUs, so the
   // weight-gradient kernels (512-1024 workgroups each) run on a second, lower-priority stream and take the idle CUs.
-  // Ordering: the side stream waits for the main stream's position before every launch (gY complete); the main
-  // stream waits for a side-stream reader only when it is about to write a buffer that reader uses, which happens
-  // when a gradient buffer is shared through the residual aliasing below (G / Gw check side_reads on every lookup
-  // of an existing buffer); backward() joins the two streams after the tape.  The side stream has its own partial-sum
-  // buffer (side_partial, sized in the forward for the largest conv) since the main stream recycles its temporaries.
+  // Launches can be queued and handed over SIDE_BATCH at a time (one event on the main stream per batch); measured,
+  // handing each launch over at once is best (c2 step 46.9 ms at 1, 47.5 at 4, 49.0 at 16: the weight gradient then
+  // overlaps the input gradient of its own layer, a kernel of the same size class).  The side stream only ever waits for the main
+  // stream; the main stream never waits for the side stream before the join at the end of the tape, because a
+  // gradient buffer with a side-stream reader is never written again: when G / Gw find such a buffer (it can only
+  // be written again through the residual aliasing below) they hand out a copy instead (copy on write).
+  // The side stream has its own partial-sum buffer (side_partial, sized in the forward for the largest conv): the
+  // main stream recycles its temporaries while the queued launches are still pending.
+  size_t SIDE_BATCH = getenv("STY_SIDE_BATCH") ? atoi(getenv("STY_SIDE_BATCH")) : 1;
   hipStream_t st2 = nullptr;
   bool side_on = getenv("STY_NO_SIDE_STREAM") == nullptr;
   std::vector<hipEvent_t> evs;
   size_t ev_used = 0;
-  std::unordered_map<const float*, size_t> side_reads;  // buffer -> event recorded after its last side-stream reader
+  std::unordered_set<const float*> side_reads;  // buffers read by a queued or running side-stream launch
+  std::vector<std::function<void(hipStream_t)>> side_q;
   bool side_dirty = false;
   size_t side_need = 0;  // floats
   float* side_partial = nullptr;
@@ -72,6 +77,7 @@ struct Trainer {
   void side_begin() {
     ev_used = 0;
     side_reads.clear();
+    side_q.clear();
     side_dirty = false;
     side_partial = side_on && side_need ? take<float>(side_need) : nullptr;
     if (side_on && !st2 && live()) {
@@ -81,41 +87,51 @@ struct Trainer {
       if (r != hipSuccess) rc = hip_fail(r, "side stream");
     }
   }
-  // stream for a weight-gradient launch that reads the current state of the main stream
-  hipStream_t side_fork() {
-    if (!side_on || !st2 || !live()) return st;
-    hipEvent_t e = next_event();
-    if (rc != STY_OK) return st;
-    hipError_t r = hipEventRecord(e, st);
-    if (r == hipSuccess) r = hipStreamWaitEvent(st2, e, 0);
-    if (r != hipSuccess) rc = hip_fail(r, "side fork");
-    return st2;
+  bool side_ready() const { return side_partial != nullptr; }  // also in the sizing pass (same allocations)
+  // queue a launch that reads gbuf (complete on the main stream at this point) and nothing the main stream writes later
+  void side_push(const float* gbuf, std::function<void(hipStream_t)> fn) {
+    side_reads.insert(gbuf);
+    if (!live() || !st2) return;
+    side_q.push_back(std::move(fn));
+    if (side_q.size() >= SIDE_BATCH) side_flush();
   }
-  void side_done(hipStream_t s, const float* gbuf) {
-    if (s == st || !live()) return;
+  void side_flush() {
+    if (side_q.empty()) return;
     hipEvent_t e = next_event();
-    if (rc != STY_OK) return;
-    hipError_t r = hipEventRecord(e, st2);
-    if (r != hipSuccess) rc = hip_fail(r, "side record");
-    side_reads[gbuf] = ev_used - 1;
+    if (rc == STY_OK) {
+      hipError_t r = hipEventRecord(e, st);
+      if (r == hipSuccess) r = hipStreamWaitEvent(st2, e, 0);
+      if (r != hipSuccess) rc = hip_fail(r, "side fork");
+    }
+    if (rc == STY_OK)
+      for (auto& fn : side_q) fn(st2);
+    side_q.clear();
     side_dirty = true;
   }
-  void side_wait(const float* gbuf) {
-    if (side_reads.empty()) return;
-    auto it = side_reads.find(gbuf);
-    if (it == side_reads.end()) return;
-    hipError_t r = hipStreamWaitEvent(st, evs[it->second], 0);
-    if (r != hipSuccess) rc = hip_fail(r, "side wait");
-    side_reads.erase(it);
-  }
   void side_join() {
-    if (!side_dirty || !st2) return;
-    hipEvent_t e = next_event();
-    hipError_t r = hipEventRecord(e, st2);
-    if (r == hipSuccess) r = hipStreamWaitEvent(st, e, 0);
-    if (r != hipSuccess) rc = hip_fail(r, "side join");
+    side_flush();
+    if (side_dirty && st2) {
+      hipEvent_t e = next_event();
+      hipError_t r = hipEventRecord(e, st2);
+      if (r == hipSuccess) r = hipStreamWaitEvent(st, e, 0);
+      if (r != hipSuccess) rc = hip_fail(r, "side join");
+    }
     side_reads.clear();
     side_dirty = false;
+  }
+  // copy on write of a gradient buffer the side stream reads
+  float* side_cow(const float* act, float* g, size_t n) {
+    if (side_reads.empty() || !side_reads.count(g)) return g;
+    return fresh_copy(act, g, n);
+  }
+  float* fresh_copy(const float* act, float* g, size_t n) {
+    float* g2 = take<float>(n);
+    if (live()) {
+      hipError_t e = hipMemcpyAsync(g2, g, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "grad copy");
+    }
+    gmap[act] = g2;
+    return g2;
   }
   const float* gbp(const AdaFc& a) const { return gb ? gb + a.off * B : nullptr; }
   float* dgbp(const AdaFc& a) const { return dgb ? dgb + a.off * B : nullptr; }
@@ -129,10 +145,7 @@ struct Trainer {
   // gradient buffer of an activation (zero-filled on first request)
   float* G(const float* act, size_t n) {
     auto it = gmap.find(act);
-    if (it != gmap.end()) {
-      side_wait(it->second);
-      return it->second;
-    }
+    if (it != gmap.end()) return side_cow(act, it->second, n);
     float* g = take<float>(n);
     if (live()) {
       hipError_t e = hipMemsetAsync(g, 0, n * sizeof(float), st);
@@ -147,8 +160,7 @@ struct Trainer {
     auto it = gmap.find(act);
     if (it != gmap.end()) {
       acc = 1;
-      side_wait(it->second);
-      return it->second;
+      return side_cow(act, it->second, n);
     }
     float* g = take<float>(n);
     gmap[act] = g;
@@ -215,6 +227,9 @@ struct Trainer {
     for (int i = 1; i < f.nsrc; ++i)
       for (int j = 0; j < i; ++j)
         if (gX[i] && gX[i] == gX[j]) accX[i] = 1;
+    if (side_ready())  // y = conv(x) + x sharing one buffer: the side stream reads gY, the input gradient needs its own
+      for (int i = 0; i < f.nsrc; ++i)
+        if (gX[i] && gX[i] == gY) gX[i] = fresh_copy(f.x[i], gY, (size_t)B * f.xc[i] * Tt);
     float* dpa = nullptr;
     float* dps = nullptr;
     float* dal = nullptr;
@@ -240,15 +255,17 @@ struct Trainer {
         chk(launch_row_scale_add(gY, nullptr, 1.0f, B * w.Cout, Tt, gR, st));
     }
     // weight gradient; the bias gradient is a by-product of the same pass over gY for K <= 12
-    float* partial = side_partial ? side_partial : take<float>(wgrad_partial_floats(w, B, Tt));
     bool bias_done = false;
-    if (live()) {
-      hipStream_t sw = side_partial ? side_fork() : st;
-      chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, w.bias ? PGpacked(w.bias) : nullptr,
-                              &bias_done, sw));
-      side_done(sw, gY);
-      for (int i = 0; i < f.nsrc; ++i)
-        if (gX[i] == gY) side_wait(gY);  // y = conv(x) + x with the shared buffer: the input gradient lands in gY
+    float* gbias = w.bias ? PGpacked(w.bias) : nullptr;
+    if (side_ready()) {
+      float* sp = side_partial;
+      float* gwp = PGpacked(w.wp);
+      const float osc = f.out_scale;
+      side_push(gY, [=](hipStream_t s) { chk(launch_conv1d_wgrad(f, gY, gmask, osc, gwp, sp, gbias, nullptr, s)); });
+      bias_done = wgrad_fuses_bias(w);
+    } else {
+      float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
+      if (live()) chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, gbias, &bias_done, st));
     }
     if (w.bias && !bias_done) {
       float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, Tt));
@@ -1001,20 +1018,26 @@ struct Trainer {
     float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
     int accX = 1;
     float* gX = wants(f.x[0]) ? Gw(f.x[0], nx, accX) : nullptr;
+    if (side_ready() && gX && gX == gY) gX = fresh_copy(f.x[0], gY, nx);
     const size_t mark = ws.off;
     // gY may carry values in the pad columns (written by element-wise backward steps): everything below sees
     // gY * mask, exactly as the forward stored y * mask
     if (gR && live())
       chk(launch_pro_bwd(PRO_MASK, gY, w.Cout, 0, gY, B, w.Cout, n, nullptr, nullptr, w.Cout, 0, nullptr, f.out_mask,
                          gR, 1, nullptr, nullptr, nullptr, st));
-    float* partial = side_partial ? side_partial : take<float>(wgrad_partial_floats(w, B, n));
     bool bias_done = false;
-    if (live()) {
-      hipStream_t sw = side_partial ? side_fork() : st;
-      chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, PGpacked(w.wp), partial,
-                              w.bias ? PGpacked(w.bias) : nullptr, &bias_done, sw));
-      side_done(sw, gY);
-      if (gX == gY) side_wait(gY);
+    float* gbias = w.bias ? PGpacked(w.bias) : nullptr;
+    if (side_ready()) {
+      float* sp = side_partial;
+      float* gwp = PGpacked(w.wp);
+      side_push(gY, [=](hipStream_t s) {
+        chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, gwp, sp, gbias, nullptr, s));
+      });
+      bias_done = wgrad_fuses_bias(w);
+    } else {
+      float* partial = take<float>(wgrad_partial_floats(w, B, n));
+      if (live())
+        chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, PGpacked(w.wp), partial, gbias, &bias_done, st));
     }
     if (w.bias && !bias_done) {
       float* bs = take<float>(bias_grad_scratch_floats(B, w.Cout, n));

@@ -15,7 +15,7 @@
 namespace sty {
 
 constexpr int WG_TW = 128;      // time samples per chunk
-constexpr int WG_TARGET = 1024;  // workgroups per launch aimed at (4 per CU): the (batch, time) list is split to get there
+static const int WG_TARGET = getenv("STY_WG_TARGET") ? atoi(getenv("STY_WG_TARGET")) : 1024;  // workgroups per launch aimed at (4 per CU): the (batch, time) list is split to get there
 
 template <int KT>  // taps per wave (K <= 4*KT); K == 1 runs on wgrad_k1_kernel below
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
