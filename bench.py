@@ -12,7 +12,9 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       off (third-party models); module.train() behaviour (BatchNorm batch statistics, spectral-norm
       power iteration, random Decoder smoothing, TextEncoder dropout).
   c2-fwd: the forward half only (AcousticStep forward + the six multi-spectrogram lists).
-  c3-fp32: LJSpeech shape, B=32, T=520, L=100, the same training step in fp32 (the bf16 variant is not built).
+  c3: LJSpeech shape, B=32, T=520, L=100, the same training step with bf16 operands on the dense convs / Linears
+      (fp32 accumulation, storage, norms, attention and losses: SURVEY.md 8(d) "bf16 autocast for conv/GEMM").
+  c3-fp32: the same shape entirely in fp32.
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
@@ -32,6 +34,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     "c2": dict(B=16, T=160, L=37, what="train"),
     "c2-fwd": dict(B=16, T=160, L=37, what="forward"),
+    "c3": dict(B=32, T=520, L=100, what="train", compute="bf16"),
     "c3-fp32": dict(B=32, T=520, L=100, what="train"),
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
 }
@@ -41,6 +44,7 @@ PASS = {
     "vocoder": "vocoder forward only (inference)",
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -229,7 +233,9 @@ def main():
     mspec = MultiSpectrogram(sample_rate=24000)
     inp = make_inputs(w, 1000 + rank, device)
     B, T = w["B"], w["T"]
-    trainer = AcousticTrainer(model, style_enc, lr=1e-4) if w["what"] == "train" else None
+    bf16 = w.get("compute") == "bf16"
+    trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"))
+               if w["what"] == "train" else None)
 
     def step(i):
         if w["what"] == "train":
@@ -270,7 +276,7 @@ def main():
         "metric": "audio frames/sec/GPU (24 kHz) forward+backward; DDP scaling 1/2/4/8 MI355X",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "bf16 GEMM operands, f32 accumulation/storage" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
                    "pass": PASS[w["what"]],
                    "x_realtime": frames / dt / 80.0},
@@ -281,8 +287,10 @@ def main():
         per = dom["ms"] / dom["launches"] * 1e-3
         tf = dom["flops"] / dom["launches"] / per / 1e12
         gbs = dom["bytes"] / dom["launches"] / per / 1e9
-        rec["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
-                           "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
+        # a kernel of the bf16 compute mode (",true>" instantiation) is priced against the bf16 MFMA peak
+        peak = PEAK_BF16_TFLOPS if dom["name"].endswith(",true>") else PEAK_FP32_TFLOPS
+        rec["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": tf, "peak": peak,
+                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
                            "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                            "avg_launch_us": per * 1e6, "launches": dom["launches"],

@@ -168,6 +168,9 @@ typedef struct {
                           FFN :391).  Draw a new seed every step.  The conformer's dropouts are dead in the reference
                           (conformer.py:278-290 never forwards the rates).                                        */
   float text_dropout;  /* model.yml text_encoder.dropout (0.2)                                                    */
+  int compute_bf16;    /* 1: config c3's "bf16 autocast for conv/GEMM": the operands of every dense conv / Linear of the
+                          training graph (forward, input gradient, weight gradient) are rounded to bf16 and multiplied
+                          on v_mfma_f32_32x32x16_bf16; accumulation, storage, norms, attention, losses stay fp32.      */
 } sty_train_opts;
 int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
 int sty_model_bind_grad(sty_model *m, const char *key, float *grad);
@@ -191,7 +194,14 @@ int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
  * bias [Cout] or NULL -> y [B,Cout,T].  (K-1)*dil <= 128.                                                     */
 int sty_conv1d_workspace_bytes(int Cout, int Cin, int K, size_t *bytes);
 int sty_conv1d_fwd(int B, int Cin, int Cout, int K, int dil, int T, const float *x, const float *w, const float *bias,
-                   float *y, void *workspace, size_t ws_bytes, void *stream);
+                   float *y, void *workspace, size_t ws_bytes, int compute_bf16, void *stream);
+/* Gradients of the same conv on the kernels the training graph uses: dw [Cout,Cin,K] and dbias [Cout] (or NULL) from
+ * (x, gy [B,Cout,T]) on the weight-gradient kernels (wgrad.hip), dx [B,Cin,T] (or NULL) on the implicit-GEMM kernel
+ * with the flipped weights.  compute_bf16 as in sty_train_opts.                                                   */
+int sty_conv1d_bwd_workspace_bytes(int B, int Cin, int Cout, int K, int T, size_t *bytes);
+int sty_conv1d_bwd(int B, int Cin, int Cout, int K, int dil, int T, const float *x, const float *w, const float *gy,
+                   float *dw, float *dbias, float *dx, void *workspace, size_t ws_bytes, int compute_bf16,
+                   void *stream);
 
 /* ---- optimizer: torch.optim.AdamW (train/optimizers.py:110-118) over one flat fp32 bucket ------------------
  * p, g, m, v: n floats each, 16-byte aligned, identically laid out; step = 1, 2, ... (bias correction).          */

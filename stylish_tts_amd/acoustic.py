@@ -68,13 +68,19 @@ class AcousticTrainer:
 
     def __init__(self, speech_predictor, style_encoder, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4,
                  w_mel=5.0, w_phase=8.0, mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0,
-                 text_dropout=0.2):
+                 text_dropout=0.2, compute="fp32"):
         import random
         from .optim import FlatAdamW
         self.train_mode = train_mode
         self.text_dropout = text_dropout  # model.yml text_encoder.dropout
         self._rng = random.Random(seed)  # the Decoder's smoothing draws (decoder.py:55-57)
         self.sp, self.se = speech_predictor.enable_training(), style_encoder.enable_training()
+        if compute not in ("fp32", "bf16"):
+            raise ValueError(f"compute must be 'fp32' or 'bf16', not {compute!r}")
+        self.bf16 = compute == "bf16"  # bf16 operands on the dense convs / Linears, fp32 everywhere else
+        if self.bf16 and not train_mode:
+            self.sp.set_train_opts(compute_bf16=True)
+            self.se.set_train_opts(compute_bf16=True)
         self.w_mel, self.w_phase, self.mean, self.std = w_mel, w_phase, mean, std
         self.base_lr = lr
         kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, bucket_bytes=bucket_bytes)
@@ -92,8 +98,9 @@ class AcousticTrainer:
             # module.train(): BatchNorm batch statistics, spectral-norm power iteration, random F0 / energy smoothing
             self.sp.set_train_opts(bn_batch_stats=True, f0_smooth=(0, 7, 15)[self._rng.randint(0, 2)],
                                    energy_smooth=(0, 7, 15, 31)[self._rng.randint(0, 3)],
-                                   dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.text_dropout)
-            self.se.set_train_opts(sn_power_iter=True)
+                                   dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.text_dropout,
+                                   compute_bf16=self.bf16)
+            self.se.set_train_opts(sn_power_iter=True, compute_bf16=self.bf16)
         mel, _, energy = calculate_mel(audio_gt, TO_MEL, self.mean, self.std, want_energy=True)
         style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)
         T = mel.shape[2]

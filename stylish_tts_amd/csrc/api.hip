@@ -1944,7 +1944,7 @@ int sty_conv1d_workspace_bytes(int Cout, int Cin, int K, size_t* bytes) {
   return STY_OK;
 }
 int sty_conv1d_fwd(int B, int Cin, int Cout, int K, int dil, int T, const float* x, const float* w, const float* bias,
-                   float* y, void* workspace, size_t ws_bytes, void* stream) {
+                   float* y, void* workspace, size_t ws_bytes, int compute_bf16, void* stream) {
   size_t need = 0;
   int rc = sty_conv1d_workspace_bytes(Cout, Cin, K, &need);
   if (rc) return rc;
@@ -1975,7 +1975,99 @@ int sty_conv1d_fwd(int B, int Cin, int Cout, int K, int dil, int T, const float*
   a.dil = dil;
   a.pad = (K - 1) * dil / 2;
   a.y = y;
+  a.bf16 = compute_bf16 != 0;
   return launch_conv1d(a, S(stream));
+}
+static PackedConv unit_conv_dims(int Cin, int Cout, int K) {
+  PackedConv pc;
+  pc.Cin = Cin;
+  pc.Cout = Cout;
+  pc.K = K;
+  pc.CinP = (int)align_up(Cin, CI_CHUNK);
+  pc.CoutP = (int)align_up(Cout, 128);
+  return pc;
+}
+int sty_conv1d_bwd_workspace_bytes(int B, int Cin, int Cout, int K, int T, size_t* bytes) {
+  if (!bytes || B <= 0 || Cin <= 0 || Cout <= 0 || K <= 0 || T <= 0) {
+    set_error("sty_conv1d_bwd_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  const PackedConv pc = unit_conv_dims(Cin, Cout, K);
+  const size_t plane = (size_t)K * pc.CinP * pc.CoutP + pc.CoutP;
+  *bytes = (3 * plane + wgrad_partial_floats(pc, B, T)) * sizeof(float) + 1024;  // weights, gradient, flipped weights
+  return STY_OK;
+}
+int sty_conv1d_bwd(int B, int Cin, int Cout, int K, int dil, int T, const float* x, const float* w, const float* gy,
+                   float* dw, float* dbias, float* dx, void* workspace, size_t ws_bytes, int compute_bf16,
+                   void* stream) {
+  size_t need = 0;
+  int rc = sty_conv1d_bwd_workspace_bytes(B, Cin, Cout, K, T, &need);
+  if (rc) return rc;
+  if (!x || !w || !gy || !dw || !workspace || dil <= 0 || (K - 1) * dil > 128 || ws_bytes < need) {
+    set_error("sty_conv1d_bwd: bad argument, halo > 128 or workspace too small");
+    return STY_EINVAL;
+  }
+  hipStream_t st = S(stream);
+  PackedConv pc = unit_conv_dims(Cin, Cout, K);
+  const size_t plane = (size_t)K * pc.CinP * pc.CoutP;
+  float* wp = reinterpret_cast<float*>(align_up(reinterpret_cast<size_t>(workspace), 256));
+  float* bp = wp + plane;
+  float* gwp = bp + pc.CoutP;  // packed gradient: [K][CinP][CoutP] + bias tail
+  float* gbp = gwp + plane;
+  PackedConv pd;
+  pd.Cin = Cout;
+  pd.Cout = Cin;
+  pd.K = K;
+  pd.CinP = pc.CoutP;  // the flipped weights are the transposed packed block (add_dgrad)
+  pd.CoutP = pc.CinP;
+  float* wd = gbp + pc.CoutP;
+  float* partial = wd + plane + pc.CoutP;
+  STY_HIP(hipMemsetAsync(wp, 0, (size_t)(partial - wp) * sizeof(float), st));
+  rc = launch_pack_conv(w, nullptr, nullptr, nullptr, Cout, Cin, K, wp, bp, pc.CinP, pc.CoutP, st);
+  if (rc) return rc;
+  pc.wp = wp;
+  pc.bias = dbias ? bp : nullptr;
+  ConvArgs a;
+  a.x[0] = x;
+  a.xc[0] = Cin;
+  a.nsrc = 1;
+  a.B = B;
+  a.T = T;
+  a.w = pc;
+  a.dil = dil;
+  a.pad = (K - 1) * dil / 2;
+  a.bf16 = compute_bf16 != 0;
+  bool bias_done = false;
+  rc = launch_conv1d_wgrad(a, gy, nullptr, 1.0f, gwp, partial, dbias ? gbp : nullptr, &bias_done, st);
+  if (rc) return rc;
+  if (dbias && !bias_done) {
+    set_error("sty_conv1d_bwd: bias gradient of K > 12 is a separate pass (launch_bias_grad), not wired here");
+    return STY_EINVAL;
+  }
+  STY_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * sizeof(float), st));
+  rc = launch_unpack_grad(gwp, nullptr, nullptr, Cout, Cin, K, pc.CinP, pc.CoutP, 0, dw, nullptr, nullptr, st);
+  if (rc) return rc;
+  if (dbias) STY_HIP(hipMemcpyAsync(dbias, gbp, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (dx) {
+    PackedConv pdm = pd;
+    rc = launch_pack_dgrad(wp, K, pc.CinP, pc.CoutP, wd, st);
+    if (rc) return rc;
+    pdm.wp = wd;
+    pdm.bias = nullptr;
+    ConvArgs d;
+    d.x[0] = gy;
+    d.xc[0] = Cout;
+    d.nsrc = 1;
+    d.B = B;
+    d.T = T;
+    d.w = pdm;
+    d.dil = dil;
+    d.pad = (K - 1) * dil - a.pad;
+    d.bf16 = a.bf16;
+    d.y = dx;
+    rc = launch_conv1d(d, st);
+  }
+  return rc;
 }
 int sty_mel_workspace_bytes(int B, int N, int n_fft, int hop, size_t* bytes) {
   if (!bytes || B <= 0 || N <= n_fft / 2 || n_fft <= 0 || hop <= 0) {

@@ -42,7 +42,12 @@ __device__ __forceinline__ float act_apply(float x, float alpha) {
 // fixed order before the epilogue.  For the small-grid GEMMs (stage A at T = 160, the text encoder, the deep layers of
 // the style encoder: fewer workgroups than CUs, 30-60 chunks each) this doubles the waves per SIMD that hide each
 // other's memory latency and halves the length of the serial chunk loop.
-template <int WM, int WN, int MT, int NT, int KS = 1>
+//
+// BF: the bf16 compute mode of config c3 ("bf16 autocast for conv/GEMM").  Activations and packed weights stay fp32 in
+// HBM and in LDS; each lane gathers the eight consecutive reduction channels v_mfma_f32_32x32x16_bf16 wants (same
+// number of LDS / L2 reads as the fp32 path: 16 per 32-channel chunk and fragment), rounds them with
+// v_cvt_pk_bf16_f32 and issues 2 MFMAs per chunk, tap and tile instead of 16.  Accumulation is fp32.
+template <int WM, int WN, int MT, int NT, int KS = 1, bool BF = false>
 __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MINW)) void conv1d_mfma_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;  // waves per reduction group (4 or 8)
   constexpr int NTHR = 64 * NW * KS;
@@ -78,7 +83,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MIN
 
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w.wp), 0, K * CinP * CoutP * 4, 0x00020000);
-  const int wv = (hi * CoutP + co0 + l31) * 4;
+  // reduction channel of fragment element c2 inside a 32-channel chunk: fp32 MFMA (k = 2): 2*c2 + hi;
+  // bf16 MFMA (k = 16, eight consecutive channels per lane): 16*(c2 / 8) + 8*hi + c2 % 8
+  const int hrow = BF ? 8 * hi : hi;
+#define STY_CROW(c2) (BF ? 16 * ((c2) >> 3) + ((c2) & 7) : 2 * (c2))
+  const int wv = (hrow * CoutP + co0 + l31) * 4;
   // Staging order: load every row of the chunk -> prologue -> LDS -> compute; overlap comes from 2-4 workgroups per
   // CU.  (A register-staged software pipeline -- next chunk's tile requested before the last tap's MFMAs -- was
   // measured on MI355X and LOST: c2 step 71.9 -> 88.6 ms, c5 12.3 -> 14.4 ms; the tile registers stay live across
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MIN
 #pragma unroll
       for (int m = 0; m < MT; ++m)
         a_nxt[c2][m] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow0 + 2 * c2 * CoutP * 4, 0));
+            float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow0 + STY_CROW(c2) * CoutP * 4, 0));
   }
 #define STY_ST(PRO, MODE) stage_chunk<PRO, NW, MAXJ, MODE, TT_BLK, NW == 4>(a, xb, xs, ci0, b, h, t0, LW, wave, lane)
 #define STY_ST2(PRO)              \
@@ -110,6 +119,27 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MIN
     STY_ST(PRO, ST_FLAT);         \
   else                            \
     STY_ST(PRO, ST_GENERIC)
+  // the MFMAs of one (chunk, tap): AV[c2][m] weights, bv[c2][n] inputs
+#define STY_MFMA_TAP(AV)                                                                                           \
+  if constexpr (BF) {                                                                                              \
+    _Pragma("unroll") for (int s8 = 0; s8 < CI_CHUNK / 2; s8 += 8) {                                               \
+      bf16x8 bp[NT];                                                                                               \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) bp[n] =                                                       \
+          sty_pack_bf16(bv[s8][n], bv[s8 + 1][n], bv[s8 + 2][n], bv[s8 + 3][n], bv[s8 + 4][n], bv[s8 + 5][n],      \
+                        bv[s8 + 6][n], bv[s8 + 7][n]);                                                             \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                             \
+        const bf16x8 ap = sty_pack_bf16(AV[s8][m], AV[s8 + 1][m], AV[s8 + 2][m], AV[s8 + 3][m], AV[s8 + 4][m],     \
+                                        AV[s8 + 5][m], AV[s8 + 6][m], AV[s8 + 7][m]);                              \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[m][n] =                                                 \
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp[n], acc[m][n], 0, 0, 0);                                \
+      }                                                                                                            \
+    }                                                                                                              \
+  } else {                                                                                                         \
+    _Pragma("unroll") for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)                                                    \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                 \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[m][n] =                                                     \
+        __builtin_amdgcn_mfma_f32_32x32x2f32(AV[c2][m], bv[c2][n], acc[m][n], 0, 0, 0);                            \
+  }
   const int nchunks = CinP / CI_CHUNK;
   for (int itc = 0; itc < (nchunks + KS - 1) / KS; ++itc) {
     const int ci0 = (itc * KS + kg) * CI_CHUNK;
@@ -168,51 +198,41 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MIN
 #pragma unroll
             for (int m = 0; m < MT; ++m)
               a_nxt[c2][m] = __builtin_bit_cast(
-                  float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
+                  float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + STY_CROW(c2) * CoutP * 4, 0));
         }
-        const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
+        const float* xrow = xs + hrow * LW + tw + l31 + k * a.dil;
         float bv[CI_CHUNK / 2][NT];
 #pragma unroll
         for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bv[c2][n] = xrow[(2 * c2) * LW + n * 32];
+          for (int n = 0; n < NT; ++n) bv[c2][n] = xrow[STY_CROW(c2) * LW + n * 32];
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c2][m], bv[c2][n], acc[m][n], 0, 0, 0);
+        STY_MFMA_TAP(a_cur)
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       for (int k = 0; k < K; ++k) {
         const int srow = (k * CinP + ci0) * CoutP * 4;
-        const float* xrow = xs + hi * LW + tw + l31 + k * a.dil;
+        const float* xrow = xs + hrow * LW + tw + l31 + k * a.dil;
         float av[CI_CHUNK / 2][MT], bv[CI_CHUNK / 2][NT];
 #pragma unroll
         for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) {
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             av[c2][m] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + 2 * c2 * CoutP * 4, 0));
+                float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv + m * 128, srow + STY_CROW(c2) * CoutP * 4, 0));
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bv[c2][n] = xrow[(2 * c2) * LW + n * 32];
+          for (int n = 0; n < NT; ++n) bv[c2][n] = xrow[STY_CROW(c2) * LW + n * 32];
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2][m], bv[c2][n], acc[m][n], 0, 0, 0);
+        STY_MFMA_TAP(av)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
 
+#undef STY_MFMA_TAP
+#undef STY_CROW
   if constexpr (KS > 1) {
     // ordered sum of the groups' partial tiles through LDS (layout [fragment element][thread of a group])
     float* red = xs_all;
@@ -339,8 +359,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MIN
   }
 }
 
-template <int WM, int WN, int MT, int NT, int KS = 1>
+template <int WM, int WN, int MT, int NT, int KS = 1, bool BF = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  if constexpr (!BF) {
+    if (a.bf16) return launch_cfg<WM, WN, MT, NT, KS, true>(a, st);
+  }
   constexpr int CO_BLK = 32 * MT * WM;
   constexpr int TT_BLK = 32 * NT * WN;
   const int halo = (a.w.K - 1) * a.dil;
@@ -354,7 +377,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     // more than the default dynamic-LDS allowance: opt in (160 KiB per CU on gfx950)
     static bool raised = false;
     if (!raised) {
-      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, MT, NT, KS>),
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, MT, NT, KS, BF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       raised = true;
     }
@@ -374,11 +397,12 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const double in_elems = (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
   const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
   char fam[48];  // the kernel's own name, as rocprofv3 prints it (minus spaces)
-  snprintf(fam, sizeof(fam), "conv1d_mfma_kernel<%d,%d,%d,%d,%d>", WM, WN, MT, NT, KS);
+  snprintf(fam, sizeof(fam), BF ? "conv1d_mfma_kernel<%d,%d,%d,%d,%d,true>" : "conv1d_mfma_kernel<%d,%d,%d,%d,%d>", WM, WN, MT,
+           NT, KS);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
   ProfScope prof(fam, flops, bytes, st, detail);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT, KS>), grid, dim3(64 * WM * WN * KS), lds, st, a);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, MT, NT, KS, BF>), grid, dim3(64 * WM * WN * KS), lds, st, a);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -193,7 +193,7 @@ struct sty_model {
   int* mj_blk_dev[3] = {nullptr, nullptr, nullptr};
   int mj_nblk[3] = {0, 0, 0};
   bool mj_ready = false;
-  sty_train_opts topts = {0, 0, 0, 0, 0.1f, 0u, 0.2f};  // train-mode behaviour of the *_fwd_train entry points
+  sty_train_opts topts = {0, 0, 0, 0, 0.1f, 0u, 0.2f, 0};  // train-mode behaviour of the *_fwd_train entry points
   struct sty::Trainer* trainer = nullptr;
 };
 

@@ -29,8 +29,26 @@ struct ProfScope {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WAVE = 64;
+
+#ifdef __HIPCC__
+// eight fp32 values -> one bf16 MFMA operand (v_cvt_pk_bf16_f32, round to nearest even)
+__device__ __forceinline__ bf16x8 sty_pack_bf16(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                                float v7) {
+  bf16x8 r;
+  r[0] = (__bf16)v0;
+  r[1] = (__bf16)v1;
+  r[2] = (__bf16)v2;
+  r[3] = (__bf16)v3;
+  r[4] = (__bf16)v4;
+  r[5] = (__bf16)v5;
+  r[6] = (__bf16)v6;
+  r[7] = (__bf16)v7;
+  return r;
+}
+#endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -76,6 +94,7 @@ struct ConvArgs {
   // and row kh reads x shifted by (kh - hpad)*flatW.  flatW == 0: plain 1-D conv.
   int hpad = 0, Cin2d = 0;
   int flatW = 0;
+  int bf16 = 0;           // 1: GEMM operands rounded to bf16 (v_mfma_f32_32x32x16_bf16), fp32 accumulation and storage
   int in_shuffle = 0;     // > 1: source 0 is stored pixel-shuffled [B][C/s][T*s] (backward of a shuffled store)
   PackedConv w;
   int pro = PRO_NONE;

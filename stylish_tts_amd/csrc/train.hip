@@ -190,11 +190,14 @@ struct Trainer {
     a.w = w;
     a.pad = (w.K - 1) / 2;
     a.y = y;
+    a.bf16 = m->topts.compute_bf16;
     return a;
   }
 
   // ---------------- ops ----------------
-  void conv(const ConvArgs& a) {
+  void conv(const ConvArgs& a0) {
+    ConvArgs a = a0;
+    a.bf16 = m->topts.compute_bf16;
     const size_t pn = wgrad_partial_floats(a.w, B, a.T);
     side_need = pn > side_need ? pn : side_need;
     if (live()) chk(launch_conv1d(a, st));
@@ -287,6 +290,7 @@ struct Trainer {
       d.T = Tt;
       d.w = it->second;
       d.dil = f.dil;
+      d.bf16 = f.bf16;
       d.pad = (w.K - 1) * f.dil - f.pad;
       d.out_scale = f.out_scale;
       d.in_shuffle = f.shuffle > 1 ? f.shuffle : 0;
@@ -1005,6 +1009,7 @@ struct Trainer {
     a.out_mask = mask;
     a.out_mask_post = 1;
     a.y = y;
+    a.bf16 = m->topts.compute_bf16;
     const size_t pn = wgrad_partial_floats(w, B, n);
     side_need = pn > side_need ? pn : side_need;
     if (live()) chk(launch_conv1d(a, st));
@@ -1058,6 +1063,7 @@ struct Trainer {
       d.B = B;
       d.T = n;
       d.pad = (w.K - 1) - f.pad;
+      d.bf16 = f.bf16;
       d.w = it->second;
       d.flatW = f.flatW;
       d.hpad = (KH - 1) - f.hpad;

@@ -17,7 +17,9 @@ namespace sty {
 constexpr int WG_TW = 128;      // time samples per chunk
 static const int WG_TARGET = getenv("STY_WG_TARGET") ? atoi(getenv("STY_WG_TARGET")) : 1024;  // workgroups per launch aimed at (4 per CU): the (batch, time) list is split to get there
 
-template <int KT>  // taps per wave (K <= 4*KT); K == 1 runs on wgrad_k1_kernel below
+// BF (all weight-gradient kernels): bf16 compute mode, see conv1d.hip -- each lane reads eight consecutive time samples
+// of its row from LDS, rounds them to bf16 and issues one v_mfma_f32_32x32x16_bf16 per 16 samples.
+template <int KT, bool BF = false>  // taps per wave (K <= 4*KT); K == 1 runs on wgrad_k1_kernel below
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                            float* __restrict__ partial, int want_bias) {
   // ax: the forward conv's input side (sources, prologue, pad, dil, weight dims); ag: the output-gradient side
@@ -120,17 +122,39 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
       __syncthreads();
     }
     {
-      float af[WG_TW / 2];
+      if constexpr (BF) {
+        bf16x8 ap[WG_TW / 16];
+        const float* gr = gs + l31 * LWg + 8 * hi;
 #pragma unroll
-      for (int q = 0; q < WG_TW / 2; ++q) af[q] = gs[l31 * LWg + 2 * q + hi];
+        for (int s = 0; s < WG_TW / 16; ++s)
+          ap[s] = sty_pack_bf16(gr[16 * s], gr[16 * s + 1], gr[16 * s + 2], gr[16 * s + 3], gr[16 * s + 4],
+                                gr[16 * s + 5], gr[16 * s + 6], gr[16 * s + 7]);
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const int k = wave + 4 * kt;
-        if (k < K) {
-          const float* xr = xs + l31 * LWx + hi + k * dil;
+        for (int kt = 0; kt < KT; ++kt) {
+          const int k = wave + 4 * kt;
+          if (k < K) {
+            const float* xr = xs + l31 * LWx + 8 * hi + k * dil;
 #pragma unroll
-          for (int q = 0; q < WG_TW / 2; ++q)
-            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[kt], 0, 0, 0);
+            for (int s = 0; s < WG_TW / 16; ++s) {
+              const bf16x8 bp = sty_pack_bf16(xr[16 * s], xr[16 * s + 1], xr[16 * s + 2], xr[16 * s + 3],
+                                              xr[16 * s + 4], xr[16 * s + 5], xr[16 * s + 6], xr[16 * s + 7]);
+              acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s], bp, acc[kt], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        float af[WG_TW / 2];
+#pragma unroll
+        for (int q = 0; q < WG_TW / 2; ++q) af[q] = gs[l31 * LWg + 2 * q + hi];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const int k = wave + 4 * kt;
+          if (k < K) {
+            const float* xr = xs + l31 * LWx + hi + k * dil;
+#pragma unroll
+            for (int q = 0; q < WG_TW / 2; ++q)
+              acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[kt], 0, 0, 0);
+          }
         }
       }
     }
@@ -172,7 +196,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
 // and each staged pair of 32-row tiles feeds 64 MFMAs per wave (34-49 TFLOP/s on the style encoder's 3x3 convs).
 // Here the four waves form a 2x2 grid over the block, every wave runs all K taps on its 32x32 tile against G fragments
 // held in registers: K x 64 MFMAs per wave and chunk from 2x the staged rows.
-template <int KN>
+template <int KN, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                                float* __restrict__ partial, int want_bias) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -251,18 +275,40 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
       }
     }
     __syncthreads();
-    float af[WG_TW / 2];
-    const float* gr = gs + (wo * 32 + l31) * LWg + hi;
+    if constexpr (BF) {
+      bf16x8 ap[WG_TW / 16];
+      const float* gr = gs + (wo * 32 + l31) * LWg + 8 * hi;
 #pragma unroll
-    for (int q = 0; q < WG_TW / 2; ++q) af[q] = gr[2 * q];
-    const float* xr0 = xs + (wi * 32 + l31) * LWx + hi;
+      for (int s = 0; s < WG_TW / 16; ++s)
+        ap[s] = sty_pack_bf16(gr[16 * s], gr[16 * s + 1], gr[16 * s + 2], gr[16 * s + 3], gr[16 * s + 4],
+                              gr[16 * s + 5], gr[16 * s + 6], gr[16 * s + 7]);
+      const float* xr0 = xs + (wi * 32 + l31) * LWx + 8 * hi;
 #pragma unroll
-    for (int k = 0; k < KN; ++k) {
-      if (k < K) {
-        const float* xr = xr0 + k * dil;
+      for (int k = 0; k < KN; ++k) {
+        if (k < K) {
+          const float* xr = xr0 + k * dil;
 #pragma unroll
-        for (int q = 0; q < WG_TW / 2; ++q)
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[k], 0, 0, 0);
+          for (int s = 0; s < WG_TW / 16; ++s) {
+            const bf16x8 bp = sty_pack_bf16(xr[16 * s], xr[16 * s + 1], xr[16 * s + 2], xr[16 * s + 3],
+                                            xr[16 * s + 4], xr[16 * s + 5], xr[16 * s + 6], xr[16 * s + 7]);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s], bp, acc[k], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      float af[WG_TW / 2];
+      const float* gr = gs + (wo * 32 + l31) * LWg + hi;
+#pragma unroll
+      for (int q = 0; q < WG_TW / 2; ++q) af[q] = gr[2 * q];
+      const float* xr0 = xs + (wi * 32 + l31) * LWx + hi;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        if (k < K) {
+          const float* xr = xr0 + k * dil;
+#pragma unroll
+          for (int q = 0; q < WG_TW / 2; ++q)
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[k], 0, 0, 0);
+        }
       }
     }
   }
@@ -337,7 +383,7 @@ __device__ __forceinline__ void w1_store(const ConvArgs& a, float* __restrict__ 
     ls[row * (W1_TW + 1) + lane] = x;
   }
 }
-template <int WI, int WO, int MI, int MO>
+template <int WI, int WO, int MI, int MO, bool BF = false>
 __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                        float* __restrict__ partial, int want_bias) {
   constexpr int TI = 32 * WI * MI, TO = 32 * WO * MO, LW = W1_TW + 1;
@@ -399,6 +445,30 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     }
     w1_store<PRO_MASK, TO>(ag, gs, co0, b, t0, wave, lane, vg, mk);
     __syncthreads();
+    if constexpr (BF) {
+      const float* gr = gs + (wo * MO * 32 + l31) * LW + 8 * hi;
+      const float* xr = xs + (wi * MI * 32 + l31) * LW + 8 * hi;
+#pragma unroll
+      for (int s = 0; s < W1_TW / 16; ++s) {
+        bf16x8 ap[MO], bp[MI];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+          const float* g8 = gr + mo * 32 * LW + 16 * s;
+          ap[mo] = sty_pack_bf16(g8[0], g8[1], g8[2], g8[3], g8[4], g8[5], g8[6], g8[7]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const float* x8 = xr + mi * 32 * LW + 16 * s;
+          bp[mi] = sty_pack_bf16(x8[0], x8[1], x8[2], x8[3], x8[4], x8[5], x8[6], x8[7]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int mo = 0; mo < MO; ++mo)
+            acc[mi][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[mo], bp[mi], acc[mi][mo], 0, 0, 0);
+      }
+      continue;
+    }
     const float* gr = gs + (wo * MO * 32 + l31) * LW + hi;
     const float* xr = xs + (wi * MI * 32 + l31) * LW + hi;
 #pragma unroll 8
@@ -553,7 +623,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     char detail[40];
     snprintf(detail, sizeof(detail), "ci%d co%d k1 T%d W%d", w.Cin, w.Cout, fwd.T, fwd.flatW);
     char fam[48];
-    snprintf(fam, sizeof(fam), "wgrad_k1_kernel<%d,%d,%d,%d>", c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 1 : (c.TO == 32 ? 4 : 2)),
+    snprintf(fam, sizeof(fam), fwd.bf16 ? "wgrad_k1_kernel<%d,%d,%d,%d,true>" : "wgrad_k1_kernel<%d,%d,%d,%d>", c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 1 : (c.TO == 32 ? 4 : 2)),
              c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 4 : (c.TO == 32 ? 1 : 2)), c.TI == 128 && c.TO == 128 ? 2 : 1,
              c.TI == 128 && c.TO == 128 ? 2 : 1);
     ProfScope prof(fam, 2.0 * w.Cin * (double)fwd.B * w.Cout * fwd.T,
@@ -562,17 +632,29 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     if (!raised) {
       STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<2, 2, 2, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<2, 2, 2, 2, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       raised = true;
     }
     const int wb = gbias != nullptr;
+#define STY_W1(WI, WO, MI, MO)                                                                                      \
+  do {                                                                                                              \
+    if (fwd.bf16)                                                                                                   \
+      hipLaunchKernelGGL((wgrad_k1_kernel<WI, WO, MI, MO, true>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb,   \
+                         partial, wb);                                                                              \
+    else                                                                                                            \
+      hipLaunchKernelGGL((wgrad_k1_kernel<WI, WO, MI, MO>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb,         \
+                         partial, wb);                                                                              \
+  } while (0)
     if (c.TI == 128 && c.TO == 128)
-      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 2, 2>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
+      STY_W1(2, 2, 2, 2);
     else if (c.TI == 32)
-      hipLaunchKernelGGL((wgrad_k1_kernel<1, 4, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
+      STY_W1(1, 4, 1, 1);
     else if (c.TO == 32)
-      hipLaunchKernelGGL((wgrad_k1_kernel<4, 1, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
+      STY_W1(4, 1, 1, 1);
     else
-      hipLaunchKernelGGL((wgrad_k1_kernel<2, 2, 1, 1>), grid, dim3(256), lds, st, ax1, ag, nsplit, cpb, partial, wb);
+      STY_W1(2, 2, 1, 1);
+#undef STY_W1
     const size_t plane = (size_t)w.CinP * w.CoutP;
     launch_wgrad_reduce(partial, nsplit, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
     if (bias_done) *bias_done = wb != 0;
@@ -590,17 +672,25 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
       STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_wgrad64_kernel<5>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_wgrad64_kernel<3, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_wgrad64_kernel<5, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
       raised = true;
     }
     dim3 grid(cdiv(w.CinP, 64), cdiv(w.CoutP, 64), nsplit);
     char detail[40], fam[48];
     snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
-    snprintf(fam, sizeof(fam), "conv1d_wgrad64_kernel<%d>", w.K <= 3 ? 3 : 5);
+    snprintf(fam, sizeof(fam), fwd.bf16 ? "conv1d_wgrad64_kernel<%d,true>" : "conv1d_wgrad64_kernel<%d>", w.K <= 3 ? 3 : 5);
     ProfScope prof(fam, 2.0 * w.Cin * w.K * (double)fwd.B * w.Cout * fwd.T,
                    4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T), st, detail);
     const int wb = gbias != nullptr;
-    if (w.K <= 3)
+    if (w.K <= 3 && fwd.bf16)
+      hipLaunchKernelGGL((conv1d_wgrad64_kernel<3, true>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
+    else if (w.K <= 3)
       hipLaunchKernelGGL((conv1d_wgrad64_kernel<3>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
+    else if (fwd.bf16)
+      hipLaunchKernelGGL((conv1d_wgrad64_kernel<5, true>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
     else
       hipLaunchKernelGGL((conv1d_wgrad64_kernel<5>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
     const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
@@ -626,7 +716,8 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
   char fam[48];
-  snprintf(fam, sizeof(fam), "conv1d_wgrad_kernel<%d>", cdiv(w.K, 4) <= 3 ? cdiv(w.K, 4) : 6);
+  snprintf(fam, sizeof(fam), fwd.bf16 ? "conv1d_wgrad_kernel<%d,true>" : "conv1d_wgrad_kernel<%d>",
+           cdiv(w.K, 4) <= 3 ? cdiv(w.K, 4) : 6);
   ProfScope prof(fam, flops, bytes, st, detail);
   const int KT = cdiv(w.K, 4);
   const int wb = (gbias != nullptr && KT >= 1 && KT <= 3) ? 1 : 0;
@@ -634,8 +725,15 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     set_error("wgrad: flat 2-D mode is built for K <= 12");
     return STY_EINVAL;
   }
-#define STY_WG(KTV)                                                                                              \
-  hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, partial, wb)
+#define STY_WG(KTV)                                                                                                \
+  do {                                                                                                             \
+    if (fwd.bf16)                                                                                                  \
+      hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV, true>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b, \
+                         partial, wb);                                                                             \
+    else                                                                                                           \
+      hipLaunchKernelGGL((conv1d_wgrad_kernel<KTV>), grid, dim3(256), lds, st, ax, ag, nsplit, chunks_per_b,       \
+                         partial, wb);                                                                             \
+  } while (0)
   switch (KT) {
     case 1: STY_WG(1); break;
     case 2: STY_WG(2); break;

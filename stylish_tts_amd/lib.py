@@ -32,7 +32,7 @@ class SpeechIO(C.Structure):
 class TrainOpts(C.Structure):
     _fields_ = [("bn_batch_stats", C.c_int), ("sn_power_iter", C.c_int), ("f0_smooth", C.c_int),
                 ("energy_smooth", C.c_int), ("bn_momentum", C.c_float), ("dropout_seed", C.c_uint),
-                ("text_dropout", C.c_float)]
+                ("text_dropout", C.c_float), ("compute_bf16", C.c_int)]
 
 
 # every symbol include/stylish_hip.h declares: name -> (restype, argtypes)
@@ -77,7 +77,9 @@ SYMBOLS = {
     "sty_style_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "sty_style_bwd": (C.c_int, [_P, _P, _P]),
     "sty_conv1d_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
-    "sty_conv1d_fwd": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_conv1d_fwd": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
+    "sty_conv1d_bwd_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _I, _SZP]),
+    "sty_conv1d_bwd": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
     "sty_adamw_step": (C.c_int, [C.c_size_t, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  _I, _P]),
     "sty_acoustic_loss_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
