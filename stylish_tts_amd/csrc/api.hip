@@ -1957,7 +1957,7 @@ int sty_conv1d_fwd(int B, int Cin, int Cout, int K, int dil, int T, const float*
   pc.Cout = Cout;
   pc.K = K;
   pc.CinP = (int)align_up(Cin, CI_CHUNK);
-  pc.CoutP = (int)align_up(Cout, 128);
+  pc.CoutP = (int)align_up(Cout, 32);  // the model's padding rule (prepare_conv)
   float* wp = reinterpret_cast<float*>(align_up(reinterpret_cast<size_t>(workspace), 256));
   float* bp = wp + (size_t)K * pc.CinP * pc.CoutP;
   STY_HIP(hipMemsetAsync(wp, 0, ((size_t)K * pc.CinP * pc.CoutP + pc.CoutP) * sizeof(float), S(stream)));
@@ -1984,7 +1984,7 @@ static PackedConv unit_conv_dims(int Cin, int Cout, int K) {
   pc.Cout = Cout;
   pc.K = K;
   pc.CinP = (int)align_up(Cin, CI_CHUNK);
-  pc.CoutP = (int)align_up(Cout, 128);
+  pc.CoutP = (int)align_up(Cout, 32);  // the model's padding rule (prepare_conv)
   return pc;
 }
 int sty_conv1d_bwd_workspace_bytes(int B, int Cin, int Cout, int K, int T, size_t* bytes) {

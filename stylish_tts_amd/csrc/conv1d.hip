@@ -431,6 +431,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     if (forced == 2 && a.w.CoutP % 64 == 0) return launch_cfg<2, 2, 1, 1>(a, st);
     if (forced == 3) return launch_cfg<1, 8, 1, 2>(a, st);
     if (forced == 4) return launch_cfg<1, 4, 1, 2>(a, st);
+    if (forced == 5 && a.w.CoutP % 64 == 0 && a.w.CinP >= 2 * CI_CHUNK) return launch_cfg<2, 2, 1, 1, 2>(a, st);
   }
   // Tile choice: the biggest output tile that still gives the chip >= ~2 workgroups per CU; the 256-channel stage
   // runs at T <= 800 frames, where 128x128 tiles would launch ~100 workgroups on 256 CUs.

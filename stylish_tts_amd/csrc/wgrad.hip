@@ -196,6 +196,45 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
 // and each staged pair of 32-row tiles feeds 64 MFMAs per wave (34-49 TFLOP/s on the style encoder's 3x3 convs).
 // Here the four waves form a 2x2 grid over the block, every wave runs all K taps on its 32x32 tile against G fragments
 // held in registers: K x 64 MFMAs per wave and chunk from 2x the staged rows.
+// Staging: plain [B][C][T] or flat-2-D x (no concatenation, no pixel shuffle: the launcher falls back otherwise), so
+// one buffer descriptor per batch slab serves all rows; the per-row byte offset / time shift / liveness are computed
+// once per workgroup, not per chunk.  The loads of chunk i+1 are issued as soon as chunk i sits in LDS and stay in
+// flight during its MFMAs (software pipeline; 80 staging registers).
+template <int PRO>
+__device__ __forceinline__ void wg64_store_x(const ConvArgs& ax, float* __restrict__ xs, const float (&vx)[16][3],
+                                             const int (&tshx)[16], int ci0, int b, int t0, int LWx, int wave,
+                                             int lane) {
+  const int T = ax.T, Cin = ax.w.Cin;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wave + 4 * i, ci = ci0 + r;
+    const bool live = ci < Cin;
+    float pa = 1.f, ps = 0.f, alpha = 1.f, ralpha = 1.f;
+    if (live) {
+      if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+        pa = ax.pa[(size_t)b * Cin + ci];
+        if constexpr (PRO != PRO_SCALE) ps = ax.ps[(size_t)b * Cin + ci];
+      }
+      if constexpr (PRO == PRO_AFFINE_SNAKE) {
+        alpha = ax.palpha[ci];
+        ralpha = 1.0f / alpha;
+      }
+    }
+    float* row = xs + r * LWx;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int j = lane + 64 * q;
+      const int t = t0 - ax.pad + j + tshx[i];
+      float v = 0.f;
+      if (live && t >= 0 && t < T) {
+        float mk = 1.f;
+        if constexpr (PRO == PRO_MASK) mk = ax.mask[(size_t)b * T + t];
+        v = pro_apply<PRO>(vx[i][q], pa, ps, alpha, ralpha, mk);
+      }
+      if (q < 2 || j < LWx) row[j] = v;
+    }
+  }
+}
 template <int KN, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                                float* __restrict__ partial, int want_bias) {
@@ -203,8 +242,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
             hi = lane >> 5;
   const int wi = wave >> 1, wo = wave & 1;
-  const int K = ax.w.K, dil = ax.dil;
-  const int halo = (K - 1) * dil;
+  const int K = ax.w.K, dil = ax.dil, T = ax.T;
+  const int halo = (K - 1) * dil;  // <= 63: three 64-column groups cover the x tile
   const int LWx = (WG_TW + halo) | 1, LWg = WG_TW + 1;
   float* xs = lds;                 // [64][LWx]
   float* gs = lds + 64 * LWx;      // [64][LWg]
@@ -215,99 +254,116 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   const bool do_bias = want_bias && blockIdx.x == 0;
-  float bsum[2][4][2];
+  float bsum[16];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
+  for (int i = 0; i < 16; ++i) bsum[i] = 0.f;
+  // per-row constants of this wave's 16 x rows and 16 G rows (rows wave, wave + 4, ...)
+  const int Cx = ax.flatW ? ax.Cin2d : ax.xc[0];  // channels of the x slab
+  const int Cg = ag.xc[0];
+  int offx[16], tshx[16], offg[16];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) bsum[hh][it][0] = bsum[hh][it][1] = 0.f;
+  for (int i = 0; i < 16; ++i) {
+    const int ci = ci0 + wave + 4 * i;
+    int cc = ci, tsh = 0;
+    if (ax.flatW) {  // reduction row (kh, cc) of the flat image: channel cc shifted by (kh - hpad) image rows
+      const int c2 = ax.Cin2d;
+      const int kh = (ci >= c2) + (ci >= 2 * c2) + (ci >= 3 * c2) + (ci >= 4 * c2);
+      cc = ci - kh * c2;
+      tsh = (kh - ax.hpad) * ax.flatW;
+    }
+    tshx[i] = tsh;
+    offx[i] = ci < ax.w.Cin ? (cc * T + tsh) * 4 : 0x7fffff00;  // dead rows: out of the descriptor's range
+    const int co = co0 + wave + 4 * i;
+    offg[i] = co < Cg ? co * T * 4 : 0x7fffff00;
+  }
+  float vx[16][3], vg[16][2], mk[2];
   const int total = ax.B * chunks_per_b;
-  constexpr int MAXJ = (WG_TW + 64 + 1 + 63) / 64;  // halo <= 64 (checked by the launcher)
-  constexpr int MAXJG = (WG_TW + 1 + 63) / 64;
-  const int xmode = stage_mode(ax), gmode = stage_mode(ag);
+  auto load_chunk = [&](int ch) {
+    const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ax.x[0] + (size_t)b * Cx * T), 0, Cx * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ag.x[0] + (size_t)b * Cg * T), 0, Cg * T * 4, 0x00020000);
+    const int v0x = (t0 - ax.pad + lane) * 4, v0g = (t0 + lane) * 4;
+    // a negative offset (left padding of the first chunk) wraps to a huge unsigned one: out of range, loads 0;
+    // columns past T read the next row and are zeroed by the store
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (q < 2 || lane + 64 * q < LWx) vx[i][q] = buf_load(rx, v0x + 256 * q + offx[i]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) vg[i][q] = buf_load(rg, v0g + 256 * q + offg[i]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = t0 + lane + 64 * q;
+      mk[q] = t < T ? (ag.pro == PRO_MASK ? ag.mask[(size_t)b * T + t] : 1.f) : 0.f;
+    }
+  };
+  if (split < total) load_chunk(split);
   for (int ch = split; ch < total; ch += nsplit) {
     const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
-    const float* xb = stage_base(ax, b);
-    const float* gb = stage_base(ag, b);
-    float mk[MAXJG];
-    if (ag.pro == PRO_MASK) {
-#pragma unroll
-      for (int q = 0; q < MAXJG; ++q) {
-        const int t = t0 + lane + 64 * q;
-        mk[q] = (t < ag.T && lane + 64 * q < LWg) ? ag.mask[(size_t)b * ag.T + t] : 0.f;
-      }
+    __syncthreads();  // the previous chunk's MFMAs are done with the tiles
+    switch (ax.pro) {
+      case PRO_AFFINE: wg64_store_x<PRO_AFFINE>(ax, xs, vx, tshx, ci0, b, t0, LWx, wave, lane); break;
+      case PRO_SCALE: wg64_store_x<PRO_SCALE>(ax, xs, vx, tshx, ci0, b, t0, LWx, wave, lane); break;
+      case PRO_AFFINE_SNAKE: wg64_store_x<PRO_AFFINE_SNAKE>(ax, xs, vx, tshx, ci0, b, t0, LWx, wave, lane); break;
+      case PRO_AFFINE_LRELU: wg64_store_x<PRO_AFFINE_LRELU>(ax, xs, vx, tshx, ci0, b, t0, LWx, wave, lane); break;
+      case PRO_MASK: wg64_store_x<PRO_MASK>(ax, xs, vx, tshx, ci0, b, t0, LWx, wave, lane); break;
+      case PRO_LRELU: wg64_store_x<PRO_LRELU>(ax, xs, vx, tshx, ci0, b, t0, LWx, wave, lane); break;
+      default: wg64_store_x<PRO_NONE>(ax, xs, vx, tshx, ci0, b, t0, LWx, wave, lane); break;
     }
-    __syncthreads();  // previous chunk's MFMAs are done with the tiles
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {  // two 32-row halves of each tile, all rows of a half in flight at once
-      StageRegs<4, MAXJ> Rx;
-      StageRegs<4, MAXJG> Rg;
-#define STY_LX(MODE) stage_load<4, MAXJ, MODE, WG_TW>(ax, xb, ci0 + 32 * hh, b, 0, t0, LWx, wave, lane, Rx)
-      STY_STAGE_DISPATCH(xmode, STY_LX);
-#undef STY_LX
-      if (gmode == ST_SIMPLE)
-        stage_load<4, MAXJG, ST_SIMPLE, WG_TW>(ag, gb, co0 + 32 * hh, b, 0, t0, LWg, wave, lane, Rg);
-      else
-        stage_load<4, MAXJG, ST_GENERIC, WG_TW>(ag, gb, co0 + 32 * hh, b, 0, t0, LWg, wave, lane, Rg);
-      float* xh = xs + hh * 32 * LWx;
-      float* gh = gs + hh * 32 * LWg;
-      switch (ax.pro) {
-        case PRO_AFFINE: stage_store<PRO_AFFINE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
-        case PRO_SCALE: stage_store<PRO_SCALE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
-        case PRO_AFFINE_SNAKE: stage_store<PRO_AFFINE_SNAKE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
-        case PRO_AFFINE_LRELU: stage_store<PRO_AFFINE_LRELU, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
-        case PRO_MASK: stage_store<PRO_MASK, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
-        case PRO_LRELU: stage_store<PRO_LRELU, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
-        default: stage_store<PRO_NONE, 4, MAXJ>(ax, xh, ci0 + 32 * hh, b, t0, LWx, wave, lane, Rx); break;
-      }
-      if (ag.pro == PRO_MASK)
-        stage_store<PRO_MASK, 4, MAXJG>(ag, gh, co0 + 32 * hh, b, t0, LWg, wave, lane, Rg, mk);
-      else
-        stage_store<PRO_NONE, 4, MAXJG>(ag, gh, co0 + 32 * hh, b, t0, LWg, wave, lane, Rg);
-      if (do_bias) {
+    for (int i = 0; i < 16; ++i) {
+      float* row = gs + (wave + 4 * i) * LWg;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int q = 0; q < MAXJG; ++q)
-              if (lane + 64 * q < WG_TW)
-                bsum[hh][it][u] = fmaf(Rg.vv[it][u][q], ag.pro == PRO_MASK ? mk[q] : 1.f, bsum[hh][it][u]);
+      for (int q = 0; q < 2; ++q) {
+        const float v = mk[q] != 0.f ? vg[i][q] * mk[q] : 0.f;  // past T the register holds the next row's samples
+        row[lane + 64 * q] = v;
+        if (do_bias) bsum[i] += v;
       }
     }
     __syncthreads();
+    if (ch + nsplit < total) load_chunk(ch + nsplit);  // in flight during the MFMAs below
     if constexpr (BF) {
       bf16x8 ap[WG_TW / 16];
       const float* gr = gs + (wo * 32 + l31) * LWg + 8 * hi;
 #pragma unroll
-      for (int s = 0; s < WG_TW / 16; ++s)
-        ap[s] = sty_pack_bf16(gr[16 * s], gr[16 * s + 1], gr[16 * s + 2], gr[16 * s + 3], gr[16 * s + 4],
-                              gr[16 * s + 5], gr[16 * s + 6], gr[16 * s + 7]);
+      for (int s8 = 0; s8 < WG_TW / 16; ++s8)
+        ap[s8] = sty_pack_bf16(gr[16 * s8], gr[16 * s8 + 1], gr[16 * s8 + 2], gr[16 * s8 + 3], gr[16 * s8 + 4],
+                               gr[16 * s8 + 5], gr[16 * s8 + 6], gr[16 * s8 + 7]);
       const float* xr0 = xs + (wi * 32 + l31) * LWx + 8 * hi;
 #pragma unroll
       for (int k = 0; k < KN; ++k) {
         if (k < K) {
           const float* xr = xr0 + k * dil;
 #pragma unroll
-          for (int s = 0; s < WG_TW / 16; ++s) {
-            const bf16x8 bp = sty_pack_bf16(xr[16 * s], xr[16 * s + 1], xr[16 * s + 2], xr[16 * s + 3],
-                                            xr[16 * s + 4], xr[16 * s + 5], xr[16 * s + 6], xr[16 * s + 7]);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s], bp, acc[k], 0, 0, 0);
+          for (int s8 = 0; s8 < WG_TW / 16; ++s8) {
+            const bf16x8 bp = sty_pack_bf16(xr[16 * s8], xr[16 * s8 + 1], xr[16 * s8 + 2], xr[16 * s8 + 3],
+                                            xr[16 * s8 + 4], xr[16 * s8 + 5], xr[16 * s8 + 6], xr[16 * s8 + 7]);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[s8], bp, acc[k], 0, 0, 0);
           }
         }
       }
     } else {
-      float af[WG_TW / 2];
-      const float* gr = gs + (wo * 32 + l31) * LWg + hi;
+      // two halves of the chunk: 32 G fragments in registers at a time (the staging registers of the next chunk
+      // are live here)
 #pragma unroll
-      for (int q = 0; q < WG_TW / 2; ++q) af[q] = gr[2 * q];
-      const float* xr0 = xs + (wi * 32 + l31) * LWx + hi;
+      for (int hq = 0; hq < 2; ++hq) {
+        float af[WG_TW / 4];
+        const float* gr = gs + (wo * 32 + l31) * LWg + hi + hq * (WG_TW / 2);
 #pragma unroll
-      for (int k = 0; k < KN; ++k) {
-        if (k < K) {
-          const float* xr = xr0 + k * dil;
+        for (int q = 0; q < WG_TW / 4; ++q) af[q] = gr[2 * q];
+        const float* xr0 = xs + (wi * 32 + l31) * LWx + hi + hq * (WG_TW / 2);
 #pragma unroll
-          for (int q = 0; q < WG_TW / 2; ++q)
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[k], 0, 0, 0);
+        for (int k = 0; k < KN; ++k) {
+          if (k < K) {
+            const float* xr = xr0 + k * dil;
+#pragma unroll
+            for (int q = 0; q < WG_TW / 4; ++q)
+              acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[2 * q], acc[k], 0, 0, 0);
+          }
         }
       }
     }
@@ -318,16 +374,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
   if (do_bias) {
     float* pb = partial + (size_t)split * stride + plane;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          float v = bsum[hh][it][u];
-          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-          const int co = co0 + 32 * hh + wave + 8 * it + 4 * u;
-          if (lane == 0 && co < CoutP) pb[co] = v;
-        }
+    for (int i = 0; i < 16; ++i) {
+      float v = bsum[i];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      const int co = co0 + wave + 4 * i;
+      if (lane == 0 && co < CoutP) pb[co] = v;
+    }
   }
   float* p = partial + (size_t)split * stride;
   const int ci = ci0 + wi * 32 + l31;
@@ -344,7 +396,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
 }
 static bool wgrad64_ok(const PackedConv& w, int dil) {
   static const bool on = getenv("STY_NO_WGRAD64") == nullptr;
-  return on && w.K >= 2 && w.K <= 5 && w.CinP >= 64 && w.CoutP >= 64 && (w.K - 1) * dil <= 64;
+  return on && w.K >= 2 && w.K <= 5 && w.CinP >= 64 && w.CoutP >= 64 && (w.K - 1) * dil <= 63;
+}
+// the blocked kernel stages plain / flat-2-D operands only (one descriptor per batch slab)
+static bool wgrad64_operands_ok(const ConvArgs& fwd) {
+  return (fwd.flatW || fwd.nsrc == 1) && fwd.in_shuffle <= 1 && fwd.shuffle <= 1;
 }
 static int wgrad64_nsplit(const PackedConv& w, int B, int T) {
   const int tiles = cdiv(w.CinP, 64) * cdiv(w.CoutP, 64);
@@ -409,9 +465,35 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
 #pragma unroll
   for (int i = 0; i < TO / 4; ++i) bsum[i] = 0.f;
   const int total = ax.B * chunks_per_b;
-  for (int ch = split; ch < total; ch += nsplit) {
+  // Software pipeline over the chunk list: the global loads of chunk i+1 are issued right after chunk i's tiles are in
+  // LDS, so their latency overlaps chunk i's LDS reads + MFMAs (which wait on lgkmcnt only).  Without it every chunk
+  // paid load latency -> LDS store -> barrier -> MFMA back to back: 21-31 TFLOP/s at config c3 in either compute mode.
+  float vx[TI / 4], vg[TO / 4];
+  float mk = 1.f, mkx = 1.f;
+  // Plain [B][C][T] operands (everything but channel-concatenated inputs and pixel-shuffled gradients): ONE buffer
+  // descriptor per batch slab and a per-row byte offset added on the VALU.  The per-row descriptors of the generic
+  // path cost ~30 scalar instructions and 4 SGPRs per row, 64-256 rows per 64-sample chunk (1300 spilled SGPRs): the
+  // scalar unit, not the matrix core, set the pace.  Columns past T read the next row (masked by w1_store / the
+  // bias mask below), addresses past the slab are suppressed by the descriptor's range check.
+  const bool simple = ax.nsrc == 1 && es == 1 && esg == 1;
+  auto load_chunk = [&](int ch) {
     const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * W1_TW;
-    float vx[TI / 4], vg[TO / 4];
+    if (simple) {
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(ax.x[0] + (size_t)b * ax.xc[0] * T), 0, ax.xc[0] * T * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(ag.x[0] + (size_t)b * ag.xc[0] * T), 0, ag.xc[0] * T * 4, 0x00020000);
+      const int v0 = (t0 + lane) * 4;
+#pragma unroll
+      for (int i = 0; i < TI / 4; ++i) vx[i] = buf_load(rx, v0 + (ci0 + wave + 4 * i) * T * 4);
+#pragma unroll
+      for (int i = 0; i < TO / 4; ++i) vg[i] = buf_load(rg, v0 + (co0 + wave + 4 * i) * T * 4);
+      mk = t0 + lane < T ? 1.f : 0.f;
+      mkx = 1.f;
+      if (ag.pro == PRO_MASK) mk = t0 + lane < T ? ag.mask[(size_t)b * T + t0 + lane] : 0.f;
+      if (ax.pro == PRO_MASK) mkx = t0 + lane < T ? ax.mask[(size_t)b * T + t0 + lane] : 0.f;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TI / 4; ++i) {
       const StageRow r = stage_row<ST_GENERIC>(ax, ax.x[0], ci0 + wave + 4 * i, b, 0, T, es);
@@ -426,12 +508,18 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(r.src), 0, (int)r.bytes, 0x00020000);
       vg[i] = buf_load(rs, (t0 + lane) * 4 * esg);
     }
-    float mk = 1.f, mkx = 1.f;
+    mk = 1.f;
+    mkx = 1.f;
     if (ag.pro == PRO_MASK) mk = t0 + lane < T ? ag.mask[(size_t)b * T + t0 + lane] : 0.f;
     if (ax.pro == PRO_MASK) mkx = t0 + lane < T ? ax.mask[(size_t)b * T + t0 + lane] : 0.f;
-    if (do_bias) {
+  };
+  if (split < total) load_chunk(split);
+  for (int ch = split; ch < total; ch += nsplit) {
+    const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * W1_TW;
+    if (do_bias) {  // generic path: rows past Cout / columns past T load 0; plain path: mk is 0 past T, rows are checked
 #pragma unroll
-      for (int i = 0; i < TO / 4; ++i) bsum[i] = fmaf(vg[i], mk, bsum[i]);  // rows past Cout / columns past T load 0
+      for (int i = 0; i < TO / 4; ++i)
+        if (!simple || co0 + wave + 4 * i < ag.xc[0]) bsum[i] = fmaf(vg[i], mk, bsum[i]);
     }
     __syncthreads();
     switch (ax.pro) {
@@ -445,6 +533,7 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     }
     w1_store<PRO_MASK, TO>(ag, gs, co0, b, t0, wave, lane, vg, mk);
     __syncthreads();
+    if (ch + nsplit < total) load_chunk(ch + nsplit);
     if constexpr (BF) {
       const float* gr = gs + (wo * MO * 32 + l31) * LW + 8 * hi;
       const float* xr = xs + (wi * MI * 32 + l31) * LW + 8 * hi;
@@ -661,7 +750,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     STY_LAUNCH_CHECK();
     return STY_OK;
   }
-  if (wgrad64_ok(w, fwd.dil)) {
+  if (wgrad64_ok(w, fwd.dil) && wgrad64_operands_ok(fwd)) {
     const int nsplit = wgrad64_nsplit(w, fwd.B, fwd.T);
     const int cpb = cdiv(fwd.T, WG_TW);
     const int halo = (w.K - 1) * fwd.dil;

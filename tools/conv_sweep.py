@@ -9,10 +9,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SHAPES = [  # (B, Cin, Cout, K, dil, T)
+SHAPES = [  # (B, Cin, Cout, K, dil, T)  -- c2 shapes of the training step (forward and input-gradient forms)
     (16, 1024, 256, 1, 1, 160), (16, 256, 1024, 1, 1, 160), (16, 128, 128, 1, 1, 37), (16, 512, 128, 3, 1, 37),
-    (16, 384, 384, 3, 1, 210), (16, 320, 320, 3, 1, 820), (16, 32, 128, 1, 1, 12000), (16, 128, 32, 1, 1, 12000),
-    (16, 32, 32, 11, 1, 12000), (1, 2048, 2050, 1, 1, 1504),
+    (16, 128, 512, 3, 1, 37), (16, 1920, 384, 5, 1, 210), (16, 384, 1920, 5, 1, 210), (16, 1152, 384, 3, 1, 210),
+    (16, 960, 320, 3, 1, 820), (16, 320, 960, 3, 1, 820), (16, 480, 160, 3, 1, 3240), (16, 240, 80, 3, 1, 12880),
+    (16, 32, 128, 1, 1, 12000), (16, 128, 32, 1, 1, 12000), (16, 32, 32, 11, 1, 12000), (16, 32, 32, 21, 1, 12000),
+    (16, 128, 128, 3, 1, 160), (16, 195, 128, 3, 1, 160), (1, 2048, 2050, 1, 1, 1504),
 ]
 
 
@@ -31,7 +33,8 @@ def run_one():
         L.check(lib.sty_conv1d_workspace_bytes(Co, Ci, K, C.byref(need)))
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        args = (B, Ci, Co, K, d, T, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(ws), ws.numel(), st)
+        args = (B, Ci, Co, K, d, T, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(ws), ws.numel(),
+                int(os.environ.get("SWEEP_BF16", "0")), st)
         for _ in range(3):
             L.check(lib.sty_conv1d_fwd(*args))
         lib.sty_prof_enable(1)
@@ -49,7 +52,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         run_one()
     else:
-        for cfg in ("", "0", "1", "2", "3", "4"):
+        for cfg in ("", "0", "1", "2", "3", "4", "5"):
             env = dict(os.environ)
             if cfg:
                 env["STY_CONV_CFG"] = cfg
