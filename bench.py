@@ -16,6 +16,7 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       (fp32 accumulation, storage, norms, attention and losses: SURVEY.md 8(d) "bf16 autocast for conv/GEMM").
   c3-fp32: the same shape entirely in fp32.
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
+  c5-bf16: the same with bf16 operands on the dense convs (outside the fp32 parity gates; reported beside c5).
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
 Prints ONE JSON line on rank 0.
@@ -37,6 +38,7 @@ WORKLOADS = {
     "c3": dict(B=32, T=520, L=100, what="train", compute="bf16"),
     "c3-fp32": dict(B=32, T=520, L=100, what="train"),
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
+    "c5-bf16": dict(B=8, T=800, L=0, what="vocoder", compute="bf16"),
 }
 PASS = {
     "train": "forward + backward + AdamW (mel + multi-phase losses; GAN/WavLM terms off; train mode)",
@@ -236,6 +238,8 @@ def main():
     bf16 = w.get("compute") == "bf16"
     trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"))
                if w["what"] == "train" else None)
+    if bf16 and trainer is None:
+        model.set_train_opts(compute_bf16=True)
 
     def step(i):
         if w["what"] == "train":

@@ -170,7 +170,8 @@ typedef struct {
   float text_dropout;  /* model.yml text_encoder.dropout (0.2)                                                    */
   int compute_bf16;    /* 1: config c3's "bf16 autocast for conv/GEMM": the operands of every dense conv / Linear of the
                           training graph (forward, input gradient, weight gradient) are rounded to bf16 and multiplied
-                          on v_mfma_f32_32x32x16_bf16; accumulation, storage, norms, attention, losses stay fp32.      */
+                          on v_mfma_f32_32x32x16_bf16; accumulation, storage, norms, attention, losses stay fp32.
+                          Also honoured by the inference entry points (sty_vocoder_fwd, sty_speech_fwd).              */
 } sty_train_opts;
 int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
 int sty_model_bind_grad(sty_model *m, const char *key, float *grad);

@@ -550,7 +550,9 @@ struct Run {
   }
   bool live() const { return ws.base != nullptr && rc == STY_OK; }
 
-  void conv(const ConvArgs& a) {
+  void conv(const ConvArgs& a0) {
+    ConvArgs a = a0;
+    a.bf16 = m->topts.compute_bf16;  // the compute mode also applies to the inference plans
     if (live()) chk(launch_conv1d(a, st));
   }
   ConvArgs base(const PackedConv& w, const float* x, int T, float* y) {
