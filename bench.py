@@ -291,14 +291,19 @@ def main():
         per = dom["ms"] / dom["launches"] * 1e-3
         tf = dom["flops"] / dom["launches"] / per / 1e12
         gbs = dom["bytes"] / dom["launches"] / per / 1e9
-        # a kernel of the bf16 compute mode (",true>" instantiation) is priced against the bf16 MFMA peak
+        # a kernel of the bf16 compute mode (",true>" instantiation) is priced against the bf16 MFMA peak; the roof
+        # quoted as `bound` is the one the kernel sits closer to (both fractions are in the record)
         peak = PEAK_BF16_TFLOPS if dom["name"].endswith(",true>") else PEAK_FP32_TFLOPS
-        rec["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": tf, "peak": peak,
-                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
-                           "traffic_source": traffic_src,
+        f_mfma, f_hbm = tf / peak, gbs / PEAK_HBM_GBS
+        hbm_bound = f_hbm > f_mfma
+        rec["roofline"] = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma",
+                           "achieved": gbs if hbm_bound else tf, "peak": PEAK_HBM_GBS if hbm_bound else peak,
+                           "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": f_hbm if hbm_bound else f_mfma,
+                           "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                            "avg_launch_us": per * 1e6, "launches": dom["launches"],
-                           "hbm_GBps_algorithmic": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
+                           "mfma_TFLOPs": tf, "mfma_peak": peak, "mfma_frac": f_mfma,
+                           "hbm_GBps_algorithmic": gbs, "hbm_frac": f_hbm,
                            "share_of_step_time": dom["ms"] / (1e3 * dt)}
         rec["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / args.steps,
                            "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,

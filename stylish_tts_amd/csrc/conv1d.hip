@@ -397,8 +397,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const double in_elems = (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
   const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
   char fam[48];  // the kernel's own name, as rocprofv3 prints it (minus spaces)
-  snprintf(fam, sizeof(fam), BF ? "conv1d_mfma_kernel<%d,%d,%d,%d,%d,true>" : "conv1d_mfma_kernel<%d,%d,%d,%d,%d>", WM, WN, MT,
-           NT, KS);
+  snprintf(fam, sizeof(fam), BF ? "conv1d_mfma_kernel<%d,%d,%d,%d,%d,true>" : "conv1d_mfma_kernel<%d,%d,%d,%d,%d,false>", WM,
+           WN, MT, NT, KS);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
   ProfScope prof(fam, flops, bytes, st, detail);

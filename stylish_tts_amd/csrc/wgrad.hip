@@ -712,7 +712,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     char detail[40];
     snprintf(detail, sizeof(detail), "ci%d co%d k1 T%d W%d", w.Cin, w.Cout, fwd.T, fwd.flatW);
     char fam[48];
-    snprintf(fam, sizeof(fam), fwd.bf16 ? "wgrad_k1_kernel<%d,%d,%d,%d,true>" : "wgrad_k1_kernel<%d,%d,%d,%d>", c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 1 : (c.TO == 32 ? 4 : 2)),
+    snprintf(fam, sizeof(fam), fwd.bf16 ? "wgrad_k1_kernel<%d,%d,%d,%d,true>" : "wgrad_k1_kernel<%d,%d,%d,%d,false>", c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 1 : (c.TO == 32 ? 4 : 2)),
              c.TI == 128 && c.TO == 128 ? 2 : (c.TI == 32 ? 4 : (c.TO == 32 ? 1 : 2)), c.TI == 128 && c.TO == 128 ? 2 : 1,
              c.TI == 128 && c.TO == 128 ? 2 : 1);
     ProfScope prof(fam, 2.0 * w.Cin * (double)fwd.B * w.Cout * fwd.T,
@@ -770,7 +770,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     dim3 grid(cdiv(w.CinP, 64), cdiv(w.CoutP, 64), nsplit);
     char detail[40], fam[48];
     snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
-    snprintf(fam, sizeof(fam), fwd.bf16 ? "conv1d_wgrad64_kernel<%d,true>" : "conv1d_wgrad64_kernel<%d>", w.K <= 3 ? 3 : 5);
+    snprintf(fam, sizeof(fam), fwd.bf16 ? "conv1d_wgrad64_kernel<%d,true>" : "conv1d_wgrad64_kernel<%d,false>", w.K <= 3 ? 3 : 5);
     ProfScope prof(fam, 2.0 * w.Cin * w.K * (double)fwd.B * w.Cout * fwd.T,
                    4.0 * ((double)fwd.B * (w.Cin + w.Cout) * fwd.T), st, detail);
     const int wb = gbias != nullptr;
@@ -805,7 +805,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, fwd.T, fwd.flatW);
   char fam[48];
-  snprintf(fam, sizeof(fam), fwd.bf16 ? "conv1d_wgrad_kernel<%d,true>" : "conv1d_wgrad_kernel<%d>",
+  snprintf(fam, sizeof(fam), fwd.bf16 ? "conv1d_wgrad_kernel<%d,true>" : "conv1d_wgrad_kernel<%d,false>",
            cdiv(w.K, 4) <= 3 ? cdiv(w.K, 4) : 6);
   ProfScope prof(fam, flops, bytes, st, detail);
   const int KT = cdiv(w.K, 4);

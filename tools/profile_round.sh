@@ -19,6 +19,8 @@ python tools/pmc_traffic.py $O/c2_fetch $O/c2_write > $O/${tag}_c2_pmc_traffic.j
 python bench.py > $O/${tag}_bench_c2.json 2> $O/bench_c2.err
 python bench.py --workload c2-fwd --no-cpu-baseline > $O/${tag}_bench_c2_fwd.json 2>/dev/null
 python bench.py --workload c3-fp32 --steps 5 --warmup 2 --no-cpu-baseline > $O/${tag}_bench_c3_fp32.json 2>/dev/null
+python bench.py --workload c3 --steps 5 --warmup 2 --no-cpu-baseline > $O/${tag}_bench_c3_bf16.json 2>/dev/null
+python bench.py --workload c5-bf16 --steps 50 --warmup 10 --no-cpu-baseline > $O/${tag}_bench_c5_bf16.json 2>/dev/null
 python bench.py --workload c5 --steps 50 --warmup 10 > $O/${tag}_bench_c5.json 2>/dev/null
 rm -rf $O/c2_trace $O/c5_trace $O/c2_fetch/*/*agent_info.csv
 ls -la $O
