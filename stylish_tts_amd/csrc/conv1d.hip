@@ -48,7 +48,7 @@ __device__ __forceinline__ float act_apply(float x, float alpha) {
 // number of LDS / L2 reads as the fp32 path: 16 per 32-channel chunk and fragment), rounds them with
 // v_cvt_pk_bf16_f32 and issues 2 MFMAs per chunk, tap and tile instead of 16.  Accumulation is fp32.
 template <int WM, int WN, int MT, int NT, int KS = 1, bool BF = false>
-__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 4 : STY_MINW)) void conv1d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS >= 8 ? 4 : STY_MINW)) void conv1d_mfma_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;  // waves per reduction group (4 or 8)
   constexpr int NTHR = 64 * NW * KS;
   extern __shared__ __attribute__((aligned(16))) float xs_all[];
@@ -432,6 +432,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     if (forced == 3) return launch_cfg<1, 8, 1, 2>(a, st);
     if (forced == 4) return launch_cfg<1, 4, 1, 2>(a, st);
     if (forced == 5 && a.w.CoutP % 64 == 0 && a.w.CinP >= 2 * CI_CHUNK) return launch_cfg<2, 2, 1, 1, 2>(a, st);
+    if (forced == 6 && a.w.CoutP % 64 == 0 && a.w.CinP >= 4 * CI_CHUNK) return launch_cfg<2, 2, 1, 1, 4>(a, st);
   }
   // Tile choice: the biggest output tile that still gives the chip >= ~2 workgroups per CU; the 256-channel stage
   // runs at T <= 800 frames, where 128x128 tiles would launch ~100 workgroups on 256 CUs.
@@ -444,9 +445,15 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   if (a.w.CoutP % 64 == 0) {
     const long tiles64 = (long)cdiv(a.T, 256) * (a.w.CoutP / 64) * a.B;
     if (tiles64 >= 512) return launch_cfg<1, 4, 2, 2>(a, st);
-    // 64 couts x 64 time; with few workgroups and a long reduction, two wave groups split the reduction
+    // 64 couts x 64 time; with few workgroups and a long reduction, two (or, below one workgroup per CU and from 8
+    // chunks up, four) wave groups split the reduction
     static const bool ks_on = getenv("STY_NO_KSPLIT") == nullptr;
     const long wgs = (long)cdiv(a.T, 64) * (a.w.CoutP / 64) * a.B;
+    static const int ks4_wgs = getenv("STY_KS4_WGS") ? atoi(getenv("STY_KS4_WGS")) : 256;
+    // (not for the DFT GEMMs of the front end / losses, ksplit_max = 2: their phase outputs are pinned at a wrapped
+    // tolerance that a different summation order moves at the magnitude gate -- n_fft 2048: 7e-3 vs 5e-3)
+    if (ks_on && wgs <= ks4_wgs && a.ksplit_max >= 4 && a.w.CinP >= 8 * CI_CHUNK && a.pro != PRO_LN_AFFINE)
+      return launch_cfg<2, 2, 1, 1, 4>(a, st);
     if (ks_on && wgs <= 768 && a.w.CinP >= 4 * CI_CHUNK && a.pro != PRO_LN_AFFINE) return launch_cfg<2, 2, 1, 1, 2>(a, st);
     return launch_cfg<2, 2, 1, 1>(a, st);
   }

@@ -111,6 +111,9 @@ struct StageRegs {
   bool live[ITER][2];
 };
 
+// (Measured and rejected: ONE descriptor per batch slab with the row as a VALU byte offset, as the weight-gradient kernels
+// do -- c2 step 45.6 -> 48.0 ms, c5 10.75 -> 11.5 ms.  Here the per-row descriptor keeps the row offset out of the VGPRs
+// and lets the hardware range check produce the zero padding.)
 // Phase 1: issue the global loads of channels [ci0, ci0+32) x LW columns (nothing waits on them here).
 // `wave` must be wave-uniform for the compiler (readfirstlane), or every load is wrapped in a waterfall loop.
 // The first TBASE/64 column groups always exist; only the halo groups are guarded (MAXJ covers a 128-sample halo).

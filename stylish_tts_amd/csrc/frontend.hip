@@ -209,6 +209,7 @@ static int dense(const PackedConv& w, const float* x, int B, int T, float* y, hi
   a.w = w;
   a.pad = 0;
   a.y = y;
+  a.ksplit_max = 2;
   return launch_conv1d(a, st);
 }
 

@@ -94,6 +94,7 @@ struct ConvArgs {
   // and row kh reads x shifted by (kh - hpad)*flatW.  flatW == 0: plain 1-D conv.
   int hpad = 0, Cin2d = 0;
   int flatW = 0;
+  int ksplit_max = 4;     // most wave groups the in-workgroup split-K may use (the front end's DFT GEMMs keep 2)
   int bf16 = 0;           // 1: GEMM operands rounded to bf16 (v_mfma_f32_32x32x16_bf16), fp32 accumulation and storage
   int in_shuffle = 0;     // > 1: source 0 is stored pixel-shuffled [B][C/s][T*s] (backward of a shuffled store)
   PackedConv w;

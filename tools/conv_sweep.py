@@ -52,7 +52,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         run_one()
     else:
-        for cfg in ("", "0", "1", "2", "3", "4", "5"):
+        for cfg in os.environ.get("SWEEP_CFGS", ",0,1,2,3,4,5,6").split(","):
             env = dict(os.environ)
             if cfg:
                 env["STY_CONV_CFG"] = cfg
