@@ -444,7 +444,7 @@ int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, 
   return STY_OK;
 }
 __global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C, int T, int K,
-                                     int pad, float* __restrict__ dx, int accumulate) {
+                                     int pad, float* __restrict__ dx, int accumulate, const float* __restrict__ src) {
   const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
   const float* p = dy + ((size_t)b * C + c) * T;
@@ -454,7 +454,7 @@ __global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* 
     if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
   }
   const size_t o = ((size_t)b * C + c) * T + t;
-  dx[o] = accumulate ? dx[o] + acc : acc;
+  dx[o] = src ? src[o] + acc : (accumulate ? dx[o] + acc : acc);  // src: out-of-place accumulate (dx = src + result)
 }
 // dw[c][k] += sum_{b,t} dy[t] x[t - pad + k], db[c] += sum dy.  Two deterministic stages: one workgroup per
 // (channel, batch row, 4096-sample segment) writes K+1 partial sums, a second kernel adds them in a fixed order.
@@ -509,10 +509,10 @@ __global__ void dwconv_bwd_w_sum_kernel(const float* __restrict__ part, int C, i
 }
 size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K) { return (size_t)C * B * cdiv(T, DW_SEG) * (K + 1); }
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
-                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st) {
+                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src) {
   if (dx)
     hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
-                       accumulate);
+                       accumulate, dx_src);
   if (dw) {
     const int nseg = cdiv(T, DW_SEG);
     if (K <= 7)

@@ -222,7 +222,7 @@ int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, 
                       hipStream_t st);
 size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K);
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
-                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st);
+                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src = nullptr);
 int launch_bn_eval_fwd(const float* x, const float* w, const float* b, const float* rm, const float* rv, float eps,
                        int B, int C, int T, float* y, hipStream_t st);
 int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const float* rm, const float* rv, float eps,

@@ -432,9 +432,19 @@ struct Trainer {
       float* gY = G(y, (size_t)B * C * Tt);
       int acc = 1;
       float* gX = wants(x) ? Gw(x, (size_t)B * C * Tt, acc) : nullptr;
+      float* gw = PG(w, (size_t)C * K);
+      float* gb = PG(bias, C);
+      if (side_ready() && gX != gY) {  // weight / bias gradient (a leaf) on the side stream, input gradient here
+        float* sc = take<float>(dwconv_bwd_scratch_floats(B, C, Tt, K));  // kept to the end of the step
+        side_push(gY, [=](hipStream_t s2) {
+          chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, nullptr, 0, gw, gb, sc, s2));
+        });
+        if (live() && gX) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, acc, nullptr, nullptr, nullptr, st));
+        return;
+      }
       const size_t mark = ws.off;
       float* sc = take<float>(dwconv_bwd_scratch_floats(B, C, Tt, K));
-      if (live()) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, acc, PG(w, (size_t)C * K), PG(bias, C), sc, st));
+      if (live()) chk(launch_dwconv_bwd(x, gY, w, B, C, Tt, K, pad, gX, acc, gw, gb, sc, st));
       ws.off = mark;
     });
     return y;
@@ -470,26 +480,48 @@ struct Trainer {
     }
     const float* gbl = gbp(c.norm);
     float* dgl = dgbp(c.norm);
+    {
+      const size_t p1n = wgrad_partial_floats(c.pw1, B, Tt), p2n = wgrad_partial_floats(c.pw2, B, Tt);
+      side_need = p1n > side_need ? p1n : side_need;
+      side_need = p2n > side_need ? p2n : side_need;
+    }
     tape.push_back([=]() {
       float* gY = G(y, n32);
-      // y = ... + x: the output gradient becomes (or is added to) the input's gradient
+      const bool side = side_ready();
+      // y = ... + x: the output gradient becomes (or is added to) the input's gradient.  With the weight gradients on
+      // the side stream gY stays read-only: the input gradient goes to a buffer of its own (gX = gY + dwconv^T(gU),
+      // written out of place by the depthwise kernel)
       float* gX;
+      const float* gx_src = nullptr;
       if (!gmap.count(x)) {
-        gmap[x] = gY;
-        gX = gY;
+        if (side) {
+          gX = take<float>(n32);
+          gmap[x] = gX;
+          gx_src = gY;
+        } else {
+          gmap[x] = gY;
+          gX = gY;
+        }
       } else {
         gX = G(x, n32);
         if (live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, 1, (int)n32, gX, st));
       }
+      // operands of the side-stream launches live until the end of the step (one set per block; the main stream
+      // never has to wait before reusing anything)
+      float* hs_p = side ? take<float>(n128) : nullptr;
+      float* gh0_p = side ? take<float>(n128) : nullptr;
+      float* xn_p = side ? take<float>(n32) : nullptr;
+      float* gu_p = side ? take<float>(n32) : nullptr;
+      float* dsc_p = side ? take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7)) : nullptr;
       const size_t mark = ws.off;
       double* pds = take<double>((size_t)B * 128 * nt);
       double* pgb = take<double>((size_t)B * 64 * nt);
       float* ds = take<float>((size_t)B * 128);
       float* coef = take<float>((size_t)B * 128);
-      float* hs = take<float>(n128);
-      float* gh0 = take<float>(n128);
-      float* xn = take<float>(n32);
-      float* gu = take<float>(n32);
+      float* hs = side ? hs_p : take<float>(n128);
+      float* gh0 = side ? gh0_p : take<float>(n128);
+      float* xn = side ? xn_p : take<float>(n32);
+      float* gu = side ? gu_p : take<float>(n32);
       Cnx32BwdArgs a;
       a.x = x;
       a.gy = gY;
@@ -514,21 +546,38 @@ struct Trainer {
       // weight gradients run on the K = 1 weight-gradient kernel: pw2 from (h s, gY), pw1 from (xn, gH0)
       ConvArgs f2 = base(c.pw2, hs, Tt, nullptr);
       ConvArgs f1 = base(c.pw1, xn, Tt, nullptr);
-      float* p2 = take<float>(wgrad_partial_floats(c.pw2, B, Tt));
-      float* p1 = take<float>(wgrad_partial_floats(c.pw1, B, Tt));
-      float* dsc = take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7));
+      float* p2 = side ? side_partial : take<float>(wgrad_partial_floats(c.pw2, B, Tt));
+      float* p1 = side ? side_partial : take<float>(wgrad_partial_floats(c.pw1, B, Tt));
+      float* dsc = side ? dsc_p : take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7));
       if (live()) {
-        bool done = false;
         chk(launch_convnext32_bwd(a, B, 1, st));
         chk(launch_cnx_partial_sum(pds, B, 128, nt, 0, ds, st));
         chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
         chk(launch_convnext32_bwd(a, B, 2, st));
         chk(launch_cnx_partial_sum(pds, B, 128, nt, 1, PG(c.alpha, 128), st));
         chk(launch_cnx_partial_sum(pgb, B, 64, nt, 2, dgl, st));
-        chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, PGpacked(c.pw2.wp), p2, PGpacked(c.pw2.bias), &done, st));
-        chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, PGpacked(c.pw1.wp), p1, PGpacked(c.pw1.bias), &done, st));
+      }
+      float* gw2 = PGpacked(c.pw2.wp);
+      float* gb2 = PGpacked(c.pw2.bias);
+      float* gw1 = PGpacked(c.pw1.wp);
+      float* gb1 = PGpacked(c.pw1.bias);
+      float* gdw = PG(c.dw_w, 32 * 7);
+      float* gdb = PG(c.dw_b, 32);
+      const float* dww = c.dw_w;
+      if (side) {
+        side_push(gY, [=](hipStream_t s2) {
+          chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, gw2, p2, gb2, nullptr, s2));
+          chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, nullptr, s2));
+          chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, s2));
+        });
+        // input gradient of the depthwise conv on the main stream
+        if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
+      } else if (live()) {
+        bool done = false;
+        chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, gw2, p2, gb2, &done, st));
+        chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, &done, st));
         // depthwise conv backward from gU; note gX may alias gY, which every kernel above has finished reading
-        chk(launch_dwconv_bwd(x, gu, c.dw_w, B, 32, Tt, 7, 3, gX, 1, PG(c.dw_w, 32 * 7), PG(c.dw_b, 32), dsc, st));
+        chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, gdw, gdb, dsc, st));
       }
       ws.off = mark;
     });
