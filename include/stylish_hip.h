@@ -231,6 +231,10 @@ typedef struct {
   double bytes; /* summed algorithmic HBM bytes (each operand tensor read once, each result written once) */
 } sty_prof_row;
 int sty_prof_enable(int on);
+/* Restrict the timing to one kernel family (its name as sty_prof_report prints it); NULL or "" = all.  Two events
+ * per launch on ~700 launches cost ~7 % of a c2 training step; bench.py times every family during warm-up, then only
+ * the dominant one inside the timed region.                                                                      */
+int sty_prof_only(const char *family);
 int sty_prof_report(sty_prof_row *rows, int cap);
 
 #ifdef __cplusplus

@@ -29,6 +29,7 @@ struct ProfEntry {
   hipEvent_t a, b;
 };
 static bool g_prof_on = false;
+static std::string g_prof_only;  // non-empty: only launches of this family are timed (sty_prof_only)
 static std::vector<ProfEntry> g_prof;
 static std::vector<hipEvent_t> g_evpool;
 static hipEvent_t prof_event() {
@@ -45,6 +46,7 @@ static hipEvent_t prof_event() {
 static const bool g_prof_shapes = getenv("STY_PROF_SHAPES") != nullptr;
 ProfScope::ProfScope(const char* family, double flops, double bytes, hipStream_t s, const char* detail) : st(s) {
   if (!g_prof_on) return;
+  if (!g_prof_only.empty() && g_prof_only != family) return;
   std::string name(family);
   if (g_prof_shapes && detail) name = name + " " + detail;
   ProfEntry e{name, flops, bytes, prof_event(), prof_event()};
@@ -1132,6 +1134,10 @@ extern "C" {
 
 int sty_prof_enable(int on) {
   g_prof_on = on != 0;
+  return STY_OK;
+}
+int sty_prof_only(const char* family) {
+  g_prof_only = family ? family : "";
   return STY_OK;
 }
 int sty_prof_report(sty_prof_row* rows, int cap) {

@@ -52,6 +52,7 @@ struct Trainer {
   // The side stream has its own partial-sum buffer (side_partial, sized in the forward for the largest conv): the
   // main stream recycles its temporaries while the queued launches are still pending.
   size_t SIDE_BATCH = getenv("STY_SIDE_BATCH") ? atoi(getenv("STY_SIDE_BATCH")) : 1;
+  std::vector<char> fcs_bwd_sent;  // last fc-backward table uploaded to m->fcs_bwd_dev
   hipStream_t st2 = nullptr;
   bool side_on = getenv("STY_NO_SIDE_STREAM") == nullptr;
   std::vector<hipEvent_t> evs;
@@ -1401,12 +1402,16 @@ struct Trainer {
         if (e != hipSuccess) rc = hip_fail(e, "fc bwd table");
       }
       if (rc == STY_OK) {
-        hipError_t e = hipMemcpyAsync(m->fcs_bwd_dev, hb.data(), hb.size() * sizeof(StyleFcBwdDesc),
-                                      hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) rc = hip_fail(e, "fc bwd table copy");
-        // the host vector must outlive the async copy
-        e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = hip_fail(e, "sync");
+        // the table only changes when gradients are re-bound: upload (with a blocking copy) when it differs from the
+        // last one sent.  (An upload + stream synchronise every step made the host wait for the whole backward here:
+        // the CPU then started issuing the style encoder's backward only after the GPU had drained.)
+        const size_t nb = hb.size() * sizeof(StyleFcBwdDesc);
+        if (fcs_bwd_sent.size() != nb || memcmp(fcs_bwd_sent.data(), hb.data(), nb) != 0) {
+          hipError_t e = hipStreamSynchronize(st);  // a previous step's kernel may still read the old table
+          if (e == hipSuccess) e = hipMemcpy(m->fcs_bwd_dev, hb.data(), nb, hipMemcpyHostToDevice);
+          if (e != hipSuccess) rc = hip_fail(e, "fc bwd table copy");
+          fcs_bwd_sent.assign(reinterpret_cast<const char*>(hb.data()), reinterpret_cast<const char*>(hb.data()) + nb);
+        }
         chk(launch_style_fc_bwd(m->fcs_bwd_dev, (int)hb.size(), B, m->style_dim, style, dgb, d_style, st));
       }
     }
