@@ -92,6 +92,9 @@ typedef struct {
   float *tap_text_encoding; /* [B,128,L] */
   float *tap_decoder_out;   /* [B,128,T] */
   sty_vocoder_io voc_taps;  /* only the tap_* fields are read */
+  void *style_stream;       /* sty_speech_fwd_train: HIP stream on which `style` is being produced (NULL: the call's own
+                               stream).  The call waits for that stream's current position right before the first use
+                               of style, i.e. after the text encoder: a style encoder on a second stream overlaps it. */
 } sty_speech_io;
 int sty_speech_workspace_bytes(const sty_model *m, int B, int L, int T, size_t *bytes);
 int sty_speech_fwd(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
@@ -183,6 +186,10 @@ int sty_vocoder_bwd(sty_model *m, const float *d_audio, float *d_mel, float *d_s
 int sty_speech_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);
 int sty_speech_fwd_train(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
 int sty_speech_bwd(sty_model *m, const float *d_audio, float *d_style, float *d_energy, void *stream);
+/* d_style of the last sty_speech_bwd is complete before the text encoder's backward has run: this makes `stream` wait
+ * for exactly that point, so that the style encoder's backward can start on `stream` while the call's own stream still
+ * works through the text encoder (AcousticTrainer does this).                                                    */
+int sty_speech_d_style_ready(sty_model *m, void *stream);
 /* Same for MelStyleEncoder.forward: gradients of every parameter (through the eval-mode spectral norm
  * W/sigma(W) with fixed u, v: torch.nn.utils.spectral_norm, mel_style_encoder.py:67-152) from d loss / d style. */
 int sty_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);

@@ -88,6 +88,15 @@ class AcousticTrainer:
         self.opt = {"speech_predictor": FlatAdamW(list(self.sp.parameters()), **kw),
                     "speech_style_encoder": FlatAdamW(list(self.se.parameters()), **kw)}
 
+    def _side_stream(self, device):
+        """second torch stream for the style encoder (STY_NO_SE_STREAM=1: everything on the current stream)"""
+        import os
+        if os.environ.get("STY_NO_SE_STREAM"):
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
     def train_batch(self, *, audio_gt, texts, text_lengths, pitch, durations, noise=None, seed=0,
                     prior_override=None):
         """One optimizer step; returns the (mel, multi_phase) loss values as a device tensor [2]."""
@@ -105,15 +114,32 @@ class AcousticTrainer:
         style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)
         T = mel.shape[2]
         alignment = duration_to_alignment(durations, T)
-        style = self.se.forward_train(style_mel.unsqueeze(1))
+        # Two streams: the style encoder (mid-size GEMMs) runs beside the text encoder (a chain of tiny kernels) in
+        # both directions.  Forward: the predictor waits for `style` only after its text encoder; backward: d_style
+        # is complete before the text encoder's backward, and the style encoder's backward starts from there.
+        main = torch.cuda.current_stream(audio_gt.device)
+        side = self._side_stream(audio_gt.device)
+        style_in = style_mel.unsqueeze(1)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                style = self.se.forward_train(style_in)
+        else:
+            style = self.se.forward_train(style_in)
         voiced = (pitch > 20).float()
         audio = self.sp.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, pitch,
-                                      noise=noise, seed=seed, prior_override=prior_override)
+                                      noise=noise, seed=seed, prior_override=prior_override, style_stream=side)
         losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase)
         d_style, _ = self.sp.backward(d_audio, want_style=True, want_energy=False)
         gp, gs = self.opt["speech_predictor"].grads, self.opt["speech_style_encoder"].grads
         gp.reduce_all()                 # overlaps the style encoder's backward
-        self.se.backward(d_style)
+        if side is not None:
+            self.sp.wait_d_style(side)
+            with torch.cuda.stream(side):
+                self.se.backward(d_style)
+            main.wait_stream(side)
+        else:
+            self.se.backward(d_style)
         gs.reduce_all()
         gp.finish()
         gs.finish()

@@ -1416,6 +1416,15 @@ int sty_speech_bwd(sty_model* m, const float* d_audio, float* d_style, float* d_
   return unpack_grads(m, S(stream));
 }
 
+int sty_speech_d_style_ready(sty_model* m, void* stream) {
+  int rc = model_ready(m, "speech_predictor");
+  if (rc) return rc;
+  if (!m->trainer) {
+    set_error("sty_speech_d_style_ready: no backward has run");
+    return STY_ESTATE;
+  }
+  return trainer_wait_d_style(m->trainer, S(stream));
+}
 int sty_vocoder_train_workspace_bytes(sty_model* m, int B, int T, size_t* bytes) {
   int rc = model_ready(m, "speech_predictor", "vocoder");
   if (rc) return rc;

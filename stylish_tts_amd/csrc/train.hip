@@ -64,6 +64,7 @@ struct Trainer {
   float* side_partial = nullptr;
   ~Trainer() {
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (d_style_done) (void)hipEventDestroy(d_style_done);
     if (st2) (void)hipStreamDestroy(st2);
   }
   hipEvent_t next_event() {
@@ -1269,8 +1270,8 @@ struct Trainer {
     scratch_param = take<float>(scratch_param_n);
     gb = take<float>(m->gb_floats_per_batch * B);
     dgb = take<float>(m->gb_floats_per_batch * B);
+    fc_bwd_done = false;
     if (live()) {
-      if (!m->fcs.empty()) chk(launch_style_fc(m->fcs_dev, (int)m->fcs.size(), B, m->style_dim, style, gb, st));
       hipError_t e = hipMemsetAsync(dgb, 0, m->gb_floats_per_batch * B * sizeof(float), st);
       if (e != hipSuccess) rc = hip_fail(e, "dgb memset");
       if (m->garena) {
@@ -1280,11 +1281,29 @@ struct Trainer {
     }
   }
 
+  // fc(style) of every AdaIN / AdaLN layer: the first use of `style`.  The speech graph runs it AFTER the text encoder
+  // (which has no style input) so that a style encoder running on another stream overlaps the text encoder.
+  void style_fc(hipStream_t style_stream) {
+    if (!live()) return;
+    if (style_stream && style_stream != st) {
+      hipEvent_t e = next_event();  // (the pool is reset at the start of the backward; this one is used before it)
+      if (rc == STY_OK) {
+        hipError_t r = hipEventRecord(e, style_stream);
+        if (r == hipSuccess) r = hipStreamWaitEvent(st, e, 0);
+        if (r != hipSuccess) rc = hip_fail(r, "style stream wait");
+      }
+    }
+    if (!m->fcs.empty()) chk(launch_style_fc(m->fcs_dev, (int)m->fcs.size(), B, m->style_dim, style, gb, st));
+  }
+
   void forward(const sty_vocoder_io& io, bool fresh = true) {
     const VocoderPlan& v = m->voc;
     T = io.T;
     const int Tt = io.T, Tu = 75 * Tt, N = 300 * Tt, C = v.hidden;
-    if (fresh) begin(io.style);
+    if (fresh) {
+      begin(io.style);
+      style_fc(nullptr);
+    }
     mel_in = io.mel;
     // harmonic source branch: no gradient (torch.no_grad in the reference, generator.py:711-729)
     float* prior = take<float>((size_t)B * N);
@@ -1365,24 +1384,17 @@ struct Trainer {
     });
   }
 
-  void backward(const float* d_audio, float* d_mel, float* d_style) {
-    // seed: gradient of the audio
-    const size_t na = (size_t)B * 300 * T;
-    side_begin();
-    float* gA = G(audio, na);
-    if (live() && d_audio) {
-      hipError_t e = hipMemcpyAsync(gA, d_audio, na * sizeof(float), hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) rc = hip_fail(e, "seed copy");
-    }
-    if (!d_mel) nograd.insert(mel_in);
-    if (d_mel == reinterpret_cast<float*>(2)) d_mel = nullptr;  // speech graph: mel is an internal activation
-    for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
-      (*it)();
-      if (rc != STY_OK) break;
-    }
-    side_join();
-    if (rc != STY_OK) return;
-    // fc(style) backward for every AdaIN / AdaLN layer
+  // fc(style) backward for every AdaIN / AdaLN layer -> d_style.  Runs once per backward: from the tape hook the speech
+  // graph places between the text encoder and the decoder (every consumer of style has run its backward by then; the
+  // text encoder's backward, still to come, does not touch d_style), or after the tape.  d_style_done is recorded
+  // behind it so that a caller can start the style encoder's backward on another stream (sty_speech_d_style_ready).
+  float* d_style_out = nullptr;
+  bool fc_bwd_done = false;
+  hipEvent_t d_style_done = nullptr;
+  void style_fc_backward() {
+    if (fc_bwd_done) return;
+    fc_bwd_done = true;
+    float* d_style = d_style_out;
     if (live() && !m->fcs.empty()) {
       if (d_style) {
         hipError_t e = hipMemsetAsync(d_style, 0, (size_t)B * m->style_dim * sizeof(float), st);
@@ -1415,6 +1427,38 @@ struct Trainer {
         chk(launch_style_fc_bwd(m->fcs_bwd_dev, (int)hb.size(), B, m->style_dim, style, dgb, d_style, st));
       }
     }
+    if (live()) {
+      if (!d_style_done) {
+        hipError_t e = hipEventCreateWithFlags(&d_style_done, hipEventDisableTiming);
+        if (e != hipSuccess) rc = hip_fail(e, "event");
+      }
+      if (d_style_done) {
+        hipError_t e = hipEventRecord(d_style_done, st);
+        if (e != hipSuccess) rc = hip_fail(e, "d_style event");
+      }
+    }
+  }
+
+  void backward(const float* d_audio, float* d_mel, float* d_style) {
+    // seed: gradient of the audio
+    const size_t na = (size_t)B * 300 * T;
+    side_begin();
+    d_style_out = d_style;
+    fc_bwd_done = false;
+    float* gA = G(audio, na);
+    if (live() && d_audio) {
+      hipError_t e = hipMemcpyAsync(gA, d_audio, na * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "seed copy");
+    }
+    if (!d_mel) nograd.insert(mel_in);
+    if (d_mel == reinterpret_cast<float*>(2)) d_mel = nullptr;  // speech graph: mel is an internal activation
+    for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
+      (*it)();
+      if (rc != STY_OK) break;
+    }
+    side_join();
+    if (rc != STY_OK) return;
+    style_fc_backward();
     if (live() && d_mel) {
       float* gm = G(mel_in, (size_t)B * m->voc.amp_input_conv.Cin * T);
       hipError_t e = hipMemcpyAsync(d_mel, gm, (size_t)B * m->voc.amp_input_conv.Cin * T * sizeof(float),
@@ -1437,6 +1481,8 @@ int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t
   t->begin(io->style);
   const int inter = t->m->te.proj_m.Cout ? t->m->te.proj_m.Cout : 128;
   float* mu = t->text_encoder(io->texts, io->text_lengths, io->L);
+  t->tape.push_back([t]() { t->style_fc_backward(); });  // runs before the text encoder's backward
+  t->style_fc(reinterpret_cast<hipStream_t>(io->style_stream));
   float* asr = t->expand(mu, io->alignment, inter, io->L, io->T);
   float* mel = t->decoder(asr, io->pitch, io->energy, io->voiced, io->T);
   if (mel) {
@@ -1480,6 +1526,16 @@ int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, fl
     return STY_ENOMEM;
   }
   return t->rc;
+}
+
+int trainer_wait_d_style(Trainer* t, hipStream_t stream) {
+  if (!t->d_style_done) {
+    set_error("sty_speech_d_style_ready: no backward has produced d_style");
+    return STY_ESTATE;
+  }
+  hipError_t e = hipStreamWaitEvent(stream, t->d_style_done, 0);
+  if (e != hipSuccess) return hip_fail(e, "d_style wait");
+  return STY_OK;
 }
 
 int trainer_style_forward(Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,

@@ -26,7 +26,7 @@ class SpeechIO(C.Structure):
         (n, C.c_void_p) for n in ("texts", "text_lengths", "alignment", "pitch", "energy", "voiced", "style",
                                   "denormal_pitch", "noise", "prior_override")
     ] + [("seed", C.c_uint64), ("audio", C.c_void_p), ("tap_text_encoding", C.c_void_p),
-         ("tap_decoder_out", C.c_void_p), ("voc_taps", VocoderIO)]
+         ("tap_decoder_out", C.c_void_p), ("voc_taps", VocoderIO), ("style_stream", C.c_void_p)]
 
 
 class TrainOpts(C.Structure):
@@ -73,6 +73,7 @@ SYMBOLS = {
     "sty_speech_train_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
     "sty_speech_fwd_train": (C.c_int, [_P, C.POINTER(SpeechIO), _P, C.c_size_t, _P]),
     "sty_speech_bwd": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sty_speech_d_style_ready": (C.c_int, [_P, _P]),
     "sty_style_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_style_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "sty_style_bwd": (C.c_int, [_P, _P, _P]),

@@ -306,8 +306,10 @@ class SpeechPredictor(_HipModule):
 
 
     def forward_train(self, texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, *, noise=None,
-                      seed=0, prior_override=None):
-        """SpeechPredictor.forward in the training graph (eval-mode statistics); follow with backward(d_audio)."""
+                      seed=0, prior_override=None, style_stream=None):
+        """SpeechPredictor.forward in the training graph (eval-mode statistics); follow with backward(d_audio).
+        style_stream: the torch stream `style` is being computed on, when it is not the current one -- the call waits
+        for it right before the first use of style, after the text encoder (sty_speech_io.style_stream)."""
         dev = style.device
         self._train = True
         lib = self._ensure(dev)
@@ -325,6 +327,7 @@ class SpeechPredictor(_HipModule):
                 keep.append(t)
                 setattr(io, name, t.data_ptr())
         io.seed = int(seed)
+        io.style_stream = style_stream.cuda_stream if style_stream is not None else None
         audio = torch.empty(B, 1, 300 * T, dtype=torch.float32, device=dev)
         io.audio = audio.data_ptr()
         need = C.c_size_t()
@@ -349,6 +352,11 @@ class SpeechPredictor(_HipModule):
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         L.check(lib.sty_speech_bwd(self._handle, L.ptr(d_audio), L.ptr(d_style), L.ptr(d_energy), st))
         return d_style, d_energy
+
+    def wait_d_style(self, stream):
+        """Make `stream` wait until d_style of the last backward() is complete (it is, before the text encoder's
+        backward has run): sty_speech_d_style_ready."""
+        L.check(L.load().sty_speech_d_style_ready(self._handle, C.c_void_p(stream.cuda_stream)))
 
 
 class MultiGenerator(SpeechPredictor):
