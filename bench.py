@@ -219,6 +219,12 @@ def main():
     # STY_BENCH_SHARE_DEVICE=1 (test aid): all ranks share device 0 and exchange gradients over gloo, so the N > 1 code
     # path can be exercised on a 1-GPU box; the numbers of such a run mean nothing
     share = os.environ.get("STY_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        # two processes time-slicing ONE GPU: cross-queue event waits then stall for whole time slices (measured:
+        # 161 ms per step single-stream, 16-28 s with the side streams).  Not a configuration anyone trains in; the
+        # test aid runs single-stream.  One process per GPU keeps its streams.
+        os.environ.setdefault("STY_NO_SIDE_STREAM", "1")
+        os.environ.setdefault("STY_NO_SE_STREAM", "1")
     local = 0 if share else local
     torch.cuda.set_device(local)
     rank, world = D.init("gloo" if share else "nccl")  # "nccl" = RCCL; one process per GPU (torchrun environment)
@@ -287,6 +293,24 @@ def main():
     lib.sty_prof_only(None)
     prof = L.prof_report(2048) if rank == 0 else []
     assert bool(torch.isfinite(out).all())
+    # After the timed region (training workloads, rank 0's view): the same step with the library's side streams off, all
+    # families timed -- the dominant kernel's duration free of the stretch from sharing the chip with the
+    # weight-gradient / style-encoder streams.  Reported beside `roofline`, never instead of it.
+    serial_prof = []
+    if trainer is not None:  # every rank: the steps contain the gradient all-reduce
+        lib.sty_set_single_stream(1)
+        trainer.single_stream = True
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        lib.sty_prof_enable(1)
+        for i in range(2):
+            step(args.warmup + args.steps + 1 + i)
+        torch.cuda.synchronize()
+        lib.sty_prof_enable(0)
+        serial_prof = L.prof_report(2048)
+        lib.sty_set_single_stream(0)
+        trainer.single_stream = False
+    barrier()
     dt = D.max_over_ranks(dt, device)
     if rank != 0:
         return
@@ -320,6 +344,15 @@ def main():
                            "mfma_TFLOPs": tf, "mfma_peak": peak, "mfma_frac": f_mfma,
                            "hbm_GBps_algorithmic": gbs, "hbm_frac": f_hbm,
                            "share_of_step_time": dom["ms"] / (1e3 * dt)}
+        sp = [r for r in serial_prof if r["name"] == dom["name"]]
+        if sp:
+            per1 = sp[0]["ms"] / sp[0]["launches"] * 1e-3
+            tf1 = sp[0]["flops"] / sp[0]["launches"] / per1 / 1e12
+            gb1 = sp[0]["bytes"] / sp[0]["launches"] / per1 / 1e9
+            rec["roofline"]["single_stream"] = {
+                "what": "same kernel, two extra steps after the timed region with the side streams off",
+                "avg_launch_us": per1 * 1e6, "mfma_TFLOPs": tf1, "mfma_frac": tf1 / peak,
+                "hbm_GBps_algorithmic": gb1, "hbm_frac": gb1 / PEAK_HBM_GBS}
         rec["kernels_source"] = f"HIP events over the last {nprof} warm-up step(s); roofline: over the timed region"
         rec["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / nprof,
                            "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,

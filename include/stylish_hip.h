@@ -242,6 +242,10 @@ int sty_prof_enable(int on);
  * per launch on ~700 launches cost ~7 % of a c2 training step; bench.py times every family during warm-up, then only
  * the dominant one inside the timed region.                                                                      */
 int sty_prof_only(const char *family);
+/* Measurement aid: 1 = the training entry points use no internal side stream (weight gradients run in line).  Kernel
+ * durations measured that way are free of the stretch from sharing the chip with another stream.  The workspace must
+ * have been sized in the same mode it is used in (call before sty_*_train_workspace_bytes).                        */
+int sty_set_single_stream(int on);
 int sty_prof_report(sty_prof_row *rows, int cap);
 
 #ifdef __cplusplus

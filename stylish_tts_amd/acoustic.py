@@ -91,7 +91,7 @@ class AcousticTrainer:
     def _side_stream(self, device):
         """second torch stream for the style encoder (STY_NO_SE_STREAM=1: everything on the current stream)"""
         import os
-        if os.environ.get("STY_NO_SE_STREAM"):
+        if os.environ.get("STY_NO_SE_STREAM") or getattr(self, "single_stream", False):
             return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=device)

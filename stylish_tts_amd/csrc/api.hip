@@ -28,6 +28,8 @@ struct ProfEntry {
   double flops, bytes;
   hipEvent_t a, b;
 };
+static bool g_single_stream = false;  // sty_set_single_stream
+bool single_stream_mode() { return g_single_stream; }
 static bool g_prof_on = false;
 static std::string g_prof_only;  // non-empty: only launches of this family are timed (sty_prof_only)
 static std::vector<ProfEntry> g_prof;
@@ -1134,6 +1136,10 @@ extern "C" {
 
 int sty_prof_enable(int on) {
   g_prof_on = on != 0;
+  return STY_OK;
+}
+int sty_set_single_stream(int on) {
+  sty::g_single_stream = on != 0;
   return STY_OK;
 }
 int sty_prof_only(const char* family) {

@@ -290,6 +290,7 @@ Trainer* trainer_create(sty_model* m);
 int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t ws_bytes, hipStream_t st,
                            size_t* need);
 int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st);
+bool single_stream_mode();  // sty_set_single_stream: no internal side streams (measurement aid)
 int trainer_wait_d_style(Trainer* t, hipStream_t stream);
 void trainer_destroy(Trainer* t);
 int trainer_vocoder_forward(Trainer* t, const sty_vocoder_io* io, void* ws, size_t ws_bytes, hipStream_t st,

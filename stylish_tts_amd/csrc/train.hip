@@ -81,8 +81,9 @@ struct Trainer {
     side_reads.clear();
     side_q.clear();
     side_dirty = false;
-    side_partial = side_on && side_need ? take<float>(side_need) : nullptr;
-    if (side_on && !st2 && live()) {
+    const bool on = side_on && !single_stream_mode();
+    side_partial = on && side_need ? take<float>(side_need) : nullptr;
+    if (on && !st2 && live()) {
       int least = 0, greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       hipError_t r = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, least);

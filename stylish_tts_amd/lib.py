@@ -87,6 +87,7 @@ SYMBOLS = {
     "sty_acoustic_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "sty_prof_enable": (C.c_int, [_I]),
     "sty_prof_only": (C.c_int, [C.c_char_p]),
+    "sty_set_single_stream": (C.c_int, [_I]),
     "sty_prof_report": (C.c_int, [_P, _I]),
 }
 
