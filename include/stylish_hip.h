@@ -124,6 +124,19 @@ int sty_multispec_fwd(int B, int N, const float *audio, float *const *mag, float
  * durations [B,L] -> alignment [B,L,T] (softmax over L)                                               */
 int sty_alignment_fwd(int B, int L, int T, const float *durations, float *alignment, void *stream);
 
+/* ---- second-stage predictors, inference ---------------------------------------
+ * Models of kind "duration_predictor" / "pitch_energy_predictor", bound by the reference's state_dict keys.
+ * DurationPredictor.forward(texts, text_lengths, style) (duration_predictor.py:74-87) -> dur_pred [B,L,classes];
+ * PitchEnergyPredictor.forward(texts, text_lengths, alignment [B,L,T], style) (pitch_energy_predictor.py:62-82)
+ * -> pitch [B,T], energy [B,T].  DurationProcessor (softmax over classes -> alignment) stays on the host side. */
+int sty_duration_workspace_bytes(const sty_model *m, int B, int L, size_t *bytes);
+int sty_duration_fwd(sty_model *m, int B, int L, const int64_t *texts, const int64_t *text_lengths, const float *style,
+                     float *dur_pred, void *workspace, size_t ws_bytes, void *stream);
+int sty_pitch_energy_workspace_bytes(const sty_model *m, int B, int L, int T, size_t *bytes);
+int sty_pitch_energy_fwd(sty_model *m, int B, int L, int T, const int64_t *texts, const int64_t *text_lengths,
+                         const float *alignment, const float *style, float *pitch, float *energy, void *workspace,
+                         size_t ws_bytes, void *stream);
+
 /* ---- fine-grained entry points for unit parity (each = one reference sub-module) ------------------ */
 /* GeneratorConvNeXtBlock (conv_next.py:80-93) of channel count C on [B,C,T]; prefix e.g.
  * "generator.basegen.phase_convnext.0".                                                              */

@@ -243,7 +243,7 @@ N3_CFG = dict(dp_layers=3, dp_classes=16, pe_inter=256, pe_layers=3, pe_heads=2)
 
 def duration_predictor_manifest(cfg=None):
     """DurationPredictor (duration_predictor.py:16-58), registration order of the reference."""
-    c = dict(DEFAULT_CFG, **N3_CFG, **(cfg or {}))
+    c = {**DEFAULT_CFG, **N3_CFG, **(cfg or {})}
     sd, d = c["style_dim"], c["inter_dim"]
     m = OrderedDict()
     _text_encoder(m, "text_encoder.", c, d)
@@ -273,7 +273,7 @@ def duration_predictor_manifest(cfg=None):
 
 def pitch_energy_predictor_manifest(cfg=None):
     """PitchEnergyPredictor (pitch_energy_predictor.py:8-60)."""
-    c = dict(DEFAULT_CFG, **N3_CFG, **(cfg or {}))
+    c = {**DEFAULT_CFG, **N3_CFG, **(cfg or {})}
     sd, d = c["style_dim"], c["pe_inter"]
     hc = d + sd
     m = OrderedDict()

@@ -5,4 +5,5 @@ fallback: importing the library without the built .so, or calling a compute entr
 device, raises.
 """
 from .lib import LIB, StyError, load  # noqa: F401
-from .modules import MelStyleEncoder, MultiGenerator, SpeechPredictor  # noqa: F401
+from .modules import (DurationPredictor, DurationProcessor, ExportModel, MelStyleEncoder, MultiGenerator,  # noqa: F401
+                      PitchEnergyPredictor, SpeechPredictor)

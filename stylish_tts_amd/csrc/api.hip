@@ -202,13 +202,14 @@ struct Builder {
     return a;
   }
 
-  ConvNeXt convnext(const std::string& p, int C) {
+  ConvNeXt convnext(const std::string& p, int C, bool snake = true) {
     ConvNeXt c;
     c.C = C;
     c.dw_w = ptr(p + ".dwconv.weight", {C, 1, 7});
     c.dw_b = ptr(p + ".dwconv.bias", {C});
     c.norm = fc(p + ".norm", C);
-    c.alpha = ptr(p + ".snake", {1, 1, 4 * C});
+    // GeneratorConvNeXtBlock has a snake parameter; AdaptiveConvNeXtBlock (duration predictor) uses GELU instead
+    c.alpha = snake ? ptr(p + ".snake", {1, 1, 4 * C}) : nullptr;
     c.grn_gamma = ptr(p + ".grn.gamma", {1, 1, 4 * C});
     const float* grn_beta = ptr(p + ".grn.beta", {1, 1, 4 * C});
     c.b1 = ptr(p + ".pwconv1.bias", {4 * C});
@@ -521,6 +522,56 @@ struct Builder {
     sp.fc_b = ptr("unshared.bias");
   }
 
+  // DurationPredictor (duration_predictor.py:16-58)
+  void duration_predictor() {
+    text_encoder("text_encoder.");
+    DurationPlan& d = m->dur;
+    const int C = m->te.proj_m.Cout;
+    d.cnx.clear();
+    for (int i = 0; has("conv_next." + std::to_string(i) + ".dwconv.weight"); ++i)
+      d.cnx.push_back(convnext("conv_next." + std::to_string(i), C, false));
+    d.proj = conv("duration_proj.linear_layer");
+    d.classes = d.proj.Cout;
+    d.qn = fc("query_norm", C);
+    d.kn = fc("key_norm", C);
+    d.cq = conv("cross_attention.conv_q");
+    d.ck = conv("cross_attention.conv_k");
+    d.cv = conv("cross_attention.conv_v");
+    d.co = conv("cross_attention.conv_o");
+    d.dw_g = ptr("cross_post.0.parametrizations.weight.original0", {C, 1, 1});
+    d.dw_v = ptr("cross_post.0.parametrizations.weight.original1", {C, 1, 5});
+    d.dw_b = ptr("cross_post.0.bias", {C});
+    d.post = conv("cross_post.2", true);
+  }
+  // PitchEnergyPredictor (pitch_energy_predictor.py:8-60)
+  void pitch_energy_predictor() {
+    text_encoder("text_encoder.");
+    PitchEnergyPlan& p = m->pe;
+    const int hc = m->te.proj_m.Cout + m->style_dim;
+    p.layers.clear();
+    const std::string pre = "prosody_encoder.";
+    for (int i = 0; has(pre + "attn_layers." + std::to_string(i) + ".conv_q.weight"); ++i) {
+      const std::string si = std::to_string(i);
+      ProsodyLayer l;
+      l.q = conv(pre + "attn_layers." + si + ".conv_q");
+      l.k = conv(pre + "attn_layers." + si + ".conv_k");
+      l.v = conv(pre + "attn_layers." + si + ".conv_v");
+      l.o = conv(pre + "attn_layers." + si + ".conv_o");
+      l.n1 = fc(pre + "norm_layers_1." + si, hc);
+      l.f1 = conv(pre + "ffn_layers." + si + ".conv_1");
+      l.f2 = conv(pre + "ffn_layers." + si + ".conv_2");
+      l.n2 = fc(pre + "norm_layers_2." + si, hc);
+      l.proj = conv(pre + "proj_layers." + si);
+      p.layers.push_back(l);
+    }
+    for (int i = 0; i < 4; ++i) {
+      p.f0[i] = dec_block("F0." + std::to_string(i));
+      p.nn[i] = dec_block("N." + std::to_string(i));
+    }
+    p.f0p = conv("F0_proj");
+    p.np = conv("N_proj");
+  }
+
   void build() {
     m->gb_floats_per_batch = 0;
     if (m->kind == "speech_predictor") {
@@ -531,6 +582,10 @@ struct Builder {
       vocoder("");
     } else if (m->kind == "mel_style_encoder") {
       style_encoder();
+    } else if (m->kind == "duration_predictor") {
+      duration_predictor();
+    } else if (m->kind == "pitch_energy_predictor") {
+      pitch_energy_predictor();
     }
   }
 };
@@ -635,7 +690,7 @@ struct Run {
     if (live()) {
       chk(launch_dwconv_adaln(x, c.dw_w, c.dw_b, B, C, T, 7, 1e-6f, gbp(c.norm), u, st));
       ConvArgs a = base(c.pw1, u, T, h);
-      a.act = ACT_SNAKE;
+      a.act = c.alpha ? ACT_SNAKE : ACT_GELU;  // Generator block: snake; AdaptiveConvNeXtBlock: exact GELU
       a.act_alpha = c.alpha;
       conv(a);
       chk(launch_row_stats(h, B * 4 * C, T, part, st));
@@ -962,6 +1017,9 @@ struct Run {
         c.out_scale = r2;
         conv(c);
         res = sc;
+      } else {  // identity shortcut (Cin == Cout): (h + x) / sqrt(2)
+        chk(launch_scale_copy(xcat, r2, (size_t)B * d.Cout * T, sc, st));
+        res = sc;
       }
       adain(xcat, d.Cin, T, d.n1, a, s, part);
       ConvArgs c1 = base(d.c1, xcat, T, h);
@@ -977,8 +1035,10 @@ struct Run {
       c2.out_scale = r2;
       c2.residual = res;
       conv(c2);
-      if (!d.has_sc) set_error("decoder block without learned shortcut is not built");
-      if (!d.has_sc) rc = STY_EINVAL;
+      if (!d.has_sc && d.Cin != d.Cout) {
+        set_error("decoder block: identity shortcut needs Cin == Cout");
+        rc = STY_EINVAL;
+      }
     }
   }
 
@@ -1120,6 +1180,151 @@ static int model_ready(const sty_model* m, const char* kind_a, const char* kind_
   return STY_OK;
 }
 
+// DurationPredictor.forward (duration_predictor.py:58-87): -> out [B][L][classes]
+static void duration_forward(Run& r, const int64_t* texts, const int64_t* lengths, int L, float* out) {
+  sty_model* m = r.m;
+  const DurationPlan& d = m->dur;
+  const int B = r.B, C = m->te.proj_m.Cout;
+  const size_t n = (size_t)B * C * L;
+  float* enc = r.ws.take<float>(n);
+  float* mask = r.ws.take<float>((size_t)B * L);
+  float* qn = r.ws.take<float>(n);
+  float* kn = r.ws.take<float>(n);
+  float* q = r.ws.take<float>(n);
+  float* k = r.ws.take<float>(n);
+  float* v = r.ws.take<float>(n);
+  float* o = r.ws.take<float>(n);
+  float* a1 = r.ws.take<float>(n);
+  float* a2 = r.ws.take<float>(n);
+  float* x = r.ws.take<float>(n);
+  float* wdw = r.ws.take<float>((size_t)C * 5);
+  float* dl = r.ws.take<float>((size_t)B * d.classes * L);
+  r.text_encoder(texts, lengths, L, enc);
+  if (r.live()) {
+    r.chk(launch_length_mask(lengths, B, L, mask, r.st));
+    // compute_cross: queries / keys are two AdaLN views of the text encoding (duration_predictor.py:61-72)
+    r.layernorm_ada(enc, qn, C, L, d.qn);
+    r.layernorm_ada(enc, kn, C, L, d.kn);
+    r.conv(r.base(d.cq, qn, L, q));
+    r.conv(r.base(d.ck, kn, L, k));
+    r.conv(r.base(d.cv, kn, L, v));
+    const int H = 8, DH = C / H;
+    r.chk(launch_rope(q, k, B, H, DH, L, 8, m->te.theta, r.st));
+    AttnArgs at;
+    at.q = q;
+    at.k = k;
+    at.v = v;
+    at.o = o;
+    at.qbs = at.kbs = at.vbs = at.obs = (size_t)C * L;
+    at.T = L;
+    at.H = H;
+    at.scale = 1.0f / sqrtf((float)DH);
+    at.lengths = lengths;
+    r.chk(launch_attention(at, B, DH, r.st));
+    r.conv(r.base(d.co, o, L, a1));
+    // cross_post: weight-normed depthwise k5 -> SiLU -> weight-normed 1x1; (. + encoding) / sqrt(2)
+    r.chk(launch_wn_dw(d.dw_g, d.dw_v, C, 5, wdw, r.st));
+    r.chk(launch_dwconv_fwd(a1, wdw, d.dw_b, B, C, L, 5, 2, a2, r.st));
+    r.chk(launch_act_fwd(ACT_SWISH, a2, nullptr, B, C, L, a1, r.st));
+    const float r2 = 0.70710678118654752f;
+    r.chk(launch_scale_copy(enc, r2, n, a2, r.st));
+    ConvArgs pc = r.base(d.post, a1, L, x);
+    pc.out_scale = r2;
+    pc.residual = a2;
+    r.conv(pc);
+  }
+  for (const ConvNeXt& c : d.cnx) {
+    r.convnext(c, x, x, L);
+    if (r.live()) r.chk(launch_mask_mul(x, mask, B, C, L, r.st));
+  }
+  if (r.live()) {
+    r.conv(r.base(d.proj, x, L, dl));
+    r.chk(launch_dur_post(dl, mask, B, d.classes, L, out, r.st));
+  }
+}
+
+// PitchEnergyPredictor.forward (pitch_energy_predictor.py:62-82): -> f0 [B][T], energy [B][T]
+static void pitch_energy_forward(Run& r, const int64_t* texts, const int64_t* lengths, const float* alignment,
+                                 const float* style, int L, int T, float* f0, float* energy) {
+  sty_model* m = r.m;
+  const PitchEnergyPlan& p = m->pe;
+  const int B = r.B, D = m->te.proj_m.Cout, S = m->style_dim, HC = D + S;
+  const size_t nh = (size_t)B * HC * L;
+  float* enc = r.ws.take<float>((size_t)B * D * L);
+  float* mask = r.ws.take<float>((size_t)B * L);
+  float* sx = r.ws.take<float>((size_t)B * S * L);
+  float* x = r.ws.take<float>(nh);
+  float* q = r.ws.take<float>(nh);
+  float* k = r.ws.take<float>(nh);
+  float* v = r.ws.take<float>(nh);
+  float* o = r.ws.take<float>(nh);
+  float* h1 = r.ws.take<float>(nh);
+  float* x2 = r.ws.take<float>(nh);
+  float* f = r.ws.take<float>(2 * nh);
+  float* pj = r.ws.take<float>((size_t)B * D * L);
+  float* xt = r.ws.take<float>((size_t)B * HC * T);
+  r.text_encoder(texts, lengths, L, enc);
+  if (r.live()) {
+    r.chk(launch_length_mask(lengths, B, L, mask, r.st));
+    r.chk(launch_style_expand(style, B, S, L, sx, r.st));
+    const float* src[2] = {enc, sx};
+    const int cs[2] = {D, S};
+    r.chk(launch_concat(src, cs, 2, B, L, x, r.st));
+    const int H = p.heads, DH = HC / H;
+    for (const ProsodyLayer& l : p.layers) {  // prosody_encoder.py:69-79, dropout off
+      r.chk(launch_mask_mul(x, mask, B, HC, L, r.st));
+      r.conv(r.base(l.q, x, L, q));
+      r.conv(r.base(l.k, x, L, k));
+      r.conv(r.base(l.v, x, L, v));
+      r.chk(launch_rope_n(q, k, B, H, DH, L, DH / 2, r.st));
+      AttnArgs at;
+      at.q = q;
+      at.k = k;
+      at.v = v;
+      at.o = o;
+      at.qbs = at.kbs = at.vbs = at.obs = (size_t)HC * L;
+      at.T = L;
+      at.H = H;
+      at.scale = 1.0f / sqrtf((float)DH);
+      at.lengths = lengths;
+      r.chk(launch_attention(at, B, DH, r.st));
+      ConvArgs ao = r.base(l.o, o, L, h1);
+      ao.residual = x;
+      r.conv(ao);
+      r.layernorm_ada(h1, x2, HC, L, l.n1);
+      ConvArgs f1 = r.base(l.f1, x2, L, f);
+      f1.pro = PRO_MASK;
+      f1.mask = mask;
+      f1.act = ACT_RELU;
+      r.conv(f1);
+      ConvArgs f2 = r.base(l.f2, f, L, h1);
+      f2.pro = PRO_MASK;
+      f2.mask = mask;
+      f2.out_mask = mask;
+      f2.residual = x2;
+      r.conv(f2);
+      r.layernorm_ada(h1, x2, HC, L, l.n2);
+      r.conv(r.base(l.proj, x2, L, pj));
+      const float* s2[2] = {pj, sx};
+      r.chk(launch_concat(s2, cs, 2, B, L, x, r.st));
+    }
+    r.chk(launch_mask_mul(x, mask, B, HC, L, r.st));
+    r.chk(launch_bmm_ct(x, alignment, B, HC, L, T, xt, r.st));
+  }
+  // two stacks of AdaptiveDecoderBlocks on the expanded prosody, 1x1 heads
+  for (int which = 0; which < 2; ++which) {
+    const DecBlock* blk = which ? p.nn : p.f0;
+    Run::Scope sc(r);
+    const float* in = xt;
+    float* bufs[2] = {r.ws.take<float>((size_t)B * D * T), r.ws.take<float>((size_t)B * D * T)};
+    for (int i = 0; i < 4; ++i) {
+      r.dec_block(blk[i], in, bufs[i & 1], T);
+      in = bufs[i & 1];
+    }
+    if (r.live()) r.conv(r.base(which ? p.np : p.f0p, in, T, which ? energy : f0));
+  }
+}
+
 static int run_style_fc(Run& r, const float* style) {
   sty_model* m = r.m;
   r.gb = r.ws.take<float>(m->gb_floats_per_batch * r.B);
@@ -1183,7 +1388,8 @@ int sty_model_create(const char* kind, sty_model** out) {
     return STY_EINVAL;
   }
   std::string k(kind);
-  if (k != "speech_predictor" && k != "vocoder" && k != "mel_style_encoder") {
+  if (k != "speech_predictor" && k != "vocoder" && k != "mel_style_encoder" && k != "duration_predictor" &&
+      k != "pitch_energy_predictor") {
     set_error("unknown model kind '%s'", kind);
     return STY_EINVAL;
   }
@@ -1728,6 +1934,87 @@ int sty_speech_fwd(sty_model* m, const sty_speech_io* io, void* workspace, size_
     if (rc) return rc;
   }
   return speech_run(m, io, workspace, ws_bytes, stream, nullptr);
+}
+
+// ---- second-stage predictors (inference) ----
+static int duration_run(sty_model* m, int B, int L, const int64_t* texts, const int64_t* lengths, const float* style,
+                        float* out, void* ws, size_t ws_bytes, void* stream, size_t* need) {
+  Run r;
+  r.m = m;
+  r.st = S(stream);
+  r.B = B;
+  r.ws.base = (char*)ws;
+  r.ws.cap = ws_bytes;
+  run_style_fc(r, style);
+  duration_forward(r, texts, lengths, L, out);
+  if (need) *need = align_up(r.peak > r.ws.off ? r.peak : r.ws.off, 256) + 256;
+  if (ws && (r.ws.overflow || r.peak > ws_bytes)) {
+    set_error("workspace too small: need %zu bytes, have %zu", r.peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return r.rc;
+}
+int sty_duration_workspace_bytes(const sty_model* m, int B, int L, size_t* bytes) {
+  int rc = model_ready(m, "duration_predictor");
+  if (rc) return rc;
+  if (!bytes || B <= 0 || L <= 0) {
+    set_error("sty_duration_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  return duration_run(const_cast<sty_model*>(m), B, L, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, bytes);
+}
+int sty_duration_fwd(sty_model* m, int B, int L, const int64_t* texts, const int64_t* text_lengths, const float* style,
+                     float* dur_pred, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "duration_predictor");
+  if (rc) return rc;
+  if (!texts || !text_lengths || !style || !dur_pred || !workspace || B <= 0 || L <= 0) {
+    set_error("sty_duration_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
+  return duration_run(m, B, L, texts, text_lengths, style, dur_pred, workspace, ws_bytes, stream, nullptr);
+}
+static int pitch_energy_run(sty_model* m, int B, int L, int T, const int64_t* texts, const int64_t* lengths,
+                            const float* alignment, const float* style, float* f0, float* energy, void* ws,
+                            size_t ws_bytes, void* stream, size_t* need) {
+  Run r;
+  r.m = m;
+  r.st = S(stream);
+  r.B = B;
+  r.ws.base = (char*)ws;
+  r.ws.cap = ws_bytes;
+  run_style_fc(r, style);
+  pitch_energy_forward(r, texts, lengths, alignment, style, L, T, f0, energy);
+  if (need) *need = align_up(r.peak > r.ws.off ? r.peak : r.ws.off, 256) + 256;
+  if (ws && (r.ws.overflow || r.peak > ws_bytes)) {
+    set_error("workspace too small: need %zu bytes, have %zu", r.peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return r.rc;
+}
+int sty_pitch_energy_workspace_bytes(const sty_model* m, int B, int L, int T, size_t* bytes) {
+  int rc = model_ready(m, "pitch_energy_predictor");
+  if (rc) return rc;
+  if (!bytes || B <= 0 || L <= 0 || T <= 0) {
+    set_error("sty_pitch_energy_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  return pitch_energy_run(const_cast<sty_model*>(m), B, L, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, 0, nullptr, bytes);
+}
+int sty_pitch_energy_fwd(sty_model* m, int B, int L, int T, const int64_t* texts, const int64_t* text_lengths,
+                         const float* alignment, const float* style, float* pitch, float* energy, void* workspace,
+                         size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "pitch_energy_predictor");
+  if (rc) return rc;
+  if (!texts || !text_lengths || !alignment || !style || !pitch || !energy || !workspace || B <= 0 || L <= 0 ||
+      T <= 0) {
+    set_error("sty_pitch_energy_fwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
+  return pitch_energy_run(m, B, L, T, texts, text_lengths, alignment, style, pitch, energy, workspace, ws_bytes,
+                          stream, nullptr);
 }
 
 // ---- fine-grained entry points ----

@@ -122,10 +122,14 @@ int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st) {
     hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, st, a);
   else if (DH == 16 && !drop)
     hipLaunchKernelGGL((attn_kernel<16, false>), grid, dim3(256), 0, st, a);
+  else if (DH == 160 && !drop)  // ProsodyEncoder: 2 heads over 256 + 64 channels (prosody_encoder.py:23-40)
+    hipLaunchKernelGGL((attn_kernel<160, false>), grid, dim3(256), 0, st, a);
+  else if (DH == 96 && !drop)   // the same encoder at inter_dim 128
+    hipLaunchKernelGGL((attn_kernel<96, false>), grid, dim3(256), 0, st, a);
   else if (DH == 16)
     hipLaunchKernelGGL((attn_kernel<16, true>), grid, dim3(256), 0, st, a);
   else {
-    set_error("attention: head dim %d%s not built (16, 64; dropout: 16)", DH, drop ? " with dropout" : "");
+    set_error("attention: head dim %d%s not built (16, 64, 96, 160; dropout: 16)", DH, drop ? " with dropout" : "");
     return STY_EINVAL;
   }
   STY_LAUNCH_CHECK();

@@ -31,6 +31,7 @@ __device__ __forceinline__ float act_apply(float x, float alpha) {
   if constexpr (ACT == ACT_RELU) return fmaxf(x, 0.f);
   if constexpr (ACT == ACT_SWISH) return x * sigmoidf_(x);
   if constexpr (ACT == ACT_SNAKE) return sty_snake(x, alpha, 1.0f / alpha);
+  if constexpr (ACT == ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
   return x;
 }
 
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS >= 8 ? 4 : STY_MIN
     case ACT_RELU: { STY_EPI_ACT(ACT_RELU) } break;
     case ACT_SWISH: { STY_EPI_ACT(ACT_SWISH) } break;
     case ACT_SNAKE: { STY_EPI_ACT(ACT_SNAKE) } break;
+    case ACT_GELU: { STY_EPI_ACT(ACT_GELU) } break;
     default: { STY_EPI_ACT(ACT_NONE) } break;
   }
 #undef STY_EPI_ACT

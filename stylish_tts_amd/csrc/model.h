@@ -18,6 +18,12 @@ int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st);
 int launch_pack_w2a(const float* w2, const float* b2, const float* grn_beta, int C, float* w2a, float* b2eff,
                     hipStream_t st);
 int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st);
+int launch_rope_n(float* q, float* k, int B, int H, int DH, int L, int d, hipStream_t st);
+int launch_style_expand(const float* style, int B, int S, int L, float* y, hipStream_t st);
+int launch_scale_copy(const float* x, float a, size_t n, float* y, hipStream_t st);
+int launch_mask_mul(float* x, const float* mask, int B, int C, int T, hipStream_t st);
+int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStream_t st);
+int launch_dur_post(const float* d, const float* mask, int B, int NC, int L, float* out, hipStream_t st);
 int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st);
 int source_workspace_floats(int B, int T);
 int launch_source(int B, int T, const float* pitch, const float* voiced, const float* noise, uint64_t seed,
@@ -142,6 +148,25 @@ struct DecoderPlan {
   const float *f0_g, *f0_v, *f0_b, *n_g, *n_v, *n_b, *v_g, *v_v, *v_b;
 };
 
+// ---- second-stage predictors, inference plans ----
+struct ProsodyLayer {  // prosody_encoder.py:33-61
+  PackedConv q, k, v, o, f1, f2, proj;
+  AdaFc n1, n2;
+};
+struct DurationPlan {  // duration_predictor.py:16-58
+  AdaFc qn, kn;
+  PackedConv cq, ck, cv, co, post, proj;
+  const float *dw_g = nullptr, *dw_v = nullptr, *dw_b = nullptr;  // weight-normed depthwise k5 of cross_post
+  std::vector<ConvNeXt> cnx;
+  int classes = 16;
+};
+struct PitchEnergyPlan {  // pitch_energy_predictor.py:8-60
+  std::vector<ProsodyLayer> layers;
+  DecBlock f0[4], nn[4];
+  PackedConv f0p, np;
+  int heads = 2;
+};
+
 struct Trainer;
 struct StyleResBlk {  // mel_style_encoder.py:69-118
   int Cin = 0, Cout = 0;
@@ -179,6 +204,8 @@ struct sty_model {
   sty::TextEncPlan te;
   sty::DecoderPlan dec;
   sty::StylePlan sty_enc;
+  sty::DurationPlan dur;
+  sty::PitchEnergyPlan pe;
   float* stft_default = nullptr;  // device [4][33][64]
   // ---- training ----
   bool train_enabled = false;

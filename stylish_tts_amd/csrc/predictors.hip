@@ -1,0 +1,114 @@
+// Small kernels of the second-stage predictors (DurationPredictor, PitchEnergyPredictor /
+// ProsodyEncoder; reference: duration_predictor.py:58-87, prosody_encoder.py:63-81, pitch_energy_predictor.py:62-82).
+// The heavy lifting (TextEncoder, 1x1 / k3 convs, attention, AdaLN, AdaptiveDecoderBlock, ConvNeXt) runs on the
+// kernels of the acoustic path; these are the few element-wise pieces that path did not need.  L <= a few hundred
+// tokens: every kernel here is latency-bound by construction.
+#include "model.h"
+
+namespace sty {
+
+// partial RoPE, any even d <= DH, in place on q and k [B][H*DH][L] (text_encoder.py:111-168):
+// theta_i = 10000^(-2i/d); (x_i, x_{i+d/2}) rotated by pos * theta_i
+__global__ void rope_n_kernel(float* __restrict__ q, float* __restrict__ k, int H, int DH, int L, int d) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (pos >= L) return;
+  const int half = d / 2;
+  float* ptr[2] = {q, k};
+  for (int i = 0; i < half; ++i) {
+    const float theta = 1.0f / powf(10000.0f, (float)(2 * i) / (float)d);
+    const float ang = (float)pos * theta;
+    const float cs = cosf(ang), sn = sinf(ang);
+    for (int w = 0; w < 2; ++w) {
+      float* base = ptr[w] + ((size_t)b * H + h) * DH * L + pos;
+      const float x0 = base[(size_t)i * L], x1 = base[(size_t)(i + half) * L];
+      base[(size_t)i * L] = x0 * cs - x1 * sn;
+      base[(size_t)(i + half) * L] = x1 * cs + x0 * sn;
+    }
+  }
+}
+int launch_rope_n(float* q, float* k, int B, int H, int DH, int L, int d, hipStream_t st) {
+  if (d <= 0 || d > DH || (d & 1)) {
+    set_error("rope: bad rotary width %d for head dim %d", d, DH);
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(rope_n_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// style [B][S] -> [B][S][L]
+__global__ void style_expand_kernel(const float* __restrict__ s, int S, int L, float* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)gridDim.y * S * L;
+  (void)n;
+  const int b = blockIdx.y;
+  if (i >= (size_t)S * L) return;
+  y[(size_t)b * S * L + i] = s[(size_t)b * S + i / L];
+}
+int launch_style_expand(const float* style, int B, int S, int L, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(style_expand_kernel, dim3(cdiv(S * L, 256), B), dim3(256), 0, st, style, S, L, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// y = a * x
+__global__ void scale_copy_kernel(const float* __restrict__ x, float a, size_t n, float* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = a * x[i];
+}
+int launch_scale_copy(const float* x, float a, size_t n, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, a, n, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// x[b][c][t] *= mask[b][t], in place
+__global__ void mask_mul_kernel(float* __restrict__ x, const float* __restrict__ mask, int C, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t < T) x[((size_t)b * C + c) * T + t] *= mask[(size_t)b * T + t];
+}
+int launch_mask_mul(float* x, const float* mask, int B, int C, int T, hipStream_t st) {
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, x, mask, C, T);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// weight_norm of a depthwise conv: w[c][k] = g[c] * v[c][k] / ||v[c]||  (one thread per channel, K <= 31)
+__global__ void wn_dw_kernel(const float* __restrict__ g, const float* __restrict__ v, int C, int K,
+                             float* __restrict__ w) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += v[c * K + k] * v[c * K + k];
+  const float sc = g[c] / sqrtf(s);
+  for (int k = 0; k < K; ++k) w[c * K + k] = v[c * K + k] * sc;
+}
+int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStream_t st) {
+  hipLaunchKernelGGL(wn_dw_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, g, v, C, K, w);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// DurationPredictor tail (duration_predictor.py:81-86): d [B][NC][L] (conv layout) -> out [B][L][NC]:
+// keep class 0, |.| of the others, cumulative sum over classes, -|.|, mask
+__global__ void dur_post_kernel(const float* __restrict__ d, const float* __restrict__ mask, int NC, int L,
+                                float* __restrict__ out) {
+  const int t = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (t >= L) return;
+  const float mk = mask[(size_t)b * L + t];
+  float run = 0.f;
+  for (int c = 0; c < NC; ++c) {
+    float v = d[((size_t)b * NC + c) * L + t];
+    if (c > 0) v = fabsf(v);
+    run += v;
+    out[((size_t)b * L + t) * NC + c] = -fabsf(run) * mk;
+  }
+}
+int launch_dur_post(const float* d, const float* mask, int B, int NC, int L, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(dur_post_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, st, d, mask, NC, L, out);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+}  // namespace sty

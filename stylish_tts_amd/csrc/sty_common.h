@@ -79,7 +79,7 @@ enum ConvPro : int {
   PRO_LRELU = 7,         // LeakyReLU(0.2) (style-encoder ResBlk, mel_style_encoder.py:106-113)
 };
 // epilogue activation applied to (acc + bias)
-enum ConvAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2, ACT_SNAKE = 3, ACT_GLU = 4 };
+enum ConvAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2, ACT_SNAKE = 3, ACT_GLU = 4, ACT_GELU = 5 };  // GELU: exact (erf)
 
 struct ConvArgs {
   // input: up to 3 channel-concatenated sources

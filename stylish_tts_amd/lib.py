@@ -77,6 +77,10 @@ SYMBOLS = {
     "sty_style_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_style_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "sty_style_bwd": (C.c_int, [_P, _P, _P]),
+    "sty_duration_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
+    "sty_duration_fwd": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_pitch_energy_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
+    "sty_pitch_energy_fwd": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_conv1d_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
     "sty_conv1d_fwd": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
     "sty_conv1d_bwd_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _I, _SZP]),

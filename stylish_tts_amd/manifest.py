@@ -210,3 +210,90 @@ def style_encoder_manifest(cfg=None):
     m["unshared.weight"] = [c["style_dim"], dim_in]
     m["unshared.bias"] = [c["style_dim"]]
     return m
+
+
+def _text_encoder(m, pre, c, inter):
+    """TextEncoder keys under `pre` (text_encoder.py:397-432) with projection width `inter`."""
+    H, Fd, L = c["te_hidden"], c["te_filter"], c["te_layers"]
+    m[pre + "emb.weight"] = [c["tokens"], H]
+    for i in range(3):
+        _conv(m, f"{pre}prenet.conv_layers.{i}", H, H, 5)
+    for i in range(3):
+        m[f"{pre}prenet.norm_layers.{i}.gamma"] = [H]
+        m[f"{pre}prenet.norm_layers.{i}.beta"] = [H]
+    _conv(m, pre + "prenet.proj", H, H, 1)
+    for i in range(L):
+        for n in ("conv_q", "conv_k", "conv_v", "conv_o"):
+            _conv(m, f"{pre}encoder.attn_layers.{i}.{n}", H, H, 1)
+    for i in range(L):
+        m[f"{pre}encoder.norm_layers_1.{i}.gamma"] = [H]
+        m[f"{pre}encoder.norm_layers_1.{i}.beta"] = [H]
+    for i in range(L):
+        _conv(m, f"{pre}encoder.ffn_layers.{i}.conv_1", Fd, H, c["te_kernel"])
+        _conv(m, f"{pre}encoder.ffn_layers.{i}.conv_2", H, Fd, c["te_kernel"])
+    for i in range(L):
+        m[f"{pre}encoder.norm_layers_2.{i}.gamma"] = [H]
+        m[f"{pre}encoder.norm_layers_2.{i}.beta"] = [H]
+    _conv(m, pre + "proj_m", inter, H, 1)
+
+
+N3_CFG = dict(dp_layers=3, dp_classes=16, pe_inter=256, pe_layers=3, pe_heads=2)
+
+
+def duration_predictor_manifest(cfg=None):
+    """DurationPredictor (duration_predictor.py:16-58), registration order of the reference."""
+    c = {**DEFAULT_CFG, **N3_CFG, **(cfg or {})}
+    sd, d = c["style_dim"], c["inter_dim"]
+    m = OrderedDict()
+    _text_encoder(m, "text_encoder.", c, d)
+    for i in range(c["dp_layers"]):
+        p = f"conv_next.{i}"
+        m[p + ".dwconv.weight"] = [d, 1, 7]
+        m[p + ".dwconv.bias"] = [d]
+        _adain(m, p + ".norm", sd, d)
+        m[p + ".pwconv1.weight"] = [4 * d, d]
+        m[p + ".pwconv1.bias"] = [4 * d]
+        m[p + ".grn.gamma"] = [1, 1, 4 * d]
+        m[p + ".grn.beta"] = [1, 1, 4 * d]
+        m[p + ".pwconv2.weight"] = [d, 4 * d]
+        m[p + ".pwconv2.bias"] = [d]
+    m["duration_proj.linear_layer.weight"] = [c["dp_classes"], d]
+    m["duration_proj.linear_layer.bias"] = [c["dp_classes"]]
+    _adain(m, "query_norm", sd, d)
+    _adain(m, "key_norm", sd, d)
+    for n in ("conv_q", "conv_k", "conv_v", "conv_o"):
+        _conv(m, f"cross_attention.{n}", d, d, 1)
+    m["cross_post.0.bias"] = [d]
+    _wn(m, "cross_post.0", [d, 1, 5])
+    m["cross_post.2.bias"] = [d]
+    _wn(m, "cross_post.2", [d, d, 1])
+    return m
+
+
+def pitch_energy_predictor_manifest(cfg=None):
+    """PitchEnergyPredictor (pitch_energy_predictor.py:8-60)."""
+    c = {**DEFAULT_CFG, **N3_CFG, **(cfg or {})}
+    sd, d = c["style_dim"], c["pe_inter"]
+    hc = d + sd
+    m = OrderedDict()
+    _text_encoder(m, "text_encoder.", c, d)
+    p = "prosody_encoder."
+    for i in range(c["pe_layers"]):
+        for n in ("conv_q", "conv_k", "conv_v", "conv_o"):
+            _conv(m, f"{p}attn_layers.{i}.{n}", hc, hc, 1)
+    for i in range(c["pe_layers"]):
+        _adain(m, f"{p}norm_layers_1.{i}", sd, hc)
+    for i in range(c["pe_layers"]):
+        _conv(m, f"{p}ffn_layers.{i}.conv_1", 2 * hc, hc, 1)
+        _conv(m, f"{p}ffn_layers.{i}.conv_2", hc, 2 * hc, 1)
+    for i in range(c["pe_layers"]):
+        _adain(m, f"{p}norm_layers_2.{i}", sd, hc)
+    for i in range(c["pe_layers"]):
+        _conv(m, f"{p}proj_layers.{i}", d, hc, 1)
+    dims = [(hc, d), (d, d // 2), (d // 2, d // 2), (d // 2, d // 2)]
+    for name in ("F0", "N"):
+        for i, (ci, co) in enumerate(dims):
+            _decoder_block(m, f"{name}.{i}", ci, co, sd)
+    _conv(m, "F0_proj", 1, d // 2, 1)
+    _conv(m, "N_proj", 1, d // 2, 1)
+    return m

@@ -15,7 +15,8 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .manifest import DEFAULT_CFG, speech_predictor_manifest, style_encoder_manifest
+from .manifest import (DEFAULT_CFG, N3_CFG, duration_predictor_manifest, pitch_energy_predictor_manifest,
+                       speech_predictor_manifest, style_encoder_manifest)
 
 
 class DecoderPrediction:  # train/utils.py:643-653
@@ -426,3 +427,135 @@ class MelStyleEncoder(_HipModule):
         d_style = _f32(d_style, d_style.device)
         st = C.c_void_p(torch.cuda.current_stream(d_style.device).cuda_stream)
         L.check(lib.sty_style_bwd(self._handle, L.ptr(d_style), st))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# second-stage predictors, inference
+# ---------------------------------------------------------------------------------------------------------------------
+def _n3_cfg(style_dim, text_config, duration_config=None, **extra):
+    cfg = dict(DEFAULT_CFG, **N3_CFG)
+    cfg["style_dim"] = style_dim
+    if text_config is not None:
+        cfg.update(tokens=text_config.tokens, te_hidden=text_config.hidden_dim, te_filter=text_config.filter_channels,
+                   te_heads=text_config.heads, te_layers=text_config.layers, te_kernel=text_config.kernel_size)
+    if duration_config is not None:
+        cfg.update(dp_layers=duration_config.n_layer, dp_classes=duration_config.duration_classes)
+    cfg.update(extra)
+    return cfg
+
+
+class DurationPredictor(_HipModule):
+    """DurationPredictor(style_dim, inter_dim, text_config, duration_config).forward(texts, text_lengths, style)
+    -> [B, L, duration_classes]   (duration_predictor.py:16-87); same state_dict keys as the reference."""
+    KIND = "duration_predictor"
+
+    def __init__(self, style_dim=64, inter_dim=128, text_config=None, duration_config=None):
+        super().__init__()
+        self.cfg = _n3_cfg(style_dim, text_config, duration_config, inter_dim=inter_dim)
+        self._build(duration_predictor_manifest(self.cfg))
+
+    def forward(self, texts, text_lengths, style):
+        _no_autograd("DurationPredictor.forward")
+        dev = style.device
+        lib = self._ensure(dev)
+        B, Lt = texts.shape
+        tx, tl = texts.to(dev, torch.int64).contiguous(), text_lengths.to(dev, torch.int64).contiguous()
+        st = _f32(style, dev)
+        out = torch.empty(B, Lt, self.cfg["dp_classes"], dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_duration_workspace_bytes(self._handle, B, Lt, C.byref(need)))
+        ws = self._workspace(need.value, dev)
+        L.check(lib.sty_duration_fwd(self._handle, B, Lt, L.ptr(tx), L.ptr(tl), L.ptr(st), L.ptr(out), L.ptr(ws),
+                                     ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out
+
+
+class PitchEnergyPredictor(_HipModule):
+    """PitchEnergyPredictor(style_dim, inter_dim, text_config, duration_config, pitch_energy_config)
+    .forward(texts, text_lengths, alignment, style) -> (F0 [B,T], N [B,T])   (pitch_energy_predictor.py:8-82)."""
+    KIND = "pitch_energy_predictor"
+
+    def __init__(self, style_dim=64, inter_dim=256, text_config=None, duration_config=None, pitch_energy_config=None):
+        super().__init__()
+        self.cfg = _n3_cfg(style_dim, text_config, duration_config, pe_inter=inter_dim)
+        self._build(pitch_energy_predictor_manifest(self.cfg))
+
+    def forward(self, texts, text_lengths, alignment, style):
+        _no_autograd("PitchEnergyPredictor.forward")
+        dev = style.device
+        lib = self._ensure(dev)
+        B, Lt = texts.shape
+        T = alignment.shape[2]
+        tx, tl = texts.to(dev, torch.int64).contiguous(), text_lengths.to(dev, torch.int64).contiguous()
+        al, st = _f32(alignment, dev), _f32(style, dev)
+        f0 = torch.empty(B, T, dtype=torch.float32, device=dev)
+        en = torch.empty(B, T, dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_pitch_energy_workspace_bytes(self._handle, B, Lt, T, C.byref(need)))
+        ws = self._workspace(need.value, dev)
+        L.check(lib.sty_pitch_energy_fwd(self._handle, B, Lt, T, L.ptr(tx), L.ptr(tl), L.ptr(al), L.ptr(st), L.ptr(f0),
+                                         L.ptr(en), L.ptr(ws), ws.numel(),
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return f0, en
+
+
+class DurationProcessor(torch.nn.Module):
+    """train/utils.py:656-803: class distribution -> expected duration -> soft alignment.  Host-side glue on device
+    tensors (a softmax over 16 classes and the same closed form sty_alignment_fwd evaluates); one .item() sync for
+    the frame count, as in the reference (utils.py:759)."""
+    TABLE = (1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 18, 22, 27, 32, 38, 46)
+
+    def __init__(self, class_count=16, max_dur=50):
+        super().__init__()
+        self.class_count, self.max_dur = class_count, max_dur
+        self.register_buffer("class_to_dur_table", torch.tensor(self.TABLE, dtype=torch.float32))
+
+    def prediction_to_duration(self, pred, text_length):
+        conf = torch.softmax(pred, dim=-1)
+        soft = (conf * self.class_to_dur_table.to(pred.device)).sum(dim=-1) / (conf.sum(dim=-1) + 1e-9)
+        mask = torch.arange(pred.shape[1], device=pred.device)[None, :] < text_length.to(pred.device)[:, None]
+        return soft * mask
+
+    def duration_to_alignment(self, duration, multiplier=1):
+        total = int(duration.sum(dim=1).round().max().long().item()) * multiplier
+        duration = duration * multiplier
+        upper = torch.cumsum(duration, dim=1)
+        lower = upper - duration
+        mean = ((lower + upper) / 2).unsqueeze(2)
+        seq = torch.arange(round(total), device=duration.device).view(1, 1, -1)
+        x = seq - mean
+        al = 1 - (x * 2 / (duration.unsqueeze(2) + 6)) ** 2
+        m = (seq > (lower - 3).unsqueeze(2)) * (seq < (upper + 3).unsqueeze(2))
+        return torch.softmax(torch.clamp(al * m, min=0.0), dim=1)
+
+    def forward(self, pred, text_length, multiplier=1):
+        return self.duration_to_alignment(self.prediction_to_duration(pred, text_length), multiplier)
+
+
+class ExportModel(torch.nn.Module):
+    """The export / inference graph of the reference (export_model.py:7-63): text -> durations -> alignment ->
+    pitch / energy -> speech, every model on the HIP path.  forward(texts, text_lengths, speech_style, pe_style,
+    duration_style) -> audio [samples] for B == 1 (as the reference), [B, samples] otherwise."""
+
+    def __init__(self, *, speech_predictor, pitch_energy_predictor, duration_predictor, class_count=16, max_dur=50,
+                 coarse_multiplier=1, **kwargs):
+        super().__init__()
+        self.speech_predictor = speech_predictor
+        self.pitch_energy_predictor = pitch_energy_predictor
+        self.duration_predictor = duration_predictor
+        self.duration_processor = DurationProcessor(class_count, max_dur)
+        self.coarse_multiplier = coarse_multiplier
+
+    @torch.no_grad()
+    def forward(self, texts, text_lengths, speech_style, pe_style, duration_style, *, noise=None, seed=0):
+        dur_pred = self.duration_predictor(texts, text_lengths, duration_style)
+        alignment = self.duration_processor(dur_pred, text_lengths)
+        alignment_fine = self.duration_processor(dur_pred, text_lengths, multiplier=self.coarse_multiplier)
+        pitch, energy = self.pitch_energy_predictor(texts, text_lengths, alignment, pe_style)
+        voiced = (pitch > 20).float()
+        if self.coarse_multiplier != 1:  # the predictor consumes frame-rate curves of the fine alignment's length
+            raise NotImplementedError("coarse_multiplier != 1: pitch / energy length differs from the fine alignment")
+        pred = self.speech_predictor(texts, text_lengths, alignment_fine, pitch, energy, voiced, speech_style, pitch,
+                                     noise=noise, seed=seed)
+        audio = pred.audio
+        return audio.reshape(-1) if audio.shape[0] == 1 else audio.squeeze(1)

@@ -930,3 +930,79 @@ def test_bench_two_ranks_on_one_device():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert "roofline" in rec and rec["config"]["workload"].startswith("c2")
 
+
+
+def _n3_models():
+    import stylish_tts_amd as S
+    from oracle.manifest import duration_predictor_manifest, pitch_energy_predictor_manifest
+    from oracle.weights import fill_state_dict
+    Pd = fill_state_dict(duration_predictor_manifest(), 3)
+    Pp = fill_state_dict(pitch_energy_predictor_manifest(), 4)
+    dp, pe = S.DurationPredictor(), S.PitchEnergyPredictor()
+    dp.load_state_dict(Pd)
+    pe.load_state_dict(Pp)
+    return dp.to(DEV), pe.to(DEV), Pd, Pp
+
+
+def test_second_stage_predictors_vs_reference_golden(env):
+    """SURVEY.md 8(f) N3 on the HIP path: DurationPredictor and PitchEnergyPredictor (ProsodyEncoder, 2 heads of 160
+    channels, rotary width 80; AdaptiveDecoderBlocks with learned and identity shortcuts) vs what the REFERENCE produced
+    (tests/golden/n3_small.safetensors) and vs the oracle; DurationProcessor glue vs the reference's alignments."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle import predictors as OP
+    gold = load_file(os.path.join(G, "n3_small.safetensors"))
+    cs = env["cs"]
+    dp, pe, Pd, Pp = _n3_models()
+    with torch.no_grad():
+        pred = dp(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["duration_style"]))
+        proc = S.DurationProcessor(16, 50)
+        dur = proc.prediction_to_duration(pred, dev(cs["text_lengths"]))
+        ali = proc(pred, dev(cs["text_lengths"]))
+        ali3 = proc(pred, dev(cs["text_lengths"]), multiplier=3)
+        f0, en = pe(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["alignment"]), dev(gold["pe_style"]))
+        # float64 oracle for the pitch / energy stacks (their fp32 rounding is amplified, see test_oracle_golden.py)
+        P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in Pp.items()}
+        f64, e64 = OP.pitch_energy_predictor(P64, cs["texts"], cs["text_lengths"], gold["alignment"].double(),
+                                             gold["pe_style"].double())
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("dur_pred vs reference", pred, gold["dur_pred"], 5e-5)
+    rep.add("duration vs reference", dur, gold["duration"], 5e-5)
+    rep.add("alignment vs reference", ali, gold["alignment"], 5e-5)
+    rep.add("alignment x3 vs reference", ali3, gold["alignment_x3"], 5e-5)
+    rep.add("pitch vs reference", f0, gold["pitch"], 1e-3)
+    rep.add("energy vs reference", en, gold["energy"], 1e-3)
+    rep.add("pitch vs float64 oracle", f0, f64.float(), 1e-3)
+    rep.add("energy vs float64 oracle", en, e64.float(), 1e-3)
+    rep.done()
+
+
+def test_export_model_text_to_audio_vs_oracle(env):
+    """ExportModel.forward (export_model.py:40-63) with every model on the HIP path: text -> durations -> alignment
+    -> pitch / energy -> audio, vs the same chain of oracle functions fed with the HIP path's own alignment (the
+    alignment's frame count depends on a rounded sum, so it is compared separately above)."""
+    import stylish_tts_amd as S
+    from oracle import predictors as OP, speech_predictor as osp
+    cs = env["cs"]
+    dp, pe, Pd, Pp = _n3_models()
+    P = {k: v.clone() for k, v in env["P"].items()}
+    sp = S.SpeechPredictor()
+    sp.load_state_dict(P, strict=False)
+    ex = S.ExportModel(speech_predictor=sp.to(DEV), pitch_energy_predictor=pe, duration_predictor=dp)
+    g = torch.Generator().manual_seed(5)
+    sstyle, pstyle, dstyle = (torch.randn(2, 64, generator=g) for _ in range(3))
+    with torch.no_grad():
+        pred = OP.duration_predictor(Pd, cs["texts"], cs["text_lengths"], dstyle)
+        ali = OP.duration_to_alignment(OP.prediction_to_duration(pred, cs["text_lengths"]))
+        f0, en = OP.pitch_energy_predictor(Pp, cs["texts"], cs["text_lengths"], ali, pstyle)
+        T = ali.shape[2]
+        gn = torch.Generator().manual_seed(9)
+        noise = torch.randn(2, 300 * T, 9, generator=gn)
+        ref = osp.speech_predictor(P, cs["texts"], cs["text_lengths"], ali, f0, en, (f0 > 20).float(), sstyle, f0, noise)
+        audio = ex(dev(cs["texts"]), dev(cs["text_lengths"]), dev(sstyle), dev(pstyle), dev(dstyle), noise=dev(noise))
+    torch.cuda.synchronize()
+    assert audio.shape == (2, 300 * T), (audio.shape, T)
+    mse = ((audio.cpu() - ref.squeeze(1)) ** 2).mean().item()
+    print(f"\n  text -> audio, {T} frames: waveform mse vs oracle chain {mse:.3e}, mel-L1 {_mel_l1(audio.cpu().unsqueeze(1), ref):.3e}")
+    assert mse <= 1e-6 and _mel_l1(audio.cpu().unsqueeze(1), ref) <= 1e-3
