@@ -17,6 +17,8 @@ A step is one pass of the hot path over one synthetic batch already resident in 
   c3-fp32: the same shape entirely in fp32.
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
   c5-bf16: the same with bf16 operands on the dense convs (outside the fp32 parity gates; reported beside c5).
+  tts: the export graph (ExportModel.forward): B=8 token strings of L=100 -> duration predictor ->
+      alignment -> pitch / energy predictor -> speech predictor -> audio, fp32 inference; frames = B x predicted frames.
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
 Prints ONE JSON line on rank 0.
@@ -39,11 +41,13 @@ WORKLOADS = {
     "c3-fp32": dict(B=32, T=520, L=100, what="train"),
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
     "c5-bf16": dict(B=8, T=800, L=0, what="vocoder", compute="bf16"),
+    "tts": dict(B=8, T=0, L=100, what="synth"),
 }
 PASS = {
     "train": "forward + backward + AdamW (mel + multi-phase losses; GAN/WavLM terms off; train mode)",
     "forward": "forward only (AcousticStep forward + multi-spectrogram features)",
     "vocoder": "vocoder forward only (inference)",
+    "synth": "text -> audio inference (duration, pitch/energy and speech predictors)",
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
@@ -58,6 +62,11 @@ def make_inputs(w, seed, device):
     pitch[unv] = 0
     d = dict(pitch=pitch, voiced=(pitch > 20).float(), energy=torch.randn(B, T, generator=g),
              style=torch.randn(B, 64, generator=g))
+    if w["what"] == "synth":
+        return {k: v.to(device) for k, v in dict(
+            texts=torch.randint(1, 178, (B, L), generator=g), text_lengths=torch.full((B,), L, dtype=torch.int64),
+            speech_style=torch.randn(B, 64, generator=g), pe_style=torch.randn(B, 64, generator=g),
+            duration_style=torch.randn(B, 64, generator=g)).items()}
     if w["what"] == "vocoder":
         d["mel"] = torch.randn(B, 128, T, generator=g)
     else:
@@ -80,12 +89,11 @@ def make_inputs(w, seed, device):
 
 def build_model(device):
     import stylish_tts_amd as S
-    from oracle.manifest import speech_predictor_manifest   # deterministic random-init weights (test infra fill)
-    from oracle.weights import fill_state_dict
+    from stylish_tts_amd.manifest import speech_predictor_manifest, style_encoder_manifest
+    from stylish_tts_amd.synthetic_weights import fill_state_dict   # deterministic random-init weights
     P = fill_state_dict(speech_predictor_manifest(), 0)
     m = S.SpeechPredictor()
     m.load_state_dict(P, strict=False)
-    from oracle.manifest import style_encoder_manifest
     se = S.MelStyleEncoder()
     se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
     return m.to(device), se.to(device), P
@@ -131,6 +139,14 @@ def _cpu_baseline_worker(w, q, budget_s):
     Pse = fill_state_dict(style_encoder_manifest(), 0)
     Bs, T = 2, w["T"]
     inp = make_inputs(dict(w, B=Bs), 99, "cpu")
+    if w["what"] == "synth":
+        from oracle import predictors as OP
+        from oracle.manifest import duration_predictor_manifest, pitch_energy_predictor_manifest
+        Pd = fill_state_dict(duration_predictor_manifest(), 3)
+        Pp = fill_state_dict(pitch_energy_predictor_manifest(), 4)
+        with torch.no_grad():
+            pred = OP.duration_predictor(Pd, inp["texts"], inp["text_lengths"], inp["duration_style"])
+            T = OP.duration_to_alignment(OP.prediction_to_duration(pred, inp["text_lengths"])).shape[2]
     noise = torch.randn(Bs, 300 * T, 9)
 
     if w["what"] == "train":
@@ -144,7 +160,14 @@ def _cpu_baseline_worker(w, q, budget_s):
 
     def once():
         t0 = time.perf_counter()
-        if w["what"] == "vocoder":
+        if w["what"] == "synth":
+            with torch.no_grad():
+                pred = OP.duration_predictor(Pd, inp["texts"], inp["text_lengths"], inp["duration_style"])
+                ali = OP.duration_to_alignment(OP.prediction_to_duration(pred, inp["text_lengths"]))
+                f0, en = OP.pitch_energy_predictor(Pp, inp["texts"], inp["text_lengths"], ali, inp["pe_style"])
+                osp.speech_predictor(P, inp["texts"], inp["text_lengths"], ali, f0, en, (f0 > 20).float(),
+                                     inp["speech_style"], f0, noise)
+        elif w["what"] == "vocoder":
             with torch.no_grad():
                 ov.multi_generator(P, "generator", inp["mel"], inp["style"], inp["pitch"], inp["voiced"], noise)
         elif w["what"] == "train":
@@ -247,7 +270,21 @@ def main():
     if bf16 and trainer is None:
         model.set_train_opts(compute_bf16=True)
 
+    synth = None
+    if w["what"] == "synth":
+        import stylish_tts_amd as S
+        from stylish_tts_amd.manifest import duration_predictor_manifest, pitch_energy_predictor_manifest
+        from stylish_tts_amd.synthetic_weights import fill_state_dict
+        dpm, pem = S.DurationPredictor(), S.PitchEnergyPredictor()
+        dpm.load_state_dict(fill_state_dict(duration_predictor_manifest(), 3))
+        pem.load_state_dict(fill_state_dict(pitch_energy_predictor_manifest(), 4))
+        synth = S.ExportModel(speech_predictor=model, pitch_energy_predictor=pem.to(device),
+                              duration_predictor=dpm.to(device))
+
     def step(i):
+        if synth is not None:
+            return synth(inp["texts"], inp["text_lengths"], inp["speech_style"], inp["pe_style"],
+                         inp["duration_style"], seed=i)
         if w["what"] == "train":
             # one train_acoustic step incl. gradient all-reduce and optimizer; returns the loss values
             return trainer.train_batch(audio_gt=inp["audio_gt"], texts=inp["texts"], text_lengths=inp["text_lengths"],
@@ -314,6 +351,8 @@ def main():
     dt = D.max_over_ranks(dt, device)
     if rank != 0:
         return
+    if synth is not None:
+        T = out.shape[-1] // 300  # frames the duration predictor asked for (same inputs every step)
     frames = world * B * T * args.steps
     rec = {
         "metric": "audio frames/sec/GPU (24 kHz) forward+backward; DDP scaling 1/2/4/8 MI355X",
