@@ -29,7 +29,13 @@ import os
 import sys
 import time
 
-import torch
+# The training step runs on four HIP streams and RCCL adds its own.  With the runtime's default of
+# four hardware queues per process, a fifth concurrently active stream sends the step from 38 to 59-70 ms (measured
+# with dummy streams); with two hardware queues it stays at 38-42 ms however many streams exist.  Must be set before
+# the HIP runtime is loaded, i.e. before `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -297,6 +303,19 @@ def main():
                                  text_lengths=inp["text_lengths"], pitch=inp["pitch"], durations=inp["durations"],
                                  T=T, seed=i, multi_spectrogram=mspec)
             return o.pred.audio
+
+    # tuning aid: STY_BENCH_DUMMY_STREAMS=k keeps k more streams busy with a tiny kernel per step (stands in for the
+    # queues a communication library adds), to see how the step reacts to more active hardware queues
+    dummies = [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("STY_BENCH_DUMMY_STREAMS", "0")))]
+    dbuf = torch.zeros(1024, device=device)
+    if dummies:
+        inner = step
+
+        def step(i):  # noqa: F811
+            for s_ in dummies:
+                with torch.cuda.stream(s_):
+                    dbuf.add_(1.0)
+            return inner(i)
 
     def barrier():
         if world > 1:

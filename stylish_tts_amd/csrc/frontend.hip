@@ -440,6 +440,9 @@ size_t acoustic_loss_workspace_floats(int B, int N) {
   return tot + tmp + 4096;
 }
 
+// (Measured and rejected: the three resolutions on three streams.  With six streams in the process the whole c2 step
+// went from 37.8 to 69 ms -- more than ~4 concurrently active hardware queues is pathological on this stack,
+// GPU_MAX_HW_QUEUES=2 brought it back to 37.9 ms with no gain left from the extra streams.)
 // losses_out: device [2] (mel, multi_phase); d_pred [B][N] is OVERWRITTEN with d seed / d audio_pred
 int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
                          float* losses_out, float* d_pred, float* ws, hipStream_t st) {

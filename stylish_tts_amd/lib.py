@@ -2,6 +2,12 @@
 import ctypes as C
 import os
 
+# Hardware queues per process: the training step uses four HIP streams and a communication library adds more; above
+# four concurrently active streams the runtime's default (4 queues) degrades badly, two queues do not (DESIGN.md
+# section 4).  Effective only when this module is imported before the HIP runtime is loaded (before `import torch`);
+# otherwise export GPU_MAX_HW_QUEUES=2 in the launch environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstylish_hip.so")
 if os.environ.get("STY_LIB_VARIANT"):  # kernel-tuning aid (tools/build_variant.sh): same ABI, different build flags
