@@ -1,11 +1,14 @@
-// Training-mode graph of the vocoder (MultiGenerator, generator.py:884-901 / 710-799) with a tape of backward steps.
+// Training-mode graphs (SpeechPredictor: text encoder -> expand -> decoder -> vocoder; MelStyleEncoder; vocoder alone)
+// with a tape of backward steps.
 //
 // The forward here is the UNFUSED-epilogue form of the inference plan in api.hip: convs keep their fused input
 // prologues (AdaIN+Snake, GRN scale, ...) but activations / LayerNorms that the backward needs the inputs of are
 // separate ops, nothing is computed in place, and no workspace is recycled, so that every backward step finds its
 // operands.  Each forward op pushes one closure; backward runs them in reverse.  Gradient buffers are zero-filled
 // when first requested and every backward kernel accumulates, which makes fan-out (residual streams) trivial.
-// Eval-mode semantics (BatchNorm running statistics, no dropout), matching the golden gradients of the oracle.
+// sty_train_opts selects module.train() behaviour (BatchNorm batch statistics, smoothing, power iteration, dropout,
+// bf16 operands); all zero = the eval-mode graph of the golden gradient fixtures.  Weight gradients run on a second
+// stream (see "side stream" below).
 #include <stdlib.h>
 #include <string.h>
 

@@ -8,7 +8,10 @@ Reference interfaces mirrored here (paths under the reference tree, src/stylish_
       .forward(*, mel, style, pitch, energy, voiced) -> DecoderPrediction     generator.py:802-901
   MelStyleEncoder(dim_in, style_dim, max_conv_dim, skip_downsamples).forward(x) -> [B, style_dim]
       mel_style_encoder.py:121-152
-Forward only in this revision: calling with autograd enabled raises (no silent PyTorch fallback).
+`forward` is inference: calling it with autograd enabled raises (there is no autograd graph to record and no silent
+PyTorch fallback); training goes through `forward_train` / `backward`, which write into `param.grad`.
+DurationPredictor / PitchEnergyPredictor / DurationProcessor / ExportModel (duration_predictor.py, pitch_energy_predictor.py,
+utils.py:656-803, export_model.py) are at the end of this file (inference only).
 """
 import ctypes as C
 
@@ -163,7 +166,8 @@ def _f32(t, device):
 
 def _no_autograd(what):
     if torch.is_grad_enabled():
-        raise L.StyError(f"{what}: backward kernels are not built in this revision; call under torch.no_grad()")
+        raise L.StyError(f"{what}: forward() records no autograd graph; call it under torch.no_grad(), or use "
+                         f"forward_train() / backward() for training")
 
 
 def _stft_buffers():
