@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=2   # as bench.py sets it for itself (rocprofv3 loads the HIP runtime first)
 rocprofv3 --kernel-trace --stats -d $O/c2_trace -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/c2_under_rocprof.json 2> $O/c2_trace.log
 rocprofv3 --kernel-trace --stats -d $O/c5_trace -- python $R/bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline > $O/c5_under_rocprof.json 2> $O/c5_trace.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c2_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c2_fetch.log
@@ -22,5 +23,6 @@ python bench.py --workload c3-fp32 --steps 5 --warmup 2 --no-cpu-baseline > $O/$
 python bench.py --workload c3 --steps 5 --warmup 2 --no-cpu-baseline > $O/${tag}_bench_c3_bf16.json 2>/dev/null
 python bench.py --workload c5-bf16 --steps 50 --warmup 10 --no-cpu-baseline > $O/${tag}_bench_c5_bf16.json 2>/dev/null
 python bench.py --workload c5 --steps 50 --warmup 10 > $O/${tag}_bench_c5.json 2>/dev/null
+python bench.py --workload tts --steps 20 --warmup 5 > $O/${tag}_bench_tts.json 2>/dev/null
 rm -rf $O/c2_trace $O/c5_trace $O/c2_fetch/*/*agent_info.csv
 ls -la $O
