@@ -729,6 +729,35 @@ def test_acoustic_train_step_bf16_compute_vs_fp32(env):
     assert med16 <= 2.0 * medc and cos16 >= cosc - 0.1
 
 
+def test_multi_stream_step_equals_single_stream_step(env):
+    """The four-stream training step (weight-gradient streams, style encoder beside the text encoder) against the same
+    step with every internal stream off (sty_set_single_stream): identical losses and gradients up to the one
+    atomically accumulated tensor (pool_fc) -- a race between the streams would show up here."""
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    cs = env["cs"]
+    B, T = cs["pitch"].shape
+    audio_gt = _test_audio(B, 300 * T, 21)
+    res = []
+    try:
+        for single in (0, 1, 0):
+            lib.sty_set_single_stream(single)
+            tr, _, _ = _train_setup(env, 0.0)
+            tr.single_stream = bool(single)
+            losses = tr.train_batch(audio_gt=dev(audio_gt), texts=dev(cs["texts"]), text_lengths=dev(cs["text_lengths"]),
+                                    pitch=dev(cs["pitch"]), durations=dev(cs["durations"]), noise=dev(cs["noise"]), seed=5)
+            torch.cuda.synchronize()
+            g = torch.cat([p.grad.detach().flatten().cpu() for m in (tr.sp, tr.se) for p in m.parameters()
+                           if p.grad is not None])
+            res.append((losses.cpu(), g))
+    finally:
+        lib.sty_set_single_stream(0)
+    for i in (0, 2):
+        rel = ((res[i][1] - res[1][1]).norm() / res[1][1].norm()).item()
+        print(f"\n  multi-stream run {i} vs single-stream: gradient relative L2 {rel:.3e}, losses {res[i][0].tolist()} / {res[1][0].tolist()}")
+        assert rel <= 1e-6 and torch.allclose(res[i][0], res[1][0], rtol=1e-6, atol=0)
+
+
 def test_acoustic_training_reduces_loss(env):
     """A few optimizer steps on one fixed batch lower both losses (forward, backward, AdamW and the weight
     re-preparation between steps all act on the same parameters)."""
