@@ -137,6 +137,12 @@ int sty_pitch_energy_fwd(sty_model *m, int B, int L, int T, const int64_t *texts
                          const float *alignment, const float *style, float *pitch, float *energy, void *workspace,
                          size_t ws_bytes, void *stream);
 
+/* PitchStyleEncoder.forward(x [B,n_mels,T], pitch [B,T], energy [B,T]) -> [B,style_dim] at coarse_multiplier 1
+ * (mel_style_encoder.py:155-205); model kind "pitch_style_encoder".                                             */
+int sty_pitch_style_workspace_bytes(const sty_model *m, int B, int T, size_t *bytes);
+int sty_pitch_style_fwd(sty_model *m, int B, int T, const float *mel, const float *pitch, const float *energy,
+                        float *style, void *workspace, size_t ws_bytes, void *stream);
+
 /* ---- fine-grained entry points for unit parity (each = one reference sub-module) ------------------ */
 /* GeneratorConvNeXtBlock (conv_next.py:80-93) of channel count C on [B,C,T]; prefix e.g.
  * "generator.basegen.phase_convnext.0".                                                              */

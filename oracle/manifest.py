@@ -298,3 +298,15 @@ def pitch_energy_predictor_manifest(cfg=None):
     _conv(m, "F0_proj", 1, d // 2, 1)
     _conv(m, "N_proj", 1, d // 2, 1)
     return m
+
+
+def pitch_style_encoder_manifest(cfg=None):
+    """PitchStyleEncoder (mel_style_encoder.py:155-186): weight-normed 1x1 preconv over (mel, pitch, energy), then the
+    MelStyleEncoder stack."""
+    c = {**DEFAULT_CFG, **(cfg or {})}
+    m = OrderedDict()
+    d = c["se_n_mels"]
+    m["preconv.bias"] = [d]
+    _wn(m, "preconv", [d, d + 2, 1])
+    m.update(style_encoder_manifest(c))
+    return m

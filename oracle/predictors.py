@@ -132,3 +132,12 @@ def duration_to_alignment(duration, multiplier=1):
     m = (seq > (lower - 3).unsqueeze(2)) * (seq < (upper + 3).unsqueeze(2))
     al = torch.clamp(al * m, min=0.0)
     return torch.softmax(al, dim=1)
+
+
+def pitch_style_encoder(P, mel, pitch, energy):
+    """PitchStyleEncoder.forward at coarse_multiplier 1 (mel_style_encoder.py:188-205): mel [B,80,T], pitch / energy
+    [B,T] -> style [B,64].  The 1x1 preconv has padding 1, so the image is two frames wider than the input."""
+    from . import style_encoder as OS
+    x = torch.cat([mel, pitch.unsqueeze(1), energy.unsqueeze(1)], dim=1)
+    x = F.conv1d(x, OB.wn_weight(P, "preconv"), P["preconv.bias"], padding=1)
+    return OS.mel_style_encoder(P, "", x.unsqueeze(1))

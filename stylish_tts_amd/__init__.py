@@ -6,4 +6,4 @@ device, raises.
 """
 from .lib import LIB, StyError, load  # noqa: F401
 from .modules import (DurationPredictor, DurationProcessor, ExportModel, MelStyleEncoder, MultiGenerator,  # noqa: F401
-                      PitchEnergyPredictor, SpeechPredictor)
+                      PitchEnergyPredictor, PitchStyleEncoder, SpeechPredictor)

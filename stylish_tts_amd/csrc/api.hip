@@ -582,6 +582,9 @@ struct Builder {
       vocoder("");
     } else if (m->kind == "mel_style_encoder") {
       style_encoder();
+    } else if (m->kind == "pitch_style_encoder") {
+      m->pse_pre = conv("preconv", true);
+      style_encoder();
     } else if (m->kind == "duration_predictor") {
       duration_predictor();
     } else if (m->kind == "pitch_energy_predictor") {
@@ -1389,7 +1392,7 @@ int sty_model_create(const char* kind, sty_model** out) {
   }
   std::string k(kind);
   if (k != "speech_predictor" && k != "vocoder" && k != "mel_style_encoder" && k != "duration_predictor" &&
-      k != "pitch_energy_predictor") {
+      k != "pitch_energy_predictor" && k != "pitch_style_encoder") {
     set_error("unknown model kind '%s'", kind);
     return STY_EINVAL;
   }
@@ -2177,6 +2180,55 @@ static int style_entry(sty_model* m, int B, int T, const float* mel, float* styl
     return STY_ENOMEM;
   }
   return r.rc;
+}
+// PitchStyleEncoder.forward at coarse_multiplier 1 (mel_style_encoder.py:188-205)
+static int pitch_style_entry(sty_model* m, int B, int T, const float* mel, const float* pitch, const float* energy,
+                             float* style, void* ws, size_t ws_bytes, void* stream, size_t* need) {
+  Run r;
+  r.m = m;
+  r.st = S(stream);
+  r.B = B;
+  r.ws.base = (char*)ws;
+  r.ws.cap = ws_bytes;
+  const int C = m->pse_pre.Cin, D = m->pse_pre.Cout, Tp = T + 2;
+  float* cat = r.ws.take<float>((size_t)B * C * T);
+  float* padded = r.ws.take<float>((size_t)B * C * Tp);
+  float* pre = r.ws.take<float>((size_t)B * D * Tp);
+  if (r.live()) {
+    const float* src[3] = {mel, pitch, energy};
+    const int cs[3] = {C - 2, 1, 1};
+    r.chk(launch_concat(src, cs, 3, B, T, cat, r.st));
+    r.chk(launch_pad_time(cat, B * C, T, 1, padded, r.st));  // Conv1d(k = 1, padding = 1): two bias-only frames
+    r.conv(r.base(m->pse_pre, padded, Tp, pre));
+  }
+  style_run(r, pre, Tp, style);
+  if (need) *need = align_up(r.peak > r.ws.off ? r.peak : r.ws.off, 256) + 256;
+  if (ws && (r.ws.overflow || r.peak > ws_bytes)) {
+    set_error("workspace too small: need %zu bytes, have %zu", r.peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return r.rc;
+}
+int sty_pitch_style_workspace_bytes(const sty_model* m, int B, int T, size_t* bytes) {
+  int rc = model_ready(m, "pitch_style_encoder");
+  if (rc) return rc;
+  if (!bytes || B <= 0 || T < 40) {
+    set_error("sty_pitch_style_workspace_bytes: bad argument (T >= 40 frames)");
+    return STY_EINVAL;
+  }
+  return pitch_style_entry(const_cast<sty_model*>(m), B, T, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                           bytes);
+}
+int sty_pitch_style_fwd(sty_model* m, int B, int T, const float* mel, const float* pitch, const float* energy,
+                        float* style, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "pitch_style_encoder");
+  if (rc) return rc;
+  if (!mel || !pitch || !energy || !style || !workspace || B <= 0 || T < 40) {
+    set_error("sty_pitch_style_fwd: bad argument (T >= 40 frames)");
+    return STY_EINVAL;
+  }
+  if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
+  return pitch_style_entry(m, B, T, mel, pitch, energy, style, workspace, ws_bytes, stream, nullptr);
 }
 int sty_style_workspace_bytes(const sty_model* m, int B, int T, size_t* bytes) {
   int rc = model_ready(m, "mel_style_encoder");

@@ -23,6 +23,7 @@ int launch_style_expand(const float* style, int B, int S, int L, float* y, hipSt
 int launch_scale_copy(const float* x, float a, size_t n, float* y, hipStream_t st);
 int launch_mask_mul(float* x, const float* mask, int B, int C, int T, hipStream_t st);
 int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStream_t st);
+int launch_pad_time(const float* x, int rows, int T, int pad, float* y, hipStream_t st);
 int launch_dur_post(const float* d, const float* mask, int B, int NC, int L, float* out, hipStream_t st);
 int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st);
 int source_workspace_floats(int B, int T);
@@ -206,6 +207,7 @@ struct sty_model {
   sty::StylePlan sty_enc;
   sty::DurationPlan dur;
   sty::PitchEnergyPlan pe;
+  sty::PackedConv pse_pre;  // PitchStyleEncoder.preconv (mel_style_encoder.py:166)
   float* stft_default = nullptr;  // device [4][33][64]
   // ---- training ----
   bool train_enabled = false;

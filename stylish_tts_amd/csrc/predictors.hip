@@ -90,6 +90,20 @@ int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStre
   return STY_OK;
 }
 
+// zero-pad the time axis: x [rows][T] -> y [rows][T + 2*pad]
+__global__ void pad_time_kernel(const float* __restrict__ x, int T, int pad, float* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  const int To = T + 2 * pad;
+  if (t >= To) return;
+  const int ts = t - pad;
+  y[(size_t)r * To + t] = (ts >= 0 && ts < T) ? x[(size_t)r * T + ts] : 0.f;
+}
+int launch_pad_time(const float* x, int rows, int T, int pad, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(pad_time_kernel, dim3(cdiv(T + 2 * pad, 256), rows), dim3(256), 0, st, x, T, pad, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // DurationPredictor tail (duration_predictor.py:81-86): d [B][NC][L] (conv layout) -> out [B][L][NC]:
 // keep class 0, |.| of the others, cumulative sum over classes, -|.|, mask
 __global__ void dur_post_kernel(const float* __restrict__ d, const float* __restrict__ mask, int NC, int L,

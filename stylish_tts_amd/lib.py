@@ -87,6 +87,8 @@ SYMBOLS = {
     "sty_duration_fwd": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_pitch_energy_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
     "sty_pitch_energy_fwd": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_pitch_style_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
+    "sty_pitch_style_fwd": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_conv1d_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
     "sty_conv1d_fwd": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
     "sty_conv1d_bwd_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _I, _SZP]),

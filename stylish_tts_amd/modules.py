@@ -19,7 +19,7 @@ import torch
 
 from . import lib as L
 from .manifest import (DEFAULT_CFG, N3_CFG, duration_predictor_manifest, pitch_energy_predictor_manifest,
-                       speech_predictor_manifest, style_encoder_manifest)
+                       pitch_style_encoder_manifest, speech_predictor_manifest, style_encoder_manifest)
 
 
 class DecoderPrediction:  # train/utils.py:643-653
@@ -501,6 +501,35 @@ class PitchEnergyPredictor(_HipModule):
                                          L.ptr(en), L.ptr(ws), ws.numel(),
                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return f0, en
+
+
+class PitchStyleEncoder(_HipModule):
+    """PitchStyleEncoder(dim_in, style_dim, max_conv_dim, skip_downsamples, coarse_multiplier).forward(x, pitch, energy)
+    -> [B, style_dim]   (mel_style_encoder.py:155-205); coarse_multiplier 1 (model.yml), where the two interpolations
+    are the identity."""
+    KIND = "pitch_style_encoder"
+
+    def __init__(self, dim_in=80, style_dim=64, max_conv_dim=384, skip_downsamples=True, coarse_multiplier=1):
+        super().__init__()
+        if coarse_multiplier != 1:
+            raise NotImplementedError("PitchStyleEncoder: coarse_multiplier != 1 is not built")
+        self.cfg = dict(DEFAULT_CFG, se_n_mels=dim_in, style_dim=style_dim, se_max_channels=max_conv_dim,
+                        se_skip_downsample=skip_downsamples)
+        self._build(pitch_style_encoder_manifest(self.cfg))
+
+    def forward(self, x, pitch, energy):
+        _no_autograd("PitchStyleEncoder.forward")
+        dev = x.device
+        lib = self._ensure(dev)
+        B, _, T = x.shape
+        x, pitch, energy = _f32(x, dev), _f32(pitch, dev), _f32(energy, dev)
+        out = torch.empty(B, self.cfg["style_dim"], dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_pitch_style_workspace_bytes(self._handle, B, T, C.byref(need)))
+        ws = self._workspace(need.value, dev)
+        L.check(lib.sty_pitch_style_fwd(self._handle, B, T, L.ptr(x), L.ptr(pitch), L.ptr(energy), L.ptr(out), L.ptr(ws),
+                                        ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out
 
 
 class DurationProcessor(torch.nn.Module):

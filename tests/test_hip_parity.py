@@ -1035,3 +1035,22 @@ def test_export_model_text_to_audio_vs_oracle(env):
     mse = ((audio.cpu() - ref.squeeze(1)) ** 2).mean().item()
     print(f"\n  text -> audio, {T} frames: waveform mse vs oracle chain {mse:.3e}, mel-L1 {_mel_l1(audio.cpu().unsqueeze(1), ref):.3e}")
     assert mse <= 1e-6 and _mel_l1(audio.cpu().unsqueeze(1), ref) <= 1e-3
+
+
+def test_pitch_style_encoder_vs_reference_golden():
+    """PitchStyleEncoder (the pe_style_encoder of build_model) on the HIP path vs the reference's output
+    (tests/golden/pse_small.safetensors): 1x1 weight-normed preconv with padding 1, then the MelStyleEncoder plan."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle.manifest import pitch_style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    g = load_file(os.path.join(G, "pse_small.safetensors"))
+    m = S.PitchStyleEncoder()
+    m.load_state_dict(fill_state_dict(pitch_style_encoder_manifest(), 5))
+    m = m.to(DEV)
+    with torch.no_grad():
+        s = m(dev(g["mel"]), dev(g["pitch"]), dev(g["energy"]))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("style vs reference", s, g["style"], 2e-5)
+    rep.done()

@@ -56,6 +56,21 @@ def main():
         ali = proc(pred, cs["text_lengths"])
         ali3 = proc(pred, cs["text_lengths"], multiplier=3)
         f0, en = pe(cs["texts"], cs["text_lengths"], ali, pstyle)
+    # PitchStyleEncoder (the pe_style_encoder of build_model, models.py:55-61)
+    from stylish_tts.train.models.mel_style_encoder import PitchStyleEncoder
+    from oracle.manifest import pitch_style_encoder_manifest
+    pse = PitchStyleEncoder(mc.style_encoder.n_mels, mc.style_dim, mc.style_encoder.max_channels,
+                            mc.style_encoder.skip_downsample, coarse_multiplier=mc.coarse_multiplier).eval()
+    json.dump({k: list(v.shape) for k, v in pse.state_dict().items()},
+              open(os.path.join(OUT, "manifest_pitch_style_encoder.json"), "w"), indent=0)
+    miss, unexp = pse.load_state_dict(fill_state_dict(pitch_style_encoder_manifest(), 5), strict=False)
+    assert not miss and not unexp, (miss, unexp)
+    se_mel = torch.randn(2, 80, 88, generator=g)
+    se_pitch, se_energy = torch.rand(2, 88, generator=g) * 200 + 60, torch.randn(2, 88, generator=g)
+    with torch.no_grad():
+        pse_style = pse(se_mel, se_pitch, se_energy)
+    save_file({"mel": se_mel, "pitch": se_pitch, "energy": se_energy, "style": pse_style.contiguous()},
+              os.path.join(OUT, "pse_small.safetensors"))
     save_file({"duration_style": dstyle, "pe_style": pstyle, "dur_pred": pred.contiguous(), "duration": dur.contiguous(),
                "alignment": ali.contiguous(), "alignment_x3": ali3.contiguous(), "pitch": f0.contiguous(),
                "energy": en.contiguous()}, os.path.join(OUT, "n3_small.safetensors"))
