@@ -322,19 +322,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up: the last warm-up step (all of them when W <= 2) is timed per kernel family with HIP events on the launch
+    # Warm-up: W untimed steps, then one more untimed step timed per kernel family with HIP events on the launch
     # streams; the per-family table `kernels` comes from there.  Timed region: only the dominant family keeps its
     # events (two events per launch on every instrumented launch cost ~7 % of a c2 step), and `roofline` is computed
     # from those -- live, inside the timed region, as the contract asks.
-    nprof = 1 if args.warmup > 2 else args.warmup
     for i in range(args.warmup):
-        if i == args.warmup - nprof:
-            torch.cuda.synchronize()
-            lib.sty_prof_enable(1)
         out = step(i)
+    # one more untimed step (also with --warmup 0) with every family timed: the per-family table and the choice of the
+    # dominant kernel
+    nprof = 1
+    torch.cuda.synchronize()
+    lib.sty_prof_enable(1)
+    out = step(args.warmup)
     barrier()
     lib.sty_prof_enable(0)
-    warm_prof = L.prof_report(2048) if nprof else []
+    warm_prof = L.prof_report(2048)
     dom_name = max(warm_prof, key=lambda r: r["ms"])["name"] if warm_prof else None
     if dom_name:
         lib.sty_prof_only(dom_name.split(" ")[0].encode())  # STY_PROF_SHAPES appends the shape to the family name
@@ -342,7 +344,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(args.warmup + i)
+        out = step(args.warmup + 1 + i)
     barrier()
     dt = time.perf_counter() - t0
     lib.sty_prof_enable(0)
@@ -356,11 +358,11 @@ def main():
     if trainer is not None:  # every rank: the steps contain the gradient all-reduce
         lib.sty_set_single_stream(1)
         trainer.single_stream = True
-        step(args.warmup + args.steps)
+        step(args.warmup + args.steps + 1)
         torch.cuda.synchronize()
         lib.sty_prof_enable(1)
         for i in range(2):
-            step(args.warmup + args.steps + 1 + i)
+            step(args.warmup + args.steps + 2 + i)
         torch.cuda.synchronize()
         lib.sty_prof_enable(0)
         serial_prof = L.prof_report(2048)
@@ -411,7 +413,7 @@ def main():
                 "what": "same kernel, two extra steps after the timed region with the side streams off",
                 "avg_launch_us": per1 * 1e6, "mfma_TFLOPs": tf1, "mfma_frac": tf1 / peak,
                 "hbm_GBps_algorithmic": gb1, "hbm_frac": gb1 / PEAK_HBM_GBS}
-        rec["kernels_source"] = f"HIP events over the last {nprof} warm-up step(s); roofline: over the timed region"
+        rec["kernels_source"] = "HIP events over one untimed step after the warm-up; roofline: over the timed region"
         rec["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / nprof,
                            "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
                            "GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
