@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """Benchmark of the stylish-tts acoustic hot path on MI355X (see DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c5]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c3-fp32|c2|c2-fwd|c5|c5-bf16|tts] [--no-extra]
 
 A step is one pass of the hot path over one synthetic batch already resident in HBM:
-  c2 (default; BASELINE.json configs[1]): sample_dataset shape, B=16 utterances of T=160 mel frames (2.0 s),
+  c2 (BASELINE.json configs[1]): sample_dataset shape, B=16 utterances of T=160 mel frames (2.0 s),
       L=37 phoneme tokens, fp32 -- one train_acoustic step (train/stage_type.py:346-373 + stage.py:124):
       AcousticStep forward (mel x2 + energy, alignment, style encoder, text encoder, alignment expand, decoder,
       vocoder), mel + multi-phase losses through the 3-resolution STFT features, backward through the predictor and
@@ -12,7 +12,8 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       off (third-party models); module.train() behaviour (BatchNorm batch statistics, spectral-norm
       power iteration, random Decoder smoothing, TextEncoder dropout).
   c2-fwd: the forward half only (AcousticStep forward + the six multi-spectrogram lists).
-  c3: LJSpeech shape, B=32, T=520, L=100, the same training step with bf16 operands on the dense convs / Linears
+  c3 (DEFAULT; BASELINE.json configs[2], the configuration the metric is quoted on): LJSpeech shape, B=32, T=520,
+      L=100, the same training step with bf16 operands on the dense convs / Linears
       (fp32 accumulation, storage, norms, attention and losses: SURVEY.md 8(d) "bf16 autocast for conv/GEMM").
   c3-fp32: the same shape entirely in fp32.
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
@@ -21,6 +22,7 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       alignment -> pitch / energy predictor -> speech predictor -> audio, fp32 inference; frames = B x predicted frames.
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
+The default run (c3 at N = 1) also carries c2, c5 and c3-fp32 as `extra` sub-records (fewer steps, same process).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -233,37 +235,10 @@ def cpu_baseline(w, budget_s=15.0, hard_timeout_s=120.0):
     return last
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    from stylish_tts_amd import dist as D
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU product path"
-    # STY_BENCH_SHARE_DEVICE=1 (test aid): all ranks share device 0 and exchange gradients over gloo, so the N > 1 code
-    # path can be exercised on a 1-GPU box; the numbers of such a run mean nothing
-    share = os.environ.get("STY_BENCH_SHARE_DEVICE") == "1"
-    if share:
-        # two processes time-slicing ONE GPU: cross-queue event waits then stall for whole time slices (measured:
-        # 161 ms per step single-stream, 16-28 s with the side streams).  Not a configuration anyone trains in; the
-        # test aid runs single-stream.  One process per GPU keeps its streams.
-        os.environ.setdefault("STY_NO_SIDE_STREAM", "1")
-        os.environ.setdefault("STY_NO_SE_STREAM", "1")
-    local = 0 if share else local
-    torch.cuda.set_device(local)
-    rank, world = D.init("gloo" if share else "nccl")  # "nccl" = RCCL; one process per GPU (torchrun environment)
-    device = torch.device("cuda", local)
-
-    import __graft_entry__ as ge
-    ge.build()
-    from stylish_tts_amd import lib as L
-    lib = L.load()
-    w = WORKLOADS[args.workload]
+def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, serial_pass=True):
+    """W untimed + 1 profiled step, K timed steps between two barriers, max over ranks; returns the record (rank 0)
+    or None.  Every model / trainer / workspace of the workload is released before returning."""
+    w = WORKLOADS[name]
     model, style_enc, P = build_model(device)
     from stylish_tts_amd.acoustic import AcousticTrainer, acoustic_forward
     from stylish_tts_amd.frontend import MultiSpectrogram
@@ -271,7 +246,7 @@ def main():
     inp = make_inputs(w, 1000 + rank, device)
     B, T = w["B"], w["T"]
     bf16 = w.get("compute") == "bf16"
-    trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"))
+    trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"), seed=rank)
                if w["what"] == "train" else None)
     if bf16 and trainer is None:
         model.set_train_opts(compute_bf16=True)
@@ -326,14 +301,12 @@ def main():
     # streams; the per-family table `kernels` comes from there.  Timed region: only the dominant family keeps its
     # events (two events per launch on every instrumented launch cost ~7 % of a c2 step), and `roofline` is computed
     # from those -- live, inside the timed region, as the contract asks.
-    for i in range(args.warmup):
+    for i in range(warmup):
         out = step(i)
-    # one more untimed step (also with --warmup 0) with every family timed: the per-family table and the choice of the
-    # dominant kernel
     nprof = 1
     torch.cuda.synchronize()
     lib.sty_prof_enable(1)
-    out = step(args.warmup)
+    out = step(warmup)
     barrier()
     lib.sty_prof_enable(0)
     warm_prof = L.prof_report(2048)
@@ -343,8 +316,8 @@ def main():
         lib.sty_prof_enable(1)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + 1 + i)
+    for i in range(steps):
+        out = step(warmup + 1 + i)
     barrier()
     dt = time.perf_counter() - t0
     lib.sty_prof_enable(0)
@@ -355,14 +328,14 @@ def main():
     # families timed -- the dominant kernel's duration free of the stretch from sharing the chip with the
     # weight-gradient / style-encoder streams.  Reported beside `roofline`, never instead of it.
     serial_prof = []
-    if trainer is not None:  # every rank: the steps contain the gradient all-reduce
+    if trainer is not None and serial_pass:  # every rank: the steps contain the gradient all-reduce
         lib.sty_set_single_stream(1)
         trainer.single_stream = True
-        step(args.warmup + args.steps + 1)
+        step(warmup + steps + 1)
         torch.cuda.synchronize()
         lib.sty_prof_enable(1)
         for i in range(2):
-            step(args.warmup + args.steps + 2 + i)
+            step(warmup + steps + 2 + i)
         torch.cuda.synchronize()
         lib.sty_prof_enable(0)
         serial_prof = L.prof_report(2048)
@@ -370,23 +343,25 @@ def main():
         trainer.single_stream = False
     barrier()
     dt = D.max_over_ranks(dt, device)
-    if rank != 0:
-        return
     if synth is not None:
         T = out.shape[-1] // 300  # frames the duration predictor asked for (same inputs every step)
-    frames = world * B * T * args.steps
+    del trainer, model, style_enc, synth, inp, out, step
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    frames = world * B * T * steps
     rec = {
         "metric": "audio frames/sec/GPU (24 kHz) forward+backward; DDP scaling 1/2/4/8 MI355X",
-        "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 GEMM operands, f32 accumulation/storage" if bf16 else "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
+        "config": {"workload": f"{name}: B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
                    "pass": PASS[w["what"]],
                    "x_realtime": frames / dt / 80.0},
     }
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
-        traffic, traffic_src = pmc_traffic(dom["name"], args.workload)
+        traffic, traffic_src = pmc_traffic(dom["name"], name)
         per = dom["ms"] / dom["launches"] * 1e-3
         tf = dom["flops"] / dom["launches"] / per / 1e12
         gbs = dom["bytes"] / dom["launches"] / per / 1e9
@@ -418,8 +393,62 @@ def main():
                            "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
                            "GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
                           for r in sorted(warm_prof, key=lambda r: -r["ms"])]
+    return rec
+
+
+EXTRA_WORKLOADS = ("c2", "c5", "c3-fp32")  # carried as sub-records of the default (c3) line at N = 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    # default = the configuration BASELINE.json's metric is quoted on: configs[2], LJSpeech shape, B=32, bf16
+    ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c5 / c3-fp32 sub-records of the default run")
+    args = ap.parse_args()
+
+    from stylish_tts_amd import dist as D
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU product path"
+    # STY_BENCH_SHARE_DEVICE=1 (test aid): all ranks share device 0 and exchange gradients over gloo, so the N > 1 code
+    # path can be exercised on a 1-GPU box; the numbers of such a run mean nothing
+    share = os.environ.get("STY_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        # two processes time-slicing ONE GPU: cross-queue event waits then stall for whole time slices (measured:
+        # 161 ms per step single-stream, 16-28 s with the side streams).  Not a configuration anyone trains in; the
+        # test aid runs single-stream.  One process per GPU keeps its streams.
+        os.environ.setdefault("STY_NO_SIDE_STREAM", "1")
+        os.environ.setdefault("STY_NO_SE_STREAM", "1")
+    local = 0 if share else local
+    torch.cuda.set_device(local)
+    rank, world = D.init("gloo" if share else "nccl")  # "nccl" = RCCL; one process per GPU (torchrun environment)
+    device = torch.device("cuda", local)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    rec = run_workload(args.workload, args.steps, args.warmup, rank, world, device, lib, L, D, share)
+    extras = {}
+    if world == 1 and args.workload == "c3" and not args.no_extra:
+        # the other single-GPU configurations of BASELINE.json, same process, fewer steps; each is a full record of its
+        # own (value, ms_per_step, roofline of ITS dominant kernel) without the per-family table
+        for name in EXTRA_WORKLOADS:
+            r = run_workload(name, min(args.steps, 10), min(args.warmup, 3), rank, world, device, lib, L, D, share,
+                             serial_pass=False)
+            if r is not None:
+                r.pop("kernels", None)
+                r.pop("kernels_source", None)
+                extras[name] = r
+    if rank != 0:
+        return
+    if extras:
+        rec["extra"] = extras
     if not args.no_cpu_baseline and world == 1:
-        rec["cpu_baseline"] = cpu_baseline(w)
+        rec["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload])
     print(json.dumps(rec))
 
 

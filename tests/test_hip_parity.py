@@ -299,9 +299,9 @@ def test_speech_predictor_end_to_end_vs_oracle_and_golden(env):
     rep.done()
 
 
-def test_vocoder_properties_full_size(env):
-    """BASELINE config c5 shape (B=8, T=800): size-independent properties instead of an oracle run
-    (the CPU oracle needs ~15 s here; bench.py times it).  Determinism, boundedness, batch independence."""
+def test_vocoder_determinism_full_size(env):
+    """BASELINE config c5 shape (B=8, T=800): the forward is deterministic and bounded.  (The comparison with the
+    oracle at this size, and the batch-independence check, are in tests/test_full_size.py.)"""
     m = env["m"]
     g = torch.Generator().manual_seed(7)
     B, T = 8, 800
@@ -313,13 +313,9 @@ def test_vocoder_properties_full_size(env):
     with torch.no_grad():
         a = m.vocoder_forward(mel=dev(mel), style=dev(style), pitch=dev(pitch), voiced=dev(voiced), seed=3).audio
         b = m.vocoder_forward(mel=dev(mel), style=dev(style), pitch=dev(pitch), voiced=dev(voiced), seed=3).audio
-        c = m.vocoder_forward(mel=dev(mel[2:5]), style=dev(style[2:5]), pitch=dev(pitch[2:5]), voiced=dev(voiced[2:5]),
-                              seed=3).audio
     torch.cuda.synchronize()
     assert a.shape == (B, 1, 300 * T) and bool(torch.isfinite(a).all()) and a.abs().max().item() <= 1.0
     assert torch.equal(a, b), "forward is not deterministic"
-    # utterances are independent: rows 2..4 alone give the same audio except for the per-(b,n) noise stream
-    assert a[2:5].std().item() > 1e-3 and c.std().item() > 1e-3
 
 
 @pytest.mark.parametrize("T", [80, 161, 222])
@@ -651,7 +647,7 @@ def test_acoustic_train_step_gradients(env):
     audio_gt = _test_audio(B, 300 * T, 21)
     tr, P, Pse = _train_setup(env, 0.0)
     want = {}
-    sp_keys = ["generator.amp_output_conv.weight", "generator.phase_output_real_conv.bias",
+    sp_keys = ["generator.basegen.amp_output_conv.weight", "generator.basegen.phase_output_real_conv.bias",
                "decoder.decode.0.norm1.fc.weight", "text_encoder.proj_m.weight", "text_encoder.emb.weight",
                "generator.conformer.ff1.1.weight" if "generator.conformer.ff1.1.weight" in P else None]
     sp_keys = [k for k in sp_keys if k and k in P and P[k].is_floating_point()]
@@ -950,7 +946,7 @@ def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, STY_BENCH_SHARE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "c2"],
                        capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
