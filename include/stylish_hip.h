@@ -56,6 +56,10 @@ const char *sty_model_key(const sty_model *m, int i);
 /* Re-derive effective weights (weight_norm g*v/|v|, spectral_norm W/sigma, MFMA operand packing, folded
  * GRN beta) from the bound parameters.  Call after every optimiser step; once for inference.          */
 int sty_model_prepare(sty_model *m, void *stream);
+/* Tell the library that bound parameters / buffers were modified in place (optimizer step, load_state_dict into the
+ * same storage, BatchNorm / spectral-norm buffer updates): the next inference entry point re-prepares.  The
+ * *_fwd_train entry points prepare on every call and leave the model marked stale.                      */
+int sty_model_invalidate(sty_model *m);
 
 /* ---- vocoder: MultiGenerator.forward (train/models/generator.py:884-901) -------------------------
  * mel [B,128,T], style [B,64], pitch [B,T], voiced [B,T]  ->  audio [B,1,300*T].

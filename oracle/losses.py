@@ -38,6 +38,12 @@ def multi_phase_loss(pred_list, target_list):
     return sum(differential_phase_loss(p, t) for p, t in zip(pred_list, target_list)) / len(pred_list)
 
 
+def backwards_total(mel, mph, w_mel=5.0, w_phase=8.0):
+    """LossLog.backwards_loss (train/loss_log.py:82-94): every non-GAN loss divided by its own detached value (+1e-9),
+    times its weight, summed."""
+    return w_mel * (mel / (mel.detach() + 1e-9)) + w_phase * (mph / (mph.detach() + 1e-9))
+
+
 def acoustic_losses(audio_gt, audio_pred, w_mel=5.0, w_phase=8.0):
     """(mel, multi_phase, backwards_total) for target / predicted waveforms [B, N]."""
     t_mag, t_ph, p_mag, p_ph = [], [], [], []
@@ -51,5 +57,4 @@ def acoustic_losses(audio_gt, audio_pred, w_mel=5.0, w_phase=8.0):
         p_ph.append(ph)
     mel = mel_loss(t_mag, p_mag)
     mph = multi_phase_loss(p_ph, t_ph)
-    total = w_mel * mel / (mel.detach() + 1e-9) + w_phase * mph / (mph.detach() + 1e-9)
-    return mel, mph, total
+    return mel, mph, backwards_total(mel, mph, w_mel, w_phase)

@@ -1615,6 +1615,7 @@ int sty_speech_fwd_train(sty_model* m, const sty_speech_io* io, void* workspace,
     return STY_EINVAL;
   }
   if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->prepared = false;  // a training step mutates buffers and is followed by an optimizer step: inference re-prepares
   if (!m->trainer) m->trainer = trainer_create(m);
   return trainer_speech_forward(m->trainer, io, workspace, ws_bytes, S(stream), nullptr);
 }
@@ -1668,6 +1669,7 @@ int sty_vocoder_fwd_train(sty_model* m, const sty_vocoder_io* io, void* workspac
     return STY_EINVAL;
   }
   if ((rc = sty_model_prepare(m, stream))) return rc;  // parameters change every step
+  m->prepared = false;
   if (!m->trainer) m->trainer = trainer_create(m);
   return trainer_vocoder_forward(m->trainer, io, workspace, ws_bytes, S(stream), nullptr);
 }
@@ -1763,6 +1765,15 @@ static int build_multi_tables(sty_model* m) {
     STY_HIP(hipMemcpy(m->mj_blk_dev[i], blk[i].data(), blk[i].size() * sizeof(int), hipMemcpyHostToDevice));
   }
   m->mj_ready = true;
+  return STY_OK;
+}
+
+int sty_model_invalidate(sty_model* m) {
+  if (!m) {
+    set_error("sty_model_invalidate: null model");
+    return STY_EINVAL;
+  }
+  m->prepared = false;
   return STY_OK;
 }
 
@@ -2282,6 +2293,7 @@ int sty_style_fwd_train(sty_model* m, int B, int T, const float* mel, float* sty
   }
   // weights change between steps: re-derive the prepared (spectral-normalised, packed) form every call
   if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->prepared = false;
   if (!m->trainer) m->trainer = trainer_create(m);
   return trainer_style_forward(m->trainer, B, T, mel, style, workspace, ws_bytes, S(stream), nullptr);
 }

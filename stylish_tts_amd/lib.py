@@ -53,6 +53,7 @@ SYMBOLS = {
     "sty_model_num_keys": (C.c_int, [_P]),
     "sty_model_key": (C.c_char_p, [_P, _I]),
     "sty_model_prepare": (C.c_int, [_P, _P]),
+    "sty_model_invalidate": (C.c_int, [_P]),
     "sty_vocoder_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_vocoder_fwd": (C.c_int, [_P, C.POINTER(VocoderIO), _P, C.c_size_t, _P]),
     "sty_speech_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),

@@ -14,6 +14,10 @@ def acoustic_loss(audio_gt, audio_pred, w_mel=5.0, w_phase=8.0):
     dev = audio_pred.device
     gt = audio_gt.to(torch.float32).contiguous()
     pr = audio_pred.detach().to(torch.float32).contiguous()
+    if pr.dim() != 2 or gt.shape != pr.shape:
+        raise L.StyError(f"acoustic_loss: audio_gt {tuple(gt.shape)} and audio_pred {tuple(pr.shape)} must both be [B,N]")
+    if gt.device != dev:
+        raise L.StyError(f"acoustic_loss: audio_gt on {gt.device}, audio_pred on {dev}")
     B, N = pr.shape
     losses = torch.empty(2, device=dev)
     d = torch.empty(B, N, device=dev)

@@ -71,6 +71,13 @@ def _conv(m, p, cout, cin, k, bias=True):
         m[p + ".bias"] = [cout]
 
 
+def multi_generator_manifest(cfg=None):
+    """MultiGenerator on its own (generator.py:802-855): the `generator.*` keys of the SpeechPredictor without the
+    prefix -- what `MultiGenerator(...).state_dict()` holds in the reference."""
+    full = speech_predictor_manifest(cfg)
+    return OrderedDict((k[len("generator."):], v) for k, v in full.items() if k.startswith("generator."))
+
+
 def speech_predictor_manifest(cfg=None):
     c = dict(DEFAULT_CFG, **(cfg or {}))
     sd = c["style_dim"]

@@ -8,8 +8,11 @@ Reference interfaces mirrored here (paths under the reference tree, src/stylish_
       .forward(*, mel, style, pitch, energy, voiced) -> DecoderPrediction     generator.py:802-901
   MelStyleEncoder(dim_in, style_dim, max_conv_dim, skip_downsamples).forward(x) -> [B, style_dim]
       mel_style_encoder.py:121-152
-`forward` is inference: calling it with autograd enabled raises (there is no autograd graph to record and no silent
-PyTorch fallback); training goes through `forward_train` / `backward`, which write into `param.grad`.
+`forward` under torch.no_grad() is inference.  With autograd enabled, SpeechPredictor.forward and MelStyleEncoder.forward
+run the library's training graph behind a torch.autograd.Function (so the reference's `train_acoustic` +
+`accelerator.backward(loss)` drive them unchanged; parameter gradients land in `param.grad`); the explicit
+`forward_train` / `backward` pair is the same thing without autograd (what AcousticTrainer uses).  The second-stage
+predictors are inference only and raise under autograd.  There is no PyTorch fallback anywhere.
 DurationPredictor / PitchEnergyPredictor / DurationProcessor / ExportModel (duration_predictor.py, pitch_energy_predictor.py,
 utils.py:656-803, export_model.py) are at the end of this file (inference only).
 """
@@ -18,8 +21,9 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .manifest import (DEFAULT_CFG, N3_CFG, duration_predictor_manifest, pitch_energy_predictor_manifest,
-                       pitch_style_encoder_manifest, speech_predictor_manifest, style_encoder_manifest)
+from .manifest import (DEFAULT_CFG, N3_CFG, duration_predictor_manifest, multi_generator_manifest,
+                       pitch_energy_predictor_manifest, pitch_style_encoder_manifest, speech_predictor_manifest,
+                       style_encoder_manifest)
 
 
 class DecoderPrediction:  # train/utils.py:643-653
@@ -81,6 +85,7 @@ class _HipModule(torch.nn.Module):
             else:
                 _register(self, key, _init_value(key, tuple(shape)), last in _BUFFER_SUFFIXES)
         self._manifest = dict(manifest)
+        self._tape_id = 0
         self._handle = None
         self._bound = None
         self._ws = None
@@ -88,6 +93,14 @@ class _HipModule(torch.nn.Module):
     # ---- C-ABI plumbing ----
     def _ensure(self, device):
         lib = L.load()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise L.StyError(f"{type(self).__name__}: inputs and parameters must live on a HIP device (got {device}); "
+                             "there is no CPU path")
+        if device.index is not None and device.index != torch.cuda.current_device():
+            # the library allocates its arenas and creates its side streams / events on the CURRENT device
+            raise L.StyError(f"{type(self).__name__}: model lives on {device} but the current device is "
+                             f"cuda:{torch.cuda.current_device()}; wrap the call in `with torch.cuda.device({device.index}):`")
         sd = {k: v for k, v in self.state_dict(keep_vars=True).items()}
         ptrs = {}
         for k, v in sd.items():
@@ -102,9 +115,19 @@ class _HipModule(torch.nn.Module):
             self._handle = h
         gptrs = {}
         if getattr(self, "_train", False):
+            # gradient buffers are owned by the shell and persistent: after torch's zero_grad(set_to_none=True) the
+            # same (zeroed) buffer is attached again, so the pointers the library holds stay valid and nothing is
+            # re-bound / re-finalized between steps
+            bufs = self.__dict__.setdefault("_grad_bufs", {})
             for k, p in self.named_parameters():
                 if p.grad is None:
-                    p.grad = torch.zeros_like(p)
+                    g = bufs.get(k)
+                    if g is None or g.shape != p.shape or g.device != p.device:
+                        g = torch.zeros_like(p)
+                    else:
+                        g.zero_()
+                    p.grad = g
+                bufs[k] = p.grad
                 gptrs[k] = p.grad.data_ptr()
         if self._bound != (ptrs, gptrs):
             for k, v in sd.items():
@@ -116,6 +139,15 @@ class _HipModule(torch.nn.Module):
                 L.check(lib.sty_model_bind_grad(self._handle, k.encode(), C.c_void_p(g)))
             L.check(lib.sty_model_finalize(self._handle))
             self._bound = (ptrs, gptrs)
+        # in-place mutation through torch (load_state_dict into the same storage, p.data.copy_, p.mul_ ...) bumps the
+        # tensors' version counters: the packed / normalised weights are then stale.  (Mutation by the library itself
+        # -- sty_adamw_step, BatchNorm / spectral-norm buffers -- is covered on the C side: every *_fwd_train leaves
+        # the model marked stale.)
+        ver = sum(v._version for v in sd.values())
+        if getattr(self, "_seen_version", None) != ver:
+            if getattr(self, "_seen_version", None) is not None:
+                L.check(lib.sty_model_invalidate(self._handle))
+            self._seen_version = ver
         if getattr(self, "_train_opts", None) is not None:
             L.check(lib.sty_model_set_train_opts(self._handle, C.byref(self._train_opts)))
         return lib
@@ -170,6 +202,23 @@ def _no_autograd(what):
                          f"forward_train() / backward() for training")
 
 
+def _check_speech_shapes(texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, noise, style_dim):
+    """The reference raises a shape error from inside torch; the library takes raw pointers, so check here."""
+    if texts.dim() != 2 or pitch.dim() != 2:
+        raise L.StyError(f"texts must be [B,L] and pitch [B,T] (got {tuple(texts.shape)}, {tuple(pitch.shape)})")
+    B, Lt = texts.shape
+    T = pitch.shape[1]
+    want = dict(text_lengths=(B,), alignment=(B, Lt, T), pitch=(B, T), energy=(B, T), voiced=(B, T),
+                style=(B, style_dim), denormal_pitch=(B, T))
+    got = dict(text_lengths=text_lengths, alignment=alignment, pitch=pitch, energy=energy, voiced=voiced, style=style,
+               denormal_pitch=denormal_pitch)
+    for k, shp in want.items():
+        if tuple(got[k].shape) != shp:
+            raise L.StyError(f"{k}: expected shape {shp}, got {tuple(got[k].shape)}")
+    if noise is not None and tuple(noise.shape) != (B, 300 * T, 9):
+        raise L.StyError(f"noise: expected shape {(B, 300 * T, 9)}, got {tuple(noise.shape)}")
+
+
 def _stft_buffers():
     """STFT(64, hop 4) bases as the reference registers them (stft.py:39-96): built by the library's host code."""
     import numpy as np
@@ -185,14 +234,61 @@ def _stft_buffers():
 
 
 def _cfg_from_model_config(mc):
+    """model.yml (the reference's ModelConfig, or stylish_tts_amd.config.load_model_config_yaml's object) -> the
+    dimension table of manifest.py.  Values the gfx950 kernels are not built for are rejected here."""
+    from .config import check_supported
+    check_supported(mc)
     g, te, se = mc.generator, mc.text_encoder, mc.style_encoder
-    return dict(sample_rate=mc.sample_rate, n_mels=mc.n_mels, n_fft=mc.n_fft, win_length=mc.win_length,
+    return dict(te_dropout=float(te.dropout),
+                sample_rate=mc.sample_rate, n_mels=mc.n_mels, n_fft=mc.n_fft, win_length=mc.win_length,
                 hop_length=mc.hop_length, style_dim=mc.style_dim, inter_dim=mc.inter_dim,
                 dec_hidden=mc.decoder.hidden_dim, dec_residual=mc.decoder.residual_dim,
                 gen_input_dim=g.input_dim, io_kernel=g.io_conv_kernel_size, conformer_layers=g.conformer_layers,
                 conv_layers=g.conv_layers, tokens=te.tokens, te_hidden=te.hidden_dim, te_filter=te.filter_channels,
                 te_heads=te.heads, te_layers=te.layers, te_kernel=te.kernel_size, se_n_mels=se.n_mels,
                 se_max_channels=se.max_channels, se_skip_downsample=se.skip_downsample)
+
+
+class _SpeechPredictorFn(torch.autograd.Function):
+    """Autograd shim over sty_speech_fwd_train / sty_speech_bwd: lets the reference's own training loop
+    (train/stage_type.py:346-373 `train_acoustic`, `accelerator.backward(loss)` at train/stage.py:104-147) drive the
+    shell.  Differentiable inputs: style, energy (the two the acoustic stage back-propagates into); parameter
+    gradients are ACCUMULATED into param.grad by the library during backward, as autograd's AccumulateGrad would."""
+
+    @staticmethod
+    def forward(ctx, anchor, style, energy, module, args, kw):
+        texts, text_lengths, alignment, pitch, voiced, denormal_pitch = args
+        audio = module.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, **kw)
+        ctx.module, ctx.tape = module, module._tape_id
+        ctx.need = (style.requires_grad, energy.requires_grad)
+        return audio
+
+    @staticmethod
+    def backward(ctx, d_audio):
+        m = ctx.module
+        if ctx.tape != m._tape_id:
+            raise L.StyError("SpeechPredictor: backward() of a forward that a later forward has replaced -- the "
+                             "library keeps ONE training graph per module (one forward, then its backward)")
+        d_style, d_energy = m.backward(d_audio.contiguous(), want_style=True, want_energy=ctx.need[1])
+        return None, d_style if ctx.need[0] else None, d_energy, None, None, None
+
+
+class _StyleEncoderFn(torch.autograd.Function):
+    """Autograd shim over sty_style_fwd_train / sty_style_bwd (the mel input is data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, module):
+        out = module.forward_train(x)
+        ctx.module, ctx.tape = module, module._tape_id
+        return out
+
+    @staticmethod
+    def backward(ctx, d_style):
+        m = ctx.module
+        if ctx.tape != m._tape_id:
+            raise L.StyError("MelStyleEncoder: backward() of a forward that a later forward has replaced")
+        m.backward(d_style.contiguous())
+        return None, None, None
 
 
 class SpeechPredictor(_HipModule):
@@ -209,7 +305,11 @@ class SpeechPredictor(_HipModule):
         """Same positional signature as the reference.  Extra keyword-only arguments make the reference's
         implicit RNG explicit: `noise` [B,300T,9] = SineGen's randn draw (generator.py:440-442); without it a
         counter-based generator seeded with `seed` is used.  `taps`: dict name -> preallocated tensor."""
-        _no_autograd("SpeechPredictor.forward")
+        if torch.is_grad_enabled():
+            return self._forward_autograd(texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch,
+                                          noise=noise, seed=seed, prior_override=prior_override)
+        _check_speech_shapes(texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, noise,
+                             self.cfg["style_dim"])
         dev = style.device
         lib = self._ensure(dev)
         B, Lt = texts.shape
@@ -238,6 +338,31 @@ class SpeechPredictor(_HipModule):
         ws = self._workspace(need.value, dev)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         L.check(lib.sty_speech_fwd(self._handle, C.byref(io), C.c_void_p(ws.data_ptr()), ws.numel(), st))
+        return DecoderPrediction(audio=audio, magnitude=None, phase=None)
+
+    def _forward_autograd(self, texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, **kw):
+        """forward() with autograd enabled: the training graph of the library behind a torch.autograd.Function.
+        self.training selects the reference's module.train() behaviour (BatchNorm batch statistics, TextEncoder
+        dropout, random Decoder smoothing widths drawn with `random.randint` as decoder.py:55-57 does)."""
+        import random
+        for name, t in (("alignment", alignment), ("pitch", pitch), ("voiced", voiced), ("denormal_pitch", denormal_pitch)):
+            if t.requires_grad:
+                raise L.StyError(f"SpeechPredictor: no gradient is produced for `{name}` (the acoustic stage "
+                                 "back-propagates into style and energy only)")
+        prev = getattr(self, "_train_opts", None)
+        bf16 = bool(prev.compute_bf16) if prev is not None else False
+        if self.training:
+            self.set_train_opts(bn_batch_stats=True, f0_smooth=(0, 7, 15)[random.randint(0, 2)],
+                                energy_smooth=(0, 7, 15, 31)[random.randint(0, 3)],
+                                dropout_seed=random.getrandbits(31) | 1,
+                                text_dropout=self.cfg.get("te_dropout", 0.2), compute_bf16=bf16)
+        else:
+            self.set_train_opts(compute_bf16=bf16)
+        self.enable_training()
+        if getattr(self, "_anchor", None) is None or self._anchor.device != style.device:
+            self._anchor = torch.zeros((), device=style.device, requires_grad=True)
+        args = (texts, text_lengths, alignment, pitch, voiced, denormal_pitch)
+        audio = _SpeechPredictorFn.apply(self._anchor, style, energy, self, args, kw)
         return DecoderPrediction(audio=audio, magnitude=None, phase=None)
 
     def vocoder_forward(self, *, mel, style, pitch, energy=None, voiced, noise=None, seed=0, prior_override=None,
@@ -273,6 +398,7 @@ class SpeechPredictor(_HipModule):
     def vocoder_forward_train(self, *, mel, style, pitch, voiced, noise=None, seed=0, prior_override=None):
         dev = style.device
         self._train = True
+        self._tape_id += 1
         lib = self._ensure(dev)
         B, _, T = mel.shape
         io = L.VocoderIO()
@@ -315,8 +441,11 @@ class SpeechPredictor(_HipModule):
         """SpeechPredictor.forward in the training graph (eval-mode statistics); follow with backward(d_audio).
         style_stream: the torch stream `style` is being computed on, when it is not the current one -- the call waits
         for it right before the first use of style, after the text encoder (sty_speech_io.style_stream)."""
+        _check_speech_shapes(texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, noise,
+                             self.cfg["style_dim"])
         dev = style.device
         self._train = True
+        self._tape_id += 1
         lib = self._ensure(dev)
         B, Lt = texts.shape
         T = pitch.shape[1]
@@ -364,23 +493,62 @@ class SpeechPredictor(_HipModule):
         L.check(L.load().sty_speech_d_style_ready(self._handle, C.c_void_p(stream.cuda_stream)))
 
 
+class _VocoderFn(torch.autograd.Function):
+    """Autograd shim over sty_vocoder_fwd_train / sty_vocoder_bwd (differentiable inputs: mel, style)."""
+
+    @staticmethod
+    def forward(ctx, anchor, mel, style, module, kw):
+        audio = module.vocoder_forward_train(mel=mel, style=style, **kw)
+        ctx.module, ctx.tape = module, module._tape_id
+        ctx.need = (mel.requires_grad, style.requires_grad)
+        return audio
+
+    @staticmethod
+    def backward(ctx, d_audio):
+        m = ctx.module
+        if ctx.tape != m._tape_id:
+            raise L.StyError("MultiGenerator: backward() of a forward that a later forward has replaced")
+        d_mel, d_style = m.vocoder_backward(d_audio.contiguous(), want_mel=ctx.need[0], want_style=True)
+        return None, d_mel, d_style if ctx.need[1] else None, None, None
+
+
 class MultiGenerator(SpeechPredictor):
-    """Vocoder-only view with the reference's keyword constructor (generator.py:803-805).  Holds the same
-    `generator.*`-free key layout as the reference MultiGenerator by prefix-stripping is NOT done here: use
-    SpeechPredictor.vocoder_forward for checkpoints of the whole predictor."""
+    """The reference's MultiGenerator (generator.py:802-901) as a module of its own: keyword constructor, forward(*,
+    mel, style, pitch, energy, voiced) -> DecoderPrediction, and the reference's state_dict keys (no `generator.`
+    prefix: `amp_input_conv.weight`, `basegen.phase_convnext.3.pwconv1.weight`, ...), bound to the library's model
+    kind "vocoder".  A `MultiGenerator.state_dict()` of the reference loads unchanged."""
+    KIND = "vocoder"
 
     def __init__(self, *, style_dim=64, n_fft=512, win_length=512, hop_length=300, sample_rate=24000, config=None):
-        cfg = dict(style_dim=style_dim, n_fft=n_fft, win_length=win_length, hop_length=hop_length,
-                   sample_rate=sample_rate)
-        if config is not None:
-            cfg.update(gen_input_dim=config.input_dim, io_kernel=config.io_conv_kernel_size,
-                       conformer_layers=config.conformer_layers, conv_layers=config.conv_layers)
         torch.nn.Module.__init__(self)
-        self.cfg = dict(DEFAULT_CFG, **cfg)
-        self._build(speech_predictor_manifest(self.cfg), _stft_buffers())
+        cfg = dict(DEFAULT_CFG)
+        want = dict(style_dim=64, n_fft=512, win_length=512, hop_length=300, sample_rate=24000)
+        got = dict(style_dim=style_dim, n_fft=n_fft, win_length=win_length, hop_length=hop_length, sample_rate=sample_rate)
+        bad = [f"{k} = {got[k]!r} (built for {v!r})" for k, v in want.items() if got[k] != v]
+        if config is not None:
+            for k, v in (("input_dim", 128), ("io_conv_kernel_size", 21), ("conformer_layers", 1)):
+                if getattr(config, k) != v:
+                    bad.append(f"config.{k} = {getattr(config, k)!r} (built for {v!r})")
+            cfg.update(conv_layers=config.conv_layers)
+        if bad:
+            raise L.StyError("MultiGenerator: not supported by the gfx950 kernels: " + "; ".join(bad))
+        self.cfg = cfg
+        self._build(multi_generator_manifest(cfg), _stft_buffers())
 
-    def forward(self, *, mel, style, pitch, energy, voiced, **kw):
+    def forward(self, *, mel, style, pitch, energy=None, voiced, **kw):
+        if torch.is_grad_enabled():
+            prev = getattr(self, "_train_opts", None)
+            self.set_train_opts(bn_batch_stats=bool(self.training),
+                                compute_bf16=bool(prev.compute_bf16) if prev is not None else False)
+            self.enable_training()
+            if getattr(self, "_anchor", None) is None or self._anchor.device != style.device:
+                self._anchor = torch.zeros((), device=style.device, requires_grad=True)
+            audio = _VocoderFn.apply(self._anchor, mel, style, self, dict(pitch=pitch, voiced=voiced, **kw))
+            return DecoderPrediction(audio=audio, magnitude=None, phase=None)
         return self.vocoder_forward(mel=mel, style=style, pitch=pitch, energy=energy, voiced=voiced, **kw)
+
+    def forward_train(self, *a, **k):
+        raise L.StyError("MultiGenerator: use vocoder_forward_train / vocoder_backward (or forward under autograd)")
 
 
 class MelStyleEncoder(_HipModule):
@@ -393,7 +561,16 @@ class MelStyleEncoder(_HipModule):
         self._build(style_encoder_manifest(self.cfg))
 
     def forward(self, x):
-        _no_autograd("MelStyleEncoder.forward")
+        if torch.is_grad_enabled():
+            # training graph behind a torch.autograd.Function; self.training = one spectral-norm power iteration per
+            # forward (mel_style_encoder.py:18-39), as torch.nn.utils.spectral_norm does in train mode
+            prev = getattr(self, "_train_opts", None)
+            self.set_train_opts(sn_power_iter=bool(self.training),
+                                compute_bf16=bool(prev.compute_bf16) if prev is not None else False)
+            self.enable_training()
+            if getattr(self, "_anchor", None) is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros((), device=x.device, requires_grad=True)
+            return _StyleEncoderFn.apply(self._anchor, x, self)
         dev = x.device
         lib = self._ensure(dev)
         B, _, _, T = x.shape
@@ -411,6 +588,7 @@ class MelStyleEncoder(_HipModule):
         """MelStyleEncoder.forward in the training graph; follow with backward(d_style)."""
         dev = x.device
         self._train = True
+        self._tape_id += 1
         lib = self._ensure(dev)
         B, _, _, T = x.shape
         x = _f32(x.detach(), dev)

@@ -39,6 +39,11 @@ class FlatAdamW:
             st = C.c_void_p(torch.cuda.current_stream(gflat.device).cuda_stream)
             L.check(lib.sty_adamw_step(gflat.numel(), L.ptr(p), L.ptr(gflat), L.ptr(m), L.ptr(v), self.lr,
                                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, st))
+        # the kernel wrote the parameters behind torch's back: bump their version counters so that the module shells
+        # see the mutation (modules._HipModule._ensure re-prepares the packed weights before the next inference call)
+        for _, items in self.grads.buckets:
+            for p, _, _ in items:
+                torch.autograd.graph.increment_version(p)
 
 
 LOGICAL_STEP_LIMIT = 10000  # train/optimizers.py:11

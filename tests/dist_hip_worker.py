@@ -1,0 +1,74 @@
+"""Worker of tests/test_boundary_gpu.py::test_two_rank_hip_gradients_equal_one_rank_on_the_concatenated_batch.
+
+Run alone (world 1): the whole B=4 batch.  Run under torchrun with 2 processes: rank r takes utterances 2r, 2r+1; both
+ranks sit on device 0 and exchange the flat gradient buckets over gloo (a 1-GPU box has no second device).  The loss is
+mean |audio| over the rank's utterances (a per-utterance mean, so that the mean over ranks of the per-rank gradients IS
+the gradient of the whole-batch loss); eval-mode graph (BatchNorm running statistics, no dropout / smoothing).  Rank 0
+saves every parameter gradient after the bucketed all-reduce + finish().
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main(out_path):
+    import stylish_tts_amd as S
+    from stylish_tts_amd import dist as D
+    from stylish_tts_amd.manifest import speech_predictor_manifest, style_encoder_manifest
+    from stylish_tts_amd.optim import FlatAdamW
+    from stylish_tts_amd.synthetic_weights import fill_state_dict
+    torch.cuda.set_device(0)
+    rank, world = D.init("gloo")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(17)
+    B, T, Lt = 4, 80, 24
+    texts = torch.randint(1, 178, (B, Lt), generator=g)
+    lengths = torch.full((B,), Lt, dtype=torch.int64)
+    dur = torch.ones(B, Lt)
+    for b in range(B):
+        dur[b] += torch.bincount(torch.multinomial(torch.ones(Lt), T - Lt, replacement=True, generator=g),
+                                 minlength=Lt).float()
+    pitch = torch.rand(B, T, generator=g) * 200 + 80
+    pitch[:, 30:40] = 0
+    energy = torch.randn(B, T, generator=g)
+    style_mel = torch.randn(B, 1, 80, T, generator=g)
+    noise = torch.randn(B, 300 * T, 9, generator=g)
+    sel = list(D.shard(B, rank, world))
+    pick = lambda t: t[sel].contiguous().to(dev)
+    from stylish_tts_amd.acoustic import duration_to_alignment
+    sp = S.SpeechPredictor()
+    sp.load_state_dict(fill_state_dict(speech_predictor_manifest(), 0), strict=False)
+    se = S.MelStyleEncoder()
+    se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+    sp, se = sp.to(dev).enable_training(), se.to(dev).enable_training()
+    opts = [FlatAdamW(list(sp.parameters()), lr=0.0), FlatAdamW(list(se.parameters()), lr=0.0)]
+    for o in opts:
+        o.zero_grad()
+    ali = duration_to_alignment(pick(dur), T)
+    style = se.forward_train(pick(style_mel))
+    p = pick(pitch)
+    audio = sp.forward_train(pick(texts), pick(lengths), ali, p, pick(energy), (p > 20).float(), style, p,
+                             noise=pick(noise))
+    d_audio = torch.sign(audio) / audio.numel()
+    d_style, _ = sp.backward(d_audio, want_energy=False)
+    opts[0].grads.reduce_all()
+    se.backward(d_style)
+    opts[1].grads.reduce_all()
+    for o in opts:
+        o.grads.finish()
+    torch.cuda.synchronize()
+    if rank == 0:
+        grads = {"sp." + k: v.grad.detach().cpu().clone() for k, v in sp.named_parameters()}
+        grads.update({"se." + k: v.grad.detach().cpu().clone() for k, v in se.named_parameters()})
+        torch.save(grads, out_path)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,0 +1,237 @@
+"""GPU-side tests of the drop-in boundary: the shells driven the way the reference drives its modules.
+
+  * MultiGenerator on its own keys (C model kind "vocoder") vs a fixture the reference's MultiGenerator wrote;
+  * SpeechPredictor built from a parsed model.yml with non-default free dimensions vs the reference built from the same;
+  * autograd: `loss.backward()` through SpeechPredictor / MelStyleEncoder shells fills param.grad with what the explicit
+    forward_train / backward pair produces, and a torch optimizer can step on it;
+  * stale prepared weights: in-place parameter updates (load_state_dict, optimizer step) are seen by the next forward;
+  * 2 processes on the HIP path: mean of the two ranks' gradients == the 1-rank gradients on the concatenated batch.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def _mel_l1(a, b):
+    from oracle.frontend import calculate_mel
+    return (calculate_mel(a.squeeze(1), 512, 512, 300) - calculate_mel(b.squeeze(1), 512, 512, 300)).abs().mean().item()
+
+
+def _ref_noise(seed, B, T):
+    g = torch.Generator().manual_seed(seed)
+    _ = torch.rand(B, 9, generator=g)  # SineGen's rand_ini draw comes first in the reference's stream
+    return torch.randn(B, 300 * T, 9, generator=g)
+
+
+def test_multi_generator_vs_reference_golden():
+    import stylish_tts_amd as S
+    from stylish_tts_amd.manifest import multi_generator_manifest
+    from stylish_tts_amd.synthetic_weights import fill_state_dict
+    fx = load_file(os.path.join(G, "mg_small.safetensors"))
+    mg = S.MultiGenerator(style_dim=64, n_fft=512, win_length=512, hop_length=300, sample_rate=24000)
+    missing, unexpected = mg.load_state_dict(fill_state_dict(multi_generator_manifest(), 5), strict=False)
+    assert not unexpected and all(".stft." in k for k in missing)
+    mg = mg.to(DEV).eval()
+    B, T = fx["pitch"].shape
+    with torch.no_grad():
+        out = mg(mel=dev(fx["mel"]), style=dev(fx["style"]), pitch=dev(fx["pitch"]), energy=dev(fx["energy"]),
+                 voiced=dev(fx["voiced"]), noise=dev(_ref_noise(77, B, T)))
+    torch.cuda.synchronize()
+    err = (out.audio.cpu() - fx["audio"]).abs()
+    mse = (err ** 2).mean().item()
+    print(f"\n  MultiGenerator vs reference: max|err| {err.max().item():.3e} mse {mse:.3e} "
+          f"mel-L1 {_mel_l1(out.audio.cpu(), fx['audio']):.3e}")
+    assert mse <= 1e-6 and _mel_l1(out.audio.cpu(), fx["audio"]) <= 1e-3  # built-in source: test_vocoder_end_to_end's gate
+    assert out.magnitude is None and out.phase is None
+
+
+def test_speech_predictor_from_non_default_model_yml_vs_reference_golden():
+    import stylish_tts_amd as S
+    from stylish_tts_amd.config import load_model_config_yaml
+    from stylish_tts_amd.manifest import speech_predictor_manifest
+    from stylish_tts_amd.synthetic_weights import fill_state_dict
+    from oracle import frontend
+    from tests.cases import make_case
+    from tests.test_boundary import _default_model_yaml
+    fxm = json.load(open(os.path.join(G, "manifest_speech_predictor_alt.json")))
+    fx = load_file(os.path.join(G, "sp_alt_small.safetensors"))
+    mc = load_model_config_yaml(_default_model_yaml(**fxm["overrides"]))
+    sp = S.SpeechPredictor(mc)
+    cfg_alt = dict(tokens=120, te_layers=4, te_filter=256, conv_layers=6)
+    missing, unexpected = sp.load_state_dict(fill_state_dict(speech_predictor_manifest(cfg_alt), 6), strict=False)
+    assert not unexpected and all(".stft." in k for k in missing)
+    sp = sp.to(DEV).eval()
+    cs = make_case("sp_small")
+    ali = frontend.duration_to_alignment(cs["durations"])
+    voiced = (cs["pitch"] > 20).float()
+    with torch.no_grad():
+        out = sp(dev(fx["texts"]), dev(cs["text_lengths"]), dev(ali), dev(cs["pitch"]), dev(cs["energy"]), dev(voiced),
+                 dev(cs["style"]), dev(cs["pitch"]), noise=dev(cs["noise"])).audio
+    torch.cuda.synchronize()
+    err = (out.cpu() - fx["audio"]).abs()
+    mse = (err ** 2).mean().item()
+    print(f"\n  non-default model.yml vs reference: max|err| {err.max().item():.3e} mse {mse:.3e}")
+    assert mse <= 1e-6 and _mel_l1(out.cpu(), fx["audio"]) <= 1e-3
+
+
+def _models(seed=0):
+    import stylish_tts_amd as S
+    from stylish_tts_amd.manifest import speech_predictor_manifest, style_encoder_manifest
+    from stylish_tts_amd.synthetic_weights import fill_state_dict
+    sp = S.SpeechPredictor()
+    sp.load_state_dict(fill_state_dict(speech_predictor_manifest(), seed), strict=False)
+    se = S.MelStyleEncoder()
+    se.load_state_dict(fill_state_dict(style_encoder_manifest(), seed))
+    return sp.to(DEV), se.to(DEV)
+
+
+def _case():
+    from oracle import frontend
+    from tests.cases import make_case
+    cs = make_case("sp_small")
+    cs["alignment"] = frontend.duration_to_alignment(cs["durations"])
+    cs["voiced"] = (cs["pitch"] > 20).float()
+    cs["style_mel"] = torch.randn(2, 1, 80, 80, generator=torch.Generator().manual_seed(5))
+    return {k: (dev(v) if torch.is_tensor(v) else v) for k, v in cs.items()}
+
+
+def test_autograd_shim_matches_explicit_backward_and_drives_a_torch_optimizer():
+    """The reference's train_acoustic shape: style = style_encoder(mel); pred = speech_predictor(...); loss(pred.audio)
+    .backward(); optimizer.step() -- with the shells in eval() so that both paths run the same deterministic graph."""
+    cs = _case()
+    # (a) explicit pair
+    sp, se = _models()
+    sp.eval(), se.eval()
+    sp.enable_training(), se.enable_training()
+    style = se.forward_train(cs["style_mel"])
+    audio = sp.forward_train(cs["texts"], cs["text_lengths"], cs["alignment"], cs["pitch"], cs["energy"], cs["voiced"],
+                             style, cs["pitch"], noise=cs["noise"])
+    d_audio = torch.sign(audio) / audio.numel()
+    d_style, _ = sp.backward(d_audio, want_energy=False)
+    se.backward(d_style)
+    torch.cuda.synchronize()
+    ref = {("sp", k): p.grad.clone() for k, p in sp.named_parameters()}
+    ref.update({("se", k): p.grad.clone() for k, p in se.named_parameters()})
+    # (b) autograd
+    sp2, se2 = _models()
+    sp2.eval(), se2.eval()
+    opt = torch.optim.AdamW(list(sp2.parameters()) + list(se2.parameters()), lr=1e-4)
+    opt.zero_grad()  # set_to_none=True: the shells re-attach their persistent gradient buffers
+    style2 = se2(cs["style_mel"])
+    assert style2.requires_grad
+    pred = sp2(cs["texts"], cs["text_lengths"], cs["alignment"], cs["pitch"], cs["energy"], cs["voiced"], style2,
+               cs["pitch"], noise=cs["noise"])
+    assert pred.audio.requires_grad and torch.equal(pred.audio.detach(), audio)
+    loss = pred.audio.abs().mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for tag, mod in (("sp", sp2), ("se", se2)):
+        for k, p in mod.named_parameters():
+            assert p.grad is not None, k
+            r = ref[(tag, k)]
+            e = (p.grad - r).abs().max().item() / max(r.abs().max().item(), 1e-20)
+            worst = max(worst, e)
+    print(f"\n  autograd vs explicit backward: worst relative gradient difference {worst:.3e}")
+    assert worst <= 1e-5
+    before = sp2.state_dict()["text_encoder.proj_m.weight"].clone()
+    opt.step()
+    assert not torch.equal(before, sp2.state_dict()["text_encoder.proj_m.weight"])
+    # a second step through autograd works (persistent grad buffers, re-prepared weights) and the loss moves
+    opt.zero_grad()
+    pred2 = sp2(cs["texts"], cs["text_lengths"], cs["alignment"], cs["pitch"], cs["energy"], cs["voiced"],
+                se2(cs["style_mel"]), cs["pitch"], noise=cs["noise"])
+    loss2 = pred2.audio.abs().mean()
+    loss2.backward()
+    torch.cuda.synchronize()
+    assert loss2.item() != loss.item()
+    # a backward of a replaced forward is refused, not silently wrong
+    from stylish_tts_amd.lib import StyError
+    p3 = sp2(cs["texts"], cs["text_lengths"], cs["alignment"], cs["pitch"], cs["energy"], cs["voiced"],
+             se2(cs["style_mel"]), cs["pitch"], noise=cs["noise"])
+    _ = sp2(cs["texts"], cs["text_lengths"], cs["alignment"], cs["pitch"], cs["energy"], cs["voiced"],
+            se2(cs["style_mel"]).detach(), cs["pitch"], noise=cs["noise"])
+    with pytest.raises((StyError, RuntimeError), match="replaced"):
+        p3.audio.sum().backward()
+
+
+def test_in_place_weight_updates_are_seen_by_the_next_forward():
+    """forward() must not run on stale packed weights after load_state_dict / an optimizer step."""
+    from stylish_tts_amd.manifest import speech_predictor_manifest
+    from stylish_tts_amd.synthetic_weights import fill_state_dict
+    cs = _case()
+    args = (cs["texts"], cs["text_lengths"], cs["alignment"], cs["pitch"], cs["energy"], cs["voiced"], cs["style"],
+            cs["pitch"])
+    sp, _ = _models(0)
+    fresh, _ = _models(3)
+    with torch.no_grad():
+        a0 = sp(*args, noise=cs["noise"]).audio.clone()
+        want = fresh(*args, noise=cs["noise"]).audio
+        sp.load_state_dict(fill_state_dict(speech_predictor_manifest(), 3), strict=False)  # same storage, new values
+        a1 = sp(*args, noise=cs["noise"]).audio
+    torch.cuda.synchronize()
+    assert not torch.equal(a0, a1), "forward ran on the old packed weights"
+    assert torch.equal(a1, want)
+    # after a training step + FlatAdamW step (the library writes the parameters itself) inference sees the new values
+    from stylish_tts_amd.optim import FlatAdamW
+    sp.enable_training()
+    opt = FlatAdamW(list(sp.parameters()), lr=1e-2)
+    audio = sp.forward_train(*args, noise=cs["noise"])
+    sp.backward(torch.sign(audio) / audio.numel(), want_energy=False)
+    opt.step()
+    with torch.no_grad():
+        a2 = sp(*args, noise=cs["noise"]).audio
+        a3 = sp(*args, noise=cs["noise"]).audio
+    torch.cuda.synchronize()
+    assert not torch.equal(a1, a2) and torch.equal(a2, a3)
+
+
+def test_shape_errors_are_raised_before_the_library_is_called():
+    from stylish_tts_amd.lib import StyError
+    from stylish_tts_amd.losses import acoustic_loss
+    cs = _case()
+    sp, _ = _models()
+    with torch.no_grad(), pytest.raises(StyError, match="alignment"):
+        sp(cs["texts"], cs["text_lengths"], cs["alignment"][:, :, :-1], cs["pitch"], cs["energy"], cs["voiced"],
+           cs["style"], cs["pitch"])
+    with pytest.raises(StyError, match="audio_gt"):
+        acoustic_loss(torch.zeros(2, 23999, device=DEV), torch.zeros(2, 24000, device=DEV))
+
+
+def test_two_rank_hip_gradients_equal_one_rank_on_the_concatenated_batch(tmp_path):
+    """SURVEY.md 8(e) correctness test on the HIP path: two processes (sharing device 0, gloo transport) each run the
+    eval-graph training step on half of a B=4 batch with lr = 0; the all-reduced mean gradient must equal what one
+    process computes on the whole batch (losses are means over the batch, BatchNorm in eval mode)."""
+    out = str(tmp_path / "grads")
+    worker = os.path.join(ROOT, "tests", "dist_hip_worker.py")
+    env = dict(os.environ, STY_NO_SIDE_STREAM="1", STY_NO_SE_STREAM="1")
+    r1 = subprocess.run([sys.executable, worker, out + "_1.pt"], capture_output=True, text=True, env=env, timeout=600,
+                        cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29519", worker, out + "_2.pt"],
+                        capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    g1, g2 = torch.load(out + "_1.pt"), torch.load(out + "_2.pt")
+    assert g1.keys() == g2.keys()
+    num = sum(((g1[k] - g2[k]).double() ** 2).sum().item() for k in g1)
+    den = sum((g1[k].double() ** 2).sum().item() for k in g1)
+    rel = (num / den) ** 0.5
+    print(f"\n  2-rank mean gradient vs 1-rank gradient on the concatenated batch: relative L2 {rel:.3e} "
+          f"over {len(g1)} tensors")
+    assert rel <= 2e-3
