@@ -425,6 +425,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     set_error("conv1d: LN epilogue needs Cout == 32");
     return STY_EINVAL;
   }
+  if (conv32p_eligible(a)) return launch_conv32p(a, st);
   // tuning aid: STY_CONV_CFG=0..5 forces one tile configuration (when the shape allows it)
   static const int forced = getenv("STY_CONV_CFG") ? atoi(getenv("STY_CONV_CFG")) : -1;
   if (forced >= 0 && a.act != ACT_GLU) {

@@ -1,0 +1,358 @@
+// Persistent, wave-specialised dense conv for the 32 -> 32 channel layers at the 75T frame rate
+// (AdaptiveGeneratorBlock convs k = 11, dilation 1 / 3 / 5, ada_norm.py:109-120; the prior / output convs of
+// generator.py:731-780; their input-gradient convs in training).
+//
+// Why a second kernel: a 32-channel conv has ONE reduction chunk, so in conv1d_mfma_kernel every workgroup runs
+// load -> prologue -> LDS -> barrier -> MFMA -> epilogue strictly in sequence and nothing inside the workgroup overlaps
+// (a fixed cost of ~9 tap times per tile, 55 % of the fp32 matrix peak at k = 11, and in the bf16
+// mode the MFMA phase is 1/16 as long, so the fixed cost is nearly everything).  Here a workgroup is persistent over a
+// contiguous range of time tiles and its eight waves have two roles:
+//   waves 4-7 (one per SIMD)  PRODUCERS: buffer-load the next tile (32 channels x (512 + halo) columns, all 72-80
+//                             loads of a wave in flight at once), apply the fused prologue (AdaIN + Snake, ...) on the
+//                             VALU and write it into the OTHER LDS buffer;
+//   waves 0-3 (one per SIMD)  CONSUMERS: read B fragments of the current tile from LDS and issue MFMAs back to back
+//                             (32 couts x 128 columns each), then bias / activation / residual / store.
+// The matrix pipe and the VALU / memory pipes of a SIMD are separate, so the producer's work hides completely behind
+// the consumer's MFMAs (fp32 mode, MFMA-bound), and in the bf16 mode (HBM-bound: 16x fewer matrix cycles) the CU always
+// has the next tile's loads, the current tile's residual loads and the previous tile's stores in flight together.
+// One barrier per tile.  Workgroup w owns tiles [first_w, first_w + count_w): its halo re-reads hit its own XCD's L2.
+//
+//   fp32 mode: LDS tile [32 ch][LW] fp32, B operand = ds_read_b32 (lanes along time), v_mfma_f32_32x32x2_f32, packed
+//              weights streamed from L2 one tap ahead (the same A path as conv1d_mfma_kernel).
+//   bf16 mode: LDS tile [LW][32 ch] bf16 with an 80-byte row pitch (conflict-free ds_read_b128 / ds_write_b128), the
+//              producer writes eight channels of a column with one ds_write_b128; weights are converted once per
+//              workgroup into bf16 A fragments in LDS (2 KB per tap); v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+#include <stdlib.h>
+
+#include "sty_common.h"
+
+namespace sty {
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+}  // namespace sty
+#include "conv_stage.h"
+
+namespace sty {
+
+constexpr int P_TT = 512;    // columns per tile
+constexpr int P_NT = 4;      // 32-column fragments per consumer wave
+constexpr int P_MAXQ = 10;   // 64-column groups of a staged row (512 + halo <= 640)
+constexpr int P_PITCH = 40;  // bf16 mode: halfs per column in LDS (32 channels + 8 pad = 80 bytes)
+
+// ---- producer: stage tile (b, t0) into `dst` ----
+// One buffer descriptor per tile for the whole batch slab [32 ch][T]; the row enters as a VALU byte offset (this is the
+// producer: its VALU is idle next to the consumer's MFMAs).  Columns outside [0, T) are zeroed AFTER the prologue by the
+// explicit `tin` predicate, so whatever a load outside the row returns (the neighbouring row, or 0 outside the slab) is
+// never used.
+template <int PRO>
+__device__ __forceinline__ void p_row_params(const ConvArgs& a, int b, int ci, bool live, float& pa, float& ps, float& al,
+                                             float& ral) {
+  pa = 1.f, ps = 0.f, al = 1.f, ral = 1.f;
+  if (live) {
+    if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+      pa = a.pa[(size_t)b * a.w.Cin + ci];
+      if constexpr (PRO != PRO_SCALE) ps = a.ps[(size_t)b * a.w.Cin + ci];
+    }
+    if constexpr (PRO == PRO_AFFINE_SNAKE) {
+      al = a.palpha[ci];
+      ral = 1.0f / al;
+    }
+  }
+}
+
+template <bool BF, int PRO>
+__device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, int tile, int tiles_per_row, int LW, int pw, int lane) {
+  const int T = a.T, Cin = a.w.Cin;
+  const int b = tile / tiles_per_row;
+  const int t0 = (tile - b * tiles_per_row) * P_TT;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x[0] + (size_t)b * Cin * T), 0, Cin * T * 4, 0x00020000);
+  const int voff = (t0 - a.pad + lane) * 4;
+  if constexpr (!BF) {
+    // fp32 tile [ch][LW]: row by row, the next row's loads in flight while this one is written (MFMA-bound mode: the
+    // consumer needs ~45k cycles per tile, staging needs a fraction of that however it is ordered)
+    float vv[2][P_MAXQ];
+#define STY_P_LOADROW(slot, r)                                                                  \
+  _Pragma("unroll") for (int q = 0; q < P_MAXQ; ++q) if (q < P_TT / 64 || 64 * q < LW) vv[slot][q] = \
+      buf_load(rs, voff + 256 * q + (8 * pw + (r)) * T * 4);
+    STY_P_LOADROW(0, 0)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (r + 1 < 8) { STY_P_LOADROW((r + 1) & 1, r + 1) }
+      const int ci = 8 * pw + r;
+      const bool live = ci < Cin;
+      float pa, ps, al, ral;
+      p_row_params<PRO>(a, b, ci, live, pa, ps, al, ral);
+      float* row = dst + ci * LW;
+#pragma unroll
+      for (int q = 0; q < P_MAXQ; ++q) {
+        if (!(q < P_TT / 64 || 64 * q < LW)) continue;
+        const int j = lane + 64 * q;
+        const int t = t0 - a.pad + j;
+        const bool tin = t >= 0 && t < T;
+        float mk = 1.f;
+        if constexpr (PRO == PRO_MASK) mk = tin ? a.mask[(size_t)b * T + t] : 0.f;
+        const float v = (live && tin) ? pro_apply<PRO>(vv[r & 1][q], pa, ps, al, ral, mk) : 0.f;
+        if (j < LW) row[j] = v;
+      }
+    }
+#undef STY_P_LOADROW
+  } else {
+    // bf16 tile [LW][32 ch]: a lane gathers the eight channels of its wave for one column and writes them with one
+    // ds_write_b128; five column groups (40 loads per lane, ~41 KB per CU with the four producers) in flight at a time
+    float pa[8], ps[8], al[8], ral[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) p_row_params<PRO>(a, b, 8 * pw + r, 8 * pw + r < Cin, pa[r], ps[r], al[r], ral[r]);
+#pragma unroll
+    for (int qh = 0; qh < P_MAXQ; qh += P_MAXQ / 2) {
+      float vv[P_MAXQ / 2][8];
+#pragma unroll
+      for (int q = 0; q < P_MAXQ / 2; ++q)
+        if (qh + q < P_TT / 64 || 64 * (qh + q) < LW)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vv[q][r] = buf_load(rs, voff + 256 * (qh + q) + (8 * pw + r) * T * 4);
+#pragma unroll
+      for (int q = 0; q < P_MAXQ / 2; ++q) {
+        if (!(qh + q < P_TT / 64 || 64 * (qh + q) < LW)) continue;
+        const int j = lane + 64 * (qh + q);
+        const int t = t0 - a.pad + j;
+        const bool tin = t >= 0 && t < T;
+        float mk = 1.f;
+        if constexpr (PRO == PRO_MASK) mk = tin ? a.mask[(size_t)b * T + t] : 0.f;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          v[r] = (8 * pw + r < Cin && tin) ? pro_apply<PRO>(vv[q][r], pa[r], ps[r], al[r], ral[r], mk) : 0.f;
+        if (j < LW)
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + 8 * pw) =
+              sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+    }
+  }
+}
+
+template <int ACT>
+__device__ __forceinline__ float p_act(float x, float alpha) {
+  if constexpr (ACT == ACT_RELU) return fmaxf(x, 0.f);
+  if constexpr (ACT == ACT_SWISH) return x * sigmoidf_(x);
+  if constexpr (ACT == ACT_SNAKE) return sty_snake(x, alpha, 1.0f / alpha);
+  if constexpr (ACT == ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  return x;
+}
+
+template <bool BF, int PRO>
+__global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_per_row, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < 4;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int T = a.T, K = a.w.K, CoutP = a.w.CoutP, CinP = a.w.CinP, Cout = a.w.Cout;
+  const int halo = (K - 1) * a.dil;
+  const int LW = P_TT + halo;
+  const int bufsz = BF ? (LW * P_PITCH) / 2 : CI_CHUNK * LW;  // floats per tile buffer
+  float* wl = lds + 2 * bufsz;                                // bf16 mode: A fragments [K][2][64 lanes] x 16 B
+
+  // contiguous tile range of this workgroup
+  const int per = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
+  const int first = (int)blockIdx.x * per + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+  const int count = per + ((int)blockIdx.x < rem ? 1 : 0);
+  if (count == 0) return;
+
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w.wp), 0, K * CinP * CoutP * 4, 0x00020000);
+  if constexpr (BF) {
+    // packed fp32 weights Wp[k][ci][co] -> bf16 A fragments: lane (co = l31, k-block = hi) of k-step s holds the
+    // eight input channels 16 s + 8 hi .. + 7
+    for (int it = tid; it < K * 2 * 64; it += 512) {
+      const int ln = it & 63, s = (it >> 6) & 1, k = it >> 7;
+      const int co = ln & 31, ci0 = 16 * s + 8 * (ln >> 5);
+      float w8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w8[e] = a.w.wp[((size_t)k * CinP + ci0 + e) * CoutP + co];
+      reinterpret_cast<bf16x8*>(wl)[it] = sty_pack_bf16(w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7]);
+    }
+  }
+  if (!consumer) p_stage<BF, PRO>(a, lds, first, tiles_per_row, LW, wave - 4, lane);
+
+  // consumer state that does not change between tiles
+  const int tw = wave * (32 * P_NT);  // consumers only
+  const int wv = (hi * CoutP + l31) * 4;
+  float a_nxt[CI_CHUNK / 2];
+  if constexpr (!BF) {
+    if (consumer) {
+#pragma unroll
+      for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+        a_nxt[c2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv, 2 * c2 * CoutP * 4, 0));
+    }
+  }
+  __syncthreads();
+
+  for (int i = 0; i < count; ++i) {
+    const int tile = first + i;
+    float* cur = lds + (i & 1) * bufsz;
+    if (!consumer) {
+      if (i + 1 < count) p_stage<BF, PRO>(a, lds + ((i + 1) & 1) * bufsz, tile + 1, tiles_per_row, LW, wave - 4, lane);
+    } else {
+      f32x16 acc[P_NT];
+#pragma unroll
+      for (int n = 0; n < P_NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+      if constexpr (BF) {
+        const __bf16* xh = reinterpret_cast<const __bf16*>(cur);
+        const bf16x8* wf = reinterpret_cast<const bf16x8*>(wl);
+        for (int k = 0; k < K; ++k) {
+          const __bf16* col = xh + (size_t)(tw + l31 + k * a.dil) * P_PITCH + 8 * hi;
+          bf16x8 av[2], bv[2][P_NT];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            av[s] = wf[(k * 2 + s) * 64 + lane];
+#pragma unroll
+            for (int n = 0; n < P_NT; ++n)
+              bv[s][n] = *reinterpret_cast<const bf16x8*>(col + (size_t)n * 32 * P_PITCH + 16 * s);
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int n = 0; n < P_NT; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], bv[s][n], acc[n], 0, 0, 0);
+        }
+      } else {
+        for (int k = 0; k < K; ++k) {
+          float a_cur[CI_CHUNK / 2];
+#pragma unroll
+          for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) a_cur[c2] = a_nxt[c2];
+          {  // next tap (tap 0 again after the last one: the next tile starts with it)
+            const int kn = k + 1 < K ? k + 1 : 0;
+            const int srow = kn * CinP * CoutP * 4;
+#pragma unroll
+            for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+              a_nxt[c2] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv, srow + 2 * c2 * CoutP * 4, 0));
+          }
+          const float* xrow = cur + hi * LW + tw + l31 + k * a.dil;
+          // B fragments in two halves of eight channel pairs: 32 registers instead of 64
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            float bv[8][P_NT];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+              for (int n = 0; n < P_NT; ++n) bv[c][n] = xrow[2 * (8 * h8 + c) * LW + n * 32];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+              for (int n = 0; n < P_NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[8 * h8 + c], bv[c][n], acc[n], 0, 0, 0);
+          }
+        }
+      }
+      // ---- epilogue: bias, activation, scale, masks, residual, store ----
+      const int b = tile / tiles_per_row;
+      const int t0 = (tile - b * tiles_per_row) * P_TT;
+#define STY_P_ACT(ACT)                                                                   \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;                                      \
+    const float bi = a.w.bias ? a.w.bias[co] : 0.f;                                      \
+    float al = 1.f;                                                                      \
+    if constexpr (ACT == ACT_SNAKE) al = a.act_alpha[co < Cout ? co : 0];                \
+    _Pragma("unroll") for (int n = 0; n < P_NT; ++n) acc[n][r] = p_act<ACT>(acc[n][r] + bi, al) * a.out_scale; \
+  }
+      switch (a.act) {
+        case ACT_RELU: { STY_P_ACT(ACT_RELU) } break;
+        case ACT_SWISH: { STY_P_ACT(ACT_SWISH) } break;
+        case ACT_SNAKE: { STY_P_ACT(ACT_SNAKE) } break;
+        case ACT_GELU: { STY_P_ACT(ACT_GELU) } break;
+        default: { STY_P_ACT(ACT_NONE) } break;
+      }
+#undef STY_P_ACT
+#pragma unroll
+      for (int n = 0; n < P_NT; ++n) {
+        const int t = t0 + tw + n * 32 + l31;
+        if (t < T) {
+          const float om_pre = (a.out_mask && !a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
+          const float om_post = (a.out_mask && a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
+          float res[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            res[r] = (a.residual && co < Cout) ? a.residual[((size_t)b * Cout + co) * T + t] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout) a.y[((size_t)b * Cout + co) * T + t] = (acc[n][r] * om_pre + res[r]) * om_post;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+template <bool BF, int PRO>
+static int launch_p(const ConvArgs& a, hipStream_t st) {
+  const int halo = (a.w.K - 1) * a.dil;
+  const int LW = P_TT + halo;
+  const size_t lds = BF ? (size_t)2 * LW * P_PITCH * 2 + (size_t)a.w.K * 2 * 64 * 16 : (size_t)2 * CI_CHUNK * LW * 4;
+  static bool raised = false;
+  if (!raised) {
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32p_kernel<BF, PRO>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised = true;
+  }
+  const int tiles_per_row = cdiv(a.T, P_TT);
+  const int ntiles = tiles_per_row * a.B;
+  const int grid = ntiles < num_cus() ? ntiles : num_cus();
+  const double outs = (double)a.B * a.w.Cout * a.T;
+  const double flops = 2.0 * a.w.Cin * a.w.K * outs;
+  const double bytes = 4.0 * ((double)a.B * a.w.Cin * a.T + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
+  char detail[40];
+  snprintf(detail, sizeof(detail), "ci%d co%d k%d d%d T%d", a.w.Cin, a.w.Cout, a.w.K, a.dil, a.T);
+  ProfScope prof(BF ? "conv32p_kernel<true>" : "conv32p_kernel<false>", flops, bytes, st, detail);
+  hipLaunchKernelGGL((conv32p_kernel<BF, PRO>), dim3(grid), dim3(512), lds, st, a, tiles_per_row, ntiles);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// Whether the persistent kernel takes this conv (launch_conv1d asks before its own tile choice).
+bool conv32p_eligible(const ConvArgs& a) {
+  static const bool off = getenv("STY_NO_CONV32P") != nullptr;
+  if (off) return false;
+  if (a.w.CinP != CI_CHUNK || a.w.CoutP != 32 || a.flatW || a.nsrc != 1 || a.in_shuffle > 1 || a.shuffle != 1 ||
+      a.ln_out || a.Tin || a.act == ACT_GLU)
+    return false;
+  if (!(a.pro == PRO_NONE || a.pro == PRO_AFFINE_SNAKE || a.pro == PRO_MASK || a.pro == PRO_AFFINE_LRELU)) return false;
+  const int halo = (a.w.K - 1) * a.dil;
+  if (halo > 64 * P_MAXQ - P_TT) return false;
+  const int LW = P_TT + halo;
+  const size_t lds = a.bf16 ? (size_t)2 * LW * P_PITCH * 2 + (size_t)a.w.K * 2 * 64 * 16 : (size_t)2 * CI_CHUNK * LW * 4;
+  if (lds > 160 * 1024) return false;
+  // worth it from ~2 tiles per CU on (below that the persistent loop has nothing to overlap)
+  static const int min_tiles = getenv("STY_CONV32P_MIN_TILES") ? atoi(getenv("STY_CONV32P_MIN_TILES")) : 512;
+  return (long)cdiv(a.T, P_TT) * a.B >= min_tiles;
+}
+
+int launch_conv32p(const ConvArgs& a, hipStream_t st) {
+#define STY_P_GO(PRO) return a.bf16 ? launch_p<true, PRO>(a, st) : launch_p<false, PRO>(a, st)
+  switch (a.pro) {
+    case PRO_AFFINE_SNAKE: STY_P_GO(PRO_AFFINE_SNAKE);
+    case PRO_AFFINE_LRELU: STY_P_GO(PRO_AFFINE_LRELU);
+    case PRO_MASK: STY_P_GO(PRO_MASK);
+    default: STY_P_GO(PRO_NONE);
+  }
+#undef STY_P_GO
+}
+
+}  // namespace sty

@@ -120,6 +120,9 @@ struct ConvArgs {
 };
 
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
+// conv32p.hip: persistent, wave-specialised kernel for the 32 -> 32 channel convs at the 75T rate
+bool conv32p_eligible(const ConvArgs& a);
+int launch_conv32p(const ConvArgs& a, hipStream_t st);
 
 // one entry of a batched weight-side launch (wgrad.hip: pack / input-gradient pack / gradient un-pack)
 struct MultiJob {

@@ -108,7 +108,9 @@ def test_c2_train_step_full_size_vs_oracle():
     sp, se, P, Pse = _models()
     tr = AcousticTrainer(sp, se, lr=0.0, train_mode=False)
     sp_keys = ["generator.basegen.amp_output_conv.weight", "generator.basegen.phase_output_real_conv.bias",
-               "generator.basegen.phase_convnext.3.pwconv1.weight", "generator.basegen.amp_prior_block.convs1.1.bias",
+               "generator.basegen.phase_convnext.3.pwconv1.weight", "generator.basegen.amp_prior_block.convs2.1.bias",
+               "generator.basegen.amp_prior_block.convs1.1.parametrizations.weight.original1",
+               # (not convs1.*.bias: a conv bias in front of AdaIN's instance norm has an exactly zero gradient)
                "decoder.decode.0.norm1.fc.weight", "text_encoder.proj_m.weight", "text_encoder.emb.weight"]
     sp_keys = [k for k in sp_keys if k in P and P[k].is_floating_point()]
     assert len(sp_keys) >= 5
