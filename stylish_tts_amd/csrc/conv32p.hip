@@ -26,9 +26,6 @@
 
 #include "sty_common.h"
 
-namespace sty {
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
-}  // namespace sty
 #include "conv_stage.h"
 
 namespace sty {
@@ -128,15 +125,6 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, int tile,
       }
     }
   }
-}
-
-template <int ACT>
-__device__ __forceinline__ float p_act(float x, float alpha) {
-  if constexpr (ACT == ACT_RELU) return fmaxf(x, 0.f);
-  if constexpr (ACT == ACT_SWISH) return x * sigmoidf_(x);
-  if constexpr (ACT == ACT_SNAKE) return sty_snake(x, alpha, 1.0f / alpha);
-  if constexpr (ACT == ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-  return x;
 }
 
 template <bool BF, int PRO>
@@ -251,22 +239,15 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
       // ---- epilogue: bias, activation, scale, masks, residual, store ----
       const int b = tile / tiles_per_row;
       const int t0 = (tile - b * tiles_per_row) * P_TT;
-#define STY_P_ACT(ACT)                                                                   \
-  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
-    const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;                                      \
-    const float bi = a.w.bias ? a.w.bias[co] : 0.f;                                      \
-    float al = 1.f;                                                                      \
-    if constexpr (ACT == ACT_SNAKE) al = a.act_alpha[co < Cout ? co : 0];                \
-    _Pragma("unroll") for (int n = 0; n < P_NT; ++n) acc[n][r] = p_act<ACT>(acc[n][r] + bi, al) * a.out_scale; \
-  }
-      switch (a.act) {
-        case ACT_RELU: { STY_P_ACT(ACT_RELU) } break;
-        case ACT_SWISH: { STY_P_ACT(ACT_SWISH) } break;
-        case ACT_SNAKE: { STY_P_ACT(ACT_SNAKE) } break;
-        case ACT_GELU: { STY_P_ACT(ACT_GELU) } break;
-        default: { STY_P_ACT(ACT_NONE) } break;
+      // (no epilogue activation: every 32 -> 32 conv of the path is linear at its output; an activation switch with
+      // the erf / exp bodies inlined costs ~100 spilled registers here, so such convs stay on conv1d_mfma_kernel)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float bi = a.w.bias ? a.w.bias[co] : 0.f;
+#pragma unroll
+        for (int n = 0; n < P_NT; ++n) acc[n][r] = (acc[n][r] + bi) * a.out_scale;
       }
-#undef STY_P_ACT
 #pragma unroll
       for (int n = 0; n < P_NT; ++n) {
         const int t = t0 + tw + n * 32 + l31;
@@ -331,7 +312,7 @@ bool conv32p_eligible(const ConvArgs& a) {
   static const bool off = getenv("STY_NO_CONV32P") != nullptr;
   if (off) return false;
   if (a.w.CinP != CI_CHUNK || a.w.CoutP != 32 || a.flatW || a.nsrc != 1 || a.in_shuffle > 1 || a.shuffle != 1 ||
-      a.ln_out || a.Tin || a.act == ACT_GLU)
+      a.ln_out || a.Tin || a.act != ACT_NONE)
     return false;
   if (!(a.pro == PRO_NONE || a.pro == PRO_AFFINE_SNAKE || a.pro == PRO_MASK || a.pro == PRO_AFFINE_LRELU)) return false;
   const int halo = (a.w.K - 1) * a.dil;
@@ -340,7 +321,8 @@ bool conv32p_eligible(const ConvArgs& a) {
   const size_t lds = a.bf16 ? (size_t)2 * LW * P_PITCH * 2 + (size_t)a.w.K * 2 * 64 * 16 : (size_t)2 * CI_CHUNK * LW * 4;
   if (lds > 160 * 1024) return false;
   // worth it from ~2 tiles per CU on (below that the persistent loop has nothing to overlap)
-  static const int min_tiles = getenv("STY_CONV32P_MIN_TILES") ? atoi(getenv("STY_CONV32P_MIN_TILES")) : 512;
+  const char* mt = getenv("STY_CONV32P_MIN_TILES");  // read per call: the parity tests lower it for small shapes
+  const int min_tiles = mt ? atoi(mt) : 512;
   return (long)cdiv(a.T, P_TT) * a.B >= min_tiles;
 }
 

@@ -87,9 +87,25 @@ struct Trainer {
     const bool on = side_on && !single_stream_mode();
     side_partial = on && side_need ? take<float>(side_need) : nullptr;
     if (on && !st2 && live()) {
-      int least = 0, greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      hipError_t r = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, least);
+      // STY_SIDE_CU_SKIP=n: the weight-gradient stream is created with a CU mask that leaves every n-th CU to the
+      // main stream.  Workgroups are not preempted: without the mask a 1024-workgroup weight-gradient kernel fills
+      // every CU and each small kernel of the main chain waits for one of those workgroups to retire.
+      const char* sk = getenv("STY_SIDE_CU_SKIP");
+      const int skip = sk ? atoi(sk) : 0;
+      hipError_t r;
+      if (skip >= 2) {
+        uint32_t mask[8];
+        for (int w = 0; w < 8; ++w) {
+          mask[w] = 0;
+          for (int bit = 0; bit < 32; ++bit)
+            if ((w * 32 + bit) % skip != skip - 1) mask[w] |= 1u << bit;
+        }
+        r = hipExtStreamCreateWithCUMask(&st2, 8, mask);
+      } else {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        r = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, least);
+      }
       if (r != hipSuccess) rc = hip_fail(r, "side stream");
     }
   }

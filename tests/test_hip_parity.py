@@ -819,6 +819,29 @@ def test_dense_conv1d_vs_torch(shape, compute):
         assert (y.cpu() - exact).abs().max().item() > 1e-4
 
 
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 11, 5, 700), (3, 32, 32, 21, 1, 1333), (2, 22, 32, 7, 1, 513),
+                                   (1, 32, 30, 11, 3, 100), (5, 32, 32, 11, 3, 2049), (300, 32, 32, 11, 1, 1100)])
+def test_persistent_conv32_vs_torch(shape, compute, monkeypatch):
+    """conv32p_kernel (persistent, producer / consumer waves; the 32 -> 32 channel convs at the 75T rate) through the
+    same unit entry points: forward and input gradient vs float64 on the same (bf16-rounded) operands.  Small shapes
+    are forced onto it with STY_CONV32P_MIN_TILES=1; the last shape takes it by itself (900 tiles, 3-4 per workgroup)."""
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    if shape[0] < 300:
+        monkeypatch.setenv("STY_CONV32P_MIN_TILES", "1")
+    L.prof_report(256)
+    lib.sty_prof_enable(1)
+    try:
+        test_dense_conv1d_vs_torch(shape, compute)
+    finally:
+        lib.sty_prof_enable(0)
+    rows = L.prof_report(256)
+    names = [r["name"] for r in rows]
+    assert any(n.startswith("conv32p_kernel") for n in names), names
+    assert sum(r["launches"] for r in rows if r["name"].startswith("conv32p_kernel")) >= 2, rows  # forward + input gradient
+
+
 def _sub(t, stride=97):
     t = t.detach().flatten()
     return t[::stride] if t.numel() > 4096 else t
