@@ -200,6 +200,16 @@ typedef struct {
                           Also honoured by the inference entry points (sty_vocoder_fwd, sty_speech_fwd).              */
 } sty_train_opts;
 int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
+
+/* Data-parallel overlap: a callback the backward entry points invoke ON THE CALLING THREAD as soon as
+ * a segment of the bound parameter gradients is final on `stream` (every later kernel of the same backward leaves it
+ * alone), so that the caller can start that segment's all-reduce while the rest of the backward still runs.
+ *   speech_predictor: segment 0 = every parameter outside `text_encoder.*` (announced before the text encoder's
+ *                     backward), segment 1 = `text_encoder.*` (announced at the end of sty_speech_bwd);
+ *   other kinds:      segment 0 = everything, announced at the end of the backward entry point.
+ * Replaces what the reference gets from accelerate's DDP reducer hooks (train/train_context.py:94-104).          */
+typedef void (*sty_grad_hook)(void *user, int segment);
+int sty_model_set_grad_hook(sty_model *m, sty_grad_hook hook, void *user);
 int sty_model_bind_grad(sty_model *m, const char *key, float *grad);
 int sty_vocoder_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
 int sty_vocoder_fwd_train(sty_model *m, const sty_vocoder_io *io, void *workspace, size_t ws_bytes, void *stream);
@@ -235,9 +245,11 @@ int sty_conv1d_bwd(int B, int Cin, int Cout, int K, int dil, int T, const float 
                    void *stream);
 
 /* ---- optimizer: torch.optim.AdamW (train/optimizers.py:110-118) over one flat fp32 bucket ------------------
- * p, g, m, v: n floats each, 16-byte aligned, identically laid out; step = 1, 2, ... (bias correction).          */
+ * p, g, m, v: n floats each, 16-byte aligned, identically laid out; step = 1, 2, ... (bias correction).
+ * grad_scale multiplies g on the way in: 1 / world_size turns the SUM all-reduce of the gradient buckets into the
+ * mean without a pass of its own (1.0f: plain AdamW, bit-identical).                                              */
 int sty_adamw_step(size_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, void *stream);
+                   float eps, float weight_decay, int step, float grad_scale, void *stream);
 
 /* ---- acoustic-stage losses without third-party models, forward + backward in one call ---------------
  * mel  = MultiResolutionSTFTLoss (train/losses.py:17-38) on log1p(mel128|X|); multi_phase = losses.py:41-91;

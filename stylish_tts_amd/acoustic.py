@@ -85,8 +85,32 @@ class AcousticTrainer:
         self.base_lr = lr
         kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, bucket_bytes=bucket_bytes)
         # one optimizer per model key, as train/optimizers.py:106-118 builds them
-        self.opt = {"speech_predictor": FlatAdamW(list(self.sp.parameters()), **kw),
-                    "speech_style_encoder": FlatAdamW(list(self.se.parameters()), **kw)}
+        # gradient segments of the predictor (sty_model_set_grad_hook): 1 = text_encoder.* (its backward runs last),
+        # 0 = everything else -- buckets never mix the two, so that segment 0 is in flight during the text encoder's
+        # backward
+        seg = lambda name: 1 if name.startswith("text_encoder.") else 0
+        self.opt = {"speech_predictor": FlatAdamW(list(self.sp.named_parameters()), group_of=seg, **kw),
+                    "speech_style_encoder": FlatAdamW(list(self.se.named_parameters()), **kw)}
+        self._hooks = {}
+        self._hook_error = None
+
+    def _install_grad_hook(self, module, key):
+        """Register the library's gradient-segment callback of `module` once its handle exists: the callback runs on
+        this thread, inside module.backward(), and starts the all-reduce of the announced segment's buckets on the
+        stream the backward is being issued on."""
+        if key in self._hooks or module._handle is None:
+            return
+        grads = self.opt[key].grads
+
+        def hook(_user, segment):
+            try:
+                grads.reduce_group(segment)
+            except BaseException as e:  # an exception must not unwind through the C frame
+                self._hook_error = e
+
+        cb = L.GRAD_HOOK(hook)
+        L.check(L.load().sty_model_set_grad_hook(module._handle, C.cast(cb, C.c_void_p), None))
+        self._hooks[key] = cb  # keep the ctypes thunk alive
 
     def _side_stream(self, device):
         """second torch stream for the style encoder (STY_NO_SE_STREAM=1: everything on the current stream)"""
@@ -130,9 +154,13 @@ class AcousticTrainer:
         audio = self.sp.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, pitch,
                                       noise=noise, seed=seed, prior_override=prior_override, style_stream=side)
         losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase)
+        self._install_grad_hook(self.sp, "speech_predictor")
+        self._install_grad_hook(self.se, "speech_style_encoder")
+        # the all-reduces are started by the gradient hooks from inside the two backward calls: the predictor's
+        # segment 0 (vocoder + decoder) while its text encoder's backward still runs, its segment 1 at the end, the style
+        # encoder's buckets at the end of its backward (on the stream that backward runs on)
         d_style, _ = self.sp.backward(d_audio, want_style=True, want_energy=False)
         gp, gs = self.opt["speech_predictor"].grads, self.opt["speech_style_encoder"].grads
-        gp.reduce_all()                 # overlaps the style encoder's backward
         if side is not None:
             self.sp.wait_d_style(side)
             with torch.cuda.stream(side):
@@ -140,13 +168,30 @@ class AcousticTrainer:
             main.wait_stream(side)
         else:
             self.se.backward(d_style)
-        gs.reduce_all()
-        gp.finish()
-        gs.finish()
+        if self._hook_error is not None:
+            e, self._hook_error = self._hook_error, None
+            raise e
+        world = gp.finish(average=False)
+        gs.finish(average=False)
         for o in self.opt.values():
-            o.step()
+            o.step(grad_scale=1.0 / world)
         self.audio = audio
         return losses
+
+    def sync_buffers(self, src=0):
+        """Broadcast the non-trainable state the training step updates per rank -- BatchNorm running statistics
+        (conformer.py:183) and the spectral-norm u / v vectors -- from rank `src`.  The reference's accelerate DDP
+        wrappers do this on every forward (broadcast_buffers=True); here ranks are left to drift between calls (the
+        statistics of 32 utterances per rank differ in the fourth digit) and are aligned when it matters: before a
+        checkpoint is written and before evaluation."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        for m in (self.sp, self.se):
+            for b in m.buffers():
+                if b.is_floating_point():
+                    dist.broadcast(b, src)
+            L.check(L.load().sty_model_invalidate(m._handle)) if m._handle is not None else None
 
     def schedule(self, step, step_limit):
         """Stage.steps / MultiOptimizer.scheduler (train/optimizers.py:96-104): cosine schedule with a 90 % plateau."""

@@ -576,6 +576,7 @@ struct Builder {
     m->gb_floats_per_batch = 0;
     if (m->kind == "speech_predictor") {
       text_encoder("text_encoder.");
+      m->seg_job_split = m->jobs.size();  // pack jobs of the module whose backward runs last (gradient segment 1)
       decoder("decoder.");
       vocoder("generator.");
     } else if (m->kind == "vocoder") {
@@ -1531,7 +1532,9 @@ int sty_model_bind_grad(sty_model* m, const char* key, float* grad) {
 
 static int build_multi_tables(sty_model* m);
 // packed gradients -> the caller's parameter gradients (+=)
-static int unpack_grads(sty_model* m, hipStream_t st) {
+// seg: -1 = every parameter; 1 = the pack jobs before seg_job_split (text encoder of a speech predictor);
+//      0 = everything else
+static int unpack_grads(sty_model* m, hipStream_t st, int seg = -1) {
   auto PG = [&](const float* p) -> float* {
     auto it = m->pgrad.find(p);
     return it == m->pgrad.end() ? nullptr : it->second;
@@ -1543,11 +1546,16 @@ static int unpack_grads(sty_model* m, hipStream_t st) {
     int r = build_multi_tables(m);
     if (r != STY_OK) return r;
   }
-  {  // every plain / weight-norm conv (weights and biases) in one launch
-    int r = launch_multi(2, m->mj_dev[2], m->mj_blk_dev[2], m->mj_nblk[2], st);
+  {  // every plain / weight-norm conv (weights and biases) of the segment in one launch
+    const int b0 = seg == 0 ? m->seg_blk_split : 0;
+    const int b1 = seg == 1 ? m->seg_blk_split : m->mj_nblk[2];
+    int r = launch_multi(2, m->mj_dev[2], m->mj_blk_dev[2], b1 - b0, st, b0);
     if (r != STY_OK) return r;
   }
+  size_t job_index = 0;
   for (const PackJob& j : m->jobs) {
+    const bool in_seg1 = job_index++ < m->seg_job_split;
+    if ((seg == 0 && in_seg1) || (seg == 1 && !in_seg1)) continue;
     if (j.kind == PK_CONV || j.kind == PK_CONV_WN) {
       // batched above
     } else if (j.kind == PK_CONV2D_SN) {
@@ -1577,7 +1585,7 @@ static int unpack_grads(sty_model* m, hipStream_t st) {
       if (r) return r;
     }
   }
-  if (m->kind == "speech_predictor" && m->dec.fnv_w) {
+  if (m->kind == "speech_predictor" && m->dec.fnv_w && seg != 1) {
     const DecoderPlan& d = m->dec;
     int r = launch_fnv_unpack(GA(d.fnv_w), d.f0_g, d.f0_v, d.n_g, d.n_v, d.v_g, d.v_v, PG(d.f0_g), PG(d.f0_v),
                               PG(d.f0_b), PG(d.n_g), PG(d.n_v), PG(d.n_b), PG(d.v_g), PG(d.v_v), PG(d.v_b), st);
@@ -1627,9 +1635,27 @@ int sty_speech_bwd(sty_model* m, const float* d_audio, float* d_style, float* d_
     set_error("sty_speech_bwd: no forward recorded or null gradient");
     return STY_ESTATE;
   }
-  rc = trainer_speech_backward(m->trainer, d_audio, d_style, d_energy, S(stream));
+  // Gradient segment 0 (everything outside the text encoder) is un-packed and announced from inside the backward, as
+  // soon as the decoder's backward and the style projections' backward have run; the text encoder's backward follows.
+  bool seg0_done = false;
+  int hook_rc = STY_OK;
+  hipStream_t st = S(stream);
+  trainer_set_segment_hook(m->trainer, [&](int) {
+    hook_rc = unpack_grads(m, st, 0);
+    if (hook_rc == STY_OK && m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
+    seg0_done = true;
+  });
+  rc = trainer_speech_backward(m->trainer, d_audio, d_style, d_energy, st);
+  trainer_set_segment_hook(m->trainer, nullptr);
   if (rc) return rc;
-  return unpack_grads(m, S(stream));
+  if (hook_rc) return hook_rc;
+  if (!seg0_done) {
+    if ((rc = unpack_grads(m, st, 0))) return rc;
+    if (m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
+  }
+  if ((rc = unpack_grads(m, st, 1))) return rc;
+  if (m->grad_hook) m->grad_hook(m->grad_hook_user, 1);
+  return STY_OK;
 }
 
 int sty_speech_d_style_ready(sty_model* m, void* stream) {
@@ -1683,7 +1709,9 @@ int sty_vocoder_bwd(sty_model* m, const float* d_audio, float* d_mel, float* d_s
   }
   rc = trainer_vocoder_backward(m->trainer, d_audio, d_mel, d_style, S(stream));
   if (rc) return rc;
-  return unpack_grads(m, S(stream));
+  if ((rc = unpack_grads(m, S(stream)))) return rc;
+  if (m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
+  return STY_OK;
 }
 
 int sty_model_num_keys(const sty_model* m) { return m ? (int)m->requested.size() : 0; }
@@ -1709,7 +1737,10 @@ static int build_multi_tables(sty_model* m) {
     for (int i = 0; i < nblocks; ++i) blk[which].push_back((int)jobs[which].size());
     jobs[which].push_back(j);
   };
+  size_t job_index = 0;
+  m->seg_blk_split = 0;
   for (const PackJob& j : m->jobs) {
+    if (job_index++ == m->seg_job_split) m->seg_blk_split = (int)blk[2].size();
     if (j.kind == PK_CONV || j.kind == PK_CONV_WN || j.kind == PK_CONV_GLU) {
       MultiJob a;
       a.p0 = j.w;
@@ -1758,6 +1789,7 @@ static int build_multi_tables(sty_model* m) {
     m->mj_dev[i] = nullptr;
     m->mj_blk_dev[i] = nullptr;
     m->mj_nblk[i] = (int)blk[i].size();
+    if (i == 2 && m->seg_job_split >= m->jobs.size()) m->seg_blk_split = (int)blk[2].size();
     if (blk[i].empty()) continue;
     STY_HIP(hipMalloc((void**)&m->mj_dev[i], jobs[i].size() * sizeof(MultiJob)));
     STY_HIP(hipMalloc((void**)&m->mj_blk_dev[i], blk[i].size() * sizeof(int)));
@@ -1765,6 +1797,16 @@ static int build_multi_tables(sty_model* m) {
     STY_HIP(hipMemcpy(m->mj_blk_dev[i], blk[i].data(), blk[i].size() * sizeof(int), hipMemcpyHostToDevice));
   }
   m->mj_ready = true;
+  return STY_OK;
+}
+
+int sty_model_set_grad_hook(sty_model* m, sty_grad_hook hook, void* user) {
+  if (!m) {
+    set_error("sty_model_set_grad_hook: null model");
+    return STY_EINVAL;
+  }
+  m->grad_hook = hook;
+  m->grad_hook_user = user;
   return STY_OK;
 }
 
@@ -2306,7 +2348,9 @@ int sty_style_bwd(sty_model* m, const float* d_style, void* stream) {
   }
   rc = trainer_style_backward(m->trainer, d_style, S(stream));
   if (rc) return rc;
-  return unpack_grads(m, S(stream));
+  if ((rc = unpack_grads(m, S(stream)))) return rc;
+  if (m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
+  return STY_OK;
 }
 // ---- one dense Conv1d ('same' padding) on the MFMA conv kernel: unit parity and kernel tuning ----
 int sty_conv1d_workspace_bytes(int Cout, int Cin, int K, size_t* bytes) {

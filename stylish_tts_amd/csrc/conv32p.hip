@@ -128,7 +128,7 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, int tile,
 }
 
 template <bool BF, int PRO>
-__global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_per_row, int ntiles) {
+__global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_per_row, int ntiles, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -166,105 +166,167 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
   // consumer state that does not change between tiles
   const int tw = wave * (32 * P_NT);  // consumers only
   const int wv = (hi * CoutP + l31) * 4;
-  float a_nxt[CI_CHUNK / 2];
-  if constexpr (!BF) {
-    if (consumer) {
-#pragma unroll
-      for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
-        a_nxt[c2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv, 2 * c2 * CoutP * 4, 0));
-    }
-  }
   __syncthreads();
 
   for (int i = 0; i < count; ++i) {
     const int tile = first + i;
     float* cur = lds + (i & 1) * bufsz;
     if (!consumer) {
-      if (i + 1 < count) p_stage<BF, PRO>(a, lds + ((i + 1) & 1) * bufsz, tile + 1, tiles_per_row, LW, wave - 4, lane);
+      if (i + 1 < count && !(dbg & 2))
+        p_stage<BF, PRO>(a, lds + ((i + 1) & 1) * bufsz, tile + 1, tiles_per_row, LW, wave - 4, lane);
     } else {
-      f32x16 acc[P_NT];
-#pragma unroll
-      for (int n = 0; n < P_NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-      if constexpr (BF) {
-        const __bf16* xh = reinterpret_cast<const __bf16*>(cur);
-        const bf16x8* wf = reinterpret_cast<const bf16x8*>(wl);
-        for (int k = 0; k < K; ++k) {
-          const __bf16* col = xh + (size_t)(tw + l31 + k * a.dil) * P_PITCH + 8 * hi;
-          bf16x8 av[2], bv[2][P_NT];
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            av[s] = wf[(k * 2 + s) * 64 + lane];
-#pragma unroll
-            for (int n = 0; n < P_NT; ++n)
-              bv[s][n] = *reinterpret_cast<const bf16x8*>(col + (size_t)n * 32 * P_PITCH + 16 * s);
-          }
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int n = 0; n < P_NT; ++n)
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], bv[s][n], acc[n], 0, 0, 0);
-        }
-      } else {
-        for (int k = 0; k < K; ++k) {
-          float a_cur[CI_CHUNK / 2];
-#pragma unroll
-          for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) a_cur[c2] = a_nxt[c2];
-          {  // next tap (tap 0 again after the last one: the next tile starts with it)
-            const int kn = k + 1 < K ? k + 1 : 0;
-            const int srow = kn * CinP * CoutP * 4;
-#pragma unroll
-            for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
-              a_nxt[c2] = __builtin_bit_cast(
-                  float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv, srow + 2 * c2 * CoutP * 4, 0));
-          }
-          const float* xrow = cur + hi * LW + tw + l31 + k * a.dil;
-          // B fragments in two halves of eight channel pairs: 32 registers instead of 64
-#pragma unroll
-          for (int h8 = 0; h8 < 2; ++h8) {
-            float bv[8][P_NT];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-              for (int n = 0; n < P_NT; ++n) bv[c][n] = xrow[2 * (8 * h8 + c) * LW + n * 32];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-              for (int n = 0; n < P_NT; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[8 * h8 + c], bv[c][n], acc[n], 0, 0, 0);
-          }
-        }
-      }
-      // ---- epilogue: bias, activation, scale, masks, residual, store ----
       const int b = tile / tiles_per_row;
       const int t0 = (tile - b * tiles_per_row) * P_TT;
-      // (no epilogue activation: every 32 -> 32 conv of the path is linear at its output; an activation switch with
-      // the erf / exp bodies inlined costs ~100 spilled registers here, so such convs stay on conv1d_mfma_kernel)
+      // The accumulators start at the bias (y = out_scale * (conv + bias) ...).
+      // ONE wave per SIMD feeds the matrix pipe here, so its instruction stream must never wait on LDS between MFMAs
+      // (hipcc's default order is ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs, every LDS round trip exposed: measured 0.37 of
+      // the matrix peak).  The loop is software-pipelined by hand: the operands of step s+1 are requested while the MFMAs
+      // of step s issue, and sched_group_barrier pins the interleaving (2 MFMAs : 1-2 LDS reads [: 1 weight load]).  The
+      // first half of the tile's residual operand is requested before the last step's MFMAs (the other half after them:
+      // 64 more live registers would spill), so that its latency is hidden too.
+      f32x16 acc[P_NT];
+      float res[P_NT][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
         const float bi = a.w.bias ? a.w.bias[co] : 0.f;
 #pragma unroll
-        for (int n = 0; n < P_NT; ++n) acc[n][r] = (acc[n][r] + bi) * a.out_scale;
+        for (int n = 0; n < P_NT; ++n) acc[n][r] = bi;
       }
+      // residual loads and output stores go through buffer descriptors of the batch slab [Cout][T]: the per-lane part of
+      // every address is ONE 32-bit offset (column, plus four rows for the upper half-wave), the row of fragment element
+      // r is a scalar offset -- 64-bit per-lane addresses for 64 loads + 64 stores cost ~60 spilled registers
+      const bool want_res = a.residual && !(dbg & 4);
+      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.residual ? a.residual + (size_t)b * Cout * T : a.y), 0, want_res ? Cout * T * 4 : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t yrs =
+          __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * Cout * T, 0, Cout * T * 4, 0x00020000);
+      const int eoff = ((4 * hi) * T + t0 + tw + l31) * 4;  // byte offset of (row 4 hi, this lane's column of fragment 0)
+#define STY_P_LOADRES(N0, N1)                                                                      \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+    const int row = (r & 3) + 8 * (r >> 2);                                                        \
+    _Pragma("unroll") for (int n = N0; n < N1; ++n) res[n][r] = __builtin_bit_cast(                \
+        float, __builtin_amdgcn_raw_buffer_load_b32(rrs, eoff + n * 128, row * T * 4, 0));         \
+  }
+#define STY_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+      const int Keff = (dbg & 1) ? 1 : K;
+      if constexpr (BF) {
+        const __bf16* xh = reinterpret_cast<const __bf16*>(cur);
+        const bf16x8* wf = reinterpret_cast<const bf16x8*>(wl);
+        bf16x8 avA[2], bvA[2][P_NT], avB[2], bvB[2][P_NT];
+#define STY_LD16(AV, BV, k)                                                                                  \
+  {                                                                                                          \
+    const __bf16* col = xh + (size_t)(tw + l31 + (k) * a.dil) * P_PITCH + 8 * hi;                             \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                          \
+      AV[s] = wf[((k) * 2 + s) * 64 + lane];                                                                 \
+      _Pragma("unroll") for (int n = 0; n < P_NT; ++n) BV[s][n] =                                            \
+          *reinterpret_cast<const bf16x8*>(col + (size_t)n * 32 * P_PITCH + 16 * s);                         \
+    }                                                                                                        \
+  }
+#define STY_MM16(AV, BV)                                   \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s)            \
+  _Pragma("unroll") for (int n = 0; n < P_NT; ++n) acc[n] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV[s], BV[s][n], acc[n], 0, 0, 0);
+#define STY_SCHED16                                                              \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                \
+    STY_SGB(0x008, 2);                                                           \
+    STY_SGB(0x100, 3);                                                           \
+  }                                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+        STY_LD16(avA, bvA, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        int k = 0;
+        for (; k + 2 < Keff; k += 2) {  // two taps per trip: the two operand sets alternate without register copies
+          STY_LD16(avB, bvB, k + 1)
+          STY_MM16(avA, bvA)
+          STY_SCHED16
+          STY_LD16(avA, bvA, k + 2)
+          STY_MM16(avB, bvB)
+          STY_SCHED16
+        }
+        if (k + 1 < Keff) {  // two taps left
+          STY_LD16(avB, bvB, k + 1)
+          STY_MM16(avA, bvA)
+          STY_SCHED16
+          STY_P_LOADRES(0, 2)
+          STY_MM16(avB, bvB)
+        } else {  // one tap left
+          STY_P_LOADRES(0, 2)
+          STY_MM16(avA, bvA)
+        }
+#undef STY_SCHED16
+#undef STY_MM16
+#undef STY_LD16
+      } else {
+        float a_cur[CI_CHUNK / 2], a_nxt[CI_CHUNK / 2], bvA[8][P_NT], bvB[8][P_NT];
+#define STY_LDA(AV, k)                                                                     \
+  _Pragma("unroll") for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) AV[c2] = __builtin_bit_cast( \
+      float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv, ((k) * CinP + 2 * c2) * CoutP * 4, 0));
+#define STY_LDB(BV, k, h8)                                                             \
+  {                                                                                    \
+    const float* xr = cur + (hi + 16 * (h8)) * LW + tw + l31 + (k) * a.dil;            \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c)                                      \
+    _Pragma("unroll") for (int n = 0; n < P_NT; ++n) BV[c][n] = xr[2 * c * LW + n * 32]; \
+  }
+#define STY_MM32(AOFF, BV)                                 \
+  _Pragma("unroll") for (int c = 0; c < 8; ++c)            \
+  _Pragma("unroll") for (int n = 0; n < P_NT; ++n) acc[n] = \
+      __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[AOFF + c], BV[c][n], acc[n], 0, 0, 0);
+#define STY_SCHED32(VM)                                                          \
+  _Pragma("unroll") for (int g = 0; g < 16; ++g) {                               \
+    STY_SGB(0x008, 2);                                                           \
+    STY_SGB(0x100, 2);                                                           \
+    if (VM) STY_SGB(0x020, 1);                                                   \
+  }                                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+        STY_LDA(a_cur, 0)
+        STY_LDB(bvA, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k + 1 < Keff; ++k) {
+          STY_LDA(a_nxt, k + 1)
+          STY_LDB(bvB, k, 1)
+          STY_MM32(0, bvA)
+          STY_SCHED32(1)
+          STY_LDB(bvA, k + 1, 0)
+          STY_MM32(8, bvB)
+          STY_SCHED32(0)
+#pragma unroll
+          for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) a_cur[c2] = a_nxt[c2];
+        }
+        {  // last tap: nothing further to prefetch from LDS; the residual operand instead
+          STY_LDB(bvB, Keff - 1, 1)
+          STY_P_LOADRES(0, 2)
+          STY_MM32(0, bvA)
+          __builtin_amdgcn_sched_barrier(0);
+          STY_MM32(8, bvB)
+        }
+#undef STY_SCHED32
+#undef STY_MM32
+#undef STY_LDB
+#undef STY_LDA
+      }
+#undef STY_SGB
+      // second half of the residual operand: its latency hides behind the first half's stores
+      STY_P_LOADRES(2, P_NT)
+#undef STY_P_LOADRES
+      // ---- epilogue: scale, masks, residual, store (no activation: see conv32p_eligible) ----
+      // (a residual value read from beyond the row -- t >= T, or a padded cout row -- is never stored)
 #pragma unroll
       for (int n = 0; n < P_NT; ++n) {
         const int t = t0 + tw + n * 32 + l31;
-        if (t < T) {
+        if (t < T && !(dbg & 4)) {
           const float om_pre = (a.out_mask && !a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
           const float om_post = (a.out_mask && a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
-          float res[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            res[r] = (a.residual && co < Cout) ? a.residual[((size_t)b * Cout + co) * T + t] : 0.f;
+            const int row = (r & 3) + 8 * (r >> 2);
+            if (row + 4 * hi < Cout)
+              __builtin_amdgcn_raw_buffer_store_b32(
+                  __builtin_bit_cast(unsigned, (acc[n][r] * a.out_scale * om_pre + res[n][r]) * om_post), yrs,
+                  eoff + n * 128, row * T * 4, 0);
           }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (co < Cout) a.y[((size_t)b * Cout + co) * T + t] = (acc[n][r] * om_pre + res[r]) * om_post;
-          }
+        } else if ((dbg & 4) && acc[n][0] == 12345.678f) {
+          a.y[0] = acc[n][1];  // keeps the MFMAs alive in the no-epilogue measurement mode
         }
       }
     }
@@ -302,7 +364,9 @@ static int launch_p(const ConvArgs& a, hipStream_t st) {
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d d%d T%d", a.w.Cin, a.w.Cout, a.w.K, a.dil, a.T);
   ProfScope prof(BF ? "conv32p_kernel<true>" : "conv32p_kernel<false>", flops, bytes, st, detail);
-  hipLaunchKernelGGL((conv32p_kernel<BF, PRO>), dim3(grid), dim3(512), lds, st, a, tiles_per_row, ntiles);
+  const char* dbgs = getenv("STY_P_DBG");  // measurement aid: 1 = one tap only, 2 = no staging after tile 0, 4 = no epilogue
+  hipLaunchKernelGGL((conv32p_kernel<BF, PRO>), dim3(grid), dim3(512), lds, st, a, tiles_per_row, ntiles,
+                     dbgs ? atoi(dbgs) : 0);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

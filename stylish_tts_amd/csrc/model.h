@@ -222,6 +222,13 @@ struct sty_model {
   int* mj_blk_dev[3] = {nullptr, nullptr, nullptr};
   int mj_nblk[3] = {0, 0, 0};
   bool mj_ready = false;
+  // gradient segments (data-parallel overlap): pack jobs [0, seg_job_split) belong to the module that runs its backward
+  // LAST (the text encoder of a speech predictor); the un-pack table splits at block seg_blk_split.  Segment 0 = every
+  // other parameter: complete, un-packed and announced through grad_hook while the last module's backward still runs.
+  size_t seg_job_split = 0;
+  int seg_blk_split = 0;
+  sty_grad_hook grad_hook = nullptr;
+  void* grad_hook_user = nullptr;
   sty_train_opts topts = {0, 0, 0, 0, 0.1f, 0u, 0.2f, 0};  // train-mode behaviour of the *_fwd_train entry points
   struct sty::Trainer* trainer = nullptr;
 };
@@ -319,6 +326,7 @@ Trainer* trainer_create(sty_model* m);
 int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t ws_bytes, hipStream_t st,
                            size_t* need);
 int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st);
+void trainer_set_segment_hook(Trainer* t, std::function<void(int)> fn);  // called once segment 0's gradients are final
 bool single_stream_mode();  // sty_set_single_stream: no internal side streams (measurement aid)
 int trainer_wait_d_style(Trainer* t, hipStream_t stream);
 void trainer_destroy(Trainer* t);

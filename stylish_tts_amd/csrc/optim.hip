@@ -11,9 +11,10 @@ namespace sty {
 __global__ __launch_bounds__(256) void adamw_kernel(size_t n4, size_t n, float4* __restrict__ p,
                                                     const float4* __restrict__ g, float4* __restrict__ m,
                                                     float4* __restrict__ v, float decay, float w1, float b2, float w2,
-                                                    float step_size, float bc2s, float eps) {
+                                                    float step_size, float bc2s, float eps, float gscale) {
   const size_t stride = (size_t)gridDim.x * 256;
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    gg *= gscale;  // 1 / world_size after a SUM all-reduce (1.0f is exact: single-GPU results are unchanged)
     pp *= decay;
     mm = mm + w1 * (gg - mm);
     vv = vv * b2 + w2 * gg * gg;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(size_t n4, size_t n, float4*
 }
 
 int launch_adamw(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, hipStream_t st) {
+                 float weight_decay, int step, float grad_scale, hipStream_t st) {
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)((double)lr / bc1);
   const float bc2s = (float)sqrt(bc2);
@@ -53,7 +54,7 @@ int launch_adamw(size_t n, float* p, const float* g, float* m, float* v, float l
   ProfScope prof("adamw_kernel", 12.0 * n, 28.0 * n, st);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n4, n, reinterpret_cast<float4*>(p),
                      reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v),
-                     1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2s, eps);
+                     1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2s, eps, grad_scale);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -61,12 +62,14 @@ int launch_adamw(size_t n, float* p, const float* g, float* m, float* v, float l
 }  // namespace sty
 
 extern "C" int sty_adamw_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, void* stream) {
+                              float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              void* stream) {
   using namespace sty;
   if (!p || !g || !m || !v || step < 1 || ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) {
     set_error("sty_adamw_step: null / unaligned (16 B) buffer or step < 1");
     return STY_EINVAL;
   }
   if (n == 0) return STY_OK;
-  return launch_adamw(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, reinterpret_cast<hipStream_t>(stream));
+  return launch_adamw(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                      reinterpret_cast<hipStream_t>(stream));
 }

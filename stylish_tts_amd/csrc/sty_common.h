@@ -130,7 +130,7 @@ struct MultiJob {
   float *q0 = nullptr, *q1 = nullptr, *q2 = nullptr, *q3 = nullptr;
   int Cout = 0, Cin = 0, K = 1, CinP = 0, CoutP = 0, glu = 0, blk0 = 0, pad = 0;
 };
-int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st);
+int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st, int blk_base = 0);
 
 // weight preparation
 int launch_pack_conv(const float* w, const float* g, const float* v, const float* bias, int Cout, int Cin, int K,

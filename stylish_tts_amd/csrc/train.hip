@@ -87,25 +87,12 @@ struct Trainer {
     const bool on = side_on && !single_stream_mode();
     side_partial = on && side_need ? take<float>(side_need) : nullptr;
     if (on && !st2 && live()) {
-      // STY_SIDE_CU_SKIP=n: the weight-gradient stream is created with a CU mask that leaves every n-th CU to the
-      // main stream.  Workgroups are not preempted: without the mask a 1024-workgroup weight-gradient kernel fills
-      // every CU and each small kernel of the main chain waits for one of those workgroups to retire.
-      const char* sk = getenv("STY_SIDE_CU_SKIP");
-      const int skip = sk ? atoi(sk) : 0;
-      hipError_t r;
-      if (skip >= 2) {
-        uint32_t mask[8];
-        for (int w = 0; w < 8; ++w) {
-          mask[w] = 0;
-          for (int bit = 0; bit < 32; ++bit)
-            if ((w * 32 + bit) % skip != skip - 1) mask[w] |= 1u << bit;
-        }
-        r = hipExtStreamCreateWithCUMask(&st2, 8, mask);
-      } else {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        r = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, least);
-      }
+      // (Measured and rejected: hipExtStreamCreateWithCUMask leaving every 2nd / 4th / 8th CU to the main stream, so
+      // that its small kernels need not wait for a resident weight-gradient workgroup to retire -- c2 38.0 -> 62 ms,
+      // c3 120.5 -> 144.5 ms at every mask: masked streams lose far more than the waiting costs.)
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      hipError_t r = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, least);
       if (r != hipSuccess) rc = hip_fail(r, "side stream");
     }
   }
@@ -1408,6 +1395,7 @@ struct Trainer {
   // graph places between the text encoder and the decoder (every consumer of style has run its backward by then; the
   // text encoder's backward, still to come, does not touch d_style), or after the tape.  d_style_done is recorded
   // behind it so that a caller can start the style encoder's backward on another stream (sty_speech_d_style_ready).
+  std::function<void(int)> on_segment;
   float* d_style_out = nullptr;
   bool fc_bwd_done = false;
   hipEvent_t d_style_done = nullptr;
@@ -1501,7 +1489,15 @@ int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t
   t->begin(io->style);
   const int inter = t->m->te.proj_m.Cout ? t->m->te.proj_m.Cout : 128;
   float* mu = t->text_encoder(io->texts, io->text_lengths, io->L);
-  t->tape.push_back([t]() { t->style_fc_backward(); });  // runs before the text encoder's backward
+  t->tape.push_back([t]() {  // runs before the text encoder's backward
+    t->style_fc_backward();
+    // every gradient outside the text encoder is final once the weight-gradient stream has caught up: announce the
+    // segment (un-pack + the caller's all-reduce) and let the text encoder's backward overlap the exchange
+    if (t->on_segment && t->live()) {
+      t->side_join();
+      if (t->rc == STY_OK) t->on_segment(0);
+    }
+  });
   t->style_fc(reinterpret_cast<hipStream_t>(io->style_stream));
   float* asr = t->expand(mu, io->alignment, inter, io->L, io->T);
   float* mel = t->decoder(asr, io->pitch, io->energy, io->voiced, io->T);
@@ -1592,6 +1588,10 @@ int trainer_style_backward(Trainer* t, const float* d_style, hipStream_t st) {
     return STY_ENOMEM;
   }
   return t->rc;
+}
+
+void trainer_set_segment_hook(Trainer* t, std::function<void(int)> fn) {
+  if (t) t->on_segment = std::move(fn);
 }
 
 Trainer* trainer_create(sty_model* m) {

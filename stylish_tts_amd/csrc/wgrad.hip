@@ -970,10 +970,11 @@ __global__ __launch_bounds__(256) void pack_dgrad_multi_kernel(const MultiJob* _
 // p0 = packed weight gradient, p1 = g, p2 = v (weight norm) or null, p3 = packed bias gradient or null;
 // q0 = dW, q1 = dg, q2 = dv, q3 = db
 __global__ __launch_bounds__(256) void unpack_grad_multi_kernel(const MultiJob* __restrict__ jobs,
-                                                                const int* __restrict__ job_of_block) {
+                                                                const int* __restrict__ job_of_block, int blk_base) {
   __shared__ float r1[256], r2[256];
-  const MultiJob j = jobs[job_of_block[blockIdx.x]];
-  const int co = blockIdx.x - j.blk0;
+  const int blk = (int)blockIdx.x + blk_base;  // a launch may cover a sub-range of the table (one gradient segment)
+  const MultiJob j = jobs[job_of_block[blk]];
+  const int co = blk - j.blk0;
   const int n = j.Cin * j.K;
   const int cp = co;
   if (threadIdx.x == 0 && j.q3 && j.p3) j.q3[co] += j.p3[cp];
@@ -1011,14 +1012,14 @@ __global__ __launch_bounds__(256) void unpack_grad_multi_kernel(const MultiJob* 
     j.q2[(size_t)co * n + i] += gg / norm * (j.p0[((size_t)k * j.CinP + ci) * j.CoutP + cp] - v * d / (norm * norm));
   }
 }
-int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st) {
+int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st, int blk_base) {
   if (nblocks <= 0) return STY_OK;
   if (which == 0)
     hipLaunchKernelGGL(pack_conv_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
   else if (which == 1)
     hipLaunchKernelGGL(pack_dgrad_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
   else
-    hipLaunchKernelGGL(unpack_grad_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
+    hipLaunchKernelGGL(unpack_grad_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block, blk_base);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -5,8 +5,10 @@ sampler batches are dealt round-robin to ranks (weak scaling) and gradients are 
 Here the exchange is explicit:
   * utterances are sharded by rank (`shard`), no data-path collective in the forward;
   * gradients live in a few flat buckets filled in REVERSE execution order (vocoder -> decoder -> text encoder, then the
-    style encoder), each all-reduced asynchronously as soon as it is complete, so the exchange overlaps the rest
-    of the backward; `finish()` waits and divides by the world size before the optimiser step.
+    style encoder) that never mix gradient segments; the library announces a segment from INSIDE the backward call
+    (sty_model_set_grad_hook: everything outside the text encoder is final before the text encoder's backward starts)
+    and the hook starts that segment's all-reduces, which then overlap the rest of the predictor's backward and the
+    style encoder's backward; `finish()` waits, and the mean's 1 / world_size is folded into the AdamW kernel.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): 89 MB of fp32 gradients is ~1 ms as a ring and ~0.15 ms as
 reduce-scatter + all-gather, against tens of ms of compute per step, so 4 buckets of ~25 MB are enough to hide it.
 """
@@ -29,7 +31,9 @@ def init(backend=None):
 
 
 def shard(n_items, rank, world):
-    """Contiguous utterance shard of this rank (weak scaling: every rank owns n_items // world utterances)."""
+    """Contiguous utterance shard of this rank (weak scaling: every rank owns n_items // world utterances; the
+    n_items % world utterances at the end of the list are not used -- the `drop_last` of the reference's batch sampler,
+    train/dataloader.py:331-383, applied across ranks)."""
     per = n_items // world
     return range(rank * per, (rank + 1) * per)
 
@@ -48,25 +52,35 @@ class GradBuckets:
     After `attach()`, each parameter's .grad is a view into its bucket, so backward kernels / autograd write
     straight into the flat buffer and no gather copy is needed before the collective."""
 
-    def __init__(self, params, bucket_bytes=25 << 20):
-        self.params = [p for p in params if p.requires_grad]
-        self.buckets = []  # list of (flat tensor, [(param, offset, numel)])
-        cur, cur_n = [], 0
-        for p in reversed(self.params):
+    def __init__(self, params, bucket_bytes=25 << 20, group_of=None):
+        """params: tensors, or (name, tensor) pairs with `group_of(name) -> int`: the gradient SEGMENT the parameter
+        belongs to (sty_model_set_grad_hook: a segment's gradients become final together, before the backward has
+        finished).  A bucket never mixes segments, so that a segment's buckets can be all-reduced as soon as the
+        library announces it."""
+        named = [(q if isinstance(q, tuple) else (None, q)) for q in params]
+        named = [(n, p) for n, p in named if p.requires_grad]
+        self.params = [p for _, p in named]
+        self.buckets = []       # list of (flat tensor, [(param, offset, numel)])
+        self.bucket_group = []  # segment of each bucket
+        cur, cur_n, cur_g = [], 0, None
+        for name, p in reversed(named):
             n = p.numel()
-            if cur and (cur_n + n) * p.element_size() > bucket_bytes:
-                self._close(cur, cur_n)
+            g = group_of(name) if (group_of is not None and name is not None) else 0
+            if cur and ((cur_n + n) * p.element_size() > bucket_bytes or g != cur_g):
+                self._close(cur, cur_n, cur_g)
                 cur, cur_n = [], 0
             cur.append((p, cur_n, n))
             cur_n += n
+            cur_g = g
         if cur:
-            self._close(cur, cur_n)
+            self._close(cur, cur_n, cur_g)
         self._work = []
 
-    def _close(self, items, n):
+    def _close(self, items, n, group=0):
         p0 = items[0][0]
         flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
         self.buckets.append((flat, items))
+        self.bucket_group.append(group)
 
     def attach(self):
         for flat, items in self.buckets:
@@ -86,12 +100,21 @@ class GradBuckets:
         for i in range(len(self.buckets)):
             self.reduce_bucket(i)
 
-    def finish(self):
-        """Wait for the outstanding collectives and turn sums into means."""
+    def reduce_group(self, group):
+        """Start the all-reduce of every bucket of one gradient segment (called from the library's gradient hook, while
+        the rest of the backward is still being issued / running)."""
+        for i, g in enumerate(self.bucket_group):
+            if g == group:
+                self.reduce_bucket(i)
+
+    def finish(self, average=True):
+        """Wait for the outstanding collectives.  average=True turns the sums into means with one pass over the buckets;
+        the trainer passes False and folds 1 / world_size into the AdamW kernel instead (sty_adamw_step grad_scale)."""
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         for w in self._work:
             w.wait()
         self._work = []
-        if world > 1:
+        if world > 1 and average:
             for flat, _ in self.buckets:
                 flat.div_(world)
+        return world

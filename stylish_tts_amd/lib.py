@@ -95,7 +95,8 @@ SYMBOLS = {
     "sty_conv1d_bwd_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _I, _SZP]),
     "sty_conv1d_bwd": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
     "sty_adamw_step": (C.c_int, [C.c_size_t, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                 _I, _P]),
+                                 _I, C.c_float, _P]),
+    "sty_model_set_grad_hook": (C.c_int, [_P, _P, _P]),
     "sty_acoustic_loss_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
     "sty_acoustic_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "sty_prof_enable": (C.c_int, [_I]),
@@ -118,6 +119,8 @@ def prof_report(cap=64):
         check(n)
     return [dict(name=r.name.decode(), launches=int(r.launches), ms=r.ms, flops=r.flops, bytes=r.bytes)
             for r in rows[:min(n, cap)]]
+
+GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int)  # sty_grad_hook(user, segment)
 
 LIB = None
 

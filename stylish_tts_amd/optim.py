@@ -12,9 +12,10 @@ from .dist import GradBuckets
 
 
 class FlatAdamW:
-    def __init__(self, params, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4, bucket_bytes=25 << 20):
+    def __init__(self, params, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4, bucket_bytes=25 << 20,
+                 group_of=None):
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.grads = GradBuckets(params, bucket_bytes)
+        self.grads = GradBuckets(params, bucket_bytes, group_of)
         self.grads.attach()
         self.flat_p, self.m, self.v = [], [], []
         for gflat, items in self.grads.buckets:
@@ -30,7 +31,8 @@ class FlatAdamW:
     def zero_grad(self):
         self.grads.zero()
 
-    def step(self):
+    def step(self, grad_scale=1.0):
+        """grad_scale multiplies the gradient inside the kernel (1 / world_size after a SUM all-reduce)."""
         lib = L.load()
         self.t += 1
         for (gflat, _), p, m, v in zip(self.grads.buckets, self.flat_p, self.m, self.v):
@@ -38,7 +40,8 @@ class FlatAdamW:
                 raise L.StyError("FlatAdamW.step: parameters must live on the GPU (there is no CPU path)")
             st = C.c_void_p(torch.cuda.current_stream(gflat.device).cuda_stream)
             L.check(lib.sty_adamw_step(gflat.numel(), L.ptr(p), L.ptr(gflat), L.ptr(m), L.ptr(v), self.lr,
-                                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, st))
+                                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                                       float(grad_scale), st))
         # the kernel wrote the parameters behind torch's back: bump their version counters so that the module shells
         # see the mutation (modules._HipModule._ensure re-prepares the packed weights before the next inference call)
         for _, items in self.grads.buckets:

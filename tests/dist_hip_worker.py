@@ -65,6 +65,41 @@ def main(out_path):
         grads = {"sp." + k: v.grad.detach().cpu().clone() for k, v in sp.named_parameters()}
         grads.update({"se." + k: v.grad.detach().cpu().clone() for k, v in se.named_parameters()})
         torch.save(grads, out_path)
+    # ---- phase 2: the trainer's own step (gradient-segment hooks start the all-reduces from inside the backward
+    # calls, 1 / world folded into AdamW).  Ranks hold DIFFERENT utterances of DIFFERENT length T; after two steps their
+    # parameters must still be bit-identical (every bucket was reduced, nothing was reduced twice) and must have moved.
+    del opts
+    from stylish_tts_amd.acoustic import AcousticTrainer
+    sp2 = S.SpeechPredictor()
+    sp2.load_state_dict(fill_state_dict(speech_predictor_manifest(), 0), strict=False)
+    se2 = S.MelStyleEncoder()
+    se2.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+    tr = AcousticTrainer(sp2.to(dev), se2.to(dev), lr=1e-3, train_mode=True, seed=rank)
+    before = torch.cat([p.detach().flatten() for p in tr.sp.parameters()]).clone()
+    Tr = 80 + 20 * rank  # a different length bin per rank (ranks take whole sampler batches)
+    g2 = torch.Generator().manual_seed(100 + rank)
+    Br = 2
+    tx = torch.randint(1, 178, (Br, Lt), generator=g2)
+    d2 = torch.ones(Br, Lt)
+    for b in range(Br):
+        d2[b] += torch.bincount(torch.multinomial(torch.ones(Lt), Tr - Lt, replacement=True, generator=g2),
+                                minlength=Lt).float()
+    p2 = torch.rand(Br, Tr, generator=g2) * 200 + 80
+    a2 = 0.1 * torch.randn(Br, 300 * Tr, generator=g2)
+    for it in range(2):
+        tr.train_batch(audio_gt=a2.to(dev), texts=tx.to(dev), text_lengths=torch.full((Br,), Lt).to(dev),
+                       pitch=p2.to(dev), durations=d2.to(dev), seed=it)
+    torch.cuda.synchronize()
+    after = torch.cat([p.detach().flatten() for m in (tr.sp, tr.se) for p in m.parameters()])
+    assert bool(torch.isfinite(after).all())
+    assert not torch.equal(after[:before.numel()], before), "parameters did not move"
+    if world > 1:
+        mine = after.cpu()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(both, mine)
+        for r, other in enumerate(both):
+            assert torch.equal(other, both[0]), f"rank {r} parameters differ from rank 0 after two trainer steps"
+        print(f"[rank {rank}] trainer steps: parameters identical on all {world} ranks")
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -128,3 +128,25 @@ def test_loss_oracle_matches_reference_losses_and_losslog():
     for i in range(3):
         for got, ref in ((p_mag[i].grad, fx[f"d_p_mag{i}"]), (p_ph[i].grad, fx[f"d_p_ph{i}"])):
             assert (got - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+
+
+def test_gradient_buckets_never_mix_segments():
+    """dist.GradBuckets with group_of: a bucket holds parameters of ONE gradient segment (sty_model_set_grad_hook), the
+    buckets are in reverse parameter order, and every parameter's .grad is a view into its bucket."""
+    from stylish_tts_amd.dist import GradBuckets
+    names = ["text_encoder.a", "text_encoder.b", "decoder.c", "generator.d", "generator.e"]
+    params = [(n, torch.nn.Parameter(torch.zeros(sz))) for n, sz in zip(names, (1000, 3000, 500, 4000, 2000))]
+    gb = GradBuckets(params, bucket_bytes=5000 * 4, group_of=lambda n: 1 if n.startswith("text_encoder.") else 0)
+    gb.attach()
+    seen = []
+    for (flat, items), g in zip(gb.buckets, gb.bucket_group):
+        for p, off, n in items:
+            name = next(nm for nm, q in params if q is p)
+            seen.append(name)
+            assert (1 if name.startswith("text_encoder.") else 0) == g
+            assert p.grad.data_ptr() == flat[off:off + n].data_ptr()
+    assert seen == names[::-1]
+    assert gb.bucket_group == sorted(gb.bucket_group)          # segment 0 (final first in the backward) comes first
+    assert len(gb.buckets) >= 3                                # 25 kB cap splits segment 0; the segment change splits again
+    gb.reduce_group(0)                                         # no process group: nothing to do, nothing raised
+    assert gb.finish(average=False) == 1
