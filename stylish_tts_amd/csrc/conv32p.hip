@@ -6,40 +6,41 @@
 // load -> prologue -> LDS -> barrier -> MFMA -> epilogue strictly in sequence and nothing inside the workgroup overlaps
 // (a fixed cost of ~9 tap times per tile, 55 % of the fp32 matrix peak at k = 11, and in the bf16
 // mode the MFMA phase is 1/16 as long, so the fixed cost is nearly everything).  Here a workgroup is persistent over a
-// contiguous range of time tiles and its eight waves have two roles:
-//   waves 4-7 (one per SIMD)  PRODUCERS: buffer-load the next tile (32 channels x (512 + halo) columns, all 72-80
-//                             loads of a wave in flight at once), apply the fused prologue (AdaIN + Snake, ...) on the
-//                             VALU and write it into the OTHER LDS buffer;
-//   waves 0-3 (one per SIMD)  CONSUMERS: read B fragments of the current tile from LDS and issue MFMAs back to back
-//                             (32 couts x 128 columns each), then bias / activation / residual / store.
-// The matrix pipe and the VALU / memory pipes of a SIMD are separate, so the producer's work hides completely behind
-// the consumer's MFMAs (fp32 mode, MFMA-bound), and in the bf16 mode (HBM-bound: 16x fewer matrix cycles) the CU always
-// has the next tile's loads, the current tile's residual loads and the previous tile's stores in flight together.
+// contiguous range of 256-column time tiles and its eight waves have two roles:
+//   waves 0-3 (one per SIMD)  CONSUMERS: LDS -> MFMA -> LDS and nothing else.  They read B fragments of the current tile
+//                             from LDS, issue MFMAs back to back (32 couts x 64 columns each; the loop is software-
+//                             pipelined by hand, the operands of step s+1 are requested while the MFMAs of step s issue)
+//                             and leave out_scale * (acc + bias) in an LDS output stage.  No global memory access.
+//   waves 4-7 (one per SIMD)  PRODUCERS: every byte of global traffic.  Per iteration they (a) request the residual
+//                             rows of the PREVIOUS tile with 16-byte loads, (b) buffer-load the NEXT tile (32 channels
+//                             x (256 + halo) columns), apply the fused prologue (AdaIN + Snake, ...) on the VALU and
+//                             write it into the other LDS tile buffer, (c) drain the previous tile's output stage: read
+//                             it with ds_read_b128, add the residual, store 16 bytes per lane (row-contiguous).
+// The matrix pipe and the VALU / memory pipes of a SIMD are separate, so in the fp32 mode (MFMA-bound) everything the
+// producers do hides behind the consumers' MFMAs, and in the bf16 mode (HBM-bound: 16x fewer matrix cycles) the CU always
+// has the next tile's loads, the previous tile's residual loads and its stores in flight while the consumers compute.
+// (First version: consumers did their own epilogue with 64 dword stores per lane -- measured 31 of 144 us at k = 11 fp32
+// and 35 of 59 us in the bf16 mode were that epilogue; it ran at the old kernel's speed.)
 // One barrier per tile.  Workgroup w owns tiles [first_w, first_w + count_w): its halo re-reads hit its own XCD's L2.
 //
-//   fp32 mode: LDS tile [32 ch][LW] fp32, B operand = ds_read_b32 (lanes along time), v_mfma_f32_32x32x2_f32, packed
-//              weights streamed from L2 one tap ahead (the same A path as conv1d_mfma_kernel).
+//   fp32 mode: LDS tile [32 ch][LW] fp32, B operand = ds_read2_b32 (lanes along time), v_mfma_f32_32x32x2_f32, packed
+//              weights streamed from L2 one tap ahead (tap 0 stays in registers).
 //   bf16 mode: LDS tile [LW][32 ch] bf16 with an 80-byte row pitch (conflict-free ds_read_b128 / ds_write_b128), the
 //              producer writes eight channels of a column with one ds_write_b128; weights are converted once per
 //              workgroup into bf16 A fragments in LDS (2 KB per tap); v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 #include <stdlib.h>
 
 #include "sty_common.h"
-
 #include "conv_stage.h"
 
 namespace sty {
 
-constexpr int P_TT = 512;    // columns per tile
-constexpr int P_NT = 4;      // 32-column fragments per consumer wave
-constexpr int P_MAXQ = 10;   // 64-column groups of a staged row (512 + halo <= 640)
+constexpr int P_TT = 256;    // columns per tile
+constexpr int P_NT = 2;      // 32-column fragments per consumer wave (4 consumers x 64 columns)
+constexpr int P_MAXQ = 6;    // 64-column groups of a staged row (256 + halo <= 384)
 constexpr int P_PITCH = 40;  // bf16 mode: halfs per column in LDS (32 channels + 8 pad = 80 bytes)
+constexpr int P_OUT = 32 * P_TT;  // floats of one output stage [32 co][256]
 
-// ---- producer: stage tile (b, t0) into `dst` ----
-// One buffer descriptor per tile for the whole batch slab [32 ch][T]; the row enters as a VALU byte offset (this is the
-// producer: its VALU is idle next to the consumer's MFMAs).  Columns outside [0, T) are zeroed AFTER the prologue by the
-// explicit `tin` predicate, so whatever a load outside the row returns (the neighbouring row, or 0 outside the slab) is
-// never used.
 template <int PRO>
 __device__ __forceinline__ void p_row_params(const ConvArgs& a, int b, int ci, bool live, float& pa, float& ps, float& al,
                                              float& ral) {
@@ -56,22 +57,92 @@ __device__ __forceinline__ void p_row_params(const ConvArgs& a, int b, int ci, b
   }
 }
 
-template <bool BF, int PRO>
-__device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, int tile, int tiles_per_row, int LW, int pw, int lane) {
+// Tile coordinates
+struct PTile {
+  int b, t0;
+};
+__device__ __forceinline__ PTile p_tile(int tile, int tiles_per_row) {
+  PTile t;
+  t.b = tile / tiles_per_row;
+  t.t0 = (tile - t.b * tiles_per_row) * P_TT;
+  return t;
+}
+
+// ---- producer, part 1: the residual rows of a tile (8 rows of this wave x 4 consecutive columns per lane) ----
+// Buffer descriptors of the batch slab [Cout][T]; a lane whose four columns would cross the end of the row takes the
+// scalar path (the slab descriptor cannot clip at a row end).
+struct PDrain {
+  float4 res[8];
+  bool wide;
+};
+__device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, int lane, bool want, PDrain& d) {
+  const int T = a.T, Cout = a.w.Cout;
+  const int t = tl.t0 + 4 * lane;
+  d.wide = t + 3 < T;
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(want ? a.residual + (size_t)tl.b * Cout * T : a.y), 0, want ? Cout * T * 4 : 0, 0x00020000);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int co = 8 * pw + r;
+    d.res[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!want || co >= Cout) continue;
+    if (d.wide) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rrs, t * 4, co * T * 4, 0);
+      d.res[r] = __builtin_bit_cast(float4, v);
+    } else {
+      float e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        e[q] = (t + q < T) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (t + q) * 4, co * T * 4, 0)) : 0.f;
+      d.res[r] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+  }
+}
+// ---- producer, part 3: drain the output stage of that tile: y = stage + residual, 16 bytes per lane and row ----
+__device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, PTile tl, int pw, int lane, const PDrain& d) {
+  const int T = a.T, Cout = a.w.Cout;
+  const int t = tl.t0 + 4 * lane;
+  const __amdgpu_buffer_rsrc_t yrs =
+      __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)tl.b * Cout * T, 0, Cout * T * 4, 0x00020000);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int co = 8 * pw + r;
+    if (co >= Cout) continue;
+    const float4 s = *reinterpret_cast<const float4*>(ostage + co * P_TT + 4 * lane);
+    float4 v = make_float4(s.x + d.res[r].x, s.y + d.res[r].y, s.z + d.res[r].z, s.w + d.res[r].w);
+    if (d.wide) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                             yrs, t * 4, co * T * 4, 0);
+    } else {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (t + q < T) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[q]), yrs, (t + q) * 4, co * T * 4, 0);
+    }
+  }
+}
+
+// ---- producer, part 2: stage tile (b, t0) into `dst` with the fused prologue ----
+// One buffer descriptor per tile for the whole batch slab [32 ch][T]; the row enters as a VALU byte offset (this is the
+// producer: its VALU is idle next to the consumer's MFMAs).  Columns outside [0, T) are zeroed AFTER the prologue by the
+// explicit `tin` predicate, so whatever a load outside the row returns (the neighbouring row, or 0 outside the slab) is
+// never used.  `mid` runs between the first batch of loads and their use (the drain of the previous tile: its stores
+// go out while this tile's loads are in flight).
+template <bool BF, int PRO, typename Mid>
+__device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl, int LW, int pw, int lane, Mid mid) {
   const int T = a.T, Cin = a.w.Cin;
-  const int b = tile / tiles_per_row;
-  const int t0 = (tile - b * tiles_per_row) * P_TT;
+  const int b = tl.b, t0 = tl.t0;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x[0] + (size_t)b * Cin * T), 0, Cin * T * 4, 0x00020000);
   const int voff = (t0 - a.pad + lane) * 4;
   if constexpr (!BF) {
-    // fp32 tile [ch][LW]: row by row, the next row's loads in flight while this one is written (MFMA-bound mode: the
-    // consumer needs ~45k cycles per tile, staging needs a fraction of that however it is ordered)
+    // fp32 tile [ch][LW]: row by row, the next row's loads in flight while this one is written
     float vv[2][P_MAXQ];
 #define STY_P_LOADROW(slot, r)                                                                  \
   _Pragma("unroll") for (int q = 0; q < P_MAXQ; ++q) if (q < P_TT / 64 || 64 * q < LW) vv[slot][q] = \
       buf_load(rs, voff + 256 * q + (8 * pw + (r)) * T * 4);
     STY_P_LOADROW(0, 0)
+    mid();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       if (r + 1 < 8) { STY_P_LOADROW((r + 1) & 1, r + 1) }
@@ -95,22 +166,26 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, int tile,
 #undef STY_P_LOADROW
   } else {
     // bf16 tile [LW][32 ch]: a lane gathers the eight channels of its wave for one column and writes them with one
-    // ds_write_b128; five column groups (40 loads per lane, ~41 KB per CU with the four producers) in flight at a time
+    // ds_write_b128; three column groups (24 loads per lane) per batch, the second batch requested before the first is
+    // processed
     float pa[8], ps[8], al[8], ral[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) p_row_params<PRO>(a, b, 8 * pw + r, 8 * pw + r < Cin, pa[r], ps[r], al[r], ral[r]);
+    constexpr int QH = P_MAXQ / 2;
+    float vv[2][QH][8];
+#define STY_P_LOADH(h)                                                                     \
+  _Pragma("unroll") for (int q = 0; q < QH; ++q) if ((h) * QH + q < P_TT / 64 || 64 * ((h) * QH + q) < LW) \
+  _Pragma("unroll") for (int r = 0; r < 8; ++r) vv[h][q][r] = buf_load(rs, voff + 256 * ((h) * QH + q) + (8 * pw + r) * T * 4);
+    STY_P_LOADH(0)
+    mid();
+    STY_P_LOADH(1)
+#undef STY_P_LOADH
 #pragma unroll
-    for (int qh = 0; qh < P_MAXQ; qh += P_MAXQ / 2) {
-      float vv[P_MAXQ / 2][8];
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < P_MAXQ / 2; ++q)
-        if (qh + q < P_TT / 64 || 64 * (qh + q) < LW)
-#pragma unroll
-          for (int r = 0; r < 8; ++r) vv[q][r] = buf_load(rs, voff + 256 * (qh + q) + (8 * pw + r) * T * 4);
-#pragma unroll
-      for (int q = 0; q < P_MAXQ / 2; ++q) {
-        if (!(qh + q < P_TT / 64 || 64 * (qh + q) < LW)) continue;
-        const int j = lane + 64 * (qh + q);
+      for (int q = 0; q < QH; ++q) {
+        if (!(h * QH + q < P_TT / 64 || 64 * (h * QH + q) < LW)) continue;
+        const int j = lane + 64 * (h * QH + q);
         const int t = t0 - a.pad + j;
         const bool tin = t >= 0 && t < T;
         float mk = 1.f;
@@ -118,12 +193,11 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, int tile,
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-          v[r] = (8 * pw + r < Cin && tin) ? pro_apply<PRO>(vv[q][r], pa[r], ps[r], al[r], ral[r], mk) : 0.f;
+          v[r] = (8 * pw + r < Cin && tin) ? pro_apply<PRO>(vv[h][q][r], pa[r], ps[r], al[r], ral[r], mk) : 0.f;
         if (j < LW)
           *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + 8 * pw) =
               sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
       }
-    }
   }
 }
 
@@ -135,11 +209,12 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool consumer = wave < 4;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int T = a.T, K = a.w.K, CoutP = a.w.CoutP, CinP = a.w.CinP, Cout = a.w.Cout;
+  const int K = a.w.K, CoutP = a.w.CoutP, CinP = a.w.CinP;
   const int halo = (K - 1) * a.dil;
   const int LW = P_TT + halo;
-  const int bufsz = BF ? (LW * P_PITCH) / 2 : CI_CHUNK * LW;  // floats per tile buffer
-  float* wl = lds + 2 * bufsz;                                // bf16 mode: A fragments [K][2][64 lanes] x 16 B
+  const int bufsz = BF ? (LW * P_PITCH) / 2 : CI_CHUNK * LW;  // floats per input tile buffer
+  float* ost = lds + 2 * bufsz;                               // two output stages [32][256] fp32
+  float* wl = ost + 2 * P_OUT;                                // bf16 mode: A fragments [K][2][64 lanes] x 16 B
 
   // contiguous tile range of this workgroup
   const int per = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
@@ -161,55 +236,55 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
       reinterpret_cast<bf16x8*>(wl)[it] = sty_pack_bf16(w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7]);
     }
   }
-  if (!consumer) p_stage<BF, PRO>(a, lds, first, tiles_per_row, LW, wave - 4, lane);
+  const bool want_res = a.residual != nullptr && !(dbg & 4);
+  if (!consumer) p_stage<BF, PRO>(a, lds, p_tile(first, tiles_per_row), LW, wave - 4, lane, []() {});
 
-  // consumer state that does not change between tiles
+  // consumer state that does not change between tiles: bias per fragment row, and (fp32 mode) the weights of tap 0
   const int tw = wave * (32 * P_NT);  // consumers only
   const int wv = (hi * CoutP + l31) * 4;
+  float bias_r[16];
+  float a0[CI_CHUNK / 2];
+  if (consumer) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = a.w.bias ? a.w.bias[(r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+    if constexpr (!BF) {
+#pragma unroll
+      for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2)
+        a0[c2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wv, 2 * c2 * CoutP * 4, 0));
+    }
+  }
   __syncthreads();
 
+#define STY_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+  const int Keff = (dbg & 1) ? 1 : K;
   for (int i = 0; i < count; ++i) {
     const int tile = first + i;
     float* cur = lds + (i & 1) * bufsz;
     if (!consumer) {
+      // ---- producer ----
+      const int pw = wave - 4;
+      PDrain d;
+      const bool have_prev = i > 0 && !(dbg & 4);
+      const PTile prev = p_tile(tile - 1, tiles_per_row);
+      if (have_prev) p_res_load(a, prev, pw, lane, want_res, d);
+      auto drain = [&]() {
+        if (have_prev) p_drain(a, ost + ((i - 1) & 1) * P_OUT, prev, pw, lane, d);
+      };
       if (i + 1 < count && !(dbg & 2))
-        p_stage<BF, PRO>(a, lds + ((i + 1) & 1) * bufsz, tile + 1, tiles_per_row, LW, wave - 4, lane);
+        p_stage<BF, PRO>(a, lds + ((i + 1) & 1) * bufsz, p_tile(tile + 1, tiles_per_row), LW, pw, lane, drain);
+      else
+        drain();
     } else {
-      const int b = tile / tiles_per_row;
-      const int t0 = (tile - b * tiles_per_row) * P_TT;
-      // The accumulators start at the bias (y = out_scale * (conv + bias) ...).
-      // ONE wave per SIMD feeds the matrix pipe here, so its instruction stream must never wait on LDS between MFMAs
-      // (hipcc's default order is ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs, every LDS round trip exposed: measured 0.37 of
-      // the matrix peak).  The loop is software-pipelined by hand: the operands of step s+1 are requested while the MFMAs
-      // of step s issue, and sched_group_barrier pins the interleaving (2 MFMAs : 1-2 LDS reads [: 1 weight load]).  The
-      // first half of the tile's residual operand is requested before the last step's MFMAs (the other half after them:
-      // 64 more live registers would spill), so that its latency is hidden too.
+      // ---- consumer: LDS -> MFMA -> LDS ----
+      // ONE wave per SIMD feeds the matrix pipe, so its instruction stream must never wait on LDS between MFMAs (hipcc's
+      // default order is ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs, every LDS round trip exposed: measured 0.37 of the
+      // matrix peak): the operands of step s+1 are requested while the MFMAs of step s issue, and sched_group_barrier
+      // pins the interleaving.  The accumulators start at the bias.
       f32x16 acc[P_NT];
-      float res[P_NT][16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float bi = a.w.bias ? a.w.bias[co] : 0.f;
+      for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int n = 0; n < P_NT; ++n) acc[n][r] = bi;
-      }
-      // residual loads and output stores go through buffer descriptors of the batch slab [Cout][T]: the per-lane part of
-      // every address is ONE 32-bit offset (column, plus four rows for the upper half-wave), the row of fragment element
-      // r is a scalar offset -- 64-bit per-lane addresses for 64 loads + 64 stores cost ~60 spilled registers
-      const bool want_res = a.residual && !(dbg & 4);
-      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(a.residual ? a.residual + (size_t)b * Cout * T : a.y), 0, want_res ? Cout * T * 4 : 0, 0x00020000);
-      const __amdgpu_buffer_rsrc_t yrs =
-          __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * Cout * T, 0, Cout * T * 4, 0x00020000);
-      const int eoff = ((4 * hi) * T + t0 + tw + l31) * 4;  // byte offset of (row 4 hi, this lane's column of fragment 0)
-#define STY_P_LOADRES(N0, N1)                                                                      \
-  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
-    const int row = (r & 3) + 8 * (r >> 2);                                                        \
-    _Pragma("unroll") for (int n = N0; n < N1; ++n) res[n][r] = __builtin_bit_cast(                \
-        float, __builtin_amdgcn_raw_buffer_load_b32(rrs, eoff + n * 128, row * T * 4, 0));         \
-  }
-#define STY_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-      const int Keff = (dbg & 1) ? 1 : K;
+        for (int n = 0; n < P_NT; ++n) acc[n][r] = bias_r[r];
       if constexpr (BF) {
         const __bf16* xh = reinterpret_cast<const __bf16*>(cur);
         const bf16x8* wf = reinterpret_cast<const bf16x8*>(wl);
@@ -229,8 +304,8 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
       __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV[s], BV[s][n], acc[n], 0, 0, 0);
 #define STY_SCHED16                                                              \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                \
-    STY_SGB(0x008, 2);                                                           \
-    STY_SGB(0x100, 3);                                                           \
+    STY_SGB(0x008, 1);                                                           \
+    STY_SGB(0x100, 2);                                                           \
   }                                                                              \
   __builtin_amdgcn_sched_barrier(0);
         STY_LD16(avA, bvA, 0)
@@ -248,10 +323,8 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
           STY_LD16(avB, bvB, k + 1)
           STY_MM16(avA, bvA)
           STY_SCHED16
-          STY_P_LOADRES(0, 2)
           STY_MM16(avB, bvB)
         } else {  // one tap left
-          STY_P_LOADRES(0, 2)
           STY_MM16(avA, bvA)
         }
 #undef STY_SCHED16
@@ -273,13 +346,14 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
   _Pragma("unroll") for (int n = 0; n < P_NT; ++n) acc[n] = \
       __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[AOFF + c], BV[c][n], acc[n], 0, 0, 0);
 #define STY_SCHED32(VM)                                                          \
-  _Pragma("unroll") for (int g = 0; g < 16; ++g) {                               \
+  _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                \
     STY_SGB(0x008, 2);                                                           \
     STY_SGB(0x100, 2);                                                           \
-    if (VM) STY_SGB(0x020, 1);                                                   \
+    if (VM) STY_SGB(0x020, 2);                                                   \
   }                                                                              \
   __builtin_amdgcn_sched_barrier(0);
-        STY_LDA(a_cur, 0)
+#pragma unroll
+        for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) a_cur[c2] = a0[c2];
         STY_LDB(bvA, 0, 0)
         __builtin_amdgcn_sched_barrier(0);
         for (int k = 0; k + 1 < Keff; ++k) {
@@ -293,11 +367,10 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
 #pragma unroll
           for (int c2 = 0; c2 < CI_CHUNK / 2; ++c2) a_cur[c2] = a_nxt[c2];
         }
-        {  // last tap: nothing further to prefetch from LDS; the residual operand instead
+        {  // last tap
           STY_LDB(bvB, Keff - 1, 1)
-          STY_P_LOADRES(0, 2)
           STY_MM32(0, bvA)
-          __builtin_amdgcn_sched_barrier(0);
+          STY_SCHED32(0)
           STY_MM32(8, bvB)
         }
 #undef STY_SCHED32
@@ -305,32 +378,24 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
 #undef STY_LDB
 #undef STY_LDA
       }
-#undef STY_SGB
-      // second half of the residual operand: its latency hides behind the first half's stores
-      STY_P_LOADRES(2, P_NT)
-#undef STY_P_LOADRES
-      // ---- epilogue: scale, masks, residual, store (no activation: see conv32p_eligible) ----
-      // (a residual value read from beyond the row -- t >= T, or a padded cout row -- is never stored)
+      // out_scale * (conv + bias) -> output stage [co][256] (rows of padded couts are written too, never stored)
+      float* ob = ost + (i & 1) * P_OUT + tw + l31;
 #pragma unroll
-      for (int n = 0; n < P_NT; ++n) {
-        const int t = t0 + tw + n * 32 + l31;
-        if (t < T && !(dbg & 4)) {
-          const float om_pre = (a.out_mask && !a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
-          const float om_post = (a.out_mask && a.out_mask_post) ? a.out_mask[(size_t)b * T + t] : 1.f;
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2);
-            if (row + 4 * hi < Cout)
-              __builtin_amdgcn_raw_buffer_store_b32(
-                  __builtin_bit_cast(unsigned, (acc[n][r] * a.out_scale * om_pre + res[n][r]) * om_post), yrs,
-                  eoff + n * 128, row * T * 4, 0);
-          }
-        } else if ((dbg & 4) && acc[n][0] == 12345.678f) {
-          a.y[0] = acc[n][1];  // keeps the MFMAs alive in the no-epilogue measurement mode
-        }
+        for (int n = 0; n < P_NT; ++n) ob[row * P_TT + n * 32] = acc[n][r] * a.out_scale;
       }
     }
     __syncthreads();
+  }
+#undef STY_SGB
+  // the last tile's output stage
+  if (!consumer && !(dbg & 4)) {
+    const PTile last = p_tile(first + count - 1, tiles_per_row);
+    PDrain d;
+    p_res_load(a, last, wave - 4, lane, want_res, d);
+    p_drain(a, ost + ((count - 1) & 1) * P_OUT, last, wave - 4, lane, d);
   }
 }
 
@@ -344,11 +409,15 @@ static int num_cus() {
   return n;
 }
 
+static size_t p_lds_bytes(const ConvArgs& a) {
+  const int LW = P_TT + (a.w.K - 1) * a.dil;
+  const size_t in = a.bf16 ? (size_t)2 * LW * P_PITCH * 2 : (size_t)2 * CI_CHUNK * LW * 4;
+  return in + (size_t)2 * P_OUT * 4 + (a.bf16 ? (size_t)a.w.K * 2 * 64 * 16 : 0);
+}
+
 template <bool BF, int PRO>
 static int launch_p(const ConvArgs& a, hipStream_t st) {
-  const int halo = (a.w.K - 1) * a.dil;
-  const int LW = P_TT + halo;
-  const size_t lds = BF ? (size_t)2 * LW * P_PITCH * 2 + (size_t)a.w.K * 2 * 64 * 16 : (size_t)2 * CI_CHUNK * LW * 4;
+  const size_t lds = p_lds_bytes(a);
   static bool raised = false;
   if (!raised) {
     STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32p_kernel<BF, PRO>),
@@ -364,7 +433,7 @@ static int launch_p(const ConvArgs& a, hipStream_t st) {
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d d%d T%d", a.w.Cin, a.w.Cout, a.w.K, a.dil, a.T);
   ProfScope prof(BF ? "conv32p_kernel<true>" : "conv32p_kernel<false>", flops, bytes, st, detail);
-  const char* dbgs = getenv("STY_P_DBG");  // measurement aid: 1 = one tap only, 2 = no staging after tile 0, 4 = no epilogue
+  const char* dbgs = getenv("STY_P_DBG");  // measurement aid: 1 = one tap only, 2 = no staging after tile 0, 4 = no drain
   hipLaunchKernelGGL((conv32p_kernel<BF, PRO>), dim3(grid), dim3(512), lds, st, a, tiles_per_row, ntiles,
                      dbgs ? atoi(dbgs) : 0);
   STY_LAUNCH_CHECK();
@@ -375,15 +444,15 @@ static int launch_p(const ConvArgs& a, hipStream_t st) {
 bool conv32p_eligible(const ConvArgs& a) {
   static const bool off = getenv("STY_NO_CONV32P") != nullptr;
   if (off) return false;
+  // one reduction chunk, <= 32 couts, one plain source, linear output (an activation switch with the erf / exp bodies
+  // inlined costs ~100 spilled registers), no output mask (text-encoder convs, not 32-channel ones)
   if (a.w.CinP != CI_CHUNK || a.w.CoutP != 32 || a.flatW || a.nsrc != 1 || a.in_shuffle > 1 || a.shuffle != 1 ||
-      a.ln_out || a.Tin || a.act != ACT_NONE)
+      a.ln_out || a.Tin || a.act != ACT_NONE || a.out_mask)
     return false;
   if (!(a.pro == PRO_NONE || a.pro == PRO_AFFINE_SNAKE || a.pro == PRO_MASK || a.pro == PRO_AFFINE_LRELU)) return false;
   const int halo = (a.w.K - 1) * a.dil;
   if (halo > 64 * P_MAXQ - P_TT) return false;
-  const int LW = P_TT + halo;
-  const size_t lds = a.bf16 ? (size_t)2 * LW * P_PITCH * 2 + (size_t)a.w.K * 2 * 64 * 16 : (size_t)2 * CI_CHUNK * LW * 4;
-  if (lds > 160 * 1024) return false;
+  if (p_lds_bytes(a) > 160 * 1024) return false;
   // worth it from ~2 tiles per CU on (below that the persistent loop has nothing to overlap)
   const char* mt = getenv("STY_CONV32P_MIN_TILES");  // read per call: the parity tests lower it for small shapes
   const int min_tiles = mt ? atoi(mt) : 512;
