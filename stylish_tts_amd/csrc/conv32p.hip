@@ -21,6 +21,10 @@
 // has the next tile's loads, the previous tile's residual loads and its stores in flight while the consumers compute.
 // (First version: consumers did their own epilogue with 64 dword stores per lane -- measured 31 of 144 us at k = 11 fp32
 // and 35 of 59 us in the bf16 mode were that epilogue; it ran at the old kernel's speed.)
+// (Also measured: EIGHT consumer waves, two per SIMD, 32 columns each, + four producers -- 136 vs 128 us at k = 11 fp32:
+// one accumulator per wave and twice the weight-fragment loads cost more than the second wave per SIMD hides.
+// tools/probes/mfma_probe.hip: one wave per SIMD sustains 71-73 cycles per v_mfma_f32_32x32x2_f32 without LDS reads,
+// 75 with four accumulators and LDS reads, 83 with two -- this kernel's 64-column fragments are the two-accumulator case.)
 // One barrier per tile.  Workgroup w owns tiles [first_w, first_w + count_w): its halo re-reads hit its own XCD's L2.
 //
 //   fp32 mode: LDS tile [32 ch][LW] fp32, B operand = ds_read2_b32 (lanes along time), v_mfma_f32_32x32x2_f32, packed
