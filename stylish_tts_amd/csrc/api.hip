@@ -707,16 +707,29 @@ struct Run {
     }
   }
 
-  // AdaptiveGeneratorBlock in place on x [B][32][T]
+  // AdaptiveGeneratorBlock in place on x [B][32][T].  When the convs run on the persistent 32-channel kernel, each one
+  // leaves the (sum, sum of squares) partials of its OUTPUT behind (ConvArgs::stat_part), so only the first AdaIN of
+  // the block needs a statistics pass of its own.
+  bool takes32p(ConvArgs a) const {
+    a.bf16 = m->topts.compute_bf16;
+    return conv32p_eligible(a);
+  }
   void resblock(const ResBlock32& r, float* x, int T) {
     Scope sc_(*this);
     float* xt = ws.take<float>((size_t)B * 32 * T);
-    double* part = ws.take<double>((size_t)B * 32 * row_stats_nseg(T) * 2);
+    const int nseg_row = row_stats_nseg(T), nseg_p = conv32p_stat_nseg(T);
+    const int nseg_max = nseg_row > nseg_p ? nseg_row : nseg_p;
+    double* part_x = ws.take<double>((size_t)B * 32 * nseg_max * 2);
+    double* part_t = ws.take<double>((size_t)B * 32 * nseg_max * 2);
     float* a = ws.take<float>(B * 32);
     float* s = ws.take<float>(B * 32);
     const int dil[3] = {1, 3, 5};
+    bool have_x = false;  // part_x holds the statistics of x (left by the previous iteration's second conv)
     for (int i = 0; i < 3 && live(); ++i) {
-      adain(x, 32, T, r.n1[i], a, s, part);
+      if (have_x)
+        chk(launch_adain_finalize(part_x, nseg_p, gbp(r.n1[i]), B, 32, T, 1e-5f, a, s, st));
+      else
+        adain(x, 32, T, r.n1[i], a, s, part_x);
       ConvArgs c1 = base(r.c1[i], x, T, xt);
       c1.dil = dil[i];
       c1.pad = 5 * dil[i];
@@ -724,14 +737,21 @@ struct Run {
       c1.pa = a;
       c1.ps = s;
       c1.palpha = r.a1[i];
+      const bool f1 = takes32p(c1);
+      if (f1) c1.stat_part = part_t;
       conv(c1);
-      adain(xt, 32, T, r.n2[i], a, s, part);
+      if (f1)
+        chk(launch_adain_finalize(part_t, nseg_p, gbp(r.n2[i]), B, 32, T, 1e-5f, a, s, st));
+      else
+        adain(xt, 32, T, r.n2[i], a, s, part_t);
       ConvArgs c2 = base(r.c2[i], xt, T, x);
       c2.pro = PRO_AFFINE_SNAKE;
       c2.pa = a;
       c2.ps = s;
       c2.palpha = r.a2[i];
       c2.residual = x;
+      have_x = takes32p(c2) && i + 1 < 3;
+      if (have_x) c2.stat_part = part_x;
       conv(c2);
     }
   }

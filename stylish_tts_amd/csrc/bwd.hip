@@ -481,18 +481,48 @@ int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, 
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
-__global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C, int T, int K,
-                                     int pad, float* __restrict__ dx, int accumulate, const float* __restrict__ src) {
-  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
-  if (t >= T) return;
+// Four consecutive outputs per thread: the K + 3 gradient samples they need are read once into registers (the first
+// version read K values per output through L1: 1.1 TB/s at C = 32, 75T frame rate -- 7.5 ms of a c3 training step), the
+// result goes out as one 16-byte store when the row allows it.
+template <int MAXK>
+__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C,
+                                                            int T, int K, int pad, float* __restrict__ dx, int accumulate,
+                                                            const float* __restrict__ src) {
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4, c = blockIdx.y, b = blockIdx.z;
+  if (t0 >= T) return;
   const float* p = dy + ((size_t)b * C + c) * T;
-  float acc = 0.f;
-  for (int k = 0; k < K; ++k) {  // y[t'] uses x[t' - pad + k]  ->  x[t] feeds y[t + pad - k]
-    const int tt = t + pad - k;
-    if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+  float wk[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) wk[k] = k < K ? w[c * K + k] : 0.f;
+  // y[t'] uses x[t' - pad + k]  ->  x[t] feeds y[t + pad - k]: outputs t0 .. t0+3 need dy[t0 + pad - K + 1 .. t0 + pad + 3]
+  float g[MAXK + 3];
+  const int lo = t0 + pad - (MAXK - 1);
+#pragma unroll
+  for (int j = 0; j < MAXK + 3; ++j) {
+    const int tt = lo + j;
+    g[j] = (tt >= 0 && tt < T) ? p[tt] : 0.f;
   }
-  const size_t o = ((size_t)b * C + c) * T + t;
-  dx[o] = src ? src[o] + acc : (accumulate ? dx[o] + acc : acc);  // src: out-of-place accumulate (dx = src + result)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) acc[e] = fmaf(wk[k], g[e + (MAXK - 1) - k], acc[e]);  // dy[t0 + e + pad - k]
+  const size_t o = ((size_t)b * C + c) * T + t0;
+  const bool wide = t0 + 3 < T && (o & 3) == 0;
+  if (wide) {
+    float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (src) {  // out-of-place accumulate (dx = src + result)
+      const float4 sv = *reinterpret_cast<const float4*>(src + o);
+      r = make_float4(r.x + sv.x, r.y + sv.y, r.z + sv.z, r.w + sv.w);
+    } else if (accumulate) {
+      const float4 dv = *reinterpret_cast<const float4*>(dx + o);
+      r = make_float4(r.x + dv.x, r.y + dv.y, r.z + dv.z, r.w + dv.w);
+    }
+    *reinterpret_cast<float4*>(dx + o) = r;
+  } else {
+    for (int e = 0; e < 4 && t0 + e < T; ++e)
+      dx[o + e] = src ? src[o + e] + acc[e] : (accumulate ? dx[o + e] + acc[e] : acc[e]);
+  }
 }
 // dw[c][k] += sum_{b,t} dy[t] x[t - pad + k], db[c] += sum dy.  Two deterministic stages: one workgroup per
 // (channel, batch row, 4096-sample segment) writes K+1 partial sums, a second kernel adds them in a fixed order.
@@ -548,9 +578,18 @@ __global__ void dwconv_bwd_w_sum_kernel(const float* __restrict__ part, int C, i
 size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K) { return (size_t)C * B * cdiv(T, DW_SEG) * (K + 1); }
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
                       int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src) {
-  if (dx)
-    hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
-                       accumulate, dx_src);
+  if (dx) {
+    if (K <= 7)
+      hipLaunchKernelGGL(dwconv_bwd_dx_kernel<7>, dim3(cdiv(T, 1024), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
+                         accumulate, dx_src);
+    else if (K <= 31)
+      hipLaunchKernelGGL(dwconv_bwd_dx_kernel<31>, dim3(cdiv(T, 1024), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
+                         accumulate, dx_src);
+    else {
+      set_error("dwconv_bwd: kernel size %d > 31", K);
+      return STY_EINVAL;
+    }
+  }
   if (dw) {
     const int nseg = cdiv(T, DW_SEG);
     if (K <= 7)

@@ -103,9 +103,11 @@ __device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, 
   }
 }
 // ---- producer, part 3: drain the output stage of that tile: y = stage + residual, 16 bytes per lane and row ----
-__device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, PTile tl, int pw, int lane, const PDrain& d) {
+__device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, PTile tl, int pw, int lane, const PDrain& d,
+                                        int tiles_per_row) {
   const int T = a.T, Cout = a.w.Cout;
   const int t = tl.t0 + 4 * lane;
+  double s1[8], s2[8];
   const __amdgpu_buffer_rsrc_t yrs =
       __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)tl.b * Cout * T, 0, Cout * T * 4, 0x00020000);
 #pragma unroll
@@ -114,6 +116,12 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
     if (co >= Cout) continue;
     const float4 s = *reinterpret_cast<const float4*>(ostage + co * P_TT + 4 * lane);
     float4 v = make_float4(s.x + d.res[r].x, s.y + d.res[r].y, s.z + d.res[r].z, s.w + d.res[r].w);
+    if (a.stat_part) {  // statistics of what is stored: this lane's (up to) four columns in fp32, across lanes in double
+      const float e0 = v.x, e1 = t + 1 < T ? v.y : 0.f, e2 = t + 2 < T ? v.z : 0.f, e3 = t + 3 < T ? v.w : 0.f;
+      const bool in = t < T;
+      s1[r] = in ? (double)((e0 + e1) + (e2 + e3)) : 0.0;
+      s2[r] = in ? (double)((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) : 0.0;
+    }
     if (d.wide) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
                                              yrs, t * 4, co * T * 4, 0);
@@ -122,6 +130,22 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (t + q < T) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[q]), yrs, (t + q) * 4, co * T * 4, 0);
+    }
+  }
+  if (a.stat_part) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (8 * pw + r >= Cout) continue;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        s1[r] += __shfl_xor(s1[r], o);
+        s2[r] += __shfl_xor(s2[r], o);
+      }
+      if (lane == 0) {
+        double* dst = a.stat_part + (((size_t)tl.b * Cout + 8 * pw + r) * tiles_per_row + tl.t0 / P_TT) * 2;
+        dst[0] = s1[r];
+        dst[1] = s2[r];
+      }
     }
   }
 }
@@ -272,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
       const PTile prev = p_tile(tile - 1, tiles_per_row);
       if (have_prev) p_res_load(a, prev, pw, lane, want_res, d);
       auto drain = [&]() {
-        if (have_prev) p_drain(a, ost + ((i - 1) & 1) * P_OUT, prev, pw, lane, d);
+        if (have_prev) p_drain(a, ost + ((i - 1) & 1) * P_OUT, prev, pw, lane, d, tiles_per_row);
       };
       if (i + 1 < count && !(dbg & 2))
         p_stage<BF, PRO>(a, lds + ((i + 1) & 1) * bufsz, p_tile(tile + 1, tiles_per_row), LW, pw, lane, drain);
@@ -399,9 +423,11 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
     const PTile last = p_tile(first + count - 1, tiles_per_row);
     PDrain d;
     p_res_load(a, last, wave - 4, lane, want_res, d);
-    p_drain(a, ost + ((count - 1) & 1) * P_OUT, last, wave - 4, lane, d);
+    p_drain(a, ost + ((count - 1) & 1) * P_OUT, last, wave - 4, lane, d, tiles_per_row);
   }
 }
+
+int conv32p_stat_nseg(int T) { return cdiv(T, P_TT); }
 
 static int num_cus() {
   static int n = 0;

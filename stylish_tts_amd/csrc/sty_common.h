@@ -116,12 +116,16 @@ struct ConvArgs {
   const float* ln_w = nullptr;
   const float* ln_b = nullptr;
   float* y = nullptr;
-  double* stats = nullptr;  // optional [B][Cout][2] (sum, sumsq) accumulated with atomics (pre-zeroed)
+  // conv32p_kernel only (conv32p_eligible(a) must hold): per-(b, cout, 256-column tile) partial (sum, sum of squares)
+  // of the OUTPUT, laid out as launch_row_stats lays out its segments: [B * Cout][conv32p_stat_nseg(T)][2] doubles.
+  // The AdaIN fold of the next layer then needs no pass of its own over the tensor.
+  double* stat_part = nullptr;
 };
 
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
 // conv32p.hip: persistent, wave-specialised kernel for the 32 -> 32 channel convs at the 75T rate
 bool conv32p_eligible(const ConvArgs& a);
+int conv32p_stat_nseg(int T);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);
 
 // one entry of a batched weight-side launch (wgrad.hip: pack / input-gradient pack / gradient un-pack)

@@ -403,15 +403,22 @@ struct Trainer {
   }
 
   // AdaIN folded to a per-(b,c) affine (a, s) consumed by the next conv's prologue
-  void adain(const float* x, int C, int Tt, const AdaFc& fc, float*& a, float*& s) {
+  // have_part: the (sum, sum of squares) partials of x were left behind by the conv that produced it (conv32p_kernel,
+  // ConvArgs::stat_part) -- no statistics pass over x
+  void adain(const float* x, int C, int Tt, const AdaFc& fc, float*& a, float*& s, const double* have_part = nullptr,
+             int have_nseg = 0) {
     a = take<float>((size_t)B * C);
     s = take<float>((size_t)B * C);
     float* mean = take<float>((size_t)B * C);
     float* rstd = take<float>((size_t)B * C);
-    const int nseg = row_stats_nseg(Tt);
-    double* part = take<double>((size_t)B * C * nseg * 2);
+    const int nseg = have_part ? have_nseg : row_stats_nseg(Tt);
+    const double* part = have_part;
+    if (!have_part) {
+      double* p2 = take<double>((size_t)B * C * nseg * 2);
+      if (live()) chk(launch_row_stats(x, B * C, Tt, p2, st));
+      part = p2;
+    }
     if (live()) {
-      chk(launch_row_stats(x, B * C, Tt, part, st));
       chk(launch_adain_finalize(part, nseg, gbp(fc), B, C, Tt, 1e-5f, a, s, st));
       chk(launch_adain_stats(part, nseg, B * C, Tt, 1e-5f, mean, rstd, st));
     }
@@ -632,12 +639,19 @@ struct Trainer {
     return y;
   }
 
-  // AdaptiveGeneratorBlock (ada_norm.py:109-120)
+  // AdaptiveGeneratorBlock (ada_norm.py:109-120).  Convs that run on the persistent 32-channel kernel leave the
+  // statistics of their output behind for the next AdaIN (see Run::resblock in api.hip).
+  bool takes32p(ConvArgs a) const {
+    a.bf16 = m->topts.compute_bf16;
+    return conv32p_eligible(a);
+  }
   float* resblock(const ResBlock32& r, float* x, int Tt) {
     const int dil[3] = {1, 3, 5};
+    const int nseg_p = conv32p_stat_nseg(Tt);
+    const double* part_x = nullptr;
     for (int i = 0; i < 3; ++i) {
       float *a, *s;
-      adain(x, 32, Tt, r.n1[i], a, s);
+      adain(x, 32, Tt, r.n1[i], a, s, part_x, nseg_p);
       float* xt = take<float>((size_t)B * 32 * Tt);
       ConvArgs c1 = base(r.c1[i], x, Tt, xt);
       c1.dil = dil[i];
@@ -646,8 +660,10 @@ struct Trainer {
       c1.pa = a;
       c1.ps = s;
       c1.palpha = r.a1[i];
+      double* part_t = nullptr;
+      if (takes32p(c1)) c1.stat_part = part_t = take<double>((size_t)B * 32 * nseg_p * 2);
       conv(c1);
-      adain(xt, 32, Tt, r.n2[i], a, s);
+      adain(xt, 32, Tt, r.n2[i], a, s, part_t, nseg_p);
       float* xn = take<float>((size_t)B * 32 * Tt);
       ConvArgs c2 = base(r.c2[i], xt, Tt, xn);
       c2.pro = PRO_AFFINE_SNAKE;
@@ -655,6 +671,12 @@ struct Trainer {
       c2.ps = s;
       c2.palpha = r.a2[i];
       c2.residual = x;
+      part_x = nullptr;
+      if (takes32p(c2) && i + 1 < 3) {
+        double* p = take<double>((size_t)B * 32 * nseg_p * 2);
+        c2.stat_part = p;
+        part_x = p;
+      }
       conv(c2);
       x = xn;
     }

@@ -76,7 +76,7 @@ def main(path, skip=1):
             agg[key] += e - s
             cnt[key] += 1
         print(f"--- stream {st}: top kernels")
-        for k, v in agg.most_common(14):
+        for k, v in agg.most_common(45 if st == main_stream else 14):
             print(f"   {v / 1e6:8.3f} ms {cnt[k]:5d}  {k}")
 
 
