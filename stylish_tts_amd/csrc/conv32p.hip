@@ -107,7 +107,7 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
                                         int tiles_per_row) {
   const int T = a.T, Cout = a.w.Cout;
   const int t = tl.t0 + 4 * lane;
-  double s1[8], s2[8];
+  float sv[16];  // [0..7] sums, [8..15] sums of squares of this lane's columns, per row of this wave
   const __amdgpu_buffer_rsrc_t yrs =
       __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)tl.b * Cout * T, 0, Cout * T * 4, 0x00020000);
 #pragma unroll
@@ -119,8 +119,8 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
     if (a.stat_part) {  // statistics of what is stored: this lane's (up to) four columns in fp32, across lanes in double
       const float e0 = v.x, e1 = t + 1 < T ? v.y : 0.f, e2 = t + 2 < T ? v.z : 0.f, e3 = t + 3 < T ? v.w : 0.f;
       const bool in = t < T;
-      s1[r] = in ? (double)((e0 + e1) + (e2 + e3)) : 0.0;
-      s2[r] = in ? (double)((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) : 0.0;
+      sv[r] = in ? (e0 + e1) + (e2 + e3) : 0.f;
+      sv[8 + r] = in ? (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3) : 0.f;
     }
     if (d.wide) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
@@ -133,20 +133,27 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
     }
   }
   if (a.stat_part) {
+    // 16 values per lane -> 16 totals over the 64 lanes with a halving butterfly: at every step a lane keeps half of its
+    // values and receives the partner's copy of that half (8 + 4 + 2 + 1 exchanges), then two full steps: 17 shuffles
+    // instead of 96 (a plain per-value reduction, in double, cost the HBM-bound bf16 mode +70 us per launch).  Lane
+    // (b5 b4 b3 b2 . .) ends up with value index 8 b5 + 4 b4 + 2 b3 + b2.  fp32 over one 256-column tile, double from there.
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (8 * pw + r >= Cout) continue;
+    for (int r = 0; r < 8; ++r)
+      if (8 * pw + r >= Cout) sv[r] = sv[8 + r] = 0.f;
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    float w8[8], w4[4], w2[2];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        s1[r] += __shfl_xor(s1[r], o);
-        s2[r] += __shfl_xor(s2[r], o);
-      }
-      if (lane == 0) {
-        double* dst = a.stat_part + (((size_t)tl.b * Cout + 8 * pw + r) * tiles_per_row + tl.t0 / P_TT) * 2;
-        dst[0] = s1[r];
-        dst[1] = s2[r];
-      }
-    }
+    for (int i = 0; i < 8; ++i) w8[i] = (b5 ? sv[8 + i] : sv[i]) + __shfl_xor(b5 ? sv[i] : sv[8 + i], 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (b4 ? w8[4 + i] : w8[i]) + __shfl_xor(b4 ? w8[i] : w8[4 + i], 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = (b3 ? w4[2 + i] : w4[i]) + __shfl_xor(b3 ? w4[i] : w4[2 + i], 8);
+    float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4);
+    w1 += __shfl_xor(w1, 2);
+    w1 += __shfl_xor(w1, 1);
+    const int idx = (lane >> 2) & 15, stat = idx >> 3, row = idx & 7;
+    if ((lane & 3) == 0 && 8 * pw + row < Cout)
+      a.stat_part[(((size_t)tl.b * Cout + 8 * pw + row) * tiles_per_row + tl.t0 / P_TT) * 2 + stat] = (double)w1;
   }
 }
 
