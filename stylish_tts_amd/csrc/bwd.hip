@@ -175,15 +175,20 @@ int launch_row_axpb(const float* x, const float* c0, const float* c1, int rows, 
 }
 
 // ---- per-row mean / rstd (InstanceNorm statistics kept for the backward) ----
-__global__ void adain_stats_kernel(const double* __restrict__ part, int nseg, int rows, int T, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void adain_stats_kernel(const double* __restrict__ part, int nseg, int rows, int T,
+                                                          float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // one wave per row (see adain_finalize_kernel)
   if (i >= rows) return;
   double sum = 0.0, sq = 0.0;
-  for (int k = 0; k < nseg; ++k) {
+  for (int k = lane; k < nseg; k += 64) {
     sum += part[((size_t)i * nseg + k) * 2];
     sq += part[((size_t)i * nseg + k) * 2 + 1];
   }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    sq += __shfl_xor(sq, o);
+  }
+  if (lane) return;
   const double m = sum / T;
   double var = sq / T - m * m;
   if (var < 0.0) var = 0.0;
@@ -192,7 +197,7 @@ __global__ void adain_stats_kernel(const double* __restrict__ part, int nseg, in
 }
 int launch_adain_stats(const double* part, int nseg, int rows, int T, float eps, float* mean, float* rstd,
                        hipStream_t st) {
-  hipLaunchKernelGGL(adain_stats_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, part, nseg, rows, T, eps, mean, rstd);
+  hipLaunchKernelGGL(adain_stats_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, part, nseg, rows, T, eps, mean, rstd);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

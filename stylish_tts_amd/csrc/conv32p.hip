@@ -479,8 +479,7 @@ static int launch_p(const ConvArgs& a, hipStream_t st) {
 
 // Whether the persistent kernel takes this conv (launch_conv1d asks before its own tile choice).
 bool conv32p_eligible(const ConvArgs& a) {
-  static const bool off = getenv("STY_NO_CONV32P") != nullptr;
-  if (off) return false;
+  if (getenv("STY_NO_CONV32P")) return false;  // (read per call: the A/B parity test toggles it)
   // one reduction chunk, <= 32 couts, one plain source, linear output (an activation switch with the erf / exp bodies
   // inlined costs ~100 spilled registers), no output mask (text-encoder convs, not 32-channel ones)
   if (a.w.CinP != CI_CHUNK || a.w.CoutP != 32 || a.flatW || a.nsrc != 1 || a.in_shuffle > 1 || a.shuffle != 1 ||

@@ -75,16 +75,25 @@ int launch_row_stats(const float* x, int rows, int T, double* part, hipStream_t 
 }
 
 // AdaptiveInstance folded to a per-(b,c) affine (ada_norm.py:129-140): InstanceNorm1d biased var, eps 1e-5
-__global__ void adain_finalize_kernel(const double* __restrict__ part, int nseg, const float* __restrict__ gb, int B,
-                                      int C, int T, float eps, float* __restrict__ a, float* __restrict__ s) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per (b, c) row: lanes stride over the segment partials (hundreds of them when the producing conv left one
+// per 256-column tile), fixed-order shuffle reduction -- deterministic.  (One THREAD per row looping over the segments
+// took 20-50 us per call at 235 segments: a 256-thread launch of serial dependent adds.)
+__global__ __launch_bounds__(256) void adain_finalize_kernel(const double* __restrict__ part, int nseg,
+                                                             const float* __restrict__ gb, int B, int C, int T, float eps,
+                                                             float* __restrict__ a, float* __restrict__ s) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= B * C) return;
   const int b = i / C, c = i % C;
   double sum = 0.0, sq = 0.0;
-  for (int k = 0; k < nseg; ++k) {
+  for (int k = lane; k < nseg; k += 64) {
     sum += part[((size_t)i * nseg + k) * 2];
     sq += part[((size_t)i * nseg + k) * 2 + 1];
   }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    sq += __shfl_xor(sq, o);
+  }
+  if (lane) return;
   const double mean = sum / T;
   double var = sq / T - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -97,7 +106,7 @@ __global__ void adain_finalize_kernel(const double* __restrict__ part, int nseg,
 
 int launch_adain_finalize(const double* part, int nseg, const float* gb, int B, int C, int T, float eps, float* a,
                           float* s, hipStream_t st) {
-  hipLaunchKernelGGL(adain_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, part, nseg, gb, B, C, T, eps, a, s);
+  hipLaunchKernelGGL(adain_finalize_kernel, dim3(cdiv(B * C, 4)), dim3(256), 0, st, part, nseg, gb, B, C, T, eps, a, s);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

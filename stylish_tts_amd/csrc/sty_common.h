@@ -126,6 +126,9 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st);
 // conv32p.hip: persistent, wave-specialised kernel for the 32 -> 32 channel convs at the 75T rate
 bool conv32p_eligible(const ConvArgs& a);
 int conv32p_stat_nseg(int T);
+// convp16.hip: persistent producer / consumer kernel of the bf16 compute mode for Cin >= 64
+bool convp16_eligible(const ConvArgs& a);
+int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);
 
 // one entry of a batched weight-side launch (wgrad.hip: pack / input-gradient pack / gradient un-pack)

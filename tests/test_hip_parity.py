@@ -842,6 +842,79 @@ def test_persistent_conv32_vs_torch(shape, compute, monkeypatch):
     assert sum(r["launches"] for r in rows if r["name"].startswith("conv32p_kernel")) >= 2, rows  # forward + input gradient
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 80, 5, 2, 203), (3, 128, 130, 1, 1, 64), (2, 512, 64, 3, 1, 37), (2, 96, 200, 3, 1, 300),
+                                   (2, 64, 96, 3, 1, 1000), (3, 130, 33, 5, 1, 257), (48, 240, 80, 3, 1, 1500)])
+def test_persistent_conv16_vs_torch(shape, monkeypatch):
+    """convp16_kernel (bf16 compute mode, Cin >= 64: producer / consumer waves over 32-channel chunks, bf16 LDS tiles)
+    through the unit entry points: forward and input gradient vs float64 on the same bf16-rounded operands.  Small shapes
+    are forced onto it with STY_CONVP16_MIN_TILES=1; the last one takes it by itself."""
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    if shape[0] < 48:
+        monkeypatch.setenv("STY_CONVP16_MIN_TILES", "1")
+    L.prof_report(256)
+    lib.sty_prof_enable(1)
+    try:
+        test_dense_conv1d_vs_torch(shape, "bf16")
+    finally:
+        lib.sty_prof_enable(0)
+    rows = L.prof_report(256)
+    assert sum(r["launches"] for r in rows if r["name"].startswith("convp16_kernel")) >= 1, rows
+
+
+def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monkeypatch):
+    """The bf16 compute mode with the persistent kernels forced on at the small test size (conv32p, convp16: flat 2-D
+    style-encoder convs with masks and residuals, LeakyReLU / AdaIN prologues, ReLU, decoder and vocoder convs, forward
+    and input gradients) against the same graphs on the tiled kernel: the operands are rounded identically, so the
+    results may differ by fp32 summation order only."""
+    import stylish_tts_amd as S
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from stylish_tts_amd import lib as L
+    cs = env["cs"]
+    mel = torch.randn(3, 1, 80, 161, generator=torch.Generator().manual_seed(9))
+    gs = torch.randn(3, 64, generator=torch.Generator().manual_seed(10))
+    out = {}
+    for mode in ("tiled", "persistent"):
+        for k in ("STY_NO_CONVP16", "STY_NO_CONV32P", "STY_CONVP16_MIN_TILES", "STY_CONV32P_MIN_TILES"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "tiled":
+            monkeypatch.setenv("STY_NO_CONVP16", "1")
+            monkeypatch.setenv("STY_NO_CONV32P", "1")
+        else:
+            monkeypatch.setenv("STY_CONVP16_MIN_TILES", "1")
+            monkeypatch.setenv("STY_CONV32P_MIN_TILES", "1")
+        se = S.MelStyleEncoder()
+        se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+        se = se.to(DEV).enable_training().set_train_opts(compute_bf16=True)
+        L.prof_report(512)
+        L.load().sty_prof_enable(1)
+        style = se.forward_train(dev(mel))
+        se.backward(dev(gs))
+        sp = S.SpeechPredictor()
+        sp.load_state_dict({k: v.clone() for k, v in env["P"].items()}, strict=False)
+        sp = sp.to(DEV).enable_training().set_train_opts(compute_bf16=True)
+        audio = sp.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(env["ali"]), dev(cs["pitch"]),
+                                 dev(cs["energy"]), dev(env["voiced"]), dev(cs["style"]), dev(cs["pitch"]),
+                                 noise=dev(cs["noise"]))
+        d_style, _ = sp.backward(torch.sign(audio) / audio.numel(), want_energy=False)
+        torch.cuda.synchronize()
+        L.load().sty_prof_enable(0)
+        names = {r["name"] for r in L.prof_report(512)}
+        has = any(n.startswith("convp16") for n in names), any(n.startswith("conv32p") for n in names)
+        assert has == ((True, True) if mode == "persistent" else (False, False)), names
+        out[mode] = dict(style=style.cpu(), audio=audio.cpu(), d_style=d_style.cpu(),
+                         gse=torch.cat([p.grad.flatten().cpu() for p in se.parameters()]),
+                         gsp=torch.cat([p.grad.flatten().cpu() for p in sp.parameters()]))
+    a, b = out["tiled"], out["persistent"]
+    rel = lambda x, y: ((x - y).norm() / y.norm()).item()
+    print(f"\n  persistent vs tiled (bf16 mode): style {rel(b['style'], a['style']):.2e}  audio {rel(b['audio'], a['audio']):.2e}  "
+          f"style-encoder grads {rel(b['gse'], a['gse']):.2e}  predictor grads {rel(b['gsp'], a['gsp']):.2e}  "
+          f"d_style {rel(b['d_style'], a['d_style']):.2e}")
+    assert rel(b["style"], a["style"]) <= 1e-5 and rel(b["gse"], a["gse"]) <= 1e-4
+    assert rel(b["audio"], a["audio"]) <= 1e-3 and rel(b["gsp"], a["gsp"]) <= 3e-2 and rel(b["d_style"], a["d_style"]) <= 3e-2
+
+
 def _sub(t, stride=97):
     t = t.detach().flatten()
     return t[::stride] if t.numel() > 4096 else t
