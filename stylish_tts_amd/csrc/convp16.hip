@@ -29,6 +29,10 @@ constexpr int Q_TT = 128;    // columns per tile
 constexpr int Q_PITCH = 40;  // halfs per column in the B ring (32 channels + 8 pad = 80 bytes)
 constexpr int Q_MAXQ = 3;    // 64-column groups of a staged row (128 + halo <= 192)
 constexpr int Q_MAXK = 5;
+constexpr int Q_NP = 12;     // producer waves: 4 row octets x 3 column groups of the input tile; weight fragments round-robin
+                             // (with 4 producers a chunk step took 4.5 us against 0.3 us of MFMAs: ~500 instructions and 72
+                             // dword loads per producer wave and step -- the staging work has to be spread wider)
+constexpr int Q_THREADS = 64 * (4 + Q_NP);
 
 struct QTile {
   int b, t0, cot;
@@ -43,98 +47,181 @@ __device__ __forceinline__ QTile q_tile(int tile, int tiles_per_row, int ncot) {
 }
 
 // registers of one staged chunk in flight (producer)
+struct QStageB {
+  float bv[8];  // input tile: 8 rows x the 64-column group of this wave
+};
 template <int NFRAG>
-struct QStage {
-  float bv[Q_MAXQ][8];  // input tile: 8 rows of this wave x 3 column groups
-  float av[NFRAG][8];   // weights: NFRAG A fragments of this wave x 8 reduction channels
+struct QStageA {
+  float av[NFRAG][8];  // weights: NFRAG A fragments of this wave x 8 reduction channels
 };
 
-template <int MTW, int PRO, int NFRAG>
-__device__ __forceinline__ void q_issue(const ConvArgs& a, QTile tl, int chunk, int LWt, int pw, int lane, QStage<NFRAG>& R) {
-  const int T = a.T, K = a.w.K, CinP = a.w.CinP, CoutP = a.w.CoutP, Cin = a.w.Cin;
-  constexpr int CO32 = 2 * MTW;
+// A position in the workgroup's sequence of chunk steps, advanced incrementally.  (The first version recomputed tile, chunk
+// and the flat-2-D row split from the step number in every wave and step: eight emulated integer divisions, ~800 scalar
+// instructions per wave and step on the CU's one scalar unit, sixteen waves: the scalar unit paced the kernel.)
+struct QCursor {
+  int n;        // chunk step number
+  int chunk;    // chunk within the tile
+  QTile tl;     // tile coordinates
+  int kh, cc;   // flat 2-D: (image-row tap, source channel) of reduction row chunk * 32 + 8 * rg
+};
+__device__ __forceinline__ void q_cursor_rows(const ConvArgs& a, QCursor& c, int rg) {  // (kh, cc) at chunk 0 of a tile
+  c.kh = 0;
+  c.cc = 8 * rg;
+  if (a.flatW)
+    while (c.cc >= a.Cin2d) {
+      c.cc -= a.Cin2d;
+      ++c.kh;
+    }
+}
+__device__ __forceinline__ QCursor q_cursor_begin(const ConvArgs& a, int first, int tiles_per_row, int ncot, int rg) {
+  QCursor c;
+  c.n = 0;
+  c.chunk = 0;
+  c.tl = q_tile(first, tiles_per_row, ncot);  // the only divisions: once per workgroup
+  q_cursor_rows(a, c, rg);
+  return c;
+}
+__device__ __forceinline__ void q_cursor_next(const ConvArgs& a, QCursor& c, int nch, int tiles_per_row, int ncot, int rg) {
+  ++c.n;
+  if (++c.chunk < nch) {
+    if (a.flatW) {
+      c.cc += 32;
+      while (c.cc >= a.Cin2d) {
+        c.cc -= a.Cin2d;
+        ++c.kh;
+      }
+    }
+    return;
+  }
+  c.chunk = 0;
+  if (++c.tl.cot == ncot) {
+    c.tl.cot = 0;
+    c.tl.t0 += Q_TT;
+    if (c.tl.t0 >= tiles_per_row * Q_TT) {
+      c.tl.t0 = 0;
+      ++c.tl.b;
+    }
+  }
+  q_cursor_rows(a, c, rg);
+}
+// The eight reduction rows a producer wave owns in the cursor's chunk: source row and time shift (flat 2-D: reduction row
+// (kh, cc) reads source row cc shifted by (kh - hpad) image rows).
+__device__ __forceinline__ void q_rows(const ConvArgs& a, const QCursor& c, int rg, int (&row)[8], int (&tsh)[8]) {
+  if (!a.flatW) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      row[r] = c.chunk * 32 + 8 * rg + r;
+      tsh[r] = 0;
+    }
+    return;
+  }
+  int kh = c.kh, cc = c.cc;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (cc >= a.Cin2d) {  // (Cin2d >= 8 on every layer of the path: at most one wrap inside eight rows)
+      cc -= a.Cin2d;
+      ++kh;
+    }
+    row[r] = cc;
+    tsh[r] = (kh - a.hpad) * a.flatW;
+    ++cc;
+  }
+}
+
+__device__ __forceinline__ void q_issue_b(const ConvArgs& a, const QCursor& cu, int LWt, int pw, int lane, QStageB& R) {
+  const QTile tl = cu.tl;
+  const int chunk = cu.chunk;
+  const int T = a.T, Cin = a.w.Cin;
+  const int rg = pw & 3, q = pw >> 2;  // row octet, 64-column group
   // ---- input tile ----
   const int crow = a.flatW ? a.Cin2d : Cin;  // rows of the source slab
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x[0] + (size_t)tl.b * crow * T), 0, crow * T * 4, 0x00020000);
-  const int voff = (tl.t0 - a.pad + lane) * 4;
+  const int voff = (tl.t0 - a.pad + lane + 64 * q) * 4;
+  // Every load is issued unconditionally: a dead row (padding up to CinP) or a column group beyond the tile gets an
+  // offset outside the descriptor's range instead (the hardware returns 0 without touching memory).  Guarding the loads
+  // with their wave-uniform conditions made hipcc branch around each one: 1 800 basic blocks, twice as slow.
+  // The whole offset goes into the VECTOR offset: the hardware range-checks voffset only, not the scalar soffset (a
+  // negative lane offset with the row in soffset read as "out of range" -- the first column of every 64-column group).
+  constexpr int OOB = 0x7FFFFF00;
+  const bool qlive = q < Q_TT / 64 || 64 * q < LWt;
+  int row[8], tsh[8];
+  q_rows(a, cu, rg, row, tsh);
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int ci = chunk * 32 + 8 * pw + r;
-    int row = ci, tsh = 0;
-    if (a.flatW) {  // flat 2-D: reduction row (kh, cc) reads source row cc shifted by (kh - hpad) image rows
-      const int kh = ci / a.Cin2d;
-      row = ci - kh * a.Cin2d;
-      tsh = (kh - a.hpad) * a.flatW;
-    }
-    const bool live = ci < Cin;
-#pragma unroll
-    for (int q = 0; q < Q_MAXQ; ++q)
-      if (q < Q_TT / 64 || 64 * q < LWt)
-        R.bv[q][r] = live ? buf_load(rs, voff + 256 * q + (row * T + tsh) * 4) : 0.f;
+    const int ci = chunk * 32 + 8 * rg + r;
+    const int roff = (ci < Cin && qlive) ? (row[r] * T + tsh[r]) * 4 : OOB;
+    R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + roff, 0, 0));
   }
-  // ---- weights: fragment f = (tap, k-step, 32-cout block) -> lane (co = l31, k-block = hi) holds 8 reduction channels ----
+}
+// ---- weights: fragment f = (tap, k-step, 32-cout block) -> lane (co = l31, k-block = hi) holds 8 reduction channels ----
+template <int MTW, int NFRAG>
+__device__ __forceinline__ void q_issue_a(const ConvArgs& a, QTile tl, int chunk, int pw, int lane, QStageA<NFRAG>& R) {
+  const int K = a.w.K, CinP = a.w.CinP, CoutP = a.w.CoutP;
+  constexpr int CO32 = 2 * MTW;
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w.wp), 0, K * CinP * CoutP * 4, 0x00020000);
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int i = 0; i < NFRAG; ++i) {
-    const int f = pw + 4 * i;
+    const int f = pw + Q_NP * i;
     const int mb = f % CO32, ks = f / CO32;  // ks = tap * 2 + k-step
     const int k = ks >> 1, s = ks & 1;
     const int co = tl.cot * (32 * CO32) + mb * 32;
     const bool ok = f < K * 2 * CO32 && co < CoutP;
+    const int base = ok ? ((k * CinP + chunk * 32 + 16 * s) * CoutP + co) * 4 : 0;
+    const int vo = ok ? l31 * 4 : 0x7FFFFF00;  // out of range (checked on the vector offset): zero fragment
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      R.av[i][e] = ok ? buf_load(wrs, (((k * CinP + chunk * 32 + 16 * s + 8 * hi + e) * CoutP) + co + l31) * 4) : 0.f;
+      R.av[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, vo + (8 * hi + e) * CoutP * 4, base, 0));
   }
 }
 
-template <int MTW, int PRO, int NFRAG>
-__device__ __forceinline__ void q_commit(const ConvArgs& a, QTile tl, int chunk, int LWt, int pw, int lane, const QStage<NFRAG>& R,
-                                         __bf16* bring, bf16x8* aring) {
-  const int T = a.T, K = a.w.K, Cin = a.w.Cin;
-  constexpr int CO32 = 2 * MTW;
-  float pa[8], ps[8], al[8], ral[8];
-  int tsh[8];
-  bool live[8];
+template <int PRO>
+__device__ __forceinline__ void q_commit_b(const ConvArgs& a, const QCursor& cu, int LWt, int pw, int lane, const QStageB& R,
+                                           __bf16* bring) {
+  const QTile tl = cu.tl;
+  const int chunk = cu.chunk;
+  const int T = a.T, Cin = a.w.Cin;
+  const int rg = pw & 3, q = pw >> 2;
+  if (!(q < Q_TT / 64 || 64 * q < LWt)) return;
+  int row_[8], tsh[8];
+  q_rows(a, cu, rg, row_, tsh);
+  const int j = lane + 64 * q;
+  const int t = tl.t0 - a.pad + j;
+  float v[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int ci = chunk * 32 + 8 * pw + r;
-    live[r] = ci < Cin;
-    tsh[r] = a.flatW ? (ci / a.Cin2d - a.hpad) * a.flatW : 0;
-    pa[r] = 1.f, ps[r] = 0.f, al[r] = 1.f, ral[r] = 1.f;
-    if (live[r]) {
+    const int ci = chunk * 32 + 8 * rg + r;
+    const bool live = ci < Cin;
+    float pa = 1.f, ps = 0.f, al = 1.f, ral = 1.f;
+    if (live) {
       if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
-        pa[r] = a.pa[(size_t)tl.b * Cin + ci];
-        if constexpr (PRO != PRO_SCALE) ps[r] = a.ps[(size_t)tl.b * Cin + ci];
+        pa = a.pa[(size_t)tl.b * Cin + ci];
+        if constexpr (PRO != PRO_SCALE) ps = a.ps[(size_t)tl.b * Cin + ci];
       }
       if constexpr (PRO == PRO_AFFINE_SNAKE) {
-        al[r] = a.palpha[ci];
-        ral[r] = 1.0f / al[r];
+        al = a.palpha[ci];
+        ral = 1.0f / al;
       }
     }
-  }
-#pragma unroll
-  for (int q = 0; q < Q_MAXQ; ++q) {
-    if (!(q < Q_TT / 64 || 64 * q < LWt)) continue;
-    const int j = lane + 64 * q;
-    const int t = tl.t0 - a.pad + j;
+    const int tt = t + tsh[r];  // the source position of this row (flat 2-D: shifted by whole image rows)
+    const bool in = live && tt >= 0 && tt < T;
     float mk = 1.f;
-    if constexpr (PRO == PRO_MASK) mk = (t >= 0 && t < T) ? a.mask[(size_t)tl.b * T + t] : 0.f;
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int tt = t + tsh[r];
-      v[r] = (live[r] && tt >= 0 && tt < T) ? pro_apply<PRO>(R.bv[q][r], pa[r], ps[r], al[r], ral[r], mk) : 0.f;  // zero padding AFTER the prologue
-    }
-    if (j < LWt)
-      *reinterpret_cast<bf16x8*>(bring + (size_t)j * Q_PITCH + 8 * pw) =
-          sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    if constexpr (PRO == PRO_MASK) mk = in ? a.mask[(size_t)tl.b * T + tt] : 0.f;
+    v[r] = in ? pro_apply<PRO>(R.bv[r], pa, ps, al, ral, mk) : 0.f;  // zero padding AFTER the prologue
   }
+  if (j < LWt)
+    *reinterpret_cast<bf16x8*>(bring + (size_t)j * Q_PITCH + 8 * rg) =
+        sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+template <int MTW, int NFRAG>
+__device__ __forceinline__ void q_commit_a(const ConvArgs& a, int pw, int lane, const QStageA<NFRAG>& R, bf16x8* aring) {
+  const int K = a.w.K;
+  constexpr int CO32 = 2 * MTW;
 #pragma unroll
   for (int i = 0; i < NFRAG; ++i) {
-    const int f = pw + 4 * i;
+    const int f = pw + Q_NP * i;
     if (f < K * 2 * CO32)
       aring[f * 64 + lane] = sty_pack_bf16(R.av[i][0], R.av[i][1], R.av[i][2], R.av[i][3], R.av[i][4], R.av[i][5],
                                            R.av[i][6], R.av[i][7]);
@@ -142,7 +229,9 @@ __device__ __forceinline__ void q_commit(const ConvArgs& a, QTile tl, int chunk,
 }
 
 // ---- producer: drain the output stage of a finished tile ----
-// stage [64 MTW rows][128] fp32; a wave takes rows pw, pw + 4, ... two at a time (lanes 0-31 / 32-63), four columns per lane
+// stage [64 MTW rows][128] fp32; a wave takes row pairs (lanes 0-31 / 32-63), four columns per lane, four pairs per batch
+// (16 registers of residual in flight).  Kept small on purpose -- a rolled batch loop, one call site, the rare row-end
+// lanes on a rolled scalar loop: fully unrolled with both store paths per row it was two thirds of the kernel's code.
 template <int MTW, int RELU>
 __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTile tl, int pw, int lane) {
   const int T = a.T, Cout = a.w.Cout;
@@ -161,58 +250,55 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
     for (int e = 0; e < 4; ++e) om[e] = t + e < T ? a.out_mask[(size_t)tl.b * T + t + e] : 0.f;
   }
   const bool post = a.out_mask && a.out_mask_post;
-  constexpr int NIT = ROWS / 8;  // row pairs per wave
-  // residual rows of the whole drain first (16-byte loads), then stage -> epilogue -> store
-  float4 res[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int co = tl.cot * ROWS + 8 * it + 2 * pw + half;
-    res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!a.residual || co >= Cout) continue;
-    if (wide) {
-      res[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, t * 4, co * T * 4, 0));
-    } else {
-      float e4[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        e4[e] = t + e < T ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (t + e) * 4, co * T * 4, 0)) : 0.f;
-      res[it] = make_float4(e4[0], e4[1], e4[2], e4[3]);
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int rl = 8 * it + 2 * pw + half;
+  const float pre_scale = a.out_scale;
+#pragma unroll 1
+  for (int rl = 2 * pw + half; rl < ROWS; rl += 2 * Q_NP) {
     const int co = tl.cot * ROWS + rl;
     if (co >= Cout) continue;
+    // (a 16-byte residual load may run past the end of the row for the last lanes of a row whose length is not a multiple
+    // of four: those lanes re-read element by element)
+    float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.residual) res = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, t * 4, co * T * 4, 0));
     const float4 sv = *reinterpret_cast<const float4*>(ost + rl * Q_TT + 4 * l);
     const float bi = a.w.bias ? a.w.bias[co] : 0.f;
     float v[4] = {sv.x + bi, sv.y + bi, sv.z + bi, sv.w + bi};
-    const float rr[4] = {res[it].x, res[it].y, res[it].z, res[it].w};
+    float rr[4] = {res.x, res.y, res.z, res.w};
+    if (!wide && a.residual) {
+#pragma unroll 1
+      for (int e = 1; e < 4; ++e) {
+        const float x = t + e < T ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (t + e) * 4, co * T * 4, 0)) : 0.f;
+        rr[1] = e == 1 ? x : rr[1];
+        rr[2] = e == 2 ? x : rr[2];
+        rr[3] = e == 3 ? x : rr[3];
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (RELU) v[e] = fmaxf(v[e], 0.f);
-      v[e] *= a.out_scale;
+      v[e] *= pre_scale;
       if (a.out_mask && !post) v[e] *= om[e];
       v[e] += rr[e];
       if (post) v[e] *= om[e];
     }
     if (wide) {
       const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o4),
-                                             yrs, t * 4, co * T * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(
+          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o4), yrs, t * 4, co * T * 4, 0);
     } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (t + e < T) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), yrs, (t + e) * 4, co * T * 4, 0);
+#pragma unroll 1
+      for (int e = 0; e < 4; ++e) {
+        const float x = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
+        if (t + e < T) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), yrs, (t + e) * 4, co * T * 4, 0);
+      }
     }
   }
 }
 
 template <int MTW, int PRO, int RELU>
-__global__ __launch_bounds__(512, 2) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles) {
+__global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CO32 = 2 * MTW;
-  constexpr int NFRAG = MTW == 2 ? 6 : 5;  // A fragments per producer wave and chunk: K <= 3 at 128 couts, K <= 5 at 64
+  constexpr int NFRAG = 2;  // A fragments per producer wave and chunk: K 2 CO32 <= 24 over 12 waves
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -232,50 +318,80 @@ __global__ __launch_bounds__(512, 2) void convp16_kernel(ConvArgs a, int tiles_p
   if (count == 0) return;
 
   const int nsteps = count * (nch + 1);  // per tile: nch chunk steps + one output-stage step
-  if (!consumer) {
-    QStage<NFRAG> R;
-    const QTile t0 = q_tile(first, tiles_per_row, ncot);
-    q_issue<MTW, PRO, NFRAG>(a, t0, 0, LWt, wave - 4, lane, R);
-    q_commit<MTW, PRO, NFRAG>(a, t0, 0, LWt, wave - 4, lane, R, bring, aring);
-  }
-  __syncthreads();
-
+  const int nchunks = count * nch;       // chunk steps of this workgroup, numbered n = tile * nch + chunk
   // The two roles run SEPARATE loops over the same step sequence (one s_barrier per step in each: the hardware counts
   // arrivals, not code addresses).  One merged loop makes the consumers' 64 accumulator registers live across the
   // producers' staging code as well: 80-260 spilled registers at 128 couts.
-#define STY_STEP_VARS                                                                             \
-  const int ti = step / (nch + 1), c = step - ti * (nch + 1); /* c == nch: output-stage step */   \
-  const QTile tl = q_tile(first + ti, tiles_per_row, ncot);
   if (!consumer) {
-    // ---- producer: stage what the consumers need in step + 1; drain the previous tile during chunk 0 ----
-    const int pw = wave - 4;
-    int g = 0;  // chunk steps done (ring slot = g & 1)
-    for (int step = 0; step < nsteps; ++step) {
-      STY_STEP_VARS
-      (void)tl;
-      const int ns = step + 1;
-      const int nti = ns / (nch + 1), nc = ns - nti * (nch + 1);
-      const bool stage = ns < nsteps && nc < nch;
-      const QTile ntl = q_tile(first + (stage ? nti : ti), tiles_per_row, ncot);
-      const int slot = (g + (c < nch ? 1 : 0)) & 1;  // the chunk after the one being consumed (or the next after a tile end)
-      QStage<NFRAG> R;
-      if (stage) q_issue<MTW, PRO, NFRAG>(a, ntl, nc, LWt, pw, lane, R);
-      if (c == 0 && ti > 0) q_drain<MTW, RELU>(a, ost, q_tile(first + ti - 1, tiles_per_row, ncot), pw, lane);
-      if (stage) q_commit<MTW, PRO, NFRAG>(a, ntl, nc, LWt, pw, lane, R, bring + slot * bsz, aring + slot * asz);
-      if (c < nch) ++g;
+    // ---- producer ----
+    // Chunk n (input tile AND weights: the memory counter retires in order, so a wait for a younger load would wait for
+    // every older one too) is committed to LDS ring slot n & 1 during the step before the consumers need it; its loads
+    // were issued TWO chunk steps earlier into register set n & 1 (a chunk step is ~0.3 us of MFMAs, a load round trip 1-2 us: with
+    // the loads issued only one step ahead every step waited for them -- measured: no faster than the tiled kernel).
+    const int pw = wave - 4, rg = pw & 3;
+    QStageB R0, R1;
+    QStageA<NFRAG> A0, A1;
+    // two cursors: the chunk being committed and the chunk whose loads are being issued (two ahead)
+    QCursor cc_ = q_cursor_begin(a, first, tiles_per_row, ncot, rg), ci_ = cc_;
+#define STY_Q_ISSUE(R, RA_)                                                  \
+  if (ci_.n < nchunks) {                                                     \
+    q_issue_a<MTW, NFRAG>(a, ci_.tl, ci_.chunk, pw, lane, RA_);              \
+    q_issue_b(a, ci_, LWt, pw, lane, R);                                     \
+  }                                                                          \
+  q_cursor_next(a, ci_, nch, tiles_per_row, ncot, rg);
+#define STY_Q_STEP(R, RA_) /* commit the commit cursor's chunk from its register set, then request the chunk two ahead */ \
+  {                                                                                                      \
+    q_commit_a<MTW, NFRAG>(a, pw, lane, RA_, aring + (cc_.n & 1) * asz);                                 \
+    q_commit_b<PRO>(a, cc_, LWt, pw, lane, R, bring + (cc_.n & 1) * bsz);                                \
+    q_cursor_next(a, cc_, nch, tiles_per_row, ncot, rg);                                                 \
+    STY_Q_ISSUE(R, RA_)                                                                                  \
+  }
+    STY_Q_ISSUE(R0, A0)
+    STY_Q_ISSUE(R1, A1)
+    STY_Q_STEP(R0, A0)
+    __syncthreads();
+    // consumers' position: tile ti, step c within the tile (c == nch: output-stage step); the tile before it for the drain
+    int ti = 0, c = 0;
+    QTile cur_tl = q_tile(first, tiles_per_row, ncot), prev_tl = cur_tl;
+    for (int step = 0; step <= nsteps; ++step) {  // one more trip than the consumers: the last tile's drain
+      if ((c == 0 && ti > 0) || step == nsteps) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane);
+      if (step == nsteps) break;
+      // the chunk the consumers need in the NEXT step is committed now: during a chunk step that is not the tile's last
+      // (after the last one comes the output-stage step), and during the output-stage step (the next tile's chunk 0)
+      const bool due = cc_.n < nchunks && (c == nch || c + 1 < nch);
+      if (due) {  // chunk n lives in register set n & 1 (copying a set would wait for its loads in flight)
+        if (cc_.n & 1) {
+          STY_Q_STEP(R1, A1)
+        } else {
+          STY_Q_STEP(R0, A0)
+        }
+      }
+      if (++c > nch) {  // next tile
+        c = 0;
+        ++ti;
+        prev_tl = cur_tl;
+        if (++cur_tl.cot == ncot) {
+          cur_tl.cot = 0;
+          cur_tl.t0 += Q_TT;
+          if (cur_tl.t0 >= tiles_per_row * Q_TT) {
+            cur_tl.t0 = 0;
+            ++cur_tl.b;
+          }
+        }
+      }
       __syncthreads();
     }
-    q_drain<MTW, RELU>(a, ost, q_tile(first + count - 1, tiles_per_row, ncot), pw, lane);
+#undef STY_Q_STEP
+#undef STY_Q_ISSUE
     return;
   }
+  __syncthreads();  // (the producers' prologue barrier)
   // ---- consumers ----
   const int wm = wave >> 1, wn = wave & 1;  // cout half, column half
   f32x16 acc[MTW][2];
-  int g = 0;
+  int g = 0, c = 0;
 #define STY_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
   for (int step = 0; step < nsteps; ++step) {
-    STY_STEP_VARS
-    (void)tl;
     if (c < nch) {
       // one 32-channel chunk
       if (c == 0) {
@@ -338,10 +454,10 @@ __global__ __launch_bounds__(512, 2) void convp16_kernel(ConvArgs a, int tiles_p
           for (int n = 0; n < 2; ++n) ost[row * Q_TT + wn * 64 + n * 32 + l31] = acc[m][n][r];
         }
     }
+    if (++c > nch) c = 0;
     __syncthreads();
   }
 #undef STY_SGB
-#undef STY_STEP_VARS
 }
 
 static int q_num_cus() {
@@ -397,7 +513,7 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   char fam[48];
   snprintf(fam, sizeof(fam), "convp16_kernel<%d,true>", MTW);
   ProfScope prof(fam, flops, bytes, st, detail);
-  hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU>), dim3(grid), dim3(512), lds, st, a, tiles_per_row, ncot, ntiles);
+  hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot, ntiles);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
