@@ -1,0 +1,155 @@
+"""Batch / wire formats either side of the hot path (stylish_tts_amd/stage_io.py): batch-size and
+normalization JSON files, the accelerate checkpoint layout (pinned against accelerate itself, the reference's own
+checkpoint writer), the bookkeeping classes (pinned against values dumped from the reference's classes), and -- on the
+GPU -- the normalization statistics pass against the oracle's mel front end."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_bookkeeping_classes_match_the_reference_values():
+    from stylish_tts_amd.stage_io import Manifest, NormalizationStats, calc_mean_std
+    fx = json.load(open(os.path.join(G, "stage_io_values.json")))
+    assert NormalizationStats().state_dict() == fx["normalization_default"]
+    ns = NormalizationStats()
+    ns.load_state_dict({})
+    assert ns.state_dict() == fx["normalization_after_empty_load"]  # energy std falls back to 0.0 there, not 1.0
+    md = {k: (v if v != float("inf") else "inf") for k, v in Manifest().state_dict().items()}
+    assert md == fx["manifest_default"]
+    cases = ((-400.0, 2000.0, 100), (3.5, 12.25, 1), (0.0, 0.0, 0))
+    for (a, b, n), want in zip(cases, fx["calc_mean_std"]):
+        got = calc_mean_std(torch.tensor(a, dtype=torch.float64), torch.tensor(b, dtype=torch.float64), n)
+        assert got == pytest.approx(tuple(want), rel=1e-12)
+
+
+def test_batch_sizes_file(tmp_path):
+    from stylish_tts_amd.stage_io import BatchSizes
+    bs = BatchSizes(str(tmp_path), "acoustic")
+    assert bs.get_batch_size(7) == 1 and not bs.batch_sizes_exist()
+    bs.set_batch_size(7, 16)
+    bs.set_batch_size(12, 8)
+    bs.save_batch_sizes()
+    assert json.load(open(tmp_path / "acoustic_batch_sizes.json")) == {"7": 16, "12": 8}  # bins are STRING keys
+    other = BatchSizes(str(tmp_path), "acoustic")
+    other.load_batch_sizes()
+    assert other.batch_sizes_exist() and other.get_batch_size(7) == 16 and other.get_batch_size("12") == 8
+    assert other.get_steps({7: list(range(40)), 12: list(range(20)), 3: list(range(5))}) == 40 // 16 + 20 // 8 + 5
+
+
+def test_checkpoint_layout_is_accelerates(tmp_path):
+    """accelerator.save_state(dir, safe_serialization=False) of thirteen models prepared in build_model's key order and
+    four registered objects (train.py:207-211, train_context.py:110-113) vs stage_io's file table, both directions."""
+    accelerate = pytest.importorskip("accelerate")
+    from stylish_tts_amd import stage_io as IO
+    acc = accelerate.Accelerator(cpu=True)
+    torch.manual_seed(0)
+    models = {n: acc.prepare(torch.nn.Linear(3 + i, 2)) for i, n in enumerate(IO.MODEL_ORDER)}
+
+    class Obj:
+        def __init__(self, v):
+            self.v = v
+
+        def state_dict(self):
+            return {"v": self.v}
+
+        def load_state_dict(self, s):
+            self.v = s["v"]
+
+    man, norm = IO.Manifest(), IO.NormalizationStats()
+    man.current_epoch, man.current_total_step, man.stage = 3, 1234, "acoustic"
+    norm.mel_log_mean, norm.frames = -5.5, 999
+    for o in (Obj("config"), Obj("model_config"), man, norm):
+        acc.register_for_checkpointing(o)
+    d = IO.checkpoint_dir(str(tmp_path), "checkpoint", man)
+    assert d.endswith("checkpoint_00003_step_000001234")
+    acc.save_state(d, safe_serialization=False)
+    for n in IO.MODEL_ORDER:
+        assert os.path.exists(os.path.join(d, IO.model_file(n))), (n, sorted(os.listdir(d)))
+    # read what accelerate wrote
+    fresh = {n: torch.nn.Linear(3 + IO.MODEL_ORDER.index(n), 2) for n in ("speech_predictor", "speech_style_encoder")}
+    man2, norm2 = IO.Manifest(), IO.NormalizationStats()
+    IO.load_checkpoint(d, fresh, man2, norm2)
+    for n, m in fresh.items():
+        assert torch.equal(m.weight, acc.unwrap_model(models[n]).weight)
+    assert man2.current_total_step == 1234 and man2.stage == "acoustic" and norm2.frames == 999 and norm2.mel_log_mean == -5.5
+    # write two models + the objects; accelerate reads the directory back
+    with torch.no_grad():
+        for m in fresh.values():
+            m.weight.add_(1.0)
+    man2.current_total_step = 2000
+    IO.save_checkpoint(d, fresh, man2, norm2)
+    acc.load_state(d)
+    for n, m in fresh.items():
+        assert torch.equal(m.weight, acc.unwrap_model(models[n]).weight)
+    assert man.current_total_step == 2000
+
+
+def test_normalization_priority_and_json_layout(tmp_path, monkeypatch):
+    from stylish_tts_amd import stage_io as IO
+    from stylish_tts_amd.config import Section
+    mc = Section(sample_rate=24000, n_mels=80, n_fft=512, hop_length=300, win_length=512)
+    out, ds = tmp_path / "out", tmp_path / "ds"
+    os.makedirs(ds)
+    calls = []
+    monkeypatch.setattr(IO, "compute_log_mel_stats", lambda *a, **k: (calls.append(1), (-6.0, 2.5, 1.25, 0.5, 4321))[1])
+    st = IO.NormalizationStats()
+    assert IO.init_normalization(st, str(out), str(ds), ["a.wav|x"], str(ds), mc) == "computed" and calls == [1]
+    want_keys = ["mel_log_mean", "mel_log_std", "energy_log2_mean", "energy_log2_std", "frames", "sample_rate", "n_mels",
+                 "n_fft", "hop_length", "win_length"]
+    for f in (out / "normalization.json", ds / "normalization.json"):
+        data = json.load(open(f))
+        assert list(data) == want_keys and data["frames"] == 4321 and data["mel_log_mean"] == -6.0
+    st2 = IO.NormalizationStats()
+    assert IO.init_normalization(st2, str(out), str(ds), [], str(ds), mc) == "file" and calls == [1]
+    assert st2.state_dict() == st.state_dict()
+    st3 = IO.NormalizationStats()
+    st3.load_state_dict(dict(mel_log_mean=-7.0, mel_log_std=3.0, energy_log2_mean=1.0, energy_log2_std=2.0, frames=10))
+    assert IO.init_normalization(st3, str(out), str(ds), [], str(ds), mc) == "checkpoint"
+    assert json.load(open(out / "normalization.json"))["mel_log_mean"] == -7.0  # a checkpoint's statistics win
+
+
+@pytest.mark.gpu
+def test_normalization_statistics_pass_vs_oracle(tmp_path):
+    """compute_log_mel_stats on the HIP mel front end over a small synthetic sample_dataset vs the same sums taken from
+    the oracle's mel front end on the CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_sample_dataset as MS
+    from oracle.frontend import calculate_mel
+    from stylish_tts_amd import stage_io as IO
+    root = str(tmp_path / "ds")
+    MS.make(root, 6, 77)
+    lines = open(os.path.join(root, "training-list.txt"), encoding="utf-8").read().splitlines()
+    got = IO.compute_log_mel_stats(lines, os.path.join(root, "wav-dir"), 24000, "cuda")
+    n = 0
+    sx = sx2 = ex = ex2 = torch.zeros((), dtype=torch.float64)
+    en = 0
+    for ln in lines:
+        w, _ = IO._read_wav(os.path.join(root, "wav-dir", ln.split("|")[0]))
+        lm = calculate_mel(torch.tensor(w, dtype=torch.float32)[None], 512, 512, 300, mean=0.0, std=1.0)[0].double()
+        n += lm.numel()
+        sx, sx2 = sx + lm.sum(), sx2 + (lm * lm).sum()
+        e = torch.log((torch.exp(lm) - 1e-5).clamp_min(0).unsqueeze(1).norm(dim=2))
+        en += e.numel()
+        ex, ex2 = ex + e.sum(), ex2 + (e * e).sum()
+    want = IO.calc_mean_std(sx, sx2, n) + IO.calc_mean_std(ex, ex2, en) + (n,)
+    print("\n  HIP", got, "\n  oracle", want)
+    assert got[4] == want[4]
+    for a, b in zip(got[:4], want[:4]):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
+
+
+@pytest.mark.gpu
+def test_pinned_prefetcher_delivers_batches_in_order():
+    from stylish_tts_amd.stage_io import PinnedPrefetcher
+    batches = [(torch.full((4, 5), float(i)), torch.arange(3) + i, ["p%d" % i]) for i in range(5)]
+    seen = []
+    for waves, ints, paths in PinnedPrefetcher(batches, "cuda:0"):
+        assert waves.is_cuda and ints.is_cuda
+        seen.append((waves.mean().item(), ints[0].item(), paths[0]))
+    assert seen == [(float(i), i, "p%d" % i) for i in range(5)]
