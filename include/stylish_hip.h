@@ -155,6 +155,21 @@ int sty_convnext_fwd(sty_model *m, const char *prefix, int B, int C, int T, cons
 /* AdaptiveGeneratorBlock (ada_norm.py:109-120), 32 channels, k=11, dil 1/3/5.                         */
 int sty_resblock_fwd(sty_model *m, const char *prefix, int B, int T, const float *x, const float *style, float *y,
                      void *workspace, size_t ws_bytes, void *stream);
+/* The same two sub-modules in the TRAINING graph, forward and backward in one call (unit parity of the fused backward
+ * kernels -- the recompute-based ConvNeXt32 backward, the AdaIN / Snake prologue backward, the depthwise-conv and
+ * LayerNorm backward): kind "convnext" or "resblock"; x, gy (= d loss / d y) [B,C,T] -> y, gx [B,C,T], d_style [B,64];
+ * parameter gradients are added to the gradients bound with sty_model_bind_grad.                             */
+int sty_block_train_workspace_bytes(sty_model *m, const char *kind, const char *prefix, int B, int C, int T,
+                                    size_t *bytes);
+int sty_block_fwd_bwd(sty_model *m, const char *kind, const char *prefix, int B, int C, int T, const float *x,
+                      const float *style, const float *gy, float *y, float *gx, float *d_style, void *workspace,
+                      size_t ws_bytes, void *stream);
+/* Softmax attention (text_encoder.py:234-280 with `lengths`, conformer.py:85-91 without) forward + backward on separate
+ * q, k, v [B, 8*DH, T] (DH = 16 or 64): d_o -> dq, dk, dv.                                                    */
+int sty_attention_workspace_bytes(int B, int H, int T, size_t *bytes);
+int sty_attention_fwd_bwd(int B, int H, int DH, int T, const float *q, const float *k, const float *v,
+                          const int64_t *lengths, const float *d_o, float *o, float *dq, float *dk, float *dv,
+                          void *workspace, size_t ws_bytes, void *stream);
 /* STFT(64, hop 4).transform -> (mag, atan2(y,x)) bins 0..31, last frame dropped (generator.py:724-729);
  * wave [B,N] -> spec, phase [B,32,N/4].                                                               */
 int sty_stft64_fwd(int B, int N, const float *wave, float *spec, float *phase, void *stream);

@@ -2174,6 +2174,130 @@ int sty_resblock_fwd(sty_model* m, const char* prefix, int B, int T, const float
   return r.rc;
 }
 
+// ---- unit backward entry points: one sub-module in the training graph, forward + backward ----
+static int find_block(sty_model* m, const char* kind, const char* prefix, int C, int* k, const void** blk) {
+  const std::string p(prefix);
+  if (std::string(kind) == "convnext") {
+    auto it = m->params.find(p + ".dwconv.weight");
+    if (it == m->params.end()) {
+      set_error("no such block: %s", prefix);
+      return STY_EINVAL;
+    }
+    auto match = [&](const ConvNeXt& c) { return c.dw_w == it->second.p; };
+    const ConvNeXt* b = nullptr;
+    for (const ConvNeXt& c : m->voc.amp_convnext)
+      if (match(c)) b = &c;
+    for (const ConvNeXt& c : m->voc.phase_convnext)
+      if (match(c)) b = &c;
+    for (int i = 0; i < 3; ++i)
+      if (match(m->voc.upblock[i])) b = &m->voc.upblock[i];
+    if (!b || b->C != C) {
+      set_error("block %s not found or channel mismatch", prefix);
+      return STY_EINVAL;
+    }
+    *k = 0;
+    *blk = b;
+    return STY_OK;
+  }
+  if (std::string(kind) == "resblock") {
+    const ResBlock32* b = nullptr;
+    if (p.size() >= 15 && p.compare(p.size() - 15, 15, "amp_prior_block") == 0) b = &m->voc.amp_prior_block;
+    if (p.size() >= 17 && p.compare(p.size() - 17, 17, "phase_prior_block") == 0) b = &m->voc.phase_prior_block;
+    if (!b || C != 32) {
+      set_error("no such resblock (32 channels): %s", prefix);
+      return STY_EINVAL;
+    }
+    *k = 1;
+    *blk = b;
+    return STY_OK;
+  }
+  set_error("sty_block: kind must be \"convnext\" or \"resblock\", not %s", kind);
+  return STY_EINVAL;
+}
+
+int sty_block_train_workspace_bytes(sty_model* m, const char* kind, const char* prefix, int B, int C, int T,
+                                    size_t* bytes) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!m->train_enabled || !kind || !prefix || !bytes || B <= 0 || C <= 0 || T <= 0) {
+    set_error("sty_block_train_workspace_bytes: bad argument or training not enabled");
+    return STY_EINVAL;
+  }
+  int k = 0;
+  const void* blk = nullptr;
+  if ((rc = find_block(m, kind, prefix, C, &k, &blk))) return rc;
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_block_fwd_bwd(m->trainer, k, blk, B, C, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                               nullptr, bytes);
+}
+
+int sty_block_fwd_bwd(sty_model* m, const char* kind, const char* prefix, int B, int C, int T, const float* x,
+                      const float* style, const float* gy, float* y, float* gx, float* d_style, void* workspace,
+                      size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "speech_predictor", "vocoder");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  if (!kind || !prefix || !x || !style || !gy || !workspace || B <= 0 || C <= 0 || T <= 0) {
+    set_error("sty_block_fwd_bwd: bad argument");
+    return STY_EINVAL;
+  }
+  int k = 0;
+  const void* blk = nullptr;
+  if ((rc = find_block(m, kind, prefix, C, &k, &blk))) return rc;
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->prepared = false;
+  if (!m->trainer) m->trainer = trainer_create(m);
+  rc = trainer_block_fwd_bwd(m->trainer, k, blk, B, C, T, x, style, gy, y, gx, d_style, workspace, ws_bytes, S(stream),
+                             nullptr);
+  if (rc) return rc;
+  return unpack_grads(m, S(stream));
+}
+
+// softmax attention forward + backward on separate q / k / v [B][H*DH][T] (DH = 16: the text encoder's VALU backward with
+// an optional length mask; DH = 64: the conformer's MFMA backward)
+int sty_attention_workspace_bytes(int B, int H, int T, size_t* bytes) {
+  if (!bytes || B <= 0 || H <= 0 || T <= 0) {
+    set_error("sty_attention_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  *bytes = (attention_bwd_ws_floats(B, H, T) + (size_t)B * H * T) * sizeof(float) + 1024;
+  return STY_OK;
+}
+int sty_attention_fwd_bwd(int B, int H, int DH, int T, const float* q, const float* k, const float* v,
+                          const int64_t* lengths, const float* d_o, float* o, float* dq, float* dk, float* dv,
+                          void* workspace, size_t ws_bytes, void* stream) {
+  size_t need = 0;
+  if (sty_attention_workspace_bytes(B, H, T, &need)) return STY_EINVAL;
+  if (!q || !k || !v || !d_o || !o || !dq || !dk || !dv || !workspace || ws_bytes < need || (DH != 16 && DH != 64) || H != 8) {
+    set_error("sty_attention_fwd_bwd: bad argument (H = 8, DH = 16 or 64, workspace >= %zu bytes)", need);
+    return STY_EINVAL;
+  }
+  hipStream_t st = S(stream);
+  const size_t n = (size_t)B * H * DH * T;
+  AttnArgs at;
+  at.q = q;
+  at.k = k;
+  at.v = v;
+  at.o = o;
+  at.qbs = at.kbs = at.vbs = at.obs = (size_t)H * DH * T;
+  at.T = T;
+  at.H = H;
+  at.scale = 1.0f / sqrtf((float)DH);
+  at.lengths = lengths;
+  float* ws = static_cast<float*>(workspace);
+  at.lse = ws;  // row log-sum-exp, kept for the MFMA backward
+  float* w2 = ws + (size_t)B * H * T;
+  STY_HIP(hipMemsetAsync(dq, 0, n * sizeof(float), st));
+  STY_HIP(hipMemsetAsync(dk, 0, n * sizeof(float), st));
+  STY_HIP(hipMemsetAsync(dv, 0, n * sizeof(float), st));
+  int rc = launch_attention(at, B, DH, st);
+  if (rc) return rc;
+  return launch_attention_bwd(at, d_o, dq, dk, dv, at.qbs, at.kbs, at.vbs, at.obs, B, DH, w2, st);
+}
+
 static float* g_bases = nullptr;  // default STFT(64) bases for the model-free entry points
 static int ensure_bases() {
   if (g_bases) return STY_OK;

@@ -1612,6 +1612,66 @@ int trainer_style_backward(Trainer* t, const float* d_style, hipStream_t st) {
   return t->rc;
 }
 
+// One sub-module in the training graph, forward and backward (unit parity of the fused backward kernels):
+// kind 0 = GeneratorConvNeXtBlock (blk = const ConvNeXt*), kind 1 = AdaptiveGeneratorBlock (blk = const ResBlock32*).
+int trainer_block_fwd_bwd(Trainer* t, int kind, const void* blk, int B, int C, int T, const float* x, const float* style,
+                          const float* gy, float* y, float* gx, float* d_style, void* ws, size_t ws_bytes, hipStream_t st,
+                          size_t* need) {
+  t->st = st;
+  t->B = B;
+  t->T = T;
+  t->rc = STY_OK;
+  t->ws = Bump();
+  t->dry = need != nullptr;
+  t->ws.base = need ? reinterpret_cast<char*>(size_t(1) << 30) : (char*)ws;
+  t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
+  t->peak = 0;
+  t->begin(style);
+  t->style_fc(nullptr);
+  const size_t n = (size_t)B * C * T;
+  float* xin = t->take<float>(n);  // the graph's own copy of the input (a resblock aliases its residual stream)
+  if (t->live()) {
+    hipError_t e = hipMemcpyAsync(xin, x, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "block input copy");
+  }
+  float* out = kind == 0 ? t->convnext(*static_cast<const ConvNeXt*>(blk), xin, T)
+                         : t->resblock(*static_cast<const ResBlock32*>(blk), xin, T);
+  if (t->live() && out && y) {
+    hipError_t e = hipMemcpyAsync(y, out, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "block output copy");
+  }
+  // backward from gy
+  t->side_begin();
+  t->d_style_out = d_style;
+  t->fc_bwd_done = false;
+  float* gO = t->G(out, n);
+  if (t->live() && gy) {
+    hipError_t e = hipMemcpyAsync(gO, gy, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "block seed copy");
+  }
+  for (auto it = t->tape.rbegin(); it != t->tape.rend(); ++it) {
+    (*it)();
+    if (t->rc != STY_OK) break;
+  }
+  t->side_join();
+  if (t->rc == STY_OK) t->style_fc_backward();
+  if (t->live() && gx) {
+    float* g = t->G(xin, n);
+    hipError_t e = hipMemcpyAsync(gx, g, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "block input-gradient copy");
+  }
+  if (need) {
+    *need = align_up(t->peak, 256) + (64 << 20);
+    t->tape.clear();
+    return t->rc;
+  }
+  if (t->ws.overflow) {
+    set_error("block workspace too small: need %zu bytes, have %zu", t->peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
 void trainer_set_segment_hook(Trainer* t, std::function<void(int)> fn) {
   if (t) t->on_segment = std::move(fn);
 }

@@ -67,6 +67,10 @@ SYMBOLS = {
     "sty_alignment_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P]),
     "sty_convnext_fwd": (C.c_int, [_P, C.c_char_p, _I, _I, _I, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_resblock_fwd": (C.c_int, [_P, C.c_char_p, _I, _I, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_block_train_workspace_bytes": (C.c_int, [_P, C.c_char_p, C.c_char_p, _I, _I, _I, _SZP]),
+    "sty_block_fwd_bwd": (C.c_int, [_P, C.c_char_p, C.c_char_p, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_attention_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
+    "sty_attention_fwd_bwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_stft64_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P]),
     "sty_istft64_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P]),
     "sty_source_fwd": (C.c_int, [_I, _I, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_size_t, _P]),

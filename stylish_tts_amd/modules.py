@@ -436,6 +436,27 @@ class SpeechPredictor(_HipModule):
         return d_mel, d_style
 
 
+    def block_forward_backward(self, kind, prefix, x, style, gy):
+        """One sub-module of the vocoder in the TRAINING graph, forward and backward (sty_block_fwd_bwd): kind "convnext"
+        (GeneratorConvNeXtBlock, conv_next.py:80-93) or "resblock" (AdaptiveGeneratorBlock, ada_norm.py:109-120) at the
+        state_dict prefix; x, gy [B,C,T], style [B,64] -> (y, d x, d style).  Parameter gradients are added to param.grad.
+        Unit parity of the fused backward kernels; not part of the reference's surface."""
+        dev = style.device
+        self._train = True
+        self._tape_id += 1
+        lib = self._ensure(dev)
+        x, style, gy = _f32(x.detach(), dev), _f32(style.detach(), dev), _f32(gy.detach(), dev)
+        B, Cc, T = x.shape
+        y, gx = torch.empty_like(x), torch.empty_like(x)
+        d_style = torch.zeros(B, self.cfg["style_dim"], device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_block_train_workspace_bytes(self._handle, kind.encode(), prefix.encode(), B, Cc, T, C.byref(need)))
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_block_fwd_bwd(self._handle, kind.encode(), prefix.encode(), B, Cc, T, L.ptr(x), L.ptr(style),
+                                      L.ptr(gy), L.ptr(y), L.ptr(gx), L.ptr(d_style), L.ptr(ws), ws.numel(), st))
+        return y, gx, d_style
+
     def forward_train(self, texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, *, noise=None,
                       seed=0, prior_override=None, style_stream=None):
         """SpeechPredictor.forward in the training graph (eval-mode statistics); follow with backward(d_audio).

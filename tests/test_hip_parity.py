@@ -196,6 +196,100 @@ def test_adain_resblock(env, prefix):
     rep.done()
 
 
+def _f64(P):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+
+
+@pytest.mark.parametrize("kind,prefix,C,T", [
+    ("convnext", "generator.basegen.phase_convnext.0", 32, 600),
+    ("convnext", "generator.basegen.upblocks.2", 32, 1031),
+    ("convnext", "generator.basegen.upblocks.1", 64, 300),
+    ("convnext", "generator.basegen.amp_convnext.2", 256, 80),
+    ("resblock", "generator.basegen.amp_prior_block", 32, 700),
+    ("resblock", "generator.basegen.phase_prior_block", 32, 513),
+])
+def test_block_backward_vs_float64_oracle(env, kind, prefix, C, T):
+    """sty_block_fwd_bwd: ONE sub-module of the vocoder in the training graph -- the recompute-based fused ConvNeXt32
+    backward (convnext32_bwd_kernel<1,2>), the generic ConvNeXt backward (depthwise conv, AdaLN, Snake, GRN), the
+    AdaIN + Snake prologue backward (pro_bwd, adain_fold_bwd) around the resblock convs -- against the autograd of the
+    oracle run in FLOAT64: input gradient, style gradient and every parameter gradient of the block at <= 1e-4 of the
+    tensor's scale.  (End to end these kernels sit behind 3e-2 gates: 20 normalisation layers amplify the fp32
+    summation-order noise there; one block does not.)"""
+    import stylish_tts_amd as S
+    from oracle import blocks
+    P = {k: v.clone() for k, v in env["P"].items()}
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(2, C, T, generator=g)
+    style = torch.randn(2, 64, generator=g)
+    gy = torch.randn(2, C, T, generator=g)
+    P64 = _f64(P)
+    keys = [k for k in P64 if k.startswith(prefix + ".") and P64[k].is_floating_point()]
+    for k in keys:
+        P64[k].requires_grad_(True)
+    x64, s64 = x.double().requires_grad_(True), style.double().requires_grad_(True)
+    fn = blocks.convnext_block if kind == "convnext" else blocks.gen_resblock
+    y64 = fn(P64, prefix, x64, s64)
+    (y64 * gy.double()).sum().backward()
+    m = S.SpeechPredictor()
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).enable_training()
+    m._ensure(torch.device(DEV))
+    for p_ in m.parameters():
+        p_.grad.zero_()
+    y, gx, d_style = m.block_forward_backward(kind, prefix, dev(x), dev(style), dev(gy))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("y", y, y64.detach().float(), 2e-5)
+    rep.add("d x", gx, x64.grad.float(), 1e-4)
+    rep.add("d style", d_style, s64.grad.float(), 1e-4)
+    named = dict(m.named_parameters())
+    for k in keys:
+        if P64[k].grad is None or k not in named:
+            continue
+        ref = P64[k].grad.float()
+        if ref.abs().max().item() < 1e-7 * max(1.0, gy.abs().max().item()):
+            continue  # structurally zero gradients (a conv bias in front of an instance norm): noise on both sides
+        rep.add("d " + k[len(prefix) + 1:], named[k].grad, ref, 1e-4)
+    rep.done()
+
+
+@pytest.mark.parametrize("DH,T,masked", [(16, 40, True), (16, 100, True), (64, 160, False), (64, 520, False)])
+def test_attention_backward_vs_float64(DH, T, masked):
+    """sty_attention_fwd_bwd: the text encoder's masked attention (DH = 16, VALU backward kernels attn_bwd_{a,b,c}) and
+    the conformer's (DH = 64, MFMA backward attn_bwd_{kv,q}_mfma) vs float64 softmax attention: o, dq, dk, dv."""
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    B, H = 3, 8
+    g = torch.Generator().manual_seed(DH + T)
+    q, k, v, do = (torch.randn(B, H * DH, T, generator=g) for _ in range(4))
+    lengths = torch.tensor([T, max(1, T - 7), max(1, T // 2)]) if masked else None
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, H, DH, T).transpose(2, 3) for t in (q64, k64, v64))
+    sc = qh @ kh.transpose(2, 3) / DH ** 0.5
+    if masked:
+        ar = torch.arange(T)
+        ok = (ar[None, :] < lengths[:, None])
+        mask2 = ok[:, None, :, None] & ok[:, None, None, :]
+        sc = sc + torch.zeros_like(sc).masked_fill(~mask2, -1e4)  # the additive -1e4 mask SDPA gets (text_encoder.py:262-276)
+    o64 = (torch.softmax(sc, dim=-1) @ vh).transpose(2, 3).reshape(B, H * DH, T)
+    (o64 * do.double()).sum().backward()
+    o, dq, dk, dv = (torch.empty(B, H * DH, T, device=DEV) for _ in range(4))
+    need = C.c_size_t()
+    L.check(lib.sty_attention_workspace_bytes(B, H, T, C.byref(need)))
+    ws = torch.empty(need.value, dtype=torch.uint8, device=DEV)
+    ln = dev(lengths) if masked else None
+    L.check(lib.sty_attention_fwd_bwd(B, H, DH, T, L.ptr(dev(q)), L.ptr(dev(k)), L.ptr(dev(v)), L.ptr(ln), L.ptr(dev(do)),
+                                      L.ptr(o), L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel(),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("o", o, o64.detach().float(), 1e-5)
+    rep.add("dq", dq, q64.grad.float(), 1e-4)
+    rep.add("dk", dk, k64.grad.float(), 1e-4)
+    rep.add("dv", dv, v64.grad.float(), 1e-4)
+    rep.done()
+
+
 def test_alignment(env):
     from oracle import frontend
     from stylish_tts_amd import lib as L
