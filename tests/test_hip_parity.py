@@ -249,7 +249,21 @@ def test_block_backward_vs_float64_oracle(env, kind, prefix, C, T):
         ref = P64[k].grad.float()
         if ref.abs().max().item() < 1e-7 * max(1.0, gy.abs().max().item()):
             continue  # structurally zero gradients (a conv bias in front of an instance norm): noise on both sides
-        rep.add("d " + k[len(prefix) + 1:], named[k].grad, ref, 1e-4)
+        got = named[k].grad
+        k1 = k.replace("original0", "original1")
+        if k.endswith(".original0") and k1 in keys:
+            # d g_c = sum_ik dW[c,i,k] v[c,i,k] / |v_c|.  In front of an instance norm (convs1 -> adain2) the sum cancels to
+            # ~0 (the norm removes the channel's scale), so the noise floor is that of the TERMS: measure the error against
+            # sum_ik |d v| |v| / g, the size of what is being cancelled, when that is the larger scale.
+            terms = (P64[k1].grad.abs() * P64[k1].detach().abs()).sum(dim=(1, 2), keepdim=True) / P64[k].detach().abs()
+            if ref.abs().max().item() < 1e-3 * terms.max().item():
+                e = (got.detach().float().cpu() - ref).abs().max().item() / terms.max().item()
+                ok = e <= 1e-4
+                rep.rows.append(f"  {'d ' + k[len(prefix) + 1:]:32s} err/cancelled {e:9.3e}  tol 1.0e-04  {'ok' if ok else 'FAIL'}")
+                if not ok:
+                    rep.bad.append(k)
+                continue
+        rep.add("d " + k[len(prefix) + 1:], got, ref, 1e-4)
     rep.done()
 
 
@@ -263,6 +277,13 @@ def test_attention_backward_vs_float64(DH, T, masked):
     g = torch.Generator().manual_seed(DH + T)
     q, k, v, do = (torch.randn(B, H * DH, T, generator=g) for _ in range(4))
     lengths = torch.tensor([T, max(1, T - 7), max(1, T // 2)]) if masked else None
+    valid = torch.ones(B, 1, T)
+    if masked:
+        # padded QUERY rows: the reference adds -1e4 to every score of the row, which in fp32 rounds the scores to 1e-3 --
+        # its own output there is noise that the encoder masks right after (text_encoder.py:157-163), and no gradient comes
+        # back through them.  The test does the same: zero d o on those rows and compare o on the valid ones.
+        valid = (torch.arange(T)[None, :] < lengths[:, None]).float()[:, None, :]
+        do = do * valid
     q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
     qh, kh, vh = (t.view(B, H, DH, T).transpose(2, 3) for t in (q64, k64, v64))
     sc = qh @ kh.transpose(2, 3) / DH ** 0.5
@@ -278,12 +299,13 @@ def test_attention_backward_vs_float64(DH, T, masked):
     L.check(lib.sty_attention_workspace_bytes(B, H, T, C.byref(need)))
     ws = torch.empty(need.value, dtype=torch.uint8, device=DEV)
     ln = dev(lengths) if masked else None
-    L.check(lib.sty_attention_fwd_bwd(B, H, DH, T, L.ptr(dev(q)), L.ptr(dev(k)), L.ptr(dev(v)), L.ptr(ln), L.ptr(dev(do)),
+    dq_, dk_, dv_, ddo = dev(q), dev(k), dev(v), dev(do)  # named: a temporary's memory would be recycled by the next one
+    L.check(lib.sty_attention_fwd_bwd(B, H, DH, T, L.ptr(dq_), L.ptr(dk_), L.ptr(dv_), L.ptr(ln), L.ptr(ddo),
                                       L.ptr(o), L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel(),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     rep = Report()
-    rep.add("o", o, o64.detach().float(), 1e-5)
+    rep.add("o", o * dev(valid), o64.detach().float() * valid, 1e-5)
     rep.add("dq", dq, q64.grad.float(), 1e-4)
     rep.add("dk", dk, k64.grad.float(), 1e-4)
     rep.add("dv", dv, v64.grad.float(), 1e-4)
