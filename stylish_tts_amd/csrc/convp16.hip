@@ -20,6 +20,9 @@
 // of one time tile adjacent (their input re-reads hit L2).
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "sty_common.h"
 #include "conv_stage.h"
 
@@ -52,7 +55,7 @@ struct QStageB {
 };
 template <int NFRAG>
 struct QStageA {
-  float av[NFRAG][8];  // weights: NFRAG A fragments of this wave x 8 reduction channels
+  bf16x8 av[NFRAG];  // weights: NFRAG ready-made A fragments (one 16-byte load each)
 };
 
 // A position in the workgroup's sequence of chunk steps, advanced incrementally.  (The first version recomputed tile, chunk
@@ -154,26 +157,28 @@ __device__ __forceinline__ void q_issue_b(const ConvArgs& a, const QCursor& cu, 
     R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + roff, 0, 0));
   }
 }
-// ---- weights: fragment f = (tap, k-step, 32-cout block) -> lane (co = l31, k-block = hi) holds 8 reduction channels ----
+// ---- weights: fragment f = (tap, k-step, 32-cout block) -> lane (co = l31, k-block = hi) holds 8 reduction channels.
+// The launcher re-packs the layer's fp32 weights into exactly that order as bf16 (frag_pack_kernel below):
+//   wf[chunk][j = tap * 2 + k-step][32-cout block][lane] = 8 bf16, 16 bytes,
+// so a fragment is ONE coalesced 1-KiB load per wave and goes to LDS untouched.  (Reading the fp32 arena instead --
+// eight dword loads and four v_cvt_pk per fragment and lane -- was 48 of the 72 loads of a producer wave and step, and a
+// chunk step took 3.2 us against 0.32 us of MFMAs.) ----
 template <int MTW, int NFRAG>
 __device__ __forceinline__ void q_issue_a(const ConvArgs& a, QTile tl, int chunk, int pw, int lane, QStageA<NFRAG>& R) {
-  const int K = a.w.K, CinP = a.w.CinP, CoutP = a.w.CoutP;
+  const int K = a.w.K, CoutP = a.w.CoutP;
   constexpr int CO32 = 2 * MTW;
-  const __amdgpu_buffer_rsrc_t wrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w.wp), 0, K * CinP * CoutP * 4, 0x00020000);
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int NMB = CoutP / 32, J = 2 * K;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.w.wf), 0, K * a.w.CinP * CoutP * 2, 0x00020000);
 #pragma unroll
   for (int i = 0; i < NFRAG; ++i) {
     const int f = pw + Q_NP * i;
-    const int mb = f % CO32, ks = f / CO32;  // ks = tap * 2 + k-step
-    const int k = ks >> 1, s = ks & 1;
-    const int co = tl.cot * (32 * CO32) + mb * 32;
-    const bool ok = f < K * 2 * CO32 && co < CoutP;
-    const int base = ok ? ((k * CinP + chunk * 32 + 16 * s) * CoutP + co) * 4 : 0;
-    const int vo = ok ? l31 * 4 : 0x7FFFFF00;  // out of range (checked on the vector offset): zero fragment
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      R.av[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, vo + (8 * hi + e) * CoutP * 4, base, 0));
+    const int mb = f % CO32, j = f / CO32;
+    const int gmb = tl.cot * CO32 + mb;
+    const bool ok = f < J * CO32 && gmb < NMB;
+    const int base = ok ? ((chunk * J + j) * NMB + gmb) * 1024 : 0;
+    const int vo = ok ? lane * 16 : 0x7FFFFF00;  // out of range (checked on the vector offset): zero fragment
+    R.av[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo, base, 0));
   }
 }
 
@@ -222,9 +227,7 @@ __device__ __forceinline__ void q_commit_a(const ConvArgs& a, int pw, int lane, 
 #pragma unroll
   for (int i = 0; i < NFRAG; ++i) {
     const int f = pw + Q_NP * i;
-    if (f < K * 2 * CO32)
-      aring[f * 64 + lane] = sty_pack_bf16(R.av[i][0], R.av[i][1], R.av[i][2], R.av[i][3], R.av[i][4], R.av[i][5],
-                                           R.av[i][6], R.av[i][7]);
+    if (f < K * 2 * CO32) aring[f * 64 + lane] = R.av[i];
   }
 }
 
@@ -295,7 +298,7 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
 }
 
 template <int MTW, int PRO, int RELU>
-__global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles) {
+__global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CO32 = 2 * MTW;
   constexpr int NFRAG = 2;  // A fragments per producer wave and chunk: K 2 CO32 <= 24 over 12 waves
@@ -335,14 +338,14 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     QCursor cc_ = q_cursor_begin(a, first, tiles_per_row, ncot, rg), ci_ = cc_;
 #define STY_Q_ISSUE(R, RA_)                                                  \
   if (ci_.n < nchunks) {                                                     \
-    q_issue_a<MTW, NFRAG>(a, ci_.tl, ci_.chunk, pw, lane, RA_);              \
-    q_issue_b(a, ci_, LWt, pw, lane, R);                                     \
+    if (!(dbg & 2)) q_issue_a<MTW, NFRAG>(a, ci_.tl, ci_.chunk, pw, lane, RA_);              \
+    if (!(dbg & 1)) q_issue_b(a, ci_, LWt, pw, lane, R);                                     \
   }                                                                          \
   q_cursor_next(a, ci_, nch, tiles_per_row, ncot, rg);
 #define STY_Q_STEP(R, RA_) /* commit the commit cursor's chunk from its register set, then request the chunk two ahead */ \
   {                                                                                                      \
-    q_commit_a<MTW, NFRAG>(a, pw, lane, RA_, aring + (cc_.n & 1) * asz);                                 \
-    q_commit_b<PRO>(a, cc_, LWt, pw, lane, R, bring + (cc_.n & 1) * bsz);                                \
+    if (!(dbg & 2)) q_commit_a<MTW, NFRAG>(a, pw, lane, RA_, aring + (cc_.n & 1) * asz);                                 \
+    if (!(dbg & 4)) q_commit_b<PRO>(a, cc_, LWt, pw, lane, R, bring + (cc_.n & 1) * bsz);                                \
     q_cursor_next(a, cc_, nch, tiles_per_row, ncot, rg);                                                 \
     STY_Q_ISSUE(R, RA_)                                                                                  \
   }
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     int ti = 0, c = 0;
     QTile cur_tl = q_tile(first, tiles_per_row, ncot), prev_tl = cur_tl;
     for (int step = 0; step <= nsteps; ++step) {  // one more trip than the consumers: the last tile's drain
-      if ((c == 0 && ti > 0) || step == nsteps) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane);
+      if (((c == 0 && ti > 0) || step == nsteps) && !(dbg & 8)) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane);
       if (step == nsteps) break;
       // the chunk the consumers need in the NEXT step is committed now: during a chunk step that is not the tile's last
       // (after the last one comes the output-stage step), and during the output-stage step (the next tile's chunk 0)
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
   int g = 0, c = 0;
 #define STY_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
   for (int step = 0; step < nsteps; ++step) {
-    if (c < nch) {
+    if (c < nch && !(dbg & 16)) {
       // one 32-channel chunk
       if (c == 0) {
 #pragma unroll
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
 #undef STY_QMM
 #undef STY_QLD
       ++g;
-    } else {
+    } else if (c == nch && !(dbg & 32)) {
       // accumulators -> output stage [64 MTW][128]
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
@@ -458,6 +461,53 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     __syncthreads();
   }
 #undef STY_SGB
+}
+
+// fp32 packed weights [K][CinP][CoutP] -> bf16 A fragments in the order q_issue_a reads them
+__global__ __launch_bounds__(256) void frag_pack_kernel(const float* __restrict__ wp, int K, int CinP, int CoutP,
+                                                        bf16x8* __restrict__ wf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (((chunk * J + j) * NMB + mb) * 64 + lane
+  const int NMB = CoutP / 32, J = 2 * K;
+  if (i >= (CinP / 32) * J * NMB * 64) return;
+  const int lane = i & 63, l31 = lane & 31, hi = lane >> 5;
+  int r = i >> 6;
+  const int mb = r % NMB;
+  r /= NMB;
+  const int j = r % J, chunk = r / J;
+  const int k = j >> 1, s = j & 1;
+  const float* src = wp + ((size_t)k * CinP + chunk * 32 + 16 * s + 8 * hi) * CoutP + mb * 32 + l31;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * CoutP];
+  wf[i] = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+
+// One fragment buffer per packed-weight pointer, kept for the life of the process and re-filled before EVERY launch on
+// the launch's stream (weights change every optimizer step; a layer's conv runs once per step in each direction, so
+// there is nothing to cache in training, and nothing to invalidate).
+static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
+  static std::mutex mu;
+  static std::unordered_map<const float*, std::pair<void*, size_t>> table;
+  const size_t bytes = (size_t)a.w.K * a.w.CinP * a.w.CoutP * 2;
+  void* wf = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = table[a.w.wp];
+    if (e.second < bytes) {
+      if (e.first) STY_HIP(hipFree(e.first));
+      e.first = nullptr;
+      e.second = 0;
+      STY_HIP(hipMalloc(&e.first, bytes));
+      e.second = bytes;
+    }
+    wf = e.first;
+  }
+  const int n = (int)(bytes / 16);
+  hipLaunchKernelGGL(frag_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.w.wp, a.w.K, a.w.CinP, a.w.CoutP,
+                     static_cast<bf16x8*>(wf));
+  STY_LAUNCH_CHECK();
+  *out = wf;
+  return STY_OK;
 }
 
 static int q_num_cus() {
@@ -513,7 +563,10 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   char fam[48];
   snprintf(fam, sizeof(fam), "convp16_kernel<%d,true>", MTW);
   ProfScope prof(fam, flops, bytes, st, detail);
-  hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot, ntiles);
+  const char* de = getenv("STY_Q_DBG");  // timing experiments only (wrong results): 1 no input loads, 2 no weight path,
+                                         // 4 no input commit, 8 no drain, 16 no MFMA loop, 32 no accumulator spill
+  hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot, ntiles,
+                     de ? atoi(de) : 0);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -525,7 +578,10 @@ static int launch_q_pro(const ConvArgs& a, hipStream_t st) {
   return relu ? launch_q<1, PRO, 1>(a, st) : launch_q<1, PRO, 0>(a, st);
 }
 
-int launch_convp16(const ConvArgs& a, hipStream_t st) {
+int launch_convp16(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  int rc = q_frags(a0, st, &a.w.wf);
+  if (rc) return rc;
   switch (a.pro) {
     case PRO_MASK: return launch_q_pro<PRO_MASK>(a, st);
     case PRO_LRELU: return launch_q_pro<PRO_LRELU>(a, st);

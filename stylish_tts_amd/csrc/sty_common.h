@@ -63,6 +63,7 @@ struct PackedConv {
   const float* wp = nullptr;    // [K][CinP][CoutP]
   const float* bias = nullptr;  // [CoutP] (zero padded) or nullptr
   int Cin = 0, Cout = 0, K = 1, CinP = 0, CoutP = 0;
+  const void* wf = nullptr;     // convp16 only, filled by its launcher: the same weights as bf16 MFMA A fragments
 };
 
 constexpr int CI_CHUNK = 32;  // channels staged in LDS per reduction chunk
@@ -127,6 +128,10 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st);
 bool conv32p_eligible(const ConvArgs& a);
 int conv32p_stat_nseg(int T);
 // convp16.hip: persistent producer / consumer kernel of the bf16 compute mode for Cin >= 64
+// wgradb.hip: bf16-mode weight gradient, K = 1 / 3, 64 x 64 blocks, operands converted once on their way into LDS
+bool wgradb_eligible(const ConvArgs& fwd, bool gmask);
+int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st);
+int wgradb_chunks(const PackedConv& w, int B, int T, int dil);
 bool convp16_eligible(const ConvArgs& a);
 int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);

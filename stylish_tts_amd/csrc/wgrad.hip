@@ -707,6 +707,18 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     ag.pad = 0;
     ConvArgs ax1 = fwd;
     ax1.flatW = 0;  // KH == KW == 1: the flat image is a plain [B][C][T] tensor
+    if (wgradb_eligible(ax1, gmask != nullptr)) {
+      const int chunks = wgradb_chunks(w, fwd.B, fwd.T, fwd.dil);
+      const int ns = nsplit < chunks ? nsplit : chunks;
+      const int wb = gbias != nullptr;
+      int rc = launch_wgradb(ax1, ag, ns, partial, wb, st);
+      if (rc) return rc;
+      const size_t plane = (size_t)w.CinP * w.CoutP;
+      launch_wgrad_reduce(partial, ns, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+      if (bias_done) *bias_done = wb != 0;
+      STY_LAUNCH_CHECK();
+      return STY_OK;
+    }
     dim3 grid(cdiv(w.CinP, c.TI), cdiv(w.CoutP, c.TO), nsplit);
     const size_t lds = (size_t)(c.TI + c.TO) * (W1_TW + 1) * sizeof(float);
     char detail[40];
@@ -746,6 +758,19 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
 #undef STY_W1
     const size_t plane = (size_t)w.CinP * w.CoutP;
     launch_wgrad_reduce(partial, nsplit, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+    if (bias_done) *bias_done = wb != 0;
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
+  if (wgrad64_ok(w, fwd.dil) && wgrad64_operands_ok(fwd) && wgradb_eligible(ax, gmask != nullptr)) {
+    const int chunks = wgradb_chunks(w, fwd.B, fwd.T, fwd.dil);
+    int ns = wgrad64_nsplit(w, fwd.B, fwd.T);
+    if (ns > chunks) ns = chunks;
+    const int wb = gbias != nullptr;
+    int rc = launch_wgradb(ax, ag, ns, partial, wb, st);
+    if (rc) return rc;
+    const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
+    launch_wgrad_reduce(partial, ns, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
     if (bias_done) *bias_done = wb != 0;
     STY_LAUNCH_CHECK();
     return STY_OK;

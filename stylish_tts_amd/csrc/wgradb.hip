@@ -1,0 +1,323 @@
+// Weight gradient of a dense conv in the bf16 compute mode, K <= 3, Cin and Cout >= 64 (style encoder 3x3 on the
+// padded-flat layout, decoder k3, every 1x1 / Linear of the conformer, the ConvNeXt blocks and the text encoder):
+//   dW[k][ci][co] = sum_{b,t} G[b][co][t] * pro(x)[b][ci][t + k dil - pad]
+// (backward of the reference's nn.Conv1d / nn.Conv2d / nn.Linear call sites: mel_style_encoder.py:69-152,
+// ada_norm.py:143-192, conformer.py:85-187, conv_next.py:80-93, text_encoder.py:214-330).
+//
+// Why a second kernel: conv1d_wgrad64_kernel<3,true> / wgrad_k1_kernel<..,true> keep fp32 tiles in LDS and build every
+// MFMA operand with eight ds_read_b32 + four v_cvt_pk, once per tap and per wave that needs it: 6 700 instructions
+// (3 300 VALU, 2 700 SALU, 330 LDS) per 128-sample chunk and wave around 24 MFMAs -- 41-46 TFLOP/s inside a c3 step,
+// the largest single kernel of that step.  Here every element is converted ONCE, on its way into LDS:
+//   * a thread owns (row, 8 consecutive samples): two 16-byte buffer loads, prologue, four v_cvt_pk, one ds_write_b128;
+//   * the x tile is staged once, the G tile K times, shifted by -k dil samples (loaded from global at the shifted
+//     address: dword alignment is all a buffer load needs), so that EVERY operand of every tap is one aligned
+//     ds_read_b128 -- G has no prologue, x does, which is why G is the one that is copied;
+//   * rows are 272 bytes apart (128 bf16 + 16 bytes): conflict-free for the 16-lane groups of a 128-bit LDS access;
+//   * zero padding / row ends are handled per 8-sample group, on a branch only the groups at a row end take.
+// 2 x 2 waves over a 64 (ci) x 64 (co) block of dW, all K taps per wave; the loads of chunk i+1 are in flight during
+// the MFMAs of chunk i (register staged).  The (batch, time) list is split over gridDim.z; partial planes
+// [split][k][ci][co] (+ bias partials) go through wgrad_reduce_kernel exactly like the other weight-gradient kernels.
+#include "sty_common.h"
+#include "conv_stage.h"
+
+namespace sty {
+
+constexpr int WB_PITCH = 136;  // bf16 elements between LDS rows
+constexpr int WB_TW_MASKED = 64;
+constexpr int WB_OOB = 0x7fffff00;
+
+// (bit-casting the builtin's result to an ext_vector_type and indexing it made hipcc emit ONE buffer_load_dword and
+// splat it; through float4 it is the 16-byte load it says)
+__device__ __forceinline__ void wb_load8(__amdgpu_buffer_rsrc_t rs, int byte_off, float (&v)[8]) {
+  const float4 a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+  const float4 b = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 16, 0, 0));
+  v[0] = a.x;
+  v[1] = a.y;
+  v[2] = a.z;
+  v[3] = a.w;
+  v[4] = b.x;
+  v[5] = b.y;
+  v[6] = b.z;
+  v[7] = b.w;
+}
+// Eight samples i0 .. i0 + 7 of a row of length T whose sample 0 sits at byte offset row_off of the descriptor.  Groups
+// inside the row take two 16-byte loads.  A group that straddles a row end is read sample by sample, samples outside
+// [0, T) from an out-of-range offset (they load 0): a 16-byte load that is only PARTLY inside the descriptor returns 0
+// for all four dwords, so the 16-byte form loses the first samples of a slab's first row and the last ones of its last.
+__device__ __forceinline__ void wb_load_row8(__amdgpu_buffer_rsrc_t rs, int row_off, int i0, int T, float (&v)[8]) {
+  if (i0 >= 0 && i0 + 7 < T) {
+    wb_load8(rs, row_off + i0 * 4, v);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool in = i0 + e >= 0 && i0 + e < T;
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, in ? row_off + (i0 + e) * 4 : 0x7fffff00, 0, 0));
+    }
+  }
+}
+__device__ __forceinline__ bf16x8 wb_pack(const float (&v)[8]) {
+  return sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+
+// TW = reduction samples per chunk: 128, or 64 where the [B][T] multiplier of G (GMASK) adds K x 8 staging registers per
+// thread and the 128-sample version spilled 64-135 of them
+template <int KN, int PRO, bool GMASK, int TW>
+__global__ __launch_bounds__(256, 2) void wgradb_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
+                                                        float* __restrict__ partial, int want_bias) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
+  __bf16* xs = wb_lds;                   // [64][WB_PITCH]
+  __bf16* gs = wb_lds + 64 * WB_PITCH;   // [KN][64][WB_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
+            hi = lane >> 5;
+  const int wi = wave >> 1, wo = wave & 1;
+  const int dil = ax.dil, T = ax.T, pad = ax.pad;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+  constexpr int GPR = TW / 8, NI = TW / 32, RSTEP = 256 / GPR;  // groups per row, items per thread, row step
+  const int g8 = (tid % GPR) * 8, r0 = tid / GPR;  // this thread's 8-sample group and first row (rows r0 + RSTEP m)
+  const bool do_bias = want_bias && blockIdx.x == 0;
+
+  f32x16 acc[KN];
+#pragma unroll
+  for (int k = 0; k < KN; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  float bsum[NI];
+#pragma unroll
+  for (int m = 0; m < NI; ++m) bsum[m] = 0.f;
+
+  // per-row constants of the four x rows and four G rows of this thread
+  const int Cx = ax.flatW ? ax.Cin2d : ax.xc[0];  // channels of one batch slab of x
+  const int Cg = ag.xc[0];
+  int offx[NI], tshx[NI], offg[NI], cix[NI];
+  float alpha[NI], ralpha[NI];
+#pragma unroll
+  for (int m = 0; m < NI; ++m) {
+    const int ci = ci0 + r0 + RSTEP * m;
+    int cc = ci, tsh = 0;
+    if (ax.flatW) {  // reduction row (kh, cc) of the flat image: channel cc shifted by (kh - hpad) image rows
+      const int c2 = ax.Cin2d;
+      const int kh = (ci >= c2) + (ci >= 2 * c2) + (ci >= 3 * c2) + (ci >= 4 * c2);
+      cc = ci - kh * c2;
+      tsh = (kh - ax.hpad) * ax.flatW;
+    }
+    const bool live = ci < ax.w.Cin;
+    tshx[m] = tsh;
+    cix[m] = live ? cc : -1;
+    offx[m] = live ? cc * T * 4 : WB_OOB;  // dead rows: out of the descriptor's range, load 0
+    const int co = co0 + r0 + RSTEP * m;
+    offg[m] = co < Cg ? co * T * 4 : WB_OOB;
+    alpha[m] = ralpha[m] = 1.f;
+    if constexpr (PRO == PRO_AFFINE_SNAKE) {
+      if (live) {
+        alpha[m] = ax.palpha[cc];
+        ralpha[m] = 1.0f / alpha[m];
+      }
+    }
+  }
+
+  float xv[NI][8], gv[KN][NI][8];
+  float pa[NI], ps[NI];
+#pragma unroll
+  for (int m = 0; m < NI; ++m) {
+    pa[m] = 1.f;
+    ps[m] = 0.f;
+  }
+  float xm[PRO == PRO_MASK ? NI : 1][8];
+  float gm[GMASK ? KN : 1][8];
+  const int total = ax.B * chunks_per_b;
+  // chunk position (batch row, chunk in the row), advanced incrementally: no division in the loop
+  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+
+  auto load_chunk = [&](int b, int c) {
+    const int t0 = c * TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ax.x[0] + (size_t)b * Cx * T), 0, Cx * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ag.x[0] + (size_t)b * Cg * T), 0, Cg * T * 4, 0x00020000);
+    const int ix0 = t0 - pad + g8, ig0 = t0 + g8;  // first sample of this thread's group: x (before the row shift), G
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      wb_load_row8(rx, offx[m], ix0 + tshx[m], T, xv[m]);
+#pragma unroll
+      for (int k = 0; k < KN; ++k) wb_load_row8(rg, offg[m], ig0 - k * dil, T, gv[k][m]);
+      if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+        pa[m] = cix[m] >= 0 ? ax.pa[(size_t)b * ax.w.Cin + cix[m]] : 0.f;
+        if constexpr (PRO != PRO_SCALE) ps[m] = cix[m] >= 0 ? ax.ps[(size_t)b * ax.w.Cin + cix[m]] : 0.f;
+      }
+    }
+    if constexpr (PRO == PRO_MASK) {  // [B][T] multiplier of x at the SOURCE position
+      const __amdgpu_buffer_rsrc_t rm =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ax.mask + (size_t)b * T), 0, T * 4, 0x00020000);
+#pragma unroll
+      for (int m = 0; m < NI; ++m) wb_load_row8(rm, 0, ix0 + tshx[m], T, xm[m]);
+    }
+    if constexpr (GMASK) {  // [B][T] multiplier of G
+      const __amdgpu_buffer_rsrc_t rm =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ag.mask + (size_t)b * T), 0, T * 4, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < KN; ++k) wb_load_row8(rm, 0, ig0 - k * dil, T, gm[k]);
+    }
+  };
+  auto advance = [&](int& b, int& c) {
+    c += nsplit;
+    while (c >= chunks_per_b) {
+      c -= chunks_per_b;
+      ++b;
+    }
+  };
+
+  int ch = split;
+  if (ch < total) load_chunk(cb, cc_);
+  for (; ch < total; ch += nsplit) {
+    const int t0 = cc_ * TW;
+    __syncthreads();  // the previous chunk's MFMAs are done with the tiles
+    // ---- registers -> bf16 tiles ----
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      const int row = r0 + RSTEP * m;
+      {  // x: prologue, then zero padding (source position s = u + tsh must lie inside the row / image)
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float mk = 1.f;
+          if constexpr (PRO == PRO_MASK) mk = xm[m][e];
+          v[e] = pro_apply<PRO>(xv[m][e], pa[m], ps[m], alpha[m], ralpha[m], mk);
+        }
+        const int s0 = t0 - pad + g8 + tshx[m];
+        if (s0 < 0 || s0 + 7 >= T) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (s0 + e >= 0 && s0 + e < T) ? v[e] : 0.f;
+        }
+        *reinterpret_cast<bf16x8*>(xs + row * WB_PITCH + g8) = wb_pack(v);
+      }
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {  // G shifted by -k dil: index t = t0 + g8 + e - k dil
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = GMASK ? gv[k][m][e] * gm[k][e] : gv[k][m][e];
+        const int i0 = t0 + g8 - k * dil;
+        if (i0 < 0 || i0 + 7 >= T) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (i0 + e >= 0 && i0 + e < T) ? v[e] : 0.f;
+        }
+        if (k == 0 && do_bias) bsum[m] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        *reinterpret_cast<bf16x8*>(gs + (k * 64 + row) * WB_PITCH + g8) = wb_pack(v);
+      }
+    }
+    __syncthreads();
+    advance(cb, cc_);
+    if (ch + nsplit < total) load_chunk(cb, cc_);  // in flight during the MFMAs below
+    // ---- MFMAs: A = G_k rows (co), B = x rows (ci), contraction over the 128 samples of the chunk ----
+    const __bf16* xr = xs + (wi * 32 + l31) * WB_PITCH + 8 * hi;
+    const __bf16* gr = gs + (wo * 32 + l31) * WB_PITCH + 8 * hi;
+#pragma unroll
+    for (int s8 = 0; s8 < TW / 16; ++s8) {
+      const bf16x8 bp = *reinterpret_cast<const bf16x8*>(xr + 16 * s8);
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + k * 64 * WB_PITCH + 16 * s8);
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp, acc[k], 0, 0, 0);
+      }
+    }
+  }
+
+  const int K = ax.w.K, CinP = ax.w.CinP, CoutP = ax.w.CoutP;
+  const size_t plane = (size_t)K * CinP * CoutP;
+  const size_t stride = plane + CoutP;
+  if (do_bias) {
+    float* pb = partial + (size_t)split * stride + plane;
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      float v = bsum[m];
+#pragma unroll
+      for (int o = 1; o < GPR; o <<= 1) v += __shfl_xor(v, o);
+      const int co = co0 + r0 + RSTEP * m;
+      if (tid % GPR == 0 && co < CoutP) pb[co] = v;
+    }
+  }
+  float* p = partial + (size_t)split * stride;
+  const int ci = ci0 + wi * 32 + l31;
+#pragma unroll
+  for (int k = 0; k < KN; ++k) {
+    if (k < K && ci < CinP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co < CoutP) p[((size_t)k * CinP + ci) * CoutP + co] = acc[k][r];
+      }
+    }
+  }
+}
+
+bool wgradb_eligible(const ConvArgs& fwd, bool gmask) {
+  (void)gmask;
+  const PackedConv& w = fwd.w;
+  if (!fwd.bf16 || getenv("STY_NO_WGRADB")) return false;  // (read per call: the A/B parity test toggles it)
+  if (!(w.K == 1 || w.K == 3) || w.CinP < 64 || w.CoutP < 64) return false;
+  if (!(fwd.flatW || fwd.nsrc == 1) || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
+  if (fwd.flatW && w.K == 1) return false;  // (the caller clears flatW for 1x1 convs)
+  if ((w.K - 1) * fwd.dil > 63) return false;
+  switch (fwd.pro) {
+    case PRO_NONE:
+    case PRO_MASK:
+    case PRO_LRELU:
+    case PRO_AFFINE:
+    case PRO_AFFINE_LRELU:
+    case PRO_AFFINE_SNAKE:
+    case PRO_SCALE: return true;
+    default: return false;
+  }
+}
+
+template <int KN, int PRO>
+static void wb_launch(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
+                      int wb, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, false, 128>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, true, WB_TW_MASKED>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    raised = true;
+  }
+  if (ag.pro == PRO_MASK)
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, true, WB_TW_MASKED>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial,
+                       wb);
+  else
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, false, 128>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
+}
+template <int KN>
+static void wb_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb,
+                          float* partial, int wb, hipStream_t st) {
+  switch (ax.pro) {
+    case PRO_MASK: wb_launch<KN, PRO_MASK>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_LRELU: wb_launch<KN, PRO_LRELU>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_AFFINE: wb_launch<KN, PRO_AFFINE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_AFFINE_LRELU: wb_launch<KN, PRO_AFFINE_LRELU>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_AFFINE_SNAKE: wb_launch<KN, PRO_AFFINE_SNAKE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_SCALE: wb_launch<KN, PRO_SCALE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    default: wb_launch<KN, PRO_NONE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+  }
+}
+
+// partial planes: [nsplit][K][CinP][CoutP] (+ CoutP bias partials per split); the caller reduces them
+int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st) {
+  const PackedConv& w = ax.w;
+  const int tw = ag.pro == PRO_MASK ? WB_TW_MASKED : 128;
+  const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, tw);  // chunks cover u = t + k dil - pad over [-pad, T + halo - pad)
+  dim3 grid(cdiv(w.CinP, 64), cdiv(w.CoutP, 64), nsplit);
+  const size_t lds = (size_t)(1 + w.K) * 64 * WB_PITCH * sizeof(__bf16);
+  char detail[40];
+  snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW);
+  ProfScope prof(w.K == 1 ? "wgradb_kernel<1>" : "wgradb_kernel<3>", 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T,
+                 4.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
+  if (w.K == 1)
+    wb_launch_pro<1>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else
+    wb_launch_pro<3>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+int wgradb_chunks(const PackedConv& w, int B, int T, int dil) { return B * cdiv(T + (w.K - 1) * dil, 128); }  // (a lower bound of the masked variant's count)
+
+}  // namespace sty

@@ -981,7 +981,8 @@ def test_persistent_conv16_vs_torch(shape, monkeypatch):
 def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monkeypatch):
     """The bf16 compute mode with the persistent kernels forced on at the small test size (conv32p, convp16: flat 2-D
     style-encoder convs with masks and residuals, LeakyReLU / AdaIN prologues, ReLU, decoder and vocoder convs, forward
-    and input gradients) against the same graphs on the tiled kernel: the operands are rounded identically, so the
+    and input gradients) and the bf16-tile weight-gradient kernel (wgradb: the same layers' weight gradients, flat 2-D
+    rows, pad-column masks on G, prologues on x) against the same graphs on the tiled kernels: the operands are rounded identically, so the
     kernels differ by fp32 summation order only -- but in the bf16 mode a 1e-7 difference flips bf16 roundings downstream
     (2^-9 each), which the vocoder's phase path amplifies: the predictor end to end is REPORTED (it is as far from the
     tiled bf16 run as that is from fp32, test_acoustic_train_step_bf16_compute_vs_fp32); the style encoder, a plain conv
@@ -995,11 +996,12 @@ def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monke
     gs = torch.randn(3, 64, generator=torch.Generator().manual_seed(10))
     out = {}
     for mode in ("tiled", "persistent"):
-        for k in ("STY_NO_CONVP16", "STY_NO_CONV32P", "STY_CONVP16_MIN_TILES", "STY_CONV32P_MIN_TILES"):
+        for k in ("STY_NO_CONVP16", "STY_NO_CONV32P", "STY_NO_WGRADB", "STY_CONVP16_MIN_TILES", "STY_CONV32P_MIN_TILES"):
             monkeypatch.delenv(k, raising=False)
         if mode == "tiled":
             monkeypatch.setenv("STY_NO_CONVP16", "1")
             monkeypatch.setenv("STY_NO_CONV32P", "1")
+            monkeypatch.setenv("STY_NO_WGRADB", "1")
         else:
             monkeypatch.setenv("STY_CONVP16_MIN_TILES", "1")
             monkeypatch.setenv("STY_CONV32P_MIN_TILES", "1")
@@ -1020,8 +1022,9 @@ def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monke
         torch.cuda.synchronize()
         L.load().sty_prof_enable(0)
         names = {r["name"] for r in L.prof_report(512)}
-        has = any(n.startswith("convp16") for n in names), any(n.startswith("conv32p") for n in names)
-        assert has == ((True, True) if mode == "persistent" else (False, False)), names
+        has = (any(n.startswith("convp16") for n in names), any(n.startswith("conv32p") for n in names),
+               any(n.startswith("wgradb") for n in names))
+        assert has == ((True, True, True) if mode == "persistent" else (False, False, False)), names
         out[mode] = dict(style=style.cpu(), audio=audio.cpu(), d_style=d_style.cpu(),
                          gse=torch.cat([p.grad.flatten().cpu() for p in se.parameters()]),
                          gsp=torch.cat([p.grad.flatten().cpu() for p in sp.parameters()]))
