@@ -339,6 +339,11 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
         torch.cuda.synchronize()
         lib.sty_prof_enable(0)
         serial_prof = L.prof_report(2048)
+        ts = time.perf_counter()  # and the single-stream step itself, without the per-launch events
+        for i in range(2):
+            step(warmup + steps + 4 + i)
+        torch.cuda.synchronize()
+        serial_ms = 1e3 * (time.perf_counter() - ts) / 2
         lib.sty_set_single_stream(0)
         trainer.single_stream = False
     barrier()
@@ -388,6 +393,13 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                 "what": "same kernel, two extra steps after the timed region with the side streams off",
                 "avg_launch_us": per1 * 1e6, "mfma_TFLOPs": tf1, "mfma_frac": tf1 / peak,
                 "hbm_GBps_algorithmic": gb1, "hbm_frac": gb1 / PEAK_HBM_GBS}
+        if serial_prof:  # every family alone on the chip: what each costs, free of the stretch from sharing it
+            rec["single_stream_step_ms"] = serial_ms
+            rec["single_stream_kernels"] = [
+                {"name": r["name"], "launches": r["launches"] // 2, "ms_per_step": r["ms"] / 2,
+                 "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
+                 "GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
+                for r in sorted(serial_prof, key=lambda r: -r["ms"])[:40]]
         rec["kernels_source"] = "HIP events over one untimed step after the warm-up; roofline: over the timed region"
         rec["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / nprof,
                            "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,

@@ -49,186 +49,143 @@ __device__ __forceinline__ QTile q_tile(int tile, int tiles_per_row, int ncot) {
   return t;
 }
 
-// registers of one staged chunk in flight (producer)
-struct QStageB {
-  float bv[8];  // input tile: 8 rows x the 64-column group of this wave
-};
+// ---- producer side ----
+// Everything a producer wave needs per chunk step is either a constant of the wave (LDS addresses, fragment numbers,
+// lane offsets) or advances by a fixed stride from one chunk to the next; the rest changes once per tile.  The first
+// version recomputed all of it from the step number in every wave and step: the kernel had 2 400 scalar against 850
+// vector instructions, a chunk step took 2.3 us (the CU's scalar unit serves its sixteen waves one instruction per
+// cycle) against 0.32 us of MFMAs, and timing it with the loads, the commit or the MFMAs switched off showed the pieces
+// adding up instead of overlapping: the producers were bound by instruction issue, not by memory.
+//
+// One chunk in flight: what its loads return and what its commit needs (it travels with the register set, so that the
+// commit does not have to re-derive the chunk's position).
 template <int NFRAG>
-struct QStageA {
-  bf16x8 av[NFRAG];  // weights: NFRAG ready-made A fragments (one 16-byte load each)
+struct QSet {
+  float bv[8];                // input tile: 8 rows x the 64-column group of this wave
+  bf16x8 av[NFRAG];           // weight fragments, ready made (one 16-byte load each)
+  float pa, ps;               // lanes 0-7: AdaIN scale / shift of the 8 rows (affine prologues)
+  float mk;                   // PRO_MASK: the [B][T] multiplier at this lane's source position
+  unsigned long long in;      // lanes whose source position lies inside the row (zero padding elsewhere)
 };
 
-// A position in the workgroup's sequence of chunk steps, advanced incrementally.  (The first version recomputed tile, chunk
-// and the flat-2-D row split from the step number in every wave and step: eight emulated integer divisions, ~800 scalar
-// instructions per wave and step on the CU's one scalar unit, sixteen waves: the scalar unit paced the kernel.)
-struct QCursor {
-  int n;        // chunk step number
-  int chunk;    // chunk within the tile
-  QTile tl;     // tile coordinates
-  int kh, cc;   // flat 2-D: (image-row tap, source channel) of reduction row chunk * 32 + 8 * rg
+// The position of the chunk whose loads are issued next.
+struct QPos {
+  int n, chunk;     // chunk step number of the workgroup, chunk within the tile
+  int b, t0, cot;   // tile
+  int roff;         // byte offset, within the batch slab, of this wave's first row at sample 0 (flat 2-D: including the shift
+                    // by whole image rows)
+  int cc, tsh;      // flat 2-D: source channel of the first row, its shift in samples
+  int abase;        // byte offset of fragment (chunk, j = 0, this tile's first 32-cout block) in the fragment buffer
 };
-__device__ __forceinline__ void q_cursor_rows(const ConvArgs& a, QCursor& c, int rg) {  // (kh, cc) at chunk 0 of a tile
-  c.kh = 0;
-  c.cc = 8 * rg;
-  if (a.flatW)
-    while (c.cc >= a.Cin2d) {
-      c.cc -= a.Cin2d;
-      ++c.kh;
-    }
+
+template <bool FLAT>
+__device__ __forceinline__ void q_pos_tile(const ConvArgs& a, QPos& p, int rg, int CO32) {  // chunk 0 of tile (b, t0, cot)
+  p.chunk = 0;
+  p.cc = 8 * rg;  // (flat 2-D: Cin2d >= 32, so chunk 0 starts in image-row tap 0)
+  p.tsh = FLAT ? -a.hpad * a.flatW : 0;
+  p.roff = (p.cc * a.T + p.tsh) * 4;
+  p.abase = p.cot * CO32 * 1024;
 }
-__device__ __forceinline__ QCursor q_cursor_begin(const ConvArgs& a, int first, int tiles_per_row, int ncot, int rg) {
-  QCursor c;
-  c.n = 0;
-  c.chunk = 0;
-  c.tl = q_tile(first, tiles_per_row, ncot);  // the only divisions: once per workgroup
-  q_cursor_rows(a, c, rg);
-  return c;
-}
-__device__ __forceinline__ void q_cursor_next(const ConvArgs& a, QCursor& c, int nch, int tiles_per_row, int ncot, int rg) {
-  ++c.n;
-  if (++c.chunk < nch) {
-    if (a.flatW) {
-      c.cc += 32;
-      while (c.cc >= a.Cin2d) {
-        c.cc -= a.Cin2d;
-        ++c.kh;
+template <bool FLAT>
+__device__ __forceinline__ void q_pos_next(const ConvArgs& a, QPos& p, int nch, int tiles_per_row, int ncot, int rg, int CO32,
+                                           int astep) {
+  ++p.n;
+  if (++p.chunk < nch) {
+    p.roff += 32 * a.T * 4;
+    p.abase += astep;
+    if (FLAT) {
+      p.cc += 32;
+      if (p.cc >= a.Cin2d) {  // next image-row tap
+        p.cc -= a.Cin2d;
+        p.tsh += a.flatW;
+        p.roff += (a.flatW - a.Cin2d * a.T) * 4;
       }
     }
     return;
   }
-  c.chunk = 0;
-  if (++c.tl.cot == ncot) {
-    c.tl.cot = 0;
-    c.tl.t0 += Q_TT;
-    if (c.tl.t0 >= tiles_per_row * Q_TT) {
-      c.tl.t0 = 0;
-      ++c.tl.b;
+  if (++p.cot == ncot) {
+    p.cot = 0;
+    p.t0 += Q_TT;
+    if (p.t0 >= tiles_per_row * Q_TT) {
+      p.t0 = 0;
+      ++p.b;
     }
   }
-  q_cursor_rows(a, c, rg);
-}
-// The eight reduction rows a producer wave owns in the cursor's chunk: source row and time shift (flat 2-D: reduction row
-// (kh, cc) reads source row cc shifted by (kh - hpad) image rows).
-__device__ __forceinline__ void q_rows(const ConvArgs& a, const QCursor& c, int rg, int (&row)[8], int (&tsh)[8]) {
-  if (!a.flatW) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      row[r] = c.chunk * 32 + 8 * rg + r;
-      tsh[r] = 0;
-    }
-    return;
-  }
-  int kh = c.kh, cc = c.cc;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    if (cc >= a.Cin2d) {  // (Cin2d >= 8 on every layer of the path: at most one wrap inside eight rows)
-      cc -= a.Cin2d;
-      ++kh;
-    }
-    row[r] = cc;
-    tsh[r] = (kh - a.hpad) * a.flatW;
-    ++cc;
-  }
+  q_pos_tile<FLAT>(a, p, rg, CO32);
 }
 
-__device__ __forceinline__ void q_issue_b(const ConvArgs& a, const QCursor& cu, int LWt, int pw, int lane, QStageB& R) {
-  const QTile tl = cu.tl;
-  const int chunk = cu.chunk;
-  const int T = a.T, Cin = a.w.Cin;
-  const int rg = pw & 3, q = pw >> 2;  // row octet, 64-column group
-  // ---- input tile ----
-  const int crow = a.flatW ? a.Cin2d : Cin;  // rows of the source slab
+// per-wave constants of the staging code
+template <int NFRAG>
+struct QConst {
+  int rg8;           // first of the wave's 8 rows within a chunk
+  int vcol;          // byte offset of this lane's column relative to the tile start, or out of range for a dead column group
+  int jcol;          // this lane's column in the staged tile (lane + 64 q)
+  bool jlive;        // ... is inside the tile + halo
+  int bdst;          // LDS element offset of this lane's 8-channel group in a B buffer
+  int va[NFRAG];     // vector offset of this wave's fragment loads (lane * 16, or out of range for fragments beyond K 2 CO32)
+  int fa[NFRAG];     // byte offset of the fragment relative to QPos::abase
+  int adst[NFRAG];   // LDS bf16x8 index of the fragment in an A buffer (-1: none)
+};
+
+template <int PRO, bool FLAT, int NFRAG>
+__device__ __forceinline__ void q_issue(const ConvArgs& a, const QPos& p, const QConst<NFRAG>& k, int lane, QSet<NFRAG>& R) {
+  const int T = a.T;
+  const int crow = FLAT ? a.Cin2d : a.w.Cin;  // rows of one batch slab: rows past it are outside the descriptor and load 0
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x[0] + (size_t)tl.b * crow * T), 0, crow * T * 4, 0x00020000);
-  const int voff = (tl.t0 - a.pad + lane + 64 * q) * 4;
-  // Every load is issued unconditionally: a dead row (padding up to CinP) or a column group beyond the tile gets an
-  // offset outside the descriptor's range instead (the hardware returns 0 without touching memory).  Guarding the loads
-  // with their wave-uniform conditions made hipcc branch around each one: 1 800 basic blocks, twice as slow.
-  // The whole offset goes into the VECTOR offset: the hardware range-checks voffset only, not the scalar soffset (a
-  // negative lane offset with the row in soffset read as "out of range" -- the first column of every 64-column group).
-  constexpr int OOB = 0x7FFFFF00;
-  const bool qlive = q < Q_TT / 64 || 64 * q < LWt;
-  int row[8], tsh[8];
-  q_rows(a, cu, rg, row, tsh);
+      const_cast<float*>(a.x[0] + (size_t)p.b * crow * T), 0, crow * T * 4, 0x00020000);
+  // The whole offset goes into the VECTOR offset: the hardware range-checks that one only, not the scalar soffset.
+  const int v0 = k.vcol + (p.t0 - a.pad) * 4 + p.roff;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int ci = chunk * 32 + 8 * rg + r;
-    const int roff = (ci < Cin && qlive) ? (row[r] * T + tsh[r]) * 4 : OOB;
-    R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + roff, 0, 0));
-  }
-}
-// ---- weights: fragment f = (tap, k-step, 32-cout block) -> lane (co = l31, k-block = hi) holds 8 reduction channels.
-// The launcher re-packs the layer's fp32 weights into exactly that order as bf16 (frag_pack_kernel below):
-//   wf[chunk][j = tap * 2 + k-step][32-cout block][lane] = 8 bf16, 16 bytes,
-// so a fragment is ONE coalesced 1-KiB load per wave and goes to LDS untouched.  (Reading the fp32 arena instead --
-// eight dword loads and four v_cvt_pk per fragment and lane -- was 48 of the 72 loads of a producer wave and step, and a
-// chunk step took 3.2 us against 0.32 us of MFMAs.) ----
-template <int MTW, int NFRAG>
-__device__ __forceinline__ void q_issue_a(const ConvArgs& a, QTile tl, int chunk, int pw, int lane, QStageA<NFRAG>& R) {
-  const int K = a.w.K, CoutP = a.w.CoutP;
-  constexpr int CO32 = 2 * MTW;
-  const int NMB = CoutP / 32, J = 2 * K;
+  for (int r = 0; r < 8; ++r)
+    R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0 + r * T * 4, 0, 0));
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(a.w.wf), 0, K * a.w.CinP * CoutP * 2, 0x00020000);
+      const_cast<void*>(a.w.wf), 0, a.w.K * a.w.CinP * a.w.CoutP * 2 + 8192, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < NFRAG; ++i) {
-    const int f = pw + Q_NP * i;
-    const int mb = f % CO32, j = f / CO32;
-    const int gmb = tl.cot * CO32 + mb;
-    const bool ok = f < J * CO32 && gmb < NMB;
-    const int base = ok ? ((chunk * J + j) * NMB + gmb) * 1024 : 0;
-    const int vo = ok ? lane * 16 : 0x7FFFFF00;  // out of range (checked on the vector offset): zero fragment
-    R.av[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo, base, 0));
+  for (int i = 0; i < NFRAG; ++i)
+    R.av[i] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, k.va[i], p.abase + k.fa[i], 0)));
+  const int tt = p.t0 - a.pad + k.jcol + p.tsh;  // source position of this lane's column
+  R.in = __ballot(tt >= 0 && tt < T);
+  if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+    // lanes 0-7 fetch the per-(batch, channel) scale / shift of the wave's 8 rows; rows past Cin read 0
+    const int Cin = a.w.Cin;
+    const int c0 = p.chunk * 32 + k.rg8;  // reduction row of the wave's first row
+    const __amdgpu_buffer_rsrc_t prs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pa + (size_t)p.b * Cin), 0, Cin * 4, 0x00020000);
+    const int vo = lane < 8 ? (c0 + lane) * 4 : 0x7FFFFF00;
+    R.pa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, vo, 0, 0));
+    if constexpr (PRO != PRO_SCALE) {
+      const __amdgpu_buffer_rsrc_t qrs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ps + (size_t)p.b * Cin), 0, Cin * 4, 0x00020000);
+      R.ps = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, vo, 0, 0));
+    }
+  }
+  if constexpr (PRO == PRO_MASK) {
+    const __amdgpu_buffer_rsrc_t mrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask + (size_t)p.b * T), 0, T * 4, 0x00020000);
+    R.mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, k.jlive ? tt * 4 : 0x7FFFFF00, 0, 0));
   }
 }
 
-template <int PRO>
-__device__ __forceinline__ void q_commit_b(const ConvArgs& a, const QCursor& cu, int LWt, int pw, int lane, const QStageB& R,
-                                           __bf16* bring) {
-  const QTile tl = cu.tl;
-  const int chunk = cu.chunk;
-  const int T = a.T, Cin = a.w.Cin;
-  const int rg = pw & 3, q = pw >> 2;
-  if (!(q < Q_TT / 64 || 64 * q < LWt)) return;
-  int row_[8], tsh[8];
-  q_rows(a, cu, rg, row_, tsh);
-  const int j = lane + 64 * q;
-  const int t = tl.t0 - a.pad + j;
+template <int PRO, int NFRAG>
+__device__ __forceinline__ void q_commit(const QConst<NFRAG>& k, const QSet<NFRAG>& R, __bf16* bbuf, bf16x8* abuf, int lane) {
+#pragma unroll
+  for (int i = 0; i < NFRAG; ++i)
+    if (k.adst[i] >= 0) abuf[k.adst[i] + lane] = R.av[i];
+  const bool in = (R.in >> lane) & 1;
   float v[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int ci = chunk * 32 + 8 * rg + r;
-    const bool live = ci < Cin;
-    float pa = 1.f, ps = 0.f, al = 1.f, ral = 1.f;
-    if (live) {
-      if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
-        pa = a.pa[(size_t)tl.b * Cin + ci];
-        if constexpr (PRO != PRO_SCALE) ps = a.ps[(size_t)tl.b * Cin + ci];
-      }
-      if constexpr (PRO == PRO_AFFINE_SNAKE) {
-        al = a.palpha[ci];
-        ral = 1.0f / al;
-      }
+    float pa = 1.f, ps = 0.f;
+    if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+      pa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, R.pa), r));
+      if constexpr (PRO != PRO_SCALE) ps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, R.ps), r));
     }
-    const int tt = t + tsh[r];  // the source position of this row (flat 2-D: shifted by whole image rows)
-    const bool in = live && tt >= 0 && tt < T;
     float mk = 1.f;
-    if constexpr (PRO == PRO_MASK) mk = in ? a.mask[(size_t)tl.b * T + tt] : 0.f;
-    v[r] = in ? pro_apply<PRO>(R.bv[r], pa, ps, al, ral, mk) : 0.f;  // zero padding AFTER the prologue
+    if constexpr (PRO == PRO_MASK) mk = R.mk;
+    v[r] = in ? pro_apply<PRO>(R.bv[r], pa, ps, 1.f, 1.f, mk) : 0.f;  // zero padding AFTER the prologue
   }
-  if (j < LWt)
-    *reinterpret_cast<bf16x8*>(bring + (size_t)j * Q_PITCH + 8 * rg) =
-        sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-}
-template <int MTW, int NFRAG>
-__device__ __forceinline__ void q_commit_a(const ConvArgs& a, int pw, int lane, const QStageA<NFRAG>& R, bf16x8* aring) {
-  const int K = a.w.K;
-  constexpr int CO32 = 2 * MTW;
-#pragma unroll
-  for (int i = 0; i < NFRAG; ++i) {
-    const int f = pw + Q_NP * i;
-    if (f < K * 2 * CO32) aring[f * 64 + lane] = R.av[i];
-  }
+  if (k.jlive)
+    *reinterpret_cast<bf16x8*>(bbuf + k.bdst) = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
 
 // ---- producer: drain the output stage of a finished tile ----
@@ -297,7 +254,7 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
   }
 }
 
-template <int MTW, int PRO, int RELU>
+template <int MTW, int PRO, int RELU, bool FLAT>
 __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CO32 = 2 * MTW;
@@ -331,27 +288,48 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     // every older one too) is committed to LDS ring slot n & 1 during the step before the consumers need it; its loads
     // were issued TWO chunk steps earlier into register set n & 1 (a chunk step is ~0.3 us of MFMAs, a load round trip 1-2 us: with
     // the loads issued only one step ahead every step waited for them -- measured: no faster than the tiled kernel).
-    const int pw = wave - 4, rg = pw & 3;
-    QStageB R0, R1;
-    QStageA<NFRAG> A0, A1;
-    // two cursors: the chunk being committed and the chunk whose loads are being issued (two ahead)
-    QCursor cc_ = q_cursor_begin(a, first, tiles_per_row, ncot, rg), ci_ = cc_;
-#define STY_Q_ISSUE(R, RA_)                                                  \
-  if (ci_.n < nchunks) {                                                     \
-    if (!(dbg & 2)) q_issue_a<MTW, NFRAG>(a, ci_.tl, ci_.chunk, pw, lane, RA_);              \
-    if (!(dbg & 1)) q_issue_b(a, ci_, LWt, pw, lane, R);                                     \
-  }                                                                          \
-  q_cursor_next(a, ci_, nch, tiles_per_row, ncot, rg);
-#define STY_Q_STEP(R, RA_) /* commit the commit cursor's chunk from its register set, then request the chunk two ahead */ \
-  {                                                                                                      \
-    if (!(dbg & 2)) q_commit_a<MTW, NFRAG>(a, pw, lane, RA_, aring + (cc_.n & 1) * asz);                                 \
-    if (!(dbg & 4)) q_commit_b<PRO>(a, cc_, LWt, pw, lane, R, bring + (cc_.n & 1) * bsz);                                \
-    q_cursor_next(a, cc_, nch, tiles_per_row, ncot, rg);                                                 \
-    STY_Q_ISSUE(R, RA_)                                                                                  \
+    const int pw = wave - 4, rg = pw & 3, q = pw >> 2;
+    const int J = 2 * K, NMB = a.w.CoutP / 32, astep = J * NMB * 1024;
+    QConst<NFRAG> kc;
+    kc.rg8 = 8 * rg;
+    kc.jcol = lane + 64 * q;
+    kc.jlive = kc.jcol < LWt;
+    kc.vcol = (q < Q_TT / 64 || 64 * q < LWt) ? kc.jcol * 4 : 0x7FFFFF00;
+    kc.bdst = kc.jcol * Q_PITCH + 8 * rg;
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) {
+      const int f = pw + Q_NP * i;
+      const int mb = f % CO32, j = f / CO32;
+      const bool ok = f < J * CO32;
+      kc.va[i] = ok ? lane * 16 : 0x7FFFFF00;
+      kc.fa[i] = ok ? (j * NMB + mb) * 1024 : 0;
+      kc.adst[i] = ok ? f * 64 : -1;
+    }
+    QSet<NFRAG> R0, R1;
+    R0.pa = R0.ps = R1.pa = R1.ps = 0.f;
+    R0.mk = R1.mk = 1.f;
+    QPos pi;  // issue position: two chunks ahead of the commit
+    {
+      const QTile t0_ = q_tile(first, tiles_per_row, ncot);  // the only divisions: once per workgroup
+      pi.n = 0;
+      pi.b = t0_.b;
+      pi.t0 = t0_.t0;
+      pi.cot = t0_.cot;
+      q_pos_tile<FLAT>(a, pi, rg, CO32);
+    }
+    int ncommit = 0;  // chunk step number of the next commit
+#define STY_Q_ISSUE(R)                                                          \
+  if (pi.n < nchunks && !(dbg & 1)) q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R); \
+  q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep);
+#define STY_Q_STEP(R) /* commit chunk `ncommit` from its register set, then request the chunk two ahead into the same set */ \
+  {                                                                                                             \
+    if (!(dbg & 4)) q_commit<PRO, NFRAG>(kc, R, bring + (ncommit & 1) * bsz, aring + (ncommit & 1) * asz, lane); \
+    ++ncommit;                                                                                                  \
+    STY_Q_ISSUE(R)                                                                                              \
   }
-    STY_Q_ISSUE(R0, A0)
-    STY_Q_ISSUE(R1, A1)
-    STY_Q_STEP(R0, A0)
+    STY_Q_ISSUE(R0)
+    STY_Q_ISSUE(R1)
+    STY_Q_STEP(R0)
     __syncthreads();
     // consumers' position: tile ti, step c within the tile (c == nch: output-stage step); the tile before it for the drain
     int ti = 0, c = 0;
@@ -361,12 +339,12 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
       if (step == nsteps) break;
       // the chunk the consumers need in the NEXT step is committed now: during a chunk step that is not the tile's last
       // (after the last one comes the output-stage step), and during the output-stage step (the next tile's chunk 0)
-      const bool due = cc_.n < nchunks && (c == nch || c + 1 < nch);
+      const bool due = ncommit < nchunks && (c == nch || c + 1 < nch);
       if (due) {  // chunk n lives in register set n & 1 (copying a set would wait for its loads in flight)
-        if (cc_.n & 1) {
-          STY_Q_STEP(R1, A1)
+        if (ncommit & 1) {
+          STY_Q_STEP(R1)
         } else {
-          STY_Q_STEP(R0, A0)
+          STY_Q_STEP(R0)
         }
       }
       if (++c > nch) {  // next tile
@@ -489,6 +467,7 @@ static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
   static std::mutex mu;
   static std::unordered_map<const float*, std::pair<void*, size_t>> table;
   const size_t bytes = (size_t)a.w.K * a.w.CinP * a.w.CoutP * 2;
+  const size_t slack = 8192;  // a cout tile that hangs over CoutP reads (and discards) up to 4 fragments past the end
   void* wf = nullptr;
   {
     std::lock_guard<std::mutex> lock(mu);
@@ -497,7 +476,7 @@ static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
       if (e.first) STY_HIP(hipFree(e.first));
       e.first = nullptr;
       e.second = 0;
-      STY_HIP(hipMalloc(&e.first, bytes));
+      STY_HIP(hipMalloc(&e.first, bytes + slack));
       e.second = bytes;
     }
     wf = e.first;
@@ -535,6 +514,7 @@ bool convp16_eligible(const ConvArgs& a) {
         a.pro == PRO_SCALE))
     return false;
   if ((a.w.K - 1) * a.dil > 64 * Q_MAXQ - Q_TT) return false;
+  if (a.flatW && (a.Cin2d < 32 || a.Cin2d % 8)) return false;  // a wave's 8 rows share one image-row tap
   if (q_lds_bytes(a) > 160 * 1024) return false;
   const int co = 64 * q_mtw(a);
   const char* mt = getenv("STY_CONVP16_MIN_TILES");  // read per call: the parity tests lower it for small shapes
@@ -547,7 +527,9 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   const size_t lds = q_lds_bytes(a);
   static bool raised = false;
   if (!raised) {
-    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convp16_kernel<MTW, PRO, RELU>),
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convp16_kernel<MTW, PRO, RELU, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convp16_kernel<MTW, PRO, RELU, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised = true;
   }
@@ -565,8 +547,12 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   ProfScope prof(fam, flops, bytes, st, detail);
   const char* de = getenv("STY_Q_DBG");  // timing experiments only (wrong results): 1 no input loads, 2 no weight path,
                                          // 4 no input commit, 8 no drain, 16 no MFMA loop, 32 no accumulator spill
-  hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot, ntiles,
-                     de ? atoi(de) : 0);
+  if (a.flatW)
+    hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU, true>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot,
+                       ntiles, de ? atoi(de) : 0);
+  else
+    hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU, false>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot,
+                       ntiles, de ? atoi(de) : 0);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
