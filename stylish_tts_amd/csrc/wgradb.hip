@@ -309,7 +309,7 @@ int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* par
   const size_t lds = (size_t)(1 + w.K) * 64 * WB_PITCH * sizeof(__bf16);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW);
-  ProfScope prof(w.K == 1 ? "wgradb_kernel<1>" : "wgradb_kernel<3>", 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T,
+  ProfScope prof(w.K == 1 ? "wgradb_kernel<1,true>" : "wgradb_kernel<3,true>", 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T,
                  4.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
   if (w.K == 1)
     wb_launch_pro<1>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
