@@ -22,6 +22,10 @@ struct FrontTables {
   PackedConv dft;           // [n_fft] -> [re_0..re_F-1, im_0..im_F-1]
   PackedConv fb;            // [F] -> [n_mels]
   PackedConv dftT;          // backward: [2F] -> [n_fft]   (transposed basis)
+  // the same transform on FOLDED frames (even part e[n] = x[n] + x[N-n], odd part o[n] = x[n] - x[N-n]): the cosine
+  // half of the basis only sees e (N/2 + 1 rows), the sine half only o (N/2 - 1 rows) -- half the multiply-adds
+  PackedConv dre, dim_;     // [N/2+1] -> [F] re;  [N/2-1] -> [F] im
+  PackedConv dreT, dimT;    // backward: [F] -> [N/2+1], [F] -> [N/2-1]
   PackedConv fbT;           // backward: [n_mels] -> [F]    (transposed filter bank)
   int n_fft = 0, F = 0, n_mels = 0;
 };
@@ -50,6 +54,18 @@ __global__ void dft_basis_kernel(float* __restrict__ wp, int N, int F, int CoutP
   const long long m = ((long long)f * n) % N;
   const double ang = 2.0 * (double)m / (double)N;
   wp[(size_t)n * CoutP + co] = co < F ? (float)cospi(ang) : (float)(-sinpi(ang));
+}
+
+// folded bases: re[f] = sum_{n=0}^{N/2} e[n] cos(2 pi f n / N), im[f] = -sum_{n=1}^{N/2-1} o[n] sin(2 pi f n / N)
+//   which = 0: wp[n][f] = cos, n = 0..N/2;  which = 1: wp[n-1][f] = -sin, n = 1..N/2-1
+__global__ void dft_fold_basis_kernel(float* __restrict__ wp, int N, int F, int CoutP, int which) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y;
+  if (f >= F) return;
+  const int n = which ? row + 1 : row;
+  const long long m = ((long long)f * n) % N;
+  const double ang = 2.0 * (double)m / (double)N;
+  wp[(size_t)row * CoutP + f] = which ? (float)(-sinpi(ang)) : (float)cospi(ang);
 }
 
 // packed HTK mel filter bank (norm=None): wp[f][m]
@@ -132,6 +148,37 @@ static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream
   STY_LAUNCH_CHECK();
   t.dftT.wp = dt;
   t.fbT.wp = ft;
+  {  // folded bases and their transposes
+    const int H = n_fft / 2;
+    auto make = [&](PackedConv& pc, int cin, int cout) {
+      pc.Cin = cin;
+      pc.CinP = (int)align_up(cin, CI_CHUNK);
+      pc.Cout = cout;
+      pc.CoutP = (int)align_up(cout, 128);
+      pc.K = 1;
+      float* q = nullptr;
+      const size_t n = (size_t)pc.CinP * pc.CoutP;
+      if (hipMalloc((void**)&q, n * sizeof(float)) != hipSuccess) return (float*)nullptr;
+      (void)hipMemsetAsync(q, 0, n * sizeof(float), st);
+      pc.wp = q;
+      return q;
+    };
+    float* a0 = make(t.dre, H + 1, F);
+    float* a1 = make(t.dim_, H - 1, F);
+    float* b0 = make(t.dreT, F, H + 1);
+    float* b1 = make(t.dimT, F, H - 1);
+    if (!a0 || !a1 || !b0 || !b1) {
+      set_error("front end: out of memory for the folded DFT bases");
+      return STY_ENOMEM;
+    }
+    hipLaunchKernelGGL(dft_fold_basis_kernel, dim3(cdiv(F, 256), H + 1), dim3(256), 0, st, a0, n_fft, F, t.dre.CoutP, 0);
+    hipLaunchKernelGGL(dft_fold_basis_kernel, dim3(cdiv(F, 256), H - 1), dim3(256), 0, st, a1, n_fft, F, t.dim_.CoutP, 1);
+    hipLaunchKernelGGL(transpose_pack_kernel, dim3(cdiv(F, 256), H + 1), dim3(256), 0, st, a0, H + 1, F, t.dre.CoutP,
+                       t.dreT.CoutP, b0);
+    hipLaunchKernelGGL(transpose_pack_kernel, dim3(cdiv(F, 256), H - 1), dim3(256), 0, st, a1, H - 1, F, t.dim_.CoutP,
+                       t.dimT.CoutP, b1);
+    STY_LAUNCH_CHECK();
+  }
   auto ins = g_tables.emplace(key, t);
   *out = &ins.first->second;
   return STY_OK;
@@ -154,13 +201,39 @@ __global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ au
   xt[b * sb + n * sc + fr] = w[n] * audio[(size_t)b * N + i];
 }
 
+// the same frames, folded: rows 0..N/2 hold e[n] = xt[n] + xt[N-n] (e[0] = xt[0], e[N/2] = xt[N/2]), rows N/2+1..N-1 hold
+// o[n] = xt[n] - xt[N-n] for n = 1..N/2-1 (row N/2 + n).  One thread per (n <= N/2, frame).
+__global__ __launch_bounds__(256) void frame_fold_kernel(const float* __restrict__ audio, const float* __restrict__ w, int N,
+                                                         int n_fft, int hop, int frames, size_t sb, size_t sc,
+                                                         float* __restrict__ xt) {
+  const int fr = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y, b = blockIdx.z;
+  if (fr >= frames) return;
+  const int H = n_fft / 2;
+  auto at = [&](int k) {
+    int i = fr * hop + k - H;
+    if (i < 0) i = -i;
+    if (i >= N) i = 2 * (N - 1) - i;
+    return w[k] * audio[(size_t)b * N + i];
+  };
+  const float u = at(n);
+  if (n == 0 || n == H) {
+    xt[b * sb + n * sc + fr] = u;
+  } else {
+    const float v = at(n_fft - n);
+    xt[b * sb + n * sc + fr] = u + v;
+    xt[b * sb + (size_t)(H + n) * sc + fr] = u - v;
+  }
+}
+
 // y [B][2F][frames] -> power [B][F][frames]
-__global__ void power_kernel(const float* __restrict__ y, int F, int frames, float* __restrict__ p) {
+// (batch-folded: element (b, c, fr) at b*sb + c*sc + fr for both tensors)
+__global__ void power_kernel(const float* __restrict__ y, int F, int frames, size_t sb, size_t sc, float* __restrict__ p) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int f = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
-  const float re = y[((size_t)b * 2 * F + f) * frames + fr], im = y[((size_t)b * 2 * F + F + f) * frames + fr];
-  p[((size_t)b * F + f) * frames + fr] = re * re + im * im;
+  const float re = y[b * sb + f * sc + fr], im = y[b * sb + (size_t)(F + f) * sc + fr];
+  p[b * sb + f * sc + fr] = re * re + im * im;
 }
 
 // y [B][2F][frames] -> |X| and (|X| > 1e-3) * angle(X)  (multi_spectrogram.py:48-49)
@@ -178,15 +251,16 @@ __global__ void magphase_kernel(const float* __restrict__ y, int F, int frames, 
 }
 
 // mel power [B][n_mels][frames] -> normalised log mel (in place allowed) + log energy [B][frames]
-__global__ void mel_finalize_kernel(const float* __restrict__ mp, int n_mels, int frames, float mean, float std_,
-                                    float* __restrict__ mel, float* __restrict__ energy) {
+// mp is batch-folded ((b, m, fr) at b*sb + m*sc + fr), mel / energy are plain [B][n_mels][frames] / [B][frames]
+__global__ void mel_finalize_kernel(const float* __restrict__ mp, int n_mels, int frames, size_t sb, size_t sc, float mean,
+                                    float std_, float* __restrict__ mel, float* __restrict__ energy) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (fr >= frames) return;
   float ss = 0.f;
   for (int m = 0; m < n_mels; ++m) {
     const size_t o = ((size_t)b * n_mels + m) * frames + fr;
-    const float v = (logf(1e-5f + mp[o]) - mean) / std_;
+    const float v = (logf(1e-5f + mp[b * sb + m * sc + fr]) - mean) / std_;
     mel[o] = v;
     const float e = expf(v * std_ + mean);  // log_norm de-normalises the stored value (utils.py:78)
     ss += e * e;
@@ -230,15 +304,20 @@ int launch_mel(int B, int N, const float* audio, int n_fft, int win, int hop, in
   float* y = xt + (size_t)B * n_fft * frames;
   float* p = y + (size_t)B * 2 * F * frames;
   float* mp = p + (size_t)B * F * frames;
-  hipLaunchKernelGGL(frame_kernel, dim3(cdiv(frames, 256), n_fft, B), dim3(256), 0, st, audio, t->window, N, n_fft, hop,
-                     frames, (size_t)n_fft * frames, (size_t)frames, xt);
-  rc = dense(t->dft, xt, B, frames, y, st);
+  // batch-folded layout [C][B*frames] for the intermediates (one GEMM problem with B*frames columns), folded frames
+  // (even / odd parts: half the DFT multiply-adds)
+  const size_t cols = (size_t)B * frames;
+  hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 2 + 1, B), dim3(256), 0, st, audio, t->window, N,
+                     n_fft, hop, frames, (size_t)frames, cols, xt);
+  rc = dense(t->dre, xt, 1, (int)cols, y, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(power_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, p);
-  rc = dense(t->fb, p, B, frames, mp, st);
+  rc = dense(t->dim_, xt + (size_t)(n_fft / 2 + 1) * cols, 1, (int)cols, y + (size_t)F * cols, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(mel_finalize_kernel, dim3(cdiv(frames, 256), B), dim3(256), 0, st, mp, n_mels, frames, mean, std_,
-                     mel, energy);
+  hipLaunchKernelGGL(power_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, (size_t)frames, cols, p);
+  rc = dense(t->fb, p, 1, (int)cols, mp, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mel_finalize_kernel, dim3(cdiv(frames, 256), B), dim3(256), 0, st, mp, n_mels, frames,
+                     (size_t)frames, cols, mean, std_, mel, energy);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -400,8 +479,9 @@ __global__ void magphase_bwd_kernel(const float* __restrict__ y, const float* __
 }
 
 // d audio[b][i] += sum over frames / reflections of w[n] * dxt[b][n][fr]   (gather, no atomics)
+// folded != 0: dxt holds d e (rows 0..N/2) and d o (rows N/2+1..N-1) of frame_fold_kernel's layout
 __global__ void frame_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ w, int N, int n_fft, int hop,
-                                 int frames, size_t sb, size_t sc, float* __restrict__ daudio) {
+                                 int frames, size_t sb, size_t sc, float* __restrict__ daudio, int folded) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= N) return;
   const int half = n_fft / 2;
@@ -421,7 +501,20 @@ __global__ void frame_bwd_kernel(const float* __restrict__ dxt, const float* __r
     if (f_lo < 0) f_lo = 0;
     for (int fr = f_lo; fr <= f_hi; ++fr) {
       const int n = q - fr * hop;
-      if (n >= 0 && n < n_fft) acc = fmaf(w[n], dxt[b * sb + n * sc + fr], acc);
+      if (n >= 0 && n < n_fft) {
+        float g;
+        if (!folded) {
+          g = dxt[b * sb + n * sc + fr];
+        } else if (n == 0 || n == half) {
+          g = dxt[b * sb + n * sc + fr];
+        } else if (n < half) {
+          g = dxt[b * sb + n * sc + fr] + dxt[b * sb + (size_t)(half + n) * sc + fr];
+        } else {
+          const int m = n_fft - n;
+          g = dxt[b * sb + m * sc + fr] - dxt[b * sb + (size_t)(half + m) * sc + fr];
+        }
+        acc = fmaf(w[n], g, acc);
+      }
     }
   }
   daudio[(size_t)b * N + i] += acc;
@@ -494,9 +587,12 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
       float* mg = side == 0 ? rb[r].t_mag : rb[r].p_mag;
       float* ph = side == 0 ? rb[r].t_phase : rb[r].p_phase;
       // batch-folded layout: (sb, sc) = (frames, B*frames) for every tensor, GEMMs over B*frames columns
-      hipLaunchKernelGGL(frame_kernel, dim3(cdiv(frames, 256), n_fft, B), dim3(256), 0, st, audio, t->window, N, n_fft,
-                         rb[r].hop, frames, (size_t)frames, (size_t)B * frames, xt);
-      rc = dense(t->dft, xt, 1, B * frames, yy, st);
+      hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 2 + 1, B), dim3(256), 0, st, audio, t->window,
+                         N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, xt);
+      const size_t cols = (size_t)B * frames;
+      rc = dense(t->dre, xt, 1, B * frames, yy, st);  // re rows from the even part
+      if (rc) return rc;
+      rc = dense(t->dim_, xt + (size_t)(n_fft / 2 + 1) * cols, 1, B * frames, yy + (size_t)F * cols, st);  // im rows from the odd part
       if (rc) return rc;
       hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, yy, F, frames,
                          (size_t)frames, (size_t)frames, (size_t)B * frames, fm, ph);
@@ -527,10 +623,13 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
     if (rc) return rc;
     hipLaunchKernelGGL(magphase_bwd_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, rb[r].p_y, dabs,
                        rb[r].d_phase, F, frames, (size_t)frames, (size_t)frames, (size_t)B * frames, dy);
-    rc = dense(t->dftT, dy, 1, B * frames, dxt, st);
+    const size_t cols = (size_t)B * frames;
+    rc = dense(t->dreT, dy, 1, B * frames, dxt, st);  // d e
+    if (rc) return rc;
+    rc = dense(t->dimT, dy + (size_t)F * cols, 1, B * frames, dxt + (size_t)(n_fft / 2 + 1) * cols, st);  // d o
     if (rc) return rc;
     hipLaunchKernelGGL(frame_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, dxt, t->window, N, n_fft, rb[r].hop,
-                       frames, (size_t)frames, (size_t)B * frames, d_pred);
+                       frames, (size_t)frames, (size_t)B * frames, d_pred, 1);
   }
   STY_LAUNCH_CHECK();
   return STY_OK;
