@@ -114,14 +114,26 @@ def pmc_traffic(family, workload):
     import glob
     import re
     key = re.sub(r"\s+", "", family)
+    base, _, targs = key.partition("<")
+    first = targs.split(",")[0].rstrip(">")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
+        # exact instantiation first; otherwise every instantiation of the family (the library's family names carry the
+        # tile parameter and the bf16 marker only, rocprofv3's carry every template argument): launch-weighted mean
+        tot = n = 0.0
         for k, v in d.items():
-            if key in re.sub(r"\s+", "", k):
+            kk = re.sub(r"\s+", "", k)
+            if key in kk:
                 return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(f, ROOT)
+            m = re.search(r"(?:sty::)?" + re.escape(base) + r"<([^,>]+)", kk)
+            if m and m.group(1) == first:
+                tot += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+                n += v["launches"]
+        if n:
+            return tot / n, os.path.relpath(f, ROOT)
     return None, None
 
 
