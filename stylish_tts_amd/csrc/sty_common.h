@@ -132,6 +132,10 @@ int conv32p_stat_nseg(int T);
 bool wgradb_eligible(const ConvArgs& fwd, bool gmask);
 int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st);
 int wgradb_chunks(const PackedConv& w, int B, int T, int dil);
+// ... and the 32 x 32 many-tap form (eight phase-shifted copies of G in LDS)
+bool wgradp32_eligible(const ConvArgs& fwd);
+int wgradp32_chunks(const ConvArgs& fwd);
+int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st);
 bool convp16_eligible(const ConvArgs& a);
 int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);

@@ -818,6 +818,20 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   const int chunks = fwd.B * chunks_per_b;
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
   if (nsplit > chunks) nsplit = chunks;
+  if (wgradp32_eligible(ax)) {
+    const int KTp = cdiv(w.K, 4);
+    const int wb = (gbias != nullptr && KTp <= 3) ? 1 : 0;  // (the caller's bookkeeping: wgrad_fuses_bias)
+    int ns = nsplit;  // the partial buffer is sized for this many planes
+    const int pc = wgradp32_chunks(ax);
+    if (ns > pc) ns = pc;
+    int rc = launch_wgradp32(ax, ag, ns, partial, wb, st);
+    if (rc) return rc;
+    const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
+    launch_wgrad_reduce(partial, ns, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+    if (bias_done) *bias_done = wb != 0;
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   const int halo = (w.K - 1) * fwd.dil;
   if (halo > 128) {
     set_error("wgrad: halo %d > 128", halo);

@@ -320,4 +320,267 @@ int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* par
 }
 int wgradb_chunks(const PackedConv& w, int B, int T, int dil) { return B * cdiv(T + (w.K - 1) * dil, 128); }  // (a lower bound of the masked variant's count)
 
+
+
+// =====================================================================================================================
+// 32 -> 32-channel convs with many taps (the vocoder's k11 dil 1/3/5 resblock convs, k7 / k21 heads, at the 75T rate),
+// bf16 mode:  dW[k][ci][co] = sum_t G[co][t] x[ci][t + k dil - pad],  K <= 24.
+// One 32 x 32 block of dW for ALL taps per workgroup; the four waves take taps k = wave, wave + 4, ...
+// K shifted copies of G would not fit in LDS.  Eight do: copy p holds G shifted by p samples (p = 0..7), with a left halo
+// of 8 ceil(s_max / 8) columns; tap k with shift s = k dil = 8 a + p reads copy p, 8 a columns to the left -- an
+// aligned ds_read_b128 again.  A thread loads sixteen consecutive samples of a G row (its eight and the eight before)
+// and writes its group into all eight copies (register selection, four v_cvt_pk each).
+// conv1d_wgrad_kernel<3|6,true> (fp32 tiles, operands gathered by ds_read_b32 + v_cvt_pk per tap): 93-107 TFLOP/s.
+// =====================================================================================================================
+constexpr int WP_TW = 64;  // reduction samples per chunk
+
+template <int KT, int PRO, bool GMASK>
+__global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b, int hg,
+                                                          int pg, float* __restrict__ partial, int want_bias) {
+  // hg: halo groups (8 columns each) on the left of every G copy; pg: bf16 elements between rows of a G copy
+  extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
+  constexpr int PX = WP_TW + 8;
+  __bf16* xs = wb_lds;             // [32][PX]
+  __bf16* gs = wb_lds + 32 * PX;   // [8][32][pg]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
+            hi = lane >> 5;
+  const int K = ax.w.K, dil = ax.dil, T = ax.T, pad = ax.pad;
+  const int split = blockIdx.z;
+  const bool do_bias = want_bias != 0;
+  f32x16 acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  // x item: row xr_ (0..31), group xg (0..7).  G items m = 0, 1: row (tid >> 4) + 16 m, group slot tid & 15 -> group
+  // gq = slot - 8 (-8..7); slots left of the halo are idle
+  const int xr_ = tid >> 3, xg8 = (tid & 7) * 8;
+  const int gslot = tid & 15, gq = gslot - 8, grow0 = tid >> 4;
+  const bool glive = gq >= -hg;
+  const int Cx = ax.xc[0], Cg = ag.xc[0];
+  const bool xlive = xr_ < ax.w.Cin;
+  const int offx = xlive ? xr_ * T * 4 : WB_OOB;
+  int offg[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) offg[m] = (grow0 + 16 * m < Cg && glive) ? (grow0 + 16 * m) * T * 4 : WB_OOB;
+  float alpha = 1.f, ralpha = 1.f;
+  if constexpr (PRO == PRO_AFFINE_SNAKE) {
+    if (xlive) {
+      alpha = ax.palpha[xr_];
+      ralpha = 1.0f / alpha;
+    }
+  }
+  float xv[8], gv[2][16], pa = 1.f, ps = 0.f, xm[8], gm[16], bsum[2] = {0.f, 0.f};
+  const int total = ax.B * chunks_per_b;
+  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+  auto load_chunk = [&](int b, int c) {
+    const int t0 = c * WP_TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ax.x[0] + (size_t)b * Cx * T), 0, Cx * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ag.x[0] + (size_t)b * Cg * T), 0, Cg * T * 4, 0x00020000);
+    wb_load_row8(rx, offx, t0 - pad + xg8, T, xv);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {  // sixteen samples: [t - 8, t + 8) with t = t0 + 8 gq
+      float lo[8], hi8[8];
+      wb_load_row8(rg, offg[m], t0 + 8 * gq - 8, T, lo);
+      wb_load_row8(rg, offg[m], t0 + 8 * gq, T, hi8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        gv[m][e] = lo[e];
+        gv[m][8 + e] = hi8[e];
+      }
+    }
+    if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
+      pa = xlive ? ax.pa[(size_t)b * ax.w.Cin + xr_] : 0.f;
+      if constexpr (PRO != PRO_SCALE) ps = xlive ? ax.ps[(size_t)b * ax.w.Cin + xr_] : 0.f;
+    }
+    if constexpr (PRO == PRO_MASK) {
+      const __amdgpu_buffer_rsrc_t rm =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ax.mask + (size_t)b * T), 0, T * 4, 0x00020000);
+      wb_load_row8(rm, 0, t0 - pad + xg8, T, xm);
+    }
+    if constexpr (GMASK) {
+      const __amdgpu_buffer_rsrc_t rm =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ag.mask + (size_t)b * T), 0, T * 4, 0x00020000);
+      float lo[8], hi8[8];
+      wb_load_row8(rm, glive ? 0 : WB_OOB, t0 + 8 * gq - 8, T, lo);
+      wb_load_row8(rm, glive ? 0 : WB_OOB, t0 + 8 * gq, T, hi8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        gm[e] = lo[e];
+        gm[8 + e] = hi8[e];
+      }
+    }
+  };
+  auto advance = [&](int& b, int& c) {
+    c += nsplit;
+    while (c >= chunks_per_b) {
+      c -= chunks_per_b;
+      ++b;
+    }
+  };
+  int ch = split;
+  if (ch < total) load_chunk(cb, cc_);
+  for (; ch < total; ch += nsplit) {
+    const int t0 = cc_ * WP_TW;
+    __syncthreads();
+    {  // x
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float mk = 1.f;
+        if constexpr (PRO == PRO_MASK) mk = xm[e];
+        v[e] = pro_apply<PRO>(xv[e], pa, ps, alpha, ralpha, mk);
+      }
+      const int s0 = t0 - pad + xg8;
+      if (s0 < 0 || s0 + 7 >= T) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (s0 + e >= 0 && s0 + e < T) ? v[e] : 0.f;
+      }
+      *reinterpret_cast<bf16x8*>(xs + xr_ * PX + xg8) = wb_pack(v);
+    }
+    if (glive) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float v[16];
+        const int i0 = t0 + 8 * gq - 8;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = GMASK ? gv[m][e] * gm[e] : gv[m][e];
+        if (i0 < 0 || i0 + 15 >= T) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = (i0 + e >= 0 && i0 + e < T) ? v[e] : 0.f;
+        }
+        if (do_bias && gq >= 0)
+          bsum[m] += ((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]));
+        __bf16* dst = gs + (size_t)(grow0 + 16 * m) * pg + (gq + hg) * 8;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {  // copy p, this group: samples t - p .. t - p + 7
+          const float w8[8] = {v[8 - p], v[9 - p], v[10 - p], v[11 - p], v[12 - p], v[13 - p], v[14 - p], v[15 - p]};
+          *reinterpret_cast<bf16x8*>(dst + (size_t)p * 32 * pg) = wb_pack(w8);
+        }
+      }
+    }
+    __syncthreads();
+    advance(cb, cc_);
+    if (ch + nsplit < total) load_chunk(cb, cc_);
+    // ---- MFMAs: this wave's taps ----
+    const __bf16* xrp = xs + l31 * PX + 8 * hi;
+    bf16x8 bp[WP_TW / 16];
+#pragma unroll
+    for (int s8 = 0; s8 < WP_TW / 16; ++s8) bp[s8] = *reinterpret_cast<const bf16x8*>(xrp + 16 * s8);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int k = wave + 4 * kt;
+      if (k < K) {
+        const int s = k * dil, a8 = s >> 3, p = s & 7;
+        const __bf16* gr = gs + ((size_t)p * 32 + l31) * pg + (hg - a8) * 8 + 8 * hi;
+#pragma unroll
+        for (int s8 = 0; s8 < WP_TW / 16; ++s8) {
+          const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + 16 * s8);
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp[s8], acc[kt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;  // 32, 32
+  const size_t plane = (size_t)K * CinP * CoutP;
+  const size_t stride = plane + CoutP;
+  if (do_bias) {
+    float* pb = partial + (size_t)split * stride + plane;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v = bsum[m];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      if (gslot == 0) pb[grow0 + 16 * m] = v;
+    }
+  }
+  float* pp = partial + (size_t)split * stride;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int k = wave + 4 * kt;
+    if (k < K) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        pp[((size_t)k * CinP + l31) * CoutP + co] = acc[kt][r];
+      }
+    }
+  }
+}
+
+static int wp_hg(const ConvArgs& fwd) { return ((fwd.w.K - 1) * fwd.dil + 7) / 8; }
+static int wp_pg(const ConvArgs& fwd) {
+  int pg = WP_TW + 8 * wp_hg(fwd) + 8;
+  if ((pg / 2) % 8 != 4) pg += 8;  // row stride = 4 (mod 8) dwords: the 16 lanes of a 128-bit LDS access hit 16 bank groups
+  return pg;
+}
+bool wgradp32_eligible(const ConvArgs& fwd) {
+  const PackedConv& w = fwd.w;
+  if (!fwd.bf16 || getenv("STY_NO_WGRADB")) return false;
+  if (w.CinP != 32 || w.CoutP != 32 || w.K < 2 || w.K > 24 || (w.K - 1) * fwd.dil > 64) return false;
+  if (fwd.flatW || fwd.nsrc != 1 || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
+  switch (fwd.pro) {
+    case PRO_NONE:
+    case PRO_MASK:
+    case PRO_LRELU:
+    case PRO_AFFINE:
+    case PRO_AFFINE_LRELU:
+    case PRO_AFFINE_SNAKE:
+    case PRO_SCALE: return true;
+    default: return false;
+  }
+}
+int wgradp32_chunks(const ConvArgs& fwd) { return fwd.B * cdiv(fwd.T + (fwd.w.K - 1) * fwd.dil, WP_TW); }
+
+template <int KT, int PRO>
+static void wp_launch(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
+                      int wb, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradp32_kernel<KT, PRO, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradp32_kernel<KT, PRO, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    raised = true;
+  }
+  const int hg = wp_hg(ax), pg = wp_pg(ax);
+  if (ag.pro == PRO_MASK)
+    hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, true>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial, wb);
+  else
+    hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, false>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial, wb);
+}
+template <int KT>
+static void wp_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
+                          int wb, hipStream_t st) {
+  switch (ax.pro) {
+    case PRO_MASK: wp_launch<KT, PRO_MASK>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_LRELU: wp_launch<KT, PRO_LRELU>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_AFFINE: wp_launch<KT, PRO_AFFINE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_AFFINE_LRELU: wp_launch<KT, PRO_AFFINE_LRELU>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_AFFINE_SNAKE: wp_launch<KT, PRO_AFFINE_SNAKE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    case PRO_SCALE: wp_launch<KT, PRO_SCALE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+    default: wp_launch<KT, PRO_NONE>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st); break;
+  }
+}
+int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st) {
+  const PackedConv& w = ax.w;
+  const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, WP_TW);
+  dim3 grid(1, 1, nsplit);
+  const size_t lds = ((size_t)32 * (WP_TW + 8) + (size_t)8 * 32 * wp_pg(ax)) * sizeof(__bf16);
+  char detail[40];
+  snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d d%d", w.Cin, w.Cout, w.K, ax.T, ax.dil);
+  ProfScope prof(w.K <= 12 ? "wgradp32_kernel<3,true>" : "wgradp32_kernel<6,true>",
+                 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T, 4.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
+  if (w.K <= 12)
+    wp_launch_pro<3>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else
+    wp_launch_pro<6>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 }  // namespace sty
