@@ -384,7 +384,7 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
         gbs = dom["bytes"] / dom["launches"] / per / 1e9
         # a kernel of the bf16 compute mode (",true>" instantiation) is priced against the bf16 MFMA peak; the roof
         # quoted as `bound` is the one the kernel sits closer to (both fractions are in the record)
-        peak = PEAK_BF16_TFLOPS if dom["name"].endswith(",true>") else PEAK_FP32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if dom["name"].endswith("true>") else PEAK_FP32_TFLOPS
         f_mfma, f_hbm = tf / peak, gbs / PEAK_HBM_GBS
         hbm_bound = f_hbm > f_mfma
         rec["roofline"] = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma",

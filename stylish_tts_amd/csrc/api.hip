@@ -680,6 +680,7 @@ struct Run {
         a.y = y;
         a.T = T;
         a.ntiles = nt;
+        a.bf16 = m->topts.compute_bf16;
         chk(launch_convnext32(a, B, 1, st));
         chk(launch_grn_finalize(part, nt, c.grn_gamma, B, 128, scale, st));
         chk(launch_convnext32(a, B, 2, st));

@@ -14,7 +14,9 @@ namespace sty {
 constexpr int CNX_TT = 256;  // time positions per block (4 waves x 2 MFMA column tiles)
 
 
-template <bool PASS2>
+// BF: bf16 compute mode -- the two GEMMs take bf16-rounded operands, eight reduction elements per lane and MFMA (for the
+// chained GEMM-2 the lane's accumulator registers 8 s .. 8 s + 7 with the packed pwconv2 fragments in the same order)
+template <bool PASS2, bool BF>
 __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
   constexpr int LW = CNX_TT + 6;
   __shared__ __attribute__((aligned(16))) float xs[32 * LW];
@@ -98,10 +100,24 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
   // output-channel chunk j: read them from LDS once (32 VGPRs) and reuse them for all four chunks.
   const float* xrow = xs + hi * LW + 3 + tw + l31;
   float bx[16][2];
+  bf16x8 bxf[2][2];  // [k-step][n]
+  if constexpr (BF) {
+    const float* xcol = xs + 3 + tw + l31;
 #pragma unroll
-  for (int c2 = 0; c2 < 16; ++c2)
+    for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) bx[c2][n] = xrow[(2 * c2) * LW + n * 32];
+      for (int n = 0; n < 2; ++n) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xcol[(16 * s_ + 8 * hi + e) * LW + n * 32];
+        bxf[s_][n] = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+  } else {
+#pragma unroll
+    for (int c2 = 0; c2 < 16; ++c2)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bx[c2][n] = xrow[(2 * c2) * LW + n * 32];
+  }
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {
     f32x16 h[2];
@@ -109,15 +125,29 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[n][r] = 0.f;
-    const float* wrow = a.w1p + hi * 128 + j * 32 + l31;
     float av[16];
+    if constexpr (BF) {
+      const float* wcol = a.w1p + j * 32 + l31;
 #pragma unroll
-    for (int c2 = 0; c2 < 16; ++c2) av[c2] = wrow[(2 * c2) * 128];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < 16; ++q) av[q] = wcol[(16 * (q >> 3) + 8 * hi + (q & 7)) * 128];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c2 = 0; c2 < 16; ++c2)
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const bf16x8 af = sty_pack_bf16(av[8 * s_], av[8 * s_ + 1], av[8 * s_ + 2], av[8 * s_ + 3], av[8 * s_ + 4],
+                                        av[8 * s_ + 5], av[8 * s_ + 6], av[8 * s_ + 7]);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) h[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2], bx[c2][n], h[n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) h[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bxf[s_][n], h[n], 0, 0, 0);
+      }
+    } else {
+      const float* wrow = a.w1p + hi * 128 + j * 32 + l31;
+#pragma unroll
+      for (int c2 = 0; c2 < 16; ++c2) av[c2] = wrow[(2 * c2) * 128];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c2 = 0; c2 < 16; ++c2)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) h[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2], bx[c2][n], h[n], 0, 0, 0);
+    }
     float sq[16];
     // Snake argument range check once per 32-element group (wave-uniform branch) instead of per element
     float amax = 0.f;
@@ -158,10 +188,24 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) aw[q] = w2[q * 64];
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BF) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const bf16x8 af = sty_pack_bf16(aw[8 * s_], aw[8 * s_ + 1], aw[8 * s_ + 2], aw[8 * s_ + 3], aw[8 * s_ + 4],
+                                          aw[8 * s_ + 5], aw[8 * s_ + 6], aw[8 * s_ + 7]);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q], h[n][q], acc2[n], 0, 0, 0);
+          for (int n = 0; n < 2; ++n) {
+            const bf16x8 bf = sty_pack_bf16(h[n][8 * s_], h[n][8 * s_ + 1], h[n][8 * s_ + 2], h[n][8 * s_ + 3],
+                                            h[n][8 * s_ + 4], h[n][8 * s_ + 5], h[n][8 * s_ + 6], h[n][8 * s_ + 7]);
+            acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc2[n], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q], h[n][q], acc2[n], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -206,11 +250,17 @@ int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st) {
   const double pos = (double)B * a.T;
   const double flops = pos * (448.0 + 8192.0 + (pass == 2 ? 8192.0 : 0.0));
   const double bytes = pos * 32 * 4.0 * (pass == 2 ? 2.0 : 1.0);
-  ProfScope prof(pass == 1 ? "convnext32_pass1_kernel" : "convnext32_pass2_kernel", flops, bytes, st);
-  if (pass == 1)
-    hipLaunchKernelGGL(convnext32_kernel<false>, grid, dim3(256), 0, st, a);
+  ProfScope prof(pass == 1 ? (a.bf16 ? "convnext32_pass1_kernel<true>" : "convnext32_pass1_kernel<false>")
+                           : (a.bf16 ? "convnext32_pass2_kernel<true>" : "convnext32_pass2_kernel<false>"),
+                 flops, bytes, st);
+  if (pass == 1 && a.bf16)
+    hipLaunchKernelGGL((convnext32_kernel<false, true>), grid, dim3(256), 0, st, a);
+  else if (pass == 1)
+    hipLaunchKernelGGL((convnext32_kernel<false, false>), grid, dim3(256), 0, st, a);
+  else if (a.bf16)
+    hipLaunchKernelGGL((convnext32_kernel<true, true>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL(convnext32_kernel<true>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((convnext32_kernel<true, false>), grid, dim3(256), 0, st, a);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -18,7 +18,11 @@ namespace sty {
 
 constexpr int CB_TT = 256;
 
-template <int PASS>
+// BF: bf16 compute mode -- GEMM-1 (h), U = W2^T gY and (pass 2) the chained gXn = W1^T gH0 each become two
+// v_mfma_f32_32x32x16_bf16 per 32-row block instead of sixteen v_mfma_f32_32x32x2_f32: operands rounded to bf16 on the
+// way in (eight reduction elements per lane: for the chained GEMM the lane's accumulator registers 8 s .. 8 s + 7, rows
+// R(hi, 8 s + e), with the A fragment gathered in the same row order), fp32 accumulation, everything else unchanged.
+template <int PASS, bool BF>
 __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) {
   constexpr int LW = CB_TT + 6, LG = CB_TT + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -128,11 +132,27 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     const bool ok = t < T;
     // B fragments: normalised input (AdaLN affine applied on the way) and the output gradient
     float bx[16], by[16];
+    bf16x8 bxf[2], byf[2];
+    if constexpr (BF) {
 #pragma unroll
-    for (int c2 = 0; c2 < 16; ++c2) {
-      const int c = 2 * c2 + hi;
-      bx[c2] = fmaf(xs[c * LW + 3 + tl], gbs[c], gbs[32 + c]);
-      by[c2] = gys[c * LG + tl];
+      for (int s_ = 0; s_ < 2; ++s_) {
+        float vx[8], vy[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = 16 * s_ + 8 * hi + e;
+          vx[e] = fmaf(xs[c * LW + 3 + tl], gbs[c], gbs[32 + c]);
+          vy[e] = gys[c * LG + tl];
+        }
+        bxf[s_] = sty_pack_bf16(vx[0], vx[1], vx[2], vx[3], vx[4], vx[5], vx[6], vx[7]);
+        byf[s_] = sty_pack_bf16(vy[0], vy[1], vy[2], vy[3], vy[4], vy[5], vy[6], vy[7]);
+      }
+    } else {
+#pragma unroll
+      for (int c2 = 0; c2 < 16; ++c2) {
+        const int c = 2 * c2 + hi;
+        bx[c2] = fmaf(xs[c * LW + 3 + tl], gbs[c], gbs[32 + c]);
+        by[c2] = gys[c * LG + tl];
+      }
     }
     f32x16 gxn;
 #pragma unroll
@@ -142,7 +162,27 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
       f32x16 h, uu;
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[r] = uu[r] = 0.f;
-      {
+      if constexpr (BF) {
+        const float* w1col = a.w1p + j * 32 + l31;  // [ci][ch]
+        const float* w2col = a.w2 + j * 32 + l31;   // raw pwconv2.weight [co][ch]
+        float av[16], a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {  // q = 8 s + e -> reduction row 16 s + 8 hi + e
+          const int c = 16 * (q >> 3) + 8 * hi + (q & 7);
+          av[q] = w1col[c * 128];
+          a2[q] = w2col[c * 128];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const bf16x8 a1f = sty_pack_bf16(av[8 * s_], av[8 * s_ + 1], av[8 * s_ + 2], av[8 * s_ + 3], av[8 * s_ + 4],
+                                           av[8 * s_ + 5], av[8 * s_ + 6], av[8 * s_ + 7]);
+          const bf16x8 a2f = sty_pack_bf16(a2[8 * s_], a2[8 * s_ + 1], a2[8 * s_ + 2], a2[8 * s_ + 3], a2[8 * s_ + 4],
+                                           a2[8 * s_ + 5], a2[8 * s_ + 6], a2[8 * s_ + 7]);
+          h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f, bxf[s_], h, 0, 0, 0);
+          uu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2f, byf[s_], uu, 0, 0, 0);
+        }
+      } else {
         const float* w1row = a.w1p + hi * 128 + j * 32 + l31;  // [ci][ch]
         const float* w2row = a.w2 + hi * 128 + j * 32 + l31;   // raw pwconv2.weight [co][ch]
         float av[16], a2[16];
@@ -158,6 +198,17 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
           uu = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[c2], by[c2], uu, 0, 0, 0);
         }
       }
+      // Snake argument range check once per 32 x 32 block (wave-uniform) instead of a branch per element
+      bool slow = false;
+      if constexpr (BF) {
+        float amax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          amax = fmaxf(amax, fabsf(prm[128 + ch] * (h[r] + prm[ch])));
+        }
+        slow = __any(amax > 8192.0f);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -166,10 +217,13 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
         const float z = h[r] + bias;
         float s2, s2a = 0.f;
         if (PASS == 1) {
-          s2 = sty_sin2(al * z);
+          s2 = (BF && !slow) ? sty_sin2_fast(al * z) : sty_sin2(al * z);
         } else {  // sin^2 and sin(2 a z) = 2 sin cos from one range reduction
           float sn, cs;
-          sty_sincos(al * z, sn, cs);
+          if (BF && !slow)
+            sty_sincos_fast(al * z, sn, cs);
+          else
+            sty_sincos(al * z, sn, cs);
           s2 = sn * sn;
           s2a = 2.f * sn * cs;
         }
@@ -202,8 +256,19 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
         for (int q = 0; q < 16; ++q) aw[q] = a.w1[(size_t)(j * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * 32 + l31];
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BF) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) gxn = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q], h[q], gxn, 0, 0, 0);
+          for (int s_ = 0; s_ < 2; ++s_) {
+            const bf16x8 af = sty_pack_bf16(aw[8 * s_], aw[8 * s_ + 1], aw[8 * s_ + 2], aw[8 * s_ + 3], aw[8 * s_ + 4],
+                                            aw[8 * s_ + 5], aw[8 * s_ + 6], aw[8 * s_ + 7]);
+            const bf16x8 bf = sty_pack_bf16(h[8 * s_], h[8 * s_ + 1], h[8 * s_ + 2], h[8 * s_ + 3], h[8 * s_ + 4],
+                                            h[8 * s_ + 5], h[8 * s_ + 6], h[8 * s_ + 7]);
+            gxn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, gxn, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) gxn = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q], h[q], gxn, 0, 0, 0);
+        }
       }
     }
     if (PASS == 2) {
@@ -291,9 +356,13 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
   constexpr size_t lds = (32 * (CB_TT + 6) + 32 * (CB_TT + 1) + 256 + 4 * 128 + 4 * 64 + 4 * 128 + 64) * sizeof(float);
   static bool raised = false;
   if (!raised) {
-    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<1>),
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<1, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<2>),
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<2, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = true;
   }
@@ -303,11 +372,17 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
   // h s, gH0 (128 each), xn, gU (32 each)
   const double flops = pos * (448.0 + 16384.0 + (pass == 2 ? 8192.0 : 0.0));
   const double bytes = pos * 4.0 * (64.0 + (pass == 2 ? 320.0 : 0.0));
-  ProfScope prof(pass == 1 ? "convnext32_bwd_kernel<1>" : "convnext32_bwd_kernel<2>", flops, bytes, st);
-  if (pass == 1)
-    hipLaunchKernelGGL(convnext32_bwd_kernel<1>, grid, dim3(256), lds, st, a);
+  ProfScope prof(pass == 1 ? (a.bf16 ? "convnext32_bwd_kernel<1,true>" : "convnext32_bwd_kernel<1,false>")
+                           : (a.bf16 ? "convnext32_bwd_kernel<2,true>" : "convnext32_bwd_kernel<2,false>"),
+                 flops, bytes, st);
+  if (pass == 1 && a.bf16)
+    hipLaunchKernelGGL((convnext32_bwd_kernel<1, true>), grid, dim3(256), lds, st, a);
+  else if (pass == 1)
+    hipLaunchKernelGGL((convnext32_bwd_kernel<1, false>), grid, dim3(256), lds, st, a);
+  else if (a.bf16)
+    hipLaunchKernelGGL((convnext32_bwd_kernel<2, true>), grid, dim3(256), lds, st, a);
   else
-    hipLaunchKernelGGL(convnext32_bwd_kernel<2>, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((convnext32_bwd_kernel<2, false>), grid, dim3(256), lds, st, a);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -224,6 +224,7 @@ struct Cnx32Args {
   double* part;         // [B][128][ntiles][2] (pass 1; slot 1 = sum of squares)
   float* y;             // [B][32][T] (pass 2)
   int T, ntiles;
+  int bf16 = 0;         // bf16 compute mode: both GEMMs on v_mfma_f32_32x32x16_bf16
 };
 
 struct Cnx32BwdArgs {       // convnext_bwd.hip
@@ -242,6 +243,7 @@ struct Cnx32BwdArgs {       // convnext_bwd.hip
   float *hs, *gh0;          // [B][128][T] (pass 2) h*s and gH0: operands of the weight-gradient GEMMs
   float *xn, *gu;           // [B][32][T]  (pass 2) normalised input, gradient of the depthwise-conv output
   int T, ntiles;
+  int bf16 = 0;             // bf16 compute mode: the three GEMMs of a pass on v_mfma_f32_32x32x16_bf16
 };
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st);
 int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mode, float* out, hipStream_t st);
@@ -328,6 +330,22 @@ __device__ __forceinline__ void sty_sincos(float x, float& s, float& c) {
     sty_sincos_slow(x, s, c);
     return;
   }
+  const float kf = rintf(x * 0.636619772f);
+  const int k = (int)kf;
+  float r = fmaf(-kf, 1.57079637050628662109375f, x);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  r = fmaf(-kf, -1.71512449e-15f, r);
+  const float r2 = r * r;
+  const float ps = fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+  const float sr = fmaf(r * r2, ps, r);
+  const float pc = fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+  const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  const float sv = (k & 1) ? cr : sr, cv = (k & 1) ? sr : cr;
+  s = (k & 2) ? -sv : sv;
+  c = ((k + 1) & 2) ? -cv : cv;
+}
+// the same without the range check: caller guarantees |x| <= 8192 (checked once per group of elements)
+__device__ __forceinline__ void sty_sincos_fast(float x, float& s, float& c) {
   const float kf = rintf(x * 0.636619772f);
   const int k = (int)kf;
   float r = fmaf(-kf, 1.57079637050628662109375f, x);

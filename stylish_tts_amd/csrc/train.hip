@@ -490,6 +490,7 @@ struct Trainer {
       a.y = y;
       a.T = Tt;
       a.ntiles = nt;
+      a.bf16 = m->topts.compute_bf16;
       chk(launch_convnext32(a, B, 1, st));
       chk(launch_grn_finalize(part, nt, c.grn_gamma, B, 128, scale, st));
       chk(launch_convnext32(a, B, 2, st));
@@ -559,6 +560,7 @@ struct Trainer {
       a.gu = gu;
       a.T = Tt;
       a.ntiles = nt;
+      a.bf16 = m->topts.compute_bf16;
       // weight gradients run on the K = 1 weight-gradient kernel: pw2 from (h s, gY), pw1 from (xn, gH0)
       ConvArgs f2 = base(c.pw2, hs, Tt, nullptr);
       ConvArgs f1 = base(c.pw1, xn, Tt, nullptr);

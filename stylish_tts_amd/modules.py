@@ -436,7 +436,7 @@ class SpeechPredictor(_HipModule):
         return d_mel, d_style
 
 
-    def block_forward_backward(self, kind, prefix, x, style, gy):
+    def block_forward_backward(self, kind, prefix, x, style, gy, compute_bf16=False):
         """One sub-module of the vocoder in the TRAINING graph, forward and backward (sty_block_fwd_bwd): kind "convnext"
         (GeneratorConvNeXtBlock, conv_next.py:80-93) or "resblock" (AdaptiveGeneratorBlock, ada_norm.py:109-120) at the
         state_dict prefix; x, gy [B,C,T], style [B,64] -> (y, d x, d style).  Parameter gradients are added to param.grad.
@@ -445,6 +445,7 @@ class SpeechPredictor(_HipModule):
         self._train = True
         self._tape_id += 1
         lib = self._ensure(dev)
+        self.set_train_opts(compute_bf16=bool(compute_bf16))
         x, style, gy = _f32(x.detach(), dev), _f32(style.detach(), dev), _f32(gy.detach(), dev)
         B, Cc, T = x.shape
         y, gx = torch.empty_like(x), torch.empty_like(x)

@@ -267,6 +267,36 @@ def test_block_backward_vs_float64_oracle(env, kind, prefix, C, T):
     rep.done()
 
 
+def test_convnext32_block_bf16_mode_vs_fp32_mode(env):
+    """The fused ConvNeXt32 backward in the bf16 compute mode (its three GEMMs on v_mfma_f32_32x32x16_bf16, the chained
+    one with the accumulator fragment as B operand in the permuted row order) against the SAME kernels in fp32 mode:
+    only the operand rounding separates them (2^-9 relative per product, averaged down by the 32 / 128-term sums), so
+    every output and every parameter gradient has to agree to 1e-2 of its scale -- a wrong fragment order is O(1)."""
+    import stylish_tts_amd as S
+    prefix, C, T = "generator.basegen.phase_convnext.3", 32, 777
+    g = torch.Generator().manual_seed(12)
+    x, style, gy = torch.randn(2, C, T, generator=g), torch.randn(2, 64, generator=g), torch.randn(2, C, T, generator=g)
+    res = {}
+    for mode in (False, True):
+        m = S.SpeechPredictor()
+        m.load_state_dict({k: v.clone() for k, v in env["P"].items()}, strict=False)
+        m = m.to(DEV).enable_training()
+        m._ensure(torch.device(DEV))
+        for p_ in m.parameters():
+            p_.grad.zero_()
+        y, gx, d_style = m.block_forward_backward("convnext", prefix, dev(x), dev(style), dev(gy), compute_bf16=mode)
+        torch.cuda.synchronize()
+        res[mode] = dict(y=y.cpu(), gx=gx.cpu(), d_style=d_style.cpu(),
+                         **{k[len(prefix) + 1:]: p_.grad.cpu().clone() for k, p_ in m.named_parameters()
+                            if k.startswith(prefix + ".")})
+    rep = Report()
+    for k in res[False]:
+        if res[False][k].abs().max().item() > 0:
+            rep.add(k, res[True][k], res[False][k], 1e-2)
+    rep.done()
+    assert not torch.equal(res[True]["gx"], res[False]["gx"])  # the bf16 kernels really ran
+
+
 @pytest.mark.parametrize("DH,T,masked", [(16, 40, True), (16, 100, True), (64, 160, False), (64, 520, False)])
 def test_attention_backward_vs_float64(DH, T, masked):
     """sty_attention_fwd_bwd: the text encoder's masked attention (DH = 16, VALU backward kernels attn_bwd_{a,b,c}) and
