@@ -210,12 +210,8 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = sq[r];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        if (l31 == 0) red[wave][j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = v;
+        v = sty_half_sum_to_lane31(v);
+        if (l31 == 31) red[wave][j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = v;
       }
     }
   }

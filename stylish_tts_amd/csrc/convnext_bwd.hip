@@ -242,12 +242,8 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
           }
           h[r] = g0;
         }
-        rsum += __shfl_xor(rsum, 1);
-        rsum += __shfl_xor(rsum, 2);
-        rsum += __shfl_xor(rsum, 4);
-        rsum += __shfl_xor(rsum, 8);
-        rsum += __shfl_xor(rsum, 16);
-        if (l31 == 0) red[wave * 128 + ch] += rsum;  // the same lane owns this slot in both passes
+        rsum = sty_half_sum_to_lane31(rsum);
+        if (l31 == 31) red[wave * 128 + ch] += rsum;  // the same lane owns this slot in both passes
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the per-channel loads / store addresses of later
                                                               // rows from being hoisted (that cost 106 spilled VGPRs)
       }
@@ -292,12 +288,9 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
         const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (ok) bst(r_gu, rs * (gxh[r] - s1 - xh[r] * s2), (c * T + t) * 4);
         float v = ok ? gxn[r] * xh[r] : 0.f, w = ok ? gxn[r] : 0.f;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-          v += __shfl_xor(v, o);
-          w += __shfl_xor(w, o);
-        }
-        if (l31 == 0) {
+        v = sty_half_sum_to_lane31(v);
+        w = sty_half_sum_to_lane31(w);
+        if (l31 == 31) {
           red2[wave * 64 + c] += v;
           red2[wave * 64 + 32 + c] += w;
         }

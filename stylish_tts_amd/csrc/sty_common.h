@@ -360,6 +360,22 @@ __device__ __forceinline__ void sty_sincos_fast(float x, float& s, float& c) {
   s = (k & 2) ? -sv : sv;
   c = ((k + 1) & 2) ? -cv : cv;
 }
+// Sum over each 32-lane half of the wave with DPP row operations: six v_add_f32 with a DPP source modifier instead of
+// five ds_bpermute round trips through the LDS crossbar (what __shfl_xor compiles to): the ConvNeXt32 backward issued
+// ~1 000 of those per tile and wave.  The total lands in lane 31 (lanes 0-31) and lane 63 (lanes 32-63) ONLY.
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ float sty_dpp(float src) {  // masked-out / out-of-row lanes read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+__device__ __forceinline__ float sty_half_sum_to_lane31(float v) {
+  float t = v + sty_dpp<0x111, 0xf, 0xf, true>(v);  // row_shr:1
+  t += sty_dpp<0x112, 0xf, 0xf, true>(v);           // row_shr:2
+  t += sty_dpp<0x113, 0xf, 0xf, true>(v);           // row_shr:3: sum of four ending at this lane
+  t += sty_dpp<0x114, 0xf, 0xe, false>(t);          // row_shr:4, banks 1-3: sum of eight
+  t += sty_dpp<0x118, 0xf, 0xc, false>(t);          // row_shr:8, banks 2-3: lane 15 of each row holds the row sum
+  t += sty_dpp<0x142, 0xa, 0xf, false>(t);          // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold 32-lane sums
+  return t;
+}
 // Snake: v + sin^2(alpha v) / alpha   (conv_next.py:78, ada_norm.py:114)
 __device__ __forceinline__ float sty_snake(float v, float alpha, float ralpha) {
   return fmaf(ralpha, sty_sin2(alpha * v), v);
