@@ -262,30 +262,58 @@ int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* 
 
 // ---- backward ----
 // depthwise 3x3 stride 2 pad 1: dx (+=), dw9 (+=, w.r.t. the EFFECTIVE weights), db (+=)
+// One thread per FOUR consecutive elements of one (batch, channel) image in its padded-flat storage [H][W + 1]: 16-byte
+// read-modify-write of dx (the image base is 16-byte aligned when H (W + 1) is a multiple of 4; otherwise element by
+// element), the pad column is skipped.  (One thread per element on a (W/256, H, B C) grid -- a third of the workgroups
+// nearly empty, scalar accesses on odd row pitches -- ran at a fifth of the HBM rate.)
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __restrict__ gy,
                                                                  const float* __restrict__ w9, int C, int H, int W,
                                                                  int Ho, int Wo, float* __restrict__ dx) {
-  const int wi = blockIdx.x * 256 + threadIdx.x;
-  const int hi = blockIdx.y, bc = blockIdx.z, c = bc % C;
-  if (wi >= W) return;
-  const int ldi = W + 1, ldo = Wo + 1;
+  const int bc = blockIdx.y, c = bc % C;
+  const int ldi = W + 1, ldo = Wo + 1, n = H * ldi;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
   const float* g = gy + (size_t)bc * Ho * ldo;
-  float acc = 0.f;
+  float* d = dx + (size_t)bc * n;
+  int hi = i0 / ldi, wi = i0 - hi * ldi;
+  float acc[4];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    const int hn = hi + 1 - kh;  // 2 ho = hi + 1 - kh
-    if (hn < 0 || (hn & 1)) continue;
-    const int ho = hn >> 1;
-    if (ho >= Ho) continue;
+  for (int e = 0; e < 4; ++e) {
+    float a = 0.f;
+    if (i0 + e < n && wi < W) {
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int wn = wi + 1 - kw;
-      if (wn < 0 || (wn & 1)) continue;
-      const int wo = wn >> 1;
-      if (wo < Wo) acc = fmaf(w9[c * 9 + kh * 3 + kw], g[(size_t)ho * ldo + wo], acc);
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hn = hi + 1 - kh;  // 2 ho = hi + 1 - kh
+        if (hn < 0 || (hn & 1)) continue;
+        const int ho = hn >> 1;
+        if (ho >= Ho) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wn = wi + 1 - kw;
+          if (wn < 0 || (wn & 1)) continue;
+          const int wo = wn >> 1;
+          if (wo < Wo) a = fmaf(w9[c * 9 + kh * 3 + kw], g[(size_t)ho * ldo + wo], a);
+        }
+      }
+    }
+    acc[e] = a;
+    if (++wi == ldi) {
+      wi = 0;
+      ++hi;
     }
   }
-  dx[((size_t)bc * H + hi) * ldi + wi] += acc;
+  if ((n & 3) == 0 && i0 + 3 < n) {
+    float4 v = *reinterpret_cast<float4*>(d + i0);
+    v.x += acc[0];
+    v.y += acc[1];
+    v.z += acc[2];
+    v.w += acc[3];
+    *reinterpret_cast<float4*>(d + i0) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e < n) d[i0 + e] += acc[e];
+  }
 }
 // one workgroup per (channel, batch row): 10 partial sums; summed over the batch in a fixed order afterwards
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_part_kernel(const float* __restrict__ x,
@@ -337,8 +365,8 @@ size_t dwconv2d_s2_bwd_scratch_floats(int B, int C) { return (size_t)B * C * 10;
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int B, int C, int H, int W, float* dx,
                            float* dw9, float* db, float* scratch, hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(dwconv2d_s2_bwd_dx_kernel, dim3(cdiv(W, 256), H, B * C), dim3(256), 0, st, gy, w9, C, H, W, Ho, Wo,
-                     dx);
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_dx_kernel, dim3(cdiv(H * (W + 1), 1024), B * C), dim3(256), 0, st, gy, w9, C, H, W,
+                     Ho, Wo, dx);
   hipLaunchKernelGGL(dwconv2d_s2_bwd_w_part_kernel, dim3(C, B), dim3(256), 0, st, x, gy, C, H, W, Ho, Wo, scratch);
   hipLaunchKernelGGL(dwconv2d_s2_bwd_w_sum_kernel, dim3(cdiv(C * 10, 64)), dim3(64), 0, st, scratch, C, B, dw9, db);
   STY_LAUNCH_CHECK();
@@ -373,19 +401,45 @@ int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const
 }
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gy, int H, int W, int Ho, int Wo,
                                                            float scale, float* __restrict__ dx) {
-  const int wi = blockIdx.x * 256 + threadIdx.x;
-  const int hi = blockIdx.y, bc = blockIdx.z;
-  if (wi >= W) return;
-  const int ho = hi >> 1;
-  const int wo = wi >> 1;
-  float g = gy[((size_t)bc * Ho + ho) * (Wo + 1) + wo];
-  // odd W: the last column was replicated, so it is read twice by the last output column
-  const float mult = (W & 1) && wi == W - 1 ? 2.f : 1.f;
-  dx[((size_t)bc * H + hi) * (W + 1) + wi] += g * 0.25f * scale * mult;
+  // (four consecutive elements of the padded-flat image per thread, as in dwconv2d_s2_bwd_dx_kernel)
+  const int bc = blockIdx.y;
+  const int ldi = W + 1, n = H * ldi;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  const float* g = gy + (size_t)bc * Ho * (Wo + 1);
+  float* d = dx + (size_t)bc * n;
+  int hi = i0 / ldi, wi = i0 - hi * ldi;
+  float acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = 0.f;
+    if (i0 + e < n && wi < W && (hi >> 1) < Ho) {
+      // odd W: the last column was replicated, so it is read twice by the last output column
+      const float mult = (W & 1) && wi == W - 1 ? 2.f : 1.f;
+      a = g[(size_t)(hi >> 1) * (Wo + 1) + (wi >> 1)] * 0.25f * scale * mult;
+    }
+    acc[e] = a;
+    if (++wi == ldi) {
+      wi = 0;
+      ++hi;
+    }
+  }
+  if ((n & 3) == 0 && i0 + 3 < n) {
+    float4 v = *reinterpret_cast<float4*>(d + i0);
+    v.x += acc[0];
+    v.y += acc[1];
+    v.z += acc[2];
+    v.w += acc[3];
+    *reinterpret_cast<float4*>(d + i0) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e < n) d[i0 + e] += acc[e];
+  }
 }
 int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, hipStream_t st) {
   const int Ho = H / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cdiv(W, 256), H, BC), dim3(256), 0, st, gy, H, W, Ho, Wo, scale, dx);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cdiv(H * (W + 1), 1024), BC), dim3(256), 0, st, gy, H, W, Ho, Wo, scale, dx);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
