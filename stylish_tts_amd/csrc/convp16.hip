@@ -518,7 +518,7 @@ bool convp16_eligible(const ConvArgs& a) {
   if (q_lds_bytes(a) > 160 * 1024) return false;
   const int co = 64 * q_mtw(a);
   const char* mt = getenv("STY_CONVP16_MIN_TILES");  // read per call: the parity tests lower it for small shapes
-  const int min_tiles = mt ? atoi(mt) : 512;
+  const int min_tiles = mt ? atoi(mt) : 256;  // one tile per CU at least (c3: 88.3 ms at 512, 87.2 at 256, 87.4 at 128)
   return (long)cdiv(a.T, Q_TT) * a.B * cdiv(a.w.CoutP, co) >= min_tiles;
 }
 

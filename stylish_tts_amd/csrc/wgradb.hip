@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
             hi = lane >> 5;
   const int K = ax.w.K, dil = ax.dil, T = ax.T, pad = ax.pad;
   const int split = blockIdx.z;
-  const bool do_bias = want_bias != 0;
+  const bool do_bias = want_bias != 0 && blockIdx.x == 0;
   f32x16 acc[KT];
 #pragma unroll
   for (int k = 0; k < KT; ++k)
@@ -357,16 +357,21 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
   const int xr_ = tid >> 3, xg8 = (tid & 7) * 8;
   const int gslot = tid & 15, gq = gslot - 8, grow0 = tid >> 4;
   const bool glive = gq >= -hg;
-  const int Cx = ax.xc[0], Cg = ag.xc[0];
-  const bool xlive = xr_ < ax.w.Cin;
-  const int offx = xlive ? xr_ * T * 4 : WB_OOB;
+  // 32-row block of the reduction rows: blockIdx.x.  One source: rows ci0 .. ci0 + 31 of it; channel-concatenated
+  // sources of 32 channels each (the launcher checks): source blockIdx.x, rows 0 .. 31
+  const int ci0 = blockIdx.x * 32, cir = ci0 + xr_;
+  const bool multi = ax.nsrc > 1;
+  const float* xsrc = multi ? (blockIdx.x == 0 ? ax.x[0] : (blockIdx.x == 1 ? ax.x[1] : ax.x[2])) : ax.x[0];
+  const int Cx = multi ? 32 : ax.xc[0], Cg = ag.xc[0];
+  const bool xlive = cir < ax.w.Cin;
+  const int offx = xlive ? (multi ? xr_ : cir) * T * 4 : WB_OOB;
   int offg[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) offg[m] = (grow0 + 16 * m < Cg && glive) ? (grow0 + 16 * m) * T * 4 : WB_OOB;
   float alpha = 1.f, ralpha = 1.f;
   if constexpr (PRO == PRO_AFFINE_SNAKE) {
     if (xlive) {
-      alpha = ax.palpha[xr_];
+      alpha = ax.palpha[cir];
       ralpha = 1.0f / alpha;
     }
   }
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
   auto load_chunk = [&](int b, int c) {
     const int t0 = c * WP_TW;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(ax.x[0] + (size_t)b * Cx * T), 0, Cx * T * 4, 0x00020000);
+        const_cast<float*>(xsrc + (size_t)b * Cx * T), 0, Cx * T * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(ag.x[0] + (size_t)b * Cg * T), 0, Cg * T * 4, 0x00020000);
     wb_load_row8(rx, offx, t0 - pad + xg8, T, xv);
@@ -392,8 +397,8 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
       }
     }
     if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
-      pa = xlive ? ax.pa[(size_t)b * ax.w.Cin + xr_] : 0.f;
-      if constexpr (PRO != PRO_SCALE) ps = xlive ? ax.ps[(size_t)b * ax.w.Cin + xr_] : 0.f;
+      pa = xlive ? ax.pa[(size_t)b * ax.w.Cin + cir] : 0.f;
+      if constexpr (PRO != PRO_SCALE) ps = xlive ? ax.ps[(size_t)b * ax.w.Cin + cir] : 0.f;
     }
     if constexpr (PRO == PRO_MASK) {
       const __amdgpu_buffer_rsrc_t rm =
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
       }
     }
   }
-  const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;  // 32, 32
+  const int CinP = ax.w.CinP, CoutP = ax.w.CoutP;  // 32 n, 32
   const size_t plane = (size_t)K * CinP * CoutP;
   const size_t stride = plane + CoutP;
   if (do_bias) {
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        pp[((size_t)k * CinP + l31) * CoutP + co] = acc[kt][r];
+        pp[((size_t)k * CinP + ci0 + l31) * CoutP + co] = acc[kt][r];
       }
     }
   }
@@ -521,8 +526,13 @@ static int wp_pg(const ConvArgs& fwd) {
 bool wgradp32_eligible(const ConvArgs& fwd) {
   const PackedConv& w = fwd.w;
   if (!fwd.bf16 || getenv("STY_NO_WGRADB")) return false;
-  if (w.CinP != 32 || w.CoutP != 32 || w.K < 2 || w.K > 24 || (w.K - 1) * fwd.dil > 64) return false;
-  if (fwd.flatW || fwd.nsrc != 1 || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
+  if (w.CinP % 32 || w.CinP > 96 || w.CoutP != 32 || w.K < 2 || w.K > 24 || (w.K - 1) * fwd.dil > 64) return false;
+  if (fwd.flatW || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
+  if (fwd.nsrc != 1) {  // channel-concatenated input: one 32-channel source per 32-row block
+    if (fwd.nsrc != w.CinP / 32) return false;
+    for (int i = 0; i < fwd.nsrc; ++i)
+      if (fwd.xc[i] != 32) return false;
+  }
   switch (fwd.pro) {
     case PRO_NONE:
     case PRO_MASK:
@@ -569,7 +579,7 @@ static void wp_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, siz
 int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st) {
   const PackedConv& w = ax.w;
   const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, WP_TW);
-  dim3 grid(1, 1, nsplit);
+  dim3 grid(w.CinP / 32, 1, nsplit);
   const size_t lds = ((size_t)32 * (WP_TW + 8) + (size_t)8 * 32 * wp_pg(ax)) * sizeof(__bf16);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d d%d", w.Cin, w.Cout, w.K, ax.T, ax.dil);

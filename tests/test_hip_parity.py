@@ -1068,6 +1068,68 @@ def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monke
     assert all(bool(torch.isfinite(v).all()) for v in b.values())
 
 
+def test_bf16_weight_gradient_kernels_match_the_fp32_tile_kernels_in_the_graphs(env, monkeypatch):
+    """A weight gradient is a leaf of the backward graph: switching ONLY the weight-gradient kernels (wgradb / wgradp32,
+    bf16 tiles in LDS, vs the fp32-tile kernels they replace in the bf16 mode; STY_NO_WGRADB) leaves every activation
+    and every input gradient bit-identical, so each parameter gradient of the two runs differs by fp32 summation order
+    alone -- a tight gate on the new kernels inside the real graphs: flat 2-D rows, pad-column masks on G, AdaIN / Snake /
+    LeakyReLU prologues, the 3 x 32-channel concatenated input of phase_input_conv, k = 1 / 3 / 11 / 21."""
+    import stylish_tts_amd as S
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from stylish_tts_amd import lib as L
+    cs = env["cs"]
+    mel = torch.randn(3, 1, 80, 161, generator=torch.Generator().manual_seed(9))
+    gs = torch.randn(3, 64, generator=torch.Generator().manual_seed(10))
+    out = {}
+    for mode in ("old", "new"):
+        monkeypatch.delenv("STY_NO_WGRADB", raising=False)
+        if mode == "old":
+            monkeypatch.setenv("STY_NO_WGRADB", "1")
+        se = S.MelStyleEncoder()
+        se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+        se = se.to(DEV).enable_training().set_train_opts(compute_bf16=True)
+        L.prof_report(512)
+        L.load().sty_prof_enable(1)
+        se.forward_train(dev(mel))
+        se.backward(dev(gs))
+        sp = S.SpeechPredictor()
+        sp.load_state_dict({k: v.clone() for k, v in env["P"].items()}, strict=False)
+        sp = sp.to(DEV).enable_training().set_train_opts(compute_bf16=True)
+        audio = sp.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(env["ali"]), dev(cs["pitch"]),
+                                 dev(cs["energy"]), dev(env["voiced"]), dev(cs["style"]), dev(cs["pitch"]),
+                                 noise=dev(cs["noise"]))
+        d_style, _ = sp.backward(torch.sign(audio) / audio.numel(), want_energy=False)
+        torch.cuda.synchronize()
+        L.load().sty_prof_enable(0)
+        names = {r["name"] for r in L.prof_report(512)}
+        has = any(n.startswith("wgradb") for n in names), any(n.startswith("wgradp32") for n in names)
+        assert has == ((True, True) if mode == "new" else (False, False)), names
+        out[mode] = dict(audio=audio.cpu(), d_style=d_style.cpu(),
+                         g={("se." + k): p.grad.cpu().clone() for k, p in se.named_parameters()}
+                         | {("sp." + k): p.grad.cpu().clone() for k, p in sp.named_parameters()})
+    assert torch.equal(out["old"]["audio"], out["new"]["audio"])
+    ds = ((out["new"]["d_style"] - out["old"]["d_style"]).norm() / out["old"]["d_style"].norm()).item()
+    print(f"\n  d_style new vs old: {ds:.2e}")
+    worst = []
+    for k, a in out["old"]["g"].items():
+        b = out["new"]["g"][k]
+        den = a.norm().item()
+        if k.endswith(".bias"):
+            # a bias in front of an instance norm (convs1.* of the resblocks, conv1 of the decoder blocks) has a structurally
+            # zero gradient: rounding noise on both sides.  Recognised by its size next to the layer's weight gradient.
+            wk = [k[:-4] + s_ for s_ in ("weight", "parametrizations.weight.original1", "weight_orig")]
+            wn = max([out["old"]["g"][q].norm().item() for q in wk if q in out["old"]["g"]] + [0.0])
+            if den < 1e-4 * wn:
+                continue
+        if den > 0:
+            worst.append(((b - a).norm().item() / den, k))
+    worst.sort(reverse=True)
+    print("\n  weight-gradient kernels, new vs old (relative L2 per tensor), worst five: " +
+          "  ".join(f"{k} {e:.2e}" for e, k in worst[:5]))
+    assert worst[0][0] <= 2e-4 and ds <= 1e-5, worst[:5]
+
+
 def _sub(t, stride=97):
     t = t.detach().flatten()
     return t[::stride] if t.numel() > 4096 else t
