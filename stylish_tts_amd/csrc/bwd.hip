@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void pro_bwd_kernel(int mode, const float* __r
     float dal = 0.f;
     if (mode == PRO_AFFINE_SNAKE) {
       const float z = a * xv + s;
-      const float s2 = sty_sin2(al * z), s2a = sty_sinf(2.f * al * z);
+      float sn, cs;  // sin^2(a z) and sin(2 a z) = 2 sin cos from ONE range reduction
+      sty_sincos(al * z, sn, cs);
+      const float s2 = sn * sn, s2a = 2.f * sn * cs;
       g = uv * (1.f + s2a);
       dal = uv * (z * s2a - s2 / al) / al;
     } else if (mode == PRO_AFFINE_LRELU) {
@@ -431,7 +433,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int kind, const float* __r
       const float sg = 1.f / (1.f + expf(-v));
       g = d * (sg + v * sg * (1.f - sg));
     } else if (kind == ACT_SNAKE) {
-      const float s2 = sty_sin2(al * v), s2a = sty_sinf(2.f * al * v);
+      float sn, cs;
+      sty_sincos(al * v, sn, cs);
+      const float s2 = sn * sn, s2a = 2.f * sn * cs;
       g = d * (1.f + s2a);
       acc[0] += (double)(d * (v * s2a - s2 / al) / al);
     } else if (kind == 100) {

@@ -42,8 +42,12 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
   // addresses of the flat form cost ~80 spilled VGPRs)
   __amdgpu_buffer_rsrc_t r_hs, r_g0, r_xn, r_gu;
   if (PASS == 2) {
-    r_hs = __builtin_amdgcn_make_buffer_rsrc(a.hs + (size_t)b * 128 * T, 0, 128 * T * 4, 0x00020000);
-    r_g0 = __builtin_amdgcn_make_buffer_rsrc(a.gh0 + (size_t)b * 128 * T, 0, 128 * T * 4, 0x00020000);
+    // (out_bf16: the two 128-channel outputs are bf16 tensors [B][128][T] in the same buffers)
+    const int esz = a.out_bf16 ? 2 : 4;
+    r_hs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.hs) + (size_t)b * 128 * T * esz, 0, 128 * T * esz,
+                                             0x00020000);
+    r_g0 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.gh0) + (size_t)b * 128 * T * esz, 0, 128 * T * esz,
+                                             0x00020000);
     r_xn = __builtin_amdgcn_make_buffer_rsrc(a.xn + (size_t)b * 32 * T, 0, 32 * T * 4, 0x00020000);
     r_gu = __builtin_amdgcn_make_buffer_rsrc(a.gu + (size_t)b * 32 * T, 0, 32 * T * 4, 0x00020000);
   }
@@ -237,8 +241,15 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
           const float g0 = gH * (1.f + s2a);
           rsum = gH * (z * s2a - s2 * ral) * ral;
           if (ok) {
-            bst(r_hs, hv * sc, (ch * T + t) * 4);
-            bst(r_g0, g0, (ch * T + t) * 4);
+            if (BF && a.out_bf16) {
+              const bf16x8 pk = sty_pack_bf16(hv * sc, g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+              const unsigned two = __builtin_bit_cast(uint4, pk).x;
+              __builtin_amdgcn_raw_buffer_store_b16((short)(two & 0xffffu), r_hs, (ch * T + t) * 2, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b16((short)(two >> 16), r_g0, (ch * T + t) * 2, 0, 0);
+            } else {
+              bst(r_hs, hv * sc, (ch * T + t) * 4);
+              bst(r_g0, g0, (ch * T + t) * 4);
+            }
           }
           h[r] = g0;
         }

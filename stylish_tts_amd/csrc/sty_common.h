@@ -136,6 +136,12 @@ int wgradb_chunks(const PackedConv& w, int B, int T, int dil);
 bool wgradp32_eligible(const ConvArgs& fwd);
 int wgradp32_chunks(const ConvArgs& fwd);
 int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st);
+// ... and the two pointwise weight gradients of a fused ConvNeXt32 block from its bf16 outputs
+int wgrad_cnx_nsplit(int B, int T);
+int launch_conv_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* gwp, float* partial,
+                          float* gbias, hipStream_t st);
+int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
+                     hipStream_t st);
 bool convp16_eligible(const ConvArgs& a);
 int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);
@@ -244,6 +250,7 @@ struct Cnx32BwdArgs {       // convnext_bwd.hip
   float *xn, *gu;           // [B][32][T]  (pass 2) normalised input, gradient of the depthwise-conv output
   int T, ntiles;
   int bf16 = 0;             // bf16 compute mode: the three GEMMs of a pass on v_mfma_f32_32x32x16_bf16
+  int out_bf16 = 0;         // (pass 2, bf16 mode) hs and gh0 are written as bf16 [B][128][T]: operands of wgrad_cnx_kernel
 };
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st);
 int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mode, float* out, hipStream_t st);

@@ -561,6 +561,9 @@ struct Trainer {
       a.T = Tt;
       a.ntiles = nt;
       a.bf16 = m->topts.compute_bf16;
+      // bf16 mode: h s and gH0 leave the kernel as bf16 and feed wgrad_cnx_kernel (T % 8: its 8-sample groups)
+      const bool cnx16 = a.bf16 && Tt % 8 == 0 && getenv("STY_NO_WGRADB") == nullptr;
+      a.out_bf16 = cnx16;
       // weight gradients run on the K = 1 weight-gradient kernel: pw2 from (h s, gY), pw1 from (xn, gH0)
       ConvArgs f2 = base(c.pw2, hs, Tt, nullptr);
       ConvArgs f1 = base(c.pw1, xn, Tt, nullptr);
@@ -584,16 +587,26 @@ struct Trainer {
       const float* dww = c.dw_w;
       if (side) {
         side_push(gY, [=](hipStream_t s2) {
-          chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, gw2, p2, gb2, nullptr, s2));
-          chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, nullptr, s2));
+          if (cnx16) {
+            chk(launch_conv_wgrad_cnx(1, hs, gY, B, Tt, gw2, p2, gb2, s2));
+            chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, s2));
+          } else {
+            chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, gw2, p2, gb2, nullptr, s2));
+            chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, nullptr, s2));
+          }
           chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, s2));
         });
         // input gradient of the depthwise conv on the main stream
         if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
       } else if (live()) {
         bool done = false;
-        chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, gw2, p2, gb2, &done, st));
-        chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, &done, st));
+        if (cnx16) {
+          chk(launch_conv_wgrad_cnx(1, hs, gY, B, Tt, gw2, p2, gb2, st));
+          chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, st));
+        } else {
+          chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, gw2, p2, gb2, &done, st));
+          chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, &done, st));
+        }
         // depthwise conv backward from gU; note gX may alias gY, which every kernel above has finished reading
         chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, gdw, gdb, dsc, st));
       }

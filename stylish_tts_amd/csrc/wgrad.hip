@@ -883,6 +883,19 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   return STY_OK;
 }
 
+// the two pointwise weight gradients of a fused ConvNeXt32 block from its bf16 outputs (wgradb.hip): kernel + reduction
+int launch_conv_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* gwp, float* partial,
+                          float* gbias, hipStream_t st) {
+  const int wb = gbias != nullptr;
+  int rc = launch_wgrad_cnx(x_wide, wide, narrow, B, T, partial, wb, st);
+  if (rc) return rc;
+  const int coutp = x_wide ? 32 : 128;
+  const size_t plane = 128 * 32;
+  launch_wgrad_reduce(partial, wgrad_cnx_nsplit(B, T), plane, plane + coutp, wb ? coutp : 0, 1.0f, gwp, gbias, st);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // ---- input-gradient weights: Wd[k'][co][ci] = Wp[K-1-k'][ci][co] ----
 __global__ void pack_dgrad_kernel(const float* __restrict__ wp, int K, int CinP, int CoutP, float* __restrict__ wd) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -594,3 +594,141 @@ int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* p
 }
 
 }  // namespace sty
+
+namespace sty {
+// =====================================================================================================================
+// The two pointwise weight gradients of a fused ConvNeXt32 block in the bf16 mode (conv_next.py:80-93, pwconv1 / pwconv2
+// at the 75T rate):  dW2[co][ch] = sum_t gY[co][t] (h s)[ch][t],   dW1[ch][ci] = sum_t gH0[ch][t] xn[ci][t].
+// convnext32_bwd_kernel<2,true> writes its two 128-channel outputs (h s, gH0) as bf16 -- they exist for these GEMMs only --
+// so the wide operand arrives ready for the MFMA: one 16-byte load, one ds_write_b128, no conversion.  HBM-bound:
+// 2 x 128 + 4 x 32 bytes per position instead of 4 x 160 (wgrad_k1_kernel<4,1|1,4>: 2.9-3.4 TB/s on 0.8 GB).
+// T % 8 == 0 (the caller checks): an 8-sample group is inside the row or past its end, never across.
+// =====================================================================================================================
+template <bool XWIDE>  // XWIDE: x is the bf16 [B][128][T] tensor and G the fp32 [B][32][T] one; else the other way round
+__global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restrict__ wide, const float* __restrict__ narrow,
+                                                           int B, int T, int nsplit, int chunks_per_b,
+                                                           float* __restrict__ partial, int want_bias) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
+  constexpr int TW = 128;
+  __bf16* ws_ = wb_lds;                    // [128][WB_PITCH]
+  __bf16* ns_ = wb_lds + 128 * WB_PITCH;   // [32][WB_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
+            hi = lane >> 5;
+  const int split = blockIdx.z;
+  const int g8 = (tid & 15) * 8, r0 = tid >> 4;  // group, first row (rows r0 + 16 m)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) bsum[m] = 0.f;
+  float4 wv[8];     // wide: 8 rows x 8 bf16
+  float nv[2][8];   // narrow: 2 rows x 8 fp32
+  const int total = B * chunks_per_b;
+  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+  auto load_chunk = [&](int b, int c) {
+    const int t = c * TW + g8;
+    const bool in = t < T;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(wide + (size_t)b * 128 * T), 0, 128 * T * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(narrow + (size_t)b * 32 * T), 0, 32 * T * 4, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      wv[m] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, in ? ((r0 + 16 * m) * T + t) * 2 : WB_OOB, 0, 0));
+#pragma unroll
+    for (int m = 0; m < 2; ++m) wb_load8(rn, in ? ((r0 + 16 * m) * T + t) * 4 : WB_OOB, nv[m]);
+  };
+  auto advance = [&](int& b, int& c) {
+    c += nsplit;
+    while (c >= chunks_per_b) {
+      c -= chunks_per_b;
+      ++b;
+    }
+  };
+  int ch = split;
+  if (ch < total) load_chunk(cb, cc_);
+  for (; ch < total; ch += nsplit) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      *reinterpret_cast<float4*>(ws_ + (r0 + 16 * m) * WB_PITCH + g8) = wv[m];
+      if (!XWIDE && want_bias) {  // bias of the wide G: sum of its (bf16) samples
+        const bf16x8 q = __builtin_bit_cast(bf16x8, wv[m]);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)q[e];
+        bsum[m] += s;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (XWIDE && want_bias)
+        bsum[m] += ((nv[m][0] + nv[m][1]) + (nv[m][2] + nv[m][3])) + ((nv[m][4] + nv[m][5]) + (nv[m][6] + nv[m][7]));
+      *reinterpret_cast<bf16x8*>(ns_ + (r0 + 16 * m) * WB_PITCH + g8) = wb_pack(nv[m]);
+    }
+    __syncthreads();
+    advance(cb, cc_);
+    if (ch + nsplit < total) load_chunk(cb, cc_);
+    const __bf16* wr = ws_ + (wave * 32 + l31) * WB_PITCH + 8 * hi;
+    const __bf16* nr = ns_ + l31 * WB_PITCH + 8 * hi;
+#pragma unroll
+    for (int s8 = 0; s8 < TW / 16; ++s8) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + 16 * s8);
+      const bf16x8 nf = *reinterpret_cast<const bf16x8*>(nr + 16 * s8);
+      // A = G rows (co), B = x rows (ci)
+      acc = XWIDE ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(nf, wf, acc, 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, nf, acc, 0, 0, 0);
+    }
+  }
+  const int CinP = XWIDE ? 128 : 32, CoutP = XWIDE ? 32 : 128;
+  const size_t plane = (size_t)CinP * CoutP, stride = plane + CoutP;
+  float* pp = partial + (size_t)split * stride;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mrow = (r & 3) + 8 * (r >> 2) + 4 * hi;  // A row (co within the 32 x 32 tile), lane = B row (ci)
+    const int ci = XWIDE ? wave * 32 + l31 : l31;
+    const int co = XWIDE ? mrow : wave * 32 + mrow;
+    pp[(size_t)ci * CoutP + co] = acc[r];
+  }
+  if (want_bias) {
+    float* pb = pp + plane;
+    constexpr int NB = XWIDE ? 2 : 8;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      float v = bsum[m];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      if ((tid & 15) == 0) pb[r0 + 16 * m] = v;
+    }
+  }
+}
+
+int wgrad_cnx_nsplit(int B, int T) {
+  const int chunks = B * cdiv(T, 128);
+  return chunks < 1024 ? chunks : 1024;
+}
+// x_wide != 0: dW [128 ci][32 co] from x = wide (bf16 [B][128][T]), G = narrow (fp32 [B][32][T]); else dW [32 ci][128 co] from
+// x = narrow, G = wide.  partial: nsplit planes of (4096 + CoutP) floats.
+int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
+                     hipStream_t st) {
+  if (T % 8) {
+    set_error("wgrad_cnx: T %% 8 != 0");
+    return STY_EINVAL;
+  }
+  const int nsplit = wgrad_cnx_nsplit(B, T), cpb = cdiv(T, 128);
+  const size_t lds = (size_t)160 * WB_PITCH * sizeof(__bf16);
+  ProfScope prof(x_wide ? "wgrad_cnx_kernel<true>" : "wgrad_cnx_kernel<false>", 2.0 * 128 * 32 * (double)B * T,
+                 (double)B * T * (128 * 2 + 32 * 4), st);
+  if (x_wide)
+    hipLaunchKernelGGL(wgrad_cnx_kernel<true>, dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide), narrow, B,
+                       T, nsplit, cpb, partial, want_bias);
+  else
+    hipLaunchKernelGGL(wgrad_cnx_kernel<false>, dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide), narrow, B,
+                       T, nsplit, cpb, partial, want_bias);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+}  // namespace sty

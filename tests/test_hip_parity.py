@@ -1123,7 +1123,13 @@ def test_bf16_weight_gradient_kernels_match_the_fp32_tile_kernels_in_the_graphs(
             if den < 1e-4 * wn:
                 continue
         if den > 0:
-            worst.append(((b - a).norm().item() / den, k))
+            e = (b - a).norm().item() / den
+            if k.endswith(".pwconv1.bias") and "phase_convnext" in k or k.endswith("upblocks.2.pwconv1.bias"):
+                # fused ConvNeXt32 blocks: in the new path gH0 is STORED as bf16 for the weight-gradient GEMM (whose MFMA
+                # rounds it to bf16 anyway), so this bias gradient is a sum of bf16-rounded values: 2^-9 per term
+                assert e <= 2e-3, (k, e)
+                continue
+            worst.append((e, k))
     worst.sort(reverse=True)
     print("\n  weight-gradient kernels, new vs old (relative L2 per tensor), worst five: " +
           "  ".join(f"{k} {e:.2e}" for e, k in worst[:5]))
