@@ -24,8 +24,13 @@ struct FrontTables {
   PackedConv dftT;          // backward: [2F] -> [n_fft]   (transposed basis)
   // the same transform on FOLDED frames (even part e[n] = x[n] + x[N-n], odd part o[n] = x[n] - x[N-n]): the cosine
   // half of the basis only sees e (N/2 + 1 rows), the sine half only o (N/2 - 1 rows) -- half the multiply-adds
-  PackedConv dre, dim_;     // [N/2+1] -> [F] re;  [N/2-1] -> [F] im
-  PackedConv dreT, dimT;    // backward: [F] -> [N/2+1], [F] -> [N/2-1]
+  // ... and folded once more over n <-> N/2 - n, which separates even from odd frequencies (cos(2 pi f (N/2 - n) / N) =
+  // (-1)^f cos(2 pi f n / N), the sine likewise with the opposite sign): four GEMMs of a quarter of the reduction length
+  // and half of the outputs each -- a quarter of the multiply-adds of the dense transform.  Q = N/4:
+  //   fold[0]: ee (Q+1 rows) -> re, even f (Q+1)     fold[1]: eo (Q rows)   -> re, odd f (Q)
+  //   fold[2]: oo (Q rows)   -> im, odd f (Q)        fold[3]: oe (Q-1 rows) -> im, even f (Q+1)
+  // Spectra produced this way keep their rows in the order [re even | re odd | im even | im odd] (dft_row below).
+  PackedConv fold[4], foldT[4];
   PackedConv fbT;           // backward: [n_mels] -> [F]    (transposed filter bank)
   int n_fft = 0, F = 0, n_mels = 0;
 };
@@ -56,17 +61,21 @@ __global__ void dft_basis_kernel(float* __restrict__ wp, int N, int F, int CoutP
   wp[(size_t)n * CoutP + co] = co < F ? (float)cospi(ang) : (float)(-sinpi(ang));
 }
 
-// folded bases: re[f] = sum_{n=0}^{N/2} e[n] cos(2 pi f n / N), im[f] = -sum_{n=1}^{N/2-1} o[n] sin(2 pi f n / N)
-//   which = 0: wp[n][f] = cos, n = 0..N/2;  which = 1: wp[n-1][f] = -sin, n = 1..N/2-1
-__global__ void dft_fold_basis_kernel(float* __restrict__ wp, int N, int F, int CoutP, int which) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// folded bases, wp[row][m] (see FrontTables::fold):
+//   which 0: cos(2 pi (2m) n / N),     row = n = 0..Q         which 1: cos(2 pi (2m+1) n / N),  row = n = 0..Q-1
+//   which 2: -sin(2 pi (2m+1) n / N),  row = n - 1, n = 1..Q  which 3: -sin(2 pi (2m) n / N),   row = n - 1, n = 1..Q-1
+__global__ void dft_fold_basis_kernel(float* __restrict__ wp, int N, int Cout, int CoutP, int which) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = blockIdx.y;
-  if (f >= F) return;
-  const int n = which ? row + 1 : row;
-  const long long m = ((long long)f * n) % N;
-  const double ang = 2.0 * (double)m / (double)N;
-  wp[(size_t)row * CoutP + f] = which ? (float)(-sinpi(ang)) : (float)cospi(ang);
+  if (m >= Cout) return;
+  const int n = which >= 2 ? row + 1 : row;
+  const int f = (which == 1 || which == 2) ? 2 * m + 1 : 2 * m;
+  const long long r = ((long long)f * n) % N;
+  const double ang = 2.0 * (double)r / (double)N;
+  wp[(size_t)row * CoutP + m] = which >= 2 ? (float)(-sinpi(ang)) : (float)cospi(ang);
 }
+// row of re[f] in a spectrum of the folded transform (im[f]: F rows further); natural order when Q == 0
+__device__ __forceinline__ int dft_row(int f, int Q) { return Q ? ((f & 1) ? Q + 1 + (f >> 1) : (f >> 1)) : f; }
 
 // packed HTK mel filter bank (norm=None): wp[f][m]
 __global__ void mel_fb_kernel(float* __restrict__ wp, int F, int n_mels, int sample_rate, int CoutP) {
@@ -149,34 +158,33 @@ static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream
   t.dftT.wp = dt;
   t.fbT.wp = ft;
   {  // folded bases and their transposes
-    const int H = n_fft / 2;
-    auto make = [&](PackedConv& pc, int cin, int cout) {
-      pc.Cin = cin;
-      pc.CinP = (int)align_up(cin, CI_CHUNK);
-      pc.Cout = cout;
-      pc.CoutP = (int)align_up(cout, 128);
-      pc.K = 1;
-      float* q = nullptr;
-      const size_t n = (size_t)pc.CinP * pc.CoutP;
-      if (hipMalloc((void**)&q, n * sizeof(float)) != hipSuccess) return (float*)nullptr;
-      (void)hipMemsetAsync(q, 0, n * sizeof(float), st);
-      pc.wp = q;
-      return q;
-    };
-    float* a0 = make(t.dre, H + 1, F);
-    float* a1 = make(t.dim_, H - 1, F);
-    float* b0 = make(t.dreT, F, H + 1);
-    float* b1 = make(t.dimT, F, H - 1);
-    if (!a0 || !a1 || !b0 || !b1) {
-      set_error("front end: out of memory for the folded DFT bases");
-      return STY_ENOMEM;
+    const int Q = n_fft / 4;
+    const int cin[4] = {Q + 1, Q, Q, Q - 1}, cout[4] = {Q + 1, Q, Q, Q + 1};
+    for (int i = 0; i < 4; ++i) {
+      auto make = [&](PackedConv& pc, int ci, int co) {
+        pc.Cin = ci;
+        pc.CinP = (int)align_up(ci, CI_CHUNK);
+        pc.Cout = co;
+        pc.CoutP = (int)align_up(co, 128);
+        pc.K = 1;
+        float* q = nullptr;
+        const size_t n = (size_t)pc.CinP * pc.CoutP;
+        if (hipMalloc((void**)&q, n * sizeof(float)) != hipSuccess) return (float*)nullptr;
+        (void)hipMemsetAsync(q, 0, n * sizeof(float), st);
+        pc.wp = q;
+        return q;
+      };
+      float* a = make(t.fold[i], cin[i], cout[i]);
+      float* b = make(t.foldT[i], cout[i], cin[i]);
+      if (!a || !b) {
+        set_error("front end: out of memory for the folded DFT bases");
+        return STY_ENOMEM;
+      }
+      hipLaunchKernelGGL(dft_fold_basis_kernel, dim3(cdiv(cout[i], 256), cin[i]), dim3(256), 0, st, a, n_fft, cout[i],
+                         t.fold[i].CoutP, i);
+      hipLaunchKernelGGL(transpose_pack_kernel, dim3(cdiv(cout[i], 256), cin[i]), dim3(256), 0, st, a, cin[i], cout[i],
+                         t.fold[i].CoutP, t.foldT[i].CoutP, b);
     }
-    hipLaunchKernelGGL(dft_fold_basis_kernel, dim3(cdiv(F, 256), H + 1), dim3(256), 0, st, a0, n_fft, F, t.dre.CoutP, 0);
-    hipLaunchKernelGGL(dft_fold_basis_kernel, dim3(cdiv(F, 256), H - 1), dim3(256), 0, st, a1, n_fft, F, t.dim_.CoutP, 1);
-    hipLaunchKernelGGL(transpose_pack_kernel, dim3(cdiv(F, 256), H + 1), dim3(256), 0, st, a0, H + 1, F, t.dre.CoutP,
-                       t.dreT.CoutP, b0);
-    hipLaunchKernelGGL(transpose_pack_kernel, dim3(cdiv(F, 256), H - 1), dim3(256), 0, st, a1, H - 1, F, t.dim_.CoutP,
-                       t.dimT.CoutP, b1);
     STY_LAUNCH_CHECK();
   }
   auto ins = g_tables.emplace(key, t);
@@ -201,49 +209,64 @@ __global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ au
   xt[b * sb + n * sc + fr] = w[n] * audio[(size_t)b * N + i];
 }
 
-// the same frames, folded: rows 0..N/2 hold e[n] = xt[n] + xt[N-n] (e[0] = xt[0], e[N/2] = xt[N/2]), rows N/2+1..N-1 hold
-// o[n] = xt[n] - xt[N-n] for n = 1..N/2-1 (row N/2 + n).  One thread per (n <= N/2, frame).
+// the same frames, folded twice.  With xt[n] the windowed frame, H = N/2, Q = N/4:
+//   e[n] = xt[n] + xt[N-n], o[n] = xt[n] - xt[N-n]  (e[0] = xt[0], e[H] = xt[H])
+//   ee[n] = e[n] + e[H-n] (n < Q), ee[Q] = e[Q];  eo[n] = e[n] - e[H-n] (n < Q)
+//   oo[n] = o[n] + o[H-n] (1 <= n < Q), oo[Q] = o[Q];  oe[n] = o[n] - o[H-n] (1 <= n < Q)
+// rows: ee at 0..Q, eo at Q+1 + n, oo at 2Q+1 + (n-1), oe at 3Q+1 + (n-1).  One thread per (n <= Q, frame).
 __global__ __launch_bounds__(256) void frame_fold_kernel(const float* __restrict__ audio, const float* __restrict__ w, int N,
                                                          int n_fft, int hop, int frames, size_t sb, size_t sc,
                                                          float* __restrict__ xt) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
-  const int H = n_fft / 2;
+  const int H = n_fft / 2, Q = n_fft / 4;
   auto at = [&](int k) {
     int i = fr * hop + k - H;
     if (i < 0) i = -i;
     if (i >= N) i = 2 * (N - 1) - i;
     return w[k] * audio[(size_t)b * N + i];
   };
-  const float u = at(n);
-  if (n == 0 || n == H) {
-    xt[b * sb + n * sc + fr] = u;
+  float* o_ = xt + b * sb + fr;
+  if (n == 0) {
+    const float e0 = at(0), eH = at(H);
+    o_[0] = e0 + eH;
+    o_[(size_t)(Q + 1) * sc] = e0 - eH;
+  } else if (n == Q) {
+    const float u = at(Q), v = at(n_fft - Q);
+    o_[(size_t)Q * sc] = u + v;              // ee[Q] = e[Q]
+    o_[(size_t)(2 * Q + Q) * sc] = u - v;    // oo[Q] = o[Q]   (row 2Q+1 + Q-1)
   } else {
-    const float v = at(n_fft - n);
-    xt[b * sb + n * sc + fr] = u + v;
-    xt[b * sb + (size_t)(H + n) * sc + fr] = u - v;
+    const float a0 = at(n), a1 = at(n_fft - n), b0 = at(H - n), b1 = at(H + n);
+    const float en = a0 + a1, on = a0 - a1, eh = b0 + b1, oh = b0 - b1;
+    o_[(size_t)n * sc] = en + eh;
+    o_[(size_t)(Q + 1 + n) * sc] = en - eh;
+    o_[(size_t)(2 * Q + n) * sc] = on + oh;
+    o_[(size_t)(3 * Q + n) * sc] = on - oh;
   }
 }
 
 // y [B][2F][frames] -> power [B][F][frames]
 // (batch-folded: element (b, c, fr) at b*sb + c*sc + fr for both tensors)
-__global__ void power_kernel(const float* __restrict__ y, int F, int frames, size_t sb, size_t sc, float* __restrict__ p) {
+__global__ void power_kernel(const float* __restrict__ y, int F, int frames, size_t sb, size_t sc, float* __restrict__ p,
+                             int Q) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int f = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
-  const float re = y[b * sb + f * sc + fr], im = y[b * sb + (size_t)(F + f) * sc + fr];
+  const int row = dft_row(f, Q);
+  const float re = y[b * sb + row * sc + fr], im = y[b * sb + (size_t)(F + row) * sc + fr];
   p[b * sb + f * sc + fr] = re * re + im * im;
 }
 
 // y [B][2F][frames] -> |X| and (|X| > 1e-3) * angle(X)  (multi_spectrogram.py:48-49)
 // strides: y is (sb2, sc) with 2F channels, mag / phase are (sb1, sc) with F channels
 __global__ void magphase_kernel(const float* __restrict__ y, int F, int frames, size_t sb2, size_t sb1, size_t sc,
-                                float* __restrict__ mag, float* __restrict__ phase) {
+                                float* __restrict__ mag, float* __restrict__ phase, int Q) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int f = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
-  const float re = y[b * sb2 + f * sc + fr], im = y[b * sb2 + (size_t)(F + f) * sc + fr];
+  const int row = dft_row(f, Q);
+  const float re = y[b * sb2 + row * sc + fr], im = y[b * sb2 + (size_t)(F + row) * sc + fr];
   const float m = hypotf(re, im);
   const size_t o = b * sb1 + f * sc + fr;
   mag[o] = m;
@@ -287,6 +310,29 @@ static int dense(const PackedConv& w, const float* x, int B, int T, float* y, hi
   return launch_conv1d(a, st);
 }
 
+// the four GEMMs of the twice-folded transform on a batch-folded frame matrix xt [N][cols] -> y [2F][cols]
+// (rows in dft_row order), and their transposes dy -> dxt
+static int dft_fold_fwd(const FrontTables& t, const float* xt, size_t cols, float* y, hipStream_t st) {
+  const int Q = t.n_fft / 4, F = t.F;
+  const size_t xin[4] = {0, (size_t)Q + 1, (size_t)2 * Q + 1, (size_t)3 * Q + 1};
+  const size_t yout[4] = {0, (size_t)Q + 1, (size_t)F + Q + 1, (size_t)F};
+  for (int i = 0; i < 4; ++i) {
+    int rc = dense(t.fold[i], xt + xin[i] * cols, 1, (int)cols, y + yout[i] * cols, st);
+    if (rc) return rc;
+  }
+  return STY_OK;
+}
+static int dft_fold_bwd(const FrontTables& t, const float* dy, size_t cols, float* dxt, hipStream_t st) {
+  const int Q = t.n_fft / 4, F = t.F;
+  const size_t xin[4] = {0, (size_t)Q + 1, (size_t)2 * Q + 1, (size_t)3 * Q + 1};
+  const size_t yout[4] = {0, (size_t)Q + 1, (size_t)F + Q + 1, (size_t)F};
+  for (int i = 0; i < 4; ++i) {
+    int rc = dense(t.foldT[i], dy + yout[i] * cols, 1, (int)cols, dxt + xin[i] * cols, st);
+    if (rc) return rc;
+  }
+  return STY_OK;
+}
+
 size_t mel_workspace_floats(int B, int N, int n_fft, int hop, int n_mels) {
   const size_t frames = N / hop + 1, F = n_fft / 2 + 1;
   return (size_t)B * frames * ((size_t)n_fft + 2 * F + F + n_mels) + 1024;
@@ -307,13 +353,12 @@ int launch_mel(int B, int N, const float* audio, int n_fft, int win, int hop, in
   // batch-folded layout [C][B*frames] for the intermediates (one GEMM problem with B*frames columns), folded frames
   // (even / odd parts: half the DFT multiply-adds)
   const size_t cols = (size_t)B * frames;
-  hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 2 + 1, B), dim3(256), 0, st, audio, t->window, N,
+  hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 4 + 1, B), dim3(256), 0, st, audio, t->window, N,
                      n_fft, hop, frames, (size_t)frames, cols, xt);
-  rc = dense(t->dre, xt, 1, (int)cols, y, st);
+  rc = dft_fold_fwd(*t, xt, cols, y, st);
   if (rc) return rc;
-  rc = dense(t->dim_, xt + (size_t)(n_fft / 2 + 1) * cols, 1, (int)cols, y + (size_t)F * cols, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(power_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, (size_t)frames, cols, p);
+  hipLaunchKernelGGL(power_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, (size_t)frames, cols, p,
+                     n_fft / 4);
   rc = dense(t->fb, p, 1, (int)cols, mp, st);
   if (rc) return rc;
   hipLaunchKernelGGL(mel_finalize_kernel, dim3(cdiv(frames, 256), B), dim3(256), 0, st, mp, n_mels, frames,
@@ -342,7 +387,7 @@ int launch_multispec_single(int B, int N, const float* audio, int n_fft, int hop
   rc = dense(t->dft, xt, B, frames, y, st);
   if (rc) return rc;
   hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames,
-                     (size_t)2 * F * frames, (size_t)F * frames, (size_t)frames, fft_mag, phase);
+                     (size_t)2 * F * frames, (size_t)F * frames, (size_t)frames, fft_mag, phase, 0);
   rc = dense(t->fb, fft_mag, B, frames, mag, st);
   if (rc) return rc;
   const size_t n = (size_t)B * 128 * frames;
@@ -456,11 +501,12 @@ __global__ void log1p_bwd_kernel(float* __restrict__ d, const float* __restrict_
 // dY[b][f / F+f][fr] from d|X| and d phase
 __global__ void magphase_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dabs,
                                     const float* __restrict__ dphase, int F, int frames, size_t sb2, size_t sb1,
-                                    size_t sc, float* __restrict__ dy) {
+                                    size_t sc, float* __restrict__ dy, int Q) {
   const int fr = blockIdx.x * 256 + threadIdx.x;
   const int f = blockIdx.y, b = blockIdx.z;
   if (fr >= frames) return;
-  const size_t ore = b * sb2 + f * sc + fr, oim = b * sb2 + (size_t)(F + f) * sc + fr;
+  const int row = dft_row(f, Q);
+  const size_t ore = b * sb2 + row * sc + fr, oim = b * sb2 + (size_t)(F + row) * sc + fr;
   const float re = y[ore], im = y[oim];
   const float m = hypotf(re, im);
   const size_t o = b * sb1 + f * sc + fr;
@@ -479,7 +525,7 @@ __global__ void magphase_bwd_kernel(const float* __restrict__ y, const float* __
 }
 
 // d audio[b][i] += sum over frames / reflections of w[n] * dxt[b][n][fr]   (gather, no atomics)
-// folded != 0: dxt holds d e (rows 0..N/2) and d o (rows N/2+1..N-1) of frame_fold_kernel's layout
+// folded != 0: dxt holds d ee | d eo | d oo | d oe in frame_fold_kernel's row layout
 __global__ void frame_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ w, int N, int n_fft, int hop,
                                  int frames, size_t sb, size_t sc, float* __restrict__ daudio, int folded) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
@@ -505,13 +551,21 @@ __global__ void frame_bwd_kernel(const float* __restrict__ dxt, const float* __r
         float g;
         if (!folded) {
           g = dxt[b * sb + n * sc + fr];
-        } else if (n == 0 || n == half) {
-          g = dxt[b * sb + n * sc + fr];
-        } else if (n < half) {
-          g = dxt[b * sb + n * sc + fr] + dxt[b * sb + (size_t)(half + n) * sc + fr];
         } else {
-          const int m = n_fft - n;
-          g = dxt[b * sb + m * sc + fr] - dxt[b * sb + (size_t)(half + m) * sc + fr];
+          // un-fold both levels (frame_fold_kernel): xt[n] feeds e[n'] and +-o[n'], n' = min(n, N - n); e[n'] feeds
+          // ee / eo at j = min(n', H - n') with sign +- for eo, o[n'] feeds oo / oe likewise
+          const int Q = half / 2;
+          const float* d_ = dxt + b * sb + fr;
+          const int np_ = n <= half ? n : n_fft - n;
+          const int j = np_ <= Q ? np_ : half - np_;
+          const float sg = np_ <= Q ? 1.f : -1.f;
+          g = d_[(size_t)j * sc];                                  // d ee[j]
+          if (np_ != Q) g += sg * d_[(size_t)(Q + 1 + j) * sc];      // d eo[j]
+          if (n != 0 && n != half) {
+            float go = d_[(size_t)(2 * Q + j) * sc];               // d oo[j]  (j >= 1)
+            if (np_ != Q) go += sg * d_[(size_t)(3 * Q + j) * sc];   // d oe[j]
+            g += n < half ? go : -go;
+          }
         }
         acc = fmaf(w[n], g, acc);
       }
@@ -587,15 +641,13 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
       float* mg = side == 0 ? rb[r].t_mag : rb[r].p_mag;
       float* ph = side == 0 ? rb[r].t_phase : rb[r].p_phase;
       // batch-folded layout: (sb, sc) = (frames, B*frames) for every tensor, GEMMs over B*frames columns
-      hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 2 + 1, B), dim3(256), 0, st, audio, t->window,
+      hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 4 + 1, B), dim3(256), 0, st, audio, t->window,
                          N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, xt);
       const size_t cols = (size_t)B * frames;
-      rc = dense(t->dre, xt, 1, B * frames, yy, st);  // re rows from the even part
-      if (rc) return rc;
-      rc = dense(t->dim_, xt + (size_t)(n_fft / 2 + 1) * cols, 1, B * frames, yy + (size_t)F * cols, st);  // im rows from the odd part
+      rc = dft_fold_fwd(*t, xt, cols, yy, st);
       if (rc) return rc;
       hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, yy, F, frames,
-                         (size_t)frames, (size_t)frames, (size_t)B * frames, fm, ph);
+                         (size_t)frames, (size_t)frames, (size_t)B * frames, fm, ph, n_fft / 4);
       rc = dense(t->fb, fm, 1, B * frames, mg, st);
       if (rc) return rc;
       const size_t n = (size_t)B * 128 * frames;
@@ -622,11 +674,9 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
     rc = dense(t->fbT, rb[r].d_mag, 1, B * frames, dabs, st);
     if (rc) return rc;
     hipLaunchKernelGGL(magphase_bwd_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, rb[r].p_y, dabs,
-                       rb[r].d_phase, F, frames, (size_t)frames, (size_t)frames, (size_t)B * frames, dy);
+                       rb[r].d_phase, F, frames, (size_t)frames, (size_t)frames, (size_t)B * frames, dy, n_fft / 4);
     const size_t cols = (size_t)B * frames;
-    rc = dense(t->dreT, dy, 1, B * frames, dxt, st);  // d e
-    if (rc) return rc;
-    rc = dense(t->dimT, dy + (size_t)F * cols, 1, B * frames, dxt + (size_t)(n_fft / 2 + 1) * cols, st);  // d o
+    rc = dft_fold_bwd(*t, dy, cols, dxt, st);
     if (rc) return rc;
     hipLaunchKernelGGL(frame_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, dxt, t->window, N, n_fft, rb[r].hop,
                        frames, (size_t)frames, (size_t)B * frames, d_pred, 1);
