@@ -193,7 +193,8 @@ __device__ __forceinline__ void q_commit(const QConst<NFRAG>& k, const QSet<NFRA
 // (16 registers of residual in flight).  Kept small on purpose -- a rolled batch loop, one call site, the rare row-end
 // lanes on a rolled scalar loop: fully unrolled with both store paths per row it was two thirds of the kernel's code.
 template <int MTW, int RELU>
-__device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTile tl, int pw, int lane) {
+__device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTile tl, int pw, int lane, int part,
+                                        int nparts) {  // part of nparts: every nparts-th batch of row pairs
   const int T = a.T, Cout = a.w.Cout;
   constexpr int ROWS = 64 * MTW;
   const int half = lane >> 5, l = lane & 31;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
   const bool post = a.out_mask && a.out_mask_post;
   const float pre_scale = a.out_scale;
 #pragma unroll 1
-  for (int rl = 2 * pw + half; rl < ROWS; rl += 2 * Q_NP) {
+  for (int rl = 2 * pw + half + 2 * Q_NP * part; rl < ROWS; rl += 2 * Q_NP * nparts) {
     const int co = tl.cot * ROWS + rl;
     if (co >= Cout) continue;
     // (a 16-byte residual load may run past the end of the row for the last lanes of a row whose length is not a multiple
@@ -277,7 +278,9 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
   const int count = per + ((int)blockIdx.x < rem ? 1 : 0);
   if (count == 0) return;
 
-  const int nsteps = count * (nch + 1);  // per tile: nch chunk steps + one output-stage step
+  const int nsteps = count * nch;        // one step per chunk; a tile's accumulators go to the output stage at the end of its
+                                         // last chunk step (a step of its own cost one barrier in nch + 1: 9-25 %)
+  const int ndr = nch - 1 < 3 ? nch - 1 : 3;  // the drain of a tile is spread over the first ndr steps of the next one
   const int nchunks = count * nch;       // chunk steps of this workgroup, numbered n = tile * nch + chunk
   // The two roles run SEPARATE loops over the same step sequence (one s_barrier per step in each: the hardware counts
   // arrivals, not code addresses).  One merged loop makes the consumers' 64 accumulator registers live across the
@@ -331,23 +334,21 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     STY_Q_ISSUE(R1)
     STY_Q_STEP(R0)
     __syncthreads();
-    // consumers' position: tile ti, step c within the tile (c == nch: output-stage step); the tile before it for the drain
+    // consumers' position: tile ti, chunk step c within the tile; the tile before it for the drain
     int ti = 0, c = 0;
     QTile cur_tl = q_tile(first, tiles_per_row, ncot), prev_tl = cur_tl;
-    for (int step = 0; step <= nsteps; ++step) {  // one more trip than the consumers: the last tile's drain
-      if (((c == 0 && ti > 0) || step == nsteps) && !(dbg & 8)) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane);
-      if (step == nsteps) break;
-      // the chunk the consumers need in the NEXT step is committed now: during a chunk step that is not the tile's last
-      // (after the last one comes the output-stage step), and during the output-stage step (the next tile's chunk 0)
-      const bool due = ncommit < nchunks && (c == nch || c + 1 < nch);
-      if (due) {  // chunk n lives in register set n & 1 (copying a set would wait for its loads in flight)
-        if (ncommit & 1) {
+    for (int step = 0; step < nsteps; ++step) {
+      // the previous tile's output stage (written at the end of its last step) is drained in ndr parts, done before this
+      // tile's last step, at whose end the consumers write the stage again
+      if (ti > 0 && c < ndr && !(dbg & 8)) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane, c, ndr);
+      if (ncommit < nchunks) {  // the chunk the consumers need in the NEXT step; chunk n lives in register set n & 1
+        if (ncommit & 1) {      // (copying a set would wait for its loads in flight)
           STY_Q_STEP(R1)
         } else {
           STY_Q_STEP(R0)
         }
       }
-      if (++c > nch) {  // next tile
+      if (++c == nch) {  // next tile
         c = 0;
         ++ti;
         prev_tl = cur_tl;
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
       }
       __syncthreads();
     }
+    if (!(dbg & 8)) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane, 0, 1);  // the last tile
 #undef STY_Q_STEP
 #undef STY_Q_ISSUE
     return;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
   int g = 0, c = 0;
 #define STY_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
   for (int step = 0; step < nsteps; ++step) {
-    if (c < nch && !(dbg & 16)) {
+    if (!(dbg & 16)) {
       // one 32-channel chunk
       if (c == 0) {
 #pragma unroll
@@ -424,7 +426,8 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
 #undef STY_QMM
 #undef STY_QLD
       ++g;
-    } else if (c == nch && !(dbg & 32)) {
+    }
+    if (c == nch - 1 && !(dbg & 32)) {
       // accumulators -> output stage [64 MTW][128]
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
           for (int n = 0; n < 2; ++n) ost[row * Q_TT + wn * 64 + n * 32 + l31] = acc[m][n][r];
         }
     }
-    if (++c > nch) c = 0;
+    if (++c == nch) c = 0;
     __syncthreads();
   }
 #undef STY_SGB
