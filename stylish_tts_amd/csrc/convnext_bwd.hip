@@ -375,7 +375,8 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
   // per position: dw 448, GEMM-1 8192, U 8192 (+ gXn 8192 in pass 2); pass 1 reads x, gY; pass 2 also writes
   // h s, gH0 (128 each), xn, gU (32 each)
   const double flops = pos * (448.0 + 16384.0 + (pass == 2 ? 8192.0 : 0.0));
-  const double bytes = pos * 4.0 * (64.0 + (pass == 2 ? 320.0 : 0.0));
+  // (h s and gH0 as bf16 in the bf16 mode: 2 x 128 x 2 bytes instead of 2 x 128 x 4)
+  const double bytes = pos * (4.0 * 64.0 + (pass == 2 ? 4.0 * 64.0 + (a.out_bf16 ? 2.0 : 4.0) * 256.0 : 0.0));
   ProfScope prof(pass == 1 ? (a.bf16 ? "convnext32_bwd_kernel<1,true>" : "convnext32_bwd_kernel<1,false>")
                            : (a.bf16 ? "convnext32_bwd_kernel<2,true>" : "convnext32_bwd_kernel<2,false>"),
                  flops, bytes, st);
