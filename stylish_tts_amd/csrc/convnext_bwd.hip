@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
   float* red2 = red + 4 * 128;     // [4][64]
   float* prm = red2 + 4 * 64;      // [4][128] b1, alpha, GRN scale, coef of this batch row (read as LDS broadcasts:
                                    // as global loads inside the element loops they were 55 % of the wave cycles)
-  float* gbs = prm + 4 * 128;      // [64] 1 + gamma | beta of the AdaLN
+  float* gbs = prm + 5 * 128;      // [64] 1 + gamma | beta of the AdaLN   (prm row 4: 1 / alpha)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.y, t0 = blockIdx.x * CB_TT, T = a.T;
   const float* xb = a.x + (size_t)b * 32 * T;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     prm[128 + tid] = a.alpha[tid];
     prm[256 + tid] = a.scale[b * 128 + tid];
     prm[384 + tid] = PASS == 2 ? a.coef[b * 128 + tid] : 0.f;
+    prm[512 + tid] = 1.0f / a.alpha[tid];  // (a full-precision division per element and (n, j) block otherwise: ~10 VALU)
   } else if (tid < 192) {
     const int c = tid - 128;
     gbs[c] = c < 32 ? 1.f + a.gb[b * 64 + c] : a.gb[b * 64 + c];
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float bias = prm[ch], al = prm[128 + ch], ral = 1.0f / al;
+        const float bias = prm[ch], al = prm[128 + ch], ral = prm[512 + ch];
         const float sc = prm[256 + ch];
         const float z = h[r] + bias;
         float s2, s2a = 0.f;
@@ -357,7 +358,7 @@ int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mod
 }
 
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st) {
-  constexpr size_t lds = (32 * (CB_TT + 6) + 32 * (CB_TT + 1) + 256 + 4 * 128 + 4 * 64 + 4 * 128 + 64) * sizeof(float);
+  constexpr size_t lds = (32 * (CB_TT + 6) + 32 * (CB_TT + 1) + 256 + 4 * 128 + 4 * 64 + 5 * 128 + 64) * sizeof(float);
   static bool raised = false;
   if (!raised) {
     STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<1, false>),
