@@ -1144,17 +1144,21 @@ static void style_run(Run& r, const float* mel, int T, float* style) {
     float* h1 = r.ws.take<float>((size_t)B * k.Cin * n);
     float* h2 = r.ws.take<float>((size_t)B * k.Cin * no);
     float* y = r.ws.take<float>((size_t)B * k.Cout * no);
-    // shortcut (scaled by 1/sqrt2 up front: pooling is linear)
-    const float* sc_src = x;
-    if (k.has_sc) {
-      conv2d(k.sc, x, k.Cin, n, W + 1, sc_full, 0, 0, PRO_NONE, r2, nullptr, mk);
-      sc_src = sc_full;
-    }
+    // shortcut (scaled by 1/sqrt2 up front: pooling is linear).  Learned shortcut + down-sampling: the reference runs
+    // conv1x1 then avg_pool2d (mel_style_encoder.py:93-99); both are linear and the 1x1 conv has no bias, so they commute --
+    // pooling FIRST puts the conv (and in training its input gradient and weight gradient) on a quarter of the positions
+    // and halves the pooled channels
     const float* res = nullptr;
-    if (k.down) {
-      if (r.live()) r.chk(launch_avgpool2(sc_src, B * k.Cout, H, W, k.has_sc ? 1.f : r2, sc, r.st));
+    if (k.down && k.has_sc) {
+      float* pooled = sc_full;  // [B][Cin][Ho][Wo + 1] fits in the full-resolution Cout buffer
+      if (r.live()) r.chk(launch_avgpool2(x, B * k.Cin, H, W, 1.f, pooled, r.st));
+      conv2d(k.sc, pooled, k.Cin, no, Wo + 1, sc, 0, 0, PRO_NONE, r2, nullptr, mko);
+      res = sc;
+    } else if (k.down) {
+      if (r.live()) r.chk(launch_avgpool2(x, B * k.Cout, H, W, r2, sc, r.st));
       res = sc;
     } else if (k.has_sc) {
+      conv2d(k.sc, x, k.Cin, n, W + 1, sc_full, 0, 0, PRO_NONE, r2, nullptr, mk);
       res = sc_full;
     }
     // residual branch

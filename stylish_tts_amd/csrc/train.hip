@@ -1208,26 +1208,31 @@ struct Trainer {
       const int n = H * (W + 1), no = Ho * (Wo + 1);
       const float* mko = k.down ? mask_for(Ho, Wo, Ho, Wo) : mk;
       const float* xin = x;
-      const float* sc_src = xin;
-      if (k.has_sc) {
-        float* sc_full = take<float>((size_t)B * k.Cout * n);
-        conv2d(k.sc, xin, k.Cin, n, W + 1, sc_full, 0, 0, PRO_NONE, r2, nullptr, mk);
-        sc_src = sc_full;
-      }
       const float* res = nullptr;
-      if (k.down) {
-        float* sc = take<float>((size_t)B * k.Cout * no);
-        const float scale = k.has_sc ? 1.f : r2;
-        if (live()) chk(launch_avgpool2(sc_src, B * k.Cout, H, W, scale, sc, st));
-        const int BC = B * k.Cout;
+      // learned shortcut + down-sampling: pool first, then the 1x1 conv (they commute, see Run::style_encoder): its
+      // forward, input gradient and weight gradient run on a quarter of the positions
+      auto pool = [&](const float* src, int Cc, float scale) {
+        float* out = take<float>((size_t)B * Cc * no);
+        if (live()) chk(launch_avgpool2(src, B * Cc, H, W, scale, out, st));
+        const int BC = B * Cc;
         tape.push_back([=]() {
-          float* g = G(sc, (size_t)BC * no);
-          float* gs = G(sc_src, (size_t)BC * n);
+          float* g = G(out, (size_t)BC * no);
+          float* gs = G(src, (size_t)BC * n);
           if (live()) chk(launch_avgpool2_bwd(g, BC, Hc, Wc, scale, gs, st));
         });
+        return out;
+      };
+      if (k.down && k.has_sc) {
+        const float* pooled = pool(xin, k.Cin, 1.f);
+        float* sc = take<float>((size_t)B * k.Cout * no);
+        conv2d(k.sc, pooled, k.Cin, no, Wo + 1, sc, 0, 0, PRO_NONE, r2, nullptr, mko);
         res = sc;
+      } else if (k.down) {
+        res = pool(xin, k.Cout, r2);
       } else if (k.has_sc) {
-        res = sc_src;
+        float* sc_full = take<float>((size_t)B * k.Cout * n);
+        conv2d(k.sc, xin, k.Cin, n, W + 1, sc_full, 0, 0, PRO_NONE, r2, nullptr, mk);
+        res = sc_full;
       }
       float* h1 = take<float>((size_t)B * k.Cin * n);
       conv2d(k.c1, xin, k.Cin, n, W + 1, h1, 1, 1, PRO_LRELU, 1.f, nullptr, mk);
