@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
   for (int n = 0; n < 2; ++n) {
     const int tl = tw + n * 32 + l31, t = t0 + tl;
     const bool ok = t < T;
+    const int vst16 = (4 * hi * T + t) * 2;  // lane part of the bf16 output offsets
     // B fragments: normalised input (AdaLN affine applied on the way) and the output gradient
     float bx[16], by[16];
     bf16x8 bxf[2], byf[2];
@@ -245,8 +246,11 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
             if (BF && a.out_bf16) {
               const bf16x8 pk = sty_pack_bf16(hv * sc, g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
               const unsigned two = __builtin_bit_cast(uint4, pk).x;
-              __builtin_amdgcn_raw_buffer_store_b16((short)(two & 0xffffu), r_hs, (ch * T + t) * 2, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b16((short)(two >> 16), r_g0, (ch * T + t) * 2, 0, 0);
+              // row offset in the SCALAR offset (wave-uniform part of ch; the hi half of the wave is 4 rows further: in
+              // the lane part), so that the per-lane offset is the same for all sixteen rows
+              const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;
+              __builtin_amdgcn_raw_buffer_store_b16((short)(two & 0xffffu), r_hs, vst16, srow, 0);
+              __builtin_amdgcn_raw_buffer_store_b16((short)(two >> 16), r_g0, vst16, srow, 0);
             } else {
               bst(r_hs, hv * sc, (ch * T + t) * 4);
               bst(r_g0, g0, (ch * T + t) * 4);
@@ -255,7 +259,8 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
           h[r] = g0;
         }
         rsum = sty_half_sum_to_lane31(rsum);
-        if (l31 == 31) red[wave * 128 + ch] += rsum;  // the same lane owns this slot in both passes
+        if (l31 == 31) atomicAdd(&red[wave * 128 + ch], rsum);  // one writer per slot (the same lane in both passes): a
+                                                                 // ds_add_f32 instead of read / add / write
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the per-channel loads / store addresses of later
                                                               // rows from being hoisted (that cost 106 spilled VGPRs)
       }
