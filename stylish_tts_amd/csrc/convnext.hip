@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const float z = h[n][r];
-        float v = fmaf(ral, slow ? sty_sin2(al * z) : sty_sin2_fast(al * z), z);
+        float v = fmaf(ral, slow ? sty_sin2(al * z) : (BF ? sty_sin2_hw(al * z) : sty_sin2_fast(al * z)), z);
         if (PASS2) {
           h[n][r] = v * sc;
         } else {

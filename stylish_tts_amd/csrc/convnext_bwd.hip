@@ -223,11 +223,11 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
         const float z = h[r] + bias;
         float s2, s2a = 0.f;
         if (PASS == 1) {
-          s2 = (BF && !slow) ? sty_sin2_fast(al * z) : sty_sin2(al * z);
+          s2 = (BF && !slow) ? sty_sin2_hw(al * z) : sty_sin2(al * z);
         } else {  // sin^2 and sin(2 a z) = 2 sin cos from one range reduction
           float sn, cs;
           if (BF && !slow)
-            sty_sincos_fast(al * z, sn, cs);
+            sty_sincos_hw(al * z, sn, cs);
           else
             sty_sincos(al * z, sn, cs);
           s2 = sn * sn;

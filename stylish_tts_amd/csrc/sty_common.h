@@ -367,6 +367,18 @@ __device__ __forceinline__ void sty_sincos_fast(float x, float& s, float& c) {
   s = (k & 2) ? -sv : sv;
   c = ((k + 1) & 2) ? -cv : cv;
 }
+// bf16 compute mode only: the hardware sine / cosine (v_sin_f32 / v_cos_f32 take revolutions and reduce the argument with
+// an fp32 fract: absolute error ~|x| 6e-8 rad, 5e-4 at the |x| = 8192 the callers allow -- below the 2^-9 of the bf16
+// values the results are stored as or multiplied into).  Three instructions instead of ~28 for sin and cos.
+__device__ __forceinline__ float sty_sin2_hw(float x) {
+  const float s = __builtin_amdgcn_sinf(x * 0.15915494309189535f);
+  return s * s;
+}
+__device__ __forceinline__ void sty_sincos_hw(float x, float& s, float& c) {
+  const float r = x * 0.15915494309189535f;
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
 // Sum over each 32-lane half of the wave with DPP row operations: six v_add_f32 with a DPP source modifier instead of
 // five ds_bpermute round trips through the LDS crossbar (what __shfl_xor compiles to): the ConvNeXt32 backward issued
 // ~1 000 of those per tile and wave.  The total lands in lane 31 (lanes 0-31) and lane 63 (lanes 32-63) ONLY.
