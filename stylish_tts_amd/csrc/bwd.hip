@@ -35,7 +35,8 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double (*red)[4]) {
 // ---- fused-prologue backward: u = d/d(prologue(x)) -> dx (+=), row sums for da, ds, dalpha ----
 // mode = ConvPro.  One workgroup per (b, c) row.  u is [B][Cu][T] with this tensor's channels starting at cu0
 // (the dgrad conv of a channel-concatenated input produces one tensor for all sources).
-__global__ __launch_bounds__(256) void pro_bwd_kernel(int mode, const float* __restrict__ u, int Cu, int cu0,
+// mode | 0x100 (bf16 compute mode): the Snake derivative takes the hardware sine / cosine (sty_sincos_hw)
+__global__ __launch_bounds__(256) void pro_bwd_kernel(int mode_, const float* __restrict__ u, int Cu, int cu0,
                                                       const float* __restrict__ x, int C, int T,
                                                       const float* __restrict__ pa, const float* __restrict__ ps,
                                                       int pC, int pc0, const float* __restrict__ alpha,
@@ -43,6 +44,8 @@ __global__ __launch_bounds__(256) void pro_bwd_kernel(int mode, const float* __r
                                                       int accumulate, float* __restrict__ dpa,
                                                       float* __restrict__ dps, float* __restrict__ dalpha) {
   __shared__ double red[3][4];
+  const int mode = mode_ & 0xff;
+  const bool hw = (mode_ & 0x100) != 0;
   const int c = blockIdx.x, b = blockIdx.y;
   const float* ur = u + ((size_t)b * Cu + cu0 + c) * T;
   const float* xr = x + ((size_t)b * C + c) * T;
@@ -61,7 +64,10 @@ __global__ __launch_bounds__(256) void pro_bwd_kernel(int mode, const float* __r
     if (mode == PRO_AFFINE_SNAKE) {
       const float z = a * xv + s;
       float sn, cs;  // sin^2(a z) and sin(2 a z) = 2 sin cos from ONE range reduction
-      sty_sincos(al * z, sn, cs);
+      if (hw && fabsf(al * z) <= 8192.0f)
+        sty_sincos_hw(al * z, sn, cs);
+      else
+        sty_sincos(al * z, sn, cs);
       const float s2 = sn * sn, s2a = 2.f * sn * cs;
       g = uv * (1.f + s2a);
       dal = uv * (z * s2a - s2 / al) / al;

@@ -325,7 +325,7 @@ struct Trainer {
       int c0 = 0;
       for (int i = 0; i < f.nsrc; ++i) {
         if (gX[i] && live())
-          chk(launch_pro_bwd(f.pro, U, w.Cin, c0, f.x[i], B, f.xc[i], Tt, f.pa, f.ps, w.Cin, c0, f.palpha, f.mask, gX[i],
+          chk(launch_pro_bwd(f.pro | (f.bf16 ? 0x100 : 0), U, w.Cin, c0, f.x[i], B, f.xc[i], Tt, f.pa, f.ps, w.Cin, c0, f.palpha, f.mask, gX[i],
                              accX[i], dpa, dps, dal, st));
         c0 += f.xc[i];
       }
