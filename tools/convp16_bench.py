@@ -7,6 +7,7 @@ import torch
 from stylish_tts_amd import lib as L
 lib = L.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+BF = int(os.environ.get("BF16", "1"))  # 0: the fp32 twin (convpf.hip)
 SHAPES = [  # B, Ci, Co, K, T
     (32, 80, 80, 3, 41600 // 8),    # style encoder block 1 (1/8 of the image rows)
     (32, 160, 160, 3, 10400 // 2),  # block 2
@@ -26,11 +27,11 @@ for B, Ci, Co, K, T in [SHAPES[int(i)] for i in sel.split(',')] if sel else SHAP
     need = C.c_size_t(); L.check(lib.sty_conv1d_workspace_bytes(Co, Ci, K, C.byref(need)))
     ws = torch.empty(need.value, dtype=torch.uint8, device="cuda")
     for _ in range(2):
-        L.check(lib.sty_conv1d_fwd(B, Ci, Co, K, 1, T, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(ws), ws.numel(), 1, None))
+        L.check(lib.sty_conv1d_fwd(B, Ci, Co, K, 1, T, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(ws), ws.numel(), BF, None))
     torch.cuda.synchronize()
     lib.sty_prof_enable(1)
     for _ in range(reps):
-        L.check(lib.sty_conv1d_fwd(B, Ci, Co, K, 1, T, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(ws), ws.numel(), 1, None))
+        L.check(lib.sty_conv1d_fwd(B, Ci, Co, K, 1, T, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(ws), ws.numel(), BF, None))
     torch.cuda.synchronize()
     lib.sty_prof_enable(0)
     flops = 2.0 * B * Ci * Co * K * T
