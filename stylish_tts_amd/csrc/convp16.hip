@@ -118,6 +118,7 @@ __device__ __forceinline__ void q_pos_next(const ConvArgs& a, QPos& p, int nch, 
 template <int NFRAG>
 struct QConst {
   int rg8;           // first of the wave's 8 rows within a chunk
+  bool qlive;        // this wave's 64-column group holds live columns (wave-uniform)
   int vcol;          // byte offset of this lane's column relative to the tile start, or out of range for a dead column group
   int jcol;          // this lane's column in the staged tile (lane + 64 q)
   bool jlive;        // ... is inside the tile + halo
@@ -135,9 +136,13 @@ __device__ __forceinline__ void q_issue(const ConvArgs& a, const QPos& p, const 
       const_cast<float*>(a.x[0] + (size_t)p.b * crow * T), 0, crow * T * 4, 0x00020000);
   // The whole offset goes into the VECTOR offset: the hardware range-checks that one only, not the scalar soffset.
   const int v0 = k.vcol + (p.t0 - a.pad) * 4 + p.roff;
+  // (a dead column group -- the third one of a K = 1 conv -- issues nothing: even loads that fall outside the descriptor
+  // are vector-memory instructions, and those are what the consumers' MFMAs do not hide, tools/probes/overlap_probe.hip)
+  if (k.qlive) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r)
-    R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0 + r * T * 4, 0, 0));
+    for (int r = 0; r < 8; ++r)
+      R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0 + r * T * 4, 0, 0));
+  }
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.w.wf), 0, a.w.K * a.w.CinP * a.w.CoutP * 2 + 8192, 0x00020000);
 #pragma unroll
@@ -297,7 +302,8 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     kc.rg8 = 8 * rg;
     kc.jcol = lane + 64 * q;
     kc.jlive = kc.jcol < LWt;
-    kc.vcol = (q < Q_TT / 64 || 64 * q < LWt) ? kc.jcol * 4 : 0x7FFFFF00;
+    kc.qlive = q < Q_TT / 64 || 64 * q < LWt;
+    kc.vcol = kc.qlive ? kc.jcol * 4 : 0x7FFFFF00;
     kc.bdst = kc.jcol * Q_PITCH + 8 * rg;
 #pragma unroll
     for (int i = 0; i < NFRAG; ++i) {
