@@ -30,5 +30,7 @@ python bench.py > $O/${tag}_bench_default.json 2> $O/bench_default.err
 python bench.py --workload c5-bf16 --steps 50 --warmup 10 --no-cpu-baseline --no-extra > $O/${tag}_bench_c5_bf16.json 2>/dev/null
 python bench.py --workload c2-fwd --no-cpu-baseline --no-extra > $O/${tag}_bench_c2_fwd.json 2>/dev/null
 python bench.py --workload tts --steps 20 --warmup 5 --no-extra > $O/${tag}_bench_tts.json 2>/dev/null
+python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
 rm -rf $O/c3_trace $O/c5_trace $O/c2_trace $O/c3_fetch/*/*agent_info.csv $O/c5_fetch/*/*agent_info.csv
 ls -la $O
