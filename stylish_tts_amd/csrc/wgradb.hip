@@ -62,11 +62,13 @@ __device__ __forceinline__ bf16x8 wb_pack(const float (&v)[8]) {
 // TW = reduction samples per chunk: 128, or 64 where the [B][T] multiplier of G (GMASK) adds K x 8 staging registers per
 // thread and the 128-sample version spilled 64-135 of them
 template <int KN, int PRO, bool GMASK, int TW>
-__global__ __launch_bounds__(256, 2) void wgradb_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
+__global__ __launch_bounds__(256, (KN > 3 ? 1 : 2)) void wgradb_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                         float* __restrict__ partial, int want_bias) {
   extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
-  __bf16* xs = wb_lds;                   // [64][WB_PITCH]
-  __bf16* gs = wb_lds + 64 * WB_PITCH;   // [KN][64][WB_PITCH]
+  constexpr int PITCH = TW + 8;       // bf16 elements between LDS rows: 272 / 144 bytes = 4 (mod 8) dwords: the 16 lanes of a
+                                      // 128-bit access hit 16 different 4-bank groups
+  __bf16* xs = wb_lds;                // [64][PITCH]
+  __bf16* gs = wb_lds + 64 * PITCH;   // [KN][64][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
             hi = lane >> 5;
   const int wi = wave >> 1, wo = wave & 1;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void wgradb_kernel(ConvArgs ax, ConvArgs ag
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (s0 + e >= 0 && s0 + e < T) ? v[e] : 0.f;
         }
-        *reinterpret_cast<bf16x8*>(xs + row * WB_PITCH + g8) = wb_pack(v);
+        *reinterpret_cast<bf16x8*>(xs + row * PITCH + g8) = wb_pack(v);
       }
 #pragma unroll
       for (int k = 0; k < KN; ++k) {  // G shifted by -k dil: index t = t0 + g8 + e - k dil
@@ -201,21 +203,21 @@ __global__ __launch_bounds__(256, 2) void wgradb_kernel(ConvArgs ax, ConvArgs ag
           for (int e = 0; e < 8; ++e) v[e] = (i0 + e >= 0 && i0 + e < T) ? v[e] : 0.f;
         }
         if (k == 0 && do_bias) bsum[m] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        *reinterpret_cast<bf16x8*>(gs + (k * 64 + row) * WB_PITCH + g8) = wb_pack(v);
+        *reinterpret_cast<bf16x8*>(gs + (k * 64 + row) * PITCH + g8) = wb_pack(v);
       }
     }
     __syncthreads();
     advance(cb, cc_);
     if (ch + nsplit < total) load_chunk(cb, cc_);  // in flight during the MFMAs below
     // ---- MFMAs: A = G_k rows (co), B = x rows (ci), contraction over the 128 samples of the chunk ----
-    const __bf16* xr = xs + (wi * 32 + l31) * WB_PITCH + 8 * hi;
-    const __bf16* gr = gs + (wo * 32 + l31) * WB_PITCH + 8 * hi;
+    const __bf16* xr = xs + (wi * 32 + l31) * PITCH + 8 * hi;
+    const __bf16* gr = gs + (wo * 32 + l31) * PITCH + 8 * hi;
 #pragma unroll
     for (int s8 = 0; s8 < TW / 16; ++s8) {
       const bf16x8 bp = *reinterpret_cast<const bf16x8*>(xr + 16 * s8);
 #pragma unroll
       for (int k = 0; k < KN; ++k) {
-        const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + k * 64 * WB_PITCH + 16 * s8);
+        const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + k * 64 * PITCH + 16 * s8);
         acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp, acc[k], 0, 0, 0);
       }
     }
@@ -253,7 +255,7 @@ bool wgradb_eligible(const ConvArgs& fwd, bool gmask) {
   (void)gmask;
   const PackedConv& w = fwd.w;
   if (!fwd.bf16 || getenv("STY_NO_WGRADB")) return false;  // (read per call: the A/B parity test toggles it)
-  if (!(w.K == 1 || w.K == 3) || w.CinP < 64 || w.CoutP < 64) return false;
+  if (!(w.K == 1 || w.K == 3 || w.K == 5) || w.CinP < 64 || w.CoutP < 64) return false;
   if (!(fwd.flatW || fwd.nsrc == 1) || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
   if (fwd.flatW && w.K == 1) return false;  // (the caller clears flatW for 1x1 convs)
   if ((w.K - 1) * fwd.dil > 63) return false;
@@ -269,22 +271,26 @@ bool wgradb_eligible(const ConvArgs& fwd, bool gmask) {
   }
 }
 
+// chunk width: 128 samples, or 64 where the staging registers of 128 do not fit (the G multiplier; five taps)
+constexpr int wb_tw(int kn, bool gmask) { return (gmask || kn > 3) ? 64 : 128; }
+
 template <int KN, int PRO>
 static void wb_launch(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
                       int wb, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, false, 128>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, false, wb_tw(KN, false)>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, true, WB_TW_MASKED>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, true, wb_tw(KN, true)>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     raised = true;
   }
   if (ag.pro == PRO_MASK)
-    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, true, WB_TW_MASKED>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial,
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, true, wb_tw(KN, true)>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial,
                        wb);
   else
-    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, false, 128>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial, wb);
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, false, wb_tw(KN, false)>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial,
+                       wb);
 }
 template <int KN>
 static void wb_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb,
@@ -303,18 +309,20 @@ static void wb_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, siz
 // partial planes: [nsplit][K][CinP][CoutP] (+ CoutP bias partials per split); the caller reduces them
 int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st) {
   const PackedConv& w = ax.w;
-  const int tw = ag.pro == PRO_MASK ? WB_TW_MASKED : 128;
+  const int tw = wb_tw(w.K, ag.pro == PRO_MASK);
   const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, tw);  // chunks cover u = t + k dil - pad over [-pad, T + halo - pad)
   dim3 grid(cdiv(w.CinP, 64), cdiv(w.CoutP, 64), nsplit);
-  const size_t lds = (size_t)(1 + w.K) * 64 * WB_PITCH * sizeof(__bf16);
+  const size_t lds = (size_t)(1 + w.K) * 64 * (tw + 8) * sizeof(__bf16);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW);
-  ProfScope prof(w.K == 1 ? "wgradb_kernel<1,true>" : "wgradb_kernel<3,true>", 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T,
+  ProfScope prof(w.K == 1 ? "wgradb_kernel<1,true>" : (w.K == 3 ? "wgradb_kernel<3,true>" : "wgradb_kernel<5,true>"), 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T,
                  4.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
   if (w.K == 1)
     wb_launch_pro<1>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
-  else
+  else if (w.K == 3)
     wb_launch_pro<3>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else
+    wb_launch_pro<5>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
