@@ -55,14 +55,31 @@ __device__ __forceinline__ void wb_load_row8(__amdgpu_buffer_rsrc_t rs, int row_
     }
   }
 }
+__device__ __forceinline__ void wb_load_row4(__amdgpu_buffer_rsrc_t rs, int row_off, int i0, int T, float (&v)[4]) {
+  if (i0 >= 0 && i0 + 3 < T) {
+    const float4 a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, row_off + i0 * 4, 0, 0));
+    v[0] = a.x;
+    v[1] = a.y;
+    v[2] = a.z;
+    v[3] = a.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool in = i0 + e >= 0 && i0 + e < T;
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, in ? row_off + (i0 + e) * 4 : 0x7fffff00, 0, 0));
+    }
+  }
+}
 __device__ __forceinline__ bf16x8 wb_pack(const float (&v)[8]) {
   return sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
 
 // TW = reduction samples per chunk: 128, or 64 where the [B][T] multiplier of G (GMASK) adds K x 8 staging registers per
 // thread and the 128-sample version spilled 64-135 of them
-template <int KN, int PRO, bool GMASK, int TW>
-__global__ __launch_bounds__(256, (KN > 3 ? 1 : 2)) void wgradb_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
+// WIN (dilation 1, KN > 1): the KN shifted copies of a G group are cut out of ONE 12-sample window [t - 4, t + 8) held in
+// registers (three 16-byte loads per row and group instead of 2 KN; 12 staging registers instead of 8 KN)
+template <int KN, int PRO, bool GMASK, int TW, bool WIN>
+__global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                         float* __restrict__ partial, int want_bias) {
   extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
   constexpr int PITCH = TW + 8;       // bf16 elements between LDS rows: 272 / 144 bytes = 4 (mod 8) dwords: the 16 lanes of a
@@ -117,7 +134,8 @@ __global__ __launch_bounds__(256, (KN > 3 ? 1 : 2)) void wgradb_kernel(ConvArgs 
     }
   }
 
-  float xv[NI][8], gv[KN][NI][8];
+  constexpr int GK = WIN ? 1 : KN, GW = WIN ? 12 : 8;
+  float xv[NI][8], gv[GK][NI][GW];
   float pa[NI], ps[NI];
 #pragma unroll
   for (int m = 0; m < NI; ++m) {
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(256, (KN > 3 ? 1 : 2)) void wgradb_kernel(ConvArgs 
     ps[m] = 0.f;
   }
   float xm[PRO == PRO_MASK ? NI : 1][8];
-  float gm[GMASK ? KN : 1][8];
+  float gm[GMASK ? GK : 1][GW];
   const int total = ax.B * chunks_per_b;
   // chunk position (batch row, chunk in the row), advanced incrementally: no division in the loop
   int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
@@ -140,8 +158,18 @@ __global__ __launch_bounds__(256, (KN > 3 ? 1 : 2)) void wgradb_kernel(ConvArgs 
 #pragma unroll
     for (int m = 0; m < NI; ++m) {
       wb_load_row8(rx, offx[m], ix0 + tshx[m], T, xv[m]);
+      if constexpr (WIN) {
+        float lo[4], hi8[8];
+        wb_load_row4(rg, offg[m], ig0 - 4, T, lo);
+        wb_load_row8(rg, offg[m], ig0, T, hi8);
 #pragma unroll
-      for (int k = 0; k < KN; ++k) wb_load_row8(rg, offg[m], ig0 - k * dil, T, gv[k][m]);
+        for (int e = 0; e < 4; ++e) gv[0][m][e] = lo[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[0][m][4 + e] = hi8[e];
+      } else {
+#pragma unroll
+        for (int k = 0; k < KN; ++k) wb_load_row8(rg, offg[m], ig0 - k * dil, T, gv[k][m]);
+      }
       if constexpr (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SNAKE || PRO == PRO_AFFINE_LRELU || PRO == PRO_SCALE) {
         pa[m] = cix[m] >= 0 ? ax.pa[(size_t)b * ax.w.Cin + cix[m]] : 0.f;
         if constexpr (PRO != PRO_SCALE) ps[m] = cix[m] >= 0 ? ax.ps[(size_t)b * ax.w.Cin + cix[m]] : 0.f;
@@ -156,8 +184,18 @@ __global__ __launch_bounds__(256, (KN > 3 ? 1 : 2)) void wgradb_kernel(ConvArgs 
     if constexpr (GMASK) {  // [B][T] multiplier of G
       const __amdgpu_buffer_rsrc_t rm =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ag.mask + (size_t)b * T), 0, T * 4, 0x00020000);
+      if constexpr (WIN) {
+        float lo[4], hi8[8];
+        wb_load_row4(rm, 0, ig0 - 4, T, lo);
+        wb_load_row8(rm, 0, ig0, T, hi8);
 #pragma unroll
-      for (int k = 0; k < KN; ++k) wb_load_row8(rm, 0, ig0 - k * dil, T, gm[k]);
+        for (int e = 0; e < 4; ++e) gm[0][e] = lo[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gm[0][4 + e] = hi8[e];
+      } else {
+#pragma unroll
+        for (int k = 0; k < KN; ++k) wb_load_row8(rm, 0, ig0 - k * dil, T, gm[k]);
+      }
     }
   };
   auto advance = [&](int& b, int& c) {
@@ -196,7 +234,12 @@ __global__ __launch_bounds__(256, (KN > 3 ? 1 : 2)) void wgradb_kernel(ConvArgs 
       for (int k = 0; k < KN; ++k) {  // G shifted by -k dil: index t = t0 + g8 + e - k dil
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = GMASK ? gv[k][m][e] * gm[k][e] : gv[k][m][e];
+        for (int e = 0; e < 8; ++e) {
+          if constexpr (WIN)  // sample t - k of the window that starts at t - 4
+            v[e] = GMASK ? gv[0][m][4 + e - k] * gm[0][4 + e - k] : gv[0][m][4 + e - k];
+          else
+            v[e] = GMASK ? gv[k][m][e] * gm[k][e] : gv[k][m][e];
+        }
         const int i0 = t0 + g8 - k * dil;
         if (i0 < 0 || i0 + 7 >= T) {
 #pragma unroll
@@ -271,26 +314,35 @@ bool wgradb_eligible(const ConvArgs& fwd, bool gmask) {
   }
 }
 
-// chunk width: 128 samples, or 64 where the staging registers of 128 do not fit (the G multiplier; five taps)
-constexpr int wb_tw(int kn, bool gmask) { return (gmask || kn > 3) ? 64 : 128; }
+// chunk width: 128 samples, or 64 where the staging registers of 128 do not fit (without the window: the G multiplier,
+// five taps)
+constexpr int wb_tw(int kn, bool gmask, bool win) { return kn > 3 ? 64 : (win ? 128 : (gmask ? 64 : 128)); }
 
-template <int KN, int PRO>
-static void wb_launch(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
-                      int wb, hipStream_t st) {
+template <int KN, int PRO, bool WIN>
+static void wb_launch_w(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
+                        int wb, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, false, wb_tw(KN, false)>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, true, wb_tw(KN, true)>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, false, wb_tw(KN, false, WIN), WIN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, true, wb_tw(KN, true, WIN), WIN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
     raised = true;
   }
   if (ag.pro == PRO_MASK)
-    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, true, wb_tw(KN, true)>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial,
-                       wb);
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, true, wb_tw(KN, true, WIN), WIN>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb,
+                       partial, wb);
   else
-    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, false, wb_tw(KN, false)>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, partial,
-                       wb);
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, false, wb_tw(KN, false, WIN), WIN>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb,
+                       partial, wb);
+}
+template <int KN, int PRO>
+static void wb_launch(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
+                      int wb, hipStream_t st) {
+  if (KN > 1 && ax.dil == 1)
+    wb_launch_w<KN, PRO, (KN > 1)>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st);
+  else
+    wb_launch_w<KN, PRO, false>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st);
 }
 template <int KN>
 static void wb_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb,
@@ -309,7 +361,7 @@ static void wb_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, siz
 // partial planes: [nsplit][K][CinP][CoutP] (+ CoutP bias partials per split); the caller reduces them
 int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st) {
   const PackedConv& w = ax.w;
-  const int tw = wb_tw(w.K, ag.pro == PRO_MASK);
+  const int tw = wb_tw(w.K, ag.pro == PRO_MASK, w.K > 1 && ax.dil == 1);
   const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, tw);  // chunks cover u = t + k dil - pad over [-pad, T + halo - pad)
   dim3 grid(cdiv(w.CinP, 64), cdiv(w.CoutP, 64), nsplit);
   const size_t lds = (size_t)(1 + w.K) * 64 * (tw + 8) * sizeof(__bf16);
