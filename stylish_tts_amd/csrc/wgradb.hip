@@ -78,28 +78,35 @@ __device__ __forceinline__ bf16x8 wb_pack(const float (&v)[8]) {
 // thread and the 128-sample version spilled 64-135 of them
 // WIN (dilation 1, KN > 1): the KN shifted copies of a G group are cut out of ONE 12-sample window [t - 4, t + 8) held in
 // registers (three 16-byte loads per row and group instead of 2 KN; 12 staging registers instead of 8 KN)
-template <int KN, int PRO, bool GMASK, int TW, bool WIN>
+// F (1 or 2): a workgroup owns a 64 F x 64 F block of dW, each wave F x F fragments (F = 2 for the wide K = 1 layers: twice
+// the MFMAs per loaded byte)
+template <int KN, int PRO, bool GMASK, int TW, bool WIN, int F>
 __global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b,
                                                         float* __restrict__ partial, int want_bias) {
   extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
   constexpr int PITCH = TW + 8;       // bf16 elements between LDS rows: 272 / 144 bytes = 4 (mod 8) dwords: the 16 lanes of a
                                       // 128-bit access hit 16 different 4-bank groups
-  __bf16* xs = wb_lds;                // [64][PITCH]
-  __bf16* gs = wb_lds + 64 * PITCH;   // [KN][64][PITCH]
+  constexpr int R = 64 * F;           // rows of x / of G per block
+  __bf16* xs = wb_lds;                // [R][PITCH]
+  __bf16* gs = wb_lds + R * PITCH;    // [KN][R][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
             hi = lane >> 5;
   const int wi = wave >> 1, wo = wave & 1;
   const int dil = ax.dil, T = ax.T, pad = ax.pad;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
-  constexpr int GPR = TW / 8, NI = TW / 32, RSTEP = 256 / GPR;  // groups per row, items per thread, row step
+  const int ci0 = blockIdx.x * R, co0 = blockIdx.y * R, split = blockIdx.z;
+  constexpr int GPR = TW / 8, NI = TW / 32 * F, RSTEP = 256 / GPR;  // groups per row, items per thread, row step
   const int g8 = (tid % GPR) * 8, r0 = tid / GPR;  // this thread's 8-sample group and first row (rows r0 + RSTEP m)
   const bool do_bias = want_bias && blockIdx.x == 0;
 
-  f32x16 acc[KN];
+  f32x16 acc[KN][F][F];
 #pragma unroll
   for (int k = 0; k < KN; ++k)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+      for (int fo = 0; fo < F; ++fo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][fi][fo][r] = 0.f;
   float bsum[NI];
 #pragma unroll
   for (int m = 0; m < NI; ++m) bsum[m] = 0.f;
@@ -246,23 +253,29 @@ __global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(C
           for (int e = 0; e < 8; ++e) v[e] = (i0 + e >= 0 && i0 + e < T) ? v[e] : 0.f;
         }
         if (k == 0 && do_bias) bsum[m] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        *reinterpret_cast<bf16x8*>(gs + (k * 64 + row) * PITCH + g8) = wb_pack(v);
+        *reinterpret_cast<bf16x8*>(gs + (k * R + row) * PITCH + g8) = wb_pack(v);
       }
     }
     __syncthreads();
     advance(cb, cc_);
     if (ch + nsplit < total) load_chunk(cb, cc_);  // in flight during the MFMAs below
     // ---- MFMAs: A = G_k rows (co), B = x rows (ci), contraction over the 128 samples of the chunk ----
-    const __bf16* xr = xs + (wi * 32 + l31) * PITCH + 8 * hi;
-    const __bf16* gr = gs + (wo * 32 + l31) * PITCH + 8 * hi;
+    const __bf16* xr = xs + (wi * 32 * F + l31) * PITCH + 8 * hi;
+    const __bf16* gr = gs + (wo * 32 * F + l31) * PITCH + 8 * hi;
 #pragma unroll
     for (int s8 = 0; s8 < TW / 16; ++s8) {
-      const bf16x8 bp = *reinterpret_cast<const bf16x8*>(xr + 16 * s8);
+      bf16x8 bp[F];
 #pragma unroll
-      for (int k = 0; k < KN; ++k) {
-        const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + k * 64 * PITCH + 16 * s8);
-        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp, acc[k], 0, 0, 0);
-      }
+      for (int fi = 0; fi < F; ++fi) bp[fi] = *reinterpret_cast<const bf16x8*>(xr + fi * 32 * PITCH + 16 * s8);
+#pragma unroll
+      for (int k = 0; k < KN; ++k)
+#pragma unroll
+        for (int fo = 0; fo < F; ++fo) {
+          const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + (k * R + fo * 32) * PITCH + 16 * s8);
+#pragma unroll
+          for (int fi = 0; fi < F; ++fi)
+            acc[k][fi][fo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp[fi], acc[k][fi][fo], 0, 0, 0);
+        }
     }
   }
 
@@ -281,17 +294,21 @@ __global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(C
     }
   }
   float* p = partial + (size_t)split * stride;
-  const int ci = ci0 + wi * 32 + l31;
 #pragma unroll
-  for (int k = 0; k < KN; ++k) {
-    if (k < K && ci < CinP) {
+  for (int k = 0; k < KN; ++k)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co < CoutP) p[((size_t)k * CinP + ci) * CoutP + co] = acc[k][r];
+    for (int fi = 0; fi < F; ++fi) {
+      const int ci = ci0 + (wi * F + fi) * 32 + l31;
+      if (k < K && ci < CinP) {
+#pragma unroll
+        for (int fo = 0; fo < F; ++fo)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (wo * F + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < CoutP) p[((size_t)k * CinP + ci) * CoutP + co] = acc[k][fi][fo][r];
+          }
       }
     }
-  }
 }
 
 bool wgradb_eligible(const ConvArgs& fwd, bool gmask) {
@@ -314,35 +331,44 @@ bool wgradb_eligible(const ConvArgs& fwd, bool gmask) {
   }
 }
 
+// K = 1 layers with both channel counts multiples of 128 (conformer / ConvNeXt-256 feed-forward): 128 x 128 blocks
+static bool wb_wide(const ConvArgs& ax) {
+  const char* e = getenv("STY_WGRADB_WIDE_MIN");  // (read per call: the parity test lowers it for its small shapes)
+  return ax.w.K == 1 && ax.w.CinP % 128 == 0 && ax.w.CoutP % 128 == 0 && (long)ax.B * ax.T >= (e ? atol(e) : 8192);
+}
 // chunk width: 128 samples, or 64 where the staging registers of 128 do not fit (without the window: the G multiplier,
 // five taps)
-constexpr int wb_tw(int kn, bool gmask, bool win) { return kn > 3 ? 64 : (win ? 128 : (gmask ? 64 : 128)); }
+constexpr int wb_tw(int kn, bool gmask, bool win, int f = 1) { return (kn > 3 || f > 1) ? 64 : (win ? 128 : (gmask ? 64 : 128)); }
 
-template <int KN, int PRO, bool WIN>
+template <int KN, int PRO, bool WIN, int F>
 static void wb_launch_w(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
                         int wb, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, false, wb_tw(KN, false, WIN), WIN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, false, wb_tw(KN, false, WIN, F), WIN, F>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, true, wb_tw(KN, true, WIN), WIN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb_kernel<KN, PRO, true, wb_tw(KN, true, WIN, F), WIN, F>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
     raised = true;
   }
   if (ag.pro == PRO_MASK)
-    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, true, wb_tw(KN, true, WIN), WIN>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb,
-                       partial, wb);
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, true, wb_tw(KN, true, WIN, F), WIN, F>), grid, dim3(256), lds, st, ax, ag, nsplit,
+                       cpb, partial, wb);
   else
-    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, false, wb_tw(KN, false, WIN), WIN>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb,
-                       partial, wb);
+    hipLaunchKernelGGL((wgradb_kernel<KN, PRO, false, wb_tw(KN, false, WIN, F), WIN, F>), grid, dim3(256), lds, st, ax, ag, nsplit,
+                       cpb, partial, wb);
 }
 template <int KN, int PRO>
 static void wb_launch(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
                       int wb, hipStream_t st) {
+  if (KN == 1 && wb_wide(ax)) {
+    wb_launch_w<1, PRO, false, 2>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st);
+    return;
+  }
   if (KN > 1 && ax.dil == 1)
-    wb_launch_w<KN, PRO, (KN > 1)>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st);
+    wb_launch_w<KN, PRO, (KN > 1), 1>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st);
   else
-    wb_launch_w<KN, PRO, false>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st);
+    wb_launch_w<KN, PRO, false, 1>(ax, ag, grid, lds, nsplit, cpb, partial, wb, st);
 }
 template <int KN>
 static void wb_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb,
@@ -361,10 +387,11 @@ static void wb_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, siz
 // partial planes: [nsplit][K][CinP][CoutP] (+ CoutP bias partials per split); the caller reduces them
 int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* partial, int want_bias, hipStream_t st) {
   const PackedConv& w = ax.w;
-  const int tw = wb_tw(w.K, ag.pro == PRO_MASK, w.K > 1 && ax.dil == 1);
+  const int f = wb_wide(ax) ? 2 : 1;
+  const int tw = wb_tw(w.K, ag.pro == PRO_MASK, w.K > 1 && ax.dil == 1, f);
   const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, tw);  // chunks cover u = t + k dil - pad over [-pad, T + halo - pad)
-  dim3 grid(cdiv(w.CinP, 64), cdiv(w.CoutP, 64), nsplit);
-  const size_t lds = (size_t)(1 + w.K) * 64 * (tw + 8) * sizeof(__bf16);
+  dim3 grid(cdiv(w.CinP, 64 * f), cdiv(w.CoutP, 64 * f), nsplit);
+  const size_t lds = (size_t)(1 + w.K) * 64 * f * (tw + 8) * sizeof(__bf16);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW);
   ProfScope prof(w.K == 1 ? "wgradb_kernel<1,true>" : (w.K == 3 ? "wgradb_kernel<3,true>" : "wgradb_kernel<5,true>"), 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T,

@@ -1083,6 +1083,7 @@ def test_bf16_weight_gradient_kernels_match_the_fp32_tile_kernels_in_the_graphs(
     mel = torch.randn(3, 1, 80, 161, generator=torch.Generator().manual_seed(9))
     gs = torch.randn(3, 64, generator=torch.Generator().manual_seed(10))
     out = {}
+    monkeypatch.setenv("STY_WGRADB_WIDE_MIN", "1")  # the 128 x 128 blocks of the wide K = 1 layers at the test size too
     for mode in ("old", "new"):
         monkeypatch.delenv("STY_NO_WGRADB", raising=False)
         if mode == "old":
