@@ -421,7 +421,9 @@ int wgradb_chunks(const PackedConv& w, int B, int T, int dil) { return B * cdiv(
 // =====================================================================================================================
 constexpr int WP_TW = 64;  // reduction samples per chunk
 
-template <int KT, int PRO, bool GMASK>
+// BF = false (fp32 modes: exact v_mfma_f32_32x32x2_f32): fp32 tiles with odd row pitches, ONE copy of G (a dword operand has no
+// alignment to respect: tap k reads it k dil columns to the left), the same staging and the same split over the waves
+template <int KT, int PRO, bool GMASK, bool BF>
 __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs ag, int nsplit, int chunks_per_b, int hg,
                                                           int pg, float* __restrict__ partial, int want_bias) {
   // hg: halo groups (8 columns each) on the left of every G copy; pg: bf16 elements between rows of a G copy
@@ -429,6 +431,10 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
   constexpr int PX = WP_TW + 8;
   __bf16* xs = wb_lds;             // [32][PX]
   __bf16* gs = wb_lds + 32 * PX;   // [8][32][pg]
+  constexpr int PXF = WP_TW + 1;   // fp32: [32][PXF], [32][pgf], pgf = WP_TW + 8 hg + 1
+  float* xsf = reinterpret_cast<float*>(wb_lds);
+  float* gsf = xsf + 32 * PXF;
+  const int pgf = WP_TW + 8 * hg + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
             hi = lane >> 5;
   const int K = ax.w.K, dil = ax.dil, T = ax.T, pad = ax.pad;
@@ -475,11 +481,11 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
 #pragma unroll
     for (int m = 0; m < 2; ++m) {  // sixteen samples: [t - 8, t + 8) with t = t0 + 8 gq
       float lo[8], hi8[8];
-      wb_load_row8(rg, offg[m], t0 + 8 * gq - 8, T, lo);
+      if constexpr (BF) wb_load_row8(rg, offg[m], t0 + 8 * gq - 8, T, lo);
       wb_load_row8(rg, offg[m], t0 + 8 * gq, T, hi8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        gv[m][e] = lo[e];
+        gv[m][e] = BF ? lo[e] : 0.f;
         gv[m][8 + e] = hi8[e];
       }
     }
@@ -530,7 +536,12 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (s0 + e >= 0 && s0 + e < T) ? v[e] : 0.f;
       }
-      *reinterpret_cast<bf16x8*>(xs + xr_ * PX + xg8) = wb_pack(v);
+      if constexpr (BF) {
+        *reinterpret_cast<bf16x8*>(xs + xr_ * PX + xg8) = wb_pack(v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xsf[xr_ * PXF + xg8 + e] = v[e];
+      }
     }
     if (glive) {
 #pragma unroll
@@ -545,11 +556,17 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
         }
         if (do_bias && gq >= 0)
           bsum[m] += ((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]));
-        __bf16* dst = gs + (size_t)(grow0 + 16 * m) * pg + (gq + hg) * 8;
+        if constexpr (BF) {
+          __bf16* dst = gs + (size_t)(grow0 + 16 * m) * pg + (gq + hg) * 8;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {  // copy p, this group: samples t - p .. t - p + 7
-          const float w8[8] = {v[8 - p], v[9 - p], v[10 - p], v[11 - p], v[12 - p], v[13 - p], v[14 - p], v[15 - p]};
-          *reinterpret_cast<bf16x8*>(dst + (size_t)p * 32 * pg) = wb_pack(w8);
+          for (int p = 0; p < 8; ++p) {  // copy p, this group: samples t - p .. t - p + 7
+            const float w8[8] = {v[8 - p], v[9 - p], v[10 - p], v[11 - p], v[12 - p], v[13 - p], v[14 - p], v[15 - p]};
+            *reinterpret_cast<bf16x8*>(dst + (size_t)p * 32 * pg) = wb_pack(w8);
+          }
+        } else {
+          float* dst = gsf + (size_t)(grow0 + 16 * m) * pgf + (gq + hg) * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dst[e] = v[8 + e];
         }
       }
     }
@@ -557,6 +574,23 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
     advance(cb, cc_);
     if (ch + nsplit < total) load_chunk(cb, cc_);
     // ---- MFMAs: this wave's taps ----
+    if constexpr (!BF) {
+      const float* xrf = xsf + l31 * PXF + hi;
+      float bpf[WP_TW / 2];
+#pragma unroll
+      for (int q = 0; q < WP_TW / 2; ++q) bpf[q] = xrf[2 * q];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int k = wave + 4 * kt;
+        if (k < K) {
+          const float* grf = gsf + (size_t)l31 * pgf + 8 * hg - k * dil + hi;
+#pragma unroll
+          for (int q = 0; q < WP_TW / 2; ++q)
+            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(grf[2 * q], bpf[q], acc[kt], 0, 0, 0);
+        }
+      }
+      continue;
+    }
     const __bf16* xrp = xs + l31 * PX + 8 * hi;
     bf16x8 bp[WP_TW / 16];
 #pragma unroll
@@ -612,7 +646,7 @@ static int wp_pg(const ConvArgs& fwd) {
 }
 bool wgradp32_eligible(const ConvArgs& fwd) {
   const PackedConv& w = fwd.w;
-  if (!fwd.bf16 || getenv("STY_NO_WGRADB")) return false;
+  if (getenv("STY_NO_WGRADB")) return false;  // (both modes: bf16 tiles with phase copies, or fp32 tiles)
   if (w.CinP % 32 || w.CinP > 96 || w.CoutP != 32 || w.K < 2 || w.K > 24 || (w.K - 1) * fwd.dil > 64) return false;
   if (fwd.flatW || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
   if (fwd.nsrc != 1) {  // channel-concatenated input: one 32-channel source per 32-row block
@@ -638,17 +672,26 @@ static void wp_launch(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t 
                       int wb, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradp32_kernel<KT, PRO, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradp32_kernel<KT, PRO, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradp32_kernel<KT, PRO, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradp32_kernel<KT, PRO, true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     raised = true;
   }
   const int hg = wp_hg(ax), pg = wp_pg(ax);
+  if (!ax.bf16) {
+    if (ag.pro == PRO_MASK)
+      hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, true, false>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial,
+                         wb);
+    else
+      hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, false, false>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial,
+                         wb);
+    return;
+  }
   if (ag.pro == PRO_MASK)
-    hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, true>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial, wb);
+    hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, true, true>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial, wb);
   else
-    hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, false>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial, wb);
+    hipLaunchKernelGGL((wgradp32_kernel<KT, PRO, false, true>), grid, dim3(256), lds, st, ax, ag, nsplit, cpb, hg, pg, partial, wb);
 }
 template <int KT>
 static void wp_launch_pro(const ConvArgs& ax, const ConvArgs& ag, dim3 grid, size_t lds, int nsplit, int cpb, float* partial,
@@ -667,10 +710,12 @@ int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* p
   const PackedConv& w = ax.w;
   const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, WP_TW);
   dim3 grid(w.CinP / 32, 1, nsplit);
-  const size_t lds = ((size_t)32 * (WP_TW + 8) + (size_t)8 * 32 * wp_pg(ax)) * sizeof(__bf16);
+  const size_t lds = ax.bf16 ? ((size_t)32 * (WP_TW + 8) + (size_t)8 * 32 * wp_pg(ax)) * sizeof(__bf16)
+                             : ((size_t)32 * (WP_TW + 1) + (size_t)32 * (WP_TW + 8 * wp_hg(ax) + 1)) * sizeof(float);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d d%d", w.Cin, w.Cout, w.K, ax.T, ax.dil);
-  ProfScope prof(w.K <= 12 ? "wgradp32_kernel<3,true>" : "wgradp32_kernel<6,true>",
+  ProfScope prof(ax.bf16 ? (w.K <= 12 ? "wgradp32_kernel<3,true>" : "wgradp32_kernel<6,true>")
+                         : (w.K <= 12 ? "wgradp32_kernel<3,false>" : "wgradp32_kernel<6,false>"),
                  2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T, 4.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
   if (w.K <= 12)
     wp_launch_pro<3>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
