@@ -275,6 +275,37 @@ int sty_acoustic_loss_fwd_bwd(int B, int N, const float *audio_gt, const float *
                               float w_phase, float *losses, float *d_audio_pred, void *workspace, size_t ws_bytes,
                               void *stream);
 
+/* ---- adversarial terms of the acoustic stage: spectrogram discriminators ---------------
+ * SpecDiscriminator (train/models/discriminator.py:13-68): five weight-normed Conv2d 3x9 / 3x3 with LeakyReLU(0.1),
+ * a weight-normed 3x3 score conv after each.  Parameters by reference key: index i = 0..4 is `discriminators.i`,
+ * 5 + i is `out.i`; g = parametrizations.weight.original0 [Cout,1,1,1], v = ...original1 [Cout,Cin,KH,KW], bias.  */
+typedef struct {
+  const float *g[10];
+  const float *v[10];
+  const float *bias[10];
+} sty_specdisc_params;
+typedef struct { /* gradients, same shapes; the calls ADD into them */
+  float *g[10];
+  float *v[10];
+  float *bias[10];
+} sty_specdisc_grads;
+/* W1 = ceil(W/2), W2 = ceil(W1/2), W3 = ceil(W2/2): the five score maps have H*W, H*W1, H*W2, H*W3, H*W3 elements
+ * per batch item; `scores` buffers hold them back to back, each [B][H*Wi] (torch.flatten(out, 1, -1) of the module). */
+int sty_specdisc_workspace_bytes(int B, int H, int W, int with_grads, size_t *bytes);
+/* SpecDiscriminator.forward: x [B,1,H,W] (H = frequency bins, W = frames) -> the five score maps.                   */
+int sty_specdisc_forward(const sty_specdisc_params *p, int B, int H, int W, const float *x, float *scores,
+                         int compute_bf16, void *workspace, size_t ws_bytes, void *stream);
+/* GeneratorLossHelper.forward + backward (train/losses.py:330-373) and / or DiscriminatorLossHelper.forward + backward
+ * (train/losses.py:228-290) of ONE discriminator on target, pred [B,1,H,W], from a single forward pass (both helpers
+ * see the same weights and tensors in the reference's step, train/stage.py:104-147):
+ *   gen_loss[0] += loss;  d_pred [B,H,W] += gen_scale * d loss / d pred            (either may be NULL; both NULL: skipped)
+ *   disc_loss[0] += loss, disc_loss[1] += loss without the relativistic term (what DiscriminatorLossHelper.last_loss
+ *   tracks);  grads += disc_scale * d loss / d parameters                           (likewise)                          */
+int sty_specdisc_losses(const sty_specdisc_params *p, int B, int H, int W, const float *target, const float *pred,
+                        float gen_scale, float *gen_loss, float *d_pred, float disc_scale, float *disc_loss,
+                        const sty_specdisc_grads *grads, int compute_bf16, void *workspace, size_t ws_bytes,
+                        void *stream);
+
 /* ---- in-situ kernel timing (used by bench.py for the roofline object) --------------------------------
  * When enabled, every launch of the instrumented kernel families is bracketed by HIP events on the launch
  * stream.  sty_prof_report synchronises the device, sums the event times per family and writes up to `cap`

@@ -135,7 +135,19 @@ __device__ __forceinline__ void stage_load_it(const ConvArgs& a, const float* xb
     const int vrow = MODE == ST_FLAT ? voff + r.tsh * 4 : voff;
 #pragma unroll
     for (int q = 0; q < MAXJ; ++q)
-      if (q < TBASE / 64 || 64 * q < LW) vv[u][q] = buf_load(rs, vrow + 256 * es * q);
+      if (q < TBASE / 64 || 64 * q < LW) {
+        if constexpr (MODE == ST_FLAT) {
+          // the row shift makes the lane offset NEGATIVE at the start of a channel row; with the column group folded
+          // into the instruction's immediate (offset:256 q) the first `pad` in-range samples came back as zeros on
+          // MI355X (image row 1, columns 0 .. pad-1 of every flat conv whose row pitch is >= 62): keep the whole
+          // offset in the VGPR, where the range check is the plain unsigned compare
+          int off = vrow + 256 * q;
+          asm volatile("" : "+v"(off));
+          vv[u][q] = buf_load(rs, off);
+        } else {
+          vv[u][q] = buf_load(rs, vrow + 256 * es * q);
+        }
+      }
   }
 }
 template <int NW, int MAXJ, int MODE, int TBASE>

@@ -1,0 +1,194 @@
+"""Adversarial terms of the acoustic stage on libstylish_hip.so.
+
+Reference interfaces mirrored here (paths under the reference tree, src/stylish_tts/train/):
+  SpecDiscriminator().forward(y) -> (five flattened score maps, [])            models/discriminator.py:13-68
+  GeneratorLossHelper(model)(target=, pred=) -> loss                            losses.py:330-373
+  DiscriminatorLossHelper(model, sub_count)(target=, pred=) -> loss             losses.py:228-290
+      .last_loss / .get_disc_lr_multiplier()                                    losses.py:236-256
+  GeneratorLoss / DiscriminatorLoss "mrd" branch (three spectrogram discriminators, one per resolution of
+      MultiSpectrogram)                                                          losses.py:191-208, 313-327
+
+`SpecDiscriminator` is an nn.Module shell with the reference's state_dict keys
+(`discriminators.{i}.parametrizations.weight.original0/1`, `discriminators.{i}.bias`, `out.{i}. ...`).  The loss helpers
+do forward AND backward in the library: the generator helper returns the loss and ADDS d loss / d pred into a gradient
+buffer, the discriminator helper ADDS the parameter gradients into `param.grad`.  `MrdLosses.step` evaluates both from a
+single forward pass of each discriminator (the reference's step evaluates them with the same weights on the same
+tensors, stage.py:104-147).  There is no PyTorch fallback.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+from .modules import _register
+
+_SHAPES = [(32, 1, 3, 9), (32, 32, 3, 9), (32, 32, 3, 9), (32, 32, 3, 9), (32, 32, 3, 3)]
+
+
+def spec_discriminator_manifest():
+    m = {}
+    for name, shapes in (("discriminators", _SHAPES), ("out", [(1, 32, 3, 3)] * 5)):
+        for i, s in enumerate(shapes):
+            m[f"{name}.{i}.bias"] = [s[0]]
+            m[f"{name}.{i}.parametrizations.weight.original0"] = [s[0], 1, 1, 1]
+            m[f"{name}.{i}.parametrizations.weight.original1"] = list(s)
+    return m
+
+
+def score_widths(W):
+    w1 = (W + 1) // 2
+    w2 = (w1 + 1) // 2
+    w3 = (w2 + 1) // 2
+    return [W, w1, w2, w3, w3]
+
+
+class SpecDiscriminator(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        for key, shape in spec_discriminator_manifest().items():
+            if key.endswith("original1"):
+                fan_in = shape[1] * shape[2] * shape[3]
+                t = (torch.rand(shape) * 2 - 1) / math.sqrt(fan_in)  # Conv2d default: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+            elif key.endswith("original0"):
+                t = None  # = ||v|| (weight_norm initialises g so that W == v), filled below
+            else:
+                t = torch.zeros(shape)
+            _register(self, key, t if t is not None else torch.ones(shape), False)
+        sd = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k.endswith("original0"):
+                    v.copy_(sd[k[:-1] + "1"].flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+        self.compute_bf16 = False
+        self._ws = None
+
+    # ---- C-ABI plumbing ----
+    def _ptrs(self, grads=False):
+        sd = dict(self.named_parameters())
+        st = L.SpecDiscPtrs()
+        for j, name in enumerate(["discriminators"] * 5 + ["out"] * 5):
+            i = j % 5
+            for field, key in (("g", f"{name}.{i}.parametrizations.weight.original0"),
+                               ("v", f"{name}.{i}.parametrizations.weight.original1"), ("bias", f"{name}.{i}.bias")):
+                p = sd[key]
+                if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise L.StyError(f"SpecDiscriminator: {key} must be contiguous fp32 on a HIP device; there is no CPU path")
+                if grads:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    getattr(st, field)[j] = p.grad.data_ptr()
+                else:
+                    getattr(st, field)[j] = p.data_ptr()
+        return st
+
+    def _workspace(self, B, H, W, with_grads, device):
+        lib = L.load()
+        need = C.c_size_t()
+        L.check(lib.sty_specdisc_workspace_bytes(B, H, W, int(with_grads), C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    @staticmethod
+    def _image(y):
+        if y.dim() == 4:
+            assert y.shape[1] == 1
+            y = y[:, 0]
+        if y.device.type != "cuda":
+            raise L.StyError("SpecDiscriminator: inputs must live on a HIP device; there is no CPU path")
+        return y.contiguous().float()
+
+    def forward(self, y):
+        lib = L.load()
+        y = self._image(y.detach())
+        B, H, W = y.shape
+        ws = self._workspace(B, H, W, False, y.device)
+        widths = score_widths(W)
+        scores = torch.empty(B * H * sum(widths), dtype=torch.float32, device=y.device)
+        st = self._ptrs()
+        L.check(lib.sty_specdisc_forward(C.byref(st), B, H, W, L.ptr(y), L.ptr(scores), int(self.compute_bf16), L.ptr(ws),
+                                         ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        out, o = [], 0
+        for wi in widths:
+            out.append(scores[o:o + B * H * wi].view(B, H * wi))
+            o += B * H * wi
+        return out, []
+
+    def losses(self, target, pred, *, gen_scale=None, d_pred=None, disc_scale=None):
+        """One forward pass of target and pred; returns (gen_loss or None, disc_loss[2] or None) as device tensors.
+        gen_scale: evaluate the generator helper and add gen_scale * d loss / d pred into d_pred [B, H, W];
+        disc_scale: evaluate the discriminator helper and add disc_scale * d loss / d parameters into .grad."""
+        lib = L.load()
+        t, p = self._image(target.detach()), self._image(pred.detach())
+        B, H, W = t.shape
+        ws = self._workspace(B, H, W, disc_scale is not None, t.device)
+        gen = torch.zeros(1, device=t.device) if gen_scale is not None else None
+        disc = torch.zeros(2, device=t.device) if disc_scale is not None else None
+        if d_pred is not None:
+            assert d_pred.shape == p.shape and d_pred.is_contiguous() and d_pred.dtype == torch.float32
+        st = self._ptrs()
+        gr = self._ptrs(grads=True) if disc_scale is not None else None
+        L.check(lib.sty_specdisc_losses(C.byref(st), B, H, W, L.ptr(t), L.ptr(p), float(gen_scale or 0.0), L.ptr(gen),
+                                        L.ptr(d_pred) if gen_scale is not None else None, float(disc_scale or 0.0),
+                                        L.ptr(disc), C.byref(gr) if gr is not None else None, int(self.compute_bf16),
+                                        L.ptr(ws), ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return gen, disc
+
+
+class GeneratorLossHelper:  # losses.py:330-373
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self, *, target, pred, d_pred=None, scale=1.0):
+        gen, _ = self.model.losses(target, pred, gen_scale=scale, d_pred=d_pred)
+        return gen[0]
+
+
+class DiscriminatorLossHelper:  # losses.py:228-290
+    def __init__(self, model, sub_count):
+        self.model = model
+        self.last_loss = 0.5 * sub_count
+        self.ideal_loss = 0.5 * sub_count
+        self.f_max = 4.0
+        self.h_min = 0.01
+        self.x_max = 0.05 * sub_count
+        self.x_min = 0.05 * sub_count
+
+    def get_disc_lr_multiplier(self):  # losses.py:241-256
+        x = abs(self.last_loss - self.ideal_loss)
+        if self.last_loss > self.ideal_loss + self.x_max:
+            return self.f_max
+        if self.last_loss < self.ideal_loss - self.x_min:
+            return self.h_min
+        if self.last_loss > self.ideal_loss:
+            return min(math.pow(self.f_max, x / self.x_max), self.f_max)
+        return max(math.pow(self.h_min, x / self.x_min), self.h_min)
+
+    def track(self, disc):
+        self.last_loss = self.last_loss * 0.95 + float(disc[1].item()) * 0.05
+
+    def __call__(self, *, target, pred, scale=1.0):
+        _, disc = self.model.losses(target, pred, disc_scale=scale)
+        self.track(disc)
+        return disc[0]
+
+
+class MrdLosses:
+    """The three spectrogram discriminators of the acoustic stage (models.py:75-77: mrd0..2, one per MultiSpectrogram
+    resolution) with both helper families, evaluated from one forward pass per discriminator."""
+
+    def __init__(self, models):
+        self.models = list(models)
+        self.disc_helpers = [DiscriminatorLossHelper(m, 5) for m in self.models]
+
+    def step(self, target_list, pred_list, *, d_pred_list, gen_scale, disc_scale):
+        """-> (generator loss, discriminator loss) summed over the discriminators, as device scalars.
+        d_pred_list[i] += gen_scale * d generator loss / d pred_list[i]; parameter .grad += disc_scale * d disc loss."""
+        gen_total, disc_total = None, None
+        for m, h, t, p, dp in zip(self.models, self.disc_helpers, target_list, pred_list, d_pred_list):
+            gen, disc = m.losses(t, p, gen_scale=gen_scale, d_pred=dp, disc_scale=disc_scale)
+            h.track(disc)
+            gen_total = gen[0] if gen_total is None else gen_total + gen[0]
+            disc_total = disc[0] if disc_total is None else disc_total + disc[0]
+        return gen_total, disc_total

@@ -41,6 +41,11 @@ class TrainOpts(C.Structure):
                 ("text_dropout", C.c_float), ("compute_bf16", C.c_int)]
 
 
+class SpecDiscPtrs(C.Structure):
+    """sty_specdisc_params / sty_specdisc_grads: g, v, bias of `discriminators.0..4` then `out.0..4`."""
+    _fields_ = [("g", C.c_void_p * 10), ("v", C.c_void_p * 10), ("bias", C.c_void_p * 10)]
+
+
 # every symbol include/stylish_hip.h declares: name -> (restype, argtypes)
 _P, _I, _SZP = C.c_void_p, C.c_int, C.POINTER(C.c_size_t)
 SYMBOLS = {
@@ -103,6 +108,10 @@ SYMBOLS = {
     "sty_model_set_grad_hook": (C.c_int, [_P, _P, _P]),
     "sty_acoustic_loss_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
     "sty_acoustic_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _P]),
+    "sty_specdisc_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _SZP]),
+    "sty_specdisc_forward": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _P]),
+    "sty_specdisc_losses": (C.c_int, [_P, _I, _I, _I, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _I, _P, C.c_size_t,
+                                      _P]),
     "sty_prof_enable": (C.c_int, [_I]),
     "sty_prof_only": (C.c_int, [C.c_char_p]),
     "sty_set_single_stream": (C.c_int, [_I]),

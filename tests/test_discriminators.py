@@ -1,0 +1,175 @@
+"""Spectrogram discriminators + adversarial loss helpers.
+
+CPU: oracle/discriminator.py against the fixture written by the reference's own classes (tools/gen_golden_disc.py).
+GPU: the HIP path (through the C ABI) against the same fixture and against the oracle on other shapes.
+"""
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fixture():
+    fx = load_file(os.path.join(G, "disc_small.safetensors"))
+    params = {k[2:]: v for k, v in fx.items() if k.startswith("w.")}
+    return fx, params
+
+
+def test_spec_discriminator_manifest_equals_reference_state_dict():
+    from stylish_tts_amd.discriminators import spec_discriminator_manifest
+    with open(os.path.join(G, "manifest_spec_discriminator.json")) as f:
+        want = json.load(f)
+    assert spec_discriminator_manifest() == want
+
+
+def test_discriminator_oracle_matches_reference_classes():
+    """oracle/discriminator.py vs SpecDiscriminator / GeneratorLossHelper / DiscriminatorLossHelper of the reference:
+    score maps, both losses, d loss / d pred, d loss / d parameters."""
+    from oracle import discriminator as od
+    fx, params = _fixture()
+    for case in range(2):
+        t = fx[f"c{case}.target"]
+        q = fx[f"c{case}.pred"].clone().requires_grad_(True)
+        rs, gs = od.spec_discriminator(params, t), od.spec_discriminator(params, q)
+        for i in range(5):
+            assert (rs[i] - fx[f"c{case}.real_score{i}"]).abs().max().item() <= 2e-6
+            assert (gs[i] - fx[f"c{case}.gen_score{i}"]).abs().max().item() <= 2e-6
+        gl = od.generator_loss_helper(rs, gs)
+        gl.backward()
+        assert abs(gl.item() - fx[f"c{case}.gen_loss"].item()) <= 1e-5
+        ref = fx[f"c{case}.d_pred"]
+        assert (q.grad - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        pp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        dl = od.discriminator_loss_helper(od.spec_discriminator(pp, t), od.spec_discriminator(pp, fx[f"c{case}.pred"]))
+        dl.backward()
+        assert abs(dl.item() - fx[f"c{case}.disc_loss"].item()) <= 1e-5
+        for k in pp:
+            ref = fx[f"c{case}.grad." + k]
+            assert (pp[k].grad - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-3), k
+
+
+def _hip_model(params, dev):
+    from stylish_tts_amd.discriminators import SpecDiscriminator
+    m = SpecDiscriminator().to(dev)
+    missing = m.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+@pytest.mark.gpu
+def test_spec_discriminator_hip_vs_reference_fixture():
+    """HIP SpecDiscriminator.forward, GeneratorLossHelper and DiscriminatorLossHelper (forward + backward) against the
+    values the reference's classes produced (fp32 mode)."""
+    from stylish_tts_amd.discriminators import DiscriminatorLossHelper, GeneratorLossHelper
+    dev = torch.device("cuda:0")
+    fx, params = _fixture()
+    m = _hip_model(params, dev)
+    for case in range(2):
+        t, q = fx[f"c{case}.target"].to(dev), fx[f"c{case}.pred"].to(dev)
+        rs, fm = m(t)
+        gs, _ = m(q)
+        assert fm == []
+        for i in range(5):
+            for got, name in ((rs[i], "real"), (gs[i], "gen")):
+                ref = fx[f"c{case}.{name}_score{i}"]
+                assert got.shape == ref.shape
+                err = (got.cpu() - ref).abs().max().item()
+                assert err <= 2e-5 * max(ref.abs().max().item(), 0.1), (case, i, name, err)
+        d_pred = torch.zeros_like(q[:, 0])
+        gl = GeneratorLossHelper(m)(target=t, pred=q, d_pred=d_pred)
+        assert abs(gl.item() - fx[f"c{case}.gen_loss"].item()) <= 2e-5 * fx[f"c{case}.gen_loss"].item()
+        ref = fx[f"c{case}.d_pred"][:, 0]
+        err = (d_pred.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * ref.abs().max().item(), (case, "d_pred", err, ref.abs().max().item())
+        for p in m.parameters():
+            p.grad = None
+        helper = DiscriminatorLossHelper(m, 5)
+        dl = helper(target=t, pred=q)
+        assert abs(dl.item() - fx[f"c{case}.disc_loss"].item()) <= 2e-5 * fx[f"c{case}.disc_loss"].item()
+        assert abs(helper.last_loss - fx[f"c{case}.last_loss"].item()) <= 1e-5
+        for k, p in m.named_parameters():
+            ref = fx[f"c{case}.grad." + k]
+            err = (p.grad.cpu() - ref).abs().max().item()
+            lim = (1e-3 if k.endswith("original0") else 2e-4) * max(ref.abs().max().item(), 1e-3)  # g: a cancelling sum
+            assert err <= lim, (case, k, err, ref.abs().max().item())
+
+
+def _check_against_oracle(m, params, t, q0, dev, tol_x, tol_w, tol_loss=2e-5):
+    """The relativistic term puts a large share of its gradient on ONE score element (the median of real - gen, as
+    torch.median's backward does), so score maps that differ in the last bit can move that spike to another element.
+    The comparison is therefore made in two exact halves: (1) the loss kernels against the oracle's loss functions ON
+    THE HIP SCORE MAPS (same inputs bit for bit -> same median element): values here, gradients through (2);
+    (2) the network backward against the oracle network's backward fed with those score gradients."""
+    from oracle import discriminator as od
+    B, _, H, W = t.shape
+    td, qd = t.to(dev), q0.to(dev)
+    rs_h = [x.cpu().clone().requires_grad_(True) for x in m(td)[0]]
+    gs_h = [x.cpu().clone().requires_grad_(True) for x in m(qd)[0]]
+    gl = od.generator_loss_helper(rs_h, gs_h)
+    g_gen = torch.autograd.grad(gl, gs_h)
+    dl = od.discriminator_loss_helper(rs_h, gs_h)
+    g_dr = torch.autograd.grad(dl, rs_h, retain_graph=True)
+    g_dg = torch.autograd.grad(dl, gs_h)
+    # oracle network, score gradients injected
+    q = q0.clone().requires_grad_(True)
+    pp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    so_t, so_q = od.spec_discriminator(pp, t), od.spec_discriminator(pp, q)
+    for a_, b_ in zip(so_t + so_q, rs_h + gs_h):  # the HIP score maps themselves
+        assert (a_ - b_).abs().max().item() <= tol_x * max(a_.abs().max().item(), 0.1)
+    dq, = torch.autograd.grad(so_q, q, grad_outputs=list(g_gen), retain_graph=True)
+    keys = sorted(pp)
+    dw = torch.autograd.grad(so_t + so_q, [pp[k] for k in keys], grad_outputs=list(g_dr) + list(g_dg))
+    for p_ in m.parameters():
+        p_.grad = None
+    d_pred = torch.zeros(B, H, W, device=dev)
+    gen, disc = m.losses(td, qd, gen_scale=2.0, d_pred=d_pred, disc_scale=3.0)
+    assert abs(gen[0].item() - gl.item()) <= tol_loss * gl.item(), (gen[0].item(), gl.item())
+    assert abs(disc[0].item() - dl.item()) <= tol_loss * dl.item(), (disc[0].item(), dl.item())
+    err = (d_pred.cpu() - 2.0 * dq[:, 0]).abs().max().item()
+    assert err <= tol_w * 2.0 * dq.abs().max().item(), ("d_pred", err, dq.abs().max().item())
+    got = dict(m.named_parameters())
+    for k, ref in zip(keys, dw):
+        ref = 3.0 * ref
+        err = (got[k].grad.cpu() - ref).abs().max().item()
+        lim = tol_w * (5.0 if k.endswith("original0") else 1.0) * max(ref.abs().max().item(), 1e-3)
+        assert err <= lim, (k, err, ref.abs().max().item())
+    return gen, disc, d_pred
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(3, 65, 203), (2, 129, 77), (1, 17, 9)])
+def test_spec_discriminator_hip_vs_oracle_other_shapes(B, H, W):
+    """Widths that are odd at every halving, a single-tile image, and the combined call (both helpers from one forward
+    pass) against the oracle; the combined call must equal the two separate calls."""
+    dev = torch.device("cuda:0")
+    _, params = _fixture()
+    m = _hip_model(params, dev)
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    t = torch.rand(B, 1, H, W, generator=g) ** 2 * 3
+    q0 = (t + 0.4 * torch.randn(B, 1, H, W, generator=g)).abs()
+    gen, disc, d_pred = _check_against_oracle(m, params, t, q0, dev, 2e-5, 2e-4)
+    for p in m.parameters():
+        p.grad = None
+    d2 = torch.zeros(B, H, W, device=dev)
+    gen2, _ = m.losses(t.to(dev), q0.to(dev), gen_scale=2.0, d_pred=d2)
+    _, disc2 = m.losses(t.to(dev), q0.to(dev), disc_scale=3.0)
+    assert torch.equal(gen2, gen) and torch.equal(d2, d_pred)
+    assert abs(disc2[0].item() - disc[0].item()) <= 1e-6 * abs(disc[0].item())
+
+
+@pytest.mark.gpu
+def test_spec_discriminator_bf16_mode():
+    """compute_bf16: the 32 -> 32 convs and their gradient convs multiply bf16-rounded operands (convp16 / wgrad kernels
+    of the acoustic path); same two-part check as in fp32 mode, bf16-sized tolerances."""
+    dev = torch.device("cuda:0")
+    _, params = _fixture()
+    m = _hip_model(params, dev)
+    m.compute_bf16 = True
+    g = torch.Generator().manual_seed(5)
+    t = torch.rand(4, 1, 129, 160, generator=g) ** 2 * 3
+    q0 = (t + 0.4 * torch.randn(t.shape, generator=g)).abs()
+    _check_against_oracle(m, params, t, q0, dev, 2e-2, 5e-2)
