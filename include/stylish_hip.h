@@ -306,6 +306,22 @@ int sty_specdisc_losses(const sty_specdisc_params *p, int B, int H, int W, const
                         const sty_specdisc_grads *grads, int compute_bf16, void *workspace, size_t ws_bytes,
                         void *stream);
 
+/* The acoustic losses WITH the adversarial term of the three spectrogram discriminators (AcousticStep.generator_loss,
+ * train/stage_type.py:208-220, "mrd" part of GeneratorLoss / DiscriminatorLoss, train/losses.py:191-208, 313-327; the
+ * waveform discriminator `disc` is not built): as sty_acoustic_loss_fwd_bwd, plus
+ *   d_audio_pred += w_gen * d (sum_r GeneratorLossHelper_r(target_fft_r, pred_fft_r)) / d audio_pred   (the "generator"
+ *   loss enters LossLog.backwards_loss un-normalised, train/loss_log.py:84-86), and, from the same forward pass,
+ *   the discriminator-side loss of every resolution; mrd_grads[r] += disc_scale * its parameter gradients for the
+ *   resolutions whose bit is set in step_mask (the reference steps mrd{disc_index} only, train/stage.py:139-141).
+ * mrd, mrd_grads: arrays of 3 (mrd0..2 = resolutions fft 512 / 1024 / 2048).  gan_losses: device [7] = generator loss
+ * summed over the three, then (discriminator loss, the same without the relativistic term) per resolution.          */
+int sty_acoustic_gan_workspace_bytes(int B, int N, int with_grads, size_t *bytes);
+int sty_acoustic_gan_loss_fwd_bwd(int B, int N, const float *audio_gt, const float *audio_pred, float w_mel,
+                                  float w_phase, float w_gen, const sty_specdisc_params *mrd, float disc_scale,
+                                  const sty_specdisc_grads *mrd_grads, int step_mask, float *losses, float *gan_losses,
+                                  float *d_audio_pred, void *workspace, size_t ws_bytes, void *gan_workspace,
+                                  size_t gan_ws_bytes, int compute_bf16, void *stream);
+
 /* ---- in-situ kernel timing (used by bench.py for the roofline object) --------------------------------
  * When enabled, every launch of the instrumented kernel families is bracketed by HIP events on the launch
  * stream.  sty_prof_report synchronises the device, sums the event times per family and writes up to `cap`

@@ -2715,4 +2715,49 @@ int sty_acoustic_loss_fwd_bwd(int B, int N, const float* audio_gt, const float* 
                               S(stream));
 }
 
+int sty_acoustic_gan_workspace_bytes(int B, int N, int with_grads, size_t* bytes) {
+  if (!bytes || B <= 0 || N <= 1024) {
+    set_error("sty_acoustic_gan_workspace_bytes: bad argument");
+    return STY_EINVAL;
+  }
+  *bytes = acoustic_gan_workspace_bytes(B, N, with_grads);
+  return STY_OK;
+}
+int sty_acoustic_gan_loss_fwd_bwd(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
+                                  float w_gen, const sty_specdisc_params* mrd, float disc_scale,
+                                  const sty_specdisc_grads* mrd_grads, int step_mask, float* losses, float* gan_losses,
+                                  float* d_audio_pred, void* workspace, size_t ws_bytes, void* gan_workspace,
+                                  size_t gan_ws_bytes, int compute_bf16, void* stream) {
+  if (!audio_gt || !audio_pred || !losses || !gan_losses || !d_audio_pred || !workspace || !gan_workspace || !mrd ||
+      B <= 0 || N <= 1024 || (step_mask && !mrd_grads)) {
+    set_error("sty_acoustic_gan_loss_fwd_bwd: bad argument");
+    return STY_EINVAL;
+  }
+  if (ws_bytes < acoustic_loss_workspace_floats(B, N) * sizeof(float) ||
+      gan_ws_bytes < acoustic_gan_workspace_bytes(B, N, step_mask != 0)) {
+    set_error("sty_acoustic_gan_loss_fwd_bwd: workspace too small");
+    return STY_ENOMEM;
+  }
+  AcousticGan gan;
+  for (int r = 0; r < 3; ++r) {
+    for (int i = 0; i < 10; ++i)
+      if (!mrd[r].g[i] || !mrd[r].v[i] || !mrd[r].bias[i] ||
+          (((step_mask >> r) & 1) && (!mrd_grads[r].g[i] || !mrd_grads[r].v[i] || !mrd_grads[r].bias[i]))) {
+        set_error("sty_acoustic_gan_loss_fwd_bwd: null parameter / gradient pointer (discriminator %d, conv %d)", r, i);
+        return STY_EINVAL;
+      }
+    gan.p[r] = &mrd[r];
+    gan.g[r] = ((step_mask >> r) & 1) ? &mrd_grads[r] : nullptr;
+  }
+  gan.w_gen = w_gen;
+  gan.disc_scale = disc_scale;
+  gan.out = gan_losses;
+  gan.bf16 = compute_bf16;
+  gan.ws = gan_workspace;
+  gan.ws_bytes = gan_ws_bytes;
+  STY_HIP(hipMemsetAsync(gan_losses, 0, 7 * sizeof(float), S(stream)));
+  return launch_acoustic_loss_gan(B, N, audio_gt, audio_pred, w_mel, w_phase, losses, d_audio_pred, (float*)workspace, &gan,
+                                  S(stream));
+}
+
 }  // extern "C"

@@ -107,18 +107,19 @@ __global__ __launch_bounds__(256) void sd_unpack_kernel(const float* __restrict_
 }
 
 // x [B][H][W] -> x27 [B][27][H][Wp]: row (kh, j) = x shifted by (kh - 1) rows and (j - 4) columns, zero outside
-__global__ __launch_bounds__(256) void sd_x27_kernel(const float* __restrict__ x, int H, int W, int Wp,
-                                                     float* __restrict__ y) {
+// (x element (b, h, w) at b*sb + h*sh + w: dense [B][H][W], or the front end's batch-folded [H][B][W])
+__global__ __launch_bounds__(256) void sd_x27_kernel(const float* __restrict__ x, size_t sb, size_t sh, int H, int W,
+                                                     int Wp, float* __restrict__ y) {
   const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
   if (i >= H * Wp) return;
   const int h = i / Wp, w = i - h * Wp;
   const int hs = h + r / 9 - 1, ws = w + r % 9 - 4;
   const bool ok = hs >= 0 && hs < H && ws >= 0 && ws < W;
-  y[((size_t)b * 27 + r) * H * Wp + i] = ok ? x[((size_t)b * H + hs) * W + ws] : 0.f;
+  y[((size_t)b * 27 + r) * H * Wp + i] = ok ? x[(size_t)b * sb + (size_t)hs * sh + ws] : 0.f;
 }
 // input gradient of layer 0: dx[h][w] += sum_r dX27[r][h - kh + 1][w - j + 4] over the valid output positions
-__global__ __launch_bounds__(256) void sd_fold27_kernel(const float* __restrict__ d27, int H, int W, int Wp,
-                                                        float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void sd_fold27_kernel(const float* __restrict__ d27, int H, int W, int Wp, size_t sb,
+                                                        size_t sh, float* __restrict__ dx) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= H * W) return;
   const int h = i / W, w = i - h * W;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void sd_fold27_kernel(const float* __restrict_
     const int ho = h - r / 9 + 1, wo = w - r % 9 + 4;
     if (ho >= 0 && ho < H && wo >= 0 && wo < W) s += d27[((size_t)b * 27 + r) * H * Wp + (size_t)ho * Wp + wo];
   }
-  dx[(size_t)b * H * W + i] += s;
+  dx[(size_t)b * sb + (size_t)h * sh + w] += s;
 }
 
 // LeakyReLU(0.1) in place on z [B][32][H][Wp] (pad columns are zero and stay zero) + the even / odd column split
@@ -380,6 +381,7 @@ struct SdRun {
   hipStream_t st;
   int rc = STY_OK;
   int B, H, W;
+  size_t sb = 0, sh = 0;  // input (and input-gradient) strides of the batch and row index
   int bf16 = 0;
   int Wl[5], Wp[5], n[5];  // valid width, row pitch, H * pitch of every layer's output
   SdLayer L[5];
@@ -502,7 +504,7 @@ struct SdRun {
   // the five layers on x [B][H][W]; the score maps go to ac.s[i] (must be set)
   void forward(const float* x, Acts& ac) {
     ac.x27 = take<float>((size_t)B * 27 * n[0]);
-    if (live()) hipLaunchKernelGGL(sd_x27_kernel, dim3(cdiv(n[0], 256), 27, B), dim3(256), 0, st, x, H, W, Wp[0], ac.x27);
+    if (live()) hipLaunchKernelGGL(sd_x27_kernel, dim3(cdiv(n[0], 256), 27, B), dim3(256), 0, st, x, sb, sh, H, W, Wp[0], ac.x27);
     for (int i = 0; i < 5; ++i) {
       ac.a[i] = take<float>((size_t)B * 32 * n[i]);
       if (i < 3) ac.as[i] = take<float>((size_t)B * 32 * n[i]);
@@ -566,7 +568,7 @@ struct SdRun {
       }
     }
     if (dx && live())
-      hipLaunchKernelGGL(sd_fold27_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, st, dnext, H, W, Wp[0], dx);
+      hipLaunchKernelGGL(sd_fold27_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, st, dnext, H, W, Wp[0], sb, sh, dx);
     ws.off = mark;
   }
 
@@ -586,11 +588,15 @@ struct SdRun {
   }
 };
 
-int specdisc_run(const sty_specdisc_params* p, int B, int H, int W, const float* target, const float* pred,
-                 float* scores_t, float* scores_p, float gen_scale, float* gen_loss, float* d_pred, float disc_scale,
-                 float* disc_loss, const sty_specdisc_grads* grads, int compute_bf16, void* workspace, size_t ws_bytes,
-                 hipStream_t st, size_t* need) {
+}  // namespace
+
+int specdisc_run(const sty_specdisc_params* p, int B, int H, int W, size_t sb, size_t sh, const float* target,
+                 const float* pred, float* scores_t, float* scores_p, float gen_scale, float* gen_loss, float* d_pred,
+                 float disc_scale, float* disc_loss, const sty_specdisc_grads* grads, int compute_bf16, void* workspace,
+                 size_t ws_bytes, hipStream_t st, size_t* need) {
   SdRun r;
+  r.sb = sb ? sb : (size_t)H * W;
+  r.sh = sh ? sh : (size_t)W;
   r.ws.base = static_cast<char*>(workspace);
   r.ws.cap = ws_bytes;
   r.st = st;
@@ -681,7 +687,6 @@ int specdisc_run(const sty_specdisc_params* p, int B, int H, int W, const float*
   if (r.ws.base) STY_LAUNCH_CHECK();
   return STY_OK;
 }
-}  // namespace
 }  // namespace sty
 
 using namespace sty;
@@ -702,7 +707,7 @@ int sty_specdisc_workspace_bytes(int B, int H, int W, int with_grads, size_t* by
   sty_specdisc_grads g = {};
   float dummy[2];
   // dry run: no workspace base -> nothing is launched, only the bump allocator advances
-  return specdisc_run(&p, B, H, W, dummy, dummy, nullptr, nullptr, 1.f, dummy, dummy, 1.f, dummy, with_grads ? &g : nullptr,
+  return specdisc_run(&p, B, H, W, 0, 0, dummy, dummy, nullptr, nullptr, 1.f, dummy, dummy, 1.f, dummy, with_grads ? &g : nullptr,
                       0, nullptr, 0, nullptr, bytes);
 }
 
@@ -712,7 +717,7 @@ int sty_specdisc_forward(const sty_specdisc_params* p, int B, int H, int W, cons
     set_error("sty_specdisc_forward: bad argument");
     return STY_EINVAL;
   }
-  return specdisc_run(p, B, H, W, x, nullptr, scores, nullptr, 0.f, nullptr, nullptr, 0.f, nullptr, nullptr, compute_bf16,
+  return specdisc_run(p, B, H, W, 0, 0, x, nullptr, scores, nullptr, 0.f, nullptr, nullptr, 0.f, nullptr, nullptr, compute_bf16,
                       workspace, ws_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
@@ -730,6 +735,6 @@ int sty_specdisc_losses(const sty_specdisc_params* p, int B, int H, int W, const
         set_error("sty_specdisc_losses: null gradient buffer %d", i);
         return STY_EINVAL;
       }
-  return specdisc_run(p, B, H, W, target, pred, nullptr, nullptr, gen_scale, gen_loss, d_pred, disc_scale, disc_loss, grads,
+  return specdisc_run(p, B, H, W, 0, 0, target, pred, nullptr, nullptr, gen_scale, gen_loss, d_pred, disc_scale, disc_loss, grads,
                       compute_bf16, workspace, ws_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
 }

@@ -13,7 +13,7 @@
 #include <map>
 #include <tuple>
 
-#include "sty_common.h"
+#include "model.h"
 
 namespace sty {
 
@@ -580,7 +580,7 @@ size_t acoustic_loss_workspace_floats(int B, int N) {
   size_t tmp = 0;
   for (auto& r : res) {
     const size_t frames = N / r[1] + 1, F = r[0] / 2 + 1;
-    tot += (size_t)B * frames * (128 * 3 + F * 4 + 2 * F + 16);   // persistent per-resolution tensors
+    tot += (size_t)B * frames * (128 * 3 + F * 5 + 2 * F + 16);   // persistent per-resolution tensors
     const size_t t = (size_t)B * frames * ((size_t)r[0] + 2 * F + F) + 1024;  // frames + y/dy + d|X|
     tmp = t > tmp ? t : tmp;
   }
@@ -591,10 +591,36 @@ size_t acoustic_loss_workspace_floats(int B, int N) {
 // went from 37.8 to 69 ms -- more than ~4 concurrently active hardware queues is pathological on this stack,
 // GPU_MAX_HW_QUEUES=2 brought it back to 37.9 ms with no gain left from the extra streams.)
 // losses_out: device [2] (mel, multi_phase); d_pred [B][N] is OVERWRITTEN with d seed / d audio_pred
+__global__ void add_into_kernel(const float* __restrict__ src, size_t n, float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+size_t acoustic_gan_workspace_bytes(int B, int N, int with_grads) {
+  const int res[3][2] = {{512, 128}, {1024, 256}, {2048, 512}};
+  size_t worst = 0;
+  sty_specdisc_params p = {};
+  sty_specdisc_grads g = {};
+  float dummy[2];
+  for (auto& r : res) {
+    size_t need = 0;
+    (void)specdisc_run(&p, B, r[0] / 2 + 1, N / r[1] + 1, 1, 1, dummy, dummy, nullptr, nullptr, 1.f, dummy, dummy, 1.f,
+                       dummy, with_grads ? &g : nullptr, 0, nullptr, 0, nullptr, &need);
+    worst = need > worst ? need : worst;
+  }
+  return worst;
+}
 int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
                          float* losses_out, float* d_pred, float* ws, hipStream_t st) {
+  return launch_acoustic_loss_gan(B, N, audio_gt, audio_pred, w_mel, w_phase, losses_out, d_pred, ws, nullptr, st);
+}
+// gan != nullptr: the generator-side adversarial term of the three spectrogram discriminators is added to the seed
+// (w_gen * d loss / d |X| joins d|X| of the mel term; LossLog.backwards_loss leaves the "generator" loss un-normalised,
+// loss_log.py:84-86), and the discriminator-side losses / parameter gradients are produced from the same forward pass
+int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
+                             float* losses_out, float* d_pred, float* ws, const AcousticGan* gan, hipStream_t st) {
   const int res[3][2] = {{512, 128}, {1024, 256}, {2048, 512}};
   ResBufs rb[3];
+  float* d_gan[3];
   float* p = ws;
   auto take = [&](size_t n) {
     float* q = p;
@@ -618,6 +644,7 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
     rb[r].d_phase = take((size_t)B * F * frames);
     rb[r].p_fft = take((size_t)B * F * frames);
     rb[r].p_y = take((size_t)B * 2 * F * frames);
+    d_gan[r] = take((size_t)B * F * frames);
     hdims[2 * r] = F;
     hdims[2 * r + 1] = frames;
   }
@@ -654,6 +681,13 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
       hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mg, n);
     }
     hipLaunchKernelGGL(loss_sums_kernel, dim3(256), dim3(256), 0, st, rb[r], r, B, sums);
+    if (gan) {  // target |X| (scratch) and predicted |X| are both live here, in the batch-folded layout [F][B][frames]
+      STY_HIP(hipMemsetAsync(d_gan[r], 0, (size_t)B * F * frames * sizeof(float), st));
+      rc = specdisc_run(gan->p[r], B, F, frames, (size_t)frames, (size_t)B * frames, tfft, rb[r].p_fft, nullptr, nullptr,
+                        gan->w_gen, gan->out, d_gan[r], gan->disc_scale, gan->out + 1 + 2 * r, gan->g[r], gan->bf16,
+                        gan->ws, gan->ws_bytes, st, nullptr);
+      if (rc) return rc;
+    }
   }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, sums, dims, B, losses_out);
   // backward
@@ -673,6 +707,8 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
     float* dxt = dy + (size_t)B * 2 * F * frames;        // [B][n_fft][frames]
     rc = dense(t->fbT, rb[r].d_mag, 1, B * frames, dabs, st);
     if (rc) return rc;
+    if (gan)
+      hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((nph + 255) / 256)), dim3(256), 0, st, d_gan[r], nph, dabs);
     hipLaunchKernelGGL(magphase_bwd_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, rb[r].p_y, dabs,
                        rb[r].d_phase, F, frames, (size_t)frames, (size_t)frames, (size_t)B * frames, dy, n_fft / 4);
     const size_t cols = (size_t)B * frames;

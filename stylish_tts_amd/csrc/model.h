@@ -41,6 +41,25 @@ size_t multispec_workspace_floats(int B, int N, int n_fft, int hop);
 size_t acoustic_loss_workspace_floats(int B, int N);
 int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
                          float* losses_out, float* d_pred, float* ws, hipStream_t st);
+// disc.hip: one spectrogram discriminator on target / pred images (element (b, h, w) at b*sb + h*sh + w; 0, 0 = dense),
+// generator- and / or discriminator-side loss + backward (see sty_specdisc_losses); workspace == nullptr: dry run -> *need
+int specdisc_run(const sty_specdisc_params* p, int B, int H, int W, size_t sb, size_t sh, const float* target,
+                 const float* pred, float* scores_t, float* scores_p, float gen_scale, float* gen_loss, float* d_pred,
+                 float disc_scale, float* disc_loss, const sty_specdisc_grads* grads, int compute_bf16, void* workspace,
+                 size_t ws_bytes, hipStream_t st, size_t* need);
+// adversarial term of the acoustic loss: the three spectrogram discriminators on the |STFT| of the three resolutions
+struct AcousticGan {
+  const sty_specdisc_params* p[3] = {nullptr, nullptr, nullptr};
+  const sty_specdisc_grads* g[3] = {nullptr, nullptr, nullptr};  // entries may be null (that discriminator is not stepped)
+  float w_gen = 1.f, disc_scale = 1.f;
+  float* out = nullptr;  // device [7]: generator loss (sum), then (loss, loss without the relativistic term) per resolution
+  int bf16 = 0;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+};
+size_t acoustic_gan_workspace_bytes(int B, int N, int with_grads);
+int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
+                             float* losses_out, float* d_pred, float* ws, const AcousticGan* gan, hipStream_t st);
 int launch_multispec_single(int B, int N, const float* audio, int n_fft, int hop, int sample_rate, float* mag,
                             float* phase, float* fft_mag, float* ws, hipStream_t st);
 

@@ -112,6 +112,9 @@ SYMBOLS = {
     "sty_specdisc_forward": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _P]),
     "sty_specdisc_losses": (C.c_int, [_P, _I, _I, _I, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _I, _P, C.c_size_t,
                                       _P]),
+    "sty_acoustic_gan_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
+    "sty_acoustic_gan_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_float, _P, _I, _P,
+                                                _P, _P, _P, C.c_size_t, _P, C.c_size_t, _I, _P]),
     "sty_prof_enable": (C.c_int, [_I]),
     "sty_prof_only": (C.c_int, [C.c_char_p]),
     "sty_set_single_stream": (C.c_int, [_I]),

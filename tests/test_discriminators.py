@@ -173,3 +173,57 @@ def test_spec_discriminator_bf16_mode():
     t = torch.rand(4, 1, 129, 160, generator=g) ** 2 * 3
     q0 = (t + 0.4 * torch.randn(t.shape, generator=g)).abs()
     _check_against_oracle(m, params, t, q0, dev, 2e-2, 5e-2)
+
+
+@pytest.mark.gpu
+def test_acoustic_loss_with_adversarial_term_composes_the_pinned_pieces():
+    """sty_acoustic_gan_loss_fwd_bwd = the acoustic losses + the "mrd" generator term + the discriminator side, all from
+    one pass.  Checked against the separately pinned pieces: mel / phase losses and their seed (sty_acoustic_loss_fwd_bwd),
+    the three discriminators on MultiSpectrogram's |X| (sty_specdisc_losses), and the oracle's STFT (torch.stft) for the
+    vector-Jacobian product that carries d loss / d |X| back to the waveform."""
+    from oracle import frontend as of
+    from stylish_tts_amd.frontend import MultiSpectrogram
+    from stylish_tts_amd.losses import acoustic_gan_loss, acoustic_loss
+    dev = torch.device("cuda:0")
+    _, params = _fixture()
+    g = torch.Generator().manual_seed(11)
+    mrd = []
+    for r in range(3):
+        p = {k: (v * (1.0 + 0.1 * torch.randn(v.shape, generator=g)) if k.endswith("original1") else v.clone())
+             for k, v in params.items()}
+        mrd.append(_hip_model(p, dev))
+    B, N = 2, 9600
+    gt = 0.3 * torch.randn(B, N, generator=g)
+    pr = gt + 0.1 * torch.randn(B, N, generator=g)
+    gtd, prd = gt.to(dev), pr.to(dev)
+    w_gen, dscale = 0.7, 1.5
+    losses0, d0 = acoustic_loss(gtd, prd, 5.0, 8.0)
+    for m in mrd:
+        for p_ in m.parameters():
+            p_.grad = None
+    losses, gan, d = acoustic_gan_loss(gtd, prd, mrd, w_mel=5.0, w_phase=8.0, w_gen=w_gen, disc_scale=dscale, step=(1,))
+    assert torch.allclose(losses, losses0, rtol=1e-6, atol=0)
+    got_grads = {k: v.grad.clone() for k, v in mrd[1].named_parameters()}
+    assert all(p_.grad is None for p_ in mrd[0].parameters()) and all(p_.grad is None for p_ in mrd[2].parameters())
+    # the pieces
+    _, _, _, _, t_fft, p_fft = MultiSpectrogram()(target=gtd, pred=prd)
+    gen_sum, vjp = 0.0, torch.zeros(B, N)
+    prc = pr.clone().requires_grad_(True)
+    for r, (fft, hop, win) in enumerate(of.RESOLUTIONS):
+        for p_ in mrd[r].parameters():
+            p_.grad = None
+        dx = torch.zeros_like(p_fft[r][:, 0])
+        gen, disc = mrd[r].losses(t_fft[r], p_fft[r], gen_scale=w_gen, d_pred=dx, disc_scale=dscale)
+        gen_sum += gen[0].item()
+        assert abs(gan[1 + 2 * r].item() - disc[0].item()) <= 1e-5 * abs(disc[0].item())
+        assert abs(gan[2 + 2 * r].item() - disc[1].item()) <= 1e-5 * abs(disc[1].item())
+        if r == 1:
+            for k, v in mrd[1].named_parameters():
+                err = (v.grad - got_grads[k]).abs().max().item()
+                assert err <= 1e-4 * max(v.grad.abs().max().item(), 1e-3), (k, err)
+        _, _, fm = of.multi_spectrogram_single(prc, fft, hop, win)
+        vjp += torch.autograd.grad(fm, prc, grad_outputs=dx.cpu().unsqueeze(1))[0]
+    assert abs(gan[0].item() - gen_sum) <= 1e-5 * abs(gen_sum)
+    diff = (d - d0).cpu()
+    err = (diff - vjp).abs().max().item()
+    assert err <= 2e-4 * vjp.abs().max().item() + 1e-6 * d0.abs().max().item(), (err, vjp.abs().max().item())
