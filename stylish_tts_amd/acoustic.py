@@ -54,7 +54,11 @@ def acoustic_forward(speech_predictor, style_encoder, *, audio_gt, texts, text_l
 
 class AcousticTrainer:
     """train_acoustic + optimizer_step (train/stage_type.py:346-373, train/stage.py:104-124) for the two acoustic
-    losses that need no third-party model (mel spectral convergence + multi-phase; GAN / WavLM terms are off):
+    losses that need no third-party model (mel spectral convergence + multi-phase; the WavLM term is off), and -- with
+    `mrd=` three SpecDiscriminator shells -- the adversarial term of the spectrogram discriminators plus the
+    discriminator step of train/stage.py:124-146 (generator_loss "mrd" part, d_loss * sqrt(batch), optimizer step of
+    mrd{disc_index} at lr = generator lr x DiscriminatorLossHelper.get_disc_lr_multiplier(); the waveform
+    discriminator `disc` is not built):
 
         zero_grad -> AcousticStep forward -> LossLog.backwards_loss() seed -> backward through the predictor and the
         style encoder -> gradient mean over ranks -> AdamW step of both models.
@@ -68,7 +72,7 @@ class AcousticTrainer:
 
     def __init__(self, speech_predictor, style_encoder, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4,
                  w_mel=5.0, w_phase=8.0, mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0,
-                 text_dropout=0.2, compute="fp32"):
+                 text_dropout=0.2, compute="fp32", mrd=None, w_gen=1.0):
         import random
         from .optim import FlatAdamW
         self.train_mode = train_mode
@@ -91,6 +95,16 @@ class AcousticTrainer:
         seg = lambda name: 1 if name.startswith("text_encoder.") else 0
         self.opt = {"speech_predictor": FlatAdamW(list(self.sp.named_parameters()), group_of=seg, **kw),
                     "speech_style_encoder": FlatAdamW(list(self.se.named_parameters()), **kw)}
+        self.mrd = list(mrd) if mrd is not None else None
+        self.w_gen = w_gen  # config.yml:76-78 loss_weight.generator
+        if self.mrd is not None:
+            from .discriminators import DiscriminatorLossHelper
+            if len(self.mrd) != 3:
+                raise ValueError("mrd: the three spectrogram discriminators mrd0..2 (models.py:75-77)")
+            for i, m in enumerate(self.mrd):
+                m.compute_bf16 = self.bf16
+                self.opt[f"mrd{i}"] = FlatAdamW(list(m.named_parameters()), **kw)
+            self.disc_helpers = [DiscriminatorLossHelper(m, 5) for m in self.mrd]
         self._hooks = {}
         self._hook_error = None
 
@@ -122,9 +136,10 @@ class AcousticTrainer:
         return self._side
 
     def train_batch(self, *, audio_gt, texts, text_lengths, pitch, durations, noise=None, seed=0,
-                    prior_override=None):
-        """One optimizer step; returns the (mel, multi_phase) loss values as a device tensor [2]."""
-        from .losses import acoustic_loss
+                    prior_override=None, disc_index=None):
+        """One optimizer step; returns the (mel, multi_phase) loss values as a device tensor [2] (with `mrd`: self.gan
+        holds the generator loss and the three discriminator losses of the step, a device tensor [7])."""
+        from .losses import acoustic_gan_loss, acoustic_loss
         for o in self.opt.values():
             o.zero_grad()
         if self.train_mode:
@@ -153,7 +168,15 @@ class AcousticTrainer:
         voiced = (pitch > 20).float()
         audio = self.sp.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, pitch,
                                       noise=noise, seed=seed, prior_override=prior_override, style_stream=side)
-        losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase)
+        if self.mrd is None:
+            losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase)
+        else:
+            # stage.py:116-121: disc_index = random.randrange(3); both sides of the adversarial game from one pass
+            if disc_index is None:
+                disc_index = self._rng.randrange(3)
+            losses, self.gan, d_audio = acoustic_gan_loss(
+                audio_gt, audio.squeeze(1), self.mrd, w_mel=self.w_mel, w_phase=self.w_phase, w_gen=self.w_gen,
+                disc_scale=float(texts.shape[0]) ** 0.5, step=(disc_index,), compute_bf16=self.bf16)
         self._install_grad_hook(self.sp, "speech_predictor")
         self._install_grad_hook(self.se, "speech_style_encoder")
         # the all-reduces are started by the gradient hooks from inside the two backward calls: the predictor's
@@ -173,8 +196,18 @@ class AcousticTrainer:
             raise e
         world = gp.finish(average=False)
         gs.finish(average=False)
-        for o in self.opt.values():
-            o.step(grad_scale=1.0 / world)
+        for key in ("speech_predictor", "speech_style_encoder"):
+            self.opt[key].step(grad_scale=1.0 / world)
+        if self.mrd is not None:
+            # optimizers.py:54-65: discriminator lr = generator lr x multiplier of the tracked discriminator loss
+            od = self.opt[f"mrd{disc_index}"]
+            od.grads.reduce_all()
+            od.grads.finish(average=False)
+            od.lr = self.opt["speech_predictor"].lr * self.disc_helpers[disc_index].get_disc_lr_multiplier()
+            od.step(grad_scale=1.0 / world)
+            plain = self.gan.tolist()  # (one host read per step; the reference's helpers call .item() three times)
+            for r, h in enumerate(self.disc_helpers):
+                h.last_loss = h.last_loss * 0.95 + plain[2 + 2 * r] * 0.05
         self.audio = audio
         return losses
 

@@ -823,6 +823,60 @@ def test_acoustic_train_step_gradients(env):
     rep.done()
 
 
+def test_acoustic_train_step_with_spectrogram_discriminators(env):
+    """train_acoustic + the discriminator step of stage.py:124-146 with the three spectrogram discriminators:
+    the mel / phase losses are those of the plain step; the generator's gradients change by the adversarial term; only
+    mrd{disc_index} is stepped, with lr = generator lr x the helper's multiplier and gradients scaled by sqrt(batch);
+    the helpers' tracked losses follow losses.py:288."""
+    from safetensors.torch import load_file
+    from stylish_tts_amd.acoustic import AcousticTrainer
+    from stylish_tts_amd.discriminators import SpecDiscriminator
+    import stylish_tts_amd as S
+    cs = env["cs"]
+    B, T = cs["pitch"].shape
+    audio_gt = _test_audio(B, 300 * T, 21)
+    fx = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "disc_small.safetensors"))
+    dparams = {k[2:]: v for k, v in fx.items() if k.startswith("w.")}
+    tr0, _, _ = _train_setup(env, 1e-4)
+    kw = dict(audio_gt=dev(audio_gt), texts=dev(cs["texts"]), text_lengths=dev(cs["text_lengths"]), pitch=dev(cs["pitch"]),
+              durations=dev(cs["durations"]), noise=dev(cs["noise"]), seed=5)
+    l0 = tr0.train_batch(**kw).cpu()
+    g0 = {k: p.grad.detach().cpu().clone() for k, p in tr0.sp.named_parameters() if p.grad is not None}
+    mrd = []
+    for r in range(3):
+        m = SpecDiscriminator().to(DEV)
+        m.load_state_dict(dparams)
+        mrd.append(m)
+    P = {k: v.clone() for k, v in env["P"].items()}
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    sp = S.SpeechPredictor()
+    sp.load_state_dict(P, strict=False)
+    se = S.MelStyleEncoder()
+    se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+    tr = AcousticTrainer(sp.to(DEV), se.to(DEV), lr=1e-4, train_mode=False, mrd=mrd, w_gen=1.0)
+    before = [{k: p.detach().cpu().clone() for k, p in m.named_parameters()} for m in mrd]
+    l1 = tr.train_batch(disc_index=2, **kw).cpu()
+    torch.cuda.synchronize()
+    gan = tr.gan.cpu()
+    print(f"\n  generator {gan[0].item():.4f}  discriminator losses {[round(gan[1 + 2 * r].item(), 4) for r in range(3)]}")
+    assert torch.allclose(l0, l1, rtol=1e-5, atol=0)
+    assert torch.isfinite(gan).all() and gan[0].item() > 0
+    g1 = {k: p.grad.detach().cpu().clone() for k, p in tr.sp.named_parameters() if p.grad is not None}
+    k = "generator.basegen.amp_output_conv.weight"
+    assert (g1[k] - g0[k]).abs().max().item() > 1e-6 * g0[k].abs().max().item()  # the adversarial term arrived
+    for r, m in enumerate(mrd):
+        moved = max((p.detach().cpu() - before[r][n]).abs().max().item() for n, p in m.named_parameters())
+        assert (moved > 0) == (r == 2), (r, moved)
+        assert abs(tr.disc_helpers[r].last_loss - (2.5 * 0.95 + gan[2 + 2 * r].item() * 0.05)) <= 1e-5
+    # first AdamW step: |delta| = lr (1 + weight decay shrink) for every element with a non-zero gradient
+    lr_d = 1e-4 * 1.0  # tracked loss == ideal loss before the first step -> multiplier 1 (losses.py:241-256)
+    p2 = dict(mrd[2].named_parameters())["discriminators.1.parametrizations.weight.original1"].detach().cpu()
+    b2 = before[2]["discriminators.1.parametrizations.weight.original1"]
+    step = (p2 - b2 * (1 - lr_d * 1e-4)).abs()
+    assert abs(step.median().item() - lr_d) <= 0.02 * lr_d, step.median().item()
+
+
 def test_acoustic_train_step_bf16_compute_vs_fp32(env):
     """Config c3's compute mode (bf16 operands on the dense convs / Linears, fp32 accumulation) on a whole training
     step, REPORTED against the fp32 step ("bf16 reported, not gated").  The kernels of the mode
