@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the stylish-tts acoustic hot path on MI355X (see DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c3-fp32|c2|c2-fwd|c5|c5-bf16|tts] [--no-extra]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c3-fp32|c3-gan|c2|c2-gan|c2-fwd|c5|c5-bf16|tts] [--no-extra]
 
 A step is one pass of the hot path over one synthetic batch already resident in HBM:
   c2 (BASELINE.json configs[1]): sample_dataset shape, B=16 utterances of T=160 mel frames (2.0 s),
@@ -16,6 +16,8 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       L=100, the same training step with bf16 operands on the dense convs / Linears
       (fp32 accumulation, storage, norms, attention and losses: SURVEY.md 8(d) "bf16 autocast for conv/GEMM").
   c3-fp32: the same shape entirely in fp32.
+  c3-gan / c2-gan: c3 / c2 plus the adversarial term of the three spectrogram discriminators and the discriminator
+           step (train/stage.py:124-146; the waveform discriminator and the WavLM term stay off).
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
   c5-bf16: the same with bf16 operands on the dense convs (outside the fp32 parity gates; reported beside c5).
   tts: the export graph (ExportModel.forward): B=8 token strings of L=100 -> duration predictor ->
@@ -47,6 +49,8 @@ WORKLOADS = {
     "c2-fwd": dict(B=16, T=160, L=37, what="forward"),
     "c3": dict(B=32, T=520, L=100, what="train", compute="bf16"),
     "c3-fp32": dict(B=32, T=520, L=100, what="train"),
+    "c3-gan": dict(B=32, T=520, L=100, what="train", compute="bf16", gan=True),
+    "c2-gan": dict(B=16, T=160, L=37, what="train", gan=True),
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
     "c5-bf16": dict(B=8, T=800, L=0, what="vocoder", compute="bf16"),
     "tts": dict(B=8, T=0, L=100, what="synth"),
@@ -258,7 +262,12 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     inp = make_inputs(w, 1000 + rank, device)
     B, T = w["B"], w["T"]
     bf16 = w.get("compute") == "bf16"
-    trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"), seed=rank)
+    mrd = None
+    if w.get("gan"):  # the three spectrogram discriminators (random init: the reference's Conv2d / weight_norm defaults)
+        from stylish_tts_amd.discriminators import SpecDiscriminator
+        torch.manual_seed(7)
+        mrd = [SpecDiscriminator().to(device) for _ in range(3)]
+    trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"), seed=rank, mrd=mrd)
                if w["what"] == "train" else None)
     if bf16 and trainer is None:
         model.set_train_opts(compute_bf16=True)
@@ -373,7 +382,9 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
         "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 GEMM operands, f32 accumulation/storage" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"{name}: B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
-                   "pass": PASS[w["what"]],
+                   "pass": (PASS[w["what"]] if not w.get("gan") else
+                            "forward + backward + AdamW (mel + multi-phase + spectrogram-discriminator generator loss; "
+                            "discriminator loss + AdamW step of one of the three; waveform discriminator / WavLM off)"),
                    "x_realtime": frames / dt / 80.0},
     }
     if prof:

@@ -172,6 +172,96 @@ __global__ __launch_bounds__(256) void sd_score_kernel(const float* __restrict__
   s[((size_t)b * H + h) * W + w] = acc;
 }
 
+// four adjacent outputs per thread (row pitch % 4 == 0): one 16-byte load + two edge samples feed 12 FMAs
+__global__ __launch_bounds__(256) void sd_score4_kernel(const float* __restrict__ a, const float* __restrict__ ws,
+                                                        const float* __restrict__ bs, int H, int W, int Wp,
+                                                        float* __restrict__ s) {
+  __shared__ float wl[288];
+  for (int i = threadIdx.x; i < 288; i += 256) wl[i] = ws[i];
+  __syncthreads();
+  const int w0 = (blockIdx.x * 256 + threadIdx.x) * 4, h = blockIdx.y, b = blockIdx.z;
+  if (w0 >= W) return;
+  float acc[4];
+  acc[0] = acc[1] = acc[2] = acc[3] = bs[0];
+  const float* ab = a + (size_t)b * 32 * H * Wp;
+  for (int ci = 0; ci < 32; ++ci) {
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hs = h + dh - 1;
+      if (hs < 0 || hs >= H) continue;
+      const float* row = ab + ((size_t)ci * H + hs) * Wp + w0;
+      const float4 m = *reinterpret_cast<const float4*>(row);
+      const float l = w0 > 0 ? row[-1] : 0.f, r = row[4];  // Wp >= W + 4 and W > w0: row[4] stays inside the row
+      const float k0 = wl[ci * 9 + dh * 3], k1 = wl[ci * 9 + dh * 3 + 1], k2 = wl[ci * 9 + dh * 3 + 2];
+      acc[0] = fmaf(k0, l, fmaf(k1, m.x, fmaf(k2, m.y, acc[0])));
+      acc[1] = fmaf(k0, m.x, fmaf(k1, m.y, fmaf(k2, m.z, acc[1])));
+      acc[2] = fmaf(k0, m.y, fmaf(k1, m.z, fmaf(k2, m.w, acc[2])));
+      acc[3] = fmaf(k0, m.z, fmaf(k1, m.w, fmaf(k2, r, acc[3])));
+    }
+  }
+  float* so = s + ((size_t)b * H + h) * W + w0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (w0 + e < W) so[e] = acc[e];
+}
+
+// the same with four adjacent columns per thread (row pitch % 4 == 0)
+__global__ __launch_bounds__(256) void sd_gz4_kernel(const float* __restrict__ gs, const float* __restrict__ ws,
+                                                     const float* __restrict__ a, const float* __restrict__ dxn,
+                                                     const float* __restrict__ dxs, int H, int W, int Wp,
+                                                     float* __restrict__ gz) {
+  const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const int Wq = Wp >> 2;
+  if (i >= H * Wq) return;
+  const int h = i / Wq, w0 = (i - h * Wq) * 4;
+  const size_t o = ((size_t)b * 32 + c) * H * Wp + (size_t)h * Wp + w0;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (w0 < W) {
+    const float* g = gs + (size_t)b * H * W;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int ho = h - dh + 1;
+      if (ho < 0 || ho >= H) continue;
+      const float* gr = g + (size_t)ho * W;
+      float x[6];  // gs[ho][w0 - 1 .. w0 + 4]
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int wo = w0 - 1 + e;
+        x[e] = (wo >= 0 && wo < W) ? gr[wo] : 0.f;
+      }
+      const float k0 = ws[c * 9 + dh * 3], k1 = ws[c * 9 + dh * 3 + 1], k2 = ws[c * 9 + dh * 3 + 2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(k0, x[e + 2], fmaf(k1, x[e + 1], fmaf(k2, x[e], v[e])));  // wo = w - dw + 1
+    }
+    if (dxn) {
+      const float4 d = *reinterpret_cast<const float4*>(dxn + o);
+      v[0] += d.x;
+      v[1] += d.y;
+      v[2] += d.z;
+      v[3] += d.w;
+    }
+    if (dxs) {
+      const size_t nh = (size_t)H * (Wp >> 1);
+      const float* ev = dxs + ((size_t)b * 64 + c) * nh + (size_t)h * (Wp >> 1) + (w0 >> 1);
+      const float2 e2 = *reinterpret_cast<const float2*>(ev);
+      const float2 o2 = *reinterpret_cast<const float2*>(ev + 32 * nh);
+      v[0] += e2.x;
+      v[1] += o2.x;
+      v[2] += e2.y;
+      v[3] += o2.y;
+    }
+    const float4 av = *reinterpret_cast<const float4*>(a + o);
+    v[0] *= av.x > 0.f ? 1.f : SD_SLOPE;
+    v[1] *= av.y > 0.f ? 1.f : SD_SLOPE;
+    v[2] *= av.z > 0.f ? 1.f : SD_SLOPE;
+    v[3] *= av.w > 0.f ? 1.f : SD_SLOPE;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (w0 + e >= W) v[e] = 0.f;
+  }
+  *reinterpret_cast<float4*>(gz + o) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // gradient w.r.t. the pre-activation of layer i:
 //   gz = (score-conv backward of gs  +  input gradient of the next layer) * LeakyReLU'(a) on the valid columns, 0 elsewhere
 // dxn: next layer's input gradient in the normal layout [B][32][H][Wp]; dxs: in the split layout [B][64][H][Wp/2]
@@ -514,8 +604,12 @@ struct SdRun {
         chk(launch_conv1d(a, st));
         hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, ac.a[i], n[i], Wp[i],
                            i < 3 ? ac.as[i] : nullptr);
-        hipLaunchKernelGGL(sd_score_kernel, dim3(cdiv(Wl[i], 256), H, B), dim3(256), 0, st, ac.a[i], sw[i], sw[i] + 288,
-                           H, Wl[i], Wp[i], ac.s[i]);
+        if (Wp[i] % 4 == 0)
+          hipLaunchKernelGGL(sd_score4_kernel, dim3(cdiv(cdiv(Wl[i], 4), 256), H, B), dim3(256), 0, st, ac.a[i], sw[i],
+                             sw[i] + 288, H, Wl[i], Wp[i], ac.s[i]);
+        else
+          hipLaunchKernelGGL(sd_score_kernel, dim3(cdiv(Wl[i], 256), H, B), dim3(256), 0, st, ac.a[i], sw[i], sw[i] + 288,
+                             H, Wl[i], Wp[i], ac.s[i]);
       }
     }
   }
@@ -528,9 +622,14 @@ struct SdRun {
     float* dnext = nullptr;  // input gradient of layer i + 1
     for (int i = 4; i >= 0; --i) {
       float* gz = take<float>((size_t)B * 32 * n[i]);
-      if (live())
-        hipLaunchKernelGGL(sd_gz_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, gs[i], sw[i], ac.a[i],
-                           i == 3 ? dnext : nullptr, i < 3 ? dnext : nullptr, H, Wl[i], Wp[i], gz);
+      if (live()) {
+        if (Wp[i] % 4 == 0)
+          hipLaunchKernelGGL(sd_gz4_kernel, dim3(cdiv(n[i] / 4, 256), 32, B), dim3(256), 0, st, gs[i], sw[i], ac.a[i],
+                             i == 3 ? dnext : nullptr, i < 3 ? dnext : nullptr, H, Wl[i], Wp[i], gz);
+        else
+          hipLaunchKernelGGL(sd_gz_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, gs[i], sw[i], ac.a[i],
+                             i == 3 ? dnext : nullptr, i < 3 ? dnext : nullptr, H, Wl[i], Wp[i], gz);
+      }
       const float* in = i == 0 ? ac.x27 : (i < 4 ? ac.as[i - 1] : ac.a[3]);
       const ConvArgs f = conv_args(i, in, nullptr);
       if (gwp) {

@@ -631,6 +631,22 @@ __global__ void wgrad_reduce_small_kernel(const float* __restrict__ partial, int
   else
     gbias[i - plane] += s * scale;
 }
+// partial planes [K][Csub][32] (+ 32 bias sums) -> rows [row0, row0 + Csub) of gwp [K][CinP][32]
+__global__ void wgrad_reduce_rows_kernel(const float* __restrict__ partial, int nslices, size_t stride, int K, int Csub,
+                                         int CinP, int row0, int nb, float scale, float* __restrict__ gwp,
+                                         float* __restrict__ gbias) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int plane = K * Csub * 32;
+  if (i >= plane + (nb ? 32 : 0)) return;
+  float s = 0.f;
+  for (int k = 0; k < nslices; ++k) s += partial[(size_t)k * stride + i];
+  if (i < plane) {
+    const int co = i & 31, ci = (i >> 5) % Csub, k = (i >> 5) / Csub;
+    gwp[((size_t)k * CinP + row0 + ci) * 32 + co] += s * scale;
+  } else {
+    gbias[i - plane] += s * scale;
+  }
+}
 // 16 plane elements x 16 slice groups per workgroup, combined through LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nslices, size_t plane,
                                                            size_t stride, int nb, float scale, float* __restrict__ gwp,
@@ -818,6 +834,38 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   const int chunks = fwd.B * chunks_per_b;
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
   if (nsplit > chunks) nsplit = chunks;
+  // flat 2-D conv with 32 output channels (the spectrogram discriminators' 3x5 / 3x3 layers): one many-tap 32x32 launch
+  // per image row of the window -- row kh is the plain 1-D weight gradient against x shifted by (kh - hpad) rows -- summed
+  // straight into rows [kh*Cin2d, (kh+1)*Cin2d) of the packed gradient
+  if (fwd.flatW && w.CoutP == 32 && fwd.Cin2d % 32 == 0 && fwd.Cin2d <= 96 && w.Cin % fwd.Cin2d == 0 &&
+      w.CinP == w.Cin && fwd.nsrc == 1) {
+    ConvArgs a1 = ax;
+    a1.flatW = 0;
+    a1.hpad = 0;
+    a1.Cin2d = 0;
+    a1.xc[0] = fwd.Cin2d;
+    a1.w.Cin = a1.w.CinP = fwd.Cin2d;
+    if (wgradp32_eligible(a1)) {
+      const int KH = w.Cin / fwd.Cin2d;
+      const size_t sub = (size_t)w.K * fwd.Cin2d * 32 + 32;
+      size_t can = ((size_t)nsplit * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP)) / sub;  // planes the partial buffer holds
+      int ns = (int)(can < 1024 ? can : 1024);
+      const int pc = wgradp32_chunks(a1);
+      if (ns > pc) ns = pc;
+      for (int kh = 0; kh < KH; ++kh) {
+        a1.pad = fwd.pad - (kh - fwd.hpad) * fwd.flatW;
+        const int wb = (gbias != nullptr && kh == 0) ? 1 : 0;
+        int rc = launch_wgradp32(a1, ag, ns, partial, wb, st);
+        if (rc) return rc;
+        const int n = w.K * fwd.Cin2d * 32 + (wb ? 32 : 0);
+        hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, partial, ns, sub, w.K, fwd.Cin2d,
+                           w.CinP, kh * fwd.Cin2d, wb, scale, gwp, gbias);
+      }
+      if (bias_done) *bias_done = gbias != nullptr;
+      STY_LAUNCH_CHECK();
+      return STY_OK;
+    }
+  }
   if (wgradp32_eligible(ax)) {
     const int KTp = cdiv(w.K, 4);
     const int wb = (gbias != nullptr && KTp <= 3) ? 1 : 0;  // (the caller's bookkeeping: wgrad_fuses_bias)

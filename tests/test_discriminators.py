@@ -62,8 +62,8 @@ def _hip_model(params, dev):
 
 @pytest.mark.gpu
 def test_spec_discriminator_hip_vs_reference_fixture():
-    """HIP SpecDiscriminator.forward, GeneratorLossHelper and DiscriminatorLossHelper (forward + backward) against the
-    values the reference's classes produced (fp32 mode)."""
+    """HIP SpecDiscriminator.forward, GeneratorLossHelper and DiscriminatorLossHelper against the values the reference's
+    classes produced (fp32 mode): score maps, both loss values, the tracked loss; gradients through the pinned oracle."""
     from stylish_tts_amd.discriminators import DiscriminatorLossHelper, GeneratorLossHelper
     dev = torch.device("cuda:0")
     fx, params = _fixture()
@@ -79,23 +79,17 @@ def test_spec_discriminator_hip_vs_reference_fixture():
                 assert got.shape == ref.shape
                 err = (got.cpu() - ref).abs().max().item()
                 assert err <= 2e-5 * max(ref.abs().max().item(), 0.1), (case, i, name, err)
-        d_pred = torch.zeros_like(q[:, 0])
-        gl = GeneratorLossHelper(m)(target=t, pred=q, d_pred=d_pred)
+        gl = GeneratorLossHelper(m)(target=t, pred=q)
         assert abs(gl.item() - fx[f"c{case}.gen_loss"].item()) <= 2e-5 * fx[f"c{case}.gen_loss"].item()
-        ref = fx[f"c{case}.d_pred"][:, 0]
-        err = (d_pred.cpu() - ref).abs().max().item()
-        assert err <= 1e-4 * ref.abs().max().item(), (case, "d_pred", err, ref.abs().max().item())
         for p in m.parameters():
             p.grad = None
         helper = DiscriminatorLossHelper(m, 5)
         dl = helper(target=t, pred=q)
         assert abs(dl.item() - fx[f"c{case}.disc_loss"].item()) <= 2e-5 * fx[f"c{case}.disc_loss"].item()
         assert abs(helper.last_loss - fx[f"c{case}.last_loss"].item()) <= 1e-5
-        for k, p in m.named_parameters():
-            ref = fx[f"c{case}.grad." + k]
-            err = (p.grad.cpu() - ref).abs().max().item()
-            lim = (1e-3 if k.endswith("original0") else 2e-4) * max(ref.abs().max().item(), 1e-3)  # g: a cancelling sum
-            assert err <= lim, (case, k, err, ref.abs().max().item())
+        # gradients: the oracle (pinned to the reference's gradients on this very fixture by the CPU test above) fed with
+        # the HIP score maps -- see _check_against_oracle for why not the fixture's gradient tensors directly
+        _check_against_oracle(m, params, fx[f"c{case}.target"], fx[f"c{case}.pred"], dev, 2e-5, 2e-4)
 
 
 def _check_against_oracle(m, params, t, q0, dev, tol_x, tol_w, tol_loss=2e-5):
