@@ -72,3 +72,38 @@ def mrd_generator_loss(params_list, target_list, pred_list):
 def mrd_discriminator_loss(params_list, target_list, pred_list):
     return sum(discriminator_loss_helper(spec_discriminator(p, t), spec_discriminator(p, q))
                for p, t, q in zip(params_list, target_list, pred_list))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ContextFreeDiscriminator (train/models/discriminator.py:91-177): the waveform discriminator `disc` of the acoustic stage.
+# Windows of 1024 samples every 512; four strided Conv1d + BatchNorm1d + GELU blocks (1 -> 64 -> 128 -> 256 -> 256,
+# k 11/11/7/5, stride 4/4/2/2, no conv bias), a sigmoid channel gate from the window mean, a temporal branch (grouped
+# k7, k3) and a spectral branch (grouped 1x1, 256 -> 768 -> 256), their concatenation fused by a 1x1 block, then
+# Conv1d(256, 512, 1) + ReLU + Conv1d(512, 1, 1).  BatchNorm in training mode (batch statistics over windows x positions).
+# Parameters: flat dict with the reference's state_dict keys.  (The `last` convs read 256 channels: dim * 2 * 2.)
+# ---------------------------------------------------------------------------------------------------------------------
+CF_BLOCKS = (("conv.0", 1, 4, 1), ("conv.1", 1, 4, 1), ("conv.2", 1, 2, 1), ("conv.3", 1, 2, 1))
+
+
+def _cf_block(p, name, x, stride=1, groups=1, eps=1e-5):
+    w = p[name + ".net.0.weight"]
+    y = F.conv1d(x, w, p.get(name + ".net.0.bias"), stride=stride, padding=w.shape[2] // 2, groups=groups)
+    y = F.batch_norm(y, None, None, p[name + ".net.1.weight"], p[name + ".net.1.bias"], training=True, eps=eps)
+    return F.gelu(y)
+
+
+def context_free_discriminator(p, x):
+    """x [B, N] -> [B, n] (one score per window and position), the single element of the module's result list."""
+    B = x.shape[0]
+    x = x.unfold(1, 1024, 512)
+    t = x.shape[1]
+    x = x.reshape(B * t, 1, 1024)
+    for name, _, stride, _ in CF_BLOCKS:
+        x = _cf_block(p, name, x, stride=stride)
+    gate = torch.sigmoid(F.conv1d(x.mean(dim=2, keepdim=True), p["attn.1.weight"], p["attn.1.bias"]))
+    x = x * gate
+    tm = _cf_block(p, "temporal.1", _cf_block(p, "temporal.0", x, groups=8), groups=8)
+    sp = _cf_block(p, "spectral.1", _cf_block(p, "spectral.0", x, groups=8), groups=8)
+    x = _cf_block(p, "fusion", torch.cat([tm, sp], dim=1))
+    x = F.conv1d(F.relu(F.conv1d(x, p["last.0.weight"], p["last.0.bias"])), p["last.2.weight"], p["last.2.bias"])
+    return x.reshape(B, -1)

@@ -30,6 +30,12 @@ python bench.py > $O/${tag}_bench_default.json 2> $O/bench_default.err
 python bench.py --workload c5-bf16 --steps 50 --warmup 10 --no-cpu-baseline --no-extra > $O/${tag}_bench_c5_bf16.json 2>/dev/null
 python bench.py --workload c2-fwd --no-cpu-baseline --no-extra > $O/${tag}_bench_c2_fwd.json 2>/dev/null
 python bench.py --workload tts --steps 20 --warmup 5 --no-extra > $O/${tag}_bench_tts.json 2>/dev/null
+# the acoustic step with the adversarial term of the three spectrogram discriminators (c3-gan / c2-gan)
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $O/c3gan_trace -- $B --workload c3-gan --steps 3 --warmup 1 > $O/${tag}_bench_c3_gan_under_rocprof.json 2> $O/c3gan_trace.log )
+python tools/rocpd_summary.py $O/c3gan_trace/*/*_results.db > $O/${tag}_c3_gan_kernel_stats.txt
+rm -rf $O/c3gan_trace
+python bench.py --workload c3-gan --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/${tag}_bench_c3_gan.json 2>/dev/null
+python bench.py --workload c2-gan --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/${tag}_bench_c2_gan.json 2>/dev/null
 python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
 rm -rf $O/c3_trace $O/c5_trace $O/c2_trace $O/c3_fetch/*/*agent_info.csv $O/c5_fetch/*/*agent_info.csv
