@@ -306,6 +306,33 @@ int sty_specdisc_losses(const sty_specdisc_params *p, int B, int H, int W, const
                         const sty_specdisc_grads *grads, int compute_bf16, void *workspace, size_t ws_bytes,
                         void *stream);
 
+/* ContextFreeDiscriminator (train/models/discriminator.py:91-177), the waveform discriminator `disc`, in training mode
+ * (BatchNorm batch statistics; running_mean / running_var are updated in place with `bn_momentum` on every forward).
+ * conv index: 0-3 `conv.i.net.0`, 4-5 `temporal.i.net.0`, 6-7 `spectral.i.net.0`, 8 `fusion.net.0`, 9 `attn.1`, 10 `last.0`,
+ * 11 `last.2` (conv_b NULL for 0-3: bias=False); bn index 0-8: the `.net.1` BatchNorm1d of the same nine blocks.          */
+typedef struct {
+  const float *conv_w[12];
+  const float *conv_b[12];
+  const float *bn_w[9];
+  const float *bn_b[9];
+  float *bn_rm[9];
+  float *bn_rv[9];
+} sty_cfdisc_params;
+typedef struct { /* gradients, same shapes; the calls ADD into them */
+  float *conv_w[12];
+  float *conv_b[12];
+  float *bn_w[9];
+  float *bn_b[9];
+} sty_cfdisc_grads;
+/* x [B,N] (N >= 1024) -> scores [B, t*16], t = (N - 1024) / 512 + 1 windows ("b (t c f)" of the module's forward).     */
+int sty_cfdisc_workspace_bytes(int B, int N, int with_grads, size_t *bytes);
+int sty_cfdisc_forward(const sty_cfdisc_params *p, int B, int N, const float *x, float *scores, float bn_momentum,
+                       int compute_bf16, void *workspace, size_t ws_bytes, void *stream);
+/* Both loss helpers on (target, pred) [B,N] from one forward pass of each, as sty_specdisc_losses.                     */
+int sty_cfdisc_losses(const sty_cfdisc_params *p, int B, int N, const float *target, const float *pred, float gen_scale,
+                      float *gen_loss, float *d_pred, float disc_scale, float *disc_loss, const sty_cfdisc_grads *grads,
+                      float bn_momentum, int compute_bf16, void *workspace, size_t ws_bytes, void *stream);
+
 /* The acoustic losses WITH the adversarial term of the three spectrogram discriminators (AcousticStep.generator_loss,
  * train/stage_type.py:208-220, "mrd" part of GeneratorLoss / DiscriminatorLoss, train/losses.py:191-208, 313-327; the
  * waveform discriminator `disc` is not built): as sty_acoustic_loss_fwd_bwd, plus

@@ -192,3 +192,131 @@ class MrdLosses:
             gen_total = gen[0] if gen_total is None else gen_total + gen[0]
             disc_total = disc[0] if disc_total is None else disc_total + disc[0]
         return gen_total, disc_total
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ContextFreeDiscriminator (models/discriminator.py:91-177): the waveform discriminator `disc`
+# ---------------------------------------------------------------------------------------------------------------------
+_CF_BLOCKS = [("conv.0", 1, 64, 11, 1, False), ("conv.1", 64, 128, 11, 1, False), ("conv.2", 128, 256, 7, 1, False),
+              ("conv.3", 256, 256, 5, 1, False), ("temporal.0", 256, 256, 7, 8, True), ("temporal.1", 256, 256, 3, 8, True),
+              ("spectral.0", 256, 768, 1, 8, True), ("spectral.1", 768, 256, 1, 8, True), ("fusion", 512, 256, 1, 1, True)]
+_CF_CONVS = [(n + ".net.0", b) for n, _, _, _, _, b in _CF_BLOCKS] + [("attn.1", True), ("last.0", True), ("last.2", True)]
+
+
+def context_free_discriminator_manifest():
+    m = {}
+    for name, cin, cout, k, groups, bias in _CF_BLOCKS:
+        m[f"{name}.net.0.weight"] = [cout, cin // groups, k]
+        if bias:
+            m[f"{name}.net.0.bias"] = [cout]
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            m[f"{name}.net.1.{leaf}"] = [cout]
+        m[f"{name}.net.1.num_batches_tracked"] = []
+    for name, cin, cout in (("attn.1", 256, 256), ("last.0", 256, 512), ("last.2", 512, 1)):
+        m[f"{name}.weight"] = [cout, cin, 1]
+        m[f"{name}.bias"] = [cout]
+    return m
+
+
+class ContextFreeDiscriminator(torch.nn.Module):
+    """forward(x [B, N]) -> ([scores [B, t*16]], []) in training mode (BatchNorm batch statistics, running buffers updated),
+    as the reference runs it inside both loss helpers."""
+
+    def __init__(self):
+        super().__init__()
+        for key, shape in context_free_discriminator_manifest().items():
+            leaf = key.rsplit(".", 1)[-1]
+            if leaf == "num_batches_tracked":
+                t = torch.zeros((), dtype=torch.int64)
+            elif len(shape) == 3:
+                fan_in = shape[1] * shape[2]
+                t = (torch.rand(shape) * 2 - 1) / math.sqrt(fan_in)
+            elif leaf in ("running_var",) or (leaf == "weight" and ".net.1." in key):
+                t = torch.ones(shape)
+            elif leaf == "bias" and ".net.1." not in key:
+                w = dict(self.named_parameters())[key[:-4] + "weight"]
+                t = (torch.rand(shape) * 2 - 1) / math.sqrt(w.shape[1] * w.shape[2])
+            else:
+                t = torch.zeros(shape)
+            _register(self, key, t, leaf in ("running_mean", "running_var", "num_batches_tracked"))
+        self.compute_bf16 = False
+        self.bn_momentum = 0.1
+        self._ws = None
+
+    def _tables(self, grads=False):
+        sd = dict(self.named_parameters())
+        bufs = dict(self.named_buffers())
+        st = L.CfDiscGrads() if grads else L.CfDiscParams()
+
+        def addr(key):
+            p = sd[key]
+            if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
+                raise L.StyError(f"ContextFreeDiscriminator: {key} must be contiguous fp32 on a HIP device; there is no CPU path")
+            if grads:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                return p.grad.data_ptr()
+            return p.data_ptr()
+
+        for i, (name, has_bias) in enumerate(_CF_CONVS):
+            st.conv_w[i] = addr(name + ".weight")
+            st.conv_b[i] = addr(name + ".bias") if has_bias else None
+        for i, (name, *_rest) in enumerate(_CF_BLOCKS):
+            st.bn_w[i] = addr(f"{name}.net.1.weight")
+            st.bn_b[i] = addr(f"{name}.net.1.bias")
+            if not grads:
+                st.bn_rm[i] = bufs[f"{name}.net.1.running_mean"].data_ptr()
+                st.bn_rv[i] = bufs[f"{name}.net.1.running_var"].data_ptr()
+        return st
+
+    def _workspace(self, B, N, with_grads, device):
+        lib = L.load()
+        need = C.c_size_t()
+        L.check(lib.sty_cfdisc_workspace_bytes(B, N, int(with_grads), C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _tracked(self, n):
+        for k, b in self.named_buffers():
+            if k.endswith("num_batches_tracked"):
+                b += n
+
+    @staticmethod
+    def _wave(x):
+        if x.device.type != "cuda":
+            raise L.StyError("ContextFreeDiscriminator: inputs must live on a HIP device; there is no CPU path")
+        return x.detach().contiguous().float()
+
+    def forward(self, x):
+        lib = L.load()
+        x = self._wave(x)
+        B, N = x.shape
+        t = (N - 1024) // 512 + 1
+        ws = self._workspace(B, N, False, x.device)
+        scores = torch.empty(B, t * 16, device=x.device)
+        st = self._tables()
+        L.check(lib.sty_cfdisc_forward(C.byref(st), B, N, L.ptr(x), L.ptr(scores), float(self.bn_momentum),
+                                       int(self.compute_bf16), L.ptr(ws), ws.numel(),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._tracked(1)
+        return [scores], []
+
+    def losses(self, target, pred, *, gen_scale=None, d_pred=None, disc_scale=None, bn_momentum=None):
+        """As SpecDiscriminator.losses, on waveforms [B, N]; d_pred [B, N]."""
+        lib = L.load()
+        t, p = self._wave(target), self._wave(pred)
+        B, N = t.shape
+        ws = self._workspace(B, N, disc_scale is not None, t.device)
+        gen = torch.zeros(1, device=t.device) if gen_scale is not None else None
+        disc = torch.zeros(2, device=t.device) if disc_scale is not None else None
+        st = self._tables()
+        gr = self._tables(grads=True) if disc_scale is not None else None
+        L.check(lib.sty_cfdisc_losses(C.byref(st), B, N, L.ptr(t), L.ptr(p), float(gen_scale or 0.0), L.ptr(gen),
+                                      L.ptr(d_pred) if gen_scale is not None else None, float(disc_scale or 0.0), L.ptr(disc),
+                                      C.byref(gr) if gr is not None else None,
+                                      float(self.bn_momentum if bn_momentum is None else bn_momentum),
+                                      int(self.compute_bf16), L.ptr(ws), ws.numel(),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._tracked(2)
+        return gen, disc

@@ -46,6 +46,17 @@ class SpecDiscPtrs(C.Structure):
     _fields_ = [("g", C.c_void_p * 10), ("v", C.c_void_p * 10), ("bias", C.c_void_p * 10)]
 
 
+class CfDiscParams(C.Structure):
+    """sty_cfdisc_params"""
+    _fields_ = [("conv_w", C.c_void_p * 12), ("conv_b", C.c_void_p * 12), ("bn_w", C.c_void_p * 9), ("bn_b", C.c_void_p * 9),
+                ("bn_rm", C.c_void_p * 9), ("bn_rv", C.c_void_p * 9)]
+
+
+class CfDiscGrads(C.Structure):
+    """sty_cfdisc_grads"""
+    _fields_ = [("conv_w", C.c_void_p * 12), ("conv_b", C.c_void_p * 12), ("bn_w", C.c_void_p * 9), ("bn_b", C.c_void_p * 9)]
+
+
 # every symbol include/stylish_hip.h declares: name -> (restype, argtypes)
 _P, _I, _SZP = C.c_void_p, C.c_int, C.POINTER(C.c_size_t)
 SYMBOLS = {
@@ -112,6 +123,10 @@ SYMBOLS = {
     "sty_specdisc_forward": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _P]),
     "sty_specdisc_losses": (C.c_int, [_P, _I, _I, _I, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _I, _P, C.c_size_t,
                                       _P]),
+    "sty_cfdisc_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
+    "sty_cfdisc_forward": (C.c_int, [_P, _I, _I, _P, _P, C.c_float, _I, _P, C.c_size_t, _P]),
+    "sty_cfdisc_losses": (C.c_int, [_P, _I, _I, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, C.c_float, _I, _P,
+                                    C.c_size_t, _P]),
     "sty_acoustic_gan_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
     "sty_acoustic_gan_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_float, _P, _I, _P,
                                                 _P, _P, _P, C.c_size_t, _P, C.c_size_t, _I, _P]),

@@ -221,3 +221,113 @@ def test_acoustic_loss_with_adversarial_term_composes_the_pinned_pieces():
     diff = (d - d0).cpu()
     err = (diff - vjp).abs().max().item()
     assert err <= 2e-4 * vjp.abs().max().item() + 1e-6 * d0.abs().max().item(), (err, vjp.abs().max().item())
+
+
+def _cf_fixture():
+    fx = load_file(os.path.join(G, "cfdisc_small.safetensors"))
+    params = {k[2:]: v for k, v in fx.items() if k.startswith("w.")}
+    return fx, params
+
+
+def test_context_free_discriminator_oracle_and_manifest_match_reference():
+    """oracle.context_free_discriminator vs the reference's ContextFreeDiscriminator in training mode: score maps, both
+    helpers' losses and gradients; the shell's key table equals the reference state_dict."""
+    from oracle import discriminator as od
+    from stylish_tts_amd.discriminators import context_free_discriminator_manifest
+    with open(os.path.join(G, "manifest_context_free_discriminator.json")) as f:
+        assert context_free_discriminator_manifest() == json.load(f)
+    fx, p = _cf_fixture()
+    t, q = fx["target"], fx["pred"].clone().requires_grad_(True)
+    rs, gs = od.context_free_discriminator(p, t), od.context_free_discriminator(p, q)
+    assert (rs - fx["real_score"]).abs().max().item() <= 1e-6 and (gs - fx["gen_score"]).abs().max().item() <= 1e-6
+    gl = od.generator_loss_helper([rs], [gs])
+    gl.backward()
+    assert abs(gl.item() - fx["gen_loss"].item()) <= 1e-6
+    assert (q.grad - fx["d_pred"]).abs().max().item() <= 1e-5 * fx["d_pred"].abs().max().item()
+    pp = {k: (v.clone().requires_grad_(True) if ("grad." + k) in fx else v) for k, v in p.items()}
+    dl = od.discriminator_loss_helper([od.context_free_discriminator(pp, t)], [od.context_free_discriminator(pp, fx["pred"])])
+    dl.backward()
+    assert abs(dl.item() - fx["disc_loss"].item()) <= 1e-6
+    for k in pp:
+        if ("grad." + k) in fx:
+            ref = fx["grad." + k]
+            assert (pp[k].grad - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-4), k
+
+
+def _cf_model(params, dev):
+    from stylish_tts_amd.discriminators import ContextFreeDiscriminator
+    m = ContextFreeDiscriminator()
+    m.load_state_dict(params, strict=True)
+    return m.to(dev)
+
+
+def _cf_check(m, params, t, q0, dev, tol_x, tol_w):
+    """same two-part scheme as _check_against_oracle (the relativistic term's median spike)"""
+    from oracle import discriminator as od
+    B, N = t.shape
+    td, qd = t.to(dev), q0.to(dev)
+    rs_h = m(td)[0][0].cpu().clone().requires_grad_(True)
+    gs_h = m(qd)[0][0].cpu().clone().requires_grad_(True)
+    gl = od.generator_loss_helper([rs_h], [gs_h])
+    g_gen, = torch.autograd.grad(gl, gs_h)
+    dl = od.discriminator_loss_helper([rs_h], [gs_h])
+    g_dr, = torch.autograd.grad(dl, rs_h, retain_graph=True)
+    g_dg, = torch.autograd.grad(dl, gs_h)
+    q = q0.clone().requires_grad_(True)
+    keys = sorted(k for k, v in params.items() if v.is_floating_point() and "running" not in k)
+    pp = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in params.items()}
+    so_t, so_q = od.context_free_discriminator(pp, t), od.context_free_discriminator(pp, q)
+    for a_, b_ in ((so_t, rs_h), (so_q, gs_h)):
+        assert (a_ - b_).abs().max().item() <= tol_x * max(a_.abs().max().item(), 0.1), (a_ - b_).abs().max().item()
+    dq, = torch.autograd.grad(so_q, q, grad_outputs=g_gen, retain_graph=True)
+    dw = torch.autograd.grad([so_t, so_q], [pp[k] for k in keys], grad_outputs=[g_dr, g_dg])
+    for p_ in m.parameters():
+        p_.grad = None
+    d_pred = torch.zeros(B, N, device=dev)
+    gen, disc = m.losses(td, qd, gen_scale=2.0, d_pred=d_pred, disc_scale=3.0)
+    assert abs(gen[0].item() - gl.item()) <= 5e-5 * gl.item(), (gen[0].item(), gl.item())
+    assert abs(disc[0].item() - dl.item()) <= 5e-5 * dl.item(), (disc[0].item(), dl.item())
+    err = (d_pred.cpu() - 2.0 * dq).abs().max().item()
+    assert err <= tol_w * 2.0 * dq.abs().max().item(), ("d_pred", err, dq.abs().max().item())
+    got = dict(m.named_parameters())
+    for k, ref in zip(keys, dw):
+        ref = 3.0 * ref
+        err = (got[k].grad.cpu() - ref).abs().max().item()
+        assert err <= tol_w * max(ref.abs().max().item(), 1e-3), (k, err, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_context_free_discriminator_hip_vs_reference_fixture():
+    """HIP ContextFreeDiscriminator (training mode) against the reference's values: score maps, both loss values, BatchNorm
+    running statistics after two forwards; gradients through the pinned oracle."""
+    dev = torch.device("cuda:0")
+    fx, params = _cf_fixture()
+    m = _cf_model(params, dev)
+    t, q = fx["target"], fx["pred"]
+    rs = m(t.to(dev))[0][0].cpu()
+    gs = m(q.to(dev))[0][0].cpu()
+    for got, ref in ((rs, fx["real_score"]), (gs, fx["gen_score"])):
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 0.1), (got - ref).abs().max().item()
+    sd = m.state_dict()
+    for k, ref in fx.items():
+        if k.startswith("after2."):
+            got = sd[k[7:]].cpu()
+            assert (got.float() - ref.float()).abs().max().item() <= 1e-5 * max(ref.float().abs().max().item(), 1.0), k
+    m = _cf_model(params, dev)
+    gen, _ = m.losses(t.to(dev), q.to(dev), gen_scale=1.0)
+    assert abs(gen[0].item() - fx["gen_loss"].item()) <= 5e-5 * fx["gen_loss"].item()
+    _, disc = m.losses(t.to(dev), q.to(dev), disc_scale=1.0)
+    assert abs(disc[0].item() - fx["disc_loss"].item()) <= 5e-5 * fx["disc_loss"].item()
+    _cf_check(_cf_model(params, dev), params, t, q, dev, 2e-5, 5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(3, 5000), (1, 1024)])
+def test_context_free_discriminator_hip_vs_oracle_other_shapes(B, N):
+    dev = torch.device("cuda:0")
+    _, params = _cf_fixture()
+    g = torch.Generator().manual_seed(N)
+    t = 0.3 * torch.randn(B, N, generator=g)
+    q = t + 0.1 * torch.randn(B, N, generator=g)
+    _cf_check(_cf_model(params, dev), params, t, q, dev, 2e-5, 5e-4)
