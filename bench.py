@@ -16,8 +16,8 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       L=100, the same training step with bf16 operands on the dense convs / Linears
       (fp32 accumulation, storage, norms, attention and losses: SURVEY.md 8(d) "bf16 autocast for conv/GEMM").
   c3-fp32: the same shape entirely in fp32.
-  c3-gan / c2-gan: c3 / c2 plus the adversarial term of the three spectrogram discriminators and the discriminator
-           step (train/stage.py:124-146; the waveform discriminator and the WavLM term stay off).
+  c3-gan / c2-gan: c3 / c2 plus the adversarial terms (three spectrogram discriminators + the waveform discriminator) and
+           the discriminator step (train/stage.py:124-146; the WavLM term stays off).
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
   c5-bf16: the same with bf16 operands on the dense convs (outside the fp32 parity gates; reported beside c5).
   tts: the export graph (ExportModel.forward): B=8 token strings of L=100 -> duration predictor ->
@@ -262,12 +262,15 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     inp = make_inputs(w, 1000 + rank, device)
     B, T = w["B"], w["T"]
     bf16 = w.get("compute") == "bf16"
-    mrd = None
+    mrd, wave_disc = None, None
     if w.get("gan"):  # the three spectrogram discriminators (random init: the reference's Conv2d / weight_norm defaults)
         from stylish_tts_amd.discriminators import SpecDiscriminator
         torch.manual_seed(7)
+        from stylish_tts_amd.discriminators import ContextFreeDiscriminator
         mrd = [SpecDiscriminator().to(device) for _ in range(3)]
-    trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"), seed=rank, mrd=mrd)
+        wave_disc = ContextFreeDiscriminator().to(device)
+    trainer = (AcousticTrainer(model, style_enc, lr=1e-4, compute=w.get("compute", "fp32"), seed=rank, mrd=mrd,
+                               disc=wave_disc if mrd is not None else None)
                if w["what"] == "train" else None)
     if bf16 and trainer is None:
         model.set_train_opts(compute_bf16=True)
@@ -383,8 +386,8 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
         "dtype": "bf16 GEMM operands, f32 accumulation/storage" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"{name}: B={B}/GPU T={T} frames ({T / 80:.1f} s) L={w['L']}",
                    "pass": (PASS[w["what"]] if not w.get("gan") else
-                            "forward + backward + AdamW (mel + multi-phase + spectrogram-discriminator generator loss; "
-                            "discriminator loss + AdamW step of one of the three; waveform discriminator / WavLM off)"),
+                            "forward + backward + AdamW (mel + multi-phase + generator loss of the three spectrogram discriminators and "
+                            "the waveform discriminator; discriminator losses + AdamW step of mrd{i} and disc; WavLM off)"),
                    "x_realtime": frames / dt / 80.0},
     }
     if prof:

@@ -57,8 +57,8 @@ class AcousticTrainer:
     losses that need no third-party model (mel spectral convergence + multi-phase; the WavLM term is off), and -- with
     `mrd=` three SpecDiscriminator shells -- the adversarial term of the spectrogram discriminators plus the
     discriminator step of train/stage.py:124-146 (generator_loss "mrd" part, d_loss * sqrt(batch), optimizer step of
-    mrd{disc_index} at lr = generator lr x DiscriminatorLossHelper.get_disc_lr_multiplier(); the waveform
-    discriminator `disc` is not built):
+    mrd{disc_index} at lr = generator lr x DiscriminatorLossHelper.get_disc_lr_multiplier()), and with `disc=` the
+    waveform discriminator (ContextFreeDiscriminator, weight 3 in both losses, stepped every batch):
 
         zero_grad -> AcousticStep forward -> LossLog.backwards_loss() seed -> backward through the predictor and the
         style encoder -> gradient mean over ranks -> AdamW step of both models.
@@ -72,7 +72,7 @@ class AcousticTrainer:
 
     def __init__(self, speech_predictor, style_encoder, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4,
                  w_mel=5.0, w_phase=8.0, mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0,
-                 text_dropout=0.2, compute="fp32", mrd=None, w_gen=1.0):
+                 text_dropout=0.2, compute="fp32", mrd=None, w_gen=1.0, disc=None):
         import random
         from .optim import FlatAdamW
         self.train_mode = train_mode
@@ -105,6 +105,14 @@ class AcousticTrainer:
                 m.compute_bf16 = self.bf16
                 self.opt[f"mrd{i}"] = FlatAdamW(list(m.named_parameters()), **kw)
             self.disc_helpers = [DiscriminatorLossHelper(m, 5) for m in self.mrd]
+        self.disc = disc  # ContextFreeDiscriminator shell (models.py:74), weight 3 in both losses (losses.py:14)
+        if disc is not None:
+            from .discriminators import DiscriminatorLossHelper
+            if self.mrd is None:
+                raise ValueError("disc= needs mrd= (the reference's GeneratorLoss always evaluates both)")
+            disc.compute_bf16 = self.bf16
+            self.opt["disc"] = FlatAdamW(list(disc.named_parameters()), **kw)
+            self.disc_helper = DiscriminatorLossHelper(disc, 1)
         self._hooks = {}
         self._hook_error = None
 
@@ -177,6 +185,13 @@ class AcousticTrainer:
             losses, self.gan, d_audio = acoustic_gan_loss(
                 audio_gt, audio.squeeze(1), self.mrd, w_mel=self.w_mel, w_phase=self.w_phase, w_gen=self.w_gen,
                 disc_scale=float(texts.shape[0]) ** 0.5, step=(disc_index,), compute_bf16=self.bf16)
+            if self.disc is not None:
+                # + disc_weight (3) x the waveform discriminator in both losses; one forward pass per input serves both
+                # helpers, so BatchNorm's running statistics see each batch once with the momentum of two updates
+                # (they are never read in training mode)
+                gen_w, dsc_w = self.disc.losses(audio_gt, audio.squeeze(1), gen_scale=3.0 * self.w_gen, d_pred=d_audio,
+                                                disc_scale=3.0 * float(texts.shape[0]) ** 0.5, bn_momentum=0.19)
+                self.gan_wave = torch.cat([gen_w, dsc_w])  # generator loss, discriminator loss, the same without tprls
         self._install_grad_hook(self.sp, "speech_predictor")
         self._install_grad_hook(self.se, "speech_style_encoder")
         # the all-reduces are started by the gradient hooks from inside the two backward calls: the predictor's
@@ -208,6 +223,13 @@ class AcousticTrainer:
             plain = self.gan.tolist()  # (one host read per step; the reference's helpers call .item() three times)
             for r, h in enumerate(self.disc_helpers):
                 h.last_loss = h.last_loss * 0.95 + plain[2 + 2 * r] * 0.05
+            if self.disc is not None:
+                ow = self.opt["disc"]
+                ow.grads.reduce_all()
+                ow.grads.finish(average=False)
+                ow.lr = self.opt["speech_predictor"].lr * self.disc_helper.get_disc_lr_multiplier()
+                ow.step(grad_scale=1.0 / world)
+                self.disc_helper.last_loss = self.disc_helper.last_loss * 0.95 + float(self.gan_wave[2].item()) * 0.05
         self.audio = audio
         return losses
 

@@ -827,7 +827,7 @@ def test_acoustic_train_step_with_spectrogram_discriminators(env):
     """train_acoustic + the discriminator step of stage.py:124-146 with the three spectrogram discriminators:
     the mel / phase losses are those of the plain step; the generator's gradients change by the adversarial term; only
     mrd{disc_index} is stepped, with lr = generator lr x the helper's multiplier and gradients scaled by sqrt(batch);
-    the helpers' tracked losses follow losses.py:288."""
+    the helpers' tracked losses follow losses.py:288; the waveform discriminator (weight 3) is stepped every batch."""
     from safetensors.torch import load_file
     from stylish_tts_amd.acoustic import AcousticTrainer
     from stylish_tts_amd.discriminators import SpecDiscriminator
@@ -854,7 +854,13 @@ def test_acoustic_train_step_with_spectrogram_discriminators(env):
     sp.load_state_dict(P, strict=False)
     se = S.MelStyleEncoder()
     se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
-    tr = AcousticTrainer(sp.to(DEV), se.to(DEV), lr=1e-4, train_mode=False, mrd=mrd, w_gen=1.0)
+    from stylish_tts_amd.discriminators import ContextFreeDiscriminator
+    cfx = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfdisc_small.safetensors"))
+    wave_disc = ContextFreeDiscriminator()
+    wave_disc.load_state_dict({k[2:]: v for k, v in cfx.items() if k.startswith("w.")})
+    wave_disc = wave_disc.to(DEV)
+    wd_before = {k: p.detach().cpu().clone() for k, p in wave_disc.named_parameters()}
+    tr = AcousticTrainer(sp.to(DEV), se.to(DEV), lr=1e-4, train_mode=False, mrd=mrd, w_gen=1.0, disc=wave_disc)
     before = [{k: p.detach().cpu().clone() for k, p in m.named_parameters()} for m in mrd]
     l1 = tr.train_batch(disc_index=2, **kw).cpu()
     torch.cuda.synchronize()
@@ -869,6 +875,11 @@ def test_acoustic_train_step_with_spectrogram_discriminators(env):
         moved = max((p.detach().cpu() - before[r][n]).abs().max().item() for n, p in m.named_parameters())
         assert (moved > 0) == (r == 2), (r, moved)
         assert abs(tr.disc_helpers[r].last_loss - (2.5 * 0.95 + gan[2 + 2 * r].item() * 0.05)) <= 1e-5
+    gw = tr.gan_wave.cpu()
+    assert torch.isfinite(gw).all() and gw[0].item() > 0 and gw[1].item() > 0
+    assert all((p.detach().cpu() - wd_before[k]).abs().max().item() > 0 for k, p in wave_disc.named_parameters())
+    assert abs(tr.disc_helper.last_loss - (0.5 * 0.95 + gw[2].item() * 0.05)) <= 1e-5
+    assert int(dict(wave_disc.named_buffers())["conv.0.net.1.num_batches_tracked"].item()) == 2
     # first AdamW step: |delta| = lr (1 + weight decay shrink) for every element with a non-zero gradient
     lr_d = 1e-4 * 1.0  # tracked loss == ideal loss before the first step -> multiplier 1 (losses.py:241-256)
     p2 = dict(mrd[2].named_parameters())["discriminators.1.parametrizations.weight.original1"].detach().cpu()
