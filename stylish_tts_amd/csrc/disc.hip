@@ -549,7 +549,23 @@ __global__ void cf_bn_finish_kernel(const double* __restrict__ acc, int C, doubl
     rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * count / (count - 1.0));
   }
 }
-// a = mask * gelu(gamma * (z - mean) * rstd + beta)
+// a = mask * gelu(gamma * (z - mean) * rstd + beta), four positions per thread (every T of the window layout is a multiple of 4)
+__global__ void cf_bn_gelu4_kernel(const float* __restrict__ z, const float* __restrict__ stats,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mask, int C, int T, float* __restrict__ a) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4, c = blockIdx.y, b = blockIdx.z;
+  if (i >= T) return;
+  const size_t o = ((size_t)b * C + c) * T + i;
+  const float4 zv = *reinterpret_cast<const float4*>(z + o);
+  const float4 mk = *reinterpret_cast<const float4*>(mask + (size_t)b * T + i);
+  const float g = gamma[c] * stats[C + c], sh = beta[c] - gamma[c] * stats[c] * stats[C + c];
+  float4 r;
+  r.x = mk.x * cf_gelu(fmaf(g, zv.x, sh));
+  r.y = mk.y * cf_gelu(fmaf(g, zv.y, sh));
+  r.z = mk.z * cf_gelu(fmaf(g, zv.z, sh));
+  r.w = mk.w * cf_gelu(fmaf(g, zv.w, sh));
+  *reinterpret_cast<float4*>(a + o) = r;
+}
 __global__ void cf_bn_gelu_kernel(const float* __restrict__ z, const float* __restrict__ stats,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float* __restrict__ mask, int C, int T, float* __restrict__ a) {
@@ -558,6 +574,62 @@ __global__ void cf_bn_gelu_kernel(const float* __restrict__ z, const float* __re
   const size_t o = ((size_t)b * C + c) * T + i;
   const float u = gamma[c] * (z[o] - stats[c]) * stats[C + c] + beta[c];
   a[o] = mask[(size_t)b * T + i] * cf_gelu(u);
+}
+// backward, both passes with four positions per thread
+__global__ __launch_bounds__(256) void cf_bn_bwd_sums4_kernel(const float* __restrict__ z, const float* __restrict__ da,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ mask, int B, int C, int T,
+                                                              double* __restrict__ acc) {
+  __shared__ float red[256];
+  const int c = blockIdx.y;
+  const float mu = stats[c], rs = stats[C + c], g = gamma[c], be = beta[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const size_t ro = ((size_t)b * C + c) * T;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < T; i += gridDim.x * 1024) {
+      const float4 zv = *reinterpret_cast<const float4*>(z + ro + i);
+      const float4 dv = *reinterpret_cast<const float4*>(da + ro + i);
+      const float4 mk = *reinterpret_cast<const float4*>(mask + (size_t)b * T + i);
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w}, mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (zz[e] - mu) * rs;
+        const float du = mm[e] * dd[e] * cf_gelu_d(fmaf(g, xh, be));
+        s1 += du;
+        s2 = fmaf(du, xh, s2);
+      }
+    }
+  }
+  s1 = sd_block_sum(s1, red);
+  s2 = sd_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[c], (double)s1);
+    atomicAdd(&acc[C + c], (double)s2);
+  }
+}
+__global__ void cf_bn_bwd_dx4_kernel(const float* __restrict__ z, const float* __restrict__ da,
+                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, const float* __restrict__ mask,
+                                     const double* __restrict__ acc, double count, int C, int T, float* __restrict__ dz) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4, c = blockIdx.y, b = blockIdx.z;
+  if (i >= T) return;
+  const size_t o = ((size_t)b * C + c) * T + i;
+  const float mu = stats[c], rs = stats[C + c], g = gamma[c], be = beta[c];
+  const float m1 = (float)(acc[c] / count), m2 = (float)(acc[C + c] / count);
+  const float4 zv = *reinterpret_cast<const float4*>(z + o);
+  const float4 dv = *reinterpret_cast<const float4*>(da + o);
+  const float4 mk = *reinterpret_cast<const float4*>(mask + (size_t)b * T + i);
+  const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w}, mm[4] = {mk.x, mk.y, mk.z, mk.w};
+  float r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xh = (zz[e] - mu) * rs;
+    const float du = mm[e] * dd[e] * cf_gelu_d(fmaf(g, xh, be));
+    r[e] = mm[e] * g * rs * (du - m1 - xh * m2);
+  }
+  *reinterpret_cast<float4*>(dz + o) = make_float4(r[0], r[1], r[2], r[3]);
 }
 // backward, pass 1: du = da * gelu'(u) on the valid positions; acc[c] += sum du, acc[C + c] += sum du * xhat
 __global__ __launch_bounds__(256) void cf_bn_bwd_sums_kernel(const float* __restrict__ z, const float* __restrict__ da,
@@ -751,7 +823,7 @@ struct SdRun : DiscBase {
     Wl[0] = W;
     for (int i = 1; i <= 3; ++i) Wl[i] = (Wl[i - 1] + 1) / 2;
     Wl[4] = Wl[3];
-    Wp[0] = 8 * (Wl[3] + 4);
+    Wp[0] = 8 * (int)align_up(Wl[3] + 4, 4);  // every level's pitch a multiple of 4: the four-column kernels take them all
     for (int i = 1; i <= 3; ++i) Wp[i] = Wp[i - 1] / 2;
     Wp[4] = Wp[3];
     for (int i = 0; i < 5; ++i) n[i] = H * Wp[i];
@@ -1043,7 +1115,7 @@ struct CfRun : DiscBase {
                        Tt, acc);
     hipLaunchKernelGGL(cf_bn_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, acc, C, (double)B * t * CF_L[l], 1e-5f,
                        update_running ? momentum : 0.f, prm->bn_rm[k], prm->bn_rv[k], ac.stats[k]);
-    hipLaunchKernelGGL(cf_bn_gelu_kernel, dim3(cdiv(Tt, 256), C, B), dim3(256), 0, st, ac.Z[k], ac.stats[k], prm->bn_w[k],
+    hipLaunchKernelGGL(cf_bn_gelu4_kernel, dim3(cdiv(Tt, 1024), C, B), dim3(256), 0, st, ac.Z[k], ac.stats[k], prm->bn_w[k],
                        prm->bn_b[k], mask[l], C, Tt, ac.A[k]);
   }
   float* conv_fwd(int i, const float* x, int Tt, const float* mk, const float* residual = nullptr, int act = ACT_NONE) {
@@ -1112,9 +1184,9 @@ struct CfRun : DiscBase {
     float* dz = take<float>((size_t)B * C * Tt);
     if (!live()) return dz;
     hipchk(hipMemsetAsync(acc, 0, 2 * C * sizeof(double), st), "cfdisc memset");
-    hipLaunchKernelGGL(cf_bn_bwd_sums_kernel, dim3(cdiv(Tt, 2048) < 64 ? cdiv(Tt, 2048) : 64, C), dim3(256), 0, st, ac.Z[k], da,
+    hipLaunchKernelGGL(cf_bn_bwd_sums4_kernel, dim3(cdiv(Tt, 4096) < 64 ? cdiv(Tt, 4096) : 64, C), dim3(256), 0, st, ac.Z[k], da,
                        ac.stats[k], prm->bn_w[k], prm->bn_b[k], mask[l], B, C, Tt, acc);
-    hipLaunchKernelGGL(cf_bn_bwd_dx_kernel, dim3(cdiv(Tt, 256), C, B), dim3(256), 0, st, ac.Z[k], da, ac.stats[k], prm->bn_w[k],
+    hipLaunchKernelGGL(cf_bn_bwd_dx4_kernel, dim3(cdiv(Tt, 1024), C, B), dim3(256), 0, st, ac.Z[k], da, ac.stats[k], prm->bn_w[k],
                        prm->bn_b[k], mask[l], acc, (double)B * t * CF_L[l], C, Tt, dz);
     if (gr)
       hipLaunchKernelGGL(cf_bn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, acc, C, 1.f, gr->bn_w[k], gr->bn_b[k]);
