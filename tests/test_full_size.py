@@ -179,3 +179,36 @@ def test_c3_forward_full_size_vs_oracle():
     torch.cuda.synchronize()
     mseb, l1b = _report("c3 audio, bf16 operands (reported)", outb.pred.audio.cpu(), ref)
     assert bool(torch.isfinite(outb.pred.audio).all()) and mseb <= 1e-2 and l1b <= 1e-1
+
+
+def test_c2_discriminators_full_size_vs_oracle():
+    """The adversarial terms at c2's size (B = 16, 2 s): one spectrogram discriminator on the fft-1024 magnitudes
+    [16, 1, 513, 188] and the waveform discriminator on [16, 48000], both loss helpers forward + backward against the oracle
+    (two-part scheme of tests/test_discriminators.py); then one c3-sized step of the spectrogram path in bf16 mode
+    (B = 32, fft 512: [32, 1, 257, 1219]) for finiteness and the generator / discriminator loss ranges."""
+    from tests.test_discriminators import _cf_check, _cf_fixture, _cf_model, _check_against_oracle, _fixture, _hip_model
+    dev_ = torch.device(DEV)
+    _, params = _fixture()
+    m = _hip_model(params, dev_)
+    g = torch.Generator().manual_seed(123)
+    t = torch.rand(16, 1, 513, 188, generator=g) ** 2 * 3
+    q = (t + 0.4 * torch.randn(t.shape, generator=g)).abs()
+    t0 = time.time()
+    _check_against_oracle(m, params, t, q, dev_, 2e-5, 3e-4)
+    print(f"\n  spectrogram discriminator at c2 size: oracle + HIP {time.time() - t0:.1f} s")
+    _, cparams = _cf_fixture()
+    tw = 0.3 * torch.randn(16, 48000, generator=g)
+    qw = tw + 0.1 * torch.randn(tw.shape, generator=g)
+    t0 = time.time()
+    _cf_check(_cf_model(cparams, dev_), cparams, tw, qw, dev_, 2e-5, 1e-3)
+    print(f"  waveform discriminator at c2 size: oracle + HIP {time.time() - t0:.1f} s")
+    m.compute_bf16 = True
+    tb = (torch.rand(32, 1, 257, 1219, generator=g) ** 2 * 3).to(dev_)
+    qb = (tb + 0.4 * torch.randn(tb.shape, generator=g).to(dev_)).abs()
+    for p in m.parameters():
+        p.grad = None
+    dx = torch.zeros_like(qb[:, 0])
+    gen, disc = m.losses(tb, qb, gen_scale=1.0, d_pred=dx, disc_scale=32 ** 0.5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+    assert 0.5 < gen[0].item() < 50 and 0.5 < disc[0].item() < 50, (gen, disc)
