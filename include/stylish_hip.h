@@ -306,6 +306,17 @@ int sty_specdisc_losses(const sty_specdisc_params *p, int B, int H, int W, const
                         const sty_specdisc_grads *grads, int compute_bf16, void *workspace, size_t ws_bytes,
                         void *stream);
 
+/* PitchDiscriminator (train/models/pitch_discriminator.py:6-68; `pitch_disc`: dim_in 2, kernel 21; `dur_disc`: dim_in 1,
+ * kernel 5): the 1-D sibling of SpecDiscriminator with the same parameter table (g, v, bias of `discriminators.0..4` and
+ * `out.0..4`).  x [B, dim_in, T] -> five score maps [B, T] back to back; losses as sty_specdisc_losses (d_pred [B,dim_in,T]). */
+int sty_pitchdisc_workspace_bytes(int B, int dim_in, int kernel, int T, int with_grads, size_t *bytes);
+int sty_pitchdisc_forward(const sty_specdisc_params *p, int B, int dim_in, int kernel, int T, const float *x,
+                          float *scores, void *workspace, size_t ws_bytes, void *stream);
+int sty_pitchdisc_losses(const sty_specdisc_params *p, int B, int dim_in, int kernel, int T, const float *target,
+                         const float *pred, float gen_scale, float *gen_loss, float *d_pred, float disc_scale,
+                         float *disc_loss, const sty_specdisc_grads *grads, void *workspace, size_t ws_bytes,
+                         void *stream);
+
 /* ContextFreeDiscriminator (train/models/discriminator.py:91-177), the waveform discriminator `disc`, in training mode
  * (BatchNorm batch statistics; running_mean / running_var are updated in place with `bn_momentum` on every forward).
  * conv index: 0-3 `conv.i.net.0`, 4-5 `temporal.i.net.0`, 6-7 `spectral.i.net.0`, 8 `fusion.net.0`, 9 `attn.1`, 10 `last.0`,

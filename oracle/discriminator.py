@@ -9,6 +9,7 @@ TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke() and bench.py's cpu_bas
                                 maps) + sum mean((1 - dg)^2) + TPRLS; note the argument order of its tprls_loss)
   discriminator_loss_helper     train/losses.py:228-290   (DiscriminatorLossHelper.forward: sum mean((1 - dr)^2) +
                                 mean(dg^2) + TPRLS with the sum / (count + 1e-9) form)
+  pitch_discriminator           train/models/pitch_discriminator.py:6-68  (the 1-D sibling: `pitch_disc`, `dur_disc`)
   mrd_generator_loss / mrd_discriminator_loss   the "mrd" branch of GeneratorLoss / DiscriminatorLoss.forward
                                 (train/losses.py:191-208, 313-327) restricted to the three spectrogram discriminators
 
@@ -27,7 +28,7 @@ TAU = 0.04
 def _wn(p, name):
     g = p[name + ".parametrizations.weight.original0"]
     v = p[name + ".parametrizations.weight.original1"]
-    return v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+    return v * (g / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1))))
 
 
 def spec_discriminator(p, y):
@@ -38,6 +39,17 @@ def spec_discriminator(p, y):
                                   padding=PADS[i]), 0.1)
         s = F.conv2d(y, _wn(p, f"out.{i}"), p[f"out.{i}.bias"], stride=1, padding=1)
         out.append(s.flatten(1))
+    return out
+
+
+def pitch_discriminator(p, y):
+    """PitchDiscriminator (train/models/pitch_discriminator.py:6-68): y [B, dim_in, T] -> five [B, T] score maps."""
+    out = []
+    for i in range(5):
+        w = _wn(p, f"discriminators.{i}")
+        y = F.leaky_relu(F.conv1d(y, w, p[f"discriminators.{i}.bias"], padding=w.shape[2] // 2), 0.1)
+        ws = _wn(p, f"out.{i}")
+        out.append(F.conv1d(y, ws, p[f"out.{i}.bias"], padding=ws.shape[2] // 2).flatten(1))
     return out
 
 

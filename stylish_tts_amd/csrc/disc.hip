@@ -34,13 +34,15 @@ namespace sty {
 
 namespace {
 constexpr float SD_SLOPE = 0.1f;
-enum SdForm : int { SD_X27 = 0, SD_SPLIT = 1, SD_PLAIN = 2, SD_SCORE = 3 };
+enum SdForm : int { SD_X27 = 0, SD_SPLIT = 1, SD_PLAIN = 2, SD_SCORE = 3, SD_1D = 4, SD_SCORE1D = 5 };
 
 // packed offset of the effective weight W[co][ci][kh][kw]
 __device__ __forceinline__ size_t sd_off(int form, int co, int ci, int kh, int kw, int CinP, int CoutP) {
   if (form == SD_X27) return (size_t)(kh * 9 + kw) * CoutP + co;
   if (form == SD_SPLIT) return ((size_t)(kw >> 1) * CinP + kh * 64 + ci + 32 * (kw & 1)) * CoutP + co;
   if (form == SD_PLAIN) return ((size_t)kw * CinP + kh * 32 + ci) * CoutP + co;
+  if (form == SD_1D) return ((size_t)kw * CinP + ci) * CoutP + co;  // Conv1d (KH == 1)
+  if (form == SD_SCORE1D) return (size_t)ci * CoutP + kw;           // 1-D score conv: [Cin][K] (CoutP carries K)
   return (size_t)ci * 9 + (size_t)(kh * 3 + kw);  // score conv: [288]
 }
 
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void sd_fold27_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void sd_post_kernel(float* __restrict__ z, int n, int Wp, float* __restrict__ split) {
   const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
   if (i >= n) return;
-  const size_t o = ((size_t)b * 32 + c) * n + i;
+  const size_t o = ((size_t)b * gridDim.y + c) * n + i;
   const float v = z[o];
   const float a = v > 0.f ? v : SD_SLOPE * v;
   z[o] = a;
@@ -507,6 +509,255 @@ struct SdRun : DiscBase {
 
 };
 
+
+// =====================================================================================================================
+// PitchDiscriminator (train/models/pitch_discriminator.py:6-68): the 1-D sibling of SpecDiscriminator used by the textual
+// (`pitch_disc`: dim_in 2, k21) and duration (`dur_disc`: dim_in 1, k5) stages -- five weight-normed Conv1d(. , 64, k) with
+// LeakyReLU(0.1), a weight-normed Conv1d(64, 1, k) score conv after each.  Tensors are [B][C][T] with T = frames / tokens
+// (hundreds): everything here is latency-bound by construction; the dense convs run on the acoustic path's kernels.
+// =====================================================================================================================
+constexpr int PD_C = 64;
+__global__ void pd_add_kernel(const float* __restrict__ src, size_t n, float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+// score conv 64 -> 1, k taps: s[b][t] = bias + sum_ci sum_k w[ci][k] a[b][ci][t + k - pad]
+__global__ void pd_score_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bs, int T,
+                                int K, float* __restrict__ s) {
+  const int t = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const int pad = K / 2;
+  float acc = bs[0];
+  for (int ci = 0; ci < PD_C; ++ci) {
+    const float* row = a + ((size_t)b * PD_C + ci) * T;
+    for (int k = 0; k < K; ++k) {
+      const int ts = t + k - pad;
+      if (ts >= 0 && ts < T) acc = fmaf(w[ci * K + k], row[ts], acc);
+    }
+  }
+  s[(size_t)b * T + t] = acc;
+}
+// gz = (score-conv backward of gs + dnext) * LeakyReLU'(a)
+__global__ void pd_gz_kernel(const float* __restrict__ gs, const float* __restrict__ w, const float* __restrict__ a,
+                             const float* __restrict__ dnext, int T, int K, float* __restrict__ gz) {
+  const int t = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const int pad = K / 2;
+  const size_t o = ((size_t)b * PD_C + c) * T + t;
+  float v = dnext ? dnext[o] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int to = t - k + pad;
+    if (to >= 0 && to < T) v = fmaf(w[c * K + k], gs[(size_t)b * T + to], v);
+  }
+  gz[o] = v * (a[o] > 0.f ? 1.f : SD_SLOPE);
+}
+// acc[c*K + k] += sum_{b,t} a[b][c][t + k - pad] gs[b][t];  acc[64*K] += sum gs   (one thread per entry; doubles)
+__global__ void pd_score_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ gs, int B, int T, int K,
+                                      double* __restrict__ acc) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i > PD_C * K) return;
+  const int pad = K / 2;
+  double s = 0.0;
+  if (i == PD_C * K) {
+    for (size_t j = 0; j < (size_t)B * T; ++j) s += gs[j];
+  } else {
+    const int c = i / K, k = i - c * K;
+    for (int b = 0; b < B; ++b) {
+      const float* row = a + ((size_t)b * PD_C + c) * T;
+      const float* g = gs + (size_t)b * T;
+      for (int t = 0; t < T; ++t) {
+        const int ts = t + k - pad;
+        if (ts >= 0 && ts < T) s += (double)row[ts] * (double)g[t];
+      }
+    }
+  }
+  acc[i] += s;
+}
+
+struct PdRun : DiscBase {
+  int B, Cin, K, T;
+  PackedConv w[5], d[5];
+  float* sw[5];  // score conv weights [64*K] + bias at [64*K]
+
+  void prepare(const sty_specdisc_params* p, bool need_dgrad0) {
+    for (int i = 0; i < 5; ++i) {
+      PackedConv& f = w[i];
+      f.Cin = i == 0 ? Cin : PD_C;
+      f.Cout = PD_C;
+      f.K = K;
+      f.CinP = (int)align_up(f.Cin, CI_CHUNK);
+      f.CoutP = PD_C;
+      const size_t nw = (size_t)K * f.CinP * f.CoutP;
+      float* wp = take<float>(nw);
+      float* bp = take<float>(PD_C);
+      f.wp = wp;
+      f.bias = bp;
+      PackedConv& g = d[i];
+      g.Cin = PD_C;
+      g.CinP = PD_C;
+      g.Cout = f.Cin;
+      g.CoutP = f.CinP;
+      g.K = K;
+      float* wd = take<float>(nw);
+      g.wp = wd;
+      g.bias = nullptr;
+      sw[i] = take<float>((size_t)PD_C * K + 8);
+      if (live()) {
+        hipchk(hipMemsetAsync(wp, 0, nw * sizeof(float), st), "pitchdisc memset");
+        hipLaunchKernelGGL(sd_pack_kernel, dim3(PD_C), dim3(256), 0, st, p->g[i], p->v[i], p->bias[i], (int)SD_1D, f.Cin, 1, K,
+                           f.CinP, f.CoutP, wp, bp);
+        hipLaunchKernelGGL(sd_pack_kernel, dim3(1), dim3(256), 0, st, p->g[5 + i], p->v[5 + i], p->bias[5 + i], (int)SD_SCORE1D,
+                           PD_C, 1, K, 0, K, sw[i], sw[i] + PD_C * K);
+        if (i > 0 || need_dgrad0) chk(launch_pack_dgrad(wp, K, f.CinP, f.CoutP, wd, st));
+      }
+    }
+  }
+  ConvArgs conv_args(int i, const float* x, float* y) const {
+    ConvArgs a;
+    a.x[0] = x;
+    a.xc[0] = w[i].Cin;
+    a.nsrc = 1;
+    a.B = B;
+    a.T = T;
+    a.pad = K / 2;
+    a.w = w[i];
+    a.y = y;
+    return a;
+  }
+  struct Acts {
+    const float* x;
+    float* a[5];
+    float* s[5];
+  };
+  void forward(const float* x, Acts& ac) {
+    ac.x = x;
+    for (int i = 0; i < 5; ++i) {
+      ac.a[i] = take<float>((size_t)B * PD_C * T);
+      if (!live()) continue;
+      chk(launch_conv1d(conv_args(i, i == 0 ? x : ac.a[i - 1], ac.a[i]), st));
+      hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(T, 256), PD_C, B), dim3(256), 0, st, ac.a[i], T, T, (float*)nullptr);
+      hipLaunchKernelGGL(pd_score_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, st, ac.a[i], sw[i], sw[i] + PD_C * K, T, K, ac.s[i]);
+    }
+  }
+  void backward(const Acts& ac, float* const gs[5], float* const gwp[5], float* const gbp[5], double* const sacc[5], float* dx) {
+    const size_t mark = ws.off;
+    float* dnext = nullptr;
+    for (int i = 4; i >= 0; --i) {
+      float* gz = take<float>((size_t)B * PD_C * T);
+      if (live())
+        hipLaunchKernelGGL(pd_gz_kernel, dim3(cdiv(T, 64), PD_C, B), dim3(64), 0, st, gs[i], sw[i], ac.a[i], dnext, T, K, gz);
+      const ConvArgs f = conv_args(i, i == 0 ? ac.x : ac.a[i - 1], nullptr);
+      if (gwp) {
+        if (live())
+          hipLaunchKernelGGL(pd_score_wgrad_kernel, dim3(cdiv(PD_C * K + 1, 64)), dim3(64), 0, st, ac.a[i], gs[i], B, T, K, sacc[i]);
+        float* partial = take<float>(wgrad_partial_floats(f.w, B, T));
+        bool done = false;
+        if (live()) chk(launch_conv1d_wgrad(f, gz, nullptr, 1.f, gwp[i], partial, gbp[i], &done, st));
+        if (!done) {
+          float* sc = take<float>(bias_grad_scratch_floats(B, PD_C, T));
+          if (live()) chk(launch_bias_grad(gz, nullptr, B, PD_C, T, 0, 1.f, gbp[i], sc, st));
+        }
+      }
+      if (i > 0 || dx) {
+        float* U = take<float>((size_t)B * d[i].CoutP * T);
+        ConvArgs a;
+        a.x[0] = gz;
+        a.xc[0] = PD_C;
+        a.nsrc = 1;
+        a.B = B;
+        a.T = T;
+        a.pad = (K - 1) - K / 2;
+        a.w = d[i];
+        a.y = U;
+        if (live()) chk(launch_conv1d(a, st));
+        dnext = U;
+      }
+    }
+    if (dx && live()) {
+      const size_t n = (size_t)B * Cin * T;
+      hipLaunchKernelGGL(pd_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dnext, n, dx);
+    }
+    ws.off = mark;
+  }
+};
+}  // namespace
+
+int pitchdisc_run(const sty_specdisc_params* p, int B, int Cin, int K, int T, const float* target, const float* pred,
+                  float* scores_t, float* scores_p, float gen_scale, float* gen_loss, float* d_pred, float disc_scale,
+                  float* disc_loss, const sty_specdisc_grads* grads, void* workspace, size_t ws_bytes, hipStream_t st,
+                  size_t* need) {
+  PdRun r;
+  r.ws.base = static_cast<char*>(workspace);
+  r.ws.cap = ws_bytes;
+  r.st = st;
+  r.B = B;
+  r.Cin = Cin;
+  r.K = K;
+  r.T = T;
+  const bool want_gen = d_pred != nullptr || gen_loss != nullptr;
+  const bool want_disc = grads != nullptr || disc_loss != nullptr;
+  r.prepare(p, d_pred != nullptr);
+  const size_t ne = (size_t)B * T;
+  PdRun::Acts at = {}, ap = {};
+  float* st_buf = scores_t ? scores_t : r.take<float>(5 * ne);
+  float* sp_buf = scores_p ? scores_p : r.take<float>(5 * ne);
+  float* gt_buf = r.take<float>(5 * ne);
+  float* gp_buf = r.take<float>(5 * ne);
+  float *gst[5], *gsp[5];
+  for (int i = 0; i < 5; ++i) {
+    at.s[i] = st_buf ? st_buf + i * ne : nullptr;
+    ap.s[i] = sp_buf ? sp_buf + i * ne : nullptr;
+    gst[i] = gt_buf ? gt_buf + i * ne : nullptr;
+    gsp[i] = gp_buf ? gp_buf + i * ne : nullptr;
+  }
+  if (target) r.forward(target, at);
+  if (pred) r.forward(pred, ap);
+  if (want_gen && target && pred) {
+    float* out2 = r.take<float>(2);
+    if (r.live()) r.hipchk(hipMemsetAsync(out2, 0, 2 * sizeof(float), st), "pitchdisc memset");
+    for (int i = 0; i < 5; ++i) r.loss_pair(at.s[i], ap.s[i], ne, 1, gen_scale, out2, nullptr, gsp[i]);
+    if (gen_loss && r.live()) hipLaunchKernelGGL(sd_add_kernel, dim3(1), dim3(1), 0, st, out2, 1, gen_loss);
+    if (d_pred) r.backward(ap, gsp, nullptr, nullptr, nullptr, d_pred);
+  }
+  if (want_disc && target && pred) {
+    float* out2 = r.take<float>(2);
+    if (r.live()) r.hipchk(hipMemsetAsync(out2, 0, 2 * sizeof(float), st), "pitchdisc memset");
+    for (int i = 0; i < 5; ++i) r.loss_pair(at.s[i], ap.s[i], ne, 0, disc_scale, out2, gst[i], gsp[i]);
+    if (disc_loss && r.live()) hipLaunchKernelGGL(sd_add_kernel, dim3(1), dim3(1), 0, st, out2, 2, disc_loss);
+    if (grads) {
+      float *gwp[5], *gbp[5];
+      double* sacc[5];
+      for (int i = 0; i < 5; ++i) {
+        const size_t nw = (size_t)K * r.w[i].CinP * r.w[i].CoutP;
+        gwp[i] = r.take<float>(nw);
+        gbp[i] = r.take<float>(PD_C);
+        sacc[i] = r.take<double>((size_t)PD_C * K + 8);
+        if (r.live()) {
+          r.hipchk(hipMemsetAsync(gwp[i], 0, nw * sizeof(float), st), "pitchdisc memset");
+          r.hipchk(hipMemsetAsync(gbp[i], 0, PD_C * sizeof(float), st), "pitchdisc memset");
+          r.hipchk(hipMemsetAsync(sacc[i], 0, ((size_t)PD_C * K + 8) * sizeof(double), st), "pitchdisc memset");
+        }
+      }
+      r.backward(at, gst, gwp, gbp, sacc, nullptr);
+      r.backward(ap, gsp, gwp, gbp, sacc, nullptr);
+      if (r.live())
+        for (int i = 0; i < 5; ++i) {
+          hipLaunchKernelGGL(sd_unpack_kernel, dim3(PD_C), dim3(256), 0, st, gwp[i], nullptr, gbp[i], nullptr, p->g[i], p->v[i],
+                             (int)SD_1D, r.w[i].Cin, 1, K, r.w[i].CinP, r.w[i].CoutP, 1.f, grads->g[i], grads->v[i],
+                             grads->bias[i]);
+          hipLaunchKernelGGL(sd_unpack_kernel, dim3(1), dim3(256), 0, st, nullptr, sacc[i], nullptr, sacc[i] + PD_C * K,
+                             p->g[5 + i], p->v[5 + i], (int)SD_SCORE1D, PD_C, 1, K, 0, K, 1.f, grads->g[5 + i], grads->v[5 + i],
+                             grads->bias[5 + i]);
+        }
+    }
+  }
+  if (need) *need = r.hwm + 4096;
+  if (r.rc) return r.rc;
+  if (r.ws.base) STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+namespace {
 }  // namespace
 
 int specdisc_run(const sty_specdisc_params* p, int B, int H, int W, size_t sb, size_t sh, const float* target,
@@ -656,4 +907,43 @@ int sty_specdisc_losses(const sty_specdisc_params* p, int B, int H, int W, const
       }
   return specdisc_run(p, B, H, W, 0, 0, target, pred, nullptr, nullptr, gen_scale, gen_loss, d_pred, disc_scale, disc_loss, grads,
                       compute_bf16, workspace, ws_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int sty_pitchdisc_workspace_bytes(int B, int dim_in, int kernel, int T, int with_grads, size_t* bytes) {
+  if (!bytes || B <= 0 || T <= 0 || dim_in <= 0 || dim_in > 32 || kernel < 1 || kernel > 31 || !(kernel & 1)) {
+    set_error("sty_pitchdisc_workspace_bytes: bad argument (dim_in <= 32, odd kernel <= 31)");
+    return STY_EINVAL;
+  }
+  sty_specdisc_params p = {};
+  sty_specdisc_grads g = {};
+  float dummy[2];
+  return pitchdisc_run(&p, B, dim_in, kernel, T, dummy, dummy, nullptr, nullptr, 1.f, dummy, dummy, 1.f, dummy,
+                       with_grads ? &g : nullptr, nullptr, 0, nullptr, bytes);
+}
+int sty_pitchdisc_forward(const sty_specdisc_params* p, int B, int dim_in, int kernel, int T, const float* x, float* scores,
+                          void* workspace, size_t ws_bytes, void* stream) {
+  if (sd_bad_params(p) || !x || !scores || !workspace || B <= 0 || T <= 0 || dim_in <= 0 || dim_in > 32 || kernel < 1 ||
+      kernel > 31 || !(kernel & 1)) {
+    set_error("sty_pitchdisc_forward: bad argument");
+    return STY_EINVAL;
+  }
+  return pitchdisc_run(p, B, dim_in, kernel, T, x, nullptr, scores, nullptr, 0.f, nullptr, nullptr, 0.f, nullptr, nullptr,
+                       workspace, ws_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+int sty_pitchdisc_losses(const sty_specdisc_params* p, int B, int dim_in, int kernel, int T, const float* target,
+                         const float* pred, float gen_scale, float* gen_loss, float* d_pred, float disc_scale,
+                         float* disc_loss, const sty_specdisc_grads* grads, void* workspace, size_t ws_bytes, void* stream) {
+  if (sd_bad_params(p) || !target || !pred || !workspace || B <= 0 || T <= 0 || dim_in <= 0 || dim_in > 32 || kernel < 1 ||
+      kernel > 31 || !(kernel & 1)) {
+    set_error("sty_pitchdisc_losses: bad argument");
+    return STY_EINVAL;
+  }
+  if (grads)
+    for (int i = 0; i < 10; ++i)
+      if (!grads->g[i] || !grads->v[i] || !grads->bias[i]) {
+        set_error("sty_pitchdisc_losses: null gradient buffer %d", i);
+        return STY_EINVAL;
+      }
+  return pitchdisc_run(p, B, dim_in, kernel, T, target, pred, nullptr, nullptr, gen_scale, gen_loss, d_pred, disc_scale,
+                       disc_loss, grads, workspace, ws_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
 }

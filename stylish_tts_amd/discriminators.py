@@ -320,3 +320,66 @@ class ContextFreeDiscriminator(torch.nn.Module):
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         self._tracked(2)
         return gen, disc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PitchDiscriminator (models/pitch_discriminator.py:6-68): `pitch_disc` (dim_in 2, kernel 21), `dur_disc` (dim_in 1, kernel 5)
+# ---------------------------------------------------------------------------------------------------------------------
+class PitchDiscriminator(torch.nn.Module):
+    def __init__(self, *, dim_in, dim_hidden=64, kernel):
+        super().__init__()
+        if dim_hidden != 64:
+            raise L.StyError("PitchDiscriminator: only dim_hidden = 64 (models.py:81-82) is built")
+        self.dim_in, self.kernel = dim_in, kernel
+        shapes = [(64, dim_in, kernel)] + [(64, 64, kernel)] * 4
+        for name, shp in (("discriminators", shapes), ("out", [(1, 64, kernel)] * 5)):
+            for i, s_ in enumerate(shp):
+                v = (torch.rand(s_) * 2 - 1) / math.sqrt(s_[1] * s_[2])
+                _register(self, f"{name}.{i}.bias", (torch.rand(s_[0]) * 2 - 1) / math.sqrt(s_[1] * s_[2]), False)
+                _register(self, f"{name}.{i}.parametrizations.weight.original0", v.flatten(1).norm(dim=1).view(-1, 1, 1), False)
+                _register(self, f"{name}.{i}.parametrizations.weight.original1", v, False)
+        self._ws = None
+
+    _ptrs = SpecDiscriminator._ptrs
+
+    def _workspace(self, B, T, with_grads, device):
+        lib = L.load()
+        need = C.c_size_t()
+        L.check(lib.sty_pitchdisc_workspace_bytes(B, self.dim_in, self.kernel, T, int(with_grads), C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _seq(self, y):
+        if y.device.type != "cuda":
+            raise L.StyError("PitchDiscriminator: inputs must live on a HIP device; there is no CPU path")
+        y = y.detach().contiguous().float()
+        assert y.dim() == 3 and y.shape[1] == self.dim_in
+        return y
+
+    def forward(self, y):
+        lib = L.load()
+        y = self._seq(y)
+        B, _, T = y.shape
+        ws = self._workspace(B, T, False, y.device)
+        scores = torch.empty(5, B, T, device=y.device)
+        st = self._ptrs()
+        L.check(lib.sty_pitchdisc_forward(C.byref(st), B, self.dim_in, self.kernel, T, L.ptr(y), L.ptr(scores), L.ptr(ws),
+                                          ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return [scores[i] for i in range(5)], []
+
+    def losses(self, target, pred, *, gen_scale=None, d_pred=None, disc_scale=None):
+        """As SpecDiscriminator.losses on [B, dim_in, T] sequences; d_pred [B, dim_in, T]."""
+        lib = L.load()
+        t, p = self._seq(target), self._seq(pred)
+        B, _, T = t.shape
+        ws = self._workspace(B, T, disc_scale is not None, t.device)
+        gen = torch.zeros(1, device=t.device) if gen_scale is not None else None
+        disc = torch.zeros(2, device=t.device) if disc_scale is not None else None
+        st = self._ptrs()
+        gr = self._ptrs(grads=True) if disc_scale is not None else None
+        L.check(lib.sty_pitchdisc_losses(C.byref(st), B, self.dim_in, self.kernel, T, L.ptr(t), L.ptr(p), float(gen_scale or 0.0),
+                                         L.ptr(gen), L.ptr(d_pred) if gen_scale is not None else None, float(disc_scale or 0.0),
+                                         L.ptr(disc), C.byref(gr) if gr is not None else None, L.ptr(ws), ws.numel(),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return gen, disc

@@ -331,3 +331,82 @@ def test_context_free_discriminator_hip_vs_oracle_other_shapes(B, N):
     t = 0.3 * torch.randn(B, N, generator=g)
     q = t + 0.1 * torch.randn(B, N, generator=g)
     _cf_check(_cf_model(params, dev), params, t, q, dev, 2e-5, 5e-4)
+
+
+def _pd_fixture(name):
+    fx = load_file(os.path.join(G, "pdisc_small.safetensors"))
+    params = {k[len(name) + 3:]: v for k, v in fx.items() if k.startswith(name + ".w.")}
+    return {k[len(name) + 1:]: v for k, v in fx.items() if k.startswith(name + ".") and ".w." not in k[:len(name) + 3]}, params
+
+
+@pytest.mark.parametrize("name", ["pitch", "dur"])
+def test_pitch_discriminator_oracle_matches_reference(name):
+    from oracle import discriminator as od
+    fx, p = _pd_fixture(name)
+    t, q = fx["target"], fx["pred"].clone().requires_grad_(True)
+    rs, gs = od.pitch_discriminator(p, t), od.pitch_discriminator(p, q)
+    for i in range(5):
+        assert (rs[i] - fx[f"real_score{i}"]).abs().max().item() <= 2e-6 and (gs[i] - fx[f"gen_score{i}"]).abs().max().item() <= 2e-6
+    gl = od.generator_loss_helper(rs, gs)
+    gl.backward()
+    assert abs(gl.item() - fx["gen_loss"].item()) <= 1e-5
+    assert (q.grad - fx["d_pred"]).abs().max().item() <= 1e-5 * fx["d_pred"].abs().max().item()
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    dl = od.discriminator_loss_helper(od.pitch_discriminator(pp, t), od.pitch_discriminator(pp, fx["pred"]))
+    dl.backward()
+    assert abs(dl.item() - fx["disc_loss"].item()) <= 1e-5
+    for k in pp:
+        ref = fx["grad." + k]
+        assert (pp[k].grad - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-3), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dim_in,kernel", [("pitch", 2, 21), ("dur", 1, 5)])
+def test_pitch_discriminator_hip(name, dim_in, kernel):
+    """HIP PitchDiscriminator (pitch_disc / dur_disc configurations): score maps and both loss values against the
+    reference fixture, gradients through the pinned oracle (two-part scheme), then a longer odd-length sequence."""
+    from oracle import discriminator as od
+    from stylish_tts_amd.discriminators import PitchDiscriminator
+    dev = torch.device("cuda:0")
+    fx, params = _pd_fixture(name)
+    m = PitchDiscriminator(dim_in=dim_in, kernel=kernel)
+    m.load_state_dict(params, strict=True)
+    m = m.to(dev)
+    cases = [(fx["target"], fx["pred"], True)]
+    g = torch.Generator().manual_seed(9)
+    tl = torch.randn(4, dim_in, 517, generator=g) * 2
+    cases.append((tl, tl + 0.5 * torch.randn(tl.shape, generator=g), False))
+    for t, q0, pinned in cases:
+        td, qd = t.to(dev), q0.to(dev)
+        rs_h = [x.cpu().clone().requires_grad_(True) for x in m(td)[0]]
+        gs_h = [x.cpu().clone().requires_grad_(True) for x in m(qd)[0]]
+        if pinned:
+            for i in range(5):
+                assert (rs_h[i] - fx[f"real_score{i}"]).abs().max().item() <= 2e-5 * max(fx[f"real_score{i}"].abs().max().item(), 0.1)
+                assert (gs_h[i] - fx[f"gen_score{i}"]).abs().max().item() <= 2e-5 * max(fx[f"gen_score{i}"].abs().max().item(), 0.1)
+        gl = od.generator_loss_helper(rs_h, gs_h)
+        g_gen = torch.autograd.grad(gl, gs_h)
+        dl = od.discriminator_loss_helper(rs_h, gs_h)
+        g_dr = torch.autograd.grad(dl, rs_h, retain_graph=True)
+        g_dg = torch.autograd.grad(dl, gs_h)
+        q = q0.clone().requires_grad_(True)
+        keys = sorted(params)
+        pp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        so_t, so_q = od.pitch_discriminator(pp, t), od.pitch_discriminator(pp, q)
+        dq, = torch.autograd.grad(so_q, q, grad_outputs=list(g_gen), retain_graph=True)
+        dw = torch.autograd.grad(so_t + so_q, [pp[k] for k in keys], grad_outputs=list(g_dr) + list(g_dg))
+        for p_ in m.parameters():
+            p_.grad = None
+        d_pred = torch.zeros_like(qd)
+        gen, disc = m.losses(td, qd, gen_scale=2.0, d_pred=d_pred, disc_scale=3.0)
+        assert abs(gen[0].item() - gl.item()) <= 2e-5 * gl.item() and abs(disc[0].item() - dl.item()) <= 2e-5 * dl.item()
+        if pinned:
+            assert abs(gen[0].item() - fx["gen_loss"].item()) <= 5e-5 * fx["gen_loss"].item()
+            assert abs(disc[0].item() - fx["disc_loss"].item()) <= 5e-5 * fx["disc_loss"].item()
+        err = (d_pred.cpu() - 2.0 * dq).abs().max().item()
+        assert err <= 2e-4 * 2.0 * dq.abs().max().item(), ("d_pred", err)
+        got = dict(m.named_parameters())
+        for k, ref in zip(keys, dw):
+            ref = 3.0 * ref
+            err = (got[k].grad.cpu() - ref).abs().max().item()
+            assert err <= (1e-3 if k.endswith("original0") else 2e-4) * max(ref.abs().max().item(), 1e-3), (k, err)
