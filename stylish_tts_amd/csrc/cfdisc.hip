@@ -108,16 +108,8 @@ __global__ void cf_bn_gelu4_kernel(const float* __restrict__ z, const float* __r
   r.w = mk.w * cf_gelu(fmaf(g, zv.w, sh));
   *reinterpret_cast<float4*>(a + o) = r;
 }
-__global__ void cf_bn_gelu_kernel(const float* __restrict__ z, const float* __restrict__ stats,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                  const float* __restrict__ mask, int C, int T, float* __restrict__ a) {
-  const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
-  if (i >= T) return;
-  const size_t o = ((size_t)b * C + c) * T + i;
-  const float u = gamma[c] * (z[o] - stats[c]) * stats[C + c] + beta[c];
-  a[o] = mask[(size_t)b * T + i] * cf_gelu(u);
-}
-// backward, both passes with four positions per thread
+// backward, four positions per thread.  Pass 1: du = da * gelu'(u) on the valid positions; acc[c] += sum du,
+// acc[C + c] += sum du * xhat.  Pass 2: dz = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat)), 0 in the gaps.
 __global__ __launch_bounds__(256) void cf_bn_bwd_sums4_kernel(const float* __restrict__ z, const float* __restrict__ da,
                                                               const float* __restrict__ stats,
                                                               const float* __restrict__ gamma,
@@ -172,48 +164,6 @@ __global__ void cf_bn_bwd_dx4_kernel(const float* __restrict__ z, const float* _
     r[e] = mm[e] * g * rs * (du - m1 - xh * m2);
   }
   *reinterpret_cast<float4*>(dz + o) = make_float4(r[0], r[1], r[2], r[3]);
-}
-// backward, pass 1: du = da * gelu'(u) on the valid positions; acc[c] += sum du, acc[C + c] += sum du * xhat
-__global__ __launch_bounds__(256) void cf_bn_bwd_sums_kernel(const float* __restrict__ z, const float* __restrict__ da,
-                                                             const float* __restrict__ stats,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
-                                                             const float* __restrict__ mask, int B, int C, int T,
-                                                             double* __restrict__ acc) {
-  __shared__ float red[256];
-  const int c = blockIdx.y;
-  const float mu = stats[c], rs = stats[C + c], g = gamma[c], be = beta[c];
-  float s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const size_t ro = ((size_t)b * C + c) * T;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < T; i += gridDim.x * 256) {
-      const float xh = (z[ro + i] - mu) * rs;
-      const float du = mask[(size_t)b * T + i] * da[ro + i] * cf_gelu_d(g * xh + be);
-      s1 += du;
-      s2 = fmaf(du, xh, s2);
-    }
-  }
-  s1 = sd_block_sum(s1, red);
-  s2 = sd_block_sum(s2, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&acc[c], (double)s1);
-    atomicAdd(&acc[C + c], (double)s2);
-  }
-}
-// pass 2: dz = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat)) on the valid positions, 0 elsewhere
-__global__ void cf_bn_bwd_dx_kernel(const float* __restrict__ z, const float* __restrict__ da,
-                                    const float* __restrict__ stats, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ mask,
-                                    const double* __restrict__ acc, double count, int C, int T, float* __restrict__ dz) {
-  const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
-  if (i >= T) return;
-  const size_t o = ((size_t)b * C + c) * T + i;
-  const float mk = mask[(size_t)b * T + i];
-  const float mu = stats[c], rs = stats[C + c], g = gamma[c];
-  const float xh = (z[o] - mu) * rs;
-  const float du = mk * da[o] * cf_gelu_d(g * xh + beta[c]);
-  const float m1 = (float)(acc[c] / count), m2 = (float)(acc[C + c] / count);
-  dz[o] = mk * g * rs * (du - m1 - xh * m2);
 }
 // dgamma += scale * sum du xhat, dbeta += scale * sum du
 __global__ void cf_bn_param_grad_kernel(const double* __restrict__ acc, int C, float scale, float* __restrict__ dgamma,

@@ -137,33 +137,8 @@ __global__ __launch_bounds__(256) void sd_post_kernel(float* __restrict__ z, int
   }
 }
 
-// score conv 32 -> 1, 3x3, pad 1 on the activation a [B][32][H][Wp] -> dense s [B][H][W]
-__global__ __launch_bounds__(256) void sd_score_kernel(const float* __restrict__ a, const float* __restrict__ ws,
-                                                       const float* __restrict__ bs, int H, int W, int Wp,
-                                                       float* __restrict__ s) {
-  __shared__ float wl[288];
-  for (int i = threadIdx.x; i < 288; i += 256) wl[i] = ws[i];
-  __syncthreads();
-  const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
-  if (w >= W) return;
-  float acc = bs[0];
-  const float* ab = a + (size_t)b * 32 * H * Wp;
-  for (int ci = 0; ci < 32; ++ci) {
-#pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int hs = h + dh - 1;
-      if (hs < 0 || hs >= H) continue;
-      const float* row = ab + ((size_t)ci * H + hs) * Wp;
-      const float l = w > 0 ? row[w - 1] : 0.f, m = row[w], r = row[w + 1];  // Wp >= W + 1: column W is a zero
-      acc = fmaf(wl[ci * 9 + dh * 3], l, acc);
-      acc = fmaf(wl[ci * 9 + dh * 3 + 1], m, acc);
-      acc = fmaf(wl[ci * 9 + dh * 3 + 2], r, acc);
-    }
-  }
-  s[((size_t)b * H + h) * W + w] = acc;
-}
-
-// four adjacent outputs per thread (row pitch % 4 == 0): one 16-byte load + two edge samples feed 12 FMAs
+// score conv 32 -> 1, 3x3, pad 1 on the activation a [B][32][H][Wp] -> dense s [B][H][W]; four adjacent outputs per
+// thread (every row pitch is a multiple of 4): one 16-byte load + two edge samples feed 12 FMAs
 __global__ __launch_bounds__(256) void sd_score4_kernel(const float* __restrict__ a, const float* __restrict__ ws,
                                                         const float* __restrict__ bs, int H, int W, int Wp,
                                                         float* __restrict__ s) {
@@ -196,7 +171,10 @@ __global__ __launch_bounds__(256) void sd_score4_kernel(const float* __restrict_
     if (w0 + e < W) so[e] = acc[e];
 }
 
-// the same with four adjacent columns per thread (row pitch % 4 == 0)
+// gradient w.r.t. the pre-activation of layer i:
+//   gz = (score-conv backward of gs  +  input gradient of the next layer) * LeakyReLU'(a) on the valid columns, 0 elsewhere
+// dxn: next layer's input gradient in the normal layout [B][32][H][Wp]; dxs: in the split layout [B][64][H][Wp/2]
+// (four adjacent columns per thread)
 __global__ __launch_bounds__(256) void sd_gz4_kernel(const float* __restrict__ gs, const float* __restrict__ ws,
                                                      const float* __restrict__ a, const float* __restrict__ dxn,
                                                      const float* __restrict__ dxs, int H, int W, int Wp,
@@ -251,38 +229,6 @@ __global__ __launch_bounds__(256) void sd_gz4_kernel(const float* __restrict__ g
       if (w0 + e >= W) v[e] = 0.f;
   }
   *reinterpret_cast<float4*>(gz + o) = make_float4(v[0], v[1], v[2], v[3]);
-}
-
-// gradient w.r.t. the pre-activation of layer i:
-//   gz = (score-conv backward of gs  +  input gradient of the next layer) * LeakyReLU'(a) on the valid columns, 0 elsewhere
-// dxn: next layer's input gradient in the normal layout [B][32][H][Wp]; dxs: in the split layout [B][64][H][Wp/2]
-__global__ __launch_bounds__(256) void sd_gz_kernel(const float* __restrict__ gs, const float* __restrict__ ws,
-                                                    const float* __restrict__ a, const float* __restrict__ dxn,
-                                                    const float* __restrict__ dxs, int H, int W, int Wp,
-                                                    float* __restrict__ gz) {
-  const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
-  const int n = H * Wp;
-  if (i >= n) return;
-  const int h = i / Wp, w = i - h * Wp;
-  const size_t o = ((size_t)b * 32 + c) * n + i;
-  float v = 0.f;
-  if (w < W) {
-    const float* g = gs + (size_t)b * H * W;
-#pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int ho = h - dh + 1;
-      if (ho < 0 || ho >= H) continue;
-#pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int wo = w - dw + 1;
-        if (wo >= 0 && wo < W) v = fmaf(ws[c * 9 + dh * 3 + dw], g[(size_t)ho * W + wo], v);
-      }
-    }
-    if (dxn) v += dxn[o];
-    if (dxs) v += dxs[((size_t)b * 64 + c + 32 * (w & 1)) * (n >> 1) + (size_t)h * (Wp >> 1) + (w >> 1)];
-    v *= a[o] > 0.f ? 1.f : SD_SLOPE;
-  }
-  gz[o] = v;
 }
 
 // score conv weight gradient: acc[c*9 + t] += sum a[c][h + dh - 1][w + dw - 1] gs[h][w]; acc[288] += sum gs  (doubles)
@@ -440,12 +386,8 @@ struct SdRun : DiscBase {
         chk(launch_conv1d(a, st));
         hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, ac.a[i], n[i], Wp[i],
                            i < 3 ? ac.as[i] : nullptr);
-        if (Wp[i] % 4 == 0)
-          hipLaunchKernelGGL(sd_score4_kernel, dim3(cdiv(cdiv(Wl[i], 4), 256), H, B), dim3(256), 0, st, ac.a[i], sw[i],
-                             sw[i] + 288, H, Wl[i], Wp[i], ac.s[i]);
-        else
-          hipLaunchKernelGGL(sd_score_kernel, dim3(cdiv(Wl[i], 256), H, B), dim3(256), 0, st, ac.a[i], sw[i], sw[i] + 288,
-                             H, Wl[i], Wp[i], ac.s[i]);
+        hipLaunchKernelGGL(sd_score4_kernel, dim3(cdiv(cdiv(Wl[i], 4), 256), H, B), dim3(256), 0, st, ac.a[i], sw[i],
+                           sw[i] + 288, H, Wl[i], Wp[i], ac.s[i]);
       }
     }
   }
@@ -458,14 +400,9 @@ struct SdRun : DiscBase {
     float* dnext = nullptr;  // input gradient of layer i + 1
     for (int i = 4; i >= 0; --i) {
       float* gz = take<float>((size_t)B * 32 * n[i]);
-      if (live()) {
-        if (Wp[i] % 4 == 0)
-          hipLaunchKernelGGL(sd_gz4_kernel, dim3(cdiv(n[i] / 4, 256), 32, B), dim3(256), 0, st, gs[i], sw[i], ac.a[i],
-                             i == 3 ? dnext : nullptr, i < 3 ? dnext : nullptr, H, Wl[i], Wp[i], gz);
-        else
-          hipLaunchKernelGGL(sd_gz_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, gs[i], sw[i], ac.a[i],
-                             i == 3 ? dnext : nullptr, i < 3 ? dnext : nullptr, H, Wl[i], Wp[i], gz);
-      }
+      if (live())
+        hipLaunchKernelGGL(sd_gz4_kernel, dim3(cdiv(n[i] / 4, 256), 32, B), dim3(256), 0, st, gs[i], sw[i], ac.a[i],
+                           i == 3 ? dnext : nullptr, i < 3 ? dnext : nullptr, H, Wl[i], Wp[i], gz);
       const float* in = i == 0 ? ac.x27 : (i < 4 ? ac.as[i - 1] : ac.a[3]);
       const ConvArgs f = conv_args(i, in, nullptr);
       if (gwp) {
