@@ -24,7 +24,7 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       alignment -> pitch / energy predictor -> speech predictor -> audio, fp32 inference; frames = B x predicted frames.
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
-The default run (c3 at N = 1) also carries c2, c5 and c3-fp32 as `extra` sub-records (fewer steps, same process).
+The default run (c3 at N = 1) also carries c2, c5, c3-fp32 and c3-gan as `extra` sub-records (fewer steps, same process).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -434,7 +434,9 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     return rec
 
 
-EXTRA_WORKLOADS = ("c2", "c5", "c3-fp32")  # carried as sub-records of the default (c3) line at N = 1
+# carried as sub-records of the default (c3) line at N = 1: the other single-GPU configurations of BASELINE.json and the
+# c3 step with the reference's adversarial terms on (what `train_acoustic` + the discriminator step cost in full)
+EXTRA_WORKLOADS = ("c2", "c5", "c3-fp32", "c3-gan")
 
 
 def main():
@@ -445,7 +447,7 @@ def main():
     # default = the configuration BASELINE.json's metric is quoted on: configs[2], LJSpeech shape, B=32, bf16
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c5 / c3-fp32 sub-records of the default run")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c5 / c3-fp32 / c3-gan sub-records of the default run")
     args = ap.parse_args()
 
     from stylish_tts_amd import dist as D
@@ -475,8 +477,9 @@ def main():
         # the other single-GPU configurations of BASELINE.json, same process, fewer steps; each is a full record of its
         # own (value, ms_per_step, roofline of ITS dominant kernel) without the per-family table
         for name in EXTRA_WORKLOADS:
-            r = run_workload(name, min(args.steps, 10), min(args.warmup, 3), rank, world, device, lib, L, D, share,
-                             serial_pass=False)
+            heavy = bool(WORKLOADS[name].get("gan"))
+            r = run_workload(name, min(args.steps, 5 if heavy else 10), min(args.warmup, 2 if heavy else 3), rank, world,
+                             device, lib, L, D, share, serial_pass=False)
             if r is not None:
                 r.pop("kernels", None)
                 r.pop("kernels_source", None)

@@ -91,22 +91,48 @@ __global__ void cf_bn_finish_kernel(const double* __restrict__ acc, int C, doubl
     rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * count / (count - 1.0));
   }
 }
+// Four consecutive positions i .. i+3 of channel c, either in the normal layout [B][C][T] (s == 1) or in the phase split
+// [B][C*s][T/s] a strided conv reads (s == 2 or 4; element (c, i) lives at channel c*s + i%s, position i/s)
+__device__ __forceinline__ void cf_store4(float* __restrict__ y, int b, int c, int C, int T, int i, int s, const float (&v)[4]) {
+  if (s == 1) {
+    *reinterpret_cast<float4*>(y + ((size_t)b * C + c) * T + i) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if (s == 2) {
+    float* p0 = y + ((size_t)b * C * 2 + (size_t)c * 2) * (T / 2) + i / 2;
+    *reinterpret_cast<float2*>(p0) = make_float2(v[0], v[2]);
+    *reinterpret_cast<float2*>(p0 + T / 2) = make_float2(v[1], v[3]);
+  } else {
+    float* p0 = y + ((size_t)b * C * 4 + (size_t)c * 4) * (T / 4) + i / 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p0[(size_t)r * (T / 4)] = v[r];
+  }
+}
+__device__ __forceinline__ void cf_load4(const float* __restrict__ y, int b, int c, int C, int T, int i, int s, float (&v)[4]) {
+  if (s == 1) {
+    const float4 q = *reinterpret_cast<const float4*>(y + ((size_t)b * C + c) * T + i);
+    v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+  } else if (s == 2) {
+    const float* p0 = y + ((size_t)b * C * 2 + (size_t)c * 2) * (T / 2) + i / 2;
+    const float2 e = *reinterpret_cast<const float2*>(p0), o = *reinterpret_cast<const float2*>(p0 + T / 2);
+    v[0] = e.x, v[1] = o.x, v[2] = e.y, v[3] = o.y;
+  } else {
+    const float* p0 = y + ((size_t)b * C * 4 + (size_t)c * 4) * (T / 4) + i / 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = p0[(size_t)r * (T / 4)];
+  }
+}
 // a = mask * gelu(gamma * (z - mean) * rstd + beta), four positions per thread (every T of the window layout is a multiple of 4)
 __global__ void cf_bn_gelu4_kernel(const float* __restrict__ z, const float* __restrict__ stats,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ mask, int C, int T, float* __restrict__ a) {
+                                   const float* __restrict__ mask, int C, int T, int s, float* __restrict__ a) {
   const int i = (blockIdx.x * 256 + threadIdx.x) * 4, c = blockIdx.y, b = blockIdx.z;
   if (i >= T) return;
   const size_t o = ((size_t)b * C + c) * T + i;
   const float4 zv = *reinterpret_cast<const float4*>(z + o);
   const float4 mk = *reinterpret_cast<const float4*>(mask + (size_t)b * T + i);
   const float g = gamma[c] * stats[C + c], sh = beta[c] - gamma[c] * stats[c] * stats[C + c];
-  float4 r;
-  r.x = mk.x * cf_gelu(fmaf(g, zv.x, sh));
-  r.y = mk.y * cf_gelu(fmaf(g, zv.y, sh));
-  r.z = mk.z * cf_gelu(fmaf(g, zv.z, sh));
-  r.w = mk.w * cf_gelu(fmaf(g, zv.w, sh));
-  *reinterpret_cast<float4*>(a + o) = r;
+  const float r[4] = {mk.x * cf_gelu(fmaf(g, zv.x, sh)), mk.y * cf_gelu(fmaf(g, zv.y, sh)), mk.z * cf_gelu(fmaf(g, zv.z, sh)),
+                      mk.w * cf_gelu(fmaf(g, zv.w, sh))};
+  cf_store4(a, b, c, C, T, i, s, r);  // s > 1: straight into the phase split the next (strided) conv reads
 }
 // backward, four positions per thread.  Pass 1: du = da * gelu'(u) on the valid positions; acc[c] += sum du,
 // acc[C + c] += sum du * xhat.  Pass 2: dz = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat)), 0 in the gaps.
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(256) void cf_bn_bwd_sums4_kernel(const float* __res
                                                               const float* __restrict__ stats,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
-                                                              const float* __restrict__ mask, int B, int C, int T,
+                                                              const float* __restrict__ mask, int B, int C, int T, int sp,
                                                               double* __restrict__ acc) {
   __shared__ float red[256];
   const int c = blockIdx.y;
@@ -124,9 +150,10 @@ __global__ __launch_bounds__(256) void cf_bn_bwd_sums4_kernel(const float* __res
     const size_t ro = ((size_t)b * C + c) * T;
     for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < T; i += gridDim.x * 1024) {
       const float4 zv = *reinterpret_cast<const float4*>(z + ro + i);
-      const float4 dv = *reinterpret_cast<const float4*>(da + ro + i);
+      float dd[4];
+      cf_load4(da, b, c, C, T, i, sp, dd);  // sp > 1: da is the input gradient of a strided conv, still phase-split
       const float4 mk = *reinterpret_cast<const float4*>(mask + (size_t)b * T + i);
-      const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w}, mm[4] = {mk.x, mk.y, mk.z, mk.w};
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, mm[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xh = (zz[e] - mu) * rs;
@@ -146,16 +173,18 @@ __global__ __launch_bounds__(256) void cf_bn_bwd_sums4_kernel(const float* __res
 __global__ void cf_bn_bwd_dx4_kernel(const float* __restrict__ z, const float* __restrict__ da,
                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, const float* __restrict__ mask,
-                                     const double* __restrict__ acc, double count, int C, int T, float* __restrict__ dz) {
+                                     const double* __restrict__ acc, double count, int C, int T, int sp,
+                                     float* __restrict__ dz) {
   const int i = (blockIdx.x * 256 + threadIdx.x) * 4, c = blockIdx.y, b = blockIdx.z;
   if (i >= T) return;
   const size_t o = ((size_t)b * C + c) * T + i;
   const float mu = stats[c], rs = stats[C + c], g = gamma[c], be = beta[c];
   const float m1 = (float)(acc[c] / count), m2 = (float)(acc[C + c] / count);
   const float4 zv = *reinterpret_cast<const float4*>(z + o);
-  const float4 dv = *reinterpret_cast<const float4*>(da + o);
+  float dd[4];
+  cf_load4(da, b, c, C, T, i, sp, dd);
   const float4 mk = *reinterpret_cast<const float4*>(mask + (size_t)b * T + i);
-  const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w}, mm[4] = {mk.x, mk.y, mk.z, mk.w};
+  const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, mm[4] = {mk.x, mk.y, mk.z, mk.w};
   float r[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -366,7 +395,8 @@ struct CfRun : DiscBase {
   };
 
   // BatchNorm (batch statistics) + GELU of block k on z [B][C][Tt] at level l
-  void bn_gelu(int k, int l, int Tt, Acts& ac, bool update_running) {
+  // split: the stride of the conv that reads this block's output (A[k] is then written phase-split, see cf_store4)
+  void bn_gelu(int k, int l, int Tt, Acts& ac, bool update_running, int split = 1) {
     const int C = CF_BN_C[k];
     double* acc = take<double>(2 * C);
     ac.stats[k] = take<float>(2 * C);
@@ -378,7 +408,7 @@ struct CfRun : DiscBase {
     hipLaunchKernelGGL(cf_bn_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, acc, C, (double)B * t * CF_L[l], 1e-5f,
                        update_running ? momentum : 0.f, prm->bn_rm[k], prm->bn_rv[k], ac.stats[k]);
     hipLaunchKernelGGL(cf_bn_gelu4_kernel, dim3(cdiv(Tt, 1024), C, B), dim3(256), 0, st, ac.Z[k], ac.stats[k], prm->bn_w[k],
-                       prm->bn_b[k], mask[l], C, Tt, ac.A[k]);
+                       prm->bn_b[k], mask[l], C, Tt, split, ac.A[k]);
   }
   float* conv_fwd(int i, const float* x, int Tt, const float* mk, const float* residual = nullptr, int act = ACT_NONE) {
     float* y = take<float>((size_t)B * w[i].CoutP * Tt);
@@ -392,15 +422,13 @@ struct CfRun : DiscBase {
   void forward(const float* x, Acts& ac, bool update_running) {
     float* X0 = take<float>((size_t)B * T[0]);
     if (live()) hipLaunchKernelGGL(cf_unfold_kernel, dim3(cdiv(T[0], 256), B), dim3(256), 0, st, x, N, t, CF_P[0], X0);
-    const float* cur = X0;
-    for (int k = 0; k < 4; ++k) {  // strided blocks: level k -> k + 1
-      const CfConvDesc& c = CF_CONV[k];
-      ac.S[k] = take<float>((size_t)B * c.Cin * T[k]);
-      if (live())
-        hipLaunchKernelGGL(cf_split_kernel, dim3(cdiv(T[k], 256), c.Cin, B), dim3(256), 0, st, cur, c.Cin, T[k], c.s, 0, ac.S[k]);
+    ac.S[0] = take<float>((size_t)B * T[0]);
+    if (live())
+      hipLaunchKernelGGL(cf_split_kernel, dim3(cdiv(T[0], 256), 1, B), dim3(256), 0, st, X0, 1, T[0], CF_CONV[0].s, 0, ac.S[0]);
+    for (int k = 0; k < 4; ++k) {  // strided blocks: level k -> k + 1; blocks 0..2 write the next block's split input
       ac.Z[k] = conv_fwd(k, ac.S[k], T[k + 1], mask[k + 1]);
-      bn_gelu(k, k + 1, T[k + 1], ac, update_running);
-      cur = ac.A[k];
+      bn_gelu(k, k + 1, T[k + 1], ac, update_running, k < 3 ? CF_CONV[k + 1].s : 1);
+      if (k < 3) ac.S[k + 1] = ac.A[k];
     }
     const int T4 = T[4];
     ac.Mn = take<float>((size_t)B * 256 * t);
@@ -440,16 +468,16 @@ struct CfRun : DiscBase {
     }
   }
   // backward through BatchNorm + GELU of block k: da -> dz; parameter gradients when bnacc != nullptr
-  float* bn_bwd(int k, int l, int Tt, const Acts& ac, const float* da, const sty_cfdisc_grads* gr) {
+  float* bn_bwd(int k, int l, int Tt, const Acts& ac, const float* da, const sty_cfdisc_grads* gr, int split = 1) {
     const int C = CF_BN_C[k];
     double* acc = take<double>(2 * C);
     float* dz = take<float>((size_t)B * C * Tt);
     if (!live()) return dz;
     hipchk(hipMemsetAsync(acc, 0, 2 * C * sizeof(double), st), "cfdisc memset");
     hipLaunchKernelGGL(cf_bn_bwd_sums4_kernel, dim3(cdiv(Tt, 4096) < 64 ? cdiv(Tt, 4096) : 64, C), dim3(256), 0, st, ac.Z[k], da,
-                       ac.stats[k], prm->bn_w[k], prm->bn_b[k], mask[l], B, C, Tt, acc);
+                       ac.stats[k], prm->bn_w[k], prm->bn_b[k], mask[l], B, C, Tt, split, acc);
     hipLaunchKernelGGL(cf_bn_bwd_dx4_kernel, dim3(cdiv(Tt, 1024), C, B), dim3(256), 0, st, ac.Z[k], da, ac.stats[k], prm->bn_w[k],
-                       prm->bn_b[k], mask[l], acc, (double)B * t * CF_L[l], C, Tt, dz);
+                       prm->bn_b[k], mask[l], acc, (double)B * t * CF_L[l], C, Tt, split, dz);
     if (gr)
       hipLaunchKernelGGL(cf_bn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, acc, C, 1.f, gr->bn_w[k], gr->bn_b[k]);
     return dz;
@@ -501,17 +529,19 @@ struct CfRun : DiscBase {
       hipLaunchKernelGGL(cf_gate_bwd2_kernel, dim3(cdiv(T4, 256), 256, B), dim3(256), 0, st, dXg, ac.Gp, dMn, 256, t, CF_P[4],
                          CF_L[4], dA);
     // strided blocks 3 .. 0
+    int sp = 1;  // dA of block 3 is in the normal layout; below it is the (phase-split) input gradient of block k + 1
     for (int k = 3; k >= 0; --k) {
-      const CfConvDesc& c = CF_CONV[k];
-      float* dZ = bn_bwd(k, k + 1, T[k + 1], ac, dA, gw ? gr : nullptr);
+      float* dZ = bn_bwd(k, k + 1, T[k + 1], ac, dA, gw ? gr : nullptr, sp);
       wgrad(k, ac.S[k], T[k + 1], dZ, gw, gb);
       if (k == 0 && !dx) break;
-      float* dS = dgrad(k, dZ, T[k + 1], nullptr);
-      dA = take<float>((size_t)B * c.Cin * T[k]);
-      if (live())
-        hipLaunchKernelGGL(cf_split_kernel, dim3(cdiv(T[k], 256), c.Cin, B), dim3(256), 0, st, dS, c.Cin, T[k], c.s, 1, dA);
+      dA = dgrad(k, dZ, T[k + 1], nullptr);  // [B][Cin * s][T[k] / s]
+      sp = CF_CONV[k].s;
     }
-    if (dx && live()) hipLaunchKernelGGL(cf_fold_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, dA, N, t, CF_P[0], dx);
+    if (dx && live()) {
+      float* dX0 = take<float>((size_t)B * T[0]);
+      hipLaunchKernelGGL(cf_split_kernel, dim3(cdiv(T[0], 256), 1, B), dim3(256), 0, st, dA, 1, T[0], CF_CONV[0].s, 1, dX0);
+      hipLaunchKernelGGL(cf_fold_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, dX0, N, t, CF_P[0], dx);
+    }
     ws.off = mark;
   }
 };
