@@ -450,11 +450,14 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(ResBufs rb, int r, int B
 }
 
 // losses[0] = mel, losses[1] = multi_phase (device scalars)
-__global__ void loss_finalize_kernel(const double* __restrict__ sums, const int* __restrict__ dims, int B,
+struct LossDims {
+  int v[6];  // (F, frames) of the three resolutions, passed by value (no host-to-device copy on the step's path)
+};
+__global__ void loss_finalize_kernel(const double* __restrict__ sums, LossDims dims, int B,
                                      float* __restrict__ losses) {
   double mel = 0.0, ph = 0.0;
   for (int r = 0; r < 3; ++r) {
-    const int F = dims[2 * r], fr = dims[2 * r + 1];
+    const int F = dims.v[2 * r], fr = dims.v[2 * r + 1];
     mel += sums[r * 5] / (sums[r * 5 + 1] + 1e-6);
     ph += sums[r * 5 + 2] / ((double)B * F * fr) + sums[r * 5 + 3] / ((double)B * (F - 1) * fr) +
           sums[r * 5 + 4] / ((double)B * F * (fr - 1));
@@ -628,8 +631,7 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
     return q;
   };
   double* sums = reinterpret_cast<double*>(take(32));
-  int* dims = reinterpret_cast<int*>(take(16));
-  int hdims[6];
+  LossDims hdims;
   for (int r = 0; r < 3; ++r) {
     const int frames = N / res[r][1] + 1, F = res[r][0] / 2 + 1;
     rb[r].n_fft = res[r][0];
@@ -645,12 +647,11 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
     rb[r].p_fft = take((size_t)B * F * frames);
     rb[r].p_y = take((size_t)B * 2 * F * frames);
     d_gan[r] = take((size_t)B * F * frames);
-    hdims[2 * r] = F;
-    hdims[2 * r + 1] = frames;
+    hdims.v[2 * r] = F;
+    hdims.v[2 * r + 1] = frames;
   }
   float* tmp = p;
   STY_HIP(hipMemsetAsync(sums, 0, 16 * sizeof(double), st));
-  STY_HIP(hipMemcpyAsync(dims, hdims, sizeof(hdims), hipMemcpyHostToDevice, st));
   STY_HIP(hipMemsetAsync(d_pred, 0, (size_t)B * N * sizeof(float), st));
   // features: target (scratch y), prediction (kept y)
   for (int r = 0; r < 3; ++r) {
@@ -689,7 +690,7 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
       if (rc) return rc;
     }
   }
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, sums, dims, B, losses_out);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, sums, hdims, B, losses_out);
   // backward
   for (int r = 0; r < 3; ++r) {
     const FrontTables* t;
