@@ -247,6 +247,9 @@ class AcousticTrainer:
                 if b.is_floating_point():
                     dist.broadcast(b, src)
             L.check(L.load().sty_model_invalidate(m._handle)) if m._handle is not None else None
+        if getattr(self, "disc", None) is not None:  # the waveform discriminator's BatchNorm running statistics
+            for b in self.disc.buffers():
+                dist.broadcast(b, src)
 
     def schedule(self, step, step_limit):
         """Stage.steps / MultiOptimizer.scheduler (train/optimizers.py:96-104): cosine schedule with a 90 % plateau."""

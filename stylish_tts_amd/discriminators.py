@@ -36,6 +36,19 @@ def spec_discriminator_manifest():
     return m
 
 
+def _check_device(module, x):
+    """Inputs, parameters and the current HIP device must agree: the library launches on the current device's stream."""
+    name = type(module).__name__
+    if x.device.type != "cuda":
+        raise L.StyError(f"{name}: inputs must live on a HIP device (got {x.device}); there is no CPU path")
+    pdev = next(module.parameters()).device
+    if pdev != x.device:
+        raise L.StyError(f"{name}: parameters on {pdev}, input on {x.device}")
+    if x.device.index is not None and x.device.index != torch.cuda.current_device():
+        raise L.StyError(f"{name}: tensors on {x.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                         f"wrap the call in `with torch.cuda.device({x.device.index}):`")
+
+
 def score_widths(W):
     w1 = (W + 1) // 2
     w2 = (w1 + 1) // 2
@@ -90,13 +103,11 @@ class SpecDiscriminator(torch.nn.Module):
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
         return self._ws
 
-    @staticmethod
-    def _image(y):
+    def _image(self, y):
         if y.dim() == 4:
             assert y.shape[1] == 1
             y = y[:, 0]
-        if y.device.type != "cuda":
-            raise L.StyError("SpecDiscriminator: inputs must live on a HIP device; there is no CPU path")
+        _check_device(self, y)
         return y.contiguous().float()
 
     def forward(self, y):
@@ -282,10 +293,8 @@ class ContextFreeDiscriminator(torch.nn.Module):
             if k.endswith("num_batches_tracked"):
                 b += n
 
-    @staticmethod
-    def _wave(x):
-        if x.device.type != "cuda":
-            raise L.StyError("ContextFreeDiscriminator: inputs must live on a HIP device; there is no CPU path")
+    def _wave(self, x):
+        _check_device(self, x)
         return x.detach().contiguous().float()
 
     def forward(self, x):
@@ -351,8 +360,7 @@ class PitchDiscriminator(torch.nn.Module):
         return self._ws
 
     def _seq(self, y):
-        if y.device.type != "cuda":
-            raise L.StyError("PitchDiscriminator: inputs must live on a HIP device; there is no CPU path")
+        _check_device(self, y)
         y = y.detach().contiguous().float()
         assert y.dim() == 3 and y.shape[1] == self.dim_in
         return y

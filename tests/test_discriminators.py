@@ -410,3 +410,25 @@ def test_pitch_discriminator_hip(name, dim_in, kernel):
             ref = 3.0 * ref
             err = (got[k].grad.cpu() - ref).abs().max().item()
             assert err <= (1e-3 if k.endswith("original0") else 2e-4) * max(ref.abs().max().item(), 1e-3), (k, err)
+
+
+def test_discriminator_shells_load_reference_state_dicts_and_refuse_the_cpu():
+    """The three shells take the reference modules' state_dicts key for key (strict), and there is no CPU path."""
+    from stylish_tts_amd import lib as L
+    from stylish_tts_amd.discriminators import ContextFreeDiscriminator, PitchDiscriminator, SpecDiscriminator
+    _, p = _fixture()
+    m = SpecDiscriminator()
+    m.load_state_dict(p, strict=True)
+    with pytest.raises(L.StyError):
+        m(torch.zeros(1, 1, 9, 9))
+    _, pc = _cf_fixture()
+    c = ContextFreeDiscriminator()
+    c.load_state_dict(pc, strict=True)
+    with pytest.raises(L.StyError):
+        c(torch.zeros(1, 2048))
+    for name, dim_in, k in (("pitch", 2, 21), ("dur", 1, 5)):
+        _, pp = _pd_fixture(name)
+        d = PitchDiscriminator(dim_in=dim_in, kernel=k)
+        d.load_state_dict(pp, strict=True)
+        with pytest.raises(L.StyError):
+            d(torch.zeros(1, dim_in, 16))
