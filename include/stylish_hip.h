@@ -244,6 +244,11 @@ int sty_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
 int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *style, void *workspace, size_t ws_bytes,
                         void *stream);
 int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
+/* PitchStyleEncoder (mel_style_encoder.py:155-205, the second-stage `pe_style_encoder`) in the training graph: forward, then
+ * sty_style_bwd; x [B,dim_in,T], pitch, energy [B,T] are data (no gradient), parameter gradients as for the other kinds.   */
+int sty_pitch_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
+int sty_pitch_style_fwd_train(sty_model *m, int B, int T, const float *mel, const float *pitch, const float *energy,
+                              float *style, void *workspace, size_t ws_bytes, void *stream);
 
 /* ---- one dense Conv1d ('same' padding, torch.nn.functional.conv1d semantics) on the MFMA implicit-GEMM kernel every
  * conv / Linear of the path runs on; for unit parity tests and kernel tuning.  x [B,Cin,T], w [Cout,Cin,K],

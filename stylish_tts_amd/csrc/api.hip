@@ -2488,8 +2488,44 @@ int sty_style_fwd_train(sty_model* m, int B, int T, const float* mel, float* sty
   if (!m->trainer) m->trainer = trainer_create(m);
   return trainer_style_forward(m->trainer, B, T, mel, style, workspace, ws_bytes, S(stream), nullptr);
 }
+// PitchStyleEncoder in the training graph (the second-stage `pe_style_encoder`): forward, then sty_style_bwd
+int sty_pitch_style_train_workspace_bytes(sty_model* m, int B, int T, size_t* bytes) {
+  int rc = model_ready(m, "pitch_style_encoder");
+  if (rc) return rc;
+  if (!m->train_enabled || !bytes || B <= 0 || T < 40) {
+    set_error("sty_pitch_style_train_workspace_bytes: bad argument or training not enabled");
+    return STY_EINVAL;
+  }
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_style_forward(m->trainer, B, T, nullptr, nullptr, nullptr, 0, nullptr, bytes);
+}
+int sty_pitch_style_fwd_train(sty_model* m, int B, int T, const float* mel, const float* pitch, const float* energy,
+                              float* style, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "pitch_style_encoder");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  if (!mel || !pitch || !energy || !style || !workspace || B <= 0 || T < 40) {
+    set_error("sty_pitch_style_fwd_train: bad argument (T >= 40 frames)");
+    return STY_EINVAL;
+  }
+  if (m->topts.sn_power_iter) {
+    for (const PackJob& j : m->jobs) {
+      if (j.kind != PK_CONV2D_SN && j.kind != PK_DW2D_SN) continue;
+      const int n = j.kind == PK_CONV2D_SN ? j.Cin * j.KH * j.K : 9;
+      rc = launch_sn_power_iter(j.w, const_cast<float*>(j.g), const_cast<float*>(j.v), j.Cout, n, j.scratch2, S(stream));
+      if (rc) return rc;
+    }
+  }
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->prepared = false;
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_style_forward(m->trainer, B, T, mel, style, workspace, ws_bytes, S(stream), nullptr, pitch, energy);
+}
 int sty_style_bwd(sty_model* m, const float* d_style, void* stream) {
-  int rc = model_ready(m, "mel_style_encoder");
+  int rc = model_ready(m, "mel_style_encoder", "pitch_style_encoder");
   if (rc) return rc;
   if (!m->trainer || !d_style) {
     set_error("sty_style_bwd: no recorded forward or null gradient");

@@ -338,7 +338,7 @@ int launch_box_smooth(const float* x, int B, int T, int width, float* y, int acc
 size_t sn_power_iter_scratch_floats(int Cout, int n);
 int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st);
 int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
-                          hipStream_t st, size_t* need);
+                          hipStream_t st, size_t* need, const float* pitch = nullptr, const float* energy = nullptr);
 int trainer_style_backward(struct Trainer* t, const float* d_style, hipStream_t st);
 struct Trainer;
 Trainer* trainer_create(sty_model* m);

@@ -1177,7 +1177,11 @@ struct Trainer {
   }
 
   float* style_out = nullptr;
-  void style_forward(const float* mel, int Tt, float* style_dst) {
+  // pitch / energy != nullptr: PitchStyleEncoder (mel_style_encoder.py:155-205, coarse_multiplier 1): the trunk runs on
+  // preconv(cat(mel, pitch, energy)) -- a weight-normed Conv1d(k = 1, padding = 1), so T + 2 frames -- and the backward
+  // reaches the preconv's parameters (the three inputs are data: no gradient)
+  void style_forward(const float* mel, int Tt, float* style_dst, const float* pitch = nullptr,
+                     const float* energy = nullptr) {
     const StylePlan& sp = m->sty_enc;
     tape.clear();
     gmap.clear();
@@ -1189,6 +1193,24 @@ struct Trainer {
       if (e != hipSuccess) rc = hip_fail(e, "grad arena memset");
     }
     const float r2 = 0.70710678118654752f;
+    const bool pse = pitch != nullptr;
+    float* pre = nullptr;
+    if (pse) {
+      const int Cc = m->pse_pre.Cin, D = m->pse_pre.Cout, Tp = Tt + 2;
+      float* cat = take<float>((size_t)B * Cc * Tt);
+      float* padded = take<float>((size_t)B * Cc * Tp);
+      pre = take<float>((size_t)B * D * Tp);
+      if (live()) {
+        const float* src[3] = {mel, pitch, energy};
+        const int cs[3] = {Cc - 2, 1, 1};
+        chk(launch_concat(src, cs, 3, B, Tt, cat, st));
+        chk(launch_pad_time(cat, B * Cc, Tt, 1, padded, st));
+      }
+      nograd.insert(padded);
+      conv(base(m->pse_pre, padded, Tp, pre));
+      mel = pre;
+      Tt = Tp;
+    }
     int H = sp.n_mels, W = Tt, C = sp.n_mels;
     auto mask_for = [&](int Hh, int Ww, int Hv, int Wv) {
       float* mk = take<float>((size_t)B * Hh * (Ww + 1));
@@ -1197,7 +1219,21 @@ struct Trainer {
     };
     float* melp = take<float>((size_t)B * H * (W + 1));
     if (live()) chk(launch_pad_cols(mel, (size_t)B * H, W, melp, st));
-    nograd.insert(melp);
+    if (!pse) {
+      nograd.insert(melp);
+    } else {  // the padded image is the preconv's output: its gradient goes back without the pad column
+      const int Wc = W, Hc = H;
+      tape.push_back([this, melp, pre, Hc, Wc]() {
+        const size_t rows = (size_t)B * Hc;
+        float* gp = G(melp, rows * (Wc + 1));
+        float* gx = G(pre, rows * Wc);
+        if (live()) {
+          hipError_t e = hipMemcpy2DAsync(gx, (size_t)Wc * 4, gp, (size_t)(Wc + 1) * 4, (size_t)Wc * 4, rows,
+                                          hipMemcpyDeviceToDevice, st);
+          if (e != hipSuccess) rc = hip_fail(e, "un-pad copy");
+        }
+      });
+    }
     const float* mk = mask_for(H, W, H, W);
     float* x = take<float>((size_t)B * C * H * (W + 1));
     conv2d(sp.stem, melp, 1, H * (W + 1), W + 1, x, 1, 1, PRO_NONE, 1.f, nullptr, mk);
@@ -1597,7 +1633,7 @@ int trainer_wait_d_style(Trainer* t, hipStream_t stream) {
 }
 
 int trainer_style_forward(Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
-                          hipStream_t st, size_t* need) {
+                          hipStream_t st, size_t* need, const float* pitch, const float* energy) {
   t->st = st;
   t->B = B;
   t->T = T;
@@ -1608,7 +1644,10 @@ int trainer_style_forward(Trainer* t, int B, int T, const float* mel, float* sty
   t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
   t->peak = 0;
   t->side_need = 0;
-  t->style_forward(need ? reinterpret_cast<const float*>(8) : mel, T, need ? reinterpret_cast<float*>(16) : style);
+  const bool pse = t->m->kind == "pitch_style_encoder";
+  t->style_forward(need ? reinterpret_cast<const float*>(8) : mel, T, need ? reinterpret_cast<float*>(16) : style,
+                   pse ? (need ? reinterpret_cast<const float*>(24) : pitch) : nullptr,
+                   pse ? (need ? reinterpret_cast<const float*>(32) : energy) : nullptr);
   if (need) {
     if (t->rc == STY_OK) t->style_backward(nullptr);
     *need = align_up(t->peak, 256) + (16 << 20);

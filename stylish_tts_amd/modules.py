@@ -731,6 +731,33 @@ class PitchStyleEncoder(_HipModule):
                                         ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return out
 
+    def forward_train(self, x, pitch, energy):
+        """PitchStyleEncoder.forward in the training graph (train_textual's `pe_style_encoder`); follow with
+        backward(d_style).  The three inputs are data: gradients go to the parameters only."""
+        dev = x.device
+        self._train = True
+        self._tape_id += 1
+        lib = self._ensure(dev)
+        B, _, T = x.shape
+        x, pitch, energy = _f32(x.detach(), dev), _f32(pitch.detach(), dev), _f32(energy.detach(), dev)
+        out = torch.empty(B, self.cfg["style_dim"], dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_pitch_style_train_workspace_bytes(self._handle, B, T, C.byref(need)))
+        if getattr(self, "_train_ws", None) is None or self._train_ws.numel() < need.value:
+            self._train_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self._train_keep = [x, pitch, energy]
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_pitch_style_fwd_train(self._handle, B, T, L.ptr(x), L.ptr(pitch), L.ptr(energy), L.ptr(out),
+                                              L.ptr(self._train_ws), self._train_ws.numel(), st))
+        return out
+
+    def backward(self, d_style):
+        """d loss / d style [B, style_dim]; parameter gradients are added to param.grad."""
+        lib = L.load()
+        d_style = _f32(d_style, d_style.device)
+        st = C.c_void_p(torch.cuda.current_stream(d_style.device).cuda_stream)
+        L.check(lib.sty_style_bwd(self._handle, L.ptr(d_style), st))
+
 
 class DurationProcessor(torch.nn.Module):
     """train/utils.py:656-803: class distribution -> expected duration -> soft alignment.  Host-side glue on device

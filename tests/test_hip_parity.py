@@ -1417,6 +1417,37 @@ def test_export_model_text_to_audio_vs_oracle(env):
     assert mse <= 1e-6 and _mel_l1(audio.cpu().unsqueeze(1), ref) <= 1e-3
 
 
+def test_pitch_style_encoder_training_graph_vs_oracle_autograd():
+    """PitchStyleEncoder forward_train + backward (the trainable `pe_style_encoder` of train_textual, stage_type.py:
+    119-121): style and parameter gradients -- preconv g / v / bias through the weight_norm chain and trunk parameters --
+    against autograd on the oracle (itself pinned to the reference's forward by pse_small)."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle import predictors as OP
+    from oracle.manifest import pitch_style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    g = load_file(os.path.join(G, "pse_small.safetensors"))
+    P = fill_state_dict(pitch_style_encoder_manifest(), 5)
+    keys = ["preconv.parametrizations.weight.original0", "preconv.parametrizations.weight.original1", "preconv.bias",
+            "shared.0.weight_orig", "shared.2.conv1.weight_orig", "shared.4.conv2.bias", "unshared.weight", "unshared.bias"]
+    Pr = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in P.items()}
+    s_ref = OP.pitch_style_encoder(Pr, g["mel"], g["pitch"], g["energy"])
+    seed = torch.randn(s_ref.shape, generator=torch.Generator().manual_seed(2))
+    (s_ref * seed).sum().backward()
+    m = S.PitchStyleEncoder()
+    m.load_state_dict(P)
+    m = m.to(DEV).enable_training()
+    s = m.forward_train(dev(g["mel"]), dev(g["pitch"]), dev(g["energy"]))
+    m.backward(dev(seed))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("style", s, s_ref.detach(), 2e-5)
+    nm = dict(m.named_parameters())
+    for k in keys:
+        rep.add("d " + k[-40:], nm[k].grad, Pr[k].grad, 5e-5)
+    rep.done()
+
+
 def test_pitch_style_encoder_vs_reference_golden():
     """PitchStyleEncoder (the pe_style_encoder of build_model) on the HIP path vs the reference's output
     (tests/golden/pse_small.safetensors): 1x1 weight-normed preconv with padding 1, then the MelStyleEncoder plan."""
