@@ -244,6 +244,13 @@ int sty_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
 int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *style, void *workspace, size_t ws_bytes,
                         void *stream);
 int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
+/* PitchEnergyPredictor (pitch_energy_predictor.py:62-82) in the training graph: forward -> pitch, energy [B,T]; backward
+ * from d_pitch, d_energy [B,T] adds the parameter gradients and writes d_style [B,64] (may be NULL).                    */
+int sty_pitch_energy_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);
+int sty_pitch_energy_fwd_train(sty_model *m, int B, int L, int T, const int64_t *texts, const int64_t *text_lengths,
+                               const float *alignment, const float *style, float *pitch, float *energy, void *workspace,
+                               size_t ws_bytes, void *stream);
+int sty_pitch_energy_bwd(sty_model *m, const float *d_pitch, const float *d_energy, float *d_style, void *stream);
 /* PitchStyleEncoder (mel_style_encoder.py:155-205, the second-stage `pe_style_encoder`) in the training graph: forward, then
  * sty_style_bwd; x [B,dim_in,T], pitch, energy [B,T] are data (no gradient), parameter gradients as for the other kinds.   */
 int sty_pitch_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);

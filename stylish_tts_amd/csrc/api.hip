@@ -2073,6 +2073,50 @@ static int pitch_energy_run(sty_model* m, int B, int L, int T, const int64_t* te
   }
   return r.rc;
 }
+// PitchEnergyPredictor in the training graph (train_textual, stage_type.py:119-127): forward, then sty_pitch_energy_bwd
+int sty_pitch_energy_train_workspace_bytes(sty_model* m, int B, int L, int T, size_t* bytes) {
+  int rc = model_ready(m, "pitch_energy_predictor");
+  if (rc) return rc;
+  if (!m->train_enabled || !bytes || B <= 0 || L <= 0 || T <= 0) {
+    set_error("sty_pitch_energy_train_workspace_bytes: bad argument or training not enabled");
+    return STY_EINVAL;
+  }
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_pitch_energy_forward(m->trainer, B, L, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                      nullptr, bytes);
+}
+int sty_pitch_energy_fwd_train(sty_model* m, int B, int L, int T, const int64_t* texts, const int64_t* text_lengths,
+                               const float* alignment, const float* style, float* pitch, float* energy, void* workspace,
+                               size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "pitch_energy_predictor");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  if (!texts || !text_lengths || !alignment || !style || !pitch || !energy || !workspace || B <= 0 || L <= 0 || T <= 0) {
+    set_error("sty_pitch_energy_fwd_train: bad argument");
+    return STY_EINVAL;
+  }
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->prepared = false;
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_pitch_energy_forward(m->trainer, B, L, T, texts, text_lengths, alignment, style, pitch, energy, workspace,
+                                      ws_bytes, S(stream), nullptr);
+}
+int sty_pitch_energy_bwd(sty_model* m, const float* d_pitch, const float* d_energy, float* d_style, void* stream) {
+  int rc = model_ready(m, "pitch_energy_predictor");
+  if (rc) return rc;
+  if (!m->trainer || !d_pitch || !d_energy) {
+    set_error("sty_pitch_energy_bwd: no recorded forward or null gradient");
+    return STY_ESTATE;
+  }
+  rc = trainer_pitch_energy_backward(m->trainer, d_pitch, d_energy, d_style, S(stream));
+  if (rc) return rc;
+  if ((rc = unpack_grads(m, S(stream)))) return rc;
+  if (m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
+  return STY_OK;
+}
 int sty_pitch_energy_workspace_bytes(const sty_model* m, int B, int L, int T, size_t* bytes) {
   int rc = model_ready(m, "pitch_energy_predictor");
   if (rc) return rc;

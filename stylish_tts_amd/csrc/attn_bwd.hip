@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void attn_bwd_b_kernel(AttnArgs a, const float
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          float* __restrict__ dK, size_t dkbs, float* __restrict__ dV,
                                                          size_t dvbs) {
-  __shared__ float ks[DH * 65], vs[DH * 65];
+  extern __shared__ float abw_lds[];  // dynamic: 2 * DH * 65 floats (83 KB at DH = 160)
+  float* ks = abw_lds;
+  float* vs = abw_lds + DH * 65;
   const int T = a.T, b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * 64, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = j0 + lane;
@@ -359,7 +361,16 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
   const bool drop = a.drop_p > 0.f;
 #define STY_ABWD(DHV, DR)                                                                                            \
   hipLaunchKernelGGL(attn_bwd_a_kernel<DHV>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta);                        \
-  hipLaunchKernelGGL((attn_bwd_b_kernel<DHV, DR>), grid, dim3(256), 0, st, a, dO, dobs, lse, delta, dK, dkbs, dV, dvbs); \
+  if ((DHV) > 96) {                                                                                                  \
+    static bool raised_ = false;                                                                                     \
+    if (!raised_) {                                                                                                  \
+      STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_b_kernel<DHV, DR>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (DHV) * 65 * 4));                  \
+      raised_ = true;                                                                                                \
+    }                                                                                                                \
+  }                                                                                                                  \
+  hipLaunchKernelGGL((attn_bwd_b_kernel<DHV, DR>), grid, dim3(256), 2 * (DHV) * 65 * sizeof(float), st, a, dO, dobs, lse, delta, \
+                     dK, dkbs, dV, dvbs);                                                                            \
   hipLaunchKernelGGL((attn_bwd_c_kernel<DHV, DR>), grid, dim3(64), 0, st, a, dO, dobs, lse, delta, dQ, dqbs)
   if (DH == 64 && !drop) {
     STY_ABWD(64, false);
@@ -367,6 +378,10 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
     STY_ABWD(16, false);
   } else if (DH == 16) {
     STY_ABWD(16, true);
+  } else if (DH == 160 && !drop) {  // prosody encoder of the pitch / energy predictor: 2 heads x (256 + 64) / 2
+    STY_ABWD(160, false);
+  } else if (DH == 160) {
+    STY_ABWD(160, true);
   } else {
     set_error("attention_bwd: head dim %d%s not built", DH, drop ? " with dropout" : "");
     return STY_EINVAL;

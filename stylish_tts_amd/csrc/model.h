@@ -18,8 +18,9 @@ int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st);
 int launch_pack_w2a(const float* w2, const float* b2, const float* grn_beta, int C, float* w2a, float* b2eff,
                     hipStream_t st);
 int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st);
-int launch_rope_n(float* q, float* k, int B, int H, int DH, int L, int d, hipStream_t st);
+int launch_rope_n(float* q, float* k, int B, int H, int DH, int L, int d, hipStream_t st, float sgn = 1.0f);
 int launch_style_expand(const float* style, int B, int S, int L, float* y, hipStream_t st);
+int launch_row_sum_add(const float* src, int rows, int L, float* dst, hipStream_t st);
 int launch_scale_copy(const float* x, float a, size_t n, float* y, hipStream_t st);
 int launch_mask_mul(float* x, const float* mask, int B, int C, int T, hipStream_t st);
 int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStream_t st);
@@ -351,6 +352,10 @@ int trainer_block_fwd_bwd(Trainer* t, int kind, const void* blk, int B, int C, i
 void trainer_set_segment_hook(Trainer* t, std::function<void(int)> fn);  // called once segment 0's gradients are final
 bool single_stream_mode();  // sty_set_single_stream: no internal side streams (measurement aid)
 int trainer_wait_d_style(Trainer* t, hipStream_t stream);
+int trainer_pitch_energy_forward(Trainer* t, int B, int L, int T, const int64_t* texts, const int64_t* lengths,
+                                 const float* alignment, const float* style, float* pitch, float* energy, void* ws,
+                                 size_t ws_bytes, hipStream_t st, size_t* need);
+int trainer_pitch_energy_backward(Trainer* t, const float* d_pitch, const float* d_energy, float* d_style, hipStream_t st);
 void trainer_destroy(Trainer* t);
 int trainer_vocoder_forward(Trainer* t, const sty_vocoder_io* io, void* ws, size_t ws_bytes, hipStream_t st,
                             size_t* need);

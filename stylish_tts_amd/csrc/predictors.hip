@@ -9,7 +9,7 @@ namespace sty {
 
 // partial RoPE, any even d <= DH, in place on q and k [B][H*DH][L] (text_encoder.py:111-168):
 // theta_i = 10000^(-2i/d); (x_i, x_{i+d/2}) rotated by pos * theta_i
-__global__ void rope_n_kernel(float* __restrict__ q, float* __restrict__ k, int H, int DH, int L, int d) {
+__global__ void rope_n_kernel(float* __restrict__ q, float* __restrict__ k, int H, int DH, int L, int d, float sgn) {
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   if (pos >= L) return;
@@ -17,7 +17,7 @@ __global__ void rope_n_kernel(float* __restrict__ q, float* __restrict__ k, int 
   float* ptr[2] = {q, k};
   for (int i = 0; i < half; ++i) {
     const float theta = 1.0f / powf(10000.0f, (float)(2 * i) / (float)d);
-    const float ang = (float)pos * theta;
+    const float ang = sgn * (float)pos * theta;  // sgn = -1: the transpose rotation (backward)
     const float cs = cosf(ang), sn = sinf(ang);
     for (int w = 0; w < 2; ++w) {
       float* base = ptr[w] + ((size_t)b * H + h) * DH * L + pos;
@@ -27,12 +27,12 @@ __global__ void rope_n_kernel(float* __restrict__ q, float* __restrict__ k, int 
     }
   }
 }
-int launch_rope_n(float* q, float* k, int B, int H, int DH, int L, int d, hipStream_t st) {
+int launch_rope_n(float* q, float* k, int B, int H, int DH, int L, int d, hipStream_t st, float sgn) {
   if (d <= 0 || d > DH || (d & 1)) {
     set_error("rope: bad rotary width %d for head dim %d", d, DH);
     return STY_EINVAL;
   }
-  hipLaunchKernelGGL(rope_n_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d);
+  hipLaunchKernelGGL(rope_n_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d, sgn);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -48,6 +48,20 @@ __global__ void style_expand_kernel(const float* __restrict__ s, int S, int L, f
 }
 int launch_style_expand(const float* style, int B, int S, int L, float* y, hipStream_t st) {
   hipLaunchKernelGGL(style_expand_kernel, dim3(cdiv(S * L, 256), B), dim3(256), 0, st, style, S, L, y);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// dst[r] += sum_t src[r][t]   (gradient of style_expand; one thread per row, L <= a few hundred)
+__global__ void row_sum_add_kernel(const float* __restrict__ src, int rows, int L, float* __restrict__ dst) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int t = 0; t < L; ++t) s += src[(size_t)r * L + t];
+  dst[r] += s;
+}
+int launch_row_sum_add(const float* src, int rows, int L, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(row_sum_add_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, st, src, rows, L, dst);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

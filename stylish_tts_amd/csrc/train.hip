@@ -728,7 +728,7 @@ struct Trainer {
     return o;
   }
   // separate q / k / v tensors [B][H*DH][L] with an optional length mask (text encoder)
-  float* attention3(const float* q, const float* k, const float* v, int Hd, int L, const int64_t* lengths) {
+  float* attention3(const float* q, const float* k, const float* v, int Hd, int L, const int64_t* lengths, int heads = 8) {
     const size_t n = (size_t)B * Hd * L;
     float* o = take<float>(n);
     AttnArgs at;
@@ -738,23 +738,23 @@ struct Trainer {
     at.o = o;
     at.qbs = at.kbs = at.vbs = at.obs = (size_t)Hd * L;
     at.T = L;
-    at.H = 8;
-    at.scale = 1.0f / sqrtf((float)(Hd / 8));
+    at.H = heads;
+    at.scale = 1.0f / sqrtf((float)(Hd / heads));
     at.lengths = lengths;
     if (dropout_on() && m->topts.text_dropout > 0.f) {  // SDPA dropout_p on the attention probabilities
       at.drop_p = m->topts.text_dropout;
       at.drop_seed = m->topts.dropout_seed;
       at.drop_site = drop_site++;
     }
-    if (live()) chk(launch_attention(at, B, Hd / 8, st));
+    if (live()) chk(launch_attention(at, B, Hd / heads, st));
     tape.push_back([=]() {
       float* gO = G(o, n);
       float* gQ = G(q, n);
       float* gK = G(k, n);
       float* gV = G(v, n);
       const size_t mark = ws.off;
-      float* w2 = take<float>(attention_bwd_ws_floats(B, 8, L));
-      if (live()) chk(launch_attention_bwd(at, gO, gQ, gK, gV, at.qbs, at.kbs, at.vbs, at.obs, B, Hd / 8, w2, st));
+      float* w2 = take<float>(attention_bwd_ws_floats(B, heads, L));
+      if (live()) chk(launch_attention_bwd(at, gO, gQ, gK, gV, at.qbs, at.kbs, at.vbs, at.obs, B, Hd / heads, w2, st));
       ws.off = mark;
     });
     return o;
@@ -902,15 +902,26 @@ struct Trainer {
   // AdaptiveDecoderBlock (ada_norm.py:180-192)
   float* dec_block(const DecBlock& d, const float* xcat, int Tt) {
     const float r2 = 0.70710678118654752f;
-    if (!d.has_sc) {
-      set_error("decoder block without learned shortcut is not built");
-      rc = STY_EINVAL;
-      return nullptr;
-    }
     float* sc = take<float>((size_t)B * d.Cout * Tt);
-    ConvArgs cs = base(d.sc, xcat, Tt, sc);
-    cs.out_scale = r2;
-    conv(cs);
+    if (d.has_sc) {
+      ConvArgs cs = base(d.sc, xcat, Tt, sc);
+      cs.out_scale = r2;
+      conv(cs);
+    } else {  // identity shortcut (pitch / energy stacks of the second stage): (h + x) / sqrt(2)
+      if (d.Cin != d.Cout) {
+        set_error("decoder block: identity shortcut needs Cin == Cout");
+        rc = STY_EINVAL;
+        return nullptr;
+      }
+      const size_t n = (size_t)B * d.Cout * Tt;
+      if (live()) chk(launch_scale_copy(xcat, r2, n, sc, st));
+      tape.push_back([=]() {
+        if (!wants(xcat)) return;
+        float* g = G(sc, n);
+        float* gx = G(xcat, n);
+        if (live()) chk(launch_row_scale_add(g, nullptr, r2, B * d.Cout, Tt, gx, st));
+      });
+    }
     float *a, *s;
     adain(xcat, d.Cin, Tt, d.n1, a, s);
     float* h = take<float>((size_t)B * d.Cout * Tt);
@@ -987,6 +998,155 @@ struct Trainer {
       if (!x) return nullptr;
     }
     return x;
+  }
+
+
+  // y = x * mask[b][t]  (out of place, on the tape)
+  float* mask_mul(const float* x, const float* mask, int C, int Tt) {
+    const size_t n = (size_t)B * C * Tt;
+    float* y = take<float>(n);
+    if (live()) {
+      hipError_t e = hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "mask copy");
+      chk(launch_mask_mul(y, mask, B, C, Tt, st));
+    }
+    tape.push_back([=]() {
+      if (!wants(x)) return;
+      float* gY = G(y, n);
+      float* gX = G(x, n);
+      if (live()) {
+        chk(launch_mask_mul(gY, mask, B, C, Tt, st));  // (gY is dead afterwards)
+        chk(launch_row_scale_add(gY, nullptr, 1.0f, B * C, Tt, gX, st));
+      }
+    });
+    return y;
+  }
+
+  // PitchEnergyPredictor.forward in the training graph (pitch_energy_predictor.py:62-82; ProsodyEncoder,
+  // prosody_encoder.py:63-81: three layers of 2-head attention with partial RoPE on head dimension 96, AdaLN, a 1x1 FFN and
+  // a projection back to inter_dim, the style re-attached after every layer; two stacks of four AdaptiveDecoderBlocks)
+  float *pe_f0 = nullptr, *pe_n = nullptr, *pe_sx = nullptr;
+  int pe_L = 0;
+  void pitch_energy(const int64_t* tokens, const int64_t* lengths, const float* ali, int L, int Tt) {
+    const PitchEnergyPlan& p = m->pe;
+    const int D = m->te.proj_m.Cout, S = m->style_dim, HC = D + S, H = p.heads, DH = HC / H;
+    const size_t nh = (size_t)B * HC * L;
+    float* enc = text_encoder(tokens, lengths, L);
+    float* mask = take<float>((size_t)B * L);
+    float* sx = take<float>((size_t)B * S * L);
+    if (live()) {
+      chk(launch_length_mask(lengths, B, L, mask, st));
+      chk(launch_style_expand(style, B, S, L, sx, st));
+    }
+    nograd.insert(mask);
+    pe_sx = sx;  // its gradient, summed over the tokens, joins d_style at the end of the backward
+    pe_L = L;
+    const float* s0[2] = {enc, sx};
+    const int cs[2] = {D, S};
+    float* x = concat(s0, cs, 2, L);
+    const float pd = m->topts.text_dropout;
+    const bool dr = dropout_on() && pd > 0.f;
+    for (const ProsodyLayer& l : p.layers) {
+      float* xm = mask_mul(x, mask, HC, L);
+      float* q = take<float>(nh);
+      float* k = take<float>(nh);
+      float* v = take<float>(nh);
+      conv(base(l.q, xm, L, q));
+      conv(base(l.k, xm, L, k));
+      conv(base(l.v, xm, L, v));
+      float* qr = take<float>(nh);
+      float* kr = take<float>(nh);
+      if (live()) {
+        hipError_t e = hipMemcpyAsync(qr, q, nh * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(kr, k, nh * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) rc = hip_fail(e, "rope copy");
+        chk(launch_rope_n(qr, kr, B, H, DH, L, DH / 2, st));
+      }
+      tape.push_back([=]() {
+        float* gqr = G(qr, nh);
+        float* gkr = G(kr, nh);
+        float* gq = G(q, nh);
+        float* gk = G(k, nh);
+        if (live()) {
+          chk(launch_rope_n(gqr, gkr, B, H, DH, L, DH / 2, st, -1.0f));
+          chk(launch_row_scale_add(gqr, nullptr, 1.0f, B * HC, L, gq, st));
+          chk(launch_row_scale_add(gkr, nullptr, 1.0f, B * HC, L, gk, st));
+        }
+      });
+      float* o = attention3(qr, kr, v, HC, L, lengths, H);
+      float* h1 = take<float>(nh);
+      ConvArgs ao = base(l.o, o, L, h1);
+      if (dr) {  // x + drop(attn(x))  (prosody_encoder.py:72-74)
+        conv(ao);
+        h1 = dropout(h1, pd, HC, L, xm);
+      } else {
+        ao.residual = xm;
+        conv(ao);
+      }
+      float* x2 = layernorm(h1, HC, L, 1e-5f, &l.n1, nullptr, nullptr);
+      const int Fc = l.f1.Cout;
+      float* f0 = take<float>((size_t)B * Fc * L);
+      ConvArgs f1 = base(l.f1, x2, L, f0);
+      f1.pro = PRO_MASK;
+      f1.mask = mask;
+      conv(f1);
+      float* fr = act(ACT_RELU, f0, nullptr, Fc, L);
+      if (dr) fr = dropout(fr, pd, Fc, L, nullptr);
+      float* h2 = take<float>(nh);
+      ConvArgs f2 = base(l.f2, fr, L, h2);
+      f2.pro = PRO_MASK;
+      f2.mask = mask;
+      f2.out_mask = mask;
+      if (dr) {
+        conv(f2);
+        h2 = dropout(h2, pd, HC, L, x2);
+      } else {
+        f2.residual = x2;
+        conv(f2);
+      }
+      float* x3 = layernorm(h2, HC, L, 1e-5f, &l.n2, nullptr, nullptr);
+      float* pj = take<float>((size_t)B * D * L);
+      conv(base(l.proj, x3, L, pj));
+      const float* s2[2] = {pj, sx};
+      x = concat(s2, cs, 2, L);
+    }
+    float* xm = mask_mul(x, mask, HC, L);
+    float* xt = expand(xm, ali, HC, L, Tt);
+    for (int which = 0; which < 2; ++which) {
+      const DecBlock* blk = which ? p.nn : p.f0;
+      const float* in = xt;
+      for (int i = 0; i < 4; ++i) {
+        in = dec_block(blk[i], in, Tt);
+        if (!in) return;
+      }
+      float* out = take<float>((size_t)B * Tt);
+      conv(base(which ? p.np : p.f0p, in, Tt, out));
+      (which ? pe_n : pe_f0) = out;
+    }
+  }
+  void pitch_energy_backward(const float* d_pitch, const float* d_energy, float* d_style) {
+    const size_t n = (size_t)B * T;
+    side_begin();
+    d_style_out = d_style;
+    fc_bwd_done = false;
+    float* g0 = G(pe_f0, n);
+    float* g1 = G(pe_n, n);
+    if (live() && d_pitch) {
+      hipError_t e = hipMemcpyAsync(g0, d_pitch, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(g1, d_energy, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "seed copy");
+    }
+    for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
+      (*it)();
+      if (rc != STY_OK) break;
+    }
+    side_join();
+    if (rc != STY_OK) return;
+    style_fc_backward();
+    if (live() && d_style && pe_sx) {  // the style channels concatenated to every prosody layer's input
+      float* gs = G(pe_sx, (size_t)B * m->style_dim * pe_L);
+      chk(launch_row_sum_add(gs, B * m->style_dim, pe_L, d_style, st));
+    }
   }
 
   // text_encoding @ alignment (speech_predictor.py:60)
@@ -1615,6 +1775,49 @@ int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, fl
     hipError_t e = hipMemcpyAsync(d_energy, g, (size_t)t->B * t->T * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) t->rc = hip_fail(e, "d_energy copy");
   }
+  if (t->ws.overflow) {
+    set_error("training workspace too small in backward: need %zu bytes", t->peak);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_pitch_energy_forward(Trainer* t, int B, int L, int T, const int64_t* texts, const int64_t* lengths,
+                                 const float* alignment, const float* style, float* pitch, float* energy, void* ws,
+                                 size_t ws_bytes, hipStream_t st, size_t* need) {
+  t->st = st;
+  t->B = B;
+  t->T = T;
+  t->rc = STY_OK;
+  t->ws = Bump();
+  t->dry = need != nullptr;
+  t->ws.base = need ? reinterpret_cast<char*>(size_t(1) << 30) : (char*)ws;
+  t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
+  t->peak = 0;
+  t->begin(style);
+  t->style_fc(nullptr);
+  t->pitch_energy(texts, lengths, alignment, L, T);
+  if (need) {
+    if (t->rc == STY_OK) t->pitch_energy_backward(nullptr, nullptr, reinterpret_cast<float*>(0));
+    *need = align_up(t->peak, 256) + (64 << 20);
+    t->tape.clear();
+    return t->rc;
+  }
+  if (t->rc == STY_OK && t->live() && t->pe_f0 && t->pe_n) {
+    hipError_t e = hipMemcpyAsync(pitch, t->pe_f0, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(energy, t->pe_n, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "output copy");
+  }
+  if (t->ws.overflow) {
+    set_error("training workspace too small: need %zu bytes, have %zu", t->peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_pitch_energy_backward(Trainer* t, const float* d_pitch, const float* d_energy, float* d_style, hipStream_t st) {
+  t->st = st;
+  t->pitch_energy_backward(d_pitch, d_energy, d_style);
   if (t->ws.overflow) {
     set_error("training workspace too small in backward: need %zu bytes", t->peak);
     return STY_ENOMEM;

@@ -123,6 +123,9 @@ SYMBOLS = {
     "sty_specdisc_forward": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _P]),
     "sty_specdisc_losses": (C.c_int, [_P, _I, _I, _I, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _I, _P, C.c_size_t,
                                       _P]),
+    "sty_pitch_energy_train_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
+    "sty_pitch_energy_fwd_train": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sty_pitch_energy_bwd": (C.c_int, [_P, _P, _P, _P, _P]),
     "sty_pitch_style_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_pitch_style_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_pitchdisc_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _I, _SZP]),

@@ -702,6 +702,39 @@ class PitchEnergyPredictor(_HipModule):
                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return f0, en
 
+    def forward_train(self, texts, text_lengths, alignment, style):
+        """PitchEnergyPredictor.forward in the training graph (train_textual, stage_type.py:119-127); follow with
+        backward(d_pitch, d_energy) -> d_style.  Dropout follows set_train_opts(dropout_seed=, text_dropout=)."""
+        dev = style.device
+        self._train = True
+        self._tape_id += 1
+        lib = self._ensure(dev)
+        B, Lt = texts.shape
+        T = alignment.shape[2]
+        tx, tl = texts.to(dev, torch.int64).contiguous(), text_lengths.to(dev, torch.int64).contiguous()
+        al, st = _f32(alignment.detach(), dev), _f32(style.detach(), dev)
+        f0 = torch.empty(B, T, dtype=torch.float32, device=dev)
+        en = torch.empty(B, T, dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_pitch_energy_train_workspace_bytes(self._handle, B, Lt, T, C.byref(need)))
+        if getattr(self, "_train_ws", None) is None or self._train_ws.numel() < need.value:
+            self._train_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self._train_keep = [tx, tl, al, st]
+        L.check(lib.sty_pitch_energy_fwd_train(self._handle, B, Lt, T, L.ptr(tx), L.ptr(tl), L.ptr(al), L.ptr(st),
+                                               L.ptr(f0), L.ptr(en), L.ptr(self._train_ws), self._train_ws.numel(),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return f0, en
+
+    def backward(self, d_pitch, d_energy):
+        """d loss / d (F0, N) [B,T] each -> d loss / d style [B, style_dim]; parameter gradients are added to .grad."""
+        lib = L.load()
+        dev = d_pitch.device
+        dp, de = _f32(d_pitch, dev), _f32(d_energy, dev)
+        d_style = torch.empty(dp.shape[0], self.cfg["style_dim"], dtype=torch.float32, device=dev)
+        L.check(lib.sty_pitch_energy_bwd(self._handle, L.ptr(dp), L.ptr(de), L.ptr(d_style),
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return d_style
+
 
 class PitchStyleEncoder(_HipModule):
     """PitchStyleEncoder(dim_in, style_dim, max_conv_dim, skip_downsamples, coarse_multiplier).forward(x, pitch, energy)

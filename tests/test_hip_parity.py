@@ -1417,6 +1417,58 @@ def test_export_model_text_to_audio_vs_oracle(env):
     assert mse <= 1e-6 and _mel_l1(audio.cpu().unsqueeze(1), ref) <= 1e-3
 
 
+def test_pitch_energy_predictor_training_graph_vs_oracle_autograd(env):
+    """PitchEnergyPredictor forward_train + backward (the trainable model of train_textual, stage_type.py:119-127), dropout
+    off: outputs, d_style and parameter gradients (text encoder, prosody encoder incl. the 2 x 160 attention with partial
+    RoPE and AdaLN, both AdaptiveDecoderBlock stacks with learned and identity shortcuts, heads) against autograd on the
+    float64 oracle (pinned to the reference's forward by n3_small)."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle import predictors as OP
+    gold = load_file(os.path.join(G, "n3_small.safetensors"))
+    cs = env["cs"]
+    _, _, _, Pp = _n3_models()
+    keys = [k for k in ("text_encoder.emb.weight", "text_encoder.proj_m.weight", "prosody_encoder.attn_layers.0.conv_q.weight",
+                        "prosody_encoder.attn_layers.2.conv_k.weight", "prosody_encoder.attn_layers.1.conv_v.bias",
+                        "prosody_encoder.attn_layers.1.conv_o.weight", "prosody_encoder.norm_layers_1.0.fc.weight",
+                        "prosody_encoder.ffn_layers.1.conv_1.weight", "prosody_encoder.ffn_layers.2.conv_2.bias",
+                        "prosody_encoder.norm_layers_2.2.fc.bias", "prosody_encoder.proj_layers.1.weight",
+                        "F0.0.conv1.parametrizations.weight.original1", "F0.0.conv1x1.parametrizations.weight.original0",
+                        "F0.2.conv2.parametrizations.weight.original1", "F0.3.norm1.fc.weight", "N.1.conv1.bias",
+                        "N.3.conv2.parametrizations.weight.original0", "F0_proj.weight", "N_proj.bias") if k in Pp]
+    assert len(keys) >= 12, [k for k in Pp][:40]
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in Pp.items()}
+    for k in keys:
+        P64[k].requires_grad_(True)
+    style64 = gold["pe_style"].double().requires_grad_(True)
+    f64, e64 = OP.pitch_energy_predictor(P64, cs["texts"], cs["text_lengths"], gold["alignment"].double(), style64)
+    g = torch.Generator().manual_seed(4)
+    s1, s2 = torch.randn(f64.shape, generator=g), torch.randn(e64.shape, generator=g)
+    (f64 * s1.double()).sum().backward(retain_graph=True)
+    (e64 * s2.double()).sum().backward()
+    pe = S.PitchEnergyPredictor()
+    pe.load_state_dict(Pp)
+    pe = pe.to(DEV).enable_training()
+    f0, en = pe.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["alignment"]), dev(gold["pe_style"]))
+    d_style = pe.backward(dev(s1), dev(s2))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("pitch", f0, f64.detach().float(), 1e-3)
+    rep.add("energy", en, e64.detach().float(), 1e-3)
+    # gate: the fp32 ORACLE's own gradients sit 1.5-2.5e-2 (of the tensor maximum) from the float64 ones on this graph
+    # (four AdaIN blocks behind three AdaLN layers: the conditioning noted in DESIGN.md section 2), so 5e-2 as for the
+    # acoustic step; biases in front of an instance norm have a structurally zero gradient and are skipped
+    rep.add("d_style", d_style, style64.grad.float(), 5e-2)
+    nm = dict(pe.named_parameters())
+    for k in keys:
+        ref = P64[k].grad.float()
+        if ref.abs().max().item() < 1e-9:
+            assert nm[k].grad.abs().max().item() < 1e-4, k
+            continue
+        rep.add("d " + k[-44:], nm[k].grad, ref, 5e-2)
+    rep.done()
+
+
 def test_pitch_style_encoder_training_graph_vs_oracle_autograd():
     """PitchStyleEncoder forward_train + backward (the trainable `pe_style_encoder` of train_textual, stage_type.py:
     119-121): style and parameter gradients -- preconv g / v / bias through the weight_norm chain and trunk parameters --
