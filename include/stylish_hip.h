@@ -234,6 +234,9 @@ int sty_vocoder_bwd(sty_model *m, const float *d_audio, float *d_mel, float *d_s
 int sty_speech_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);
 int sty_speech_fwd_train(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
 int sty_speech_bwd(sty_model *m, const float *d_audio, float *d_style, float *d_energy, void *stream);
+/* ... and d loss / d pitch [B,T] (the textual stage feeds the PREDICTED pitch and energy to the frozen speech predictor,
+ * train/stage_type.py:139-160; the harmonic source and the voiced flag carry no gradient).  Any output may be NULL.   */
+int sty_speech_bwd_pe(sty_model *m, const float *d_audio, float *d_style, float *d_pitch, float *d_energy, void *stream);
 /* d_style of the last sty_speech_bwd is complete before the text encoder's backward has run: this makes `stream` wait
  * for exactly that point, so that the style encoder's backward can start on `stream` while the call's own stream still
  * works through the text encoder (AcousticTrainer does this).                                                    */
@@ -244,6 +247,11 @@ int sty_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
 int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *style, void *workspace, size_t ws_bytes,
                         void *stream);
 int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
+/* AcousticStep.pitch_loss for one curve (train/stage_type.py:236-262: smooth_l1(target, pred) + smooth_l1 of their first
+ * differences, means): loss[0] = value; d_pred [B,T] += k * d loss / d pred with k = weight / (loss + 1e-9) when `normalize`
+ * (LossLog.backwards_loss, train/loss_log.py:82-94) or k = weight.  workspace: 16 bytes.                               */
+int sty_pitch_loss_fwd_bwd(int B, int T, const float *target, const float *pred, float weight, int normalize,
+                           float *loss, float *d_pred, void *workspace, size_t ws_bytes, void *stream);
 /* PitchEnergyPredictor (pitch_energy_predictor.py:62-82) in the training graph: forward -> pitch, energy [B,T]; backward
  * from d_pitch, d_energy [B,T] adds the parameter gradients and writes d_style [B,64] (may be NULL).                    */
 int sty_pitch_energy_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);

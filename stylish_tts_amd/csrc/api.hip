@@ -1654,6 +1654,11 @@ int sty_speech_fwd_train(sty_model* m, const sty_speech_io* io, void* workspace,
 }
 
 int sty_speech_bwd(sty_model* m, const float* d_audio, float* d_style, float* d_energy, void* stream) {
+  return sty_speech_bwd_pe(m, d_audio, d_style, nullptr, d_energy, stream);
+}
+// ... also d loss / d pitch through the Decoder's F0 conv (train_textual feeds the PREDICTED pitch / energy to the frozen
+// speech predictor, stage_type.py:139-160; the harmonic source and the voiced flag carry no gradient)
+int sty_speech_bwd_pe(sty_model* m, const float* d_audio, float* d_style, float* d_pitch, float* d_energy, void* stream) {
   int rc = model_ready(m, "speech_predictor");
   if (rc) return rc;
   if (!m->trainer || !d_audio) {
@@ -1670,7 +1675,7 @@ int sty_speech_bwd(sty_model* m, const float* d_audio, float* d_style, float* d_
     if (hook_rc == STY_OK && m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
     seg0_done = true;
   });
-  rc = trainer_speech_backward(m->trainer, d_audio, d_style, d_energy, st);
+  rc = trainer_speech_backward(m->trainer, d_audio, d_style, d_energy, st, d_pitch);
   trainer_set_segment_hook(m->trainer, nullptr);
   if (rc) return rc;
   if (hook_rc) return hook_rc;

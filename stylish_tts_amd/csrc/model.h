@@ -345,7 +345,8 @@ struct Trainer;
 Trainer* trainer_create(sty_model* m);
 int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t ws_bytes, hipStream_t st,
                            size_t* need);
-int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st);
+int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st,
+                            float* d_pitch = nullptr);
 int trainer_block_fwd_bwd(Trainer* t, int kind, const void* blk, int B, int C, int T, const float* x, const float* style,
                           const float* gy, float* y, float* gx, float* d_style, void* ws, size_t ws_bytes, hipStream_t st,
                           size_t* need);

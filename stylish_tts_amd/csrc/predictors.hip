@@ -139,4 +139,67 @@ int launch_dur_post(const float* d, const float* mask, int B, int NC, int L, flo
   return STY_OK;
 }
 
+// AcousticStep.pitch_loss (train/stage_type.py:236-262): smooth_l1(target, pred) + smooth_l1(diff(target), diff(pred)), both
+// means (beta = 1), for one [B][T] curve.  acc[0] = sum over B*T, acc[1] = sum over B*(T-1)  (doubles, zeroed by the caller)
+__device__ __forceinline__ float sl1(float d) { return fabsf(d) < 1.f ? 0.5f * d * d : fabsf(d) - 0.5f; }
+__device__ __forceinline__ float sl1_d(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
+__global__ void pitch_loss_sums_kernel(const float* __restrict__ tg, const float* __restrict__ pr, int T,
+                                       double* __restrict__ acc) {
+  __shared__ float r0[64], r1[64];
+  const int b = blockIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+  for (int t = threadIdx.x; t < T; t += 64) {
+    const size_t o = (size_t)b * T + t;
+    s0 += sl1(pr[o] - tg[o]);
+    if (t + 1 < T) s1 += sl1((pr[o + 1] - pr[o]) - (tg[o + 1] - tg[o]));
+  }
+  r0[threadIdx.x] = s0;
+  r1[threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, c = 0.0;
+    for (int i = 0; i < 64; ++i) {
+      a += r0[i];
+      c += r1[i];
+    }
+    atomicAdd(&acc[0], a);
+    atomicAdd(&acc[1], c);
+  }
+}
+// loss[0] = value; d_pred += k * d loss / d pred with k = weight / (loss + 1e-9) (LossLog.backwards_loss) or weight
+__global__ void pitch_loss_grad_kernel(const float* __restrict__ tg, const float* __restrict__ pr, int B, int T,
+                                       const double* __restrict__ acc, float weight, int normalize, float* __restrict__ loss,
+                                       float* __restrict__ d_pred) {
+  const int t = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  const double n0 = (double)B * T, n1 = (double)B * (T - 1);
+  const float L = (float)(acc[0] / n0 + (T > 1 ? acc[1] / n1 : 0.0));
+  if (t == 0 && b == 0) loss[0] = L;
+  if (t >= T) return;
+  const float k = normalize ? weight / (L + 1e-9f) : weight;
+  const size_t o = (size_t)b * T + t;
+  float g = sl1_d(pr[o] - tg[o]) / (float)n0;
+  if (t + 1 < T) g -= sl1_d((pr[o + 1] - pr[o]) - (tg[o + 1] - tg[o])) / (float)n1;
+  if (t > 0) g += sl1_d((pr[o] - pr[o - 1]) - (tg[o] - tg[o - 1])) / (float)n1;
+  d_pred[o] += k * g;
+}
+int launch_pitch_loss(const float* target, const float* pred, int B, int T, float weight, int normalize, float* loss,
+                      float* d_pred, double* acc, hipStream_t st) {
+  STY_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
+  hipLaunchKernelGGL(pitch_loss_sums_kernel, dim3(B), dim3(64), 0, st, target, pred, T, acc);
+  hipLaunchKernelGGL(pitch_loss_grad_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, st, target, pred, B, T, acc, weight, normalize,
+                     loss, d_pred);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 }  // namespace sty
+
+extern "C" int sty_pitch_loss_fwd_bwd(int B, int T, const float* target, const float* pred, float weight, int normalize,
+                                      float* loss, float* d_pred, void* workspace, size_t ws_bytes, void* stream) {
+  if (!target || !pred || !loss || !d_pred || !workspace || ws_bytes < 16 || B <= 0 || T <= 0) {
+    sty::set_error("sty_pitch_loss_fwd_bwd: bad argument (workspace >= 16 bytes)");
+    return STY_EINVAL;
+  }
+  return sty::launch_pitch_loss(target, pred, B, T, weight, normalize, loss, d_pred, static_cast<double*>(workspace),
+                                reinterpret_cast<hipStream_t>(stream));
+}

@@ -953,7 +953,16 @@ struct Trainer {
     // train-mode box smoothing of the F0 curve and the energy (decoder.py:53-75); the widths are the caller's draw
     if (m->topts.f0_smooth > 1) {
       float* ps = take<float>((size_t)B * Tt);
-      if (live()) chk(launch_box_smooth(pitch, B, Tt, m->topts.f0_smooth, ps, 0, st));
+      const int wdt = m->topts.f0_smooth;
+      if (live()) chk(launch_box_smooth(pitch, B, Tt, wdt, ps, 0, st));
+      const float* p0 = pitch;
+      tape.push_back([=]() {  // (only the textual stage asks for d loss / d pitch)
+        if (!wants(p0)) return;
+        float* g = G(ps, (size_t)B * Tt);
+        int acc = 1;
+        float* g0 = Gw(p0, (size_t)B * Tt, acc);
+        if (live()) chk(launch_box_smooth(g, B, Tt, wdt, g0, acc, st));
+      });
       pitch = ps;
     }
     if (m->topts.energy_smooth > 1) {
@@ -973,14 +982,15 @@ struct Trainer {
     }
     float* fnv = take<float>((size_t)B * 3 * Tt);
     if (live()) chk(launch_fnv(pitch, energy, voiced, d.fnv_w, B, Tt, fnv, st));
-    nograd.insert(pitch);
     nograd.insert(voiced);
     {
       const float* w34 = d.fnv_w;
+      const float* pin = in_pitch;
       tape.push_back([=]() {
         float* g = G(fnv, (size_t)B * 3 * Tt);
         float* de = wants(energy) ? G(energy, (size_t)B * Tt) : nullptr;
-        if (live()) chk(launch_fnv_bwd(pitch, energy, voiced, w34, g, B, Tt, PGpacked(w34), nullptr, de, nullptr, st));
+        float* dp = wants(pin) ? G(pitch, (size_t)B * Tt) : nullptr;  // (pitch == pin unless it was smoothed)
+        if (live()) chk(launch_fnv_bwd(pitch, energy, voiced, w34, g, B, Tt, PGpacked(w34), dp, de, nullptr, st));
       });
     }
     const float* s1[2] = {asr, fnv};
@@ -1766,10 +1776,17 @@ int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t
   return t->rc;
 }
 
-int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st) {
+int trainer_speech_backward(Trainer* t, const float* d_audio, float* d_style, float* d_energy, hipStream_t st,
+                            float* d_pitch) {
   t->st = st;
   if (!d_energy && t->in_energy) t->nograd.insert(t->in_energy);
+  if (!d_pitch && t->in_pitch) t->nograd.insert(t->in_pitch);
   t->backward(d_audio, reinterpret_cast<float*>(2), d_style);
+  if (t->rc == STY_OK && d_pitch && t->in_pitch && t->live()) {
+    float* g = t->G(t->in_pitch, (size_t)t->B * t->T);
+    hipError_t e = hipMemcpyAsync(d_pitch, g, (size_t)t->B * t->T * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "d_pitch copy");
+  }
   if (t->rc == STY_OK && d_energy && t->in_energy && t->live()) {
     float* g = t->G(t->in_energy, (size_t)t->B * t->T);
     hipError_t e = hipMemcpyAsync(d_energy, g, (size_t)t->B * t->T * sizeof(float), hipMemcpyDeviceToDevice, st);

@@ -100,6 +100,7 @@ SYMBOLS = {
     "sty_speech_train_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
     "sty_speech_fwd_train": (C.c_int, [_P, C.POINTER(SpeechIO), _P, C.c_size_t, _P]),
     "sty_speech_bwd": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sty_speech_bwd_pe": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "sty_speech_d_style_ready": (C.c_int, [_P, _P]),
     "sty_style_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_style_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
@@ -123,6 +124,7 @@ SYMBOLS = {
     "sty_specdisc_forward": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _P]),
     "sty_specdisc_losses": (C.c_int, [_P, _I, _I, _I, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _I, _P, C.c_size_t,
                                       _P]),
+    "sty_pitch_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _I, _P, _P, _P, C.c_size_t, _P]),
     "sty_pitch_energy_train_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
     "sty_pitch_energy_fwd_train": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_pitch_energy_bwd": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -497,17 +497,19 @@ class SpeechPredictor(_HipModule):
                                          self._train_ws.numel(), st))
         return audio
 
-    def backward(self, d_audio, want_style=True, want_energy=True):
-        """d loss / d audio -> (d_style [B,64], d_energy [B,T]); parameter gradients are added to param.grad."""
+    def backward(self, d_audio, want_style=True, want_energy=True, want_pitch=False):
+        """d loss / d audio -> (d_style [B,64], d_energy [B,T]) (+ d_pitch [B,T] with want_pitch: the textual stage);
+        parameter gradients are added to param.grad."""
         lib = L.load()
         dev = d_audio.device
         B, T = self._train_shape
         d_audio = _f32(d_audio, dev)
         d_style = torch.zeros(B, self.cfg["style_dim"], device=dev) if want_style else None
         d_energy = torch.zeros(B, T, device=dev) if want_energy else None
+        d_pitch = torch.zeros(B, T, device=dev) if want_pitch else None
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        L.check(lib.sty_speech_bwd(self._handle, L.ptr(d_audio), L.ptr(d_style), L.ptr(d_energy), st))
-        return d_style, d_energy
+        L.check(lib.sty_speech_bwd_pe(self._handle, L.ptr(d_audio), L.ptr(d_style), L.ptr(d_pitch), L.ptr(d_energy), st))
+        return (d_style, d_energy, d_pitch) if want_pitch else (d_style, d_energy)
 
     def wait_d_style(self, stream):
         """Make `stream` wait until d_style of the last backward() is complete (it is, before the text encoder's

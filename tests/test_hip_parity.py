@@ -1469,6 +1469,91 @@ def test_pitch_energy_predictor_training_graph_vs_oracle_autograd(env):
     rep.done()
 
 
+def test_textual_train_step_vs_oracle(env):
+    """train_textual (stage_type.py:415-450) assembled: trainable pe_style_encoder + pitch_energy_predictor, the frozen
+    speech predictor / style encoder carrying d loss / d (pitch, energy) back from the mel loss, pitch / energy losses, the
+    pitch_disc generator term, LossLog normalisation; lr = 0 so that parameters stay put.  Losses and gradients of the
+    two trained models against autograd on the oracle (gates as in the acoustic step: fp32 conditioning)."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle import discriminator as od, frontend as ofe, losses as ol, predictors as OP, speech_predictor as osp
+    from oracle import style_encoder as ose
+    from oracle.manifest import (pitch_energy_predictor_manifest, pitch_style_encoder_manifest, style_encoder_manifest)
+    from oracle.weights import fill_state_dict
+    from stylish_tts_amd.discriminators import PitchDiscriminator
+    from stylish_tts_amd.textual import TextualTrainer
+    cs = env["cs"]
+    B, T = cs["pitch"].shape
+    audio_gt = _test_audio(B, 300 * T, 21)
+    Psp = {k: v.clone() for k, v in env["P"].items()}
+    Pse = fill_state_dict(style_encoder_manifest(), 0)
+    Ppep = fill_state_dict(pitch_energy_predictor_manifest(), 4)
+    Ppse = fill_state_dict(pitch_style_encoder_manifest(), 5)
+    fx = load_file(os.path.join(G, "pdisc_small.safetensors"))
+    Pd = {k[len("pitch.w."):]: v for k, v in fx.items() if k.startswith("pitch.w.")}
+    pep_keys = ["prosody_encoder.attn_layers.0.conv_q.weight", "prosody_encoder.proj_layers.1.weight",
+                "F0.0.conv1.parametrizations.weight.original1", "N.3.conv2.parametrizations.weight.original1",
+                "F0_proj.weight", "N_proj.weight", "text_encoder.proj_m.weight"]
+    pse_keys = ["preconv.parametrizations.weight.original1", "shared.2.conv1.weight_orig", "unshared.weight"]
+    for k in pep_keys:
+        Ppep[k].requires_grad_(True)
+    for k in pse_keys:
+        Ppse[k].requires_grad_(True)
+    # ---- oracle ----
+    with torch.no_grad():
+        mel = ofe.calculate_mel(audio_gt, 512, 512, 300)
+        style_mel = ofe.calculate_mel(audio_gt, 2048, 1200, 300)
+        energy = ofe.log_energy(mel)
+    pitch = cs["pitch"]
+    ali = ofe.duration_to_alignment(cs["durations"])
+    voiced = (pitch > 10).float()
+    pe_style = OP.pitch_style_encoder(Ppse, style_mel, pitch, energy)
+    pp, pe = OP.pitch_energy_predictor(Ppep, cs["texts"], cs["text_lengths"], ali, pe_style)
+    with torch.no_grad():
+        sstyle = ose.mel_style_encoder(Pse, "", style_mel[:, None])
+    want = {}
+    audio = osp.speech_predictor(Psp, cs["texts"], cs["text_lengths"], ali, pp, pe, (pp > 20).float(), sstyle, pp,
+                                 cs["noise"], want)
+    l_mel, _, _ = ol.acoustic_losses(audio_gt, audio.squeeze(1))
+
+    def pl(t, p):
+        return torch.nn.functional.smooth_l1_loss(t, p) + torch.nn.functional.smooth_l1_loss(torch.diff(t), torch.diff(p))
+
+    l_p, l_e = pl(pitch, pp), pl(energy, pe)
+    cat_t, cat_p = torch.stack([pitch * voiced, energy], 1), torch.stack([pp * voiced, pe], 1)
+    l_gen = od.generator_loss_helper(od.pitch_discriminator(Pd, cat_t), od.pitch_discriminator(Pd, cat_p))
+    total = 5.0 * l_mel / (l_mel.detach() + 1e-9) + 1.0 * l_gen + 8.0 * l_p / (l_p.detach() + 1e-9) + \
+        8.0 * l_e / (l_e.detach() + 1e-9)
+    total.backward()
+    # ---- HIP ----
+    def shell(cls, P, **kw):
+        m = cls(**kw)
+        m.load_state_dict({k: v.detach() for k, v in P.items()}, strict=False)
+        return m.to(DEV)
+
+    pd = PitchDiscriminator(dim_in=2, kernel=21)
+    pd.load_state_dict(Pd)
+    tr = TextualTrainer(shell(S.PitchEnergyPredictor, Ppep), shell(S.PitchStyleEncoder, Ppse), shell(S.SpeechPredictor, Psp),
+                        shell(S.MelStyleEncoder, Pse), pd.to(DEV), lr=0.0, train_mode=False)
+    log = tr.train_batch(audio_gt=dev(audio_gt), texts=dev(cs["texts"]), text_lengths=dev(cs["text_lengths"]),
+                         pitch=dev(pitch), durations=dev(cs["durations"]), noise=dev(cs["noise"]),
+                         prior_override=dev(want["prior"]))
+    torch.cuda.synchronize()
+    print(f"\n  mel {log['mel'].item():.5f} vs {l_mel.item():.5f}  pitch {log['pitch'].item():.4f} vs {l_p.item():.4f}  "
+          f"energy {log['energy'].item():.4f} vs {l_e.item():.4f}  generator {log['generator'].item():.4f} vs {l_gen.item():.4f}")
+    assert abs(log["mel"].item() - l_mel.item()) <= 2e-3 * l_mel.item()
+    assert abs(log["pitch"].item() - l_p.item()) <= 2e-3 * l_p.item()
+    assert abs(log["energy"].item() - l_e.item()) <= 2e-3 * l_e.item()
+    assert abs(log["generator"].item() - l_gen.item()) <= 2e-3 * l_gen.item()
+    rep = Report()
+    npep, npse = dict(tr.pep.named_parameters()), dict(tr.pse.named_parameters())
+    for k in pep_keys:
+        rep.add("d pep." + k[-40:], npep[k].grad, Ppep[k].grad, 8e-2)
+    for k in pse_keys:
+        rep.add("d pse." + k[-40:], npse[k].grad, Ppse[k].grad, 8e-2)
+    rep.done()
+
+
 def test_pitch_style_encoder_training_graph_vs_oracle_autograd():
     """PitchStyleEncoder forward_train + backward (the trainable `pe_style_encoder` of train_textual, stage_type.py:
     119-121): style and parameter gradients -- preconv g / v / bias through the weight_norm chain and trunk parameters --
