@@ -252,6 +252,12 @@ int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
  * (LossLog.backwards_loss, train/loss_log.py:82-94) or k = weight.  workspace: 16 bytes.                               */
 int sty_pitch_loss_fwd_bwd(int B, int T, const float *target, const float *pred, float weight, int normalize,
                            float *loss, float *d_pred, void *workspace, size_t ws_bytes, void *stream);
+/* DurationPredictor (duration_predictor.py:58-87) in the training graph: forward -> out [B,L,classes]; backward from
+ * d_out adds the parameter gradients and writes d_style [B,64] (may be NULL).                                            */
+int sty_duration_train_workspace_bytes(sty_model *m, int B, int L, size_t *bytes);
+int sty_duration_fwd_train(sty_model *m, int B, int L, const int64_t *texts, const int64_t *text_lengths,
+                           const float *style, float *out, void *workspace, size_t ws_bytes, void *stream);
+int sty_duration_bwd(sty_model *m, const float *d_out, float *d_style, void *stream);
 /* PitchEnergyPredictor (pitch_energy_predictor.py:62-82) in the training graph: forward -> pitch, energy [B,T]; backward
  * from d_pitch, d_energy [B,T] adds the parameter gradients and writes d_style [B,64] (may be NULL).                    */
 int sty_pitch_energy_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);

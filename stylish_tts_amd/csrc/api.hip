@@ -2078,6 +2078,47 @@ static int pitch_energy_run(sty_model* m, int B, int L, int T, const int64_t* te
   }
   return r.rc;
 }
+// DurationPredictor in the training graph (train_duration, stage_type.py:495-556): forward, then sty_duration_bwd
+int sty_duration_train_workspace_bytes(sty_model* m, int B, int L, size_t* bytes) {
+  int rc = model_ready(m, "duration_predictor");
+  if (rc) return rc;
+  if (!m->train_enabled || !bytes || B <= 0 || L <= 0) {
+    set_error("sty_duration_train_workspace_bytes: bad argument or training not enabled");
+    return STY_EINVAL;
+  }
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_duration_forward(m->trainer, B, L, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, bytes);
+}
+int sty_duration_fwd_train(sty_model* m, int B, int L, const int64_t* texts, const int64_t* text_lengths, const float* style,
+                           float* out, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = model_ready(m, "duration_predictor");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  if (!texts || !text_lengths || !style || !out || !workspace || B <= 0 || L <= 0) {
+    set_error("sty_duration_fwd_train: bad argument");
+    return STY_EINVAL;
+  }
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->prepared = false;
+  if (!m->trainer) m->trainer = trainer_create(m);
+  return trainer_duration_forward(m->trainer, B, L, texts, text_lengths, style, out, workspace, ws_bytes, S(stream), nullptr);
+}
+int sty_duration_bwd(sty_model* m, const float* d_out, float* d_style, void* stream) {
+  int rc = model_ready(m, "duration_predictor");
+  if (rc) return rc;
+  if (!m->trainer || !d_out) {
+    set_error("sty_duration_bwd: no recorded forward or null gradient");
+    return STY_ESTATE;
+  }
+  rc = trainer_duration_backward(m->trainer, d_out, d_style, S(stream));
+  if (rc) return rc;
+  if ((rc = unpack_grads(m, S(stream)))) return rc;
+  if (m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
+  return STY_OK;
+}
 // PitchEnergyPredictor in the training graph (train_textual, stage_type.py:119-127): forward, then sty_pitch_energy_bwd
 int sty_pitch_energy_train_workspace_bytes(sty_model* m, int B, int L, int T, size_t* bytes) {
   int rc = model_ready(m, "pitch_energy_predictor");

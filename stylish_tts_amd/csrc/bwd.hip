@@ -386,7 +386,7 @@ int launch_grn_bwd(const double* part, int nseg, const float* gamma, const float
 }
 
 // ---- pointwise activations, forward (training graph keeps the pre-activation) and backward ----
-// kind: ACT_RELU / ACT_SWISH / ACT_SNAKE (alpha per channel) / ACT_GLU (x [B][2C][T] -> y [B][C][T]) / 100 = tanh
+// kind: ACT_RELU / ACT_SWISH / ACT_SNAKE (alpha per channel) / ACT_GLU (x [B][2C][T] -> y [B][C][T]) / ACT_GELU / 100 = tanh
 __global__ void act_fwd_kernel(int kind, const float* __restrict__ x, const float* __restrict__ alpha, int C, int T,
                                float* __restrict__ y) {
   const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
@@ -403,6 +403,7 @@ __global__ void act_fwd_kernel(int kind, const float* __restrict__ x, const floa
   else if (kind == ACT_SWISH) r = v / (1.f + expf(-v));
   else if (kind == ACT_SNAKE) r = sty_snake(v, alpha[c], 1.f / alpha[c]);
   else if (kind == 100) r = tanhf(v);
+  else if (kind == ACT_GELU) r = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
   y[o] = r;
 }
 int launch_act_fwd(int kind, const float* x, const float* alpha, int B, int C, int T, float* y, hipStream_t st) {
@@ -447,6 +448,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int kind, const float* __r
     } else if (kind == 100) {
       const float th = tanhf(v);
       g = d * (1.f - th * th);
+    } else if (kind == ACT_GELU) {  // exact (erf) form
+      g = d * (0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v));
     }
     dx[row + t] = accumulate ? dx[row + t] + g : g;
   }

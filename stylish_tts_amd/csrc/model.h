@@ -21,6 +21,11 @@ int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st);
 int launch_rope_n(float* q, float* k, int B, int H, int DH, int L, int d, hipStream_t st, float sgn = 1.0f);
 int launch_style_expand(const float* style, int B, int S, int L, float* y, hipStream_t st);
 int launch_row_sum_add(const float* src, int rows, int L, float* dst, hipStream_t st);
+int launch_wn_dw_bwd(const float* dw, const float* g, const float* v, int C, int K, float* dg, float* dv, hipStream_t st);
+int launch_dur_post_bwd(const float* d, const float* mask, const float* go, int B, int NC, int L, float* gd, hipStream_t st);
+int trainer_duration_forward(struct Trainer* t, int B, int L, const int64_t* texts, const int64_t* lengths, const float* style,
+                             float* out, void* ws, size_t ws_bytes, hipStream_t st, size_t* need);
+int trainer_duration_backward(struct Trainer* t, const float* d_out, float* d_style, hipStream_t st);
 int launch_scale_copy(const float* x, float a, size_t n, float* y, hipStream_t st);
 int launch_mask_mul(float* x, const float* mask, int B, int C, int T, hipStream_t st);
 int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStream_t st);

@@ -104,6 +104,26 @@ int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStre
   return STY_OK;
 }
 
+// backward of wn_dw: dw [C][K] -> dg[c] += <dw, v> / ||v||, dv += (g / ||v||) (dw - v <dw, v> / ||v||^2)
+__global__ void wn_dw_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ g, const float* __restrict__ v,
+                                 int C, int K, float* __restrict__ dg, float* __restrict__ dv) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float svv = 0.f, sgv = 0.f;
+  for (int k = 0; k < K; ++k) {
+    svv = fmaf(v[c * K + k], v[c * K + k], svv);
+    sgv = fmaf(dw[c * K + k], v[c * K + k], sgv);
+  }
+  const float nrm = sqrtf(svv);
+  dg[c] += sgv / nrm;
+  for (int k = 0; k < K; ++k) dv[c * K + k] += (g[c] / nrm) * (dw[c * K + k] - v[c * K + k] * sgv / svv);
+}
+int launch_wn_dw_bwd(const float* dw, const float* g, const float* v, int C, int K, float* dg, float* dv, hipStream_t st) {
+  hipLaunchKernelGGL(wn_dw_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, dw, g, v, C, K, dg, dv);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // zero-pad the time axis: x [rows][T] -> y [rows][T + 2*pad]
 __global__ void pad_time_kernel(const float* __restrict__ x, int T, int pad, float* __restrict__ y) {
   const int t = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
@@ -135,6 +155,37 @@ __global__ void dur_post_kernel(const float* __restrict__ d, const float* __rest
 }
 int launch_dur_post(const float* d, const float* mask, int B, int NC, int L, float* out, hipStream_t st) {
   hipLaunchKernelGGL(dur_post_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, st, d, mask, NC, L, out);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// backward of dur_post: g_out [B][L][NC] -> gd [B][NC][L] (+=)
+__global__ void dur_post_bwd_kernel(const float* __restrict__ d, const float* __restrict__ mask, const float* __restrict__ go,
+                                    int NC, int L, float* __restrict__ gd) {
+  const int t = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (t >= L) return;
+  const float mk = mask[(size_t)b * L + t];
+  float run = 0.f, gr[32];
+  for (int c = 0; c < NC; ++c) {  // d out_c / d run_c = -sign(run_c) mask
+    float v = d[((size_t)b * NC + c) * L + t];
+    if (c > 0) v = fabsf(v);
+    run += v;
+    gr[c] = -(run > 0.f ? 1.f : (run < 0.f ? -1.f : 0.f)) * mk * go[((size_t)b * L + t) * NC + c];
+  }
+  float suffix = 0.f;
+  for (int c = NC - 1; c >= 0; --c) {  // run_c = sum_{j <= c} v_j
+    suffix += gr[c];
+    const float x = d[((size_t)b * NC + c) * L + t];
+    const float sg = c == 0 ? 1.f : (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
+    gd[((size_t)b * NC + c) * L + t] += suffix * sg;
+  }
+}
+int launch_dur_post_bwd(const float* d, const float* mask, const float* go, int B, int NC, int L, float* gd, hipStream_t st) {
+  if (NC > 32) {
+    set_error("dur_post_bwd: more than 32 duration classes");
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(dur_post_bwd_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, st, d, mask, go, NC, L, gd);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -624,7 +624,8 @@ struct Trainer {
     float* xn = layernorm(u, C, Tt, 1e-6f, &c.norm, nullptr, nullptr);
     float* h0 = take<float>((size_t)B * 4 * C * Tt);
     conv(base(c.pw1, xn, Tt, h0));
-    float* h = act(ACT_SNAKE, h0, c.alpha, 4 * C, Tt);
+    float* h = c.alpha ? act(ACT_SNAKE, h0, c.alpha, 4 * C, Tt)
+                       : act(ACT_GELU, h0, nullptr, 4 * C, Tt);  // AdaptiveConvNeXtBlock (duration predictor): exact GELU
     // GRN scale
     const int nseg = row_stats_nseg(Tt);
     double* part = take<double>((size_t)B * 4 * C * nseg * 2);
@@ -1157,6 +1158,120 @@ struct Trainer {
       float* gs = G(pe_sx, (size_t)B * m->style_dim * pe_L);
       chk(launch_row_sum_add(gs, B * m->style_dim, pe_L, d_style, st));
     }
+  }
+
+  // DurationPredictor.forward in the training graph (duration_predictor.py:58-87): cross attention between two AdaLN views
+  // of the text encoding, weight-normed depthwise k5 + SiLU + 1x1 with a residual, AdaptiveConvNeXt blocks, class head
+  float *du_out = nullptr, *du_dl = nullptr;
+  int du_L = 0;
+  void duration(const int64_t* tokens, const int64_t* lengths, int L) {
+    const DurationPlan& d = m->dur;
+    const int C = m->te.proj_m.Cout, H = 8;
+    const size_t n = (size_t)B * C * L;
+    float* enc = text_encoder(tokens, lengths, L);
+    float* mask = take<float>((size_t)B * L);
+    if (live()) chk(launch_length_mask(lengths, B, L, mask, st));
+    nograd.insert(mask);
+    float* qn = layernorm(enc, C, L, 1e-5f, &d.qn, nullptr, nullptr);
+    float* kn = layernorm(enc, C, L, 1e-5f, &d.kn, nullptr, nullptr);
+    float* q = take<float>(n);
+    float* k = take<float>(n);
+    float* v = take<float>(n);
+    conv(base(d.cq, qn, L, q));
+    conv(base(d.ck, kn, L, k));
+    conv(base(d.cv, kn, L, v));
+    float* qr = take<float>(n);
+    float* kr = take<float>(n);
+    const float* th = m->te.theta;
+    if (live()) {
+      hipError_t e = hipMemcpyAsync(qr, q, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(kr, k, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "rope copy");
+      chk(launch_rope(qr, kr, B, H, C / H, L, 8, th, st));
+    }
+    tape.push_back([=]() {
+      float* gqr = G(qr, n);
+      float* gkr = G(kr, n);
+      float* gq = G(q, n);
+      float* gk = G(k, n);
+      if (live()) {
+        chk(launch_rope_signed(gqr, gkr, B, H, C / H, L, 8, th, -1.0f, st));
+        chk(launch_row_scale_add(gqr, nullptr, 1.0f, B * C, L, gq, st));
+        chk(launch_row_scale_add(gkr, nullptr, 1.0f, B * C, L, gk, st));
+      }
+    });
+    float* o = attention3(qr, kr, v, C, L, lengths);
+    float* a1 = take<float>(n);
+    conv(base(d.co, o, L, a1));
+    // weight-normed depthwise conv: the effective weights are a scratch tensor; their gradient goes through the
+    // weight_norm chain by hand (the gradient map is told where dwconv's backward should put it)
+    float* wdw = take<float>((size_t)C * 5);
+    float* gwdw = take<float>((size_t)C * 5);
+    if (live()) {
+      chk(launch_wn_dw(d.dw_g, d.dw_v, C, 5, wdw, st));
+      hipError_t e = hipMemsetAsync(gwdw, 0, (size_t)C * 5 * sizeof(float), st);
+      if (e != hipSuccess) rc = hip_fail(e, "memset");
+      m->pgrad[wdw] = gwdw;
+    }
+    {
+      const float *g_ = d.dw_g, *v_ = d.dw_v;
+      tape.push_back([=]() {  // runs after dwconv's backward (pushed later = executed earlier)
+        side_join();          // (its weight gradient may have run on the side stream)
+        if (live()) chk(launch_wn_dw_bwd(gwdw, g_, v_, C, 5, PG(g_, C), PG(v_, (size_t)C * 5), st));
+      });
+    }
+    float* a2 = dwconv(a1, wdw, d.dw_b, C, L, 5, 2);
+    float* a3 = act(ACT_SWISH, a2, nullptr, C, L);
+    const float r2 = 0.70710678118654752f;
+    float* x = take<float>(n);
+    {
+      float* encs = take<float>(n);
+      if (live()) chk(launch_scale_copy(enc, r2, n, encs, st));
+      tape.push_back([=]() {
+        float* g = G(encs, n);
+        float* ge = G(enc, n);
+        if (live()) chk(launch_row_scale_add(g, nullptr, r2, B * C, L, ge, st));
+      });
+      ConvArgs pc = base(d.post, a3, L, x);
+      pc.out_scale = r2;
+      pc.residual = encs;
+      conv(pc);
+    }
+    for (const ConvNeXt& c : d.cnx) {
+      float* y = convnext(c, x, L);
+      x = mask_mul(y, mask, C, L);
+    }
+    float* dl = take<float>((size_t)B * d.classes * L);
+    conv(base(d.proj, x, L, dl));
+    float* out = take<float>((size_t)B * L * d.classes);
+    if (live()) chk(launch_dur_post(dl, mask, B, d.classes, L, out, st));
+    const int NC = d.classes;
+    tape.push_back([=]() {
+      float* go = G(out, (size_t)B * L * NC);
+      float* gd = G(dl, (size_t)B * NC * L);
+      if (live()) chk(launch_dur_post_bwd(dl, mask, go, B, NC, L, gd, st));
+    });
+    du_out = out;
+    du_dl = dl;
+    du_L = L;
+  }
+  void duration_backward(const float* d_out, float* d_style) {
+    const size_t n = (size_t)B * du_L * m->dur.classes;
+    side_begin();
+    d_style_out = d_style;
+    fc_bwd_done = false;
+    float* g = G(du_out, n);
+    if (live() && d_out) {
+      hipError_t e = hipMemcpyAsync(g, d_out, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = hip_fail(e, "seed copy");
+    }
+    for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
+      (*it)();
+      if (rc != STY_OK) break;
+    }
+    side_join();
+    if (rc != STY_OK) return;
+    style_fc_backward();
   }
 
   // text_encoding @ alignment (speech_predictor.py:60)
@@ -1835,6 +1950,47 @@ int trainer_pitch_energy_forward(Trainer* t, int B, int L, int T, const int64_t*
 int trainer_pitch_energy_backward(Trainer* t, const float* d_pitch, const float* d_energy, float* d_style, hipStream_t st) {
   t->st = st;
   t->pitch_energy_backward(d_pitch, d_energy, d_style);
+  if (t->ws.overflow) {
+    set_error("training workspace too small in backward: need %zu bytes", t->peak);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_duration_forward(Trainer* t, int B, int L, const int64_t* texts, const int64_t* lengths, const float* style,
+                             float* out, void* ws, size_t ws_bytes, hipStream_t st, size_t* need) {
+  t->st = st;
+  t->B = B;
+  t->T = L;
+  t->rc = STY_OK;
+  t->ws = Bump();
+  t->dry = need != nullptr;
+  t->ws.base = need ? reinterpret_cast<char*>(size_t(1) << 30) : (char*)ws;
+  t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
+  t->peak = 0;
+  t->begin(style);
+  t->style_fc(nullptr);
+  t->duration(texts, lengths, L);
+  if (need) {
+    if (t->rc == STY_OK) t->duration_backward(nullptr, nullptr);
+    *need = align_up(t->peak, 256) + (64 << 20);
+    t->tape.clear();
+    return t->rc;
+  }
+  if (t->rc == STY_OK && t->live() && t->du_out) {
+    hipError_t e = hipMemcpyAsync(out, t->du_out, (size_t)B * L * t->m->dur.classes * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) t->rc = hip_fail(e, "output copy");
+  }
+  if (t->ws.overflow) {
+    set_error("training workspace too small: need %zu bytes, have %zu", t->peak, ws_bytes);
+    return STY_ENOMEM;
+  }
+  return t->rc;
+}
+
+int trainer_duration_backward(Trainer* t, const float* d_out, float* d_style, hipStream_t st) {
+  t->st = st;
+  t->duration_backward(d_out, d_style);
   if (t->ws.overflow) {
     set_error("training workspace too small in backward: need %zu bytes", t->peak);
     return STY_ENOMEM;

@@ -675,6 +675,37 @@ class DurationPredictor(_HipModule):
                                      ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return out
 
+    def forward_train(self, texts, text_lengths, style):
+        """DurationPredictor.forward in the training graph (train_duration, stage_type.py:495-556); follow with
+        backward(d_out) -> d_style."""
+        dev = style.device
+        self._train = True
+        self._tape_id += 1
+        lib = self._ensure(dev)
+        B, Lt = texts.shape
+        tx, tl = texts.to(dev, torch.int64).contiguous(), text_lengths.to(dev, torch.int64).contiguous()
+        st = _f32(style.detach(), dev)
+        out = torch.empty(B, Lt, self.cfg["dp_classes"], dtype=torch.float32, device=dev)
+        need = C.c_size_t()
+        L.check(lib.sty_duration_train_workspace_bytes(self._handle, B, Lt, C.byref(need)))
+        if getattr(self, "_train_ws", None) is None or self._train_ws.numel() < need.value:
+            self._train_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        self._train_keep = [tx, tl, st]
+        L.check(lib.sty_duration_fwd_train(self._handle, B, Lt, L.ptr(tx), L.ptr(tl), L.ptr(st), L.ptr(out),
+                                           L.ptr(self._train_ws), self._train_ws.numel(),
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out
+
+    def backward(self, d_out):
+        """d loss / d out [B, L, classes] -> d loss / d style [B, style_dim]; parameter gradients are added to .grad."""
+        lib = L.load()
+        dev = d_out.device
+        d_out = _f32(d_out, dev)
+        d_style = torch.empty(d_out.shape[0], self.cfg["style_dim"], dtype=torch.float32, device=dev)
+        L.check(lib.sty_duration_bwd(self._handle, L.ptr(d_out), L.ptr(d_style),
+                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return d_style
+
 
 class PitchEnergyPredictor(_HipModule):
     """PitchEnergyPredictor(style_dim, inter_dim, text_config, duration_config, pitch_energy_config)

@@ -1469,6 +1469,49 @@ def test_pitch_energy_predictor_training_graph_vs_oracle_autograd(env):
     rep.done()
 
 
+def test_duration_predictor_training_graph_vs_oracle_autograd(env):
+    """DurationPredictor forward_train + backward (the trainable model of train_duration, stage_type.py:495-556), dropout
+    off: output, d_style and parameter gradients (cross attention between two AdaLN views, weight-normed depthwise conv,
+    AdaptiveConvNeXt blocks with GELU + GRN, the cumulative class head) against autograd on the float64 oracle."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle import predictors as OP
+    gold = load_file(os.path.join(G, "n3_small.safetensors"))
+    cs = env["cs"]
+    _, _, Pd, _ = _n3_models()
+    want_keys = ("text_encoder.proj_m.weight", "query_norm.fc.weight", "key_norm.fc.bias", "cross_attention.conv_q.weight",
+                 "cross_attention.conv_k.weight", "cross_attention.conv_v.bias", "cross_attention.conv_o.weight",
+                 "cross_post.0.parametrizations.weight.original0", "cross_post.0.parametrizations.weight.original1",
+                 "cross_post.0.bias", "cross_post.2.parametrizations.weight.original1", "conv_next.0.dwconv.weight",
+                 "conv_next.1.pwconv1.weight", "conv_next.2.pwconv2.weight", "conv_next.1.grn.gamma", "conv_next.1.grn.beta",
+                 "conv_next.0.norm.fc.weight", "duration_proj.linear_layer.weight", "duration_proj.linear_layer.bias")
+    keys = [k for k in want_keys if k in Pd]
+    assert len(keys) >= 10, sorted(Pd)[:60]
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in Pd.items()}
+    for k in keys:
+        P64[k].requires_grad_(True)
+    style64 = gold["duration_style"].double().requires_grad_(True)
+    out64 = OP.duration_predictor(P64, cs["texts"], cs["text_lengths"], style64)
+    seed = torch.randn(out64.shape, generator=torch.Generator().manual_seed(6))
+    (out64 * seed.double()).sum().backward()
+    dp = S.DurationPredictor()
+    dp.load_state_dict(Pd)
+    dp = dp.to(DEV).enable_training()
+    out = dp.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["duration_style"]))
+    d_style = dp.backward(dev(seed))
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("out", out, out64.detach().float(), 5e-5)
+    rep.add("d_style", d_style, style64.grad.float(), 5e-4)
+    nm = dict(dp.named_parameters())
+    for k in keys:
+        ref = P64[k].grad.float()
+        if ref.abs().max().item() < 1e-9:
+            continue
+        rep.add("d " + k[-44:], nm[k].grad, ref, 5e-4)
+    rep.done()
+
+
 def test_textual_train_step_vs_oracle(env):
     """train_textual (stage_type.py:415-450) assembled: trainable pe_style_encoder + pitch_energy_predictor, the frozen
     speech predictor / style encoder carrying d loss / d (pitch, energy) back from the mel loss, pitch / energy losses, the
