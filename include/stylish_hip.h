@@ -252,6 +252,20 @@ int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
  * (LossLog.backwards_loss, train/loss_log.py:82-94) or k = weight.  workspace: 16 bytes.                               */
 int sty_pitch_loss_fwd_bwd(int B, int T, const float *target, const float *pred, float weight, int normalize,
                            float *loss, float *d_pred, void *workspace, size_t ws_bytes, void *stream);
+/* Duration stage losses (train_duration, train/stage_type.py:495-556).
+ * sty_prediction_to_duration: DurationProcessor.prediction_to_duration (train/utils.py:745-750): pred [B,L,NC] ->
+ *   duration [B,L] = mask * sum_c softmax(pred)_c class_table_c / (sum_c softmax_c + 1e-9).
+ * sty_duration_loss_fwd_bwd: losses[0] = mean over items of smooth_l1(duration[:len], target_dur[:len]) ("duration"),
+ *   losses[1] = mean over items of CrossEntropy(pred[:len], target_class[:len], weight = ce_weight) ("duration_ce",
+ *   DurationLoss, train/losses.py:430-446); d_pred [B,L,NC] = gradient of w_duration * duration / duration.detach() +
+ *   w_ce * ce / ce.detach() (LossLog.backwards_loss) plus d_duration_extra [B,L] (e.g. the generator-side gradient of
+ *   dur_disc; may be NULL) carried through prediction_to_duration.  workspace: 16 + 4 B bytes.                          */
+int sty_prediction_to_duration(int B, int L, int NC, const float *pred, const int64_t *text_lengths,
+                               const float *class_table, float *duration, void *stream);
+int sty_duration_loss_fwd_bwd(int B, int L, int NC, const float *pred, const int64_t *text_lengths,
+                              const float *target_dur, const int64_t *target_class, const float *class_table,
+                              const float *ce_weight, float w_duration, float w_ce, const float *d_duration_extra,
+                              float *losses, float *d_pred, void *workspace, size_t ws_bytes, void *stream);
 /* DurationPredictor (duration_predictor.py:58-87) in the training graph: forward -> out [B,L,classes]; backward from
  * d_out adds the parameter gradients and writes d_style [B,64] (may be NULL).                                            */
 int sty_duration_train_workspace_bytes(sty_model *m, int B, int L, size_t *bytes);

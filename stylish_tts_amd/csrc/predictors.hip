@@ -243,6 +243,97 @@ int launch_pitch_loss(const float* target, const float* pred, int B, int T, floa
   return STY_OK;
 }
 
+// ---- duration stage losses (train_duration, stage_type.py:495-556; DurationProcessor.prediction_to_duration,
+// utils.py:745-750; DurationLoss, losses.py:430-446) ----
+// duration[b][l] = mask * sum_c softmax(pred)_c table_c / (sum_c softmax_c + 1e-9)
+__device__ __forceinline__ void dur_softmax(const float* __restrict__ z, int NC, float* p, const float* __restrict__ tab,
+                                            float& S, float& E) {
+  float mx = z[0];
+  for (int c = 1; c < NC; ++c) mx = fmaxf(mx, z[c]);
+  float den = 0.f;
+  for (int c = 0; c < NC; ++c) {
+    p[c] = expf(z[c] - mx);
+    den += p[c];
+  }
+  S = 0.f;
+  E = 0.f;
+  for (int c = 0; c < NC; ++c) {
+    p[c] /= den;
+    S += p[c];
+    E = fmaf(p[c], tab[c], E);
+  }
+}
+__global__ void pred_to_duration_kernel(const float* __restrict__ pred, const int64_t* __restrict__ lengths,
+                                        const float* __restrict__ tab, int L, int NC, float* __restrict__ dur) {
+  const int l = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (l >= L) return;
+  float p[32], S, E;
+  dur_softmax(pred + ((size_t)b * L + l) * NC, NC, p, tab, S, E);
+  dur[(size_t)b * L + l] = l < (int)lengths[b] ? E / (S + 1e-9f) : 0.f;
+}
+// per item: mean smooth_l1(duration - target) over its tokens, weighted cross entropy (mean reduction = weighted mean);
+// acc[0] += item_dur / B, acc[1] += item_ce / B;  itemW[b] = sum of the class weights of its targets
+__global__ void duration_loss_sums_kernel(const float* __restrict__ pred, const int64_t* __restrict__ lengths,
+                                          const float* __restrict__ tgt, const int64_t* __restrict__ cls,
+                                          const float* __restrict__ tab, const float* __restrict__ cw, int B, int L, int NC,
+                                          double* __restrict__ acc, float* __restrict__ itemW) {
+  __shared__ float r0[64], r1[64], r2[64];
+  const int b = blockIdx.x, len = (int)lengths[b];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int l = threadIdx.x; l < len; l += 64) {
+    float p[32], S, E;
+    dur_softmax(pred + ((size_t)b * L + l) * NC, NC, p, tab, S, E);
+    s0 += sl1(E / (S + 1e-9f) - tgt[(size_t)b * L + l]);
+    const int y = (int)cls[(size_t)b * L + l];
+    s1 -= cw[y] * logf(fmaxf(p[y], 1e-38f));
+    s2 += cw[y];
+  }
+  r0[threadIdx.x] = s0;
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, c = 0.0, w = 0.0;
+    for (int i = 0; i < 64; ++i) {
+      a += r0[i];
+      c += r1[i];
+      w += r2[i];
+    }
+    itemW[b] = (float)w;
+    atomicAdd(&acc[0], a / ((double)len * B));
+    atomicAdd(&acc[1], c / (w * B));
+  }
+}
+// d_pred [B][L][NC] = d (w_dur dur / dur.detach + w_ce ce / ce.detach) / d pred + extra[b][l] * d duration / d pred
+__global__ void duration_loss_grad_kernel(const float* __restrict__ pred, const int64_t* __restrict__ lengths,
+                                          const float* __restrict__ tgt, const int64_t* __restrict__ cls,
+                                          const float* __restrict__ tab, const float* __restrict__ cw,
+                                          const float* __restrict__ extra, int B, int L, int NC,
+                                          const double* __restrict__ acc, const float* __restrict__ itemW, float w_dur,
+                                          float w_ce, float* __restrict__ losses, float* __restrict__ d_pred) {
+  const int l = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  const float Ld = (float)acc[0], Lc = (float)acc[1];
+  if (l == 0 && b == 0) {
+    losses[0] = Ld;
+    losses[1] = Lc;
+  }
+  if (l >= L) return;
+  float* dp = d_pred + ((size_t)b * L + l) * NC;
+  const int len = (int)lengths[b];
+  if (l >= len) {
+    for (int c = 0; c < NC; ++c) dp[c] = 0.f;
+    return;
+  }
+  float p[32], S, E;
+  dur_softmax(pred + ((size_t)b * L + l) * NC, NC, p, tab, S, E);
+  const float dur = E / (S + 1e-9f);
+  float gdur = (w_dur / (Ld + 1e-9f)) * sl1_d(dur - tgt[(size_t)b * L + l]) / ((float)len * B);
+  if (extra) gdur += extra[(size_t)b * L + l];
+  const int y = (int)cls[(size_t)b * L + l];
+  const float kce = (w_ce / (Lc + 1e-9f)) * cw[y] / (itemW[b] * B);
+  for (int c = 0; c < NC; ++c)
+    dp[c] = gdur * p[c] * (tab[c] - E) / (S + 1e-9f) + kce * (p[c] - (c == y ? 1.f : 0.f));
+}
 }  // namespace sty
 
 extern "C" int sty_pitch_loss_fwd_bwd(int B, int T, const float* target, const float* pred, float weight, int normalize,
@@ -253,4 +344,37 @@ extern "C" int sty_pitch_loss_fwd_bwd(int B, int T, const float* target, const f
   }
   return sty::launch_pitch_loss(target, pred, B, T, weight, normalize, loss, d_pred, static_cast<double*>(workspace),
                                 reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int sty_prediction_to_duration(int B, int L, int NC, const float* pred, const int64_t* text_lengths,
+                                          const float* class_table, float* duration, void* stream) {
+  if (!pred || !text_lengths || !class_table || !duration || B <= 0 || L <= 0 || NC <= 0 || NC > 32) {
+    sty::set_error("sty_prediction_to_duration: bad argument (<= 32 classes)");
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(sty::pred_to_duration_kernel, dim3(sty::cdiv(L, 64), B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                     pred, text_lengths, class_table, L, NC, duration);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+extern "C" int sty_duration_loss_fwd_bwd(int B, int L, int NC, const float* pred, const int64_t* text_lengths,
+                                         const float* target_dur, const int64_t* target_class, const float* class_table,
+                                         const float* ce_weight, float w_duration, float w_ce, const float* d_duration_extra,
+                                         float* losses, float* d_pred, void* workspace, size_t ws_bytes, void* stream) {
+  if (!pred || !text_lengths || !target_dur || !target_class || !class_table || !ce_weight || !losses || !d_pred ||
+      !workspace || B <= 0 || L <= 0 || NC <= 0 || NC > 32 || ws_bytes < 16 + (size_t)B * 4) {
+    sty::set_error("sty_duration_loss_fwd_bwd: bad argument (<= 32 classes, workspace >= 16 + 4 B bytes)");
+    return STY_EINVAL;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* acc = static_cast<double*>(workspace);
+  float* itemW = reinterpret_cast<float*>(acc + 2);
+  STY_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
+  hipLaunchKernelGGL(sty::duration_loss_sums_kernel, dim3(B), dim3(64), 0, st, pred, text_lengths, target_dur, target_class,
+                     class_table, ce_weight, B, L, NC, acc, itemW);
+  hipLaunchKernelGGL(sty::duration_loss_grad_kernel, dim3(sty::cdiv(L, 64), B), dim3(64), 0, st, pred, text_lengths, target_dur,
+                     target_class, class_table, ce_weight, d_duration_extra, B, L, NC, acc, itemW, w_duration, w_ce, losses,
+                     d_pred);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
 }

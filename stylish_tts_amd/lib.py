@@ -124,6 +124,9 @@ SYMBOLS = {
     "sty_specdisc_forward": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _P]),
     "sty_specdisc_losses": (C.c_int, [_P, _I, _I, _I, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _I, _P, C.c_size_t,
                                       _P]),
+    "sty_prediction_to_duration": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "sty_duration_loss_fwd_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P,
+                                            C.c_size_t, _P]),
     "sty_duration_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_duration_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_duration_bwd": (C.c_int, [_P, _P, _P, _P]),

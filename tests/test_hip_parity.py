@@ -1512,6 +1512,80 @@ def test_duration_predictor_training_graph_vs_oracle_autograd(env):
     rep.done()
 
 
+def test_duration_train_step_vs_oracle(env):
+    """train_duration (stage_type.py:495-556) assembled: trainable duration_style_encoder + duration_predictor,
+    prediction_to_duration, the per-utterance smooth-L1 and the weighted cross entropy with LossLog normalisation, the
+    dur_disc generator term; lr = 0.  Losses and gradients against autograd on the oracle."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle import discriminator as od, frontend as ofe, predictors as OP, style_encoder as ose
+    from oracle.manifest import duration_predictor_manifest, style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from stylish_tts_amd.discriminators import PitchDiscriminator
+    from stylish_tts_amd.duration import CLASS_TO_DUR, DUR_TO_CLASS, DurationTrainer
+    cs = env["cs"]
+    B, T = cs["pitch"].shape
+    audio_gt = _test_audio(B, 300 * T, 21)
+    Pdp = fill_state_dict(duration_predictor_manifest(), 3)
+    Pse = fill_state_dict(style_encoder_manifest(), 7)
+    fx = load_file(os.path.join(G, "pdisc_small.safetensors"))
+    Pd = {k[len("dur.w."):]: v for k, v in fx.items() if k.startswith("dur.w.")}
+    dp_keys = ["cross_attention.conv_q.weight", "cross_post.0.parametrizations.weight.original1", "conv_next.1.pwconv1.weight",
+               "duration_proj.linear_layer.weight", "query_norm.fc.weight", "text_encoder.proj_m.weight"]
+    se_keys = ["shared.0.weight_orig", "shared.2.conv1.weight_orig", "unshared.weight"]
+    for k in dp_keys:
+        Pdp[k].requires_grad_(True)
+    for k in se_keys:
+        Pse[k].requires_grad_(True)
+    weights = torch.linspace(0.5, 2.0, 16)
+    tlen = cs["text_lengths"]
+    target_dur = cs["durations"].long()
+    table, d2c = torch.tensor(CLASS_TO_DUR, dtype=torch.float32), torch.tensor(DUR_TO_CLASS)
+    targets = d2c[target_dur.clamp(1, 50)]
+    # ---- oracle ----
+    with torch.no_grad():
+        style_mel = ofe.calculate_mel(audio_gt, 2048, 1200, 300)
+    style = ose.mel_style_encoder(Pse, "", style_mel[:, None])
+    raw = OP.duration_predictor(Pdp, cs["texts"], tlen, style)
+    conf = torch.softmax(raw, dim=-1)
+    soft = (conf * table).sum(-1) / (conf.sum(-1) + 1e-9)
+    mask = (torch.arange(raw.shape[1])[None, :] < tlen[:, None]).float()
+    duration = soft * mask
+    l_dur = sum(torch.nn.functional.smooth_l1_loss(duration[i, :tlen[i]], target_dur[i, :tlen[i]].float())
+                for i in range(B)) / B
+    ce = torch.nn.CrossEntropyLoss(weight=torch.sqrt(weights))
+    l_ce = sum(ce(raw[i, :tlen[i]], targets[i, :tlen[i]]) for i in range(B)) / B
+    l_gen = od.generator_loss_helper(od.pitch_discriminator(Pd, target_dur.float().unsqueeze(1)),
+                                     od.pitch_discriminator(Pd, duration.unsqueeze(1)))
+    total = 1.0 * l_gen + 8.0 * l_ce / (l_ce.detach() + 1e-9) + 8.0 * l_dur / (l_dur.detach() + 1e-9)
+    total.backward()
+    # ---- HIP ----
+    def shell(cls, P):
+        m = cls()
+        m.load_state_dict({k: v.detach() for k, v in P.items()})
+        return m.to(DEV)
+
+    dd = PitchDiscriminator(dim_in=1, kernel=5)
+    dd.load_state_dict(Pd)
+    tr = DurationTrainer(shell(S.DurationPredictor, Pdp), shell(S.MelStyleEncoder, Pse), dd.to(DEV), weights, lr=0.0,
+                         train_mode=False)
+    log = tr.train_batch(audio_gt=dev(audio_gt), texts=dev(cs["texts"]), text_lengths=dev(tlen), durations=dev(cs["durations"]))
+    torch.cuda.synchronize()
+    print(f"\n  duration {log['duration'].item():.5f} vs {l_dur.item():.5f}  ce {log['duration_ce'].item():.5f} vs "
+          f"{l_ce.item():.5f}  generator {log['generator'].item():.5f} vs {l_gen.item():.5f}")
+    assert abs(log["duration"].item() - l_dur.item()) <= 1e-4 * l_dur.item()
+    assert abs(log["duration_ce"].item() - l_ce.item()) <= 1e-4 * l_ce.item()
+    assert abs(log["generator"].item() - l_gen.item()) <= 1e-4 * l_gen.item()
+    rep = Report()
+    rep.add("duration", tr.duration, duration.detach(), 1e-4)
+    ndp, nse = dict(tr.dp.named_parameters()), dict(tr.se.named_parameters())
+    for k in dp_keys:
+        rep.add("d dp." + k[-40:], ndp[k].grad, Pdp[k].grad, 3e-4)
+    for k in se_keys:
+        rep.add("d se." + k[-40:], nse[k].grad, Pse[k].grad, 3e-4)
+    rep.done()
+
+
 def test_textual_train_step_vs_oracle(env):
     """train_textual (stage_type.py:415-450) assembled: trainable pe_style_encoder + pitch_energy_predictor, the frozen
     speech predictor / style encoder carrying d loss / d (pitch, energy) back from the mel loss, pitch / energy losses, the
