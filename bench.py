@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the stylish-tts acoustic hot path on MI355X (see DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c3-fp32|c3-gan|c2|c2-gan|c2-fwd|c5|c5-bf16|tts] [--no-extra]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c3-fp32|c3-gan|c3-textual|c3-duration|c2|c2-gan|c2-fwd|c5|c5-bf16|tts] [--no-extra]
 
 A step is one pass of the hot path over one synthetic batch already resident in HBM:
   c2 (BASELINE.json configs[1]): sample_dataset shape, B=16 utterances of T=160 mel frames (2.0 s),
@@ -18,6 +18,7 @@ A step is one pass of the hot path over one synthetic batch already resident in 
   c3-fp32: the same shape entirely in fp32.
   c3-gan / c2-gan: c3 / c2 plus the adversarial terms (three spectrogram discriminators + the waveform discriminator) and
            the discriminator step (train/stage.py:124-146; the WavLM term stays off).
+  c3-textual / c3-duration: the second- and third-stage training steps (train_textual / train_duration) at c3's shape.
   c5: vocoder only, B=8, T=800 (10 s utterances), the roofline workload of SURVEY.md 8(d).
   c5-bf16: the same with bf16 operands on the dense convs (outside the fp32 parity gates; reported beside c5).
   tts: the export graph (ExportModel.forward): B=8 token strings of L=100 -> duration predictor ->
@@ -51,12 +52,18 @@ WORKLOADS = {
     "c3-fp32": dict(B=32, T=520, L=100, what="train"),
     "c3-gan": dict(B=32, T=520, L=100, what="train", compute="bf16", gan=True),
     "c2-gan": dict(B=16, T=160, L=37, what="train", gan=True),
+    "c3-textual": dict(B=32, T=520, L=100, what="textual", compute="bf16"),
+    "c3-duration": dict(B=32, T=520, L=100, what="duration"),
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
     "c5-bf16": dict(B=8, T=800, L=0, what="vocoder", compute="bf16"),
     "tts": dict(B=8, T=0, L=100, what="synth"),
 }
 PASS = {
     "train": "forward + backward + AdamW (mel + multi-phase losses; GAN/WavLM terms off; train mode)",
+    "textual": "train_textual step (pitch / energy predictor + pitch style encoder trained through the frozen speech "
+               "predictor: mel, pitch, energy, pitch_disc generator losses; pitch_disc step)",
+    "duration": "train_duration step (duration predictor + duration style encoder: duration, duration_ce, dur_disc "
+                "generator losses; dur_disc step)",
     "forward": "forward only (AcousticStep forward + multi-spectrogram features)",
     "vocoder": "vocoder forward only (inference)",
     "synth": "text -> audio inference (duration, pitch/energy and speech predictors)",
@@ -275,6 +282,29 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     if bf16 and trainer is None:
         model.set_train_opts(compute_bf16=True)
 
+    stage_trainer = None
+    if w["what"] in ("textual", "duration"):
+        import stylish_tts_amd as S
+        from stylish_tts_amd.discriminators import PitchDiscriminator
+        from stylish_tts_amd.manifest import (duration_predictor_manifest, pitch_energy_predictor_manifest,
+                                              pitch_style_encoder_manifest, style_encoder_manifest)
+        from stylish_tts_amd.synthetic_weights import fill_state_dict
+        torch.manual_seed(11)
+        if w["what"] == "textual":
+            from stylish_tts_amd.textual import TextualTrainer
+            pem, pse = S.PitchEnergyPredictor(), S.PitchStyleEncoder()
+            pem.load_state_dict(fill_state_dict(pitch_energy_predictor_manifest(), 4))
+            pse.load_state_dict(fill_state_dict(pitch_style_encoder_manifest(), 5))
+            stage_trainer = TextualTrainer(pem.to(device), pse.to(device), model, style_enc,
+                                           PitchDiscriminator(dim_in=2, kernel=21).to(device), lr=1e-4, seed=rank,
+                                           compute=w.get("compute", "fp32"))
+        else:
+            from stylish_tts_amd.duration import DurationTrainer
+            dpm, dse = S.DurationPredictor(), S.MelStyleEncoder()
+            dpm.load_state_dict(fill_state_dict(duration_predictor_manifest(), 3))
+            dse.load_state_dict(fill_state_dict(style_encoder_manifest(), 7))
+            stage_trainer = DurationTrainer(dpm.to(device), dse.to(device), PitchDiscriminator(dim_in=1, kernel=5).to(device),
+                                            torch.ones(16), lr=1e-4, seed=rank)
     synth = None
     if w["what"] == "synth":
         import stylish_tts_amd as S
@@ -290,6 +320,14 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
         if synth is not None:
             return synth(inp["texts"], inp["text_lengths"], inp["speech_style"], inp["pe_style"],
                          inp["duration_style"], seed=i)
+        if w["what"] == "textual":
+            log = stage_trainer.train_batch(audio_gt=inp["audio_gt"], texts=inp["texts"], text_lengths=inp["text_lengths"],
+                                            pitch=inp["pitch"], durations=inp["durations"], seed=i)
+            return torch.stack([log["mel"], log["pitch"], log["energy"], log["generator"]])
+        if w["what"] == "duration":
+            log = stage_trainer.train_batch(audio_gt=inp["audio_gt"], texts=inp["texts"], text_lengths=inp["text_lengths"],
+                                            durations=inp["durations"])
+            return torch.stack([log["duration"], log["duration_ce"], log["generator"]])
         if w["what"] == "train":
             # one train_acoustic step incl. gradient all-reduce and optimizer; returns the loss values
             return trainer.train_batch(audio_gt=inp["audio_gt"], texts=inp["texts"], text_lengths=inp["text_lengths"],

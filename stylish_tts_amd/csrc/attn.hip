@@ -128,8 +128,10 @@ int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st) {
     hipLaunchKernelGGL((attn_kernel<96, false>), grid, dim3(256), 0, st, a);
   else if (DH == 16)
     hipLaunchKernelGGL((attn_kernel<16, true>), grid, dim3(256), 0, st, a);
+  else if (DH == 160)  // the prosody encoder in training mode (textual stage)
+    hipLaunchKernelGGL((attn_kernel<160, true>), grid, dim3(256), 0, st, a);
   else {
-    set_error("attention: head dim %d%s not built (16, 64, 96, 160; dropout: 16)", DH, drop ? " with dropout" : "");
+    set_error("attention: head dim %d%s not built (16, 64, 96, 160; dropout: 16, 160)", DH, drop ? " with dropout" : "");
     return STY_EINVAL;
   }
   STY_LAUNCH_CHECK();

@@ -378,6 +378,8 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
     STY_ABWD(16, false);
   } else if (DH == 16) {
     STY_ABWD(16, true);
+  } else if (DH == 96 && !drop) {  // the same encoder at inter_dim 128
+    STY_ABWD(96, false);
   } else if (DH == 160 && !drop) {  // prosody encoder of the pitch / energy predictor: 2 heads x (256 + 64) / 2
     STY_ABWD(160, false);
   } else if (DH == 160) {

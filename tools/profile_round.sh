@@ -36,6 +36,8 @@ python tools/rocpd_summary.py $O/c3gan_trace/*/*_results.db > $O/${tag}_c3_gan_k
 rm -rf $O/c3gan_trace
 python bench.py --workload c3-gan --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/${tag}_bench_c3_gan.json 2>/dev/null
 python bench.py --workload c2-gan --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/${tag}_bench_c2_gan.json 2>/dev/null
+python bench.py --workload c3-textual --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/${tag}_bench_c3_textual.json 2>/dev/null
+python bench.py --workload c3-duration --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/${tag}_bench_c3_duration.json 2>/dev/null
 python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
 rm -rf $O/c3_trace $O/c5_trace $O/c2_trace $O/c3_fetch/*/*agent_info.csv $O/c5_fetch/*/*agent_info.csv
