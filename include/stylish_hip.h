@@ -213,6 +213,9 @@ typedef struct {
                           training graph (forward, input gradient, weight gradient) are rounded to bf16 and multiplied
                           on v_mfma_f32_32x32x16_bf16; accumulation, storage, norms, attention, losses stay fp32.
                           Also honoured by the inference entry points (sty_vocoder_fwd, sty_speech_fwd).              */
+  int frozen;          /* 1: the model is one of a stage's eval_models (the speech predictor in train_textual,
+                          stage_type.py:461): the backward produces input gradients only -- the weight-gradient GEMMs
+                          of the dense convs are skipped and the bound parameter gradients must be ignored.          */
 } sty_train_opts;
 int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
 

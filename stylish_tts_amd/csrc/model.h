@@ -254,7 +254,7 @@ struct sty_model {
   int seg_blk_split = 0;
   sty_grad_hook grad_hook = nullptr;
   void* grad_hook_user = nullptr;
-  sty_train_opts topts = {0, 0, 0, 0, 0.1f, 0u, 0.2f, 0};  // train-mode behaviour of the *_fwd_train entry points
+  sty_train_opts topts = {0, 0, 0, 0, 0.1f, 0u, 0.2f, 0, 0};  // train-mode behaviour of the *_fwd_train entry points
   struct sty::Trainer* trainer = nullptr;
 };
 

@@ -269,7 +269,9 @@ struct Trainer {
     // weight gradient; the bias gradient is a by-product of the same pass over gY for K <= 12
     bool bias_done = false;
     float* gbias = w.bias ? PGpacked(w.bias) : nullptr;
-    if (side_ready()) {
+    if (m->topts.frozen) {  // eval_models of a stage (e.g. the speech predictor in train_textual): input gradients only
+      bias_done = true;
+    } else if (side_ready()) {
       float* sp = side_partial;
       float* gwp = PGpacked(w.wp);
       const float osc = f.out_scale;
@@ -585,7 +587,9 @@ struct Trainer {
       float* gdw = PG(c.dw_w, 32 * 7);
       float* gdb = PG(c.dw_b, 32);
       const float* dww = c.dw_w;
-      if (side) {
+      if (m->topts.frozen) {
+        if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
+      } else if (side) {
         side_push(gY, [=](hipStream_t s2) {
           if (cnx16) {
             chk(launch_conv_wgrad_cnx(1, hs, gY, B, Tt, gw2, p2, gb2, s2));
@@ -1412,7 +1416,9 @@ struct Trainer {
                          gR, 1, nullptr, nullptr, nullptr, st));
     bool bias_done = false;
     float* gbias = w.bias ? PGpacked(w.bias) : nullptr;
-    if (side_ready()) {
+    if (m->topts.frozen) {
+      bias_done = true;
+    } else if (side_ready()) {
       float* sp = side_partial;
       float* gwp = PGpacked(w.wp);
       side_push(gY, [=](hipStream_t s) {

@@ -52,8 +52,10 @@ class TextualTrainer:
         self.bf16 = compute == "bf16"  # bf16 operands on the dense convs of all three graphs (as AcousticTrainer)
         self._rng = random.Random(seed)
         if self.bf16:
-            for m_ in (self.pep, self.pse, self.sp):
+            for m_ in (self.pep, self.pse):
                 m_.set_train_opts(compute_bf16=True)
+        # StageType.eval_models: the speech predictor only carries gradients to its pitch / energy inputs
+        self.sp.set_train_opts(compute_bf16=self.bf16, frozen=True)
         kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, bucket_bytes=bucket_bytes)
         self.opt = {"pitch_energy_predictor": FlatAdamW(list(self.pep.named_parameters()), **kw),
                     "pe_style_encoder": FlatAdamW(list(self.pse.named_parameters()), **kw),
