@@ -17,7 +17,7 @@ from . import text_encoder as OT
 CLASS_TO_DUR = torch.tensor([1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 18, 22, 27, 32, 38, 46], dtype=torch.float32)
 
 
-def mha_cross(P, p, x, c, attn_mask, n_heads):
+def mha_cross(P, p, x, c, attn_mask, n_heads, p_drop=0.0):
     """MultiHeadAttention.forward(x, c): queries from x, keys / values from c (text_encoder.py:214-280)."""
     Bn, C, L = x.shape
     dh = C // n_heads
@@ -28,13 +28,15 @@ def mha_cross(P, p, x, c, attn_mask, n_heads):
     q, k, v = OT.rope(heads(q), dh // 2), OT.rope(heads(k), dh // 2), heads(v)
     add = torch.zeros_like(attn_mask, dtype=x.dtype).masked_fill(attn_mask == 0, -1e4)
     att = torch.softmax(q @ k.transpose(2, 3) / math.sqrt(dh) + add, dim=-1)
+    att = OB.drop(att, p_drop)  # SDPA dropout_p (training mode only; hash masks as in oracle.blocks)
     o = (att @ v).transpose(2, 3).reshape(Bn, C, L)
     return F.conv1d(o, P[p + ".conv_o.weight"], P[p + ".conv_o.bias"])
 
 
-def ada_convnext_block(P, p, x, style):
+def ada_convnext_block(P, p, x, style, drop_path=0.0):
     """AdaptiveConvNeXtBlock on [B,C,T]: dwconv k7, AdaLN(eps 1e-6), Linear, exact GELU, GRN, Linear, residual
-    (conv_next.py:97-134; DropPath is the identity in eval mode)."""
+    (conv_next.py:97-134).  drop_path: DropPath rate of the branch in training mode (one draw per sample, conv_next.py:
+    138-153), a hash mask like every other dropout of the oracle (identity when the oracle is not in training mode)."""
     C = x.shape[1]
     h = F.conv1d(x, P[p + ".dwconv.weight"], P[p + ".dwconv.bias"], padding=3, groups=C)
     h = OB.adaln(P, p + ".norm", h, style, eps=1e-6)
@@ -43,7 +45,8 @@ def ada_convnext_block(P, p, x, style):
     s = OB.grn_scale(h, P[p + ".grn.gamma"])
     h = h * s[:, :, None] + P[p + ".grn.beta"].view(1, -1, 1)
     h = F.conv1d(h, P[p + ".pwconv2.weight"][:, :, None], P[p + ".pwconv2.bias"])
-    return x + h
+    m = OB.keep_mask((x.shape[0], 1, 1), drop_path)
+    return x + (h if m is None else h * m.to(h.dtype))
 
 
 def duration_predictor(P, texts, text_lengths, style, want=None):
@@ -55,7 +58,7 @@ def duration_predictor(P, texts, text_lengths, style, want=None):
     q = OB.adaln(P, "query_norm", enc, style)
     k = OB.adaln(P, "key_norm", enc, style)
     attn_mask = mask.unsqueeze(2) * mask.unsqueeze(-1)
-    a = mha_cross(P, "cross_attention", q, k, attn_mask, n_heads=8)
+    a = mha_cross(P, "cross_attention", q, k, attn_mask, n_heads=8, p_drop=0.5)  # p_dropout=0.5 (duration_predictor.py:40)
     a = F.conv1d(a, OB.wn_weight(P, "cross_post.0"), P["cross_post.0.bias"], padding=2, groups=a.shape[1])
     a = F.silu(a)
     a = F.conv1d(a, OB.wn_weight(P, "cross_post.2"), P["cross_post.2.bias"])
@@ -64,7 +67,10 @@ def duration_predictor(P, texts, text_lengths, style, want=None):
         want["dp.cross"] = x
     i = 0
     while f"conv_next.{i}.dwconv.weight" in P:
-        x = ada_convnext_block(P, f"conv_next.{i}", x, style) * mask
+        x = ada_convnext_block(P, f"conv_next.{i}", x, style, drop_path=0.5) * mask  # dropout=0.5 (:25)
+        m1 = OB.keep_mask((x.shape[0], x.shape[1], 1), 0.5)  # Dropout1d(last_dropout = 0.5): whole channels (:30, :79)
+        if m1 is not None:
+            x = x * m1.to(x.dtype)
         i += 1
     d = F.linear(x.transpose(1, 2), P["duration_proj.linear_layer.weight"], P["duration_proj.linear_layer.bias"])
     d = torch.cat([d[:, :, :1], d[:, :, 1:].abs()], dim=2)
@@ -82,11 +88,13 @@ def prosody_encoder(P, p, x, style, lengths, n_heads=2):
     i = 0
     while f"{p}.attn_layers.{i}.conv_q.weight" in P:
         x = x * mask
-        y = mha_cross(P, f"{p}.attn_layers.{i}", x, x, attn_mask, n_heads)
+        pd = OB.TRAIN.get("text_dropout", 0.2)  # ProsodyEncoder(dropout=0.2) (pitch_energy_predictor.py:26)
+        y = OB.drop(mha_cross(P, f"{p}.attn_layers.{i}", x, x, attn_mask, n_heads, p_drop=pd), pd)
         x = OB.adaln(P, f"{p}.norm_layers_1.{i}", x + y, style)
         f = f"{p}.ffn_layers.{i}"
         y = F.conv1d(x * mask, P[f + ".conv_1.weight"], P[f + ".conv_1.bias"])
-        y = F.conv1d(torch.relu(y) * mask, P[f + ".conv_2.weight"], P[f + ".conv_2.bias"]) * mask
+        y = OB.drop(torch.relu(y), pd)
+        y = OB.drop(F.conv1d(y * mask, P[f + ".conv_2.weight"], P[f + ".conv_2.bias"]) * mask, pd)
         x = OB.adaln(P, f"{p}.norm_layers_2.{i}", x + y, style)
         x = F.conv1d(x, P[f"{p}.proj_layers.{i}.weight"], P[f"{p}.proj_layers.{i}.bias"])
         x = torch.cat([x, st], dim=1)

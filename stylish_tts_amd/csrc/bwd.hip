@@ -707,18 +707,19 @@ int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const fl
 
 // ---- nn.Dropout with the counter-based hash mask: y = keep(seed, site, i) ? x / (1-p) : 0 (+ residual) ----
 // The backward is the same kernel on the output gradient (residual = nullptr, accumulate as needed).
+// group > 1: one draw per `group` consecutive elements (Dropout1d: group = T, one per (b, c); DropPath: group = C*T, one per b)
 __global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ res, size_t n, float p,
-                               unsigned seed, unsigned site, float* __restrict__ y, int accumulate) {
+                               unsigned seed, unsigned site, float* __restrict__ y, int accumulate, size_t group) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float v = sty_hash_u(seed, site, (unsigned)i) >= p ? x[i] / (1.0f - p) : 0.f;
+  float v = sty_hash_u(seed, site, (unsigned)(i / group)) >= p ? x[i] / (1.0f - p) : 0.f;
   if (res) v += res[i];
   y[i] = accumulate ? y[i] + v : v;
 }
 int launch_dropout(const float* x, const float* res, size_t n, float p, unsigned seed, unsigned site, float* y,
-                   int accumulate, hipStream_t st) {
+                   int accumulate, hipStream_t st, size_t group) {
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, res, n, p, seed, site, y,
-                     accumulate);
+                     accumulate, group ? group : 1);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

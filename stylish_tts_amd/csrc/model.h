@@ -339,7 +339,7 @@ int launch_bn_train_fwd(const float* x, const float* w, const float* b, float* r
 int launch_bn_train_bwd(const float* x, const float* dy, const float* w, const float* mean, const float* rstd, int B,
                         int C, int T, float* dx, int accumulate, float* dw, float* db, float* sums, hipStream_t st);
 int launch_dropout(const float* x, const float* res, size_t n, float p, unsigned seed, unsigned site, float* y,
-                   int accumulate, hipStream_t st);
+                   int accumulate, hipStream_t st, size_t group = 1);
 int launch_box_smooth(const float* x, int B, int T, int width, float* y, int accumulate, hipStream_t st);
 size_t sn_power_iter_scratch_floats(int Cout, int n);
 int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st);

@@ -354,11 +354,11 @@ struct Trainer {
   // y = drop(x) (+ residual).  Sites are numbered in execution order; the backward recomputes the mask.
   unsigned drop_site = 0;
   bool dropout_on() const { return m->topts.dropout_seed != 0; }
-  float* dropout(const float* x, float p, int C, int Tt, const float* residual) {
+  float* dropout(const float* x, float p, int C, int Tt, const float* residual, size_t group = 1) {
     const size_t n = (size_t)B * C * Tt;
     float* y = take<float>(n);
     const unsigned seed = m->topts.dropout_seed, site = drop_site++;
-    if (live()) chk(launch_dropout(x, residual, n, p, seed, site, y, 0, st));
+    if (live()) chk(launch_dropout(x, residual, n, p, seed, site, y, 0, st, group));
     tape.push_back([=]() {
       float* gY = G(y, n);
       if (residual && wants(residual)) {
@@ -376,7 +376,7 @@ struct Trainer {
         rc = STY_ESTATE;
         return;
       }
-      if (live()) chk(launch_dropout(gY, nullptr, n, p, seed, site, gX, acc, st));
+      if (live()) chk(launch_dropout(gY, nullptr, n, p, seed, site, gX, acc, st, group));
     });
     return y;
   }
@@ -620,7 +620,7 @@ struct Trainer {
   }
 
   // GeneratorConvNeXtBlock (conv_next.py:80-93), any channel count
-  float* convnext(const ConvNeXt& c, const float* x, int Tt) {
+  float* convnext(const ConvNeXt& c, const float* x, int Tt, bool branch_only = false) {
     const int C = c.C;
     static const bool fuse32 = getenv("STY_NO_CNX_FUSED") == nullptr;
     if (C == 32 && fuse32 && c.w2a && c.w1_raw && c.w2_raw) return convnext32_fused(c, x, Tt);
@@ -654,7 +654,7 @@ struct Trainer {
     ConvArgs b2 = base(c.pw2, h, Tt, y);
     b2.pro = PRO_SCALE;
     b2.pa = scale;
-    b2.residual = x;
+    if (!branch_only) b2.residual = x;  // (branch_only: the caller applies DropPath before adding the residual)
     conv(b2);
     return y;
   }
@@ -733,7 +733,8 @@ struct Trainer {
     return o;
   }
   // separate q / k / v tensors [B][H*DH][L] with an optional length mask (text encoder)
-  float* attention3(const float* q, const float* k, const float* v, int Hd, int L, const int64_t* lengths, int heads = 8) {
+  float* attention3(const float* q, const float* k, const float* v, int Hd, int L, const int64_t* lengths, int heads = 8,
+                    float p_attn = -1.f) {  // p_attn >= 0: dropout rate of the probabilities (default: text_dropout)
     const size_t n = (size_t)B * Hd * L;
     float* o = take<float>(n);
     AttnArgs at;
@@ -746,8 +747,9 @@ struct Trainer {
     at.H = heads;
     at.scale = 1.0f / sqrtf((float)(Hd / heads));
     at.lengths = lengths;
-    if (dropout_on() && m->topts.text_dropout > 0.f) {  // SDPA dropout_p on the attention probabilities
-      at.drop_p = m->topts.text_dropout;
+    const float pa = p_attn >= 0.f ? p_attn : m->topts.text_dropout;
+    if (dropout_on() && pa > 0.f) {  // SDPA dropout_p on the attention probabilities
+      at.drop_p = pa;
       at.drop_seed = m->topts.dropout_seed;
       at.drop_site = drop_site++;
     }
@@ -1204,7 +1206,10 @@ struct Trainer {
         chk(launch_row_scale_add(gkr, nullptr, 1.0f, B * C, L, gk, st));
       }
     });
-    float* o = attention3(qr, kr, v, C, L, lengths);
+    // train mode (duration_predictor.py:25-40, 79; model.yml last_dropout): probabilities p = 0.5, DropPath(0.5) per block,
+    // Dropout1d(0.5) after every block
+    const bool dr = dropout_on();
+    float* o = attention3(qr, kr, v, C, L, lengths, 8, 0.5f);
     float* a1 = take<float>(n);
     conv(base(d.co, o, L, a1));
     // weight-normed depthwise conv: the effective weights are a scratch tensor; their gradient goes through the
@@ -1242,8 +1247,10 @@ struct Trainer {
       conv(pc);
     }
     for (const ConvNeXt& c : d.cnx) {
-      float* y = convnext(c, x, L);
+      float* y = dr ? dropout(convnext(c, x, L, true), 0.5f, C, L, x, (size_t)C * L)  // residual + DropPath(branch)
+                    : convnext(c, x, L);
       x = mask_mul(y, mask, C, L);
+      if (dr) x = dropout(x, 0.5f, C, L, nullptr, (size_t)L);  // Dropout1d: whole channels
     }
     float* dl = take<float>((size_t)B * d.classes * L);
     conv(base(d.proj, x, L, dl));

@@ -1586,6 +1586,59 @@ def test_duration_train_step_vs_oracle(env):
     rep.done()
 
 
+@pytest.mark.parametrize("which", ["duration", "pitch_energy"])
+def test_second_stage_predictors_train_mode_dropouts_vs_oracle(env, which):
+    """Training-mode dropouts of the two trainable predictors -- text encoder sites, attention probabilities (0.5 / 0.2),
+    DropPath(0.5) per AdaptiveConvNeXt block and Dropout1d(0.5) after it (duration_predictor.py:25-40, 79), the prosody
+    encoder's three sites per layer (prosody_encoder.py:72-78) -- with the counter-based hash masks shared by the oracle
+    and the library (same site order, same element indexing): outputs and parameter gradients."""
+    import stylish_tts_amd as S
+    from safetensors.torch import load_file
+    from oracle import blocks as OB, predictors as OP
+    gold = load_file(os.path.join(G, "n3_small.safetensors"))
+    cs = env["cs"]
+    _, _, Pd, Pp = _n3_models()
+    P = Pd if which == "duration" else Pp
+    keys = (["cross_attention.conv_v.weight", "conv_next.1.pwconv1.weight", "duration_proj.linear_layer.weight",
+             "text_encoder.proj_m.weight"] if which == "duration" else
+            ["prosody_encoder.attn_layers.1.conv_v.weight", "prosody_encoder.ffn_layers.0.conv_2.weight", "F0_proj.weight",
+             "N.0.conv1.parametrizations.weight.original1"])
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    for k in keys:
+        P64[k].requires_grad_(True)
+    OB.TRAIN.update(dropout_seed=4321, _site=0, text_dropout=0.2)
+    try:
+        if which == "duration":
+            outs = (OP.duration_predictor(P64, cs["texts"], cs["text_lengths"], gold["duration_style"].double()),)
+        else:
+            outs = OP.pitch_energy_predictor(P64, cs["texts"], cs["text_lengths"], gold["alignment"].double(),
+                                             gold["pe_style"].double())
+    finally:
+        OB.TRAIN.update(dropout_seed=0, _site=0)
+    g = torch.Generator().manual_seed(8)
+    seeds = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * s_.double()).sum() for o, s_ in zip(outs, seeds)).backward()
+    m = (S.DurationPredictor() if which == "duration" else S.PitchEnergyPredictor())
+    m.load_state_dict(P)
+    m = m.to(DEV).enable_training()
+    m.set_train_opts(dropout_seed=4321, text_dropout=0.2)
+    if which == "duration":
+        got = (m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["duration_style"])),)
+        m.backward(dev(seeds[0]))
+    else:
+        got = m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["alignment"]), dev(gold["pe_style"]))
+        m.backward(dev(seeds[0]), dev(seeds[1]))
+    torch.cuda.synchronize()
+    rep = Report()
+    tol_o, tol_g = (1e-4, 1e-3) if which == "duration" else (2e-3, 8e-2)
+    for i, (a, b) in enumerate(zip(got, outs)):
+        rep.add(f"out{i}", a, b.detach().float(), tol_o)
+    nm = dict(m.named_parameters())
+    for k in keys:
+        rep.add("d " + k[-44:], nm[k].grad, P64[k].grad.float(), tol_g)
+    rep.done()
+
+
 def test_textual_train_step_vs_oracle(env):
     """train_textual (stage_type.py:415-450) assembled: trainable pe_style_encoder + pitch_energy_predictor, the frozen
     speech predictor / style encoder carrying d loss / d (pitch, energy) back from the mel loss, pitch / energy losses, the
