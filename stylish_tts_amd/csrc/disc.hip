@@ -122,6 +122,52 @@ __global__ __launch_bounds__(256) void sd_fold27_kernel(const float* __restrict_
   dx[(size_t)b * sb + (size_t)h * sh + w] += s;
 }
 
+// Layer 0 in one pass: 3 x 9 conv of the one-channel spectrogram -> 32 channels, bias, LeakyReLU(0.1), zero pad columns,
+// written both as the activation [B][32][H][Wp] and as the even / odd column split [B][64][H][Wp/2] of layer 1's input.
+// fp32 on the VALU (27 inputs x 32 outputs per position: the matrix pipe would see K = 27; the weights are wave-uniform
+// scalar loads), four adjacent columns per thread.  wt: the packed weights [27][32] (row r = kh*9 + kw).
+__global__ __launch_bounds__(256) void sd_l0_kernel(const float* __restrict__ x, size_t sb, size_t sh,
+                                                    const float* __restrict__ wt, const float* __restrict__ bias, int H,
+                                                    int W, int Wp, float* __restrict__ a, float* __restrict__ split) {
+  const int w0 = (blockIdx.x * 256 + threadIdx.x) * 4, h = blockIdx.y, b = blockIdx.z;
+  if (w0 >= Wp) return;
+  float in[3][12];  // rows h-1 .. h+1, columns w0-4 .. w0+7
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hs = h + kh - 1;
+    const bool rowok = hs >= 0 && hs < H;
+    const float* row = x + (size_t)b * sb + (size_t)(rowok ? hs : 0) * sh;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int ws = w0 - 4 + j;
+      in[kh][j] = (rowok && ws >= 0 && ws < W) ? row[ws] : 0.f;
+    }
+  }
+  const size_t plane = (size_t)H * Wp, o = (size_t)h * Wp + w0;
+  float* ab = a + (size_t)b * 32 * plane + o;
+  float* sbp = split + (size_t)b * 64 * (plane >> 1) + (size_t)h * (Wp >> 1) + (w0 >> 1);
+  for (int co = 0; co < 32; ++co) {
+    float acc[4];
+    acc[0] = acc[1] = acc[2] = acc[3] = bias[co];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 9; ++kw) {
+        const float wv = wt[(kh * 9 + kw) * 32 + co];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, in[kh][kw + e], acc[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = acc[e] > 0.f ? acc[e] : SD_SLOPE * acc[e];
+      acc[e] = w0 + e < W ? v : 0.f;
+    }
+    *reinterpret_cast<float4*>(ab + (size_t)co * plane) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float2*>(sbp + (size_t)co * (plane >> 1)) = make_float2(acc[0], acc[2]);
+    *reinterpret_cast<float2*>(sbp + (size_t)(co + 32) * (plane >> 1)) = make_float2(acc[1], acc[3]);
+  }
+}
+
 // LeakyReLU(0.1) in place on z [B][32][H][Wp] (pad columns are zero and stay zero) + the even / odd column split
 // [B][64][H][Wp/2] the next stride-2 layer reads
 __global__ __launch_bounds__(256) void sd_post_kernel(float* __restrict__ z, int n, int Wp, float* __restrict__ split) {
@@ -366,6 +412,7 @@ struct SdRun : DiscBase {
   }
 
   struct Acts {
+    const float* x = nullptr;  // the input image (strided): layer 0's weight gradient builds its 27 shifted copies from it
     float* x27 = nullptr;
     float* a[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // activations, normal layout
     float* as[3] = {nullptr, nullptr, nullptr};                    // even / odd split of a[0..2]
@@ -375,17 +422,20 @@ struct SdRun : DiscBase {
 
   // the five layers on x [B][H][W]; the score maps go to ac.s[i] (must be set)
   void forward(const float* x, Acts& ac) {
-    ac.x27 = take<float>((size_t)B * 27 * n[0]);
-    if (live()) hipLaunchKernelGGL(sd_x27_kernel, dim3(cdiv(n[0], 256), 27, B), dim3(256), 0, st, x, sb, sh, H, W, Wp[0], ac.x27);
+    ac.x = x;
     for (int i = 0; i < 5; ++i) {
       ac.a[i] = take<float>((size_t)B * 32 * n[i]);
       if (i < 3) ac.as[i] = take<float>((size_t)B * 32 * n[i]);
-      const float* in = i == 0 ? ac.x27 : (i < 4 ? ac.as[i - 1] : ac.a[3]);
       if (live()) {
-        const ConvArgs a = conv_args(i, in, ac.a[i]);
-        chk(launch_conv1d(a, st));
-        hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, ac.a[i], n[i], Wp[i],
-                           i < 3 ? ac.as[i] : nullptr);
+        if (i == 0) {  // conv + LeakyReLU + split in one pass over the spectrogram
+          hipLaunchKernelGGL(sd_l0_kernel, dim3(cdiv(Wp[0] / 4, 256), H, B), dim3(256), 0, st, x, sb, sh, L[0].w.wp,
+                             L[0].w.bias, H, W, Wp[0], ac.a[0], ac.as[0]);
+        } else {
+          const ConvArgs a = conv_args(i, i < 4 ? ac.as[i - 1] : ac.a[3], ac.a[i]);
+          chk(launch_conv1d(a, st));
+          hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, ac.a[i], n[i], Wp[i],
+                             i < 3 ? ac.as[i] : nullptr);
+        }
         hipLaunchKernelGGL(sd_score4_kernel, dim3(cdiv(cdiv(Wl[i], 4), 256), H, B), dim3(256), 0, st, ac.a[i], sw[i],
                            sw[i] + 288, H, Wl[i], Wp[i], ac.s[i]);
       }
@@ -403,7 +453,13 @@ struct SdRun : DiscBase {
       if (live())
         hipLaunchKernelGGL(sd_gz4_kernel, dim3(cdiv(n[i] / 4, 256), 32, B), dim3(256), 0, st, gs[i], sw[i], ac.a[i],
                            i == 3 ? dnext : nullptr, i < 3 ? dnext : nullptr, H, Wl[i], Wp[i], gz);
-      const float* in = i == 0 ? ac.x27 : (i < 4 ? ac.as[i - 1] : ac.a[3]);
+      const float* in = i == 0 ? nullptr : (i < 4 ? ac.as[i - 1] : ac.a[3]);
+      if (i == 0 && gwp) {  // the 27 shifted copies are only needed as the weight gradient's operand
+        float* x27 = take<float>((size_t)B * 27 * n[0]);
+        if (live())
+          hipLaunchKernelGGL(sd_x27_kernel, dim3(cdiv(n[0], 256), 27, B), dim3(256), 0, st, ac.x, sb, sh, H, W, Wp[0], x27);
+        in = x27;
+      }
       const ConvArgs f = conv_args(i, in, nullptr);
       if (gwp) {
         if (live())
