@@ -238,11 +238,17 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (RELU) v[e] = fmaxf(v[e], 0.f);
+      if (RELU == 1) v[e] = fmaxf(v[e], 0.f);
+      if (RELU == 2) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
       v[e] *= pre_scale;
       if (a.out_mask && !post) v[e] *= om[e];
       v[e] += rr[e];
       if (post) v[e] *= om[e];
+    }
+    if (RELU == 2 && a.y_split) {  // (T % 4 == 0: always the wide path) even / odd split for the next stride-2 layer
+      float* sp = a.y_split + (size_t)tl.b * 2 * Cout * (T >> 1) + (size_t)co * (T >> 1) + (t >> 1);
+      *reinterpret_cast<float2*>(sp) = make_float2(v[0], v[2]);
+      *reinterpret_cast<float2*>(sp + (size_t)Cout * (T >> 1)) = make_float2(v[1], v[3]);
     }
     if (wide) {
       const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
@@ -520,7 +526,8 @@ static size_t q_lds_bytes(const ConvArgs& a) {
 bool convp16_eligible(const ConvArgs& a) {
   if (!a.bf16 || getenv("STY_NO_CONVP16")) return false;  // (read per call: the A/B parity test toggles it)
   if (a.w.CinP < 2 * CI_CHUNK || a.nsrc != 1 || a.in_shuffle > 1 || a.shuffle != 1 || a.ln_out || a.Tin ||
-      !(a.act == ACT_NONE || a.act == ACT_RELU) || a.w.K > Q_MAXK)
+      !(a.act == ACT_NONE || a.act == ACT_RELU || (a.act == ACT_LRELU01 && a.pro == PRO_NONE && a.T % 4 == 0)) ||
+      a.w.K > Q_MAXK)
     return false;
   if (!(a.pro == PRO_NONE || a.pro == PRO_MASK || a.pro == PRO_LRELU || a.pro == PRO_AFFINE_LRELU || a.pro == PRO_AFFINE ||
         a.pro == PRO_SCALE))
@@ -571,6 +578,9 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
 
 template <int PRO>
 static int launch_q_pro(const ConvArgs& a, hipStream_t st) {
+  if constexpr (PRO == PRO_NONE) {
+    if (a.act == ACT_LRELU01) return q_mtw(a) == 2 ? launch_q<2, PRO, 2>(a, st) : launch_q<1, PRO, 2>(a, st);
+  }
   const bool relu = a.act == ACT_RELU;
   if (q_mtw(a) == 2) return relu ? launch_q<2, PRO, 1>(a, st) : launch_q<2, PRO, 0>(a, st);
   return relu ? launch_q<1, PRO, 1>(a, st) : launch_q<1, PRO, 0>(a, st);

@@ -431,10 +431,18 @@ struct SdRun : DiscBase {
           hipLaunchKernelGGL(sd_l0_kernel, dim3(cdiv(Wp[0] / 4, 256), H, B), dim3(256), 0, st, x, sb, sh, L[0].w.wp,
                              L[0].w.bias, H, W, Wp[0], ac.a[0], ac.as[0]);
         } else {
-          const ConvArgs a = conv_args(i, i < 4 ? ac.as[i - 1] : ac.a[3], ac.a[i]);
-          chk(launch_conv1d(a, st));
-          hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, ac.a[i], n[i], Wp[i],
-                             i < 3 ? ac.as[i] : nullptr);
+          ConvArgs a = conv_args(i, i < 4 ? ac.as[i - 1] : ac.a[3], ac.a[i]);
+          a.act = ACT_LRELU01;  // bf16 mode: LeakyReLU and the column split happen in convp16's output stage
+          a.y_split = i < 3 ? ac.as[i] : nullptr;
+          if (convp16_eligible(a)) {
+            chk(launch_conv1d(a, st));
+          } else {
+            a.act = ACT_NONE;
+            a.y_split = nullptr;
+            chk(launch_conv1d(a, st));
+            hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(n[i], 256), 32, B), dim3(256), 0, st, ac.a[i], n[i], Wp[i],
+                               i < 3 ? ac.as[i] : nullptr);
+          }
         }
         hipLaunchKernelGGL(sd_score4_kernel, dim3(cdiv(cdiv(Wl[i], 4), 256), H, B), dim3(256), 0, st, ac.a[i], sw[i],
                            sw[i] + 288, H, Wl[i], Wp[i], ac.s[i]);

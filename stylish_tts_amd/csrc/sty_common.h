@@ -80,7 +80,8 @@ enum ConvPro : int {
   PRO_LRELU = 7,         // LeakyReLU(0.2) (style-encoder ResBlk, mel_style_encoder.py:106-113)
 };
 // epilogue activation applied to (acc + bias)
-enum ConvAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2, ACT_SNAKE = 3, ACT_GLU = 4, ACT_GELU = 5 };  // GELU: exact (erf)
+enum ConvAct : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2, ACT_SNAKE = 3, ACT_GLU = 4, ACT_GELU = 5,  // GELU: exact (erf)
+                     ACT_LRELU01 = 6 };  // LeakyReLU(0.1): convp16_kernel only (spectrogram discriminators), see y_split
 
 struct ConvArgs {
   // input: up to 3 channel-concatenated sources
@@ -117,6 +118,9 @@ struct ConvArgs {
   const float* ln_w = nullptr;
   const float* ln_b = nullptr;
   float* y = nullptr;
+  // convp16_kernel with ACT_LRELU01 only: second copy of the output split into even / odd time samples,
+  // [B][2 Cout][T/2] with the even samples in channels [0, Cout) (the input layout of a stride-2 conv, disc.hip); T % 4 == 0
+  float* y_split = nullptr;
   // conv32p_kernel only (conv32p_eligible(a) must hold): per-(b, cout, 256-column tile) partial (sum, sum of squares)
   // of the OUTPUT, laid out as launch_row_stats lays out its segments: [B * Cout][conv32p_stat_nseg(T)][2] doubles.
   // The AdaIN fold of the next layer then needs no pass of its own over the tensor.
