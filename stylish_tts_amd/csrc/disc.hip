@@ -11,10 +11,10 @@
 //
 //   * every activation is a padded-flat image [B][C][H][Wp] (conv2d.hip) with zeros in the columns past the valid
 //     width; Wp of the first layer is 8 (W3 + 4), so that three halvings keep >= 4 zero columns (the 3x9 window's reach);
-//   * layer 0 (one input channel) runs as a 27 -> 32 pointwise conv over 27 shifted copies of the spectrogram (the
-//     matrix pipe sees K = 27 -> 32 instead of 3 rows padded to 32 for each of 9 taps);
+//   * layer 0 (one input channel) is one fp32 VALU pass (conv + LeakyReLU + split); its weight gradient is a 27 -> 32
+//     pointwise GEMM over 27 shifted copies of the spectrogram, built only for the discriminator that is stepped;
 //   * the stride-2 layers read their input split into even and odd columns (64 channels [B][64][H][Wp/2], written by
-//     the LeakyReLU pass of the producing layer): out[wo] = sum_e W[2e] even[wo + e - 2] + W[2e + 1] odd[wo + e - 2] is
+//     the producing layer: convp16's output stage in bf16 mode, a LeakyReLU pass otherwise): out[wo] = sum_e W[2e] even[wo + e - 2] + W[2e + 1] odd[wo + e - 2] is
 //     a stride-1 3x5 conv over 64 channels -- the flat conv kernels of the acoustic path (convp16 in bf16 mode), their
 //     weight-gradient and input-gradient kernels run unchanged; one tap in ten is a structural zero;
 //   * the 32 -> 1 score convs and their backward are bandwidth-bound VALU kernels (a 32x padded MFMA tile would cost
