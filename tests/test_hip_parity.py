@@ -1321,23 +1321,25 @@ def test_training_from_sample_dataset_files(tmp_path, env):
     assert seen == len(lines)
 
 
-def test_bench_two_ranks_on_one_device():
+@pytest.mark.parametrize("workload,port", [("c2", 29517), ("c2-gan", 29518)])
+def test_bench_two_ranks_on_one_device(workload, port):
     """The N > 1 path of bench.py end to end (torchrun, utterance sharding, bucketed gradient all-reduce, max-over-ranks
-    timing, one JSON line on rank 0) with both ranks on device 0 and gloo as the transport (STY_BENCH_SHARE_DEVICE=1)."""
+    timing, one JSON line on rank 0) with both ranks on device 0 and gloo as the transport (STY_BENCH_SHARE_DEVICE=1);
+    c2-gan: the same with the discriminators' gradient buckets and optimizer steps in the exchange."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, STY_BENCH_SHARE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "c2"],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", workload],
                        capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
-    assert "roofline" in rec and rec["config"]["workload"].startswith("c2")
+    assert "roofline" in rec and rec["config"]["workload"].startswith(workload)
 
 
 
