@@ -320,6 +320,9 @@ struct CfRun : DiscBase {
       const int qmin = -((pad + c.s - 1) / c.s), qmax = (c.K - 1 - pad) / c.s;
       Kp[i] = qmax - qmin + 1;
       padp[i] = -qmin;
+      // four taps -> five with a structural zero: the bf16 weight-gradient kernel (wgradb) takes 1, 3 or 5 taps; the
+      // generic tile kernel it replaces ran these two layers at 112 TF
+      if (Kp[i] == 4 && c.Cin * c.s >= 64 && c.Cout >= 64) Kp[i] = 5;
       PackedConv& f = w[i];
       f.Cin = c.Cin * c.s;
       f.Cout = c.Cout;
