@@ -53,7 +53,7 @@ WORKLOADS = {
     "c3-gan": dict(B=32, T=520, L=100, what="train", compute="bf16", gan=True),
     "c2-gan": dict(B=16, T=160, L=37, what="train", gan=True),
     "c3-textual": dict(B=32, T=520, L=100, what="textual", compute="bf16"),
-    "c3-duration": dict(B=32, T=520, L=100, what="duration"),
+    "c3-duration": dict(B=32, T=520, L=100, what="duration", compute="bf16"),
     "c5": dict(B=8, T=800, L=0, what="vocoder"),
     "c5-bf16": dict(B=8, T=800, L=0, what="vocoder", compute="bf16"),
     "tts": dict(B=8, T=0, L=100, what="synth"),
@@ -304,7 +304,7 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
             dpm.load_state_dict(fill_state_dict(duration_predictor_manifest(), 3))
             dse.load_state_dict(fill_state_dict(style_encoder_manifest(), 7))
             stage_trainer = DurationTrainer(dpm.to(device), dse.to(device), PitchDiscriminator(dim_in=1, kernel=5).to(device),
-                                            torch.ones(16), lr=1e-4, seed=rank)
+                                            torch.ones(16), lr=1e-4, seed=rank, compute=w.get("compute", "fp32"))
     synth = None
     if w["what"] == "synth":
         import stylish_tts_amd as S

@@ -71,7 +71,7 @@ def duration_losses(pred, text_lengths, target_dur, target_class, ce_weight, w_d
 class DurationTrainer:
     def __init__(self, duration_predictor, duration_style_encoder, dur_disc, duration_weights, lr=1e-4, betas=(0.85, 0.99),
                  eps=1e-9, weight_decay=1e-4, w_gen=1.0, w_duration=8.0, w_ce=8.0, mean=-4.0, std=4.0,
-                 bucket_bytes=25 << 20, train_mode=True, seed=0, dropout=0.2):
+                 bucket_bytes=25 << 20, train_mode=True, seed=0, dropout=0.2, compute="fp32"):
         import random
         from .discriminators import DiscriminatorLossHelper
         from .optim import FlatAdamW
@@ -81,6 +81,10 @@ class DurationTrainer:
         self.w = dict(generator=w_gen, duration=w_duration, duration_ce=w_ce)  # config.yml:73-101
         self.mean, self.std = mean, std
         self.train_mode, self.dropout = train_mode, dropout
+        self.bf16 = compute == "bf16"  # bf16 operands on the dense convs of both graphs (as AcousticTrainer)
+        if self.bf16:
+            self.dp.set_train_opts(compute_bf16=True)
+            self.se.set_train_opts(compute_bf16=True)
         self._rng = random.Random(seed)
         kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, bucket_bytes=bucket_bytes)
         self.opt = {"duration_predictor": FlatAdamW(list(self.dp.named_parameters()), **kw),
@@ -94,8 +98,9 @@ class DurationTrainer:
         for o in self.opt.values():
             o.zero_grad()
         if self.train_mode:
-            self.dp.set_train_opts(dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.dropout)
-            self.se.set_train_opts(sn_power_iter=True)
+            self.dp.set_train_opts(dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.dropout,
+                                   compute_bf16=self.bf16)
+            self.se.set_train_opts(sn_power_iter=True, compute_bf16=self.bf16)
         style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)
         target_dur = durations.long()
         targets = dur_to_class(target_dur)

@@ -56,6 +56,8 @@ class TextualTrainer:
                 m_.set_train_opts(compute_bf16=True)
         # StageType.eval_models: the speech predictor only carries gradients to its pitch / energy inputs
         self.sp.set_train_opts(compute_bf16=self.bf16, frozen=True)
+        if self.bf16:
+            self.se.set_train_opts(compute_bf16=True)  # (honoured by the inference entry point the frozen encoder runs on)
         kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, bucket_bytes=bucket_bytes)
         self.opt = {"pitch_energy_predictor": FlatAdamW(list(self.pep.named_parameters()), **kw),
                     "pe_style_encoder": FlatAdamW(list(self.pse.named_parameters()), **kw),
