@@ -1120,6 +1120,7 @@ static void style_run(Run& r, const float* mel, int T, float* style) {
     a.out_mask = mask;
     a.out_mask_post = 1;
     a.y = y;
+    a.bf16 = r.m->topts.compute_bf16;  // the compute mode also applies to the inference plan (a frozen encoder of a stage)
     r.chk(launch_conv1d(a, r.st));
   };
   auto mask_for = [&](int Hh, int Ww, int Hv, int Wv) {
