@@ -138,9 +138,9 @@ __device__ __forceinline__ void stage_load_it(const ConvArgs& a, const float* xb
       if (q < TBASE / 64 || 64 * q < LW) {
         if constexpr (MODE == ST_FLAT) {
           // the row shift makes the lane offset NEGATIVE at the start of a channel row; with the column group folded
-          // into the instruction's immediate (offset:256 q) the first `pad` in-range samples came back as zeros on
-          // MI355X (image row 1, columns 0 .. pad-1 of every flat conv whose row pitch is >= 62): keep the whole
-          // offset in the VGPR, where the range check is the plain unsigned compare
+          // into the instruction's immediate (offset:256 q) the lanes whose sum is byte 0 or 4 of the row came back
+          // as zeros on MI355X (image row 1, columns 0 and 1 of every flat conv whose row pitch is >= 62;
+          // tools/probes/buffer_offset_probe.hip): keep the whole offset in the VGPR
           int off = vrow + 256 * q;
           asm volatile("" : "+v"(off));
           vv[u][q] = buf_load(rs, off);

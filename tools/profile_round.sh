@@ -40,5 +40,6 @@ python bench.py --workload c3-textual --steps 5 --warmup 2 --no-cpu-baseline --n
 python bench.py --workload c3-duration --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/${tag}_bench_c3_duration.json 2>/dev/null
 python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/buffer_offset_probe.hip -o /tmp/buffer_offset_probe 2>/dev/null && /tmp/buffer_offset_probe > $O/${tag}_buffer_offset_probe.txt
 rm -rf $O/c3_trace $O/c5_trace $O/c2_trace $O/c3_fetch/*/*agent_info.csv $O/c5_fetch/*/*agent_info.csv
 ls -la $O
