@@ -291,7 +291,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
     for (int i = 0; i < 16; ++i) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        if (q < 2 || lane + 64 * q < LWx) vx[i][q] = buf_load(rx, v0x + 256 * q + offx[i]);
+        if (q < 2 || lane + 64 * q < LWx) {
+          // (offset kept whole in the VGPR: a negative lane offset plus an instruction immediate returns zeros for bytes 0
+          // and 4 of the slab -- channel 0's first two samples under a row shift; tools/probes/buffer_offset_probe.hip)
+          int off = v0x + 256 * q + offx[i];
+          asm volatile("" : "+v"(off));
+          vx[i][q] = buf_load(rx, off);
+        }
 #pragma unroll
       for (int q = 0; q < 2; ++q) vg[i][q] = buf_load(rg, v0g + 256 * q + offg[i]);
     }
