@@ -389,7 +389,7 @@ int sty_cfdisc_losses(const sty_cfdisc_params *p, int B, int N, const float *tar
 
 /* The acoustic losses WITH the adversarial term of the three spectrogram discriminators (AcousticStep.generator_loss,
  * train/stage_type.py:208-220, "mrd" part of GeneratorLoss / DiscriminatorLoss, train/losses.py:191-208, 313-327; the
- * waveform discriminator `disc` is not built): as sty_acoustic_loss_fwd_bwd, plus
+ * waveform discriminator `disc` adds into the same d_audio_pred through sty_cfdisc_losses): as sty_acoustic_loss_fwd_bwd, plus
  *   d_audio_pred += w_gen * d (sum_r GeneratorLossHelper_r(target_fft_r, pred_fft_r)) / d audio_pred   (the "generator"
  *   loss enters LossLog.backwards_loss un-normalised, train/loss_log.py:84-86), and, from the same forward pass,
  *   the discriminator-side loss of every resolution; mrd_grads[r] += disc_scale * its parameter gradients for the

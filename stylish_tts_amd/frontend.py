@@ -3,8 +3,8 @@
   calculate_mel(audio, to_mel, mean, std)          train/utils.py:825-834 (to_mel = a MelSpec descriptor here)
   log_energy(mel, mean, std)                       train/utils.py:73-85 + stage_type.py:88-97 (returned by calculate_mel)
   MultiSpectrogram(sample_rate=).forward(*, target, pred)   train/multi_spectrogram.py:25-81
-Forward only (the reference computes the target side under no_grad; the prediction side needs the backward
-kernels, which are not built yet).
+Forward only: the backward of the prediction side lives inside the loss layer (sty_acoustic_loss_fwd_bwd /
+sty_acoustic_gan_loss_fwd_bwd compute the features and their gradient in one call).
 """
 import ctypes as C
 

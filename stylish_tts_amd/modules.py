@@ -12,9 +12,10 @@ Reference interfaces mirrored here (paths under the reference tree, src/stylish_
 run the library's training graph behind a torch.autograd.Function (so the reference's `train_acoustic` +
 `accelerator.backward(loss)` drive them unchanged; parameter gradients land in `param.grad`); the explicit
 `forward_train` / `backward` pair is the same thing without autograd (what AcousticTrainer uses).  The second-stage
-predictors are inference only and raise under autograd.  There is no PyTorch fallback anywhere.
+predictors have `forward_train` / `backward` (textual.py, duration.py drive them) but no autograd shim: their plain
+`forward` raises under autograd.  There is no PyTorch fallback anywhere.
 DurationPredictor / PitchEnergyPredictor / DurationProcessor / ExportModel (duration_predictor.py, pitch_energy_predictor.py,
-utils.py:656-803, export_model.py) are at the end of this file (inference only).
+utils.py:656-803, export_model.py) are at the end of this file.
 """
 import ctypes as C
 
