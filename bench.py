@@ -506,9 +506,16 @@ def main():
     device = torch.device("cuda", local)
 
     import __graft_entry__ as ge
+    from stylish_tts_amd import build as sbuild
+    before = os.path.getmtime(sbuild.LIB) if os.path.exists(sbuild.LIB) else None
     ge.build()
     from stylish_tts_amd import lib as L
     lib = L.load()
+    # which native library this run measured: the in-tree .so as shipped, or rebuilt here because a source was newer
+    import hashlib
+    with open(sbuild.LIB, "rb") as f:
+        lib_info = {"file": os.path.relpath(sbuild.LIB, ROOT), "sha1": hashlib.sha1(f.read()).hexdigest()[:12],
+                    "rebuilt_here": before is None or os.path.getmtime(sbuild.LIB) != before}
     rec = run_workload(args.workload, args.steps, args.warmup, rank, world, device, lib, L, D, share)
     extras = {}
     if world == 1 and args.workload == "c3" and not args.no_extra:
@@ -524,6 +531,7 @@ def main():
                 extras[name] = r
     if rank != 0:
         return
+    rec["library"] = lib_info
     if extras:
         rec["extra"] = extras
     if not args.no_cpu_baseline and world == 1:
