@@ -185,36 +185,53 @@ __global__ __launch_bounds__(256) void sd_post_kernel(float* __restrict__ z, int
 
 // score conv 32 -> 1, 3x3, pad 1 on the activation a [B][32][H][Wp] -> dense s [B][H][W]; four adjacent outputs per
 // thread (every row pitch is a multiple of 4): one 16-byte load + two edge samples feed 12 FMAs
+template <int RH>
 __global__ __launch_bounds__(256) void sd_score4_kernel(const float* __restrict__ a, const float* __restrict__ ws,
                                                         const float* __restrict__ bs, int H, int W, int Wp,
                                                         float* __restrict__ s) {
+  // One thread: 4 columns x RH output rows, so each input row is loaded once for the (up to) three output rows it feeds
+  // instead of once per output row (row-adjacent workgroups land on different XCDs and would not share an L2).
   __shared__ float wl[288];
   for (int i = threadIdx.x; i < 288; i += 256) wl[i] = ws[i];
   __syncthreads();
-  const int w0 = (blockIdx.x * 256 + threadIdx.x) * 4, h = blockIdx.y, b = blockIdx.z;
+  const int w0 = (blockIdx.x * 256 + threadIdx.x) * 4, h0 = blockIdx.y * RH, b = blockIdx.z;
   if (w0 >= W) return;
-  float acc[4];
-  acc[0] = acc[1] = acc[2] = acc[3] = bs[0];
+  float acc[RH][4];
+  const float bias = bs[0];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = bias;
   const float* ab = a + (size_t)b * 32 * H * Wp;
   for (int ci = 0; ci < 32; ++ci) {
+    float k[9];
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int hs = h + dh - 1;
+    for (int e = 0; e < 9; ++e) k[e] = wl[ci * 9 + e];
+#pragma unroll
+    for (int r = 0; r < RH + 2; ++r) {
+      const int hs = h0 + r - 1;
       if (hs < 0 || hs >= H) continue;
       const float* row = ab + ((size_t)ci * H + hs) * Wp + w0;
       const float4 m = *reinterpret_cast<const float4*>(row);
-      const float l = w0 > 0 ? row[-1] : 0.f, r = row[4];  // Wp >= W + 4 and W > w0: row[4] stays inside the row
-      const float k0 = wl[ci * 9 + dh * 3], k1 = wl[ci * 9 + dh * 3 + 1], k2 = wl[ci * 9 + dh * 3 + 2];
-      acc[0] = fmaf(k0, l, fmaf(k1, m.x, fmaf(k2, m.y, acc[0])));
-      acc[1] = fmaf(k0, m.x, fmaf(k1, m.y, fmaf(k2, m.z, acc[1])));
-      acc[2] = fmaf(k0, m.y, fmaf(k1, m.z, fmaf(k2, m.w, acc[2])));
-      acc[3] = fmaf(k0, m.z, fmaf(k1, m.w, fmaf(k2, r, acc[3])));
+      const float l = w0 > 0 ? row[-1] : 0.f, rr = row[4];  // Wp >= W + 4 and W > w0: row[4] stays inside the row
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) {  // input row hs is tap dh of output row hs - dh + 1; per output the order stays (ci, dh)
+        const int ro = r - dh;
+        if (ro < 0 || ro >= RH) continue;
+        const float k0 = k[dh * 3], k1 = k[dh * 3 + 1], k2 = k[dh * 3 + 2];
+        acc[ro][0] = fmaf(k0, l, fmaf(k1, m.x, fmaf(k2, m.y, acc[ro][0])));
+        acc[ro][1] = fmaf(k0, m.x, fmaf(k1, m.y, fmaf(k2, m.z, acc[ro][1])));
+        acc[ro][2] = fmaf(k0, m.y, fmaf(k1, m.z, fmaf(k2, m.w, acc[ro][2])));
+        acc[ro][3] = fmaf(k0, m.z, fmaf(k1, m.w, fmaf(k2, rr, acc[ro][3])));
+      }
     }
   }
-  float* so = s + ((size_t)b * H + h) * W + w0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (w0 + e < W) so[e] = acc[e];
+  for (int r = 0; r < RH; ++r) {
+    if (h0 + r >= H) break;
+    float* so = s + ((size_t)b * H + h0 + r) * W + w0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (w0 + e < W) so[e] = acc[r][e];
+  }
 }
 
 // gradient w.r.t. the pre-activation of layer i:
@@ -444,7 +461,7 @@ struct SdRun : DiscBase {
                                i < 3 ? ac.as[i] : nullptr);
           }
         }
-        hipLaunchKernelGGL(sd_score4_kernel, dim3(cdiv(cdiv(Wl[i], 4), 256), H, B), dim3(256), 0, st, ac.a[i], sw[i],
+        hipLaunchKernelGGL(sd_score4_kernel<4>, dim3(cdiv(cdiv(Wl[i], 4), 256), cdiv(H, 4), B), dim3(256), 0, st, ac.a[i], sw[i],
                            sw[i] + 288, H, Wl[i], Wp[i], ac.s[i]);
       }
     }
