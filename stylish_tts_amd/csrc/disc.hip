@@ -296,34 +296,54 @@ __global__ __launch_bounds__(256) void sd_gz4_kernel(const float* __restrict__ g
 
 // score conv weight gradient: acc[c*9 + t] += sum a[c][h + dh - 1][w + dw - 1] gs[h][w]; acc[288] += sum gs  (doubles)
 __global__ __launch_bounds__(256) void sd_score_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ gs,
-                                                             int B, int H, int W, int Wp, double* __restrict__ acc) {
-  __shared__ float red[256];
-  const int c = blockIdx.y;
+                                                             int H, int W, int Wp, double* __restrict__ acc) {
+  // One thread: four activations of channel c (one float4) against the 3 x 6 score gradients they met in the forward,
+  // so the activation tensor is read exactly once with vector loads; gs is small and stays in L2.
+  __shared__ float red[4][10];
+  const int c = blockIdx.y, b = blockIdx.z, Wq = Wp >> 2;
   float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sb = 0.f;
-  const size_t total = (size_t)B * H * W;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int w = (int)(i % W), h = (int)((i / W) % H), b = (int)(i / ((size_t)W * H));
-    const float g = gs[i];
-    sb += g;
-    const float* ab = a + ((size_t)b * 32 + c) * H * Wp;
+  const float* ab = a + ((size_t)b * 32 + c) * H * Wp;
+  const float* g = gs + (size_t)b * H * W;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * Wq; i += gridDim.x * 256) {
+    const int h = i / Wq, w0 = (i - h * Wq) * 4;
+    if (w0 >= W) continue;
+    const float4 av = *reinterpret_cast<const float4*>(ab + (size_t)h * Wp + w0);
+    float v[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int hs = h + dh - 1;
-      if (hs < 0 || hs >= H) continue;
-      const float* row = ab + (size_t)hs * Wp;
-      s[dh * 3] = fmaf(w > 0 ? row[w - 1] : 0.f, g, s[dh * 3]);
-      s[dh * 3 + 1] = fmaf(row[w], g, s[dh * 3 + 1]);
-      s[dh * 3 + 2] = fmaf(row[w + 1], g, s[dh * 3 + 2]);
+    for (int e = 0; e < 4; ++e)
+      if (w0 + e >= W) v[e] = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {  // a[h][w] was tap (dh, dw) of the score at (h - dh + 1, w - dw + 1)
+      const int ho = h - dh + 1;
+      if (ho < 0 || ho >= H) continue;
+      const float* gr = g + (size_t)ho * W;
+      float x[6];  // gs[ho][w0 - 1 .. w0 + 4]
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int wo = w0 - 1 + e;
+        x[e] = (wo >= 0 && wo < W) ? gr[wo] : 0.f;
+      }
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[dh * 3 + dw] = fmaf(v[e], x[e + 2 - dw], s[dh * 3 + dw]);
+      if (dh == 1 && c == 0) sb += (x[1] + x[2]) + (x[3] + x[4]);
     }
   }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const float r = sd_block_sum(s[t], red);
-    if (threadIdx.x == 0) atomicAdd(&acc[c * 9 + t], (double)r);
+    float r = s[t];
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+    if (lane == 0) red[wave][t] = r;
   }
-  if (c == 0) {
-    const float r = sd_block_sum(sb, red);
-    if (threadIdx.x == 0) atomicAdd(&acc[288], (double)r);
+  for (int o = 32; o > 0; o >>= 1) sb += __shfl_xor(sb, o);
+  if (lane == 0) red[wave][9] = sb;
+  __syncthreads();
+  if (threadIdx.x < 9 || (threadIdx.x == 9 && c == 0)) {
+    const int t = threadIdx.x;
+    const float r = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    atomicAdd(&acc[t == 9 ? 288 : c * 9 + t], (double)r);
   }
 }
 
@@ -488,8 +508,8 @@ struct SdRun : DiscBase {
       const ConvArgs f = conv_args(i, in, nullptr);
       if (gwp) {
         if (live())
-          hipLaunchKernelGGL(sd_score_wgrad_kernel, dim3(256, 32), dim3(256), 0, st, ac.a[i], gs[i], B, H, Wl[i], Wp[i],
-                             sacc[i]);
+          hipLaunchKernelGGL(sd_score_wgrad_kernel, dim3(min(64, cdiv(n[i] / 4, 256)), 32, B), dim3(256), 0, st, ac.a[i],
+                             gs[i], H, Wl[i], Wp[i], sacc[i]);
         float* partial = take<float>(wgrad_partial_floats(f.w, B, n[i]));
         bool bias_done = false;
         if (live()) chk(launch_conv1d_wgrad(f, gz, nullptr, 1.f, gwp[i], partial, gbp[i], &bias_done, st));

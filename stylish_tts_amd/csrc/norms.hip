@@ -111,45 +111,39 @@ int launch_adain_finalize(const double* part, int nseg, const float* gb, int B, 
   return STY_OK;
 }
 
-// GRN over time (conv_next.py:15-18): one block per batch row; the per-segment partials of one channel are summed
-// by 256/C4 threads in parallel (fixed order -> deterministic), then combined through LDS.
-__global__ __launch_bounds__(256) void grn_finalize_kernel(const double* __restrict__ part, int nseg,
-                                                           const float* __restrict__ gamma, int C4,
-                                                           float* __restrict__ scale) {
-  __shared__ float red[256];
+// GRN over time (conv_next.py:15-18): one block of 16 waves per batch row.  The per-segment partials of one channel are
+// summed by a group of G lanes (G = power of two covering nseg, at most a wave) in a fixed order -> deterministic; a wave
+// works on 64 / G channels at a time.  (256 threads with one serial loop per channel took 17-25 us per call.)
+__global__ __launch_bounds__(1024) void grn_finalize_kernel(const double* __restrict__ part, int nseg, int G,
+                                                            const float* __restrict__ gamma, int C4,
+                                                            float* __restrict__ scale) {
+  __shared__ float red[16];
   __shared__ float gxs[1024];
-  __shared__ double psum[256];
-  const int b = blockIdx.x;
-  const int cw = C4 < 256 ? C4 : 256;  // channels handled concurrently
-  const int ngr = 256 / cw;            // threads cooperating on one channel
-  const int cl = threadIdx.x % cw, g = threadIdx.x / cw;
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cpw = 64 / G, sub = lane / G, gl = lane % G;
   float loc = 0.f;
-  for (int c0 = 0; c0 < C4; c0 += cw) {
-    const int c = c0 + cl;
+  for (int c0 = wave * cpw; c0 < C4; c0 += 16 * cpw) {
+    const int c = c0 + sub;
     double sq = 0.0;
-    if (g < ngr && c < C4) {
+    if (c < C4) {
       const double* p = part + ((size_t)b * C4 + c) * nseg * 2 + 1;
-      for (int k = g; k < nseg; k += ngr) sq += p[(size_t)k * 2];
+      for (int k = gl; k < nseg; k += G) sq += p[(size_t)k * 2];
     }
-    psum[threadIdx.x] = sq;
-    __syncthreads();
-    if (g == 0 && c < C4) {
-      double t = 0.0;
-      for (int i = 0; i < ngr; ++i) t += psum[i * cw + cl];
-      const float gx = (float)sqrt(t);
+    for (int o = G >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (gl == 0 && c < C4) {
+      const float gx = (float)sqrt(sq);
       gxs[c] = gx;
       loc += gx;
     }
-    __syncthreads();
   }
-  red[threadIdx.x] = loc;
+  for (int o = 32; o > 0; o >>= 1) loc += __shfl_xor(loc, o);
+  if (lane == 0) red[wave] = loc;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  const float mean = red[0] / (float)C4;
-  for (int c = threadIdx.x; c < C4; c += 256) scale[(size_t)b * C4 + c] = 1.f + gamma[c] * (gxs[c] / (mean + 1e-6f));
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tot += red[i];
+  const float mean = tot / (float)C4;
+  for (int c = threadIdx.x; c < C4; c += 1024) scale[(size_t)b * C4 + c] = 1.f + gamma[c] * (gxs[c] / (mean + 1e-6f));
 }
 
 int launch_grn_finalize(const double* part, int nseg, const float* gamma, int B, int C4, float* scale,
@@ -158,7 +152,9 @@ int launch_grn_finalize(const double* part, int nseg, const float* gamma, int B,
     set_error("grn_finalize: 4C = %d > 1024", C4);
     return STY_EINVAL;
   }
-  hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, st, part, nseg, gamma, C4, scale);
+  int G = 1;
+  while (G < 64 && G < nseg) G <<= 1;
+  hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(1024), 0, st, part, nseg, G, gamma, C4, scale);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
