@@ -380,6 +380,7 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     t0 = time.perf_counter()
     for i in range(steps):
         out = step(warmup + 1 + i)
+    host_dt = time.perf_counter() - t0  # the host's time to ISSUE the steps (no sync yet): far below dt = it runs ahead
     barrier()
     dt = time.perf_counter() - t0
     lib.sty_prof_enable(0)
@@ -427,6 +428,7 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                             "forward + backward + AdamW (mel + multi-phase + generator loss of the three spectrogram discriminators and "
                             "the waveform discriminator; discriminator losses + AdamW step of mrd{i} and disc; WavLM off)"),
                    "x_realtime": frames / dt / 80.0},
+        "host_issue_ms_per_step": 1e3 * host_dt / steps,
     }
     if prof:
         dom = max(prof, key=lambda r: r["ms"])

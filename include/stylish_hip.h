@@ -250,6 +250,11 @@ int sty_style_train_workspace_bytes(sty_model *m, int B, int T, size_t *bytes);
 int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *style, void *workspace, size_t ws_bytes,
                         void *stream);
 int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
+/* Optional: the weight-side half of the next sty_style_fwd_train / sty_pitch_style_fwd_train (spectral-norm power
+ * iteration of module.train(), normalised and packed weights) issued on `stream` ahead of time, e.g. while another stream
+ * still computes the mel input; that forward (which must be issued on the same stream) then skips it.  The parameters
+ * and train opts must not change in between.                                                                        */
+int sty_style_prepare_train(sty_model *m, void *stream);
 /* AcousticStep.pitch_loss for one curve (train/stage_type.py:236-262: smooth_l1(target, pred) + smooth_l1 of their first
  * differences, means): loss[0] = value; d_pred [B,T] += k * d loss / d pred with k = weight / (loss + 1e-9) when `normalize`
  * (LossLog.backwards_loss, train/loss_log.py:82-94) or k = weight.  workspace: 16 bytes.                               */

@@ -157,6 +157,14 @@ class AcousticTrainer:
                                    dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.text_dropout,
                                    compute_bf16=self.bf16)
             self.se.set_train_opts(sn_power_iter=True, compute_bf16=self.bf16)
+        # the style encoder's weight-side work (spectral-norm power iteration, normalised + packed weights: ~1 ms of small
+        # launches) needs no input: it goes to the side stream before the mel front ends are issued on the main stream
+        main = torch.cuda.current_stream(audio_gt.device)
+        side = self._side_stream(audio_gt.device)
+        if side is not None:
+            side.wait_stream(main)  # (the previous step's optimizer)
+            with torch.cuda.stream(side):
+                self.se.prepare_train(audio_gt.device)
         mel, _, energy = calculate_mel(audio_gt, TO_MEL, self.mean, self.std, want_energy=True)
         style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)
         T = mel.shape[2]
@@ -164,8 +172,6 @@ class AcousticTrainer:
         # Two streams: the style encoder (mid-size GEMMs) runs beside the text encoder (a chain of tiny kernels) in
         # both directions.  Forward: the predictor waits for `style` only after its text encoder; backward: d_style
         # is complete before the text encoder's backward, and the style encoder's backward starts from there.
-        main = torch.cuda.current_stream(audio_gt.device)
-        side = self._side_stream(audio_gt.device)
         style_in = style_mel.unsqueeze(1)
         if side is not None:
             side.wait_stream(main)

@@ -1461,6 +1461,7 @@ int sty_model_finalize(sty_model* m) {
     set_error("null model");
     return STY_EINVAL;
   }
+  m->train_prepared = false;
   if (m->arena) {
     (void)hipFree(m->arena);
     m->arena = nullptr;
@@ -1847,6 +1848,7 @@ int sty_model_invalidate(sty_model* m) {
     return STY_EINVAL;
   }
   m->prepared = false;
+  m->train_prepared = false;
   return STY_OK;
 }
 
@@ -2543,6 +2545,40 @@ int sty_style_fwd(sty_model* m, int B, int T, const float* mel, float* style, vo
   if (!m->prepared && (rc = sty_model_prepare(m, stream))) return rc;
   return style_entry(m, B, T, mel, style, workspace, ws_bytes, stream, nullptr);
 }
+// Weight-side half of a style encoder's training forward: the training-mode spectral-norm power iteration (u, v in the
+// caller's buffers) and the prepared (normalised, packed) weights.  It depends on the parameters only, so a caller may
+// issue it early (sty_style_prepare_train) beside the work that produces the encoder's input; the forward then skips it.
+static int style_train_prepare(sty_model* m, void* stream) {
+  if (m->train_prepared) {  // done by sty_style_prepare_train since the last forward
+    m->train_prepared = false;
+    return STY_OK;
+  }
+  int rc;
+  if (m->topts.sn_power_iter) {
+    for (const PackJob& j : m->jobs) {
+      if (j.kind != PK_CONV2D_SN && j.kind != PK_DW2D_SN) continue;
+      const int n = j.kind == PK_CONV2D_SN ? j.Cin * j.KH * j.K : 9;
+      rc = launch_sn_power_iter(j.w, const_cast<float*>(j.g), const_cast<float*>(j.v), j.Cout, n, j.scratch2, S(stream));
+      if (rc) return rc;
+    }
+  }
+  // weights change between steps: re-derive the prepared form every step
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->prepared = false;
+  return STY_OK;
+}
+int sty_style_prepare_train(sty_model* m, void* stream) {
+  int rc = model_ready(m, "mel_style_encoder", "pitch_style_encoder");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  m->train_prepared = false;
+  if ((rc = style_train_prepare(m, stream))) return rc;
+  m->train_prepared = true;
+  return STY_OK;
+}
 int sty_style_train_workspace_bytes(sty_model* m, int B, int T, size_t* bytes) {
   int rc = model_ready(m, "mel_style_encoder");
   if (rc) return rc;
@@ -2565,17 +2601,7 @@ int sty_style_fwd_train(sty_model* m, int B, int T, const float* mel, float* sty
     set_error("sty_style_fwd_train: bad argument (T >= 40 frames)");
     return STY_EINVAL;
   }
-  if (m->topts.sn_power_iter) {  // training-mode spectral norm: refresh u, v (in the caller's buffers) first
-    for (const PackJob& j : m->jobs) {
-      if (j.kind != PK_CONV2D_SN && j.kind != PK_DW2D_SN) continue;
-      const int n = j.kind == PK_CONV2D_SN ? j.Cin * j.KH * j.K : 9;
-      rc = launch_sn_power_iter(j.w, const_cast<float*>(j.g), const_cast<float*>(j.v), j.Cout, n, j.scratch2, S(stream));
-      if (rc) return rc;
-    }
-  }
-  // weights change between steps: re-derive the prepared (spectral-normalised, packed) form every call
-  if ((rc = sty_model_prepare(m, stream))) return rc;
-  m->prepared = false;
+  if ((rc = style_train_prepare(m, stream))) return rc;
   if (!m->trainer) m->trainer = trainer_create(m);
   return trainer_style_forward(m->trainer, B, T, mel, style, workspace, ws_bytes, S(stream), nullptr);
 }
@@ -2602,16 +2628,7 @@ int sty_pitch_style_fwd_train(sty_model* m, int B, int T, const float* mel, cons
     set_error("sty_pitch_style_fwd_train: bad argument (T >= 40 frames)");
     return STY_EINVAL;
   }
-  if (m->topts.sn_power_iter) {
-    for (const PackJob& j : m->jobs) {
-      if (j.kind != PK_CONV2D_SN && j.kind != PK_DW2D_SN) continue;
-      const int n = j.kind == PK_CONV2D_SN ? j.Cin * j.KH * j.K : 9;
-      rc = launch_sn_power_iter(j.w, const_cast<float*>(j.g), const_cast<float*>(j.v), j.Cout, n, j.scratch2, S(stream));
-      if (rc) return rc;
-    }
-  }
-  if ((rc = sty_model_prepare(m, stream))) return rc;
-  m->prepared = false;
+  if ((rc = style_train_prepare(m, stream))) return rc;
   if (!m->trainer) m->trainer = trainer_create(m);
   return trainer_style_forward(m->trainer, B, T, mel, style, workspace, ws_bytes, S(stream), nullptr, pitch, energy);
 }

@@ -216,6 +216,7 @@ struct sty_model {
   std::unordered_map<std::string, sty::Param> params;
   std::vector<std::string> requested;
   bool finalized = false, prepared = false;
+  bool train_prepared = false;  // sty_style_prepare_train ran and the next training forward has not consumed it yet
   int style_dim = 64;
   // prepared-weight arena
   char* arena = nullptr;
