@@ -23,7 +23,7 @@ python tools/pmc_traffic.py $O/c5_fetch $O/c5_write > $O/${tag}_c5_pmc_traffic.j
 python tools/rocpd_summary.py $O/c3_trace/*/*_results.db > $O/${tag}_c3_kernel_stats.txt
 python tools/rocpd_summary.py $O/c5_trace/*/*_results.db > $O/${tag}_c5_kernel_stats.txt
 python tools/rocpd_summary.py $O/c2_trace/*/*_results.db > $O/${tag}_c2_kernel_stats.txt
-python tools/stream_busy.py $O/c3_trace/*/*_results.db > $O/${tag}_c3_streams.txt
+python tools/stream_busy.py $O/c3_trace/*/*_results.db 6 > $O/${tag}_c3_streams.txt
 # where the main stream waits inside one timed step (the last steps of a bench run are its single-stream extras: skip 6)
 python tools/step_gaps.py $O/c3_trace/*/*_results.db 6 150 > $O/${tag}_c3_gaps.txt
 python tools/step_gaps.py $O/c2_trace/*/*_results.db 6 150 > $O/${tag}_c2_gaps.txt
