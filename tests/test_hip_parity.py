@@ -1266,6 +1266,44 @@ def test_style_encoder_train_mode_vs_reference_golden():
     rep.done()
 
 
+def test_style_encoder_prepare_train_then_forward_matches_reference_golden():
+    """sty_style_prepare_train (the weight-side half issued ahead of the input, here on another stream) followed by
+    forward_train must be the same training forward: one power iteration, not two, same style and gradients as the
+    REFERENCE in .train() (tests/golden/se_train_small.safetensors); the call after it prepares for itself again."""
+    import stylish_tts_amd as S
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    from safetensors.torch import load_file
+    from tests.cases import make_case
+    gold = load_file(os.path.join(G, "se_train_small.safetensors"))
+    se = S.MelStyleEncoder()
+    se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+    se = se.to(DEV).enable_training().set_train_opts(sn_power_iter=True)
+    mel = dev(make_case("se_small")["mel"])
+    side = torch.cuda.Stream(device=DEV)
+    main = torch.cuda.current_stream(DEV)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        se.prepare_train(DEV)
+        out = se.forward_train(mel)
+        se.backward(dev(gold["cotangent"]))
+    main.wait_stream(side)
+    torch.cuda.synchronize()
+    rep = Report()
+    rep.add("style", out, gold["style"], 1e-5)
+    sd = se.state_dict()
+    named = dict(se.named_parameters())
+    for k in ("shared.0", "shared.2.conv1", "shared.6"):
+        rep.add(k + ".weight_u", sd[k + ".weight_u"], gold[k + ".weight_u"], 1e-5)
+        rep.add("d " + k + ".weight_orig", _sub(named[k + ".weight_orig"].grad), gold["grad." + k + ".weight_orig"], 1e-3)
+    rep.done()
+    # a second forward without prepare_train runs its own power iteration: u moves on
+    u1 = sd["shared.0.weight_u"].clone()
+    se.forward_train(mel)
+    torch.cuda.synchronize()
+    assert not torch.equal(u1, se.state_dict()["shared.0.weight_u"])
+
+
 def test_speech_predictor_dropout_vs_patched_reference_golden(env):
     """Dropout on the HIP path (counter-based hash masks in the TextEncoder: prenet, attention probabilities inside the
     MFMA attention kernel and its backward, post-attention, FFN) vs the REFERENCE run in .train() with F.dropout / SDPA
