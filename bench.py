@@ -482,6 +482,22 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
 EXTRA_WORKLOADS = ("c2", "c5", "c3-fp32", "c3-gan")
 
 
+def _launch_ranks(n):
+    """Re-run this command as n ranks under torch.distributed.run (127.0.0.1 rendezvous on a free port) and pass its
+    output through; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -492,6 +508,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c5 / c3-fp32 / c3-gan sub-records of the default run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` called directly: become the launcher.  One process per GPU, as the reference gets
+        # its ranks from accelerate (train/train_context.py:94-104, train/train.py:188,208-211); the ranks run this
+        # same file with the torchrun environment set and rank 0 prints the one JSON line.
+        sys.exit(_launch_ranks(args.gpus))
 
     from stylish_tts_amd import dist as D
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -507,7 +529,12 @@ def main():
         os.environ.setdefault("STY_NO_SE_STREAM", "1")
     local = 0 if share else local
     torch.cuda.set_device(local)
+    if not share and torch.cuda.device_count() < int(os.environ.get("WORLD_SIZE", "1")):
+        raise SystemExit(f"bench.py: {os.environ['WORLD_SIZE']} ranks asked for, {torch.cuda.device_count()} HIP devices "
+                         "visible (one process per GPU; STY_BENCH_SHARE_DEVICE=1 is the 1-GPU test aid)")
     rank, world = D.init("gloo" if share else "nccl")  # "nccl" = RCCL; one process per GPU (torchrun environment)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
     device = torch.device("cuda", local)
 
     import __graft_entry__ as ge
@@ -520,7 +547,8 @@ def main():
     import hashlib
     with open(sbuild.LIB, "rb") as f:
         lib_info = {"file": os.path.relpath(sbuild.LIB, ROOT), "sha1": hashlib.sha1(f.read()).hexdigest()[:12],
-                    "rebuilt_here": before is None or os.path.getmtime(sbuild.LIB) != before}
+                    "rebuilt_here": before is None or os.path.getmtime(sbuild.LIB) != before,
+                    "hipcc": sbuild.hipcc_version()}
     rec = run_workload(args.workload, args.steps, args.warmup, rank, world, device, lib, L, D, share)
     extras = {}
     if world == 1 and args.workload == "c3" and not args.no_extra:
@@ -534,9 +562,16 @@ def main():
                 r.pop("kernels", None)
                 r.pop("kernels_source", None)
                 extras[name] = r
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     rec["library"] = lib_info
+    rec["ranks"] = {"world_size": world, "launcher": "torch.distributed.run, one process per GPU" if world > 1 else "single process",
+                    "backend": (torch.distributed.get_backend() + (" (RCCL)" if not share else " (share-device test aid)"))
+                    if world > 1 else None,
+                    "devices": 1 if share else world}
     if extras:
         rec["extra"] = extras
     if not args.no_cpu_baseline and world == 1:

@@ -72,12 +72,17 @@ class AcousticTrainer:
 
     def __init__(self, speech_predictor, style_encoder, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4,
                  w_mel=5.0, w_phase=8.0, mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0,
-                 text_dropout=0.2, compute="fp32", mrd=None, w_gen=1.0, disc=None):
+                 text_dropout=0.2, compute="fp32", mrd=None, w_gen=1.0, disc=None, shared_seed=1):
         import random
         from .optim import FlatAdamW
         self.train_mode = train_mode
         self.text_dropout = text_dropout  # model.yml text_encoder.dropout
-        self._rng = random.Random(seed)  # the Decoder's smoothing draws (decoder.py:55-57)
+        self._rng = random.Random(seed)  # the Decoder's smoothing draws (decoder.py:55-57): per rank
+        # which spectrogram discriminator a step trains (stage.py:119 random.randrange(3)) must be the SAME on every
+        # rank -- the three mrd buckets have equal sizes, so ranks that disagreed would sum mrd0's gradients into
+        # mrd2's without an error.  The reference seeds `random` with 1 in every process (train/train.py:88); this
+        # generator is seeded identically on all ranks and used for nothing else.
+        self._shared_rng = random.Random(shared_seed)
         self.sp, self.se = speech_predictor.enable_training(), style_encoder.enable_training()
         if compute not in ("fp32", "bf16"):
             raise ValueError(f"compute must be 'fp32' or 'bf16', not {compute!r}")
@@ -92,7 +97,9 @@ class AcousticTrainer:
         # gradient segments of the predictor (sty_model_set_grad_hook): 1 = text_encoder.* (its backward runs last),
         # 0 = everything else -- buckets never mix the two, so that segment 0 is in flight during the text encoder's
         # backward
-        seg = lambda name: 1 if name.startswith("text_encoder.") else 0
+        # -1 = never stepped: m_source.l_linear runs under torch.no_grad() in the reference (generator.py:711-729), its
+        # .grad stays None there and torch's AdamW leaves it alone (no weight decay either)
+        seg = lambda name: -1 if ".m_source.l_linear." in name else (1 if name.startswith("text_encoder.") else 0)
         self.opt = {"speech_predictor": FlatAdamW(list(self.sp.named_parameters()), group_of=seg, **kw),
                     "speech_style_encoder": FlatAdamW(list(self.se.named_parameters()), **kw)}
         self.mrd = list(mrd) if mrd is not None else None
@@ -187,7 +194,8 @@ class AcousticTrainer:
         else:
             # stage.py:116-121: disc_index = random.randrange(3); both sides of the adversarial game from one pass
             if disc_index is None:
-                disc_index = self._rng.randrange(3)
+                disc_index = self._shared_rng.randrange(3)
+            self.disc_index = disc_index
             losses, self.gan, d_audio = acoustic_gan_loss(
                 audio_gt, audio.squeeze(1), self.mrd, w_mel=self.w_mel, w_phase=self.w_phase, w_gen=self.w_gen,
                 disc_scale=float(texts.shape[0]) ** 0.5, step=(disc_index,), compute_bf16=self.bf16)
@@ -242,9 +250,11 @@ class AcousticTrainer:
     def sync_buffers(self, src=0):
         """Broadcast the non-trainable state the training step updates per rank -- BatchNorm running statistics
         (conformer.py:183) and the spectral-norm u / v vectors -- from rank `src`.  The reference's accelerate DDP
-        wrappers do this on every forward (broadcast_buffers=True); here ranks are left to drift between calls (the
-        statistics of 32 utterances per rank differ in the fourth digit) and are aligned when it matters: before a
-        checkpoint is written and before evaluation."""
+        wrappers are built with broadcast_buffers=False (train/train_context.py:94-96): its ranks drift too, and its
+        checkpoint holds rank 0's buffers because only the main process writes it.  Same behaviour here: ranks drift
+        between calls (the statistics of 32 utterances per rank differ in the fourth digit); this call makes every rank
+        hold rank 0's, and stage_io.save_checkpoint(trainer=...) makes it before writing.  Call it before evaluation on
+        ranks other than 0 as well."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
@@ -253,9 +263,25 @@ class AcousticTrainer:
                 if b.is_floating_point():
                     dist.broadcast(b, src)
             L.check(L.load().sty_model_invalidate(m._handle)) if m._handle is not None else None
-        if getattr(self, "disc", None) is not None:  # the waveform discriminator's BatchNorm running statistics
-            for b in self.disc.buffers():
-                dist.broadcast(b, src)
+        # the discriminators' buffers: the waveform discriminator's BatchNorm running statistics
+        for m in ([self.disc] if getattr(self, "disc", None) is not None else []) + list(self.mrd or []):
+            for b in m.buffers():
+                if b.is_floating_point():
+                    dist.broadcast(b, src)
+
+    def checkpoint_state(self):
+        """What stage_io.save_checkpoint / load_checkpoint take for this trainer: models, optimizers and loss helpers under
+        the reference's model keys (models.py:69-83)."""
+        models = {"speech_predictor": self.sp, "speech_style_encoder": self.se}
+        helpers = {}
+        if self.mrd is not None:
+            for i, m in enumerate(self.mrd):
+                models[f"mrd{i}"] = m
+                helpers[f"mrd{i}"] = self.disc_helpers[i]
+        if self.disc is not None:
+            models["disc"] = self.disc
+            helpers["disc"] = self.disc_helper
+        return dict(models=models, optimizers=dict(self.opt), disc_helpers=helpers, trainer=self)
 
     def schedule(self, step, step_limit):
         """Stage.steps / MultiOptimizer.scheduler (train/optimizers.py:96-104): cosine schedule with a 90 % plateau."""

@@ -19,6 +19,18 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def hipcc_version():
+    """first line of `hipcc --version` that names the HIP version (what compiled the shipped library), or None"""
+    try:
+        out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception:
+        return None
+    for ln in out.splitlines():
+        if "HIP version" in ln:
+            return ln.strip()
+    return out.splitlines()[0].strip() if out else None
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True

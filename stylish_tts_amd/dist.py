@@ -98,7 +98,8 @@ class GradBuckets:
 
     def reduce_all(self):
         for i in range(len(self.buckets)):
-            self.reduce_bucket(i)
+            if self.bucket_group[i] >= 0:  # (a negative segment holds parameters that never get a gradient)
+                self.reduce_bucket(i)
 
     def reduce_group(self, group):
         """Start the all-reduce of every bucket of one gradient segment (called from the library's gradient hook, while

@@ -12,9 +12,19 @@ from .dist import GradBuckets
 
 
 class FlatAdamW:
+    """`group_of(name) -> int` (with (name, tensor) pairs): gradient segment of a parameter (dist.GradBuckets).  A NEGATIVE
+    group marks parameters that never receive a gradient (the harmonic source's l_linear sits under torch.no_grad() in
+    the reference, generator.py:711-729): torch.optim.AdamW skips a parameter whose .grad is None -- no moment update, no
+    weight decay -- so their buckets are bound like the others (the library wants a gradient pointer for every key) but
+    never stepped, and they carry no entry in state_dict()."""
+
     def __init__(self, params, lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4, bucket_bytes=25 << 20,
                  group_of=None):
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        params = list(params)
+        # index of every parameter in the list torch.optim.AdamW(module.parameters()) would hold (frozen ones included):
+        # the key of its entry in an optimizer state_dict
+        self._all = [(q[1] if isinstance(q, tuple) else q) for q in params]
         self.grads = GradBuckets(params, bucket_bytes, group_of)
         self.grads.attach()
         self.flat_p, self.m, self.v = [], [], []
@@ -35,7 +45,9 @@ class FlatAdamW:
         """grad_scale multiplies the gradient inside the kernel (1 / world_size after a SUM all-reduce)."""
         lib = L.load()
         self.t += 1
-        for (gflat, _), p, m, v in zip(self.grads.buckets, self.flat_p, self.m, self.v):
+        for (gflat, _), p, m, v, grp in zip(self.grads.buckets, self.flat_p, self.m, self.v, self.grads.bucket_group):
+            if grp < 0:
+                continue
             if not gflat.is_cuda:
                 raise L.StyError("FlatAdamW.step: parameters must live on the GPU (there is no CPU path)")
             st = C.c_void_p(torch.cuda.current_stream(gflat.device).cuda_stream)
@@ -47,6 +59,70 @@ class FlatAdamW:
         for _, items in self.grads.buckets:
             for p, _, _ in items:
                 torch.autograd.graph.increment_version(p)
+
+
+    # ---- torch.optim.AdamW's state_dict format (what accelerate writes as optimizer[_i].bin) ---------------------------
+    def _slots(self):
+        """parameter index (torch's numbering) -> (bucket, offset, numel, shape)"""
+        index = {id(p): i for i, p in enumerate(self._all)}
+        out = {}
+        for b, (_, items) in enumerate(self.grads.buckets):
+            if self.grads.bucket_group[b] < 0:
+                continue
+            for p, off, n in items:
+                out[index[id(p)]] = (b, off, n, tuple(p.shape))
+        return out
+
+    def state_dict(self):
+        """The optimizer's state un-flattened into torch.optim.AdamW's layout: state[i] = {step, exp_avg, exp_avg_sq}
+        for every parameter that has been stepped, one param_group with the hyper-parameters; torch.optim.AdamW built
+        over the same module's parameters loads it unchanged (train/optimizers.py:110-118 builds exactly that)."""
+        state = {}
+        if self.t > 0:
+            for i, (b, off, n, shape) in sorted(self._slots().items()):
+                state[i] = {"step": torch.tensor(float(self.t)),
+                            "exp_avg": self.m[b][off:off + n].detach().reshape(shape).clone(),
+                            "exp_avg_sq": self.v[b][off:off + n].detach().reshape(shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": True, "initial_lr": getattr(self, "initial_lr", self.lr),
+                 "params": list(range(len(self._all)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Inverse of state_dict; also reads what torch.optim.AdamW.state_dict() / accelerate's optimizer.bin hold.
+        Parameters without an entry (never stepped) restart from zero moments, as torch does."""
+        slots = self._slots()
+        groups = sd.get("param_groups", [])
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self._all):
+            raise L.StyError(f"optimizer state: expected one param_group over {len(self._all)} parameters, got "
+                             f"{[len(g['params']) for g in groups]}")
+        g = groups[0]
+        lr = g["lr"]
+        self.lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]
+        if "initial_lr" in g:
+            il = g["initial_lr"]
+            self.initial_lr = float(il.item()) if torch.is_tensor(il) else float(il)
+        for m, v in zip(self.m, self.v):
+            m.zero_()
+            v.zero_()
+        steps = set()
+        for i, st in sd.get("state", {}).items():
+            i = int(i)
+            if i not in slots:
+                raise L.StyError(f"optimizer state: parameter {i} has state but is never stepped here")
+            b, off, n, shape = slots[i]
+            if tuple(st["exp_avg"].shape) != shape:
+                raise L.StyError(f"optimizer state: parameter {i} is {shape} here, {tuple(st['exp_avg'].shape)} in the file")
+            self.m[b][off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[b][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            # one bias-correction counter per bucket kernel: parameters of one optimizer are always stepped together here
+            # and in the reference (find_unused_parameters only skips parameters that NEVER get a gradient)
+            raise L.StyError(f"optimizer state: parameters at different step counts {sorted(steps)}")
+        self.t = steps.pop() if steps else 0
 
 
 LOGICAL_STEP_LIMIT = 10000  # train/optimizers.py:11

@@ -5,6 +5,8 @@ writes and reads them, so that a user's existing output directory keeps working:
   <out>/<stage>/normalization.json         log-mel / energy statistics           train/train_context.py:190-354,
                                                                                  train/utils.py:89-169
   <out>/<stage>/checkpoint_*/              accelerate `save_state` layout        train/train.py:453-469, :207-211
+                                           (model, optimizer and registered-object files; NOT the scheduler and RNG
+                                           files -- see save_checkpoint)
   PinnedPrefetcher                         pinned-memory, side-stream H2D of the Collater tuple (the reference's
                                            DataLoader runs with pin_memory=False: an easy win it leaves on the table)
 
@@ -59,12 +61,14 @@ class BatchSizes:
             json.dump(self.batch_sizes, o)
 
     def get_steps(self, time_bins):
-        """train/stage.py:95-106: steps = sum over bins of len(bin) // batch_size (bins with batch size 0 are skipped)."""
+        """train/stage.py:95-106: steps = sum over bins of len(bin) // batch_size + 1 (bins with batch size 0 are
+        skipped).  The "+ 1" counts a step for a bin whose length divides evenly too; it is the reference's figure and
+        feeds manifest.steps_per_epoch, step_limit and with it the cosine schedule, so it is kept as is."""
         total = 0
         for key, val in time_bins.items():
             bs = self.get_batch_size(key)
             if bs > 0:
-                total += len(val) // bs
+                total += len(val) // bs + 1
         return total
 
 
@@ -221,7 +225,22 @@ def init_normalization(stats, out_dir, dataset_path, train_lines, wav_root, mode
 # (train_context.py:110-113: config, model_config, manifest, normalization) in custom_checkpoint_<j>.pkl.
 MODEL_ORDER = ("text_aligner", "duration_predictor", "pitch_energy_predictor", "speech_predictor", "disc", "mrd0", "mrd1",
                "mrd2", "speech_style_encoder", "pe_style_encoder", "duration_style_encoder", "pitch_disc", "dur_disc")
-CUSTOM_ORDER = ("config", "model_config", "manifest", "normalization")
+CUSTOM_ORDER = ("config", "model_config", "manifest", "normalization", "discriminator_loss")  # + optimizers.py:34
+
+
+def optimizer_file(name):
+    """MultiOptimizer.prepare (train/optimizers.py:29-34) prepares one AdamW per model key in build_model's order."""
+    i = MODEL_ORDER.index(name)
+    return "optimizer.bin" if i == 0 else f"optimizer_{i}.bin"
+
+
+def discriminator_loss_state(helpers):
+    """DiscriminatorLoss.state_dict (train/losses.py:209-214): helpers = {model key: helper with .last_loss}"""
+    state = {}
+    for key, h in helpers.items():
+        state[f"discriminators.{key}.last_loss"] = float(h.last_loss)
+        state[f"discriminators.{key}.weight"] = 1
+    return state
 
 
 def model_file(name):
@@ -237,22 +256,46 @@ def checkpoint_dir(out_dir, prefix="checkpoint", manifest=None, long=True):
     return d
 
 
-def save_checkpoint(path, models, manifest=None, normalization=None):
-    """Write the state_dicts of the models this package owns (name -> module, names from MODEL_ORDER) and the manifest /
-    normalization objects into an accelerate-layout directory.  Models that are not given are left alone, so a
-    directory the reference wrote keeps its other files (aligner, discriminators, optimizers)."""
+def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=None, disc_helpers=None, trainer=None):
+    """Write the state_dicts of the models this package owns (name -> module, names from MODEL_ORDER), their optimizers
+    (name -> FlatAdamW: AdamW moments, step count and lr un-flattened into torch.optim.AdamW's state_dict,
+    `optimizer[_i].bin`), the discriminator-loss EMA state (`disc_helpers`: name -> helper, the reference's registered
+    DiscriminatorLoss, custom_checkpoint_4.pkl) and the manifest / normalization objects into an accelerate-layout
+    directory.  Files of models that are not given are left alone, so a directory the reference wrote keeps them.
+    `trainer` (an AcousticTrainer): rank 0's BatchNorm / spectral-norm buffers are broadcast first (sync_buffers), the
+    state a multi-rank run lets drift between checkpoints.
+
+    NOT written: accelerate's `scheduler*.bin` and `random_states_*.pkl`.  This package keeps no scheduler object (the
+    lr is a pure function of the manifest's step, optim.scheduled_lr) and its stochastic pieces are seeded per step, so
+    `load_checkpoint` resumes exactly from what is here; the REFERENCE's accelerator.load_state on a directory written
+    ONLY by this function stops at the missing scheduler file -- resume there with the reference's own checkpoint as the
+    base directory and let this function overwrite the model / optimizer files in it."""
+    if trainer is not None:
+        trainer.sync_buffers()
     os.makedirs(path, exist_ok=True)
     for name, m in models.items():
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         torch.save(sd, osp.join(path, model_file(name)))
+    for name, o in (optimizers or {}).items():
+        sd = o.state_dict()
+        for st in sd["state"].values():
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+        torch.save(sd, osp.join(path, optimizer_file(name)))
+    if disc_helpers:
+        f = osp.join(path, f"custom_checkpoint_{CUSTOM_ORDER.index('discriminator_loss')}.pkl")
+        state = torch.load(f, map_location="cpu", weights_only=True) if osp.exists(f) else {}
+        state.update(discriminator_loss_state(disc_helpers))  # helpers of other stages keep their entries
+        torch.save(state, f)
     for name, obj in (("manifest", manifest), ("normalization", normalization)):
         if obj is not None:
             torch.save(obj.state_dict(), osp.join(path, f"custom_checkpoint_{CUSTOM_ORDER.index(name)}.pkl"))
     return path
 
 
-def load_checkpoint(path, models, manifest=None, normalization=None, strict=True):
-    """Load what save_checkpoint / the reference's accelerator.save_state wrote for the models given."""
+def load_checkpoint(path, models, manifest=None, normalization=None, strict=True, optimizers=None, disc_helpers=None):
+    """Load what save_checkpoint / the reference's accelerator.save_state wrote for the models (and optimizers / loss
+    helpers) given.  A missing optimizer file is an error when an optimizer was asked for: resuming with zero moments is
+    a different training run."""
     for name, m in models.items():
         f = osp.join(path, model_file(name))
         if not osp.exists(f):
@@ -260,10 +303,23 @@ def load_checkpoint(path, models, manifest=None, normalization=None, strict=True
         sd = torch.load(f, map_location="cpu", weights_only=True)
         sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}  # a DDP-wrapped save
         m.load_state_dict(sd, strict=strict)
+    for name, o in (optimizers or {}).items():
+        f = osp.join(path, optimizer_file(name))
+        if not osp.exists(f):
+            raise L.StyError(f"{f} not found (optimizer of {name}); pass optimizers=None for a weights-only load")
+        o.load_state_dict(torch.load(f, map_location="cpu", weights_only=True))
+    if disc_helpers:
+        f = osp.join(path, f"custom_checkpoint_{CUSTOM_ORDER.index('discriminator_loss')}.pkl")
+        if osp.exists(f):
+            state = torch.load(f, map_location="cpu", weights_only=True)
+            for key, h in disc_helpers.items():  # losses.py:216-220
+                if f"discriminators.{key}.last_loss" in state:
+                    h.last_loss = float(state[f"discriminators.{key}.last_loss"])
     for name, obj in (("manifest", manifest), ("normalization", normalization)):
         f = osp.join(path, f"custom_checkpoint_{CUSTOM_ORDER.index(name)}.pkl")
         if obj is not None and osp.exists(f):
-            obj.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))
+            # dicts of numbers / strings / lists only: nothing in them needs the unpickler to build objects
+            obj.load_state_dict(torch.load(f, map_location="cpu", weights_only=True))
     return path
 
 
@@ -300,4 +356,7 @@ class PinnedPrefetcher:
                 yield cur[0]
         if nxt is not None:
             torch.cuda.current_stream(self.device).wait_event(nxt[1])
+            for t in nxt[0]:  # allocated on the side stream: tell the allocator the consumer's stream reads them too
+                if torch.is_tensor(t):
+                    t.record_stream(torch.cuda.current_stream(self.device))
             yield nxt[0]

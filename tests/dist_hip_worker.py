@@ -100,6 +100,38 @@ def main(out_path):
         for r, other in enumerate(both):
             assert torch.equal(other, both[0]), f"rank {r} parameters differ from rank 0 after two trainer steps"
         print(f"[rank {rank}] trainer steps: parameters identical on all {world} ranks")
+    # ---- phase 3: the adversarial step.  Ranks are seeded differently (seed=rank) for dropout / smoothing, but the
+    # discriminator a step trains (stage.py:119) must be the same one on every rank: the mrd buckets have equal sizes, so
+    # a disagreement would all-reduce mrd0's gradients against mrd2's silently.
+    del tr
+    from stylish_tts_amd.discriminators import ContextFreeDiscriminator, SpecDiscriminator
+    torch.manual_seed(7)
+    mrd = [SpecDiscriminator().to(dev) for _ in range(3)]
+    wd = ContextFreeDiscriminator().to(dev)
+    sp3 = S.SpeechPredictor()
+    sp3.load_state_dict(fill_state_dict(speech_predictor_manifest(), 0), strict=False)
+    se3 = S.MelStyleEncoder()
+    se3.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
+    tr = AcousticTrainer(sp3.to(dev), se3.to(dev), lr=1e-3, train_mode=True, seed=rank, mrd=mrd, disc=wd)
+    picks = []
+    for it in range(3):
+        tr.train_batch(audio_gt=a2.to(dev), texts=tx.to(dev), text_lengths=torch.full((Br,), Lt).to(dev),
+                       pitch=p2.to(dev), durations=d2.to(dev), seed=it)
+        picks.append(tr.disc_index)
+    torch.cuda.synchronize()
+    dparams = torch.cat([p.detach().flatten() for m in mrd + [wd] for p in m.parameters()]).cpu()
+    assert bool(torch.isfinite(dparams).all())
+    if world > 1:
+        mine = torch.tensor(picks, dtype=torch.int64)
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allp, mine)
+        for r, other in enumerate(allp):
+            assert torch.equal(other, allp[0]), f"rank {r} trained discriminators {other.tolist()}, rank 0 {allp[0].tolist()}"
+        both = [torch.empty_like(dparams) for _ in range(world)]
+        torch.distributed.all_gather(both, dparams)
+        for r, other in enumerate(both):
+            assert torch.equal(other, both[0]), f"rank {r} discriminator parameters differ from rank 0"
+        print(f"[rank {rank}] adversarial steps: disc_index {picks} and discriminator parameters identical on all ranks")
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

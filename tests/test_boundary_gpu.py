@@ -235,3 +235,67 @@ def test_two_rank_hip_gradients_equal_one_rank_on_the_concatenated_batch(tmp_pat
     print(f"\n  2-rank mean gradient vs 1-rank gradient on the concatenated batch: relative L2 {rel:.3e} "
           f"over {len(g1)} tensors")
     assert rel <= 2e-3
+
+
+def test_checkpoint_resume_continues_the_same_training_run(tmp_path):
+    """save_checkpoint after two optimizer steps (models, AdamW moments + step count + lr, discriminator-loss EMA), a
+    FRESH trainer loads it and takes step three: its parameters equal, bit for bit, those of the run that never stopped.
+    (A weights-only resume restarts the moments and the bias correction from zero: a different run.)  The harmonic
+    source's l_linear -- never given a gradient in the reference (generator.py:711-729) -- must not move at all."""
+    import stylish_tts_amd as S
+    from stylish_tts_amd import stage_io as IO
+    from stylish_tts_amd.acoustic import AcousticTrainer
+    from stylish_tts_amd.discriminators import ContextFreeDiscriminator, SpecDiscriminator
+    from stylish_tts_amd.manifest import speech_predictor_manifest, style_encoder_manifest
+    from stylish_tts_amd.synthetic_weights import fill_state_dict
+
+    def fresh(seed):
+        sp = S.SpeechPredictor()
+        sp.load_state_dict(fill_state_dict(speech_predictor_manifest(), seed), strict=False)
+        se = S.MelStyleEncoder()
+        se.load_state_dict(fill_state_dict(style_encoder_manifest(), seed))
+        torch.manual_seed(7 + seed)
+        mrd = [SpecDiscriminator().to(DEV) for _ in range(3)]
+        return AcousticTrainer(sp.to(DEV), se.to(DEV), lr=1e-3, train_mode=False, mrd=mrd,
+                               disc=ContextFreeDiscriminator().to(DEV))
+
+    g = torch.Generator().manual_seed(5)
+    B, T, Lt = 2, 80, 24
+    tx = torch.randint(1, 178, (B, Lt), generator=g)
+    d = torch.ones(B, Lt)
+    for b in range(B):
+        d[b] += torch.bincount(torch.multinomial(torch.ones(Lt), T - Lt, replacement=True, generator=g), minlength=Lt).float()
+    kw = dict(audio_gt=dev(0.1 * torch.randn(B, 300 * T, generator=g)), texts=dev(tx),
+              text_lengths=dev(torch.full((B,), Lt)), pitch=dev(torch.rand(B, T, generator=g) * 200 + 80), durations=dev(d))
+    picks = (0, 2, 2)
+
+    def flat(tr):
+        st = tr.checkpoint_state()
+        return torch.cat([p.detach().flatten() for m in st["models"].values() for p in m.parameters()]).cpu()
+
+    a = fresh(0)
+    src0 = a.sp.state_dict()["generator.basegen.m_source.l_linear.weight"].clone()
+    for i in range(3):
+        a.train_batch(seed=i, disc_index=picks[i], **kw)
+    assert torch.equal(a.sp.state_dict()["generator.basegen.m_source.l_linear.weight"], src0)
+    b = fresh(0)
+    for i in range(2):
+        b.train_batch(seed=i, disc_index=picks[i], **kw)
+    man = IO.Manifest()
+    man.current_total_step = 2
+    st = b.checkpoint_state()
+    path = IO.save_checkpoint(str(tmp_path / "ck"), st["models"], man, IO.NormalizationStats(),
+                              optimizers=st["optimizers"], disc_helpers=st["disc_helpers"], trainer=b)
+    c = fresh(1)  # different weights: everything must come from the files
+    stc = c.checkpoint_state()
+    IO.load_checkpoint(path, stc["models"], optimizers=stc["optimizers"], disc_helpers=stc["disc_helpers"])
+    assert c.opt["speech_predictor"].t == 2 and c.opt["mrd1"].t == 0 and c.opt["mrd0"].t == 1
+    assert c.disc_helpers[0].last_loss == b.disc_helpers[0].last_loss
+    c.train_batch(seed=2, disc_index=picks[2], **kw)
+    torch.cuda.synchronize()
+    pa, pc = flat(a), flat(c)
+    assert torch.equal(pa, pc), f"resumed run differs from the uninterrupted one: max {float((pa - pc).abs().max()):.3e}"
+    w = fresh(0)  # control: a weights-only resume is NOT the same run
+    IO.load_checkpoint(path, w.checkpoint_state()["models"])
+    w.train_batch(seed=2, disc_index=picks[2], **kw)
+    assert not torch.equal(flat(w), pa)

@@ -1381,6 +1381,25 @@ def test_bench_two_ranks_on_one_device(workload, port):
 
 
 
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` called DIRECTLY (no torchrun around it, as the driver's N=1 command line with N=2):
+    the script has to start one process per rank itself and report n_gpus = 2 from a 2-rank process group."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["STY_BENCH_SHARE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--workload", "c2"], capture_output=True, text=True, env=env, timeout=600,
+                       cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks"]["world_size"] == 2 and rec["value"] > 0
+    assert rec["config"]["workload"].startswith("c2: B=16/GPU")
+
+
 def _n3_models():
     import stylish_tts_amd as S
     from oracle.manifest import duration_predictor_manifest, pitch_energy_predictor_manifest

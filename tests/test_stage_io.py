@@ -39,7 +39,12 @@ def test_batch_sizes_file(tmp_path):
     other = BatchSizes(str(tmp_path), "acoustic")
     other.load_batch_sizes()
     assert other.batch_sizes_exist() and other.get_batch_size(7) == 16 and other.get_batch_size("12") == 8
-    assert other.get_steps({7: list(range(40)), 12: list(range(20)), 3: list(range(5))}) == 40 // 16 + 20 // 8 + 5
+    # Stage.get_steps: the figures are what the reference's own function returned (tools/gen_golden_boundary.py)
+    for case in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "stage_io_values.json")))["get_steps"]:
+        b = BatchSizes(str(tmp_path), "x")
+        for k, v in case["batch_sizes"].items():
+            b.set_batch_size(k, v)
+        assert b.get_steps({int(k): list(range(n)) for k, n in case["bin_lengths"].items()}) == case["steps"], case
 
 
 def test_checkpoint_layout_is_accelerates(tmp_path):
@@ -88,6 +93,112 @@ def test_checkpoint_layout_is_accelerates(tmp_path):
     for n, m in fresh.items():
         assert torch.equal(m.weight, acc.unwrap_model(models[n]).weight)
     assert man.current_total_step == 2000
+
+
+def test_flat_adamw_state_is_torch_adamw_state(tmp_path):
+    """FlatAdamW.state_dict() loads into torch.optim.AdamW over the same parameters (what the reference's
+    accelerator.load_state does with optimizer[_i].bin, train/optimizers.py:110-118) and the other way round; a
+    never-stepped group (negative segment) and a frozen parameter carry no state, as a torch parameter whose .grad is None."""
+    from stylish_tts_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    names = ["a.weight", "a.bias", "src.l_linear.weight", "b.weight", "frozen.weight"]
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in ((4, 3), (4,), (1, 9), (2, 4, 3), (5,))]
+    ps[4].requires_grad_(False)
+    opt = FlatAdamW(list(zip(names, ps)), lr=3e-4, bucket_bytes=64, group_of=lambda n: -1 if "l_linear" in n else 0)
+    assert opt.state_dict()["state"] == {}  # nothing stepped yet
+    opt.t = 7
+    for m, v in zip(opt.m, opt.v):
+        m.copy_(torch.randn_like(m))
+        v.copy_(torch.rand_like(v))
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == [0, 1, 3] and sd["param_groups"][0]["params"] == [0, 1, 2, 3, 4]
+    ref = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-4, weight_decay=1e-4,
+                            betas=(0.85, 0.99), eps=1e-9)
+    torch.save(sd, tmp_path / "optimizer.bin")
+    ref.load_state_dict(torch.load(tmp_path / "optimizer.bin", weights_only=True))
+    assert ref.param_groups[0]["lr"] == 3e-4
+    rp = ref.param_groups[0]["params"]
+    assert float(ref.state[rp[0]]["step"]) == 7.0 and rp[2] not in ref.state and rp[4] not in ref.state
+    # torch takes a step on (0, 1, 3); its state_dict comes back into a fresh FlatAdamW
+    for i in (0, 1, 3):
+        rp[i].grad = torch.randn_like(rp[i])
+    ref.step()
+    opt2 = FlatAdamW(list(zip(names, [torch.nn.Parameter(p.detach().clone()) for p in ps[:4]] + [ps[4]])), bucket_bytes=64,
+                     group_of=lambda n: -1 if "l_linear" in n else 0)
+    opt2.load_state_dict(ref.state_dict())
+    assert opt2.t == 8 and opt2.lr == 3e-4
+    back = opt2.state_dict()["state"]
+    for i in (0, 1, 3):
+        assert torch.equal(back[i]["exp_avg"], ref.state[rp[i]]["exp_avg"])
+        assert torch.equal(back[i]["exp_avg_sq"], ref.state[rp[i]]["exp_avg_sq"])
+    bad = ref.state_dict()
+    bad["state"][2] = bad["state"][0]
+    with pytest.raises(Exception, match="never stepped"):
+        opt2.load_state_dict(bad)
+
+
+def test_checkpoint_optimizer_and_discriminator_loss_files_are_accelerates(tmp_path):
+    """optimizer[_i].bin and custom_checkpoint_4.pkl: accelerate's numbering for thirteen AdamW prepared in build_model's
+    order (optimizers.py:29-34) and a fifth registered object (DiscriminatorLoss, losses.py:209-220), both directions."""
+    accelerate = pytest.importorskip("accelerate")
+    from stylish_tts_amd import stage_io as IO
+    from stylish_tts_amd.optim import FlatAdamW
+    acc = accelerate.Accelerator(cpu=True)
+    torch.manual_seed(0)
+    nets = {n: torch.nn.Linear(3 + i, 2) for i, n in enumerate(IO.MODEL_ORDER)}
+    opts = {}
+    for n in IO.MODEL_ORDER:
+        nets[n] = acc.prepare(nets[n])
+        opts[n] = acc.prepare(torch.optim.AdamW(nets[n].parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.85, 0.99), eps=1e-9))
+
+    class Helper:
+        last_loss = 0.5
+
+    class DiscLoss:  # losses.py:209-220
+        def __init__(self):
+            self.discriminators = {k: Helper() for k in ("mrd0", "mrd1", "mrd2", "disc", "pitch_disc", "dur_disc")}
+
+        def state_dict(self):
+            return IO.discriminator_loss_state(self.discriminators)
+
+        def load_state_dict(self, sd):
+            for k, h in self.discriminators.items():
+                h.last_loss = sd[f"discriminators.{k}.last_loss"]
+
+    class Obj:
+        def state_dict(self):
+            return {}
+
+        def load_state_dict(self, s):
+            pass
+
+    dl = DiscLoss()
+    dl.discriminators["mrd1"].last_loss = 0.321
+    for o in (Obj(), Obj(), IO.Manifest(), IO.NormalizationStats(), dl):
+        acc.register_for_checkpointing(o)
+    for n in ("speech_predictor", "mrd1"):
+        nets[n](torch.randn(4, 3 + IO.MODEL_ORDER.index(n))).sum().backward()
+        opts[n].step()
+    d = str(tmp_path / "ckpt")
+    acc.save_state(d, safe_serialization=False)
+    for n in IO.MODEL_ORDER:
+        assert os.path.exists(os.path.join(d, IO.optimizer_file(n))), (n, sorted(os.listdir(d)))
+    mine = {n: torch.nn.Linear(3 + IO.MODEL_ORDER.index(n), 2) for n in ("speech_predictor", "mrd1")}
+    fo = {n: FlatAdamW(list(m.named_parameters())) for n, m in mine.items()}
+    helpers = {"mrd1": Helper(), "disc": Helper()}
+    IO.load_checkpoint(d, mine, optimizers=fo, disc_helpers=helpers)
+    assert fo["speech_predictor"].t == 1 and helpers["mrd1"].last_loss == 0.321
+    ref_state = opts["mrd1"].optimizer.state_dict()["state"]
+    assert torch.equal(fo["mrd1"].state_dict()["state"][0]["exp_avg"], ref_state[0]["exp_avg"])
+    # the other way: this package writes, accelerate reads
+    fo["mrd1"].m[0].mul_(2.0)
+    fo["mrd1"].t = 5
+    helpers["mrd1"].last_loss = 0.77
+    IO.save_checkpoint(d, mine, optimizers=fo, disc_helpers=helpers)
+    acc.load_state(d)
+    st = opts["mrd1"].optimizer.state_dict()["state"]
+    assert float(st[0]["step"]) == 5.0 and torch.equal(st[0]["exp_avg"], fo["mrd1"].state_dict()["state"][0]["exp_avg"])
+    assert dl.discriminators["mrd1"].last_loss == 0.77 and dl.discriminators["pitch_disc"].last_loss == 0.5
 
 
 def test_normalization_priority_and_json_layout(tmp_path, monkeypatch):
