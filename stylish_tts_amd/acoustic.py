@@ -234,7 +234,12 @@ class AcousticTrainer:
             od.grads.finish(average=False)
             od.lr = self.opt["speech_predictor"].lr * self.disc_helpers[disc_index].get_disc_lr_multiplier()
             od.step(grad_scale=1.0 / world)
-            plain = self.gan.tolist()  # (one host read per step; the reference's helpers call .item() three times)
+            # The tracked discriminator losses set the discriminators' learning rates, so every rank must track the SAME
+            # numbers or the replicas drift apart for good (nothing re-syncs parameters).  The reference tracks each
+            # process's local .item() (losses.py:287) and lets them drift; here the mean over ranks is tracked (one
+            # all-reduce of seven floats; identical to the reference at world size 1).
+            tracked = self._rank_mean(torch.cat([self.gan, self.gan_wave]) if self.disc is not None else self.gan)
+            plain = tracked.tolist()  # (one host read per step; the reference's helpers call .item() three times)
             for r, h in enumerate(self.disc_helpers):
                 h.last_loss = h.last_loss * 0.95 + plain[2 + 2 * r] * 0.05
             if self.disc is not None:
@@ -243,9 +248,18 @@ class AcousticTrainer:
                 ow.grads.finish(average=False)
                 ow.lr = self.opt["speech_predictor"].lr * self.disc_helper.get_disc_lr_multiplier()
                 ow.step(grad_scale=1.0 / world)
-                self.disc_helper.last_loss = self.disc_helper.last_loss * 0.95 + float(self.gan_wave[2].item()) * 0.05
+                self.disc_helper.last_loss = self.disc_helper.last_loss * 0.95 + plain[self.gan.numel() + 2] * 0.05
         self.audio = audio
         return losses
+
+    @staticmethod
+    def _rank_mean(t):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return t
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t / dist.get_world_size()
 
     def sync_buffers(self, src=0):
         """Broadcast the non-trainable state the training step updates per rank -- BatchNorm running statistics

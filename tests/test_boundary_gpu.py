@@ -238,10 +238,13 @@ def test_two_rank_hip_gradients_equal_one_rank_on_the_concatenated_batch(tmp_pat
 
 
 def test_checkpoint_resume_continues_the_same_training_run(tmp_path):
-    """save_checkpoint after two optimizer steps (models, AdamW moments + step count + lr, discriminator-loss EMA), a
-    FRESH trainer loads it and takes step three: its parameters equal, bit for bit, those of the run that never stopped.
-    (A weights-only resume restarts the moments and the bias correction from zero: a different run.)  The harmonic
-    source's l_linear -- never given a gradient in the reference (generator.py:711-729) -- must not move at all."""
+    """save_checkpoint after two optimizer steps (models, AdamW moments + step count + lr, discriminator-loss EMA); a
+    FRESH trainer with other weights loads it: every parameter, both moments of every optimizer, the step counts, the
+    learning rates and the tracked discriminator losses are bit-identical to the saved run's, and step three of both
+    runs agrees (up to the two float-atomic sums of the backward, which Adam's normalisation turns into a +-lr flip on
+    parameters whose gradient is rounding noise: a handful of elements).  A weights-only resume restarts the moments and
+    the bias correction from zero -- a different run, on most elements.  The harmonic source's l_linear, never given a
+    gradient in the reference (generator.py:711-729), must not move at all."""
     import stylish_tts_amd as S
     from stylish_tts_amd import stage_io as IO
     from stylish_tts_amd.acoustic import AcousticTrainer
@@ -273,14 +276,14 @@ def test_checkpoint_resume_continues_the_same_training_run(tmp_path):
         st = tr.checkpoint_state()
         return torch.cat([p.detach().flatten() for m in st["models"].values() for p in m.parameters()]).cpu()
 
-    a = fresh(0)
-    src0 = a.sp.state_dict()["generator.basegen.m_source.l_linear.weight"].clone()
-    for i in range(3):
-        a.train_batch(seed=i, disc_index=picks[i], **kw)
-    assert torch.equal(a.sp.state_dict()["generator.basegen.m_source.l_linear.weight"], src0)
+    def moments(tr):
+        return torch.cat([t.flatten() for o in tr.opt.values() for t in o.m + o.v]).cpu()
+
     b = fresh(0)
+    src0 = b.sp.state_dict()["generator.basegen.m_source.l_linear.weight"].clone()
     for i in range(2):
         b.train_batch(seed=i, disc_index=picks[i], **kw)
+    assert torch.equal(b.sp.state_dict()["generator.basegen.m_source.l_linear.weight"], src0)
     man = IO.Manifest()
     man.current_total_step = 2
     st = b.checkpoint_state()
@@ -289,13 +292,19 @@ def test_checkpoint_resume_continues_the_same_training_run(tmp_path):
     c = fresh(1)  # different weights: everything must come from the files
     stc = c.checkpoint_state()
     IO.load_checkpoint(path, stc["models"], optimizers=stc["optimizers"], disc_helpers=stc["disc_helpers"])
-    assert c.opt["speech_predictor"].t == 2 and c.opt["mrd1"].t == 0 and c.opt["mrd0"].t == 1
-    assert c.disc_helpers[0].last_loss == b.disc_helpers[0].last_loss
-    c.train_batch(seed=2, disc_index=picks[2], **kw)
     torch.cuda.synchronize()
-    pa, pc = flat(a), flat(c)
-    assert torch.equal(pa, pc), f"resumed run differs from the uninterrupted one: max {float((pa - pc).abs().max()):.3e}"
-    w = fresh(0)  # control: a weights-only resume is NOT the same run
+    assert c.opt["speech_predictor"].t == 2 and c.opt["mrd1"].t == 0 and c.opt["mrd0"].t == 1 and c.opt["disc"].t == 2
+    assert torch.equal(flat(b), flat(c)) and torch.equal(moments(b), moments(c))
+    assert [o.lr for o in b.opt.values()] == [o.lr for o in c.opt.values()]
+    assert [h.last_loss for h in b.disc_helpers + [b.disc_helper]] == [h.last_loss for h in c.disc_helpers + [c.disc_helper]]
+    w = fresh(0)  # control: a weights-only resume
     IO.load_checkpoint(path, w.checkpoint_state()["models"])
-    w.train_batch(seed=2, disc_index=picks[2], **kw)
-    assert not torch.equal(flat(w), pa)
+    for tr in (b, c, w):
+        tr.train_batch(seed=2, disc_index=picks[2], **kw)
+    torch.cuda.synchronize()
+    pb, pc, pw = flat(b), flat(c), flat(w)
+    moved = (pb - pc).abs() > 1e-6
+    print(f"\n  step 3 after resume: {int(moved.sum())} of {pb.numel()} parameters differ from the uninterrupted run; "
+          f"weights-only resume: {int(((pb - pw).abs() > 1e-6).sum())}")
+    assert moved.float().mean().item() < 1e-3
+    assert ((pb - pw).abs() > 1e-6).float().mean().item() > 0.5
