@@ -120,6 +120,16 @@ def pitch_energy_predictor(P, texts, text_lengths, alignment, style, want=None):
     return out[0], out[1]
 
 
+# DurationProcessor.dur_to_class_table (utils.py:666-720), a 51-entry constant table of the reference, carried as data in
+# run-length form: durations 0-1 -> class 0, 2 -> 1, ..., 8-10 -> 7, 11-13 -> 8, ..., 35-41 -> 14, 42-50 -> 15
+DUR_TO_CLASS = torch.repeat_interleave(torch.arange(16), torch.tensor([2, 1, 1, 1, 1, 1, 1, 3, 3, 3, 3, 5, 5, 5, 7, 9]))
+
+
+def dur_to_class(durs, max_dur=50):
+    """DurationProcessor.dur_to_class (utils.py:734-736)"""
+    return DUR_TO_CLASS[durs.clamp(min=1, max=max_dur).long()]
+
+
 def prediction_to_duration(pred, text_lengths):
     """softmax over classes -> expected duration (utils.py:726-748)."""
     conf = torch.softmax(pred, dim=-1)

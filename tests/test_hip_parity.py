@@ -1574,50 +1574,26 @@ def test_duration_predictor_training_graph_vs_oracle_autograd(env):
 def test_duration_train_step_vs_oracle(env):
     """train_duration (stage_type.py:495-556) assembled: trainable duration_style_encoder + duration_predictor,
     prediction_to_duration, the per-utterance smooth-L1 and the weighted cross entropy with LossLog normalisation, the
-    dur_disc generator term; lr = 0.  Losses and gradients against autograd on the oracle."""
+    dur_disc generator term; lr = 0.  Losses, predicted durations and gradients against (1) what the REFERENCE's own
+    train_duration logged and left on the parameters (tests/golden/stages_small, tools/gen_golden_stages.py) and (2)
+    autograd on the oracle's assembly (oracle/stages.py, itself pinned to the same fixture)."""
     import stylish_tts_amd as S
-    from safetensors.torch import load_file
-    from oracle import discriminator as od, frontend as ofe, predictors as OP, style_encoder as ose
-    from oracle.manifest import duration_predictor_manifest, style_encoder_manifest
-    from oracle.weights import fill_state_dict
+    from oracle import stages
     from stylish_tts_amd.discriminators import PitchDiscriminator
-    from stylish_tts_amd.duration import CLASS_TO_DUR, DUR_TO_CLASS, DurationTrainer
-    cs = env["cs"]
-    B, T = cs["pitch"].shape
-    audio_gt = _test_audio(B, 300 * T, 21)
-    Pdp = fill_state_dict(duration_predictor_manifest(), 3)
-    Pse = fill_state_dict(style_encoder_manifest(), 7)
-    fx = load_file(os.path.join(G, "pdisc_small.safetensors"))
-    Pd = {k[len("dur.w."):]: v for k, v in fx.items() if k.startswith("dur.w.")}
-    dp_keys = ["cross_attention.conv_q.weight", "cross_post.0.parametrizations.weight.original1", "conv_next.1.pwconv1.weight",
-               "duration_proj.linear_layer.weight", "query_norm.fc.weight", "text_encoder.proj_m.weight"]
-    se_keys = ["shared.0.weight_orig", "shared.2.conv1.weight_orig", "unshared.weight"]
+    from stylish_tts_amd.duration import DurationTrainer
+    from tests.test_oracle_golden import STAGE_KEYS, stage_inputs, stage_sub
+    fx, P, cs = stage_inputs()
+    Pdp, Pse, Pd = P["dp"], P["dse"], P["dur_disc"]
+    dp_keys, se_keys = STAGE_KEYS["dp"], STAGE_KEYS["se"]
     for k in dp_keys:
         Pdp[k].requires_grad_(True)
     for k in se_keys:
         Pse[k].requires_grad_(True)
-    weights = torch.linspace(0.5, 2.0, 16)
-    tlen = cs["text_lengths"]
-    target_dur = cs["durations"].long()
-    table, d2c = torch.tensor(CLASS_TO_DUR, dtype=torch.float32), torch.tensor(DUR_TO_CLASS)
-    targets = d2c[target_dur.clamp(1, 50)]
-    # ---- oracle ----
-    with torch.no_grad():
-        style_mel = ofe.calculate_mel(audio_gt, 2048, 1200, 300)
-    style = ose.mel_style_encoder(Pse, "", style_mel[:, None])
-    raw = OP.duration_predictor(Pdp, cs["texts"], tlen, style)
-    conf = torch.softmax(raw, dim=-1)
-    soft = (conf * table).sum(-1) / (conf.sum(-1) + 1e-9)
-    mask = (torch.arange(raw.shape[1])[None, :] < tlen[:, None]).float()
-    duration = soft * mask
-    l_dur = sum(torch.nn.functional.smooth_l1_loss(duration[i, :tlen[i]], target_dur[i, :tlen[i]].float())
-                for i in range(B)) / B
-    ce = torch.nn.CrossEntropyLoss(weight=torch.sqrt(weights))
-    l_ce = sum(ce(raw[i, :tlen[i]], targets[i, :tlen[i]]) for i in range(B)) / B
-    l_gen = od.generator_loss_helper(od.pitch_discriminator(Pd, target_dur.float().unsqueeze(1)),
-                                     od.pitch_discriminator(Pd, duration.unsqueeze(1)))
-    total = 1.0 * l_gen + 8.0 * l_ce / (l_ce.detach() + 1e-9) + 8.0 * l_dur / (l_dur.detach() + 1e-9)
+    audio_gt, weights, tlen = fx["audio_gt"], fx["class_weights"], cs["text_lengths"]
+    assert torch.equal(audio_gt, _test_audio(2, audio_gt.shape[1], 21))
+    olog, total, duration = stages.train_duration(Pdp, Pse, Pd, audio_gt, cs["texts"], tlen, cs["durations"], weights)
     total.backward()
+    l_dur, l_ce, l_gen = olog["duration"], olog["duration_ce"], olog["generator"]
     # ---- HIP ----
     def shell(cls, P):
         m = cls()
@@ -1632,16 +1608,20 @@ def test_duration_train_step_vs_oracle(env):
     torch.cuda.synchronize()
     print(f"\n  duration {log['duration'].item():.5f} vs {l_dur.item():.5f}  ce {log['duration_ce'].item():.5f} vs "
           f"{l_ce.item():.5f}  generator {log['generator'].item():.5f} vs {l_gen.item():.5f}")
-    assert abs(log["duration"].item() - l_dur.item()) <= 1e-4 * l_dur.item()
-    assert abs(log["duration_ce"].item() - l_ce.item()) <= 1e-4 * l_ce.item()
-    assert abs(log["generator"].item() - l_gen.item()) <= 1e-4 * l_gen.item()
+    for k in ("duration", "duration_ce", "generator"):
+        assert abs(log[k].item() - olog[k].item()) <= 1e-4 * olog[k].item()
+        ref = fx["duration.log." + k].item()  # the reference's own LossLog
+        assert abs(log[k].item() - ref) <= 1e-4 * ref, (k, log[k].item(), ref)
     rep = Report()
     rep.add("duration", tr.duration, duration.detach(), 1e-4)
+    rep.add("duration (reference)", tr.duration, fx["duration.pred_duration"], 1e-4)
     ndp, nse = dict(tr.dp.named_parameters()), dict(tr.se.named_parameters())
     for k in dp_keys:
         rep.add("d dp." + k[-40:], ndp[k].grad, Pdp[k].grad, 3e-4)
+        rep.add("d dp(ref)." + k[-36:], stage_sub(ndp[k].grad), fx["duration.grad.dp." + k], 4e-4)
     for k in se_keys:
         rep.add("d se." + k[-40:], nse[k].grad, Pse[k].grad, 3e-4)
+        rep.add("d se(ref)." + k[-36:], stage_sub(nse[k].grad), fx["duration.grad.se." + k], 4e-4)
     rep.done()
 
 
@@ -1701,58 +1681,27 @@ def test_second_stage_predictors_train_mode_dropouts_vs_oracle(env, which):
 def test_textual_train_step_vs_oracle(env):
     """train_textual (stage_type.py:415-450) assembled: trainable pe_style_encoder + pitch_energy_predictor, the frozen
     speech predictor / style encoder carrying d loss / d (pitch, energy) back from the mel loss, pitch / energy losses, the
-    pitch_disc generator term, LossLog normalisation; lr = 0 so that parameters stay put.  Losses and gradients of the
-    two trained models against autograd on the oracle (gates as in the acoustic step: fp32 conditioning)."""
+    pitch_disc generator term, LossLog normalisation; lr = 0 so that parameters stay put.  Losses, predictions and
+    gradients of the two trained models against (1) the REFERENCE's own train_textual (tests/golden/stages_small,
+    tools/gen_golden_stages.py) and (2) autograd on the oracle's assembly (oracle/stages.py, pinned to the same fixture).
+    Gradient gates as in the acoustic step: fp32 conditioning behind ~20 normalisation layers (the fp32 oracle itself
+    sits up to 1.4e-2 from the fp32 reference)."""
     import stylish_tts_amd as S
-    from safetensors.torch import load_file
-    from oracle import discriminator as od, frontend as ofe, losses as ol, predictors as OP, speech_predictor as osp
-    from oracle import style_encoder as ose
-    from oracle.manifest import (pitch_energy_predictor_manifest, pitch_style_encoder_manifest, style_encoder_manifest)
-    from oracle.weights import fill_state_dict
+    from oracle import stages
     from stylish_tts_amd.discriminators import PitchDiscriminator
     from stylish_tts_amd.textual import TextualTrainer
-    cs = env["cs"]
-    B, T = cs["pitch"].shape
-    audio_gt = _test_audio(B, 300 * T, 21)
-    Psp = {k: v.clone() for k, v in env["P"].items()}
-    Pse = fill_state_dict(style_encoder_manifest(), 0)
-    Ppep = fill_state_dict(pitch_energy_predictor_manifest(), 4)
-    Ppse = fill_state_dict(pitch_style_encoder_manifest(), 5)
-    fx = load_file(os.path.join(G, "pdisc_small.safetensors"))
-    Pd = {k[len("pitch.w."):]: v for k, v in fx.items() if k.startswith("pitch.w.")}
-    pep_keys = ["prosody_encoder.attn_layers.0.conv_q.weight", "prosody_encoder.proj_layers.1.weight",
-                "F0.0.conv1.parametrizations.weight.original1", "N.3.conv2.parametrizations.weight.original1",
-                "F0_proj.weight", "N_proj.weight", "text_encoder.proj_m.weight"]
-    pse_keys = ["preconv.parametrizations.weight.original1", "shared.2.conv1.weight_orig", "unshared.weight"]
+    from tests.test_oracle_golden import STAGE_KEYS, stage_inputs, stage_sub
+    fx, P, cs = stage_inputs()
+    Ppep, Ppse, Psp, Pse, Pd = P["pep"], P["pse"], P["sp"], P["se"], P["pitch_disc"]
+    pep_keys, pse_keys = STAGE_KEYS["pep"], STAGE_KEYS["pse"]
     for k in pep_keys:
         Ppep[k].requires_grad_(True)
     for k in pse_keys:
         Ppse[k].requires_grad_(True)
-    # ---- oracle ----
-    with torch.no_grad():
-        mel = ofe.calculate_mel(audio_gt, 512, 512, 300)
-        style_mel = ofe.calculate_mel(audio_gt, 2048, 1200, 300)
-        energy = ofe.log_energy(mel)
-    pitch = cs["pitch"]
-    ali = ofe.duration_to_alignment(cs["durations"])
-    voiced = (pitch > 10).float()
-    pe_style = OP.pitch_style_encoder(Ppse, style_mel, pitch, energy)
-    pp, pe = OP.pitch_energy_predictor(Ppep, cs["texts"], cs["text_lengths"], ali, pe_style)
-    with torch.no_grad():
-        sstyle = ose.mel_style_encoder(Pse, "", style_mel[:, None])
+    audio_gt, pitch = fx["audio_gt"], cs["pitch"]
     want = {}
-    audio = osp.speech_predictor(Psp, cs["texts"], cs["text_lengths"], ali, pp, pe, (pp > 20).float(), sstyle, pp,
-                                 cs["noise"], want)
-    l_mel, _, _ = ol.acoustic_losses(audio_gt, audio.squeeze(1))
-
-    def pl(t, p):
-        return torch.nn.functional.smooth_l1_loss(t, p) + torch.nn.functional.smooth_l1_loss(torch.diff(t), torch.diff(p))
-
-    l_p, l_e = pl(pitch, pp), pl(energy, pe)
-    cat_t, cat_p = torch.stack([pitch * voiced, energy], 1), torch.stack([pp * voiced, pe], 1)
-    l_gen = od.generator_loss_helper(od.pitch_discriminator(Pd, cat_t), od.pitch_discriminator(Pd, cat_p))
-    total = 5.0 * l_mel / (l_mel.detach() + 1e-9) + 1.0 * l_gen + 8.0 * l_p / (l_p.detach() + 1e-9) + \
-        8.0 * l_e / (l_e.detach() + 1e-9)
+    olog, total, cat_p = stages.train_textual(Ppep, Ppse, Psp, Pse, Pd, audio_gt, cs["texts"], cs["text_lengths"], pitch,
+                                              cs["durations"], cs["noise"], want)
     total.backward()
     # ---- HIP ----
     def shell(cls, P, **kw):
@@ -1768,18 +1717,23 @@ def test_textual_train_step_vs_oracle(env):
                          pitch=dev(pitch), durations=dev(cs["durations"]), noise=dev(cs["noise"]),
                          prior_override=dev(want["prior"]))
     torch.cuda.synchronize()
-    print(f"\n  mel {log['mel'].item():.5f} vs {l_mel.item():.5f}  pitch {log['pitch'].item():.4f} vs {l_p.item():.4f}  "
-          f"energy {log['energy'].item():.4f} vs {l_e.item():.4f}  generator {log['generator'].item():.4f} vs {l_gen.item():.4f}")
-    assert abs(log["mel"].item() - l_mel.item()) <= 2e-3 * l_mel.item()
-    assert abs(log["pitch"].item() - l_p.item()) <= 2e-3 * l_p.item()
-    assert abs(log["energy"].item() - l_e.item()) <= 2e-3 * l_e.item()
-    assert abs(log["generator"].item() - l_gen.item()) <= 2e-3 * l_gen.item()
+    print("\n  " + "  ".join(f"{k} {log[k].item():.5f} vs {olog[k].item():.5f} (reference {fx['textual.log.' + k].item():.5f})"
+                            for k in ("mel", "pitch", "energy", "generator")))
+    for k in ("mel", "pitch", "energy", "generator"):
+        assert abs(log[k].item() - olog[k].item()) <= 2e-3 * olog[k].item()
+        ref = fx["textual.log." + k].item()  # the reference's own LossLog
+        assert abs(log[k].item() - ref) <= 2e-3 * ref, (k, log[k].item(), ref)
     rep = Report()
+    got_cat = torch.stack([tr.pred_pitch * (dev(pitch) > 10).float(), tr.pred_energy], 1)
+    rep.add("pred pitchcat", got_cat, cat_p.detach(), 2e-3)
+    rep.add("pred pitchcat (reference)", got_cat, fx["textual.pred_pitchcat"], 2e-3)
     npep, npse = dict(tr.pep.named_parameters()), dict(tr.pse.named_parameters())
     for k in pep_keys:
         rep.add("d pep." + k[-40:], npep[k].grad, Ppep[k].grad, 8e-2)
+        rep.add("d pep(ref)." + k[-36:], stage_sub(npep[k].grad), fx["textual.grad.pep." + k], 8e-2)
     for k in pse_keys:
         rep.add("d pse." + k[-40:], npse[k].grad, Ppse[k].grad, 8e-2)
+        rep.add("d pse(ref)." + k[-36:], stage_sub(npse[k].grad), fx["textual.grad.pse." + k], 8e-2)
     rep.done()
 
 
