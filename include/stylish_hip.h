@@ -216,6 +216,10 @@ typedef struct {
   int frozen;          /* 1: the model is one of a stage's eval_models (the speech predictor in train_textual,
                           stage_type.py:461): the backward produces input gradients only -- the weight-gradient GEMMs
                           of the dense convs are skipped and the bound parameter gradients must be ignored.          */
+  float block_dropout; /* PitchEnergyPredictor only: nn.Dropout(model.yml pitch_energy_predictor.dropout = 0.2) between
+                          the AdaIN + LeakyReLU and each conv of its eight AdaptiveDecoderBlocks
+                          (pitch_energy_predictor.py:22,33-56; ada_norm.py:157,172-179).  Active with dropout_seed != 0;
+                          the speech predictor's Decoder builds its blocks with the default 0 (decoder.py:19-35).    */
 } sty_train_opts;
 int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
 

@@ -152,14 +152,15 @@ def gen_resblock(P, p, x, style):
     return x
 
 
-def decoder_block(P, p, x, style):
-    """AdaptiveDecoderBlock: AdaIN -> LeakyReLU(0.2) -> wn conv k3, twice; learned 1x1 shortcut; /sqrt2
-    (ada_norm.py:172-192)."""
+def decoder_block(P, p, x, style, p_drop=0.0):
+    """AdaptiveDecoderBlock: AdaIN -> LeakyReLU(0.2) -> [Dropout(p_drop)] -> wn conv k3, twice; learned 1x1 shortcut;
+    /sqrt2 (ada_norm.py:172-192).  p_drop: the block's dropout_p (ada_norm.py:157; 0 in the speech predictor's Decoder,
+    pitch_energy_predictor.dropout in the pitch / energy stacks), a hash mask in training mode like every other dropout."""
     h = adain(P, p + ".norm1", x, style)
-    h = F.leaky_relu(h, 0.2)
+    h = drop(F.leaky_relu(h, 0.2), p_drop)
     h = F.conv1d(h, wn_weight(P, p + ".conv1"), P[p + ".conv1.bias"], padding=1)
     h = adain(P, p + ".norm2", h, style)
-    h = F.leaky_relu(h, 0.2)
+    h = drop(F.leaky_relu(h, 0.2), p_drop)
     h = F.conv1d(h, wn_weight(P, p + ".conv2"), P[p + ".conv2.bias"], padding=1)
     sc = x
     if (p + ".conv1x1.parametrizations.weight.original0") in P:

@@ -114,7 +114,8 @@ def pitch_energy_predictor(P, texts, text_lengths, alignment, style, want=None):
         h = x
         i = 0
         while f"{name}.{i}.conv1.bias" in P:
-            h = OB.decoder_block(P, f"{name}.{i}", h, style)
+            # dropout_p = pitch_energy_config.dropout (pitch_energy_predictor.py:22,33-56; model.yml: 0.2)
+            h = OB.decoder_block(P, f"{name}.{i}", h, style, p_drop=OB.TRAIN.get("block_dropout", 0.2))
             i += 1
         out.append(F.conv1d(h, P[f"{name}_proj.weight"], P[f"{name}_proj.bias"]).squeeze(1))
     return out[0], out[1]

@@ -906,8 +906,35 @@ struct Trainer {
     return y;
   }
 
-  // AdaptiveDecoderBlock (ada_norm.py:180-192)
-  float* dec_block(const DecBlock& d, const float* xcat, int Tt) {
+  // z = a x + s of a folded AdaIN, materialised (instead of applied in the next conv's prologue).  Backward through
+  // pro_bwd in its PRO_AFFINE mode: dx += a g, and the per-(b,c) sums da = sum g x, ds = sum g that adain()'s backward
+  // closure turns into d gamma / d beta / d x.
+  float* affine(const float* x, const float* a, const float* s, int C, int Tt) {
+    const size_t n = (size_t)B * C * Tt;
+    float* y = take<float>(n);
+    if (live()) {
+      hipError_t e = hipMemsetAsync(y, 0, n * sizeof(float), st);
+      if (e != hipSuccess) rc = hip_fail(e, "affine memset");
+      chk(launch_row_axpb(x, s, a, B * C, Tt, y, st));
+    }
+    tape.push_back([=]() {
+      float* gY = G(y, n);
+      int acc = 1, dummy;
+      float* gX = Gw(x, n, acc);
+      float* dpa = Gw(a, (size_t)B * C, dummy);
+      float* dps = Gw(s, (size_t)B * C, dummy);
+      if (live())
+        chk(launch_pro_bwd(PRO_AFFINE, gY, C, 0, x, B, C, Tt, a, s, C, 0, nullptr, nullptr, gX, acc, dpa, dps, nullptr, st));
+    });
+    return y;
+  }
+
+  // AdaptiveDecoderBlock (ada_norm.py:180-192).  pdrop > 0 (and dropout on): nn.Dropout between each AdaIN + LeakyReLU and
+  // its conv (ada_norm.py:172-179; the pitch / energy predictor builds its blocks with dropout_p = 0.2).  A keep mask is
+  // 0 or 1 / (1 - p) >= 0 and LeakyReLU is positively homogeneous, so drop(lrelu(z)) = lrelu(drop(z)): the folded affine
+  // is materialised, masked, and the LeakyReLU stays the conv's prologue.
+  float* dec_block(const DecBlock& d, const float* xcat, int Tt, float pdrop = 0.f) {
+    const bool dr = dropout_on() && pdrop > 0.f;
     const float r2 = 0.70710678118654752f;
     float* sc = take<float>((size_t)B * d.Cout * Tt);
     if (d.has_sc) {
@@ -933,16 +960,26 @@ struct Trainer {
     adain(xcat, d.Cin, Tt, d.n1, a, s);
     float* h = take<float>((size_t)B * d.Cout * Tt);
     ConvArgs c1 = base(d.c1, xcat, Tt, h);
-    c1.pro = PRO_AFFINE_LRELU;
-    c1.pa = a;
-    c1.ps = s;
+    if (dr) {
+      c1.x[0] = dropout(affine(xcat, a, s, d.Cin, Tt), pdrop, d.Cin, Tt, nullptr);
+      c1.pro = PRO_LRELU;
+    } else {
+      c1.pro = PRO_AFFINE_LRELU;
+      c1.pa = a;
+      c1.ps = s;
+    }
     conv(c1);
     adain(h, d.Cout, Tt, d.n2, a, s);
     float* out = take<float>((size_t)B * d.Cout * Tt);
     ConvArgs c2 = base(d.c2, h, Tt, out);
-    c2.pro = PRO_AFFINE_LRELU;
-    c2.pa = a;
-    c2.ps = s;
+    if (dr) {
+      c2.x[0] = dropout(affine(h, a, s, d.Cout, Tt), pdrop, d.Cout, Tt, nullptr);
+      c2.pro = PRO_LRELU;
+    } else {
+      c2.pro = PRO_AFFINE_LRELU;
+      c2.pa = a;
+      c2.ps = s;
+    }
     c2.out_scale = r2;
     c2.residual = sc;
     conv(c2);
@@ -1133,7 +1170,7 @@ struct Trainer {
       const DecBlock* blk = which ? p.nn : p.f0;
       const float* in = xt;
       for (int i = 0; i < 4; ++i) {
-        in = dec_block(blk[i], in, Tt);
+        in = dec_block(blk[i], in, Tt, m->topts.block_dropout);
         if (!in) return;
       }
       float* out = take<float>((size_t)B * Tt);

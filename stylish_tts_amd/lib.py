@@ -38,7 +38,8 @@ class SpeechIO(C.Structure):
 class TrainOpts(C.Structure):
     _fields_ = [("bn_batch_stats", C.c_int), ("sn_power_iter", C.c_int), ("f0_smooth", C.c_int),
                 ("energy_smooth", C.c_int), ("bn_momentum", C.c_float), ("dropout_seed", C.c_uint),
-                ("text_dropout", C.c_float), ("compute_bf16", C.c_int), ("frozen", C.c_int)]
+                ("text_dropout", C.c_float), ("compute_bf16", C.c_int), ("frozen", C.c_int),
+                ("block_dropout", C.c_float)]
 
 
 class SpecDiscPtrs(C.Structure):

@@ -211,16 +211,19 @@ class _HipModule(torch.nn.Module):
         return self
 
     def set_train_opts(self, *, bn_batch_stats=False, sn_power_iter=False, f0_smooth=0, energy_smooth=0,
-                       bn_momentum=0.1, dropout_seed=0, text_dropout=0.2, compute_bf16=False, frozen=False):
+                       bn_momentum=0.1, dropout_seed=0, text_dropout=0.2, compute_bf16=False, frozen=False,
+                       block_dropout=0.2):
         """module.train() behaviour of forward_train (sty_train_opts): BatchNorm batch statistics, spectral-norm
         power iteration, Decoder smoothing widths (decoder.py:53-75; the caller draws them per step).
         compute_bf16: the dense convs / Linears of the training graph multiply bf16-rounded operands (fp32
         accumulation and storage) -- config c3's "bf16 autocast for conv/GEMM".
         frozen: the model is one of a stage's eval_models: backward() returns input gradients only (no weight-gradient
-        GEMMs; param.grad of this model must be ignored)."""
+        GEMMs; param.grad of this model must be ignored).
+        block_dropout: model.yml pitch_energy_predictor.dropout -- the Dropout in front of both convs of the pitch / energy
+        predictor's AdaptiveDecoderBlocks (active with dropout_seed != 0; other model kinds ignore it)."""
         self._train_opts = L.TrainOpts(int(bn_batch_stats), int(sn_power_iter), int(f0_smooth), int(energy_smooth),
                                        float(bn_momentum), int(dropout_seed) & 0xFFFFFFFF, float(text_dropout),
-                                       int(compute_bf16), int(frozen))
+                                       int(compute_bf16), int(frozen), float(block_dropout))
         if self._handle is not None:
             L.check(L.load().sty_model_set_train_opts(self._handle, C.byref(self._train_opts)))
         return self

@@ -39,7 +39,8 @@ def pitch_loss(target, pred, weight, d_pred, normalize=True):
 class TextualTrainer:
     def __init__(self, pitch_energy_predictor, pe_style_encoder, speech_predictor, speech_style_encoder, pitch_disc,
                  lr=1e-4, betas=(0.85, 0.99), eps=1e-9, weight_decay=1e-4, w_mel=5.0, w_gen=1.0, w_pitch=8.0, w_energy=8.0,
-                 mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0, dropout=0.2, compute="fp32"):
+                 mean=-4.0, std=4.0, bucket_bytes=25 << 20, train_mode=True, seed=0, dropout=0.2, compute="fp32",
+                 block_dropout=0.2):
         import random
         from .discriminators import DiscriminatorLossHelper
         from .optim import FlatAdamW
@@ -49,6 +50,7 @@ class TextualTrainer:
         self.w = dict(mel=w_mel, generator=w_gen, pitch=w_pitch, energy=w_energy)  # config.yml:73-101
         self.mean, self.std = mean, std
         self.train_mode, self.dropout = train_mode, dropout
+        self.block_dropout = block_dropout  # model.yml pitch_energy_predictor.dropout (the AdaptiveDecoderBlocks' Dropout)
         self.bf16 = compute == "bf16"  # bf16 operands on the dense convs of all three graphs (as AcousticTrainer)
         self._rng = random.Random(seed)
         if self.bf16:
@@ -73,7 +75,7 @@ class TextualTrainer:
         if self.train_mode:  # module.train() of the two trained models: dropout in the prosody / text encoder, one
             # spectral-norm power iteration of the style encoder per step
             self.pep.set_train_opts(dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.dropout,
-                                    compute_bf16=self.bf16)
+                                    compute_bf16=self.bf16, block_dropout=self.block_dropout)
             self.pse.set_train_opts(sn_power_iter=True, compute_bf16=self.bf16)
         mel, _, energy = calculate_mel(audio_gt, TO_MEL, self.mean, self.std, want_energy=True)
         style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)

@@ -1629,52 +1629,51 @@ def test_duration_train_step_vs_oracle(env):
 def test_second_stage_predictors_train_mode_dropouts_vs_oracle(env, which):
     """Training-mode dropouts of the two trainable predictors -- text encoder sites, attention probabilities (0.5 / 0.2),
     DropPath(0.5) per AdaptiveConvNeXt block and Dropout1d(0.5) after it (duration_predictor.py:25-40, 79), the prosody
-    encoder's three sites per layer (prosody_encoder.py:72-78) -- with the counter-based hash masks shared by the oracle
-    and the library (same site order, same element indexing): outputs and parameter gradients."""
+    encoder's three sites per layer (prosody_encoder.py:72-78), Dropout(0.2) in front of both convs of the pitch / energy
+    stacks' AdaptiveDecoderBlocks (ada_norm.py:172-179) -- with the counter-based hash masks: outputs, d_style and
+    parameter gradients against (1) the REFERENCE run in .train() with its random masks patched to the same function
+    (tests/golden/n3_dropout_small, tools/gen_golden_dropout.py) and (2) autograd on the float64 oracle."""
     import stylish_tts_amd as S
     from safetensors.torch import load_file
-    from oracle import blocks as OB, predictors as OP
+    from tests.test_oracle_golden import DROPOUT_KEYS, oracle_predictor_with_dropout, stage_sub
     gold = load_file(os.path.join(G, "n3_small.safetensors"))
+    fx = load_file(os.path.join(G, "n3_dropout_small.safetensors"))
     cs = env["cs"]
     _, _, Pd, Pp = _n3_models()
     P = Pd if which == "duration" else Pp
-    keys = (["cross_attention.conv_v.weight", "conv_next.1.pwconv1.weight", "duration_proj.linear_layer.weight",
-             "text_encoder.proj_m.weight"] if which == "duration" else
-            ["prosody_encoder.attn_layers.1.conv_v.weight", "prosody_encoder.ffn_layers.0.conv_2.weight", "F0_proj.weight",
-             "N.0.conv1.parametrizations.weight.original1"])
+    keys = DROPOUT_KEYS[which]
     P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
     for k in keys:
         P64[k].requires_grad_(True)
-    OB.TRAIN.update(dropout_seed=4321, _site=0, text_dropout=0.2)
-    try:
-        if which == "duration":
-            outs = (OP.duration_predictor(P64, cs["texts"], cs["text_lengths"], gold["duration_style"].double()),)
-        else:
-            outs = OP.pitch_energy_predictor(P64, cs["texts"], cs["text_lengths"], gold["alignment"].double(),
-                                             gold["pe_style"].double())
-    finally:
-        OB.TRAIN.update(dropout_seed=0, _site=0)
+    style_name = "duration_style" if which == "duration" else "pe_style"
+    style64 = gold[style_name].double().requires_grad_(True)
+    outs, nsites = oracle_predictor_with_dropout(which, P64, cs, gold, style64, torch.float64)
+    assert nsites == int(fx[which + ".nsites"].item())
     g = torch.Generator().manual_seed(8)
     seeds = [torch.randn(o.shape, generator=g) for o in outs]
     sum((o * s_.double()).sum() for o, s_ in zip(outs, seeds)).backward()
     m = (S.DurationPredictor() if which == "duration" else S.PitchEnergyPredictor())
     m.load_state_dict(P)
     m = m.to(DEV).enable_training()
-    m.set_train_opts(dropout_seed=4321, text_dropout=0.2)
+    m.set_train_opts(dropout_seed=4321, text_dropout=0.2, block_dropout=0.2)
     if which == "duration":
         got = (m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["duration_style"])),)
-        m.backward(dev(seeds[0]))
+        d_style = m.backward(dev(seeds[0]))
     else:
         got = m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(gold["alignment"]), dev(gold["pe_style"]))
-        m.backward(dev(seeds[0]), dev(seeds[1]))
+        d_style = m.backward(dev(seeds[0]), dev(seeds[1]))
     torch.cuda.synchronize()
     rep = Report()
     tol_o, tol_g = (1e-4, 1e-3) if which == "duration" else (2e-3, 8e-2)
-    for i, (a, b) in enumerate(zip(got, outs)):
-        rep.add(f"out{i}", a, b.detach().float(), tol_o)
+    for i, (a_, b_) in enumerate(zip(got, outs)):
+        rep.add(f"out{i}", a_, b_.detach().float(), tol_o)
+        rep.add(f"out{i} (reference)", a_, fx[f"{which}.out{i}"], tol_o)
+    rep.add("d_style", d_style, style64.grad.float(), tol_g)
+    rep.add("d_style (reference)", d_style, fx[which + ".d_style"], tol_g)
     nm = dict(m.named_parameters())
     for k in keys:
         rep.add("d " + k[-44:], nm[k].grad, P64[k].grad.float(), tol_g)
+        rep.add("d(ref) " + k[-40:], stage_sub(nm[k].grad), fx[f"{which}.grad.{k}"], tol_g)
     rep.done()
 
 
