@@ -30,6 +30,8 @@ def mel_style_encoder(P, p, mel, want=None):
     """MelStyleEncoder.forward: mel [B,1,80,T] -> style [B,64] (mel_style_encoder.py:147-152)."""
     pre = (p + ".") if p else ""
     x = F.conv2d(mel, sn_weight(P, pre + "shared.0"), P[pre + "shared.0.bias"], padding=1)
+    if want is not None:
+        want["se.block0"] = x
     for i in range(1, 5):
         down = (f"{pre}shared.{i}.downsample_res.conv.weight_orig") in P
         x = _resblk(P, f"{pre}shared.{i}", x, down)
@@ -37,6 +39,8 @@ def mel_style_encoder(P, p, mel, want=None):
             want[f"se.block{i}"] = x
     x = F.leaky_relu(x, 0.2)
     x = F.conv2d(x, sn_weight(P, pre + "shared.6"), P[pre + "shared.6.bias"])
+    if want is not None:
+        want["se.head"] = x
     x = x.mean(dim=(2, 3))
     x = F.leaky_relu(x, 0.2)
     return F.linear(x, P[pre + "unshared.weight"], P[pre + "unshared.bias"])

@@ -2645,6 +2645,16 @@ int sty_style_bwd(sty_model* m, const float* d_style, void* stream) {
   if (m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
   return STY_OK;
 }
+// parity taps of the style encoder's training graph: activation (grad = 0) or its gradient (grad = 1, after sty_style_bwd)
+int sty_style_tap(sty_model* m, int index, int grad, float* dst, int* C, int* H, int* W, void* stream) {
+  int rc = model_ready(m, "mel_style_encoder", "pitch_style_encoder");
+  if (rc) return rc;
+  if (!m->trainer) {
+    set_error("sty_style_tap: no recorded forward");
+    return STY_ESTATE;
+  }
+  return trainer_style_tap(m->trainer, index, grad, dst, C, H, W, S(stream));
+}
 // ---- one dense Conv1d ('same' padding) on the MFMA conv kernel: unit parity and kernel tuning ----
 int sty_conv1d_workspace_bytes(int Cout, int Cin, int K, size_t* bytes) {
   if (!bytes || Cout <= 0 || Cin <= 0 || K <= 0) {

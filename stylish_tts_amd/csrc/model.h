@@ -347,6 +347,7 @@ int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, fl
 int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
                           hipStream_t st, size_t* need, const float* pitch = nullptr, const float* energy = nullptr);
 int trainer_style_backward(struct Trainer* t, const float* d_style, hipStream_t st);
+int trainer_style_tap(struct Trainer* t, int i, int grad, float* dst, int* C, int* H, int* W, hipStream_t st);
 struct Trainer;
 Trainer* trainer_create(sty_model* m);
 int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t ws_bytes, hipStream_t st,

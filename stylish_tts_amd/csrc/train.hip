@@ -1512,6 +1512,13 @@ struct Trainer {
   }
 
   float* style_out = nullptr;
+  // parity taps of the style encoder's training graph (sty_style_tap): the stem's output, the four ResBlk outputs and the
+  // head conv's output, as padded-flat images
+  struct SeTap {
+    const float* act;
+    int C, H, W;
+  };
+  std::vector<SeTap> se_taps;
   // pitch / energy != nullptr: PitchStyleEncoder (mel_style_encoder.py:155-205, coarse_multiplier 1): the trunk runs on
   // preconv(cat(mel, pitch, energy)) -- a weight-normed Conv1d(k = 1, padding = 1), so T + 2 frames -- and the backward
   // reaches the preconv's parameters (the three inputs are data: no gradient)
@@ -1572,6 +1579,8 @@ struct Trainer {
     const float* mk = mask_for(H, W, H, W);
     float* x = take<float>((size_t)B * C * H * (W + 1));
     conv2d(sp.stem, melp, 1, H * (W + 1), W + 1, x, 1, 1, PRO_NONE, 1.f, nullptr, mk);
+    se_taps.clear();
+    se_taps.push_back({x, C, H, W});
     for (int i = 0; i < 4; ++i) {
       const StyleResBlk& k = sp.blk[i];
       const int Ho = k.down ? H / 2 : H, Wo = k.down ? (W + 1) / 2 : W;
@@ -1640,6 +1649,7 @@ struct Trainer {
       W = Wo;
       C = k.Cout;
       mk = mko;
+      se_taps.push_back({x, C, H, W});
     }
     const int KH = 5;
     const int Hh = H - KH + 1, Wh = W - sp.head.K + 1;
@@ -1653,6 +1663,7 @@ struct Trainer {
     const float* mkh = mask_for(H, W, Hh, Wh);
     float* hd = take<float>((size_t)B * C * n);
     conv2d(sp.head, x, C, n, W + 1, hd, 0, 0, PRO_LRELU, 1.f, nullptr, mkh);
+    se_taps.push_back({hd, C, H, W});
     style_out = style_dst;
     if (live()) chk(launch_pool_fc(hd, B, C, n, Hh * Wh, sp.fc_w, sp.fc_b, sp.style_dim, style_dst, st));
     const float* fw = sp.fc_w;
@@ -2085,6 +2096,32 @@ int trainer_style_forward(Trainer* t, int B, int T, const float* mel, float* sty
     return STY_ENOMEM;
   }
   return t->rc;
+}
+
+int trainer_style_tap(Trainer* t, int i, int grad, float* dst, int* C, int* H, int* W, hipStream_t st) {
+  if (i < 0 || i >= (int)t->se_taps.size()) {
+    set_error("style tap %d: the last style forward recorded %zu taps", i, t->se_taps.size());
+    return STY_EINVAL;
+  }
+  const Trainer::SeTap& tp = t->se_taps[i];
+  if (C) *C = tp.C;
+  if (H) *H = tp.H;
+  if (W) *W = tp.W;
+  if (!dst) return STY_OK;
+  const float* src = tp.act;
+  if (grad) {
+    auto it = t->gmap.find(tp.act);
+    if (it == t->gmap.end()) {
+      set_error("style tap %d: no gradient (call sty_style_bwd first)", i);
+      return STY_ESTATE;
+    }
+    src = it->second;
+  }
+  // padded-flat [B][C][H][W+1] -> [B][C][H][W]
+  hipError_t e = hipMemcpy2DAsync(dst, (size_t)tp.W * 4, src, (size_t)(tp.W + 1) * 4, (size_t)tp.W * 4,
+                                  (size_t)t->B * tp.C * tp.H, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return hip_fail(e, "style tap copy");
+  return STY_OK;
 }
 
 int trainer_style_backward(Trainer* t, const float* d_style, hipStream_t st) {

@@ -107,6 +107,7 @@ SYMBOLS = {
     "sty_style_fwd_train": (C.c_int, [_P, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "sty_style_prepare_train": (C.c_int, [_P, _P]),
     "sty_style_bwd": (C.c_int, [_P, _P, _P]),
+    "sty_style_tap": (C.c_int, [_P, _I, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     "sty_duration_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),
     "sty_duration_fwd": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sty_pitch_energy_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),

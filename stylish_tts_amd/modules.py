@@ -701,6 +701,19 @@ class MelStyleEncoder(_HipModule):
         st = C.c_void_p(torch.cuda.current_stream(d_style.device).cuda_stream)
         L.check(lib.sty_style_bwd(self._handle, L.ptr(d_style), st))
 
+    def tap(self, index, grad=False):
+        """Parity tap of the last forward_train (sty_style_tap): 0 = the stem's output, 1..4 = the ResBlk outputs, 5 = the
+        head conv's output at every position; grad=True (after backward): d loss / d that activation.  [B,C,H,W]."""
+        lib = L.load()
+        dev = self._train_keep[0].device
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.sty_style_tap(self._handle, index, int(grad), None, C.byref(c), C.byref(h), C.byref(w), st))
+        out = torch.empty(self._train_keep[0].shape[0], c.value, h.value, w.value, dtype=torch.float32, device=dev)
+        L.check(lib.sty_style_tap(self._handle, index, int(grad), C.c_void_p(out.data_ptr()), C.byref(c), C.byref(h),
+                                  C.byref(w), st))
+        return out
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # second-stage predictors (SURVEY.md 8(f) N3), inference
