@@ -212,3 +212,68 @@ def test_c2_discriminators_full_size_vs_oracle():
     torch.cuda.synchronize()
     assert torch.isfinite(dx).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
     assert 0.5 < gen[0].item() < 50 and 0.5 < disc[0].item() < 50, (gen, disc)
+
+
+def test_c3_slice_bf16_train_step_gated():
+    """The headline MODE at the headline shape, gated: one train_acoustic step with bf16 GEMM operands on a B = 4 slice of
+    configs[2] (T = 520 frames, L = 100 tokens; eval-mode graph, lr = 0) against the fp32 CPU oracle's forward + autograd.
+    What can be held through ~60 bf16 GEMM layers: both losses (to 1e-3; they are averages), the audio (waveform MSE
+    relative to the signal power, mel-L1) and the DIRECTION and SIZE of parameter gradients (cosine, norm ratio; the median
+    cosine >= 0.9) -- a mis-scaled or mis-indexed bf16 kernel moves these by O(1), bf16 rounding by what is asserted below.  (Element-wise agreement of the gradients is
+    not a property the model has at random initialisation: an fp32 control run with bf16-sized weight noise moves them as
+    far, test_acoustic_train_step_bf16_compute_vs_fp32.)  The single kernels of the mode are pinned at 1e-3 ... 1e-4 on
+    rounded operands by test_block_bf16_mode_vs_float64_oracle_on_rounded_operands, test_dense_conv1d_vs_torch[bf16],
+    test_persistent_conv32_vs_torch and test_persistent_conv16_vs_torch."""
+    from oracle import losses as ol, speech_predictor as osp
+    from stylish_tts_amd.acoustic import AcousticTrainer
+    w, inp = _inputs("c3", 2000)
+    Bs = 4
+    inp = {k: v[:Bs].contiguous() for k, v in inp.items()}
+    sp, se, P, Pse = _models()
+    tr = AcousticTrainer(sp, se, lr=0.0, train_mode=False, compute="bf16")
+    sp_keys = ["generator.basegen.amp_output_conv.weight", "generator.basegen.phase_convnext.3.pwconv1.weight",
+               "generator.basegen.phase_convnext.6.pwconv2.weight", "generator.basegen.amp_convnext.2.pwconv1.weight",
+               "generator.basegen.amp_prior_block.convs1.1.parametrizations.weight.original1",
+               "generator.amp_conformer.layers.0.ff1.fn.fn.net.0.weight", "decoder.decode.1.conv1.parametrizations.weight.original1",
+               "text_encoder.encoder.ffn_layers.3.conv_1.weight", "text_encoder.proj_m.weight"]
+    sp_keys = [k for k in sp_keys if k in P and P[k].is_floating_point()]
+    assert len(sp_keys) >= 7, [k for k in sp_keys]
+    se_keys = ["shared.0.weight_orig", "shared.2.conv1.weight_orig", "shared.4.conv2.weight_orig", "unshared.weight"]
+    for k in sp_keys:
+        P[k].requires_grad_(True)
+    for k in se_keys:
+        Pse[k].requires_grad_(True)
+    want = {}
+    t0 = time.perf_counter()
+    ref = osp.acoustic_forward(P, Pse, inp["audio_gt"], inp["texts"], inp["text_lengths"], inp["pitch"],
+                               inp["durations"], inp["noise"], want)
+    mel, mph, tot = ol.acoustic_losses(inp["audio_gt"], ref.squeeze(1))
+    tot.backward()
+    print(f"\n  oracle forward + backward (B = {Bs}, T = {w['T']}): {time.perf_counter() - t0:.1f} s")
+    losses = tr.train_batch(audio_gt=dev(inp["audio_gt"]), texts=dev(inp["texts"]), text_lengths=dev(inp["text_lengths"]),
+                            pitch=dev(inp["pitch"]), durations=dev(inp["durations"]), noise=dev(inp["noise"]),
+                            prior_override=dev(want["prior"]))
+    torch.cuda.synchronize()
+    mse, l1 = _report("c3 slice, bf16 operands: audio", tr.audio.cpu(), ref.detach())
+    power = (ref.detach() ** 2).mean().item()
+    print(f"  signal power {power:.3e}: relative waveform error {mse / power:.3e}")
+    gate_audio = mse <= 2e-2 * power and l1 <= 3e-2  # measured 6.4e-3, 1.3e-2
+    print(f"  mel {losses[0].item():.6f} vs {mel.item():.6f}   multi_phase {losses[1].item():.6f} vs {mph.item():.6f}")
+    gate_loss = (abs(losses[0].item() - mel.item()) <= 1e-3 * abs(mel.item()) and  # measured 1e-4, 3e-6
+                 abs(losses[1].item() - mph.item()) <= 1e-3 * abs(mph.item()))
+    nsp, nse = dict(tr.sp.named_parameters()), dict(tr.se.named_parameters())
+    bad, cosines = [], []
+    for tag, keys, got, refd in (("sp", sp_keys, nsp, P), ("se", se_keys, nse, Pse)):
+        for k in keys:
+            g, r = got[k].grad.detach().cpu(), refd[k].grad
+            cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
+            ratio = g.norm().item() / max(r.norm().item(), 1e-30)
+            print(f"  d {tag}.{k[-52:]:52s} cosine {cos:.4f}  |g| / |g_ref| {ratio:.4f}")
+            cosines.append(cos)
+            # measured: cosine 0.37 (the prior block's dilated conv, behind twelve instance norms) ... 0.998, ratio 0.94 ... 1.33
+            if cos < 0.25 or not 0.66 <= ratio <= 1.5:
+                bad.append((k, cos, ratio))
+    cosines.sort()
+    print(f"  median cosine {cosines[len(cosines) // 2]:.4f}")
+    assert cosines[len(cosines) // 2] >= 0.9
+    assert gate_audio and gate_loss and not bad, (gate_audio, gate_loss, bad)
