@@ -177,7 +177,15 @@ class DiscriminatorLossHelper:  # losses.py:228-290
         return max(math.pow(self.h_min, x / self.x_min), self.h_min)
 
     def track(self, disc):
-        self.last_loss = self.last_loss * 0.95 + float(disc[1].item()) * 0.05
+        """EMA of the tracked discriminator loss (losses.py:287).  It sets the discriminator's learning rate, so with more
+        than one rank the MEAN over ranks is tracked: ranks that tracked their local values would step their replicas at
+        different rates and drift apart for good (identical to the reference at world size 1)."""
+        import torch.distributed as dist
+        v = disc[1].detach().clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            v = v / dist.get_world_size()
+        self.last_loss = self.last_loss * 0.95 + float(v.item()) * 0.05
 
     def __call__(self, *, target, pred, scale=1.0):
         _, disc = self.model.losses(target, pred, disc_scale=scale)
