@@ -206,6 +206,12 @@ class AcousticTrainer:
                 gen_w, dsc_w = self.disc.losses(audio_gt, audio.squeeze(1), gen_scale=3.0 * self.w_gen, d_pred=d_audio,
                                                 disc_scale=3.0 * float(texts.shape[0]) ** 0.5, bn_momentum=0.19)
                 self.gan_wave = torch.cat([gen_w, dsc_w])  # generator loss, discriminator loss, the same without tprls
+        if self.mrd is not None:
+            # the discriminators' weight gradients are final here (the loss calls above produced them from the same forward
+            # pass as the generator term): their buckets travel while the whole predictor / style-encoder backward runs
+            self.opt[f"mrd{disc_index}"].grads.reduce_all()
+            if self.disc is not None:
+                self.opt["disc"].grads.reduce_all()
         self._install_grad_hook(self.sp, "speech_predictor")
         self._install_grad_hook(self.se, "speech_style_encoder")
         # the all-reduces are started by the gradient hooks from inside the two backward calls: the predictor's
@@ -230,7 +236,6 @@ class AcousticTrainer:
         if self.mrd is not None:
             # optimizers.py:54-65: discriminator lr = generator lr x multiplier of the tracked discriminator loss
             od = self.opt[f"mrd{disc_index}"]
-            od.grads.reduce_all()
             od.grads.finish(average=False)
             od.lr = self.opt["speech_predictor"].lr * self.disc_helpers[disc_index].get_disc_lr_multiplier()
             od.step(grad_scale=1.0 / world)
@@ -244,7 +249,6 @@ class AcousticTrainer:
                 h.last_loss = h.last_loss * 0.95 + plain[2 + 2 * r] * 0.05
             if self.disc is not None:
                 ow = self.opt["disc"]
-                ow.grads.reduce_all()
                 ow.grads.finish(average=False)
                 ow.lr = self.opt["speech_predictor"].lr * self.disc_helper.get_disc_lr_multiplier()
                 ow.step(grad_scale=1.0 / world)

@@ -86,10 +86,38 @@ def main(out_path):
                                 minlength=Lt).float()
     p2 = torch.rand(Br, Tr, generator=g2) * 200 + 80
     a2 = 0.1 * torch.randn(Br, 300 * Tr, generator=g2)
+    # Overlap: the predictor's segment-0 buckets (vocoder + decoder: 85 % of the bytes) must be handed to the collective from
+    # INSIDE sty_speech_bwd, i.e. before the text encoder's backward has been issued -- seen as (1) the hook firing before
+    # sp.backward returns and (2) device time between an event recorded where the all-reduce starts and one recorded
+    # when the backward call returns (the text encoder's backward kernels lie between them).
+    marks = {}
+    gp = tr.opt["speech_predictor"].grads
+    orig_group, orig_backward = gp.reduce_group, tr.sp.backward
+
+    def reduce_group(segment):
+        if segment == 0 and "hook" not in marks:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks["hook"] = ev
+            marks["returned_when_hook_fired"] = "returned" in marks
+        return orig_group(segment)
+
+    def backward(*a, **k):
+        out = orig_backward(*a, **k)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.setdefault("returned", ev)
+        return out
+
+    gp.reduce_group, tr.sp.backward = reduce_group, backward
     for it in range(2):
         tr.train_batch(audio_gt=a2.to(dev), texts=tx.to(dev), text_lengths=torch.full((Br,), Lt).to(dev),
                        pitch=p2.to(dev), durations=d2.to(dev), seed=it)
     torch.cuda.synchronize()
+    assert "hook" in marks and marks["returned_when_hook_fired"] is False, "segment 0 was not announced inside the backward"
+    ms = marks["hook"].elapsed_time(marks["returned"])
+    print(f"[rank {rank}] first all-reduce handed over {ms:.2f} ms of device time before sty_speech_bwd's work ended")
+    assert ms > 0.0
     after = torch.cat([p.detach().flatten() for m in (tr.sp, tr.se) for p in m.parameters()])
     assert bool(torch.isfinite(after).all())
     assert not torch.equal(after[:before.numel()], before), "parameters did not move"
