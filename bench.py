@@ -562,6 +562,7 @@ def main():
                 r.pop("kernels", None)
                 r.pop("kernels_source", None)
                 extras[name] = r
+    backend = torch.distributed.get_backend() if world > 1 else None
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -569,8 +570,7 @@ def main():
         return
     rec["library"] = lib_info
     rec["ranks"] = {"world_size": world, "launcher": "torch.distributed.run, one process per GPU" if world > 1 else "single process",
-                    "backend": (torch.distributed.get_backend() + (" (RCCL)" if not share else " (share-device test aid)"))
-                    if world > 1 else None,
+                    "backend": (backend + (" (RCCL)" if not share else " (share-device test aid)")) if world > 1 else None,
                     "devices": 1 if share else world}
     if extras:
         rec["extra"] = extras

@@ -328,6 +328,11 @@ int sty_adamw_step(size_t n, float *p, const float *g, float *m, float *v, float
  * seed = w_mel*mel/(mel.detach()+1e-9) + w_phase*multi_phase/(multi_phase.detach()+1e-9)  (loss_log.py:82-94).
  * audio_gt, audio_pred [B,N] -> losses[2] (device: mel, multi_phase), d_audio_pred [B,N] = d seed / d audio_pred. */
 int sty_acoustic_loss_workspace_bytes(int B, int N, size_t *bytes);
+/* Optional: the TARGET side of the loss features (the three STFT resolutions of audio_gt, multi_spectrogram.py:57-66 under
+ * no_grad) depends on data only.  sty_acoustic_loss_target computes it into `workspace` ahead of time -- e.g. on the main
+ * stream while it waits for the style encoder -- and a later sty_acoustic_loss_fwd_bwd / sty_acoustic_gan_loss_fwd_bwd with
+ * the SAME workspace, B and N and audio_gt = NULL uses it instead of recomputing it.                              */
+int sty_acoustic_loss_target(int B, int N, const float *audio_gt, void *workspace, size_t ws_bytes, void *stream);
 int sty_acoustic_loss_fwd_bwd(int B, int N, const float *audio_gt, const float *audio_pred, float w_mel,
                               float w_phase, float *losses, float *d_audio_pred, void *workspace, size_t ws_bytes,
                               void *stream);

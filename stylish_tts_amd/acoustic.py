@@ -120,6 +120,8 @@ class AcousticTrainer:
             disc.compute_bf16 = self.bf16
             self.opt["disc"] = FlatAdamW(list(disc.named_parameters()), **kw)
             self.disc_helper = DiscriminatorLossHelper(disc, 1)
+        import os
+        self.early_target = os.environ.get("STY_NO_EARLY_TARGET") is None
         self._hooks = {}
         self._hook_error = None
 
@@ -154,7 +156,7 @@ class AcousticTrainer:
                     prior_override=None, disc_index=None):
         """One optimizer step; returns the (mel, multi_phase) loss values as a device tensor [2] (with `mrd`: self.gan
         holds the generator loss and the three discriminator losses of the step, a device tensor [7])."""
-        from .losses import acoustic_gan_loss, acoustic_loss
+        from .losses import acoustic_gan_loss, acoustic_loss, acoustic_loss_target
         for o in self.opt.values():
             o.zero_grad()
         if self.train_mode:
@@ -187,10 +189,13 @@ class AcousticTrainer:
         else:
             style = self.se.forward_train(style_in)
         voiced = (pitch > 20).float()
+        # the target side of the loss features (three STFT resolutions of audio_gt) needs no forward pass: issued here, in
+        # front of the predictor, its kernels run while the main stream would otherwise wait for the style encoder
+        target = acoustic_loss_target(audio_gt) if self.early_target else None
         audio = self.sp.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, pitch,
                                       noise=noise, seed=seed, prior_override=prior_override, style_stream=side)
         if self.mrd is None:
-            losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase)
+            losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase, target=target)
         else:
             # stage.py:116-121: disc_index = random.randrange(3); both sides of the adversarial game from one pass
             if disc_index is None:
@@ -198,7 +203,7 @@ class AcousticTrainer:
             self.disc_index = disc_index
             losses, self.gan, d_audio = acoustic_gan_loss(
                 audio_gt, audio.squeeze(1), self.mrd, w_mel=self.w_mel, w_phase=self.w_phase, w_gen=self.w_gen,
-                disc_scale=float(texts.shape[0]) ** 0.5, step=(disc_index,), compute_bf16=self.bf16)
+                disc_scale=float(texts.shape[0]) ** 0.5, step=(disc_index,), compute_bf16=self.bf16, target=target)
             if self.disc is not None:
                 # + disc_weight (3) x the waveform discriminator in both losses; one forward pass per input serves both
                 # helpers, so BatchNorm's running statistics see each batch once with the momentum of two updates

@@ -2857,7 +2857,7 @@ int sty_acoustic_loss_workspace_bytes(int B, int N, size_t* bytes) {
 }
 int sty_acoustic_loss_fwd_bwd(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
                               float* losses, float* d_audio_pred, void* workspace, size_t ws_bytes, void* stream) {
-  if (!audio_gt || !audio_pred || !losses || !d_audio_pred || !workspace || B <= 0 || N <= 1024) {
+  if (!audio_pred || !losses || !d_audio_pred || !workspace || B <= 0 || N <= 1024) {  // (audio_gt may be NULL: header)
     set_error("sty_acoustic_loss_fwd_bwd: bad argument");
     return STY_EINVAL;
   }
@@ -2867,6 +2867,18 @@ int sty_acoustic_loss_fwd_bwd(int B, int N, const float* audio_gt, const float* 
   }
   return launch_acoustic_loss(B, N, audio_gt, audio_pred, w_mel, w_phase, losses, d_audio_pred, (float*)workspace,
                               S(stream));
+}
+
+int sty_acoustic_loss_target(int B, int N, const float* audio_gt, void* workspace, size_t ws_bytes, void* stream) {
+  if (!audio_gt || !workspace || B <= 0 || N <= 1024) {
+    set_error("sty_acoustic_loss_target: bad argument");
+    return STY_EINVAL;
+  }
+  if (ws_bytes < acoustic_loss_workspace_floats(B, N) * sizeof(float)) {
+    set_error("sty_acoustic_loss_target: workspace too small");
+    return STY_ENOMEM;
+  }
+  return launch_acoustic_loss(B, N, audio_gt, nullptr, 0.f, 0.f, nullptr, nullptr, (float*)workspace, S(stream));
 }
 
 int sty_acoustic_gan_workspace_bytes(int B, int N, int with_grads, size_t* bytes) {
@@ -2882,8 +2894,8 @@ int sty_acoustic_gan_loss_fwd_bwd(int B, int N, const float* audio_gt, const flo
                                   const sty_specdisc_grads* mrd_grads, int step_mask, float* losses, float* gan_losses,
                                   float* d_audio_pred, void* workspace, size_t ws_bytes, void* gan_workspace,
                                   size_t gan_ws_bytes, int compute_bf16, void* stream) {
-  if (!audio_gt || !audio_pred || !losses || !gan_losses || !d_audio_pred || !workspace || !gan_workspace || !mrd ||
-      B <= 0 || N <= 1024 || (step_mask && !mrd_grads)) {
+  if (!audio_pred || !losses || !gan_losses || !d_audio_pred || !workspace || !gan_workspace || !mrd ||  // (audio_gt may
+      B <= 0 || N <= 1024 || (step_mask && !mrd_grads)) {                                                 // be NULL: header)
     set_error("sty_acoustic_gan_loss_fwd_bwd: bad argument");
     return STY_EINVAL;
   }

@@ -583,7 +583,7 @@ size_t acoustic_loss_workspace_floats(int B, int N) {
   size_t tmp = 0;
   for (auto& r : res) {
     const size_t frames = N / r[1] + 1, F = r[0] / 2 + 1;
-    tot += (size_t)B * frames * (128 * 3 + F * 5 + 2 * F + 16);   // persistent per-resolution tensors
+    tot += (size_t)B * frames * (128 * 3 + F * 6 + 2 * F + 16);   // persistent per-resolution tensors
     const size_t t = (size_t)B * frames * ((size_t)r[0] + 2 * F + F) + 1024;  // frames + y/dy + d|X|
     tmp = t > tmp ? t : tmp;
   }
@@ -622,8 +622,12 @@ int launch_acoustic_loss(int B, int N, const float* audio_gt, const float* audio
 int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* audio_pred, float w_mel, float w_phase,
                              float* losses_out, float* d_pred, float* ws, const AcousticGan* gan, hipStream_t st) {
   const int res[3][2] = {{512, 128}, {1024, 256}, {2048, 512}};
+  // audio_pred == nullptr: the TARGET side only (sty_acoustic_loss_target: the features of audio_gt depend on data
+  // only and can be computed ahead of the forward pass); audio_gt == nullptr: the target side is already in `ws`
+  const bool target_only = audio_pred == nullptr, have_target = audio_gt == nullptr;
   ResBufs rb[3];
   float* d_gan[3];
+  float* t_fft[3];
   float* p = ws;
   auto take = [&](size_t n) {
     float* q = p;
@@ -647,12 +651,15 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
     rb[r].p_fft = take((size_t)B * F * frames);
     rb[r].p_y = take((size_t)B * 2 * F * frames);
     d_gan[r] = take((size_t)B * F * frames);
+    t_fft[r] = take((size_t)B * F * frames);
     hdims.v[2 * r] = F;
     hdims.v[2 * r + 1] = frames;
   }
   float* tmp = p;
-  STY_HIP(hipMemsetAsync(sums, 0, 16 * sizeof(double), st));
-  STY_HIP(hipMemsetAsync(d_pred, 0, (size_t)B * N * sizeof(float), st));
+  if (!target_only) {
+    STY_HIP(hipMemsetAsync(sums, 0, 16 * sizeof(double), st));
+    STY_HIP(hipMemsetAsync(d_pred, 0, (size_t)B * N * sizeof(float), st));
+  }
   // features: target (scratch y), prediction (kept y)
   for (int r = 0; r < 3; ++r) {
     const FrontTables* t;
@@ -661,8 +668,8 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
     const int frames = rb[r].frames, F = rb[r].F, n_fft = rb[r].n_fft;
     float* xt = tmp;
     float* y = xt + (size_t)B * n_fft * frames;
-    float* tfft = y + (size_t)B * 2 * F * frames;
-    for (int side = 0; side < 2; ++side) {
+    float* tfft = t_fft[r];
+    for (int side = have_target ? 1 : 0; side < (target_only ? 1 : 2); ++side) {
       const float* audio = side == 0 ? audio_gt : audio_pred;
       float* yy = side == 0 ? y : rb[r].p_y;
       float* fm = side == 0 ? tfft : rb[r].p_fft;
@@ -681,6 +688,7 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
       const size_t n = (size_t)B * 128 * frames;
       hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mg, n);
     }
+    if (target_only) continue;
     hipLaunchKernelGGL(loss_sums_kernel, dim3(256), dim3(256), 0, st, rb[r], r, B, sums);
     if (gan) {  // target |X| (scratch) and predicted |X| are both live here, in the batch-folded layout [F][B][frames]
       STY_HIP(hipMemsetAsync(d_gan[r], 0, (size_t)B * F * frames * sizeof(float), st));
@@ -689,6 +697,10 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
                         gan->ws, gan->ws_bytes, st, nullptr);
       if (rc) return rc;
     }
+  }
+  if (target_only) {
+    STY_LAUNCH_CHECK();
+    return STY_OK;
   }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, sums, hdims, B, losses_out);
   // backward

@@ -122,6 +122,7 @@ SYMBOLS = {
                                  _I, C.c_float, _P]),
     "sty_model_set_grad_hook": (C.c_int, [_P, _P, _P]),
     "sty_acoustic_loss_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
+    "sty_acoustic_loss_target": (C.c_int, [_I, _I, _P, _P, C.c_size_t, _P]),
     "sty_acoustic_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "sty_specdisc_workspace_bytes": (C.c_int, [_I, _I, _I, _I, _SZP]),
     "sty_specdisc_forward": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, C.c_size_t, _P]),
