@@ -89,6 +89,19 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
   __syncthreads();
 
   const int tw = wave * 64;
+  // (training, bf16 mode) h leaves pass 2 as bf16 [B][128][T]; lane part of the store offsets: row 4 hi, column t
+  const bool keep_h = PASS2 && BF && a.h16 != nullptr;
+  __amdgpu_buffer_rsrc_t r_h16;
+  int hoff[2] = {0, 0};
+  if (PASS2 && BF) {
+    r_h16 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.h16) + (size_t)b * 128 * T * 2, 0,
+                                              keep_h ? 128 * T * 2 : 0, 0x00020000);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int t = t0 + tw + n * 32 + l31;
+      hoff[n] = t < T ? (4 * hi * T + t) * 2 : 0x7FFFFF00;  // columns past the end: outside the descriptor, dropped
+    }
+  }
   f32x16 acc2[2];
   if (PASS2) {
 #pragma unroll
@@ -174,6 +187,13 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
         const float z = h[n][r];
         float v = fmaf(ral, slow ? sty_sin2(al * z) : (BF ? sty_sin2_hw(al * z) : sty_sin2_fast(al * z)), z);
         if (PASS2) {
+          if constexpr (BF) {
+            if (keep_h) {  // h (before the GRN scale) as bf16 for the backward's M = gY h^T (wave-uniform branch)
+              const bf16x8 pk = sty_pack_bf16(v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+              const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;  // wave-uniform part of the row offset
+              __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(uint4, pk).x & 0xffffu), r_h16, hoff[n], srow, 0);
+            }
+          }
           h[n][r] = v * sc;
         } else {
           const int t = t0 + tw + n * 32 + l31;

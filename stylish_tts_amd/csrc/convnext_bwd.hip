@@ -22,7 +22,10 @@ constexpr int CB_TT = 256;
 // v_mfma_f32_32x32x16_bf16 per 32-row block instead of sixteen v_mfma_f32_32x32x2_f32: operands rounded to bf16 on the
 // way in (eight reduction elements per lane: for the chained GEMM the lane's accumulator registers 8 s .. 8 s + 7, rows
 // R(hi, 8 s + e), with the A fragment gathered in the same row order), fp32 accumulation, everything else unchanged.
-template <int PASS, bool BF>
+// LEAN (pass 2, bf16 mode): the lean backward -- h s is not written and d alpha is not accumulated here (see the note on
+// the lean backward at the end of this file): ten of the ~45 vector instructions per hidden element and a quarter of the
+// kernel's output bytes.
+template <int PASS, bool BF, bool LEAN = false>
 __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) {
   constexpr int LW = CB_TT + 6, LG = CB_TT + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -234,16 +237,20 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
           s2a = 2.f * sn * cs;
         }
         const float hv = fmaf(ral, s2, z);
-        float rsum;
+        float rsum = 0.f;
         if (PASS == 1) {
           rsum = ok ? uu[r] * hv : 0.f;
         } else {
           const float cf = prm[384 + ch];
           const float gH = ok ? fmaf(uu[r], sc, cf * hv) : 0.f;
           const float g0 = gH * (1.f + s2a);
-          rsum = gH * (z * s2a - s2 * ral) * ral;
+          if constexpr (!LEAN) rsum = gH * (z * s2a - s2 * ral) * ral;
           if (ok) {
-            if (BF && a.out_bf16) {
+            if (LEAN) {
+              const bf16x8 pk = sty_pack_bf16(g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+              const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;
+              __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(uint4, pk).x & 0xffffu), r_g0, vst16, srow, 0);
+            } else if (BF && a.out_bf16) {
               const bf16x8 pk = sty_pack_bf16(hv * sc, g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
               const unsigned two = __builtin_bit_cast(uint4, pk).x;
               // row offset in the SCALAR offset (wave-uniform part of ch; the hi half of the wave is 4 rows further: in
@@ -258,9 +265,11 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
           }
           h[r] = g0;
         }
-        rsum = sty_half_sum_to_lane31(rsum);
-        if (l31 == 31) atomicAdd(&red[wave * 128 + ch], rsum);  // one writer per slot (the same lane in both passes): a
-                                                                 // ds_add_f32 instead of read / add / write
+        if constexpr (!(PASS == 2 && LEAN)) {
+          rsum = sty_half_sum_to_lane31(rsum);
+          if (l31 == 31) atomicAdd(&red[wave * 128 + ch], rsum);  // one writer per slot (the same lane in both passes): a
+                                                                   // ds_add_f32 instead of read / add / write
+        }
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the per-channel loads / store addresses of later
                                                               // rows from being hoisted (that cost 106 spilled VGPRs)
       }
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     }
   }
   __syncthreads();
-  if (tid < 128) {
+  if (tid < 128 && !(PASS == 2 && LEAN)) {
     const double s = (double)red[tid] + (double)red[128 + tid] + (double)red[256 + tid] + (double)red[384 + tid];
     // pass 1: ds partial; pass 2: d alpha partial
     a.part[((size_t)b * 128 + tid) * a.ntiles + blockIdx.x] = s;
@@ -374,6 +383,8 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext32_bwd_kernel<2, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = true;
   }
   dim3 grid(a.ntiles, B);
@@ -382,7 +393,8 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
   // h s, gH0 (128 each), xn, gU (32 each)
   const double flops = pos * (448.0 + 16384.0 + (pass == 2 ? 8192.0 : 0.0));
   // (h s and gH0 as bf16 in the bf16 mode: 2 x 128 x 2 bytes instead of 2 x 128 x 4)
-  const double bytes = pos * (4.0 * 64.0 + (pass == 2 ? 4.0 * 64.0 + (a.out_bf16 ? 2.0 : 4.0) * 256.0 : 0.0));
+  const bool lean = pass == 2 && a.bf16 && a.out_bf16 && a.lean;
+  const double bytes = pos * (4.0 * 64.0 + (pass == 2 ? 4.0 * 64.0 + (a.out_bf16 ? 2.0 : 4.0) * (lean ? 128.0 : 256.0) : 0.0));
   ProfScope prof(pass == 1 ? (a.bf16 ? "convnext32_bwd_kernel<1,true>" : "convnext32_bwd_kernel<1,false>")
                            : (a.bf16 ? "convnext32_bwd_kernel<2,true>" : "convnext32_bwd_kernel<2,false>"),
                  flops, bytes, st);
@@ -390,10 +402,113 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
     hipLaunchKernelGGL((convnext32_bwd_kernel<1, true>), grid, dim3(256), lds, st, a);
   else if (pass == 1)
     hipLaunchKernelGGL((convnext32_bwd_kernel<1, false>), grid, dim3(256), lds, st, a);
+  else if (lean)
+    hipLaunchKernelGGL((convnext32_bwd_kernel<2, true, true>), grid, dim3(256), lds, st, a);
   else if (a.bf16)
     hipLaunchKernelGGL((convnext32_bwd_kernel<2, true>), grid, dim3(256), lds, st, a);
   else
     hipLaunchKernelGGL((convnext32_bwd_kernel<2, false>), grid, dim3(256), lds, st, a);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// =====================================================================================================================
+// The lean backward (bf16 mode).  Two row sums over the whole utterance used to cost a kernel pass and a tenth of the
+// second one; both are diagonals of products the weight-gradient GEMMs compute anyway:
+//   ds[b,ch]   = sum_t U h,  U = W2^T gY        = sum_co W2[co,ch] M_b[co,ch],   M_b = gY_b h_b^T  (32 x 128 per utterance)
+//                -> pass 1 (GEMM-1 + U + Snake per element) becomes ONE bandwidth-bound GEMM over (gY fp32, h bf16 kept by
+//                   the forward: wgrad_cnx_kernel in its per-utterance mode), and the same M gives the weight gradient
+//                   dW2[co,ch] = sum_b s[b,ch] M_b[co,ch] -- the separate (h s, gY) GEMM and the h s output of pass 2 go away;
+//   d alpha[ch] = sum_t gH (z sin(2 a z) - sin^2(a z) / a) / a  =  (sum_t z gH0 - sum_t gH h) / a,   h = z + sin^2(a z) / a,
+//                gH0 = gH (1 + sin(2 a z)), and with z = W1 xn + b1, gH = U s + coef h:
+//                sum_t z gH0 = <W1[ch,:], dW1[ch,:]> + b1[ch] db1[ch],     sum_t gH h = s ds + coef sum_t h^2
+//                -> no per-element work at all: a 128-thread kernel after the dW1 GEMM.
+// The forward pays 256 bytes per position to keep h.  d alpha inherits the bf16 rounding of the dW1 GEMM's operands
+// (gH0, xn) instead of being summed from fp32 terms: the same error class as every weight gradient of the mode.
+// =====================================================================================================================
+__device__ __forceinline__ float cnx_bf16_round(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  return __builtin_bit_cast(float, (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+}
+// partial: [B * SB] planes of (128 ch x 32 co + 32 bias sums) floats from wgrad_cnx_kernel<true> in per-utterance mode.
+// One workgroup per (hidden channel, utterance): thread = (co, plane group of 8).  M_b[ch][co] = sum of the utterance's SB
+// planes (fixed order); ds[b][ch] = sum_co bf(W2[co][ch]) M_b; plane 0 of the utterance is OVERWRITTEN with s[b][ch] M_b (and
+// its bias slots with the utterance's bias sums), so that a plain slice reduction over the B utterances gives dW2 and db2.
+__global__ __launch_bounds__(256) void cnx_m_finish_kernel(float* __restrict__ partial, int SB, const float* __restrict__ w2raw,
+                                                           const float* __restrict__ scale, float* __restrict__ ds) {
+  __shared__ float acc_s[8][32];
+  const int ch = blockIdx.x, b = blockIdx.y, co = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const size_t stride = 4096 + 32;
+  float* base = partial + (size_t)b * SB * stride;
+  float mb = 0.f, bs = 0.f;
+  for (int s_ = sg; s_ < SB; s_ += 8) {
+    mb += base[(size_t)s_ * stride + ch * 32 + co];
+    if (ch == 0) bs += base[(size_t)s_ * stride + 4096 + co];
+  }
+  acc_s[sg][co] = mb;
+  __syncthreads();
+  if (sg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += acc_s[k][co];
+    float d = cnx_bf16_round(w2raw[(size_t)co * 128 + ch]) * t;  // U = bf(W2)^T bf(gY) in the kernels
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) d += __shfl_xor(d, o);  // over the 32 output channels (one half-wave)
+    if (co == 0) ds[(size_t)b * 128 + ch] = d;
+    base[ch * 32 + co] = scale[(size_t)b * 128 + ch] * t;
+  }
+  if (ch == 0) {  // (uniform per workgroup) bias gradient of pwconv2 = sum of gY: the planes' by-product
+    __syncthreads();
+    acc_s[sg][co] = bs;
+    __syncthreads();
+    if (sg == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += acc_s[k][co];
+      base[4096 + co] = t;
+    }
+  }
+}
+void launch_wgrad_reduce_planes(const float* partial, int nslices, size_t plane, size_t stride, int nb, float* gwp,
+                                float* gbias, hipStream_t st);  // wgrad.hip
+int launch_cnx_m_finish(float* partial, int B, int SB, const float* w2raw, const float* scale, float* ds, float* gw2,
+                        float* gb2, hipStream_t st) {
+  hipLaunchKernelGGL(cnx_m_finish_kernel, dim3(128, B), dim3(256), 0, st, partial, SB, w2raw, scale, ds);
+  if (gw2) launch_wgrad_reduce_planes(partial, B, 4096, (size_t)SB * (4096 + 32), gb2 ? 32 : 0, gw2, gb2, st);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// gw1: this block's packed dW1 [32 ci][128 ch], gb1 [128] (zero before the block's weight-gradient GEMM: each conv runs once
+// per step); part: the forward's GRN partials [B][128][nseg][2] (slot 1 = sum of h^2 of a tile)
+__global__ __launch_bounds__(256) void cnx_dalpha_kernel(const float* __restrict__ w1raw, const float* __restrict__ b1,
+                                                         const float* __restrict__ alpha, const float* __restrict__ gw1,
+                                                         const float* __restrict__ gb1, const float* __restrict__ scale,
+                                                         const float* __restrict__ ds, const float* __restrict__ coef,
+                                                         const double* __restrict__ part, int nseg, int B,
+                                                         float* __restrict__ dalpha) {
+  // one workgroup per hidden channel; the B x nseg tile sums of h^2 are spread over the threads (fixed order: deterministic)
+  __shared__ double red[4];
+  const int ch = blockIdx.x, tid = threadIdx.x;
+  double bt = 0.0;
+  for (int i = tid; i < B * nseg; i += 256) {
+    const int b = i / nseg, k = i - b * nseg;
+    bt += (double)coef[(size_t)b * 128 + ch] * part[(((size_t)b * 128 + ch) * nseg + k) * 2 + 1];
+  }
+  for (int b = tid; b < B; b += 256) bt += (double)scale[(size_t)b * 128 + ch] * (double)ds[(size_t)b * 128 + ch];
+  double a = 0.0;
+  if (tid < 32) a = (double)cnx_bf16_round(w1raw[(size_t)ch * 32 + tid]) * (double)gw1[tid * 128 + ch];
+  if (tid == 32) a = (double)b1[ch] * (double)gb1[ch];
+  double v = a - bt;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) dalpha[ch] += (float)((red[0] + red[1] + red[2] + red[3]) / (double)alpha[ch]);
+}
+int launch_cnx_dalpha(const float* w1raw, const float* b1, const float* alpha, const float* gw1, const float* gb1,
+                      const float* scale, const float* ds, const float* coef, const double* part, int nseg, int B,
+                      float* dalpha, hipStream_t st) {
+  hipLaunchKernelGGL(cnx_dalpha_kernel, dim3(128), dim3(256), 0, st, w1raw, b1, alpha, gw1, gb1, scale, ds, coef, part, nseg,
+                     B, dalpha);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -144,8 +144,9 @@ int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* p
 int wgrad_cnx_nsplit(int B, int T);
 int launch_conv_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* gwp, float* partial,
                           float* gbias, hipStream_t st);
+int wgrad_cnx_per_b(int B, int T);
 int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
-                     hipStream_t st);
+                     hipStream_t st, int per_b = 0);
 bool convp16_eligible(const ConvArgs& a);
 int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);
@@ -235,6 +236,8 @@ struct Cnx32Args {
   float* y;             // [B][32][T] (pass 2)
   int T, ntiles;
   int bf16 = 0;         // bf16 compute mode: both GEMMs on v_mfma_f32_32x32x16_bf16
+  void* h16 = nullptr;  // (pass 2, bf16 mode, training) the Snake output h as bf16 [B][128][T], kept for the backward:
+                        // operand of the per-utterance GEMM M = gY h^T that replaces its first pass (convnext_bwd.hip)
 };
 
 struct Cnx32BwdArgs {       // convnext_bwd.hip
@@ -255,7 +258,15 @@ struct Cnx32BwdArgs {       // convnext_bwd.hip
   int T, ntiles;
   int bf16 = 0;             // bf16 compute mode: the three GEMMs of a pass on v_mfma_f32_32x32x16_bf16
   int out_bf16 = 0;         // (pass 2, bf16 mode) hs and gh0 are written as bf16 [B][128][T]: operands of wgrad_cnx_kernel
+  int lean = 0;             // (pass 2, bf16 mode with out_bf16) h s is not written and d alpha is not accumulated: both come
+                            // from the weight-gradient GEMMs (launch_cnx_m_finish / launch_cnx_dalpha)
 };
+// The lean backward of the fused block (bf16 mode): see convnext_bwd.hip
+int launch_cnx_m_finish(float* partial, int B, int SB, const float* w2raw, const float* scale, float* ds, float* gw2,
+                        float* gb2, hipStream_t st);
+int launch_cnx_dalpha(const float* w1raw, const float* b1, const float* alpha, const float* gw1, const float* gb1,
+                      const float* scale, const float* ds, const float* coef, const double* part, int nseg, int B,
+                      float* dalpha, hipStream_t st);
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st);
 int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mode, float* out, hipStream_t st);
 

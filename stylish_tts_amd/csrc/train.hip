@@ -476,6 +476,10 @@ struct Trainer {
     double* part = take<double>((size_t)B * 128 * nt * 2);
     float* scale = take<float>((size_t)B * 128);
     float* y = take<float>(n32);
+    // bf16 mode: the forward keeps the Snake output h as bf16 for the lean backward (convnext_bwd.hip, end of file)
+    const bool lean = m->topts.compute_bf16 && Tt % 8 == 0 && getenv("STY_NO_WGRADB") == nullptr &&
+                      getenv("STY_NO_CNX_LEAN") == nullptr;
+    __bf16* h16 = lean ? take<__bf16>(n128) : nullptr;
     if (live()) {
       Cnx32Args a;
       a.x = x;
@@ -493,6 +497,7 @@ struct Trainer {
       a.T = Tt;
       a.ntiles = nt;
       a.bf16 = m->topts.compute_bf16;
+      a.h16 = h16;
       chk(launch_convnext32(a, B, 1, st));
       chk(launch_grn_finalize(part, nt, c.grn_gamma, B, 128, scale, st));
       chk(launch_convnext32(a, B, 2, st));
@@ -527,18 +532,21 @@ struct Trainer {
       }
       // operands of the side-stream launches live until the end of the step (one set per block; the main stream
       // never has to wait before reusing anything)
-      float* hs_p = side ? take<float>(n128) : nullptr;
-      float* gh0_p = side ? take<float>(n128) : nullptr;
+      float* hs_p = side && !lean ? take<float>(n128) : nullptr;
+      float* gh0_p = side ? take<float>(lean ? n128 / 2 : n128) : nullptr;
+      // (lean: read by the d alpha kernel behind the dW1 GEMM on the side stream)
+      float* ds_p = side && lean ? take<float>((size_t)B * 128) : nullptr;
+      float* coef_p = side && lean ? take<float>((size_t)B * 128) : nullptr;
       float* xn_p = side ? take<float>(n32) : nullptr;
       float* gu_p = side ? take<float>(n32) : nullptr;
       float* dsc_p = side ? take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7)) : nullptr;
       const size_t mark = ws.off;
       double* pds = take<double>((size_t)B * 128 * nt);
       double* pgb = take<double>((size_t)B * 64 * nt);
-      float* ds = take<float>((size_t)B * 128);
-      float* coef = take<float>((size_t)B * 128);
-      float* hs = side ? hs_p : take<float>(n128);
-      float* gh0 = side ? gh0_p : take<float>(n128);
+      float* ds = ds_p ? ds_p : take<float>((size_t)B * 128);
+      float* coef = coef_p ? coef_p : take<float>((size_t)B * 128);
+      float* hs = lean ? nullptr : (side ? hs_p : take<float>(n128));
+      float* gh0 = side ? gh0_p : take<float>(lean ? n128 / 2 : n128);
       float* xn = side ? xn_p : take<float>(n32);
       float* gu = side ? gu_p : take<float>(n32);
       Cnx32BwdArgs a;
@@ -572,18 +580,37 @@ struct Trainer {
       float* p2 = side ? side_partial : take<float>(wgrad_partial_floats(c.pw2, B, Tt));
       float* p1 = side ? side_partial : take<float>(wgrad_partial_floats(c.pw1, B, Tt));
       float* dsc = side ? dsc_p : take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7));
-      if (live()) {
-        chk(launch_convnext32_bwd(a, B, 1, st));
-        chk(launch_cnx_partial_sum(pds, B, 128, nt, 0, ds, st));
-        chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
-        chk(launch_convnext32_bwd(a, B, 2, st));
-        chk(launch_cnx_partial_sum(pds, B, 128, nt, 1, PG(c.alpha, 128), st));
-        chk(launch_cnx_partial_sum(pgb, B, 64, nt, 2, dgl, st));
-      }
       float* gw2 = PGpacked(c.pw2.wp);
       float* gb2 = PGpacked(c.pw2.bias);
       float* gw1 = PGpacked(c.pw1.wp);
       float* gb1 = PGpacked(c.pw1.bias);
+      const bool frozen = m->topts.frozen;
+      float* dal = PG(c.alpha, 128);
+      if (lean) {
+        // ds and dW2 from the per-utterance GEMM M_b = gY_b h_b^T, d alpha from dW1 (no first pass, no h s)
+        const int SB = wgrad_cnx_per_b(B, Tt);
+        float* pM = take<float>((size_t)B * SB * (4096 + 32));
+        a.lean = 1;
+        if (live()) {
+          chk(launch_wgrad_cnx(1, h16, gY, B, Tt, pM, 1, st, 1));
+          chk(launch_cnx_m_finish(pM, B, SB, c.w2_raw, scale, ds, frozen ? nullptr : gw2, frozen ? nullptr : gb2, st));
+          chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
+          chk(launch_convnext32_bwd(a, B, 2, st));
+          chk(launch_cnx_partial_sum(pgb, B, 64, nt, 2, dgl, st));
+        }
+      } else if (live()) {
+        chk(launch_convnext32_bwd(a, B, 1, st));
+        chk(launch_cnx_partial_sum(pds, B, 128, nt, 0, ds, st));
+        chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
+        chk(launch_convnext32_bwd(a, B, 2, st));
+        chk(launch_cnx_partial_sum(pds, B, 128, nt, 1, dal, st));
+        chk(launch_cnx_partial_sum(pgb, B, 64, nt, 2, dgl, st));
+      }
+      const float *w1r = c.w1_raw, *b1p = c.b1, *alp = c.alpha;
+      auto lean_w1 = [=](hipStream_t s_) {  // dW1 (+ db1) from (gH0, xn), then d alpha from it
+        chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, s_));
+        chk(launch_cnx_dalpha(w1r, b1p, alp, gw1, gb1, scale, ds, coef, part, nt, B, dal, s_));
+      };
       float* gdw = PG(c.dw_w, 32 * 7);
       float* gdb = PG(c.dw_b, 32);
       const float* dww = c.dw_w;
@@ -591,7 +618,9 @@ struct Trainer {
         if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
       } else if (side) {
         side_push(gY, [=](hipStream_t s2) {
-          if (cnx16) {
+          if (lean) {
+            lean_w1(s2);
+          } else if (cnx16) {
             chk(launch_conv_wgrad_cnx(1, hs, gY, B, Tt, gw2, p2, gb2, s2));
             chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, s2));
           } else {
@@ -604,7 +633,10 @@ struct Trainer {
         if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
       } else if (live()) {
         bool done = false;
-        if (cnx16) {
+        if (lean) {
+          chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, st));
+          chk(launch_cnx_dalpha(w1r, b1p, alp, gw1, gb1, scale, ds, coef, part, nt, B, dal, st));
+        } else if (cnx16) {
           chk(launch_conv_wgrad_cnx(1, hs, gY, B, Tt, gw2, p2, gb2, st));
           chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, st));
         } else {

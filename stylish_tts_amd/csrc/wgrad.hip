@@ -687,6 +687,11 @@ static void launch_wgrad_reduce(const float* partial, int nslices, size_t plane,
                        plane, stride, nb, scale, gwp, gbias);
 }
 
+void launch_wgrad_reduce_planes(const float* partial, int nslices, size_t plane, size_t stride, int nb, float* gwp,
+                                float* gbias, hipStream_t st) {
+  launch_wgrad_reduce(partial, nslices, plane, stride, nb, 1.0f, gwp, gbias, st);
+}
+
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x output rows in 2-D mode
   if (w.K == 1) return (size_t)w1_nsplit(w, B, T, w1_cfg(w, B, T)) * ((size_t)w.CinP * w.CoutP + w.CoutP);
   size_t n64 = 0;

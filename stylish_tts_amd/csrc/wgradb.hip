@@ -737,9 +737,11 @@ namespace sty {
 // T % 8 == 0 (the caller checks): an 8-sample group is inside the row or past its end, never across.
 // =====================================================================================================================
 template <bool XWIDE>  // XWIDE: x is the bf16 [B][128][T] tensor and G the fp32 [B][32][T] one; else the other way round
+// SB > 0: per-utterance mode -- workgroup z handles utterance z / SB only (chunks z % SB, z % SB + SB, ...), so that the SB
+// partial planes of an utterance sum to ITS 128 x 32 product (the lean ConvNeXt32 backward needs M_b = gY_b h_b^T per b).
 __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restrict__ wide, const float* __restrict__ narrow,
                                                            int B, int T, int nsplit, int chunks_per_b,
-                                                           float* __restrict__ partial, int want_bias) {
+                                                           float* __restrict__ partial, int want_bias, int SB) {
   extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
   constexpr int TW = 128;
   __bf16* ws_ = wb_lds;                    // [128][WB_PITCH]
@@ -756,8 +758,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
   for (int m = 0; m < 8; ++m) bsum[m] = 0.f;
   float4 wv[8];     // wide: 8 rows x 8 bf16
   float nv[2][8];   // narrow: 2 rows x 8 fp32
-  const int total = B * chunks_per_b;
-  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+  const int total = SB ? chunks_per_b : B * chunks_per_b, step = SB ? SB : nsplit;
+  int cb = SB ? split / SB : split / chunks_per_b, cc_ = SB ? split - cb * SB : split - cb * chunks_per_b;
   auto load_chunk = [&](int b, int c) {
     const int t = c * TW + g8;
     const bool in = t < T;
@@ -772,15 +774,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
     for (int m = 0; m < 2; ++m) wb_load8(rn, in ? ((r0 + 16 * m) * T + t) * 4 : WB_OOB, nv[m]);
   };
   auto advance = [&](int& b, int& c) {
-    c += nsplit;
+    c += step;
+    if (SB) return;
     while (c >= chunks_per_b) {
       c -= chunks_per_b;
       ++b;
     }
   };
-  int ch = split;
+  int ch = SB ? cc_ : split;
   if (ch < total) load_chunk(cb, cc_);
-  for (; ch < total; ch += nsplit) {
+  for (; ch < total; ch += step) {
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
     }
     __syncthreads();
     advance(cb, cc_);
-    if (ch + nsplit < total) load_chunk(cb, cc_);
+    if (ch + step < total) load_chunk(cb, cc_);
     const __bf16* wr = ws_ + (wave * 32 + l31) * WB_PITCH + 8 * hi;
     const __bf16* nr = ns_ + l31 * WB_PITCH + 8 * hi;
 #pragma unroll
@@ -844,22 +847,28 @@ int wgrad_cnx_nsplit(int B, int T) {
 }
 // x_wide != 0: dW [128 ci][32 co] from x = wide (bf16 [B][128][T]), G = narrow (fp32 [B][32][T]); else dW [32 ci][128 co] from
 // x = narrow, G = wide.  partial: nsplit planes of (4096 + CoutP) floats.
+int wgrad_cnx_per_b(int B, int T) {  // planes per utterance in the per-utterance mode: ~1024 workgroups in all
+  const int cpb = cdiv(T, 128);
+  int sb = cdiv(1024, B);
+  return sb < cpb ? sb : cpb;
+}
 int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
-                     hipStream_t st) {
+                     hipStream_t st, int per_b) {
   if (T % 8) {
     set_error("wgrad_cnx: T %% 8 != 0");
     return STY_EINVAL;
   }
-  const int nsplit = wgrad_cnx_nsplit(B, T), cpb = cdiv(T, 128);
+  const int SB = per_b ? wgrad_cnx_per_b(B, T) : 0;
+  const int nsplit = per_b ? B * SB : wgrad_cnx_nsplit(B, T), cpb = cdiv(T, 128);
   const size_t lds = (size_t)160 * WB_PITCH * sizeof(__bf16);
   ProfScope prof(x_wide ? "wgrad_cnx_kernel<true>" : "wgrad_cnx_kernel<false>", 2.0 * 128 * 32 * (double)B * T,
                  (double)B * T * (128 * 2 + 32 * 4), st);
   if (x_wide)
     hipLaunchKernelGGL(wgrad_cnx_kernel<true>, dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide), narrow, B,
-                       T, nsplit, cpb, partial, want_bias);
+                       T, nsplit, cpb, partial, want_bias, SB);
   else
     hipLaunchKernelGGL(wgrad_cnx_kernel<false>, dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide), narrow, B,
-                       T, nsplit, cpb, partial, want_bias);
+                       T, nsplit, cpb, partial, want_bias, SB);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

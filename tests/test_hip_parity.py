@@ -269,6 +269,8 @@ def test_block_backward_vs_float64_oracle(env, kind, prefix, C, T):
 
 @pytest.mark.parametrize("kind,prefix,C,T", [
     ("convnext", "generator.basegen.phase_convnext.3", 32, 777),   # fused convnext32_kernel / _bwd_kernel<*,true>, wgrad_cnx
+    ("convnext", "generator.basegen.phase_convnext.5", 32, 1032),  # T % 8 == 0: the LEAN backward (h kept as bf16, ds / dW2
+    ("convnext", "generator.basegen.upblocks.2", 32, 520),         # from M = gY h^T, d alpha from dW1; convnext_bwd.hip)
     ("convnext", "generator.basegen.upblocks.2", 32, 1031),
     ("convnext", "generator.basegen.amp_convnext.2", 256, 120),    # generic plan: pointwise convs on the bf16 conv kernels
     ("resblock", "generator.basegen.amp_prior_block", 32, 700),    # conv32p_kernel<true>, wgradp32_kernel
@@ -310,6 +312,11 @@ def test_block_bf16_mode_vs_float64_oracle_on_rounded_operands(env, kind, prefix
     # a Snake whose 7th-digit differences re-round their inputs -- the flips compound (its single convs are pinned at the
     # fp32 tolerance by test_persistent_conv32_vs_torch)
     tol = 1e-3 if kind == "convnext" else 6e-3
+    if kind == "convnext" and C == 32 and T % 8 == 0:
+        # the lean backward takes ds and dW2 from M = bf(gY) bf(h)^T -- h rounded BEFORE the GRN scale where the forward's GEMM
+        # rounded h s, and where the two-pass kernel summed U h with h in fp32 -- and d alpha from the bf16-operand dW1 GEMM:
+        # rounding points one factor earlier, 2^-9 per product, the error class of every weight gradient of the mode
+        tol = 6e-3
     rep.add("y", y, y64.detach().float(), tol)
     rep.add("d x", gx, x64.grad.float(), tol)
     rep.add("d style", d_style, s64.grad.float(), tol)
