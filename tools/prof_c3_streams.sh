@@ -1,0 +1,10 @@
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=2
+rm -rf /tmp/prof_q
+rocprofv3 --kernel-trace --stats -d /tmp/prof_q -- python $R/bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 2 > /tmp/prof_q.json 2> /tmp/prof_q.log
+DB=$(find /tmp/prof_q -name "*_results.db" | head -1)
+cd $R
+python tools/step_gaps.py $DB 6 150 > gpurun_out/c3_gaps.txt
+python tools/stream_busy.py $DB 6 > gpurun_out/c3_streams.txt
+python tools/rocpd_summary.py $DB > gpurun_out/prof_c3.txt
