@@ -750,9 +750,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
             hi = lane >> 5;
   const int split = blockIdx.z;
   const int g8 = (tid & 15) * 8, r0 = tid >> 4;  // group, first row (rows r0 + 16 m)
-  f32x16 acc;
+  f32x16 acc, accb;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = accb[r] = 0.f;
+  const bf16x8 ones = sty_pack_bf16(1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f);
   float bsum[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) bsum[m] = 0.f;
@@ -788,13 +789,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       *reinterpret_cast<float4*>(ws_ + (r0 + 16 * m) * WB_PITCH + g8) = wv[m];
-      if (!XWIDE && want_bias) {  // bias of the wide G: sum of its (bf16) samples
-        const bf16x8 q = __builtin_bit_cast(bf16x8, wv[m]);
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)q[e];
-        bsum[m] += s;
-      }
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -814,6 +808,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
       // A = G rows (co), B = x rows (ci)
       acc = XWIDE ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(nf, wf, acc, 0, 0, 0)
                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, nf, acc, 0, 0, 0);
+      // bias of the wide G = the row sums of its (bf16) samples: one more MFMA against a fragment of ones (every column of
+      // the product holds them) instead of 8 conversions + 8 additions per thread and row: that scalar sum was what
+      // paced this otherwise bandwidth-bound kernel (242 us per launch in a c3 step against 120 for its twin)
+      if (!XWIDE && want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, ones, accb, 0, 0, 0);
     }
   }
   const int CinP = XWIDE ? 128 : 32, CoutP = XWIDE ? 32 : 128;
@@ -826,7 +824,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
     const int co = XWIDE ? mrow : wave * 32 + mrow;
     pp[(size_t)ci * CoutP + co] = acc[r];
   }
-  if (want_bias) {
+  if (want_bias && !XWIDE) {  // accb[r] = sum over the chunks' samples of G row (wave * 32 + mrow): any column; take lane 0 / 32
+    float* pb = pp + plane;
+    if (l31 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pb[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = accb[r];
+    }
+  } else if (want_bias) {
     float* pb = pp + plane;
     constexpr int NB = XWIDE ? 2 : 8;
 #pragma unroll
