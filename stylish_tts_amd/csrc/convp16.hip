@@ -77,6 +77,7 @@ struct QPos {
                     // by whole image rows)
   int cc, tsh;      // flat 2-D: source channel of the first row, its shift in samples
   int abase;        // byte offset of fragment (chunk, j = 0, this tile's first 32-cout block) in the fragment buffer
+  __amdgpu_buffer_rsrc_t rs;  // descriptor of the tile's batch slab (rebuilt once per tile, not once per chunk step)
 };
 
 template <bool FLAT>
@@ -86,6 +87,8 @@ __device__ __forceinline__ void q_pos_tile(const ConvArgs& a, QPos& p, int rg, i
   p.tsh = FLAT ? -a.hpad * a.flatW : 0;
   p.roff = (p.cc * a.T + p.tsh) * 4;
   p.abase = p.cot * CO32 * 1024;
+  const int crow = FLAT ? a.Cin2d : a.w.Cin;  // rows of one batch slab: rows past it are outside the descriptor and load 0
+  p.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x[0] + (size_t)p.b * crow * a.T), 0, crow * a.T * 4, 0x00020000);
 }
 template <bool FLAT>
 __device__ __forceinline__ void q_pos_next(const ConvArgs& a, QPos& p, int nch, int tiles_per_row, int ncot, int rg, int CO32,
@@ -129,9 +132,7 @@ struct QConst {
 template <int PRO, bool FLAT, int NFRAG>
 __device__ __forceinline__ void q_issue(const ConvArgs& a, const QPos& p, const QConst<NFRAG>& k, int lane, QSet<NFRAG>& R) {
   const int T = a.T;
-  const int crow = FLAT ? a.Cin2d : a.w.Cin;  // rows of one batch slab: rows past it are outside the descriptor and load 0
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x[0] + (size_t)p.b * crow * T), 0, crow * T * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = p.rs;
   // The whole offset goes into the VECTOR offset: the hardware range-checks that one only, not the scalar soffset.
   const int v0 = k.vcol + (p.t0 - a.pad) * 4 + p.roff;
   // (a dead column group -- the third one of a K = 1 conv -- issues nothing: even loads that fall outside the descriptor
@@ -265,7 +266,9 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
 }
 
 template <int MTW, int PRO, int RELU, bool FLAT>
-__global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles, int dbg) {
+__global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles, int dbg_) {
+  constexpr int dbg = 0;  // (the STY_Q_DBG phase switches of round 2 cost scalar instructions in every wave and step)
+  (void)dbg_;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CO32 = 2 * MTW;
   constexpr int NFRAG = 2;  // A fragments per producer wave and chunk: K 2 CO32 <= 24 over 12 waves
@@ -358,26 +361,30 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     int ti = 0, c = 0;
     QTile cur_tl = q_tile(first, tiles_per_row, ncot), prev_tl = cur_tl;
     int cur_tile = first;
-    for (int step = 0; step < nsteps; ++step) {
-      // the previous tile's output stage (written at the end of its last step) is drained in ndr parts, done before this
-      // tile's last step, at whose end the consumers write the stage again
-      if (ti > 0 && c < ndr && !(dbg & 8)) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane, c, ndr);
-      if (ncommit < nchunks) {  // the chunk the consumers need in the NEXT step; chunk n lives in register set n & 1
-        if (ncommit & 1) {      // (copying a set would wait for its loads in flight)
-          STY_Q_STEP(R1)
-        } else {
-          STY_Q_STEP(R0)
-        }
-      }
-      if (++c == nch) {  // next tile
-        c = 0;
-        ++ti;
-        prev_tl = cur_tl;
-        cur_tile += tstride;
-        cur_tl = q_tile(cur_tile, tiles_per_row, ncot);
-      }
-      __syncthreads();
+    // One step: the previous tile's output stage (written at the end of its last step) is drained in ndr parts, done before
+    // this tile's last step, at whose end the consumers write the stage again; then the chunk the consumers need in the
+    // NEXT step is committed from its register set and the chunk two ahead requested into the same set.  Chunk n lives in
+    // set n & 1 and step s commits chunk s + 1, so the loop is unrolled by two with the set fixed at compile time: a
+    // run-time choice made hipcc merge the two sets through copies (sixteen v_mov_b64 and a full vmcnt(0) per step).
+#define STY_Q_BODY(R)                                                                                  \
+  {                                                                                                    \
+    if (ti > 0 && c < ndr) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane, c, ndr);                      \
+    if (ncommit < nchunks) STY_Q_STEP(R)                                                               \
+    if (++c == nch) { /* next tile */                                                                  \
+      c = 0;                                                                                           \
+      ++ti;                                                                                            \
+      prev_tl = cur_tl;                                                                                \
+      cur_tile += tstride;                                                                             \
+      cur_tl = q_tile(cur_tile, tiles_per_row, ncot);                                                  \
+    }                                                                                                  \
+    __syncthreads();                                                                                   \
+  }
+    for (int step = 0; step < nsteps; step += 2) {
+      STY_Q_BODY(R1)
+      if (step + 1 >= nsteps) break;
+      STY_Q_BODY(R0)
     }
+#undef STY_Q_BODY
     if (!(dbg & 8)) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane, 0, 1);  // the last tile
 #undef STY_Q_STEP
 #undef STY_Q_ISSUE
