@@ -430,6 +430,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     set_error("conv1d: output statistics requested for a conv the persistent 32-channel kernel does not take");
     return STY_EINVAL;
   }
+  if (convk1_eligible(a)) return launch_convk1(a, st);
   if (convp16_eligible(a)) return launch_convp16(a, st);
   // tuning aid: STY_CONV_CFG=0..5 forces one tile configuration (when the shape allows it)
   static const int forced = getenv("STY_CONV_CFG") ? atoi(getenv("STY_CONV_CFG")) : -1;

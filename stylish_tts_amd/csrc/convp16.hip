@@ -593,6 +593,8 @@ static int launch_q_pro(const ConvArgs& a, hipStream_t st) {
   return relu ? launch_q<1, PRO, 1>(a, st) : launch_q<1, PRO, 0>(a, st);
 }
 
+int convp16_frags(const ConvArgs& a, hipStream_t st, const void** out) { return q_frags(a, st, out); }  // (convk1.hip)
+
 int launch_convp16(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   int rc = q_frags(a0, st, &a.w.wf);

@@ -147,6 +147,8 @@ int launch_conv_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int
 int wgrad_cnx_per_b(int B, int T);
 int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
                      hipStream_t st, int per_b = 0);
+bool convk1_eligible(const ConvArgs& a);  // convk1.hip: K = 1 as a plain GEMM (transposing LDS reads)
+int launch_convk1(const ConvArgs& a, hipStream_t st);
 bool convp16_eligible(const ConvArgs& a);
 int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);

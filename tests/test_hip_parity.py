@@ -1202,6 +1202,28 @@ def test_persistent_conv16_vs_torch(shape, monkeypatch):
     assert sum(r["launches"] for r in rows if r["name"].startswith("convp16_kernel")) >= 1, rows
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 130, 1, 1, 64), (2, 256, 1024, 1, 1, 520), (2, 1024, 256, 1, 1, 132), (5, 320, 96, 1, 1, 1000),
+                                   (40, 64, 512, 1, 1, 520)])
+def test_pointwise_gemm_kernel_vs_torch(shape, monkeypatch):
+    """convk1_kernel (bf16 compute mode, K = 1: a plain GEMM whose B operands come out of LDS through the transposing read
+    ds_read_b64_tr_b16, 16-byte loads of the [B][C][T] activations) through the unit entry points: forward and input
+    gradient vs float64 on the same bf16-rounded operands -- Cin / Cout that are not multiples of the 64-channel chunk or
+    the 128-row tile, T that is not a multiple of the 128-column tile, the last shape big enough to take the kernel by
+    itself."""
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    if shape[0] < 40:
+        monkeypatch.setenv("STY_CONVK1_MIN_TILES", "1")
+    L.prof_report(256)
+    lib.sty_prof_enable(1)
+    try:
+        test_dense_conv1d_vs_torch(shape, "bf16")
+    finally:
+        lib.sty_prof_enable(0)
+    rows = L.prof_report(256)
+    assert sum(r["launches"] for r in rows if r["name"].startswith("convk1_kernel")) >= 1, [r["name"] for r in rows]
+
+
 def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monkeypatch):
     """The bf16 compute mode with the persistent kernels forced on at the small test size (conv32p, convp16: flat 2-D
     style-encoder convs with masks and residuals, LeakyReLU / AdaIN prologues, ReLU, decoder and vocoder convs, forward
