@@ -431,6 +431,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     return STY_EINVAL;
   }
   if (convk1_eligible(a)) return launch_convk1(a, st);
+  if (convk3_eligible(a)) return launch_convk3(a, st);
   if (convp16_eligible(a)) return launch_convp16(a, st);
   // tuning aid: STY_CONV_CFG=0..5 forces one tile configuration (when the shape allows it)
   static const int forced = getenv("STY_CONV_CFG") ? atoi(getenv("STY_CONV_CFG")) : -1;

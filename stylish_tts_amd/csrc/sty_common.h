@@ -149,6 +149,8 @@ int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, i
                      hipStream_t st, int per_b = 0);
 bool convk1_eligible(const ConvArgs& a);  // convk1.hip: K = 1 as a plain GEMM (transposing LDS reads)
 int launch_convk1(const ConvArgs& a, hipStream_t st);
+bool convk3_eligible(const ConvArgs& a);  // convk3.hip: K = 3 on the same data path (three shifted LDS images)
+int launch_convk3(const ConvArgs& a, hipStream_t st);
 bool convp16_eligible(const ConvArgs& a);
 int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);
