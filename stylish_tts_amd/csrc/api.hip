@@ -1435,7 +1435,7 @@ void sty_model_destroy(sty_model* m) {
   if (m->stft_default) (void)hipFree(m->stft_default);
   if (m->garena) (void)hipFree(m->garena);
   if (m->fcs_bwd_dev) (void)hipFree(m->fcs_bwd_dev);
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if (m->mj_dev[i]) (void)hipFree(m->mj_dev[i]);
     if (m->mj_blk_dev[i]) (void)hipFree(m->mj_blk_dev[i]);
   }
@@ -1586,17 +1586,7 @@ static int unpack_grads(sty_model* m, hipStream_t st, int seg = -1) {
     if (j.kind == PK_CONV || j.kind == PK_CONV_WN) {
       // batched above
     } else if (j.kind == PK_CONV2D_SN) {
-      float* dW = PG(j.w);
-      if (dW) {  // the gradient-arena twin of the sigma scratch holds the <G, W> row sums
-        int r = launch_sn_unpack(GA(j.wp), j.w, j.g, j.v, j.scratch, j.Cout, j.Cin, j.KH, j.K, j.CinP, j.CoutP,
-                                 GA(j.scratch), dW, st);
-        if (r) return r;
-      }
-      float* db = (j.bias && j.bp) ? PG(j.bias) : nullptr;
-      if (db) {
-        int r = launch_axpy(GA(j.bp), 1.0f, db, (size_t)j.Cout, st);
-        if (r) return r;
-      }
+      // batched below (table 3)
     } else if (j.kind == PK_DW2D_SN) {
       float* dW = PG(j.w);
       if (dW) {
@@ -1611,6 +1601,10 @@ static int unpack_grads(sty_model* m, hipStream_t st, int seg = -1) {
       int r = launch_b2eff_bwd(GA(j.bp), j.w, j.extra, j.Cout, db2, dbeta, dW2, st);
       if (r) return r;
     }
+  }
+  if (seg != 1) {  // every spectral-norm conv (weights and biases) in two launches; no model has them in segment 1
+    int r = launch_sn_unpack_multi(m->mj_dev[3], m->mj_blk_dev[3], m->mj_nblk[3], st);
+    if (r != STY_OK) return r;
   }
   if (m->kind == "speech_predictor" && m->dec.fnv_w && seg != 1) {
     const DecoderPlan& d = m->dec;
@@ -1754,8 +1748,8 @@ const char* sty_model_key(const sty_model* m, int i) {
 
 // device tables for the batched pack / input-gradient pack / gradient un-pack launches
 static int build_multi_tables(sty_model* m) {
-  std::vector<MultiJob> jobs[3];
-  std::vector<int> blk[3];
+  std::vector<MultiJob> jobs[4];
+  std::vector<int> blk[4];
   auto PG = [&](const float* p) -> float* {
     auto it = p ? m->pgrad.find(p) : m->pgrad.end();
     return it == m->pgrad.end() ? nullptr : it->second;
@@ -1813,9 +1807,27 @@ static int build_multi_tables(sty_model* m) {
       a.CinP = j.CinP;
       a.CoutP = j.CoutP;
       add(1, a, (int)(((size_t)j.K * j.CinP * j.CoutP + 255) / 256));
+    } else if (j.kind == PK_CONV2D_SN && m->garena) {
+      MultiJob u;  // sn_unpack_multi_kernel
+      u.p0 = GA(j.wp);
+      u.p1 = j.w;
+      u.p2 = j.g;
+      u.p3 = j.v;
+      u.p4 = j.scratch;
+      u.q0 = PG(j.w);
+      u.q1 = GA(j.scratch);  // the gradient-arena twin of the sigma scratch holds the <G, W> row sums
+      u.q3 = (j.bias && j.bp) ? PG(j.bias) : nullptr;
+      u.q4 = (j.bias && j.bp) ? GA(j.bp) : nullptr;
+      u.Cout = j.Cout;
+      u.Cin = j.Cin;
+      u.K = j.K;
+      u.KH = j.KH;
+      u.CinP = j.CinP;
+      u.CoutP = j.CoutP;
+      if (u.q0 || u.q3) add(3, u, j.Cout);
     }
   }
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if (m->mj_dev[i]) (void)hipFree(m->mj_dev[i]);
     if (m->mj_blk_dev[i]) (void)hipFree(m->mj_blk_dev[i]);
     m->mj_dev[i] = nullptr;

@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void pro_bwd_kernel(int mode_, const float* __
 int launch_pro_bwd(int mode, const float* u, int Cu, int cu0, const float* x, int B, int C, int T, const float* pa,
                    const float* ps, int pC, int pc0, const float* alpha, const float* mask, float* dx, int accumulate,
                    float* dpa, float* dps, float* dalpha, hipStream_t st) {
+  char detail[40];
+  snprintf(detail, sizeof(detail), "m%d C%d T%d acc%d", mode & 0xff, C, T, accumulate);
+  const double n = (double)B * C * T;
+  ProfScope prof("pro_bwd_kernel", 0.0, 4.0 * n * (accumulate ? 4.0 : 3.0), st, detail);
   hipLaunchKernelGGL(pro_bwd_kernel, dim3(C, B), dim3(256), 0, st, mode, u, Cu, cu0, x, C, T, pa, ps, pC, pc0, alpha,
                      mask, dx, accumulate, dpa, dps, dalpha);
   STY_LAUNCH_CHECK();

@@ -229,32 +229,45 @@ int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y,
 
 // AdaptiveAvgPool2d(1) -> LeakyReLU(0.2) -> Linear (mel_style_encoder.py:140-152): x [B][C][n] (positions outside the
 // valid region are zero) -> s [B][S]; the mean divides by `count` valid positions
-__global__ __launch_bounds__(256) void pool_fc_kernel(const float* __restrict__ x, int C, int n, float inv_count,
-                                                      const float* __restrict__ W, const float* __restrict__ bvec,
-                                                      int S, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void pool_fc_kernel(const float* __restrict__ x, int C, int n, float inv_count,
+                                                       const float* __restrict__ W, const float* __restrict__ bvec,
+                                                       int S, float* __restrict__ out) {
   extern __shared__ float pooled[];  // [C]
+  // one workgroup of 16 waves per utterance (the output needs every channel's mean); a wave takes two channel rows at a
+  // time so that their loads overlap -- with 4 waves and one row at a time this was a chain of 96 load latencies, 0.3 ms
   const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = wave; c < C; c += 4) {
-    const float* p = x + ((size_t)b * C + c) * n;
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += p[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int c = 2 * wave; c < C; c += 2 * nw) {
+    const float* p0 = x + ((size_t)b * C + c) * n;
+    const bool two = c + 1 < C;
+    const float* p1 = two ? p0 + n : p0;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      s0 += p0[i];
+      s1 += p1[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      s0 += __shfl_xor(s0, o);
+      s1 += __shfl_xor(s1, o);
+    }
     if (lane == 0) {
-      const float m = s * inv_count;
-      pooled[c] = m > 0.f ? m : 0.2f * m;
+      const float m0 = s0 * inv_count, m1 = s1 * inv_count;
+      pooled[c] = m0 > 0.f ? m0 : 0.2f * m0;
+      if (two) pooled[c + 1] = m1 > 0.f ? m1 : 0.2f * m1;
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < S; j += 256) {
-    float acc = bvec[j];
-    for (int c = 0; c < C; ++c) acc = fmaf(W[(size_t)j * C + c], pooled[c], acc);
-    out[(size_t)b * S + j] = acc;
+  // out[j] = bias + sum_c W[j][c] pooled[c]: one wave per output, lanes over c, summed in a fixed order
+  for (int j = wave; j < S; j += nw) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(W[(size_t)j * C + c], pooled[c], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[(size_t)b * S + j] = acc + bvec[j];
   }
 }
 int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* W, const float* bvec, int S, float* out,
                    hipStream_t st) {
-  hipLaunchKernelGGL(pool_fc_kernel, dim3(B), dim3(256), C * sizeof(float), st, x, C, n, 1.0f / (float)count, W, bvec, S,
+  hipLaunchKernelGGL(pool_fc_kernel, dim3(B), dim3(1024), C * sizeof(float), st, x, C, n, 1.0f / (float)count, W, bvec, S,
                      out);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -449,37 +462,33 @@ __global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restric
                                                           float inv_count, const float* __restrict__ W, int S,
                                                           const float* __restrict__ gs, float* __restrict__ dW,
                                                           float* __restrict__ db, float* __restrict__ dx) {
-  extern __shared__ float sh[];  // pooled[C] (pre-activation mean), gp[C]
-  float* pooled = sh;
-  float* gp = sh + C;
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = wave; c < C; c += 4) {
-    const float* p = x + ((size_t)b * C + c) * n;
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += p[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) pooled[c] = s * inv_count;
+  // one wave per (b, c) row, grid (C / 4, B): the first version ran one workgroup per utterance over all C * n elements
+  // (32 workgroups on 256 CUs, 0.7 ms at the head of the style encoder's backward, which is the tail of the c3 step)
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const float* p = x + ((size_t)b * C + c) * n;
+  float s = 0.f;
+  for (int i = lane; i < n; i += 64) s += p[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float pooled = s * inv_count;  // pre-activation mean
+  const float* g = gs + (size_t)b * S;
+  float acc = 0.f;
+  for (int j = lane; j < S; j += 64) acc = fmaf(W[(size_t)j * C + c], g[j], acc);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  const float gp = acc * (pooled > 0.f ? 1.f : 0.2f) * inv_count;
+  float* d = dx + ((size_t)b * C + c) * n;
+  for (int i = lane; i < n; i += 64) d[i] += gp;
+  const float a = pooled > 0.f ? pooled : 0.2f * pooled;
+  for (int j = lane; j < S; j += 64) {
+    atomicAdd(&dW[(size_t)j * C + c], g[j] * a);
+    if (c == 0) atomicAdd(&db[j], g[j]);
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float acc = 0.f;
-    for (int j = 0; j < S; ++j) acc = fmaf(W[(size_t)j * C + c], gs[(size_t)b * S + j], acc);
-    gp[c] = acc * (pooled[c] > 0.f ? 1.f : 0.2f) * inv_count;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C * n; i += 256) dx[(size_t)b * C * n + i] += gp[i / n];
-  for (int i = threadIdx.x; i < S * C; i += 256) {
-    const int j = i / C, c = i % C;
-    const float a = pooled[c] > 0.f ? pooled[c] : 0.2f * pooled[c];
-    atomicAdd(&dW[i], gs[(size_t)b * S + j] * a);
-  }
-  for (int j = threadIdx.x; j < S; j += 256) atomicAdd(&db[j], gs[(size_t)b * S + j]);
 }
 int launch_pool_fc_bwd(const float* x, int B, int C, int n, int count, const float* W, int S, const float* gs,
                        float* dW, float* db, float* dx, hipStream_t st) {
-  hipLaunchKernelGGL(pool_fc_bwd_kernel, dim3(B), dim3(256), 2 * C * sizeof(float), st, x, B, C, n,
-                     1.0f / (float)count, W, S, gs, dW, db, dx);
+  hipLaunchKernelGGL(pool_fc_bwd_kernel, dim3(cdiv(C, 4), B), dim3(256), 0, st, x, B, C, n, 1.0f / (float)count, W, S, gs,
+                     dW, db, dx);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -244,9 +244,9 @@ struct sty_model {
   std::unordered_map<const float*, sty::PackedConv> plain_of;   // GLU-ordered packed conv -> plain-ordered copy
   void* fcs_bwd_dev = nullptr;
   // batched weight-side launches: device tables [0] pack, [1] input-gradient pack, [2] gradient un-pack
-  sty::MultiJob* mj_dev[3] = {nullptr, nullptr, nullptr};
-  int* mj_blk_dev[3] = {nullptr, nullptr, nullptr};
-  int mj_nblk[3] = {0, 0, 0};
+  sty::MultiJob* mj_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* mj_blk_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int mj_nblk[4] = {0, 0, 0, 0};  // 0 pack, 1 input-gradient pack, 2 gradient un-pack, 3 spectral-norm gradient un-pack
   bool mj_ready = false;
   // gradient segments (data-parallel overlap): pack jobs [0, seg_job_split) belong to the module that runs its backward
   // LAST (the text encoder of a speech predictor); the un-pack table splits at block seg_blk_split.  Segment 0 = every
@@ -323,8 +323,6 @@ int launch_fnv_unpack(const float* dw34, const float* g0, const float* v0, const
                       float* db1, float* dg2, float* dv2, float* db2, hipStream_t st);
 int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int CinP, int CoutP, int CinPd, int CoutPd,
                         float* wd, hipStream_t st);
-int launch_sn_unpack(const float* gwp, const float* w, const float* u, const float* v, const float* t, int Cout,
-                     int Cin, int KH, int KW, int CinP, int CoutP, float* gw_scratch, float* dW, hipStream_t st);
 size_t dwconv2d_s2_bwd_scratch_floats(int B, int C);
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int B, int C, int H, int W, float* dx,
                            float* dw9, float* db, float* scratch, hipStream_t st);

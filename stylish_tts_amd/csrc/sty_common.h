@@ -157,11 +157,12 @@ int launch_conv32p(const ConvArgs& a, hipStream_t st);
 
 // one entry of a batched weight-side launch (wgrad.hip: pack / input-gradient pack / gradient un-pack)
 struct MultiJob {
-  const float *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
-  float *q0 = nullptr, *q1 = nullptr, *q2 = nullptr, *q3 = nullptr;
-  int Cout = 0, Cin = 0, K = 1, CinP = 0, CoutP = 0, glu = 0, blk0 = 0, pad = 0;
+  const float *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
+  float *q0 = nullptr, *q1 = nullptr, *q2 = nullptr, *q3 = nullptr, *q4 = nullptr;
+  int Cout = 0, Cin = 0, K = 1, CinP = 0, CoutP = 0, glu = 0, blk0 = 0, KH = 1;
 };
 int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st, int blk_base = 0);
+int launch_sn_unpack_multi(const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st);
 
 // weight preparation
 int launch_pack_conv(const float* w, const float* g, const float* v, const float* bias, int Cout, int Cin, int K,

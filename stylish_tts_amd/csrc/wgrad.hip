@@ -1157,19 +1157,23 @@ int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int 
   return STY_OK;
 }
 
-// spectral norm (eval mode, fixed u, v): W_eff = W / sigma, sigma = u^T W v
+// spectral norm (fixed u, v within a step): W_eff = W / sigma, sigma = u^T W v
 //   dW[co][i] += G[co][i]/sigma - (<G, W>/sigma^2) u[co] v[i],   G taken from the packed gradient.
-// t[co] = u[co] <W[co,:], v> (sn_rowdot_kernel) gives sigma = sum t.  Two kernels: <G,W> per row, then apply.
-__global__ __launch_bounds__(256) void sn_gw_rowdot_kernel(const float* __restrict__ gwp, const float* __restrict__ w,
-                                                           int Cin, int KH, int KW, int CinP, int CoutP,
-                                                           float* __restrict__ gw) {
+// t[co] = u[co] <W[co,:], v> (sn_rowdot_kernel) gives sigma = sum t.  Two steps: <G,W> per row, then apply -- for EVERY
+// spectral-norm conv of a model in two launches (one block per output row of every layer;
+// the style encoder has 13 such layers, and its un-pack is the last thing of the c3 step: 40 serial launches before).
+// p0 = packed weight gradient, p1 = W, p2 = u, p3 = v, p4 = t (sigma row terms), q0 = dW, q1 = <G,W> row sums (scratch),
+// q3 = db, q4 = packed bias gradient (read only)
+__global__ __launch_bounds__(256) void sn_gw_rowdot_multi_kernel(const MultiJob* __restrict__ jobs,
+                                                                 const int* __restrict__ job_of_block) {
   __shared__ float red[256];
-  const int co = blockIdx.x;
-  const int n = Cin * KH * KW;
+  const MultiJob j = jobs[job_of_block[blockIdx.x]];
+  const int co = (int)blockIdx.x - j.blk0;
+  const int KW = j.K, KH = j.KH, n = j.Cin * KH * KW;
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int kw = i % KW, kh = (i / KW) % KH, ci = i / (KW * KH);
-    s = fmaf(gwp[((size_t)kw * CinP + kh * Cin + ci) * CoutP + co], w[(size_t)co * n + i], s);
+    s = fmaf(j.p0[((size_t)kw * j.CinP + kh * j.Cin + ci) * j.CoutP + co], j.p1[(size_t)co * n + i], s);
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -1177,36 +1181,36 @@ __global__ __launch_bounds__(256) void sn_gw_rowdot_kernel(const float* __restri
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) gw[co] = red[0];
+  if (threadIdx.x == 0) j.q1[co] = red[0];
 }
-__global__ __launch_bounds__(256) void sn_unpack_kernel(const float* __restrict__ gwp, const float* __restrict__ t,
-                                                        const float* __restrict__ gw, const float* __restrict__ u,
-                                                        const float* __restrict__ v, int Cout, int Cin, int KH, int KW,
-                                                        int CinP, int CoutP, float* __restrict__ dW) {
+__global__ __launch_bounds__(256) void sn_unpack_multi_kernel(const MultiJob* __restrict__ jobs,
+                                                              const int* __restrict__ job_of_block) {
   __shared__ float sig, dot;
-  const int co = blockIdx.x;
+  const MultiJob j = jobs[job_of_block[blockIdx.x]];
+  const int co = (int)blockIdx.x - j.blk0;
   if (threadIdx.x == 0) {
     float s = 0.f, d = 0.f;
-    for (int i = 0; i < Cout; ++i) {
-      s += t[i];
-      d += gw[i];
+    for (int i = 0; i < j.Cout; ++i) {
+      s += j.p4[i];
+      d += j.q1[i];
     }
     sig = s;
     dot = d;
+    if (j.q3 && j.q4) j.q3[co] += j.q4[co];
   }
   __syncthreads();
-  const int n = Cin * KH * KW;
+  if (!j.q0) return;
+  const int KW = j.K, KH = j.KH, n = j.Cin * KH * KW;
   const float inv = 1.0f / sig, k = dot * inv * inv;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int kw = i % KW, kh = (i / KW) % KH, ci = i / (KW * KH);
-    dW[(size_t)co * n + i] += gwp[((size_t)kw * CinP + kh * Cin + ci) * CoutP + co] * inv - k * u[co] * v[i];
+    j.q0[(size_t)co * n + i] += j.p0[((size_t)kw * j.CinP + kh * j.Cin + ci) * j.CoutP + co] * inv - k * j.p2[co] * j.p3[i];
   }
 }
-int launch_sn_unpack(const float* gwp, const float* w, const float* u, const float* v, const float* t, int Cout,
-                     int Cin, int KH, int KW, int CinP, int CoutP, float* gw_scratch, float* dW, hipStream_t st) {
-  hipLaunchKernelGGL(sn_gw_rowdot_kernel, dim3(Cout), dim3(256), 0, st, gwp, w, Cin, KH, KW, CinP, CoutP, gw_scratch);
-  hipLaunchKernelGGL(sn_unpack_kernel, dim3(Cout), dim3(256), 0, st, gwp, t, gw_scratch, u, v, Cout, Cin, KH, KW, CinP,
-                     CoutP, dW);
+int launch_sn_unpack_multi(const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st) {
+  if (nblocks <= 0) return STY_OK;
+  hipLaunchKernelGGL(sn_gw_rowdot_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
+  hipLaunchKernelGGL(sn_unpack_multi_kernel, dim3(nblocks), dim3(256), 0, st, jobs, job_of_block);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
