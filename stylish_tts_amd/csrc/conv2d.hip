@@ -279,7 +279,9 @@ int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* 
 // read-modify-write of dx (the image base is 16-byte aligned when H (W + 1) is a multiple of 4; otherwise element by
 // element), the pad column is skipped.  (One thread per element on a (W/256, H, B C) grid -- a third of the workgroups
 // nearly empty, scalar accesses on odd row pitches -- ran at a fifth of the HBM rate.)
+// gate != nullptr: gy is taken times lrelu'(gate) (0.2 slope), gate laid out as gy (a deferred gate, train.hip `ungated`)
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __restrict__ gy,
+                                                                 const float* __restrict__ gate,
                                                                  const float* __restrict__ w9, int C, int H, int W,
                                                                  int Ho, int Wo, float* __restrict__ dx) {
   const int bc = blockIdx.y, c = bc % C;
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= n) return;
   const float* g = gy + (size_t)bc * Ho * ldo;
+  const float* gt = gate ? gate + (size_t)bc * Ho * ldo : nullptr;
   float* d = dx + (size_t)bc * n;
   int hi = i0 / ldi, wi = i0 - hi * ldi;
   float acc[4];
@@ -305,7 +308,11 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __
           const int wn = wi + 1 - kw;
           if (wn < 0 || (wn & 1)) continue;
           const int wo = wn >> 1;
-          if (wo < Wo) a = fmaf(w9[c * 9 + kh * 3 + kw], g[(size_t)ho * ldo + wo], a);
+          if (wo < Wo) {
+            float gv = g[(size_t)ho * ldo + wo];
+            if (gt && !(gt[(size_t)ho * ldo + wo] > 0.f)) gv *= 0.2f;
+            a = fmaf(w9[c * 9 + kh * 3 + kw], gv, a);
+          }
         }
       }
     }
@@ -330,19 +337,22 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __
 }
 // one workgroup per (channel, batch row): 10 partial sums; summed over the batch in a fixed order afterwards
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_part_kernel(const float* __restrict__ x,
-                                                                     const float* __restrict__ gy, int C, int H, int W,
+                                                                     const float* __restrict__ gy,
+                                                                     const float* __restrict__ gate, int C, int H, int W,
                                                                      int Ho, int Wo, float* __restrict__ part) {
   __shared__ float red[4];
   const int c = blockIdx.x, b = blockIdx.y;
   const int ldi = W + 1, ldo = Wo + 1;
   const float* p = x + ((size_t)b * C + c) * H * ldi;
   const float* g = gy + ((size_t)b * C + c) * Ho * ldo;
+  const float* gt = gate ? gate + ((size_t)b * C + c) * Ho * ldo : nullptr;
   float acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.f;
   for (int i = threadIdx.x; i < Ho * Wo; i += 256) {
     const int ho = i / Wo, wo = i % Wo;
-    const float gv = g[(size_t)ho * ldo + wo];
+    float gv = g[(size_t)ho * ldo + wo];
+    if (gt && !(gt[(size_t)ho * ldo + wo] > 0.f)) gv *= 0.2f;
     acc[9] += gv;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -375,12 +385,12 @@ __global__ void dwconv2d_s2_bwd_w_sum_kernel(const float* __restrict__ part, int
   }
 }
 size_t dwconv2d_s2_bwd_scratch_floats(int B, int C) { return (size_t)B * C * 10; }
-int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* w9, int B, int C, int H, int W, float* dx,
-                           float* dw9, float* db, float* scratch, hipStream_t st) {
+int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* gate, const float* w9, int B, int C, int H, int W,
+                           float* dx, float* dw9, float* db, float* scratch, hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(dwconv2d_s2_bwd_dx_kernel, dim3(cdiv(H * (W + 1), 1024), B * C), dim3(256), 0, st, gy, w9, C, H, W,
-                     Ho, Wo, dx);
-  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_part_kernel, dim3(C, B), dim3(256), 0, st, x, gy, C, H, W, Ho, Wo, scratch);
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_dx_kernel, dim3(cdiv(H * (W + 1), 1024), B * C), dim3(256), 0, st, gy, gate, w9, C, H,
+                     W, Ho, Wo, dx);
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_part_kernel, dim3(C, B), dim3(256), 0, st, x, gy, gate, C, H, W, Ho, Wo, scratch);
   hipLaunchKernelGGL(dwconv2d_s2_bwd_w_sum_kernel, dim3(cdiv(C * 10, 64)), dim3(64), 0, st, scratch, C, B, dw9, db);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -412,8 +422,11 @@ int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
+// gate != nullptr (laid out as dx): dx = dx * lrelu'(gate) + up(gy) -- a deferred gate (train.hip `ungated`) applied in
+// the pass that accumulates into dx anyway
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gy, int H, int W, int Ho, int Wo,
-                                                           float scale, float* __restrict__ dx) {
+                                                           float scale, float* __restrict__ dx,
+                                                           const float* __restrict__ gate) {
   // (four consecutive elements of the padded-flat image per thread, as in dwconv2d_s2_bwd_dx_kernel)
   const int bc = blockIdx.y;
   const int ldi = W + 1, n = H * ldi;
@@ -437,8 +450,16 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
       ++hi;
     }
   }
+  const float* gt = gate ? gate + (size_t)bc * n : nullptr;
   if ((n & 3) == 0 && i0 + 3 < n) {
     float4 v = *reinterpret_cast<float4*>(d + i0);
+    if (gt) {
+      const float4 q = *reinterpret_cast<const float4*>(gt + i0);
+      v.x = q.x > 0.f ? v.x : 0.2f * v.x;
+      v.y = q.y > 0.f ? v.y : 0.2f * v.y;
+      v.z = q.z > 0.f ? v.z : 0.2f * v.z;
+      v.w = q.w > 0.f ? v.w : 0.2f * v.w;
+    }
     v.x += acc[0];
     v.y += acc[1];
     v.z += acc[2];
@@ -447,12 +468,17 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (i0 + e < n) d[i0 + e] += acc[e];
+      if (i0 + e < n) {
+        float v = d[i0 + e];
+        if (gt && !(gt[i0 + e] > 0.f)) v *= 0.2f;
+        d[i0 + e] = v + acc[e];
+      }
   }
 }
-int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, hipStream_t st) {
+int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, const float* gate, hipStream_t st) {
   const int Ho = H / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cdiv(H * (W + 1), 1024), BC), dim3(256), 0, st, gy, H, W, Ho, Wo, scale, dx);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cdiv(H * (W + 1), 1024), BC), dim3(256), 0, st, gy, H, W, Ho, Wo, scale, dx,
+                     gate);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -135,13 +135,12 @@ __device__ __forceinline__ void q_issue(const ConvArgs& a, const QPos& p, const 
   const __amdgpu_buffer_rsrc_t rs = p.rs;
   // The whole offset goes into the VECTOR offset: the hardware range-checks that one only, not the scalar soffset.
   const int v0 = k.vcol + (p.t0 - a.pad) * 4 + p.roff;
-  // (a dead column group -- the third one of a K = 1 conv -- issues nothing: even loads that fall outside the descriptor
-  // are vector-memory instructions, and those are what the consumers' MFMAs do not hide, tools/probes/overlap_probe.hip)
-  if (k.qlive) {
+  // (a dead column group -- the third one of a K = 1 conv -- loads from outside the descriptor.  No branch around the
+  // loads: every path through a chunk step must issue the SAME number of vector-memory instructions, or the compiler's
+  // s_waitcnt for the other register set, whose loads are one step younger, degrades to vmcnt(0) -- see the step loop.)
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-      R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0 + r * T * 4, 0, 0));
-  }
+  for (int r = 0; r < 8; ++r)
+    R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0 + r * T * 4, 0, 0));
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.w.wf), 0, a.w.K * a.w.CinP * a.w.CoutP * 2 + 8192, 0x00020000);
 #pragma unroll
@@ -197,8 +196,10 @@ __device__ __forceinline__ void q_commit(const QConst<NFRAG>& k, const QSet<NFRA
 // (16 registers of residual in flight).  Kept small on purpose -- a rolled batch loop, one call site, the rare row-end
 // lanes on a rolled scalar loop: fully unrolled with both store paths per row it was two thirds of the kernel's code.
 template <int MTW, int RELU>
-__device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTile tl, int pw, int lane, int part,
-                                        int nparts) {  // part of nparts: every nparts-th batch of row pairs
+__device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, const float* bias_lds, QTile tl, int pw,
+                                        int lane, int part, int nparts) {
+  // part of nparts: every nparts-th batch of row pairs; the bias comes from its LDS copy (a global load here costs a
+  // full memory wait per row, chunk loads included)
   const int T = a.T, Cout = a.w.Cout;
   constexpr int ROWS = 64 * MTW;
   const int half = lane >> 5, l = lane & 31;
@@ -216,8 +217,9 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
   }
   const bool post = a.out_mask && a.out_mask_post;
   const float pre_scale = a.out_scale;
+  const int rl0 = 2 * pw + half + 2 * Q_NP * part;
 #pragma unroll 1
-  for (int rl = 2 * pw + half + 2 * Q_NP * part; rl < ROWS; rl += 2 * Q_NP * nparts) {
+  for (int rl = rl0; rl < ROWS; rl += 2 * Q_NP * nparts) {
     const int co = tl.cot * ROWS + rl;
     if (co >= Cout) continue;
     // (a 16-byte residual load may run past the end of the row for the last lanes of a row whose length is not a multiple
@@ -225,7 +227,7 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, QTi
     float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.residual) res = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, t * 4, co * T * 4, 0));
     const float4 sv = *reinterpret_cast<const float4*>(ost + rl * Q_TT + 4 * l);
-    const float bi = a.w.bias ? a.w.bias[co] : 0.f;
+    const float bi = bias_lds[co];
     float v[4] = {sv.x + bi, sv.y + bi, sv.z + bi, sv.w + bi};
     float rr[4] = {res.x, res.y, res.z, res.w};
     if (!wide && a.residual) {
@@ -284,6 +286,8 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
   __bf16* bring = reinterpret_cast<__bf16*>(lds);
   bf16x8* aring = reinterpret_cast<bf16x8*>(bring + 2 * bsz);
   float* ost = reinterpret_cast<float*>(aring + 2 * asz);
+  float* bias_lds = ost + 64 * MTW * Q_TT;  // [CoutP]
+  for (int i = tid; i < a.w.CoutP; i += Q_THREADS) bias_lds[i] = (a.w.bias && i < a.w.Cout) ? a.w.bias[i] : 0.f;
 
   // Tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The tile list is cut into 8
   // contiguous ranges, one per XCD, and the workgroups of an XCD take the tiles of their range with a stride of their
@@ -353,23 +357,27 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     ++ncommit;                                                                                                  \
     STY_Q_ISSUE(R)                                                                                              \
   }
-    STY_Q_ISSUE(R0)
-    STY_Q_ISSUE(R1)
-    STY_Q_STEP(R0)
+    const bool steady = nsteps > 4;  // the unconditional loop below runs (and then so does this prologue: see there)
+    if (steady) {
+      q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R0);
+      q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
+      q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R1);
+      q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
+      q_commit<PRO, NFRAG>(kc, R0, bring, aring, lane);
+      ++ncommit;
+      q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R0);
+      q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
+    } else {
+      STY_Q_ISSUE(R0)
+      STY_Q_ISSUE(R1)
+      STY_Q_STEP(R0)
+    }
     __syncthreads();
     // consumers' position: tile ti, chunk step c within the tile; the tile before it for the drain
     int ti = 0, c = 0;
     QTile cur_tl = q_tile(first, tiles_per_row, ncot), prev_tl = cur_tl;
     int cur_tile = first;
-    // One step: the previous tile's output stage (written at the end of its last step) is drained in ndr parts, done before
-    // this tile's last step, at whose end the consumers write the stage again; then the chunk the consumers need in the
-    // NEXT step is committed from its register set and the chunk two ahead requested into the same set.  Chunk n lives in
-    // set n & 1 and step s commits chunk s + 1, so the loop is unrolled by two with the set fixed at compile time: a
-    // run-time choice made hipcc merge the two sets through copies (sixteen v_mov_b64 and a full vmcnt(0) per step).
-#define STY_Q_BODY(R)                                                                                  \
-  {                                                                                                    \
-    if (ti > 0 && c < ndr) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane, c, ndr);                      \
-    if (ncommit < nchunks) STY_Q_STEP(R)                                                               \
+#define STY_Q_NEXT                                                                                      \
     if (++c == nch) { /* next tile */                                                                  \
       c = 0;                                                                                           \
       ++ti;                                                                                            \
@@ -377,15 +385,43 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
       cur_tile += tstride;                                                                             \
       cur_tl = q_tile(cur_tile, tiles_per_row, ncot);                                                  \
     }                                                                                                  \
-    __syncthreads();                                                                                   \
+    __syncthreads();
+#define STY_Q_BODY(R)                                                                                  \
+  {                                                                                                    \
+    if (ti > 0 && c < ndr) q_drain<MTW, RELU>(a, ost, bias_lds, prev_tl, pw, lane, c, ndr); \
+    if (ncommit < nchunks) STY_Q_STEP(R)                                                               \
+    STY_Q_NEXT                                                                                         \
   }
-    for (int step = 0; step < nsteps; step += 2) {
+    // The steady state (every step but the last four) commits and issues WITHOUT conditions: with the same number of
+    // vector-memory instructions on every path the compiler can count them, and the commit of a set waits with
+    // s_waitcnt vmcnt(n), n = the loads of the OTHER set, issued after it.  With `if (chunk exists)`
+    // around the issue it assumed the shortest path -- vmcnt(0) at every commit, i.e. every step waited for the loads
+    // issued ONE step earlier, a full memory round trip (1-2 us) per 0.3 us of MFMAs.
+#define STY_Q_FAST(R)                                                                                  \
+  {                                                                                                    \
+    if (ti > 0 && c < ndr) q_drain<MTW, RELU>(a, ost, bias_lds, prev_tl, pw, lane, c, ndr); \
+    q_commit<PRO, NFRAG>(kc, R, bring + (ncommit & 1) * bsz, aring + (ncommit & 1) * asz, lane);       \
+    ++ncommit;                                                                                         \
+    q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R);                                                     \
+    q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);                       \
+    STY_Q_NEXT                                                                                         \
+  }
+    int step = 0;
+    if (steady) {
+      for (; step + 4 < nsteps; step += 2) {
+        STY_Q_FAST(R1)
+        STY_Q_FAST(R0)
+      }
+    }
+    for (; step < nsteps; step += 2) {
       STY_Q_BODY(R1)
       if (step + 1 >= nsteps) break;
       STY_Q_BODY(R0)
     }
+#undef STY_Q_FAST
+#undef STY_Q_NEXT
 #undef STY_Q_BODY
-    if (!(dbg & 8)) q_drain<MTW, RELU>(a, ost, prev_tl, pw, lane, 0, 1);  // the last tile
+    if (!(dbg & 8)) q_drain<MTW, RELU>(a, ost, bias_lds, prev_tl, pw, lane, 0, 1);  // the last tile
 #undef STY_Q_STEP
 #undef STY_Q_ISSUE
     return;
@@ -527,7 +563,8 @@ static int q_num_cus() {
 static int q_mtw(const ConvArgs& a) { return a.w.CoutP <= 64 || a.w.K > 3 ? 1 : 2; }
 static size_t q_lds_bytes(const ConvArgs& a) {
   const int mtw = q_mtw(a), LWt = Q_TT + (a.w.K - 1) * a.dil;
-  return (size_t)2 * LWt * Q_PITCH * 2 + (size_t)2 * a.w.K * 2 * (2 * mtw) * 1024 + (size_t)64 * mtw * Q_TT * 4;
+  return (size_t)2 * LWt * Q_PITCH * 2 + (size_t)2 * a.w.K * 2 * (2 * mtw) * 1024 + (size_t)64 * mtw * Q_TT * 4 +
+         (size_t)a.w.CoutP * 4;  // B ring, A ring, output stage, bias
 }
 
 bool convp16_eligible(const ConvArgs& a) {

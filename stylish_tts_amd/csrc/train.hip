@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <unordered_map>
 
 #include "model.h"
@@ -152,7 +153,25 @@ struct Trainer {
     return p;
   }
   // gradient buffer of an activation (zero-filled on first request)
-  float* G(const float* act, size_t n) {
+  // Deferred LeakyReLU gates (style encoder): `ungated` holds activations a whose gradient buffer still lacks the factor
+  // lrelu'(a) -- the input-gradient conv of a LeakyReLU-prologue conv wrote its raw output there (conv2d_bwd).  The next
+  // element-wise step that touches the buffer anyway applies the factor on its way (avgpool2_bwd accumulating into it,
+  // dwconv2d_s2_bwd reading it); anybody else gets it through G / Gw, which run the plain pass first.
+  std::map<const float*, std::pair<int, int>> ungated;  // activation -> (channels, positions)
+  bool gate_pending(const float* act) const { return !ungated.empty() && ungated.count(act) != 0; }
+  void gate_flush(const float* act) {
+    auto it = ungated.find(act);
+    if (it == ungated.end()) return;
+    const int C = it->second.first, n = it->second.second;
+    ungated.erase(it);
+    auto gi = gmap.find(act);
+    if (gi == gmap.end() || !live()) return;
+    float* g = gi->second;  // in place: one element per thread, read then written
+    chk(launch_pro_bwd(PRO_LRELU, g, C, 0, act, B, C, n, nullptr, nullptr, C, 0, nullptr, nullptr, g, 0, nullptr, nullptr,
+                       nullptr, st));
+  }
+  float* G(const float* act, size_t n, bool raw = false) {  // raw: the caller deals with a deferred gate itself
+    if (!raw && !ungated.empty()) gate_flush(act);
     auto it = gmap.find(act);
     if (it != gmap.end()) return side_cow(act, it->second, n);
     float* g = take<float>(n);
@@ -166,6 +185,7 @@ struct Trainer {
   // same, for a producer that can either overwrite or accumulate: the first writer of a buffer overwrites it
   // (acc = 0) and no zero-fill is issued; later writers accumulate
   float* Gw(const float* act, size_t n, int& acc) {
+    if (!ungated.empty()) gate_flush(act);
     auto it = gmap.find(act);
     if (it != gmap.end()) {
       acc = 1;
@@ -1534,6 +1554,18 @@ struct Trainer {
       d.mask = f.out_mask;
       d.out_scale = f.out_scale;
       d.y = U;
+      static const bool defer_gate = getenv("STY_NO_DEFERRED_GATE") == nullptr;  // A/B switch: pro_bwd_kernel after every conv
+      if (gX != gY && (f.pro == PRO_NONE || (f.pro == PRO_LRELU && !accX && defer_gate))) {
+        // no pass of its own for the prologue's derivative: the input-gradient conv writes (or, without a prologue,
+        // accumulates through its residual operand) the gradient buffer.  LeakyReLU prologue, first writer of the buffer:
+        // the factor lrelu'(x) is left to the next element-wise step that touches the buffer (`ungated`).
+        d.y = gX;
+        d.residual = accX ? gX : nullptr;
+        if (live()) chk(launch_conv1d(d, st));
+        if (f.pro == PRO_LRELU) ungated[f.x[0]] = std::make_pair(f.Cin2d, n);
+        ws.off = mark;
+        return;
+      }
       if (live()) {
         chk(launch_conv1d(d, st));
         chk(launch_pro_bwd(f.pro, U, f.Cin2d, 0, f.x[0], B, f.Cin2d, n, nullptr, nullptr, f.Cin2d, 0, nullptr, nullptr,
@@ -1560,6 +1592,7 @@ struct Trainer {
     tape.clear();
     gmap.clear();
     nograd.clear();
+    ungated.clear();
     scratch_param_n = 1 << 16;
     scratch_param = take<float>(scratch_param_n);
     if (live() && m->garena) {
@@ -1629,8 +1662,11 @@ struct Trainer {
         const int BC = B * Cc;
         tape.push_back([=]() {
           float* g = G(out, (size_t)BC * no);
+          // gs = gs * lrelu'(src) + up(g) in the one pass that accumulates into gs anyway
+          const bool gated = gate_pending(src);
+          if (gated) ungated.erase(src);
           float* gs = G(src, (size_t)BC * n);
-          if (live()) chk(launch_avgpool2_bwd(g, BC, Hc, Wc, scale, gs, st));
+          if (live()) chk(launch_avgpool2_bwd(g, BC, Hc, Wc, scale, gs, gated ? src : nullptr, st));
         });
         return out;
       };
@@ -1656,11 +1692,14 @@ struct Trainer {
         const float* dwb = k.dw_b;
         const int Cc = k.Cin;
         tape.push_back([=]() {
-          float* g = G(h2, (size_t)B * Cc * no);
+          // a deferred gate on g(h2) is applied as g is read (the buffer itself stays as it is, and stays marked)
+          const bool gated = gate_pending(h2);
+          float* g = G(h2, (size_t)B * Cc * no, gated);
           float* gx = G(h1, (size_t)B * Cc * n);
           const size_t mark = ws.off;
           float* sc = take<float>(dwconv2d_s2_bwd_scratch_floats(B, Cc));
-          if (live()) chk(launch_dwconv2d_s2_bwd(h1, g, w9, B, Cc, Hc, Wc, gx, PGpacked(w9), PG(dwb, Cc), sc, st));
+          if (live())
+            chk(launch_dwconv2d_s2_bwd(h1, g, gated ? h2 : nullptr, w9, B, Cc, Hc, Wc, gx, PGpacked(w9), PG(dwb, Cc), sc, st));
           ws.off = mark;
         });
         h = h2;
@@ -2142,6 +2181,8 @@ int trainer_style_tap(Trainer* t, int i, int grad, float* dst, int* C, int* H, i
   if (!dst) return STY_OK;
   const float* src = tp.act;
   if (grad) {
+    t->st = st;
+    t->gate_flush(tp.act);  // (a deferred gate nobody had to apply yet)
     auto it = t->gmap.find(tp.act);
     if (it == t->gmap.end()) {
       set_error("style tap %d: no gradient (call sty_style_bwd first)", i);
