@@ -412,6 +412,7 @@ static int wgrad64_nsplit(const PackedConv& w, int B, int T) {
   const int tiles = cdiv(w.CinP, 64) * cdiv(w.CoutP, 64);
   const int chunks = B * cdiv(T, WG_TW);
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
+  if (nsplit >= 8) nsplit = (nsplit + 7) & ~7;  // a multiple of 8: wgradb_kernel then keeps the blocks of a split on one XCD
   if (nsplit > chunks) nsplit = chunks;
   return nsplit;
 }

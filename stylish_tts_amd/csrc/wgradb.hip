@@ -93,10 +93,24 @@ __global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(C
             hi = lane >> 5;
   const int wi = wave >> 1, wo = wave & 1;
   const int dil = ax.dil, T = ax.T, pad = ax.pad;
-  const int ci0 = blockIdx.x * R, co0 = blockIdx.y * R, split = blockIdx.z;
+  // Workgroup -> (block of dW, reduction split).  The hardware deals workgroup ids round-robin to the 8 XCDs (each with
+  // its own L2), so with the split in blockIdx.z the gx gy blocks of ONE split -- which read the same samples of x and G
+  // at the same time -- land on gx gy different XCDs and every one of them fetches its operands from the fabric itself.
+  // With nsplit a multiple of 8, id -> (xcd = id % 8, slot = id / 8): the blocks of a split take consecutive slots of one XCD.
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if ((nsplit & 7) == 0) {
+    const int gx = gridDim.x, nb = gx * (int)gridDim.y;
+    const int id = bx + gx * (by + (int)gridDim.y * split);
+    const int xcd = id & 7, slot = id >> 3;
+    const int blk = slot % nb;
+    split = (slot / nb) * 8 + xcd;
+    bx = blk % gx;
+    by = blk / gx;
+  }
+  const int ci0 = bx * R, co0 = by * R;
   constexpr int GPR = TW / 8, NI = TW / 32 * F, RSTEP = 256 / GPR;  // groups per row, items per thread, row step
   const int g8 = (tid % GPR) * 8, r0 = tid / GPR;  // this thread's 8-sample group and first row (rows r0 + RSTEP m)
-  const bool do_bias = want_bias && blockIdx.x == 0;
+  const bool do_bias = want_bias && bx == 0;
 
   f32x16 acc[KN][F][F];
 #pragma unroll
