@@ -166,15 +166,17 @@ int launch_flat_mask(int B, int H, int Wp, int Hv, int Wv, float* m, hipStream_t
 
 // LearnedDownSample 'half': depthwise 3x3, stride 2, pad 1 (mel_style_encoder.py:28-38); rows of x have stride
 // W + 1, rows of y stride Wo + 1 (the pad column is written as zero)
+// One thread per output of the flattened image [Ho][Wo + 1] (a (Wo / 256, Ho, B C) grid left every second workgroup with
+// five live threads at W = 521).
 __global__ __launch_bounds__(256) void dwconv2d_s2_kernel(const float* __restrict__ x, const float* __restrict__ w9,
                                                           const float* __restrict__ bias, int C, int H, int W, int Ho,
                                                           int Wo, float* __restrict__ y) {
-  const int wo = blockIdx.x * 256 + threadIdx.x;
-  const int ho = blockIdx.y;
-  const int bc = blockIdx.z, c = bc % C;
-  if (wo > Wo) return;
   const int ldi = W + 1, ldo = Wo + 1;
-  float* out = y + ((size_t)bc * Ho + ho) * ldo + wo;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Ho * ldo) return;
+  const int ho = i / ldo, wo = i - ho * ldo;
+  const int bc = blockIdx.y, c = bc % C;
+  float* out = y + (size_t)bc * Ho * ldo + i;
   if (wo == Wo) {
     *out = 0.f;
     return;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_kernel(const float* __restric
 int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B, int C, int H, int W, float* y,
                        hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(dwconv2d_s2_kernel, dim3(cdiv(Wo + 1, 256), Ho, B * C), dim3(256), 0, st, x, w9, bias, C, H, W, Ho,
+  hipLaunchKernelGGL(dwconv2d_s2_kernel, dim3(cdiv(Ho * (Wo + 1), 256), B * C), dim3(256), 0, st, x, w9, bias, C, H, W, Ho,
                      Wo, y);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -205,11 +207,12 @@ int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B
 // DownSample 'half': avg_pool2d(2) after replicating the last column when W is odd (mel_style_encoder.py:58-61)
 __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x, int H, int W, int Ho, int Wo,
                                                        float scale, float* __restrict__ y) {
-  const int wo = blockIdx.x * 256 + threadIdx.x;
-  const int ho = blockIdx.y, bc = blockIdx.z;
-  if (wo > Wo) return;
   const int ldi = W + 1, ldo = Wo + 1;
-  float* out = y + ((size_t)bc * Ho + ho) * ldo + wo;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // flattened [Ho][Wo + 1], as dwconv2d_s2_kernel
+  if (i >= Ho * ldo) return;
+  const int ho = i / ldo, wo = i - ho * ldo;
+  const int bc = blockIdx.y;
+  float* out = y + (size_t)bc * Ho * ldo + i;
   if (wo == Wo) {
     *out = 0.f;
     return;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__
 }
 int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st) {
   const int Ho = H / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(Wo + 1, 256), Ho, BC), dim3(256), 0, st, x, H, W, Ho, Wo, scale, y);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(Ho * (Wo + 1), 256), BC), dim3(256), 0, st, x, H, W, Ho, Wo, scale, y);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -274,124 +277,147 @@ int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* 
 }
 
 // ---- backward ----
-// depthwise 3x3 stride 2 pad 1: dx (+=), dw9 (+=, w.r.t. the EFFECTIVE weights), db (+=)
-// One thread per FOUR consecutive elements of one (batch, channel) image in its padded-flat storage [H][W + 1]: 16-byte
-// read-modify-write of dx (the image base is 16-byte aligned when H (W + 1) is a multiple of 4; otherwise element by
-// element), the pad column is skipped.  (One thread per element on a (W/256, H, B C) grid -- a third of the workgroups
-// nearly empty, scalar accesses on odd row pitches -- ran at a fifth of the HBM rate.)
+// depthwise 3x3 stride 2 pad 1: dx (= or +=), dw9 (+=, w.r.t. the EFFECTIVE weights), db (+=) in ONE pass over x, gy, dx.
+// One thread per FOUR consecutive elements of one (batch, channel) image in its padded-flat storage [H][W + 1] (16-byte
+// accesses when H (W + 1) is a multiple of 4), the pad column is skipped.  For its input positions a thread walks the
+// (at most four) taps that reach an output sample: dx gets w gy, the tap's weight gradient gy x; the bias gradient
+// counts an output at its centre tap.  The ten sums are reduced over the workgroup and written as one partial per
+// workgroup; dwconv2d_s2_bwd_w_sum_kernel adds them up over batch and workgroups in a fixed order.
+// (Two kernels -- dx by input position, the weight gradient by output position with nine strided reads of x per output --
+// moved 1.9 GB for the first ResBlk at ~1.5 TB/s, plus the zero-fill of dx; this one moves 0.96 GB.)
 // gate != nullptr: gy is taken times lrelu'(gate) (0.2 slope), gate laid out as gy (a deferred gate, train.hip `ungated`)
-__global__ __launch_bounds__(256) void dwconv2d_s2_bwd_dx_kernel(const float* __restrict__ gy,
-                                                                 const float* __restrict__ gate,
-                                                                 const float* __restrict__ w9, int C, int H, int W,
-                                                                 int Ho, int Wo, float* __restrict__ dx) {
+template <bool ACC>
+__global__ __launch_bounds__(256) void dwconv2d_s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                              const float* __restrict__ gate,
+                                                              const float* __restrict__ w9, int C, int H, int W, int Ho,
+                                                              int Wo, float* __restrict__ dx, float* __restrict__ part) {
+  __shared__ float red[4][10];
   const int bc = blockIdx.y, c = bc % C;
   const int ldi = W + 1, ldo = Wo + 1, n = H * ldi;
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i0 >= n) return;
   const float* g = gy + (size_t)bc * Ho * ldo;
   const float* gt = gate ? gate + (size_t)bc * Ho * ldo : nullptr;
+  const float* p = x + (size_t)bc * n;
   float* d = dx + (size_t)bc * n;
-  int hi = i0 / ldi, wi = i0 - hi * ldi;
-  float acc[4];
+  float wk[9];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float a = 0.f;
-    if (i0 + e < n && wi < W) {
+  for (int k = 0; k < 9; ++k) wk[k] = w9[c * 9 + k];
+  float wacc[10];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hn = hi + 1 - kh;  // 2 ho = hi + 1 - kh
-        if (hn < 0 || (hn & 1)) continue;
-        const int ho = hn >> 1;
-        if (ho >= Ho) continue;
+  for (int k = 0; k < 10; ++k) wacc[k] = 0.f;
+  if (i0 < n) {
+    const bool vec = (n & 3) == 0 && i0 + 3 < n;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      const float4 q = *reinterpret_cast<const float4*>(p + i0);
+      xv[0] = q.x;
+      xv[1] = q.y;
+      xv[2] = q.z;
+      xv[3] = q.w;
+    } else {
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int wn = wi + 1 - kw;
-          if (wn < 0 || (wn & 1)) continue;
-          const int wo = wn >> 1;
-          if (wo < Wo) {
-            float gv = g[(size_t)ho * ldo + wo];
-            if (gt && !(gt[(size_t)ho * ldo + wo] > 0.f)) gv *= 0.2f;
-            a = fmaf(w9[c * 9 + kh * 3 + kw], gv, a);
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e < n) xv[e] = p[i0 + e];
+    }
+    int hi = i0 / ldi, wi = i0 - hi * ldi;
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = 0.f;
+      if (i0 + e < n && wi < W) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hn = hi + 1 - kh;  // 2 ho = hi + 1 - kh
+          if (hn < 0 || (hn & 1)) continue;
+          const int ho = hn >> 1;
+          if (ho >= Ho) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int wn = wi + 1 - kw;
+            if (wn < 0 || (wn & 1)) continue;
+            const int wo = wn >> 1;
+            if (wo < Wo) {
+              float gv = g[(size_t)ho * ldo + wo];
+              if (gt && !(gt[(size_t)ho * ldo + wo] > 0.f)) gv *= 0.2f;
+              a = fmaf(wk[kh * 3 + kw], gv, a);
+              wacc[kh * 3 + kw] = fmaf(gv, xv[e], wacc[kh * 3 + kw]);
+              if (kh == 1 && kw == 1) wacc[9] += gv;
+            }
           }
         }
       }
+      acc[e] = a;
+      if (++wi == ldi) {
+        wi = 0;
+        ++hi;
+      }
     }
-    acc[e] = a;
-    if (++wi == ldi) {
-      wi = 0;
-      ++hi;
-    }
-  }
-  if ((n & 3) == 0 && i0 + 3 < n) {
-    float4 v = *reinterpret_cast<float4*>(d + i0);
-    v.x += acc[0];
-    v.y += acc[1];
-    v.z += acc[2];
-    v.w += acc[3];
-    *reinterpret_cast<float4*>(d + i0) = v;
-  } else {
+    if (vec) {
+      float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (ACC) {
+        const float4 o = *reinterpret_cast<float4*>(d + i0);
+        v.x += o.x;
+        v.y += o.y;
+        v.z += o.z;
+        v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(d + i0) = v;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (i0 + e < n) d[i0 + e] += acc[e];
-  }
-}
-// one workgroup per (channel, batch row): 10 partial sums; summed over the batch in a fixed order afterwards
-__global__ __launch_bounds__(256) void dwconv2d_s2_bwd_w_part_kernel(const float* __restrict__ x,
-                                                                     const float* __restrict__ gy,
-                                                                     const float* __restrict__ gate, int C, int H, int W,
-                                                                     int Ho, int Wo, float* __restrict__ part) {
-  __shared__ float red[4];
-  const int c = blockIdx.x, b = blockIdx.y;
-  const int ldi = W + 1, ldo = Wo + 1;
-  const float* p = x + ((size_t)b * C + c) * H * ldi;
-  const float* g = gy + ((size_t)b * C + c) * Ho * ldo;
-  const float* gt = gate ? gate + ((size_t)b * C + c) * Ho * ldo : nullptr;
-  float acc[10];
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-  for (int i = threadIdx.x; i < Ho * Wo; i += 256) {
-    const int ho = i / Wo, wo = i % Wo;
-    float gv = g[(size_t)ho * ldo + wo];
-    if (gt && !(gt[(size_t)ho * ldo + wo] > 0.f)) gv *= 0.2f;
-    acc[9] += gv;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int hi = 2 * ho + k / 3 - 1, wi = 2 * wo + k % 3 - 1;
-      if (hi >= 0 && hi < H && wi >= 0 && wi < W) acc[k] = fmaf(gv, p[(size_t)hi * ldi + wi], acc[k]);
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e < n) d[i0 + e] = ACC ? d[i0 + e] + acc[e] : acc[e];
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
-    float v = acc[k];
+    float v = wacc[k];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * 10 + k] = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    const int k = threadIdx.x;
+    part[((size_t)bc * gridDim.x + blockIdx.x) * 10 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
   }
 }
-__global__ void dwconv2d_s2_bwd_w_sum_kernel(const float* __restrict__ part, int C, int B, float* __restrict__ dw9,
-                                             float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * 10) return;
-  const int c = i / 10, k = i % 10;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += part[((size_t)c * B + b) * 10 + k];
-  if (k == 9) {
-    if (db) db[c] += s;
-  } else {
-    dw9[c * 9 + k] += s;
+// one wave per channel: the partials of its B images x nblk workgroups, ten sums each
+__global__ __launch_bounds__(64) void dwconv2d_s2_bwd_w_sum_kernel(const float* __restrict__ part, int C, int B, int nblk,
+                                                                   float* __restrict__ dw9, float* __restrict__ db) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float s[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) s[k] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* pp = part + ((size_t)(b * C + c) * nblk) * 10;
+    for (int j = lane; j < nblk; j += 64)
+#pragma unroll
+      for (int k = 0; k < 10; ++k) s[k] += pp[(size_t)j * 10 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    float v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    s[k] = v;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dw9[c * 9 + k] += s[k];
+    if (db) db[c] += s[9];
   }
 }
-size_t dwconv2d_s2_bwd_scratch_floats(int B, int C) { return (size_t)B * C * 10; }
+size_t dwconv2d_s2_bwd_scratch_floats(int B, int C, int H, int W) { return (size_t)B * C * cdiv(H * (W + 1), 1024) * 10; }
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* gate, const float* w9, int B, int C, int H, int W,
-                           float* dx, float* dw9, float* db, float* scratch, hipStream_t st) {
+                           float* dx, int accumulate, float* dw9, float* db, float* scratch, hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(dwconv2d_s2_bwd_dx_kernel, dim3(cdiv(H * (W + 1), 1024), B * C), dim3(256), 0, st, gy, gate, w9, C, H,
-                     W, Ho, Wo, dx);
-  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_part_kernel, dim3(C, B), dim3(256), 0, st, x, gy, gate, C, H, W, Ho, Wo, scratch);
-  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_sum_kernel, dim3(cdiv(C * 10, 64)), dim3(64), 0, st, scratch, C, B, dw9, db);
+  const int nblk = cdiv(H * (W + 1), 1024);
+  if (accumulate)
+    hipLaunchKernelGGL(dwconv2d_s2_bwd_kernel<true>, dim3(nblk, B * C), dim3(256), 0, st, x, gy, gate, w9, C, H, W, Ho, Wo, dx,
+                       scratch);
+  else
+    hipLaunchKernelGGL(dwconv2d_s2_bwd_kernel<false>, dim3(nblk, B * C), dim3(256), 0, st, x, gy, gate, w9, C, H, W, Ho, Wo, dx,
+                       scratch);
+  hipLaunchKernelGGL(dwconv2d_s2_bwd_w_sum_kernel, dim3(C), dim3(64), 0, st, scratch, C, B, nblk, dw9, db);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -487,7 +513,7 @@ int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, floa
 __global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restrict__ x, int B, int C, int n,
                                                           float inv_count, const float* __restrict__ W, int S,
                                                           const float* __restrict__ gs, float* __restrict__ dW,
-                                                          float* __restrict__ db, float* __restrict__ dx) {
+                                                          float* __restrict__ db, float* __restrict__ dx, int accumulate) {
   // one wave per (b, c) row, grid (C / 4, B): the first version ran one workgroup per utterance over all C * n elements
   // (32 workgroups on 256 CUs, 0.7 ms at the head of the style encoder's backward, which is the tail of the c3 step)
   const int b = blockIdx.y;
@@ -504,7 +530,7 @@ __global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restric
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   const float gp = acc * (pooled > 0.f ? 1.f : 0.2f) * inv_count;
   float* d = dx + ((size_t)b * C + c) * n;
-  for (int i = lane; i < n; i += 64) d[i] += gp;
+  for (int i = lane; i < n; i += 64) d[i] = accumulate ? d[i] + gp : gp;
   const float a = pooled > 0.f ? pooled : 0.2f * pooled;
   for (int j = lane; j < S; j += 64) {
     atomicAdd(&dW[(size_t)j * C + c], g[j] * a);
@@ -512,9 +538,9 @@ __global__ __launch_bounds__(256) void pool_fc_bwd_kernel(const float* __restric
   }
 }
 int launch_pool_fc_bwd(const float* x, int B, int C, int n, int count, const float* W, int S, const float* gs,
-                       float* dW, float* db, float* dx, hipStream_t st) {
+                       float* dW, float* db, float* dx, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(pool_fc_bwd_kernel, dim3(cdiv(C, 4), B), dim3(256), 0, st, x, B, C, n, 1.0f / (float)count, W, S, gs,
-                     dW, db, dx);
+                     dW, db, dx, accumulate);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

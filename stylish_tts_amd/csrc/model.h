@@ -323,16 +323,16 @@ int launch_fnv_unpack(const float* dw34, const float* g0, const float* v0, const
                       float* db1, float* dg2, float* dv2, float* db2, hipStream_t st);
 int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int CinP, int CoutP, int CinPd, int CoutPd,
                         float* wd, hipStream_t st);
-size_t dwconv2d_s2_bwd_scratch_floats(int B, int C);
+size_t dwconv2d_s2_bwd_scratch_floats(int B, int C, int H, int W);
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* gate, const float* w9, int B, int C, int H, int W, float* dx,
-                           float* dw9, float* db, float* scratch, hipStream_t st);
+                           int accumulate, float* dw9, float* db, float* scratch, hipStream_t st);
 int launch_pad_cols(const float* x, size_t rows, int W, float* y, hipStream_t st);
 int launch_flat_mask(int B, int H, int Wp, int Hv, int Wv, float* m, hipStream_t st);
 int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const float* v, const float* t, int C,
                           float* dW, hipStream_t st);
 int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, const float* gate, hipStream_t st);
 int launch_pool_fc_bwd(const float* x, int B, int C, int n, int count, const float* W, int S, const float* gs,
-                       float* dW, float* db, float* dx, hipStream_t st);
+                       float* dW, float* db, float* dx, int accumulate, hipStream_t st);
 int launch_bn_train_fwd(const float* x, const float* w, const float* b, float* rm, float* rv, float eps, float momentum,
                         int B, int C, int T, float* y, float* mean, float* rstd, double* part, hipStream_t st);
 int launch_bn_train_bwd(const float* x, const float* dy, const float* w, const float* mean, const float* rstd, int B,

@@ -1500,7 +1500,8 @@ struct Trainer {
     const int KH = w.Cin / f.Cin2d, n = f.T;
     const size_t ny = (size_t)B * w.Cout * n, nx = (size_t)B * f.Cin2d * n;
     float* gY = G(f.y, ny);
-    float* gR = (f.residual && wants(f.residual)) ? G(f.residual, ny) : nullptr;
+    int accR = 1;  // (the first writer of the residual's gradient overwrites: no zero-fill, no read)
+    float* gR = (f.residual && wants(f.residual)) ? Gw(f.residual, ny, accR) : nullptr;
     int accX = 1;
     float* gX = wants(f.x[0]) ? Gw(f.x[0], nx, accX) : nullptr;
     if (side_ready() && gX && gX == gY) gX = fresh_copy(f.x[0], gY, nx);
@@ -1509,7 +1510,7 @@ struct Trainer {
     // gY * mask, exactly as the forward stored y * mask
     if (gR && live())
       chk(launch_pro_bwd(PRO_MASK, gY, w.Cout, 0, gY, B, w.Cout, n, nullptr, nullptr, w.Cout, 0, nullptr, f.out_mask,
-                         gR, 1, nullptr, nullptr, nullptr, st));
+                         gR, accR, nullptr, nullptr, nullptr, st));
     bool bias_done = false;
     float* gbias = w.bias ? PGpacked(w.bias) : nullptr;
     if (m->topts.frozen) {
@@ -1695,11 +1696,13 @@ struct Trainer {
           // a deferred gate on g(h2) is applied as g is read (the buffer itself stays as it is, and stays marked)
           const bool gated = gate_pending(h2);
           float* g = G(h2, (size_t)B * Cc * no, gated);
-          float* gx = G(h1, (size_t)B * Cc * n);
+          int acc = 1;  // (h1 feeds nothing else: this is the first writer of its gradient, no zero-fill, no read)
+          float* gx = Gw(h1, (size_t)B * Cc * n, acc);
           const size_t mark = ws.off;
-          float* sc = take<float>(dwconv2d_s2_bwd_scratch_floats(B, Cc));
+          float* sc = take<float>(dwconv2d_s2_bwd_scratch_floats(B, Cc, Hc, Wc));
           if (live())
-            chk(launch_dwconv2d_s2_bwd(h1, g, gated ? h2 : nullptr, w9, B, Cc, Hc, Wc, gx, PGpacked(w9), PG(dwb, Cc), sc, st));
+            chk(launch_dwconv2d_s2_bwd(h1, g, gated ? h2 : nullptr, w9, B, Cc, Hc, Wc, gx, acc, PGpacked(w9), PG(dwb, Cc), sc,
+                                       st));
           ws.off = mark;
         });
         h = h2;
@@ -1742,8 +1745,9 @@ struct Trainer {
     const int S = sp.style_dim, cnt = Hh * Wh, Cc = C;
     tape.push_back([=]() {
       float* gs = G(style_dst, (size_t)B * S);
-      float* gx = G(hd, (size_t)B * Cc * n);
-      if (live()) chk(launch_pool_fc_bwd(hd, B, Cc, n, cnt, fw, S, gs, PG(fw, (size_t)S * Cc), PG(fb, S), gx, st));
+      int acc = 1;
+      float* gx = Gw(hd, (size_t)B * Cc * n, acc);
+      if (live()) chk(launch_pool_fc_bwd(hd, B, Cc, n, cnt, fw, S, gs, PG(fw, (size_t)S * Cc), PG(fb, S), gx, acc, st));
     });
   }
   void style_backward(const float* d_style) {
