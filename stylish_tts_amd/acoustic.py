@@ -166,16 +166,19 @@ class AcousticTrainer:
                                    dropout_seed=self._rng.getrandbits(31) | 1, text_dropout=self.text_dropout,
                                    compute_bf16=self.bf16)
             self.se.set_train_opts(sn_power_iter=True, compute_bf16=self.bf16)
-        # the style encoder's weight-side work (spectral-norm power iteration, normalised + packed weights: ~1 ms of small
-        # launches) needs no input: it goes to the side stream before the mel front ends are issued on the main stream
+        # the style encoder's weight-side work (spectral-norm power iteration, normalised + packed weights: ~100 small
+        # launches, ~1 ms) needs no input: it runs on the side stream beside the mel front ends.  The front ends are ISSUED
+        # first: when the host is not ahead of the GPU at the start of a step, the main stream would otherwise sit idle
+        # for as long as the host needs to issue the hundred launches.
         main = torch.cuda.current_stream(audio_gt.device)
         side = self._side_stream(audio_gt.device)
         if side is not None:
             side.wait_stream(main)  # (the previous step's optimizer)
-            with torch.cuda.stream(side):
-                self.se.prepare_train(audio_gt.device)
         mel, _, energy = calculate_mel(audio_gt, TO_MEL, self.mean, self.std, want_energy=True)
         style_mel, _ = calculate_mel(audio_gt, TO_STYLE_MEL, self.mean, self.std)
+        if side is not None:
+            with torch.cuda.stream(side):
+                self.se.prepare_train(audio_gt.device)
         T = mel.shape[2]
         alignment = duration_to_alignment(durations, T)
         # Two streams: the style encoder (mid-size GEMMs) runs beside the text encoder (a chain of tiny kernels) in

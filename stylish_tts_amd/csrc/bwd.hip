@@ -546,6 +546,38 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restr
       dx[o + e] = src ? src[o + e] + acc[e] : (accumulate ? dx[o + e] + acc[e] : acc[e]);
   }
 }
+// K = 7, pad = 3, T % 4 == 0 (every ConvNeXt block of the decoder and the text encoder): the ten gradient samples a thread
+// needs lie in three aligned 16-byte groups, and the threads run over the flattened (row, group) list -- at T = 520 the
+// kernel above had 130 live threads per 256-thread workgroup and ten 4-byte loads per thread (0.9 TB/s).
+__global__ __launch_bounds__(256) void dwconv7_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C,
+                                                             int T4, size_t ngroups, float* __restrict__ dx, int accumulate,
+                                                             const float* __restrict__ src) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ngroups) return;
+  const size_t row = idx / T4;
+  const int q = (int)(idx - row * T4), c = (int)(row % C);
+  const float4* p4 = reinterpret_cast<const float4*>(dy) + row * T4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 a = q > 0 ? p4[q - 1] : z, b = p4[q], d = q + 1 < T4 ? p4[q + 1] : z;
+  const float g[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};  // dy[4 q - 4 + j]
+  float wk[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) wk[k] = w[c * 7 + k];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[e] = fmaf(wk[k], g[e + 7 - k], acc[e]);  // dy[t0 + e + 3 - k], same order as above
+  float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (src) {
+    const float4 sv = reinterpret_cast<const float4*>(src)[idx];
+    r = make_float4(r.x + sv.x, r.y + sv.y, r.z + sv.z, r.w + sv.w);
+  } else if (accumulate) {
+    const float4 dv = reinterpret_cast<const float4*>(dx)[idx];
+    r = make_float4(r.x + dv.x, r.y + dv.y, r.z + dv.z, r.w + dv.w);
+  }
+  reinterpret_cast<float4*>(dx)[idx] = r;
+}
 // dw[c][k] += sum_{b,t} dy[t] x[t - pad + k], db[c] += sum dy.  Two deterministic stages: one workgroup per
 // (channel, batch row, 4096-sample segment) writes K+1 partial sums, a second kernel adds them in a fixed order.
 // (The first version used one workgroup per channel looping over the whole batch: 1.1 ms per call at C = 32.)
@@ -633,7 +665,12 @@ size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K) { return (size_t)C 
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
                       int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src) {
   if (dx) {
-    if (K <= 7)
+    const bool al16 = (((size_t)dy | (size_t)dx | (size_t)dx_src) & 15) == 0;
+    if (K == 7 && pad == 3 && T % 4 == 0 && al16) {
+      const size_t ng = (size_t)B * C * (T / 4);
+      hipLaunchKernelGGL(dwconv7_bwd_dx_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, dy, w, C, T / 4, ng, dx,
+                         accumulate, dx_src);
+    } else if (K <= 7)
       hipLaunchKernelGGL(dwconv_bwd_dx_kernel<7>, dim3(cdiv(T, 1024), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
                          accumulate, dx_src);
     else if (K <= 31)
