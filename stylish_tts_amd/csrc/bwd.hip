@@ -550,13 +550,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restr
 // needs lie in three aligned 16-byte groups, and the threads run over the flattened (row, group) list -- at T = 520 the
 // kernel above had 130 live threads per 256-thread workgroup and ten 4-byte loads per thread (0.9 TB/s).
 __global__ __launch_bounds__(256) void dwconv7_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C,
-                                                             int T4, size_t ngroups, float* __restrict__ dx, int accumulate,
+                                                             int T4, unsigned ngroups, float* __restrict__ dx, int accumulate,
                                                              const float* __restrict__ src) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;  // (32-bit: a 64-bit division costs more than the memory traffic)
   if (idx >= ngroups) return;
-  const size_t row = idx / T4;
-  const int q = (int)(idx - row * T4), c = (int)(row % C);
-  const float4* p4 = reinterpret_cast<const float4*>(dy) + row * T4;
+  const unsigned row = idx / (unsigned)T4;
+  const int q = (int)(idx - row * (unsigned)T4), c = (int)(row % (unsigned)C);
+  const float4* p4 = reinterpret_cast<const float4*>(dy) + (size_t)row * T4;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 a = q > 0 ? p4[q - 1] : z, b = p4[q], d = q + 1 < T4 ? p4[q + 1] : z;
   const float g[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};  // dy[4 q - 4 + j]
@@ -666,9 +666,9 @@ int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, in
                       int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src) {
   if (dx) {
     const bool al16 = (((size_t)dy | (size_t)dx | (size_t)dx_src) & 15) == 0;
-    if (K == 7 && pad == 3 && T % 4 == 0 && al16) {
-      const size_t ng = (size_t)B * C * (T / 4);
-      hipLaunchKernelGGL(dwconv7_bwd_dx_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, dy, w, C, T / 4, ng, dx,
+    const size_t ng = (size_t)B * C * (T / 4);
+    if (K == 7 && pad == 3 && T % 4 == 0 && al16 && ng < ((size_t)1 << 31)) {
+      hipLaunchKernelGGL(dwconv7_bwd_dx_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, dy, w, C, T / 4, (unsigned)ng, dx,
                          accumulate, dx_src);
     } else if (K <= 7)
       hipLaunchKernelGGL(dwconv_bwd_dx_kernel<7>, dim3(cdiv(T, 1024), C, B), dim3(256), 0, st, dy, w, C, T, K, pad, dx,
