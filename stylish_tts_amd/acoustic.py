@@ -231,16 +231,22 @@ class AcousticTrainer:
             self.sp.wait_d_style(side)
             with torch.cuda.stream(side):
                 self.se.backward(d_style)
+            # the style encoder's backward is the tail of the step and the main stream has nothing left to do beside it:
+            # the predictor's gradients are final, so its exchange is finished and its AdamW runs here, under the tail
+            if self._hook_error is None:
+                world = gp.finish(average=False)
+                self.opt["speech_predictor"].step(grad_scale=1.0 / world)
             main.wait_stream(side)
         else:
             self.se.backward(d_style)
         if self._hook_error is not None:
             e, self._hook_error = self._hook_error, None
             raise e
-        world = gp.finish(average=False)
+        if side is None:
+            world = gp.finish(average=False)
+            self.opt["speech_predictor"].step(grad_scale=1.0 / world)
         gs.finish(average=False)
-        for key in ("speech_predictor", "speech_style_encoder"):
-            self.opt[key].step(grad_scale=1.0 / world)
+        self.opt["speech_style_encoder"].step(grad_scale=1.0 / world)
         if self.mrd is not None:
             # optimizers.py:54-65: discriminator lr = generator lr x multiplier of the tracked discriminator loss
             od = self.opt[f"mrd{disc_index}"]
