@@ -1435,10 +1435,11 @@ void sty_model_destroy(sty_model* m) {
   if (m->stft_default) (void)hipFree(m->stft_default);
   if (m->garena) (void)hipFree(m->garena);
   if (m->fcs_bwd_dev) (void)hipFree(m->fcs_bwd_dev);
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     if (m->mj_dev[i]) (void)hipFree(m->mj_dev[i]);
     if (m->mj_blk_dev[i]) (void)hipFree(m->mj_blk_dev[i]);
   }
+  if (m->mj_blk1_dev) (void)hipFree(m->mj_blk1_dev);
   if (m->trainer) trainer_destroy(m->trainer);
   delete m;
 }
@@ -1748,8 +1749,9 @@ const char* sty_model_key(const sty_model* m, int i) {
 
 // device tables for the batched pack / input-gradient pack / gradient un-pack launches
 static int build_multi_tables(sty_model* m) {
-  std::vector<MultiJob> jobs[4];
-  std::vector<int> blk[4];
+  std::vector<MultiJob> jobs[5];
+  std::vector<int> blk[5];
+  std::vector<int> blk1;  // table 4: the W^T u grid of the power iteration (SN_SLICES x ceil(n / 256) blocks per layer)
   auto PG = [&](const float* p) -> float* {
     auto it = p ? m->pgrad.find(p) : m->pgrad.end();
     return it == m->pgrad.end() ? nullptr : it->second;
@@ -1807,7 +1809,30 @@ static int build_multi_tables(sty_model* m) {
       a.CinP = j.CinP;
       a.CoutP = j.CoutP;
       add(1, a, (int)(((size_t)j.K * j.CinP * j.CoutP + 255) / 256));
-    } else if (j.kind == PK_CONV2D_SN && m->garena) {
+    }
+    if (j.kind == PK_CONV2D_SN || j.kind == PK_DW2D_SN) {  // launch_sn_prep_multi
+      MultiJob a;
+      a.p0 = j.w;
+      a.p1 = j.bias;
+      a.p2 = j.kind == PK_CONV2D_SN ? j.bp : nullptr;
+      a.q0 = const_cast<float*>(j.g);
+      a.q1 = const_cast<float*>(j.v);
+      a.q2 = j.scratch;
+      a.q3 = j.scratch2;
+      a.q4 = j.wp;
+      a.Cout = j.Cout;
+      a.Cin = j.Cin;
+      a.K = j.K;
+      a.KH = j.KH;
+      a.CinP = j.CinP;
+      a.CoutP = j.CoutP;
+      a.glu = j.kind == PK_DW2D_SN;
+      const int n = a.glu ? 9 : j.Cin * j.KH * j.K;
+      a.blk1 = (int)blk1.size();
+      for (int i = 0; i < 8 * ((n + 255) / 256); ++i) blk1.push_back((int)jobs[4].size());  // (SN_SLICES = 8, conv2d.hip)
+      add(4, a, j.Cout);
+    }
+    if (j.kind == PK_CONV2D_SN && m->garena) {
       MultiJob u;  // sn_unpack_multi_kernel
       u.p0 = GA(j.wp);
       u.p1 = j.w;
@@ -1827,7 +1852,15 @@ static int build_multi_tables(sty_model* m) {
       if (u.q0 || u.q3) add(3, u, j.Cout);
     }
   }
-  for (int i = 0; i < 4; ++i) {
+  if (m->mj_blk1_dev) (void)hipFree(m->mj_blk1_dev);
+  m->mj_blk1_dev = nullptr;
+  m->mj_nblk1 = (int)blk1.size();
+  m->mj_nsn = (int)jobs[4].size();
+  if (!blk1.empty()) {
+    STY_HIP(hipMalloc((void**)&m->mj_blk1_dev, blk1.size() * sizeof(int)));
+    STY_HIP(hipMemcpy(m->mj_blk1_dev, blk1.data(), blk1.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  for (int i = 0; i < 5; ++i) {
     if (m->mj_dev[i]) (void)hipFree(m->mj_dev[i]);
     if (m->mj_blk_dev[i]) (void)hipFree(m->mj_blk_dev[i]);
     m->mj_dev[i] = nullptr;
@@ -1892,13 +1925,14 @@ int sty_model_prepare(sty_model* m, void* stream) {
         r = launch_pack_w2a(j.w, j.bias, j.extra, j.Cout, j.wp, j.bp, st);
         break;
       case PK_CONV2D_SN:
-        r = launch_pack_conv2d_sn(j.w, j.g, j.v, j.bias, j.Cout, j.Cin, j.KH, j.K, j.wp, j.bp, j.CinP, j.CoutP,
-                                  j.scratch, st);
-        break;
       case PK_DW2D_SN:
-        r = launch_pack_dw2d_sn(j.w, j.g, j.v, j.Cout, j.wp, j.scratch, st);
-        break;
+        break;  // batched below (table 4)
     }
+    if (r != STY_OK) return r;
+  }
+  {  // sigma and W / sigma of every spectral-norm layer: two launches
+    int r = launch_sn_prep_multi(m->mj_dev[4], m->mj_nsn, m->mj_blk_dev[4], m->mj_nblk[4], m->mj_blk1_dev, m->mj_nblk1, false,
+                                 true, st);
     if (r != STY_OK) return r;
   }
   {
@@ -2566,13 +2600,11 @@ static int style_train_prepare(sty_model* m, void* stream) {
     return STY_OK;
   }
   int rc;
-  if (m->topts.sn_power_iter) {
-    for (const PackJob& j : m->jobs) {
-      if (j.kind != PK_CONV2D_SN && j.kind != PK_DW2D_SN) continue;
-      const int n = j.kind == PK_CONV2D_SN ? j.Cin * j.KH * j.K : 9;
-      rc = launch_sn_power_iter(j.w, const_cast<float*>(j.g), const_cast<float*>(j.v), j.Cout, n, j.scratch2, S(stream));
-      if (rc) return rc;
-    }
+  if (m->topts.sn_power_iter) {  // every spectral-norm layer in four launches (u, v in the caller's buffers)
+    if (!m->mj_ready && (rc = build_multi_tables(m))) return rc;
+    rc = launch_sn_prep_multi(m->mj_dev[4], m->mj_nsn, m->mj_blk_dev[4], m->mj_nblk[4], m->mj_blk1_dev, m->mj_nblk1, true,
+                              false, S(stream));
+    if (rc) return rc;
   }
   // weights change between steps: re-derive the prepared form every step
   if ((rc = sty_model_prepare(m, stream))) return rc;

@@ -5,43 +5,43 @@
 
 namespace sty {
 
-// sigma = u . (W v) of the old-hook spectral_norm in eval mode; t[co] = u[co] * <W[co,:], v>
-__global__ __launch_bounds__(256) void sn_rowdot_kernel(const float* __restrict__ w, const float* __restrict__ u,
-                                                        const float* __restrict__ v, int n, float* __restrict__ t) {
-  __shared__ float red[256];
-  const int co = blockIdx.x;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s = fmaf(w[(size_t)co * n + i], v[i], s);
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) t[co] = u[co] * red[0];
-}
-
-// One power iteration of torch.nn.utils.spectral_norm in training mode (n_power_iterations = 1, eps 1e-12):
-//   v = normalize(W^T u), u = normalize(W v), written back into the module's weight_u / weight_v buffers.
-// vraw[s][i] = sum over the s-th slice of co of W[co][i] u[co]   (grid: (n/256, SN_SLICES))
+// Spectral norm (torch.nn.utils.spectral_norm, old hook): W_eff = W / sigma, sigma = u . (W v) = sum_co t[co],
+// t[co] = u[co] <W[co,:], v>.  Training mode runs ONE power iteration per forward first (n_power_iterations = 1, eps
+// 1e-12): v = normalize(W^T u), u = normalize(W v), written back into the module's weight_u / weight_v buffers;
+// W^T u is summed in SN_SLICES slices of the output channels (partials in a fixed order).
 constexpr int SN_SLICES = 8;
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ w, const float* __restrict__ u, int Cout,
-                                                      int n, float* __restrict__ vraw) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// power-iteration scratch of one layer: SN_SLICES * n + Cout floats
+size_t sn_power_iter_scratch_floats(int Cout, int n) { return (size_t)SN_SLICES * n + Cout; }
+
+// ---- every spectral-norm layer of a model in one launch per step of the recipe (device-side job table) ----
+// The style encoder has 13 spectral-norm convs and 3 depthwise ones: layer by layer that was ~96 launches of a few
+// microseconds each at the head of its forward, i.e. ~1 ms in front of the kernel the whole step waits for (style).
+// MultiJob: p0 = W, p1 = bias, p2 = packed bias (written), q0 = u, q1 = v, q2 = t [Cout] (sigma row terms), q3 = power
+// iteration scratch (SN_SLICES n + Cout), q4 = packed weights (written); K = KW, glu = 1: depthwise [C][9];
+// blk0: first block of the layer in the row list (one block per output channel), blk1: in the W^T u list.
+__device__ __forceinline__ int snj_n(const MultiJob& j) { return j.glu ? 9 : j.Cin * j.KH * j.K; }
+__global__ __launch_bounds__(256) void sn_wt_u_multi_kernel(const MultiJob* __restrict__ jobs, const int* __restrict__ job_of_blk) {
+  const MultiJob j = jobs[job_of_blk[blockIdx.x]];
+  const int n = snj_n(j), nib = (n + 255) / 256;
+  const int local = (int)blockIdx.x - j.blk1, slice = local / nib, i = (local - slice * nib) * 256 + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int co = blockIdx.y; co < Cout; co += SN_SLICES) s = fmaf(w[(size_t)co * n + i], u[co], s);
-  vraw[(size_t)blockIdx.y * n + i] = s;
+  for (int co = slice; co < j.Cout; co += SN_SLICES) s = fmaf(j.p0[(size_t)co * n + i], j.q0[co], s);
+  j.q3[(size_t)slice * n + i] = s;
 }
-// out = normalize(sum of `slices` partial vectors raw[s][.]) (slices summed in a fixed order)
-__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ raw, int n, int slices,
-                                                           float* __restrict__ out) {
+// which = 0: v = normalize(sum of the slices of W^T u); which = 1: u = normalize(W v)
+__global__ __launch_bounds__(256) void sn_normalize_multi_kernel(const MultiJob* __restrict__ jobs, int which) {
   __shared__ double red[256];
+  const MultiJob j = jobs[blockIdx.x];
+  const int nv = snj_n(j);
+  const int n = which ? j.Cout : nv, slices = which ? 1 : SN_SLICES;
+  const float* raw = which ? j.q3 + (size_t)SN_SLICES * nv : j.q3;
+  float* out = which ? j.q0 : j.q1;
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
     float v = 0.f;
     for (int k = 0; k < slices; ++k) v += raw[(size_t)k * n + i];
-    out[i] = v;  // un-normalised sum, scaled below
+    out[i] = v;
     s += (double)v * v;
   }
   red[threadIdx.x] = s;
@@ -53,76 +53,62 @@ __global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restri
   const float nrm = fmaxf((float)sqrt(red[0]), 1e-12f);
   for (int i = threadIdx.x; i < n; i += 256) out[i] = out[i] / nrm;
 }
-__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ w, const float* __restrict__ v, int n,
-                                                     float* __restrict__ uraw) {
+// what = 0: uraw[co] = <W[co,:], v>;  what = 1: t[co] = u[co] <W[co,:], v>
+__global__ __launch_bounds__(256) void sn_rowdot_multi_kernel(const MultiJob* __restrict__ jobs, const int* __restrict__ job_of_row,
+                                                              int what) {
   __shared__ float red[256];
-  const int co = blockIdx.x;
+  const MultiJob j = jobs[job_of_row[blockIdx.x]];
+  const int co = (int)blockIdx.x - j.blk0, n = snj_n(j);
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s = fmaf(w[(size_t)co * n + i], v[i], s);
+  for (int i = threadIdx.x; i < n; i += 256) s = fmaf(j.p0[(size_t)co * n + i], j.q1[i], s);
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) uraw[co] = red[0];
+  if (threadIdx.x == 0) {
+    if (what)
+      j.q2[co] = j.q0[co] * red[0];
+    else
+      j.q3[(size_t)SN_SLICES * n + co] = red[0];
+  }
 }
-// scratch: SN_SLICES * n + Cout floats
-size_t sn_power_iter_scratch_floats(int Cout, int n) { return (size_t)SN_SLICES * n + Cout; }
-int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st) {
-  float* vraw = scratch;
-  float* uraw = scratch + (size_t)SN_SLICES * n;
-  hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cdiv(n, 256), SN_SLICES), dim3(256), 0, st, w, u, Cout, n, vraw);
-  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, n, SN_SLICES, v);
-  hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, w, v, n, uraw);
-  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, uraw, Cout, 1, u);
-  STY_LAUNCH_CHECK();
-  return STY_OK;
-}
-
-// W[co][ci][kh][kw] / sigma  ->  Wp[kw][(kh*Cin + ci)][co]   (+ bias copy); one block per output channel
-__global__ __launch_bounds__(256) void pack_conv2d_sn_kernel(const float* __restrict__ w, const float* __restrict__ t,
-                                                             const float* __restrict__ bias, int Cout, int Cin, int KH,
-                                                             int KW, float* __restrict__ wp, float* __restrict__ bp,
-                                                             int CinP, int CoutP) {
+__global__ __launch_bounds__(256) void sn_pack_multi_kernel(const MultiJob* __restrict__ jobs, const int* __restrict__ job_of_row) {
   __shared__ float sig;
-  const int co = blockIdx.x;
+  const MultiJob j = jobs[job_of_row[blockIdx.x]];
+  const int co = (int)blockIdx.x - j.blk0;
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int i = 0; i < Cout; ++i) s += t[i];
+    for (int i = 0; i < j.Cout; ++i) s += j.q2[i];
     sig = s;
   }
   __syncthreads();
   const float inv = 1.0f / sig;
-  const int n = Cin * KH * KW;
+  if (j.glu) {  // depthwise [C][1][3][3] / sigma -> w9[c][9]
+    if (threadIdx.x < 9) j.q4[co * 9 + threadIdx.x] = j.p0[co * 9 + threadIdx.x] * inv;
+    return;
+  }
+  const int KW = j.K, KH = j.KH, n = j.Cin * KH * KW;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int kw = i % KW, kh = (i / KW) % KH, ci = i / (KW * KH);
-    wp[((size_t)kw * CinP + kh * Cin + ci) * CoutP + co] = w[(size_t)co * n + i] * inv;
+    j.q4[((size_t)kw * j.CinP + kh * j.Cin + ci) * j.CoutP + co] = j.p0[(size_t)co * n + i] * inv;
   }
-  if (threadIdx.x == 0 && bp) bp[co] = bias ? bias[co] : 0.f;
+  if (threadIdx.x == 0 && j.p2) const_cast<float*>(j.p2)[co] = j.p1 ? j.p1[co] : 0.f;
 }
-
-int launch_pack_conv2d_sn(const float* w, const float* u, const float* v, const float* bias, int Cout, int Cin, int KH,
-                          int KW, float* wp, float* bp, int CinP, int CoutP, float* tscratch, hipStream_t st) {
-  hipLaunchKernelGGL(sn_rowdot_kernel, dim3(Cout), dim3(256), 0, st, w, u, v, Cin * KH * KW, tscratch);
-  hipLaunchKernelGGL(pack_conv2d_sn_kernel, dim3(Cout), dim3(256), 0, st, w, tscratch, bias, Cout, Cin, KH, KW, wp, bp,
-                     CinP, CoutP);
-  STY_LAUNCH_CHECK();
-  return STY_OK;
-}
-
-// depthwise [C][1][3][3] / sigma -> w9[c][9]
-__global__ void pack_dw2d_sn_kernel(const float* __restrict__ w, const float* __restrict__ t, int C,
-                                    float* __restrict__ w9) {
-  float s = 0.f;
-  for (int i = 0; i < C; ++i) s += t[i];
-  const float inv = 1.0f / s;
-  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < C * 9; i += blockDim.x * gridDim.x) w9[i] = w[i] * inv;
-}
-int launch_pack_dw2d_sn(const float* w, const float* u, const float* v, int C, float* w9, float* tscratch,
-                        hipStream_t st) {
-  hipLaunchKernelGGL(sn_rowdot_kernel, dim3(C), dim3(256), 0, st, w, u, v, 9, tscratch);
-  hipLaunchKernelGGL(pack_dw2d_sn_kernel, dim3(cdiv(C * 9, 256)), dim3(256), 0, st, w, tscratch, C, w9);
+int launch_sn_prep_multi(const MultiJob* jobs, int njobs, const int* job_of_row, int nrows, const int* job_of_blk1, int nblk1,
+                         bool power_iter, bool pack, hipStream_t st) {
+  if (njobs <= 0) return STY_OK;
+  if (power_iter) {
+    hipLaunchKernelGGL(sn_wt_u_multi_kernel, dim3(nblk1), dim3(256), 0, st, jobs, job_of_blk1);
+    hipLaunchKernelGGL(sn_normalize_multi_kernel, dim3(njobs), dim3(256), 0, st, jobs, 0);
+    hipLaunchKernelGGL(sn_rowdot_multi_kernel, dim3(nrows), dim3(256), 0, st, jobs, job_of_row, 0);
+    hipLaunchKernelGGL(sn_normalize_multi_kernel, dim3(njobs), dim3(256), 0, st, jobs, 1);
+  }
+  if (pack) {
+    hipLaunchKernelGGL(sn_rowdot_multi_kernel, dim3(nrows), dim3(256), 0, st, jobs, job_of_row, 1);
+    hipLaunchKernelGGL(sn_pack_multi_kernel, dim3(nrows), dim3(256), 0, st, jobs, job_of_row);
+  }
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

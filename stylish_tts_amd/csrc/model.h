@@ -85,10 +85,6 @@ struct Bump {
 };
 
 enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A, PK_CONV2D_SN, PK_DW2D_SN, PK_DGRAD, PK_DGRAD2D };
-int launch_pack_conv2d_sn(const float* w, const float* u, const float* v, const float* bias, int Cout, int Cin, int KH,
-                          int KW, float* wp, float* bp, int CinP, int CoutP, float* tscratch, hipStream_t st);
-int launch_pack_dw2d_sn(const float* w, const float* u, const float* v, int C, float* w9, float* tscratch,
-                        hipStream_t st);
 int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B, int C, int H, int W, float* y,
                        hipStream_t st);
 int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st);
@@ -244,9 +240,12 @@ struct sty_model {
   std::unordered_map<const float*, sty::PackedConv> plain_of;   // GLU-ordered packed conv -> plain-ordered copy
   void* fcs_bwd_dev = nullptr;
   // batched weight-side launches: device tables [0] pack, [1] input-gradient pack, [2] gradient un-pack
-  sty::MultiJob* mj_dev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int* mj_blk_dev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int mj_nblk[4] = {0, 0, 0, 0};  // 0 pack, 1 input-gradient pack, 2 gradient un-pack, 3 spectral-norm gradient un-pack
+  sty::MultiJob* mj_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int* mj_blk_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int mj_nblk[5] = {0, 0, 0, 0, 0};  // 0 pack, 1 input-gradient pack, 2 gradient un-pack, 3 spectral-norm gradient un-pack,
+                                    // 4 spectral-norm weight preparation (rows; mj_blk1_dev: its W^T u block list)
+  int* mj_blk1_dev = nullptr;
+  int mj_nblk1 = 0, mj_nsn = 0;
   bool mj_ready = false;
   // gradient segments (data-parallel overlap): pack jobs [0, seg_job_split) belong to the module that runs its backward
   // LAST (the text encoder of a speech predictor); the un-pack table splits at block seg_blk_split.  Segment 0 = every
@@ -341,7 +340,6 @@ int launch_dropout(const float* x, const float* res, size_t n, float p, unsigned
                    int accumulate, hipStream_t st, size_t group = 1);
 int launch_box_smooth(const float* x, int B, int T, int width, float* y, int accumulate, hipStream_t st);
 size_t sn_power_iter_scratch_floats(int Cout, int n);
-int launch_sn_power_iter(const float* w, float* u, float* v, int Cout, int n, float* scratch, hipStream_t st);
 int trainer_style_forward(struct Trainer* t, int B, int T, const float* mel, float* style, void* ws, size_t ws_bytes,
                           hipStream_t st, size_t* need, const float* pitch = nullptr, const float* energy = nullptr);
 int trainer_style_backward(struct Trainer* t, const float* d_style, hipStream_t st);

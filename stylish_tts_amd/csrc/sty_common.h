@@ -160,9 +160,14 @@ struct MultiJob {
   const float *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
   float *q0 = nullptr, *q1 = nullptr, *q2 = nullptr, *q3 = nullptr, *q4 = nullptr;
   int Cout = 0, Cin = 0, K = 1, CinP = 0, CoutP = 0, glu = 0, blk0 = 0, KH = 1;
+  int blk1 = 0, pad = 0;  // a job's first block in a second block list (launch_sn_prep_multi: the W^T u grid)
 };
 int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st, int blk_base = 0);
 int launch_sn_unpack_multi(const MultiJob* jobs, const int* job_of_block, int nblocks, hipStream_t st);
+// conv2d.hip: spectral-norm weight preparation of EVERY spectral-norm layer of a model in a few launches (power_iter: the
+// training-mode power iteration first; then sigma and the packed W / sigma)
+int launch_sn_prep_multi(const MultiJob* jobs, int njobs, const int* job_of_row, int nrows, const int* job_of_blk1, int nblk1,
+                         bool power_iter, bool pack, hipStream_t st);
 
 // weight preparation
 int launch_pack_conv(const float* w, const float* g, const float* v, const float* bias, int Cout, int Cin, int K,

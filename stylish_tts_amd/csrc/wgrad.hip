@@ -1160,7 +1160,7 @@ int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int 
 
 // spectral norm (fixed u, v within a step): W_eff = W / sigma, sigma = u^T W v
 //   dW[co][i] += G[co][i]/sigma - (<G, W>/sigma^2) u[co] v[i],   G taken from the packed gradient.
-// t[co] = u[co] <W[co,:], v> (sn_rowdot_kernel) gives sigma = sum t.  Two steps: <G,W> per row, then apply -- for EVERY
+// t[co] = u[co] <W[co,:], v> (sn_rowdot_multi_kernel) gives sigma = sum t.  Two steps: <G,W> per row, then apply -- for EVERY
 // spectral-norm conv of a model in two launches (one block per output row of every layer;
 // the style encoder has 13 such layers, and its un-pack is the last thing of the c3 step: 40 serial launches before).
 // p0 = packed weight gradient, p1 = W, p2 = u, p3 = v, p4 = t (sigma row terms), q0 = dW, q1 = <G,W> row sums (scratch),
