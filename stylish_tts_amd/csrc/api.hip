@@ -1430,7 +1430,10 @@ int sty_model_create(const char* kind, sty_model** out) {
 
 void sty_model_destroy(sty_model* m) {
   if (!m) return;
-  if (m->arena) (void)hipFree(m->arena);
+  if (m->arena) {
+    convp16_forget_range(m->arena, m->arena + m->arena_bytes);
+    (void)hipFree(m->arena);
+  }
   if (m->fcs_dev) (void)hipFree(m->fcs_dev);
   if (m->stft_default) (void)hipFree(m->stft_default);
   if (m->garena) (void)hipFree(m->garena);
@@ -1464,6 +1467,7 @@ int sty_model_finalize(sty_model* m) {
   }
   m->train_prepared = false;
   if (m->arena) {
+    convp16_forget_range(m->arena, m->arena + m->arena_bytes);
     (void)hipFree(m->arena);
     m->arena = nullptr;
   }
@@ -1949,6 +1953,10 @@ int sty_model_prepare(sty_model* m, void* stream) {
   if (m->kind == "speech_predictor") {
     const DecoderPlan& d = m->dec;
     int r = launch_prep_fnv(d.f0_g, d.f0_v, d.f0_b, d.n_g, d.n_v, d.n_b, d.v_g, d.v_v, d.v_b, d.fnv_w, st);
+    if (r != STY_OK) return r;
+  }
+  if (m->arena) {  // the bf16 fragment buffers the persistent kernels read the packed weights through (bf16 mode)
+    int r = convp16_repack_range(m->arena, m->arena + m->arena_bytes, st);
     if (r != STY_OK) return r;
   }
   m->prepared = true;

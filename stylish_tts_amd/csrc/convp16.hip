@@ -23,6 +23,9 @@
 #include <mutex>
 #include <unordered_map>
 
+#include <algorithm>
+#include <vector>
+
 #include "sty_common.h"
 #include "conv_stage.h"
 
@@ -521,32 +524,145 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const float* __restrict_
   wf[i] = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
 
-// One fragment buffer per packed-weight pointer, kept for the life of the process and re-filled before EVERY launch on
-// the launch's stream (weights change every optimizer step; a layer's conv runs once per step in each direction, so
-// there is nothing to cache in training, and nothing to invalidate).
+// All fragment buffers of one model in one launch: job = (packed weights, shape, fragment buffer, first block)
+struct FragJob {
+  const float* wp;
+  bf16x8* wf;
+  int K, CinP, CoutP, blk0;
+};
+__global__ __launch_bounds__(256) void frag_pack_multi_kernel(const FragJob* __restrict__ jobs, const int* __restrict__ job_of_block) {
+  const FragJob j = jobs[job_of_block[blockIdx.x]];
+  const int i = ((int)blockIdx.x - j.blk0) * 256 + threadIdx.x;
+  const int NMB = j.CoutP / 32, J = 2 * j.K;
+  if (i >= (j.CinP / 32) * J * NMB * 64) return;
+  const int lane = i & 63, l31 = lane & 31, hi = lane >> 5;
+  int r = i >> 6;
+  const int mb = r % NMB;
+  r /= NMB;
+  const int jj = r % J, chunk = r / J;
+  const int k = jj >> 1, s = jj & 1;
+  const float* src = j.wp + ((size_t)k * j.CinP + chunk * 32 + 16 * s + 8 * hi) * j.CoutP + mb * 32 + l31;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * j.CoutP];
+  j.wf[i] = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+
+// One fragment buffer per packed-weight pointer, kept for the life of the process.  Weights change every optimizer step
+// and a layer's conv runs once per step in each direction, so the fragments are re-made once per step: for the packed
+// weights of a MODEL by convp16_repack_range, which sty_model_prepare calls with the model's arena after it has re-derived
+// the packed weights (one launch for every buffer of the model that has been used so far); for everything else (unit
+// entry points, discriminators: weights in caller-owned memory that may change at any time) before every launch.
+struct FragEntry {
+  void* wf = nullptr;
+  size_t bytes = 0;
+  int K = 0, CinP = 0, CoutP = 0;
+  bool batched = false;  // re-made by convp16_repack_range since the weights last changed: launches skip the re-pack
+};
+static std::mutex g_frag_mu;
+static std::unordered_map<const float*, FragEntry> g_frags;
+struct FragBatch {  // the device-side job table of one arena, rebuilt when its set of buffers changes
+  std::vector<const float*> keys;
+  FragJob* jobs = nullptr;
+  int* blk = nullptr;
+  int nblk = 0;
+};
+static std::unordered_map<const void*, FragBatch> g_batches;
+
 static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
-  static std::mutex mu;
-  static std::unordered_map<const float*, std::pair<void*, size_t>> table;
   const size_t bytes = (size_t)a.w.K * a.w.CinP * a.w.CoutP * 2;
   const size_t slack = 8192;  // a cout tile that hangs over CoutP reads (and discards) up to 4 fragments past the end
   void* wf = nullptr;
+  bool fresh = false;
   {
-    std::lock_guard<std::mutex> lock(mu);
-    auto& e = table[a.w.wp];
-    if (e.second < bytes) {
-      if (e.first) STY_HIP(hipFree(e.first));
-      e.first = nullptr;
-      e.second = 0;
-      STY_HIP(hipMalloc(&e.first, bytes + slack));
-      e.second = bytes;
+    std::lock_guard<std::mutex> lock(g_frag_mu);
+    FragEntry& e = g_frags[a.w.wp];
+    if (e.bytes < bytes || e.K != a.w.K || e.CinP != a.w.CinP || e.CoutP != a.w.CoutP) {
+      if (e.bytes < bytes) {
+        if (e.wf) STY_HIP(hipFree(e.wf));
+        e.wf = nullptr;
+        e.bytes = 0;
+        STY_HIP(hipMalloc(&e.wf, bytes + slack));
+        e.bytes = bytes;
+      }
+      e.K = a.w.K;
+      e.CinP = a.w.CinP;
+      e.CoutP = a.w.CoutP;
+      e.batched = false;
     }
-    wf = e.first;
+    wf = e.wf;
+    fresh = e.batched;
   }
-  const int n = (int)(bytes / 16);
-  hipLaunchKernelGGL(frag_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.w.wp, a.w.K, a.w.CinP, a.w.CoutP,
-                     static_cast<bf16x8*>(wf));
-  STY_LAUNCH_CHECK();
+  if (!fresh) {
+    const int n = (int)(bytes / 16);
+    hipLaunchKernelGGL(frag_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.w.wp, a.w.K, a.w.CinP, a.w.CoutP,
+                       static_cast<bf16x8*>(wf));
+    STY_LAUNCH_CHECK();
+  }
   *out = wf;
+  return STY_OK;
+}
+
+// The arena [lo, hi) is about to be freed (or re-laid out): its fragment buffers and job table go with it -- another model
+// may get the same addresses.
+void convp16_forget_range(const void* lo, const void* hi) {
+  std::lock_guard<std::mutex> lock(g_frag_mu);
+  for (auto it = g_frags.begin(); it != g_frags.end();) {
+    if ((const void*)it->first >= lo && (const void*)it->first < hi) {
+      if (it->second.wf) (void)hipFree(it->second.wf);
+      it = g_frags.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  auto b = g_batches.find(lo);
+  if (b != g_batches.end()) {
+    if (b->second.jobs) (void)hipFree(b->second.jobs);
+    if (b->second.blk) (void)hipFree(b->second.blk);
+    g_batches.erase(b);
+  }
+}
+
+// Re-make every fragment buffer whose packed weights lie in [lo, hi) (a model's arena), on `st`, in one launch.
+int convp16_repack_range(const void* lo, const void* hi, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_frag_mu);
+  std::vector<const float*> keys;
+  for (auto& kv : g_frags)
+    if ((const void*)kv.first >= lo && (const void*)kv.first < hi && kv.second.wf) keys.push_back(kv.first);
+  if (keys.empty()) return STY_OK;
+  std::sort(keys.begin(), keys.end());
+  FragBatch& b = g_batches[lo];
+  if (b.keys != keys) {  // (first steps only: a synchronous upload)
+    std::vector<FragJob> jobs;
+    std::vector<int> blk;
+    for (const float* k : keys) {
+      const FragEntry& e = g_frags[k];
+      FragJob j;
+      j.wp = k;
+      j.wf = static_cast<bf16x8*>(e.wf);
+      j.K = e.K;
+      j.CinP = e.CinP;
+      j.CoutP = e.CoutP;
+      j.blk0 = (int)blk.size();
+      const int n = (int)((size_t)e.K * e.CinP * e.CoutP * 2 / 16);
+      for (int i = 0; i < cdiv(n, 256); ++i) blk.push_back((int)jobs.size());
+      jobs.push_back(j);
+    }
+    STY_HIP(hipStreamSynchronize(st));  // a previous launch may still read the old table
+    if (b.jobs) (void)hipFree(b.jobs);
+    if (b.blk) (void)hipFree(b.blk);
+    b.jobs = nullptr;
+    b.blk = nullptr;
+    STY_HIP(hipMalloc((void**)&b.jobs, jobs.size() * sizeof(FragJob)));
+    STY_HIP(hipMalloc((void**)&b.blk, blk.size() * sizeof(int)));
+    STY_HIP(hipMemcpy(b.jobs, jobs.data(), jobs.size() * sizeof(FragJob), hipMemcpyHostToDevice));
+    STY_HIP(hipMemcpy(b.blk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+    b.nblk = (int)blk.size();
+    b.keys = keys;
+  }
+  hipLaunchKernelGGL(frag_pack_multi_kernel, dim3(b.nblk), dim3(256), 0, st, b.jobs, b.blk);
+  STY_LAUNCH_CHECK();
+  for (const float* k : keys) g_frags[k].batched = true;
   return STY_OK;
 }
 

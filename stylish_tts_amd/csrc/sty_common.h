@@ -152,6 +152,8 @@ int launch_convk1(const ConvArgs& a, hipStream_t st);
 bool convk3_eligible(const ConvArgs& a);  // convk3.hip: K = 3 on the same data path (three shifted LDS images)
 int launch_convk3(const ConvArgs& a, hipStream_t st);
 bool convp16_eligible(const ConvArgs& a);
+int convp16_repack_range(const void* lo, const void* hi, hipStream_t st);
+void convp16_forget_range(const void* lo, const void* hi);  // before the arena is freed or re-laid out  // bf16 weight fragments of a model's packed weights, one launch
 int launch_convp16(const ConvArgs& a, hipStream_t st);
 int launch_conv32p(const ConvArgs& a, hipStream_t st);
 
