@@ -1813,6 +1813,20 @@ static int build_multi_tables(sty_model* m) {
       a.CinP = j.CinP;
       a.CoutP = j.CoutP;
       add(1, a, (int)(((size_t)j.K * j.CinP * j.CoutP + 255) / 256));
+    } else if (j.kind == PK_DGRAD2D) {  // (source: the spectral-norm pack of table 4, launched before table 1)
+      MultiJob a;
+      a.p0 = j.w;
+      a.q0 = j.wp;
+      a.K = j.K;
+      a.KH = j.KH;
+      a.Cin = j.Cin;
+      a.Cout = j.Cout;
+      a.CinP = j.CinP;
+      a.CoutP = j.CoutP;
+      a.glu = 2;
+      a.blk1 = (int)align_up(j.KH * j.Cout, CI_CHUNK);
+      a.pad = (int)align_up(j.Cin, 32);
+      add(1, a, (int)(((size_t)j.K * j.KH * j.Cout * j.Cin + 255) / 256));
     }
     if (j.kind == PK_CONV2D_SN || j.kind == PK_DW2D_SN) {  // launch_sn_prep_multi
       MultiJob a;
@@ -1920,7 +1934,7 @@ int sty_model_prepare(sty_model* m, void* stream) {
     switch (j.kind) {
       case PK_DGRAD:
       case PK_DGRAD2D:
-        break;  // second pass below
+        break;  // batched below (table 1, after the spectral-norm packs it reads)
       case PK_CONV:
       case PK_CONV_WN:
       case PK_CONV_GLU:
@@ -1941,13 +1955,6 @@ int sty_model_prepare(sty_model* m, void* stream) {
   }
   {
     int r = launch_multi(1, m->mj_dev[1], m->mj_blk_dev[1], m->mj_nblk[1], st);
-    if (r != STY_OK) return r;
-  }
-  for (const PackJob& j : m->jobs) {
-    int r = STY_OK;
-    if (j.kind == PK_DGRAD2D)
-      r = launch_pack_dgrad2d(j.w, j.K, j.KH, j.Cin, j.Cout, j.CinP, j.CoutP, (int)align_up(j.KH * j.Cout, CI_CHUNK),
-                              (int)align_up(j.Cin, 32), j.wp, st);
     if (r != STY_OK) return r;
   }
   if (m->kind == "speech_predictor") {

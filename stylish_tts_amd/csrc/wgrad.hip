@@ -1072,6 +1072,17 @@ __global__ __launch_bounds__(256) void pack_dgrad_multi_kernel(const MultiJob* _
                                                                const int* __restrict__ job_of_block) {
   const MultiJob j = jobs[job_of_block[blockIdx.x]];
   const size_t i = (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x;
+  if (j.glu == 2) {  // 2-D (flat layout): Wd[kw'][kh' Cout + co][ci] = Wp[KW-1-kw'][(KH-1-kh') Cin + ci][co]; blk1 / pad = CinPd / CoutPd
+    const size_t n2 = (size_t)j.K * j.KH * j.Cout * j.Cin;
+    if (i >= n2) return;
+    const int ci = (int)(i % j.Cin);
+    const int co = (int)((i / j.Cin) % j.Cout);
+    const int kh = (int)((i / ((size_t)j.Cin * j.Cout)) % j.KH);
+    const int kw = (int)(i / ((size_t)j.Cin * j.Cout * j.KH));
+    j.q0[((size_t)kw * j.blk1 + kh * j.Cout + co) * j.pad + ci] =
+        j.p0[((size_t)(j.K - 1 - kw) * j.CinP + (j.KH - 1 - kh) * j.Cin + ci) * j.CoutP + co];
+    return;
+  }
   const size_t n = (size_t)j.K * j.CinP * j.CoutP;
   if (i >= n) return;
   const int ci = (int)(i % j.CinP);
@@ -1136,7 +1147,8 @@ int launch_multi(int which, const MultiJob* jobs, const int* job_of_block, int n
   return STY_OK;
 }
 
-// 2-D: Wd[kw'][kh'*Cout + co][ci] = Wp[KW-1-kw'][(KH-1-kh')*Cin + ci][co]
+// 2-D: Wd[kw'][kh'*Cout + co][ci] = Wp[KW-1-kw'][(KH-1-kh')*Cin + ci][co]   (one layer: the spectrogram discriminators,
+// disc.hip; a model's layers go through pack_dgrad_multi_kernel)
 __global__ void pack_dgrad2d_kernel(const float* __restrict__ wp, int KW, int KH, int Cin, int Cout, int CinP,
                                     int CoutP, int CinPd, int CoutPd, float* __restrict__ wd) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
