@@ -23,7 +23,7 @@ def main(path, skip=1, min_gap=100.0):
     ends = [r[1] for r in rows if "adamw_kernel" in r[3]]
     groups = []
     for e in ends:
-        if groups and e - groups[-1][-1] < 2e6:
+        if groups and e - groups[-1][-1] < 15e6:  # (one step: the predictor's AdamW runs ~8 ms before the style encoder's)
             groups[-1].append(e)
         else:
             groups.append([e])

@@ -21,7 +21,7 @@ def main(path, skip=1):
     # group adamw launches that belong to one step (gaps < 2 ms)
     groups = []
     for e in ends:
-        if groups and e - groups[-1][-1] < 2e6:
+        if groups and e - groups[-1][-1] < 15e6:  # (one step: the predictor's AdamW runs ~8 ms before the style encoder's)
             groups[-1].append(e)
         else:
             groups.append([e])
