@@ -1555,7 +1555,7 @@ struct Trainer {
       d.mask = f.out_mask;
       d.out_scale = f.out_scale;
       d.y = U;
-      static const bool defer_gate = getenv("STY_NO_DEFERRED_GATE") == nullptr;  // A/B switch: pro_bwd_kernel after every conv
+      const bool defer_gate = getenv("STY_NO_DEFERRED_GATE") == nullptr;  // A/B switch, read per call (the parity test toggles it)
       if (gX != gY && (f.pro == PRO_NONE || (f.pro == PRO_LRELU && !accX && defer_gate))) {
         // no pass of its own for the prologue's derivative: the input-gradient conv writes (or, without a prologue,
         // accumulates through its residual operand) the gradient buffer.  LeakyReLU prologue, first writer of the buffer:

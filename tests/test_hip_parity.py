@@ -875,6 +875,46 @@ def test_mel_style_encoder_block_taps_forward_and_gradient(W):
     rep.done()
 
 
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_style_encoder_deferred_gates_equal_the_separate_passes(compute, monkeypatch):
+    """The style encoder's backward with the LeakyReLU gates deferred into avgpool2_bwd_kernel / dwconv2d_s2_bwd_kernel and
+    the no-prologue input gradients written straight into the gradient buffers against the same backward
+    with a pro_bwd_kernel pass after every input-gradient conv (STY_NO_DEFERRED_GATE=1): the same products and sums in the
+    same order, so every tap gradient and every parameter gradient must agree to fp32 rounding (the head's Linear weight
+    gradient is summed over the batch with float atomics in both runs: 1e-5)."""
+    import stylish_tts_amd as S
+    from oracle.manifest import style_encoder_manifest
+    from oracle.weights import fill_state_dict
+    P = fill_state_dict(style_encoder_manifest(), 0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 1, 80, 84, generator=g) * 0.8 - 0.3
+    cot = torch.randn(3, 64, generator=g)
+    runs = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("STY_NO_DEFERRED_GATE", "1")
+        else:
+            monkeypatch.delenv("STY_NO_DEFERRED_GATE", raising=False)
+        m = S.MelStyleEncoder()
+        m.load_state_dict(P, strict=False)
+        m = m.to(DEV).enable_training()
+        m.set_train_opts(compute_bf16=(compute == "bf16"))
+        m.forward_train(dev(x))
+        m.backward(dev(cot))
+        taps = [m.tap(i, grad=True).cpu() for i in range(6)]
+        grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+        torch.cuda.synchronize()
+        runs.append((taps, grads))
+    (ta, ga), (tb, gb) = runs
+    rep = Report()
+    for i, (a, b) in enumerate(zip(ta, tb)):
+        rep.add(f"d tap {i}", a, b, 1e-6)
+    assert ga.keys() == gb.keys() and len(ga) > 20
+    for k in ga:
+        rep.add(f"d {k}", ga[k], gb[k], 1e-5 if k.startswith("unshared") or "fc" in k else 2e-6)
+    rep.done()
+
+
 def test_adamw_matches_torch():
     """sty_adamw_step on a flat bucket vs torch.optim.AdamW (the reference's optimizer, optimizers.py:110-118)."""
     from stylish_tts_amd.optim import FlatAdamW
