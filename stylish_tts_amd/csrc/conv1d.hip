@@ -425,6 +425,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     set_error("conv1d: LN epilogue needs Cout == 32");
     return STY_EINVAL;
   }
+  if (stem2d_eligible(a)) return launch_stem2d(a, st);
   if (conv32p_eligible(a)) return launch_conv32p(a, st);
   if (a.stat_part) {
     set_error("conv1d: output statistics requested for a conv the persistent 32-channel kernel does not take");

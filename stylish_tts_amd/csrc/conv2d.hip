@@ -1,6 +1,8 @@
 // MelStyleEncoder pieces that are not the dense implicit-GEMM conv (which runs on conv1d_mfma_kernel in 2-D mode):
 // spectral-norm weight preparation, learned depthwise stride-2 down-sampling, average pooling, and the
 // global-pool + Linear head.  Reference: train/models/mel_style_encoder.py:9-152.
+#include <stdlib.h>
+
 #include "sty_common.h"
 
 namespace sty {
@@ -146,6 +148,92 @@ __global__ void flat_mask_kernel(int B, int H, int Wp, int Hv, int Wv, float* __
 }
 int launch_flat_mask(int B, int H, int Wp, int Hv, int Wv, float* m, hipStream_t st) {
   hipLaunchKernelGGL(flat_mask_kernel, dim3(cdiv(B * H * Wp, 256)), dim3(256), 0, st, B, H, Wp, Hv, Wv, m);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
+// ---- the style encoder's stem: Conv2d(1 -> C, 3 x 3, 'same') on the padded-flat layout ----
+// Nine products per output: on the implicit-GEMM kernel (reduction 3 rows padded to a 32-channel chunk, 8 waves per 32 couts)
+// this store-bound layer ran at 0.7-1.6 TB/s and sits at the head of the style encoder's forward, which the whole step
+// waits for.  Here a thread owns FOUR consecutive flattened positions of one utterance, reads the 3 x 6 input samples
+// around them once, and walks over all output channels (weights from LDS, broadcast reads): 36 FMAs and one 16-byte store
+// per channel.  bf16 compute mode: both operands rounded to bf16 first (the products are then exact in fp32), fp32 sums.
+// Positions outside [0, n) read zero; the pad column supplies the left / right padding, out_mask zeroes it in the output.
+__global__ __launch_bounds__(256) void stem2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                     const float* __restrict__ bias, const float* __restrict__ out_mask,
+                                                     int n, int Wp, int Cout, int CinP, int CoutP, float out_scale, int bf16,
+                                                     float* __restrict__ y) {
+  extern __shared__ float stem_w[];  // [Cout][12]: nine weights (kh, kw) + bias + pad
+  for (int i = threadIdx.x; i < Cout * 12; i += 256) {
+    const int co = i / 12, k = i - co * 12;
+    float v = 0.f;
+    if (k < 9) {
+      const int kh = k / 3, kw = k - kh * 3;
+      v = wp[((size_t)kw * CinP + kh) * CoutP + co];
+      if (bf16) v = (float)(__bf16)v;
+    } else if (k == 9) {
+      v = bias ? bias[co] : 0.f;
+    }
+    stem_w[i] = v;
+  }
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (n0 >= n) return;
+  const float* p = x + (size_t)b * n;
+  float xv[3][6];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int q = n0 + (kh - 1) * Wp + j - 1;
+      float v = (q >= 0 && q < n) ? p[q] : 0.f;
+      if (bf16) v = (float)(__bf16)v;
+      xv[kh][j] = v;
+    }
+  float mk[4] = {1.f, 1.f, 1.f, 1.f};
+  if (out_mask) {
+    const float4 m4 = *reinterpret_cast<const float4*>(out_mask + (size_t)b * n + n0);
+    mk[0] = m4.x;
+    mk[1] = m4.y;
+    mk[2] = m4.z;
+    mk[3] = m4.w;
+  }
+  float* out = y + (size_t)b * Cout * n + n0;
+  for (int co = 0; co < Cout; ++co) {
+    const float4 wa = *reinterpret_cast<const float4*>(stem_w + co * 12);
+    const float4 wb = *reinterpret_cast<const float4*>(stem_w + co * 12 + 4);
+    const float4 wc = *reinterpret_cast<const float4*>(stem_w + co * 12 + 8);
+    const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)  // (the packed layout's order: tap kw, then the three image rows)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[kh * 3 + kw], xv[kh][e + kw], acc[e]);
+    float4 o;
+    o.x = (acc[0] + wc.y) * out_scale * mk[0];
+    o.y = (acc[1] + wc.y) * out_scale * mk[1];
+    o.z = (acc[2] + wc.y) * out_scale * mk[2];
+    o.w = (acc[3] + wc.y) * out_scale * mk[3];
+    *reinterpret_cast<float4*>(out + (size_t)co * n) = o;
+  }
+}
+bool stem2d_eligible(const ConvArgs& a) {
+  static const bool off = getenv("STY_NO_STEM2D") != nullptr;
+  return !off && a.flatW > 0 && a.Cin2d == 1 && a.w.Cin == 3 && a.w.K == 3 && a.hpad == 1 && a.pad == 1 && a.dil == 1 &&
+         a.nsrc == 1 && a.pro == PRO_NONE && a.act == ACT_NONE && !a.residual && a.shuffle == 1 && a.in_shuffle <= 1 &&
+         !a.ln_out && !a.Tin && !a.y_split && !a.stat_part && a.T % 4 == 0 && (!a.out_mask || a.out_mask_post) &&
+         a.w.Cout <= 1024 && ((((size_t)a.y | (size_t)a.out_mask) & 15) == 0);
+}
+int launch_stem2d(const ConvArgs& a, hipStream_t st) {
+  const double outs = (double)a.B * a.w.Cout * a.T;
+  char detail[40];
+  snprintf(detail, sizeof(detail), "co%d n%d W%d", a.w.Cout, a.T, a.flatW);
+  ProfScope prof("stem2d_kernel", 18.0 * outs, 4.0 * (outs + (double)a.B * a.T), st, detail);
+  hipLaunchKernelGGL(stem2d_kernel, dim3(cdiv(a.T / 4, 256), a.B), dim3(256), (size_t)a.w.Cout * 12 * sizeof(float), st, a.x[0],
+                     a.w.wp, a.w.bias, a.out_mask, a.T, a.flatW, a.w.Cout, a.w.CinP, a.w.CoutP, a.out_scale, a.bf16, a.y);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

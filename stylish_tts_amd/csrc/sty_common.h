@@ -147,6 +147,8 @@ int launch_conv_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int
 int wgrad_cnx_per_b(int B, int T);
 int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
                      hipStream_t st, int per_b = 0);
+bool stem2d_eligible(const ConvArgs& a);  // conv2d.hip: Conv2d(1 -> C, 3 x 3) of the style encoder's stem, VALU, store-bound
+int launch_stem2d(const ConvArgs& a, hipStream_t st);
 bool convk1_eligible(const ConvArgs& a);  // convk1.hip: K = 1 as a plain GEMM (transposing LDS reads)
 int launch_convk1(const ConvArgs& a, hipStream_t st);
 bool convk3_eligible(const ConvArgs& a);  // convk3.hip: K = 3 on the same data path (three shifted LDS images)
