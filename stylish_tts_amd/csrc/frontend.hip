@@ -246,6 +246,72 @@ __global__ __launch_bounds__(256) void frame_fold_kernel(const float* __restrict
   }
 }
 
+// The same values through a 32 (n) x 32 (frames) tile: in the kernel above a wave's 64 lanes are 64 frames, i.e. 64 reads
+// `hop` samples apart for each of the four taps (one cache line per lane).  Here the lanes of a half-wave run over n -- the
+// four taps of a frame are four contiguous 128-byte runs of the signal (two ascending, two descending) -- and the results
+// go through LDS so that the stores still run along the frame axis (128 bytes per row of the tile).
+__global__ __launch_bounds__(256) void frame_fold_tiled_kernel(const float* __restrict__ audio, const float* __restrict__ w,
+                                                               int N, int n_fft, int hop, int frames, size_t sb, size_t sc,
+                                                               float* __restrict__ xt) {
+  __shared__ float tile[4][32][33];
+  const int f0 = blockIdx.x * 32, n0 = blockIdx.y * 32, b = blockIdx.z;
+  const int H = n_fft / 2, Q = n_fft / 4;
+  {
+    const int tn = threadIdx.x & 31, n = n0 + tn;
+    for (int r = 0; r < 4; ++r) {
+      const int lf = (threadIdx.x >> 5) + 8 * r, fr = f0 + lf;
+      if (fr >= frames || n > Q) continue;
+      auto at = [&](int k) {
+        int i = fr * hop + k - H;
+        if (i < 0) i = -i;
+        if (i >= N) i = 2 * (N - 1) - i;
+        return w[k] * audio[(size_t)b * N + i];
+      };
+      if (n == 0) {
+        const float e0 = at(0), eH = at(H);
+        tile[0][tn][lf] = e0 + eH;
+        tile[1][tn][lf] = e0 - eH;
+      } else if (n == Q) {
+        const float u = at(Q), v = at(n_fft - Q);
+        tile[0][tn][lf] = u + v;
+        tile[2][tn][lf] = u - v;
+      } else {
+        const float a0 = at(n), a1 = at(n_fft - n), b0 = at(H - n), b1 = at(H + n);
+        const float en = a0 + a1, on = a0 - a1, eh = b0 + b1, oh = b0 - b1;
+        tile[0][tn][lf] = en + eh;
+        tile[1][tn][lf] = en - eh;
+        tile[2][tn][lf] = on + oh;
+        tile[3][tn][lf] = on - oh;
+      }
+    }
+  }
+  __syncthreads();
+  const int lf = threadIdx.x & 31, fr = f0 + lf;
+  if (fr >= frames) return;
+  float* o_ = xt + b * sb + fr;
+  for (int r = 0; r < 16; ++r) {
+    const int q = (threadIdx.x >> 5) + 8 * r;  // 0..127: group g, n index tn
+    const int g = q >> 5, tn = q & 31, n = n0 + tn;
+    if (n > Q) continue;
+    int row = -1;  // rows: ee at n, eo at Q+1+n (n < Q), oo at 2Q+n (1 <= n <= Q), oe at 3Q+n (1 <= n < Q)
+    if (g == 0) row = n;
+    else if (g == 1) row = n < Q ? Q + 1 + n : -1;
+    else if (g == 2) row = n >= 1 ? 2 * Q + n : -1;
+    else row = (n >= 1 && n < Q) ? 3 * Q + n : -1;
+    if (row >= 0) o_[(size_t)row * sc] = tile[g][tn][lf];
+  }
+}
+static void launch_frame_fold(const float* audio, const float* w, int B, int N, int n_fft, int hop, int frames, size_t sb,
+                              size_t sc, float* xt, hipStream_t st) {
+  static const bool off = getenv("STY_NO_FRAME_FOLD_TILED") != nullptr;
+  if (off)
+    hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 4 + 1, B), dim3(256), 0, st, audio, w, N, n_fft, hop,
+                       frames, sb, sc, xt);
+  else
+    hipLaunchKernelGGL(frame_fold_tiled_kernel, dim3(cdiv(frames, 32), cdiv(n_fft / 4 + 1, 32), B), dim3(256), 0, st, audio, w, N,
+                       n_fft, hop, frames, sb, sc, xt);
+}
+
 // y [B][2F][frames] -> power [B][F][frames]
 // (batch-folded: element (b, c, fr) at b*sb + c*sc + fr for both tensors)
 __global__ void power_kernel(const float* __restrict__ y, int F, int frames, size_t sb, size_t sc, float* __restrict__ p,
@@ -353,8 +419,7 @@ int launch_mel(int B, int N, const float* audio, int n_fft, int win, int hop, in
   // batch-folded layout [C][B*frames] for the intermediates (one GEMM problem with B*frames columns), folded frames
   // (even / odd parts: half the DFT multiply-adds)
   const size_t cols = (size_t)B * frames;
-  hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 4 + 1, B), dim3(256), 0, st, audio, t->window, N,
-                     n_fft, hop, frames, (size_t)frames, cols, xt);
+  launch_frame_fold(audio, t->window, B, N, n_fft, hop, frames, (size_t)frames, cols, xt, st);
   rc = dft_fold_fwd(*t, xt, cols, y, st);
   if (rc) return rc;
   hipLaunchKernelGGL(power_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, (size_t)frames, cols, p,
@@ -765,8 +830,7 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
       float* mg = side == 0 ? rb[r].t_mag : rb[r].p_mag;
       float* ph = side == 0 ? rb[r].t_phase : rb[r].p_phase;
       // batch-folded layout: (sb, sc) = (frames, B*frames) for every tensor, GEMMs over B*frames columns
-      hipLaunchKernelGGL(frame_fold_kernel, dim3(cdiv(frames, 256), n_fft / 4 + 1, B), dim3(256), 0, st, audio, t->window,
-                         N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, xt);
+      launch_frame_fold(audio, t->window, B, N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, xt, st);
       const size_t cols = (size_t)B * frames;
       rc = dft_fold_fwd(*t, xt, cols, yy, st);
       if (rc) return rc;
