@@ -180,7 +180,34 @@ __global__ void row_axpb_kernel(const float* __restrict__ x, const float* __rest
   const size_t o = (size_t)row * T + t;
   dx[o] += c0[row] + c1[row] * x[o];
 }
+// T % 4 == 0, 16-byte aligned: four elements per thread over the flattened (row, group) list (at T = 520 the grid above
+// has three workgroups per row, the third with eight live threads, and moves four bytes per lane)
+__global__ __launch_bounds__(256) void row_axpb4_kernel(const float* __restrict__ x, const float* __restrict__ c0,
+                                                        const float* __restrict__ c1, unsigned T4, unsigned n4,
+                                                        float* __restrict__ dx) {
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= n4) return;
+  const unsigned row = idx / T4;
+  const float a = c0[row], b = c1[row];
+  const float4 xv = reinterpret_cast<const float4*>(x)[idx];
+  float4 d = reinterpret_cast<float4*>(dx)[idx];
+  d.x += a + b * xv.x;
+  d.y += a + b * xv.y;
+  d.z += a + b * xv.z;
+  d.w += a + b * xv.w;
+  reinterpret_cast<float4*>(dx)[idx] = d;
+}
+static inline bool vec4_ok(size_t n4, int T, const void* p0, const void* p1, const void* p2 = nullptr) {
+  return T % 4 == 0 && n4 < ((size_t)1 << 31) && ((((size_t)p0 | (size_t)p1 | (size_t)p2) & 15) == 0);
+}
 int launch_row_axpb(const float* x, const float* c0, const float* c1, int rows, int T, float* dx, hipStream_t st) {
+  const size_t n4 = (size_t)rows * (T / 4);
+  if (vec4_ok(n4, T, x, dx)) {
+    hipLaunchKernelGGL(row_axpb4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, c0, c1, (unsigned)(T / 4),
+                       (unsigned)n4, dx);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   hipLaunchKernelGGL(row_axpb_kernel, dim3(cdiv(T, 256), rows), dim3(256), 0, st, x, c0, c1, T, dx);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -410,7 +437,41 @@ __global__ void act_fwd_kernel(int kind, const float* __restrict__ x, const floa
   else if (kind == ACT_GELU) r = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
   y[o] = r;
 }
+__device__ __forceinline__ float act_apply1(int kind, float v, float al, float ral) {
+  float r = v;
+  if (kind == ACT_RELU) r = fmaxf(v, 0.f);
+  else if (kind == ACT_SWISH) r = v / (1.f + expf(-v));
+  else if (kind == ACT_SNAKE) r = sty_snake(v, al, ral);
+  else if (kind == 100) r = tanhf(v);
+  else if (kind == ACT_GELU) r = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  return r;
+}
+// every kind but GLU, T % 4 == 0: four elements per thread over the flattened tensor (see row_axpb4_kernel)
+__global__ __launch_bounds__(256) void act_fwd4_kernel(int kind, const float* __restrict__ x, const float* __restrict__ alpha,
+                                                       unsigned C, unsigned T4, unsigned n4, float* __restrict__ y) {
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= n4) return;
+  float al = 1.f, ral = 1.f;
+  if (kind == ACT_SNAKE) {
+    al = alpha[(idx / T4) % C];
+    ral = 1.f / al;
+  }
+  const float4 v = reinterpret_cast<const float4*>(x)[idx];
+  float4 r;
+  r.x = act_apply1(kind, v.x, al, ral);
+  r.y = act_apply1(kind, v.y, al, ral);
+  r.z = act_apply1(kind, v.z, al, ral);
+  r.w = act_apply1(kind, v.w, al, ral);
+  reinterpret_cast<float4*>(y)[idx] = r;
+}
 int launch_act_fwd(int kind, const float* x, const float* alpha, int B, int C, int T, float* y, hipStream_t st) {
+  const size_t n4 = (size_t)B * C * (T / 4);
+  if (kind != ACT_GLU && T % 4 == 0 && n4 < ((size_t)1 << 31) && ((((size_t)x | (size_t)y) & 15) == 0)) {
+    hipLaunchKernelGGL(act_fwd4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, kind, x, alpha, (unsigned)C,
+                       (unsigned)(T / 4), (unsigned)n4, y);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   hipLaunchKernelGGL(act_fwd_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, kind, x, alpha, C, T, y);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -477,7 +538,27 @@ __global__ void row_scale_add_kernel(const float* __restrict__ src, const float*
   const size_t o = (size_t)row * T + t;
   dst[o] += src[o] * (coef ? coef[row] : k);
 }
+__global__ __launch_bounds__(256) void row_scale_add4_kernel(const float* __restrict__ src, const float* __restrict__ coef,
+                                                             float k, unsigned T4, unsigned n4, float* __restrict__ dst) {
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= n4) return;
+  const float f = coef ? coef[idx / T4] : k;
+  const float4 sv = reinterpret_cast<const float4*>(src)[idx];
+  float4 d = reinterpret_cast<float4*>(dst)[idx];
+  d.x += sv.x * f;
+  d.y += sv.y * f;
+  d.z += sv.z * f;
+  d.w += sv.w * f;
+  reinterpret_cast<float4*>(dst)[idx] = d;
+}
 int launch_row_scale_add(const float* src, const float* coef, float k, int rows, int T, float* dst, hipStream_t st) {
+  const size_t n4 = (size_t)rows * (T / 4);
+  if (vec4_ok(n4, T, src, dst)) {
+    hipLaunchKernelGGL(row_scale_add4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, coef, k,
+                       (unsigned)(T / 4), (unsigned)n4, dst);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   hipLaunchKernelGGL(row_scale_add_kernel, dim3(cdiv(T, 256), rows), dim3(256), 0, st, src, coef, k, T, dst);
   STY_LAUNCH_CHECK();
   return STY_OK;
