@@ -376,14 +376,27 @@ __global__ __launch_bounds__(256) void grn_bwd_kernel(const double* __restrict__
   __shared__ float gxs[1024];
   __shared__ double red[2][4];
   const int b = blockIdx.x;
-  double acc[1] = {0.0};
-  for (int c = threadIdx.x; c < C4; c += 256) {
-    double sq = 0.0;
-    for (int k = 0; k < nseg; ++k) sq += part[(((size_t)b * C4 + c) * nseg + k) * 2 + 1];
-    const float gx = (float)sqrt(sq);
-    gxs[c] = gx;
-    acc[0] += gx;
+  // ||h||^2 per channel: a wave per channel, lanes over the row's segments (one thread per channel walking the 150
+  // segments of a 75T-rate row alone made this 50 us of latency, sixteen times per step, on a tensor of a few KB)
+  if (nseg < 32) {  // short rows (decoder, T = 520: three segments, 1024 channels): a thread per channel
+    for (int c = threadIdx.x; c < C4; c += 256) {
+      double sq = 0.0;
+      for (int k = 0; k < nseg; ++k) sq += part[(((size_t)b * C4 + c) * nseg + k) * 2 + 1];
+      gxs[c] = (float)sqrt(sq);
+    }
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C4; c += 4) {
+      const double* pp = part + ((size_t)b * C4 + c) * nseg * 2 + 1;
+      double sq = 0.0;
+      for (int k = lane; k < nseg; k += 64) sq += pp[(size_t)k * 2];
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+      if (lane == 0) gxs[c] = (float)sqrt(sq);
+    }
   }
+  __syncthreads();
+  double acc[1] = {0.0};
+  for (int c = threadIdx.x; c < C4; c += 256) acc[0] += gxs[c];
   __shared__ float mean_s, dot_s;
   block_sum<1>(acc, red);
   if (threadIdx.x == 0) mean_s = (float)(acc[0] / C4);
