@@ -246,6 +246,96 @@ int launch_adain_stats(const double* part, int nseg, int rows, int T, float eps,
 // TC time columns x (256/TC) channel groups per workgroup; the per-column sums are combined through LDS in a fixed
 // order.  TC = 16 keeps >= 160 workgroups in flight for the short tensors (stage A: T = 160; text encoder: L ~ 40);
 // the first version ran one THREAD per column over all channels and left most of the chip idle there.
+// The same kernel with the workgroup's tile of x and of the masked / gated gradient held in registers (NR channels per
+// thread: C <= NR * 256 / TC): one read of x, dy (and y) instead of four / two through 64-byte row segments.  Same
+// mapping of channels to threads and same order of every sum as chan_ln_bwd_dx_kernel (equal up to fma contraction).
+template <int TC, int NR>
+__global__ __launch_bounds__(256) void chan_ln_bwd_dx_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ y, int C, int T, float eps,
+                                                                 int ada, const float* __restrict__ w,
+                                                                 const float* __restrict__ gb, int relu,
+                                                                 const float* __restrict__ out_mask,
+                                                                 float* __restrict__ dx, int accumulate,
+                                                                 float* __restrict__ mu_out, float* __restrict__ r_out) {
+  constexpr int CG = 256 / TC;
+  __shared__ float red[2][CG][TC];
+  const int col = threadIdx.x % TC, cg = threadIdx.x / TC;
+  const int t = blockIdx.x * TC + col, b = blockIdx.y;
+  const bool in = t < T;
+  const size_t base = (size_t)b * C * T + (in ? t : 0);
+  auto combine = [&](float a, float bb, float& ra, float& rb) {
+    red[0][cg][col] = a;
+    red[1][cg][col] = bb;
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CG; ++k) {
+      s0 += red[0][k][col];
+      s1 += red[1][k][col];
+    }
+    __syncthreads();
+    ra = s0;
+    rb = s1;
+  };
+  const float om = (in && out_mask) ? out_mask[(size_t)b * T + t] : 1.f;
+  float xr[NR], gr[NR];  // x and g A (the gradient after mask, ReLU gate and scale)
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int c = cg + i * CG;
+    xr[i] = gr[i] = 0.f;
+    if (in && c < C) {
+      const size_t o = base + (size_t)c * T;
+      xr[i] = x[o];
+      float g = dy[o] * om;
+      if (relu && !(y[o] > 0.f)) g = 0.f;
+      const float A = ada ? 1.f + gb[(size_t)b * 2 * C + c] : w[c];
+      gr[i] = g * A;
+    }
+  }
+  float p0 = 0.f, p1 = 0.f, mean, dummy;
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (in && cg + i * CG < C) p0 += xr[i];
+  combine(p0, 0.f, mean, dummy);
+  mean /= (float)C;
+  p0 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (in && cg + i * CG < C) {
+      const float d = xr[i] - mean;
+      p0 += d * d;
+    }
+  float var;
+  combine(p0, 0.f, var, dummy);
+  const float r = 1.0f / sqrtf(var / (float)C + eps);
+  p0 = p1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (in && cg + i * CG < C) {
+      const float dxh = gr[i], xh = (xr[i] - mean) * r;
+      p0 += dxh;
+      p1 += dxh * xh;
+    }
+  float s1, s2;
+  combine(p0, p1, s1, s2);
+  s1 /= (float)C;
+  s2 /= (float)C;
+  if (!in) return;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int c = cg + i * CG;
+    if (c < C) {
+      const size_t o = base + (size_t)c * T;
+      const float xh = (xr[i] - mean) * r;
+      const float d = r * (gr[i] - s1 - xh * s2);
+      dx[o] = accumulate ? dx[o] + d : d;
+    }
+  }
+  if (cg == 0) {
+    mu_out[(size_t)b * T + t] = mean;
+    r_out[(size_t)b * T + t] = r;
+  }
+}
 template <int TC>
 __global__ __launch_bounds__(256) void chan_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ y, int C, int T, float eps,
@@ -354,7 +444,11 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __r
 int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,
                        const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
                        float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st) {
-  if ((size_t)B * T >= 65536)
+  static const bool noreg = getenv("STY_NO_LN_BWD_REG") != nullptr;
+  if ((size_t)B * T < 65536 && C <= 256 && !noreg)
+    hipLaunchKernelGGL((chan_ln_bwd_dx_reg_kernel<16, 16>), dim3(cdiv(T, 16), B), dim3(256), 0, st, x, dy, y, C, T, eps, ada, w,
+                       gb, relu, out_mask, dx, accumulate, mu_tmp, r_tmp);
+  else if ((size_t)B * T >= 65536)
     hipLaunchKernelGGL(chan_ln_bwd_dx_kernel<64>, dim3(cdiv(T, 64), B), dim3(256), 0, st, x, dy, y, C, T, eps, ada, w, gb,
                        relu, out_mask, dx, accumulate, mu_tmp, r_tmp);
   else
