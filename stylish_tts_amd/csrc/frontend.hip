@@ -480,9 +480,16 @@ __device__ __forceinline__ float aw_res(float x) { return x - 6.2831853071795864
 // sums[r*5 + {0: sum|T-P|, 1: sum|T|, 2: sum aw0 W, 3: sum aw1 W, 4: sum aw2 W}]  (double atomics)
 __global__ __launch_bounds__(256) void loss_sums_kernel(ResBufs rb, int r, int B, double* __restrict__ sums) {
   __shared__ double red[5][4];
+  __shared__ float wtab[1025];  // the frequency weights, once per workgroup (a double-precision exp per ELEMENT, ten
+                                // million of them per resolution, and two 64-bit divisions made this 0.2 ms per launch)
   const int F = rb.F, fr = rb.frames;
   const size_t nph = (size_t)B * F * fr, nmag = (size_t)B * 128 * fr;
   const double lb = log(2.5) / (double)(F / 2);
+  const bool tab = F <= 1025 && nph < ((size_t)1 << 31);
+  if (tab) {
+    for (int f = threadIdx.x; f < F; f += 256) wtab[f] = (float)exp(lb * f);
+    __syncthreads();
+  }
   double acc[5] = {0, 0, 0, 0, 0};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nmag; i += (size_t)gridDim.x * 256) {
     acc[0] += fabsf(rb.t_mag[i] - rb.p_mag[i]);
@@ -490,8 +497,18 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(ResBufs rb, int r, int B
   }
   const size_t fs = (size_t)B * fr;  // batch-folded layout [F][B][frames]: frequency stride
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nph; i += (size_t)gridDim.x * 256) {
-    const int t = (int)(i % fr), f = (int)(i / fs);
-    const float w = (float)exp(lb * f);
+    int t, f;
+    float w;
+    if (tab) {
+      const unsigned iu = (unsigned)i;
+      t = (int)(iu % (unsigned)fr);
+      f = (int)(iu / (unsigned)fs);
+      w = wtab[f];
+    } else {
+      t = (int)(i % fr);
+      f = (int)(i / fs);
+      w = (float)exp(lb * f);
+    }
     const float d0 = rb.p_phase[i] - rb.t_phase[i];
     acc[2] += fabsf(aw_res(d0)) * w;
     if (f + 1 < F) {
@@ -544,7 +561,14 @@ __global__ void loss_grad_kernel(ResBufs rb, int r, int B, const double* __restr
   if (i < nmag) rb.d_mag[i] = -kmel * sgnf(rb.t_mag[i] - rb.p_mag[i]);
   if (i < nph) {
     const size_t fs = (size_t)B * fr;
-    const int t = (int)(i % fr), f = (int)(i / fs);
+    int t, f;
+    if (nph < ((size_t)1 << 31)) {
+      t = (int)((unsigned)i % (unsigned)fr);
+      f = (int)((unsigned)i / (unsigned)fs);
+    } else {
+      t = (int)(i % fr);
+      f = (int)(i / fs);
+    }
     const double lb = log(2.5) / (double)(F / 2);
     const float w = (float)exp(lb * f), wm = f > 0 ? (float)exp(lb * (f - 1)) : 0.f;
     const float n0 = 1.0f / ((float)B * F * fr), n1 = 1.0f / ((float)B * (F - 1) * fr),
@@ -842,7 +866,7 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
       hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mg, n);
     }
     if (target_only) continue;
-    hipLaunchKernelGGL(loss_sums_kernel, dim3(256), dim3(256), 0, st, rb[r], r, B, sums);
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(1024), dim3(256), 0, st, rb[r], r, B, sums);
     if (gan) {  // target |X| (scratch) and predicted |X| are both live here, in the batch-folded layout [F][B][frames]
       STY_HIP(hipMemsetAsync(d_gan[r], 0, (size_t)B * F * frames * sizeof(float), st));
       rc = specdisc_run(gan->p[r], B, F, frames, (size_t)frames, (size_t)B * frames, tfft, rb[r].p_fft, nullptr, nullptr,
