@@ -19,6 +19,7 @@ namespace sty {
 
 struct FrontTables {
   float* window = nullptr;  // [n_fft] (hann(win) zero-padded centred)
+  float* wfreq = nullptr;   // [F] frequency weights of the multi-phase loss, exp(f ln 2.5 / (F / 2)) (loss_grad_kernel)
   PackedConv dft;           // [n_fft] -> [re_0..re_F-1, im_0..im_F-1]
   PackedConv fb;            // [F] -> [n_mels]
   PackedConv dftT;          // backward: [2F] -> [n_fft]   (transposed basis)
@@ -42,6 +43,10 @@ __global__ void transpose_pack_kernel(const float* __restrict__ w, int rows, int
   if (c < cols) wt[(size_t)c * rowsP + r] = w[(size_t)r * colsP + c];
 }
 
+__global__ void freq_weight_kernel(float* __restrict__ w, int F) {  // the expression loss_sums_kernel evaluates per row
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f < F) w[f] = (float)exp(log(2.5) / (double)(F / 2) * f);
+}
 __global__ void window_kernel(float* __restrict__ w, int n_fft, int win) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= n_fft) return;
@@ -126,6 +131,10 @@ static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream
   STY_HIP(hipMalloc((void**)&f, fn * sizeof(float)));
   STY_HIP(hipMemsetAsync(d, 0, dn * sizeof(float), st));
   STY_HIP(hipMemsetAsync(f, 0, fn * sizeof(float), st));
+  float* wq;
+  STY_HIP(hipMalloc((void**)&wq, F * sizeof(float)));
+  hipLaunchKernelGGL(freq_weight_kernel, dim3(cdiv(F, 256)), dim3(256), 0, st, wq, F);
+  t.wfreq = wq;
   hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_fft, 256)), dim3(256), 0, st, w, n_fft, win);
   hipLaunchKernelGGL(dft_basis_kernel, dim3(cdiv(2 * F, 256), n_fft), dim3(256), 0, st, d, n_fft, F, t.dft.CoutP);
   hipLaunchKernelGGL(mel_fb_kernel, dim3(cdiv(n_mels, 64), F), dim3(64), 0, st, f, F, n_mels, sample_rate, t.fb.CoutP);
@@ -472,6 +481,7 @@ int launch_multispec_single(int B, int N, const float* audio, int n_fft, int hop
 struct ResBufs {  // per resolution, all [B][.][frames]
   float *t_mag, *t_phase, *p_mag, *p_phase, *p_fft, *p_y;  // p_y = predicted re/im [B][2F][frames]
   float *d_mag, *d_phase;
+  const float* wfreq;  // FrontTables::wfreq of the resolution
   int n_fft, hop, F, frames;
 };
 
@@ -569,8 +579,7 @@ __global__ void loss_grad_kernel(ResBufs rb, int r, int B, const double* __restr
       t = (int)(i % fr);
       f = (int)(i / fs);
     }
-    const double lb = log(2.5) / (double)(F / 2);
-    const float w = (float)exp(lb * f), wm = f > 0 ? (float)exp(lb * (f - 1)) : 0.f;
+    const float w = rb.wfreq[f], wm = f > 0 ? rb.wfreq[f - 1] : 0.f;  // (two double-precision exps per element before)
     const float n0 = 1.0f / ((float)B * F * fr), n1 = 1.0f / ((float)B * (F - 1) * fr),
                 n2 = 1.0f / ((float)B * F * (fr - 1));
     auto D = [&](size_t j) { return rb.p_phase[j] - rb.t_phase[j]; };
@@ -888,6 +897,7 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
     const int frames = rb[r].frames, F = rb[r].F, n_fft = rb[r].n_fft;
     const size_t nph = (size_t)B * F * frames, nmag = (size_t)B * 128 * frames;
     const size_t nmax = nph > nmag ? nph : nmag;
+    rb[r].wfreq = t->wfreq;
     hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, st, rb[r], r, B, sums,
                        losses_out, w_mel, w_phase);
     hipLaunchKernelGGL(log1p_bwd_kernel, dim3((unsigned)((nmag + 255) / 256)), dim3(256), 0, st, rb[r].d_mag,
