@@ -15,7 +15,13 @@
 namespace sty {
 
 constexpr int WG_TW = 128;      // time samples per chunk
-static const int WG_TARGET = getenv("STY_WG_TARGET") ? atoi(getenv("STY_WG_TARGET")) : 1024;  // workgroups per launch aimed at (4 per CU): the (batch, time) list is split to get there
+// workgroups per launch aimed at: the (batch, time) list is split to get there.  4 per CU in the fp32 modes; 3 per CU in the
+// bf16 mode, whose weight-gradient kernels share the chip with a main stream of much shorter kernels (c3, one A/B run:
+// 61.3-61.6 ms at 1024, 61.05-61.2 at 768, 61.0-61.4 at 640, 61.5 at 896, 62.2 at 1536; c2 (fp32): 32.7 at 1024, 32.8 at 768).
+// The scratch for the partial planes is sized for the larger count (wgrad_partial_floats).
+static const int WG_TARGET_ENV = getenv("STY_WG_TARGET") ? atoi(getenv("STY_WG_TARGET")) : 0;
+static const int WG_TARGET = WG_TARGET_ENV ? WG_TARGET_ENV : 1024;
+static inline int wg_target(bool bf16) { return WG_TARGET_ENV ? WG_TARGET_ENV : (bf16 ? 768 : 1024); }
 
 // BF (all weight-gradient kernels): bf16 compute mode, see conv1d.hip -- each lane reads eight consecutive time samples
 // of its row from LDS, rounds them to bf16 and issues one v_mfma_f32_32x32x16_bf16 per 16 samples.
@@ -408,10 +414,11 @@ static bool wgrad64_ok(const PackedConv& w, int dil) {
 static bool wgrad64_operands_ok(const ConvArgs& fwd) {
   return (fwd.flatW || fwd.nsrc == 1) && fwd.in_shuffle <= 1 && fwd.shuffle <= 1;
 }
-static int wgrad64_nsplit(const PackedConv& w, int B, int T) {
+static int wgrad64_nsplit(const PackedConv& w, int B, int T, bool bf16 = false) {
   const int tiles = cdiv(w.CinP, 64) * cdiv(w.CoutP, 64);
   const int chunks = B * cdiv(T, WG_TW);
-  int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
+  const int target = wg_target(bf16);
+  int nsplit = cdiv(tiles >= 16 ? target : target / 2, tiles);
   if (nsplit >= 8) nsplit = (nsplit + 7) & ~7;  // a multiple of 8: wgradb_kernel then keeps the blocks of a split on one XCD
   if (nsplit > chunks) nsplit = chunks;
   return nsplit;
@@ -617,10 +624,10 @@ static W1Cfg w1_cfg(const PackedConv& w, int B, int T) {
   if (w.CoutP <= 32) return {128, 32};
   return {64, 64};
 }
-static int w1_nsplit(const PackedConv& w, int B, int T, W1Cfg c) {
+static int w1_nsplit(const PackedConv& w, int B, int T, W1Cfg c, bool bf16 = false) {
   const int tiles = cdiv(w.CinP, c.TI) * cdiv(w.CoutP, c.TO);
   const int chunks = B * cdiv(T, W1_TW);
-  int nsplit = cdiv(WG_TARGET, tiles);
+  int nsplit = cdiv(wg_target(bf16), tiles);
   if (nsplit > chunks) nsplit = chunks;
   return nsplit;
 }
@@ -730,7 +737,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   ag.mask = gmask;
   if (w.K == 1) {
     const W1Cfg c = w1_cfg(w, fwd.B, fwd.T);
-    const int nsplit = w1_nsplit(w, fwd.B, fwd.T, c);
+    const int nsplit = w1_nsplit(w, fwd.B, fwd.T, c, fwd.bf16 != 0);
     const int cpb = cdiv(fwd.T, W1_TW);
     ag.pad = 0;
     ConvArgs ax1 = fwd;
@@ -792,7 +799,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   }
   if (wgrad64_ok(w, fwd.dil) && wgrad64_operands_ok(fwd) && wgradb_eligible(ax, gmask != nullptr)) {
     const int chunks = wgradb_chunks(w, fwd.B, fwd.T, fwd.dil);
-    int ns = wgrad64_nsplit(w, fwd.B, fwd.T);
+    int ns = wgrad64_nsplit(w, fwd.B, fwd.T, fwd.bf16 != 0);
     if (ns > chunks) ns = chunks;
     const int wb = gbias != nullptr;
     int rc = launch_wgradb(ax, ag, ns, partial, wb, st);
@@ -804,7 +811,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     return STY_OK;
   }
   if (wgrad64_ok(w, fwd.dil) && wgrad64_operands_ok(fwd)) {
-    const int nsplit = wgrad64_nsplit(w, fwd.B, fwd.T);
+    const int nsplit = wgrad64_nsplit(w, fwd.B, fwd.T, fwd.bf16 != 0);
     const int cpb = cdiv(fwd.T, WG_TW);
     const int halo = (w.K - 1) * fwd.dil;
     const size_t lds = ((size_t)64 * ((WG_TW + halo) | 1) + (size_t)64 * (WG_TW + 1)) * sizeof(float);
@@ -844,7 +851,8 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks_per_b = cdiv(fwd.T, WG_TW);
   const int chunks = fwd.B * chunks_per_b;
-  int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);
+  const int target = wg_target(fwd.bf16 != 0);
+  int nsplit = cdiv(tiles >= 16 ? target : target / 2, tiles);
   if (nsplit > chunks) nsplit = chunks;
   // flat 2-D conv with 32 output channels (the spectrogram discriminators' 3x5 / 3x3 layers): one many-tap 32x32 launch
   // per image row of the window -- row kh is the plain 1-D weight gradient against x shifted by (kh - hpad) rows -- summed
