@@ -456,16 +456,20 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   if (a.w.CoutP % 64 == 0) {
     const long tiles64 = (long)cdiv(a.T, 256) * (a.w.CoutP / 64) * a.B;
     if (tiles64 >= 512) return launch_cfg<1, 4, 2, 2>(a, st);
-    // 64 couts x 64 time; with few workgroups and a long reduction, two (or, below one workgroup per CU and from 8
-    // chunks up, four) wave groups split the reduction
+    // 64 couts x 64 time; with few workgroups (<= one per CU) and a long reduction two wave groups split the reduction,
+    // with very few (<= 64) and from 8 chunks up, four
     static const bool ks_on = getenv("STY_NO_KSPLIT") == nullptr;
     const long wgs = (long)cdiv(a.T, 64) * (a.w.CoutP / 64) * a.B;
-    static const int ks4_wgs = getenv("STY_KS4_WGS") ? atoi(getenv("STY_KS4_WGS")) : 256;
+    // thresholds re-tuned at the end of round 3 with both workloads in one call (ms per step, c3 / c2): KS2 <= 768 and
+    // KS4 <= 256 (round 2): 60.95 / 33.0; 384 / 64: 60.9 / 33.1; 256 / 64: 60.6-61.1 / 31.5-31.7; 256 / 32: 60.8 / 32.1;
+    // 256 / 0: 61.0 / 33.1; 192 / 64: 60.5-60.7 / 31.9-32.1; no split at all: 60.9-61.1 / 34.3
+    static const int ks4_wgs = getenv("STY_KS4_WGS") ? atoi(getenv("STY_KS4_WGS")) : 64;
     // (not for the DFT GEMMs of the front end / losses, ksplit_max = 2: their phase outputs are pinned at a wrapped
     // tolerance that a different summation order moves at the magnitude gate -- n_fft 2048: 7e-3 vs 5e-3)
     if (ks_on && wgs <= ks4_wgs && a.ksplit_max >= 4 && a.w.CinP >= 8 * CI_CHUNK && a.pro != PRO_LN_AFFINE)
       return launch_cfg<2, 2, 1, 1, 4>(a, st);
-    if (ks_on && wgs <= 768 && a.w.CinP >= 4 * CI_CHUNK && a.pro != PRO_LN_AFFINE) return launch_cfg<2, 2, 1, 1, 2>(a, st);
+    static const int ks2_wgs = getenv("STY_KS2_WGS") ? atoi(getenv("STY_KS2_WGS")) : 256;
+    if (ks_on && wgs <= ks2_wgs && a.w.CinP >= 4 * CI_CHUNK && a.pro != PRO_LN_AFFINE) return launch_cfg<2, 2, 1, 1, 2>(a, st);
     return launch_cfg<2, 2, 1, 1>(a, st);
   }
   // 32-cout blocks: at the 75T frame rate use 8 waves on a 512-sample tile (2 workgroups = 16 waves per CU, halo
