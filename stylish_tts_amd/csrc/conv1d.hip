@@ -448,14 +448,17 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   // Tile choice: the biggest output tile that still gives the chip >= ~2 workgroups per CU; the 256-channel stage
   // runs at T <= 800 frames, where 128x128 tiles would launch ~100 workgroups on 256 CUs.
   const long tiles128 = (long)cdiv(a.T, 128) * (a.w.CoutP / 128) * a.B;
+  static const long t128_min = getenv("STY_T128_TILES") ? atol(getenv("STY_T128_TILES")) : 512;
+  static const long t64_min = getenv("STY_T64_TILES") ? atol(getenv("STY_T64_TILES")) : 512;
+  static const long t32_min = getenv("STY_T32_TILES") ? atol(getenv("STY_T32_TILES")) : 512;
   if (a.act == ACT_GLU) {
-    if (a.w.CoutP % 128 == 0 && tiles128 >= 512) return launch_cfg<2, 2, 2, 2>(a, st);
+    if (a.w.CoutP % 128 == 0 && tiles128 >= t128_min) return launch_cfg<2, 2, 2, 2>(a, st);
     return launch_cfg<1, 4, 2, 1>(a, st);  // 64 packed couts (value+gate) x 128 time
   }
-  if (a.w.CoutP % 128 == 0 && tiles128 >= 512) return launch_cfg<2, 2, 2, 2>(a, st);
+  if (a.w.CoutP % 128 == 0 && tiles128 >= t128_min) return launch_cfg<2, 2, 2, 2>(a, st);
   if (a.w.CoutP % 64 == 0) {
     const long tiles64 = (long)cdiv(a.T, 256) * (a.w.CoutP / 64) * a.B;
-    if (tiles64 >= 512) return launch_cfg<1, 4, 2, 2>(a, st);
+    if (tiles64 >= t64_min) return launch_cfg<1, 4, 2, 2>(a, st);
     // 64 couts x 64 time; with few workgroups (<= one per CU) and a long reduction two wave groups split the reduction,
     // with very few (<= 64) and from 8 chunks up, four
     static const bool ks_on = getenv("STY_NO_KSPLIT") == nullptr;
@@ -475,7 +478,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   // 32-cout blocks: at the 75T frame rate use 8 waves on a 512-sample tile (2 workgroups = 16 waves per CU, halo
   // overhead halved); short sequences keep the 4-wave 256-sample tile for grid size.
   static const bool w8 = getenv("STY_CO32_W4") == nullptr;  // A/B switch; 8 waves measured 73 vs 69 TF on config c5
-  if (w8 && (long)cdiv(a.T, 512) * (a.w.CoutP / 32) * a.B >= 512) return launch_cfg<1, 8, 1, 2>(a, st);
+  if (w8 && (long)cdiv(a.T, 512) * (a.w.CoutP / 32) * a.B >= t32_min) return launch_cfg<1, 8, 1, 2>(a, st);
   return launch_cfg<1, 4, 1, 2>(a, st);
 }
 
