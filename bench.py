@@ -148,6 +148,36 @@ def pmc_traffic(family, workload):
     return None, None
 
 
+def rocprof_avg_us(family, workload):
+    """Average launch duration (us) of a kernel family in the committed rocprofv3 --kernel-trace --stats summary of this
+    same command (profiles/*_<workload>_kernel_stats.txt, tools/profile_round.sh), launch-weighted over the family's
+    instantiations -- the figure `roofline.avg_launch_us` (HIP events, live) has to agree with in order of magnitude; the
+    event time is taken on a chip the kernel shares with three other streams and includes queueing behind them."""
+    import glob
+    import re
+    key = re.sub(r"\s+", "", family)
+    base, _, targs = key.partition("<")
+    first = targs.split(",")[0].rstrip(">")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_kernel_stats.txt")), reverse=True):
+        tot = n = 0.0
+        try:
+            lines = open(f).read().splitlines()
+        except Exception:
+            continue
+        for ln in lines:
+            parts = ln.split(None, 4)
+            if len(parts) < 5 or not parts[0].isdigit():
+                continue
+            kk = re.sub(r"\s+", "", parts[4])
+            m = re.search(r"(?:sty::)?" + re.escape(base) + (r"<([^,>]+)" if targs else r"\b"), kk)
+            if m and (not targs or m.group(1) == first):
+                tot += float(parts[1])
+                n += int(parts[0])
+        if n:
+            return tot / n, os.path.relpath(f, ROOT)
+    return None, None
+
+
 def _usable_cpus():
     """cores this process may actually use: affinity mask intersected with the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -450,6 +480,12 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                            "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                            "avg_launch_us": per * 1e6, "launches": dom["launches"],
+                           "avg_launch_us_is": "HIP events on the launch stream inside the timed region: the kernel shares the "
+                                               "chip with up to three other streams, so this includes queueing behind them; "
+                                               "rocprof_avg_launch_us is the committed rocprofv3 --kernel-trace --stats average "
+                                               "of the same command, single_stream.avg_launch_us the kernel alone on the chip",
+                           "rocprof_avg_launch_us": rocprof_avg_us(dom["name"], name)[0],
+                           "rocprof_source": rocprof_avg_us(dom["name"], name)[1],
                            "mfma_TFLOPs": tf, "mfma_peak": peak, "mfma_frac": f_mfma,
                            "hbm_GBps_algorithmic": gbs, "hbm_frac": f_hbm,
                            "share_of_step_time": dom["ms"] / (1e3 * dt)}
@@ -469,6 +505,33 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                  "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
                  "GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
                 for r in sorted(serial_prof, key=lambda r: -r["ms"])[:40]]
+        # the same table grouped by kernel NAME (all instantiations of a template together): the legacy tiled conv kernel
+        # is the largest family of the step by name and no single instantiation of it shows that
+        by_name = {}
+        for r in warm_prof:
+            b = by_name.setdefault(r["name"].split("<")[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            b["launches"] += r["launches"]
+            b["ms"] += r["ms"]
+            b["flops"] += r["flops"]
+            b["bytes"] += r["bytes"]
+        rec["kernels_by_name"] = [
+            {"name": k, "launches": v["launches"], "ms_per_step": v["ms"] / nprof,
+             "TFLOPs": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0,
+             "GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0.0}
+            for k, v in sorted(by_name.items(), key=lambda kv: -kv[1]["ms"])]
+        # step level: algorithmic flops and bytes of every instrumented family of ONE step (the GEMM-like families and the
+        # large element-wise ones carry a model; the small element-wise kernels do not and are not counted) against the
+        # step time -- the honest whole-step position under both roofs
+        sflops = sum(r["flops"] for r in warm_prof) / nprof
+        sbytes = sum(r["bytes"] for r in warm_prof) / nprof
+        step_s = dt / steps
+        peak_step = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
+        rec["roofline_step"] = {
+            "what": "sum over the instrumented kernel families of one step / ms_per_step",
+            "algorithmic_TFLOP_per_step": sflops / 1e12, "algorithmic_GB_per_step": sbytes / 1e9,
+            "TFLOPs": sflops / step_s / 1e12, "mfma_peak": peak_step, "mfma_frac": sflops / step_s / 1e12 / peak_step,
+            "GBps": sbytes / step_s / 1e9, "hbm_peak": PEAK_HBM_GBS, "hbm_frac": sbytes / step_s / 1e9 / PEAK_HBM_GBS,
+            "launches_instrumented": sum(r["launches"] for r in warm_prof) // nprof}
         rec["kernels_source"] = "HIP events over one untimed step after the warm-up; roofline: over the timed region"
         rec["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / nprof,
                            "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
@@ -566,12 +629,40 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    rccl1 = None
+    if world == 1 and args.workload == "c3" and not args.no_extra and not share:
+        # RCCL under the step on a 1-GPU box: backend "nccl" with ONE rank and the gradient exchange forced
+        # (STY_DIST_FORCE_COLLECTIVE=1, dist.force_collective): every bucket goes through all_reduce(async_op=True) from the
+        # library's gradient hooks, RCCL's streams run beside the trainer's four under GPU_MAX_HW_QUEUES=2.
+        import socket
+        try:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            os.environ.update(STY_DIST_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+                              WORLD_SIZE="1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            D.init("nccl")
+            r = run_workload("c3", min(args.steps, 10), min(args.warmup, 3), 0, 1, device, lib, L, D, share, serial_pass=False)
+            rccl1 = {"what": "the c3 step with backend nccl (RCCL), world size 1, every gradient bucket all-reduced "
+                             "(STY_DIST_FORCE_COLLECTIVE=1) -- the collective path of an N-GPU run minus the wire",
+                     "ms_per_step": r["ms_per_step"], "vs_no_process_group": r["ms_per_step"] / rec["ms_per_step"],
+                     "host_issue_ms_per_step": r["host_issue_ms_per_step"],
+                     "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        except Exception as e:  # never fail the bench line on this
+            rccl1 = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            os.environ.pop("STY_DIST_FORCE_COLLECTIVE", None)
     if rank != 0:
         return
     rec["library"] = lib_info
     rec["ranks"] = {"world_size": world, "launcher": "torch.distributed.run, one process per GPU" if world > 1 else "single process",
                     "backend": (backend + (" (RCCL)" if not share else " (share-device test aid)")) if world > 1 else None,
                     "devices": 1 if share else world}
+    if rccl1 is not None:
+        rec["ranks"]["rccl_world1"] = rccl1
     if extras:
         rec["extra"] = extras
     if not args.no_cpu_baseline and world == 1:

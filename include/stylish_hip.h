@@ -261,7 +261,7 @@ int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
 int sty_style_prepare_train(sty_model *m, void *stream);
 /* Parity taps of the last sty_style_fwd_train / sty_pitch_style_fwd_train: index 0 = the stem conv's output, 1..4 = the
  * ResBlk outputs (mel_style_encoder.py:96-118), 5 = the 5x5 head conv's output at every position (valid where the window
- * fits).  grad = 0: the activation; grad = 1 (after sty_style_bwd): d loss / d activation.  Writes [B,C,H,W] (the library's
+ * fits), 6..9 = the input of the second LeakyReLU of ResBlk 1..4 (mel_style_encoder.py:110-113).  grad = 0: the activation; grad = 1 (after sty_style_bwd): d loss / d activation.  Writes [B,C,H,W] (the library's
  * zero pad column removed) to dst and the dimensions to C, H, W; dst = NULL only reports the dimensions.             */
 int sty_style_tap(sty_model *m, int index, int grad, float *dst, int *C, int *H, int *W, void *stream);
 /* AcousticStep.pitch_loss for one curve (train/stage_type.py:236-262: smooth_l1(target, pred) + smooth_l1 of their first

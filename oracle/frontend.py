@@ -30,11 +30,11 @@ def mel_filterbank(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
 
 def mel_spectrogram(audio, n_fft, win_length, hop, n_mels=80, sample_rate=24000):
     """MelSpectrogram(power=2, centre/reflect, periodic hann zero-padded to n_fft) (train_context.py:155-169)."""
-    win = torch.hann_window(win_length, periodic=True)
+    win = torch.hann_window(win_length, periodic=True, dtype=audio.dtype)
     spec = torch.stft(audio, n_fft, hop, win_length, window=win, center=True, pad_mode="reflect",
                       normalized=False, onesided=True, return_complex=True)
     power = spec.real ** 2 + spec.imag ** 2  # [B, F, frames]
-    fb = mel_filterbank(n_fft // 2 + 1, n_mels, sample_rate)
+    fb = mel_filterbank(n_fft // 2 + 1, n_mels, sample_rate).to(power.dtype)  # (float64 runs of the oracle: conditioning studies)
     return torch.matmul(power.transpose(1, 2), fb).transpose(1, 2)
 
 
@@ -56,11 +56,11 @@ RESOLUTIONS = ((512, 128, 512), (1024, 256, 1024), (2048, 512, 2048))  # multi_s
 def multi_spectrogram_single(audio, n_fft, hop, win_length, sample_rate=24000):
     """(log1p(mel128(|X|)), angle gated at |X|>1e-3, |X|) (multi_spectrogram.py:40-55).  Non-periodic...
     torch.hann_window default is periodic=True (multi_spectrogram.py:29)."""
-    win = torch.hann_window(win_length)
+    win = torch.hann_window(win_length, dtype=audio.dtype)
     st = torch.stft(audio, n_fft=n_fft, hop_length=hop, win_length=win_length, window=win, return_complex=True)
     fft_mag = torch.abs(st)
     phase = (fft_mag > 1e-3).detach() * torch.angle(st)
-    fb = mel_filterbank(n_fft // 2 + 1, 128, sample_rate)
+    fb = mel_filterbank(n_fft // 2 + 1, 128, sample_rate).to(fft_mag.dtype)
     mag = torch.log1p(torch.matmul(fft_mag.transpose(1, 2), fb).transpose(1, 2))
     return mag[:, None], phase, fft_mag[:, None]
 

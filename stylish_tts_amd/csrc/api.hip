@@ -2756,6 +2756,21 @@ int sty_conv1d_fwd(int B, int Cin, int Cout, int K, int dil, int T, const float*
   a.pad = (K - 1) * dil / 2;
   a.y = y;
   a.bf16 = compute_bf16 != 0;
+  if (compute_bf16 == 2) {
+    // the input as its bf16 operand twin (ConvArgs::x16), made here by the cast pass, and a twin of the OUTPUT written by
+    // the conv's output stage (ConvArgs::y16), which is read back and checked against y by ... the caller: the twin
+    // occupies the tail of the workspace, [B][Cin][T] then [B][Cout][T] bf16
+    const size_t tw = ((size_t)B * (Cin + Cout) * T) * sizeof(__bf16) + 512;
+    if (ws_bytes < need + tw) {
+      set_error("sty_conv1d_fwd: compute_bf16 = 2 needs %zu more workspace bytes for the operand twins", tw);
+      return STY_EINVAL;
+    }
+    __bf16* x16 = reinterpret_cast<__bf16*>(align_up(reinterpret_cast<size_t>(static_cast<char*>(workspace) + need), 256));
+    if ((rc = launch_twin_cast(x, nullptr, PRO_NONE, B, Cin, T, x16, S(stream)))) return rc;
+    a.x16 = x16;
+    a.y16 = x16 + (size_t)B * Cin * T;
+    a.y16_act = PRO_LRELU;
+  }
   return launch_conv1d(a, S(stream));
 }
 static PackedConv unit_conv_dims(int Cin, int Cout, int K) {
@@ -2775,6 +2790,7 @@ int sty_conv1d_bwd_workspace_bytes(int B, int Cin, int Cout, int K, int T, size_
   const PackedConv pc = unit_conv_dims(Cin, Cout, K);
   const size_t plane = (size_t)K * pc.CinP * pc.CoutP + pc.CoutP;
   *bytes = (3 * plane + wgrad_partial_floats(pc, B, T)) * sizeof(float) + 1024;  // weights, gradient, flipped weights
+  *bytes += (size_t)B * (Cin + Cout) * T * sizeof(__bf16) + 512;                   // compute_bf16 = 2: the two operand twins
   return STY_OK;
 }
 int sty_conv1d_bwd(int B, int Cin, int Cout, int K, int dil, int T, const float* x, const float* w, const float* gy,
@@ -2817,6 +2833,14 @@ int sty_conv1d_bwd(int B, int Cin, int Cout, int K, int dil, int T, const float*
   a.dil = dil;
   a.pad = (K - 1) * dil / 2;
   a.bf16 = compute_bf16 != 0;
+  if (compute_bf16 == 2) {  // bf16 operand twins of x and gy (ConvArgs::x16 / g16), made here by the cast pass
+    __bf16* x16 = reinterpret_cast<__bf16*>(align_up(reinterpret_cast<size_t>(partial + wgrad_partial_floats(pc, B, T)), 256));
+    __bf16* g16 = x16 + (size_t)B * Cin * T;
+    if ((rc = launch_twin_cast(x, nullptr, PRO_NONE, B, Cin, T, x16, st))) return rc;
+    if ((rc = launch_twin_cast(gy, nullptr, PRO_NONE, B, Cout, T, g16, st))) return rc;
+    a.x16 = x16;
+    a.g16 = g16;
+  }
   bool bias_done = false;
   rc = launch_conv1d_wgrad(a, gy, nullptr, 1.0f, gwp, partial, dbias ? gbp : nullptr, &bias_done, st);
   if (rc) return rc;
@@ -2845,6 +2869,7 @@ int sty_conv1d_bwd(int B, int Cin, int Cout, int K, int dil, int T, const float*
     d.pad = (K - 1) * dil - a.pad;
     d.bf16 = a.bf16;
     d.y = dx;
+    d.x16 = a.g16;  // (compute_bf16 = 2) the input-gradient conv reads the gradient's operand twin as well
     rc = launch_conv1d(d, st);
   }
   return rc;

@@ -409,7 +409,23 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   return STY_OK;
 }
 
+static int launch_conv1d_dispatch(const ConvArgs& a, hipStream_t st);
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
+  // ConvArgs::y16 (the bf16 operand twin of the output): convp16_kernel writes it from its output stage; for every other
+  // kernel the cast pass makes it behind the conv -- the caller gets the twin either way
+  const bool native16 = a.y16 && (stem2d_eligible(a) || (!conv32p_eligible(a) && !convk1_eligible(a) && !convk3_eligible(a) &&
+                                                         convp16_eligible(a)));
+  int rc = launch_conv1d_dispatch(a, st);
+  if (rc == STY_OK && a.y16 && !native16) {
+    if (a.shuffle > 1) {
+      set_error("conv1d: no output twin for a pixel-shuffled store");
+      return STY_EINVAL;
+    }
+    rc = launch_twin_cast(a.y, nullptr, a.y16_act, a.B, a.w.Cout, a.T, a.y16, st);
+  }
+  return rc;
+}
+static int launch_conv1d_dispatch(const ConvArgs& a, hipStream_t st) {
   int cin = 0;
   for (int i = 0; i < a.nsrc; ++i) cin += a.xc[i];
   if (a.flatW) cin = a.w.Cin;  // 2-D mode: Cin of the packed weight = kh * Cin2d, checked by the caller

@@ -162,7 +162,7 @@ int launch_flat_mask(int B, int H, int Wp, int Hv, int Wv, float* m, hipStream_t
 __global__ __launch_bounds__(256) void stem2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                      const float* __restrict__ bias, const float* __restrict__ out_mask,
                                                      int n, int Wp, int Cout, int CinP, int CoutP, float out_scale, int bf16,
-                                                     float* __restrict__ y) {
+                                                     float* __restrict__ y, __bf16* __restrict__ y16, int act16) {
   extern __shared__ float stem_w[];  // [Cout][12]: nine weights (kh, kw) + bias + pad
   for (int i = threadIdx.x; i < Cout * 12; i += 256) {
     const int co = i / 12, k = i - co * 12;
@@ -218,6 +218,14 @@ __global__ __launch_bounds__(256) void stem2d_kernel(const float* __restrict__ x
     o.z = (acc[2] + wc.y) * out_scale * mk[2];
     o.w = (acc[3] + wc.y) * out_scale * mk[3];
     *reinterpret_cast<float4*>(out + (size_t)co * n) = o;
+    if (y16) {  // the bf16 operand twin the first ResBlk's conv reads (ConvArgs::y16): act16(y), four samples = 8 bytes
+      float u[4] = {o.x, o.y, o.z, o.w};
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (__bf16)((act16 == PRO_LRELU && u[e] < 0.f) ? 0.2f * u[e] : u[e]);
+      *reinterpret_cast<bf16x4*>(y16 + (size_t)b * Cout * n + (size_t)co * n + n0) = h;
+    }
   }
 }
 bool stem2d_eligible(const ConvArgs& a) {
@@ -233,7 +241,7 @@ int launch_stem2d(const ConvArgs& a, hipStream_t st) {
   snprintf(detail, sizeof(detail), "co%d n%d W%d", a.w.Cout, a.T, a.flatW);
   ProfScope prof("stem2d_kernel", 18.0 * outs, 4.0 * (outs + (double)a.B * a.T), st, detail);
   hipLaunchKernelGGL(stem2d_kernel, dim3(cdiv(a.T / 4, 256), a.B), dim3(256), (size_t)a.w.Cout * 12 * sizeof(float), st, a.x[0],
-                     a.w.wp, a.w.bias, a.out_mask, a.T, a.flatW, a.w.Cout, a.w.CinP, a.w.CoutP, a.out_scale, a.bf16, a.y);
+                     a.w.wp, a.w.bias, a.out_mask, a.T, a.flatW, a.w.Cout, a.w.CinP, a.w.CoutP, a.out_scale, a.bf16, a.y, a.y16, a.y16_act);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -244,15 +252,17 @@ int launch_stem2d(const ConvArgs& a, hipStream_t st) {
 // five live threads at W = 521).
 __global__ __launch_bounds__(256) void dwconv2d_s2_kernel(const float* __restrict__ x, const float* __restrict__ w9,
                                                           const float* __restrict__ bias, int C, int H, int W, int Ho,
-                                                          int Wo, float* __restrict__ y) {
+                                                          int Wo, float* __restrict__ y, __bf16* __restrict__ y16) {
   const int ldi = W + 1, ldo = Wo + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= Ho * ldo) return;
   const int ho = i / ldo, wo = i - ho * ldo;
   const int bc = blockIdx.y, c = bc % C;
   float* out = y + (size_t)bc * Ho * ldo + i;
+  __bf16* out16 = y16 ? y16 + (size_t)bc * Ho * ldo + i : nullptr;  // twin: bf16(LeakyReLU(0.2)(y)), what conv2 multiplies
   if (wo == Wo) {
     *out = 0.f;
+    if (out16) *out16 = (__bf16)0.f;
     return;
   }
   const float* p = x + (size_t)bc * H * ldi;
@@ -268,27 +278,30 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_kernel(const float* __restric
     }
   }
   *out = acc;
+  if (out16) *out16 = (__bf16)(acc < 0.f ? 0.2f * acc : acc);
 }
 int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B, int C, int H, int W, float* y,
-                       hipStream_t st) {
+                       hipStream_t st, __bf16* y16_lrelu) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   hipLaunchKernelGGL(dwconv2d_s2_kernel, dim3(cdiv(Ho * (Wo + 1), 256), B * C), dim3(256), 0, st, x, w9, bias, C, H, W, Ho,
-                     Wo, y);
+                     Wo, y, y16_lrelu);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
 
 // DownSample 'half': avg_pool2d(2) after replicating the last column when W is odd (mel_style_encoder.py:58-61)
 __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x, int H, int W, int Ho, int Wo,
-                                                       float scale, float* __restrict__ y) {
+                                                       float scale, float* __restrict__ y, __bf16* __restrict__ y16) {
   const int ldi = W + 1, ldo = Wo + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;  // flattened [Ho][Wo + 1], as dwconv2d_s2_kernel
   if (i >= Ho * ldo) return;
   const int ho = i / ldo, wo = i - ho * ldo;
   const int bc = blockIdx.y;
   float* out = y + (size_t)bc * Ho * ldo + i;
+  __bf16* out16 = y16 ? y16 + (size_t)bc * Ho * ldo + i : nullptr;  // twin: bf16(y), what the learned shortcut conv multiplies
   if (wo == Wo) {
     *out = 0.f;
+    if (out16) *out16 = (__bf16)0.f;
     return;
   }
   const float* p = x + (size_t)bc * H * ldi;
@@ -296,10 +309,11 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__
   const float s = p[(size_t)(2 * ho) * ldi + w0] + p[(size_t)(2 * ho) * ldi + w1] +
                   p[(size_t)(2 * ho + 1) * ldi + w0] + p[(size_t)(2 * ho + 1) * ldi + w1];
   *out = s * 0.25f * scale;
+  if (out16) *out16 = (__bf16)(s * 0.25f * scale);
 }
-int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st) {
+int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st, __bf16* y16) {
   const int Ho = H / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(Ho * (Wo + 1), 256), BC), dim3(256), 0, st, x, H, W, Ho, Wo, scale, y);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(Ho * (Wo + 1), 256), BC), dim3(256), 0, st, x, H, W, Ho, Wo, scale, y, y16);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -364,7 +378,10 @@ template <bool ACC>
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               const float* __restrict__ gate,
                                                               const float* __restrict__ w9, int C, int H, int W, int Ho,
-                                                              int Wo, float* __restrict__ dx, float* __restrict__ part) {
+                                                              int Wo, float* __restrict__ dx, float* __restrict__ part,
+                                                              __bf16* __restrict__ dx16, const float* __restrict__ mask16) {
+  // dx16 (with ACC = false only): the bf16 operand twin of dx times its [B][n] mask -- what the weight gradient and the
+  // input gradient of the conv in front (ConvArgs::g16 / x16) multiply; this kernel is the last writer of dx
   __shared__ float red[4][10];
   const int bc = blockIdx.y, c = bc % C;
   const int ldi = W + 1, ldo = Wo + 1, n = H * ldi;
@@ -436,10 +453,23 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_kernel(const float* __res
         v.w += o.w;
       }
       *reinterpret_cast<float4*>(d + i0) = v;
+      if (!ACC && dx16) {
+        const float4 m = *reinterpret_cast<const float4*>(mask16 + (size_t)(bc / C) * n + i0);
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 h;
+        h[0] = (__bf16)(v.x * m.x);
+        h[1] = (__bf16)(v.y * m.y);
+        h[2] = (__bf16)(v.z * m.z);
+        h[3] = (__bf16)(v.w * m.w);
+        *reinterpret_cast<bf16x4*>(dx16 + (size_t)bc * n + i0) = h;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (i0 + e < n) d[i0 + e] = ACC ? d[i0 + e] + acc[e] : acc[e];
+        if (i0 + e < n) {
+          d[i0 + e] = ACC ? d[i0 + e] + acc[e] : acc[e];
+          if (!ACC && dx16) dx16[(size_t)bc * n + i0 + e] = (__bf16)(acc[e] * mask16[(size_t)(bc / C) * n + i0 + e]);
+        }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -482,15 +512,20 @@ __global__ __launch_bounds__(64) void dwconv2d_s2_bwd_w_sum_kernel(const float* 
 }
 size_t dwconv2d_s2_bwd_scratch_floats(int B, int C, int H, int W) { return (size_t)B * C * cdiv(H * (W + 1), 1024) * 10; }
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* gate, const float* w9, int B, int C, int H, int W,
-                           float* dx, int accumulate, float* dw9, float* db, float* scratch, hipStream_t st) {
+                           float* dx, int accumulate, float* dw9, float* db, float* scratch, hipStream_t st, __bf16* dx16,
+                           const float* mask16) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int nblk = cdiv(H * (W + 1), 1024);
+  if (dx16 && (accumulate || !mask16)) {
+    set_error("dwconv2d_s2_bwd: the operand twin of dx needs the overwriting form and the mask");
+    return STY_EINVAL;
+  }
   if (accumulate)
     hipLaunchKernelGGL(dwconv2d_s2_bwd_kernel<true>, dim3(nblk, B * C), dim3(256), 0, st, x, gy, gate, w9, C, H, W, Ho, Wo, dx,
-                       scratch);
+                       scratch, nullptr, nullptr);
   else
     hipLaunchKernelGGL(dwconv2d_s2_bwd_kernel<false>, dim3(nblk, B * C), dim3(256), 0, st, x, gy, gate, w9, C, H, W, Ho, Wo, dx,
-                       scratch);
+                       scratch, dx16, mask16);
   hipLaunchKernelGGL(dwconv2d_s2_bwd_w_sum_kernel, dim3(C), dim3(64), 0, st, scratch, C, B, nblk, dw9, db);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -526,8 +561,11 @@ int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const
 // the pass that accumulates into dx anyway
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gy, int H, int W, int Ho, int Wo,
                                                            float scale, float* __restrict__ dx,
-                                                           const float* __restrict__ gate) {
+                                                           const float* __restrict__ gate, __bf16* __restrict__ dx16,
+                                                           const float* __restrict__ mask16, int C) {
   // (four consecutive elements of the padded-flat image per thread, as in dwconv2d_s2_bwd_dx_kernel)
+  // dx16: the bf16 operand twin of the finished dx times its [B][n] mask (this pass is dx's last writer), for the weight
+  // gradient and the input gradient of the conv that produced the activation (ConvArgs::g16 / x16)
   const int bc = blockIdx.y;
   const int ldi = W + 1, n = H * ldi;
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -565,6 +603,16 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
     v.z += acc[2];
     v.w += acc[3];
     *reinterpret_cast<float4*>(d + i0) = v;
+    if (dx16) {
+      const float4 m = *reinterpret_cast<const float4*>(mask16 + (size_t)(bc / C) * n + i0);
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 h;
+      h[0] = (__bf16)(v.x * m.x);
+      h[1] = (__bf16)(v.y * m.y);
+      h[2] = (__bf16)(v.z * m.z);
+      h[3] = (__bf16)(v.w * m.w);
+      *reinterpret_cast<bf16x4*>(dx16 + (size_t)bc * n + i0) = h;
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -572,13 +620,19 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
         float v = d[i0 + e];
         if (gt && !(gt[i0 + e] > 0.f)) v *= 0.2f;
         d[i0 + e] = v + acc[e];
+        if (dx16) dx16[(size_t)bc * n + i0 + e] = (__bf16)((v + acc[e]) * mask16[(size_t)(bc / C) * n + i0 + e]);
       }
   }
 }
-int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, const float* gate, hipStream_t st) {
+int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, const float* gate, hipStream_t st,
+                        __bf16* dx16, const float* mask16, int C) {
   const int Ho = H / 2, Wo = (W + 1) / 2;
+  if (dx16 && (!mask16 || C <= 0)) {
+    set_error("avgpool2_bwd: the operand twin of dx needs the mask and the channel count");
+    return STY_EINVAL;
+  }
   hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cdiv(H * (W + 1), 1024), BC), dim3(256), 0, st, gy, H, W, Ho, Wo, scale, dx,
-                     gate);
+                     gate, dx16, mask16, C > 0 ? C : 1);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

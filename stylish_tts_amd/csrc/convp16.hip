@@ -64,7 +64,8 @@ __device__ __forceinline__ QTile q_tile(int tile, int tiles_per_row, int ncot) {
 // commit does not have to re-derive the chunk's position).
 template <int NFRAG>
 struct QSet {
-  float bv[8];                // input tile: 8 rows x the 64-column group of this wave
+  float bv[8];                // input tile: 8 rows x the 64-column group of this wave (X16: bv[0..3] hold the rows as four
+                              // dwords of bf16 pairs -- rows (0,1), (2,3), (4,5), (6,7) -- straight from the operand twin)
   bf16x8 av[NFRAG];           // weight fragments, ready made (one 16-byte load each)
   float pa, ps;               // lanes 0-7: AdaIN scale / shift of the 8 rows (affine prologues)
   float mk;                   // PRO_MASK: the [B][T] multiplier at this lane's source position
@@ -83,29 +84,34 @@ struct QPos {
   __amdgpu_buffer_rsrc_t rs;  // descriptor of the tile's batch slab (rebuilt once per tile, not once per chunk step)
 };
 
-template <bool FLAT>
+template <bool FLAT, bool X16 = false>
 __device__ __forceinline__ void q_pos_tile(const ConvArgs& a, QPos& p, int rg, int CO32) {  // chunk 0 of tile (b, t0, cot)
+  constexpr int ES = X16 ? 2 : 4;  // bytes per input element: the bf16 operand twin (ConvArgs::x16) or the fp32 tensor
   p.chunk = 0;
   p.cc = 8 * rg;  // (flat 2-D: Cin2d >= 32, so chunk 0 starts in image-row tap 0)
   p.tsh = FLAT ? -a.hpad * a.flatW : 0;
-  p.roff = (p.cc * a.T + p.tsh) * 4;
+  p.roff = (p.cc * a.T + p.tsh) * ES;
   p.abase = p.cot * CO32 * 1024;
   const int crow = FLAT ? a.Cin2d : a.w.Cin;  // rows of one batch slab: rows past it are outside the descriptor and load 0
-  p.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x[0] + (size_t)p.b * crow * a.T), 0, crow * a.T * 4, 0x00020000);
+  if constexpr (X16)
+    p.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x16 + (size_t)p.b * crow * a.T), 0, crow * a.T * 2, 0x00020000);
+  else
+    p.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x[0] + (size_t)p.b * crow * a.T), 0, crow * a.T * 4, 0x00020000);
 }
-template <bool FLAT>
+template <bool FLAT, bool X16 = false>
 __device__ __forceinline__ void q_pos_next(const ConvArgs& a, QPos& p, int nch, int tiles_per_row, int ncot, int rg, int CO32,
                                            int astep, int tstride) {
+  constexpr int ES = X16 ? 2 : 4;
   ++p.n;
   if (++p.chunk < nch) {
-    p.roff += 32 * a.T * 4;
+    p.roff += 32 * a.T * ES;
     p.abase += astep;
     if (FLAT) {
       p.cc += 32;
       if (p.cc >= a.Cin2d) {  // next image-row tap
         p.cc -= a.Cin2d;
         p.tsh += a.flatW;
-        p.roff += (a.flatW - a.Cin2d * a.T) * 4;
+        p.roff += (a.flatW - a.Cin2d * a.T) * ES;
       }
     }
     return;
@@ -115,7 +121,7 @@ __device__ __forceinline__ void q_pos_next(const ConvArgs& a, QPos& p, int nch, 
   p.b = t.b;
   p.t0 = t.t0;
   p.cot = t.cot;
-  q_pos_tile<FLAT>(a, p, rg, CO32);
+  q_pos_tile<FLAT, X16>(a, p, rg, CO32);
 }
 
 // per-wave constants of the staging code
@@ -132,18 +138,30 @@ struct QConst {
   int adst[NFRAG];   // LDS bf16x8 index of the fragment in an A buffer (-1: none)
 };
 
-template <int PRO, bool FLAT, int NFRAG>
+template <int PRO, bool FLAT, int NFRAG, bool X16 = false>
 __device__ __forceinline__ void q_issue(const ConvArgs& a, const QPos& p, const QConst<NFRAG>& k, int lane, QSet<NFRAG>& R) {
   const int T = a.T;
   const __amdgpu_buffer_rsrc_t rs = p.rs;
+  constexpr int ES = X16 ? 2 : 4;
   // The whole offset goes into the VECTOR offset: the hardware range-checks that one only, not the scalar soffset.
-  const int v0 = k.vcol + (p.t0 - a.pad) * 4 + p.roff;
+  const int v0 = k.vcol + (p.t0 - a.pad) * ES + p.roff;
   // (a dead column group -- the third one of a K = 1 conv -- loads from outside the descriptor.  No branch around the
   // loads: every path through a chunk step must issue the SAME number of vector-memory instructions, or the compiler's
   // s_waitcnt for the other register set, whose loads are one step younger, degrades to vmcnt(0) -- see the step loop.)
+  if constexpr (X16) {
+    // the operand twin: the same eight rows, two bytes each, already what the MFMA multiplies (prologue applied, rounded
+    // by the tensor's producer); eight 16-bit loads, paired into four dwords -- no conversion, no prologue in q_commit
 #pragma unroll
-  for (int r = 0; r < 8; ++r)
-    R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0 + r * T * 4, 0, 0));
+    for (int r = 0; r < 4; ++r) {
+      const unsigned lo = __builtin_amdgcn_raw_buffer_load_b16(rs, v0 + (2 * r) * T * 2, 0, 0);
+      const unsigned hi = __builtin_amdgcn_raw_buffer_load_b16(rs, v0 + (2 * r + 1) * T * 2, 0, 0);
+      R.bv[r] = __builtin_bit_cast(float, lo | (hi << 16));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      R.bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0 + r * T * 4, 0, 0));
+  }
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.w.wf), 0, a.w.K * a.w.CinP * a.w.CoutP * 2 + 8192, 0x00020000);
 #pragma unroll
@@ -172,12 +190,21 @@ __device__ __forceinline__ void q_issue(const ConvArgs& a, const QPos& p, const 
   }
 }
 
-template <int PRO, int NFRAG>
+template <int PRO, int NFRAG, bool X16 = false>
 __device__ __forceinline__ void q_commit(const QConst<NFRAG>& k, const QSet<NFRAG>& R, __bf16* bbuf, bf16x8* abuf, int lane) {
 #pragma unroll
   for (int i = 0; i < NFRAG; ++i)
     if (k.adst[i] >= 0) abuf[k.adst[i] + lane] = R.av[i];
   const bool in = (R.in >> lane) & 1;
+  if constexpr (X16) {  // four dwords of bf16 pairs = the column's eight channels as the B ring holds them
+    uint4 v;
+    v.x = in ? __builtin_bit_cast(unsigned, R.bv[0]) : 0u;
+    v.y = in ? __builtin_bit_cast(unsigned, R.bv[1]) : 0u;
+    v.z = in ? __builtin_bit_cast(unsigned, R.bv[2]) : 0u;
+    v.w = in ? __builtin_bit_cast(unsigned, R.bv[3]) : 0u;
+    if (k.jlive) *reinterpret_cast<uint4*>(bbuf + k.bdst) = v;
+    return;
+  }
   float v[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -256,6 +283,33 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, con
       *reinterpret_cast<float2*>(sp) = make_float2(v[0], v[2]);
       *reinterpret_cast<float2*>(sp + (size_t)Cout * (T >> 1)) = make_float2(v[1], v[3]);
     }
+    if (a.y16) {  // the bf16 operand twin of the output for the conv that reads it next (ConvArgs::y16): act16(y), rounded here
+      float u[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = (a.y16_act == PRO_LRELU && v[e] < 0.f) ? 0.2f * v[e] : v[e];
+      const __amdgpu_buffer_rsrc_t trs =
+          __builtin_amdgcn_make_buffer_rsrc(a.y16 + (size_t)tl.b * Cout * T, 0, Cout * T * 2, 0x00020000);
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      bf16x2 p0, p1;
+      p0[0] = (__bf16)u[0];
+      p0[1] = (__bf16)u[1];
+      p1[0] = (__bf16)u[2];
+      p1[1] = (__bf16)u[3];
+      const unsigned d0 = __builtin_bit_cast(unsigned, p0), d1 = __builtin_bit_cast(unsigned, p1);
+      if (wide) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 dd;
+        dd[0] = d0;
+        dd[1] = d1;
+        __builtin_amdgcn_raw_buffer_store_b64(dd, trs, t * 2, co * T * 2, 0);
+      } else {
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {
+          const unsigned h = e == 0 ? d0 : e == 1 ? d0 >> 16 : e == 2 ? d1 : d1 >> 16;
+          if (t + e < T) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h, trs, (t + e) * 2, co * T * 2, 0);
+        }
+      }
+    }
     if (wide) {
       const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
       __builtin_amdgcn_raw_buffer_store_b128(
@@ -270,7 +324,7 @@ __device__ __forceinline__ void q_drain(const ConvArgs& a, const float* ost, con
   }
 }
 
-template <int MTW, int PRO, int RELU, bool FLAT>
+template <int MTW, int PRO, int RELU, bool FLAT, bool X16 = false>
 __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles, int dbg_) {
   constexpr int dbg = 0;  // (the STY_Q_DBG phase switches of round 2 cost scalar instructions in every wave and step)
   (void)dbg_;
@@ -326,7 +380,7 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
     kc.jcol = lane + 64 * q;
     kc.jlive = kc.jcol < LWt;
     kc.qlive = q < Q_TT / 64 || 64 * q < LWt;
-    kc.vcol = kc.qlive ? kc.jcol * 4 : 0x7FFFFF00;
+    kc.vcol = kc.qlive ? kc.jcol * (X16 ? 2 : 4) : 0x7FFFFF00;
     kc.bdst = kc.jcol * Q_PITCH + 8 * rg;
 #pragma unroll
     for (int i = 0; i < NFRAG; ++i) {
@@ -348,28 +402,28 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
       pi.b = t0_.b;
       pi.t0 = t0_.t0;
       pi.cot = t0_.cot;
-      q_pos_tile<FLAT>(a, pi, rg, CO32);
+      q_pos_tile<FLAT, X16>(a, pi, rg, CO32);
     }
     int ncommit = 0;  // chunk step number of the next commit
 #define STY_Q_ISSUE(R)                                                          \
-  if (pi.n < nchunks && !(dbg & 1)) q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R); \
-  q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
+  if (pi.n < nchunks && !(dbg & 1)) q_issue<PRO, FLAT, NFRAG, X16>(a, pi, kc, lane, R); \
+  q_pos_next<FLAT, X16>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
 #define STY_Q_STEP(R) /* commit chunk `ncommit` from its register set, then request the chunk two ahead into the same set */ \
   {                                                                                                             \
-    if (!(dbg & 4)) q_commit<PRO, NFRAG>(kc, R, bring + (ncommit & 1) * bsz, aring + (ncommit & 1) * asz, lane); \
+    if (!(dbg & 4)) q_commit<PRO, NFRAG, X16>(kc, R, bring + (ncommit & 1) * bsz, aring + (ncommit & 1) * asz, lane); \
     ++ncommit;                                                                                                  \
     STY_Q_ISSUE(R)                                                                                              \
   }
     const bool steady = nsteps > 4;  // the unconditional loop below runs (and then so does this prologue: see there)
     if (steady) {
-      q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R0);
-      q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
-      q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R1);
-      q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
-      q_commit<PRO, NFRAG>(kc, R0, bring, aring, lane);
+      q_issue<PRO, FLAT, NFRAG, X16>(a, pi, kc, lane, R0);
+      q_pos_next<FLAT, X16>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
+      q_issue<PRO, FLAT, NFRAG, X16>(a, pi, kc, lane, R1);
+      q_pos_next<FLAT, X16>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
+      q_commit<PRO, NFRAG, X16>(kc, R0, bring, aring, lane);
       ++ncommit;
-      q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R0);
-      q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
+      q_issue<PRO, FLAT, NFRAG, X16>(a, pi, kc, lane, R0);
+      q_pos_next<FLAT, X16>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);
     } else {
       STY_Q_ISSUE(R0)
       STY_Q_ISSUE(R1)
@@ -403,10 +457,10 @@ __global__ __launch_bounds__(Q_THREADS, 4) void convp16_kernel(ConvArgs a, int t
 #define STY_Q_FAST(R)                                                                                  \
   {                                                                                                    \
     if (ti > 0 && c < ndr) q_drain<MTW, RELU>(a, ost, bias_lds, prev_tl, pw, lane, c, ndr); \
-    q_commit<PRO, NFRAG>(kc, R, bring + (ncommit & 1) * bsz, aring + (ncommit & 1) * asz, lane);       \
+    q_commit<PRO, NFRAG, X16>(kc, R, bring + (ncommit & 1) * bsz, aring + (ncommit & 1) * asz, lane);       \
     ++ncommit;                                                                                         \
-    q_issue<PRO, FLAT, NFRAG>(a, pi, kc, lane, R);                                                     \
-    q_pos_next<FLAT>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);                       \
+    q_issue<PRO, FLAT, NFRAG, X16>(a, pi, kc, lane, R);                                                     \
+    q_pos_next<FLAT, X16>(a, pi, nch, tiles_per_row, ncot, rg, CO32, astep, tstride);                       \
     STY_Q_NEXT                                                                                         \
   }
     int step = 0;
@@ -701,14 +755,14 @@ bool convp16_eligible(const ConvArgs& a) {
   return (long)cdiv(a.T, Q_TT) * a.B * cdiv(a.w.CoutP, co) >= min_tiles;
 }
 
-template <int MTW, int PRO, int RELU>
+template <int MTW, int PRO, int RELU, bool X16 = false>
 static int launch_q(const ConvArgs& a, hipStream_t st) {
   const size_t lds = q_lds_bytes(a);
   static bool raised = false;
   if (!raised) {
-    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convp16_kernel<MTW, PRO, RELU, false>),
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convp16_kernel<MTW, PRO, RELU, false, X16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convp16_kernel<MTW, PRO, RELU, true>),
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convp16_kernel<MTW, PRO, RELU, true, X16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised = true;
   }
@@ -718,7 +772,8 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   const double outs = (double)a.B * a.w.Cout * a.T;
   const double flops = 2.0 * a.w.Cin * a.w.K * outs;
   const double in_elems = (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;
-  const double bytes = 4.0 * (in_elems + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
+  const double bytes = (X16 ? 2.0 : 4.0) * in_elems + 4.0 * (outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K) +
+                       (a.y16 ? 2.0 * outs : 0.0);
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
   char fam[48];
@@ -727,10 +782,10 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   const char* de = getenv("STY_Q_DBG");  // timing experiments only (wrong results): 1 no input loads, 2 no weight path,
                                          // 4 no input commit, 8 no drain, 16 no MFMA loop, 32 no accumulator spill
   if (a.flatW)
-    hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU, true>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot,
+    hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU, true, X16>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot,
                        ntiles, de ? atoi(de) : 0);
   else
-    hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU, false>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot,
+    hipLaunchKernelGGL((convp16_kernel<MTW, PRO, RELU, false, X16>), dim3(grid), dim3(Q_THREADS), lds, st, a, tiles_per_row, ncot,
                        ntiles, de ? atoi(de) : 0);
   STY_LAUNCH_CHECK();
   return STY_OK;
@@ -752,6 +807,14 @@ int launch_convp16(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   int rc = q_frags(a0, st, &a.w.wf);
   if (rc) return rc;
+  if (a.x16 && a.act != ACT_LRELU01 && getenv("STY_NO_CONVP16_X16") == nullptr) {
+    // source 0 comes as its bf16 operand twin: the prologue (LeakyReLU / the [B][T] mask) is already in it
+    a.pro = PRO_NONE;
+    a.mask = nullptr;
+    const bool relu = a.act == ACT_RELU;
+    if (q_mtw(a) == 2) return relu ? launch_q<2, PRO_NONE, 1, true>(a, st) : launch_q<2, PRO_NONE, 0, true>(a, st);
+    return relu ? launch_q<1, PRO_NONE, 1, true>(a, st) : launch_q<1, PRO_NONE, 0, true>(a, st);
+  }
   switch (a.pro) {
     case PRO_MASK: return launch_q_pro<PRO_MASK>(a, st);
     case PRO_LRELU: return launch_q_pro<PRO_LRELU>(a, st);

@@ -302,4 +302,51 @@ int launch_axpy(const float* x, float a, float* y, size_t n, hipStream_t st) {
   return STY_OK;
 }
 
+// bf16 operand twin of an activation / gradient tensor (ConvArgs::x16): y16[r][t] = bf16(pro(x[r][t]) * mask[b][t]),
+// rows r = b * C + c.  Eight elements per thread: two 16-byte loads, one 16-byte store.  The fused producers (conv output
+// stages, the element-wise backward kernels) write the same values; this pass serves tensors nobody fused yet.
+__global__ __launch_bounds__(256) void twin_cast_kernel(const float* __restrict__ x, const float* __restrict__ mask, int pro,
+                                                        int C, int T, size_t n8, __bf16* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const int per_row = (T + 7) >> 3;
+  const size_t row = i / per_row;
+  const int t0 = (int)(i - row * per_row) * 8;
+  const float* xr = x + row * T;
+  const float* mr = mask ? mask + (row / C) * T : nullptr;
+  float v[8];
+  const bool full = t0 + 7 < T && ((reinterpret_cast<size_t>(xr + t0) & 15) == 0);
+  if (full) {
+    const float4 a = *reinterpret_cast<const float4*>(xr + t0), b = *reinterpret_cast<const float4*>(xr + t0 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = t0 + e < T ? xr[t0 + e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (pro == PRO_LRELU) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+    if (mr) v[e] *= t0 + e < T ? mr[t0 + e] : 0.f;
+  }
+  __bf16* yr = y + row * T + t0;
+  if (t0 + 7 < T && ((reinterpret_cast<size_t>(yr) & 15) == 0)) {
+    *reinterpret_cast<bf16x8*>(yr) = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (t0 + e < T) yr[e] = (__bf16)v[e];
+  }
+}
+int launch_twin_cast(const float* x, const float* mask, int pro, int B, int C, int T, __bf16* y16, hipStream_t st) {
+  if (!(pro == PRO_NONE || pro == PRO_LRELU)) {
+    set_error("twin_cast: prologue %d has no twin form", pro);
+    return STY_EINVAL;
+  }
+  const size_t n8 = (size_t)B * C * ((T + 7) >> 3);
+  ProfScope prof("twin_cast_kernel", 0.0, 6.0 * (double)B * C * T, st);
+  hipLaunchKernelGGL(twin_cast_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, x, mask, pro, C, T, n8, y16);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 }  // namespace sty

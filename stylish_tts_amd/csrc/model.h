@@ -85,9 +85,11 @@ struct Bump {
 };
 
 enum PackKind { PK_CONV, PK_CONV_WN, PK_CONV_GLU, PK_W2A, PK_CONV2D_SN, PK_DW2D_SN, PK_DGRAD, PK_DGRAD2D };
+// y16 (optional): the bf16 operand twin of the output for the conv that reads it next (ConvArgs::x16) -- bf16(lrelu(y))
+// behind the learned down-sampling, bf16(y) behind the pooling
 int launch_dwconv2d_s2(const float* x, const float* w9, const float* bias, int B, int C, int H, int W, float* y,
-                       hipStream_t st);
-int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st);
+                       hipStream_t st, __bf16* y16_lrelu = nullptr);
+int launch_avgpool2(const float* x, int BC, int H, int W, float scale, float* y, hipStream_t st, __bf16* y16 = nullptr);
 int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* W, const float* bvec, int S,
                    float* out, hipStream_t st);
 struct PackJob {
@@ -297,6 +299,15 @@ int launch_istft64_bwd(int B, int F, const float* audio, const float* daudio, co
                        const float* imag, const float* bbr, const float* bbi, float* dlogamp, float* dreal,
                        float* dimag, hipStream_t st);
 size_t wgrad_partial_floats(const PackedConv& w, int B, int T);
+// wgrad.hip, "deferred, grouped reduction": while a WgReduceDefer is current on the calling thread, the reduction that
+// follows every weight-gradient kernel is recorded instead of launched (each launch then needs a partial buffer of its
+// own that lives until the flush); wgrad_defer_flush sums all recorded jobs in one launch on `st`.
+struct WgReduceDefer;
+WgReduceDefer* wgrad_defer_create();
+void wgrad_defer_destroy(WgReduceDefer* d);
+WgReduceDefer* wgrad_defer_set(WgReduceDefer* d);  // returns the previous one (nullptr = immediate reductions)
+size_t wgrad_defer_pending(const WgReduceDefer* d);
+int wgrad_defer_flush(WgReduceDefer* d, int site, hipStream_t st);
 // whether launch_conv1d_wgrad produces the bias gradient as a by-product (every kernel for K <= 12 does)
 inline bool wgrad_fuses_bias(const PackedConv& w) { return w.K <= 12; }
 int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask, float scale, float* gwp,
@@ -323,13 +334,16 @@ int launch_fnv_unpack(const float* dw34, const float* g0, const float* v0, const
 int launch_pack_dgrad2d(const float* wp, int KW, int KH, int Cin, int Cout, int CinP, int CoutP, int CinPd, int CoutPd,
                         float* wd, hipStream_t st);
 size_t dwconv2d_s2_bwd_scratch_floats(int B, int C, int H, int W);
+// dx16 / mask16 (optional; overwriting form only): also write bf16(dx * mask16[b][n]), the operand twin of dx
 int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* gate, const float* w9, int B, int C, int H, int W, float* dx,
-                           int accumulate, float* dw9, float* db, float* scratch, hipStream_t st);
+                           int accumulate, float* dw9, float* db, float* scratch, hipStream_t st, __bf16* dx16 = nullptr,
+                           const float* mask16 = nullptr);
 int launch_pad_cols(const float* x, size_t rows, int W, float* y, hipStream_t st);
 int launch_flat_mask(int B, int H, int Wp, int Hv, int Wv, float* m, hipStream_t st);
 int launch_dw2d_sn_unpack(const float* g9, const float* w, const float* u, const float* v, const float* t, int C,
                           float* dW, hipStream_t st);
-int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, const float* gate, hipStream_t st);
+int launch_avgpool2_bwd(const float* gy, int BC, int H, int W, float scale, float* dx, const float* gate, hipStream_t st,
+                        __bf16* dx16 = nullptr, const float* mask16 = nullptr, int C = 0);
 int launch_pool_fc_bwd(const float* x, int B, int C, int n, int count, const float* W, int S, const float* gs,
                        float* dW, float* db, float* dx, int accumulate, hipStream_t st);
 int launch_bn_train_fwd(const float* x, const float* w, const float* b, float* rm, float* rv, float eps, float momentum,

@@ -125,7 +125,24 @@ struct ConvArgs {
   // of the OUTPUT, laid out as launch_row_stats lays out its segments: [B * Cout][conv32p_stat_nseg(T)][2] doubles.
   // The AdaIN fold of the next layer then needs no pass of its own over the tensor.
   double* stat_part = nullptr;
+  // ---- bf16 operand twins (bf16 compute mode) ----
+  // x16: source 0 as the GEMM will see it -- the prologue already applied, rounded to bf16 (RNE) -- stored [B][C][T] like
+  // the fp32 tensor, written by the kernel that produced x (or by launch_twin_cast).  A kernel that takes it loads two
+  // bytes per element, converts nothing and applies no prologue; the rounding point is the one the fp32 path has (every
+  // operand is rounded on its way into LDS), so results are bit-identical.  Under autocast the reference's conv inputs
+  // live in HBM as bf16 in exactly this sense (config/config.yml:9-12, train/train_context.py:94-104).
+  // g16 (weight gradient only): the output gradient times its [B][T] mask, the same way.
+  const __bf16* x16 = nullptr;
+  const __bf16* g16 = nullptr;
+  // y16 (producers): also store act16(y) as bf16 [B][Cout][T] -- the twin the next conv reads; y16_act = PRO_NONE or PRO_LRELU
+  __bf16* y16 = nullptr;
+  int y16_act = PRO_NONE;
 };
+// misc.hip: y16 = bf16(pro(x) * mask[b][t]) for [B*C][T] rows; pro = PRO_NONE or PRO_LRELU; mask optional
+int launch_twin_cast(const float* x, const float* mask, int pro, int B, int C, int T, __bf16* y16, hipStream_t st);
+// wgradb.hip: the K = 1 / 3 / 5 weight gradient on two bf16 twins (fwd.x16, fwd.g16)
+bool wgradb16_eligible(const ConvArgs& fwd);
+int launch_wgradb16(const ConvArgs& fwd, int nsplit, float* partial, int want_bias, hipStream_t st);
 
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
 // conv32p.hip: persistent, wave-specialised kernel for the 32 -> 32 channel convs at the 75T rate

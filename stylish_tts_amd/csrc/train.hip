@@ -66,7 +66,73 @@ struct Trainer {
   bool side_dirty = false;
   size_t side_need = 0;  // floats
   float* side_partial = nullptr;
+  // ---- deferred, grouped reduction of the weight-gradient partial sums (wgrad.hip) ----
+  // Every weight-gradient launch of a backward gets a partial buffer of its own (wg_take, out of one region sized in the
+  // forward: wg_sum), its reduction is recorded instead of launched, and reduce_flush sums everything recorded so far in
+  // one launch on the stream the weight gradients run on -- before a gradient segment is announced and at the end of the
+  // backward -- followed by the few steps that READ a reduced gradient (`after_reduce`: d alpha of the lean ConvNeXt32
+  // backward is a function of dW1).
+  WgReduceDefer* defer = wgrad_defer_create();
+  bool defer_on = getenv("STY_NO_DEFERRED_REDUCE") == nullptr;
+  size_t wg_sum = 0, wg_off = 0;  // floats
+  float* wg_base = nullptr;
+  int flush_site = 0;
+  std::vector<std::function<void(hipStream_t)>> after_reduce;
+  bool deferring() const { return wg_base != nullptr; }
+  float* wg_take(size_t n) {
+    n = (n + 63) & ~size_t(63);
+    float* p = wg_base + wg_off;
+    wg_off += n;
+    if (wg_off > wg_sum && rc == STY_OK) {
+      set_error("training: weight-gradient partial region too small (%zu > %zu floats)", wg_off, wg_sum);
+      rc = STY_ESTATE;
+    }
+    return p;
+  }
+  void wg_need(size_t n) { wg_sum += (n + 63) & ~size_t(63); }
+  struct DeferScope {  // the defer context is current on this thread while a backward issues launches
+    WgReduceDefer* old;
+    explicit DeferScope(Trainer* t) { old = wgrad_defer_set(t->deferring() && t->live() ? t->defer : nullptr); }
+    ~DeferScope() { (void)wgrad_defer_set(old); }
+  };
+  void reduce_flush(hipStream_t s) {
+    if (!deferring() || !live()) {
+      after_reduce.clear();
+      return;
+    }
+    chk(wgrad_defer_flush(defer, flush_site++, s));
+    WgReduceDefer* cur = wgrad_defer_set(nullptr);  // (what runs now reduces at once, should it reduce at all)
+    if (rc == STY_OK)
+      for (auto& fn : after_reduce) fn(s);
+    (void)wgrad_defer_set(cur);
+    after_reduce.clear();
+  }
+  // ---- bf16 operand twins (ConvArgs::x16 / g16; bf16 compute mode) ----
+  // tw_x[pro]: activation -> its twin bf16(pro(x)) (pro = PRO_NONE, PRO_LRELU), written by the kernel that produced the
+  // activation where that kernel has the output stage for it, by the cast pass (launch_twin_cast) otherwise; kept to the
+  // end of the step (the forward conv reads it, the weight gradient reads it again in the backward).
+  bool twins_env = getenv("STY_NO_TWINS") == nullptr;
+  bool twins_on() const { return twins_env && m->topts.compute_bf16 != 0; }
+  std::unordered_map<const float*, __bf16*> tw_x[2];
+  // gradient twins: tw_want = activations y whose conv will read G(y) as a twin (its weight gradient runs on wgradb16);
+  // tw_g = gradient buffer -> (twin, the [B][n] mask it was multiplied by), registered by the element-wise backward
+  // kernel that writes the buffer LAST (pooling / learned down-sampling backward); the conv's backward takes it when
+  // the mask is its own, and makes the twin with the cast pass otherwise
+  std::unordered_set<const float*> tw_want;
+  std::unordered_map<const float*, std::pair<__bf16*, const float*>> tw_g;
+  static int tw_slot(int pro) { return pro == PRO_LRELU ? 1 : 0; }
+  void twin_register(const float* x, int pro, __bf16* t) { tw_x[tw_slot(pro)][x] = t; }
+  const __bf16* xtwin(const float* x, int pro, int C, int n) {
+    auto& mp = tw_x[tw_slot(pro)];
+    auto it = mp.find(x);
+    if (it != mp.end()) return it->second;
+    __bf16* t = take<__bf16>((size_t)B * C * n);
+    if (live()) chk(launch_twin_cast(x, nullptr, pro, B, C, n, t, st));
+    mp[x] = t;
+    return t;
+  }
   ~Trainer() {
+    wgrad_defer_destroy(defer);
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     if (d_style_done) (void)hipEventDestroy(d_style_done);
     if (st2) (void)hipStreamDestroy(st2);
@@ -87,6 +153,10 @@ struct Trainer {
     side_dirty = false;
     const bool on = side_on && !single_stream_mode();
     side_partial = on && side_need ? take<float>(side_need) : nullptr;
+    wg_base = defer_on && wg_sum ? take<float>(wg_sum) : nullptr;
+    wg_off = 0;
+    flush_site = 0;
+    after_reduce.clear();
     if (on && !st2 && live()) {
       // (Measured and rejected: hipExtStreamCreateWithCUMask leaving every 2nd / 4th / 8th CU to the main stream, so
       // that its small kernels need not wait for a resident weight-gradient workgroup to retire -- c2 38.0 -> 62 ms,
@@ -113,13 +183,16 @@ struct Trainer {
       if (r == hipSuccess) r = hipStreamWaitEvent(st2, e, 0);
       if (r != hipSuccess) rc = hip_fail(r, "side fork");
     }
-    if (rc == STY_OK)
+    if (rc == STY_OK) {
+      DeferScope ds(this);
       for (auto& fn : side_q) fn(st2);
+    }
     side_q.clear();
     side_dirty = true;
   }
   void side_join() {
     side_flush();
+    reduce_flush(side_dirty && st2 ? st2 : st);
     if (side_dirty && st2) {
       hipEvent_t e = next_event();
       hipError_t r = hipEventRecord(e, st2);
@@ -229,6 +302,7 @@ struct Trainer {
     a.bf16 = m->topts.compute_bf16;
     const size_t pn = wgrad_partial_floats(a.w, B, a.T);
     side_need = pn > side_need ? pn : side_need;
+    wg_need(pn);
     if (live()) chk(launch_conv1d(a, st));
     ConvArgs f = a;
     tape.push_back([this, f]() { conv_bwd(f); });
@@ -292,13 +366,15 @@ struct Trainer {
     if (m->topts.frozen) {  // eval_models of a stage (e.g. the speech predictor in train_textual): input gradients only
       bias_done = true;
     } else if (side_ready()) {
-      float* sp = side_partial;
+      float* sp = deferring() ? wg_take(wgrad_partial_floats(w, B, Tt)) : side_partial;
       float* gwp = PGpacked(w.wp);
       const float osc = f.out_scale;
       side_push(gY, [=](hipStream_t s) { chk(launch_conv1d_wgrad(f, gY, gmask, osc, gwp, sp, gbias, nullptr, s)); });
       bias_done = wgrad_fuses_bias(w);
     } else {
-      float* partial = take<float>(wgrad_partial_floats(w, B, Tt));
+      const size_t pn = wgrad_partial_floats(w, B, Tt);
+      float* partial = deferring() ? wg_take(pn) : take<float>(pn);
+      DeferScope ds(this);
       if (live()) chk(launch_conv1d_wgrad(f, gY, gmask, f.out_scale, PGpacked(w.wp), partial, gbias, &bias_done, st));
     }
     if (w.bias && !bias_done) {
@@ -488,6 +564,12 @@ struct Trainer {
     return y;
   }
 
+  // partial planes of a fused block's pointwise weight gradient: the generic K = 1 kernel's or wgrad_cnx_kernel's
+  // (bf16 outputs; its own split count), whichever is larger
+  size_t cnx_partial_floats(const PackedConv& w, int Tt) const {
+    const size_t a = wgrad_partial_floats(w, B, Tt), b = (size_t)wgrad_cnx_nsplit(B, Tt) * (4096 + 128);
+    return a > b ? a : b;
+  }
   // GeneratorConvNeXtBlock at C = 32 (the nine blocks at the 75T frame rate): fused two-pass forward, recompute-based
   // fused backward (convnext_bwd.hip); only x and the GRN statistics are kept between the two
   float* convnext32_fused(const ConvNeXt& c, const float* x, int Tt) {
@@ -525,9 +607,11 @@ struct Trainer {
     const float* gbl = gbp(c.norm);
     float* dgl = dgbp(c.norm);
     {
-      const size_t p1n = wgrad_partial_floats(c.pw1, B, Tt), p2n = wgrad_partial_floats(c.pw2, B, Tt);
+      const size_t p1n = cnx_partial_floats(c.pw1, Tt), p2n = cnx_partial_floats(c.pw2, Tt);
       side_need = p1n > side_need ? p1n : side_need;
       side_need = p2n > side_need ? p2n : side_need;
+      wg_need(p1n);
+      wg_need(p2n);
     }
     tape.push_back([=]() {
       float* gY = G(y, n32);
@@ -555,8 +639,9 @@ struct Trainer {
       float* hs_p = side && !lean ? take<float>(n128) : nullptr;
       float* gh0_p = side ? take<float>(lean ? n128 / 2 : n128) : nullptr;
       // (lean: read by the d alpha kernel behind the dW1 GEMM on the side stream)
-      float* ds_p = side && lean ? take<float>((size_t)B * 128) : nullptr;
-      float* coef_p = side && lean ? take<float>((size_t)B * 128) : nullptr;
+      // (... or, with the reductions deferred, behind the grouped reduction at the end of the segment: `after_reduce`)
+      float* ds_p = (side || deferring()) && lean ? take<float>((size_t)B * 128) : nullptr;
+      float* coef_p = (side || deferring()) && lean ? take<float>((size_t)B * 128) : nullptr;
       float* xn_p = side ? take<float>(n32) : nullptr;
       float* gu_p = side ? take<float>(n32) : nullptr;
       float* dsc_p = side ? take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7)) : nullptr;
@@ -597,8 +682,9 @@ struct Trainer {
       // weight gradients run on the K = 1 weight-gradient kernel: pw2 from (h s, gY), pw1 from (xn, gH0)
       ConvArgs f2 = base(c.pw2, hs, Tt, nullptr);
       ConvArgs f1 = base(c.pw1, xn, Tt, nullptr);
-      float* p2 = side ? side_partial : take<float>(wgrad_partial_floats(c.pw2, B, Tt));
-      float* p1 = side ? side_partial : take<float>(wgrad_partial_floats(c.pw1, B, Tt));
+      const size_t p1n_ = cnx_partial_floats(c.pw1, Tt), p2n_ = cnx_partial_floats(c.pw2, Tt);
+      float* p2 = deferring() ? wg_take(p2n_) : side ? side_partial : take<float>(p2n_);
+      float* p1 = deferring() ? wg_take(p1n_) : side ? side_partial : take<float>(p1n_);
       float* dsc = side ? dsc_p : take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7));
       float* gw2 = PGpacked(c.pw2.wp);
       float* gb2 = PGpacked(c.pw2.bias);
@@ -629,7 +715,13 @@ struct Trainer {
       const float *w1r = c.w1_raw, *b1p = c.b1, *alp = c.alpha;
       auto lean_w1 = [=](hipStream_t s_) {  // dW1 (+ db1) from (gH0, xn), then d alpha from it
         chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, s_));
-        chk(launch_cnx_dalpha(w1r, b1p, alp, gw1, gb1, scale, ds, coef, part, nt, B, dal, s_));
+        auto dalpha = [=](hipStream_t s3) {
+          chk(launch_cnx_dalpha(w1r, b1p, alp, gw1, gb1, scale, ds, coef, part, nt, B, dal, s3));
+        };
+        if (deferring())  // dW1 is complete only after the grouped reduction: d alpha follows it there
+          after_reduce.push_back(dalpha);
+        else
+          dalpha(s_);
       };
       float* gdw = PG(c.dw_w, 32 * 7);
       float* gdb = PG(c.dw_b, 32);
@@ -653,9 +745,9 @@ struct Trainer {
         if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
       } else if (live()) {
         bool done = false;
+        DeferScope dsc_(this);
         if (lean) {
-          chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, st));
-          chk(launch_cnx_dalpha(w1r, b1p, alp, gw1, gb1, scale, ds, coef, part, nt, B, dal, st));
+          lean_w1(st);
         } else if (cnx16) {
           chk(launch_conv_wgrad_cnx(1, hs, gY, B, Tt, gw2, p2, gb2, st));
           chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, st));
@@ -1470,8 +1562,10 @@ struct Trainer {
 
   // ---------------- MelStyleEncoder (mel_style_encoder.py:9-152) in the padded-flat image layout (conv2d.hip) -------
   // every activation is [B][C][H][W+1] with a zero last column; n = H*(W+1) flattened positions
+  // y16_act >= 0: the conv also writes the bf16 operand twin act16(y) of its output (PRO_NONE / PRO_LRELU), registered for
+  // the conv that reads y next
   void conv2d(const PackedConv& w, const float* x, int Cin2d, int n, int Wp, float* y, int hpad, int pad, int pro,
-              float out_scale, const float* residual, const float* mask) {
+              float out_scale, const float* residual, const float* mask, int y16_act = -1) {
     ConvArgs a;
     a.x[0] = x;
     a.xc[0] = w.Cin;
@@ -1490,16 +1584,37 @@ struct Trainer {
     a.out_mask_post = 1;
     a.y = y;
     a.bf16 = m->topts.compute_bf16;
+    if (twins_on() && (pro == PRO_NONE || pro == PRO_LRELU) && w.CinP >= 64 && w.CoutP >= 64 && n % 2 == 0 && wants(x)) {
+      a.x16 = xtwin(x, pro, Cin2d, n);
+      tw_want.insert(y);
+    }
+    if (twins_on() && y16_act >= 0 && n % 2 == 0 && w.CoutP >= 64) {
+      a.y16 = take<__bf16>((size_t)B * w.Cout * n);
+      a.y16_act = y16_act;
+      twin_register(y, y16_act, a.y16);
+    }
     const size_t pn = wgrad_partial_floats(w, B, n);
     side_need = pn > side_need ? pn : side_need;
+    wg_need(pn);
     if (live()) chk(launch_conv1d(a, st));
     tape.push_back([this, a]() { conv2d_bwd(a); });
   }
-  void conv2d_bwd(const ConvArgs& f) {
+  void conv2d_bwd(const ConvArgs& f0) {
+    ConvArgs f = f0;
     const PackedConv& w = f.w;
     const int KH = w.Cin / f.Cin2d, n = f.T;
     const size_t ny = (size_t)B * w.Cout * n, nx = (size_t)B * f.Cin2d * n;
     float* gY = G(f.y, ny);
+    if (f.x16) {  // the weight gradient and the input gradient read gY * mask as a bf16 twin, rounded once
+      auto tg = tw_g.find(gY);
+      if (tg != tw_g.end() && tg->second.second == f.out_mask) {
+        f.g16 = tg->second.first;  // written by gY's last writer
+      } else {
+        __bf16* g16 = take<__bf16>(ny);  // (kept to the end of the step: a side-stream launch reads it)
+        if (live()) chk(launch_twin_cast(gY, f.out_mask, PRO_NONE, B, w.Cout, n, g16, st));
+        f.g16 = g16;
+      }
+    }
     int accR = 1;  // (the first writer of the residual's gradient overwrites: no zero-fill, no read)
     float* gR = (f.residual && wants(f.residual)) ? Gw(f.residual, ny, accR) : nullptr;
     int accX = 1;
@@ -1516,14 +1631,16 @@ struct Trainer {
     if (m->topts.frozen) {
       bias_done = true;
     } else if (side_ready()) {
-      float* sp = side_partial;
+      float* sp = deferring() ? wg_take(wgrad_partial_floats(w, B, n)) : side_partial;
       float* gwp = PGpacked(w.wp);
       side_push(gY, [=](hipStream_t s) {
         chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, gwp, sp, gbias, nullptr, s));
       });
       bias_done = wgrad_fuses_bias(w);
     } else {
-      float* partial = take<float>(wgrad_partial_floats(w, B, n));
+      const size_t pn = wgrad_partial_floats(w, B, n);
+      float* partial = deferring() ? wg_take(pn) : take<float>(pn);
+      DeferScope ds(this);
       if (live())
         chk(launch_conv1d_wgrad(f, gY, f.out_mask, f.out_scale, PGpacked(w.wp), partial, gbias, &bias_done, st));
     }
@@ -1553,6 +1670,7 @@ struct Trainer {
       d.Cin2d = w.Cout;
       d.pro = PRO_MASK;
       d.mask = f.out_mask;
+      d.x16 = f.g16;  // (the mask is in the twin)
       d.out_scale = f.out_scale;
       d.y = U;
       const bool defer_gate = getenv("STY_NO_DEFERRED_GATE") == nullptr;  // A/B switch, read per call (the parity test toggles it)
@@ -1584,6 +1702,7 @@ struct Trainer {
     int C, H, W;
   };
   std::vector<SeTap> se_taps;
+  SeTap se_pre2[4] = {};
   // pitch / energy != nullptr: PitchStyleEncoder (mel_style_encoder.py:155-205, coarse_multiplier 1): the trunk runs on
   // preconv(cat(mel, pitch, energy)) -- a weight-normed Conv1d(k = 1, padding = 1), so T + 2 frames -- and the backward
   // reaches the preconv's parameters (the three inputs are data: no gradient)
@@ -1592,6 +1711,10 @@ struct Trainer {
     const StylePlan& sp = m->sty_enc;
     tape.clear();
     gmap.clear();
+    tw_x[0].clear();
+    tw_x[1].clear();
+    tw_want.clear();
+    tw_g.clear();
     nograd.clear();
     ungated.clear();
     scratch_param_n = 1 << 16;
@@ -1644,7 +1767,7 @@ struct Trainer {
     }
     const float* mk = mask_for(H, W, H, W);
     float* x = take<float>((size_t)B * C * H * (W + 1));
-    conv2d(sp.stem, melp, 1, H * (W + 1), W + 1, x, 1, 1, PRO_NONE, 1.f, nullptr, mk);
+    conv2d(sp.stem, melp, 1, H * (W + 1), W + 1, x, 1, 1, PRO_NONE, 1.f, nullptr, mk, PRO_LRELU);
     se_taps.clear();
     se_taps.push_back({x, C, H, W});
     for (int i = 0; i < 4; ++i) {
@@ -1657,22 +1780,28 @@ struct Trainer {
       const float* res = nullptr;
       // learned shortcut + down-sampling: pool first, then the 1x1 conv (they commute, see Run::style_encoder): its
       // forward, input gradient and weight gradient run on a quarter of the positions
-      auto pool = [&](const float* src, int Cc, float scale) {
+      auto pool = [&](const float* src, int Cc, float scale, bool twin = false) {
         float* out = take<float>((size_t)B * Cc * no);
-        if (live()) chk(launch_avgpool2(src, B * Cc, H, W, scale, out, st));
+        __bf16* o16 = twin && twins_on() && no % 2 == 0 ? take<__bf16>((size_t)B * Cc * no) : nullptr;
+        if (o16) twin_register(out, PRO_NONE, o16);
+        if (live()) chk(launch_avgpool2(src, B * Cc, H, W, scale, out, st, o16));
         const int BC = B * Cc;
+        const float* mk_in = mk;  // the mask of the activation being pooled (its producer's output mask)
         tape.push_back([=]() {
           float* g = G(out, (size_t)BC * no);
           // gs = gs * lrelu'(src) + up(g) in the one pass that accumulates into gs anyway
           const bool gated = gate_pending(src);
           if (gated) ungated.erase(src);
           float* gs = G(src, (size_t)BC * n);
-          if (live()) chk(launch_avgpool2_bwd(g, BC, Hc, Wc, scale, gs, gated ? src : nullptr, st));
+          // this pass is the last writer of d loss / d src: it also leaves the bf16 operand twin for src's producer
+          __bf16* g16 = twins_on() && tw_want.count(src) && n % 4 == 0 ? take<__bf16>((size_t)BC * n) : nullptr;
+          if (g16) tw_g[gs] = std::make_pair(g16, mk_in);
+          if (live()) chk(launch_avgpool2_bwd(g, BC, Hc, Wc, scale, gs, gated ? src : nullptr, st, g16, mk_in, Cc));
         });
         return out;
       };
       if (k.down && k.has_sc) {
-        const float* pooled = pool(xin, k.Cin, 1.f);
+        const float* pooled = pool(xin, k.Cin, 1.f, true);
         float* sc = take<float>((size_t)B * k.Cout * no);
         conv2d(k.sc, pooled, k.Cin, no, Wo + 1, sc, 0, 0, PRO_NONE, r2, nullptr, mko);
         res = sc;
@@ -1684,31 +1813,38 @@ struct Trainer {
         res = sc_full;
       }
       float* h1 = take<float>((size_t)B * k.Cin * n);
-      conv2d(k.c1, xin, k.Cin, n, W + 1, h1, 1, 1, PRO_LRELU, 1.f, nullptr, mk);
+      conv2d(k.c1, xin, k.Cin, n, W + 1, h1, 1, 1, PRO_LRELU, 1.f, nullptr, mk, k.down ? -1 : PRO_LRELU);
       const float* h = h1;
       if (k.down) {
         float* h2 = take<float>((size_t)B * k.Cin * no);
-        if (live()) chk(launch_dwconv2d_s2(h1, k.dw_w9, k.dw_b, B, k.Cin, H, W, h2, st));
+        __bf16* h2_16 = twins_on() && no % 2 == 0 ? take<__bf16>((size_t)B * k.Cin * no) : nullptr;
+        if (h2_16) twin_register(h2, PRO_LRELU, h2_16);
+        if (live()) chk(launch_dwconv2d_s2(h1, k.dw_w9, k.dw_b, B, k.Cin, H, W, h2, st, h2_16));
         const float* w9 = k.dw_w9;
         const float* dwb = k.dw_b;
         const int Cc = k.Cin;
+        const float* mk1 = mk;  // conv1's output mask
         tape.push_back([=]() {
           // a deferred gate on g(h2) is applied as g is read (the buffer itself stays as it is, and stays marked)
           const bool gated = gate_pending(h2);
           float* g = G(h2, (size_t)B * Cc * no, gated);
           int acc = 1;  // (h1 feeds nothing else: this is the first writer of its gradient, no zero-fill, no read)
           float* gx = Gw(h1, (size_t)B * Cc * n, acc);
+          // ... and the last: the bf16 operand twin of d loss / d h1 (times conv1's output mask) for conv1's backward
+          __bf16* g16 = twins_on() && !acc && tw_want.count(h1) && n % 4 == 0 ? take<__bf16>((size_t)B * Cc * n) : nullptr;
+          if (g16) tw_g[gx] = std::make_pair(g16, mk1);
           const size_t mark = ws.off;
           float* sc = take<float>(dwconv2d_s2_bwd_scratch_floats(B, Cc, Hc, Wc));
           if (live())
             chk(launch_dwconv2d_s2_bwd(h1, g, gated ? h2 : nullptr, w9, B, Cc, Hc, Wc, gx, acc, PGpacked(w9), PG(dwb, Cc), sc,
-                                       st));
+                                       st, g16, mk1));
           ws.off = mark;
         });
         h = h2;
       }
+      se_pre2[i] = {h, k.Cin, Ho, Wo};
       float* y = take<float>((size_t)B * k.Cout * no);
-      conv2d(k.c2, h, k.Cin, no, Wo + 1, y, 1, 1, PRO_LRELU, r2, res, mko);
+      conv2d(k.c2, h, k.Cin, no, Wo + 1, y, 1, 1, PRO_LRELU, r2, res, mko, res ? PRO_LRELU : -1);
       if (!res) {  // identity shortcut: y += x / sqrt2
         const size_t ne = (size_t)B * k.Cout * no;
         if (live()) chk(launch_axpy(xin, r2, y, ne, st));
@@ -1738,6 +1874,7 @@ struct Trainer {
     float* hd = take<float>((size_t)B * C * n);
     conv2d(sp.head, x, C, n, W + 1, hd, 0, 0, PRO_LRELU, 1.f, nullptr, mkh);
     se_taps.push_back({hd, C, H, W});
+    for (int i = 0; i < 4; ++i) se_taps.push_back(se_pre2[i]);  // taps 6..9: the input of each ResBlk's second LeakyReLU
     style_out = style_dst;
     if (live()) chk(launch_pool_fc(hd, B, C, n, Hh * Wh, sp.fc_w, sp.fc_b, sp.style_dim, style_dst, st));
     const float* fw = sp.fc_w;
@@ -1768,9 +1905,14 @@ struct Trainer {
   void begin(const float* style_in) {
     style = style_in;
     side_need = 0;
+    wg_sum = 0;
     drop_site = 0;
     tape.clear();
     gmap.clear();
+    tw_x[0].clear();
+    tw_x[1].clear();
+    tw_want.clear();
+    tw_g.clear();
     nograd.clear();
     scratch_param_n = 1 << 20;
     scratch_param = take<float>(scratch_param_n);
@@ -2156,6 +2298,7 @@ int trainer_style_forward(Trainer* t, int B, int T, const float* mel, float* sty
   t->ws.cap = need ? (size_t(1) << 46) : ws_bytes;
   t->peak = 0;
   t->side_need = 0;
+  t->wg_sum = 0;
   const bool pse = t->m->kind == "pitch_style_encoder";
   t->style_forward(need ? reinterpret_cast<const float*>(8) : mel, T, need ? reinterpret_cast<float*>(16) : style,
                    pse ? (need ? reinterpret_cast<const float*>(24) : pitch) : nullptr,

@@ -9,6 +9,9 @@
 // registers and writes ONE partial result; a second kernel sums the partials in a fixed order (deterministic, no
 // float atomics) into the packed gradient.
 #include <stdlib.h>
+#include <string.h>
+
+#include <vector>
 
 #include "conv_stage.h"
 
@@ -22,6 +25,20 @@ constexpr int WG_TW = 128;      // time samples per chunk
 static const int WG_TARGET_ENV = getenv("STY_WG_TARGET") ? atoi(getenv("STY_WG_TARGET")) : 0;
 static const int WG_TARGET = WG_TARGET_ENV ? WG_TARGET_ENV : 1024;
 static inline int wg_target(bool bf16) { return WG_TARGET_ENV ? WG_TARGET_ENV : (bf16 ? 768 : 1024); }
+// The partial planes are traffic too: nsplit planes written by the weight-gradient kernel and read back by the reduction.
+// On the layers with few positions and many weights (the 256 <-> 1024 pointwise convs at T = 520: 16 640 positions, planes
+// of 0.25-1 M elements) a split aimed at ~3 workgroups per CU moved 50 MB of partial sums for 85 MB of operands -- 3 GB
+// per c3 step in all.  STY_WG_PARTIAL_FRAC = f caps the split so that the partial planes stay below f x the operand bytes
+// (0 = no cap).
+static const float WG_PARTIAL_FRAC = getenv("STY_WG_PARTIAL_FRAC") ? (float)atof(getenv("STY_WG_PARTIAL_FRAC")) : 0.f;
+static inline int wg_cap_partial(int nsplit, const PackedConv& w, int B, int T) {
+  if (WG_PARTIAL_FRAC <= 0.f) return nsplit;
+  const double operands = (double)B * T * (w.Cin + w.Cout), plane = (double)w.K * w.CinP * w.CoutP;
+  int cap = (int)(WG_PARTIAL_FRAC * operands / plane);
+  if (cap < 1) cap = 1;
+  if (cap >= 8) cap &= ~7;
+  return nsplit < cap ? nsplit : cap;
+}
 
 // BF (all weight-gradient kernels): bf16 compute mode, see conv1d.hip -- each lane reads eight consecutive time samples
 // of its row from LDS, rounds them to bf16 and issues one v_mfma_f32_32x32x16_bf16 per 16 samples.
@@ -421,7 +438,7 @@ static int wgrad64_nsplit(const PackedConv& w, int B, int T, bool bf16 = false) 
   int nsplit = cdiv(tiles >= 16 ? target : target / 2, tiles);
   if (nsplit >= 8) nsplit = (nsplit + 7) & ~7;  // a multiple of 8: wgradb_kernel then keeps the blocks of a split on one XCD
   if (nsplit > chunks) nsplit = chunks;
-  return nsplit;
+  return wg_cap_partial(nsplit, w, B, T);
 }
 
 // ---- K == 1 (Linear / 1x1 conv) weight gradient: dW[co][ci] = sum_{b,t} G[co][t] x[ci][t] ----
@@ -629,7 +646,7 @@ static int w1_nsplit(const PackedConv& w, int B, int T, W1Cfg c, bool bf16 = fal
   const int chunks = B * cdiv(T, W1_TW);
   int nsplit = cdiv(wg_target(bf16), tiles);
   if (nsplit > chunks) nsplit = chunks;
-  return nsplit;
+  return wg_cap_partial(nsplit, w, B, T);
 }
 
 // Slices are `stride` floats apart: [plane weight partials][nb bias partials (fused bias gradient, or unused)].
@@ -684,8 +701,187 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       gbias[i - plane] += t * scale;
   }
 }
+// ---- deferred, grouped reduction ----
+// Every weight-gradient launch used to be followed by a reduction launch of its own (c3: 141 per step, 10 us each of
+// mostly launch latency, 1.5 ms serial).  With a WgReduceDefer current on the calling thread (the trainer sets one for the
+// duration of a backward, wgrad_defer_set) the reduction is only RECORDED -- the caller hands every weight-gradient launch
+// a partial buffer of its own instead of one shared scratch -- and wgrad_defer_flush sums all recorded jobs in ONE launch
+// over a device-side job table (before a gradient segment is announced / at the end of the backward).  The arithmetic per
+// element is exactly that of the two kernels above (same slice order, same 16-group tree), so both paths give the same bits.
+struct WgReduceJob {
+  const float* partial;
+  float* gwp;
+  float* gbias;
+  unsigned long long plane, stride;
+  int nslices, nb;
+  float scale;
+  unsigned blk0;  // first workgroup of this job in the grouped launch
+};
+struct WgReduceSlot {  // one flush site: device table + pinned staging + the event of the last launch that read it
+  WgReduceJob* dev = nullptr;
+  WgReduceJob* host = nullptr;
+  size_t cap = 0;  // jobs
+  hipEvent_t done = nullptr;
+  std::vector<char> sent;
+};
+struct WgReduceDefer {
+  std::vector<WgReduceJob> jobs;
+  std::vector<WgReduceSlot> slots;
+  size_t launches_saved = 0;
+  ~WgReduceDefer() {
+    for (WgReduceSlot& s : slots) {
+      if (s.dev) (void)hipFree(s.dev);
+      if (s.host) (void)hipHostFree(s.host);
+      if (s.done) (void)hipEventDestroy(s.done);
+    }
+  }
+};
+static thread_local WgReduceDefer* g_wg_defer = nullptr;
+WgReduceDefer* wgrad_defer_create() { return new WgReduceDefer(); }
+void wgrad_defer_destroy(WgReduceDefer* d) {
+  if (g_wg_defer == d) g_wg_defer = nullptr;
+  delete d;
+}
+WgReduceDefer* wgrad_defer_set(WgReduceDefer* d) {
+  WgReduceDefer* old = g_wg_defer;
+  g_wg_defer = d;
+  return old;
+}
+size_t wgrad_defer_pending(const WgReduceDefer* d) { return d ? d->jobs.size() : 0; }
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgReduceJob* __restrict__ jobs, int njobs) {
+  __shared__ float red[16][17];
+  // the job of this workgroup: the last one whose first workgroup is <= blockIdx.x (wave-uniform binary search)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgReduceJob j = jobs[lo];
+  const unsigned blk = blockIdx.x - j.blk0;
+  const size_t n = j.plane + j.nb;
+  if (j.nslices >= 16) {  // wgrad_reduce_kernel
+    const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const size_t i = (size_t)blk * 16 + e;
+    float s = 0.f;
+    if (i < n)
+      for (int k = sg; k < j.nslices; k += 16) s += j.partial[(size_t)k * j.stride + i];
+    red[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && i < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][e];
+      if (i < j.plane)
+        j.gwp[i] += t * j.scale;
+      else
+        j.gbias[i - j.plane] += t * j.scale;
+    }
+  } else {  // wgrad_reduce_small_kernel
+    const size_t i = (size_t)blk * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < j.nslices; ++k) s += j.partial[(size_t)k * j.stride + i];
+    if (i < j.plane)
+      j.gwp[i] += s * j.scale;
+    else
+      j.gbias[i - j.plane] += s * j.scale;
+  }
+}
+
+// One launch for every recorded job (jobs that write the same packed gradient -- a weight used twice in a graph -- go to
+// consecutive launches).  `site`: ordinal of the flush within the backward; a site's table is the same every step of a
+// training run (the workspace is laid out deterministically), so in the steady state nothing is uploaded; when it
+// changes, the slot's previous reader is waited for (an event, normally long complete) and the table goes through the
+// slot's pinned buffer with an asynchronous copy on `st`: no stream synchronisation in the middle of a backward.
+int wgrad_defer_flush(WgReduceDefer* d, int site, hipStream_t st) {
+  if (!d || d->jobs.empty()) return STY_OK;
+  std::vector<WgReduceJob> all;
+  all.swap(d->jobs);
+  if (getenv("STY_WG_DUMP")) {  // tuning aid: the partial volume of every recorded reduction
+    double tot = 0.0;
+    for (const WgReduceJob& j : all) {
+      fprintf(stderr, "wg_reduce site %d: plane %llu nb %d nslices %d -> %.2f MB\n", site, j.plane, j.nb, j.nslices,
+              4e-6 * (double)(j.plane + j.nb) * j.nslices);
+      tot += 4e-6 * (double)(j.plane + j.nb) * j.nslices;
+    }
+    fprintf(stderr, "wg_reduce site %d: %zu jobs, %.1f MB of partial sums\n", site, all.size(), tot);
+  }
+  // split into rounds without overlapping destinations (stable: a job goes to the first round after every job it overlaps)
+  std::vector<int> round(all.size(), 0);
+  int nrounds = 1;
+  for (size_t a = 0; a < all.size(); ++a)
+    for (size_t b = 0; b < a; ++b) {
+      const float *al = all[a].gwp, *ah = all[a].gwp + all[a].plane, *bl = all[b].gwp, *bh = all[b].gwp + all[b].plane;
+      const bool wov = al < bh && bl < ah;
+      const bool bov = all[a].nb && all[b].nb && all[a].gbias < all[b].gbias + all[b].nb && all[b].gbias < all[a].gbias + all[a].nb;
+      if ((wov || bov) && round[a] <= round[b]) {
+        round[a] = round[b] + 1;
+        nrounds = round[a] + 1 > nrounds ? round[a] + 1 : nrounds;
+      }
+    }
+  for (int r = 0; r < nrounds; ++r) {
+    std::vector<WgReduceJob> tab;
+    unsigned nblk = 0;
+    for (size_t a = 0; a < all.size(); ++a) {
+      if (round[a] != r) continue;
+      WgReduceJob j = all[a];
+      const size_t n = j.plane + j.nb;
+      j.blk0 = nblk;
+      nblk += (unsigned)(j.nslices >= 16 ? (n + 15) / 16 : (n + 255) / 256);
+      tab.push_back(j);
+    }
+    if (tab.empty()) continue;
+    const size_t slot_i = (size_t)site * 4 + (size_t)(r < 3 ? r : 3);
+    if (d->slots.size() <= slot_i) d->slots.resize(slot_i + 1);
+    WgReduceSlot& sl = d->slots[slot_i];
+    const size_t nbytes = tab.size() * sizeof(WgReduceJob);
+    const bool same = sl.sent.size() == nbytes && memcmp(sl.sent.data(), tab.data(), nbytes) == 0;
+    if (!same) {
+      if (sl.done) STY_HIP(hipEventSynchronize(sl.done));  // the slot's last reader (normally finished long ago)
+      if (sl.cap < tab.size()) {
+        if (sl.dev) STY_HIP(hipFree(sl.dev));
+        if (sl.host) STY_HIP(hipHostFree(sl.host));
+        sl.dev = nullptr;
+        sl.host = nullptr;
+        sl.cap = tab.size() + 64;
+        STY_HIP(hipMalloc((void**)&sl.dev, sl.cap * sizeof(WgReduceJob)));
+        STY_HIP(hipHostMalloc((void**)&sl.host, sl.cap * sizeof(WgReduceJob), hipHostMallocDefault));
+      }
+      memcpy(sl.host, tab.data(), nbytes);
+      STY_HIP(hipMemcpyAsync(sl.dev, sl.host, nbytes, hipMemcpyHostToDevice, st));
+      sl.sent.assign(reinterpret_cast<const char*>(tab.data()), reinterpret_cast<const char*>(tab.data()) + nbytes);
+    }
+    double bytes = 0.0;
+    for (const WgReduceJob& j : tab) bytes += 4.0 * (double)(j.plane + j.nb) * (j.nslices + 2);
+    {
+      ProfScope prof("wgrad_reduce_multi_kernel", 0.0, bytes, st, nullptr);
+      hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblk), dim3(256), 0, st, sl.dev, (int)tab.size());
+    }
+    STY_LAUNCH_CHECK();
+    if (!sl.done) STY_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    STY_HIP(hipEventRecord(sl.done, st));
+    d->launches_saved += tab.size() - 1;
+  }
+  return STY_OK;
+}
+
 static void launch_wgrad_reduce(const float* partial, int nslices, size_t plane, size_t stride, int nb, float scale,
                                 float* gwp, float* gbias, hipStream_t st) {
+  if (g_wg_defer) {  // recorded; summed by wgrad_defer_flush (the caller gave this launch a partial buffer of its own)
+    WgReduceJob j;
+    j.partial = partial;
+    j.gwp = gwp;
+    j.gbias = gbias;
+    j.plane = plane;
+    j.stride = stride;
+    j.nslices = nslices;
+    j.nb = nb;
+    j.scale = scale;
+    j.blk0 = 0;
+    g_wg_defer->jobs.push_back(j);
+    return;
+  }
   const size_t n = plane + nb;
   if (nslices >= 16)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, partial, nslices, plane,
@@ -746,7 +942,8 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
       const int chunks = wgradb_chunks(w, fwd.B, fwd.T, fwd.dil);
       const int ns = nsplit < chunks ? nsplit : chunks;
       const int wb = gbias != nullptr;
-      int rc = launch_wgradb(ax1, ag, ns, partial, wb, st);
+      // both operands as bf16 twins (x16: prologue applied; g16: mask applied): no conversion, half the bytes
+      int rc = wgradb16_eligible(ax1) ? launch_wgradb16(ax1, ns, partial, wb, st) : launch_wgradb(ax1, ag, ns, partial, wb, st);
       if (rc) return rc;
       const size_t plane = (size_t)w.CinP * w.CoutP;
       launch_wgrad_reduce(partial, ns, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
@@ -802,7 +999,7 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
     int ns = wgrad64_nsplit(w, fwd.B, fwd.T, fwd.bf16 != 0);
     if (ns > chunks) ns = chunks;
     const int wb = gbias != nullptr;
-    int rc = launch_wgradb(ax, ag, ns, partial, wb, st);
+    int rc = wgradb16_eligible(ax) ? launch_wgradb16(ax, ns, partial, wb, st) : launch_wgradb(ax, ag, ns, partial, wb, st);
     if (rc) return rc;
     const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
     launch_wgrad_reduce(partial, ns, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);

@@ -419,6 +419,291 @@ int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* par
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
+// =====================================================================================================================
+// The same weight gradient on bf16 OPERAND TWINS (ConvArgs::x16, ::g16): both operands already live in HBM as the bf16
+// values the GEMM multiplies (prologue / mask applied, rounded once by the kernel that produced the tensor), [B][C][T]
+// like their fp32 masters.  Nothing is converted and no prologue runs here:
+//   * a thread owns (row, 8 consecutive samples) as FOUR dwords of bf16 pairs: x by one 16-byte + one 4-byte load from the
+//     even sample below its first one and a v_alignbit per dword when that first sample is odd (the tap / image-row shift
+//     decides); G by one 8-byte + one 16-byte load of the 12-sample window [t - 4, t + 8), out of which the K copies
+//     shifted by one sample each are cut with compile-time shifts (even shifts: the dwords as they are, odd: v_alignbit);
+//   * half the bytes of the fp32 path from L2 (the 64 x 64 blocks re-read x Cout / 64 and G Cin / 64 times: that traffic
+//     was the kernel's limit) and from HBM; ~40 VALU instructions per chunk and thread where the fp32 path had ~200;
+//   * groups that straddle a row end take a sample-by-sample path (16-bit loads, out-of-row samples from an out-of-range
+//     offset = 0): a 16-byte load that is only partly inside the descriptor returns 0 for all of it;
+//   * the bias gradient is one more MFMA of the k = 0 copy against a fragment of ones (its row sums), as in wgrad_cnx_kernel.
+// Same blocks, same XCD slot mapping, same partial planes + reduction as wgradb_kernel; T must be even (dword-aligned rows).
+// =====================================================================================================================
+__device__ __forceinline__ unsigned wb16_one(__amdgpu_buffer_rsrc_t rs, int row_off, int i, int T) {
+  const bool in = i >= 0 && i < T;
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, in ? row_off + i * 2 : WB_OOB, 0, 0);
+}
+// samples i0 .. i0 + 2 N - 1 of a row as N dwords of pairs, sample by sample (row ends)
+template <int N>
+__device__ __forceinline__ void wb16_slow(__amdgpu_buffer_rsrc_t rs, int row_off, int i0, int T, unsigned (&d)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) d[j] = wb16_one(rs, row_off, i0 + 2 * j, T) | (wb16_one(rs, row_off, i0 + 2 * j + 1, T) << 16);
+}
+
+template <int KN, int TW, int F>
+__global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nsplit, int chunks_per_b,
+                                                          float* __restrict__ partial, int want_bias) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
+  constexpr int PITCH = TW + 8;
+  constexpr int R = 64 * F;
+  __bf16* xs = wb_lds;                // [R][PITCH]
+  __bf16* gs = wb_lds + R * PITCH;    // [KN][R][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
+            hi = lane >> 5;
+  const int wi = wave >> 1, wo = wave & 1;
+  const int T = ax.T, pad = ax.pad;
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if ((nsplit & 7) == 0) {  // the blocks of one reduction split on one XCD (see wgradb_kernel)
+    const int gx = gridDim.x, nb = gx * (int)gridDim.y;
+    const int id = bx + gx * (by + (int)gridDim.y * split);
+    const int xcd = id & 7, slot = id >> 3;
+    const int blk = slot % nb;
+    split = (slot / nb) * 8 + xcd;
+    bx = blk % gx;
+    by = blk / gx;
+  }
+  const int ci0 = bx * R, co0 = by * R;
+  constexpr int GPR = TW / 8, NI = TW / 32 * F, RSTEP = 256 / GPR;
+  const int g8 = (tid % GPR) * 8, r0 = tid / GPR;
+  const bool do_bias = want_bias && bx == 0;
+
+  f32x16 acc[KN][F][F];
+#pragma unroll
+  for (int k = 0; k < KN; ++k)
+#pragma unroll
+    for (int fi = 0; fi < F; ++fi)
+#pragma unroll
+      for (int fo = 0; fo < F; ++fo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][fi][fo][r] = 0.f;
+  f32x16 accb[F];
+#pragma unroll
+  for (int fo = 0; fo < F; ++fo)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[fo][r] = 0.f;
+  const bf16x8 ones = sty_pack_bf16(1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f);
+
+  const int Cx = ax.flatW ? ax.Cin2d : ax.xc[0];
+  const int Cg = ax.w.Cout;
+  int offx[NI], tshx[NI], offg[NI];
+#pragma unroll
+  for (int m = 0; m < NI; ++m) {
+    const int ci = ci0 + r0 + RSTEP * m;
+    int cc = ci, tsh = 0;
+    if (ax.flatW) {
+      const int c2 = ax.Cin2d;
+      const int kh = (ci >= c2) + (ci >= 2 * c2) + (ci >= 3 * c2) + (ci >= 4 * c2);
+      cc = ci - kh * c2;
+      tsh = (kh - ax.hpad) * ax.flatW;
+    }
+    tshx[m] = tsh;
+    offx[m] = ci < ax.w.Cin ? cc * T * 2 : WB_OOB;
+    const int co = co0 + r0 + RSTEP * m;
+    offg[m] = co < Cg ? co * T * 2 : WB_OOB;
+  }
+  constexpr int GN = KN > 1 ? 6 : 4;  // dwords of the G window
+  unsigned xw[NI][5], gw[NI][GN];
+  const int total = ax.B * chunks_per_b;
+  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+
+  auto load_chunk = [&](int b, int c) {
+    const int t0 = c * TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(ax.x16 + (size_t)b * Cx * T), 0, Cx * T * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(ax.g16 + (size_t)b * Cg * T), 0, Cg * T * 2, 0x00020000);
+    const int ig0 = t0 + g8;
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      {  // x: samples s0 .. s0 + 7 of the row; loaded from the even sample at or below s0
+        const int s0 = t0 - pad + g8 + tshx[m];
+        const int base = s0 & ~1;
+        if (base >= 0 && base + 9 < T) {
+          const uint4 a = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, offx[m] + base * 2, 0, 0));
+          xw[m][0] = a.x;
+          xw[m][1] = a.y;
+          xw[m][2] = a.z;
+          xw[m][3] = a.w;
+          xw[m][4] = __builtin_amdgcn_raw_buffer_load_b32(rx, offx[m] + base * 2 + 16, 0, 0);
+        } else {
+          wb16_slow<5>(rx, offx[m], base, T, xw[m]);
+        }
+      }
+      if constexpr (KN > 1) {  // G: the window [ig0 - 4, ig0 + 8)
+        if (ig0 - 4 >= 0 && ig0 + 7 < T) {
+          const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, offg[m] + (ig0 - 4) * 2, 0, 0));
+          const uint4 a = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, offg[m] + ig0 * 2, 0, 0));
+          gw[m][0] = lo.x;
+          gw[m][1] = lo.y;
+          gw[m][2] = a.x;
+          gw[m][3] = a.y;
+          gw[m][4] = a.z;
+          gw[m][5] = a.w;
+        } else {
+          wb16_slow<GN>(rg, offg[m], ig0 - 4, T, gw[m]);
+        }
+      } else {
+        if (ig0 + 7 < T) {
+          const uint4 a = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, offg[m] + ig0 * 2, 0, 0));
+          gw[m][0] = a.x;
+          gw[m][1] = a.y;
+          gw[m][2] = a.z;
+          gw[m][3] = a.w;
+        } else {
+          wb16_slow<GN>(rg, offg[m], ig0, T, gw[m]);
+        }
+      }
+    }
+  };
+  auto advance = [&](int& b, int& c) {
+    c += nsplit;
+    while (c >= chunks_per_b) {
+      c -= chunks_per_b;
+      ++b;
+    }
+  };
+
+  int ch = split;
+  if (ch < total) load_chunk(cb, cc_);
+  for (; ch < total; ch += nsplit) {
+    const int t0 = cc_ * TW;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      const int row = r0 + RSTEP * m;
+      {
+        const unsigned sh = ((unsigned)(t0 - pad + g8 + tshx[m]) & 1u) * 16u;
+        uint4 v;
+        v.x = __builtin_amdgcn_alignbit(xw[m][1], xw[m][0], sh);
+        v.y = __builtin_amdgcn_alignbit(xw[m][2], xw[m][1], sh);
+        v.z = __builtin_amdgcn_alignbit(xw[m][3], xw[m][2], sh);
+        v.w = __builtin_amdgcn_alignbit(xw[m][4], xw[m][3], sh);
+        *reinterpret_cast<uint4*>(xs + row * PITCH + g8) = v;
+      }
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {  // copy k: samples ig0 - k .. ig0 - k + 7 = window positions 4 - k ..
+        uint4 v;
+        if constexpr (KN == 1) {
+          v = make_uint4(gw[m][0], gw[m][1], gw[m][2], gw[m][3]);
+        } else {
+          const int p = 4 - k;  // compile-time after unrolling
+          if ((p & 1) == 0) {
+            v = make_uint4(gw[m][p / 2], gw[m][p / 2 + 1], gw[m][p / 2 + 2], gw[m][p / 2 + 3]);
+          } else {
+            const int q = (p - 1) / 2;
+            v.x = __builtin_amdgcn_alignbit(gw[m][q + 1], gw[m][q], 16);
+            v.y = __builtin_amdgcn_alignbit(gw[m][q + 2], gw[m][q + 1], 16);
+            v.z = __builtin_amdgcn_alignbit(gw[m][q + 3], gw[m][q + 2], 16);
+            v.w = __builtin_amdgcn_alignbit(gw[m][q + 4], gw[m][q + 3], 16);
+          }
+        }
+        *reinterpret_cast<uint4*>(gs + (k * R + row) * PITCH + g8) = v;
+      }
+    }
+    __syncthreads();
+    advance(cb, cc_);
+    if (ch + nsplit < total) load_chunk(cb, cc_);
+    const __bf16* xr = xs + (wi * 32 * F + l31) * PITCH + 8 * hi;
+    const __bf16* gr = gs + (wo * 32 * F + l31) * PITCH + 8 * hi;
+#pragma unroll
+    for (int s8 = 0; s8 < TW / 16; ++s8) {
+      bf16x8 bp[F];
+#pragma unroll
+      for (int fi = 0; fi < F; ++fi) bp[fi] = *reinterpret_cast<const bf16x8*>(xr + fi * 32 * PITCH + 16 * s8);
+#pragma unroll
+      for (int k = 0; k < KN; ++k)
+#pragma unroll
+        for (int fo = 0; fo < F; ++fo) {
+          const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + (k * R + fo * 32) * PITCH + 16 * s8);
+#pragma unroll
+          for (int fi = 0; fi < F; ++fi)
+            acc[k][fi][fo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp[fi], acc[k][fi][fo], 0, 0, 0);
+          if (k == 0 && do_bias && wi == 0) accb[fo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, ones, accb[fo], 0, 0, 0);
+        }
+    }
+  }
+
+  const int K = ax.w.K, CinP = ax.w.CinP, CoutP = ax.w.CoutP;
+  const size_t plane = (size_t)K * CinP * CoutP;
+  const size_t stride = plane + CoutP;
+  if (do_bias && wi == 0 && l31 == 0) {  // accb[fo][r] = sum_t G[co][t] for the A row (co) of register r, in every column
+    float* pb = partial + (size_t)split * stride + plane;
+#pragma unroll
+    for (int fo = 0; fo < F; ++fo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wo * F + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co < CoutP) pb[co] = accb[fo][r];
+      }
+  }
+  float* p = partial + (size_t)split * stride;
+#pragma unroll
+  for (int k = 0; k < KN; ++k)
+#pragma unroll
+    for (int fi = 0; fi < F; ++fi) {
+      const int ci = ci0 + (wi * F + fi) * 32 + l31;
+      if (k < K && ci < CinP) {
+#pragma unroll
+        for (int fo = 0; fo < F; ++fo)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (wo * F + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < CoutP) p[((size_t)k * CinP + ci) * CoutP + co] = acc[k][fi][fo][r];
+          }
+      }
+    }
+}
+
+static bool wb_wide(const ConvArgs& ax);
+bool wgradb16_eligible(const ConvArgs& fwd) {
+  const PackedConv& w = fwd.w;
+  if (!fwd.x16 || !fwd.g16 || !fwd.bf16 || getenv("STY_NO_WGRADB16")) return false;
+  if (!(w.K == 1 || w.K == 3 || w.K == 5) || w.CinP < 64 || w.CoutP < 64) return false;
+  if (!(fwd.flatW || fwd.nsrc == 1) || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
+  if (fwd.flatW && w.K == 1) return false;
+  if (w.K > 1 && fwd.dil != 1) return false;  // the shifted copies are cut out of one window of G
+  if (fwd.T & 1) return false;                // rows start on dword boundaries
+  return true;
+}
+constexpr int wb16_tw(int kn, int f) { return (kn > 3 || f > 1) ? 64 : 128; }
+template <int KN, int F>
+static void wb16_launch(const ConvArgs& ax, dim3 grid, size_t lds, int nsplit, int cpb, float* partial, int wb, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb16_kernel<KN, wb16_tw(KN, F), F>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    raised = true;
+  }
+  hipLaunchKernelGGL((wgradb16_kernel<KN, wb16_tw(KN, F), F>), grid, dim3(256), lds, st, ax, nsplit, cpb, partial, wb);
+}
+int launch_wgradb16(const ConvArgs& ax, int nsplit, float* partial, int want_bias, hipStream_t st) {
+  const PackedConv& w = ax.w;
+  const int f = wb_wide(ax) ? 2 : 1;
+  const int tw = wb16_tw(w.K, f);
+  const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, tw);
+  dim3 grid(cdiv(w.CinP, 64 * f), cdiv(w.CoutP, 64 * f), nsplit);
+  const size_t lds = (size_t)(1 + w.K) * 64 * f * (tw + 8) * sizeof(__bf16);
+  char detail[40];
+  snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW);
+  ProfScope prof(w.K == 1 ? "wgradb16_kernel<1,true>" : (w.K == 3 ? "wgradb16_kernel<3,true>" : "wgradb16_kernel<5,true>"),
+                 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T, 2.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
+  if (w.K == 1 && f == 2)
+    wb16_launch<1, 2>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else if (w.K == 1)
+    wb16_launch<1, 1>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else if (w.K == 3)
+    wb16_launch<3, 1>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else
+    wb16_launch<5, 1>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 int wgradb_chunks(const PackedConv& w, int B, int T, int dil) { return B * cdiv(T + (w.K - 1) * dil, 128); }  // (a lower bound of the masked variant's count)
 
 

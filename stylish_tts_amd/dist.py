@@ -18,11 +18,19 @@ import torch
 import torch.distributed as dist
 
 
+def force_collective():
+    """STY_DIST_FORCE_COLLECTIVE=1: run the gradient exchange through the backend even when the world has ONE rank (a
+    sum over one rank is the identity).  A 1-GPU box can then put RCCL itself under the step -- library load, communicator
+    set-up, the gradient hook -> all_reduce(async_op=True) -> AdamW-wait stream ordering, RCCL's own streams beside the
+    trainer's four -- which is what tests/test_boundary_gpu.py::test_rccl_world1_* and bench.py's `c3-rccl1` record do."""
+    return os.environ.get("STY_DIST_FORCE_COLLECTIVE") == "1"
+
+
 def init(backend=None):
     """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collective()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -75,6 +83,7 @@ class GradBuckets:
         if cur:
             self._close(cur, cur_n, cur_g)
         self._work = []
+        self.collectives = 0  # all-reduces started since construction (tests: the forced world-1 path really ran them)
 
     def _close(self, items, n, group=0):
         p0 = items[0][0]
@@ -93,8 +102,9 @@ class GradBuckets:
 
     def reduce_bucket(self, i):
         """Start the all-reduce of bucket i (call once its last gradient has been written)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective()):
             self._work.append(dist.all_reduce(self.buckets[i][0], op=dist.ReduceOp.SUM, async_op=True))
+            self.collectives += 1
 
     def reduce_all(self):
         for i in range(len(self.buckets)):

@@ -703,7 +703,8 @@ class MelStyleEncoder(_HipModule):
 
     def tap(self, index, grad=False):
         """Parity tap of the last forward_train (sty_style_tap): 0 = the stem's output, 1..4 = the ResBlk outputs, 5 = the
-        head conv's output at every position; grad=True (after backward): d loss / d that activation.  [B,C,H,W]."""
+        head conv's output at every position, 6..9 = the input of the second LeakyReLU of ResBlk 1..4 (mel_style_encoder.py:
+        110-113); grad=True (after backward): d loss / d that activation.  [B,C,H,W]."""
         lib = L.load()
         dev = self._train_keep[0].device
         c, h, w = C.c_int(), C.c_int(), C.c_int()

@@ -265,37 +265,60 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
     `trainer` (an AcousticTrainer): rank 0's BatchNorm / spectral-norm buffers are broadcast first (sync_buffers), the
     state a multi-rank run lets drift between checkpoints.
 
+    Multi-rank runs: EVERY rank must call this (it holds two collectives: the buffer broadcast and a closing barrier);
+    only rank 0 touches the file system.  Do not wrap the call in `if rank == 0:` -- the other ranks would leave rank 0
+    waiting in the broadcast.
+
     NOT written: accelerate's `scheduler*.bin` and `random_states_*.pkl`.  This package keeps no scheduler object (the
     lr is a pure function of the manifest's step, optim.scheduled_lr) and its stochastic pieces are seeded per step, so
     `load_checkpoint` resumes exactly from what is here; the REFERENCE's accelerator.load_state on a directory written
     ONLY by this function stops at the missing scheduler file -- resume there with the reference's own checkpoint as the
     base directory and let this function overwrite the model / optimizer files in it."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # COLLECTIVE part, every rank: the buffer broadcast (rank 0's BatchNorm / spectral-norm state)
     if trainer is not None:
         trainer.sync_buffers()
-    os.makedirs(path, exist_ok=True)
-    for name, m in models.items():
-        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-        torch.save(sd, osp.join(path, model_file(name)))
-    for name, o in (optimizers or {}).items():
-        sd = o.state_dict()
-        for st in sd["state"].values():
-            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
-        torch.save(sd, osp.join(path, optimizer_file(name)))
-    if disc_helpers:
-        f = osp.join(path, f"custom_checkpoint_{CUSTOM_ORDER.index('discriminator_loss')}.pkl")
-        state = torch.load(f, map_location="cpu", weights_only=True) if osp.exists(f) else {}
-        state.update(discriminator_loss_state(disc_helpers))  # helpers of other stages keep their entries
-        torch.save(state, f)
-    for name, obj in (("manifest", manifest), ("normalization", normalization)):
-        if obj is not None:
-            torch.save(obj.state_dict(), osp.join(path, f"custom_checkpoint_{CUSTOM_ORDER.index(name)}.pkl"))
+    # I/O part, rank 0 only (the reference saves from the main process: train/train.py:453-469 under
+    # accelerator.is_main_process); each file is written beside its final name and moved over it (os.replace), so that a
+    # reader never sees a half-written file.  Parameters and optimizer state are identical on every rank (all-reduced
+    # gradients, the same AdamW), the tracked discriminator losses are the rank mean: rank 0's copy is THE state.
+    if not multi or dist.get_rank() == 0:
+        os.makedirs(path, exist_ok=True)
+
+        def write(obj, name):
+            tmp = osp.join(path, f".{name}.tmp{os.getpid()}")
+            torch.save(obj, tmp)
+            os.replace(tmp, osp.join(path, name))
+
+        for name, m in models.items():
+            write({k: v.detach().cpu() for k, v in m.state_dict().items()}, model_file(name))
+        for name, o in (optimizers or {}).items():
+            sd = o.state_dict()
+            for st in sd["state"].values():
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+            write(sd, optimizer_file(name))
+        if disc_helpers:
+            fn = f"custom_checkpoint_{CUSTOM_ORDER.index('discriminator_loss')}.pkl"
+            f = osp.join(path, fn)
+            state = torch.load(f, map_location="cpu", weights_only=True) if osp.exists(f) else {}
+            state.update(discriminator_loss_state(disc_helpers))  # helpers of other stages keep their entries
+            write(state, fn)
+        for name, obj in (("manifest", manifest), ("normalization", normalization)):
+            if obj is not None:
+                write(obj.state_dict(), f"custom_checkpoint_{CUSTOM_ORDER.index(name)}.pkl")
+    if multi:
+        dist.barrier()  # nobody returns (and possibly loads the directory) before rank 0 has finished writing
     return path
 
 
-def load_checkpoint(path, models, manifest=None, normalization=None, strict=True, optimizers=None, disc_helpers=None):
+def load_checkpoint(path, models, manifest=None, normalization=None, strict=True, optimizers=None, disc_helpers=None,
+                    trainer=None):
     """Load what save_checkpoint / the reference's accelerator.save_state wrote for the models (and optimizers / loss
     helpers) given.  A missing optimizer file is an error when an optimizer was asked for: resuming with zero moments is
-    a different training run."""
+    a different training run.  `trainer` is accepted so that `load_checkpoint(path, **trainer.checkpoint_state())` mirrors
+    the save call (nothing of it is needed: load_state_dict on the shells already invalidates the packed weights)."""
+    del trainer
     for name, m in models.items():
         f = osp.join(path, model_file(name))
         if not osp.exists(f):

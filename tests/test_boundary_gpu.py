@@ -237,6 +237,42 @@ def test_two_rank_hip_gradients_equal_one_rank_on_the_concatenated_batch(tmp_pat
     assert rel <= 2e-3
 
 
+def test_rccl_world1_step_equals_the_step_without_a_process_group(tmp_path):
+    """RCCL under the trainer once (reference: accelerate's DDP, train/train_context.py:94-104).
+    Backend "nccl" at world size 1 with the collectives forced (STY_DIST_FORCE_COLLECTIVE=1), train-mode steps with the
+    default four streams; every gradient bucket travels through `all_reduce(async_op=True)` started from the library's
+    gradient hook inside sty_speech_bwd / sty_style_bwd, AdamW waits for it.  Two steps at lr = 0: losses and gradients
+    must equal those of the same run without a process group (1e-6 on the whole vector: the style head's weight gradient
+    is summed with float atomics in both runs); then three real optimizer steps: finite, moved, by the same amount."""
+    worker = os.path.join(ROOT, "tests", "rccl_world1_worker.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for mode in ("plain", "rccl"):
+        env = dict(base)
+        if mode == "rccl":
+            env["STY_DIST_FORCE_COLLECTIVE"] = "1"
+        else:
+            env.pop("STY_DIST_FORCE_COLLECTIVE", None)
+        out = str(tmp_path / f"{mode}.pt")
+        r = subprocess.run([sys.executable, worker, out, mode], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, (mode, r.stdout[-1500:], r.stderr[-3000:])
+        print("\n  " + r.stdout.strip().splitlines()[-1])
+        outs[mode] = torch.load(out)
+    a, b = outs["plain"], outs["rccl"]
+    assert a["collectives"] == 0 and a["collectives_b"] == 0
+    # every bucket that can carry a gradient went through RCCL in every step (one bucket holds the never-stepped l_linear)
+    assert b["collectives"] >= 2 * (b["nbuckets"] - 1) > 0 and b["collectives_b"] >= 3 * (b["nbuckets"] - 1), \
+        (b["collectives"], b["collectives_b"], b["nbuckets"])
+    assert torch.allclose(a["losses"], b["losses"], rtol=1e-6, atol=0), (a["losses"], b["losses"])
+    rel = ((a["grads"] - b["grads"]).norm() / a["grads"].norm()).item()
+    same = (a["grads"] == b["grads"]).float().mean().item()
+    print(f"  gradients of step 2 (lr = 0): RCCL run vs no process group relative L2 {rel:.3e}, {100 * same:.3f} % of the "
+          f"elements bit-equal; three optimizer steps moved the parameters by {b['moved']:.2e} (plain: {a['moved']:.2e})")
+    assert rel <= 1e-6
+    assert b["moved"] > 0 and abs(b["moved"] - a["moved"]) <= 0.5 * a["moved"]
+
+
 def test_checkpoint_resume_continues_the_same_training_run(tmp_path):
     """save_checkpoint after two optimizer steps (models, AdamW moments + step count + lr, discriminator-loss EMA); a
     FRESH trainer with other weights loads it: every parameter, both moments of every optimizer, the step counts, the

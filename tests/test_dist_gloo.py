@@ -79,3 +79,57 @@ def test_two_rank_gradient_mean_equals_single_rank_batch():
         for r in res:
             d = (torch.from_numpy(r[3][k]) - v.grad).abs().max().item()
             assert d <= 1e-5 * (v.grad.abs().max().item() + 1e-6) + 1e-8, (k, d)
+
+
+class _FakeTrainer:
+    """sync_buffers of AcousticTrainer without a device: a broadcast of one buffer from rank 0"""
+
+    def __init__(self, buf):
+        self.buf = buf
+
+    def sync_buffers(self, src=0):
+        torch.distributed.broadcast(self.buf, src)
+
+
+def _ckpt_worker(rank, world, port, path, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from stylish_tts_amd import dist as D, stage_io as IO
+    D.init("gloo")
+    m = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.fill_(float(rank + 1))  # ranks disagree on purpose: the files must hold rank 0's values
+    buf = torch.full((4,), float(rank))
+    man = IO.Manifest()
+    man.current_total_step = 7
+    wrote_before = os.path.exists(path)
+    IO.save_checkpoint(path, {"speech_predictor": m}, man, IO.NormalizationStats(), trainer=_FakeTrainer(buf))
+    # after the call (its closing barrier) every rank sees the complete directory and rank 0's buffer
+    files = sorted(os.listdir(path))
+    sd = torch.load(os.path.join(path, IO.model_file("speech_predictor")), weights_only=True)
+    q.put((rank, wrote_before, files, float(sd["weight"][0, 0]), buf.tolist()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_save_checkpoint_is_collective_and_only_rank0_writes(tmp_path):
+    """stage_io.save_checkpoint on two gloo ranks: every rank calls it -- the buffer broadcast and the
+    closing barrier are collectives --, only rank 0 writes (the reference saves from the main process, train/train.py:
+    453-469), through temp files + os.replace, and no rank returns before the directory is complete."""
+    world, port = 2, _free_port()
+    path = str(tmp_path / "ck")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, world, port, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, wrote_before, files, w00, buf in res:
+        assert not wrote_before
+        assert files == sorted(["pytorch_model_3.bin", "custom_checkpoint_2.pkl", "custom_checkpoint_3.pkl"]), files
+        assert w00 == 1.0          # rank 0's parameters, also as seen from rank 1
+        assert buf == [0.0] * 4    # rank 0's buffer after sync_buffers
