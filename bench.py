@@ -571,11 +571,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c5 / c3-fp32 / c3-gan sub-records of the default run")
     args = ap.parse_args()
+    # ONE JSON line on stdout: anything a library prints there (RCCL's version banner when the process group comes up)
+    # goes to stderr instead -- file descriptor 1 is pointed at stderr for the whole run, the record is written to the
+    # saved descriptor at the end
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` called directly: become the launcher.  One process per GPU, as the reference gets
         # its ranks from accelerate (train/train_context.py:94-104, train/train.py:188,208-211); the ranks run this
         # same file with the torchrun environment set and rank 0 prints the one JSON line.
+        os.dup2(out_fd, 1)  # (the ranks inherit the real stdout; rank 0 does the same redirection for itself)
         sys.exit(_launch_ranks(args.gpus))
 
     from stylish_tts_amd import dist as D
@@ -667,7 +674,8 @@ def main():
         rec["extra"] = extras
     if not args.no_cpu_baseline and world == 1:
         rec["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload])
-    print(json.dumps(rec))
+    sys.stdout.flush()
+    os.write(out_fd, (json.dumps(rec) + "\n").encode())
 
 
 if __name__ == "__main__":

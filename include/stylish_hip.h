@@ -322,6 +322,17 @@ int sty_conv1d_bwd(int B, int Cin, int Cout, int K, int dil, int T, const float 
  * mean without a pass of its own (1.0f: plain AdamW, bit-identical).                                              */
 int sty_adamw_step(size_t n, float *p, const float *g, float *m, float *v, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void *stream);
+/* The same step at the rate lr * *lr_mult, lr_mult a DEVICE double: the discriminators' learning-rate multiplier
+ * (train/optimizers.py:54-65) never leaves the GPU, so a GAN step has no host read-back.  sty_disc_lr_track keeps it:
+ * state (DEVICE double[2]) = { last_loss, multiplier }; one call writes state[1] = get_disc_lr_multiplier() of the
+ * current last_loss (train/losses.py:241-256) and THEN folds *loss (DEVICE float, may be NULL: multiplier only) into the
+ * running mean, last_loss = 0.95 last_loss + 0.05 loss (losses.py:287) -- the order of train/stage.py, where the optimizer
+ * steps with the multiplier of the previous mean.                                                                  */
+int sty_adamw_step_scaled(size_t n, float *p, const float *g, float *m, float *v, double lr, const double *lr_mult,
+                          float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                          void *stream);
+int sty_disc_lr_track(double *state, const float *loss, double ideal_loss, double f_max, double h_min, double x_max,
+                      double x_min, void *stream);
 
 /* ---- acoustic-stage losses without third-party models, forward + backward in one call ---------------
  * mel  = MultiResolutionSTFTLoss (train/losses.py:17-38) on log1p(mel128|X|); multi_phase = losses.py:41-91;

@@ -249,24 +249,24 @@ class AcousticTrainer:
         self.opt["speech_style_encoder"].step(grad_scale=1.0 / world)
         if self.mrd is not None:
             # optimizers.py:54-65: discriminator lr = generator lr x multiplier of the tracked discriminator loss
-            od = self.opt[f"mrd{disc_index}"]
-            od.grads.finish(average=False)
-            od.lr = self.opt["speech_predictor"].lr * self.disc_helpers[disc_index].get_disc_lr_multiplier()
-            od.step(grad_scale=1.0 / world)
             # The tracked discriminator losses set the discriminators' learning rates, so every rank must track the SAME
             # numbers or the replicas drift apart for good (nothing re-syncs parameters).  The reference tracks each
             # process's local .item() (losses.py:287) and lets them drift; here the mean over ranks is tracked (one
-            # all-reduce of seven floats; identical to the reference at world size 1).
+            # all-reduce of seven floats; identical to the reference at world size 1).  Multiplier and running mean live on
+            # the device (sty_disc_lr_track): the reference's helpers call .item() three times per step, this step reads
+            # nothing back, so the host keeps running ahead of the GPU across steps.
             tracked = self._rank_mean(torch.cat([self.gan, self.gan_wave]) if self.disc is not None else self.gan)
-            plain = tracked.tolist()  # (one host read per step; the reference's helpers call .item() three times)
-            for r, h in enumerate(self.disc_helpers):
-                h.last_loss = h.last_loss * 0.95 + plain[2 + 2 * r] * 0.05
+            mults = [h.track_device(tracked[2 + 2 * r:3 + 2 * r]) for r, h in enumerate(self.disc_helpers)]
+            od = self.opt[f"mrd{disc_index}"]
+            od.grads.finish(average=False)
+            od.lr = self.opt["speech_predictor"].lr  # x the multiplier of the previous running mean, inside the kernel
+            od.step(grad_scale=1.0 / world, lr_mult=mults[disc_index])
             if self.disc is not None:
+                n = self.gan.numel()
                 ow = self.opt["disc"]
                 ow.grads.finish(average=False)
-                ow.lr = self.opt["speech_predictor"].lr * self.disc_helper.get_disc_lr_multiplier()
-                ow.step(grad_scale=1.0 / world)
-                self.disc_helper.last_loss = self.disc_helper.last_loss * 0.95 + plain[self.gan.numel() + 2] * 0.05
+                ow.lr = self.opt["speech_predictor"].lr
+                ow.step(grad_scale=1.0 / world, lr_mult=self.disc_helper.track_device(tracked[n + 2:n + 3]))
         self.audio = audio
         return losses
 

@@ -413,8 +413,7 @@ static int launch_conv1d_dispatch(const ConvArgs& a, hipStream_t st);
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
   // ConvArgs::y16 (the bf16 operand twin of the output): convp16_kernel writes it from its output stage; for every other
   // kernel the cast pass makes it behind the conv -- the caller gets the twin either way
-  const bool native16 = a.y16 && (stem2d_eligible(a) || (!conv32p_eligible(a) && !convk1_eligible(a) && !convk3_eligible(a) &&
-                                                         convp16_eligible(a)));
+  const bool native16 = a.y16 && (stem2d_eligible(a) || (!conv32p_eligible(a) && !convk1_eligible(a) && convp16_eligible(a)));
   int rc = launch_conv1d_dispatch(a, st);
   if (rc == STY_OK && a.y16 && !native16) {
     if (a.shuffle > 1) {
@@ -448,7 +447,6 @@ static int launch_conv1d_dispatch(const ConvArgs& a, hipStream_t st) {
     return STY_EINVAL;
   }
   if (convk1_eligible(a)) return launch_convk1(a, st);
-  if (convk3_eligible(a)) return launch_convk3(a, st);
   if (convp16_eligible(a)) return launch_convp16(a, st);
   // tuning aid: STY_CONV_CFG=0..5 forces one tile configuration (when the shape allows it)
   static const int forced = getenv("STY_CONV_CFG") ? atoi(getenv("STY_CONV_CFG")) : -1;

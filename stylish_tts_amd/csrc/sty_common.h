@@ -168,8 +168,6 @@ bool stem2d_eligible(const ConvArgs& a);  // conv2d.hip: Conv2d(1 -> C, 3 x 3) o
 int launch_stem2d(const ConvArgs& a, hipStream_t st);
 bool convk1_eligible(const ConvArgs& a);  // convk1.hip: K = 1 as a plain GEMM (transposing LDS reads)
 int launch_convk1(const ConvArgs& a, hipStream_t st);
-bool convk3_eligible(const ConvArgs& a);  // convk3.hip: K = 3 on the same data path (three shifted LDS images)
-int launch_convk3(const ConvArgs& a, hipStream_t st);
 bool convp16_eligible(const ConvArgs& a);
 int convp16_repack_range(const void* lo, const void* hi, hipStream_t st);
 void convp16_forget_range(const void* lo, const void* hi);  // before the arena is freed or re-laid out  // bf16 weight fragments of a model's packed weights, one launch

@@ -159,12 +159,40 @@ class GeneratorLossHelper:  # losses.py:330-373
 class DiscriminatorLossHelper:  # losses.py:228-290
     def __init__(self, model, sub_count):
         self.model = model
-        self.last_loss = 0.5 * sub_count
+        self._dev = None  # DEVICE double[2] = (last_loss, multiplier) once track_device has been used (sty_disc_lr_track)
+        self._host_loss = 0.5 * sub_count
         self.ideal_loss = 0.5 * sub_count
         self.f_max = 4.0
         self.h_min = 0.01
         self.x_max = 0.05 * sub_count
         self.x_min = 0.05 * sub_count
+
+    @property
+    def last_loss(self):
+        """the running mean; with the device-side tracker this is a host read (checkpoints, logging: not in the step)"""
+        if self._dev is not None:
+            self._host_loss = float(self._dev[0].item())
+        return self._host_loss
+
+    @last_loss.setter
+    def last_loss(self, v):
+        self._host_loss = float(v)
+        if self._dev is not None:
+            self._dev[0] = self._host_loss
+
+    def track_device(self, loss):
+        """Device-side form of `get_disc_lr_multiplier()` followed by the running-mean update of losses.py:287: `loss` is a
+        DEVICE float (one element, or None: multiplier only).  Returns the DEVICE double holding the multiplier of the
+        mean BEFORE this loss was folded in, for FlatAdamW.step(lr_mult=...): the step never reads a loss back."""
+        if self._dev is None:
+            dev = loss.device if loss is not None else torch.device("cuda", torch.cuda.current_device())
+            self._dev = torch.tensor([self._host_loss, 1.0], dtype=torch.float64, device=dev)
+        if loss is not None:
+            assert loss.dtype == torch.float32 and loss.numel() == 1 and loss.device == self._dev.device
+        L.check(L.load().sty_disc_lr_track(L.ptr(self._dev), L.ptr(loss), self.ideal_loss, self.f_max, self.h_min,
+                                           self.x_max, self.x_min,
+                                           C.c_void_p(torch.cuda.current_stream(self._dev.device).cuda_stream)))
+        return self._dev[1:2]
 
     def get_disc_lr_multiplier(self):  # losses.py:241-256
         x = abs(self.last_loss - self.ideal_loss)

@@ -120,6 +120,9 @@ SYMBOLS = {
     "sty_conv1d_bwd": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
     "sty_adamw_step": (C.c_int, [C.c_size_t, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  _I, C.c_float, _P]),
+    "sty_adamw_step_scaled": (C.c_int, [C.c_size_t, _P, _P, _P, _P, C.c_double, _P, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, _I, C.c_float, _P]),
+    "sty_disc_lr_track": (C.c_int, [_P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "sty_model_set_grad_hook": (C.c_int, [_P, _P, _P]),
     "sty_acoustic_loss_workspace_bytes": (C.c_int, [_I, _I, _SZP]),
     "sty_acoustic_loss_target": (C.c_int, [_I, _I, _P, _P, C.c_size_t, _P]),

@@ -41,8 +41,10 @@ class FlatAdamW:
     def zero_grad(self):
         self.grads.zero()
 
-    def step(self, grad_scale=1.0):
-        """grad_scale multiplies the gradient inside the kernel (1 / world_size after a SUM all-reduce)."""
+    def step(self, grad_scale=1.0, lr_mult=None):
+        """grad_scale multiplies the gradient inside the kernel (1 / world_size after a SUM all-reduce).  lr_mult: a DEVICE
+        double (tensor of one element) that multiplies self.lr inside the kernel -- the discriminators' rate multiplier,
+        kept on the GPU by DiscriminatorLossHelper.track_device (no host read-back in the step)."""
         lib = L.load()
         self.t += 1
         for (gflat, _), p, m, v, grp in zip(self.grads.buckets, self.flat_p, self.m, self.v, self.grads.bucket_group):
@@ -51,6 +53,12 @@ class FlatAdamW:
             if not gflat.is_cuda:
                 raise L.StyError("FlatAdamW.step: parameters must live on the GPU (there is no CPU path)")
             st = C.c_void_p(torch.cuda.current_stream(gflat.device).cuda_stream)
+            if lr_mult is not None:
+                assert lr_mult.dtype == torch.float64 and lr_mult.device == gflat.device
+                L.check(lib.sty_adamw_step_scaled(gflat.numel(), L.ptr(p), L.ptr(gflat), L.ptr(m), L.ptr(v), float(self.lr),
+                                                  L.ptr(lr_mult), self.betas[0], self.betas[1], self.eps,
+                                                  self.weight_decay, self.t, float(grad_scale), st))
+                continue
             L.check(lib.sty_adamw_step(gflat.numel(), L.ptr(p), L.ptr(gflat), L.ptr(m), L.ptr(v), self.lr,
                                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
                                        float(grad_scale), st))

@@ -1495,27 +1495,6 @@ def test_pointwise_gemm_kernel_vs_torch(shape, monkeypatch):
     assert sum(r["launches"] for r in rows if r["name"].startswith("convk1_kernel")) >= 1, [r["name"] for r in rows]
 
 
-@pytest.mark.parametrize("shape", [(2, 512, 64, 3, 1, 36), (2, 96, 200, 3, 1, 300), (2, 64, 96, 3, 1, 1000), (3, 130, 133, 3, 1, 260),
-                                   (48, 240, 80, 3, 1, 1500)])
-def test_three_tap_gemm_kernel_vs_torch(shape, monkeypatch):
-    """convk3_kernel (bf16 compute mode, K = 3: three shifted LDS images of every chunk, built with whole-wave DPP shifts
-    and v_alignbit, read with ds_read_b64_tr_b16) through the unit entry points: forward and input gradient vs float64
-    on the same bf16-rounded operands -- row ends inside a tile, channel counts off the chunk / tile sizes."""
-    from stylish_tts_amd import lib as L
-    lib = L.load()
-    monkeypatch.setenv("STY_CONVK3", "1")  # opt-in: at parity with convp16, which the dispatch keeps
-    if shape[0] < 48:
-        monkeypatch.setenv("STY_CONVK3_MIN_TILES", "1")
-    L.prof_report(256)
-    lib.sty_prof_enable(1)
-    try:
-        test_dense_conv1d_vs_torch(shape, "bf16")
-    finally:
-        lib.sty_prof_enable(0)
-    rows = L.prof_report(256)
-    assert sum(r["launches"] for r in rows if r["name"].startswith("convk3_kernel")) >= 1, [r["name"] for r in rows]
-
-
 def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monkeypatch):
     """The bf16 compute mode with the persistent kernels forced on at the small test size (conv32p, convp16: flat 2-D
     style-encoder convs with masks and residuals, LeakyReLU / AdaIN prologues, ReLU, decoder and vocoder convs, forward

@@ -3,7 +3,7 @@
 #   kernel-trace summaries (rocprofv3 --kernel-trace --stats) of the default bench command (c3) and of c5 / c2,
 #   HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes) of the default bench command and of c5,
 #   the per-stream picture of one c3 step, bench JSON lines of every workload.
-tag=${1:-r02}
+tag=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 rm -rf $O; mkdir -p $O
@@ -17,7 +17,18 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c3_fetch -- 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c3_write -- $B --steps 2 --warmup 1 > /dev/null 2> $O/c3_write.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c5_fetch -- $B --workload c5 --steps 5 --warmup 2 > /dev/null 2> $O/c5_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c5_write -- $B --workload c5 --steps 5 --warmup 2 > /dev/null 2> $O/c5_write.log
+# ... and of the other workloads the bench line carries a roofline for (c2, c3-fp32, c3-gan), on THIS round's library
+for wl in c2 c3-fp32 c3-gan; do
+  n=2; [ $wl = c2 ] && n=4
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${wl}_fetch -- $B --workload $wl --steps $n --warmup 1 > /dev/null 2> $O/${wl}_fetch.log
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${wl}_write -- $B --workload $wl --steps $n --warmup 1 > /dev/null 2> $O/${wl}_write.log
+done
 cd $R
+for wl in c2 c3-fp32 c3-gan; do
+  python tools/pmc_traffic.py $O/${wl}_fetch $O/${wl}_write > $O/${tag}_${wl}_pmc_traffic.json
+  cp $O/${tag}_${wl}_pmc_traffic.json $R/profiles/
+  rm -rf $O/${wl}_fetch $O/${wl}_write
+done
 python tools/pmc_traffic.py $O/c3_fetch $O/c3_write > $O/${tag}_c3_pmc_traffic.json
 python tools/pmc_traffic.py $O/c5_fetch $O/c5_write > $O/${tag}_c5_pmc_traffic.json
 python tools/rocpd_summary.py $O/c3_trace/*/*_results.db > $O/${tag}_c3_kernel_stats.txt
