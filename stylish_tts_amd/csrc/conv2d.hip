@@ -374,6 +374,17 @@ int launch_pool_fc(const float* x, int B, int C, int n, int count, const float* 
 // (Two kernels -- dx by input position, the weight gradient by output position with nine strided reads of x per output --
 // moved 1.9 GB for the first ResBlk at ~1.5 TB/s, plus the zero-fill of dx; this one moves 0.96 GB.)
 // gate != nullptr: gy is taken times lrelu'(gate) (0.2 slope), gate laid out as gy (a deferred gate, train.hip `ungated`)
+// Round 4: one thread per 2 x 2 QUAD of input positions (rows 2 qh, 2 qh + 1, columns 2 qw, 2 qw + 1) instead of four
+// consecutive elements with nine parity tests each (the kernel was bound by its ~75 vector instructions per element, not by
+// memory: 1.3 ms per c3 step at 2 TB/s, on the tail of the step).  With stride 2 the parity of an input position selects its
+// taps: (even, even) is reached by the centre tap only, (even, odd) / (odd, even) by two, (odd, odd) by the four corners --
+// and all of them read the 2 x 2 output neighbourhood G00 = gy[qh][qw], G01 = gy[qh][qw + 1], G10 = gy[qh + 1][qw], G11:
+//   dx_ee = w11 G00                     dx_eo = w10 G01 + w12 G00
+//   dx_oe = w01 G10 + w21 G00           dx_oo = w00 G11 + w02 G10 + w20 G01 + w22 G00
+// nine multiply-adds for four outputs, and every (tap, output) pair of the weight gradient exactly once.  DW2_R quads per
+// thread (lanes along qw), then the ten-value reduction once per workgroup.  The thread of the last quad column also writes
+// the zero of the pad column (first-writer semantics: dx is not pre-filled).
+constexpr int DW2_R = 4;
 template <bool ACC>
 __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               const float* __restrict__ gate,
@@ -385,91 +396,64 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_bwd_kernel(const float* __res
   __shared__ float red[4][10];
   const int bc = blockIdx.y, c = bc % C;
   const int ldi = W + 1, ldo = Wo + 1, n = H * ldi;
-  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   const float* g = gy + (size_t)bc * Ho * ldo;
   const float* gt = gate ? gate + (size_t)bc * Ho * ldo : nullptr;
   const float* p = x + (size_t)bc * n;
   float* d = dx + (size_t)bc * n;
+  __bf16* d16 = dx16 ? dx16 + (size_t)bc * n : nullptr;
+  const float* mk = mask16 ? mask16 + (size_t)(bc / C) * n : nullptr;
   float wk[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wk[k] = w9[c * 9 + k];
   float wacc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) wacc[k] = 0.f;
-  if (i0 < n) {
-    const bool vec = (n & 3) == 0 && i0 + 3 < n;
-    float xv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-      const float4 q = *reinterpret_cast<const float4*>(p + i0);
-      xv[0] = q.x;
-      xv[1] = q.y;
-      xv[2] = q.z;
-      xv[3] = q.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (i0 + e < n) xv[e] = p[i0 + e];
+  const int nq = Ho * Wo;
+  auto put = [&](int o, float v) {  // one element of dx (and of its twin)
+    if (ACC) v += d[o];
+    d[o] = v;
+    if (!ACC && d16) d16[o] = (__bf16)(v * mk[o]);
+  };
+#pragma unroll 1
+  for (int rr = 0; rr < DW2_R; ++rr) {
+    const int q = (blockIdx.x * DW2_R + rr) * 256 + threadIdx.x;
+    if (q >= nq) break;
+    const int qh = q / Wo, qw = q - qh * Wo;
+    const bool w1 = qw + 1 < Wo, h1 = qh + 1 < Ho;
+    auto G = [&](int ho, int wo, bool ok) {
+      if (!ok) return 0.f;
+      float v = g[(size_t)ho * ldo + wo];
+      if (gt && !(gt[(size_t)ho * ldo + wo] > 0.f)) v *= 0.2f;
+      return v;
+    };
+    const float G00 = G(qh, qw, true), G01 = G(qh, qw + 1, w1), G10 = G(qh + 1, qw, h1), G11 = G(qh + 1, qw + 1, w1 && h1);
+    const int hi = 2 * qh, wi = 2 * qw;
+    const bool c1 = wi + 1 < W, r1 = hi + 1 < H;   // second column / row of the quad inside the image
+    const int o0 = hi * ldi + wi, o1 = o0 + ldi;
+    const float xee = p[o0], xeo = c1 ? p[o0 + 1] : 0.f, xoe = r1 ? p[o1] : 0.f, xoo = (c1 && r1) ? p[o1 + 1] : 0.f;
+    put(o0, wk[4] * G00);
+    wacc[4] = fmaf(G00, xee, wacc[4]);
+    wacc[9] += G00;
+    if (c1) {
+      put(o0 + 1, fmaf(wk[3], G01, wk[5] * G00));
+      wacc[3] = fmaf(G01, xeo, wacc[3]);
+      wacc[5] = fmaf(G00, xeo, wacc[5]);
     }
-    int hi = i0 / ldi, wi = i0 - hi * ldi;
-    float acc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = 0.f;
-      if (i0 + e < n && wi < W) {
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int hn = hi + 1 - kh;  // 2 ho = hi + 1 - kh
-          if (hn < 0 || (hn & 1)) continue;
-          const int ho = hn >> 1;
-          if (ho >= Ho) continue;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int wn = wi + 1 - kw;
-            if (wn < 0 || (wn & 1)) continue;
-            const int wo = wn >> 1;
-            if (wo < Wo) {
-              float gv = g[(size_t)ho * ldo + wo];
-              if (gt && !(gt[(size_t)ho * ldo + wo] > 0.f)) gv *= 0.2f;
-              a = fmaf(wk[kh * 3 + kw], gv, a);
-              wacc[kh * 3 + kw] = fmaf(gv, xv[e], wacc[kh * 3 + kw]);
-              if (kh == 1 && kw == 1) wacc[9] += gv;
-            }
-          }
-        }
-      }
-      acc[e] = a;
-      if (++wi == ldi) {
-        wi = 0;
-        ++hi;
+    if (r1) {
+      put(o1, fmaf(wk[1], G10, wk[7] * G00));
+      wacc[1] = fmaf(G10, xoe, wacc[1]);
+      wacc[7] = fmaf(G00, xoe, wacc[7]);
+      if (c1) {
+        put(o1 + 1, fmaf(wk[0], G11, fmaf(wk[2], G10, fmaf(wk[6], G01, wk[8] * G00))));
+        wacc[0] = fmaf(G11, xoo, wacc[0]);
+        wacc[2] = fmaf(G10, xoo, wacc[2]);
+        wacc[6] = fmaf(G01, xoo, wacc[6]);
+        wacc[8] = fmaf(G00, xoo, wacc[8]);
       }
     }
-    if (vec) {
-      float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      if (ACC) {
-        const float4 o = *reinterpret_cast<float4*>(d + i0);
-        v.x += o.x;
-        v.y += o.y;
-        v.z += o.z;
-        v.w += o.w;
-      }
-      *reinterpret_cast<float4*>(d + i0) = v;
-      if (!ACC && dx16) {
-        const float4 m = *reinterpret_cast<const float4*>(mask16 + (size_t)(bc / C) * n + i0);
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        bf16x4 h;
-        h[0] = (__bf16)(v.x * m.x);
-        h[1] = (__bf16)(v.y * m.y);
-        h[2] = (__bf16)(v.z * m.z);
-        h[3] = (__bf16)(v.w * m.w);
-        *reinterpret_cast<bf16x4*>(dx16 + (size_t)bc * n + i0) = h;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (i0 + e < n) {
-          d[i0 + e] = ACC ? d[i0 + e] + acc[e] : acc[e];
-          if (!ACC && dx16) dx16[(size_t)bc * n + i0 + e] = (__bf16)(acc[e] * mask16[(size_t)(bc / C) * n + i0 + e]);
-        }
+    if (qw == Wo - 1) {  // the pad column (index W) of the quad's rows: W even -> the column after the quad, W odd -> its second
+      put(hi * ldi + W, 0.f);
+      if (r1) put((hi + 1) * ldi + W, 0.f);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -515,7 +499,7 @@ int launch_dwconv2d_s2_bwd(const float* x, const float* gy, const float* gate, c
                            float* dx, int accumulate, float* dw9, float* db, float* scratch, hipStream_t st, __bf16* dx16,
                            const float* mask16) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const int nblk = cdiv(H * (W + 1), 1024);
+  const int nblk = cdiv(Ho * Wo, 256 * DW2_R);  // <= the cdiv(H (W + 1), 1024) dwconv2d_s2_bwd_scratch_floats sizes for
   if (dx16 && (accumulate || !mask16)) {
     set_error("dwconv2d_s2_bwd: the operand twin of dx needs the overwriting form and the mask");
     return STY_EINVAL;

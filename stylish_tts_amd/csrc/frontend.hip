@@ -33,6 +33,9 @@ struct FrontTables {
   // Spectra produced this way keep their rows in the order [re even | re odd | im even | im odd] (dft_row below).
   PackedConv fold[4], foldT[4];
   PackedConv fbT;           // backward: [n_mels] -> [F]    (transposed filter bank)
+  float2* tw = nullptr;     // [n_fft/2 + 1] (cos, -sin)(2 pi f / n_fft): twiddles of the LDS FFT (stft_fft_kernel)
+  int* mband = nullptr;     // [n_mels][2]: the frequency rows [lo, hi) a mel filter is non-zero on (fb_sparse_fwd_kernel)
+  int* fband = nullptr;     // [F][2]: the mel filters [lo, hi) a frequency row feeds (fb_sparse_bwd_kernel)
   int n_fft = 0, F = 0, n_mels = 0;
 };
 
@@ -46,6 +49,13 @@ __global__ void transpose_pack_kernel(const float* __restrict__ w, int rows, int
 __global__ void freq_weight_kernel(float* __restrict__ w, int F) {  // the expression loss_sums_kernel evaluates per row
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f < F) w[f] = (float)exp(log(2.5) / (double)(F / 2) * f);
+}
+__global__ void fft_twiddle_kernel(float2* __restrict__ tw, int n_fft) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f > n_fft / 2) return;
+  double sn, cs;
+  sincospi(2.0 * (double)f / (double)n_fft, &sn, &cs);
+  tw[f] = make_float2((float)cs, (float)-sn);
 }
 __global__ void window_kernel(float* __restrict__ w, int n_fft, int win) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,6 +110,73 @@ __global__ void mel_fb_kernel(float* __restrict__ wp, int F, int n_mels, int sam
   wp[(size_t)f * CoutP + m] = (float)v;
 }
 
+
+// The mel filter bank is triangular: a filter is non-zero on a short run of frequency rows (1-60 of 1 025) and a frequency
+// row feeds at most two or three filters.  The dense GEMMs spent F x n_mels multiply-adds per column on it (six launches of
+// ~110 us per c3 step on the fp32 matrix pipe, three more in the backward); these read each |X| element about twice.
+__global__ void fb_band_kernel(const float* __restrict__ wp, int F, int n_mels, int CoutP, int* __restrict__ mband,
+                               int* __restrict__ fband) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_mels) {
+    int lo = F, hi = 0;
+    for (int f = 0; f < F; ++f)
+      if (wp[(size_t)f * CoutP + i] != 0.f) {
+        lo = f < lo ? f : lo;
+        hi = f + 1;
+      }
+    mband[2 * i] = lo < hi ? lo : 0;
+    mband[2 * i + 1] = hi;
+  }
+  if (i < F) {
+    int lo = n_mels, hi = 0;
+    for (int m = 0; m < n_mels; ++m)
+      if (wp[(size_t)i * CoutP + m] != 0.f) {
+        lo = m < lo ? m : lo;
+        hi = m + 1;
+      }
+    fband[2 * i] = lo < hi ? lo : 0;
+    fband[2 * i + 1] = hi;
+  }
+}
+// y[m][col] = sum_f wp[f][m] x[f][col] over the filter's band (rows in ascending order); LOG1P: log1p of the sum
+template <bool LOG1P>
+__global__ __launch_bounds__(256) void fb_sparse_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, int CoutP,
+                                                            const int* __restrict__ mband, size_t cols,
+                                                            float* __restrict__ y) {
+  const size_t col = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  if (col >= cols) return;
+  const int lo = mband[2 * m], hi = mband[2 * m + 1];
+  float acc = 0.f;
+  int f = lo;
+  for (; f + 4 <= hi; f += 4) {
+    const float x0 = x[(size_t)f * cols + col], x1 = x[(size_t)(f + 1) * cols + col], x2 = x[(size_t)(f + 2) * cols + col],
+                x3 = x[(size_t)(f + 3) * cols + col];
+    acc = fmaf(wp[(size_t)f * CoutP + m], x0, acc);
+    acc = fmaf(wp[(size_t)(f + 1) * CoutP + m], x1, acc);
+    acc = fmaf(wp[(size_t)(f + 2) * CoutP + m], x2, acc);
+    acc = fmaf(wp[(size_t)(f + 3) * CoutP + m], x3, acc);
+  }
+  for (; f < hi; ++f) acc = fmaf(wp[(size_t)f * CoutP + m], x[(size_t)f * cols + col], acc);
+  y[(size_t)m * cols + col] = LOG1P ? log1pf(acc) : acc;
+}
+// dx[f][col] = sum_m wp[f][m] dy[m][col] over the filters row f feeds
+__global__ __launch_bounds__(256) void fb_sparse_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ wp, int CoutP,
+                                                            const int* __restrict__ fband, size_t cols,
+                                                            float* __restrict__ dx) {
+  const size_t col = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (col >= cols) return;
+  const int lo = fband[2 * f], hi = fband[2 * f + 1];
+  float acc = 0.f;
+  for (int m = lo; m < hi; ++m) acc = fmaf(wp[(size_t)f * CoutP + m], dy[(size_t)m * cols + col], acc);
+  dx[(size_t)f * cols + col] = acc;
+}
+static bool fb_sparse_enabled() {
+  static const bool off = getenv("STY_FB_GEMM") != nullptr;
+  return !off;
+}
+
 static std::map<std::tuple<int, int, int, int>, FrontTables> g_tables;
 
 static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream_t st, const FrontTables** out) {
@@ -135,6 +212,10 @@ static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream
   STY_HIP(hipMalloc((void**)&wq, F * sizeof(float)));
   hipLaunchKernelGGL(freq_weight_kernel, dim3(cdiv(F, 256)), dim3(256), 0, st, wq, F);
   t.wfreq = wq;
+  float2* twq;
+  STY_HIP(hipMalloc((void**)&twq, (size_t)F * sizeof(float2)));
+  hipLaunchKernelGGL(fft_twiddle_kernel, dim3(cdiv(F, 256)), dim3(256), 0, st, twq, n_fft);
+  t.tw = twq;
   hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_fft, 256)), dim3(256), 0, st, w, n_fft, win);
   hipLaunchKernelGGL(dft_basis_kernel, dim3(cdiv(2 * F, 256), n_fft), dim3(256), 0, st, d, n_fft, F, t.dft.CoutP);
   hipLaunchKernelGGL(mel_fb_kernel, dim3(cdiv(n_mels, 64), F), dim3(64), 0, st, f, F, n_mels, sample_rate, t.fb.CoutP);
@@ -142,6 +223,15 @@ static int get_tables(int n_fft, int win, int n_mels, int sample_rate, hipStream
   t.window = w;
   t.dft.wp = d;
   t.fb.wp = f;
+  {
+    int* bands;
+    STY_HIP(hipMalloc((void**)&bands, (size_t)(n_mels + F) * 2 * sizeof(int)));
+    t.mband = bands;
+    t.fband = bands + 2 * n_mels;
+    hipLaunchKernelGGL(fb_band_kernel, dim3(cdiv(F > n_mels ? F : n_mels, 256)), dim3(256), 0, st, f, F, n_mels, t.fb.CoutP,
+                       t.mband, t.fband);
+    STY_LAUNCH_CHECK();
+  }
   // transposed copies for the backward pass
   t.dftT.Cin = 2 * F;
   t.dftT.CinP = (int)align_up(2 * F, CI_CHUNK);
@@ -321,6 +411,263 @@ static void launch_frame_fold(const float* audio, const float* w, int B, int N, 
                        n_fft, hop, frames, sb, sc, xt);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same transform as an FFT in LDS (round 4).  The GEMM formulation above costs n_fft / 4 multiply-adds per output and
+// five launches per transform (fold + four GEMMs on the fp32 matrix pipe: 3.9 ms of a 61 ms c3 step for eleven
+// transforms); an FFT is bound by writing the spectrum.  One workgroup owns TF consecutive frames of one utterance:
+//   A  frames -> LDS: buf[fr][n] = w[n] * audio[reflect(fr * hop + n - n_fft / 2)], lanes along n.  The real frame IS the
+//      complex sequence z[k] = x[2k] + i x[2k+1] of the half-size trick, no repacking;
+//   B  in-place radix-2 decimation-in-frequency FFT of size M = n_fft / 2 on all TF frames at once (log2 M passes, one
+//      barrier each; a butterfly owns its two slots, so a pass has no hazards); output in bit-reversed order;
+//   C  X[f] = (Z[f] + conj Z[M-f]) / 2 - i/2 e^(-2 pi i f / n_fft) (Z[f] - conj Z[M-f]),  f = 0..M, read through the bit
+//      reversal, stored with the lanes along the frame axis (64-byte runs per spectrum row) into the rows the folded GEMMs
+//      wrote (dft_row order: re even | re odd | im even | im odd), so every consumer is unchanged.
+// The adjoint (backward of the loss features): d xt[n] = Re sum_{f=0..M} (dRe_f + i dIm_f) e^(+2 pi i f n / n_fft) is half the
+// un-normalised inverse transform of the Hermitian extension Y (Y_0 = 2 dRe_0, Y_M = 2 dRe_M, Y_f = dRe_f + i dIm_f):
+//   Z_k = (Y_k + conj Y_{M-k}) + i e^(+2 pi i k / n_fft) (Y_k - conj Y_{M-k}),  z = IFFT_M(Z),  d xt[2m] = Re z[m] / 2,
+//   d xt[2m+1] = Im z[m] / 2 -- the same passes with conjugated twiddles.  It writes the UNFOLDED frame gradient; the
+// overlap-add (frame_bwd, folded = 0) is unchanged.
+// tw[f] = (cos, -sin)(2 pi f / n_fft), f = 0..M, computed in double precision; the pass with span h uses tw[pos * n_fft / (2h)].
+constexpr int FFT_NT = 1024;
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// radix-4 passes (two radix-2 decimation-in-frequency stages in one trip through LDS, same bit-reversed output order:
+// y0, y2, y1, y3 go to i0, i0 + q, i0 + 2q, i0 + 3q), one radix-2 pass at the end when log2 M is odd
+template <int LN, int TF, int P, bool INV>  // n_fft = 1 << LN
+__device__ __forceinline__ void fft_passes(float* buf, const float2* twl) {
+  constexpr int N = 1 << LN, M = N / 2;
+  int lL = LN - 1;
+#pragma unroll 1
+  for (; lL >= 2; lL -= 2) {
+    const int lq = lL - 2, q = 1 << lq;
+#pragma unroll 2
+    for (int idx = threadIdx.x; idx < TF * (M / 4); idx += FFT_NT) {
+      const int fr = idx >> (LN - 3), j = idx & (M / 4 - 1);
+      const int pos = j & (q - 1), i0 = ((j >> lq) << lL) + pos;
+      float2* c = reinterpret_cast<float2*>(buf + fr * P);
+      const float2 a = c[i0], b = c[i0 + q], cc = c[i0 + 2 * q], d = c[i0 + 3 * q];
+      float2 w1 = twl[pos << (LN - lL)], w2 = twl[pos << (LN - lL + 1)];
+      if (INV) {
+        w1.y = -w1.y;
+        w2.y = -w2.y;
+      }
+      const float2 w3 = cmul(w1, w2);
+      const float2 t0 = make_float2(a.x + cc.x, a.y + cc.y), t1 = make_float2(a.x - cc.x, a.y - cc.y);
+      const float2 t2 = make_float2(b.x + d.x, b.y + d.y), t3 = make_float2(b.x - d.x, b.y - d.y);
+      // forward: y1 = (t1 - i t3) w1, y3 = (t1 + i t3) w3;  inverse: the signs of i swap
+      const float2 m = make_float2(t1.x + t3.y, t1.y - t3.x), pl = make_float2(t1.x - t3.y, t1.y + t3.x);
+      c[i0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+      c[i0 + q] = cmul(make_float2(t0.x - t2.x, t0.y - t2.y), w2);
+      c[i0 + 2 * q] = cmul(INV ? pl : m, w1);
+      c[i0 + 3 * q] = cmul(INV ? m : pl, w3);
+    }
+    __syncthreads();
+  }
+  if (lL == 1) {
+#pragma unroll 2
+    for (int idx = threadIdx.x; idx < TF * (M / 2); idx += FFT_NT) {
+      const int fr = idx >> (LN - 2), j = idx & (M / 2 - 1);
+      float2* c = reinterpret_cast<float2*>(buf + fr * P) + 2 * j;  // the pair (2j, 2j + 1), twiddle 1
+      const float2 u = c[0], v = c[1];
+      c[0] = make_float2(u.x + v.x, u.y + v.y);
+      c[1] = make_float2(u.x - v.x, u.y - v.y);
+    }
+    __syncthreads();
+  }
+}
+
+template <int LN, int TF>
+__global__ __launch_bounds__(FFT_NT) void stft_fft_kernel(const float* __restrict__ audio, const float* __restrict__ w,
+                                                         const float2* __restrict__ tw, int Ns, int hop, int frames, size_t sb,
+                                                         size_t sc, float* __restrict__ y, int folded_rows) {
+  constexpr int N = 1 << LN, M = N / 2, F = M + 1, P = N + 2;
+  extern __shared__ float fft_lds[];
+  float* buf = fft_lds;                                         // [TF][P]
+  float2* twl = reinterpret_cast<float2*>(fft_lds + TF * P);     // [F]
+  const int b = blockIdx.y, f0 = blockIdx.x * TF;
+  for (int f = threadIdx.x; f < F; f += FFT_NT) twl[f] = tw[f];
+  const float* au = audio + (size_t)b * Ns;
+  // a tile whose frames all lie inside the signal and start on 16-byte boundaries is read with 16-byte loads
+  const bool interior = (hop & 3) == 0 && (Ns & 3) == 0 && f0 * hop - M >= 0 && f0 + TF <= frames &&
+                        (f0 + TF - 1) * hop - M + N <= Ns;
+  if (interior) {
+    const float* a0 = au + (f0 * hop - M);
+#pragma unroll 8
+    for (int idx = threadIdx.x; idx < TF * (N / 4); idx += FFT_NT) {
+      const int fl = idx >> (LN - 2), n = (idx & (N / 4 - 1)) * 4;
+      const float4 x = *reinterpret_cast<const float4*>(a0 + fl * hop + n);
+      const float4 ww = *reinterpret_cast<const float4*>(w + n);
+      float* o = buf + fl * P + n;  // P * 4 bytes is a multiple of 8, not of 16
+      *reinterpret_cast<float2*>(o) = make_float2(x.x * ww.x, x.y * ww.y);
+      *reinterpret_cast<float2*>(o + 2) = make_float2(x.z * ww.z, x.w * ww.w);
+    }
+  } else {
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < TF * N; idx += FFT_NT) {
+      const int fl = idx >> LN, n = idx & (N - 1), fr = f0 + fl;
+      float v = 0.f;
+      if (fr < frames) {
+        int i = fr * hop + n - M;
+        if (i < 0) i = -i;
+        if (i >= Ns) i = 2 * (Ns - 1) - i;
+        v = w[n] * au[i];
+      }
+      buf[fl * P + n] = v;
+    }
+  }
+  __syncthreads();
+  fft_passes<LN, TF, P, false>(buf, twl);
+  const int Q = folded_rows ? N / 4 : 0;
+  float* yb = y + (size_t)b * sb;
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < TF * F; idx += FFT_NT) {
+    const int fl = idx % TF, f = idx / TF, fr = f0 + fl;
+    if (fr >= frames) continue;
+    const float2* c = reinterpret_cast<const float2*>(buf + fl * P);
+    const float2 a = c[__brev((unsigned)(f & (M - 1))) >> (33 - LN)];
+    float2 q = c[__brev((unsigned)((M - f) & (M - 1))) >> (33 - LN)];
+    q.y = -q.y;
+    const float2 t = twl[f];
+    const float dr = a.x - q.x, di = a.y - q.y;
+    const float re = 0.5f * (a.x + q.x) + 0.5f * (t.x * di + t.y * dr);
+    const float im = 0.5f * (a.y + q.y) - 0.5f * (t.x * dr - t.y * di);
+    const int row = dft_row(f, Q);
+    yb[(size_t)row * sc + fr] = re;
+    yb[(size_t)(F + row) * sc + fr] = im;
+  }
+}
+
+template <int LN, int TF>
+__global__ __launch_bounds__(FFT_NT) void stft_fft_adj_kernel(const float* __restrict__ dy, const float2* __restrict__ tw,
+                                                             int frames, size_t sb, size_t sc, float* __restrict__ dxt,
+                                                             int folded_rows) {
+  constexpr int N = 1 << LN, M = N / 2, F = M + 1, P = N + 4;  // slot M of a frame holds Y_M
+  extern __shared__ float fft_lds[];
+  float* buf = fft_lds;
+  float2* twl = reinterpret_cast<float2*>(fft_lds + TF * P);
+  const int b = blockIdx.y, f0 = blockIdx.x * TF;
+  for (int f = threadIdx.x; f < F; f += FFT_NT) twl[f] = tw[f];
+  const int Q = folded_rows ? N / 4 : 0;
+  const float* db = dy + (size_t)b * sb;
+#pragma unroll 8
+  for (int idx = threadIdx.x; idx < TF * F; idx += FFT_NT) {
+    const int fl = idx % TF, f = idx / TF, fr = f0 + fl;
+    float2 v = make_float2(0.f, 0.f);
+    if (fr < frames) {
+      const int row = dft_row(f, Q);
+      v.x = db[(size_t)row * sc + fr];
+      v.y = db[(size_t)(F + row) * sc + fr];
+      if (f == 0 || f == M) v = make_float2(2.f * v.x, 0.f);
+    }
+    reinterpret_cast<float2*>(buf + fl * P)[f] = v;
+  }
+  __syncthreads();
+  // Y -> Z, the pair (k, M - k) in place by one thread
+#pragma unroll 2
+  for (int idx = threadIdx.x; idx < TF * (M / 2 + 1); idx += FFT_NT) {
+    const int fl = idx / (M / 2 + 1), k = idx - fl * (M / 2 + 1);
+    float2* c = reinterpret_cast<float2*>(buf + fl * P);
+    const float2 a = c[k], q = c[M - k];
+    const float2 t = twl[k];  // e^(+2 pi i k / N) = (t.x, -t.y);  e^(+2 pi i (M - k) / N) = (-t.x, -t.y)
+    {
+      const float sr = a.x + q.x, si = a.y - q.y, dr = a.x - q.x, di = a.y + q.y;  // a +- conj q
+      // i w d, w = (t.x, -t.y): w d = (t.x dr + t.y di, t.x di - t.y dr)
+      c[k] = make_float2(sr - (t.x * di - t.y * dr), si + (t.x * dr + t.y * di));
+    }
+    if (k != 0 && k != M - k) {
+      const float sr = q.x + a.x, si = q.y - a.y, dr = q.x - a.x, di = q.y + a.y;  // q +- conj a
+      // w = (-t.x, -t.y): w d = (-t.x dr + t.y di, -t.x di - t.y dr)
+      c[M - k] = make_float2(sr - (-t.x * di - t.y * dr), si + (-t.x * dr + t.y * di));
+    }
+  }
+  __syncthreads();
+  fft_passes<LN, TF, P, true>(buf, twl);
+  float* xb = dxt + (size_t)b * sb;
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < TF * M; idx += FFT_NT) {
+    const int fl = idx % TF, m = idx / TF, fr = f0 + fl;
+    if (fr >= frames) continue;
+    const float2 v = reinterpret_cast<const float2*>(buf + fl * P)[__brev((unsigned)m) >> (33 - LN)];
+    xb[(size_t)(2 * m) * sc + fr] = 0.5f * v.x;
+    xb[(size_t)(2 * m + 1) * sc + fr] = 0.5f * v.y;
+  }
+}
+
+static bool fft_enabled(int n_fft) {
+  static const bool off = getenv("STY_DFT_GEMM") != nullptr;
+  return !off && (n_fft == 512 || n_fft == 1024 || n_fft == 2048);
+}
+template <int LN, int TF>
+static int launch_stft_fft_t(const float* audio, const FrontTables& t, int B, int Ns, int hop, int frames, size_t sb, size_t sc,
+                             float* y, hipStream_t st) {
+  constexpr int N = 1 << LN;
+  const size_t lds = (size_t)TF * (N + 2) * 4 + (size_t)(N / 2 + 1) * 8;
+  static bool attr = false;
+  if (!attr) {
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_fft_kernel<LN, TF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  // algorithmic work: 5 M log2 M flops per frame for the half-size complex FFT + ~10 per output bin; bytes: the signal once,
+  // the spectrum (2 F rows) once
+  ProfScope prof("stft_fft_kernel", (double)B * frames * (5.0 * (N / 2) * (LN - 1) + 10.0 * (N / 2 + 1)),
+                 4.0 * ((double)B * Ns + (double)B * frames * (N + 2)), st);
+  hipLaunchKernelGGL((stft_fft_kernel<LN, TF>), dim3(cdiv(frames, TF), B), dim3(FFT_NT), lds, st, audio, t.window, t.tw, Ns, hop,
+                     frames, sb, sc, y, 1);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+template <int LN, int TF>
+static int launch_stft_fft_adj_t(const float* dy, const FrontTables& t, int B, int frames, size_t sb, size_t sc, float* dxt,
+                                 hipStream_t st) {
+  constexpr int N = 1 << LN;
+  const size_t lds = (size_t)TF * (N + 4) * 4 + (size_t)(N / 2 + 1) * 8;
+  static bool attr = false;
+  if (!attr) {
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_fft_adj_kernel<LN, TF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  ProfScope prof("stft_fft_adj_kernel", (double)B * frames * (5.0 * (N / 2) * (LN - 1) + 10.0 * (N / 2 + 1)),
+                 4.0 * ((double)B * frames * (N + 2) + (double)B * frames * N), st);
+  hipLaunchKernelGGL((stft_fft_adj_kernel<LN, TF>), dim3(cdiv(frames, TF), B), dim3(FFT_NT), lds, st, dy, t.tw, frames, sb, sc,
+                     dxt, 1);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+// frames per workgroup: 16 (64-byte runs per spectrum row); STY_FFT_TF=8 halves the tile of the 2048-point transform
+// (70 instead of 139 KB of LDS: two workgroups per CU)
+static bool fft_small_tile() {
+  static const bool v = getenv("STY_FFT_TF") && atoi(getenv("STY_FFT_TF")) == 8;
+  return v;
+}
+// windowed frames of `audio` -> spectrum y [2F][B * frames] in dft_row order (what launch_frame_fold + dft_fold_fwd produce)
+static int launch_stft_fft(const float* audio, const FrontTables& t, int B, int Ns, int hop, int frames, size_t sb, size_t sc,
+                           float* y, hipStream_t st) {
+  switch (t.n_fft) {
+    case 512: return launch_stft_fft_t<9, 16>(audio, t, B, Ns, hop, frames, sb, sc, y, st);
+    case 1024: return launch_stft_fft_t<10, 16>(audio, t, B, Ns, hop, frames, sb, sc, y, st);
+    case 2048:
+      return fft_small_tile() ? launch_stft_fft_t<11, 8>(audio, t, B, Ns, hop, frames, sb, sc, y, st)
+                              : launch_stft_fft_t<11, 16>(audio, t, B, Ns, hop, frames, sb, sc, y, st);
+  }
+  set_error("front end: no FFT for this n_fft");
+  return STY_EINVAL;
+}
+// d spectrum (dft_row order) -> d windowed frames, UNFOLDED rows [n_fft][B * frames]
+static int launch_stft_fft_adj(const float* dy, const FrontTables& t, int B, int frames, size_t sb, size_t sc, float* dxt,
+                               hipStream_t st) {
+  switch (t.n_fft) {
+    case 512: return launch_stft_fft_adj_t<9, 16>(dy, t, B, frames, sb, sc, dxt, st);
+    case 1024: return launch_stft_fft_adj_t<10, 16>(dy, t, B, frames, sb, sc, dxt, st);
+    case 2048:
+      return fft_small_tile() ? launch_stft_fft_adj_t<11, 8>(dy, t, B, frames, sb, sc, dxt, st)
+                              : launch_stft_fft_adj_t<11, 16>(dy, t, B, frames, sb, sc, dxt, st);
+  }
+  set_error("front end: no FFT for this n_fft");
+  return STY_EINVAL;
+}
+
 // y [B][2F][frames] -> power [B][F][frames]
 // (batch-folded: element (b, c, fr) at b*sb + c*sc + fr for both tensors)
 __global__ void power_kernel(const float* __restrict__ y, int F, int frames, size_t sb, size_t sc, float* __restrict__ p,
@@ -428,12 +775,22 @@ int launch_mel(int B, int N, const float* audio, int n_fft, int win, int hop, in
   // batch-folded layout [C][B*frames] for the intermediates (one GEMM problem with B*frames columns), folded frames
   // (even / odd parts: half the DFT multiply-adds)
   const size_t cols = (size_t)B * frames;
-  launch_frame_fold(audio, t->window, B, N, n_fft, hop, frames, (size_t)frames, cols, xt, st);
-  rc = dft_fold_fwd(*t, xt, cols, y, st);
+  if (fft_enabled(n_fft)) {
+    rc = launch_stft_fft(audio, *t, B, N, hop, frames, (size_t)frames, cols, y, st);
+  } else {
+    launch_frame_fold(audio, t->window, B, N, n_fft, hop, frames, (size_t)frames, cols, xt, st);
+    rc = dft_fold_fwd(*t, xt, cols, y, st);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(power_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, y, F, frames, (size_t)frames, cols, p,
                      n_fft / 4);
-  rc = dense(t->fb, p, 1, (int)cols, mp, st);
+  if (fb_sparse_enabled()) {
+    hipLaunchKernelGGL(fb_sparse_fwd_kernel<false>, dim3((unsigned)((cols + 255) / 256), n_mels), dim3(256), 0, st, p, t->fb.wp,
+                       t->fb.CoutP, t->mband, cols, mp);
+    rc = STY_OK;
+  } else {
+    rc = dense(t->fb, p, 1, (int)cols, mp, st);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(mel_finalize_kernel, dim3(cdiv(frames, 256), B), dim3(256), 0, st, mp, n_mels, frames,
                      (size_t)frames, cols, mean, std_, mel, energy);
@@ -863,16 +1220,25 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
       float* mg = side == 0 ? rb[r].t_mag : rb[r].p_mag;
       float* ph = side == 0 ? rb[r].t_phase : rb[r].p_phase;
       // batch-folded layout: (sb, sc) = (frames, B*frames) for every tensor, GEMMs over B*frames columns
-      launch_frame_fold(audio, t->window, B, N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, xt, st);
       const size_t cols = (size_t)B * frames;
-      rc = dft_fold_fwd(*t, xt, cols, yy, st);
+      if (fft_enabled(n_fft)) {
+        rc = launch_stft_fft(audio, *t, B, N, rb[r].hop, frames, (size_t)frames, cols, yy, st);
+      } else {
+        launch_frame_fold(audio, t->window, B, N, n_fft, rb[r].hop, frames, (size_t)frames, cols, xt, st);
+        rc = dft_fold_fwd(*t, xt, cols, yy, st);
+      }
       if (rc) return rc;
       hipLaunchKernelGGL(magphase_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, yy, F, frames,
                          (size_t)frames, (size_t)frames, (size_t)B * frames, fm, ph, n_fft / 4);
-      rc = dense(t->fb, fm, 1, B * frames, mg, st);
-      if (rc) return rc;
-      const size_t n = (size_t)B * 128 * frames;
-      hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mg, n);
+      if (fb_sparse_enabled()) {  // filter bank + log1p in one pass
+        hipLaunchKernelGGL(fb_sparse_fwd_kernel<true>, dim3((unsigned)((cols + 255) / 256), 128), dim3(256), 0, st, fm, t->fb.wp,
+                           t->fb.CoutP, t->mband, cols, mg);
+      } else {
+        rc = dense(t->fb, fm, 1, B * frames, mg, st);
+        if (rc) return rc;
+        const size_t n = (size_t)B * 128 * frames;
+        hipLaunchKernelGGL(log1p_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mg, n);
+      }
     }
     if (target_only) continue;
     hipLaunchKernelGGL(loss_sums_kernel, dim3(1024), dim3(256), 0, st, rb[r], r, B, sums);
@@ -905,16 +1271,23 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
     float* dabs = tmp;                                   // [B][F][frames]
     float* dy = dabs + (size_t)B * F * frames;           // [B][2F][frames]
     float* dxt = dy + (size_t)B * 2 * F * frames;        // [B][n_fft][frames]
-    rc = dense(t->fbT, rb[r].d_mag, 1, B * frames, dabs, st);
-    if (rc) return rc;
+    if (fb_sparse_enabled()) {
+      hipLaunchKernelGGL(fb_sparse_bwd_kernel, dim3((unsigned)(((size_t)B * frames + 255) / 256), F), dim3(256), 0, st,
+                         rb[r].d_mag, t->fb.wp, t->fb.CoutP, t->fband, (size_t)B * frames, dabs);
+    } else {
+      rc = dense(t->fbT, rb[r].d_mag, 1, B * frames, dabs, st);
+      if (rc) return rc;
+    }
     if (gan)
       hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((nph + 255) / 256)), dim3(256), 0, st, d_gan[r], nph, dabs);
     hipLaunchKernelGGL(magphase_bwd_kernel, dim3(cdiv(frames, 256), F, B), dim3(256), 0, st, rb[r].p_y, dabs,
                        rb[r].d_phase, F, frames, (size_t)frames, (size_t)frames, (size_t)B * frames, dy, n_fft / 4);
     const size_t cols = (size_t)B * frames;
-    rc = dft_fold_bwd(*t, dy, cols, dxt, st);
+    const bool fft = fft_enabled(n_fft);
+    rc = fft ? launch_stft_fft_adj(dy, *t, B, frames, (size_t)frames, cols, dxt, st) : dft_fold_bwd(*t, dy, cols, dxt, st);
     if (rc) return rc;
-    rc = launch_frame_bwd(dxt, t->window, B, N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, d_pred, 1, st);
+    rc = launch_frame_bwd(dxt, t->window, B, N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, d_pred,
+                          fft ? 0 : 1, st);
     if (rc) return rc;
   }
   STY_LAUNCH_CHECK();

@@ -127,10 +127,16 @@ class FlatAdamW:
             self.v[b][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))
         if len(steps) > 1:
-            # one bias-correction counter per bucket kernel: parameters of one optimizer are always stepped together here
-            # and in the reference (find_unused_parameters only skips parameters that NEVER get a gradient)
-            raise L.StyError(f"optimizer state: parameters at different step counts {sorted(steps)}")
-        self.t = steps.pop() if steps else 0
+            # one bias-correction counter per bucket kernel.  torch.optim.AdamW keeps one per parameter, and under the
+            # reference's DDP(find_unused_parameters=True) a parameter that had no gradient on some steps is behind the
+            # rest; such a file is valid.  The flat buckets continue at the largest count (bias correction of the lagging
+            # parameters is slightly ahead -- a factor 1 - beta^t that is ~1 after a few hundred steps) instead of
+            # refusing the checkpoint.  Parameters that never receive a gradient here are still decayed every step;
+            # torch skips a grad=None parameter entirely.
+            import warnings
+            warnings.warn(f"optimizer state: parameters at different step counts {sorted(steps)}; continuing at "
+                          f"{max(steps)}", stacklevel=2)
+        self.t = max(steps) if steps else 0
 
 
 LOGICAL_STEP_LIMIT = 10000  # train/optimizers.py:11
