@@ -463,6 +463,12 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                    "x_realtime": frames / dt / 80.0},
         "host_issue_ms_per_step": 1e3 * host_dt / steps,
     }
+    if trainer is not None and getattr(trainer, "_probe_on", False):
+        # STY_STEP_PROBE=1 (a tuning aid, not part of the default line): device time stamps of the phases of one more step
+        step(warmup + steps + 50)
+        step(warmup + steps + 51)
+        torch.cuda.synchronize()
+        rec["phases_ms"] = [[n, round(t, 3)] for n, t in trainer.probe_report()]
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
         traffic, traffic_src = pmc_traffic(dom["name"], name)

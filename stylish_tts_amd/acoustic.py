@@ -122,6 +122,8 @@ class AcousticTrainer:
             self.disc_helper = DiscriminatorLossHelper(disc, 1)
         import os
         self.early_target = os.environ.get("STY_NO_EARLY_TARGET") is None
+        self._probe_on = os.environ.get("STY_STEP_PROBE") is not None
+        self._probe_events, self._probe_last = [], None
         self._hooks = {}
         self._hook_error = None
 
@@ -142,6 +144,20 @@ class AcousticTrainer:
         cb = L.GRAD_HOOK(hook)
         L.check(L.load().sty_model_set_grad_hook(module._handle, C.cast(cb, C.c_void_p), None))
         self._hooks[key] = cb  # keep the ctypes thunk alive
+
+    def _probe(self, name, stream=None):
+        """STY_STEP_PROBE=1: device time stamps of the step's phases (events on the stream a phase was issued on, read at the
+        start of the NEXT step), for tools/probes/step_phases.py -- the kernel trace serialises the two encoders, this does not."""
+        if not self._probe_on:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream if stream is not None else torch.cuda.current_stream())
+        self._probe_events.append((name, e))
+
+    def probe_report(self):
+        """[(phase, ms since the step's first stamp)] of the last finished step (after a synchronize)"""
+        ev = self._probe_last
+        return [(n, ev[0][1].elapsed_time(e)) for n, e in ev] if ev else []
 
     def _side_stream(self, device):
         """second torch stream for the style encoder (STY_NO_SE_STREAM=1: everything on the current stream)"""
@@ -172,6 +188,9 @@ class AcousticTrainer:
         # for as long as the host needs to issue the hundred launches.
         main = torch.cuda.current_stream(audio_gt.device)
         side = self._side_stream(audio_gt.device)
+        if self._probe_on:
+            self._probe_last, self._probe_events = self._probe_events, []
+        self._probe("start", main)
         if side is not None:
             side.wait_stream(main)  # (the previous step's optimizer)
         mel, _, energy = calculate_mel(audio_gt, TO_MEL, self.mean, self.std, want_energy=True)
@@ -180,6 +199,7 @@ class AcousticTrainer:
             with torch.cuda.stream(side):
                 self.se.prepare_train(audio_gt.device)
         T = mel.shape[2]
+        self._probe("mel front ends issued->done (main)", main)
         alignment = duration_to_alignment(durations, T)
         # Two streams: the style encoder (mid-size GEMMs) runs beside the text encoder (a chain of tiny kernels) in
         # both directions.  Forward: the predictor waits for `style` only after its text encoder; backward: d_style
@@ -189,14 +209,17 @@ class AcousticTrainer:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 style = self.se.forward_train(style_in)
+            self._probe("style encoder forward done (side)", side)
         else:
             style = self.se.forward_train(style_in)
         voiced = (pitch > 20).float()
         # the target side of the loss features (three STFT resolutions of audio_gt) needs no forward pass: issued here, in
         # front of the predictor, its kernels run while the main stream would otherwise wait for the style encoder
         target = acoustic_loss_target(audio_gt) if self.early_target else None
+        self._probe("target loss features done (main)", main)
         audio = self.sp.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, pitch,
                                       noise=noise, seed=seed, prior_override=prior_override, style_stream=side)
+        self._probe("predictor forward done (main)", main)
         if self.mrd is None:
             losses, d_audio = acoustic_loss(audio_gt, audio.squeeze(1), self.w_mel, self.w_phase, target=target)
         else:
@@ -225,12 +248,15 @@ class AcousticTrainer:
         # the all-reduces are started by the gradient hooks from inside the two backward calls: the predictor's
         # segment 0 (vocoder + decoder) while its text encoder's backward still runs, its segment 1 at the end, the style
         # encoder's buckets at the end of its backward (on the stream that backward runs on)
+        self._probe("loss + seed done (main)", main)
         d_style, _ = self.sp.backward(d_audio, want_style=True, want_energy=False)
+        self._probe("predictor backward done (main)", main)
         gp, gs = self.opt["speech_predictor"].grads, self.opt["speech_style_encoder"].grads
         if side is not None:
             self.sp.wait_d_style(side)
             with torch.cuda.stream(side):
                 self.se.backward(d_style)
+            self._probe("style encoder backward done (side)", side)
             # the style encoder's backward is the tail of the step and the main stream has nothing left to do beside it:
             # the predictor's gradients are final, so its exchange is finished and its AdamW runs here, under the tail
             if self._hook_error is None:
@@ -267,6 +293,7 @@ class AcousticTrainer:
                 ow.grads.finish(average=False)
                 ow.lr = self.opt["speech_predictor"].lr
                 ow.step(grad_scale=1.0 / world, lr_mult=self.disc_helper.track_device(tracked[n + 2:n + 3]))
+        self._probe("step done (main)", main)
         self.audio = audio
         return losses
 

@@ -430,6 +430,26 @@ static void launch_frame_fold(const float* audio, const float* w, int B, int N, 
 // overlap-add (frame_bwd, folded = 0) is unchanged.
 // tw[f] = (cos, -sin)(2 pi f / n_fft), f = 0..M, computed in double precision; the pass with span h uses tw[pos * n_fft / (2h)].
 constexpr int FFT_NT = 1024;
+// which (utterance, first frame) a workgroup works on.  xcd != 0 (= the number of utterances): the hardware deals consecutive workgroup ids to the eight
+// XCDs in turn, so two neighbouring frame tiles -- which write the two halves of the same 128-byte lines of every spectrum
+// row -- would sit in different L2s; id -> (xcd = id % 8, slot = id / 8) -> tile xcd * per + slot keeps neighbours on one XCD
+__device__ __forceinline__ bool fft_tile(int frames, int TF, int xcd, int& b, int& f0) {
+  const int ntx = (frames + TF - 1) / TF;
+  int tile = blockIdx.x;
+  if (xcd) {
+    const int total = ntx * xcd, per = (total + 7) / 8;
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    tile = (id & 7) * per + (id >> 3);
+    if (tile >= total || (id >> 3) >= per) return false;
+    b = tile / ntx;
+    f0 = (tile - b * ntx) * TF;
+    return true;
+  }
+  b = blockIdx.y;
+  f0 = tile * TF;
+  return true;
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // radix-4 passes (two radix-2 decimation-in-frequency stages in one trip through LDS, same bit-reversed output order:
 // y0, y2, y1, y3 go to i0, i0 + q, i0 + 2q, i0 + 3q), one radix-2 pass at the end when log2 M is odd
@@ -479,12 +499,13 @@ __device__ __forceinline__ void fft_passes(float* buf, const float2* twl) {
 template <int LN, int TF>
 __global__ __launch_bounds__(FFT_NT) void stft_fft_kernel(const float* __restrict__ audio, const float* __restrict__ w,
                                                          const float2* __restrict__ tw, int Ns, int hop, int frames, size_t sb,
-                                                         size_t sc, float* __restrict__ y, int folded_rows) {
+                                                         size_t sc, float* __restrict__ y, int folded_rows, int xcd) {
   constexpr int N = 1 << LN, M = N / 2, F = M + 1, P = N + 2;
   extern __shared__ float fft_lds[];
   float* buf = fft_lds;                                         // [TF][P]
   float2* twl = reinterpret_cast<float2*>(fft_lds + TF * P);     // [F]
-  const int b = blockIdx.y, f0 = blockIdx.x * TF;
+  int b, f0;
+  if (!fft_tile(frames, TF, xcd, b, f0)) return;
   for (int f = threadIdx.x; f < F; f += FFT_NT) twl[f] = tw[f];
   const float* au = audio + (size_t)b * Ns;
   // a tile whose frames all lie inside the signal and start on 16-byte boundaries is read with 16-byte loads
@@ -540,12 +561,14 @@ __global__ __launch_bounds__(FFT_NT) void stft_fft_kernel(const float* __restric
 template <int LN, int TF>
 __global__ __launch_bounds__(FFT_NT) void stft_fft_adj_kernel(const float* __restrict__ dy, const float2* __restrict__ tw,
                                                              int frames, size_t sb, size_t sc, float* __restrict__ dxt,
-                                                             int folded_rows) {
+                                                             int folded_rows, int xcd, const float* __restrict__ w, int hop,
+                                                             float* __restrict__ span) {
   constexpr int N = 1 << LN, M = N / 2, F = M + 1, P = N + 4;  // slot M of a frame holds Y_M
   extern __shared__ float fft_lds[];
   float* buf = fft_lds;
   float2* twl = reinterpret_cast<float2*>(fft_lds + TF * P);
-  const int b = blockIdx.y, f0 = blockIdx.x * TF;
+  int b, f0;
+  if (!fft_tile(frames, TF, xcd, b, f0)) return;
   for (int f = threadIdx.x; f < F; f += FFT_NT) twl[f] = tw[f];
   const int Q = folded_rows ? N / 4 : 0;
   const float* db = dy + (size_t)b * sb;
@@ -582,6 +605,29 @@ __global__ __launch_bounds__(FFT_NT) void stft_fft_adj_kernel(const float* __res
   }
   __syncthreads();
   fft_passes<LN, TF, P, true>(buf, twl);
+  if (span) {
+    // windowed overlap-add of the tile's own frames: span[s] = sum_fl w[n] d xt_fl[n], n = s - fl hop, frames in ascending
+    // order; one contiguous run of (TF - 1) hop + N floats per tile (16-byte aligned rows, coalesced) instead of N rows of
+    // TF floats each.  span_gather_kernel adds the (at most two) tiles that cover a sample and the reflections.
+    const int SPAN = (TF - 1) * hop + N;
+    float* so = span + ((size_t)b * ((frames + TF - 1) / TF) + f0 / TF) * SPAN;
+#pragma unroll 2
+    for (int sidx = threadIdx.x; sidx < SPAN; sidx += FFT_NT) {
+      int fl_hi = sidx / hop;
+      if (fl_hi > TF - 1) fl_hi = TF - 1;
+      int fl_lo = (sidx - N + hop) / hop;
+      if (sidx - N + 1 <= 0 || fl_lo < 0) fl_lo = 0;
+      float acc = 0.f;
+      for (int fl = fl_lo; fl <= fl_hi; ++fl) {
+        const int n = sidx - fl * hop;
+        if (n < 0 || n >= N) continue;
+        const float2 v = reinterpret_cast<const float2*>(buf + fl * P)[__brev((unsigned)(n >> 1)) >> (33 - LN)];
+        acc = fmaf(w[n], 0.5f * ((n & 1) ? v.y : v.x), acc);
+      }
+      so[sidx] = acc;
+    }
+    return;
+  }
   float* xb = dxt + (size_t)b * sb;
 #pragma unroll 4
   for (int idx = threadIdx.x; idx < TF * M; idx += FFT_NT) {
@@ -593,9 +639,51 @@ __global__ __launch_bounds__(FFT_NT) void stft_fft_adj_kernel(const float* __res
   }
 }
 
+// d audio[b][i] += the spans of the tiles that cover sample i's padded positions (itself, its left mirror, its right mirror:
+// centre = True / reflect padding), tiles in ascending order: the deterministic second half of the overlap-add
+__global__ __launch_bounds__(256) void span_gather_kernel(const float* __restrict__ span, int Ns, int n_fft, int hop, int TF,
+                                                          int ntx, float* __restrict__ daudio) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= Ns) return;
+  const int half = n_fft / 2, SPAN = (TF - 1) * hop + n_fft, step = TF * hop;
+  const float* sb_ = span + (size_t)b * ntx * SPAN;
+  int ps[3];
+  int np = 0;
+  ps[np++] = i;
+  if (i >= 1 && i <= half) ps[np++] = -i;
+  if (i <= Ns - 2 && i >= Ns - 1 - half) ps[np++] = 2 * (Ns - 1) - i;
+  float acc = 0.f;
+  for (int k = 0; k < np; ++k) {
+    const int q = ps[k] + half;  // index into the padded signal; tile t covers [t step, t step + SPAN)
+    int t_hi = q / step;
+    if (t_hi > ntx - 1) t_hi = ntx - 1;
+    int t_lo = (q - SPAN + step) / step;
+    if (q - SPAN + 1 <= 0 || t_lo < 0) t_lo = 0;
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const int o = q - t * step;
+      if (o >= 0 && o < SPAN) acc += sb_[(size_t)t * SPAN + o];
+    }
+  }
+  daudio[(size_t)b * Ns + i] += acc;
+}
+
 static bool fft_enabled(int n_fft) {
   static const bool off = getenv("STY_DFT_GEMM") != nullptr;
   return !off && (n_fft == 512 || n_fft == 1024 || n_fft == 2048);
+}
+// (measured alone on the chip, B = 32 x 6.5 s, tools/probes/fft_variants.sh: 2048 points 102 -> 93 us with the XCD map, -> 72 with
+// 8-frame tiles on top of it (two workgroups per CU); 1024 points 62 -> 51, 512 points 47 -> 41; adjoint 123 / 80 / 73 ->
+// 78 / 67 / 64; 32-frame tiles gain nothing)
+static int fft_xcd() {
+  static const int v = getenv("STY_FFT_XCD") ? atoi(getenv("STY_FFT_XCD")) : 1;
+  return v;
+}
+// (xcd mode: the id -> tile map needs a multiple of eight workgroups; one extra row of the grid covers the remainder)
+static dim3 fft_grid(int frames, int TF, int B) {
+  const int ntx = cdiv(frames, TF);
+  if (!fft_xcd()) return dim3(ntx, B);
+  const int total = ntx * B, per = cdiv(total, 8);
+  return dim3(ntx, cdiv(per * 8, ntx));
 }
 template <int LN, int TF>
 static int launch_stft_fft_t(const float* audio, const FrontTables& t, int B, int Ns, int hop, int frames, size_t sb, size_t sc,
@@ -612,14 +700,14 @@ static int launch_stft_fft_t(const float* audio, const FrontTables& t, int B, in
   // the spectrum (2 F rows) once
   ProfScope prof("stft_fft_kernel", (double)B * frames * (5.0 * (N / 2) * (LN - 1) + 10.0 * (N / 2 + 1)),
                  4.0 * ((double)B * Ns + (double)B * frames * (N + 2)), st);
-  hipLaunchKernelGGL((stft_fft_kernel<LN, TF>), dim3(cdiv(frames, TF), B), dim3(FFT_NT), lds, st, audio, t.window, t.tw, Ns, hop,
-                     frames, sb, sc, y, 1);
+  hipLaunchKernelGGL((stft_fft_kernel<LN, TF>), fft_grid(frames, TF, B), dim3(FFT_NT), lds, st, audio, t.window, t.tw, Ns, hop,
+                     frames, sb, sc, y, 1, fft_xcd() ? B : 0);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
 template <int LN, int TF>
 static int launch_stft_fft_adj_t(const float* dy, const FrontTables& t, int B, int frames, size_t sb, size_t sc, float* dxt,
-                                 hipStream_t st) {
+                                 hipStream_t st, int hop, float* span) {
   constexpr int N = 1 << LN;
   const size_t lds = (size_t)TF * (N + 4) * 4 + (size_t)(N / 2 + 1) * 8;
   static bool attr = false;
@@ -630,40 +718,77 @@ static int launch_stft_fft_adj_t(const float* dy, const FrontTables& t, int B, i
   }
   ProfScope prof("stft_fft_adj_kernel", (double)B * frames * (5.0 * (N / 2) * (LN - 1) + 10.0 * (N / 2 + 1)),
                  4.0 * ((double)B * frames * (N + 2) + (double)B * frames * N), st);
-  hipLaunchKernelGGL((stft_fft_adj_kernel<LN, TF>), dim3(cdiv(frames, TF), B), dim3(FFT_NT), lds, st, dy, t.tw, frames, sb, sc,
-                     dxt, 1);
+  hipLaunchKernelGGL((stft_fft_adj_kernel<LN, TF>), fft_grid(frames, TF, B), dim3(FFT_NT), lds, st, dy, t.tw, frames, sb, sc,
+                     dxt, 1, fft_xcd() ? B : 0, t.window, hop, span);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
-// frames per workgroup: 16 (64-byte runs per spectrum row); STY_FFT_TF=8 halves the tile of the 2048-point transform
-// (70 instead of 139 KB of LDS: two workgroups per CU)
-static bool fft_small_tile() {
-  static const bool v = getenv("STY_FFT_TF") && atoi(getenv("STY_FFT_TF")) == 8;
-  return v;
+// frames per workgroup: 16 (64-byte runs per spectrum row), 8 for the 2048-point transform (70 instead of 139 KB of LDS: two
+// workgroups per CU overlap their load / butterfly / store phases); STY_FFT_TF = 8 / 16 / 32 overrides (32 does not fit at
+// 2048 points)
+static int fft_tf(int n_fft) {
+  static const int v = getenv("STY_FFT_TF") ? atoi(getenv("STY_FFT_TF")) : 0;
+  return v ? v : (n_fft >= 2048 ? 8 : 16);
 }
 // windowed frames of `audio` -> spectrum y [2F][B * frames] in dft_row order (what launch_frame_fold + dft_fold_fwd produce)
 static int launch_stft_fft(const float* audio, const FrontTables& t, int B, int Ns, int hop, int frames, size_t sb, size_t sc,
                            float* y, hipStream_t st) {
+  const int tf = fft_tf(t.n_fft);
+#define STY_FFT_FWD(LN_, TF_) return launch_stft_fft_t<LN_, TF_>(audio, t, B, Ns, hop, frames, sb, sc, y, st)
   switch (t.n_fft) {
-    case 512: return launch_stft_fft_t<9, 16>(audio, t, B, Ns, hop, frames, sb, sc, y, st);
-    case 1024: return launch_stft_fft_t<10, 16>(audio, t, B, Ns, hop, frames, sb, sc, y, st);
+    case 512:
+      if (tf == 8) STY_FFT_FWD(9, 8);
+      if (tf == 32) STY_FFT_FWD(9, 32);
+      STY_FFT_FWD(9, 16);
+    case 1024:
+      if (tf == 8) STY_FFT_FWD(10, 8);
+      if (tf == 32) STY_FFT_FWD(10, 32);
+      STY_FFT_FWD(10, 16);
     case 2048:
-      return fft_small_tile() ? launch_stft_fft_t<11, 8>(audio, t, B, Ns, hop, frames, sb, sc, y, st)
-                              : launch_stft_fft_t<11, 16>(audio, t, B, Ns, hop, frames, sb, sc, y, st);
+      if (tf == 8) STY_FFT_FWD(11, 8);
+      STY_FFT_FWD(11, 16);
   }
+#undef STY_FFT_FWD
   set_error("front end: no FFT for this n_fft");
   return STY_EINVAL;
 }
 // d spectrum (dft_row order) -> d windowed frames, UNFOLDED rows [n_fft][B * frames]
+static int launch_stft_fft_adj_sel(const float* dy, const FrontTables& t, int B, int frames, size_t sb, size_t sc, float* dxt,
+                                   hipStream_t st, int hop, float* span, int tf);
+// span_out != nullptr (with hop and the signal length Ns): the windowed overlap-add straight into d audio (+=) through per-tile
+// spans kept in `dxt` -- stft_fft_adj_kernel's span mode + span_gather_kernel -- instead of the frame gradient
 static int launch_stft_fft_adj(const float* dy, const FrontTables& t, int B, int frames, size_t sb, size_t sc, float* dxt,
-                               hipStream_t st) {
-  switch (t.n_fft) {
-    case 512: return launch_stft_fft_adj_t<9, 16>(dy, t, B, frames, sb, sc, dxt, st);
-    case 1024: return launch_stft_fft_adj_t<10, 16>(dy, t, B, frames, sb, sc, dxt, st);
-    case 2048:
-      return fft_small_tile() ? launch_stft_fft_adj_t<11, 8>(dy, t, B, frames, sb, sc, dxt, st)
-                              : launch_stft_fft_adj_t<11, 16>(dy, t, B, frames, sb, sc, dxt, st);
+                               hipStream_t st, int hop = 0, int Ns = 0, float* daudio = nullptr) {
+  const int tf = fft_tf(t.n_fft);
+  if (daudio) {
+    int tfe = (t.n_fft == 2048 && tf > 16) ? 16 : tf;
+    if (tfe != 8 && tfe != 16 && tfe != 32) tfe = 16;
+    int rc = launch_stft_fft_adj_sel(dy, t, B, frames, sb, sc, dxt, st, hop, dxt, tfe);
+    if (rc) return rc;
+    hipLaunchKernelGGL(span_gather_kernel, dim3(cdiv(Ns, 256), B), dim3(256), 0, st, dxt, Ns, t.n_fft, hop, tfe, cdiv(frames, tfe),
+                       daudio);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
   }
+  return launch_stft_fft_adj_sel(dy, t, B, frames, sb, sc, dxt, st, 0, nullptr, tf);
+}
+static int launch_stft_fft_adj_sel(const float* dy, const FrontTables& t, int B, int frames, size_t sb, size_t sc, float* dxt,
+                                   hipStream_t st, int hop, float* span, int tf) {
+#define STY_FFT_ADJ(LN_, TF_) return launch_stft_fft_adj_t<LN_, TF_>(dy, t, B, frames, sb, sc, dxt, st, hop, span)
+  switch (t.n_fft) {
+    case 512:
+      if (tf == 8) STY_FFT_ADJ(9, 8);
+      if (tf == 32) STY_FFT_ADJ(9, 32);
+      STY_FFT_ADJ(9, 16);
+    case 1024:
+      if (tf == 8) STY_FFT_ADJ(10, 8);
+      if (tf == 32) STY_FFT_ADJ(10, 32);
+      STY_FFT_ADJ(10, 16);
+    case 2048:
+      if (tf == 8) STY_FFT_ADJ(11, 8);
+      STY_FFT_ADJ(11, 16);
+  }
+#undef STY_FFT_ADJ
   set_error("front end: no FFT for this n_fft");
   return STY_EINVAL;
 }
@@ -1284,6 +1409,12 @@ int launch_acoustic_loss_gan(int B, int N, const float* audio_gt, const float* a
                        rb[r].d_phase, F, frames, (size_t)frames, (size_t)frames, (size_t)B * frames, dy, n_fft / 4);
     const size_t cols = (size_t)B * frames;
     const bool fft = fft_enabled(n_fft);
+    static const bool no_span = getenv("STY_FFT_NO_SPAN") != nullptr;
+    if (fft && !no_span) {  // inverse transform + windowed overlap-add into d_pred (two launches, no frame-gradient tensor)
+      rc = launch_stft_fft_adj(dy, *t, B, frames, (size_t)frames, cols, dxt, st, rb[r].hop, N, d_pred);
+      if (rc) return rc;
+      continue;
+    }
     rc = fft ? launch_stft_fft_adj(dy, *t, B, frames, (size_t)frames, cols, dxt, st) : dft_fold_bwd(*t, dy, cols, dxt, st);
     if (rc) return rc;
     rc = launch_frame_bwd(dxt, t->window, B, N, n_fft, rb[r].hop, frames, (size_t)frames, (size_t)B * frames, d_pred,

@@ -251,7 +251,9 @@ def test_context_free_discriminator_oracle_and_manifest_match_reference():
     for k in pp:
         if ("grad." + k) in fx:
             ref = fx["grad." + k]
-            assert (pp[k].grad - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-4), k
+            # (a bias in front of a BatchNorm has a structurally zero gradient: |ref| ~ 1e-8 of rounding noise on both sides,
+            # whose size depends on the host's conv kernels -- the floor keeps such a tensor from being compared to itself)
+            assert (pp[k].grad - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-3), k
 
 
 def _cf_model(params, dev):

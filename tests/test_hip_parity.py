@@ -973,9 +973,10 @@ def test_style_encoder_operand_twins_equal_the_fp32_operand_path(W, monkeypatch)
     y16: written by the producing kernel's output stage -- stem, convp16_kernel, learned down-sampling, pooling and their
     backward kernels -- or by the cast pass; read by convp16_kernel with two-byte loads and by wgradb16_kernel with no
     conversion) against the same mode with fp32 operands converted on the way into LDS (STY_NO_TWINS=1): a twin holds
-    exactly the value the fp32 path rounds to, so every forward tap, every gradient tap and every weight gradient must
-    agree BIT FOR BIT (the head's Linear weight gradient is a float-atomic sum in both runs: 1e-6; conv BIAS gradients are
-    row sums of the rounded twin in one run and of the unrounded gradient in the other: 2^-8) -- a stale twin (a
+    exactly the value the fp32 path rounds to, so every forward tap and every gradient tap must agree BIT FOR BIT, and every
+    weight gradient up to the fp32 summation order of the two kernels' different splits (2e-6; the head's Linear weight
+    gradient is a float-atomic sum in both runs; conv BIAS gradients are row sums of the rounded twin in one run and of the
+    unrounded gradient in the other: 2^-8) -- a stale twin (a
     gradient buffer written again after its twin was taken), a wrong mask or a wrong row end shows up here.  Widths: even
     row pitch, odd width (the pooled rows replicate the last column), and the width at which an image row holds fewer
     than one 64-column group.  convp16 / wgradb16 are forced onto the small shapes and checked to have run."""
@@ -1031,7 +1032,9 @@ def test_style_encoder_operand_twins_equal_the_fp32_operand_path(W, monkeypatch)
             # bf16 twin of G (wgradb16_kernel: an MFMA against ones), without them wgradb_kernel sums G before rounding
             assert rel_err(gb[k], ga[k]) <= 4e-3, (k, rel_err(gb[k], ga[k]))
         else:
-            assert torch.equal(ga[k], gb[k]), f"d {k} differs: {rel_err(gb[k], ga[k]):.3e}"
+            # same rounded operands, but wgradb16_kernel and wgradb_kernel walk the (batch, time) chunks in different
+            # splits: fp32 summation order (measured 2e-7)
+            assert rel_err(gb[k], ga[k]) <= 2e-6, f"d {k} differs: {rel_err(gb[k], ga[k]):.3e}"
 
 
 def test_adamw_matches_torch():
