@@ -446,6 +446,17 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     dt = D.max_over_ranks(dt, device)
     if synth is not None:
         T = out.shape[-1] // 300  # frames the duration predictor asked for (same inputs every step)
+    phases = None
+    if trainer is not None and getattr(trainer, "_probe_on", False):
+        # STY_STEP_PROBE=1 (a tuning aid, not part of the default line): device time stamps of the phases of one more step
+        if getattr(trainer, "single_stream", False):
+            lib.sty_set_single_stream(0)
+            trainer.single_stream = False
+        step(warmup + steps + 50)
+        step(warmup + steps + 51)
+        step(warmup + steps + 52)
+        torch.cuda.synchronize()
+        phases = [[n, round(t, 3)] for n, t in trainer.probe_report()]
     del trainer, model, style_enc, synth, inp, out, step
     torch.cuda.empty_cache()
     if rank != 0:
@@ -463,12 +474,8 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                    "x_realtime": frames / dt / 80.0},
         "host_issue_ms_per_step": 1e3 * host_dt / steps,
     }
-    if trainer is not None and getattr(trainer, "_probe_on", False):
-        # STY_STEP_PROBE=1 (a tuning aid, not part of the default line): device time stamps of the phases of one more step
-        step(warmup + steps + 50)
-        step(warmup + steps + 51)
-        torch.cuda.synchronize()
-        rec["phases_ms"] = [[n, round(t, 3)] for n, t in trainer.probe_report()]
+    if phases:
+        rec["phases_ms"] = phases
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
         traffic, traffic_src = pmc_traffic(dom["name"], name)

@@ -254,6 +254,7 @@ class AcousticTrainer:
         gp, gs = self.opt["speech_predictor"].grads, self.opt["speech_style_encoder"].grads
         if side is not None:
             self.sp.wait_d_style(side)
+            self._probe("d_style ready (side; the text encoder's backward is what is left of the predictor's)", side)
             with torch.cuda.stream(side):
                 self.se.backward(d_style)
             self._probe("style encoder backward done (side)", side)

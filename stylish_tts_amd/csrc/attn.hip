@@ -138,24 +138,31 @@ int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st) {
   return STY_OK;
 }
 
-// partial RoPE in place on q and k [B][H*DH][L]: first `d` dims of every head (text_encoder.py:146-168)
-__global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, int H, int DH, int L, int d, float t0,
-                            float t1, float t2, float t3, float sgn) {
+// partial RoPE on q and k [B][H*DH][L]: first `d` dims of every head (text_encoder.py:146-168); in place (qs == q) or out of
+// place (the training graph keeps the un-rotated tensors for the tape: the kernel then copies the other DH - d dims as well,
+// which replaces two device-to-device copies per layer in front of it)
+__global__ void rope_kernel(const float* qs, const float* ks, float* q, float* k, int H, int DH, int L, int d, float t0, float t1, float t2, float t3,
+                            float sgn) {
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   if (pos >= L) return;
   const float theta[4] = {t0, t1, t2, t3};
   const int half = d / 2;
+  const float* src[2] = {qs, ks};
   float* ptr[2] = {q, k};
   for (int w = 0; w < 2; ++w) {
-    float* base = ptr[w] + ((size_t)b * H + h) * DH * L + pos;
+    const size_t o = ((size_t)b * H + h) * DH * L + pos;
+    const float* sb_ = src[w] + o;
+    float* base = ptr[w] + o;
     float x[8];
-    for (int i = 0; i < d; ++i) x[i] = base[(size_t)i * L];
+    for (int i = 0; i < d; ++i) x[i] = sb_[(size_t)i * L];
     for (int i = 0; i < d; ++i) {
       const float ang = (float)pos * theta[i % half];
       const float rot = i < half ? -x[i + half] : x[i - half];
       base[(size_t)i * L] = x[i] * cosf(ang) + rot * (sgn * sinf(ang));
     }
+    if (sb_ != base)
+      for (int i = d; i < DH; ++i) base[(size_t)i * L] = sb_[(size_t)i * L];
   }
 }
 
@@ -166,8 +173,19 @@ int launch_rope_signed(float* q, float* k, int B, int H, int DH, int L, int d, c
     set_error("rope: only d == 8 built");
     return STY_EINVAL;
   }
-  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, H, DH, L, d, theta4[0], theta4[1],
+  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, q, k, q, k, H, DH, L, d, theta4[0], theta4[1],
                      theta4[2], theta4[3], sgn);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+int launch_rope_copy(const float* qs, const float* ks, float* q, float* k, int B, int H, int DH, int L, int d,
+                     const float* theta4, hipStream_t st) {
+  if (d != 8) {
+    set_error("rope: only d == 8 built");
+    return STY_EINVAL;
+  }
+  hipLaunchKernelGGL(rope_kernel, dim3(cdiv(L, 64), H, B), dim3(64), 0, st, qs, ks, q, k, H, DH, L, d, theta4[0], theta4[1],
+                     theta4[2], theta4[3], 1.0f);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -729,6 +729,15 @@ static int q_num_cus() {
   }
   return n;
 }
+// The style encoder's launches (flat 2-D convs, on a stream of their own beside the text encoder's chain of ~20 us kernels)
+// leave some CUs alone: a persistent launch holds one workgroup on every CU it was given until it ends, and a kernel of
+// another stream that becomes ready in the meantime waits for the whole launch.  Measured on c3 with time stamps on the
+// streams (STY_STEP_PROBE): 0 / 8 / 16 / 32 / 64 free CUs -> predictor forward done at 17.8 / 17.8 / 18.0 / 17.2 / 17.2 ms,
+// step 56.9 / 57.0 / 57.2 / 56.5 / 56.3 ms.  STY_CONVP16_FREE_CUS overrides (0 = the whole chip).
+static int q_style_free_cus() {
+  static const int v = getenv("STY_CONVP16_FREE_CUS") ? atoi(getenv("STY_CONVP16_FREE_CUS")) : 32;
+  return v;
+}
 
 static int q_mtw(const ConvArgs& a) { return a.w.CoutP <= 64 || a.w.K > 3 ? 1 : 2; }
 static size_t q_lds_bytes(const ConvArgs& a) {
@@ -768,7 +777,9 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   }
   const int tiles_per_row = cdiv(a.T, Q_TT), ncot = cdiv(a.w.CoutP, 64 * MTW);
   const int ntiles = tiles_per_row * a.B * ncot;
-  const int grid = ntiles < q_num_cus() ? ntiles : q_num_cus();
+  int cus = q_num_cus();
+  if (a.flatW && q_style_free_cus() > 0 && q_style_free_cus() < cus / 2) cus -= q_style_free_cus();
+  const int grid = ntiles < cus ? ntiles : cus;
   const double outs = (double)a.B * a.w.Cout * a.T;
   const double flops = 2.0 * a.w.Cin * a.w.K * outs;
   const double in_elems = (double)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T;

@@ -32,6 +32,8 @@ int launch_wn_dw(const float* g, const float* v, int C, int K, float* w, hipStre
 int launch_pad_time(const float* x, int rows, int T, int pad, float* y, hipStream_t st);
 int launch_dur_post(const float* d, const float* mask, int B, int NC, int L, float* out, hipStream_t st);
 int launch_rope(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, hipStream_t st);
+int launch_rope_copy(const float* qs, const float* ks, float* q, float* k, int B, int H, int DH, int L, int d,
+                     const float* theta4, hipStream_t st);
 int source_workspace_floats(int B, int T);
 int launch_source(int B, int T, const float* pitch, const float* voiced, const float* noise, uint64_t seed,
                   const float* lin_w, const float* lin_b, float* prior, float* ws, hipStream_t st);

@@ -216,6 +216,13 @@ struct Trainer {
     gmap[act] = g2;
     return g2;
   }
+  // the gradient of `act` IS the buffer g (act has exactly one consumer, whose backward produced g in place): no zero-fill,
+  // no accumulate pass.  false if act already has a gradient buffer (another consumer wrote first): the caller adds instead.
+  bool alias_grad(const float* act, float* g) {
+    if (gmap.count(act)) return false;
+    gmap[act] = g;
+    return true;
+  }
   const float* gbp(const AdaFc& a) const { return gb ? gb + a.off * B : nullptr; }
   float* dgbp(const AdaFc& a) const { return dgb ? dgb + a.off * B : nullptr; }
 
@@ -965,24 +972,23 @@ struct Trainer {
       // partial RoPE (out of place for the tape)
       float* qr = take<float>(n);
       float* kr = take<float>(n);
-      if (live()) {
-        hipError_t e = hipMemcpyAsync(qr, q, n * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(kr, k, n * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) rc = hip_fail(e, "rope copy");
-        chk(launch_rope(qr, kr, B, 8, H / 8, L, 8, t.theta, st));
-      }
+      if (live()) chk(launch_rope_copy(q, k, qr, kr, B, 8, H / 8, L, 8, t.theta, st));
       {
         const float* th = t.theta;
         tape.push_back([=]() {
           float* gqr = G(qr, n);
           float* gkr = G(kr, n);
-          float* gq = G(q, n);
-          float* gk = G(k, n);
-          if (live()) {
-            // transpose rotation in place on the (dead afterwards) rotated-tensor gradients, then accumulate
-            chk(launch_rope_signed(gqr, gkr, B, 8, H / 8, L, 8, th, -1.0f, st));
-            chk(launch_row_scale_add(gqr, nullptr, 1.0f, B * H, L, gq, st));
-            chk(launch_row_scale_add(gkr, nullptr, 1.0f, B * H, L, gk, st));
+          // transpose rotation in place on the (dead afterwards) rotated-tensor gradients.  q and k feed nothing but the
+          // rotation, so the rotated buffers ARE their gradients (two zero-fills and two accumulate passes per layer less
+          // on a chain whose every launch costs ~20 us of latency while the style encoder's backward holds the chip)
+          if (live()) chk(launch_rope_signed(gqr, gkr, B, 8, H / 8, L, 8, th, -1.0f, st));
+          if (!alias_grad(q, gqr)) {
+            float* gq = G(q, n);
+            if (live()) chk(launch_row_scale_add(gqr, nullptr, 1.0f, B * H, L, gq, st));
+          }
+          if (!alias_grad(k, gkr)) {
+            float* gk = G(k, n);
+            if (live()) chk(launch_row_scale_add(gkr, nullptr, 1.0f, B * H, L, gk, st));
           }
         });
       }
