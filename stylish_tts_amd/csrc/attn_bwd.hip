@@ -6,6 +6,8 @@
 //   B: dV[d][j] = sum_i p_ij dO[d][i],   dK[d][j] = scale * sum_i ds_ij q[d][i]
 //   C: dQ[d][i] = scale * sum_j ds_ij k[d][j],   with p_ij = exp(s_ij - lse_i), ds_ij = p_ij (dp_ij - delta_i),
 //      dp_ij = sum_d v[d][j] dO[d][i],  s_ij = scale q_i.k_j (+ -1e4 where i or j >= length).
+#include <stdlib.h>
+
 #include "sty_common.h"
 
 namespace sty {
@@ -341,6 +343,167 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnArgs a, const 
   }
 }
 
+
+// =====================================================================================================
+// One kernel for short sequences (T <= 128: the text encoder, L = 100 tokens, 8 heads x 16): a workgroup owns one (batch, head),
+// Q, K, V and dO (four [DH][T] tiles, 33 KB) sit in LDS, and the three passes of the kernels above run back to back on them --
+// A (row log-sum-exp, delta), C (dQ, threads along the query index), B (dK / dV, threads along the key index).  256 threads:
+// thread t works on index t & 127 and on half t >> 7 of the loop range, the two halves are combined through LDS in a
+// fixed order.  The three-kernel form took 57 + 36 + 85 us per layer alone (every operand of the inner loops a global load),
+// on the chain that ends the c3 step; gradients are ACCUMULATED as above.
+// =====================================================================================================
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
+                                                            float* __restrict__ dQ, size_t dqbs, float* __restrict__ dK,
+                                                            size_t dkbs, float* __restrict__ dV, size_t dvbs) {
+  constexpr int TP = 129;
+  __shared__ float qs[DH * TP], ks[DH * TP], vs[DH * TP], gs[DH * TP];
+  __shared__ float lse_s[128], del_s[128], pm_s[128], pl_s[128];
+  const int T = a.T, h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int r = tid & 127, half = tid >> 7;
+  const size_t ho = (size_t)h * DH * T;
+  const float* qb = a.q + (size_t)b * a.qbs + ho;
+  const float* kb = a.k + (size_t)b * a.kbs + ho;
+  const float* vb = a.v + (size_t)b * a.vbs + ho;
+  const float* gb = dO + (size_t)b * dobs + ho;
+  const float* ob = a.o + (size_t)b * a.obs + ho;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  for (int e = tid; e < DH * T; e += 256) {
+    const int d = e / T, t = e - d * T;
+    qs[d * TP + t] = qb[e] * a.scale;  // (pre-scaled, as attn_bwd_a / c do)
+    ks[d * TP + t] = kb[e];
+    vs[d * TP + t] = vb[e];
+    gs[d * TP + t] = gb[e];
+  }
+  __syncthreads();
+  const int per = (T + 1) / 2, lo = half * per, hi = min(T, lo + per);
+  const bool live = r < T;
+  const bool rpad = a.lengths && r >= len;
+  // ---- A: lse_i over all j (two partial (max, sum) pairs), delta_i ----
+  float q[DH], g[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    q[d] = live ? qs[d * TP + r] : 0.f;
+    g[d] = live ? gs[d * TP + r] : 0.f;
+  }
+  {
+    float m = -3.0e38f, l = 0.f;
+    if (live)
+      for (int j = lo; j < hi; ++j) {
+        float sv = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) sv = fmaf(q[d], ks[d * TP + j], sv);
+        if (a.lengths && (rpad || j >= len)) sv += -1e4f;
+        const float mn = fmaxf(m, sv);
+        l = l * expf(m - mn) + expf(sv - mn);
+        m = mn;
+      }
+    if (half == 1) {
+      pm_s[r] = m;
+      pl_s[r] = l;
+    } else if (live) {
+      float dl = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dl = fmaf(g[d], ob[(size_t)d * T + r], dl);
+      del_s[r] = dl;
+    }
+    __syncthreads();
+    if (half == 0 && live) {
+      const float m1 = pm_s[r], l1 = pl_s[r];
+      const float mn = fmaxf(m, m1);
+      lse_s[r] = mn + logf(l * expf(m - mn) + l1 * expf(m1 - mn));
+    }
+    __syncthreads();
+  }
+  const float inv_keep = DROP ? 1.0f / (1.0f - a.drop_p) : 1.f;
+  const unsigned rowbase = (unsigned)(b * a.H + h) * (unsigned)T;
+  // ---- C: dQ_i = scale sum_j ds_ij k_j ----
+  {
+    float acc[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+    if (live) {
+      const float L = lse_s[r], dl = del_s[r];
+      for (int j = lo; j < hi; ++j) {
+        float sv = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+          sv = fmaf(q[d], ks[d * TP + j], sv);
+          dp = fmaf(g[d], vs[d * TP + j], dp);
+        }
+        if (a.lengths && (rpad || j >= len)) sv += -1e4f;
+        if constexpr (DROP) {
+          const unsigned idx = (rowbase + (unsigned)r) * (unsigned)T + (unsigned)j;
+          dp = sty_hash_u(a.drop_seed, a.drop_site, idx) >= a.drop_p ? dp * inv_keep : 0.f;
+        }
+        const float ds = expf(sv - L) * (dp - dl);
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = fmaf(ds, ks[d * TP + j], acc[d]);
+      }
+    }
+    // the two halves are added channel by channel through pm_s (the four operand tiles are still needed by pass B)
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      __syncthreads();
+      if (half == 1) pm_s[r] = acc[d];
+      __syncthreads();
+      if (half == 0 && live) {
+        float* dq = dQ + (size_t)b * dqbs + ho;
+        dq[(size_t)d * T + r] += (acc[d] + pm_s[r]) * a.scale;
+      }
+    }
+  }
+  // ---- B: dV_j = sum_i pm_ij dO_i,  dK_j = scale sum_i ds_ij q_i  (threads along the key index) ----
+  {
+    float kk[DH], vv[DH], ak[DH], av[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      kk[d] = live ? ks[d * TP + r] : 0.f;
+      vv[d] = live ? vs[d * TP + r] : 0.f;
+      ak[d] = av[d] = 0.f;
+    }
+    if (live)
+      for (int i = lo; i < hi; ++i) {
+        float sv = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+          sv = fmaf(qs[d * TP + i], kk[d], sv);  // qs is pre-scaled
+          dp = fmaf(gs[d * TP + i], vv[d], dp);
+        }
+        if (a.lengths && (i >= len || rpad)) sv += -1e4f;
+        const float p = expf(sv - lse_s[i]);
+        float pm = p;
+        if constexpr (DROP) {
+          const unsigned idx = (rowbase + (unsigned)i) * (unsigned)T + (unsigned)r;
+          const float mf = sty_hash_u(a.drop_seed, a.drop_site, idx) >= a.drop_p ? inv_keep : 0.f;
+          pm = p * mf;
+          dp *= mf;
+        }
+        const float ds = p * (dp - del_s[i]);
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+          av[d] = fmaf(pm, gs[d * TP + i], av[d]);
+          ak[d] = fmaf(ds, qs[d * TP + i], ak[d]);  // pre-scaled q: the factor `scale` is already in
+        }
+      }
+    float* dk = dK + (size_t)b * dkbs + ho;
+    float* dv = dV + (size_t)b * dvbs + ho;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      __syncthreads();
+      if (half == 1) {
+        pm_s[r] = ak[d];
+        pl_s[r] = av[d];
+      }
+      __syncthreads();
+      if (half == 0 && live) {
+        dk[(size_t)d * T + r] += ak[d] + pm_s[r];
+        dv[(size_t)d * T + r] += av[d] + pl_s[r];
+      }
+    }
+  }
+}
+
 size_t attention_bwd_ws_floats(int B, int H, int T) { return (size_t)2 * B * H * T; }
 
 // gradients are ACCUMULATED into dQ / dK / dV
@@ -357,8 +520,19 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
     STY_LAUNCH_CHECK();
     return STY_OK;
   }
-  dim3 grid(cdiv(a.T, 64), a.H, B);
   const bool drop = a.drop_p > 0.f;
+  static const bool no_small = getenv("STY_NO_ATTN_BWD_SMALL") != nullptr;
+  if (DH == 16 && a.T <= 128 && !no_small) {  // the text encoder: one workgroup per (batch, head), everything in LDS
+    if (drop)
+      hipLaunchKernelGGL((attn_bwd_small_kernel<16, true>), dim3(a.H, B), dim3(256), 0, st, a, dO, dobs, dQ, dqbs, dK, dkbs, dV,
+                         dvbs);
+    else
+      hipLaunchKernelGGL((attn_bwd_small_kernel<16, false>), dim3(a.H, B), dim3(256), 0, st, a, dO, dobs, dQ, dqbs, dK, dkbs,
+                         dV, dvbs);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
+  dim3 grid(cdiv(a.T, 64), a.H, B);
 #define STY_ABWD(DHV, DR)                                                                                            \
   hipLaunchKernelGGL(attn_bwd_a_kernel<DHV>, grid, dim3(64), 0, st, a, dO, dobs, lse, delta);                        \
   if ((DHV) > 96) {                                                                                                  \
