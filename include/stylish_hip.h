@@ -241,6 +241,11 @@ int sty_vocoder_bwd(sty_model *m, const float *d_audio, float *d_mel, float *d_s
 int sty_speech_train_workspace_bytes(sty_model *m, int B, int L, int T, size_t *bytes);
 int sty_speech_fwd_train(sty_model *m, const sty_speech_io *io, void *workspace, size_t ws_bytes, void *stream);
 int sty_speech_bwd(sty_model *m, const float *d_audio, float *d_style, float *d_energy, void *stream);
+/* Optional: the weight-side half of the next sty_speech_fwd_train (weight-norm / packed weights, input-gradient packs, bf16
+ * fragments) issued on `stream` ahead of time -- after the optimizer step that produced the parameters (train/stage.py:
+ * 104-124 steps the optimizer at the end of train_batch); that forward (same stream, or ordered after this call) then
+ * skips it.  The parameters must not change in between (sty_model_invalidate cancels it).                              */
+int sty_speech_prepare_train(sty_model *m, void *stream);
 /* ... and d loss / d pitch [B,T] (the textual stage feeds the PREDICTED pitch and energy to the frozen speech predictor,
  * train/stage_type.py:139-160; the harmonic source and the voiced flag carry no gradient).  Any output may be NULL.   */
 int sty_speech_bwd_pe(sty_model *m, const float *d_audio, float *d_style, float *d_pitch, float *d_energy, void *stream);

@@ -123,6 +123,9 @@ class AcousticTrainer:
         import os
         self.early_target = os.environ.get("STY_NO_EARLY_TARGET") is None
         self._probe_on = os.environ.get("STY_STEP_PROBE") is not None
+        # (measured: the predictor's forward ends 0.25 ms earlier, the step does not -- the ~20 launches then compete with the
+        # two chains that end the previous step; off by default, STY_EARLY_PREPARE=1 turns it on)
+        self._early_prepare = os.environ.get("STY_EARLY_PREPARE") is not None
         self._probe_events, self._probe_last = [], None
         self._hooks = {}
         self._hook_error = None
@@ -215,6 +218,8 @@ class AcousticTrainer:
         voiced = (pitch > 20).float()
         # the target side of the loss features (three STFT resolutions of audio_gt) needs no forward pass: issued here, in
         # front of the predictor, its kernels run while the main stream would otherwise wait for the style encoder
+        # (the same call on the style encoder's stream, behind its forward, so that it runs beside the predictor's forward:
+        # measured, predictor forward done 0.12 ms earlier, step unchanged -- the work only moves)
         target = acoustic_loss_target(audio_gt) if self.early_target else None
         self._probe("target loss features done (main)", main)
         audio = self.sp.forward_train(texts, text_lengths, alignment, pitch, energy, voiced, style, pitch,
@@ -263,6 +268,8 @@ class AcousticTrainer:
             if self._hook_error is None:
                 world = gp.finish(average=False)
                 self.opt["speech_predictor"].step(grad_scale=1.0 / world)
+                if self._early_prepare:  # ... and the weight-side half of the NEXT step's predictor forward (~20 launches)
+                    self.sp.prepare_train(audio_gt.device)
             main.wait_stream(side)
         else:
             self.se.backward(d_style)

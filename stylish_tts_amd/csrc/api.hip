@@ -1648,10 +1648,29 @@ int sty_speech_fwd_train(sty_model* m, const sty_speech_io* io, void* workspace,
     set_error("sty_speech_fwd_train: bad argument");
     return STY_EINVAL;
   }
-  if ((rc = sty_model_prepare(m, stream))) return rc;
+  if (m->train_prepared) {  // done by sty_speech_prepare_train since the last optimizer step
+    m->train_prepared = false;
+  } else if ((rc = sty_model_prepare(m, stream))) {
+    return rc;
+  }
   m->prepared = false;  // a training step mutates buffers and is followed by an optimizer step: inference re-prepares
   if (!m->trainer) m->trainer = trainer_create(m);
   return trainer_speech_forward(m->trainer, io, workspace, ws_bytes, S(stream), nullptr);
+}
+// The weight-side half of the next sty_speech_fwd_train (packs, input-gradient packs, bf16 fragments: ~20 launches that depend
+// on the parameters only) ahead of time: AcousticTrainer issues it right after the predictor's AdamW step, while the style
+// encoder's backward still runs on its streams, so the next step's forward starts with the text encoder.
+int sty_speech_prepare_train(sty_model* m, void* stream) {
+  int rc = model_ready(m, "speech_predictor");
+  if (rc) return rc;
+  if (!m->train_enabled) {
+    set_error("training not enabled: call sty_model_enable_training / sty_model_bind_grad before finalize");
+    return STY_ESTATE;
+  }
+  m->train_prepared = false;
+  if ((rc = sty_model_prepare(m, stream))) return rc;
+  m->train_prepared = true;
+  return STY_OK;
 }
 
 int sty_speech_bwd(sty_model* m, const float* d_audio, float* d_style, float* d_energy, void* stream) {
@@ -2446,6 +2465,7 @@ int sty_attention_fwd_bwd(int B, int H, int DH, int T, const float* q, const flo
   at.H = H;
   at.scale = 1.0f / sqrtf((float)DH);
   at.lengths = lengths;
+  at.bf16 = getenv("STY_ATTN_UNIT_BF16") != nullptr;  // (read per call: the unit test of attn16.hip sets it)
   float* ws = static_cast<float*>(workspace);
   at.lse = ws;  // row log-sum-exp, kept for the MFMA backward
   float* w2 = ws + (size_t)B * H * T;

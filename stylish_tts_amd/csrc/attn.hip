@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 }
 
 int launch_attention(const AttnArgs& a, int B, int DH, hipStream_t st) {
+  if (attention16_eligible(a, DH)) return launch_attention16(a, B, st);
   dim3 grid(cdiv(a.T, 128), a.H, B);
   const bool drop = a.drop_p > 0.f;
   if (DH == 64 && !drop)

@@ -509,6 +509,8 @@ size_t attention_bwd_ws_floats(int B, int H, int T) { return (size_t)2 * B * H *
 // gradients are ACCUMULATED into dQ / dK / dV
 int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* dK, float* dV, size_t dqbs, size_t dkbs,
                          size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st) {
+  if (attention16_eligible(a, DH) && a.lse)
+    return launch_attention16_bwd(a, dO, dQ, dK, dV, dqbs, dkbs, dvbs, dobs, B, ws, st);
   float* lse = ws;
   float* delta = ws + (size_t)B * a.H * a.T;
   if (DH == 64 && a.lse && !a.lengths && a.drop_p <= 0.f) {  // matrix-core path; lse kept by the forward kernel

@@ -313,7 +313,13 @@ struct AttnArgs {
   float drop_p = 0.f;
   unsigned drop_seed = 0, drop_site = 0;
   float* lse = nullptr;  // optional [B][H][T]: log-sum-exp of every score row, kept for the MFMA backward
+  int bf16 = 0;          // bf16 compute mode: the contractions on v_mfma_f32_32x32x16_bf16 (attn16.hip; 8 x 64 heads, no mask)
 };
+// attn16.hip: the conformer's attention in the bf16 compute mode
+bool attention16_eligible(const AttnArgs& a, int DH);
+int launch_attention16(const AttnArgs& a, int B, hipStream_t st);
+int launch_attention16_bwd(const AttnArgs& a, const float* dO, float* dQ, float* dK, float* dV, size_t dqbs, size_t dkbs,
+                           size_t dvbs, size_t dobs, int B, float* ws, hipStream_t st);
 }  // namespace sty
 
 #ifdef __HIPCC__

@@ -868,6 +868,7 @@ struct Trainer {
     at.H = 8;
     at.scale = 1.0f / sqrtf((float)(inner / 8));
     at.lengths = nullptr;
+    at.bf16 = m->topts.compute_bf16;  // bf16 mode: the five contractions on the bf16 matrix cores (attn16.hip)
     at.lse = take<float>((size_t)B * 8 * Tt);  // row log-sum-exp, kept for the MFMA backward
     if (live()) chk(launch_attention(at, B, inner / 8, st));
     tape.push_back([=]() {

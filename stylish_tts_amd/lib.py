@@ -101,6 +101,7 @@ SYMBOLS = {
     "sty_speech_train_workspace_bytes": (C.c_int, [_P, _I, _I, _I, _SZP]),
     "sty_speech_fwd_train": (C.c_int, [_P, C.POINTER(SpeechIO), _P, C.c_size_t, _P]),
     "sty_speech_bwd": (C.c_int, [_P, _P, _P, _P, _P]),
+    "sty_speech_prepare_train": (C.c_int, [_P, _P]),
     "sty_speech_bwd_pe": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "sty_speech_d_style_ready": (C.c_int, [_P, _P]),
     "sty_style_train_workspace_bytes": (C.c_int, [_P, _I, _I, _SZP]),

@@ -516,6 +516,14 @@ class SpeechPredictor(_HipModule):
                                       L.ptr(gy), L.ptr(y), L.ptr(gx), L.ptr(d_style), L.ptr(ws), ws.numel(), st))
         return y, gx, d_style
 
+    def prepare_train(self, device):
+        """Optional: the weight-side half of the next forward_train (packed / weight-normed weights, input-gradient packs,
+        bf16 fragments) on the current stream, right after the optimizer step that produced the parameters
+        (sty_speech_prepare_train); the next forward_train then starts with the text encoder."""
+        self._train = True
+        lib = self._ensure(device)
+        L.check(lib.sty_speech_prepare_train(self._handle, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+
     def forward_train(self, texts, text_lengths, alignment, pitch, energy, voiced, style, denormal_pitch, *, noise=None,
                       seed=0, prior_override=None, style_stream=None):
         """SpeechPredictor.forward in the training graph (eval-mode statistics); follow with backward(d_audio).

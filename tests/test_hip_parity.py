@@ -411,6 +411,47 @@ def test_attention_backward_vs_float64(DH, T, masked):
     rep.done()
 
 
+@pytest.mark.parametrize("T", [160, 520])
+def test_attention_bf16_mode_vs_float64_on_rounded_operands(T, monkeypatch):
+    """attn16.hip (the conformer's attention in the bf16 compute mode: 8 x 64 heads, no mask; the five contractions on the
+    bf16 matrix cores, softmax statistics in fp32) through sty_attention_fwd_bwd with STY_ATTN_UNIT_BF16=1, against float64
+    softmax attention on the bf16-ROUNDED q, k, v, d o.  What is left between the two is the rounding of P and dS (2^-9 per
+    element, inside the kernels only): 1e-2 of the tensor scale; the same call without the switch (fp32 kernels) on the same
+    rounded inputs must sit 100 x closer to the float64 result, so a wrong fragment map cannot hide in the tolerance."""
+    from stylish_tts_amd import lib as L
+    lib = L.load()
+    B, H, DH = 2, 8, 64
+    g = torch.Generator().manual_seed(T)
+    q, k, v, do = (torch.randn(B, H * DH, T, generator=g).bfloat16().float() for _ in range(4))
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, H, DH, T).transpose(2, 3) for t in (q64, k64, v64))
+    o64 = (torch.softmax(qh @ kh.transpose(2, 3) / DH ** 0.5, dim=-1) @ vh).transpose(2, 3).reshape(B, H * DH, T)
+    (o64 * do.double()).sum().backward()
+    ref = dict(o=o64.detach().float(), dq=q64.grad.float(), dk=k64.grad.float(), dv=v64.grad.float())
+    need = C.c_size_t()
+    L.check(lib.sty_attention_workspace_bytes(B, H, T, C.byref(need)))
+    res = {}
+    for mode in ("fp32", "bf16"):
+        if mode == "bf16":
+            monkeypatch.setenv("STY_ATTN_UNIT_BF16", "1")
+        else:
+            monkeypatch.delenv("STY_ATTN_UNIT_BF16", raising=False)
+        ws = torch.empty(need.value, dtype=torch.uint8, device=DEV)
+        o, dq, dk, dv = (torch.empty(B, H * DH, T, device=DEV) for _ in range(4))
+        dq_, dk_, dv_, ddo = dev(q), dev(k), dev(v), dev(do)
+        L.check(lib.sty_attention_fwd_bwd(B, H, DH, T, L.ptr(dq_), L.ptr(dk_), L.ptr(dv_), None, L.ptr(ddo), L.ptr(o), L.ptr(dq),
+                                          L.ptr(dk), L.ptr(dv), L.ptr(ws), ws.numel(),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        res[mode] = dict(o=o.cpu(), dq=dq.cpu(), dk=dk.cpu(), dv=dv.cpu())
+    rep = Report()
+    for kx in ("o", "dq", "dk", "dv"):
+        rep.add(f"fp32 kernels {kx}", res["fp32"][kx], ref[kx], 1e-4)
+        rep.add(f"bf16 kernels {kx}", res["bf16"][kx], ref[kx], 1e-2)
+    rep.done()
+    assert not torch.equal(res["fp32"]["o"], res["bf16"]["o"])  # the bf16 kernels really ran
+
+
 def test_alignment(env):
     from oracle import frontend
     from stylish_tts_amd import lib as L
@@ -1296,7 +1337,10 @@ def test_grouped_weight_gradient_reduction_equals_the_per_launch_reductions(env,
         same = (a[1] == b[1]).float().mean().item()
         print(f"\n  {'single' if single else 'four'}-stream, {compute}: grouped vs per-launch reductions: gradient relative L2 "
               f"{rel:.3e}, {100 * same:.3f} % of the elements bit-equal, losses {a[0].tolist()} / {b[0].tolist()}")
-        assert rel <= 1e-6 and torch.allclose(a[0], b[0], rtol=1e-6, atol=0)
+        # the compared gradients are those of the SECOND step: the first step's float-atomic sum (pool_fc) differs in the last
+        # bit between any two runs, AdamW carries that into the parameters, and in the bf16 mode a last-bit difference of an
+        # operand flips bf16 roundings downstream (measured 0 ... 4e-6 between runs of the same configuration)
+        assert rel <= (3e-5 if compute == "bf16" else 1e-6) and torch.allclose(a[0], b[0], rtol=1e-6, atol=0)
 
 
 def test_acoustic_training_reduces_loss(env):

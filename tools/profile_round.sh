@@ -52,6 +52,20 @@ python bench.py --workload c3-gan --steps 5 --warmup 2 --no-cpu-baseline --no-ex
 python bench.py --workload c2-gan --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/${tag}_bench_c2_gan.json 2>/dev/null
 python bench.py --workload c3-textual --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/${tag}_bench_c3_textual.json 2>/dev/null
 python bench.py --workload c3-duration --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/${tag}_bench_c3_duration.json 2>/dev/null
+# the phases of one c3 / c2 step UNTRACED (device time stamps on the streams: the tracer serialises the two encoders)
+for wl in c3 c2; do
+  STY_STEP_PROBE=1 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 8 --warmup 3 2>/dev/null | python -c '
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(sys.argv[1], "step", round(d["ms_per_step"], 3), "ms; device time stamps of one step (ms since its first launch):")
+for n, t in d.get("phases_ms", []): print(f"{t:9.3f}  {n}")
+' $wl >> $O/${tag}_c3_phases.txt
+done
+# the c3 step serialised (style encoder on the main stream, weight-gradient streams off): every kernel alone on the chip
+( cd /tmp && STY_NO_SIDE_STREAM=1 STY_NO_SE_STREAM=1 rocprofv3 --kernel-trace --stats -d $O/serial_trace -- $B --steps 6 --warmup 2 > /dev/null 2> $O/serial_trace.log )
+python tools/rocpd_summary.py $O/serial_trace/*/*_results.db > $O/${tag}_c3_serial_kernel_stats.txt
+rm -rf $O/serial_trace
+bash tools/probes/fft_variants.sh > $O/${tag}_fft_variants.txt 2>&1
 python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/buffer_offset_probe.hip -o /tmp/buffer_offset_probe 2>/dev/null && /tmp/buffer_offset_probe > $O/${tag}_buffer_offset_probe.txt
