@@ -445,7 +445,8 @@ int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, i
                        const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
                        float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st) {
   static const bool noreg = getenv("STY_NO_LN_BWD_REG") != nullptr;
-  if ((size_t)B * T < 65536 && C <= 256 && !noreg)
+  static const bool regall = getenv("STY_LN_BWD_REG_ALL") != nullptr;  // experiment: the register form for the long rows too
+  if (((size_t)B * T < 65536 || regall) && C <= 256 && !noreg)
     hipLaunchKernelGGL((chan_ln_bwd_dx_reg_kernel<16, 16>), dim3(cdiv(T, 16), B), dim3(256), 0, st, x, dy, y, C, T, eps, ada, w,
                        gb, relu, out_mask, dx, accumulate, mu_tmp, r_tmp);
   else if ((size_t)B * T >= 65536)
@@ -1171,12 +1172,33 @@ __global__ __launch_bounds__(256) void style_fc_bwd_kernel(const StyleFcBwdDesc*
   if (dstyle) {
     // d style[b][k] += sum_j dgb[b][j] W[j][k]: one wave per (b, slice of j), lanes along k (style_dim <= 64)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (four independent chains, eight loads in flight: the one-chain form was 2 048 dependent load -> fma steps on the
+    // widest layer, 0.27 ms alone, and this kernel is the last thing in front of d loss / d style)
     for (int b = wave; b < B; b += 4) {
-      float acc = 0.f;
-      if (lane < style_dim)
-        for (int j = blockIdx.y; j < d.n; j += SFC_SLICES)
-          acc = fmaf(dgb[(size_t)b * d.n + j], d.W[(size_t)j * style_dim + lane], acc);
-      if (lane < style_dim) atomicAdd(&dstyle[(size_t)b * style_dim + lane], acc);
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      if (lane < style_dim) {
+        const float* gr = dgb + (size_t)b * d.n;
+        const float* wr = d.W + lane;
+        int j = blockIdx.y;
+        for (; j + 7 * SFC_SLICES < d.n; j += 8 * SFC_SLICES) {
+          float g[8], w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            g[u] = gr[j + u * SFC_SLICES];
+            w[u] = wr[(size_t)(j + u * SFC_SLICES) * style_dim];
+          }
+          acc0 = fmaf(g[0], w[0], acc0);
+          acc1 = fmaf(g[1], w[1], acc1);
+          acc2 = fmaf(g[2], w[2], acc2);
+          acc3 = fmaf(g[3], w[3], acc3);
+          acc0 = fmaf(g[4], w[4], acc0);
+          acc1 = fmaf(g[5], w[5], acc1);
+          acc2 = fmaf(g[6], w[6], acc2);
+          acc3 = fmaf(g[7], w[7], acc3);
+        }
+        for (; j < d.n; j += SFC_SLICES) acc0 = fmaf(gr[j], wr[(size_t)j * style_dim], acc0);
+        atomicAdd(&dstyle[(size_t)b * style_dim + lane], (acc0 + acc1) + (acc2 + acc3));
+      }
     }
   }
 }
@@ -1242,19 +1264,21 @@ __global__ __launch_bounds__(256) void istft64_bwd_kernel(const float* __restric
       const int bin = (r & 3) + 8 * (r >> 2) + 4 * hi;
       const size_t o = ((size_t)b * 32 + bin) * F + fs;
       const float re = real[o], im = imag[o];
-      const float ph = atan2f(im, re), mag = expf(logamp[o]);
-      const float c = cosf(ph), s = sinf(ph);
+      const float mag = expf(logamp[o]);
+      float c, s;
+      sty_unit_vec(re, im, c, s);
       const float gc = dc[r], gs = -dsn[r];
       const float dla = (gc * c + gs * s) * mag;
       const float dph = mag * (-gc * s + gs * c);
       const float h2 = re * re + im * im;
       const float dre = h2 > 0.f ? dph * (-im / h2) : 0.f, dim_ = h2 > 0.f ? dph * (re / h2) : 0.f;
-      if (f < F) {
-        // frame F-1 also receives frame F's share: accumulate, buffers are pre-zeroed by the caller
-        atomicAdd(&dlogamp[o], dla);
-        atomicAdd(&dreal[o], dre);
-        atomicAdd(&dimag[o], dim_);
+      if (f < F - 1) {  // the only writer of its element
+        dlogamp[o] = dla;
+        dreal[o] = dre;
+        dimag[o] = dim_;
       } else {
+        // frame F-1 also receives frame F's share (the replicate pad): two writers, the launcher zeroed the element; the sum
+        // of two values onto zero does not depend on their order
         atomicAdd(&dlogamp[o], dla);
         atomicAdd(&dreal[o], dre);
         atomicAdd(&dimag[o], dim_);
@@ -1262,13 +1286,19 @@ __global__ __launch_bounds__(256) void istft64_bwd_kernel(const float* __restric
     }
   }
 }
+__global__ void istft64_zero_last_kernel(int rows, int F, float* __restrict__ a, float* __restrict__ b, float* __restrict__ c) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const size_t o = (size_t)r * F + F - 1;
+  a[o] = 0.f;
+  b[o] = 0.f;
+  c[o] = 0.f;
+}
 int launch_istft64_bwd(int B, int F, const float* audio, const float* daudio, const float* logamp, const float* real,
                        const float* imag, const float* bbr, const float* bbi, float* dlogamp, float* dreal,
                        float* dimag, hipStream_t st) {
-  const size_t n = (size_t)B * 32 * F * sizeof(float);
-  STY_HIP(hipMemsetAsync(dlogamp, 0, n, st));
-  STY_HIP(hipMemsetAsync(dreal, 0, n, st));
-  STY_HIP(hipMemsetAsync(dimag, 0, n, st));
+  // (three 160 MB zero-fills and an atomic per element before: only the last frame of every row has two writers)
+  hipLaunchKernelGGL(istft64_zero_last_kernel, dim3(cdiv(B * 32, 256)), dim3(256), 0, st, B * 32, F, dlogamp, dreal, dimag);
   hipLaunchKernelGGL(istft64_bwd_kernel, dim3(cdiv(F + 1, 128), B), dim3(256), 0, st, audio, daudio, logamp, real, imag,
                      bbr, bbi, F, dlogamp, dreal, dimag);
   STY_LAUNCH_CHECK();

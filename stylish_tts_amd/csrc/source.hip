@@ -204,10 +204,10 @@ __global__ __launch_bounds__(256) void istft64_kernel(const float* __restrict__ 
     if (f >= 0 && f <= F) {
       const int fs = f < F ? f : F - 1;  // replicate pad of the last frame
       const size_t o = ((size_t)b * 32 + bin) * F + fs;
-      const float ph = atan2f(imag[o], real[o]);
       const float mag = expf(logamp[o]);
-      c = mag * cosf(ph);
-      s = mag * sinf(ph);
+      sty_unit_vec(real[o], imag[o], c, s);
+      c *= mag;
+      s *= mag;
     }
     mc[e] = c;
     ms[e] = s;

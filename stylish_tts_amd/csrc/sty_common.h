@@ -335,6 +335,21 @@ __device__ __forceinline__ float sty_hash_u(unsigned seed, unsigned site, unsign
   x ^= x >> 16;
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
+// (cos, sin) of atan2(im, re) without the angle: the unit vector of (re, im); atan2(0, 0) = 0 -> (1, 0).  The synthesis head
+// (generator.py:782-799: exp(logamp) * (cos, sin)(atan2(imag, real))) evaluated atan2f + cosf + sinf per element of the
+// [B][32][75T] spectrum in both directions
+__device__ __forceinline__ void sty_unit_vec(float re, float im, float& c, float& s) {
+  const float h2 = re * re + im * im;
+  if (h2 > 0.f && h2 < 3.0e38f) {
+    const float r = 1.0f / sqrtf(h2);
+    c = re * r;
+    s = im * r;
+  } else {  // zero vector, or an overflowing / non-finite one: the library's own answer
+    const float ph = atan2f(im, re);
+    c = cosf(ph);
+    s = sinf(ph);
+  }
+}
 // sin(x) to ~1 ulp for |x| <= 8192 (3-constant Cody-Waite reduction by pi/2 + cephes minimax polynomials, ~20 VALU);
 // beyond that the library sinf (Payne-Hanek).  The Snake activations evaluate this 256x per 75T-rate position
 // per ConvNeXt block, where ocml's sinf with its huge-argument path costs about 3x more.
