@@ -1826,6 +1826,57 @@ def test_style_encoder_prepare_train_then_forward_matches_reference_golden():
     assert not torch.equal(u1, se.state_dict()["shared.0.weight_u"])
 
 
+def test_speech_predictor_prepare_train_then_forward_equals_the_plain_forward(env):
+    """sty_speech_prepare_train (the weight-side half of the predictor's training forward issued ahead of time, here on
+    another stream) followed by forward_train + backward: the audio equals that of a model that prepares inside
+    forward_train bit for bit, d style and every parameter gradient to 1e-5 (float-atomic sums); a second forward_train
+    without the call prepares itself again (the flag is consumed), and a parameter change after prepare_train cancels it."""
+    import stylish_tts_amd as S
+    cs, ali = env["cs"], env["ali"]
+
+    def run(early):
+        m = S.SpeechPredictor()
+        m.load_state_dict({k: v.clone() for k, v in env["P"].items()}, strict=False)
+        m = m.to(DEV).enable_training()
+        args = (dev(cs["texts"]), dev(cs["text_lengths"]), dev(ali), dev(cs["pitch"]), dev(cs["energy"]), dev(env["voiced"]),
+                dev(cs["style"]), dev(cs["pitch"]))
+        a0 = m.forward_train(*args, noise=dev(cs["noise"]))          # builds the plan, leaves the model "stale"
+        m.backward(torch.sign(a0) / a0.numel(), want_energy=False)
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        if early:
+            side = torch.cuda.Stream(device=DEV)
+            side.wait_stream(torch.cuda.current_stream(DEV))
+            with torch.cuda.stream(side):
+                m.prepare_train(DEV)
+            torch.cuda.current_stream(DEV).wait_stream(side)
+        audio = m.forward_train(*args, noise=dev(cs["noise"]))
+        d_style, _ = m.backward(torch.sign(audio) / audio.numel(), want_energy=False)
+        torch.cuda.synchronize()
+        return audio.cpu(), d_style.cpu(), {k: p.grad.cpu().clone() for k, p in m.named_parameters() if p.grad is not None}, m
+
+    a1, s1, g1, _ = run(False)
+    a2, s2, g2, m = run(True)
+    assert torch.equal(a1, a2)  # same prepared weights -> the same forward, bit for bit
+    # the backward holds float-atomic sums (d style over the style projections, Snake alpha, GRN gamma): two runs of the
+    # SAME configuration differ in the last bit there, so the gradients are compared at 1e-5 of their scale
+    assert rel_err(s2, s1) <= 1e-5
+    assert g1.keys() == g2.keys() and len(g1) > 100
+    for k in g1:
+        assert rel_err(g2[k], g1[k]) <= 1e-5, (k, rel_err(g2[k], g1[k]))
+    # a parameter change after prepare_train must not be lost: load_state_dict bumps the version counters -> invalidate
+    m.prepare_train(DEV)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    k0 = "text_encoder.prenet.conv_layers.0.weight"  # a PACKED weight: a stale pack would reproduce a2
+    sd[k0] = sd[k0] * 1.5
+    m.load_state_dict(sd, strict=False)
+    a3 = m.forward_train(dev(cs["texts"]), dev(cs["text_lengths"]), dev(ali), dev(cs["pitch"]), dev(cs["energy"]),
+                         dev(env["voiced"]), dev(cs["style"]), dev(cs["pitch"]), noise=dev(cs["noise"]))
+    torch.cuda.synchronize()
+    assert not torch.equal(a3.cpu(), a2)
+
+
 def test_speech_predictor_dropout_vs_patched_reference_golden(env):
     """Dropout on the HIP path (counter-based hash masks in the TextEncoder: prenet, attention probabilities inside the
     MFMA attention kernel and its backward, post-attention, FFN) vs the REFERENCE run in .train() with F.dropout / SDPA
