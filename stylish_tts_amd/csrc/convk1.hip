@@ -47,23 +47,29 @@ __global__ __launch_bounds__(256, 2) void convk1_kernel(ConvArgs a, int tiles_pe
   // time tile (adjacent tile numbers) re-read its input from ONE L2
   const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (tile >= ntiles) return;
-  const int cot = tile % ncot, rr = tile / ncot;
-  const int b = rr / tiles_per_row, t0 = (rr - b * tiles_per_row) * 128;
+  // K = 1 has no halo, so the 128 columns of a tile are taken from the FLATTENED (batch, time) axis: T = 520 is 4 x 128 + 8, a
+  // tile grid per batch row made every fifth tile 94 % empty (160 tiles per cout tile at c3 instead of 130).  T % 4 == 0, so a
+  // thread's four consecutive columns never straddle two utterances; b / t are per thread.
+  const int cot = tile % ncot, n0 = (tile / ncot) * 128;
   const int T = a.T, Cin = a.w.Cin, Cout = a.w.Cout;
+  const int NT = a.B * T;  // flattened columns
   const int nch = a.w.CinP / G_KC;  // (CinP is a multiple of 64)
   const int NMB = a.w.CoutP / 32;
 
   // ---- staging: thread = (row r0 + 8 i, four columns 4 cg ..) ----
   const int cg = tid & 31, r0 = tid >> 5;
   const __amdgpu_buffer_rsrc_t rx =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x[0] + (size_t)b * Cin * T), 0, Cin * T * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x[0]), 0, (unsigned)((size_t)a.B * Cin * T * 4), 0x00020000);
+  const int ns = n0 + 4 * cg;                      // this thread's first column
+  const int b = ns < NT ? ns / T : 0, ts = ns - b * T;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.w.wf), 0, a.w.CinP * a.w.CoutP * 2, 0x00020000);
-  const int xoff = (r0 * T + t0 + 4 * cg) * 4;  // + (chunk * 64 + 8 i) * T * 4
+  // (columns past the end: an offset outside the descriptor, the load returns zeros)
+  const int xoff = ns < NT ? ((b * Cin + r0) * T + ts) * 4 : 0x7FFFFF00;  // + (chunk * 64 + 8 i) * T * 4
   float mk[4] = {1.f, 1.f, 1.f, 1.f};
   if constexpr (PRO == PRO_MASK) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) mk[e] = t0 + 4 * cg + e < T ? a.mask[(size_t)b * T + t0 + 4 * cg + e] : 0.f;
+    for (int e = 0; e < 4; ++e) mk[e] = ns < NT ? a.mask[(size_t)ns + e] : 0.f;  // [B][T] is the flattened axis
   }
   float4 xv[8];
   float pa[8];
@@ -71,7 +77,10 @@ __global__ __launch_bounds__(256, 2) void convk1_kernel(ConvArgs a, int tiles_pe
   auto issue = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      xv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + (c * G_KC + 8 * i) * T * 4, 0, 0));
+      // rows past Cin of the last chunk: a row offset would land in the next utterance's channels, so they are zeroed here
+      xv[i] = c * G_KC + r0 + 8 * i < Cin
+                  ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + (c * G_KC + 8 * i) * T * 4, 0, 0))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (PRO == PRO_SCALE) {
         const int ci = c * G_KC + r0 + 8 * i;
         pa[i] = ci < Cin ? a.pa[(size_t)b * Cin + ci] : 0.f;
@@ -168,16 +177,19 @@ __global__ __launch_bounds__(256, 2) void convk1_kernel(ConvArgs a, int tiles_pe
   // past its end, never across.
   __syncthreads();  // every wave is done with the operand tiles: their LDS is the stage now
   float* stg = reinterpret_cast<float*>(g_lds) + wave * 32 * 68;
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * Cout * T, 0, Cout * T * 4, 0x00020000);
+  const unsigned ybytes = (unsigned)((size_t)a.B * Cout * T * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.residual ? a.residual + (size_t)b * Cout * T : a.y), 0, a.residual ? Cout * T * 4 : 0, 0x00020000);
+      const_cast<float*>(a.residual ? a.residual : a.y), 0, a.residual ? ybytes : 0, 0x00020000);
   const bool post = a.out_mask && a.out_mask_post;
   const int c4 = lane & 15, rq = lane >> 4;  // this lane's four columns 4 c4 .. and row rq + 4 i of the stage
-  const int tq = t0 + wn * 64 + 4 * c4;
+  const int nq = n0 + wn * 64 + 4 * c4;      // flattened column; (utterance, time) of the four
+  const bool qin = nq < NT;
+  const int bq = qin ? nq / T : 0, tq = nq - bq * T;
   float om[4] = {1.f, 1.f, 1.f, 1.f};
-  if (a.out_mask && tq < T) {
+  if (a.out_mask && qin) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) om[e] = a.out_mask[(size_t)b * T + tq + e];
+    for (int e = 0; e < 4; ++e) om[e] = a.out_mask[(size_t)nq + e];
   }
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -190,12 +202,13 @@ __global__ __launch_bounds__(256, 2) void convk1_kernel(ConvArgs a, int tiles_pe
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = rq + 4 * i, co = cobase + row;
-      if (co < Cout && tq < T) {
+      if (co < Cout && qin) {
+        const int yo = ((bq * Cout + co) * T + tq) * 4;
         const float4 sv = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * c4);
         const float bi = a.w.bias ? a.w.bias[co] : 0.f;
         float v[4] = {sv.x + bi, sv.y + bi, sv.z + bi, sv.w + bi};
         float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.residual) res = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rres, (co * T + tq) * 4, 0, 0));
+        if (a.residual) res = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rres, yo, 0, 0));
         const float rr[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void convk1_kernel(ConvArgs a, int tiles_pe
         }
         const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
         __builtin_amdgcn_raw_buffer_store_b128(
-            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o4), ry, (co * T + tq) * 4, 0, 0);
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o4), ry, yo, 0, 0);
       }
     }
     __syncthreads();
@@ -222,9 +235,10 @@ bool convk1_eligible(const ConvArgs& a) {
   if (!(a.act == ACT_NONE || a.act == ACT_RELU)) return false;
   if (!(a.pro == PRO_NONE || a.pro == PRO_MASK || a.pro == PRO_SCALE)) return false;
   if (a.T % 4 || a.w.CinP % G_KC || a.w.CinP < 64 || a.w.CoutP < 64) return false;
-  if ((size_t)a.w.Cin * a.T * 4 >= (size_t)1 << 31 || (size_t)a.w.Cout * a.T * 4 >= (size_t)1 << 31) return false;
+  // one buffer descriptor over the whole tensor, 31-bit byte offsets
+  if ((size_t)a.B * a.w.CinP * a.T * 4 >= (size_t)1 << 31 || (size_t)a.B * a.w.CoutP * a.T * 4 >= (size_t)1 << 31) return false;
   const char* mt = getenv("STY_CONVK1_MIN_TILES");  // read per call: the parity tests lower it for small shapes
-  return (long)cdiv(a.T, 128) * a.B * cdiv(a.w.CoutP, 128) >= (mt ? atoi(mt) : 256);
+  return (long)cdiv(a.B * a.T, 128) * cdiv(a.w.CoutP, 128) >= (mt ? atoi(mt) : 256);
 }
 
 template <int PRO>
@@ -239,8 +253,8 @@ int launch_convk1(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   int rc = convp16_frags(a0, st, &a.w.wf);
   if (rc) return rc;
-  const int tpr = cdiv(a.T, 128), ncot = cdiv(a.w.CoutP, 128);
-  const int ntiles = tpr * a.B * ncot, per = cdiv(ntiles, 8);
+  const int tpr = cdiv(a.B * a.T, 128), ncot = cdiv(a.w.CoutP, 128);  // column tiles over the flattened (batch, time) axis
+  const int ntiles = tpr * ncot, per = cdiv(ntiles, 8);
   const size_t lds = (size_t)2 * G_KC * G_PITCH * sizeof(__bf16);
   const double outs = (double)a.B * a.w.Cout * a.T;
   char detail[40];
