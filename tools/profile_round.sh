@@ -66,6 +66,8 @@ done
 python tools/rocpd_summary.py $O/serial_trace/*/*_results.db > $O/${tag}_c3_serial_kernel_stats.txt
 rm -rf $O/serial_trace
 bash tools/probes/fft_variants.sh > $O/${tag}_fft_variants.txt 2>&1
+# matrix-pipe utilisation counters (SQ_VALU_MFMA_BUSY_CYCLES) of the serialised c3 step -> gpurun_out/pmc_mfma/${tag}_c3_pmc_mfma.txt
+bash tools/pmc_mfma.sh $tag; cp $R/gpurun_out/pmc_mfma/${tag}_c3_pmc_mfma.txt $O/ 2>/dev/null
 python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/buffer_offset_probe.hip -o /tmp/buffer_offset_probe 2>/dev/null && /tmp/buffer_offset_probe > $O/${tag}_buffer_offset_probe.txt
