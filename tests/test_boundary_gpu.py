@@ -23,6 +23,16 @@ G = os.path.join(ROOT, "tests", "golden")
 DEV = "cuda:0"
 
 
+
+def _free_port():
+    """a TCP port nobody listens on right now (fixed numbers collide with rendezvous sockets lingering from earlier tests)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
 def dev(t):
     return t.to(DEV)
 
@@ -224,7 +234,7 @@ def test_two_rank_hip_gradients_equal_one_rank_on_the_concatenated_batch(tmp_pat
                         cwd=ROOT)
     assert r1.returncode == 0, r1.stderr[-2000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", "29519", worker, out + "_2.pt"],
+                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, out + "_2.pt"],
                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r2.returncode == 0, r2.stderr[-2000:]
     g1, g2 = torch.load(out + "_1.pt"), torch.load(out + "_2.pt")
@@ -246,7 +256,7 @@ def test_rccl_world1_step_equals_the_step_without_a_process_group(tmp_path):
     is summed with float atomics in both runs); then three real optimizer steps: finite, moved, by the same amount."""
     worker = os.path.join(ROOT, "tests", "rccl_world1_worker.py")
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = {}
     for mode in ("plain", "rccl"):
         env = dict(base)

@@ -1932,8 +1932,19 @@ def test_training_from_sample_dataset_files(tmp_path, env):
     assert seen == len(lines)
 
 
-@pytest.mark.parametrize("workload,port", [("c2", 29517), ("c2-gan", 29518)])
-def test_bench_two_ranks_on_one_device(workload, port):
+def _free_port():
+    """a TCP port nobody listens on right now (a fixed number collides with a rendezvous socket still lingering from an
+    earlier two-rank test of the same session)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("workload", ["c2", "c2-gan"])
+def test_bench_two_ranks_on_one_device(workload):
     """The N > 1 path of bench.py end to end (torchrun, utterance sharding, bucketed gradient all-reduce, max-over-ranks
     timing, one JSON line on rank 0) with both ranks on device 0 and gloo as the transport (STY_BENCH_SHARE_DEVICE=1);
     c2-gan: the same with the discriminators' gradient buckets and optimizer steps in the exchange."""
@@ -1942,7 +1953,7 @@ def test_bench_two_ranks_on_one_device(workload, port):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, STY_BENCH_SHARE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", workload],
                        capture_output=True, text=True, env=env, timeout=600, cwd=root)
     errs = [ln for ln in r.stderr.splitlines() if "Error" in ln or "error" in ln or "assert" in ln.lower()]

@@ -1,16 +1,2 @@
-python -m pytest tests/test_hip_parity.py -q -k "attention_bf16 or acoustic_train_step_bf16 or vocoder_bf16" 2>&1 | grep -v "^$" | tail -8 > gpurun_out/t_fix.log
-python -m pytest tests/test_full_size.py -q -k "c3" 2>&1 | grep -v "^$" | tail -4 >> gpurun_out/t_fix.log
-run() { # name, wl, env...
-  n=$1; wl=$2; shift 2
-  env "$@" STY_STEP_PROBE=1 python bench.py --no-cpu-baseline --no-extra --steps 8 --warmup 3 --workload $wl 2>gpurun_out/phase_err.txt | python -c '
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(sys.argv[1], d["ms_per_step"])
-for n,t in d.get("phases_ms",[]): print(f"{t:9.3f}  {n}")
-' $n >> gpurun_out/phases.txt 2>&1
-}
-: > gpurun_out/phases.txt
-run c3 c3 X=1
-run c3b c3 X=1
-run c3c c3 X=1
+python -m pytest tests/test_hip_parity.py tests/test_boundary_gpu.py -q -k "bench_two_ranks or bench_gpus_flag or two_rank or rccl" 2>&1 | grep -v "^$" | tail -12 > gpurun_out/t_fix.log
 echo done
