@@ -1,2 +1,9 @@
-python -m pytest tests/test_hip_parity.py tests/test_boundary_gpu.py -q -k "bench_two_ranks or bench_gpus_flag or two_rank or rccl" 2>&1 | grep -v "^$" | tail -12 > gpurun_out/t_fix.log
+python tools/soak.py 300 > gpurun_out/soak.txt 2>&1
+python - <<'PY' >> gpurun_out/soak.txt 2>&1
+# 300 consecutive c3 steps (bf16 mode, train mode): time and finiteness
+import os, time, json, subprocess, sys
+r = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-extra", "--steps", "300", "--warmup", "5"], capture_output=True, text=True)
+d = json.loads(r.stdout.strip().splitlines()[-1])
+print("c3 300 steps:", d["ms_per_step"], "ms/step", d["value"], "frames/s")
+PY
 echo done
