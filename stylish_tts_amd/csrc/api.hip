@@ -1948,23 +1948,25 @@ int sty_model_prepare(sty_model* m, void* stream) {
     int r = launch_multi(0, m->mj_dev[0], m->mj_blk_dev[0], m->mj_nblk[0], st);
     if (r != STY_OK) return r;
   }
-  for (const PackJob& j : m->jobs) {
-    int r = STY_OK;
-    switch (j.kind) {
-      case PK_DGRAD:
-      case PK_DGRAD2D:
-        break;  // batched below (table 1, after the spectral-norm packs it reads)
-      case PK_CONV:
-      case PK_CONV_WN:
-      case PK_CONV_GLU:
-        break;  // batched above
-      case PK_W2A:
-        r = launch_pack_w2a(j.w, j.bias, j.extra, j.Cout, j.wp, j.bp, st);
-        break;
-      case PK_CONV2D_SN:
-      case PK_DW2D_SN:
-        break;  // batched below (table 4)
+  {  // the pwconv2 fragment packs of the fused ConvNeXt blocks: one launch per W2A_MAXJ blocks (every other kind is batched
+     // through the device-side job tables above / below)
+    W2aJobs wj;
+    for (const PackJob& j : m->jobs) {
+      if (j.kind != PK_W2A) continue;
+      const int k = wj.n++;
+      wj.w2[k] = j.w;
+      wj.b2[k] = j.bias;
+      wj.gb[k] = j.extra;
+      wj.w2a[k] = j.wp;
+      wj.b2eff[k] = j.bp;
+      wj.C[k] = j.Cout;
+      if (wj.n == W2A_MAXJ) {
+        int r = launch_pack_w2a_multi(wj, st);
+        if (r != STY_OK) return r;
+        wj.n = 0;
+      }
     }
+    int r = launch_pack_w2a_multi(wj, st);
     if (r != STY_OK) return r;
   }
   {  // sigma and W / sigma of every spectral-norm layer: two launches

@@ -307,6 +307,43 @@ __global__ __launch_bounds__(64) void b2eff_kernel(const float* __restrict__ w2,
   if (lane == 0) b2eff[co] = b2[co] + acc;
 }
 
+// the same two kernels for up to W2A_MAXJ blocks in ONE launch (the job list travels as a kernel argument): sixteen ConvNeXt
+// blocks made 32 launches of a few microseconds at the head of every training step's forward
+__global__ __launch_bounds__(256) void pack_w2a_multi_kernel(W2aJobs jobs) {
+  const int j = blockIdx.y;
+  const int C = jobs.C[j], C4 = 4 * C;
+  const float* w2 = jobs.w2[j];
+  const int npack = (C4 * C + 255) / 256;  // blocks that do the fragment pack; the next C / 4 blocks the b2eff rows
+  if ((int)blockIdx.x < npack) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < C4 * C) {
+      const int co = i % C, rest = i / C;
+      const int hi = rest & 1, q = (rest >> 1) & 15, jj = rest >> 5;
+      const int ch = 32 * jj + (q & 3) + 8 * (q >> 2) + 4 * hi;
+      jobs.w2a[j][i] = w2[(size_t)co * C4 + ch];
+    }
+    return;
+  }
+  const int co = ((int)blockIdx.x - npack) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // a wave per output channel
+  if (co >= C) return;
+  const float* gb = jobs.gb[j];
+  float acc = 0.f;
+  for (int ch = lane; ch < C4; ch += 64) acc = fmaf(w2[(size_t)co * C4 + ch], gb[ch], acc);  // (b2eff_kernel's order)
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) jobs.b2eff[j][co] = jobs.b2[j][co] + acc;
+}
+int launch_pack_w2a_multi(const W2aJobs& jobs, hipStream_t st) {
+  if (jobs.n <= 0) return STY_OK;
+  int maxb = 0;
+  for (int j = 0; j < jobs.n; ++j) {
+    const int C = jobs.C[j], nb = (4 * C * C + 255) / 256 + (C + 3) / 4;
+    maxb = nb > maxb ? nb : maxb;
+  }
+  hipLaunchKernelGGL(pack_w2a_multi_kernel, dim3(maxb, jobs.n), dim3(256), 0, st, jobs);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 int launch_pack_w2a(const float* w2, const float* b2, const float* grn_beta, int C, float* w2a, float* b2eff,
                     hipStream_t st) {
   hipLaunchKernelGGL(pack_w2a_kernel, dim3(cdiv(4 * C * C, 256)), dim3(256), 0, st, w2, b2, grn_beta, C, w2a, b2eff);

@@ -299,6 +299,17 @@ int launch_cnx_dalpha(const float* w1raw, const float* b1, const float* alpha, c
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st);
 int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mode, float* out, hipStream_t st);
 
+constexpr int W2A_MAXJ = 16;
+struct W2aJobs {  // pack_w2a_multi_kernel: the pwconv2 fragment packs + b2eff rows of up to W2A_MAXJ ConvNeXt blocks
+  const float* w2[W2A_MAXJ];
+  const float* b2[W2A_MAXJ];
+  const float* gb[W2A_MAXJ];
+  float* w2a[W2A_MAXJ];
+  float* b2eff[W2A_MAXJ];
+  int C[W2A_MAXJ];
+  int n = 0;
+};
+int launch_pack_w2a_multi(const W2aJobs& jobs, hipStream_t st);
 struct AttnArgs {
   const float* q;  // [B][H*DH][T]   (batch stride qbs floats)
   const float* k;

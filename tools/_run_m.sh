@@ -1,9 +1,16 @@
-python tools/soak.py 300 > gpurun_out/soak.txt 2>&1
-python - <<'PY' >> gpurun_out/soak.txt 2>&1
-# 300 consecutive c3 steps (bf16 mode, train mode): time and finiteness
-import os, time, json, subprocess, sys
-r = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-extra", "--steps", "300", "--warmup", "5"], capture_output=True, text=True)
-d = json.loads(r.stdout.strip().splitlines()[-1])
-print("c3 300 steps:", d["ms_per_step"], "ms/step", d["value"], "frames/s")
-PY
+python -m pytest tests/test_hip_parity.py -q -k "convnext_block or vocoder_end_to_end or speech_predictor_end_to_end or block_backward or block_bf16 or acoustic_train_step_gradients or training_reduces" 2>&1 | grep -v "^$" | tail -6 > gpurun_out/t_fix.log
+run() { # name, wl, env...
+  n=$1; wl=$2; shift 2
+  env "$@" STY_STEP_PROBE=1 python bench.py --no-cpu-baseline --no-extra --steps 8 --warmup 3 --workload $wl 2>gpurun_out/phase_err.txt | python -c '
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(sys.argv[1], d["ms_per_step"])
+for n,t in d.get("phases_ms",[]): print(f"{t:9.3f}  {n}")
+' $n >> gpurun_out/phases.txt 2>&1
+}
+: > gpurun_out/phases.txt
+run c3 c3 X=1
+run c3b c3 X=1
+run c2 c2 X=1
+run c5bf16 c5-bf16 X=1
 echo done
