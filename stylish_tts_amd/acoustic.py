@@ -136,6 +136,9 @@ class AcousticTrainer:
         stream the backward is being issued on."""
         if key in self._hooks or module._handle is None:
             return
+        from .dist import collectives_on
+        if not collectives_on():  # one rank: nothing to overlap, and the backward need not stop to announce a segment
+            return
         grads = self.opt[key].grads
 
         def hook(_user, segment):

@@ -1690,11 +1690,14 @@ int sty_speech_bwd_pe(sty_model* m, const float* d_audio, float* d_style, float*
   bool seg0_done = false;
   int hook_rc = STY_OK;
   hipStream_t st = S(stream);
-  trainer_set_segment_hook(m->trainer, [&](int) {
-    hook_rc = unpack_grads(m, st, 0);
-    if (hook_rc == STY_OK && m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
-    seg0_done = true;
-  });
+  // (Nobody to announce it to -- no gradient hook, i.e. no data-parallel exchange to overlap: the main stream then does
+  // not stop for the weight-gradient stream in the middle of the backward, and both segments are un-packed at the end.)
+  if (m->grad_hook)
+    trainer_set_segment_hook(m->trainer, [&](int) {
+      hook_rc = unpack_grads(m, st, 0);
+      if (hook_rc == STY_OK && m->grad_hook) m->grad_hook(m->grad_hook_user, 0);
+      seg0_done = true;
+    });
   rc = trainer_speech_backward(m->trainer, d_audio, d_style, d_energy, st, d_pitch);
   trainer_set_segment_hook(m->trainer, nullptr);
   if (rc) return rc;

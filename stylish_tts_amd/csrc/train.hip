@@ -190,6 +190,10 @@ struct Trainer {
     side_q.clear();
     side_dirty = true;
   }
+  void side_reduce_nowait() {
+    side_flush();
+    if (side_dirty && st2) reduce_flush(st2);
+  }
   void side_join() {
     side_flush();
     reduce_flush(side_dirty && st2 ? st2 : st);
@@ -2144,6 +2148,11 @@ int trainer_speech_forward(Trainer* t, const sty_speech_io* io, void* ws, size_t
     if (t->on_segment && t->live()) {
       t->side_join();
       if (t->rc == STY_OK) t->on_segment(0);
+    } else if (t->live()) {
+      // nobody to announce the segment to: the grouped reduction of what has been recorded so far still runs here, on the
+      // weight-gradient stream and without the main stream waiting for it, so that the join at the end of the backward
+      // finds only the text encoder's few reductions left
+      t->side_reduce_nowait();
     }
   });
   t->style_fc(reinterpret_cast<hipStream_t>(io->style_stream));

@@ -908,6 +908,105 @@ size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x
   return n32 > n64 ? n32 : n64;
 }
 
+// ---- the style encoder's stem: a 3x3 conv of a ONE-channel image (flat 2-D mode, Cin2d = 1, reduction rows = kh) ----
+// dW has 9 x Cout elements and the reduction runs over every position of the batch: all there is to do is to read G once.
+// The general kernel spends a barrier-separated memory round trip per 128 positions and 32 output channels on it (0.47 ms
+// for the 426 MB of c3 = 0.9 TB/s, as the LAST weight gradient of the step's tail).  Here a thread keeps the 9 sums of
+// STEM_CO output channels in registers, reads four positions of each channel per step (one 16-byte load per channel, all
+// issued before the first is used) and the 3 x 6 image values around them once for all channels.  Same operands as the
+// general kernel: G * mask and x rounded to bf16 in the bf16 mode (products exact, fp32 sums), the bias gradient from the
+// unrounded G * mask.
+constexpr int STEM_CO = 8;
+template <bool BF>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                         const float* __restrict__ x, int B, int Cout, int n, int Wp,
+                                                         int hpad, int pad, int CinP, int CoutP, int nsplit,
+                                                         float* __restrict__ partial, size_t stride, int want_bias) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.x * STEM_CO, split = blockIdx.y;
+  const int cpb = (n / 4 + 255) / 256;  // chunks of 1024 positions per image
+  const int total = B * cpb;
+  float acc[STEM_CO][9], bs[STEM_CO];
+#pragma unroll
+  for (int i = 0; i < STEM_CO; ++i) {
+    bs[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[i][t] = 0.f;
+  }
+  for (int ch = split; ch < total; ch += nsplit) {
+    const int b = ch / cpb, p = ((ch - b * cpb) * 256 + tid) * 4;
+    if (p >= n) continue;
+    float4 gv[STEM_CO];
+#pragma unroll
+    for (int i = 0; i < STEM_CO; ++i) {
+      const int co = co0 + i;
+      gv[i] = co < Cout ? *reinterpret_cast<const float4*>(g + ((size_t)b * Cout + co) * n + p)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 mk = mask ? *reinterpret_cast<const float4*>(mask + (size_t)b * n + p) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float* xb = x + (size_t)b * n;
+    float xv[3][6];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int base = p - pad + (kh - hpad) * Wp;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int idx = base + j;
+        float v = (idx >= 0 && idx < n) ? xb[idx] : 0.f;
+        if constexpr (BF) v = (float)(__bf16)v;
+        xv[kh][j] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < STEM_CO; ++i) {
+      float g0 = gv[i].x * mk.x, g1 = gv[i].y * mk.y, g2 = gv[i].z * mk.z, g3 = gv[i].w * mk.w;
+      bs[i] += (g0 + g1) + (g2 + g3);
+      if constexpr (BF) {
+        g0 = (float)(__bf16)g0;
+        g1 = (float)(__bf16)g1;
+        g2 = (float)(__bf16)g2;
+        g3 = (float)(__bf16)g3;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          acc[i][kh * 3 + k] = fmaf(g3, xv[kh][k + 3], fmaf(g2, xv[kh][k + 2], fmaf(g1, xv[kh][k + 1], fmaf(g0, xv[kh][k], acc[i][kh * 3 + k]))));
+    }
+  }
+  __shared__ float red[4][STEM_CO * 10];
+#pragma unroll
+  for (int i = 0; i < STEM_CO; ++i) {
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      float v = t < 9 ? acc[i][t] : bs[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wave][i * 10 + t] = v;
+    }
+  }
+  __syncthreads();
+  // this workgroup's STEM_CO columns of the plane [k][kh (padded to CinP)][co], zeros included (the reduction sums whole planes)
+  float* pl = partial + (size_t)split * stride;
+  for (int e = tid; e < 3 * CinP * STEM_CO; e += 256) {
+    const int i = e % STEM_CO, ci = (e / STEM_CO) % CinP, k = e / (STEM_CO * CinP), co = co0 + i;
+    float v = 0.f;
+    if (ci < 3 && co < Cout) v = (red[0][i * 10 + ci * 3 + k] + red[1][i * 10 + ci * 3 + k]) + (red[2][i * 10 + ci * 3 + k] + red[3][i * 10 + ci * 3 + k]);
+    pl[((size_t)k * CinP + ci) * CoutP + co] = v;
+  }
+  if (want_bias && tid < STEM_CO) {
+    const int co = co0 + tid;
+    pl[(size_t)3 * CinP * CoutP + co] = co < Cout ? (red[0][tid * 10 + 9] + red[1][tid * 10 + 9]) + (red[2][tid * 10 + 9] + red[3][tid * 10 + 9]) : 0.f;
+  }
+}
+static bool stem_wgrad_eligible(const ConvArgs& f, const float* g, const float* gmask) {
+  static const bool off = getenv("STY_NO_STEM_WGRAD") != nullptr;
+  const PackedConv& w = f.w;
+  return !off && f.flatW && f.Cin2d == 1 && w.K == 3 && w.Cin == 3 && f.pro == PRO_NONE && f.nsrc == 1 && f.in_shuffle <= 1 &&
+         f.shuffle <= 1 && f.dil == 1 && f.T % 4 == 0 && w.CoutP % STEM_CO == 0 &&
+         ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gmask)) & 15) == 0;
+}
+
 // ax: forward ConvArgs (sources, prologue, dil, pad, w); g: output gradient [B][Cout][T] (shuffled when ax.shuffle > 1);
 // gmask: optional [B][T] multiplier of g; scale: constant factor (the forward out_scale); gwp += result.
 // gbias: packed bias gradient (+=) or nullptr; *bias_done tells the caller whether this launch produced it (K == 1 and
@@ -1082,6 +1181,30 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
       STY_LAUNCH_CHECK();
       return STY_OK;
     }
+  }
+  if (stem_wgrad_eligible(fwd, g, gmask)) {
+    const int cpb = cdiv(fwd.T / 4, 256);
+    int ns = nsplit;  // the partial buffer is sized for this many planes
+    if (ns > fwd.B * cpb) ns = fwd.B * cpb;
+    const int wb = gbias != nullptr;
+    const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
+    {
+      char detail[40];
+      snprintf(detail, sizeof(detail), "co%d T%d W%d", w.Cout, fwd.T, fwd.flatW);
+      ProfScope prof("stem_wgrad_kernel", 2.0 * 9 * (double)fwd.B * w.Cout * fwd.T, 4.0 * (double)fwd.B * (w.Cout + 2) * fwd.T, st,
+                     detail);
+      dim3 grid(w.CoutP / STEM_CO, ns);
+      if (fwd.bf16)
+        hipLaunchKernelGGL(stem_wgrad_kernel<true>, grid, dim3(256), 0, st, g, gmask, fwd.x[0], fwd.B, w.Cout, fwd.T, fwd.flatW,
+                           fwd.hpad, fwd.pad, w.CinP, w.CoutP, ns, partial, plane + w.CoutP, wb);
+      else
+        hipLaunchKernelGGL(stem_wgrad_kernel<false>, grid, dim3(256), 0, st, g, gmask, fwd.x[0], fwd.B, w.Cout, fwd.T, fwd.flatW,
+                           fwd.hpad, fwd.pad, w.CinP, w.CoutP, ns, partial, plane + w.CoutP, wb);
+    }
+    launch_wgrad_reduce(partial, ns, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);
+    if (bias_done) *bias_done = wb != 0;
+    STY_LAUNCH_CHECK();
+    return STY_OK;
   }
   if (wgradp32_eligible(ax)) {
     const int KTp = cdiv(w.K, 4);

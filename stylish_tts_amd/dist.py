@@ -26,6 +26,11 @@ def force_collective():
     return os.environ.get("STY_DIST_FORCE_COLLECTIVE") == "1"
 
 
+def collectives_on():
+    """True when a step's gradients go through the backend (more than one rank, or the forced one-rank exchange)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective())
+
+
 def init(backend=None):
     """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +107,7 @@ class GradBuckets:
 
     def reduce_bucket(self, i):
         """Start the all-reduce of bucket i (call once its last gradient has been written)."""
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective()):
+        if collectives_on():
             self._work.append(dist.all_reduce(self.buckets[i][0], op=dist.ReduceOp.SUM, async_op=True))
             self.collectives += 1
 

@@ -114,10 +114,14 @@ def main(out_path):
         tr.train_batch(audio_gt=a2.to(dev), texts=tx.to(dev), text_lengths=torch.full((Br,), Lt).to(dev),
                        pitch=p2.to(dev), durations=d2.to(dev), seed=it)
     torch.cuda.synchronize()
-    assert "hook" in marks and marks["returned_when_hook_fired"] is False, "segment 0 was not announced inside the backward"
-    ms = marks["hook"].elapsed_time(marks["returned"])
-    print(f"[rank {rank}] first all-reduce handed over {ms:.2f} ms of device time before sty_speech_bwd's work ended")
-    assert ms > 0.0
+    if world > 1:
+        assert "hook" in marks and marks["returned_when_hook_fired"] is False, \
+            "segment 0 was not announced inside the backward"
+        ms = marks["hook"].elapsed_time(marks["returned"])
+        print(f"[rank {rank}] first all-reduce handed over {ms:.2f} ms of device time before sty_speech_bwd's work ended")
+        assert ms > 0.0
+    else:  # one rank, no exchange: no hook is installed and the backward does not stop to announce a segment
+        assert "hook" not in marks
     after = torch.cat([p.detach().flatten() for m in (tr.sp, tr.se) for p in m.parameters()])
     assert bool(torch.isfinite(after).all())
     assert not torch.equal(after[:before.numel()], before), "parameters did not move"

@@ -1,4 +1,4 @@
-python -m pytest tests/test_hip_parity.py -q -k "convnext_block or vocoder_end_to_end or speech_predictor_end_to_end or block_backward or block_bf16 or acoustic_train_step_gradients or training_reduces" 2>&1 | grep -v "^$" | tail -6 > gpurun_out/t_fix.log
+python -m pytest tests/test_boundary_gpu.py tests/test_hip_parity.py -q -k "style or acoustic_train_step or twin or weight_gradient or grouped or full_size" 2>&1 | grep -v "^$" | tail -6 > gpurun_out/t_fix.log
 run() { # name, wl, env...
   n=$1; wl=$2; shift 2
   env "$@" STY_STEP_PROBE=1 python bench.py --no-cpu-baseline --no-extra --steps 8 --warmup 3 --workload $wl 2>gpurun_out/phase_err.txt | python -c '
