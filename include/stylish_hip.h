@@ -229,6 +229,8 @@ int sty_model_set_train_opts(sty_model *m, const sty_train_opts *opts);
  *   speech_predictor: segment 0 = every parameter outside `text_encoder.*` (announced before the text encoder's
  *                     backward), segment 1 = `text_encoder.*` (announced at the end of sty_speech_bwd);
  *   other kinds:      segment 0 = everything, announced at the end of the backward entry point.
+ * Without a hook (one rank: nothing to overlap) no segment is announced early and sty_speech_bwd does not make the
+ * calling stream wait for the library's weight-gradient stream in the middle of the backward.
  * Replaces what the reference gets from accelerate's DDP reducer hooks (train/train_context.py:94-104).          */
 typedef void (*sty_grad_hook)(void *user, int segment);
 int sty_model_set_grad_hook(sty_model *m, sty_grad_hook hook, void *user);

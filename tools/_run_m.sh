@@ -10,7 +10,11 @@ for n,t in d.get("phases_ms",[]): print(f"{t:9.3f}  {n}")
 }
 : > gpurun_out/phases.txt
 run c3 c3 X=1
+run c3_dual0 c3 STY_SIDE_DUAL=0
+run c3_dual2 c3 STY_SIDE_DUAL=2
 run c3b c3 X=1
+run c3_dual0b c3 STY_SIDE_DUAL=0
 run c2 c2 X=1
-run c5bf16 c5-bf16 X=1
+run c2_dual0 c2 STY_SIDE_DUAL=0
+run c2_dual2 c2 STY_SIDE_DUAL=2
 echo done
