@@ -452,7 +452,13 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
   constexpr int PITCH = TW + 8;
   constexpr int R = 64 * F;
   __bf16* xs = wb_lds;                // [R][PITCH]
-  __bf16* gs = wb_lds + R * PITCH;    // [KN][R][PITCH]
+  // G: ONE copy [R][8 + TW] -- position 8 + j of a row holds sample t0 + j, positions 4 .. 7 the four samples below the
+  // chunk.  The K tap fragments (samples shifted down by k) are cut out of a lane's 12-sample window [p - 4, p + 8) in
+  // registers (one ds_read_b64 + one ds_read_b128, v_alignbit for the odd shifts).  (Until the end of round 4 the tile was
+  // kept as K shifted copies: (1 + K) x 64 rows written and K + 1 16-byte fragment reads per K MFMAs -- 64 KB written and
+  // 128 KB read per 128-sample chunk against 768 matrix-pipe cycles per SIMD at K = 3, i.e. the LDS pipe allowed 0.5 of the
+  // matrix pipe at best; now 32 KB and 80 KB.)
+  __bf16* gs = wb_lds + R * PITCH;    // [R][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
             hi = lane >> 5;
   const int wi = wave >> 1, wo = wave & 1;
@@ -506,8 +512,8 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     const int co = co0 + r0 + RSTEP * m;
     offg[m] = co < Cg ? co * T * 2 : WB_OOB;
   }
-  constexpr int GN = KN > 1 ? 6 : 4;  // dwords of the G window
-  unsigned xw[NI][5], gw[NI][GN];
+  constexpr int GN = 4;  // dwords of a thread's eight G samples
+  unsigned xw[NI][5], gw[NI][GN], gh[NI][2];  // gh: the four samples below the chunk (threads of the first group only)
   const int total = ax.B * chunks_per_b;
   int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
 
@@ -534,20 +540,18 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
           wb16_slow<5>(rx, offx[m], base, T, xw[m]);
         }
       }
-      if constexpr (KN > 1) {  // G: the window [ig0 - 4, ig0 + 8)
-        if (ig0 - 4 >= 0 && ig0 + 7 < T) {
-          const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, offg[m] + (ig0 - 4) * 2, 0, 0));
-          const uint4 a = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, offg[m] + ig0 * 2, 0, 0));
-          gw[m][0] = lo.x;
-          gw[m][1] = lo.y;
-          gw[m][2] = a.x;
-          gw[m][3] = a.y;
-          gw[m][4] = a.z;
-          gw[m][5] = a.w;
-        } else {
-          wb16_slow<GN>(rg, offg[m], ig0 - 4, T, gw[m]);
+      if constexpr (KN > 1) {
+        if (g8 == 0) {  // the samples [t0 - 4, t0) of the row
+          if (ig0 - 4 >= 0 && ig0 - 1 < T) {
+            const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rg, offg[m] + (ig0 - 4) * 2, 0, 0));
+            gh[m][0] = lo.x;
+            gh[m][1] = lo.y;
+          } else {
+            wb16_slow<2>(rg, offg[m], ig0 - 4, T, gh[m]);
+          }
         }
-      } else {
+      }
+      {
         if (ig0 + 7 < T) {
           const uint4 a = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, offg[m] + ig0 * 2, 0, 0));
           gw[m][0] = a.x;
@@ -585,46 +589,53 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
         v.w = __builtin_amdgcn_alignbit(xw[m][4], xw[m][3], sh);
         *reinterpret_cast<uint4*>(xs + row * PITCH + g8) = v;
       }
-#pragma unroll
-      for (int k = 0; k < KN; ++k) {  // copy k: samples ig0 - k .. ig0 - k + 7 = window positions 4 - k ..
-        uint4 v;
-        if constexpr (KN == 1) {
-          v = make_uint4(gw[m][0], gw[m][1], gw[m][2], gw[m][3]);
-        } else {
-          const int p = 4 - k;  // compile-time after unrolling
-          if ((p & 1) == 0) {
-            v = make_uint4(gw[m][p / 2], gw[m][p / 2 + 1], gw[m][p / 2 + 2], gw[m][p / 2 + 3]);
-          } else {
-            const int q = (p - 1) / 2;
-            v.x = __builtin_amdgcn_alignbit(gw[m][q + 1], gw[m][q], 16);
-            v.y = __builtin_amdgcn_alignbit(gw[m][q + 2], gw[m][q + 1], 16);
-            v.z = __builtin_amdgcn_alignbit(gw[m][q + 3], gw[m][q + 2], 16);
-            v.w = __builtin_amdgcn_alignbit(gw[m][q + 4], gw[m][q + 3], 16);
-          }
-        }
-        *reinterpret_cast<uint4*>(gs + (k * R + row) * PITCH + g8) = v;
+      if constexpr (KN == 1) {
+        *reinterpret_cast<uint4*>(gs + row * PITCH + g8) = make_uint4(gw[m][0], gw[m][1], gw[m][2], gw[m][3]);
+      } else {
+        *reinterpret_cast<uint4*>(gs + row * PITCH + 8 + g8) = make_uint4(gw[m][0], gw[m][1], gw[m][2], gw[m][3]);
+        if (g8 == 0) *reinterpret_cast<uint2*>(gs + row * PITCH + 4) = make_uint2(gh[m][0], gh[m][1]);
       }
     }
     __syncthreads();
     advance(cb, cc_);
     if (ch + nsplit < total) load_chunk(cb, cc_);
     const __bf16* xr = xs + (wi * 32 * F + l31) * PITCH + 8 * hi;
-    const __bf16* gr = gs + (wo * 32 * F + l31) * PITCH + 8 * hi;
+    const __bf16* gr = gs + (wo * 32 * F + l31) * PITCH + 8 * hi + (KN > 1 ? 8 : 0);
 #pragma unroll
     for (int s8 = 0; s8 < TW / 16; ++s8) {
       bf16x8 bp[F];
 #pragma unroll
       for (int fi = 0; fi < F; ++fi) bp[fi] = *reinterpret_cast<const bf16x8*>(xr + fi * 32 * PITCH + 16 * s8);
 #pragma unroll
-      for (int k = 0; k < KN; ++k)
+      for (int fo = 0; fo < F; ++fo) {
+        const __bf16* q = gr + fo * 32 * PITCH + 16 * s8;
+        const uint4 a = *reinterpret_cast<const uint4*>(q);
+        unsigned win[6] = {0u, 0u, a.x, a.y, a.z, a.w};  // samples p - 4 .. p + 7 of the row as pairs
+        if constexpr (KN > 1) {
+          const uint2 lo = *reinterpret_cast<const uint2*>(q - 4);
+          win[0] = lo.x;
+          win[1] = lo.y;
+        }
 #pragma unroll
-        for (int fo = 0; fo < F; ++fo) {
-          const bf16x8 ap = *reinterpret_cast<const bf16x8*>(gr + (k * R + fo * 32) * PITCH + 16 * s8);
+        for (int k = 0; k < KN; ++k) {  // tap k: samples p - k .. p - k + 7 = window positions 4 - k ..
+          uint4 v;
+          const int p = 4 - k;  // compile-time after unrolling
+          if ((p & 1) == 0) {
+            v = make_uint4(win[p / 2], win[p / 2 + 1], win[p / 2 + 2], win[p / 2 + 3]);
+          } else {
+            const int o = (p - 1) / 2;
+            v.x = __builtin_amdgcn_alignbit(win[o + 1], win[o], 16);
+            v.y = __builtin_amdgcn_alignbit(win[o + 2], win[o + 1], 16);
+            v.z = __builtin_amdgcn_alignbit(win[o + 3], win[o + 2], 16);
+            v.w = __builtin_amdgcn_alignbit(win[o + 4], win[o + 3], 16);
+          }
+          const bf16x8 ap = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
           for (int fi = 0; fi < F; ++fi)
             acc[k][fi][fo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp[fi], acc[k][fi][fo], 0, 0, 0);
           if (k == 0 && do_bias && wi == 0) accb[fo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, ones, accb[fo], 0, 0, 0);
         }
+      }
     }
   }
 
@@ -687,7 +698,7 @@ int launch_wgradb16(const ConvArgs& ax, int nsplit, float* partial, int want_bia
   const int tw = wb16_tw(w.K, f);
   const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, tw);
   dim3 grid(cdiv(w.CinP, 64 * f), cdiv(w.CoutP, 64 * f), nsplit);
-  const size_t lds = (size_t)(1 + w.K) * 64 * f * (tw + 8) * sizeof(__bf16);
+  const size_t lds = (size_t)2 * 64 * f * (tw + 8) * sizeof(__bf16);  // x tile + ONE G tile (taps cut in registers)
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW);
   ProfScope prof(w.K == 1 ? "wgradb16_kernel<1,true>" : (w.K == 3 ? "wgradb16_kernel<3,true>" : "wgradb16_kernel<5,true>"),
