@@ -425,8 +425,9 @@ int launch_wgradb(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* par
 // like their fp32 masters.  Nothing is converted and no prologue runs here:
 //   * a thread owns (row, 8 consecutive samples) as FOUR dwords of bf16 pairs: x by one 16-byte + one 4-byte load from the
 //     even sample below its first one and a v_alignbit per dword when that first sample is odd (the tap / image-row shift
-//     decides); G by one 8-byte + one 16-byte load of the 12-sample window [t - 4, t + 8), out of which the K copies
-//     shifted by one sample each are cut with compile-time shifts (even shifts: the dwords as they are, odd: v_alignbit);
+//     decides); G by one 16-byte load, stored to LDS as it is (plus the four samples below the chunk, loaded by the
+//     first thread of a row); the K tap fragments are cut out of a 12-sample window when the MATRIX phase reads the tile
+//     (compile-time shifts -- even: the dwords as they are, odd: v_alignbit -- see the LDS layout note in the kernel);
 //   * half the bytes of the fp32 path from L2 (the 64 x 64 blocks re-read x Cout / 64 and G Cin / 64 times: that traffic
 //     was the kernel's limit) and from HBM; ~40 VALU instructions per chunk and thread where the fp32 path had ~200;
 //   * groups that straddle a row end take a sample-by-sample path (16-bit loads, out-of-row samples from an out-of-range
