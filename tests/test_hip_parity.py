@@ -862,6 +862,41 @@ def test_fft_front_end_equals_the_gemm_front_end(B, N, tmp_path):
     assert rel <= 2e-2 and cos >= 0.9995
 
 
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_stem_weight_gradient_streaming_kernel_equals_the_tiled_kernel(tmp_path, bf16):
+    """stem_wgrad_kernel (wgrad.hip: the 3 x 3 conv of the one-channel mel image, G read once, sums in registers) against the
+    general tiled weight-gradient kernel it replaced (STY_NO_STEM_WGRAD=1), same process input, both modes.  Same operands
+    (bf16 mode: G * mask and x rounded to bf16, exact products), fp32 sums in a different order: every element of the stem's
+    weight and bias gradient within 2e-6 of the tensor scale (measured: 2e-7); every OTHER gradient of the encoder within 1e-6 of its scale
+    (nothing else may change; not bit-equal because the style head's weight gradient is a float-atomic sum over the batch,
+    DESIGN.md section 7 item 7)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("stream", "tiled"):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("STY_NO_STEM_WGRAD", None)
+        if mode == "tiled":
+            env["STY_NO_STEM_WGRAD"] = "1"
+        f = str(tmp_path / f"{mode}.pt")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "stem_wgrad_ab_worker.py"), f, "3", "130", str(bf16)],
+                           capture_output=True, text=True, env=env, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(f)
+    a, b = outs["stream"], outs["tiled"]
+    rep = Report()
+    rep.add("d stem weight", a["stem_w"], b["stem_w"], 2e-6)
+    rep.add("d stem bias", a["stem_b"], b["stem_b"], 2e-6)
+    rep.done()
+    assert float(b["stem_w"].abs().max()) > 0
+    for k in a:
+        if k in ("stem_key", "stem_w", "stem_b") or k.startswith("shared.0."):
+            continue
+        scale = float(b[k].abs().max())
+        assert float((a[k] - b[k]).abs().max()) <= 1e-6 * scale, f"{k} changed with the stem's weight-gradient kernel"
+
+
 @pytest.mark.parametrize("T", [80, 161])
 def test_mel_style_encoder_backward(T):
     """A2 backward: gradients of every MelStyleEncoder parameter (through the eval-mode spectral norm) vs the

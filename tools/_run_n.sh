@@ -1,2 +1,1 @@
-python -m pytest tests/ -q -m gpu -x 2>&1 | tail -15 > gpurun_out/t_full.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
+python -m pytest tests/test_hip_parity.py -q -k "stem_weight_gradient" -s 2>&1 | tail -30 > gpurun_out/t_fix.log
