@@ -1,10 +1,4 @@
 : > gpurun_out/phases.txt
-python - <<'PY' >> gpurun_out/phases.txt 2>&1
-import ctypes as C
-hip = C.CDLL("libamdhip64.so")
-lo, hi = C.c_int(), C.c_int()
-print("prio range rc", hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)), "least", lo.value, "greatest", hi.value)
-PY
 run() { # name, env...
   n=$1; shift 1
   env "$@" STY_STEP_PROBE=1 python bench.py --no-cpu-baseline --no-extra --steps 10 --warmup 3 2>gpurun_out/phase_err.txt | python -c '
@@ -14,9 +8,11 @@ print(sys.argv[1], round(d["ms_per_step"],3), " ".join(f"{t:.2f}" for n,t in d.g
 ' $n >> gpurun_out/phases.txt 2>&1
 }
 run base X=1
-run prio1 STY_SE_STREAM_PRIO=1
-run prio0 STY_SE_STREAM_PRIO=0
+run wg1024 STY_WG_TARGET=1024
+run wg896 STY_WG_TARGET=896
+run wg640 STY_WG_TARGET=640
 run base2 X=1
-run prio1b STY_SE_STREAM_PRIO=1
-run prio2 STY_SE_STREAM_PRIO=2
+run wg1024b STY_WG_TARGET=1024
+run free16 STY_CONVP16_FREE_CUS=16
+run free48 STY_CONVP16_FREE_CUS=48
 echo done
