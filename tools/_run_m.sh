@@ -1,3 +1,4 @@
+python -m pytest tests/test_hip_parity.py tests/test_boundary_gpu.py -q -x -k "text_encoder or conformer or acoustic_train_step or layernorm or speech_predictor_end or two_rank_hip or textual or duration_trainer or soak or grouped" 2>&1 | grep -v "^$" | tail -6 > gpurun_out/t_fix.log
 : > gpurun_out/phases.txt
 run() { # name, env...
   n=$1; shift 1
@@ -7,12 +8,8 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(sys.argv[1], round(d["ms_per_step"],3), " ".join(f"{t:.2f}" for n,t in d.get("phases_ms",[])))
 ' $n >> gpurun_out/phases.txt 2>&1
 }
-run base X=1
-run wg1024 STY_WG_TARGET=1024
-run wg896 STY_WG_TARGET=896
-run wg640 STY_WG_TARGET=640
-run base2 X=1
-run wg1024b STY_WG_TARGET=1024
-run free16 STY_CONVP16_FREE_CUS=16
-run free48 STY_CONVP16_FREE_CUS=48
+run new X=1
+run old STY_NO_LN_PARAM_SIDE=1
+run new2 X=1
+run old2 STY_NO_LN_PARAM_SIDE=1
 echo done
