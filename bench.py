@@ -25,8 +25,9 @@ A step is one pass of the hot path over one synthetic batch already resident in 
       alignment -> pitch / energy predictor -> speech predictor -> audio, fp32 inference; frames = B x predicted frames.
 N > 1: one process per GPU (torch.distributed, RCCL), utterances sharded across ranks (weak scaling, no data-path
 collective in the forward); time = max over ranks between two barriers; value = frames of all ranks / time.
-The default run (c3 at N = 1) also carries c2, c5, c3-fp32 and c3-gan as `extra` sub-records (fewer steps, same process).
-Prints ONE JSON line on rank 0.
+The default run (c3 at N = 1) also carries c5 / c5-bf16 (vocoder only) as `extra` summaries and the c3 step under RCCL at world
+size 1; `--extra` adds c2, c3-fp32 and c3-gan.  Prints ONE JSON line (< 8 000 bytes: headline, roofline, cpu_baseline) on
+rank 0; the per-family kernel tables and the extras' full records go to `bench_detail.json`.
 """
 import argparse
 import json
@@ -555,7 +556,86 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
 
 # carried as sub-records of the default (c3) line at N = 1: the other single-GPU configurations of BASELINE.json and the
 # c3 step with the reference's adversarial terms on (what `train_acoustic` + the discriminator step cost in full)
-EXTRA_WORKLOADS = ("c2", "c5", "c3-fp32", "c3-gan")
+EXTRA_DEFAULT = ("c5-bf16", "c5")               # the vocoder-only configuration of the north-star (HBM GB/s on the conv stack)
+EXTRA_WORKLOADS = ("c5-bf16", "c5", "c2", "c3-fp32", "c3-gan")   # with --extra
+
+
+LINE_LIMIT = 8000   # the driver's record keeps the last 8 000 characters of stdout: the ONE line must fit in it whole
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the line is a record, not a lab notebook)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+              "algorithmic_bytes_per_launch", "avg_launch_us", "rocprof_avg_launch_us", "launches", "mfma_frac", "hbm_frac",
+              "share_of_step_time")
+
+
+def _short_roofline(r):
+    if not r:
+        return None
+    out = {k: r[k] for k in _ROOF_KEYS if k in r}
+    ss = r.get("single_stream")
+    if ss:  # the same kernel alone on the chip (side streams off), after the timed region
+        out["single_stream"] = {k: ss[k] for k in ("avg_launch_us", "mfma_frac", "hbm_frac") if k in ss}
+    return out
+
+
+def format_line(rec, detail_path=None):
+    """The ONE stdout line: headline, roofline, step-level roofline, cpu_baseline and a four-field summary of every
+    extra workload -- always under LINE_LIMIT bytes.  Everything else of `rec` (per-family kernel tables, the extras' full
+    records) is the sidecar `bench_detail.json`.  tests/test_boundary.py formats a recorded `rec` through this function."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+           "vs_baseline", "dtype", "data", "config", "host_issue_ms_per_step", "launches_per_step",
+           "single_stream_step_ms")
+    line = {k: rec[k] for k in top if k in rec}
+    if "roofline" in rec:
+        line["roofline"] = _short_roofline(rec["roofline"])
+    if "roofline_step" in rec:
+        line["roofline_step"] = {k: rec["roofline_step"][k] for k in
+                                 ("algorithmic_TFLOP_per_step", "algorithmic_GB_per_step", "TFLOPs", "GBps", "mfma_frac",
+                                  "hbm_frac") if k in rec["roofline_step"]}
+    if "cpu_baseline" in rec:
+        line["cpu_baseline"] = rec["cpu_baseline"]
+    if "library" in rec:
+        line["library"] = {k: rec["library"][k] for k in ("sha1", "rebuilt_here") if k in rec["library"]}
+    if "ranks" in rec:
+        rk = dict(rec["ranks"])
+        r1 = rk.get("rccl_world1")
+        if isinstance(r1, dict) and "error" not in r1:
+            rk["rccl_world1"] = {k: r1[k] for k in ("ms_per_step", "vs_no_process_group", "GPU_MAX_HW_QUEUES") if k in r1}
+        line["ranks"] = rk
+    if rec.get("extra"):
+        line["extra"] = {}
+        for name, r in rec["extra"].items():
+            rf = r.get("roofline") or {}
+            e = {"ms_per_step": r.get("ms_per_step"), "value": r.get("value"),
+                 "roofline": {k: rf[k] for k in ("kernel", "bound", "frac", "achieved", "unit", "traffic") if k in rf}}
+            for k in ("hbm_counter_GBps", "hbm_counter_source"):
+                if k in r:
+                    e[k] = r[k]
+            line["extra"][name] = e
+    if "phases_ms" in rec:
+        line["phases_ms"] = rec["phases_ms"]
+    if detail_path:
+        line["detail"] = detail_path
+    line = _r(line)
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("phases_ms", "extra", "roofline_step", "library"):  # cannot happen with the fields above; a guard, not a plan
+        if len(s) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < LINE_LIMIT, len(s)
+    return s
 
 
 def _launch_ranks(n):
@@ -582,7 +662,10 @@ def main():
     # default = the configuration BASELINE.json's metric is quoted on: configs[2], LJSpeech shape, B=32, bf16
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c5 / c3-fp32 / c3-gan sub-records of the default run")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c5 sub-records and the RCCL world-1 record of the default run")
+    ap.add_argument("--extra", action="store_true", help="also run c2 / c3-fp32 / c3-gan as sub-records (the default run carries c5 only)")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json beside bench.py, "
+                                                   "and gpurun_out/ when that directory exists)")
     args = ap.parse_args()
     # ONE JSON line on stdout: anything a library prints there (RCCL's version banner when the process group comes up)
     # goes to stderr instead -- file descriptor 1 is pointed at stderr for the whole run, the record is written to the
@@ -637,7 +720,7 @@ def main():
     if world == 1 and args.workload == "c3" and not args.no_extra:
         # the other single-GPU configurations of BASELINE.json, same process, fewer steps; each is a full record of its
         # own (value, ms_per_step, roofline of ITS dominant kernel) without the per-family table
-        for name in EXTRA_WORKLOADS:
+        for name in (EXTRA_WORKLOADS if args.extra else EXTRA_DEFAULT):
             heavy = bool(WORKLOADS[name].get("gan"))
             r = run_workload(name, min(args.steps, 5 if heavy else 10), min(args.warmup, 2 if heavy else 3), rank, world,
                              device, lib, L, D, share, serial_pass=False)
@@ -687,8 +770,20 @@ def main():
         rec["extra"] = extras
     if not args.no_cpu_baseline and world == 1:
         rec["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload])
+    # the full record (per-family kernel tables, the extras' whole records) goes to the sidecar; stdout gets the ONE line
+    detail = args.detail or os.path.join(ROOT, "bench_detail.json")
+    paths = [detail] + ([os.path.join(ROOT, "gpurun_out", "bench_detail.json")]
+                        if not args.detail and os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])
+    written = None
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                json.dump(rec, f, indent=1)
+            written = written or os.path.relpath(pth, ROOT)
+        except OSError:
+            pass
     sys.stdout.flush()
-    os.write(out_fd, (json.dumps(rec) + "\n").encode())
+    os.write(out_fd, (format_line(rec, written) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -150,3 +150,32 @@ def test_gradient_buckets_never_mix_segments():
     assert len(gb.buckets) >= 3                                # 25 kB cap splits segment 0; the segment change splits again
     gb.reduce_group(0)                                         # no process group: nothing to do, nothing raised
     assert gb.finish(average=False) == 1
+
+
+def test_bench_line_fits_the_drivers_record():
+    """The driver keeps the last 8 000 characters of bench.py's stdout and parses the ONE line out of them (round 4: a
+    30 KB line, `parsed: null`).  Format the largest recorded `rec` (round 4's full default run: per-family tables, four
+    extras) through the function bench.py prints with: under the limit, round-trips, carries the contract's fields."""
+    import glob
+    import bench
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_default*.json")))
+    assert recs
+    for f in recs:
+        rec = json.load(open(f))
+        if "metric" not in rec:
+            continue
+        s = bench.format_line(rec, "bench_detail.json")
+        assert len(s) < bench.LINE_LIMIT and "\n" not in s, (f, len(s))
+        back = json.loads(s)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in back, (f, k)
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in back["roofline"], (f, k)
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in back["cpu_baseline"], (f, k)
+        assert abs(back["value"] / rec["value"] - 1) < 1e-4
+        assert "kernels" not in back and "single_stream_kernels" not in back
+        for e in back.get("extra", {}).values():
+            assert set(e) <= {"ms_per_step", "value", "roofline", "hbm_counter_GBps", "hbm_counter_source"}
