@@ -48,11 +48,19 @@ def _chunk_terms(audio_gt, audio_pred):
     return out
 
 
-def chunked_acoustic_step(P, Pse, inp, chunk, w_mel=5.0, w_phase=8.0, want_prior=True):
+def chunked_acoustic_step(P, Pse, inp, chunk, w_mel=5.0, w_phase=8.0, want_prior=True, constants=None, after_chunk=None):
     """returns (audio [B,1,N] detached, mel, multi_phase, prior or None); parameter gradients of `backwards_total`
-    accumulate in .grad of the leaves of P / Pse that require grad."""
+    accumulate in .grad of the leaves of P / Pse that require grad.
+
+    constants: the dict an earlier call returned in its 5th element (the sums of pass 1) -- pass 1 is skipped and those
+    values are used, so that runs of the SAME step in another dtype / rounding mode (float64, bf16 operands) differentiate
+    the same function (the detached normalisers are constants of the step either way; their 1e-7 relative difference
+    between dtypes would only rescale the gradient by that much).  Inputs and parameters may be float64.
+    after_chunk(i): called after chunk i's backward (the caller snapshots per-chunk gradients)."""
     B = inp["audio_gt"].shape[0]
     rows = [slice(i, min(i + chunk, B)) for i in range(0, B, chunk)]
+    if constants is not None and "_B" in constants:
+        B = constants["_B"]  # `inp` holds some rows of a step of _B utterances: their share of THAT step's loss
     keys = ("audio_gt", "texts", "text_lengths", "pitch", "durations", "noise")
     nres = len(RESOLUTIONS)
     num = [0.0] * nres
@@ -60,8 +68,13 @@ def chunked_acoustic_step(P, Pse, inp, chunk, w_mel=5.0, w_phase=8.0, want_prior
     ph = [[0.0, 0.0, 0.0] for _ in range(nres)]
     cnt = [None] * nres
     audio, priors = [], []
+    if constants is not None:
+        num, den, ph, cnt, mel, mph = (constants[k] for k in ("num", "den", "ph", "cnt", "mel", "mph"))
+        rows_p1 = []
+    else:
+        rows_p1 = rows
     with torch.no_grad():
-        for r in rows:
+        for r in rows_p1:
             c = {k: inp[k][r] for k in keys}
             want = {}
             a = osp.acoustic_forward(P, Pse, c["audio_gt"], c["texts"], c["text_lengths"], c["pitch"], c["durations"],
@@ -74,9 +87,10 @@ def chunked_acoustic_step(P, Pse, inp, chunk, w_mel=5.0, w_phase=8.0, want_prior
                 for j in range(3):
                     ph[i][j] += s_[j].double().item()
                 cnt[i] = k_
-    mel = sum(num[i] / (den[i] + 1e-6) for i in range(nres)) / nres
-    mph = sum(sum(ph[i][j] / (cnt[i][j] * B) for j in range(3)) for i in range(nres)) / nres
-    for r in rows:
+    if constants is None:
+        mel = sum(num[i] / (den[i] + 1e-6) for i in range(nres)) / nres
+        mph = sum(sum(ph[i][j] / (cnt[i][j] * B) for j in range(3)) for i in range(nres)) / nres
+    for ci, r in enumerate(rows):
         c = {k: inp[k][r] for k in keys}
         a = osp.acoustic_forward(P, Pse, c["audio_gt"], c["texts"], c["text_lengths"], c["pitch"], c["durations"], c["noise"])
         tot = 0.0
@@ -85,5 +99,9 @@ def chunked_acoustic_step(P, Pse, inp, chunk, w_mel=5.0, w_phase=8.0, want_prior
             for j in range(3):
                 tot = tot + (w_phase / (mph + 1e-9)) * s_[j] / (k_[j] * B * nres)
         tot.backward()
+        if after_chunk is not None:
+            after_chunk(ci)
+    if constants is not None:
+        return None, mel, mph, None, constants
     prior = torch.cat(priors) if want_prior and priors[0] is not None else None
-    return torch.cat(audio), mel, mph, prior
+    return torch.cat(audio), mel, mph, prior, dict(num=num, den=den, ph=ph, cnt=cnt, mel=mel, mph=mph)
