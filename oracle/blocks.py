@@ -130,43 +130,67 @@ def grn_scale(h, gamma, eps=1e-6):
 # corr(bf(x), bf(gy)); bias, norms, activations, depthwise convs stay fp32.  Inside `with bf16_operands():` the dense convs
 # of the block functions below follow the same rule (in the caller's dtype, float64 for the tests), so that the HIP
 # kernels are held to the SAME rounded operands at close to the fp32 tolerance instead of to an fp32 run at 1e-2.
-_DENSE = {"bf16": False}
+#
+# bf16 STORAGE (`bf16_operands(storage=True)`, the product's default in the bf16 mode where its two-byte kernels apply --
+# T % 8 == 0 and the persistent 32-channel kernel takes every conv of the block): what autocast keeps in HBM
+# (config/config.yml:9-12, train/train_context.py:97-103: conv outputs are bf16 tensors).  Rounding points, each a single
+# round-to-nearest-even of a value computed in fp32:
+#   * the output of every conv INSIDE an AdaptiveGeneratorBlock (after bias; after the residual add for convs2.0 / convs2.1),
+#     and the output of the prior conv in front of the block: `store16`;
+#   * the input gradient of a conv whose input is such a tensor (d loss / d prologue(x), before the prologue's derivative):
+#     `_BfConv1d(..., round_gx=True)`.
+# Gradient accumulators stay fp32 in the product, so nothing else is rounded on the way back.
+_DENSE = {"bf16": False, "store16": False}
 
 
 class bf16_operands:
+    def __init__(self, storage=False):
+        self.storage = storage
+
     def __enter__(self):
-        self.prev = _DENSE["bf16"]
+        self.prev = dict(_DENSE)
         _DENSE["bf16"] = True
+        _DENSE["store16"] = bool(self.storage)
 
     def __exit__(self, *a):
-        _DENSE["bf16"] = self.prev
+        _DENSE.update(self.prev)
 
 
 def bf(t):
     return t.detach().float().bfloat16().to(t.dtype)
 
 
+def store16(t, on=True):
+    """a tensor the product stores as bf16: rounded once in the forward; the gradient passes unchanged (its accumulator is fp32)"""
+    if not (_DENSE["store16"] and on):
+        return t
+    return t + (bf(t) - t.detach())
+
+
 class _BfConv1d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, padding, dilation):
+    def forward(ctx, x, w, padding, dilation, round_gx):
         ctx.save_for_backward(x, w)
-        ctx.pd = (padding, dilation)
+        ctx.pd = (padding, dilation, round_gx)
         return F.conv1d(bf(x), bf(w), None, padding=padding, dilation=dilation)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        padding, dilation = ctx.pd
+        padding, dilation, round_gx = ctx.pd
         gx = torch.nn.grad.conv1d_input(x.shape, bf(w), bf(gy), padding=padding, dilation=dilation)
+        if round_gx:
+            gx = bf(gx)
         gw = torch.nn.grad.conv1d_weight(bf(x), w.shape, bf(gy), padding=padding, dilation=dilation)
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
-def dense_conv1d(x, w, b, padding=0, dilation=1):
-    """a dense Conv1d / Linear of the path: F.conv1d, or the bf16-operand rule above inside `with bf16_operands():`"""
+def dense_conv1d(x, w, b, padding=0, dilation=1, x_stored16=False):
+    """a dense Conv1d / Linear of the path: F.conv1d, or the bf16-operand rule above inside `with bf16_operands():`
+    (x_stored16: the conv's input is a tensor the product stores as bf16 -- its input gradient is stored the same way)"""
     if not _DENSE["bf16"]:
         return F.conv1d(x, w, b, padding=padding, dilation=dilation)
-    y = _BfConv1d.apply(x, w, padding, dilation)
+    y = _BfConv1d.apply(x, w, padding, dilation, bool(x_stored16 and _DENSE["store16"]))
     return y if b is None else y + b.view(1, -1, 1)
 
 
@@ -190,16 +214,19 @@ def convnext_block(P, p, x, style, want=None):
     return x + h
 
 
-def gen_resblock(P, p, x, style):
-    """AdaptiveGeneratorBlock(k=11, dil 1/3/5) (ada_norm.py:109-120)."""
+def gen_resblock(P, p, x, style, x_stored16=False):
+    """AdaptiveGeneratorBlock(k=11, dil 1/3/5) (ada_norm.py:109-120).  x_stored16: the block's input is itself a tensor
+    the product stores as bf16 (the prior conv's output in the vocoder; a plain fp32 tensor in the block tests)."""
     for i, d in enumerate((1, 3, 5)):
         xt = adain(P, f"{p}.adain1.{i}", x, style)
         xt = snake(xt, P[f"{p}.alpha1.{i}"])
-        xt = dense_conv1d(xt, wn_weight(P, f"{p}.convs1.{i}"), P[f"{p}.convs1.{i}.bias"], padding=5 * d, dilation=d)
+        xt = dense_conv1d(xt, wn_weight(P, f"{p}.convs1.{i}"), P[f"{p}.convs1.{i}.bias"], padding=5 * d, dilation=d,
+                          x_stored16=x_stored16 or i > 0)
+        xt = store16(xt)
         xt = adain(P, f"{p}.adain2.{i}", xt, style)
         xt = snake(xt, P[f"{p}.alpha2.{i}"])
-        xt = dense_conv1d(xt, wn_weight(P, f"{p}.convs2.{i}"), P[f"{p}.convs2.{i}.bias"], padding=5)
-        x = xt + x
+        xt = dense_conv1d(xt, wn_weight(P, f"{p}.convs2.{i}"), P[f"{p}.convs2.{i}.bias"], padding=5, x_stored16=True)
+        x = store16(xt + x, on=i < 2)  # (the block's output feeds kernels without a two-byte form: fp32)
     return x
 
 

@@ -58,10 +58,12 @@ def generator(P, p, mel, style, pitch, voiced, noise, want=None, prior=None):
         har_phase = torch.atan2(hy, hx)[:, :32, :-1]
     if want is not None:
         want["prior"], want["har_spec"], want["har_phase"] = prior, har_spec, har_phase
-    logamp_prior = F.conv1d(har_spec, P[p + ".amp_prior_conv.weight"], P[p + ".amp_prior_conv.bias"], padding=10)
-    logamp_prior = B.gen_resblock(P, p + ".amp_prior_block", logamp_prior, style)
-    phase_prior = F.conv1d(har_phase, P[p + ".phase_prior_conv.weight"], P[p + ".phase_prior_conv.bias"], padding=10)
-    phase_prior = B.gen_resblock(P, p + ".phase_prior_block", phase_prior, style)
+    # (dense_conv1d = F.conv1d outside `with bf16_operands():`; inside it the prior convs follow the mode's rounding rule, and
+    # with storage=True their outputs -- the resblocks' inputs -- are the bf16 tensors the product stores)
+    logamp_prior = B.store16(B.dense_conv1d(har_spec, P[p + ".amp_prior_conv.weight"], P[p + ".amp_prior_conv.bias"], padding=10))
+    logamp_prior = B.gen_resblock(P, p + ".amp_prior_block", logamp_prior, style, x_stored16=True)
+    phase_prior = B.store16(B.dense_conv1d(har_phase, P[p + ".phase_prior_conv.weight"], P[p + ".phase_prior_conv.bias"], padding=10))
+    phase_prior = B.gen_resblock(P, p + ".phase_prior_block", phase_prior, style, x_stored16=True)
     x = mel
     i = 0
     while (f"{p}.amp_convnext.{i}.dwconv.weight") in P:

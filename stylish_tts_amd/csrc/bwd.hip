@@ -146,6 +146,126 @@ int launch_pro_bwd(int mode, const float* u, int Cu, int cu0, const float* x, in
   return STY_OK;
 }
 
+// ---- AdaIN + Snake prologue backward WITH the instance-norm statistics term, one launch (resblock convs) ----
+// pro_bwd_kernel wrote dx (+)= g a and the row sums (da, ds), adain_fold_bwd_kernel turned them into (c0, c1) and the fc(style)
+// gradient, row_axpb added c0 + c1 x: three launches and three passes over the rows (u, x, dx; x, dx, dx).  The sums a row's
+// coefficients need are sums over THAT row, and a workgroup owns a row: sweep 1 reads (u, x) and forms the sums, thread 0 folds
+// them (adain_fold_bwd_kernel's arithmetic), sweep 2 -- backwards, the tail of sweep 1 is still in L2 -- recomputes
+// g = u snake'(a x + s) and writes dx (+)= g a + c0 + c1 x once.  u and x may be bf16 tensors (uh, xh: two-byte storage of the
+// 75T-rate activations), dx fp32 or bf16 (dh).  T % 8 == 0, rows 16-byte aligned.
+__device__ __forceinline__ void ld8_any(const void* p, size_t i8, bool h, float (&v)[8]) {
+  if (h) {
+    const uint4 q = reinterpret_cast<const uint4*>(p)[i8];
+    v[0] = sty_bf_lo(q.x), v[1] = sty_bf_hi(q.x), v[2] = sty_bf_lo(q.y), v[3] = sty_bf_hi(q.y);
+    v[4] = sty_bf_lo(q.z), v[5] = sty_bf_hi(q.z), v[6] = sty_bf_lo(q.w), v[7] = sty_bf_hi(q.w);
+  } else {
+    const float4 a = reinterpret_cast<const float4*>(p)[2 * i8], b = reinterpret_cast<const float4*>(p)[2 * i8 + 1];
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+  }
+}
+__device__ __forceinline__ void st8_any(void* p, size_t i8, bool h, const float (&v)[8]) {
+  if (h) {
+    reinterpret_cast<uint4*>(p)[i8] = make_uint4(sty_pack2_bf16(v[0], v[1]), sty_pack2_bf16(v[2], v[3]),
+                                                 sty_pack2_bf16(v[4], v[5]), sty_pack2_bf16(v[6], v[7]));
+  } else {
+    reinterpret_cast<float4*>(p)[2 * i8] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[2 * i8 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+__global__ __launch_bounds__(256) void pro_bwd_adain_kernel(const void* __restrict__ u, int uh, const void* __restrict__ x, int xh,
+                                                            int C, int T, const float* __restrict__ pa,
+                                                            const float* __restrict__ ps, const float* __restrict__ alpha,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gb, void* __restrict__ dx, int dh,
+                                                            int accumulate, float* __restrict__ dgb,
+                                                            float* __restrict__ dalpha, int hw) {
+  __shared__ double red[3][4];
+  __shared__ float cc[2];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const size_t row = (size_t)b * C + c;
+  const float a = pa[row], s = ps[row], al = alpha[c], ral = 1.0f / al;
+  const int n8 = T / 8;
+  const size_t r8 = row * n8;
+  auto deriv = [&](float uv, float xv, float& dal) -> float {
+    const float z = fmaf(a, xv, s);
+    float sn, cs;
+    if (hw && fabsf(al * z) <= 8192.0f)
+      sty_sincos_hw(al * z, sn, cs);
+    else
+      sty_sincos(al * z, sn, cs);
+    const float s2a = 2.f * sn * cs;
+    dal = uv * (z * s2a - sn * sn * ral) * ral;
+    return uv * (1.f + s2a);
+  };
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n8; i += 256) {
+    float uv[8], xv[8];
+    ld8_any(u, r8 + i, uh != 0, uv);
+    ld8_any(x, r8 + i, xh != 0, xv);
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float dal;
+      const float g = deriv(uv[e], xv[e], dal);
+      p0 = fmaf(g, xv[e], p0);
+      p1 += g;
+      p2 += dal;
+    }
+    acc[0] += (double)p0;
+    acc[1] += (double)p1;
+    acc[2] += (double)p2;
+  }
+  block_sum<3>(acc, red);
+  if (threadIdx.x == 0) {
+    const float mu = mean[row], r = rstd[row], g1 = 1.f + gb[(size_t)b * 2 * C + c];
+    const float dA = (float)acc[0], dS = (float)acc[1];
+    dgb[(size_t)b * 2 * C + c] += r * (dA - mu * dS);
+    dgb[(size_t)b * 2 * C + C + c] += dS;
+    const float dmu = -(g1 * r) * dS, dr = g1 * (dA - mu * dS);
+    const float k1 = -dr * r * r * r / (float)T;
+    cc[1] = k1;
+    cc[0] = dmu / (float)T - k1 * mu;
+    if (dalpha) atomicAdd(&dalpha[c], (float)acc[2]);
+  }
+  __syncthreads();
+  const float c0 = cc[0], c1 = cc[1];
+  for (int i = n8 - 1 - (int)threadIdx.x; i >= 0; i -= 256) {
+    float uv[8], xv[8], d[8];
+    ld8_any(u, r8 + i, uh != 0, uv);
+    ld8_any(x, r8 + i, xh != 0, xv);
+    if (accumulate) {
+      ld8_any(dx, r8 + i, dh != 0, d);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float dal;
+      const float g = deriv(uv[e], xv[e], dal);
+      d[e] += fmaf(g, a, fmaf(c1, xv[e], c0));
+    }
+    st8_any(dx, r8 + i, dh != 0, d);
+  }
+}
+int launch_pro_bwd_adain(const void* u, int uh, const void* x, int xh, int B, int C, int T, const float* pa, const float* ps,
+                         const float* alpha, const float* mean, const float* rstd, const float* gb, void* dx, int dh,
+                         int accumulate, float* dgb, float* dalpha, int hw, hipStream_t st) {
+  if (T % 8 != 0 || ((((size_t)u | (size_t)x | (size_t)dx) & 15) != 0)) {
+    set_error("pro_bwd_adain: T %% 8 != 0 or unaligned rows");
+    return STY_EINVAL;
+  }
+  char detail[40];
+  snprintf(detail, sizeof(detail), "C%d T%d acc%d h%d%d%d", C, T, accumulate, uh, xh, dh);
+  const double n = (double)B * C * T;
+  ProfScope prof("pro_bwd_adain_kernel", 0.0, n * (2.0 * ((uh ? 2 : 4) + (xh ? 2 : 4)) + (accumulate ? 2.0 : 1.0) * (dh ? 2 : 4)), st,
+                 detail);
+  hipLaunchKernelGGL(pro_bwd_adain_kernel, dim3(C, B), dim3(256), 0, st, u, uh, x, xh, C, T, pa, ps, alpha, mean, rstd, gb, dx,
+                     dh, accumulate, dgb, dalpha, hw);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 // ---- AdaIN fold backward: (da, ds, mean, rstd, gb) -> dgb (+=), row coefficients c0, c1 with dx += c0 + c1 x ----
 __global__ void adain_fold_bwd_kernel(const float* __restrict__ da, const float* __restrict__ ds,
                                       const float* __restrict__ mean, const float* __restrict__ rstd,

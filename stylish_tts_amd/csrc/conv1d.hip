@@ -442,6 +442,11 @@ static int launch_conv1d_dispatch(const ConvArgs& a, hipStream_t st) {
   }
   if (stem2d_eligible(a)) return launch_stem2d(a, st);
   if (conv32p_eligible(a)) return launch_conv32p(a, st);
+  if (a.xh || a.yh || a.rh) {
+    set_error("conv1d: bf16-stored operand (xh %d yh %d rh %d) on a conv the persistent 32-channel kernel does not take", a.xh,
+              a.yh, a.rh);
+    return STY_EINVAL;
+  }
   if (a.stat_part) {
     set_error("conv1d: output statistics requested for a conv the persistent 32-channel kernel does not take");
     return STY_EINVAL;

@@ -83,6 +83,21 @@ __device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, 
   const int T = a.T, Cout = a.w.Cout;
   const int t = tl.t0 + 4 * lane;
   d.wide = t + 3 < T;
+  if (a.rh) {  // bf16 residual tensor (T % 4 == 0: a lane's four columns are all inside the row or all outside): 8-byte loads
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(want ? reinterpret_cast<const char*>(a.residual) + (size_t)tl.b * Cout * T * 2
+                               : reinterpret_cast<const char*>(a.y)),
+        0, want ? Cout * T * 2 : 0, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int co = 8 * pw + r;
+      d.res[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!want || co >= Cout || !d.wide) continue;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(rrs, t * 2, co * T * 2, 0);
+      d.res[r] = make_float4(sty_bf_lo(v[0]), sty_bf_hi(v[0]), sty_bf_lo(v[1]), sty_bf_hi(v[1]));
+    }
+    return;
+  }
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(want ? a.residual + (size_t)tl.b * Cout * T : a.y), 0, want ? Cout * T * 4 : 0, 0x00020000);
 #pragma unroll
@@ -108,21 +123,31 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
   const int T = a.T, Cout = a.w.Cout;
   const int t = tl.t0 + 4 * lane;
   float sv[16];  // [0..7] sums, [8..15] sums of squares of this lane's columns, per row of this wave
-  const __amdgpu_buffer_rsrc_t yrs =
-      __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)tl.b * Cout * T, 0, Cout * T * 4, 0x00020000);
+  const int esz = a.yh ? 2 : 4;  // (yh: the output tensor is bf16; T % 4 == 0, so d.wide == (t < T))
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(a.y) + (size_t)tl.b * Cout * T * esz, 0, Cout * T * esz, 0x00020000);
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int co = 8 * pw + r;
     if (co >= Cout) continue;
     const float4 s = *reinterpret_cast<const float4*>(ostage + co * P_TT + 4 * lane);
     float4 v = make_float4(s.x + d.res[r].x, s.y + d.res[r].y, s.z + d.res[r].z, s.w + d.res[r].w);
+    unsigned pk0 = 0, pk1 = 0;
+    if (a.yh) {  // what is stored is what the next layer's instance norm sees: round first, statistics of the rounded values
+      pk0 = sty_pack2_bf16(v.x, v.y);
+      pk1 = sty_pack2_bf16(v.z, v.w);
+      v = make_float4(sty_bf_lo(pk0), sty_bf_hi(pk0), sty_bf_lo(pk1), sty_bf_hi(pk1));
+    }
     if (a.stat_part) {  // statistics of what is stored: this lane's (up to) four columns in fp32, across lanes in double
       const float e0 = v.x, e1 = t + 1 < T ? v.y : 0.f, e2 = t + 2 < T ? v.z : 0.f, e3 = t + 3 < T ? v.w : 0.f;
       const bool in = t < T;
       sv[r] = in ? (e0 + e1) + (e2 + e3) : 0.f;
       sv[8 + r] = in ? (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3) : 0.f;
     }
-    if (d.wide) {
+    if (a.yh) {
+      typedef unsigned u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
+      if (d.wide) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk0, pk1}, yrs, t * 2, co * T * 2, 0);
+    } else if (d.wide) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
                                              yrs, t * 4, co * T * 4, 0);
     } else {
@@ -206,6 +231,43 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
     float pa[8], ps[8], al[8], ral[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) p_row_params<PRO>(a, b, 8 * pw + r, 8 * pw + r < Cin, pa[r], ps[r], al[r], ral[r]);
+    if (a.xh) {
+      // bf16 SOURCE tensor: a lane loads a dword = two consecutive samples of a row, 8 rows x 3 pair groups = 24 loads for
+      // the whole tile (48 in the fp32 form), all in flight before the drain of the previous tile.  The tile starts at an
+      // EVEN sample (one column further left when the padding is odd: sh), so that every dword is aligned; T is even.
+      const int sh = a.pad & 1, LWs = LW + sh;
+      const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.x[0]) + (size_t)b * Cin * T * 2), 0, Cin * T * 2, 0x00020000);
+      const int vo = (t0 - a.pad - sh + 2 * lane) * 2;
+      unsigned vh[P_MAXQ / 2][8];
+#pragma unroll
+      for (int q = 0; q < P_MAXQ / 2; ++q)
+        if (q < P_TT / 128 || 128 * q < LWs)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vh[q][r] = __builtin_amdgcn_raw_buffer_load_b32(rsh, vo + 256 * q, (8 * pw + r) * T * 2, 0);
+      mid();
+#pragma unroll
+      for (int q = 0; q < P_MAXQ / 2; ++q) {
+        if (!(q < P_TT / 128 || 128 * q < LWs)) continue;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int j = 2 * lane + 128 * q + e;
+          const int t = t0 - a.pad - sh + j;
+          const bool tin = t >= 0 && t < T;
+          float mk = 1.f;
+          if constexpr (PRO == PRO_MASK) mk = tin ? a.mask[(size_t)b * T + t] : 0.f;
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            v[r] = (8 * pw + r < Cin && tin) ? pro_apply<PRO>(e ? sty_bf_hi(vh[q][r]) : sty_bf_lo(vh[q][r]), pa[r], ps[r], al[r], ral[r], mk)
+                                            : 0.f;
+          if (j < LWs)
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + 8 * pw) =
+                sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
+      }
+      return;
+    }
     constexpr int QH = P_MAXQ / 2;
     float vv[2][QH][8];
 #define STY_P_LOADH(h)                                                                     \
@@ -247,7 +309,8 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
   const int K = a.w.K, CoutP = a.w.CoutP, CinP = a.w.CinP;
   const int halo = (K - 1) * a.dil;
   const int LW = P_TT + halo;
-  const int bufsz = BF ? (LW * P_PITCH) / 2 : CI_CHUNK * LW;  // floats per input tile buffer
+  const int xsh = BF && a.xh ? (a.pad & 1) : 0;  // bf16 source tensor: the staged tile starts one column further left (p_stage)
+  const int bufsz = BF ? ((LW + xsh) * P_PITCH) / 2 : CI_CHUNK * LW;  // floats per input tile buffer
   float* ost = lds + 2 * bufsz;                               // two output stages [32][256] fp32
   float* wl = ost + 2 * P_OUT;                                // bf16 mode: A fragments [K][2][64 lanes] x 16 B
 
@@ -326,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
         bf16x8 avA[2], bvA[2][P_NT], avB[2], bvB[2][P_NT];
 #define STY_LD16(AV, BV, k)                                                                                  \
   {                                                                                                          \
-    const __bf16* col = xh + (size_t)(tw + l31 + (k) * a.dil) * P_PITCH + 8 * hi;                             \
+    const __bf16* col = xh + (size_t)(tw + l31 + xsh + (k) * a.dil) * P_PITCH + 8 * hi;                       \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                          \
       AV[s] = wf[((k) * 2 + s) * 64 + lane];                                                                 \
       _Pragma("unroll") for (int n = 0; n < P_NT; ++n) BV[s][n] =                                            \
@@ -447,7 +510,7 @@ static int num_cus() {
 }
 
 static size_t p_lds_bytes(const ConvArgs& a) {
-  const int LW = P_TT + (a.w.K - 1) * a.dil;
+  const int LW = P_TT + (a.w.K - 1) * a.dil + (a.bf16 && a.xh ? (a.pad & 1) : 0);
   const size_t in = a.bf16 ? (size_t)2 * LW * P_PITCH * 2 : (size_t)2 * CI_CHUNK * LW * 4;
   return in + (size_t)2 * P_OUT * 4 + (a.bf16 ? (size_t)a.w.K * 2 * 64 * 16 : 0);
 }
@@ -466,7 +529,8 @@ static int launch_p(const ConvArgs& a, hipStream_t st) {
   const int grid = ntiles < num_cus() ? ntiles : num_cus();
   const double outs = (double)a.B * a.w.Cout * a.T;
   const double flops = 2.0 * a.w.Cin * a.w.K * outs;
-  const double bytes = 4.0 * ((double)a.B * a.w.Cin * a.T + outs * (a.residual ? 2.0 : 1.0) + (double)a.w.Cout * a.w.Cin * a.w.K);
+  const double bytes = (a.xh ? 2.0 : 4.0) * a.B * a.w.Cin * a.T + (a.yh ? 2.0 : 4.0) * outs +
+                       (a.residual ? (a.rh ? 2.0 : 4.0) * outs : 0.0) + 4.0 * a.w.Cout * a.w.Cin * a.w.K;
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d d%d T%d", a.w.Cin, a.w.Cout, a.w.K, a.dil, a.T);
   ProfScope prof(BF ? "conv32p_kernel<true>" : "conv32p_kernel<false>", flops, bytes, st, detail);
@@ -487,7 +551,8 @@ bool conv32p_eligible(const ConvArgs& a) {
     return false;
   if (!(a.pro == PRO_NONE || a.pro == PRO_AFFINE_SNAKE || a.pro == PRO_MASK || a.pro == PRO_AFFINE_LRELU)) return false;
   const int halo = (a.w.K - 1) * a.dil;
-  if (halo > 64 * P_MAXQ - P_TT) return false;
+  if (halo + 1 > 64 * P_MAXQ - P_TT) return false;
+  if ((a.xh || a.yh || a.rh) && (!a.bf16 || a.T % 4 != 0)) return false;  // two-byte tensors: bf16 mode, 8-byte row groups
   if (p_lds_bytes(a) > 160 * 1024) return false;
   // worth it from ~2 tiles per CU on (below that the persistent loop has nothing to overlap)
   const char* mt = getenv("STY_CONV32P_MIN_TILES");  // read per call: the parity tests lower it for small shapes

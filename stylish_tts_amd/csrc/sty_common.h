@@ -50,6 +50,46 @@ __device__ __forceinline__ bf16x8 sty_pack_bf16(float v0, float v1, float v2, fl
 }
 #endif
 
+#ifdef __HIPCC__
+// two-byte storage helpers: a dword of two bf16 (even element in the low half) <-> fp32
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sty_bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float sty_bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned sty_pack2_bf16(float lo, float hi) {  // v_cvt_pk_bf16_f32, round to nearest even
+  bf16x2 r;
+  r[0] = (__bf16)lo;
+  r[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float sty_round_bf16(float v) {
+  return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v) << 16);
+}
+// element i of a tensor stored as fp32 (h = false) or bf16 (h = true); h is wave-uniform at every call site
+__device__ __forceinline__ float sty_ld_any(const void* p, size_t i, bool h) {
+  return h ? sty_bf_lo(reinterpret_cast<const unsigned short*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void sty_st_any(void* p, size_t i, float v, bool h) {
+  if (h)
+    reinterpret_cast<unsigned short*>(p)[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+  else
+    reinterpret_cast<float*>(p)[i] = v;
+}
+// four consecutive elements (i4 = index of the group; 16-byte / 8-byte aligned)
+__device__ __forceinline__ float4 sty_ld4_any(const void* p, size_t i4, bool h) {
+  if (h) {
+    const uint2 u = reinterpret_cast<const uint2*>(p)[i4];
+    return make_float4(sty_bf_lo(u.x), sty_bf_hi(u.x), sty_bf_lo(u.y), sty_bf_hi(u.y));
+  }
+  return reinterpret_cast<const float4*>(p)[i4];
+}
+__device__ __forceinline__ void sty_st4_any(void* p, size_t i4, float4 v, bool h) {
+  if (h)
+    reinterpret_cast<uint2*>(p)[i4] = make_uint2(sty_pack2_bf16(v.x, v.y), sty_pack2_bf16(v.z, v.w));
+  else
+    reinterpret_cast<float4*>(p)[i4] = v;
+}
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -137,6 +177,14 @@ struct ConvArgs {
   // y16 (producers): also store act16(y) as bf16 [B][Cout][T] -- the twin the next conv reads; y16_act = PRO_NONE or PRO_LRELU
   __bf16* y16 = nullptr;
   int y16_act = PRO_NONE;
+  // ---- bf16 STORAGE of the 75T-rate activations (bf16 compute mode) ----
+  // What autocast stores (config/config.yml:9-12, train/train_context.py:97-103: conv outputs live in HBM as bf16): the
+  // tensor itself is two bytes per element, there is no fp32 copy.  xh: source 0 is a bf16 tensor [B][Cin][T] (x[0] is an
+  // opaque handle to it); yh: the output is STORED as bf16 [B][Cout][T], rounded to nearest even once, after bias, out_scale
+  // and residual; rh: the residual is a bf16 tensor; gh (weight gradient only): the output gradient handed to the weight
+  // gradient is a bf16 tensor.  Honoured by conv32p_kernel, wgradp32_kernel and the element-wise kernels of the resblock /
+  // ConvNeXt32 chains; launch_conv1d refuses them on any other kernel (no silent fp32 reinterpretation of two-byte data).
+  int xh = 0, yh = 0, rh = 0, gh = 0;
 };
 // misc.hip: y16 = bf16(pro(x) * mask[b][t]) for [B*C][T] rows; pro = PRO_NONE or PRO_LRELU; mask optional
 int launch_twin_cast(const float* x, const float* mask, int pro, int B, int C, int T, __bf16* y16, hipStream_t st);

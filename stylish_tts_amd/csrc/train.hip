@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <unordered_map>
 
 #include "model.h"
@@ -236,6 +237,23 @@ struct Trainer {
     peak = ws.off > peak ? ws.off : peak;
     return p;
   }
+  // ---- bf16 STORAGE of the 75T-rate activations (bf16 compute mode) ----
+  // What autocast stores: conv outputs live in HBM as bf16 (config/config.yml:9-12, train/train_context.py:97-103).  A tensor
+  // taken with take_act(n, true) IS two bytes per element -- there is no fp32 copy -- and travels through the graph as an
+  // opaque `float*` handle; half_ records which handles are such tensors and every launch site passes the flag of each
+  // operand (ConvArgs::xh / yh / rh, the uh / xh / dh arguments of the element-wise kernels).  Kernels that have no
+  // two-byte form refuse the flag loudly (launch_conv1d, launch_conv1d_wgrad).  Gradient ACCUMULATORS (G / Gw buffers)
+  // stay fp32: they are summed into by several kernels, and the rounding points of the mode stay those of single stores.
+  std::unordered_set<const void*> half_;
+  bool act16_env = getenv("STY_NO_ACT16") == nullptr;
+  bool act16_on() const { return act16_env && m->topts.compute_bf16 != 0; }
+  bool is16(const void* p) const { return p && !half_.empty() && half_.count(p) != 0; }
+  float* take_act(size_t n, bool h) {
+    if (!h) return take<float>(n);
+    float* p = reinterpret_cast<float*>(take<__bf16>((n + 7) & ~size_t(7)));
+    half_.insert(p);
+    return p;
+  }
   // gradient buffer of an activation (zero-filled on first request)
   // Deferred LeakyReLU gates (style encoder): `ungated` holds activations a whose gradient buffer still lacks the factor
   // lrelu'(a) -- the input-gradient conv of a LeakyReLU-prologue conv wrote its raw output there (conv2d_bwd).  The next
@@ -311,6 +329,14 @@ struct Trainer {
   void conv(const ConvArgs& a0) {
     ConvArgs a = a0;
     a.bf16 = m->topts.compute_bf16;
+    a.xh = is16(a.x[0]);  // two-byte storage: the flag of each operand travels with the launch
+    a.yh = is16(a.y);
+    a.rh = is16(a.residual);
+    if (a.nsrc > 1 && (is16(a.x[1]) || is16(a.x[2]))) {
+      set_error("training: a bf16-stored tensor as source 1 / 2 of a channel-concatenated conv");
+      rc = STY_ESTATE;
+      return;
+    }
     const size_t pn = wgrad_partial_floats(a.w, B, a.T);
     side_need = pn > side_need ? pn : side_need;
     wg_need(pn);
@@ -350,7 +376,17 @@ struct Trainer {
     float* dpa = nullptr;
     float* dps = nullptr;
     float* dal = nullptr;
-    if (any) {
+    // AdaIN + Snake prologue whose (a, s) came from adain() of this very input (the resblock convs): the prologue backward,
+    // the fold and the instance-norm statistics term run as ONE launch (launch_pro_bwd_adain); adain()'s tape entry then has
+    // nothing left to do
+    AdainInfo* fuse = nullptr;
+    if (any && f.pro == PRO_AFFINE_SNAKE && f.nsrc == 1 && pro_fuse_on && Tt % 8 == 0) {
+      auto it = adain_of.find(f.pa);
+      if (it != adain_of.end() && it->second.x == f.x[0] && it->second.s == f.ps && !*it->second.done) fuse = &it->second;
+    }
+    if (any && fuse) {
+      dal = PG(f.palpha, w.Cin);
+    } else if (any) {
       if (f.pro == PRO_AFFINE_SNAKE || f.pro == PRO_AFFINE_LRELU || f.pro == PRO_AFFINE) {
         int dummy;  // pro_bwd OVERWRITES these per-(b,c) sums (each folded affine feeds exactly one conv): no zero-fill
         dpa = Gw(f.pa, (size_t)B * w.Cin, dummy);
@@ -399,7 +435,9 @@ struct Trainer {
         rc = STY_ESTATE;
         return;
       }
-      float* U = take<float>((size_t)B * w.Cin * Tt);
+      // (the input gradient of a conv whose input is a bf16 tensor is stored the same way: d loss / d prologue(x), rounded once)
+      const bool u16 = f.xh && f.nsrc == 1 && act16_on();
+      float* U = take_act((size_t)B * w.Cin * Tt, u16);
       ConvArgs d;
       d.x[0] = gY;
       d.xc[0] = w.Cout;
@@ -417,10 +455,14 @@ struct Trainer {
         d.mask = gmask;
       }
       d.y = U;
+      d.yh = u16;
+      d.xh = is16(gY);
       if (f.nsrc == 1 && (f.pro == PRO_NONE || f.pro == PRO_MASK) && gX[0] != gY) {
         // no prologue derivative to apply: the input-gradient conv writes (or accumulates, through its residual
         // operand) straight into the gradient buffer; the forward's input mask becomes an output mask
         d.y = gX[0];
+        d.yh = is16(gX[0]);
+        d.rh = d.yh;
         d.residual = accX[0] ? gX[0] : nullptr;
         if (f.pro == PRO_MASK) {
           d.out_mask = f.mask;
@@ -431,6 +473,19 @@ struct Trainer {
         return;
       }
       if (live()) chk(launch_conv1d(d, st));
+      if (fuse) {
+        *fuse->done = true;
+        if (live())
+          chk(launch_pro_bwd_adain(U, u16, f.x[0], f.xh, B, w.Cin, Tt, f.pa, f.ps, f.palpha, fuse->mean, fuse->rstd, fuse->gbl,
+                                   gX[0], is16(gX[0]), accX[0], fuse->dgl, dal, f.bf16 ? 1 : 0, st));
+        ws.off = mark;
+        return;
+      }
+      if (u16 || f.xh) {
+        set_error("training: bf16-stored conv input without the fused prologue backward");
+        rc = STY_ESTATE;
+        return;
+      }
       int c0 = 0;
       for (int i = 0; i < f.nsrc; ++i) {
         if (gX[i] && live())
@@ -514,6 +569,13 @@ struct Trainer {
   // AdaIN folded to a per-(b,c) affine (a, s) consumed by the next conv's prologue
   // have_part: the (sum, sum of squares) partials of x were left behind by the conv that produced it (conv32p_kernel,
   // ConvArgs::stat_part) -- no statistics pass over x
+  struct AdainInfo {
+    const float *x, *s, *mean, *rstd, *gbl;
+    float* dgl;
+    std::shared_ptr<bool> done;
+  };
+  std::unordered_map<const float*, AdainInfo> adain_of;  // folded scale a -> the instance norm it came from
+  bool pro_fuse_on = getenv("STY_NO_PRO_FUSE") == nullptr;
   void adain(const float* x, int C, int Tt, const AdaFc& fc, float*& a, float*& s, const double* have_part = nullptr,
              int have_nseg = 0) {
     a = take<float>((size_t)B * C);
@@ -535,7 +597,19 @@ struct Trainer {
     float* dgl = dgbp(fc);
     float* aa = a;
     float* ss = s;
+    auto done = std::make_shared<bool>(false);
+    adain_of[aa] = AdainInfo{x, ss, mean, rstd, gbl, dgl, done};
+    if (!have_part && is16(x)) {
+      set_error("training: instance-norm statistics pass over a bf16-stored tensor (the producing conv leaves them behind)");
+      rc = STY_ESTATE;
+    }
     tape.push_back([=]() {
+      if (*done) return;  // conv_bwd ran the fused prologue + statistics backward (launch_pro_bwd_adain)
+      if (is16(x)) {
+        set_error("training: AdaIN backward over a bf16-stored tensor outside the fused prologue backward");
+        rc = STY_ESTATE;
+        return;
+      }
       float* da = G(aa, (size_t)B * C);
       float* ds = G(ss, (size_t)B * C);
       float* gX = G(x, (size_t)B * C * Tt);
@@ -820,14 +894,36 @@ struct Trainer {
     a.bf16 = m->topts.compute_bf16;
     return conv32p_eligible(a);
   }
-  float* resblock(const ResBlock32& r, float* x, int Tt) {
+  // part_x: the statistics partials of x when the conv that produced x left them behind (ConvArgs::stat_part)
+  bool resblock16(const ResBlock32& r, int Tt) const {
+    // two-byte storage of the block's internal tensors: every conv of the block has to run on the persistent kernel (the only
+    // one with the two-byte input / residual / output stages) and the fused prologue backward needs T % 8 == 0
+    if (!act16_on() || !pro_fuse_on || Tt % 8 != 0) return false;
+    const int dil[3] = {1, 3, 5};
+    for (int i = 0; i < 3; ++i) {
+      ConvArgs c1, c2;
+      c1.B = c2.B = B, c1.T = c2.T = Tt, c1.nsrc = c2.nsrc = 1, c1.w = r.c1[i], c2.w = r.c2[i];
+      c1.xc[0] = c2.xc[0] = 32;
+      c1.dil = dil[i], c1.pad = 5 * dil[i], c2.pad = 5;
+      c1.pro = c2.pro = PRO_AFFINE_SNAKE;
+      c1.xh = c1.yh = c2.xh = c2.yh = c2.rh = 1;
+      if (!takes32p(c1) || !takes32p(c2)) return false;
+    }
+    return true;
+  }
+  float* resblock(const ResBlock32& r, float* x, int Tt, const double* part_x = nullptr) {
     const int dil[3] = {1, 3, 5};
     const int nseg_p = conv32p_stat_nseg(Tt);
-    const double* part_x = nullptr;
+    const bool h16 = resblock16(r, Tt);
+    if (is16(x) && (!h16 || !part_x)) {
+      set_error("training: bf16-stored resblock input without the two-byte path");
+      rc = STY_ESTATE;
+      return x;
+    }
     for (int i = 0; i < 3; ++i) {
       float *a, *s;
       adain(x, 32, Tt, r.n1[i], a, s, part_x, nseg_p);
-      float* xt = take<float>((size_t)B * 32 * Tt);
+      float* xt = take_act((size_t)B * 32 * Tt, h16);
       ConvArgs c1 = base(r.c1[i], x, Tt, xt);
       c1.dil = dil[i];
       c1.pad = 5 * dil[i];
@@ -839,7 +935,7 @@ struct Trainer {
       if (takes32p(c1)) c1.stat_part = part_t = take<double>((size_t)B * 32 * nseg_p * 2);
       conv(c1);
       adain(xt, 32, Tt, r.n2[i], a, s, part_t, nseg_p);
-      float* xn = take<float>((size_t)B * 32 * Tt);
+      float* xn = take_act((size_t)B * 32 * Tt, h16 && i + 1 < 3);  // (the block's output feeds kernels without a two-byte form)
       ConvArgs c2 = base(r.c2[i], xt, Tt, xn);
       c2.pro = PRO_AFFINE_SNAKE;
       c2.pa = a;
@@ -1925,6 +2021,8 @@ struct Trainer {
     tw_want.clear();
     tw_g.clear();
     nograd.clear();
+    half_.clear();
+    adain_of.clear();
     scratch_param_n = 1 << 20;
     scratch_param = take<float>(scratch_param_n);
     gb = take<float>(m->gb_floats_per_batch * B);
@@ -1977,12 +2075,26 @@ struct Trainer {
     }
     nograd.insert(hs);
     nograd.insert(hp);
-    float* lap0 = take<float>((size_t)B * 32 * Tu);
-    float* pp0 = take<float>((size_t)B * 32 * Tu);
-    conv(base(v.amp_prior_conv, hs, Tu, lap0));
-    conv(base(v.phase_prior_conv, hp, Tu, pp0));
-    float* lap = resblock(v.amp_prior_block, lap0, Tu);
-    float* pp = resblock(v.phase_prior_block, pp0, Tu);
+    // the prior convs' outputs are the resblocks' inputs: bf16 tensors when the blocks run the two-byte path (the persistent
+    // kernel then also leaves the instance-norm statistics of what it stored behind: no statistics pass over a bf16 tensor)
+    float* prior_out[2];
+    const double* prior_part[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) {
+      const PackedConv& pc = i ? v.phase_prior_conv : v.amp_prior_conv;
+      ConvArgs ca = base(pc, i ? hp : hs, Tu, nullptr);
+      ConvArgs probe = ca;
+      probe.yh = 1;
+      const bool h16 = resblock16(i ? v.phase_prior_block : v.amp_prior_block, Tu) && takes32p(probe);
+      prior_out[i] = ca.y = take_act((size_t)B * 32 * Tu, h16);
+      if (h16) {
+        double* p = take<double>((size_t)B * 32 * conv32p_stat_nseg(Tu) * 2);
+        ca.stat_part = p;
+        prior_part[i] = p;
+      }
+      conv(ca);
+    }
+    float* lap = resblock(v.amp_prior_block, prior_out[0], Tu, prior_part[0]);
+    float* pp = resblock(v.phase_prior_block, prior_out[1], Tu, prior_part[1]);
     // stage A
     float* x0 = take<float>((size_t)B * C * Tt);
     conv(base(v.amp_input_conv, io.mel, Tt, x0));

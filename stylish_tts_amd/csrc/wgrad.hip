@@ -1030,6 +1030,10 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   ag.in_shuffle = fwd.shuffle > 1 ? fwd.shuffle : 0;
   ag.pro = gmask ? PRO_MASK : PRO_NONE;
   ag.mask = gmask;
+  if ((fwd.xh || fwd.gh) && !(w.K > 1 && !fwd.flatW && wgradp32_eligible(ax) && !fwd.gh)) {
+    set_error("wgrad: bf16-stored operand (xh %d gh %d) on a conv wgradp32_kernel does not take", fwd.xh, fwd.gh);
+    return STY_EINVAL;
+  }
   if (w.K == 1) {
     const W1Cfg c = w1_cfg(w, fwd.B, fwd.T);
     const int nsplit = w1_nsplit(w, fwd.B, fwd.T, c, fwd.bf16 != 0);

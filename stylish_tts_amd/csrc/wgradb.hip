@@ -70,6 +70,31 @@ __device__ __forceinline__ void wb_load_row4(__amdgpu_buffer_rsrc_t rs, int row_
     }
   }
 }
+// eight consecutive samples [i0, i0 + 8) of a row of a bf16 TENSOR (two-byte storage; row_off in bytes, T even so that rows
+// start on a dword): one 16-byte load when i0 is even, a 16-byte + a 4-byte load from i0 - 1 when it is odd (the parity of
+// i0 is the parity of the conv's padding: uniform over the launch), sample by sample where the group straddles a row end
+__device__ __forceinline__ void wb_load_row8_h(__amdgpu_buffer_rsrc_t rs, int row_off, int i0, int T, float (&v)[8]) {
+  const int odd = i0 & 1, j0 = i0 - odd;
+  if (j0 >= 0 && j0 + 9 < T) {
+    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, row_off + j0 * 2, 0, 0);
+    if (!odd) {
+      v[0] = sty_bf_lo(q[0]), v[1] = sty_bf_hi(q[0]), v[2] = sty_bf_lo(q[1]), v[3] = sty_bf_hi(q[1]);
+      v[4] = sty_bf_lo(q[2]), v[5] = sty_bf_hi(q[2]), v[6] = sty_bf_lo(q[3]), v[7] = sty_bf_hi(q[3]);
+    } else {
+      const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(rs, row_off + (j0 + 8) * 2, 0, 0);
+      v[0] = sty_bf_hi(q[0]), v[1] = sty_bf_lo(q[1]), v[2] = sty_bf_hi(q[1]), v[3] = sty_bf_lo(q[2]);
+      v[4] = sty_bf_hi(q[2]), v[5] = sty_bf_lo(q[3]), v[6] = sty_bf_hi(q[3]), v[7] = sty_bf_lo(e);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool in = i0 + e >= 0 && i0 + e < T;
+      // (the dword that holds the sample: aligned, inside the row)
+      const unsigned d = __builtin_amdgcn_raw_buffer_load_b32(rs, in ? row_off + ((i0 + e) & ~1) * 2 : 0x7fffff00, 0, 0);
+      v[e] = ((i0 + e) & 1) ? sty_bf_hi(d) : sty_bf_lo(d);
+    }
+  }
+}
 __device__ __forceinline__ bf16x8 wb_pack(const float (&v)[8]) {
   return sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
@@ -768,7 +793,8 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
   const float* xsrc = multi ? (blockIdx.x == 0 ? ax.x[0] : (blockIdx.x == 1 ? ax.x[1] : ax.x[2])) : ax.x[0];
   const int Cx = multi ? 32 : ax.xc[0], Cg = ag.xc[0];
   const bool xlive = cir < ax.w.Cin;
-  const int offx = xlive ? (multi ? xr_ : cir) * T * 4 : WB_OOB;
+  const int xes = ax.xh ? 2 : 4;  // source 0 stored as bf16 (two-byte storage of the 75T-rate activations) or fp32
+  const int offx = xlive ? (multi ? xr_ : cir) * T * xes : WB_OOB;
   int offg[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) offg[m] = (grow0 + 16 * m < Cg && glive) ? (grow0 + 16 * m) * T * 4 : WB_OOB;
@@ -785,10 +811,13 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
   auto load_chunk = [&](int b, int c) {
     const int t0 = c * WP_TW;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(xsrc + (size_t)b * Cx * T), 0, Cx * T * 4, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(xsrc) + (size_t)b * Cx * T * xes), 0, Cx * T * xes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(ag.x[0] + (size_t)b * Cg * T), 0, Cg * T * 4, 0x00020000);
-    wb_load_row8(rx, offx, t0 - pad + xg8, T, xv);
+    if (ax.xh)
+      wb_load_row8_h(rx, offx, t0 - pad + xg8, T, xv);
+    else
+      wb_load_row8(rx, offx, t0 - pad + xg8, T, xv);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {  // sixteen samples: [t - 8, t + 8) with t = t0 + 8 gq
       float lo[8], hi8[8];
@@ -960,6 +989,7 @@ bool wgradp32_eligible(const ConvArgs& fwd) {
   if (getenv("STY_NO_WGRADB")) return false;  // (both modes: bf16 tiles with phase copies, or fp32 tiles)
   if (w.CinP % 32 || w.CinP > 96 || w.CoutP != 32 || w.K < 2 || w.K > 24 || (w.K - 1) * fwd.dil > 64) return false;
   if (fwd.flatW || fwd.in_shuffle > 1 || fwd.shuffle > 1 || fwd.Tin) return false;
+  if (fwd.xh && (fwd.nsrc != 1 || fwd.T % 2 != 0)) return false;  // bf16 source tensor: one source, rows on dword boundaries
   if (fwd.nsrc != 1) {  // channel-concatenated input: one 32-channel source per 32-row block
     if (fwd.nsrc != w.CinP / 32) return false;
     for (int i = 0; i < fwd.nsrc; ++i)
@@ -1027,7 +1057,8 @@ int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* p
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d d%d", w.Cin, w.Cout, w.K, ax.T, ax.dil);
   ProfScope prof(ax.bf16 ? (w.K <= 12 ? "wgradp32_kernel<3,true>" : "wgradp32_kernel<6,true>")
                          : (w.K <= 12 ? "wgradp32_kernel<3,false>" : "wgradp32_kernel<6,false>"),
-                 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T, 4.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
+                 2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T,
+                 (double)ax.B * ax.T * ((ax.xh ? 2.0 : 4.0) * w.Cin + 4.0 * w.Cout), st, detail);
   if (w.K <= 12)
     wp_launch_pro<3>(ax, ag, grid, lds, nsplit, cpb, partial, want_bias, st);
   else

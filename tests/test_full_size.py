@@ -213,7 +213,18 @@ C3_SE_KEYS = ["shared.0.weight_orig", "shared.2.conv1.weight_orig", "shared.4.co
 # float64 than 0.3 of its scale / 5e-2 in angle / 10 % in norm however ill-conditioned the graph is at this shape
 GATE_K, GATE_FLOOR, GATE_CAP = 1.5, (5e-2, 1e-3, 2e-2), (0.3, 5e-2, 0.1)
 # bf16 mode: the same construction; floors and caps of a 2^-9 arithmetic
-GATE16_FLOOR, GATE16_CAP = (1e-1, 1e-2, 5e-2), (0.9, 0.45, 0.25)
+GATE16_FLOOR, GATE16_CAP = (1e-1, 1e-2, 5e-2), (0.5, 0.1, 0.25)
+# Tensors whose gradient under THIS loss at THIS shape fp32 arithmetic does not determine: the fp32 oracle itself sits 0.27 ... 0.89
+# of the tensor's scale (cosine down to 0.65) from the float64 oracle on the same 32 utterances (profiles/r05_c3_parity_table.txt)
+# -- the anti-wrapping phase loss flips branches on 7th-digit differences of the waveform, and these are the deepest tensors
+# behind it.  No cap can hold them in the full step (HIP sits where the fp32 oracle sits: 1.0-1.25 x its distance); they are
+# held at 1.5 x the fp32 oracle's own distance here and PINNED at the same B = 32 / T = 520 / L = 100 under a well-conditioned
+# cotangent by test_c3_backward_full_size_under_a_well_conditioned_loss (3e-2 of the scale; measured <= 4e-3).  Every other
+# tensor must have a reference distance under the cap -- a tensor that newly needs this list fails the test.
+C3_ILL_CONDITIONED = {("sp", "generator.basegen.amp_prior_block.convs1.1.parametrizations.weight.original1"),
+                      ("sp", "decoder.decode.0.norm1.fc.weight"),
+                      ("sp", "decoder.decode.1.conv1.parametrizations.weight.original1"),
+                      ("sp", "text_encoder.emb.weight")}
 
 
 def _table_line(key, d, y, gate, ok):
@@ -304,7 +315,9 @@ def test_c3_train_step_full_size_vs_oracle():
         return {("sp", k): nsp[k].grad.detach().cpu().double() for k in sp_keys} | \
                {("se", k): nse[k].grad.detach().cpu().double() for k in se_keys}
 
-    def gate(y, floor, cap):
+    def gate(key, y, floor, cap):
+        if key in C3_ILL_CONDITIONED:  # held to the reference arithmetic's own distance, pinned elsewhere (see the list)
+            return tuple(max(floor[i], GATE_K * y[i]) for i in range(3))
         return tuple(min(cap[i], max(floor[i], GATE_K * y[i])) for i in range(3))
 
     table = [f"c3 train step, B = {w['B']}, T = {w['T']}, L = {w['L']}: per-tensor distance to the FLOAT64 oracle "
@@ -323,9 +336,12 @@ def test_c3_train_step_full_size_vs_oracle():
     table.append("fp32: HIP vs float64 (ref = fp32 oracle vs float64, all 32 utterances)")
     for key in keys:
         d, y = _dist(gh[key], g64[key]), _dist(g32[key], g64[key])
-        gt = gate(y, GATE_FLOOR, GATE_CAP)
+        gt = gate(key, y, GATE_FLOOR, GATE_CAP)
         ok = all(d[i] <= gt[i] for i in range(3))
-        table.append(_table_line(key, d, y, gt, ok))
+        if key not in C3_ILL_CONDITIONED and not all(y[i] <= GATE_CAP[i] for i in range(3)):
+            ok = False  # the fp32 oracle itself is beyond the cap: the tensor belongs on the list, with a pin of its own
+        table.append(_table_line(key, d, y, gt, ok) + ("  [ill-conditioned under this loss: pinned by the well-conditioned test]"
+                                                       if key in C3_ILL_CONDITIONED else ""))
         if not ok:
             bad.append((key, d, gt))
     del tr
@@ -344,10 +360,12 @@ def test_c3_train_step_full_size_vs_oracle():
     cosines = []
     for key in keys:
         d, y = _dist(ghb[key], g64[key]), _dist(g16_c0[key], g64_c0[key])
-        gt = gate(y, GATE16_FLOOR, GATE16_CAP)
+        gt = gate(key, y, GATE16_FLOOR, GATE16_CAP)
+        if key in C3_ILL_CONDITIONED:  # (the yardstick is an 8-utterance chunk; these tensors are noise-dominated on both sides)
+            gt = (max(gt[0], 1.2), max(gt[1], 0.6), max(gt[2], 0.4))
         ok = all(d[i] <= gt[i] for i in range(3))
         cosines.append(1.0 - d[1])
-        table.append(_table_line(key, d, y, gt, ok))
+        table.append(_table_line(key, d, y, gt, ok) + ("  [ill-conditioned]" if key in C3_ILL_CONDITIONED else ""))
         if not ok:
             badb.append((key, d, gt))
     cosines.sort()
@@ -358,6 +376,72 @@ def test_c3_train_step_full_size_vs_oracle():
     assert mseb <= 2e-2 * power and l1b <= 3e-2
     assert abs(lb[0].item() - mel) <= 1e-3 * abs(mel) and abs(lb[1].item() - mph) <= 1e-3 * abs(mph)
     assert cosines[len(cosines) // 2] >= 0.9 and not badb, badb
+
+
+def test_c3_backward_full_size_under_a_well_conditioned_loss():
+    """The backward of the whole predictor at c3's OWN size (B = 32, T = 520, L = 100: the benchmark's grids, split-K choices
+    and weight-gradient splits) under a cotangent that does not amplify fp32 rounding: d <audio, R> with R = sign(oracle
+    audio) / N fixed on both sides (d mean|audio|, the small tests' cotangent).  The acoustic losses make four of the listed
+    tensors undeterminable in fp32 at this shape (C3_ILL_CONDITIONED); the kernels that produce them are the same under any
+    cotangent, and under this one EVERY listed tensor -- the embedding and the deep text-encoder weights included -- is held
+    at 3e-2 of its scale / 1 - cos 1e-3 against the fp32 oracle's autograd (eval-mode graph: no op couples utterances, the
+    oracle sums the gradient over chunks of 8).  bf16 mode on the same inputs: against the same oracle gradient at
+    0.25 / 3e-2 (the mode's own rounding on a well-conditioned graph)."""
+    import stylish_tts_amd as S
+    from oracle import frontend, speech_predictor as osp
+    _oracle_threads()
+    w, inp = _inputs("c3", 4242)
+    _, _, P, _ = _models()
+    g = torch.Generator().manual_seed(9)
+    B = w["B"]
+    style = torch.randn(B, 64, generator=g)
+    energy = torch.randn(B, w["T"], generator=g)
+    ali = frontend.duration_to_alignment(inp["durations"])
+    voiced = (inp["pitch"] > 20).float()
+    keys = [k for k in C3_SP_KEYS if k in P and P[k].is_floating_point()]
+    Pd = {k: v.detach().clone() for k, v in P.items()}
+    for k in keys:
+        Pd[k].requires_grad_(True)
+    st = style.clone().requires_grad_(True)
+    audio, priors, cot = [], [], []
+    t0 = time.perf_counter()
+    for i in range(0, B, 8):
+        r = slice(i, i + 8)
+        want = {}
+        a = osp.speech_predictor(Pd, inp["texts"][r], inp["text_lengths"][r], ali[r], inp["pitch"][r], energy[r], voiced[r],
+                                 st[r], inp["pitch"][r], inp["noise"][r], want)
+        R = torch.sign(a.detach()) / (a[0].numel() * B)
+        (a * R).sum().backward()
+        audio.append(a.detach())
+        priors.append(want["prior"])
+        cot.append(R)
+    ref, prior, R = torch.cat(audio), torch.cat(priors), torch.cat(cot)
+    print(f"\n  fp32 oracle forward + backward of the predictor (B = {B}, chunks of 8): {time.perf_counter() - t0:.1f} s")
+    lines = [f"c3 predictor backward under d<audio, sign(audio)/N>, B = {B}, T = {w['T']}, L = {w['L']}: HIP vs the fp32 oracle's autograd"]
+    bad = []
+    for mode, tol_e, tol_c in (("fp32", 3e-2, 1e-3), ("bf16", 0.25, 3e-2)):
+        m = S.SpeechPredictor()
+        m.load_state_dict({k: v.detach() for k, v in P.items()}, strict=False)
+        m = m.to(DEV).enable_training().set_train_opts(compute_bf16=(mode == "bf16"))
+        a = m.forward_train(dev(inp["texts"]), dev(inp["text_lengths"]), dev(ali), dev(inp["pitch"]), dev(energy), dev(voiced),
+                            dev(style), dev(inp["pitch"]), noise=dev(inp["noise"]), prior_override=dev(prior))
+        d_style, _ = m.backward(dev(R), want_energy=False)
+        torch.cuda.synchronize()
+        mse = ((a.cpu() - ref) ** 2).mean().item()
+        lines.append(f" {mode}: audio mse {mse:.3e}")
+        if mode == "fp32":
+            assert mse <= 1e-8
+        named = dict(m.named_parameters())
+        for name, got, r_ in [("d style", d_style, st.grad)] + [("d " + k[-50:], named[k].grad, Pd[k].grad) for k in keys]:
+            d = _dist(got.detach().cpu(), r_)
+            ok = d[0] <= tol_e and d[1] <= tol_c
+            lines.append(f"  {mode} {name:54s} err {d[0]:.2e}  1-cos {d[1]:.2e}  |norm-1| {d[2]:.2e}  {'ok' if ok else 'FAIL'}")
+            if not ok:
+                bad.append((mode, name, d))
+        del m
+    print("\n".join(lines))
+    _write_table("c3_well_conditioned_table.txt", lines)
+    assert not bad, bad
 
 
 def test_c3_train_mode_full_size_vs_oracle():

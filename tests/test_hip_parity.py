@@ -336,6 +336,68 @@ def test_block_bf16_mode_vs_float64_oracle_on_rounded_operands(env, kind, prefix
     rep.done()
 
 
+@pytest.mark.parametrize("prefix,T", [("generator.basegen.amp_prior_block", 704), ("generator.basegen.phase_prior_block", 1544)])
+def test_resblock_bf16_storage_vs_float64_oracle_with_the_same_rounding_points(env, prefix, T, monkeypatch):
+    """bf16 STORAGE of the resblock's internal tensors (conv32p_kernel's two-byte input / residual /
+    output stages, wgradp32_kernel's two-byte source, the fused prologue + instance-norm backward pro_bwd_adain_kernel) against
+    the float64 oracle with the SAME rounding points (oracle.blocks.bf16_operands(storage=True): conv outputs inside the block
+    rounded once after bias / residual, the input gradient of a conv on a stored tensor rounded once) at the tolerance of the
+    operand-rounding test above.  The persistent kernel is forced onto these small shapes (STY_CONV32P_MIN_TILES=1); the
+    same block with STY_NO_ACT16=1 (fp32 storage) must differ from it -- the rounding is real -- and sit within the same
+    tolerance of the oracle WITHOUT the storage rule."""
+    import stylish_tts_amd as S
+    from oracle import blocks
+    monkeypatch.setenv("STY_CONV32P_MIN_TILES", "1")
+    P = {k: v.clone() for k, v in env["P"].items()}
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(2, 32, T, generator=g)
+    style = torch.randn(2, 64, generator=g)
+    gy = torch.randn(2, 32, T, generator=g)
+    outs = {}
+    for storage in (True, False):
+        if not storage:
+            monkeypatch.setenv("STY_NO_ACT16", "1")
+        P64 = _f64(P)
+        keys = [k for k in P64 if k.startswith(prefix + ".") and P64[k].is_floating_point()]
+        for k in keys:
+            P64[k].requires_grad_(True)
+        x64, s64 = x.double().requires_grad_(True), style.double().requires_grad_(True)
+        with blocks.bf16_operands(storage=storage):
+            y64 = blocks.gen_resblock(P64, prefix, x64, s64)
+            (y64 * gy.double()).sum().backward()
+        m = S.SpeechPredictor()
+        m.load_state_dict(P, strict=False)
+        m = m.to(DEV).enable_training()
+        m._ensure(torch.device(DEV))
+        for p_ in m.parameters():
+            p_.grad.zero_()
+        y, gx, d_style = m.block_forward_backward("resblock", prefix, dev(x), dev(style), dev(gy), compute_bf16=True)
+        torch.cuda.synchronize()
+        outs[storage] = (y.cpu(), gx.cpu())
+        rep = Report()
+        tol = 6e-3
+        rep.add(f"y (storage={storage})", y, y64.detach().float(), tol)
+        rep.add("d x", gx, x64.grad.float(), tol)
+        rep.add("d style", d_style, s64.grad.float(), tol)
+        named = dict(m.named_parameters())
+        for k in keys:
+            if P64[k].grad is None or k not in named:
+                continue
+            ref = P64[k].grad.float()
+            if ref.abs().max().item() < 1e-7 * max(1.0, gy.abs().max().item()):
+                continue
+            k1 = k.replace("original0", "original1")
+            if k.endswith(".original0") and k1 in keys:
+                terms = (P64[k1].grad.abs() * P64[k1].detach().abs()).sum(dim=(1, 2), keepdim=True) / P64[k].detach().abs()
+                if ref.abs().max().item() < 1e-3 * terms.max().item():
+                    continue
+            rep.add("d " + k[len(prefix) + 1:], named[k].grad, ref, tol)
+        rep.done()
+    dy = (outs[True][0] - outs[False][0]).abs().max().item() / outs[False][0].abs().max().item()
+    print(f"  two-byte storage vs fp32 storage: y differs by {dy:.2e} of its scale")
+    assert 1e-5 < dy < 5e-2, dy
+
+
 def test_convnext32_block_bf16_mode_vs_fp32_mode(env):
     """The fused ConvNeXt32 backward in the bf16 compute mode (its three GEMMs on v_mfma_f32_32x32x16_bf16, the chained
     one with the accumulator fragment as B operand in the permuted row order) against the SAME kernels in fp32 mode:
