@@ -173,6 +173,10 @@ int sty_attention_fwd_bwd(int B, int H, int DH, int T, const float *q, const flo
 /* STFT(64, hop 4).transform -> (mag, atan2(y,x)) bins 0..31, last frame dropped (generator.py:724-729);
  * wave [B,N] -> spec, phase [B,32,N/4].                                                               */
 int sty_stft64_fwd(int B, int N, const float *wave, float *spec, float *phase, void *stream);
+/* the bases sty_stft64_fwd / sty_istft64_fwd use when a model binds none: the reference's registered buffers
+ * (models/stft.py:39-96, to 2 ulp) forward_real, forward_imag, backward_real, backward_imag, each [33][64];
+ * out = HOST memory, 4 * 33 * 64 floats.                                                              */
+void sty_stft64_bases_host(float *out);
 /* synthesis head: exp/atan2-free cos,sin + conv-transpose iSTFT + tanh (generator.py:782-799,896);
  * logamp, real, imag [B,32,F] -> audio [B,1,4F].                                                      */
 int sty_istft64_fwd(int B, int F, const float *logamp, const float *real, const float *imag, float *audio,

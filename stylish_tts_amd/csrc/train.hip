@@ -478,10 +478,12 @@ struct Trainer {
         if (live())
           chk(launch_pro_bwd_adain(U, u16, f.x[0], f.xh, B, w.Cin, Tt, f.pa, f.ps, f.palpha, fuse->mean, fuse->rstd, fuse->gbl,
                                    gX[0], is16(gX[0]), accX[0], fuse->dgl, dal, f.bf16 ? 1 : 0, st));
+        half_.erase(U);  // (a temporary: the address is handed out again as soon as the mark is restored)
         ws.off = mark;
         return;
       }
       if (u16 || f.xh) {
+        half_.erase(U);
         set_error("training: bf16-stored conv input without the fused prologue backward");
         rc = STY_ESTATE;
         return;

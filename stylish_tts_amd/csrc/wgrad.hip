@@ -832,7 +832,9 @@ int wgrad_defer_flush(WgReduceDefer* d, int site, hipStream_t st) {
       tab.push_back(j);
     }
     if (tab.empty()) continue;
-    const size_t slot_i = (size_t)site * 4 + (size_t)(r < 3 ? r : 3);
+    // one device table per (site, round): sites take slots 0, 64, 128, ... and a site's rounds the slots behind its own (a
+    // flush with more overlap rounds than that is not a graph of this library; it would fall back to re-uploading round 63+)
+    const size_t slot_i = (size_t)site * 64 + (size_t)(r < 63 ? r : 63);
     if (d->slots.size() <= slot_i) d->slots.resize(slot_i + 1);
     WgReduceSlot& sl = d->slots[slot_i];
     const size_t nbytes = tab.size() * sizeof(WgReduceJob);

@@ -71,28 +71,31 @@ __device__ __forceinline__ void wb_load_row4(__amdgpu_buffer_rsrc_t rs, int row_
   }
 }
 // eight consecutive samples [i0, i0 + 8) of a row of a bf16 TENSOR (two-byte storage; row_off in bytes, T even so that rows
-// start on a dword): one 16-byte load when i0 is even, a 16-byte + a 4-byte load from i0 - 1 when it is odd (the parity of
-// i0 is the parity of the conv's padding: uniform over the launch), sample by sample where the group straddles a row end
-__device__ __forceinline__ void wb_load_row8_h(__amdgpu_buffer_rsrc_t rs, int row_off, int i0, int T, float (&v)[8]) {
-  const int odd = i0 & 1, j0 = i0 - odd;
+// start on a dword and a dword never straddles a row end): the five dwords that hold samples [i0 & ~1, (i0 & ~1) + 10) are
+// REQUESTED here and unpacked where they are used (wb_unpack_row8_h) -- a conversion at the load would wait for the load
+// and make the prefetch of the next chunk synchronous.  One 16-byte + one 4-byte load inside the row, dword by dword (from
+// an out-of-range offset, which loads 0, outside [0, T)) where the group straddles a row end.
+__device__ __forceinline__ void wb_load_row8_h(__amdgpu_buffer_rsrc_t rs, int row_off, int i0, int T, unsigned (&raw)[5]) {
+  const int j0 = i0 & ~1;
   if (j0 >= 0 && j0 + 9 < T) {
     const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, row_off + j0 * 2, 0, 0);
-    if (!odd) {
-      v[0] = sty_bf_lo(q[0]), v[1] = sty_bf_hi(q[0]), v[2] = sty_bf_lo(q[1]), v[3] = sty_bf_hi(q[1]);
-      v[4] = sty_bf_lo(q[2]), v[5] = sty_bf_hi(q[2]), v[6] = sty_bf_lo(q[3]), v[7] = sty_bf_hi(q[3]);
-    } else {
-      const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(rs, row_off + (j0 + 8) * 2, 0, 0);
-      v[0] = sty_bf_hi(q[0]), v[1] = sty_bf_lo(q[1]), v[2] = sty_bf_hi(q[1]), v[3] = sty_bf_lo(q[2]);
-      v[4] = sty_bf_hi(q[2]), v[5] = sty_bf_lo(q[3]), v[6] = sty_bf_hi(q[3]), v[7] = sty_bf_lo(e);
-    }
+    raw[0] = q[0], raw[1] = q[1], raw[2] = q[2], raw[3] = q[3];
+    raw[4] = __builtin_amdgcn_raw_buffer_load_b32(rs, row_off + (j0 + 8) * 2, 0, 0);
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool in = i0 + e >= 0 && i0 + e < T;
-      // (the dword that holds the sample: aligned, inside the row)
-      const unsigned d = __builtin_amdgcn_raw_buffer_load_b32(rs, in ? row_off + ((i0 + e) & ~1) * 2 : 0x7fffff00, 0, 0);
-      v[e] = ((i0 + e) & 1) ? sty_bf_hi(d) : sty_bf_lo(d);
+    for (int d = 0; d < 5; ++d) {
+      const int j = j0 + 2 * d;
+      raw[d] = __builtin_amdgcn_raw_buffer_load_b32(rs, (j >= 0 && j < T) ? row_off + j * 2 : 0x7fffff00, 0, 0);
     }
+  }
+}
+__device__ __forceinline__ void wb_unpack_row8_h(const unsigned (&raw)[5], int odd, float (&v)[8]) {
+  if (!odd) {
+    v[0] = sty_bf_lo(raw[0]), v[1] = sty_bf_hi(raw[0]), v[2] = sty_bf_lo(raw[1]), v[3] = sty_bf_hi(raw[1]);
+    v[4] = sty_bf_lo(raw[2]), v[5] = sty_bf_hi(raw[2]), v[6] = sty_bf_lo(raw[3]), v[7] = sty_bf_hi(raw[3]);
+  } else {
+    v[0] = sty_bf_hi(raw[0]), v[1] = sty_bf_lo(raw[1]), v[2] = sty_bf_hi(raw[1]), v[3] = sty_bf_lo(raw[2]);
+    v[4] = sty_bf_hi(raw[2]), v[5] = sty_bf_lo(raw[3]), v[6] = sty_bf_hi(raw[3]), v[7] = sty_bf_lo(raw[4]);
   }
 }
 __device__ __forceinline__ bf16x8 wb_pack(const float (&v)[8]) {
@@ -806,6 +809,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
     }
   }
   float xv[8], gv[2][16], pa = 1.f, ps = 0.f, xm[8], gm[16], bsum[2] = {0.f, 0.f};
+  unsigned xraw[5] = {0u, 0u, 0u, 0u, 0u};  // bf16 source tensor: the dwords of the group, unpacked when it is staged
   const int total = ax.B * chunks_per_b;
   int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
   auto load_chunk = [&](int b, int c) {
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(ag.x[0] + (size_t)b * Cg * T), 0, Cg * T * 4, 0x00020000);
     if (ax.xh)
-      wb_load_row8_h(rx, offx, t0 - pad + xg8, T, xv);
+      wb_load_row8_h(rx, offx, t0 - pad + xg8, T, xraw);
     else
       wb_load_row8(rx, offx, t0 - pad + xg8, T, xv);
 #pragma unroll
@@ -865,6 +869,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
     __syncthreads();
     {  // x
       float v[8];
+      if (ax.xh) wb_unpack_row8_h(xraw, (t0 - pad + xg8) & 1, xv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float mk = 1.f;

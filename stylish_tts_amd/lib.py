@@ -63,6 +63,7 @@ _P, _I, _SZP = C.c_void_p, C.c_int, C.POINTER(C.c_size_t)
 SYMBOLS = {
     "sty_version": (C.c_int, []),
     "sty_last_error": (C.c_char_p, []),
+    "sty_stft64_bases_host": (None, [_P]),
     "sty_model_create": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "sty_model_destroy": (None, [_P]),
     "sty_model_bind": (C.c_int, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64)]),

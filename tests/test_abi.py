@@ -29,6 +29,32 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.sty_version() >= 1
 
 
+def test_every_exported_symbol_is_declared(lib):
+    """the other direction: nothing `sty_*` leaves the library without a declaration in include/stylish_hip.h (round 4:
+    sty_stft64_bases_host was exported and undeclared)"""
+    import subprocess
+    from stylish_tts_amd import build as sbuild, lib as L
+    out = subprocess.run(["nm", "-D", "--defined-only", sbuild.LIB], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and re.fullmatch(r"sty_[a-z0-9_]+", ln.split()[-1])}
+    assert exported == set(L.SYMBOLS), exported ^ set(L.SYMBOLS)
+
+
+def test_default_stft_bases_are_the_reference_buffers(lib):
+    """sty_stft64_bases_host (host only: no device needed) against the buffers the reference's STFT module registers
+    (tests/golden/stft_buffers.safetensors, dumped by tools/gen_golden.py): within 2 ulp of fp32 (the library's host
+    builder rounds a double-precision product once; the module shells bind the reference's buffers bit for bit, see
+    test_module_shells_have_reference_state_dict_layout -- these defaults serve the stand-alone entry points)"""
+    import ctypes as C
+    from safetensors.torch import load_file
+    bufs = load_file(os.path.join(ROOT, "tests", "golden", "stft_buffers.safetensors"))
+    out = (C.c_float * (4 * 33 * 64))()
+    lib.sty_stft64_bases_host(out)
+    got = torch.tensor(list(out)).view(4, 33, 64)
+    for i, k in enumerate(("weight_forward_real", "weight_forward_imag", "weight_backward_real", "weight_backward_imag")):
+        ref = bufs[k][:, 0, :]
+        assert (got[i] - ref).abs().max().item() <= 2.4e-7 * ref.abs().max().item(), k
+
+
 def test_error_paths_without_gpu(lib):
     import ctypes as C
     h = C.c_void_p()

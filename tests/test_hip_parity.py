@@ -375,9 +375,18 @@ def test_resblock_bf16_storage_vs_float64_oracle_with_the_same_rounding_points(e
         torch.cuda.synchronize()
         outs[storage] = (y.cpu(), gx.cpu())
         rep = Report()
-        tol = 6e-3
+        # (a STORED value that rounds the other way because fp32 and float64 differ in its 7th digit moves by one bf16 ulp,
+        # 2^-7 of its magnitude, where an operand flip moved one product of 352: the max-norm gate is two such flips wide,
+        # and the flips are sparse -- the relative L2 distance stays at the operand test's level)
+        tol = 1.6e-2 if storage else 6e-3
         rep.add(f"y (storage={storage})", y, y64.detach().float(), tol)
         rep.add("d x", gx, x64.grad.float(), tol)
+        # (relative L2: y behind two stored tensors, d x behind five stored tensors and six stored input gradients)
+        for name, got, ref_, t2 in (("y", y, y64.detach(), 4e-3), ("d x", gx, x64.grad, 1e-2)):
+            l2 = ((got.detach().cpu().double() - ref_) ** 2).sum().sqrt().item() / ref_.norm().item()
+            rep.rows.append(f"  {name + ' (relative L2)':32s} rel_err {l2:9.3e}  tol {t2:.1e}  {'ok' if l2 <= t2 else 'FAIL'}")
+            if l2 > t2:
+                rep.bad.append(name + " L2")
         rep.add("d style", d_style, s64.grad.float(), tol)
         named = dict(m.named_parameters())
         for k in keys:

@@ -32,11 +32,18 @@ def main():
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for bf in modes:
-            variants = (("old kernel", dict(STY_NO_CONV32P_CALL="1")), ("conv32p", {}), ("conv32p dbg=1 (1 tap)", dict(STY_P_DBG="1")),
+            variants = (("old kernel", dict(STY_NO_CONV32P_CALL="1")), ("conv32p", {}),
+                        ("conv32p bf16 source", dict(STY_P_FORCE_H="1")), ("conv32p bf16 output", dict(STY_P_FORCE_H="2")),
+                        ("conv32p bf16 source+output", dict(STY_P_FORCE_H="3")),
+                        ("conv32p bf16 src+out, no staging", dict(STY_P_FORCE_H="3", STY_P_DBG="2")),
+                        ("conv32p bf16 src+out, no epilogue", dict(STY_P_FORCE_H="3", STY_P_DBG="4")),
+                        ("conv32p dbg=1 (1 tap)", dict(STY_P_DBG="1")),
                              ("conv32p dbg=2 (no staging)", dict(STY_P_DBG="2")), ("conv32p dbg=4 (no epilogue)", dict(STY_P_DBG="4")),
                              ("conv32p dbg=6 (MFMA only)", dict(STY_P_DBG="6")))
             for tag, env in (variants[1:2] if plain else variants):
-                for k in ("STY_P_DBG", "STY_CONV32P_MIN_TILES"):
+                if bf == 0 and "STY_P_FORCE_H" in env:
+                    continue
+                for k in ("STY_P_DBG", "STY_CONV32P_MIN_TILES", "STY_P_FORCE_H"):
                     os.environ.pop(k, None)
                 if "STY_NO_CONV32P_CALL" in env:
                     os.environ["STY_CONV32P_MIN_TILES"] = "1000000000"
