@@ -144,20 +144,80 @@ _DENSE = {"bf16": False, "store16": False}
 
 
 class bf16_operands:
-    def __init__(self, storage=False):
+    """storage: the two-byte storage rule above.  all_dense: EVERY dense conv of the oracle (groups == 1 F.conv1d / F.conv2d
+    in blocks, text_encoder, vocoder, style_encoder, predictors -- the product runs every one of them, Linears included, as a
+    conv with bf16-rounded operands in this mode) follows the operand rule, not only the block functions that call
+    dense_conv1d: the yardstick of the full-size bf16-mode gates (tests/test_full_size.py).  Depthwise convs, norms, the
+    style fc Linears, attention and the loss front ends stay exact, as in the product."""
+
+    def __init__(self, storage=False, all_dense=False):
         self.storage = storage
+        self.all_dense = all_dense
+        self.patched = []
 
     def __enter__(self):
         self.prev = dict(_DENSE)
         _DENSE["bf16"] = True
         _DENSE["store16"] = bool(self.storage)
+        if self.all_dense:
+            import importlib
+            for name in ("blocks", "text_encoder", "vocoder", "style_encoder", "predictors"):
+                mod = importlib.import_module("oracle." + name)
+                if hasattr(mod, "F") and not isinstance(mod.F, _FProxy):
+                    self.patched.append((mod, mod.F))
+                    mod.F = _FProxy(mod.F)
 
     def __exit__(self, *a):
+        for mod, real in self.patched:
+            mod.F = real
+        self.patched = []
         _DENSE.update(self.prev)
 
 
 def bf(t):
     return t.detach().float().bfloat16().to(t.dtype)
+
+
+class _BfConvNd(torch.autograd.Function):
+    """F.conv1d / F.conv2d (groups == 1) with both operands of each of its three GEMMs rounded to bf16"""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, dilation):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, dilation)
+        f = torch.nn.functional.conv1d if w.dim() == 3 else torch.nn.functional.conv2d  # (not `F`: it may be the proxy)
+        return f(bf(x), bf(w), None, stride=stride, padding=padding, dilation=dilation)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation = ctx.cfg
+        gi = torch.nn.grad.conv1d_input if w.dim() == 3 else torch.nn.grad.conv2d_input
+        gw = torch.nn.grad.conv1d_weight if w.dim() == 3 else torch.nn.grad.conv2d_weight
+        return (gi(x.shape, bf(w), bf(gy), stride=stride, padding=padding, dilation=dilation),
+                gw(bf(x), w.shape, bf(gy), stride=stride, padding=padding, dilation=dilation), None, None, None)
+
+
+class _FProxy:
+    """torch.nn.functional with the dense convs replaced (bf16_operands(all_dense=True)); everything else passes through"""
+
+    def __init__(self, real):
+        self._r = real
+
+    def __getattr__(self, n):
+        return getattr(self._r, n)
+
+    def _conv(self, real, x, w, b, stride, padding, dilation, groups):
+        if groups != 1 or not _DENSE["bf16"] or isinstance(padding, str):
+            return real(x, w, b, stride=stride, padding=padding, dilation=dilation, groups=groups)
+        y = _BfConvNd.apply(x, w, stride, padding, dilation)
+        return y if b is None else y + b.view(1, -1, *([1] * (w.dim() - 2)))
+
+    def conv1d(self, x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        return self._conv(self._r.conv1d, x, w, b, stride, padding, dilation, groups)
+
+    def conv2d(self, x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        return self._conv(self._r.conv2d, x, w, b, stride, padding, dilation, groups)
 
 
 def store16(t, on=True):
@@ -172,7 +232,7 @@ class _BfConv1d(torch.autograd.Function):
     def forward(ctx, x, w, padding, dilation, round_gx):
         ctx.save_for_backward(x, w)
         ctx.pd = (padding, dilation, round_gx)
-        return F.conv1d(bf(x), bf(w), None, padding=padding, dilation=dilation)
+        return torch.nn.functional.conv1d(bf(x), bf(w), None, padding=padding, dilation=dilation)
 
     @staticmethod
     def backward(ctx, gy):

@@ -441,6 +441,17 @@ static int wgrad64_nsplit(const PackedConv& w, int B, int T, bool bf16 = false) 
   return wg_cap_partial(nsplit, w, B, T);
 }
 
+// wgradb16_kernel's 128 x 64 / 128 x 96 blocks (round 5; 240-248 registers, two workgroups per CU): the split count that puts
+// ~512 workgroups on the chip for `blocks` workgroups per split
+int wgradb16_blocks(const ConvArgs& ax);  // wgradb.hip
+static int wgrad16_nsplit(int blocks, const PackedConv& w, int B, int T) {
+  int ns = cdiv(512, blocks);
+  if (ns >= 8) ns = (ns + 7) & ~7;
+  const int chunks = B * cdiv(T, 128);
+  if (ns > chunks) ns = chunks;
+  return wg_cap_partial(ns, w, B, T);
+}
+
 // ---- K == 1 (Linear / 1x1 conv) weight gradient: dW[co][ci] = sum_{b,t} G[co][t] x[ci][t] ----
 // The general kernel above gives each workgroup ONE 32x32 output tile, so for K == 1 a wave issues 16 MFMAs per pair
 // of staged tiles and the kernel is staging-bound (10-15 TFLOP/s).  Here a workgroup owns a (32 WI MI) x (32 WO MO)
@@ -902,6 +913,12 @@ size_t wgrad_partial_floats(const PackedConv& w, int B, int T) {  // B = batch x
   if (w.K == 1) return (size_t)w1_nsplit(w, B, T, w1_cfg(w, B, T)) * ((size_t)w.CinP * w.CoutP + w.CoutP);
   size_t n64 = 0;
   if (wgrad64_ok(w, 1)) n64 = (size_t)wgrad64_nsplit(w, B, T) * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
+  if (wgrad64_ok(w, 1) && w.K == 3 && w.CinP >= 128) {  // wgradb16_kernel's larger blocks: fewer workgroups per split, more splits
+    const int b2 = cdiv(w.CinP, 128) * cdiv(w.CoutP, 64), b3 = w.CoutP <= 96 ? cdiv(w.CinP, 128) : b2;
+    const int n2 = wgrad16_nsplit(b2, w, B, T), n3 = wgrad16_nsplit(b3, w, B, T);
+    const size_t n16 = (size_t)(n2 > n3 ? n2 : n3) * ((size_t)w.K * w.CinP * w.CoutP + w.CoutP);
+    n64 = n16 > n64 ? n16 : n64;
+  }
   const int tiles = (w.CinP / 32) * (w.CoutP / 32);
   const int chunks = B * cdiv(T, WG_TW);
   int nsplit = cdiv(tiles >= 16 ? WG_TARGET : WG_TARGET / 2, tiles);  // few tiles: keep the partial planes small
@@ -1102,9 +1119,11 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
   if (wgrad64_ok(w, fwd.dil) && wgrad64_operands_ok(fwd) && wgradb_eligible(ax, gmask != nullptr)) {
     const int chunks = wgradb_chunks(w, fwd.B, fwd.T, fwd.dil);
     int ns = wgrad64_nsplit(w, fwd.B, fwd.T, fwd.bf16 != 0);
+    const bool tw16 = wgradb16_eligible(ax);
+    if (tw16 && wgradb16_blocks(ax) != cdiv(w.CinP, 64) * cdiv(w.CoutP, 64)) ns = wgrad16_nsplit(wgradb16_blocks(ax), w, fwd.B, fwd.T);
     if (ns > chunks) ns = chunks;
     const int wb = gbias != nullptr;
-    int rc = wgradb16_eligible(ax) ? launch_wgradb16(ax, ns, partial, wb, st) : launch_wgradb(ax, ag, ns, partial, wb, st);
+    int rc = tw16 ? launch_wgradb16(ax, ns, partial, wb, st) : launch_wgradb(ax, ag, ns, partial, wb, st);
     if (rc) return rc;
     const size_t plane = (size_t)w.K * w.CinP * w.CoutP;
     launch_wgrad_reduce(partial, ns, plane, plane + w.CoutP, wb ? w.CoutP : 0, scale, gwp, gbias, st);

@@ -474,23 +474,30 @@ __device__ __forceinline__ void wb16_slow(__amdgpu_buffer_rsrc_t rs, int row_off
   for (int j = 0; j < N; ++j) d[j] = wb16_one(rs, row_off, i0 + 2 * j, T) | (wb16_one(rs, row_off, i0 + 2 * j + 1, T) << 16);
 }
 
-template <int KN, int TW, int F>
+// Block shape: the four waves are arranged WI x (4 / WI) over (ci, co), each owns FI x FO 32 x 32 fragments, i.e. a workgroup
+// owns 32 FI WI input channels x 32 FO (4 / WI) output channels of dW for all taps:
+//   <1,1,2>  64 x 64    (rounds 3-4: per 128-sample chunk a block fetches 16 KB of x and 16 KB of G for 3.1 MFLOP at K = 3)
+//   <2,2,2>  128 x 128  (K = 1, wide layers)
+//   <2,1,2>  128 x 64   round 5: half the G fetches per output, 6 MFMAs per G window + 2 x fragments (3 : 1 + 1 before)
+//   <1,3,4>  128 x 96   round 5, Cout <= 96 (the first two style-encoder stages, Cout = 80, were 1.6 x padded on 2 x 64 output
+//                       channels: 1.2 x on 96): 9 MFMAs per x fragment + 3 G windows
+template <int KN, int TW, int FI, int FO, int WI>
 __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nsplit, int chunks_per_b,
                                                           float* __restrict__ partial, int want_bias) {
   extern __shared__ __attribute__((aligned(16))) __bf16 wb_lds[];
   constexpr int PITCH = TW + 8;
-  constexpr int R = 64 * F;
-  __bf16* xs = wb_lds;                // [R][PITCH]
+  constexpr int WO = 4 / WI, RX = 32 * FI * WI, RG = 32 * FO * WO;
+  __bf16* xs = wb_lds;                // [RX][PITCH]
   // G: ONE copy [R][8 + TW] -- position 8 + j of a row holds sample t0 + j, positions 4 .. 7 the four samples below the
   // chunk.  The K tap fragments (samples shifted down by k) are cut out of a lane's 12-sample window [p - 4, p + 8) in
   // registers (one ds_read_b64 + one ds_read_b128, v_alignbit for the odd shifts).  (Until the end of round 4 the tile was
   // kept as K shifted copies: (1 + K) x 64 rows written and K + 1 16-byte fragment reads per K MFMAs -- 64 KB written and
   // 128 KB read per 128-sample chunk against 768 matrix-pipe cycles per SIMD at K = 3, i.e. the LDS pipe allowed 0.5 of the
   // matrix pipe at best; now 32 KB and 80 KB.)
-  __bf16* gs = wb_lds + R * PITCH;    // [R][PITCH]
+  __bf16* gs = wb_lds + RX * PITCH;   // [RG][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31,
             hi = lane >> 5;
-  const int wi = wave >> 1, wo = wave & 1;
+  const int wi = wave / WO, wo = wave % WO;
   const int T = ax.T, pad = ax.pad;
   int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
   if ((nsplit & 7) == 0) {  // the blocks of one reduction split on one XCD (see wgradb_kernel)
@@ -502,32 +509,31 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     bx = blk % gx;
     by = blk / gx;
   }
-  const int ci0 = bx * R, co0 = by * R;
-  constexpr int GPR = TW / 8, NI = TW / 32 * F, RSTEP = 256 / GPR;
+  const int ci0 = bx * RX, co0 = by * RG;
+  constexpr int GPR = TW / 8, RSTEP = 256 / GPR, NIX = RX / RSTEP, NIG = RG / RSTEP;
   const int g8 = (tid % GPR) * 8, r0 = tid / GPR;
   const bool do_bias = want_bias && bx == 0;
 
-  f32x16 acc[KN][F][F];
+  f32x16 acc[KN][FI][FO];
 #pragma unroll
   for (int k = 0; k < KN; ++k)
 #pragma unroll
-    for (int fi = 0; fi < F; ++fi)
+    for (int fi = 0; fi < FI; ++fi)
 #pragma unroll
-      for (int fo = 0; fo < F; ++fo)
+      for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][fi][fo][r] = 0.f;
-  f32x16 accb[F];
+  // bias gradient = row sums of G: a thread adds up the eight samples it stages (fp32; until round 5 one more MFMA per G
+  // fragment against ones: 16 FO accumulator registers that the 128 x 96 shape does not have)
+  float bsum[NIG];
 #pragma unroll
-  for (int fo = 0; fo < F; ++fo)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[fo][r] = 0.f;
-  const bf16x8 ones = sty_pack_bf16(1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f);
+  for (int m = 0; m < NIG; ++m) bsum[m] = 0.f;
 
   const int Cx = ax.flatW ? ax.Cin2d : ax.xc[0];
   const int Cg = ax.w.Cout;
-  int offx[NI], tshx[NI], offg[NI];
+  int offx[NIX], tshx[NIX], offg[NIG];
 #pragma unroll
-  for (int m = 0; m < NI; ++m) {
+  for (int m = 0; m < NIX; ++m) {
     const int ci = ci0 + r0 + RSTEP * m;
     int cc = ci, tsh = 0;
     if (ax.flatW) {
@@ -538,11 +544,14 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     }
     tshx[m] = tsh;
     offx[m] = ci < ax.w.Cin ? cc * T * 2 : WB_OOB;
+  }
+#pragma unroll
+  for (int m = 0; m < NIG; ++m) {
     const int co = co0 + r0 + RSTEP * m;
     offg[m] = co < Cg ? co * T * 2 : WB_OOB;
   }
   constexpr int GN = 4;  // dwords of a thread's eight G samples
-  unsigned xw[NI][5], gw[NI][GN], gh[NI][2];  // gh: the four samples below the chunk (threads of the first group only)
+  unsigned xw[NIX][5], gw[NIG][GN], gh[NIG][2];  // gh: the four samples below the chunk (threads of the first group only)
   const int total = ax.B * chunks_per_b;
   int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
 
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
         const_cast<__bf16*>(ax.g16 + (size_t)b * Cg * T), 0, Cg * T * 2, 0x00020000);
     const int ig0 = t0 + g8;
 #pragma unroll
-    for (int m = 0; m < NI; ++m) {
+    for (int m = 0; m < NIX; ++m) {
       {  // x: samples s0 .. s0 + 7 of the row; loaded from the even sample at or below s0
         const int s0 = t0 - pad + g8 + tshx[m];
         const int base = s0 & ~1;
@@ -569,6 +578,9 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
           wb16_slow<5>(rx, offx[m], base, T, xw[m]);
         }
       }
+    }
+#pragma unroll
+    for (int m = 0; m < NIG; ++m) {
       if constexpr (KN > 1) {
         if (g8 == 0) {  // the samples [t0 - 4, t0) of the row
           if (ig0 - 4 >= 0 && ig0 - 1 < T) {
@@ -607,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     const int t0 = cc_ * TW;
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < NI; ++m) {
+    for (int m = 0; m < NIX; ++m) {
       const int row = r0 + RSTEP * m;
       {
         const unsigned sh = ((unsigned)(t0 - pad + g8 + tshx[m]) & 1u) * 16u;
@@ -618,6 +630,13 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
         v.w = __builtin_amdgcn_alignbit(xw[m][4], xw[m][3], sh);
         *reinterpret_cast<uint4*>(xs + row * PITCH + g8) = v;
       }
+    }
+#pragma unroll
+    for (int m = 0; m < NIG; ++m) {
+      const int row = r0 + RSTEP * m;
+      if (do_bias)
+        bsum[m] += ((sty_bf_lo(gw[m][0]) + sty_bf_hi(gw[m][0])) + (sty_bf_lo(gw[m][1]) + sty_bf_hi(gw[m][1]))) +
+                   ((sty_bf_lo(gw[m][2]) + sty_bf_hi(gw[m][2])) + (sty_bf_lo(gw[m][3]) + sty_bf_hi(gw[m][3])));
       if constexpr (KN == 1) {
         *reinterpret_cast<uint4*>(gs + row * PITCH + g8) = make_uint4(gw[m][0], gw[m][1], gw[m][2], gw[m][3]);
       } else {
@@ -628,15 +647,15 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     __syncthreads();
     advance(cb, cc_);
     if (ch + nsplit < total) load_chunk(cb, cc_);
-    const __bf16* xr = xs + (wi * 32 * F + l31) * PITCH + 8 * hi;
-    const __bf16* gr = gs + (wo * 32 * F + l31) * PITCH + 8 * hi + (KN > 1 ? 8 : 0);
+    const __bf16* xr = xs + (wi * 32 * FI + l31) * PITCH + 8 * hi;
+    const __bf16* gr = gs + (wo * 32 * FO + l31) * PITCH + 8 * hi + (KN > 1 ? 8 : 0);
 #pragma unroll
     for (int s8 = 0; s8 < TW / 16; ++s8) {
-      bf16x8 bp[F];
+      bf16x8 bp[FI];
 #pragma unroll
-      for (int fi = 0; fi < F; ++fi) bp[fi] = *reinterpret_cast<const bf16x8*>(xr + fi * 32 * PITCH + 16 * s8);
+      for (int fi = 0; fi < FI; ++fi) bp[fi] = *reinterpret_cast<const bf16x8*>(xr + fi * 32 * PITCH + 16 * s8);
 #pragma unroll
-      for (int fo = 0; fo < F; ++fo) {
+      for (int fo = 0; fo < FO; ++fo) {
         const __bf16* q = gr + fo * 32 * PITCH + 16 * s8;
         const uint4 a = *reinterpret_cast<const uint4*>(q);
         unsigned win[6] = {0u, 0u, a.x, a.y, a.z, a.w};  // samples p - 4 .. p + 7 of the row as pairs
@@ -660,9 +679,8 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
           }
           const bf16x8 ap = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-          for (int fi = 0; fi < F; ++fi)
+          for (int fi = 0; fi < FI; ++fi)
             acc[k][fi][fo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp[fi], acc[k][fi][fo], 0, 0, 0);
-          if (k == 0 && do_bias && wi == 0) accb[fo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, ones, accb[fo], 0, 0, 0);
         }
       }
     }
@@ -671,28 +689,29 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
   const int K = ax.w.K, CinP = ax.w.CinP, CoutP = ax.w.CoutP;
   const size_t plane = (size_t)K * CinP * CoutP;
   const size_t stride = plane + CoutP;
-  if (do_bias && wi == 0 && l31 == 0) {  // accb[fo][r] = sum_t G[co][t] for the A row (co) of register r, in every column
+  if (do_bias) {  // the GPR threads of a row are consecutive lanes of one wave
     float* pb = partial + (size_t)split * stride + plane;
 #pragma unroll
-    for (int fo = 0; fo < F; ++fo)
+    for (int m = 0; m < NIG; ++m) {
+      float v = bsum[m];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (wo * F + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co < CoutP) pb[co] = accb[fo][r];
-      }
+      for (int o = 1; o < GPR; o <<= 1) v += __shfl_xor(v, o);
+      const int co = co0 + r0 + RSTEP * m;
+      if (g8 == 0 && co < CoutP) pb[co] = v;
+    }
   }
   float* p = partial + (size_t)split * stride;
 #pragma unroll
   for (int k = 0; k < KN; ++k)
 #pragma unroll
-    for (int fi = 0; fi < F; ++fi) {
-      const int ci = ci0 + (wi * F + fi) * 32 + l31;
+    for (int fi = 0; fi < FI; ++fi) {
+      const int ci = ci0 + (wi * FI + fi) * 32 + l31;
       if (k < K && ci < CinP) {
 #pragma unroll
-        for (int fo = 0; fo < F; ++fo)
+        for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int co = co0 + (wo * F + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int co = co0 + (wo * FO + fo) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (co < CoutP) p[((size_t)k * CinP + ci) * CoutP + co] = acc[k][fi][fo][r];
           }
       }
@@ -711,35 +730,60 @@ bool wgradb16_eligible(const ConvArgs& fwd) {
   return true;
 }
 constexpr int wb16_tw(int kn, int f) { return (kn > 3 || f > 1) ? 64 : 128; }
-template <int KN, int F>
+template <int KN, int TW, int FI, int FO, int WI>
 static void wb16_launch(const ConvArgs& ax, dim3 grid, size_t lds, int nsplit, int cpb, float* partial, int wb, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb16_kernel<KN, wb16_tw(KN, F), F>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgradb16_kernel<KN, TW, FI, FO, WI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
     raised = true;
   }
-  hipLaunchKernelGGL((wgradb16_kernel<KN, wb16_tw(KN, F), F>), grid, dim3(256), lds, st, ax, nsplit, cpb, partial, wb);
+  hipLaunchKernelGGL((wgradb16_kernel<KN, TW, FI, FO, WI>), grid, dim3(256), lds, st, ax, nsplit, cpb, partial, wb);
+}
+// block shape of a launch: 0 = 64 x 64, 1 = 128 x 128 (K = 1 wide), 2 = 128 ci x 64 co, 3 = 128 ci x 96 co (K = 3)
+static int wb16_shape(const ConvArgs& ax) {
+  const PackedConv& w = ax.w;
+  const char* fs = getenv("STY_WGRADB16_SHAPE");  // tuning aid, read per call (the A/B test toggles it): 0 = 64 x 64 everywhere
+  if (w.K == 1) return wb_wide(ax) ? 1 : 0;
+  if (w.K != 3) return 0;
+  if (fs) return atoi(fs) == 1 ? 0 : atoi(fs);
+  if (w.CoutP <= 96 && w.CinP >= 128) return 3;
+  if (w.CinP >= 128) return 2;
+  return 0;
+}
+int wgradb16_blocks(const ConvArgs& ax) {  // workgroups per reduction split (the caller sizes the split count with it)
+  const PackedConv& w = ax.w;
+  switch (wb16_shape(ax)) {
+    case 1: return cdiv(w.CinP, 128) * cdiv(w.CoutP, 128);
+    case 2: return cdiv(w.CinP, 128) * cdiv(w.CoutP, 64);
+    case 3: return cdiv(w.CinP, 128) * cdiv(w.CoutP, 96);
+    default: return cdiv(w.CinP, 64) * cdiv(w.CoutP, 64);
+  }
 }
 int launch_wgradb16(const ConvArgs& ax, int nsplit, float* partial, int want_bias, hipStream_t st) {
   const PackedConv& w = ax.w;
-  const int f = wb_wide(ax) ? 2 : 1;
-  const int tw = wb16_tw(w.K, f);
+  const int shp = wb16_shape(ax);
+  const int rx = shp == 0 ? 64 : 128, rg = shp == 0 ? 64 : (shp == 1 ? 128 : (shp == 2 ? 64 : 96));
+  const int tw = shp == 3 ? 64 : wb16_tw(w.K, shp == 1 ? 2 : 1);  // (128 x 96: 144 accumulator registers; 64-sample chunks keep the staging registers at 38)
   const int cpb = cdiv(ax.T + (w.K - 1) * ax.dil, tw);
-  dim3 grid(cdiv(w.CinP, 64 * f), cdiv(w.CoutP, 64 * f), nsplit);
-  const size_t lds = (size_t)2 * 64 * f * (tw + 8) * sizeof(__bf16);  // x tile + ONE G tile (taps cut in registers)
+  dim3 grid(cdiv(w.CinP, rx), cdiv(w.CoutP, rg), nsplit);
+  const size_t lds = (size_t)(rx + rg) * (tw + 8) * sizeof(__bf16);  // x tile + ONE G tile (taps cut in registers)
   char detail[40];
-  snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW);
+  snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d s%d", w.Cin, w.Cout, w.K, ax.T, ax.flatW, shp);
   ProfScope prof(w.K == 1 ? "wgradb16_kernel<1,true>" : (w.K == 3 ? "wgradb16_kernel<3,true>" : "wgradb16_kernel<5,true>"),
                  2.0 * w.Cin * w.K * (double)ax.B * w.Cout * ax.T, 2.0 * ((double)ax.B * (w.Cin + w.Cout) * ax.T), st, detail);
-  if (w.K == 1 && f == 2)
-    wb16_launch<1, 2>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+  if (w.K == 1 && shp == 1)
+    wb16_launch<1, 64, 2, 2, 2>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
   else if (w.K == 1)
-    wb16_launch<1, 1>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+    wb16_launch<1, 128, 1, 1, 2>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else if (w.K == 3 && shp == 2)
+    wb16_launch<3, 128, 2, 1, 2>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+  else if (w.K == 3 && shp == 3)
+    wb16_launch<3, 64, 1, 3, 4>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
   else if (w.K == 3)
-    wb16_launch<3, 1>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+    wb16_launch<3, 128, 1, 1, 2>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
   else
-    wb16_launch<5, 1>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
+    wb16_launch<5, 64, 1, 1, 2>(ax, grid, lds, nsplit, cpb, partial, want_bias, st);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

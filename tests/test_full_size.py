@@ -213,7 +213,7 @@ C3_SE_KEYS = ["shared.0.weight_orig", "shared.2.conv1.weight_orig", "shared.4.co
 # float64 than 0.3 of its scale / 5e-2 in angle / 10 % in norm however ill-conditioned the graph is at this shape
 GATE_K, GATE_FLOOR, GATE_CAP = 1.5, (5e-2, 1e-3, 2e-2), (0.3, 5e-2, 0.1)
 # bf16 mode: the same construction; floors and caps of a 2^-9 arithmetic
-GATE16_FLOOR, GATE16_CAP = (1e-1, 1e-2, 5e-2), (0.5, 0.1, 0.25)
+GATE16_FLOOR, GATE16_CAP = (1e-1, 1e-2, 1e-1), (0.5, 0.1, 0.25)
 # Tensors whose gradient under THIS loss at THIS shape fp32 arithmetic does not determine: the fp32 oracle itself sits 0.27 ... 0.89
 # of the tensor's scale (cosine down to 0.65) from the float64 oracle on the same 32 utterances (profiles/r05_c3_parity_table.txt)
 # -- the anti-wrapping phase loss flips branches on 7th-digit differences of the waveform, and these are the deepest tensors
@@ -300,7 +300,7 @@ def test_c3_train_step_full_size_vs_oracle():
     Pb, Pseb = _cast(P, torch.float32), _cast(Pse, torch.float32)
     leaves(Pb, Pseb)
     t0 = time.perf_counter()
-    with blocks.bf16_operands(storage=True):  # (75 T % 8 == 0 at this shape: the product stores the resblock tensors as bf16)
+    with blocks.bf16_operands(storage=True, all_dense=True):  # (75 T % 8 == 0 here: the product stores the resblock tensors as bf16)
         chunked_acoustic_step(Pb, Pseb, {k: v[:8] for k, v in inp.items()}, 8,
                               constants=dict(consts, _B=w["B"]))
     g16_c0 = grads_of(Pb, Pseb)
@@ -316,8 +316,10 @@ def test_c3_train_step_full_size_vs_oracle():
                {("se", k): nse[k].grad.detach().cpu().double() for k in se_keys}
 
     def gate(key, y, floor, cap):
-        if key in C3_ILL_CONDITIONED:  # held to the reference arithmetic's own distance, pinned elsewhere (see the list)
-            return tuple(max(floor[i], GATE_K * y[i]) for i in range(3))
+        if key in C3_ILL_CONDITIONED:
+            # held to the reference arithmetic's own distance (2.5 x: two noise-dominated evaluations are sqrt(2) apart before
+            # anything is wrong, and the norm of a noise-dominated tensor is not additive), pinned elsewhere (see the list)
+            return tuple(max(floor[i], 2.5 * y[i]) for i in range(3))
         return tuple(min(cap[i], max(floor[i], GATE_K * y[i])) for i in range(3))
 
     table = [f"c3 train step, B = {w['B']}, T = {w['T']}, L = {w['L']}: per-tensor distance to the FLOAT64 oracle "
@@ -385,8 +387,11 @@ def test_c3_backward_full_size_under_a_well_conditioned_loss():
     tensors undeterminable in fp32 at this shape (C3_ILL_CONDITIONED); the kernels that produce them are the same under any
     cotangent, and under this one EVERY listed tensor -- the embedding and the deep text-encoder weights included -- is held
     at 3e-2 of its scale / 1 - cos 1e-3 against the fp32 oracle's autograd (eval-mode graph: no op couples utterances, the
-    oracle sums the gradient over chunks of 8).  bf16 mode on the same inputs: against the same oracle gradient at
-    0.25 / 3e-2 (the mode's own rounding on a well-conditioned graph)."""
+    oracle sums the gradient over chunks of 8).  bf16 mode on the same inputs: its distance to the fp32 oracle's gradient held to
+    2 x the distance of the bf16-rule ORACLE (oracle.blocks.bf16_operands(storage=True), first chunk of 8 utterances) from the
+    fp32 oracle on the same chunk, floors 0.25 of the scale / 1 - cos 3e-2 / norm 5 % -- a weight-norm direction gradient in
+    front of an instance norm (convs1.*.original1) is a cancellation and is moved by O(1) by ANY 2^-9 arithmetic, the
+    oracle's included; what the gate excludes is a kernel that moves it further than the rounding rule does."""
     import stylish_tts_amd as S
     from oracle import frontend, speech_predictor as osp
     _oracle_threads()
@@ -415,11 +420,28 @@ def test_c3_backward_full_size_under_a_well_conditioned_loss():
         audio.append(a.detach())
         priors.append(want["prior"])
         cot.append(R)
+        if i == 0:
+            g_c0 = {k: Pd[k].grad.clone() for k in keys}
+            g_c0["style"] = st.grad[:8].clone()
     ref, prior, R = torch.cat(audio), torch.cat(priors), torch.cat(cot)
+    # the bf16 rule's own distance from fp32 on chunk 0 (same cotangent): the yardstick of the bf16-mode gates
+    from oracle import blocks
+    Pb = {k: v.detach().clone() for k, v in P.items()}
+    for k in keys:
+        Pb[k].requires_grad_(True)
+    stb = style[:8].clone().requires_grad_(True)
+    r0 = slice(0, 8)
+    with blocks.bf16_operands(storage=True, all_dense=True):
+        ab = osp.speech_predictor(Pb, inp["texts"][r0], inp["text_lengths"][r0], ali[r0], inp["pitch"][r0], energy[r0],
+                                  voiced[r0], stb, inp["pitch"][r0], inp["noise"][r0], prior=prior[r0])
+        (ab * R[r0]).sum().backward()
+    yard = {"d " + k[-50:]: _dist(Pb[k].grad, g_c0[k]) for k in keys}
+    yard["d style"] = _dist(stb.grad, g_c0["style"])
     print(f"\n  fp32 oracle forward + backward of the predictor (B = {B}, chunks of 8): {time.perf_counter() - t0:.1f} s")
     lines = [f"c3 predictor backward under d<audio, sign(audio)/N>, B = {B}, T = {w['T']}, L = {w['L']}: HIP vs the fp32 oracle's autograd"]
     bad = []
     for mode, tol_e, tol_c in (("fp32", 3e-2, 1e-3), ("bf16", 0.25, 3e-2)):
+        tol_n = 1.0 if mode == "fp32" else 5e-2
         m = S.SpeechPredictor()
         m.load_state_dict({k: v.detach() for k, v in P.items()}, strict=False)
         m = m.to(DEV).enable_training().set_train_opts(compute_bf16=(mode == "bf16"))
@@ -434,8 +456,13 @@ def test_c3_backward_full_size_under_a_well_conditioned_loss():
         named = dict(m.named_parameters())
         for name, got, r_ in [("d style", d_style, st.grad)] + [("d " + k[-50:], named[k].grad, Pd[k].grad) for k in keys]:
             d = _dist(got.detach().cpu(), r_)
-            ok = d[0] <= tol_e and d[1] <= tol_c
-            lines.append(f"  {mode} {name:54s} err {d[0]:.2e}  1-cos {d[1]:.2e}  |norm-1| {d[2]:.2e}  {'ok' if ok else 'FAIL'}")
+            gt = (tol_e, tol_c, tol_n)
+            if mode == "bf16":
+                gt = tuple(max(gt[i], 2.0 * yard[name][i]) for i in range(3))
+            ok = all(d[i] <= gt[i] for i in range(3))
+            lines.append(f"  {mode} {name:54s} err {d[0]:.2e}  1-cos {d[1]:.2e}  |norm-1| {d[2]:.2e}  "
+                         + (f"(bf16 oracle: {yard[name][0]:.2e} {yard[name][1]:.2e} {yard[name][2]:.2e})  " if mode == "bf16" else "")
+                         + ("ok" if ok else "FAIL"))
             if not ok:
                 bad.append((mode, name, d))
         del m
