@@ -7,6 +7,8 @@
 //          registers into the second GEMM (the D fragment of GEMM-1 is already a legal B fragment of
 //          GEMM-2 when the reduction index is enumerated as (q, hi) -> row (q&3)+8(q>>2)+4hi),
 // so x is read twice and y written once: the 4C intermediate never touches HBM or even LDS.
+#include <type_traits>
+
 #include "sty_common.h"
 
 namespace sty {
@@ -175,33 +177,47 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
       }
     }
     const bool slow = __any(amax > 8192.0f);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float al = prm[1][ch];
-      const float ral = __builtin_amdgcn_rcpf(al);
-      const float sc = prm[2][ch];
-      float s2 = 0.f;
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const float z = h[n][r];
-        float v = fmaf(ral, slow ? sty_sin2(al * z) : (BF ? sty_sin2_hw(al * z) : sty_sin2_fast(al * z)), z);
-        if (PASS2) {
-          if constexpr (BF) {
-            if (keep_h) {  // h (before the GRN scale) as bf16 for the backward's M = gY h^T (wave-uniform branch)
-              const bf16x8 pk = sty_pack_bf16(v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
-              const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;  // wave-uniform part of the row offset
-              __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(uint4, pk).x & 0xffffu), r_h16, hoff[n], srow, 0);
+    // The element loop as a generic lambda over the "this block needs the library sine" flag: with STY_CNX_FWD_SPLIT (a build
+    // variant, tools/build_variant.sh) it exists twice -- the ordinary block without the library-sine path in its body, the rare
+    // one with it -- as in convnext_bwd.hip; by default the flag is a run-time value (measured: profiles/r05_cnx_variants.txt)
+    auto elem_loop = [&](auto slow_c) {
+      const bool SLOWP = slow_c;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float al = prm[1][ch];
+        const float ral = __builtin_amdgcn_rcpf(al);
+        const float sc = prm[2][ch];
+        float s2 = 0.f;
+  #pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const float z = h[n][r];
+          float v = fmaf(ral, SLOWP ? sty_sin2(al * z) : (BF ? sty_sin2_hw(al * z) : sty_sin2_fast(al * z)), z);
+          if (PASS2) {
+            if constexpr (BF) {
+              if (keep_h) {  // h (before the GRN scale) as bf16 for the backward's M = gY h^T (wave-uniform branch)
+                const bf16x8 pk = sty_pack_bf16(v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+                const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;  // wave-uniform part of the row offset
+                __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(uint4, pk).x & 0xffffu), r_h16, hoff[n], srow, 0);
+              }
             }
+            h[n][r] = v * sc;
+          } else {
+            const int t = t0 + tw + n * 32 + l31;
+            if (t < T) s2 += v * v;
           }
-          h[n][r] = v * sc;
-        } else {
-          const int t = t0 + tw + n * 32 + l31;
-          if (t < T) s2 += v * v;
         }
+        sq[r] = s2;
       }
-      sq[r] = s2;
-    }
+    };
+#ifdef STY_CNX_FWD_SPLIT
+    if (slow)
+      elem_loop(std::true_type{});
+    else
+      elem_loop(std::false_type{});
+#else
+    elem_loop(slow);
+#endif
     if (PASS2) {
       const float* w2 = a.w2a + ((j * 16) * 2 + hi) * 32 + l31;
       float aw[16];

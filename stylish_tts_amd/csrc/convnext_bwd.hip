@@ -12,6 +12,8 @@
 //            weight-gradient GEMMs, which run on wgrad_k1_kernel) and per-tile partials of d alpha, d(gamma,beta)_AdaLN.
 // The depthwise-conv backward runs on the existing kernels from gU.  HBM traffic per time column: ~1 100 floats for
 // forward + backward against ~3 300 before.
+#include <type_traits>
+
 #include "sty_common.h"
 
 namespace sty {
@@ -138,7 +140,11 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
   for (int n = 0; n < 2; ++n) {
     const int tl = tw + n * 32 + l31, t = t0 + tl;
     const bool ok = t < T;
-    const int vst16 = (4 * hi * T + t) * 2;  // lane part of the bf16 output offsets
+    // lane part of the bf16 output offsets; columns past the end: outside the descriptor, the store is dropped by the range
+    // check (no exec-mask branch around each of the 128 stores per lane and pass)
+    const int vst16 = ok ? (4 * hi * T + t) * 2 : 0x7FFFFF00;
+    const int vst32 = ok ? (4 * hi * T + t) * 4 : 0x7FFFFF00;
+    const float okf = ok ? 1.f : 0.f;  // (the hi half of the wave holds the rows 4 further down)
     // B fragments: normalised input (AdaLN affine applied on the way) and the output gradient
     float bx[16], by[16];
     bf16x8 bxf[2], byf[2];
@@ -218,61 +224,82 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
         }
         slow = __any(amax > 8192.0f);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float bias = prm[ch], al = prm[128 + ch], ral = prm[512 + ch];
-        const float sc = prm[256 + ch];
-        const float z = h[r] + bias;
-        float s2, s2a = 0.f;
-        if (PASS == 1) {
-          s2 = (BF && !slow) ? sty_sin2_hw(al * z) : sty_sin2(al * z);
-        } else {  // sin^2 and sin(2 a z) = 2 sin cos from one range reduction
-          float sn, cs;
-          if (BF && !slow)
-            sty_sincos_hw(al * z, sn, cs);
-          else
-            sty_sincos(al * z, sn, cs);
-          s2 = sn * sn;
-          s2a = 2.f * sn * cs;
-        }
-        const float hv = fmaf(ral, s2, z);
-        float rsum = 0.f;
-        if (PASS == 1) {
-          rsum = ok ? uu[r] * hv : 0.f;
-        } else {
-          const float cf = prm[384 + ch];
+      // The element loop exists twice: the ordinary block (every Snake argument in the hardware sine's range) without the
+      // library-sine path in it -- that path is a function call per element, and merely having it in the loop body cost the
+      // fast path its schedule (registers saved around the calls, a wait in front of every branch) -- and the rare block with it.
+      auto elem_loop = [&](auto slow_c) {
+        const bool SLOWP = slow_c;  // (a compile-time constant after inlining, except in the STY_CNX_BWD_OLD build variant)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float bias = prm[ch], al = prm[128 + ch], ral = prm[512 + ch];
+          const float sc = prm[256 + ch];
+          const float z = h[r] + bias;
+          float s2, s2a = 0.f;
+          if (PASS == 1) {
+            s2 = (BF && !SLOWP) ? sty_sin2_hw(al * z) : sty_sin2(al * z);
+          } else {  // sin^2 and sin(2 a z) = 2 sin cos from one range reduction
+            float sn, cs;
+            if (BF && !SLOWP)
+              sty_sincos_hw(al * z, sn, cs);
+            else
+              sty_sincos(al * z, sn, cs);
+            s2 = sn * sn;
+            s2a = 2.f * sn * cs;
+          }
+          const float hv = fmaf(ral, s2, z);
+          float rsum = 0.f;
+          if (PASS == 1) {
+            rsum = ok ? uu[r] * hv : 0.f;
+          } else {
+            const float cf = prm[384 + ch];
+            
+#ifdef STY_CNX_BWD_OLD
           const float gH = ok ? fmaf(uu[r], sc, cf * hv) : 0.f;
-          const float g0 = gH * (1.f + s2a);
-          if constexpr (!LEAN) rsum = gH * (z * s2a - s2 * ral) * ral;
-          if (ok) {
+#else
+          const float gH = okf * fmaf(uu[r], sc, cf * hv);  // (a multiply, not a select: hipcc turned `ok ? ... : 0` into an
+              // exec-mask branch around the parameter reads of EVERY element, and the basic-block boundary kept the LDS reads of the next
+              // rows from being requested early: three exposed LDS round trips per element; columns past the end hold finite values)
+#endif
+            const float g0 = gH * (1.f + s2a);
+            if constexpr (!LEAN) rsum = gH * (z * s2a - s2 * ral) * ral;
             if (LEAN) {
               const bf16x8 pk = sty_pack_bf16(g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
               const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;
               __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(uint4, pk).x & 0xffffu), r_g0, vst16, srow, 0);
-            } else if (BF && a.out_bf16) {
-              const bf16x8 pk = sty_pack_bf16(hv * sc, g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
-              const unsigned two = __builtin_bit_cast(uint4, pk).x;
-              // row offset in the SCALAR offset (wave-uniform part of ch; the hi half of the wave is 4 rows further: in
-              // the lane part), so that the per-lane offset is the same for all sixteen rows
-              const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;
-              __builtin_amdgcn_raw_buffer_store_b16((short)(two & 0xffffu), r_hs, vst16, srow, 0);
-              __builtin_amdgcn_raw_buffer_store_b16((short)(two >> 16), r_g0, vst16, srow, 0);
-            } else {
-              bst(r_hs, hv * sc, (ch * T + t) * 4);
-              bst(r_g0, g0, (ch * T + t) * 4);
+            } else if (ok) {
+              if (BF && a.out_bf16) {
+                const bf16x8 pk = sty_pack_bf16(hv * sc, g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+                const unsigned two = __builtin_bit_cast(uint4, pk).x;
+                // row offset in the SCALAR offset (wave-uniform part of ch; the hi half of the wave is 4 rows further: in
+                // the lane part), so that the per-lane offset is the same for all sixteen rows
+                const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;
+                __builtin_amdgcn_raw_buffer_store_b16((short)(two & 0xffffu), r_hs, vst16, srow, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)(two >> 16), r_g0, vst16, srow, 0);
+              } else {
+                bst(r_hs, hv * sc, (ch * T + t) * 4);
+                bst(r_g0, g0, (ch * T + t) * 4);
+              }
             }
+            h[r] = g0;
           }
-          h[r] = g0;
+          if constexpr (!(PASS == 2 && LEAN)) {
+            rsum = sty_half_sum_to_lane31(rsum);
+            if (l31 == 31) atomicAdd(&red[wave * 128 + ch], rsum);  // one writer per slot (the same lane in both passes): a
+                                                                     // ds_add_f32 instead of read / add / write
+          }
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the per-channel loads / store addresses of later
+                                                                // rows from being hoisted (that cost 106 spilled VGPRs)
         }
-        if constexpr (!(PASS == 2 && LEAN)) {
-          rsum = sty_half_sum_to_lane31(rsum);
-          if (l31 == 31) atomicAdd(&red[wave * 128 + ch], rsum);  // one writer per slot (the same lane in both passes): a
-                                                                   // ds_add_f32 instead of read / add / write
-        }
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the per-channel loads / store addresses of later
-                                                              // rows from being hoisted (that cost 106 spilled VGPRs)
-      }
+      };
+#ifdef STY_CNX_BWD_OLD
+      elem_loop(slow);
+#else
+      if (slow)
+        elem_loop(std::true_type{});
+      else
+        elem_loop(std::false_type{});
+#endif
       if (PASS == 2) {  // gXn[ci][t] += sum_ch W1[ch][ci] gH0[ch][t]: the gH0 fragment is the B operand
         float aw[16];
 #pragma unroll
@@ -312,7 +339,8 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (ok) bst(r_gu, rs * (gxh[r] - s1 - xh[r] * s2), (c * T + t) * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rs * (gxh[r] - s1 - xh[r] * s2)), r_gu, vst32,
+                                              ((r & 3) + 8 * (r >> 2)) * T * 4, 0);
         float v = ok ? gxn[r] * xh[r] : 0.f, w = ok ? gxn[r] : 0.f;
         v = sty_half_sum_to_lane31(v);
         w = sty_half_sum_to_lane31(w);
