@@ -75,11 +75,13 @@ __device__ __forceinline__ PTile p_tile(int tile, int tiles_per_row) {
 // ---- producer, part 1: the residual rows of a tile (8 rows of this wave x 4 consecutive columns per lane) ----
 // Buffer descriptors of the batch slab [Cout][T]; a lane whose four columns would cross the end of the row takes the
 // scalar path (the slab descriptor cannot clip at a row end).
+template <int RPW>  // rows of a producer wave: 8 with four producer waves (fp32 mode), 4 with eight (bf16 mode)
 struct PDrain {
-  float4 res[8];
+  float4 res[RPW];
   bool wide;
 };
-__device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, int lane, bool want, PDrain& d) {
+template <int RPW>
+__device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, int lane, bool want, PDrain<RPW>& d) {
   const int T = a.T, Cout = a.w.Cout;
   const int t = tl.t0 + 4 * lane;
   d.wide = t + 3 < T;
@@ -89,8 +91,8 @@ __device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, 
                                : reinterpret_cast<const char*>(a.y)),
         0, want ? Cout * T * 2 : 0, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int co = 8 * pw + r;
+    for (int r = 0; r < RPW; ++r) {
+      const int co = RPW * pw + r;
       d.res[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!want || co >= Cout || !d.wide) continue;
       const auto v = __builtin_amdgcn_raw_buffer_load_b64(rrs, t * 2, co * T * 2, 0);
@@ -101,8 +103,8 @@ __device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, 
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(want ? a.residual + (size_t)tl.b * Cout * T : a.y), 0, want ? Cout * T * 4 : 0, 0x00020000);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int co = 8 * pw + r;
+  for (int r = 0; r < RPW; ++r) {
+    const int co = RPW * pw + r;
     d.res[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!want || co >= Cout) continue;
     if (d.wide) {
@@ -118,17 +120,18 @@ __device__ __forceinline__ void p_res_load(const ConvArgs& a, PTile tl, int pw, 
   }
 }
 // ---- producer, part 3: drain the output stage of that tile: y = stage + residual, 16 bytes per lane and row ----
-__device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, PTile tl, int pw, int lane, const PDrain& d,
+template <int RPW>
+__device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, PTile tl, int pw, int lane, const PDrain<RPW>& d,
                                         int tiles_per_row) {
   const int T = a.T, Cout = a.w.Cout;
   const int t = tl.t0 + 4 * lane;
-  float sv[16];  // [0..7] sums, [8..15] sums of squares of this lane's columns, per row of this wave
+  float sv[2 * RPW];  // [0..RPW) sums, [RPW..2 RPW) sums of squares of this lane's columns, per row of this wave
   const int esz = a.yh ? 2 : 4;  // (yh: the output tensor is bf16; T % 4 == 0, so d.wide == (t < T))
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(a.y) + (size_t)tl.b * Cout * T * esz, 0, Cout * T * esz, 0x00020000);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int co = 8 * pw + r;
+  for (int r = 0; r < RPW; ++r) {
+    const int co = RPW * pw + r;
     if (co >= Cout) continue;
     const float4 s = *reinterpret_cast<const float4*>(ostage + co * P_TT + 4 * lane);
     float4 v = make_float4(s.x + d.res[r].x, s.y + d.res[r].y, s.z + d.res[r].z, s.w + d.res[r].w);
@@ -142,7 +145,7 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
       const float e0 = v.x, e1 = t + 1 < T ? v.y : 0.f, e2 = t + 2 < T ? v.z : 0.f, e3 = t + 3 < T ? v.w : 0.f;
       const bool in = t < T;
       sv[r] = in ? (e0 + e1) + (e2 + e3) : 0.f;
-      sv[8 + r] = in ? (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3) : 0.f;
+      sv[RPW + r] = in ? (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3) : 0.f;
     }
     if (a.yh) {
       typedef unsigned u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
@@ -158,27 +161,43 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
     }
   }
   if (a.stat_part) {
-    // 16 values per lane -> 16 totals over the 64 lanes with a halving butterfly: at every step a lane keeps half of its
-    // values and receives the partner's copy of that half (8 + 4 + 2 + 1 exchanges), then two full steps: 17 shuffles
-    // instead of 96 (a plain per-value reduction, in double, cost the HBM-bound bf16 mode +70 us per launch).  Lane
-    // (b5 b4 b3 b2 . .) ends up with value index 8 b5 + 4 b4 + 2 b3 + b2.  fp32 over one 256-column tile, double from there.
+    // 2 RPW values per lane -> 2 RPW totals over the 64 lanes with a halving butterfly: at every step a lane keeps half of its
+    // values and receives the partner's copy of that half, then full steps over the remaining lane bits (RPW = 8: 8 + 4 + 2 + 1
+    // exchanges + 2 full steps = 17 shuffles instead of 96; RPW = 4: 4 + 2 + 1 + 3).  A plain per-value reduction, in double,
+    // cost the HBM-bound bf16 mode +70 us per launch.  fp32 over one 256-column tile, double from there.
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (8 * pw + r >= Cout) sv[r] = sv[8 + r] = 0.f;
+    for (int r = 0; r < RPW; ++r)
+      if (RPW * pw + r >= Cout) sv[r] = sv[RPW + r] = 0.f;
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-    float w8[8], w4[4], w2[2];
+    float w1;
+    int idx;
+    if constexpr (RPW == 8) {
+      float w8[8], w4[4], w2[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w8[i] = (b5 ? sv[8 + i] : sv[i]) + __shfl_xor(b5 ? sv[i] : sv[8 + i], 32);
+      for (int i = 0; i < 8; ++i) w8[i] = (b5 ? sv[8 + i] : sv[i]) + __shfl_xor(b5 ? sv[i] : sv[8 + i], 32);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w4[i] = (b4 ? w8[4 + i] : w8[i]) + __shfl_xor(b4 ? w8[i] : w8[4 + i], 16);
+      for (int i = 0; i < 4; ++i) w4[i] = (b4 ? w8[4 + i] : w8[i]) + __shfl_xor(b4 ? w8[i] : w8[4 + i], 16);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w2[i] = (b3 ? w4[2 + i] : w4[i]) + __shfl_xor(b3 ? w4[i] : w4[2 + i], 8);
-    float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4);
-    w1 += __shfl_xor(w1, 2);
-    w1 += __shfl_xor(w1, 1);
-    const int idx = (lane >> 2) & 15, stat = idx >> 3, row = idx & 7;
-    if ((lane & 3) == 0 && 8 * pw + row < Cout)
-      a.stat_part[(((size_t)tl.b * Cout + 8 * pw + row) * tiles_per_row + tl.t0 / P_TT) * 2 + stat] = (double)w1;
+      for (int i = 0; i < 2; ++i) w2[i] = (b3 ? w4[2 + i] : w4[i]) + __shfl_xor(b3 ? w4[i] : w4[2 + i], 8);
+      w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4);
+      w1 += __shfl_xor(w1, 2);
+      w1 += __shfl_xor(w1, 1);
+      idx = (lane >> 2) & 15;  // lane (b5 b4 b3 b2 . .) holds value 8 b5 + 4 b4 + 2 b3 + b2
+    } else {
+      float w4[4], w2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4[i] = (b5 ? sv[4 + i] : sv[i]) + __shfl_xor(b5 ? sv[i] : sv[4 + i], 32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w2[i] = (b4 ? w4[2 + i] : w4[i]) + __shfl_xor(b4 ? w4[i] : w4[2 + i], 16);
+      w1 = (b3 ? w2[1] : w2[0]) + __shfl_xor(b3 ? w2[0] : w2[1], 8);
+      w1 += __shfl_xor(w1, 4);
+      w1 += __shfl_xor(w1, 2);
+      w1 += __shfl_xor(w1, 1);
+      idx = (lane >> 3) & 7;  // lane (b5 b4 b3 . . .) holds value 4 b5 + 2 b4 + b3
+    }
+    const int stat = idx / RPW, row = idx % RPW;
+    if ((lane & (RPW == 8 ? 3 : 7)) == 0 && RPW * pw + row < Cout)
+      a.stat_part[(((size_t)tl.b * Cout + RPW * pw + row) * tiles_per_row + tl.t0 / P_TT) * 2 + stat] = (double)w1;
   }
 }
 
@@ -188,7 +207,16 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
 // explicit `tin` predicate, so whatever a load outside the row returns (the neighbouring row, or 0 outside the slab) is
 // never used.  `mid` runs between the first batch of loads and their use (the drain of the previous tile: its stores
 // go out while this tile's loads are in flight).
-template <bool BF, int PRO, typename Mid>
+// the RPW channels of one column of the bf16 tile (one ds_write_b128, or one ds_write_b64 with eight producer waves)
+template <int RPW>
+__device__ __forceinline__ void p_put(__bf16* dst, const float (&v)[RPW]) {
+  if constexpr (RPW == 8) {
+    *reinterpret_cast<bf16x8*>(dst) = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  } else {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(sty_pack2_bf16(v[0], v[1]), sty_pack2_bf16(v[2], v[3]));
+  }
+}
+template <bool BF, int PRO, int RPW, typename Mid>
 __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl, int LW, int pw, int lane, Mid mid) {
   const int T = a.T, Cin = a.w.Cin;
   const int b = tl.b, t0 = tl.t0;
@@ -200,13 +228,13 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
     float vv[2][P_MAXQ];
 #define STY_P_LOADROW(slot, r)                                                                  \
   _Pragma("unroll") for (int q = 0; q < P_MAXQ; ++q) if (q < P_TT / 64 || 64 * q < LW) vv[slot][q] = \
-      buf_load(rs, voff + 256 * q + (8 * pw + (r)) * T * 4);
+      buf_load(rs, voff + 256 * q + (RPW * pw + (r)) * T * 4);
     STY_P_LOADROW(0, 0)
     mid();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (r + 1 < 8) { STY_P_LOADROW((r + 1) & 1, r + 1) }
-      const int ci = 8 * pw + r;
+    for (int r = 0; r < RPW; ++r) {
+      if (r + 1 < RPW) { STY_P_LOADROW((r + 1) & 1, r + 1) }
+      const int ci = RPW * pw + r;
       const bool live = ci < Cin;
       float pa, ps, al, ral;
       p_row_params<PRO>(a, b, ci, live, pa, ps, al, ral);
@@ -228,9 +256,9 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
     // bf16 tile [LW][32 ch]: a lane gathers the eight channels of its wave for one column and writes them with one
     // ds_write_b128; three column groups (24 loads per lane) per batch, the second batch requested before the first is
     // processed
-    float pa[8], ps[8], al[8], ral[8];
+    float pa[RPW], ps[RPW], al[RPW], ral[RPW];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) p_row_params<PRO>(a, b, 8 * pw + r, 8 * pw + r < Cin, pa[r], ps[r], al[r], ral[r]);
+    for (int r = 0; r < RPW; ++r) p_row_params<PRO>(a, b, RPW * pw + r, RPW * pw + r < Cin, pa[r], ps[r], al[r], ral[r]);
     if (a.xh) {
       // bf16 SOURCE tensor: a lane loads a dword = two consecutive samples of a row, 8 rows x 3 pair groups = 24 loads for
       // the whole tile (48 in the fp32 form), sixteen of them in flight over the drain of the previous tile.  The tile starts at an
@@ -239,11 +267,11 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
       const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(reinterpret_cast<const char*>(a.x[0]) + (size_t)b * Cin * T * 2), 0, Cin * T * 2, 0x00020000);
       const int vo = (t0 - a.pad - sh + 2 * lane) * 2;
-      unsigned vh[P_MAXQ / 2][8];
+      unsigned vh[P_MAXQ / 2][RPW];
 #define STY_P_LOADQ(q)                                 \
   if ((q) < P_TT / 128 || 128 * (q) < LWs)             \
-  _Pragma("unroll") for (int r = 0; r < 8; ++r) vh[q][r] = \
-      __builtin_amdgcn_raw_buffer_load_b32(rsh, vo + 256 * (q), (8 * pw + r) * T * 2, 0);
+  _Pragma("unroll") for (int r = 0; r < RPW; ++r) vh[q][r] = \
+      __builtin_amdgcn_raw_buffer_load_b32(rsh, vo + 256 * (q), (RPW * pw + r) * T * 2, 0);
       STY_P_LOADQ(0)
       STY_P_LOADQ(1)
       mid();
@@ -259,23 +287,22 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
           const bool tin = t >= 0 && t < T;
           float mk = 1.f;
           if constexpr (PRO == PRO_MASK) mk = tin ? a.mask[(size_t)b * T + t] : 0.f;
-          float v[8];
+          float v[RPW];
 #pragma unroll
-          for (int r = 0; r < 8; ++r)
-            v[r] = (8 * pw + r < Cin && tin) ? pro_apply<PRO>(e ? sty_bf_hi(vh[q][r]) : sty_bf_lo(vh[q][r]), pa[r], ps[r], al[r], ral[r], mk)
+          for (int r = 0; r < RPW; ++r)
+            v[r] = (RPW * pw + r < Cin && tin) ? pro_apply<PRO>(e ? sty_bf_hi(vh[q][r]) : sty_bf_lo(vh[q][r]), pa[r], ps[r], al[r], ral[r], mk)
                                             : 0.f;
           if (j < LWs)
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + 8 * pw) =
-                sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            p_put<RPW>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + RPW * pw, v);
         }
       }
       return;
     }
     constexpr int QH = P_MAXQ / 2;
-    float vv[2][QH][8];
+    float vv[2][QH][RPW];
 #define STY_P_LOADH(h)                                                                     \
   _Pragma("unroll") for (int q = 0; q < QH; ++q) if ((h) * QH + q < P_TT / 64 || 64 * ((h) * QH + q) < LW) \
-  _Pragma("unroll") for (int r = 0; r < 8; ++r) vv[h][q][r] = buf_load(rs, voff + 256 * ((h) * QH + q) + (8 * pw + r) * T * 4);
+  _Pragma("unroll") for (int r = 0; r < RPW; ++r) vv[h][q][r] = buf_load(rs, voff + 256 * ((h) * QH + q) + (RPW * pw + r) * T * 4);
     STY_P_LOADH(0)
     mid();
     STY_P_LOADH(1)
@@ -290,19 +317,25 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
         const bool tin = t >= 0 && t < T;
         float mk = 1.f;
         if constexpr (PRO == PRO_MASK) mk = tin ? a.mask[(size_t)b * T + t] : 0.f;
-        float v[8];
+        float v[RPW];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-          v[r] = (8 * pw + r < Cin && tin) ? pro_apply<PRO>(vv[h][q][r], pa[r], ps[r], al[r], ral[r], mk) : 0.f;
+        for (int r = 0; r < RPW; ++r)
+          v[r] = (RPW * pw + r < Cin && tin) ? pro_apply<PRO>(vv[h][q][r], pa[r], ps[r], al[r], ral[r], mk) : 0.f;
         if (j < LW)
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + 8 * pw) =
-              sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+          p_put<RPW>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + RPW * pw, v);
       }
   }
 }
 
+// Producer waves: four of eight rows each in the fp32 mode (the consumers' MFMAs are the limit there), EIGHT of four rows each in
+// the bf16 mode (round 5): a producer requests a tile, waits, runs the prologue and drains the previous tile one after the
+// other, and with four of them a CU had too few bytes in flight -- the kernel ran at 3.3 TB/s with its MFMAs taking a third
+// of the time.  Twelve waves per workgroup need <= 170 registers: the producers' per-row state halves.
+template <bool BF>
+constexpr int p_npw() { return BF ? 8 : 4; }
 template <bool BF, int PRO>
-__global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_per_row, int ntiles, int dbg) {
+__global__ __launch_bounds__(64 * (4 + p_npw<BF>()), 1) void conv32p_kernel(ConvArgs a, int tiles_per_row, int ntiles, int dbg) {
+  constexpr int NPW = p_npw<BF>(), RPW = 32 / NPW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -328,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
   if constexpr (BF) {
     // packed fp32 weights Wp[k][ci][co] -> bf16 A fragments: lane (co = l31, k-block = hi) of k-step s holds the
     // eight input channels 16 s + 8 hi .. + 7
-    for (int it = tid; it < K * 2 * 64; it += 512) {
+    for (int it = tid; it < K * 2 * 64; it += 64 * (4 + NPW)) {
       const int ln = it & 63, s = (it >> 6) & 1, k = it >> 7;
       const int co = ln & 31, ci0 = 16 * s + 8 * (ln >> 5);
       float w8[8];
@@ -338,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
     }
   }
   const bool want_res = a.residual != nullptr && !(dbg & 4);
-  if (!consumer) p_stage<BF, PRO>(a, lds, p_tile(first, tiles_per_row), LW, wave - 4, lane, []() {});
+  if (!consumer) p_stage<BF, PRO, RPW>(a, lds, p_tile(first, tiles_per_row), LW, wave - 4, lane, []() {});
 
   // consumer state that does not change between tiles: bias per fragment row, and (fp32 mode) the weights of tap 0
   const int tw = wave * (32 * P_NT);  // consumers only
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
     if (!consumer) {
       // ---- producer ----
       const int pw = wave - 4;
-      PDrain d;
+      PDrain<RPW> d;
       const bool have_prev = i > 0 && !(dbg & 4);
       const PTile prev = p_tile(tile - 1, tiles_per_row);
       if (have_prev) p_res_load(a, prev, pw, lane, want_res, d);
@@ -376,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
       // k = 11 conv at c3's size, 77.7 -> 84.6 with bf16 source and output tensors.  The kernel moves 39 KB in and 32 KB out
       // per tile and CU at ~3.3 TB/s chip-wide; reads alone run at 3.6, writes alone at 2.9: profiles/r05_conv32p_variants.txt)
       if (i + 1 < count && !(dbg & 2))
-        p_stage<BF, PRO>(a, lds + ((i + 1) & 1) * bufsz, p_tile(tile + 1, tiles_per_row), LW, pw, lane, drain);
+        p_stage<BF, PRO, RPW>(a, lds + ((i + 1) & 1) * bufsz, p_tile(tile + 1, tiles_per_row), LW, pw, lane, drain);
       else
         drain();
     } else {
@@ -498,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void conv32p_kernel(ConvArgs a, int tiles_p
   // the last tile's output stage
   if (!consumer && !(dbg & 4)) {
     const PTile last = p_tile(first + count - 1, tiles_per_row);
-    PDrain d;
+    PDrain<RPW> d;
     p_res_load(a, last, wave - 4, lane, want_res, d);
     p_drain(a, ost + ((count - 1) & 1) * P_OUT, last, wave - 4, lane, d, tiles_per_row);
   }
@@ -542,7 +575,7 @@ static int launch_p(const ConvArgs& a, hipStream_t st) {
   snprintf(detail, sizeof(detail), "ci%d co%d k%d d%d T%d", a.w.Cin, a.w.Cout, a.w.K, a.dil, a.T);
   ProfScope prof(BF ? "conv32p_kernel<true>" : "conv32p_kernel<false>", flops, bytes, st, detail);
   const char* dbgs = getenv("STY_P_DBG");  // measurement aid: 1 = one tap only, 2 = no staging after tile 0, 4 = no drain
-  hipLaunchKernelGGL((conv32p_kernel<BF, PRO>), dim3(grid), dim3(512), lds, st, a, tiles_per_row, ntiles,
+  hipLaunchKernelGGL((conv32p_kernel<BF, PRO>), dim3(grid), dim3(64 * (4 + p_npw<BF>())), lds, st, a, tiles_per_row, ntiles,
                      dbgs ? atoi(dbgs) : 0);
   STY_LAUNCH_CHECK();
   return STY_OK;

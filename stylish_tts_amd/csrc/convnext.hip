@@ -177,9 +177,8 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
       }
     }
     const bool slow = __any(amax > 8192.0f);
-    // The element loop as a generic lambda over the "this block needs the library sine" flag: with STY_CNX_FWD_SPLIT (a build
-    // variant, tools/build_variant.sh) it exists twice -- the ordinary block without the library-sine path in its body, the rare
-    // one with it -- as in convnext_bwd.hip; by default the flag is a run-time value (measured: profiles/r05_cnx_variants.txt)
+    // The element loop exists twice, as in convnext_bwd.hip: the ordinary block without the library-sine path in its body, the
+    // rare one with it (the kernel had 221 basic blocks, a diamond per element; pass 1 1.14 -> 1.08 ms per step, pass 2 unchanged)
     auto elem_loop = [&](auto slow_c) {
       const bool SLOWP = slow_c;
   #pragma unroll
@@ -208,16 +207,15 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
           }
         }
         sq[r] = s2;
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (keeps the loads of later rows from being hoisted: with
+                                                              // one basic block per 32 x 32 block pass 2 went from 148 to 180 registers,
+                                                              // three waves per SIMD to two, and from 2.20 to 2.49 ms per step)
       }
     };
-#ifdef STY_CNX_FWD_SPLIT
     if (slow)
       elem_loop(std::true_type{});
     else
       elem_loop(std::false_type{});
-#else
-    elem_loop(slow);
-#endif
     if (PASS2) {
       const float* w2 = a.w2a + ((j * 16) * 2 + hi) * 32 + l31;
       float aw[16];

@@ -29,10 +29,16 @@ static inline int wg_target(bool bf16) { return WG_TARGET_ENV ? WG_TARGET_ENV : 
 // On the layers with few positions and many weights (the 256 <-> 1024 pointwise convs at T = 520: 16 640 positions, planes
 // of 0.25-1 M elements) a split aimed at ~3 workgroups per CU moved 50 MB of partial sums for 85 MB of operands -- 3 GB
 // per c3 step in all.  STY_WG_PARTIAL_FRAC = f caps the split so that the partial planes stay below f x the operand bytes
-// (0 = no cap).
-static const float WG_PARTIAL_FRAC = getenv("STY_WG_PARTIAL_FRAC") ? (float)atof(getenv("STY_WG_PARTIAL_FRAC")) : 0.f;
-static inline int wg_cap_partial(int nsplit, const PackedConv& w, int B, int T) {
-  if (WG_PARTIAL_FRAC <= 0.f) return nsplit;
+// (0 = no cap).  Default 0.25 since round 5 (A/B on the c3 step, one gpurun call, profiles/r05_ab_env.txt: no cap 54.06 ms,
+// f = 1.0 53.71, 0.5 53.45, 0.25 51.71 [the grouped reduction 1.43 -> 0.81 ms], 0.125 52.94, 0.06 58.37: below 0.25 the
+// weight-gradient launches of those layers no longer fill the chip).  Round 4 had it off: with a reduction launch per
+// weight gradient the cap bought nothing; with the grouped reduction the partial planes are its whole cost.
+static const float WG_PARTIAL_FRAC = getenv("STY_WG_PARTIAL_FRAC") ? (float)atof(getenv("STY_WG_PARTIAL_FRAC")) : 0.25f;
+// bf16 mode only (or wherever the variable is set explicitly): on c2 -- fp32 MFMAs, 16x longer matrix phases -- the same cap
+// COSTS 1.4 ms (30.92 ms without, 31.53 at f = 0.5, 32.31 at 0.25): there the splits are what fills the chip.
+static const bool WG_PARTIAL_FRAC_SET = getenv("STY_WG_PARTIAL_FRAC") != nullptr;
+static inline int wg_cap_partial(int nsplit, const PackedConv& w, int B, int T, bool bf16) {
+  if (WG_PARTIAL_FRAC <= 0.f || !(bf16 || WG_PARTIAL_FRAC_SET)) return nsplit;
   const double operands = (double)B * T * (w.Cin + w.Cout), plane = (double)w.K * w.CinP * w.CoutP;
   int cap = (int)(WG_PARTIAL_FRAC * operands / plane);
   if (cap < 1) cap = 1;
@@ -438,7 +444,7 @@ static int wgrad64_nsplit(const PackedConv& w, int B, int T, bool bf16 = false) 
   int nsplit = cdiv(tiles >= 16 ? target : target / 2, tiles);
   if (nsplit >= 8) nsplit = (nsplit + 7) & ~7;  // a multiple of 8: wgradb_kernel then keeps the blocks of a split on one XCD
   if (nsplit > chunks) nsplit = chunks;
-  return wg_cap_partial(nsplit, w, B, T);
+  return wg_cap_partial(nsplit, w, B, T, bf16);
 }
 
 // wgradb16_kernel's 128 x 64 / 128 x 96 blocks (round 5; 240-248 registers, two workgroups per CU): the split count that puts
@@ -449,7 +455,7 @@ static int wgrad16_nsplit(int blocks, const PackedConv& w, int B, int T) {
   if (ns >= 8) ns = (ns + 7) & ~7;
   const int chunks = B * cdiv(T, 128);
   if (ns > chunks) ns = chunks;
-  return wg_cap_partial(ns, w, B, T);
+  return wg_cap_partial(ns, w, B, T, true);
 }
 
 // ---- K == 1 (Linear / 1x1 conv) weight gradient: dW[co][ci] = sum_{b,t} G[co][t] x[ci][t] ----
@@ -657,7 +663,7 @@ static int w1_nsplit(const PackedConv& w, int B, int T, W1Cfg c, bool bf16 = fal
   const int chunks = B * cdiv(T, W1_TW);
   int nsplit = cdiv(wg_target(bf16), tiles);
   if (nsplit > chunks) nsplit = chunks;
-  return wg_cap_partial(nsplit, w, B, T);
+  return wg_cap_partial(nsplit, w, B, T, bf16);
 }
 
 // Slices are `stride` floats apart: [plane weight partials][nb bias partials (fused bias gradient, or unused)].
