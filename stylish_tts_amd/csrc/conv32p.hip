@@ -11,7 +11,8 @@
 //                             from LDS, issue MFMAs back to back (32 couts x 64 columns each; the loop is software-
 //                             pipelined by hand, the operands of step s+1 are requested while the MFMAs of step s issue)
 //                             and leave out_scale * (acc + bias) in an LDS output stage.  No global memory access.
-//   waves 4-7 (one per SIMD)  PRODUCERS: every byte of global traffic.  Per iteration they (a) request the residual
+//   waves 4-7 (fp32 mode; bf16 mode since round 5: waves 4-11, two per SIMD, four rows each instead of eight)
+//                             PRODUCERS: every byte of global traffic.  Per iteration they (a) request the residual
 //                             rows of the PREVIOUS tile with 16-byte loads, (b) buffer-load the NEXT tile (32 channels
 //                             x (256 + halo) columns), apply the fused prologue (AdaIN + Snake, ...) on the VALU and
 //                             write it into the other LDS tile buffer, (c) drain the previous tile's output stage: read

@@ -172,30 +172,40 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     f32x16 gxn;
 #pragma unroll
     for (int r = 0; r < 16; ++r) gxn[r] = 0.f;
+    // bf16 mode: the A fragments of the three GEMMs come READY MADE from a.wfrag (cnx_frag_pack_kernel: bf16, MFMA lane order,
+    // one 16-byte load per fragment; rounds 3-4: sixteen strided dword loads + eight v_cvt_pk per fragment and block), and the
+    // six fragments of block j + 1 are REQUESTED IN THE MIDDLE of block j's element loop.  vmcnt counts loads and stores in one
+    // in-order queue: a load issued behind the sixteen gH0 stores of an element loop is only "back" when those stores have
+    // been acknowledged by the memory system, so with the loads at the top of a block every block began with a full write
+    // latency, and the chained GEMM's fragments -- loaded behind the loop -- with another.  Requested after row 7, they wait
+    // for eight stores issued half a loop earlier and have the other half of the loop to arrive.  24 registers.
+    bf16x8 wf1[2], wf2[2], wf3[2];
+    auto load_w = [&](int jj) {
+      if constexpr (BF) {
+        const bf16x8* fr = reinterpret_cast<const bf16x8*>(a.wfrag) + (size_t)jj * 128 + lane;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          wf1[s_] = fr[s_ * 64];
+          wf2[s_] = fr[512 + s_ * 64];
+          if (PASS == 2) wf3[s_] = fr[1024 + s_ * 64];
+        }
+      }
+    };
+    load_w(0);
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
       f32x16 h, uu;
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[r] = uu[r] = 0.f;
+      bf16x8 awf[2];
       if constexpr (BF) {
-        const float* w1col = a.w1p + j * 32 + l31;  // [ci][ch]
-        const float* w2col = a.w2 + j * 32 + l31;   // raw pwconv2.weight [co][ch]
-        float av[16], a2[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {  // q = 8 s + e -> reduction row 16 s + 8 hi + e
-          const int c = 16 * (q >> 3) + 8 * hi + (q & 7);
-          av[q] = w1col[c * 128];
-          a2[q] = w2col[c * 128];
-        }
+        // this block's fragments: requested half an element loop ago (load_w), or just now for the first block of a pass
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
-          const bf16x8 a1f = sty_pack_bf16(av[8 * s_], av[8 * s_ + 1], av[8 * s_ + 2], av[8 * s_ + 3], av[8 * s_ + 4],
-                                           av[8 * s_ + 5], av[8 * s_ + 6], av[8 * s_ + 7]);
-          const bf16x8 a2f = sty_pack_bf16(a2[8 * s_], a2[8 * s_ + 1], a2[8 * s_ + 2], a2[8 * s_ + 3], a2[8 * s_ + 4],
-                                           a2[8 * s_ + 5], a2[8 * s_ + 6], a2[8 * s_ + 7]);
-          h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f, bxf[s_], h, 0, 0, 0);
-          uu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2f, byf[s_], uu, 0, 0, 0);
+          awf[s_] = wf3[s_];
+          h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s_], bxf[s_], h, 0, 0, 0);
+          uu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[s_], byf[s_], uu, 0, 0, 0);
         }
       } else {
         const float* w1row = a.w1p + hi * 128 + j * 32 + l31;  // [ci][ch]
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
             if (l31 == 31) atomicAdd(&red[wave * 128 + ch], rsum);  // one writer per slot (the same lane in both passes): a
                                                                      // ds_add_f32 instead of read / add / write
           }
+          if (BF && r == 7 && j < 3) load_w(j + 1);
           if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the per-channel loads / store addresses of later
                                                                 // rows from being hoisted (that cost 106 spilled VGPRs)
         }
@@ -301,20 +312,19 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
         elem_loop(std::false_type{});
 #endif
       if (PASS == 2) {  // gXn[ci][t] += sum_ch W1[ch][ci] gH0[ch][t]: the gH0 fragment is the B operand
-        float aw[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) aw[q] = a.w1[(size_t)(j * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * 32 + l31];
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr (BF) {
 #pragma unroll
           for (int s_ = 0; s_ < 2; ++s_) {
-            const bf16x8 af = sty_pack_bf16(aw[8 * s_], aw[8 * s_ + 1], aw[8 * s_ + 2], aw[8 * s_ + 3], aw[8 * s_ + 4],
-                                            aw[8 * s_ + 5], aw[8 * s_ + 6], aw[8 * s_ + 7]);
+            const bf16x8 af = awf[s_];
             const bf16x8 bf = sty_pack_bf16(h[8 * s_], h[8 * s_ + 1], h[8 * s_ + 2], h[8 * s_ + 3], h[8 * s_ + 4],
                                             h[8 * s_ + 5], h[8 * s_ + 6], h[8 * s_ + 7]);
             gxn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, gxn, 0, 0, 0);
           }
         } else {
+          float aw[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) aw[q] = a.w1[(size_t)(j * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * 32 + l31];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int q = 0; q < 16; ++q) gxn = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q], h[q], gxn, 0, 0, 0);
         }
@@ -399,7 +409,42 @@ int launch_cnx_partial_sum(const double* part, int B, int C, int ntiles, int mod
   return STY_OK;
 }
 
+// bf16 A fragments of a block's three backward GEMMs in the lane order v_mfma_f32_32x32x16_bf16 reads them (lane = (l31, hi), eight
+// reduction elements per lane and k-step s):
+//   m = 0  h  = W1 xn      element e: w1p[16 s + 8 hi + e][32 j + l31]
+//   m = 1  U  = W2^T gY    element e: w2raw[16 s + 8 hi + e][32 j + l31]
+//   m = 2  gXn += W1^T gH0 element e: w1raw[32 j + R(8 s + e, hi)][l31],  R(q, hi) = (q & 3) + 8 (q >> 2) + 4 hi (the row order
+//          of an accumulator fragment's registers: the chained GEMM takes gH0 straight from them)
+// One thread per (m, j, s, lane); rounded to nearest even once, as the kernel's own v_cvt_pk did per block and tile.
+__global__ __launch_bounds__(256) void cnx_frag_pack_kernel(const float* __restrict__ w1p, const float* __restrict__ w2raw,
+                                                            const float* __restrict__ w1raw, bf16x8* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * 4 * 2 * 64) return;
+  const int lane = i & 63, s_ = (i >> 6) & 1, j = (i >> 7) & 3, mtx = i >> 9;
+  const int l31 = lane & 31, hi = lane >> 5;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (mtx == 2) {
+      const int q = 8 * s_ + e;
+      v[e] = w1raw[(size_t)(32 * j + (q & 3) + 8 * (q >> 2) + 4 * hi) * 32 + l31];
+    } else {
+      v[e] = (mtx == 0 ? w1p : w2raw)[(size_t)(16 * s_ + 8 * hi + e) * 128 + 32 * j + l31];
+    }
+  }
+  out[i] = sty_pack_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+int launch_cnx_frag_pack(const float* w1p, const float* w2raw, const float* w1raw, void* wfrag, hipStream_t st) {
+  hipLaunchKernelGGL(cnx_frag_pack_kernel, dim3(6), dim3(256), 0, st, w1p, w2raw, w1raw, reinterpret_cast<bf16x8*>(wfrag));
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st) {
+  if (a.bf16 && !a.wfrag) {
+    set_error("convnext32_bwd: bf16 mode needs the packed weight fragments (launch_cnx_frag_pack)");
+    return STY_EINVAL;
+  }
   constexpr size_t lds = (32 * (CB_TT + 6) + 32 * (CB_TT + 1) + 256 + 4 * 128 + 4 * 64 + 5 * 128 + 64) * sizeof(float);
   static bool raised = false;
   if (!raised) {

@@ -337,7 +337,12 @@ struct Cnx32BwdArgs {       // convnext_bwd.hip
   int out_bf16 = 0;         // (pass 2, bf16 mode) hs and gh0 are written as bf16 [B][128][T]: operands of wgrad_cnx_kernel
   int lean = 0;             // (pass 2, bf16 mode with out_bf16) h s is not written and d alpha is not accumulated: both come
                             // from the weight-gradient GEMMs (launch_cnx_m_finish / launch_cnx_dalpha)
+  const void* wfrag = nullptr;  // bf16 mode (required): the A fragments of the three GEMMs, made by launch_cnx_frag_pack:
+                                // [3 matrices][4 blocks][2 k-steps][64 lanes] x 8 bf16 (24 KB)
 };
+constexpr size_t CNX_FRAG_HALFS = 3 * 4 * 2 * 64 * 8;
+// w1p: packed pwconv1 [32 ci][128 ch]; w2raw: pwconv2.weight [32][128]; w1raw: pwconv1.weight [128][32]
+int launch_cnx_frag_pack(const float* w1p, const float* w2raw, const float* w1raw, void* wfrag, hipStream_t st);
 // The lean backward of the fused block (bf16 mode): see convnext_bwd.hip
 int launch_cnx_m_finish(float* partial, int B, int SB, const float* w2raw, const float* scale, float* ds, float* gw2,
                         float* gb2, hipStream_t st);

@@ -669,6 +669,9 @@ struct Trainer {
     const bool lean = m->topts.compute_bf16 && Tt % 8 == 0 && getenv("STY_NO_WGRADB") == nullptr &&
                       getenv("STY_NO_CNX_LEAN") == nullptr;
     __bf16* h16 = lean ? take<__bf16>(n128) : nullptr;
+    // bf16 mode: the backward's A fragments, made once per step and block (24 KB; convnext_bwd.hip)
+    __bf16* wfrag = m->topts.compute_bf16 ? take<__bf16>(CNX_FRAG_HALFS) : nullptr;
+    if (live() && wfrag) chk(launch_cnx_frag_pack(c.w1p, c.w2_raw, c.w1_raw, wfrag, st));
     if (live()) {
       Cnx32Args a;
       a.x = x;
@@ -763,6 +766,7 @@ struct Trainer {
       a.T = Tt;
       a.ntiles = nt;
       a.bf16 = m->topts.compute_bf16;
+      a.wfrag = wfrag;
       // bf16 mode: h s and gH0 leave the kernel as bf16 and feed wgrad_cnx_kernel (T % 8: its 8-sample groups)
       const bool cnx16 = a.bf16 && Tt % 8 == 0 && getenv("STY_NO_WGRADB") == nullptr;
       a.out_bf16 = cnx16;
