@@ -477,6 +477,20 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     }
     if phases:
         rec["phases_ms"] = phases
+    if w["what"] == "vocoder":
+        # achieved HBM rate of the vocoder stack from the committed PMC passes of this same workload (FETCH_SIZE x2 + WRITE_SIZE
+        # summed over every kernel of a forward, tools/profile_round.sh) over THIS run's time per forward
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{name}_pmc_traffic.json")), reverse=True):
+            try:
+                tot = json.load(open(f)).get("_total")
+            except Exception:
+                tot = None
+            if tot:
+                rec["hbm_counter_GBps"] = (tot["fetch_bytes_per_pass"] + tot["write_bytes_per_pass"]) / (dt / steps) / 1e9
+                rec["hbm_counter_bytes_per_pass"] = tot["fetch_bytes_per_pass"] + tot["write_bytes_per_pass"]
+                rec["hbm_counter_source"] = os.path.relpath(f, ROOT)
+                break
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
         traffic, traffic_src = pmc_traffic(dom["name"], name)

@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
       }
     }
     const bool slow = __any(amax > 8192.0f);
+    // (Measured and rejected, round 5: ready-made bf16 A fragments requested in the middle of the element loop, as the lean
+    // backward does -- pass 2 went from 163 to 190 registers, three waves per SIMD to two, and from 2.12 to 2.44 ms per c3 step;
+    // profiles/r05_ab_env.txt block 6.  This kernel lives on its third wave.)
     // The element loop exists twice, as in convnext_bwd.hip: the ordinary block without the library-sine path in its body, the
     // rare one with it (the kernel had 221 basic blocks, a diamond per element; pass 1 1.14 -> 1.08 ms per step, pass 2 unchanged)
     auto elem_loop = [&](auto slow_c) {

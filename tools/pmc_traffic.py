@@ -22,7 +22,7 @@ def collect(d, name):
     return tot, n
 
 
-def main(fetch_dir, write_dir):
+def main(fetch_dir, write_dir, forwards=0):
     ft, fn = collect(fetch_dir, "FETCH_SIZE")
     wt, wn = collect(write_dir, "WRITE_SIZE")
     out = {}
@@ -32,8 +32,14 @@ def main(fetch_dir, write_dir):
         out[k] = {"launches": fn[k], "fetch_bytes_per_launch": 2.0 * 1024.0 * ft[k] / fn[k],
                   "write_bytes_per_launch": 1024.0 * wt.get(k, 0.0) / max(1, wn.get(k, 0)),
                   "note": "FETCH_SIZE x2 (gfx950 correction) x1024; WRITE_SIZE x1024 uncorrected"}
+    if forwards:
+        # the whole command: every kernel of every pass (steps + warm-up + the profiled step; preparation kernels once)
+        fb = sum(v["fetch_bytes_per_launch"] * v["launches"] for v in out.values())
+        wb = sum(v["write_bytes_per_launch"] * v["launches"] for v in out.values())
+        out["_total"] = {"passes": forwards, "fetch_bytes_per_pass": fb / forwards, "write_bytes_per_pass": wb / forwards,
+                         "note": "sum over all kernels of the profiled command / number of passes of the workload in it"}
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)

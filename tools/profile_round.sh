@@ -3,7 +3,7 @@
 #   kernel-trace summaries (rocprofv3 --kernel-trace --stats) of the default bench command (c3) and of c5 / c2,
 #   HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes) of the default bench command and of c5,
 #   the per-stream picture of one c3 step, bench JSON lines of every workload.
-tag=${1:-r04}
+tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 rm -rf $O; mkdir -p $O
@@ -13,27 +13,30 @@ B="python $R/bench.py --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats -d $O/c3_trace -- $B --steps 6 --warmup 2 > $O/c3_under_rocprof.json 2> $O/c3_trace.log
 rocprofv3 --kernel-trace --stats -d $O/c5_trace -- $B --workload c5 --steps 20 --warmup 5 > $O/c5_under_rocprof.json 2> $O/c5_trace.log
 rocprofv3 --kernel-trace --stats -d $O/c2_trace -- $B --workload c2 --steps 10 --warmup 3 > $O/c2_under_rocprof.json 2> $O/c2_trace.log
+rocprofv3 --kernel-trace --stats -d $O/c5b_trace -- $B --workload c5-bf16 --steps 20 --warmup 5 > $O/c5_bf16_under_rocprof.json 2> $O/c5b_trace.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c3_fetch -- $B --steps 2 --warmup 1 > /dev/null 2> $O/c3_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c3_write -- $B --steps 2 --warmup 1 > /dev/null 2> $O/c3_write.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c5_fetch -- $B --workload c5 --steps 5 --warmup 2 > /dev/null 2> $O/c5_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c5_write -- $B --workload c5 --steps 5 --warmup 2 > /dev/null 2> $O/c5_write.log
-# ... and of the other workloads the bench line carries a roofline for (c2, c3-fp32, c3-gan), on THIS round's library
-for wl in c2 c3-fp32 c3-gan; do
+# ... and of the other workloads with a roofline of their own (c2; c5-bf16: the tracked vocoder figure since round 5), on THIS round's library
+for wl in c2 c5-bf16; do
   n=2; [ $wl = c2 ] && n=4
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${wl}_fetch -- $B --workload $wl --steps $n --warmup 1 > /dev/null 2> $O/${wl}_fetch.log
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${wl}_write -- $B --workload $wl --steps $n --warmup 1 > /dev/null 2> $O/${wl}_write.log
 done
 cd $R
-for wl in c2 c3-fp32 c3-gan; do
-  python tools/pmc_traffic.py $O/${wl}_fetch $O/${wl}_write > $O/${tag}_${wl}_pmc_traffic.json
+for wl in c2 c5-bf16; do
+  np=0; [ $wl = c5-bf16 ] && np=4   # c5-bf16: 2 timed + 1 warm-up + 1 profiled forward in the command above
+  python tools/pmc_traffic.py $O/${wl}_fetch $O/${wl}_write $np > $O/${tag}_${wl}_pmc_traffic.json
   cp $O/${tag}_${wl}_pmc_traffic.json $R/profiles/
   rm -rf $O/${wl}_fetch $O/${wl}_write
 done
 python tools/pmc_traffic.py $O/c3_fetch $O/c3_write > $O/${tag}_c3_pmc_traffic.json
-python tools/pmc_traffic.py $O/c5_fetch $O/c5_write > $O/${tag}_c5_pmc_traffic.json
+python tools/pmc_traffic.py $O/c5_fetch $O/c5_write 8 > $O/${tag}_c5_pmc_traffic.json   # 5 timed + 2 warm-up + 1 profiled forward
 python tools/rocpd_summary.py $O/c3_trace/*/*_results.db > $O/${tag}_c3_kernel_stats.txt
 python tools/rocpd_summary.py $O/c5_trace/*/*_results.db > $O/${tag}_c5_kernel_stats.txt
 python tools/rocpd_summary.py $O/c2_trace/*/*_results.db > $O/${tag}_c2_kernel_stats.txt
+python tools/rocpd_summary.py $O/c5b_trace/*/*_results.db > $O/${tag}_c5-bf16_kernel_stats.txt
 python tools/stream_busy.py $O/c3_trace/*/*_results.db 6 > $O/${tag}_c3_streams.txt
 # where the main stream waits inside one timed step (the last steps of a bench run are its single-stream extras: skip 6)
 python tools/step_gaps.py $O/c3_trace/*/*_results.db 6 150 > $O/${tag}_c3_gaps.txt
@@ -71,5 +74,5 @@ bash tools/pmc_mfma.sh $tag; cp $R/gpurun_out/pmc_mfma/${tag}_c3_pmc_mfma.txt $O
 python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/buffer_offset_probe.hip -o /tmp/buffer_offset_probe 2>/dev/null && /tmp/buffer_offset_probe > $O/${tag}_buffer_offset_probe.txt
-rm -rf $O/c3_trace $O/c5_trace $O/c2_trace $O/c3_fetch/*/*agent_info.csv $O/c5_fetch/*/*agent_info.csv
+rm -rf $O/c3_trace $O/c5_trace $O/c2_trace $O/c5b_trace $O/c3_fetch/*/*agent_info.csv $O/c5_fetch/*/*agent_info.csv
 ls -la $O
