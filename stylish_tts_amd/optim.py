@@ -97,9 +97,15 @@ class FlatAdamW:
                  "params": list(range(len(self._all)))}
         return {"state": state, "param_groups": [group]}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, allow_mixed_steps=False):
         """Inverse of state_dict; also reads what torch.optim.AdamW.state_dict() / accelerate's optimizer.bin hold.
-        Parameters without an entry (never stepped) restart from zero moments, as torch does."""
+        Parameters without an entry (never stepped) restart from zero moments, as torch does.
+        allow_mixed_steps: a file whose parameters sit at different step counts (torch keeps one counter per parameter; under
+        the reference's DDP(find_unused_parameters=True) a parameter without a gradient on some steps lags) is accepted and
+        continued at the largest count.  Off by default: the flat buckets have ONE bias-correction counter, so the lagging
+        parameters resume with a bias correction that is ahead of torch's -- a silent divergence from a torch.optim.AdamW
+        resume of the same file unless every count is large enough that 1 - beta^t is ~1 (accepted without the flag when
+        the smallest count is >= 1000: the correction factors then differ by < 5e-5 at beta2 = 0.99)."""
         slots = self._slots()
         groups = sd.get("param_groups", [])
         if len(groups) != 1 or len(groups[0]["params"]) != len(self._all):
@@ -133,6 +139,9 @@ class FlatAdamW:
             # parameters is slightly ahead -- a factor 1 - beta^t that is ~1 after a few hundred steps) instead of
             # refusing the checkpoint.  Parameters that never receive a gradient here are still decayed every step;
             # torch skips a grad=None parameter entirely.
+            if not allow_mixed_steps and min(steps) < 1000:
+                raise L.StyError(f"optimizer state: parameters at different step counts {sorted(steps)} (pass "
+                                 "allow_mixed_steps=True to continue at the largest)")
             import warnings
             warnings.warn(f"optimizer state: parameters at different step counts {sorted(steps)}; continuing at "
                           f"{max(steps)}", stacklevel=2)

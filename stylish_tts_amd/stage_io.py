@@ -283,11 +283,17 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
     # accelerator.is_main_process); each file is written beside its final name and moved over it (os.replace), so that a
     # reader never sees a half-written file.  Parameters and optimizer state are identical on every rank (all-reduced
     # gradients, the same AdamW), the tracked discriminator losses are the rank mean: rank 0's copy is THE state.
-    if not multi or dist.get_rank() == 0:
+    # A failure of rank 0's I/O (disk full, permissions) must not leave the other ranks in the closing collective for good:
+    # the error is caught, every rank learns of it through a one-int broadcast, temp files are removed, and ALL ranks raise.
+    # `path` has to be on a file system every rank that will load it can see (rank 0 is the only writer).
+    tmps = []
+
+    def _write_all():
         os.makedirs(path, exist_ok=True)
 
         def write(obj, name):
             tmp = osp.join(path, f".{name}.tmp{os.getpid()}")
+            tmps.append(tmp)
             torch.save(obj, tmp)
             os.replace(tmp, osp.join(path, name))
 
@@ -307,8 +313,26 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
         for name, obj in (("manifest", manifest), ("normalization", normalization)):
             if obj is not None:
                 write(obj.state_dict(), f"custom_checkpoint_{CUSTOM_ORDER.index(name)}.pkl")
+
+    err = None
+    if not multi or dist.get_rank() == 0:
+        try:
+            _write_all()
+        except Exception as e:  # noqa: BLE001 -- re-raised below, on every rank
+            err = e
+            for t in tmps:
+                try:
+                    os.unlink(t)
+                except OSError:
+                    pass
     if multi:
-        dist.barrier()  # nobody returns (and possibly loads the directory) before rank 0 has finished writing
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32,
+                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.broadcast(flag, 0)  # also the closing barrier: nobody returns before rank 0 has finished writing
+        if err is None and int(flag.item()):
+            err = L.StyError(f"save_checkpoint: rank 0 failed to write {path}")
+    if err is not None:
+        raise err
     return path
 
 

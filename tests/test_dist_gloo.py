@@ -133,3 +133,47 @@ def test_save_checkpoint_is_collective_and_only_rank0_writes(tmp_path):
         assert files == sorted(["pytorch_model_3.bin", "custom_checkpoint_2.pkl", "custom_checkpoint_3.pkl"]), files
         assert w00 == 1.0          # rank 0's parameters, also as seen from rank 1
         assert buf == [0.0] * 4    # rank 0's buffer after sync_buffers
+
+
+def _ckpt_fail_worker(rank, world, port, q, good, bad):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from stylish_tts_amd import dist as D, stage_io
+    D.init("gloo")
+    m = torch.nn.Linear(3, 2)
+    out = []
+    # (1) a writable directory: rank 0 writes, both ranks return
+    stage_io.save_checkpoint(good, {"speech_predictor": m})
+    out.append(os.path.exists(os.path.join(good, stage_io.model_file("speech_predictor"))))
+    # (2) rank 0 cannot write (the "directory" is a file): BOTH ranks must raise, nobody may hang in the closing collective
+    try:
+        stage_io.save_checkpoint(bad, {"speech_predictor": m})
+        out.append("returned")
+    except Exception as e:  # noqa: BLE001
+        out.append(type(e).__name__)
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_save_checkpoint_failure_on_rank0_raises_on_every_rank(tmp_path):
+    """stage_io.save_checkpoint at world size 2 (round-4 advisor finding): when rank 0's I/O fails, the other rank used to wait
+    in the closing barrier for good.  Now the failure is broadcast and every rank raises; temp files do not stay behind."""
+    world = 2
+    port = _free_port()
+    good = str(tmp_path / "ok")
+    blocker = tmp_path / "blocker"
+    blocker.write_text("a file where a directory is wanted")
+    bad = str(blocker / "ckpt")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ckpt_fail_worker, args=(r, world, port, q, good, bad)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][0] is True and res[1][0] is True
+    assert res[0][1] != "returned" and res[1][1] != "returned", res
+    assert not [f for f in os.listdir(good) if ".tmp" in f]
