@@ -249,8 +249,9 @@ int sty_speech_fwd_train(sty_model *m, const sty_speech_io *io, void *workspace,
 int sty_speech_bwd(sty_model *m, const float *d_audio, float *d_style, float *d_energy, void *stream);
 /* Optional: the weight-side half of the next sty_speech_fwd_train (weight-norm / packed weights, input-gradient packs, bf16
  * fragments) issued on `stream` ahead of time -- after the optimizer step that produced the parameters (train/stage.py:
- * 104-124 steps the optimizer at the end of train_batch); that forward (same stream, or ordered after this call) then
- * skips it.  The parameters must not change in between (sty_model_invalidate cancels it).                              */
+ * 104-124 steps the optimizer at the end of train_batch); that forward then skips it and waits, on ITS stream, for an event
+ * recorded behind this call.  The parameters must not change in between: the library cannot see an optimizer step (it runs
+ * on flat buffers) -- sty_model_invalidate cancels the preparation and is the caller's statement that they did.          */
 int sty_speech_prepare_train(sty_model *m, void *stream);
 /* ... and d loss / d pitch [B,T] (the textual stage feeds the PREDICTED pitch and energy to the frozen speech predictor,
  * train/stage_type.py:139-160; the harmonic source and the voiced flag carry no gradient).  Any output may be NULL.   */
@@ -267,8 +268,8 @@ int sty_style_fwd_train(sty_model *m, int B, int T, const float *mel, float *sty
 int sty_style_bwd(sty_model *m, const float *d_style, void *stream);
 /* Optional: the weight-side half of the next sty_style_fwd_train / sty_pitch_style_fwd_train (spectral-norm power
  * iteration of module.train(), normalised and packed weights) issued on `stream` ahead of time, e.g. while another stream
- * still computes the mel input; that forward (which must be issued on the same stream) then skips it.  The parameters
- * and train opts must not change in between.                                                                        */
+ * still computes the mel input; that forward then skips it (any stream: it waits for an event recorded behind this call).
+ * The parameters and train opts must not change in between (sty_model_invalidate cancels it).                        */
 int sty_style_prepare_train(sty_model *m, void *stream);
 /* Parity taps of the last sty_style_fwd_train / sty_pitch_style_fwd_train: index 0 = the stem conv's output, 1..4 = the
  * ResBlk outputs (mel_style_encoder.py:96-118), 5 = the 5x5 head conv's output at every position (valid where the window

@@ -1434,6 +1434,7 @@ void sty_model_destroy(sty_model* m) {
     convp16_forget_range(m->arena, m->arena + m->arena_bytes);
     (void)hipFree(m->arena);
   }
+  if (m->prepared_ev) (void)hipEventDestroy(m->prepared_ev);
   if (m->fcs_dev) (void)hipFree(m->fcs_dev);
   if (m->stft_default) (void)hipFree(m->stft_default);
   if (m->garena) (void)hipFree(m->garena);
@@ -1636,6 +1637,19 @@ int sty_speech_train_workspace_bytes(sty_model* m, int B, int L, int T, size_t* 
   return trainer_speech_forward(m->trainer, &io, nullptr, 0, nullptr, bytes);
 }
 
+// sty_*_prepare_train may run on another stream than the forward that consumes it: an event recorded behind the preparation
+// orders the two (a no-op on the same stream).  The library cannot see a parameter update between the two calls (AdamW runs
+// on flat buffers, not on a model): sty_model_invalidate is the caller's statement that the parameters changed.
+static int prepared_mark(sty_model* m, void* stream) {
+  if (!m->prepared_ev) STY_HIP(hipEventCreateWithFlags(&m->prepared_ev, hipEventDisableTiming));
+  STY_HIP(hipEventRecord(m->prepared_ev, S(stream)));
+  return STY_OK;
+}
+static int prepared_consume(sty_model* m, void* stream) {
+  m->train_prepared = false;
+  if (m->prepared_ev) STY_HIP(hipStreamWaitEvent(S(stream), m->prepared_ev, 0));
+  return STY_OK;
+}
 int sty_speech_fwd_train(sty_model* m, const sty_speech_io* io, void* workspace, size_t ws_bytes, void* stream) {
   int rc = model_ready(m, "speech_predictor");
   if (rc) return rc;
@@ -1649,7 +1663,7 @@ int sty_speech_fwd_train(sty_model* m, const sty_speech_io* io, void* workspace,
     return STY_EINVAL;
   }
   if (m->train_prepared) {  // done by sty_speech_prepare_train since the last optimizer step
-    m->train_prepared = false;
+    if ((rc = prepared_consume(m, stream))) return rc;
   } else if ((rc = sty_model_prepare(m, stream))) {
     return rc;
   }
@@ -1669,6 +1683,7 @@ int sty_speech_prepare_train(sty_model* m, void* stream) {
   }
   m->train_prepared = false;
   if ((rc = sty_model_prepare(m, stream))) return rc;
+  if ((rc = prepared_mark(m, stream))) return rc;
   m->train_prepared = true;
   return STY_OK;
 }
@@ -2635,10 +2650,8 @@ int sty_style_fwd(sty_model* m, int B, int T, const float* mel, float* style, vo
 // caller's buffers) and the prepared (normalised, packed) weights.  It depends on the parameters only, so a caller may
 // issue it early (sty_style_prepare_train) beside the work that produces the encoder's input; the forward then skips it.
 static int style_train_prepare(sty_model* m, void* stream) {
-  if (m->train_prepared) {  // done by sty_style_prepare_train since the last forward
-    m->train_prepared = false;
-    return STY_OK;
-  }
+  if (m->train_prepared)  // done by sty_style_prepare_train since the last forward
+    return prepared_consume(m, stream);
   int rc;
   if (m->topts.sn_power_iter) {  // every spectral-norm layer in four launches (u, v in the caller's buffers)
     if (!m->mj_ready && (rc = build_multi_tables(m))) return rc;
@@ -2660,6 +2673,7 @@ int sty_style_prepare_train(sty_model* m, void* stream) {
   }
   m->train_prepared = false;
   if ((rc = style_train_prepare(m, stream))) return rc;
+  if ((rc = prepared_mark(m, stream))) return rc;
   m->train_prepared = true;
   return STY_OK;
 }

@@ -217,6 +217,7 @@ struct sty_model {
   std::vector<std::string> requested;
   bool finalized = false, prepared = false;
   bool train_prepared = false;  // sty_style_prepare_train ran and the next training forward has not consumed it yet
+  hipEvent_t prepared_ev = nullptr;  // recorded behind that preparation on ITS stream: the consuming forward waits for it
   int style_dim = 64;
   // prepared-weight arena
   char* arena = nullptr;
