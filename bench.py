@@ -678,6 +678,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c5 sub-records and the RCCL world-1 record of the default run")
     ap.add_argument("--extra", action="store_true", help="also run c2 / c3-fp32 / c3-gan as sub-records (the default run carries c5 only)")
+    ap.add_argument("--rccl1", action="store_true", help="tuning aid: the main record IS the step under RCCL at world size 1 with every "
+                    "gradient bucket all-reduced (what `ranks.rccl_world1` measures), e.g. under rocprofv3 (tools/prof_rccl1.sh)")
     ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json beside bench.py, "
                                                    "and gpurun_out/ when that directory exists)")
     args = ap.parse_args()
@@ -712,6 +714,13 @@ def main():
     if not share and torch.cuda.device_count() < int(os.environ.get("WORLD_SIZE", "1")):
         raise SystemExit(f"bench.py: {os.environ['WORLD_SIZE']} ranks asked for, {torch.cuda.device_count()} HIP devices "
                          "visible (one process per GPU; STY_BENCH_SHARE_DEVICE=1 is the 1-GPU test aid)")
+    if args.rccl1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.environ.update(STY_DIST_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world = D.init("gloo" if share else "nccl")  # "nccl" = RCCL; one process per GPU (torchrun environment)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
@@ -747,7 +756,7 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     rccl1 = None
-    if world == 1 and args.workload == "c3" and not args.no_extra and not share:
+    if world == 1 and args.workload == "c3" and not args.no_extra and not share and not args.rccl1:
         # RCCL under the step on a 1-GPU box: backend "nccl" with ONE rank and the gradient exchange forced
         # (STY_DIST_FORCE_COLLECTIVE=1, dist.force_collective): every bucket goes through all_reduce(async_op=True) from the
         # library's gradient hooks, RCCL's streams run beside the trainer's four under GPU_MAX_HW_QUEUES=2.
@@ -760,7 +769,8 @@ def main():
                               WORLD_SIZE="1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             D.init("nccl")
-            r = run_workload("c3", min(args.steps, 10), min(args.warmup, 3), 0, 1, device, lib, L, D, share, serial_pass=False)
+            r = run_workload("c3", args.steps, args.warmup, 0, 1, device, lib, L, D, share, serial_pass=False)  # (the headline's own K / W:
+            # measured with 10 / 3 the record read 1.07 where the same step as a run of its own -- bench.py --rccl1 -- reads 1.00)
             rccl1 = {"what": "the c3 step with backend nccl (RCCL), world size 1, every gradient bucket all-reduced "
                              "(STY_DIST_FORCE_COLLECTIVE=1) -- the collective path of an N-GPU run minus the wire",
                      "ms_per_step": r["ms_per_step"], "vs_no_process_group": r["ms_per_step"] / rec["ms_per_step"],

@@ -186,30 +186,58 @@ __global__ __launch_bounds__(256) void pro_bwd_adain_kernel(const void* __restri
   const float a = pa[row], s = ps[row], al = alpha[c], ral = 1.0f / al;
   const int n8 = T / 8;
   const size_t r8 = row * n8;
-  auto deriv = [&](float uv, float xv, float& dal) -> float {
-    const float z = fmaf(a, xv, s);
-    float sn, cs;
-    if (hw && fabsf(al * z) <= 8192.0f)
-      sty_sincos_hw(al * z, sn, cs);
-    else
-      sty_sincos(al * z, sn, cs);
-    const float s2a = 2.f * sn * cs;
-    dal = uv * (z * s2a - sn * sn * ral) * ral;
-    return uv * (1.f + s2a);
+  // g = u snake'(a x + s) (and the d alpha term) for a thread's eight samples: the hardware sine / cosine behind ONE range check
+  // per group and wave in the bf16 mode (a check and an inlined library path per element before: a diamond per element)
+  auto deriv8 = [&](const float (&uv)[8], const float (&xv)[8], float (&g)[8], float (&dal)[8]) {
+    float z[8], amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      z[e] = fmaf(a, xv[e], s);
+      amax = fmaxf(amax, fabsf(al * z[e]));
+    }
+    // (sine and cosine stay scalars inside each branch: as arrays shared with the library path, whose out-of-line call takes
+    // their address, they lived in scratch memory on the fast path too -- 112 bytes per lane, 1.31 -> 2.79 ms per c3 step)
+    auto fin = [&](int e, float sn, float cs) {
+      const float s2a = 2.f * sn * cs;
+      dal[e] = uv[e] * (z[e] * s2a - sn * sn * ral) * ral;
+      g[e] = uv[e] * (1.f + s2a);
+    };
+    const bool big = __any(amax > 8192.0f);
+    if (hw && !big) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float sn, cs;
+        sty_sincos_hw(al * z[e], sn, cs);
+        fin(e, sn, cs);
+      }
+    } else if (!big) {  // fp32 mode: the same polynomials as sty_sincos, without its per-element range check
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float sn, cs;
+        sty_sincos_fast(al * z[e], sn, cs);
+        fin(e, sn, cs);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float sn, cs;
+        sty_sincos(al * z[e], sn, cs);
+        fin(e, sn, cs);
+      }
+    }
   };
   double acc[3] = {0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < n8; i += 256) {
     float uv[8], xv[8];
     ld8_any(u, r8 + i, uh != 0, uv);
     ld8_any(x, r8 + i, xh != 0, xv);
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, g[8], dal[8];
+    deriv8(uv, xv, g, dal);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float dal;
-      const float g = deriv(uv[e], xv[e], dal);
-      p0 = fmaf(g, xv[e], p0);
-      p1 += g;
-      p2 += dal;
+      p0 = fmaf(g[e], xv[e], p0);
+      p1 += g[e];
+      p2 += dal[e];
     }
     acc[0] += (double)p0;
     acc[1] += (double)p1;
@@ -239,12 +267,10 @@ __global__ __launch_bounds__(256) void pro_bwd_adain_kernel(const void* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) d[e] = 0.f;
     }
+    float g[8], dal[8];
+    deriv8(uv, xv, g, dal);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float dal;
-      const float g = deriv(uv[e], xv[e], dal);
-      d[e] += fmaf(g, a, fmaf(c1, xv[e], c0));
-    }
+    for (int e = 0; e < 8; ++e) d[e] += fmaf(g[e], a, fmaf(c1, xv[e], c0));
     st8_any(dx, r8 + i, dh != 0, d);
   }
 }

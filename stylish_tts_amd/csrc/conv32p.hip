@@ -208,6 +208,21 @@ __device__ __forceinline__ void p_drain(const ConvArgs& a, const float* ostage, 
 // explicit `tin` predicate, so whatever a load outside the row returns (the neighbouring row, or 0 outside the slab) is
 // never used.  `mid` runs between the first batch of loads and their use (the drain of the previous tile: its stores
 // go out while this tile's loads are in flight).
+// the prologue of one column's RPW channels in the bf16 tile mode: AdaIN + Snake takes the hardware sine behind ONE range
+// check per group (sty_snake_group_hw); values of dead rows / columns are zeroed by the caller afterwards
+template <int PRO, int RPW>
+__device__ __forceinline__ void p_pro_group(const float (&x)[RPW], const float (&pa)[RPW], const float (&ps)[RPW],
+                                            const float (&al)[RPW], const float (&ral)[RPW], float mk, float (&v)[RPW]) {
+  if constexpr (PRO == PRO_AFFINE_SNAKE) {
+    float z[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) z[r] = fmaf(x[r], pa[r], ps[r]);
+    sty_snake_group_hw<RPW>(z, al, ral, v);
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) v[r] = pro_apply<PRO>(x[r], pa[r], ps[r], al[r], ral[r], mk);
+  }
+}
 // the RPW channels of one column of the bf16 tile (one ds_write_b128, or one ds_write_b64 with eight producer waves)
 template <int RPW>
 __device__ __forceinline__ void p_put(__bf16* dst, const float (&v)[RPW]) {
@@ -288,11 +303,12 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
           const bool tin = t >= 0 && t < T;
           float mk = 1.f;
           if constexpr (PRO == PRO_MASK) mk = tin ? a.mask[(size_t)b * T + t] : 0.f;
-          float v[RPW];
+          float v[RPW], xin[RPW];
 #pragma unroll
-          for (int r = 0; r < RPW; ++r)
-            v[r] = (RPW * pw + r < Cin && tin) ? pro_apply<PRO>(e ? sty_bf_hi(vh[q][r]) : sty_bf_lo(vh[q][r]), pa[r], ps[r], al[r], ral[r], mk)
-                                            : 0.f;
+          for (int r = 0; r < RPW; ++r) xin[r] = e ? sty_bf_hi(vh[q][r]) : sty_bf_lo(vh[q][r]);
+          p_pro_group<PRO, RPW>(xin, pa, ps, al, ral, mk, v);
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) v[r] = (RPW * pw + r < Cin && tin) ? v[r] : 0.f;
           if (j < LWs)
             p_put<RPW>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + RPW * pw, v);
         }
@@ -319,9 +335,9 @@ __device__ __forceinline__ void p_stage(const ConvArgs& a, float* dst, PTile tl,
         float mk = 1.f;
         if constexpr (PRO == PRO_MASK) mk = tin ? a.mask[(size_t)b * T + t] : 0.f;
         float v[RPW];
+        p_pro_group<PRO, RPW>(vv[h][q], pa, ps, al, ral, mk, v);
 #pragma unroll
-        for (int r = 0; r < RPW; ++r)
-          v[r] = (RPW * pw + r < Cin && tin) ? pro_apply<PRO>(vv[h][q][r], pa[r], ps[r], al[r], ral[r], mk) : 0.f;
+        for (int r = 0; r < RPW; ++r) v[r] = (RPW * pw + r < Cin && tin) ? v[r] : 0.f;
         if (j < LW)
           p_put<RPW>(reinterpret_cast<__bf16*>(dst) + (size_t)j * P_PITCH + RPW * pw, v);
       }

@@ -524,9 +524,45 @@ __device__ __forceinline__ float sty_half_sum_to_lane31(float v) {
   t += sty_dpp<0x142, 0xa, 0xf, false>(t);          // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold 32-lane sums
   return t;
 }
+// Snake of a group of N values in the bf16 compute mode: the hardware sine when every argument of the WAVE's group is inside
+// its range (|alpha z| <= 8192: always, in practice), the exact path for the whole group otherwise -- ONE wave-uniform branch
+// per group.  The per-element form (a range check and an out-of-line library call inside sty_sin2) put a diamond and ~14
+// vector instructions per element into the prologues of conv32p_kernel / wgradp32_kernel, whose producers are bound by
+// exactly that: two thirds of a producer wave's vector instructions in the AdaIN + Snake variant (profiles/r05_cnx_pmc_sq_counters.txt).
+// The result is rounded to bf16 by every caller, as in the fused ConvNeXt32 kernels that have used v_sin_f32 since round 3.
+template <int N>
+__device__ __forceinline__ void sty_snake_group_hw(const float (&z)[N], const float (&al)[N], const float (&ral)[N], float (&out)[N]);
+template <int N>  // ... the same with one alpha for the group (a thread's eight samples of one row)
+__device__ __forceinline__ void sty_snake_group_hw1(const float (&z)[N], float al, float ral, float (&out)[N]);
 // Snake: v + sin^2(alpha v) / alpha   (conv_next.py:78, ada_norm.py:114)
 __device__ __forceinline__ float sty_snake(float v, float alpha, float ralpha) {
   return fmaf(ralpha, sty_sin2(alpha * v), v);
+}
+template <int N>
+__device__ __forceinline__ void sty_snake_group_hw1(const float (&z)[N], float al, float ral, float (&out)[N]) {
+  float amax = 0.f;
+#pragma unroll
+  for (int r = 0; r < N; ++r) amax = fmaxf(amax, fabsf(al * z[r]));
+  if (__any(amax > 8192.0f)) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) out[r] = sty_snake(z[r], al, ral);
+  } else {
+#pragma unroll
+    for (int r = 0; r < N; ++r) out[r] = fmaf(ral, sty_sin2_hw(al * z[r]), z[r]);
+  }
+}
+template <int N>
+__device__ __forceinline__ void sty_snake_group_hw(const float (&z)[N], const float (&al)[N], const float (&ral)[N], float (&out)[N]) {
+  float amax = 0.f;
+#pragma unroll
+  for (int r = 0; r < N; ++r) amax = fmaxf(amax, fabsf(al[r] * z[r]));
+  if (__any(amax > 8192.0f)) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) out[r] = sty_snake(z[r], al[r], ral[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < N; ++r) out[r] = fmaf(ral[r], sty_sin2_hw(al[r] * z[r]), z[r]);
+  }
 }
 }  // namespace sty
 #endif

@@ -914,11 +914,18 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
     {  // x
       float v[8];
       if (ax.xh) wb_unpack_row8_h(xraw, (t0 - pad + xg8) & 1, xv);
+      if constexpr (PRO == PRO_AFFINE_SNAKE && BF) {  // hardware sine behind one range check per group (sty_common.h)
+        float z[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float mk = 1.f;
-        if constexpr (PRO == PRO_MASK) mk = xm[e];
-        v[e] = pro_apply<PRO>(xv[e], pa, ps, alpha, ralpha, mk);
+        for (int e = 0; e < 8; ++e) z[e] = fmaf(xv[e], pa, ps);
+        sty_snake_group_hw1<8>(z, alpha, ralpha, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float mk = 1.f;
+          if constexpr (PRO == PRO_MASK) mk = xm[e];
+          v[e] = pro_apply<PRO>(xv[e], pa, ps, alpha, ralpha, mk);
+        }
       }
       const int s0 = t0 - pad + xg8;
       if (s0 < 0 || s0 + 7 >= T) {

@@ -378,7 +378,7 @@ def test_resblock_bf16_storage_vs_float64_oracle_with_the_same_rounding_points(e
         # (a STORED value that rounds the other way because fp32 and float64 differ in its 7th digit moves by one bf16 ulp,
         # 2^-7 of its magnitude, where an operand flip moved one product of 352: the max-norm gate is two such flips wide,
         # and the flips are sparse -- the relative L2 distance stays at the operand test's level)
-        tol = 1.6e-2 if storage else 6e-3
+        tol = 1.6e-2 if storage else 8e-3  # (fp32 storage: the operand test's 6e-3 + the persistent kernels' hardware sine, round 5)
         rep.add(f"y (storage={storage})", y, y64.detach().float(), tol)
         rep.add("d x", gx, x64.grad.float(), tol)
         # (relative L2: y behind two stored tensors, d x behind five stored tensors and six stored input gradients)
@@ -400,7 +400,10 @@ def test_resblock_bf16_storage_vs_float64_oracle_with_the_same_rounding_points(e
                 terms = (P64[k1].grad.abs() * P64[k1].detach().abs()).sum(dim=(1, 2), keepdim=True) / P64[k].detach().abs()
                 if ref.abs().max().item() < 1e-3 * terms.max().item():
                     continue
-            rep.add("d " + k[len(prefix) + 1:], named[k].grad, ref, tol)
+            # (d alpha = sum_t u (z sin(2 a z) - sin^2(a z) / a) / a is a cancellation of two terms of the size of the tensor it
+            # scales: a stored value that rounds the other way moves it by a multiple of its own 2^-8 -- measured 1.0e-2 ... 2.2e-2
+            # over the library versions of round 5, against 2e-3 for the same tensors with fp32 storage)
+            rep.add("d " + k[len(prefix) + 1:], named[k].grad, ref, 3e-2 if (storage and ".alpha" in k) else tol)
         rep.done()
     dy = (outs[True][0] - outs[False][0]).abs().max().item() / outs[False][0].abs().max().item()
     print(f"  two-byte storage vs fp32 storage: y differs by {dy:.2e} of its scale")
@@ -1823,6 +1826,15 @@ def test_bf16_weight_gradient_kernels_match_the_fp32_tile_kernels_in_the_graphs(
                 # autocast's conv backward sums as well; the fp32-operand kernels sum the values before rounding.  2^-9 per
                 # term, 2^-8 as the bound for a sum with cancellation
                 assert e <= 4e-3, (k, e)
+                continue
+            if "_prior_block.convs" in k:
+                # the resblock convs: since round 5 the persistent kernels (conv32p_kernel, wgradp32_kernel) evaluate the Snake
+                # of their AdaIN + Snake prologue with the hardware sine behind one range check per group, the tiled kernels of
+                # the old path with the polynomial: operands that sit on a bf16 rounding boundary round the other way in one of
+                # the two (1e-6 apart before rounding, 2^-8 after).  The forward and the weight gradient of the NEW path see the
+                # same operands (both kernels take the same sine); measured 3e-4 ... 8.5e-3, the largest on the weight-norm
+                # gains (original0: a cancellation, see test_block_backward_vs_float64_oracle)
+                assert e <= (2e-2 if k.endswith("original0") else 5e-3), (k, e)
                 continue
             worst.append((e, k))
     worst.sort(reverse=True)

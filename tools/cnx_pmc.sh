@@ -1,21 +1,25 @@
 #!/bin/bash
-# SQ counters of the 75T-rate training kernels (tools/cnx_pmc.py), one --pmc pass per counter set; summary -> gpurun_out/cnx_pmc.txt
+# SQ counters of the 75T-rate training kernels (tools/cnx_pmc.py; `tools/cnx_pmc.sh se`: the style encoder's, tools/se_pmc.py),
+# one --pmc pass per counter set; summary -> gpurun_out/cnx_pmc.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+wl=${1:-cnx}
+export PMC_FILTER="convnext32 wgrad_cnx conv32p pro_bwd wgradp32 dwconv"
+[ $wl = se ] && export PMC_FILTER="convp16 wgradb16 wgradb_ dwconv2d avgpool stem pool_fc twin_cast"
 out=$R/gpurun_out/cnx_pmc
 rm -rf $out; mkdir -p $out
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$tag -- python $R/tools/cnx_pmc.py 3 > $out/$tag.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$tag -- python $R/tools/${wl}_pmc.py 3 > $out/$tag.log 2>&1
 done
 cd $R
 python - > gpurun_out/cnx_pmc.txt <<'PY'
-import csv, glob, collections, re
+import csv, glob, collections, re, os
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob("gpurun_out/cnx_pmc/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void sty::", "").replace("sty::", "")
-        if not any(s in k for s in ("convnext32", "wgrad_cnx", "conv32p", "pro_bwd", "wgradp32", "dwconv")): continue
+        if not any(s in k for s in os.environ["PMC_FILTER"].split()): continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 print("# tools/cnx_pmc.sh: SQ counters per launch (mean over launches), B = 8, T = 39000, bf16 mode")
 for k, v in sorted(agg.items()):
