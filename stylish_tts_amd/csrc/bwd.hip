@@ -587,11 +587,110 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __r
     }
   }
 }
+// ---- LayerNorm over C = 32 channels at the long frame rates (the three LayerNorms of the vocoder's 75T-rate heads), backward ----
+// One THREAD per time column with the column's 32 x and 32 dy values in registers (64 coalesced loads in flight per lane, no
+// LDS, no barrier in the data path): x and dy are read once and dx written once -- the general kernel read x four times and dy
+// twice through its three workgroup-wide combines (237 us per launch at c3's size = 2 TB/s) and the parameter gradients took a
+// second kernel over x and dy.  Here the per-channel sums over time (sum g xh, sum g) are reduced across each 32-lane half with
+// DPP adds, across the workgroup with LDS atomics and leave as ONE partial row per workgroup; chan_ln32_param_sum_kernel adds
+// the rows in a fixed order (deterministic; the general path's one atomic per (b, c) row is not).
+__global__ __launch_bounds__(256) void chan_ln32_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int T,
+                                                            float eps, int ada, const float* __restrict__ w,
+                                                            const float* __restrict__ gb, const float* __restrict__ out_mask,
+                                                            float* __restrict__ dx, int accumulate, float* __restrict__ part) {
+  __shared__ float A_s[32];
+  __shared__ float red[64];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int t = blockIdx.x * 256 + tid;
+  const bool in = t < T;
+  if (tid < 32) A_s[tid] = ada ? 1.f + gb[(size_t)b * 64 + tid] : w[tid];
+  if (tid < 64) red[tid] = 0.f;
+  __syncthreads();
+  const size_t base = (size_t)b * 32 * T + (in ? t : 0);
+  float xv[32], gv[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    xv[c] = in ? x[base + (size_t)c * T] : 0.f;
+    gv[c] = in ? dy[base + (size_t)c * T] : 0.f;
+  }
+  const float om = (in && out_mask) ? out_mask[(size_t)b * T + t] : 1.f;
+  float mean = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) mean += xv[c];
+  mean *= (1.0f / 32.0f);
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    xv[c] -= mean;
+    var = fmaf(xv[c], xv[c], var);
+  }
+  const float r = 1.0f / sqrtf(var * (1.0f / 32.0f) + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    xv[c] *= r;       // x-hat
+    gv[c] *= om;      // masked gradient
+    const float dxh = gv[c] * A_s[c];
+    s1 += dxh;
+    s2 = fmaf(dxh, xv[c], s2);
+  }
+  s1 *= (1.0f / 32.0f);
+  s2 *= (1.0f / 32.0f);
+  if (in) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float d = r * (gv[c] * A_s[c] - s1 - xv[c] * s2);
+      float* o = dx + base + (size_t)c * T;
+      *o = accumulate ? *o + d : d;
+    }
+  }
+  // parameter sums of this workgroup's 256 columns (columns past the end hold zeros)
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float a0 = sty_half_sum_to_lane31(gv[c] * xv[c]);
+    const float a1 = sty_half_sum_to_lane31(gv[c]);
+    if ((tid & 31) == 31) {
+      atomicAdd(&red[c], a0);
+      atomicAdd(&red[32 + c], a1);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) part[((size_t)b * gridDim.x + blockIdx.x) * 64 + tid] = red[tid];
+}
+// out: ada ? dgb[b][0..31 | 32..63] += sum over the row's workgroups : dw[c] / db[c] += sum over (b, workgroup); fixed order
+__global__ __launch_bounds__(64) void chan_ln32_param_sum_kernel(const float* __restrict__ part, int B, int nblk, int ada,
+                                                                 float* __restrict__ dgb, float* __restrict__ dw,
+                                                                 float* __restrict__ db) {
+  const int i = blockIdx.x, lane = threadIdx.x;  // i: ada ? b * 64 + slot : slot
+  const int slot = ada ? (i & 63) : i, b0 = ada ? i >> 6 : 0, nb = ada ? 1 : B;
+  double s = 0.0;
+  for (int b = b0; b < b0 + nb; ++b)
+    for (int k = lane; k < nblk; k += 64) s += (double)part[((size_t)b * nblk + k) * 64 + slot];
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (ada)
+      dgb[(size_t)b0 * 64 + slot] += (float)s;
+    else if (slot < 32)
+      dw[slot] += (float)s;
+    else
+      db[slot - 32] += (float)s;
+  }
+}
+
 int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,
                        const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
                        float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st) {
   static const bool noreg = getenv("STY_NO_LN_BWD_REG") != nullptr;
   static const bool regall = getenv("STY_LN_BWD_REG_ALL") != nullptr;  // experiment: the register form for the long rows too
+  const bool no32 = getenv("STY_NO_LN32_BWD") != nullptr;  // (read per call: the A/B test toggles it)
+  if (C == 32 && !relu && (size_t)B * T >= 65536 && !no32) {  // the 75T-rate LayerNorms: one thread per column (above)
+    const int nblk = cdiv(T, 256);                           // partial rows live in mu_tmp (B T floats >= 64 B nblk)
+    hipLaunchKernelGGL(chan_ln32_bwd_kernel, dim3(nblk, B), dim3(256), 0, st, x, dy, T, eps, ada, w, gb, out_mask, dx, accumulate,
+                       mu_tmp);
+    hipLaunchKernelGGL(chan_ln32_param_sum_kernel, dim3(ada ? B * 64 : 64), dim3(64), 0, st, mu_tmp, B, nblk, ada, dgb, dw, db);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   if (((size_t)B * T < 65536 || regall) && C <= 256 && !noreg)
     hipLaunchKernelGGL((chan_ln_bwd_dx_reg_kernel<16, 16>), dim3(cdiv(T, 16), B), dim3(256), 0, st, x, dy, y, C, T, eps, ada, w,
                        gb, relu, out_mask, dx, accumulate, mu_tmp, r_tmp);

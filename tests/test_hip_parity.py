@@ -826,6 +826,55 @@ def test_vocoder_backward(env):
     rep.done()
 
 
+def test_layernorm32_backward_one_thread_per_column_equals_the_general_kernel(env, monkeypatch):
+    """chan_ln32_bwd_kernel (round 5: the LayerNorms of the vocoder's 75T-rate heads, one thread per column, parameter sums
+    through per-workgroup partial rows) against the general three-combine kernel + chan_ln_bwd_param_kernel on the same
+    vocoder backward (B = 2, T = 440: B x 75T >= 65536 positions selects it; STY_NO_LN32_BWD=1 the general pair): input
+    gradients, the three LayerNorms' weight / bias gradients and everything upstream of them."""
+    import stylish_tts_amd as S
+    P = {k: v.clone() for k, v in env["P"].items()}
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, 440
+    mel = torch.randn(B, 256, T, generator=g)
+    style = torch.randn(B, 64, generator=g)
+    pitch = torch.rand(B, T, generator=g) * 200 + 80
+    voiced = torch.ones(B, T)
+    noise = torch.randn(B, 300 * T, 9, generator=g)
+    out = {}
+    for mode in ("general", "ln32"):
+        if mode == "general":
+            monkeypatch.setenv("STY_NO_LN32_BWD", "1")
+        else:
+            monkeypatch.delenv("STY_NO_LN32_BWD")
+        m = S.SpeechPredictor()
+        m.load_state_dict(P, strict=False)
+        m = m.to(DEV).enable_training()
+        audio = m.vocoder_forward_train(mel=dev(mel), style=dev(style), pitch=dev(pitch), voiced=dev(voiced), noise=dev(noise))
+        d_mel, d_style = m.vocoder_backward(torch.sign(audio) / audio.numel())
+        torch.cuda.synchronize()
+        out[mode] = dict(d_mel=d_mel.cpu(), d_style=d_style.cpu(),
+                         g={k: p.grad.cpu().clone() for k, p in m.named_parameters() if p.grad is not None})
+    rep = Report()
+    rep.add("d mel", out["ln32"]["d_mel"], out["general"]["d_mel"], 2e-5)
+    rep.add("d style", out["ln32"]["d_style"], out["general"]["d_style"], 2e-5)
+    worst, worst_k = 0.0, None
+    gmax = max(a.abs().max().item() for a in out["general"]["g"].values())
+    for k, a in out["general"]["g"].items():
+        if not k.startswith("generator."):
+            continue
+        b = out["ln32"]["g"][k]
+        den = a.abs().max().item()
+        if den > 1e-6 * gmax:  # (a conv bias in front of an instance norm has a structurally zero gradient: noise on both sides)
+            e = (b - a).abs().max().item() / den
+            if e > worst:
+                worst, worst_k = e, k
+            if "layer_norm" in k or k.endswith("phase_norm.weight") or k.endswith("phase_norm.bias"):
+                rep.add("d " + k[-44:], b, a, 2e-5)
+    print(f"\n  worst generator parameter gradient, one-thread-per-column vs general: {worst:.2e} ({worst_k})")
+    rep.done()
+    assert worst <= 2e-4  # (fp32 summation orders differ; behind nine ConvNeXt blocks and two resblocks)
+
+
 def test_speech_predictor_backward_vs_oracle_and_reference_golden(env):
     """K15: SpeechPredictor backward (text encoder, alignment expand, decoder, vocoder) vs the oracle's autograd and
     vs the gradients the REFERENCE produced (tests/golden/sp_small_grads.safetensors)."""
