@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void pro_bwd_adain_kernel(const void* __restri
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gb, void* __restrict__ dx, int dh,
                                                             int accumulate, float* __restrict__ dgb,
-                                                            float* __restrict__ dalpha, int hw) {
+                                                            float* __restrict__ dalpha, int hw, const void* __restrict__ dsrc) {
   __shared__ double red[3][4];
   __shared__ float cc[2];
   const int c = blockIdx.x, b = blockIdx.y;
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void pro_bwd_adain_kernel(const void* __restri
     float uv[8], xv[8], d[8];
     ld8_any(u, r8 + i, uh != 0, uv);
     ld8_any(x, r8 + i, xh != 0, xv);
-    if (accumulate) {
-      ld8_any(dx, r8 + i, dh != 0, d);
+    if (accumulate) {  // (dsrc: the gradient so far lives in ANOTHER buffer -- one a side-stream launch still reads -- and is
+      ld8_any(dsrc ? dsrc : dx, r8 + i, dh != 0, d);  // read from there: no copy-on-write pass over 160 MB in front of this kernel)
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) d[e] = 0.f;
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256) void pro_bwd_adain_kernel(const void* __restri
 }
 int launch_pro_bwd_adain(const void* u, int uh, const void* x, int xh, int B, int C, int T, const float* pa, const float* ps,
                          const float* alpha, const float* mean, const float* rstd, const float* gb, void* dx, int dh,
-                         int accumulate, float* dgb, float* dalpha, int hw, hipStream_t st) {
-  if (T % 8 != 0 || ((((size_t)u | (size_t)x | (size_t)dx) & 15) != 0)) {
+                         int accumulate, float* dgb, float* dalpha, int hw, hipStream_t st, const void* dsrc) {
+  if (T % 8 != 0 || ((((size_t)u | (size_t)x | (size_t)dx | (size_t)dsrc) & 15) != 0)) {
     set_error("pro_bwd_adain: T %% 8 != 0 or unaligned rows");
     return STY_EINVAL;
   }
@@ -287,7 +287,7 @@ int launch_pro_bwd_adain(const void* u, int uh, const void* x, int xh, int B, in
   ProfScope prof("pro_bwd_adain_kernel", 0.0, n * (2.0 * ((uh ? 2 : 4) + (xh ? 2 : 4)) + (accumulate ? 2.0 : 1.0) * (dh ? 2 : 4)), st,
                  detail);
   hipLaunchKernelGGL(pro_bwd_adain_kernel, dim3(C, B), dim3(256), 0, st, u, uh, x, xh, C, T, pa, ps, alpha, mean, rstd, gb, dx,
-                     dh, accumulate, dgb, dalpha, hw);
+                     dh, accumulate, dgb, dalpha, hw, dsrc);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -375,6 +375,7 @@ __global__ __launch_bounds__(64 * (4 + p_npw<BF>()), 1) void conv32p_kernel(Conv
 
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w.wp), 0, K * CinP * CoutP * 4, 0x00020000);
+  const int wrow = a.w_row ? a.w_row : CoutP, wtap = a.w_tap ? a.w_tap : CinP * CoutP;  // (a 32 x 32 block of a larger weight)
   if constexpr (BF) {
     // packed fp32 weights Wp[k][ci][co] -> bf16 A fragments: lane (co = l31, k-block = hi) of k-step s holds the
     // eight input channels 16 s + 8 hi .. + 7
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(64 * (4 + p_npw<BF>()), 1) void conv32p_kernel(Conv
       const int co = ln & 31, ci0 = 16 * s + 8 * (ln >> 5);
       float w8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w8[e] = a.w.wp[((size_t)k * CinP + ci0 + e) * CoutP + co];
+      for (int e = 0; e < 8; ++e) w8[e] = a.w.wp[(size_t)k * wtap + (size_t)(ci0 + e) * wrow + co];
       reinterpret_cast<bf16x8*>(wl)[it] = sty_pack_bf16(w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7]);
     }
   }
@@ -610,6 +611,7 @@ bool conv32p_eligible(const ConvArgs& a) {
   const int halo = (a.w.K - 1) * a.dil;
   if (halo + 1 > 64 * P_MAXQ - P_TT) return false;
   if ((a.xh || a.yh || a.rh) && (!a.bf16 || a.T % 4 != 0)) return false;  // two-byte tensors: bf16 mode, 8-byte row groups
+  if ((a.w_row || a.w_tap) && !a.bf16) return false;  // weight blocks: only the bf16 mode's fragment conversion indexes them
   if (p_lds_bytes(a) > 160 * 1024) return false;
   // worth it from ~2 tiles per CU on (below that the persistent loop has nothing to overlap)
   const char* mt = getenv("STY_CONV32P_MIN_TILES");  // read per call: the parity tests lower it for small shapes

@@ -276,7 +276,7 @@ int launch_row_axpb(const float* x, const float* c0, const float* c1, int rows, 
 // AdaIN + Snake prologue backward with the instance-norm statistics term in ONE launch (bwd.hip); u / x / dx fp32 or bf16 tensors
 int launch_pro_bwd_adain(const void* u, int uh, const void* x, int xh, int B, int C, int T, const float* pa, const float* ps,
                          const float* alpha, const float* mean, const float* rstd, const float* gb, void* dx, int dh,
-                         int accumulate, float* dgb, float* dalpha, int hw, hipStream_t st);
+                         int accumulate, float* dgb, float* dalpha, int hw, hipStream_t st, const void* dsrc = nullptr);
 int launch_adain_stats(const double* part, int nseg, int rows, int T, float eps, float* mean, float* rstd,
                        hipStream_t st);
 int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,

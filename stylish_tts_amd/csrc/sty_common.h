@@ -185,6 +185,11 @@ struct ConvArgs {
   // gradient is a bf16 tensor.  Honoured by conv32p_kernel, wgradp32_kernel and the element-wise kernels of the resblock /
   // ConvNeXt32 chains; launch_conv1d refuses them on any other kernel (no silent fp32 reinterpretation of two-byte data).
   int xh = 0, yh = 0, rh = 0, gh = 0;
+  // conv32p_kernel, bf16 mode only: `w.wp` points INTO a larger packed weight [K][CinP_full][CoutP_full] and this launch uses a
+  // 32 x 32 block of every tap: w_row = floats between consecutive input-channel rows (CoutP_full), w_tap = floats between taps
+  // (CinP_full CoutP_full); 0 = the weight is the dense [K][32][32] array.  (A conv over three concatenated 32-channel sources
+  // runs as three accumulating launches, its input gradient as three launches that write each source's gradient directly.)
+  int w_row = 0, w_tap = 0;
 };
 // misc.hip: y16 = bf16(pro(x) * mask[b][t]) for [B*C][T] rows; pro = PRO_NONE or PRO_LRELU; mask optional
 int launch_twin_cast(const float* x, const float* mask, int pro, int B, int C, int T, __bf16* y16, hipStream_t st);

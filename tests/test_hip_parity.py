@@ -875,6 +875,48 @@ def test_layernorm32_backward_one_thread_per_column_equals_the_general_kernel(en
     assert worst <= 2e-4  # (fp32 summation orders differ; behind nine ConvNeXt blocks and two resblocks)
 
 
+def test_three_source_conv_on_the_persistent_kernel_equals_the_tiled_kernel(env, monkeypatch):
+    """phase_input_conv (k = 21 over three concatenated 32-channel sources) as three accumulating conv32p_kernel launches
+    forward and three direct input-gradient launches backward (Trainer::conv_cat3, bf16 mode, round 5) against the tiled
+    kernel with its 96-channel input gradient + PRO_NONE copies (STY_NO_CAT3=1) in the same vocoder training graph: same bf16
+    operands, another fp32 summation order.  In the bf16 mode a 1e-7 difference in front of the eight phase ConvNeXt blocks
+    flips bf16 roundings inside them and the phase head amplifies that to ~1e-2 of the audio (measured here:
+    audio 7.5e-3, gradients 0.11-0.19 in relative L2), so this A/B can only exclude a WRONG block of the weight (relative L2 ~1);
+    the values are pinned by the float64-anchored bf16 gates of tests/test_full_size.py, whose shapes take this path."""
+    import stylish_tts_amd as S
+    from stylish_tts_amd import lib as L
+    monkeypatch.setenv("STY_CONV32P_MIN_TILES", "1")
+    P = {k: v.clone() for k, v in env["P"].items()}
+    cs, want = env["cs"], env["want"]
+    out = {}
+    for mode in ("tiled", "cat3"):
+        if mode == "tiled":
+            monkeypatch.setenv("STY_NO_CAT3", "1")
+        else:
+            monkeypatch.delenv("STY_NO_CAT3")
+        m = S.SpeechPredictor()
+        m.load_state_dict(P, strict=False)
+        m = m.to(DEV).enable_training().set_train_opts(compute_bf16=True)
+        L.load().sty_prof_enable(1)
+        audio = m.vocoder_forward_train(mel=dev(want["decoder_out"]), style=dev(cs["style"]), pitch=dev(cs["pitch"]),
+                                        voiced=dev(env["voiced"]), noise=dev(cs["noise"]), prior_override=dev(want["prior"]))
+        d_mel, d_style = m.vocoder_backward(torch.sign(audio) / audio.numel())
+        torch.cuda.synchronize()
+        L.load().sty_prof_enable(0)
+        n32p = sum(r["launches"] for r in L.prof_report(512) if r["name"].startswith("conv32p"))
+        named = dict(m.named_parameters())
+        out[mode] = dict(audio=audio.cpu(), d_mel=d_mel.cpu(), d_style=d_style.cpu(), n32p=n32p,
+                         gw=named["generator.basegen.phase_input_conv.weight"].grad.cpu().clone(),
+                         gb=named["generator.basegen.phase_input_conv.bias"].grad.cpu().clone())
+    assert out["cat3"]["n32p"] == out["tiled"]["n32p"] + 6, (out["cat3"]["n32p"], out["tiled"]["n32p"])
+
+    def l2(a, b):
+        return ((a - b).norm() / b.norm()).item()
+    rows = {k: l2(out["cat3"][k], out["tiled"][k]) for k in ("audio", "gw", "gb", "d_mel", "d_style")}
+    print("\n  three launches vs tiled kernel, relative L2: " + "  ".join(f"{k} {v:.2e}" for k, v in rows.items()))
+    assert rows["audio"] <= 3e-2 and max(rows["gw"], rows["gb"], rows["d_mel"], rows["d_style"]) <= 0.4, rows
+
+
 def test_speech_predictor_backward_vs_oracle_and_reference_golden(env):
     """K15: SpeechPredictor backward (text encoder, alignment expand, decoder, vocoder) vs the oracle's autograd and
     vs the gradients the REFERENCE produced (tests/golden/sp_small_grads.safetensors)."""
