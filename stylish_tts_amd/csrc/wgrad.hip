@@ -37,10 +37,15 @@ static const float WG_PARTIAL_FRAC = getenv("STY_WG_PARTIAL_FRAC") ? (float)atof
 // bf16 mode only (or wherever the variable is set explicitly): on c2 -- fp32 MFMAs, 16x longer matrix phases -- the same cap
 // COSTS 1.4 ms (30.92 ms without, 31.53 at f = 0.5, 32.31 at 0.25): there the splits are what fills the chip.
 static const bool WG_PARTIAL_FRAC_SET = getenv("STY_WG_PARTIAL_FRAC") != nullptr;
-static inline int wg_cap_partial(int nsplit, const PackedConv& w, int B, int T, bool bf16) {
+// ... but never below the split that puts WG_MIN_WGS workgroups on the chip (`tiles` workgroups per split): on the text encoder's
+// k = 3 FFN layers (3 200 positions, planes of 0.2 M elements) the bare cap left 32 workgroups per launch -- 108 us alone for
+// 1.3 GFLOP (STY_WG_MIN_WGS, default 128; 0 = no floor; A/B in profiles/r05_ab_env.txt block 11: 256 and 512 buy the serial step 3 ms but cost the overlapped step 0.4 ms -- these launches run on the side stream).
+static const int WG_MIN_WGS = getenv("STY_WG_MIN_WGS") ? atoi(getenv("STY_WG_MIN_WGS")) : 128;
+static inline int wg_cap_partial(int nsplit, const PackedConv& w, int B, int T, bool bf16, int tiles = 0) {
   if (WG_PARTIAL_FRAC <= 0.f || !(bf16 || WG_PARTIAL_FRAC_SET)) return nsplit;
   const double operands = (double)B * T * (w.Cin + w.Cout), plane = (double)w.K * w.CinP * w.CoutP;
   int cap = (int)(WG_PARTIAL_FRAC * operands / plane);
+  if (tiles > 0 && WG_MIN_WGS > 0 && cap < cdiv(WG_MIN_WGS, tiles)) cap = cdiv(WG_MIN_WGS, tiles);
   if (cap < 1) cap = 1;
   if (cap >= 8) cap &= ~7;
   return nsplit < cap ? nsplit : cap;
@@ -444,7 +449,7 @@ static int wgrad64_nsplit(const PackedConv& w, int B, int T, bool bf16 = false) 
   int nsplit = cdiv(tiles >= 16 ? target : target / 2, tiles);
   if (nsplit >= 8) nsplit = (nsplit + 7) & ~7;  // a multiple of 8: wgradb_kernel then keeps the blocks of a split on one XCD
   if (nsplit > chunks) nsplit = chunks;
-  return wg_cap_partial(nsplit, w, B, T, bf16);
+  return wg_cap_partial(nsplit, w, B, T, bf16, tiles);
 }
 
 // wgradb16_kernel's 128 x 64 / 128 x 96 blocks (round 5; 240-248 registers, two workgroups per CU): the split count that puts
@@ -455,7 +460,7 @@ static int wgrad16_nsplit(int blocks, const PackedConv& w, int B, int T) {
   if (ns >= 8) ns = (ns + 7) & ~7;
   const int chunks = B * cdiv(T, 128);
   if (ns > chunks) ns = chunks;
-  return wg_cap_partial(ns, w, B, T, true);
+  return wg_cap_partial(ns, w, B, T, true, blocks);
 }
 
 // ---- K == 1 (Linear / 1x1 conv) weight gradient: dW[co][ci] = sum_{b,t} G[co][t] x[ci][t] ----
@@ -663,7 +668,7 @@ static int w1_nsplit(const PackedConv& w, int B, int T, W1Cfg c, bool bf16 = fal
   const int chunks = B * cdiv(T, W1_TW);
   int nsplit = cdiv(wg_target(bf16), tiles);
   if (nsplit > chunks) nsplit = chunks;
-  return wg_cap_partial(nsplit, w, B, T, bf16);
+  return wg_cap_partial(nsplit, w, B, T, bf16, tiles);
 }
 
 // Slices are `stride` floats apart: [plane weight partials][nb bias partials (fused bias gradient, or unused)].
