@@ -40,12 +40,17 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
                                    // as global loads inside the element loops they were 55 % of the wave cycles)
   float* gbs = prm + 5 * 128;      // [64] 1 + gamma | beta of the AdaLN   (prm row 4: 1 / alpha)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.y, t0 = blockIdx.x * CB_TT, T = a.T;
+  // FUSED (lean pass 2 with a.gx): overlapping tiles -- 256 columns computed, the owned ones [own_lo, own_hi) stored and summed,
+  // and the input gradient gX = gY + dwconv^T(gU) written from this kernel (the epilogue at the end): every owned column finds
+  // the gU of its three neighbours on either side in this workgroup's LDS
+  const bool fused = PASS == 2 && LEAN && a.gx != nullptr;
+  const int b = blockIdx.y, t0 = blockIdx.x * (fused ? CNX_BWD_FUSED_STRIDE : CB_TT), T = a.T;
+  const int own_lo = fused && blockIdx.x > 0 ? 4 : 0, own_hi = fused ? 4 + CNX_BWD_FUSED_STRIDE : CB_TT;
   const float* xb = a.x + (size_t)b * 32 * T;
   const float* gb_ = a.gy + (size_t)b * 32 * T;
   // pass-2 outputs go through buffer descriptors of this batch row (32-bit offsets: the 64-bit per-row store
   // addresses of the flat form cost ~80 spilled VGPRs)
-  __amdgpu_buffer_rsrc_t r_hs, r_g0, r_xn, r_gu;
+  __amdgpu_buffer_rsrc_t r_hs, r_g0, r_xn, r_gu, r_gx;
   if (PASS == 2) {
     // (out_bf16: the two 128-channel outputs are bf16 tensors [B][128][T] in the same buffers)
     const int esz = a.out_bf16 ? 2 : 4;
@@ -53,8 +58,10 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
                                              0x00020000);
     r_g0 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.gh0) + (size_t)b * 128 * T * esz, 0, 128 * T * esz,
                                              0x00020000);
-    r_xn = __builtin_amdgcn_make_buffer_rsrc(a.xn + (size_t)b * 32 * T, 0, 32 * T * 4, 0x00020000);
+    const int xsz = a.xn16 ? 2 : 4;
+    r_xn = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.xn) + (size_t)b * 32 * T * xsz, 0, 32 * T * xsz, 0x00020000);
     r_gu = __builtin_amdgcn_make_buffer_rsrc(a.gu + (size_t)b * 32 * T, 0, 32 * T * 4, 0x00020000);
+    r_gx = __builtin_amdgcn_make_buffer_rsrc(fused ? a.gx + (size_t)b * 32 * T : a.gu, 0, 32 * T * 4, 0x00020000);
   }
   auto bst = [](__amdgpu_buffer_rsrc_t rs, float v, int off) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
@@ -119,11 +126,29 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     __syncthreads();
     rstd_s[tid] = rstd;
     const int t = t0 + tid;
+    const bool own1 = t < T && tid >= own_lo && tid < own_hi;
+    if (PASS == 2 && a.xn16) {
+      // two-byte xn: a lane pair (columns t, t + 1; t0 and the owned range are multiples of four) shares its values so that
+      // every lane stores ONE dword per channel PAIR -- the even lane (c, t .. t + 1), the odd lane (c + 1, t - 1 .. t)
+      const bool odd = tid & 1;
+      const int voff = own1 ? ((odd ? T + t - 1 : t)) * 2 : 0x7FFFFF00;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const float xh = (u[c] - mean) * rstd;
-      xs[c * LW + 3 + tid] = xh;
-      if (PASS == 2 && t < T) bst(r_xn, fmaf(xh, gbs[c], gbs[32 + c]), (c * T + t) * 4);
+      for (int c = 0; c < 32; c += 2) {
+        const float xh0 = (u[c] - mean) * rstd, xh1 = (u[c + 1] - mean) * rstd;
+        xs[c * LW + 3 + tid] = xh0;
+        xs[(c + 1) * LW + 3 + tid] = xh1;
+        const float v0 = fmaf(xh0, gbs[c], gbs[32 + c]), v1 = fmaf(xh1, gbs[c + 1], gbs[33 + c]);
+        const float got = __shfl_xor(odd ? v0 : v1, 1);  // even: the partner's channel c; odd: the partner's channel c + 1
+        const unsigned two = odd ? sty_pack2_bf16(got, v1) : sty_pack2_bf16(v0, got);
+        __builtin_amdgcn_raw_buffer_store_b32(two, r_xn, voff, c * T * 2, 0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const float xh = (u[c] - mean) * rstd;
+        xs[c * LW + 3 + tid] = xh;
+        if (PASS == 2 && own1) bst(r_xn, fmaf(xh, gbs[c], gbs[32 + c]), (c * T + t) * 4);
+      }
     }
   }
   __syncthreads();
@@ -139,12 +164,13 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll 1
   for (int n = 0; n < 2; ++n) {
     const int tl = tw + n * 32 + l31, t = t0 + tl;
-    const bool ok = t < T;
+    const bool okT = t < T;                                // the column exists: it is computed (a neighbour may need its gU)
+    const bool ok = okT && tl >= own_lo && tl < own_hi;    // ... and this tile owns it: stored, summed
     // lane part of the bf16 output offsets; columns past the end: outside the descriptor, the store is dropped by the range
     // check (no exec-mask branch around each of the 128 stores per lane and pass)
     const int vst16 = ok ? (4 * hi * T + t) * 2 : 0x7FFFFF00;
     const int vst32 = ok ? (4 * hi * T + t) * 4 : 0x7FFFFF00;
-    const float okf = ok ? 1.f : 0.f;  // (the hi half of the wave holds the rows 4 further down)
+    const float okf = okT ? 1.f : 0.f;  // (the hi half of the wave holds the rows 4 further down)
     // B fragments: normalised input (AdaLN affine applied on the way) and the output gradient
     float bx[16], by[16];
     bf16x8 bxf[2], byf[2];
@@ -349,8 +375,10 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rs * (gxh[r] - s1 - xh[r] * s2)), r_gu, vst32,
-                                              ((r & 3) + 8 * (r >> 2)) * T * 4, 0);
+        const float guv = rs * (gxh[r] - s1 - xh[r] * s2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, guv), r_gu, vst32, ((r & 3) + 8 * (r >> 2)) * T * 4, 0);
+        // FUSED: gU takes x-hat's place in LDS (this lane was the cell's only reader); columns past the end hold zero
+        if (fused) xs[c * LW + 3 + tl] = okf * guv;
         float v = ok ? gxn[r] * xh[r] : 0.f, w = ok ? gxn[r] : 0.f;
         v = sty_half_sum_to_lane31(v);
         w = sty_half_sum_to_lane31(w);
@@ -362,6 +390,34 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     }
   }
   __syncthreads();
+  if (fused) {
+    // gX[c][t] = gY[c][t] + sum_k w[c][k] gU[c][t + 3 - k] (the transpose of u[t] = sum_k w[k] x[t + k - 3]): one thread per
+    // column pair; gU of local column j sits in xs cell 3 + j, the cells left of the first
+    // tile hold the zeros loaded for t < 0.  Replaces dwconv7_bwd_dx_kernel's pass over gU, gY and gX (0.48 GB per block).
+    // A thread takes TWO adjacent columns of sixteen channels: the eight cells both windows live in come as four ds_read_b64
+    // (one thread per column and 7 + 1 ds_read_b32 per channel: +51 us per launch; the owned range and T are multiples of four,
+    // so a pair is owned or not as a whole), the pair leaves as one 8-byte store.
+    typedef unsigned u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
+    const int p2 = 2 * (tid & 127), half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int t = t0 + p2;
+    const int voff = (t < T && p2 >= own_lo && p2 < own_hi) ? t * 4 : 0x7FFFFF00;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = 16 * half + i;
+      const float2* wp = reinterpret_cast<const float2*>(xs + c * LW + p2);  // cells p2 .. p2 + 7 = gU of columns p2 - 3 .. p2 + 4
+      const float2 q0 = wp[0], q1 = wp[1], q2 = wp[2], q3 = wp[3];
+      const float win[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+      float a0 = gys[c * LG + p2], a1 = gys[c * LG + p2 + 1];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float w = a.dw_w[c * 7 + k];
+        a0 = fmaf(w, win[6 - k], a0);
+        a1 = fmaf(w, win[7 - k], a1);
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1)}, r_gx,
+                                            voff, c * T * 4, 0);
+    }
+  }
   if (tid < 128 && !(PASS == 2 && LEAN)) {
     const double s = (double)red[tid] + (double)red[128 + tid] + (double)red[256 + tid] + (double)red[384 + tid];
     // pass 1: ds partial; pass 2: d alpha partial
@@ -440,7 +496,26 @@ int launch_cnx_frag_pack(const float* w1p, const float* w2raw, const float* w1ra
   return STY_OK;
 }
 
+int convnext32_bwd_ntiles(int T, int fused) {
+  if (!fused) return cdiv(T, CB_TT);
+  const int n = cdiv(T - 4, CNX_BWD_FUSED_STRIDE);  // the last tile owns up to 248 (n - 1) + 252 >= T
+  return n < 1 ? 1 : n;
+}
+
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st) {
+  const bool fused_ = pass == 2 && a.bf16 && a.out_bf16 && a.lean && a.gx;
+  if (a.gx && (!fused_ || a.gx == a.gy || a.T % 4)) {
+    set_error("convnext32_bwd: the fused input gradient needs the lean pass 2, T %% 4 == 0 and gx != gy");
+    return STY_EINVAL;
+  }
+  if (a.xn16 && (pass != 2 || a.T % 2)) {
+    set_error("convnext32_bwd: two-byte xn needs pass 2 and an even T");
+    return STY_EINVAL;
+  }
+  if (a.ntiles != convnext32_bwd_ntiles(a.T, fused_)) {
+    set_error("convnext32_bwd: ntiles does not match convnext32_bwd_ntiles(T, fused)");
+    return STY_EINVAL;
+  }
   if (a.bf16 && !a.wfrag) {
     set_error("convnext32_bwd: bf16 mode needs the packed weight fragments (launch_cnx_frag_pack)");
     return STY_EINVAL;
@@ -467,7 +542,9 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
   const double flops = pos * (448.0 + 16384.0 + (pass == 2 ? 8192.0 : 0.0));
   // (h s and gH0 as bf16 in the bf16 mode: 2 x 128 x 2 bytes instead of 2 x 128 x 4)
   const bool lean = pass == 2 && a.bf16 && a.out_bf16 && a.lean;
-  const double bytes = pos * (4.0 * 64.0 + (pass == 2 ? 4.0 * 64.0 + (a.out_bf16 ? 2.0 : 4.0) * (lean ? 128.0 : 256.0) : 0.0));
+  const double bytes = pos * (4.0 * 64.0 + (pass == 2 ? (a.xn16 ? 2.0 : 4.0) * 32.0 + 4.0 * 32.0 + (fused_ ? 4.0 * 32.0 : 0.0) +
+                                                           (a.out_bf16 ? 2.0 : 4.0) * (lean ? 128.0 : 256.0)
+                                                     : 0.0));
   ProfScope prof(pass == 1 ? (a.bf16 ? "convnext32_bwd_kernel<1,true>" : "convnext32_bwd_kernel<1,false>")
                            : (a.bf16 ? "convnext32_bwd_kernel<2,true>" : "convnext32_bwd_kernel<2,false>"),
                  flops, bytes, st);

@@ -213,10 +213,10 @@ int launch_wgradp32(const ConvArgs& ax, const ConvArgs& ag, int nsplit, float* p
 // ... and the two pointwise weight gradients of a fused ConvNeXt32 block from its bf16 outputs
 int wgrad_cnx_nsplit(int B, int T);
 int launch_conv_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* gwp, float* partial,
-                          float* gbias, hipStream_t st);
+                          float* gbias, hipStream_t st, int narrow16 = 0);  // narrow16: `narrow` is a bf16 tensor (x_wide == 0)
 int wgrad_cnx_per_b(int B, int T);
 int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
-                     hipStream_t st, int per_b = 0);
+                     hipStream_t st, int per_b = 0, int narrow16 = 0);
 bool stem2d_eligible(const ConvArgs& a);  // conv2d.hip: Conv2d(1 -> C, 3 x 3) of the style encoder's stem, VALU, store-bound
 int launch_stem2d(const ConvArgs& a, hipStream_t st);
 bool convk1_eligible(const ConvArgs& a);  // convk1.hip: K = 1 as a plain GEMM (transposing LDS reads)
@@ -344,7 +344,15 @@ struct Cnx32BwdArgs {       // convnext_bwd.hip
                             // from the weight-gradient GEMMs (launch_cnx_m_finish / launch_cnx_dalpha)
   const void* wfrag = nullptr;  // bf16 mode (required): the A fragments of the three GEMMs, made by launch_cnx_frag_pack:
                                 // [3 matrices][4 blocks][2 k-steps][64 lanes] x 8 bf16 (24 KB)
+  // lean pass 2, fused input gradient (round 5): gx != nullptr -> the kernel also writes gX = gY + dwconv^T(gU) [B][32][T]
+  // (out of place: gx != gy).  Tiles then OVERLAP: a workgroup still computes 256 columns but tiles start every
+  // CNX_BWD_FUSED_STRIDE columns and a tile stores / sums only the columns it owns (local [4, 252), the first tile from 0), so
+  // that the three neighbours of every owned column's gU are in its own LDS; ntiles = convnext32_bwd_ntiles(T, 1).
+  float* gx = nullptr;
+  int xn16 = 0;                 // xn is written as bf16 [B][32][T] (the B operand of the dW1 GEMM, rounded where it is stored)
 };
+constexpr int CNX_BWD_FUSED_STRIDE = 248;
+int convnext32_bwd_ntiles(int T, int fused);
 constexpr size_t CNX_FRAG_HALFS = 3 * 4 * 2 * 64 * 8;
 // w1p: packed pwconv1 [32 ci][128 ch]; w2raw: pwconv2.weight [32][128]; w1raw: pwconv1.weight [128][32]
 int launch_cnx_frag_pack(const float* w1p, const float* w2raw, const float* w1raw, void* wfrag, hipStream_t st);

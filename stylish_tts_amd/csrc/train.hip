@@ -732,8 +732,12 @@ struct Trainer {
       // written out of place by the depthwise kernel)
       float* gX;
       const float* gx_src = nullptr;
+      // lean backward, x's gradient not written yet (the chain's ordinary case): the fused kernel writes gX = gY + dwconv^T(gU)
+      // itself, out of place, on overlapping tiles (convnext_bwd.hip) -- no dwconv7_bwd_dx pass over gU, gY and gX
+      const bool fuse_gx = lean && !gmap.count(x) && Tt % 4 == 0 && getenv("STY_NO_CNX_GX") == nullptr;
+      const bool xn16 = lean && getenv("STY_NO_CNX_XN16") == nullptr;  // xn (an MFMA operand of dW1 only) as bf16
       if (!gmap.count(x)) {
-        if (side) {
+        if (side || fuse_gx) {
           gX = take<float>(n32);
           gmap[x] = gX;
           gx_src = gY;
@@ -745,6 +749,7 @@ struct Trainer {
         gX = G(x, n32);
         if (live()) chk(launch_row_scale_add(gY, nullptr, 1.0f, 1, (int)n32, gX, st));
       }
+      const int nt_b = convnext32_bwd_ntiles(Tt, fuse_gx);
       // operands of the side-stream launches live until the end of the step (one set per block; the main stream
       // never has to wait before reusing anything)
       float* hs_p = side && !lean ? take<float>(n128) : nullptr;
@@ -753,17 +758,17 @@ struct Trainer {
       // (... or, with the reductions deferred, behind the grouped reduction at the end of the segment: `after_reduce`)
       float* ds_p = (side || deferring()) && lean ? take<float>((size_t)B * 128) : nullptr;
       float* coef_p = (side || deferring()) && lean ? take<float>((size_t)B * 128) : nullptr;
-      float* xn_p = side ? take<float>(n32) : nullptr;
+      float* xn_p = side ? take<float>(xn16 ? n32 / 2 : n32) : nullptr;
       float* gu_p = side ? take<float>(n32) : nullptr;
       float* dsc_p = side ? take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7)) : nullptr;
       const size_t mark = ws.off;
-      double* pds = take<double>((size_t)B * 128 * nt);
-      double* pgb = take<double>((size_t)B * 64 * nt);
+      double* pds = take<double>((size_t)B * 128 * nt_b);
+      double* pgb = take<double>((size_t)B * 64 * nt_b);
       float* ds = ds_p ? ds_p : take<float>((size_t)B * 128);
       float* coef = coef_p ? coef_p : take<float>((size_t)B * 128);
       float* hs = lean ? nullptr : (side ? hs_p : take<float>(n128));
       float* gh0 = side ? gh0_p : take<float>(lean ? n128 / 2 : n128);
-      float* xn = side ? xn_p : take<float>(n32);
+      float* xn = side ? xn_p : take<float>(xn16 ? n32 / 2 : n32);
       float* gu = side ? gu_p : take<float>(n32);
       Cnx32BwdArgs a;
       a.x = x;
@@ -785,7 +790,9 @@ struct Trainer {
       a.xn = xn;
       a.gu = gu;
       a.T = Tt;
-      a.ntiles = nt;
+      a.ntiles = nt_b;
+      a.gx = fuse_gx ? gX : nullptr;
+      a.xn16 = xn16;
       a.bf16 = m->topts.compute_bf16;
       a.wfrag = wfrag;
       // bf16 mode: h s and gH0 leave the kernel as bf16 and feed wgrad_cnx_kernel (T % 8: its 8-sample groups)
@@ -814,7 +821,7 @@ struct Trainer {
           chk(launch_cnx_m_finish(pM, B, SB, c.w2_raw, scale, ds, frozen ? nullptr : gw2, frozen ? nullptr : gb2, st));
           chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
           chk(launch_convnext32_bwd(a, B, 2, st));
-          chk(launch_cnx_partial_sum(pgb, B, 64, nt, 2, dgl, st));
+          chk(launch_cnx_partial_sum(pgb, B, 64, nt_b, 2, dgl, st));
         }
       } else if (live()) {
         chk(launch_convnext32_bwd(a, B, 1, st));
@@ -826,7 +833,7 @@ struct Trainer {
       }
       const float *w1r = c.w1_raw, *b1p = c.b1, *alp = c.alpha;
       auto lean_w1 = [=](hipStream_t s_) {  // dW1 (+ db1) from (gH0, xn), then d alpha from it
-        chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, s_));
+        chk(launch_conv_wgrad_cnx(0, gh0, xn, B, Tt, gw1, p1, gb1, s_, xn16));
         auto dalpha = [=](hipStream_t s3) {
           chk(launch_cnx_dalpha(w1r, b1p, alp, gw1, gb1, scale, ds, coef, part, nt, B, dal, s3));
         };
@@ -839,7 +846,7 @@ struct Trainer {
       float* gdb = PG(c.dw_b, 32);
       const float* dww = c.dw_w;
       if (m->topts.frozen) {
-        if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
+        if (live() && !fuse_gx) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
       } else if (side) {
         side_push(gY, [=](hipStream_t s2) {
           if (lean) {
@@ -853,8 +860,8 @@ struct Trainer {
           }
           chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, s2));
         });
-        // input gradient of the depthwise conv on the main stream
-        if (live()) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
+        // input gradient of the depthwise conv on the main stream (unless the fused kernel wrote it)
+        if (live() && !fuse_gx) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
       } else if (live()) {
         bool done = false;
         DeferScope dsc_(this);
@@ -868,7 +875,10 @@ struct Trainer {
           chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, &done, st));
         }
         // depthwise conv backward from gU; note gX may alias gY, which every kernel above has finished reading
-        chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, gdw, gdb, dsc, st));
+        if (fuse_gx)
+          chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, st));
+        else
+          chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, gdw, gdb, dsc, st));
       }
       ws.off = mark;
     });

@@ -1309,9 +1309,9 @@ int launch_conv1d_wgrad(const ConvArgs& fwd, const float* g, const float* gmask,
 
 // the two pointwise weight gradients of a fused ConvNeXt32 block from its bf16 outputs (wgradb.hip): kernel + reduction
 int launch_conv_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* gwp, float* partial,
-                          float* gbias, hipStream_t st) {
+                          float* gbias, hipStream_t st, int narrow16) {
   const int wb = gbias != nullptr;
-  int rc = launch_wgrad_cnx(x_wide, wide, narrow, B, T, partial, wb, st);
+  int rc = launch_wgrad_cnx(x_wide, wide, narrow, B, T, partial, wb, st, 0, narrow16);
   if (rc) return rc;
   const int coutp = x_wide ? 32 : 128;
   const size_t plane = 128 * 32;

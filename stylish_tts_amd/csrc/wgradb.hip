@@ -1134,7 +1134,8 @@ namespace sty {
 // 2 x 128 + 4 x 32 bytes per position instead of 4 x 160 (wgrad_k1_kernel<4,1|1,4>: 2.9-3.4 TB/s on 0.8 GB).
 // T % 8 == 0 (the caller checks): an 8-sample group is inside the row or past its end, never across.
 // =====================================================================================================================
-template <bool XWIDE>  // XWIDE: x is the bf16 [B][128][T] tensor and G the fp32 [B][32][T] one; else the other way round
+// N16 (round 5, with !XWIDE): the narrow tensor (xn of the lean ConvNeXt32 backward) is bf16 too -- 16-byte loads straight to LDS
+template <bool XWIDE, bool N16 = false>  // XWIDE: x is the bf16 [B][128][T] tensor and G the fp32 [B][32][T] one; else the other way round
 // SB > 0: per-utterance mode -- workgroup z handles utterance z / SB only (chunks z % SB, z % SB + SB, ...), so that the SB
 // partial planes of an utterance sum to ITS 128 x 32 product (the lean ConvNeXt32 backward needs M_b = gY_b h_b^T per b).
 __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restrict__ wide, const float* __restrict__ narrow,
@@ -1157,6 +1158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
   for (int m = 0; m < 8; ++m) bsum[m] = 0.f;
   float4 wv[8];     // wide: 8 rows x 8 bf16
   float nv[2][8];   // narrow: 2 rows x 8 fp32
+  float4 nh[2];     // (N16: 2 rows x 8 bf16)
   const int total = SB ? chunks_per_b : B * chunks_per_b, step = SB ? SB : nsplit;
   int cb = SB ? split / SB : split / chunks_per_b, cc_ = SB ? split - cb * SB : split - cb * chunks_per_b;
   auto load_chunk = [&](int b, int c) {
@@ -1165,12 +1167,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(wide + (size_t)b * 128 * T), 0, 128 * T * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(narrow + (size_t)b * 32 * T), 0, 32 * T * 4, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(narrow) + (size_t)b * 32 * T * (N16 ? 2 : 4)), 0, 32 * T * (N16 ? 2 : 4),
+        0x00020000);
 #pragma unroll
     for (int m = 0; m < 8; ++m)
       wv[m] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, in ? ((r0 + 16 * m) * T + t) * 2 : WB_OOB, 0, 0));
 #pragma unroll
-    for (int m = 0; m < 2; ++m) wb_load8(rn, in ? ((r0 + 16 * m) * T + t) * 4 : WB_OOB, nv[m]);
+    for (int m = 0; m < 2; ++m) {
+      if constexpr (N16)
+        nh[m] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rn, in ? ((r0 + 16 * m) * T + t) * 2 : WB_OOB, 0, 0));
+      else
+        wb_load8(rn, in ? ((r0 + 16 * m) * T + t) * 4 : WB_OOB, nv[m]);
+    }
   };
   auto advance = [&](int& b, int& c) {
     c += step;
@@ -1192,7 +1200,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
     for (int m = 0; m < 2; ++m) {
       if (XWIDE && want_bias)
         bsum[m] += ((nv[m][0] + nv[m][1]) + (nv[m][2] + nv[m][3])) + ((nv[m][4] + nv[m][5]) + (nv[m][6] + nv[m][7]));
-      *reinterpret_cast<bf16x8*>(ns_ + (r0 + 16 * m) * WB_PITCH + g8) = wb_pack(nv[m]);
+      if constexpr (N16)
+        *reinterpret_cast<float4*>(ns_ + (r0 + 16 * m) * WB_PITCH + g8) = nh[m];
+      else
+        *reinterpret_cast<bf16x8*>(ns_ + (r0 + 16 * m) * WB_PITCH + g8) = wb_pack(nv[m]);
     }
     __syncthreads();
     advance(cb, cc_);
@@ -1255,7 +1266,11 @@ int wgrad_cnx_per_b(int B, int T) {  // planes per utterance in the per-utteranc
   return sb < cpb ? sb : cpb;
 }
 int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
-                     hipStream_t st, int per_b) {
+                     hipStream_t st, int per_b, int narrow16) {
+  if (narrow16 && x_wide) {
+    set_error("wgrad_cnx: a two-byte narrow tensor only in the dW1 form (x narrow)");
+    return STY_EINVAL;
+  }
   if (T % 8) {
     set_error("wgrad_cnx: T %% 8 != 0");
     return STY_EINVAL;
@@ -1264,10 +1279,13 @@ int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, i
   const int nsplit = per_b ? B * SB : wgrad_cnx_nsplit(B, T), cpb = cdiv(T, 128);
   const size_t lds = (size_t)160 * WB_PITCH * sizeof(__bf16);
   ProfScope prof(x_wide ? "wgrad_cnx_kernel<true>" : "wgrad_cnx_kernel<false>", 2.0 * 128 * 32 * (double)B * T,
-                 (double)B * T * (128 * 2 + 32 * 4), st);
+                 (double)B * T * (128 * 2 + 32 * (narrow16 ? 2 : 4)), st);
   if (x_wide)
     hipLaunchKernelGGL(wgrad_cnx_kernel<true>, dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide), narrow, B,
                        T, nsplit, cpb, partial, want_bias, SB);
+  else if (narrow16)
+    hipLaunchKernelGGL((wgrad_cnx_kernel<false, true>), dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide),
+                       narrow, B, T, nsplit, cpb, partial, want_bias, SB);
   else
     hipLaunchKernelGGL(wgrad_cnx_kernel<false>, dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide), narrow, B,
                        T, nsplit, cpb, partial, want_bias, SB);

@@ -440,6 +440,43 @@ def test_convnext32_block_bf16_mode_vs_fp32_mode(env):
     assert not torch.equal(res[True]["gx"], res[False]["gx"])  # the bf16 kernels really ran
 
 
+@pytest.mark.parametrize("T", [8, 248, 256, 264, 504, 1032])
+def test_convnext32_lean_backward_with_the_input_gradient_fused_equals_the_separate_kernels(env, T, monkeypatch):
+    """Round 5: the lean ConvNeXt32 backward writes gX = gY + dwconv^T(gU) itself (overlapping tiles of 248 owned columns,
+    convnext_bwd.hip) and leaves xn as bf16 for the dW1 GEMM.  Against the same block with both switched off
+    (STY_NO_CNX_GX / STY_NO_CNX_XN16: dwconv7_bwd_dx_kernel, fp32 xn rounded at the GEMM's load): d x to fp32 summation order,
+    every parameter gradient to the order of the per-tile partial sums (the tiles differ: 248 vs 256 columns).  T covers one
+    tile, the tile edges (248, 256, 264: the second tile owns 4 ... 16 columns) and many tiles."""
+    import stylish_tts_amd as S
+    prefix, C = "generator.basegen.phase_convnext.2", 32
+    g = torch.Generator().manual_seed(100 + T)
+    x, style, gy = torch.randn(2, C, T, generator=g), torch.randn(2, 64, generator=g), torch.randn(2, C, T, generator=g)
+    res = {}
+    for fused in (False, True):
+        for k in ("STY_NO_CNX_GX", "STY_NO_CNX_XN16"):
+            if fused:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, "1")
+        m = S.SpeechPredictor()
+        m.load_state_dict({k: v.clone() for k, v in env["P"].items()}, strict=False)
+        m = m.to(DEV).enable_training()
+        m._ensure(torch.device(DEV))
+        for p_ in m.parameters():
+            p_.grad.zero_()
+        y, gx, d_style = m.block_forward_backward("convnext", prefix, dev(x), dev(style), dev(gy), compute_bf16=True)
+        torch.cuda.synchronize()
+        res[fused] = dict(y=y.cpu(), gx=gx.cpu(), d_style=d_style.cpu(),
+                          **{k[len(prefix) + 1:]: p_.grad.cpu().clone() for k, p_ in m.named_parameters()
+                             if k.startswith(prefix + ".")})
+    rep = Report()
+    assert torch.equal(res[True]["y"], res[False]["y"])
+    for k in res[False]:
+        if res[False][k].abs().max().item() > 0:
+            rep.add(k, res[True][k], res[False][k], 2e-6 if k == "gx" else 2e-5)
+    rep.done()
+
+
 @pytest.mark.parametrize("DH,T,masked", [(16, 40, True), (16, 100, True), (64, 160, False), (64, 520, False)])
 def test_attention_backward_vs_float64(DH, T, masked):
     """sty_attention_fwd_bwd: the text encoder's masked attention (DH = 16, VALU backward kernels attn_bwd_{a,b,c}) and
