@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
   // FUSED (lean pass 2 with a.gx): overlapping tiles -- 256 columns computed, the owned ones [own_lo, own_hi) stored and summed,
   // and the input gradient gX = gY + dwconv^T(gU) written from this kernel (the epilogue at the end): every owned column finds
   // the gU of its three neighbours on either side in this workgroup's LDS
-  const bool fused = PASS == 2 && LEAN && a.gx != nullptr;
+  const bool fused = PASS == 2 && a.gx != nullptr;
   const int b = blockIdx.y, t0 = blockIdx.x * (fused ? CNX_BWD_FUSED_STRIDE : CB_TT), T = a.T;
   const int own_lo = fused && blockIdx.x > 0 ? 4 : 0, own_hi = fused ? 4 + CNX_BWD_FUSED_STRIDE : CB_TT;
   const float* xb = a.x + (size_t)b * 32 * T;
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     const int vst16 = ok ? (4 * hi * T + t) * 2 : 0x7FFFFF00;
     const int vst32 = ok ? (4 * hi * T + t) * 4 : 0x7FFFFF00;
     const float okf = okT ? 1.f : 0.f;  // (the hi half of the wave holds the rows 4 further down)
+    const float ownf = ok ? 1.f : 0.f;
     // B fragments: normalised input (AdaLN affine applied on the way) and the output gradient
     float bx[16], by[16];
     bf16x8 bxf[2], byf[2];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
               // rows from being requested early: three exposed LDS round trips per element; columns past the end hold finite values)
 #endif
             const float g0 = gH * (1.f + s2a);
-            if constexpr (!LEAN) rsum = gH * (z * s2a - s2 * ral) * ral;
+            if constexpr (!LEAN) rsum = ownf * gH * (z * s2a - s2 * ral) * ral;  // (d alpha: owned columns only)
             if (LEAN) {
               const bf16x8 pk = sty_pack_bf16(g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
               const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;
@@ -503,9 +504,9 @@ int convnext32_bwd_ntiles(int T, int fused) {
 }
 
 int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st) {
-  const bool fused_ = pass == 2 && a.bf16 && a.out_bf16 && a.lean && a.gx;
+  const bool fused_ = pass == 2 && a.gx;
   if (a.gx && (!fused_ || a.gx == a.gy || a.T % 4)) {
-    set_error("convnext32_bwd: the fused input gradient needs the lean pass 2, T %% 4 == 0 and gx != gy");
+    set_error("convnext32_bwd: the fused input gradient needs pass 2, T %% 4 == 0 and gx != gy");
     return STY_EINVAL;
   }
   if (a.xn16 && (pass != 2 || a.T % 2)) {

@@ -734,7 +734,7 @@ struct Trainer {
       const float* gx_src = nullptr;
       // lean backward, x's gradient not written yet (the chain's ordinary case): the fused kernel writes gX = gY + dwconv^T(gU)
       // itself, out of place, on overlapping tiles (convnext_bwd.hip) -- no dwconv7_bwd_dx pass over gU, gY and gX
-      const bool fuse_gx = lean && !gmap.count(x) && Tt % 4 == 0 && getenv("STY_NO_CNX_GX") == nullptr;
+      const bool fuse_gx = !gmap.count(x) && Tt % 4 == 0 && getenv("STY_NO_CNX_GX") == nullptr;
       const bool xn16 = lean && getenv("STY_NO_CNX_XN16") == nullptr;  // xn (an MFMA operand of dW1 only) as bf16
       if (!gmap.count(x)) {
         if (side || fuse_gx) {
@@ -824,12 +824,15 @@ struct Trainer {
           chk(launch_cnx_partial_sum(pgb, B, 64, nt_b, 2, dgl, st));
         }
       } else if (live()) {
-        chk(launch_convnext32_bwd(a, B, 1, st));
+        Cnx32BwdArgs a1 = a;  // pass 1 (ds partials) on the plain tiling
+        a1.gx = nullptr;
+        a1.ntiles = nt;
+        chk(launch_convnext32_bwd(a1, B, 1, st));
         chk(launch_cnx_partial_sum(pds, B, 128, nt, 0, ds, st));
         chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
         chk(launch_convnext32_bwd(a, B, 2, st));
-        chk(launch_cnx_partial_sum(pds, B, 128, nt, 1, dal, st));
-        chk(launch_cnx_partial_sum(pgb, B, 64, nt, 2, dgl, st));
+        chk(launch_cnx_partial_sum(pds, B, 128, nt_b, 1, dal, st));
+        chk(launch_cnx_partial_sum(pgb, B, 64, nt_b, 2, dgl, st));
       }
       const float *w1r = c.w1_raw, *b1p = c.b1, *alp = c.alpha;
       auto lean_w1 = [=](hipStream_t s_) {  // dW1 (+ db1) from (gH0, xn), then d alpha from it

@@ -440,13 +440,15 @@ def test_convnext32_block_bf16_mode_vs_fp32_mode(env):
     assert not torch.equal(res[True]["gx"], res[False]["gx"])  # the bf16 kernels really ran
 
 
-@pytest.mark.parametrize("T", [8, 248, 256, 264, 504, 1032])
-def test_convnext32_lean_backward_with_the_input_gradient_fused_equals_the_separate_kernels(env, T, monkeypatch):
+@pytest.mark.parametrize("T,bf16", [(8, True), (248, True), (256, True), (264, True), (504, True), (1032, True),
+                                    (260, True), (264, False), (1032, False)])
+def test_convnext32_backward_with_the_input_gradient_fused_equals_the_separate_kernels(env, T, bf16, monkeypatch):
     """Round 5: the lean ConvNeXt32 backward writes gX = gY + dwconv^T(gU) itself (overlapping tiles of 248 owned columns,
     convnext_bwd.hip) and leaves xn as bf16 for the dW1 GEMM.  Against the same block with both switched off
     (STY_NO_CNX_GX / STY_NO_CNX_XN16: dwconv7_bwd_dx_kernel, fp32 xn rounded at the GEMM's load): d x to fp32 summation order,
     every parameter gradient to the order of the per-tile partial sums (the tiles differ: 248 vs 256 columns).  T covers one
-    tile, the tile edges (248, 256, 264: the second tile owns 4 ... 16 columns) and many tiles."""
+    tile, the tile edges (248, 256, 264: the second tile owns 4 ... 16 columns) and many tiles; T = 260 is the two-pass bf16
+    kernel (T % 8 != 0), bf16 = False the fp32 mode (c2): there only the fused input gradient applies."""
     import stylish_tts_amd as S
     prefix, C = "generator.basegen.phase_convnext.2", 32
     g = torch.Generator().manual_seed(100 + T)
@@ -464,7 +466,7 @@ def test_convnext32_lean_backward_with_the_input_gradient_fused_equals_the_separ
         m._ensure(torch.device(DEV))
         for p_ in m.parameters():
             p_.grad.zero_()
-        y, gx, d_style = m.block_forward_backward("convnext", prefix, dev(x), dev(style), dev(gy), compute_bf16=True)
+        y, gx, d_style = m.block_forward_backward("convnext", prefix, dev(x), dev(style), dev(gy), compute_bf16=bf16)
         torch.cuda.synchronize()
         res[fused] = dict(y=y.cpu(), gx=gx.cpu(), d_style=d_style.cpu(),
                           **{k[len(prefix) + 1:]: p_.grad.cpu().clone() for k, p_ in m.named_parameters()
