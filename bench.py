@@ -760,28 +760,28 @@ def main():
         # RCCL under the step on a 1-GPU box: backend "nccl" with ONE rank and the gradient exchange forced
         # (STY_DIST_FORCE_COLLECTIVE=1, dist.force_collective): every bucket goes through all_reduce(async_op=True) from the
         # library's gradient hooks, RCCL's streams run beside the trainer's four under GPU_MAX_HW_QUEUES=2.
-        import socket
+        # Measured as a run of its own (`bench.py --rccl1` in a child process, the headline's K / W): as a second trainer inside
+        # this process -- behind the headline and the extras -- the same step read 1.06-1.08 with or without RCCL in it
+        # (profiles/r05_ab_env.txt block 8), which is this process's history, not the collective path.
+        import subprocess
+        import tempfile
         try:
-            with socket.socket() as s_:
-                s_.bind(("127.0.0.1", 0))
-                port = s_.getsockname()[1]
-            os.environ.update(STY_DIST_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
-                              WORLD_SIZE="1")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            D.init("nccl")
-            r = run_workload("c3", args.steps, args.warmup, 0, 1, device, lib, L, D, share, serial_pass=False)  # (the headline's own K / W:
-            # measured with 10 / 3 the record read 1.07 where the same step as a run of its own -- bench.py --rccl1 -- reads 1.00)
+            with tempfile.TemporaryDirectory() as td:
+                cmd = [sys.executable, os.path.abspath(__file__), "--rccl1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                       "--no-extra", "--no-cpu-baseline", "--detail", os.path.join(td, "detail.json")]
+                env = dict(os.environ)
+                for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                    env.pop(k, None)
+                out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True)
+                r = json.loads(out.stdout.decode().strip().splitlines()[-1])
             rccl1 = {"what": "the c3 step with backend nccl (RCCL), world size 1, every gradient bucket all-reduced "
-                             "(STY_DIST_FORCE_COLLECTIVE=1) -- the collective path of an N-GPU run minus the wire",
+                             "(STY_DIST_FORCE_COLLECTIVE=1) -- the collective path of an N-GPU run minus the wire; a run of its own "
+                             "(bench.py --rccl1 in a child process)",
                      "ms_per_step": r["ms_per_step"], "vs_no_process_group": r["ms_per_step"] / rec["ms_per_step"],
-                     "host_issue_ms_per_step": r["host_issue_ms_per_step"],
+                     "host_issue_ms_per_step": r["host_issue_ms_per_step"], "backend": "nccl (RCCL)",
                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
-            torch.distributed.barrier()
-            torch.distributed.destroy_process_group()
         except Exception as e:  # never fail the bench line on this
             rccl1 = {"error": f"{type(e).__name__}: {e}"[:300]}
-        finally:
-            os.environ.pop("STY_DIST_FORCE_COLLECTIVE", None)
     if rank != 0:
         return
     rec["library"] = lib_info
