@@ -139,7 +139,11 @@ def grn_scale(h, gamma, eps=1e-6):
 #     and the output of the prior conv in front of the block: `store16`;
 #   * the input gradient of a conv whose input is such a tensor (d loss / d prologue(x), before the prologue's derivative):
 #     `_BfConv1d(..., round_gx=True)`.
-# Gradient accumulators stay fp32 in the product, so nothing else is rounded on the way back.
+# Gradient accumulators stay fp32 in the product, so nothing else is rounded on the way back -- except on the 32-channel
+# ConvNeXt chain of the vocoder's phase path (round 5, `round_grad`): under autocast that residual stream and its gradient
+# are bf16 tensors (conv_next.py:80-93); the product keeps the chain's GRADIENTS as two-byte tensors where its fused lean
+# backward applies (C == 32, T % 8 == 0): d loss / d x of every block input between the chain's two LayerNorms and
+# d loss / d (depthwise-conv output) of every such block are each rounded once, where they are stored.
 _DENSE = {"bf16": False, "store16": False}
 
 
@@ -220,6 +224,23 @@ class _FProxy:
         return self._conv(self._r.conv2d, x, w, b, stride, padding, dilation, groups)
 
 
+class _RoundGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bf(g)
+
+
+def round_grad(t, on=True):
+    """a tensor whose GRADIENT the product stores as bf16 (storage rule): identity forward, one rounding of the gradient"""
+    if not (_DENSE["store16"] and on):
+        return t
+    return _RoundGrad.apply(t)
+
+
 def store16(t, on=True):
     """a tensor the product stores as bf16: rounded once in the forward; the gradient passes unchanged (its accumulator is fp32)"""
     if not (_DENSE["store16"] and on):
@@ -254,10 +275,13 @@ def dense_conv1d(x, w, b, padding=0, dilation=1, x_stored16=False):
     return y if b is None else y + b.view(1, -1, 1)
 
 
-def convnext_block(P, p, x, style, want=None):
-    """GeneratorConvNeXtBlock on [B,C,T] (conv_next.py:80-93)."""
+def convnext_block(P, p, x, style, want=None, grad16=False):
+    """GeneratorConvNeXtBlock on [B,C,T] (conv_next.py:80-93).  grad16: the block sits inside the two-byte gradient chain (its
+    input's gradient is a bf16 tensor in the product: storage rule, `round_grad`)."""
     C = x.shape[1]
-    h = F.conv1d(x, P[p + ".dwconv.weight"], P[p + ".dwconv.bias"], padding=3, groups=C)
+    lean = C == 32 and x.shape[2] % 8 == 0  # where the product's lean fused backward (and with it the two-byte gU) applies
+    x = round_grad(x, on=grad16 and lean)
+    h = round_grad(F.conv1d(x, P[p + ".dwconv.weight"], P[p + ".dwconv.bias"], padding=3, groups=C), on=lean)
     h = adaln(P, p + ".norm", h, style, eps=1e-6)
     h = dense_conv1d(h, P[p + ".pwconv1.weight"][:, :, None], P[p + ".pwconv1.bias"])
     h = snake(h, P[p + ".snake"].view(1, -1, 1))

@@ -81,9 +81,13 @@ def generator(P, p, mel, style, pitch, voiced, noise, want=None, prior=None):
     ph = F.conv1d(ph, P[p + ".phase_input_conv.weight"], P[p + ".phase_input_conv.bias"], padding=10)
     ph = B.chan_layer_norm(ph, P[p + ".phase_norm.weight"], P[p + ".phase_norm.bias"], 1e-6)
     i = 0
+    # (storage rule: between the two LayerNorms the gradient of every block input / output is a two-byte tensor in the product --
+    #  where its long-row LayerNorm(32) kernel applies: B T >= 65536)
+    g16 = ph.shape[0] * ph.shape[2] >= 65536
     while (f"{p}.phase_convnext.{i}.dwconv.weight") in P:
-        ph = B.convnext_block(P, f"{p}.phase_convnext.{i}", ph, style, want)
+        ph = B.convnext_block(P, f"{p}.phase_convnext.{i}", ph, style, want, grad16=g16)
         i += 1
+    ph = B.round_grad(ph, on=g16 and ph.shape[2] % 8 == 0)
     ph = B.chan_layer_norm(ph, P[p + ".phase_final_layer_norm.weight"], P[p + ".phase_final_layer_norm.bias"], 1e-6)
     real = F.conv1d(ph, P[p + ".phase_output_real_conv.weight"], P[p + ".phase_output_real_conv.bias"], padding=10)
     imag = F.conv1d(ph, P[p + ".phase_output_imag_conv.weight"], P[p + ".phase_output_imag_conv.bias"], padding=10)

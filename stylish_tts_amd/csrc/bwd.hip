@@ -594,10 +594,12 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __r
 // second kernel over x and dy.  Here the per-channel sums over time (sum g xh, sum g) are reduced across each 32-lane half with
 // DPP adds, across the workgroup with LDS atomics and leave as ONE partial row per workgroup; chan_ln32_param_sum_kernel adds
 // the rows in a fixed order (deterministic; the general path's one atomic per (b, c) row is not).
-__global__ __launch_bounds__(256) void chan_ln32_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int T,
+// h16 bits: 1 = x, 2 = dy, 4 = dx are bf16 tensors (the two ends of a two-byte ConvNeXt32 chain; dx then without accumulate)
+__global__ __launch_bounds__(256) void chan_ln32_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, int T,
                                                             float eps, int ada, const float* __restrict__ w,
                                                             const float* __restrict__ gb, const float* __restrict__ out_mask,
-                                                            float* __restrict__ dx, int accumulate, float* __restrict__ part) {
+                                                            void* __restrict__ dx, int accumulate, float* __restrict__ part,
+                                                            int h16) {
   __shared__ float A_s[32];
   __shared__ float red[64];
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -610,8 +612,8 @@ __global__ __launch_bounds__(256) void chan_ln32_bwd_kernel(const float* __restr
   float xv[32], gv[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) {
-    xv[c] = in ? x[base + (size_t)c * T] : 0.f;
-    gv[c] = in ? dy[base + (size_t)c * T] : 0.f;
+    xv[c] = in ? sty_ld_any(x, base + (size_t)c * T, h16 & 1) : 0.f;
+    gv[c] = in ? sty_ld_any(dy, base + (size_t)c * T, h16 & 2) : 0.f;
   }
   const float om = (in && out_mask) ? out_mask[(size_t)b * T + t] : 1.f;
   float mean = 0.f;
@@ -640,8 +642,12 @@ __global__ __launch_bounds__(256) void chan_ln32_bwd_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
       const float d = r * (gv[c] * A_s[c] - s1 - xv[c] * s2);
-      float* o = dx + base + (size_t)c * T;
-      *o = accumulate ? *o + d : d;
+      if (h16 & 4) {
+        sty_st_any(dx, base + (size_t)c * T, d, true);
+      } else {
+        float* o = reinterpret_cast<float*>(dx) + base + (size_t)c * T;
+        *o = accumulate ? *o + d : d;
+      }
     }
   }
   // parameter sums of this workgroup's 256 columns (columns past the end hold zeros)
@@ -677,19 +683,44 @@ __global__ __launch_bounds__(64) void chan_ln32_param_sum_kernel(const float* __
   }
 }
 
+__global__ void cast_any_kernel(const void* __restrict__ x, size_t n, void* __restrict__ y, int to16) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) sty_st_any(y, i, sty_ld_any(x, i, !to16), to16);
+}
+int launch_cast_f32_to_16(const float* x, size_t n, void* y16, hipStream_t st) {
+  hipLaunchKernelGGL(cast_any_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, y16, 1);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+int launch_cast_16_to_f32(const void* x16, size_t n, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(cast_any_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x16, n, y, 0);
+  STY_LAUNCH_CHECK();
+  return STY_OK;
+}
+bool chan_ln32_eligible(int B, int C, int T, int relu) {
+  return C == 32 && !relu && (size_t)B * T >= 65536 && getenv("STY_NO_LN32_BWD") == nullptr;
+}
 int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,
                        const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
-                       float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st) {
+                       float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st, int h16) {
   static const bool noreg = getenv("STY_NO_LN_BWD_REG") != nullptr;
   static const bool regall = getenv("STY_LN_BWD_REG_ALL") != nullptr;  // experiment: the register form for the long rows too
   const bool no32 = getenv("STY_NO_LN32_BWD") != nullptr;  // (read per call: the A/B test toggles it)
   if (C == 32 && !relu && (size_t)B * T >= 65536 && !no32) {  // the 75T-rate LayerNorms: one thread per column (above)
     const int nblk = cdiv(T, 256);                           // partial rows live in mu_tmp (B T floats >= 64 B nblk)
+    if ((h16 & 4) && accumulate) {
+      set_error("chan_ln_bwd: a two-byte dx cannot be accumulated into");
+      return STY_EINVAL;
+    }
     hipLaunchKernelGGL(chan_ln32_bwd_kernel, dim3(nblk, B), dim3(256), 0, st, x, dy, T, eps, ada, w, gb, out_mask, dx, accumulate,
-                       mu_tmp);
+                       mu_tmp, h16);
     hipLaunchKernelGGL(chan_ln32_param_sum_kernel, dim3(ada ? B * 64 : 64), dim3(64), 0, st, mu_tmp, B, nblk, ada, dgb, dw, db);
     STY_LAUNCH_CHECK();
     return STY_OK;
+  }
+  if (h16) {
+    set_error("chan_ln_bwd: two-byte tensors only on the C = 32 long-row kernel (chan_ln32_eligible)");
+    return STY_EINVAL;
   }
   if (((size_t)B * T < 65536 || regall) && C <= 256 && !noreg)
     hipLaunchKernelGGL((chan_ln_bwd_dx_reg_kernel<16, 16>), dim3(cdiv(T, 16), B), dim3(256), 0, st, x, dy, y, C, T, eps, ada, w,
@@ -1056,12 +1087,13 @@ __global__ __launch_bounds__(256) void dwconv7_bwd_dx_kernel(const float* __rest
 // (The first version used one workgroup per channel looping over the whole batch: 1.1 ms per call at C = 32.)
 constexpr int DW_SEG = 4096;
 template <int MAXK>
-__global__ __launch_bounds__(256) void dwconv_bwd_w_part_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ dy, int C, int T, int K,
-                                                                int pad, int nseg, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void dwconv_bwd_w_part_kernel(const void* __restrict__ x,
+                                                                const void* __restrict__ dy, int C, int T, int K,
+                                                                int pad, int nseg, float* __restrict__ part, int xh, int gh) {
   const int seg = blockIdx.x % nseg, b = blockIdx.x / nseg, c = blockIdx.y;
-  const float* xr = x + ((size_t)b * C + c) * T;
-  const float* gr = dy + ((size_t)b * C + c) * T;
+  // xh / gh: x / dy are bf16 tensors (round 5: the fused ConvNeXt32 backward's gU, a two-byte chain's x)
+  const char* xr = reinterpret_cast<const char*>(x) + ((size_t)b * C + c) * T * (xh ? 2 : 4);
+  const char* gr = reinterpret_cast<const char*>(dy) + ((size_t)b * C + c) * T * (gh ? 2 : 4);
   float acc[MAXK + 1];
 #pragma unroll
   for (int k = 0; k <= MAXK; ++k) acc[k] = 0.f;
@@ -1071,13 +1103,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_part_kernel(const float* __r
   // sample and ran at a third of the HBM rate
   if (MAXK <= 7 && pad <= 4 && (T & 3) == 0 && ((((size_t)xr | (size_t)gr) & 15) == 0)) {
     for (int t = seg * DW_SEG + 4 * threadIdx.x; t < t1; t += 1024) {
-      const float4 g4 = *reinterpret_cast<const float4*>(gr + t);
+      const float4 g4 = sty_ld4_any(gr, t >> 2, gh);
       float xv[12];  // x[t - 4 .. t + 7]
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int tq = t - 4 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tq >= 0 && tq < T) v = *reinterpret_cast<const float4*>(xr + tq);
+        if (tq >= 0 && tq < T) v = sty_ld4_any(xr, tq >> 2, xh);
         xv[4 * q] = v.x;
         xv[4 * q + 1] = v.y;
         xv[4 * q + 2] = v.z;
@@ -1096,12 +1128,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_part_kernel(const float* __r
     }
   } else {
     for (int t = seg * DW_SEG + threadIdx.x; t < t1; t += 256) {
-      const float g = gr[t];
+      const float g = sty_ld_any(gr, t, gh);
       acc[MAXK] += g;
 #pragma unroll
       for (int k = 0; k < MAXK; ++k) {
         const int tt = t - pad + k;
-        if (k < K && tt >= 0 && tt < T) acc[k] = fmaf(g, xr[tt], acc[k]);
+        if (k < K && tt >= 0 && tt < T) acc[k] = fmaf(g, sty_ld_any(xr, tt, xh), acc[k]);
       }
     }
   }
@@ -1136,7 +1168,12 @@ __global__ void dwconv_bwd_w_sum_kernel(const float* __restrict__ part, int C, i
 }
 size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K) { return (size_t)C * B * cdiv(T, DW_SEG) * (K + 1); }
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
-                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src) {
+                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src, int x16,
+                      int dy16) {
+  if ((x16 || dy16) && (dx || T % 4)) {
+    set_error("dwconv_bwd: two-byte x / dy only for the weight gradient (dx == nullptr), T %% 4 == 0");
+    return STY_EINVAL;
+  }
   if (dx) {
     const bool al16 = (((size_t)dy | (size_t)dx | (size_t)dx_src) & 15) == 0;
     const size_t ng = (size_t)B * C * (T / 4);
@@ -1158,10 +1195,10 @@ int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, in
     const int nseg = cdiv(T, DW_SEG);
     if (K <= 7)
       hipLaunchKernelGGL(dwconv_bwd_w_part_kernel<7>, dim3(nseg * B, C), dim3(256), 0, st, x, dy, C, T, K, pad, nseg,
-                         scratch);
+                         scratch, x16, dy16);
     else if (K <= 31)
       hipLaunchKernelGGL(dwconv_bwd_w_part_kernel<31>, dim3(nseg * B, C), dim3(256), 0, st, x, dy, C, T, K, pad, nseg,
-                         scratch);
+                         scratch, x16, dy16);
     else {
       set_error("dwconv_bwd: kernel size %d > 31", K);
       return STY_EINVAL;

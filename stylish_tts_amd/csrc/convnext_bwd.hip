@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
   const bool fused = PASS == 2 && a.gx != nullptr;
   const int b = blockIdx.y, t0 = blockIdx.x * (fused ? CNX_BWD_FUSED_STRIDE : CB_TT), T = a.T;
   const int own_lo = fused && blockIdx.x > 0 ? 4 : 0, own_hi = fused ? 4 + CNX_BWD_FUSED_STRIDE : CB_TT;
-  const float* xb = a.x + (size_t)b * 32 * T;
-  const float* gb_ = a.gy + (size_t)b * 32 * T;
+  const bool gy16 = a.gy16;  // a two-byte output gradient (kernel-uniform)
+  const void* xb = reinterpret_cast<const char*>(a.x) + (size_t)b * 32 * T * 4;
+  const void* gb_ = reinterpret_cast<const char*>(a.gy) + (size_t)b * 32 * T * (gy16 ? 2 : 4);
   // pass-2 outputs go through buffer descriptors of this batch row (32-bit offsets: the 64-bit per-row store
   // addresses of the flat form cost ~80 spilled VGPRs)
   __amdgpu_buffer_rsrc_t r_hs, r_g0, r_xn, r_gu, r_gx;
@@ -60,8 +61,10 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
                                              0x00020000);
     const int xsz = a.xn16 ? 2 : 4;
     r_xn = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.xn) + (size_t)b * 32 * T * xsz, 0, 32 * T * xsz, 0x00020000);
-    r_gu = __builtin_amdgcn_make_buffer_rsrc(a.gu + (size_t)b * 32 * T, 0, 32 * T * 4, 0x00020000);
-    r_gx = __builtin_amdgcn_make_buffer_rsrc(fused ? a.gx + (size_t)b * 32 * T : a.gu, 0, 32 * T * 4, 0x00020000);
+    const int usz = a.gu16 ? 2 : 4, gsz = a.gx16 ? 2 : 4;
+    r_gu = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.gu) + (size_t)b * 32 * T * usz, 0, 32 * T * usz, 0x00020000);
+    r_gx = __builtin_amdgcn_make_buffer_rsrc(fused ? reinterpret_cast<char*>(a.gx) + (size_t)b * 32 * T * gsz
+                                                   : reinterpret_cast<char*>(a.gu), 0, 32 * T * gsz, 0x00020000);
   }
   auto bst = [](__amdgpu_buffer_rsrc_t rs, float v, int off) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
@@ -85,12 +88,22 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
         const int j = lane + 64 * q, t = t0 - 3 + j;
-        v[i][q] = (j < LW && t >= 0 && t < T) ? xb[(size_t)row * T + t] : 0.f;
+        v[i][q] = (j < LW && t >= 0 && t < T) ? reinterpret_cast<const float*>(xb)[(size_t)row * T + t] : 0.f;
       }
+      if (gy16) {  // two-byte gY: a lane loads TWO adjacent columns (one dword; t0 and T are even), half the requests
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = t0 + lane + 64 * q;
-        g[i][q] = t < T ? gb_[(size_t)row * T + t] : 0.f;
+        for (int q = 0; q < 2; ++q) {
+          const int t = t0 + 2 * (lane + 64 * q);
+          const unsigned u = t < T ? reinterpret_cast<const unsigned*>(gb_)[((size_t)row * T + t) >> 1] : 0u;
+          g[i][2 * q] = sty_bf_lo(u);
+          g[i][2 * q + 1] = sty_bf_hi(u);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t0 + lane + 64 * q;
+          g[i][q] = t < T ? reinterpret_cast<const float*>(gb_)[(size_t)row * T + t] : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -99,8 +112,13 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
 #pragma unroll
       for (int q = 0; q < 5; ++q)
         if (lane + 64 * q < LW) xs[row * LW + lane + 64 * q] = v[i][q];
+      if (gy16) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) gys[row * LG + lane + 64 * q] = g[i][q];
+        for (int q = 0; q < 4; ++q) gys[row * LG + 2 * (lane + 64 * (q >> 1)) + (q & 1)] = g[i][q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gys[row * LG + lane + 64 * q] = g[i][q];
+      }
     }
   }
   __syncthreads();
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
         xs[c * LW + 3 + tid] = xh0;
         xs[(c + 1) * LW + 3 + tid] = xh1;
         const float v0 = fmaf(xh0, gbs[c], gbs[32 + c]), v1 = fmaf(xh1, gbs[c + 1], gbs[33 + c]);
-        const float got = __shfl_xor(odd ? v0 : v1, 1);  // even: the partner's channel c; odd: the partner's channel c + 1
+        const float got = sty_pair_swap(odd ? v0 : v1);  // even: the partner's channel c; odd: the partner's channel c + 1
         const unsigned two = odd ? sty_pack2_bf16(got, v1) : sty_pack2_bf16(v0, got);
         __builtin_amdgcn_raw_buffer_store_b32(two, r_xn, voff, c * T * 2, 0);
       }
@@ -170,6 +188,10 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     // check (no exec-mask branch around each of the 128 stores per lane and pass)
     const int vst16 = ok ? (4 * hi * T + t) * 2 : 0x7FFFFF00;
     const int vst32 = ok ? (4 * hi * T + t) * 4 : 0x7FFFFF00;
+    // paired two-byte stores (lean gH0, two-byte gU): the even lane of a pair stores (its row, columns t, t + 1), the odd lane
+    // (the next row, columns t - 1, t); a pair is owned or not as a whole
+    const bool oddl = l31 & 1;
+    const int vstp = ok ? (4 * hi * T + (oddl ? T + t - 1 : t)) * 2 : 0x7FFFFF00;
     const float okf = okT ? 1.f : 0.f;  // (the hi half of the wave holds the rows 4 further down)
     const float ownf = ok ? 1.f : 0.f;
     // B fragments: normalised input (AdaLN affine applied on the way) and the output gradient
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
       // fast path its schedule (registers saved around the calls, a wait in front of every branch) -- and the rare block with it.
       auto elem_loop = [&](auto slow_c) {
         const bool SLOWP = slow_c;  // (a compile-time constant after inlining, except in the STY_CNX_BWD_OLD build variant)
+        float g0e = 0.f;
   #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -301,9 +324,17 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
             const float g0 = gH * (1.f + s2a);
             if constexpr (!LEAN) rsum = ownf * gH * (z * s2a - s2 * ral) * ral;  // (d alpha: owned columns only)
             if (LEAN) {
-              const bf16x8 pk = sty_pack_bf16(g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
-              const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;
-              __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(uint4, pk).x & 0xffffu), r_g0, vst16, srow, 0);
+              // gH0 leaves as DWORDS: rows r, r + 1 (r even) are adjacent channels and a lane pair holds adjacent columns, so
+              // after one swap the even lane stores (row r: columns t, t + 1) and the odd lane (row r + 1: columns t - 1, t) --
+              // eight stores per 32 x 32 block and lane where there were sixteen 2-byte ones
+              if ((r & 1) == 0) {
+                g0e = g0;
+              } else {
+                const float got = sty_pair_swap(oddl ? g0e : g0);
+                const unsigned two = oddl ? sty_pack2_bf16(got, g0) : sty_pack2_bf16(g0e, got);
+                const int srow = (j * 32 + ((r - 1) & 3) + 8 * ((r - 1) >> 2)) * T * 2;
+                __builtin_amdgcn_raw_buffer_store_b32(two, r_g0, vstp, srow, 0);
+              }
             } else if (ok) {
               if (BF && a.out_bf16) {
                 const bf16x8 pk = sty_pack_bf16(hv * sc, g0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
@@ -373,11 +404,21 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
       s1 *= (1.0f / 32.0f);
       s2 *= (1.0f / 32.0f);
       const float rs = rstd_s[tl];
+      float gue = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
         const float guv = rs * (gxh[r] - s1 - xh[r] * s2);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, guv), r_gu, vst32, ((r & 3) + 8 * (r >> 2)) * T * 4, 0);
+        if (a.gu16) {
+          if ((r & 1) == 0) {
+            gue = guv;
+          } else {
+            const float got = sty_pair_swap(oddl ? gue : guv);
+            const unsigned two = oddl ? sty_pack2_bf16(got, guv) : sty_pack2_bf16(gue, got);
+            __builtin_amdgcn_raw_buffer_store_b32(two, r_gu, vstp, (((r - 1) & 3) + 8 * ((r - 1) >> 2)) * T * 2, 0);
+          }
+        } else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, guv), r_gu, vst32, ((r & 3) + 8 * (r >> 2)) * T * 4, 0);
         // FUSED: gU takes x-hat's place in LDS (this lane was the cell's only reader); columns past the end hold zero
         if (fused) xs[c * LW + 3 + tl] = okf * guv;
         float v = ok ? gxn[r] * xh[r] : 0.f, w = ok ? gxn[r] : 0.f;
@@ -401,7 +442,8 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
     typedef unsigned u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
     const int p2 = 2 * (tid & 127), half = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int t = t0 + p2;
-    const int voff = (t < T && p2 >= own_lo && p2 < own_hi) ? t * 4 : 0x7FFFFF00;
+    const bool own2 = t < T && p2 >= own_lo && p2 < own_hi;
+    const int voff = own2 ? t * 4 : 0x7FFFFF00, voff16 = own2 ? t * 2 : 0x7FFFFF00;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int c = 16 * half + i;
@@ -415,8 +457,11 @@ __global__ __launch_bounds__(256, 2) void convnext32_bwd_kernel(Cnx32BwdArgs a) 
         a0 = fmaf(w, win[6 - k], a0);
         a1 = fmaf(w, win[7 - k], a1);
       }
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1)}, r_gx,
-                                            voff, c * T * 4, 0);
+      if (a.gx16)
+        __builtin_amdgcn_raw_buffer_store_b32(sty_pack2_bf16(a0, a1), r_gx, voff16, c * T * 2, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1)}, r_gx,
+                                              voff, c * T * 4, 0);
     }
   }
   if (tid < 128 && !(PASS == 2 && LEAN)) {
@@ -509,6 +554,14 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
     set_error("convnext32_bwd: the fused input gradient needs pass 2, T %% 4 == 0 and gx != gy");
     return STY_EINVAL;
   }
+  if (a.x16) {
+    set_error("convnext32_bwd: a two-byte x is not built");
+    return STY_EINVAL;
+  }
+  if ((a.gx16 && !fused_) || ((a.gx16 || a.gu16 || a.gy16) && a.T % 2)) {
+    set_error("convnext32_bwd: two-byte gX needs the fused input gradient; two-byte gX / gU an even T");
+    return STY_EINVAL;
+  }
   if (a.xn16 && (pass != 2 || a.T % 2)) {
     set_error("convnext32_bwd: two-byte xn needs pass 2 and an even T");
     return STY_EINVAL;
@@ -543,7 +596,8 @@ int launch_convnext32_bwd(const Cnx32BwdArgs& a, int B, int pass, hipStream_t st
   const double flops = pos * (448.0 + 16384.0 + (pass == 2 ? 8192.0 : 0.0));
   // (h s and gH0 as bf16 in the bf16 mode: 2 x 128 x 2 bytes instead of 2 x 128 x 4)
   const bool lean = pass == 2 && a.bf16 && a.out_bf16 && a.lean;
-  const double bytes = pos * (4.0 * 64.0 + (pass == 2 ? (a.xn16 ? 2.0 : 4.0) * 32.0 + 4.0 * 32.0 + (fused_ ? 4.0 * 32.0 : 0.0) +
+  const double bytes = pos * ((a.x16 ? 2.0 : 4.0) * 32.0 + (a.gy16 ? 2.0 : 4.0) * 32.0 +
+                              (pass == 2 ? (a.xn16 ? 2.0 : 4.0) * 32.0 + (a.gu16 ? 2.0 : 4.0) * 32.0 + (fused_ ? (a.gx16 ? 2.0 : 4.0) * 32.0 : 0.0) +
                                                            (a.out_bf16 ? 2.0 : 4.0) * (lean ? 128.0 : 256.0)
                                                      : 0.0));
   ProfScope prof(pass == 1 ? (a.bf16 ? "convnext32_bwd_kernel<1,true>" : "convnext32_bwd_kernel<1,false>")

@@ -279,9 +279,14 @@ int launch_pro_bwd_adain(const void* u, int uh, const void* x, int xh, int B, in
                          int accumulate, float* dgb, float* dalpha, int hw, hipStream_t st, const void* dsrc = nullptr);
 int launch_adain_stats(const double* part, int nseg, int rows, int T, float eps, float* mean, float* rstd,
                        hipStream_t st);
+// plain casts between an fp32 tensor and a two-byte one (test aids of the block entry point)
+int launch_cast_f32_to_16(const float* x, size_t n, void* y16, hipStream_t st);
+int launch_cast_16_to_f32(const void* x16, size_t n, float* y, hipStream_t st);
+bool chan_ln32_eligible(int B, int C, int T, int relu);  // the one-thread-per-column form (the only one with two-byte tensors)
+// h16 bits: 1 = x, 2 = dy, 4 = dx are bf16 tensors
 int launch_chan_ln_bwd(const float* x, const float* dy, const float* y, int B, int C, int T, float eps, int ada,
                        const float* w, const float* gb, int relu, const float* out_mask, float* dx, int accumulate,
-                       float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st);
+                       float* mu_tmp, float* r_tmp, float* dgb, float* dw, float* db, hipStream_t st, int h16 = 0);
 int launch_grn_bwd(const double* part, int nseg, const float* gamma, const float* ds, int B, int C4, float* coef,
                    float* dgamma, hipStream_t st);
 int launch_act_fwd(int kind, const float* x, const float* alpha, int B, int C, int T, float* y, hipStream_t st);
@@ -292,7 +297,8 @@ int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, 
                       hipStream_t st);
 size_t dwconv_bwd_scratch_floats(int B, int C, int T, int K);
 int launch_dwconv_bwd(const float* x, const float* dy, const float* w, int B, int C, int T, int K, int pad, float* dx,
-                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src = nullptr);
+                      int accumulate, float* dw, float* db, float* scratch, hipStream_t st, const float* dx_src = nullptr,
+                      int x16 = 0, int dy16 = 0);  // x16 / dy16: bf16 tensors (weight-gradient part only: dx == nullptr)
 int launch_bn_eval_fwd(const float* x, const float* w, const float* b, const float* rm, const float* rv, float eps,
                        int B, int C, int T, float* y, hipStream_t st);
 int launch_bn_eval_bwd(const float* x, const float* dy, const float* w, const float* rm, const float* rv, float eps,

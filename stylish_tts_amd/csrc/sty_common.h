@@ -350,6 +350,10 @@ struct Cnx32BwdArgs {       // convnext_bwd.hip
   // that the three neighbours of every owned column's gU are in its own LDS; ntiles = convnext32_bwd_ntiles(T, 1).
   float* gx = nullptr;
   int xn16 = 0;                 // xn is written as bf16 [B][32][T] (the B operand of the dW1 GEMM, rounded where it is stored)
+  // two-byte gradients of the chain (round 5; autocast keeps this residual stream's gradient in bf16): gy is a bf16 tensor /
+  // gx (fused form only) and gu are written as bf16 -- each value rounded once, where it is stored
+  int gy16 = 0, gx16 = 0, gu16 = 0;
+  int x16 = 0;                  // x is a bf16 tensor
 };
 constexpr int CNX_BWD_FUSED_STRIDE = 248;
 int convnext32_bwd_ntiles(int T, int fused);
@@ -528,6 +532,8 @@ template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
 __device__ __forceinline__ float sty_dpp(float src) {  // masked-out / out-of-row lanes read 0
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, BANK_MASK, BOUND));
 }
+// the value of the other lane of this lane's pair (lane ^ 1): one v_mov_b32 with quad_perm:[1,0,3,2], no LDS crossbar trip
+__device__ __forceinline__ float sty_pair_swap(float v) { return sty_dpp<0xB1, 0xf, 0xf, false>(v); }
 __device__ __forceinline__ float sty_half_sum_to_lane31(float v) {
   float t = v + sty_dpp<0x111, 0xf, 0xf, true>(v);  // row_shr:1
   t += sty_dpp<0x112, 0xf, 0xf, true>(v);           // row_shr:2

@@ -254,6 +254,21 @@ struct Trainer {
     half_.insert(p);
     return p;
   }
+  // ---- two-byte GRADIENTS of the 32-channel ConvNeXt chain (round 5) ----
+  // Under autocast the chain's residual stream is a bf16 tensor and so is its gradient (conv_next.py:80-93).  g16_ok holds the
+  // activations whose PRODUCER reads its output gradient as bf16 (a fused lean ConvNeXt32 block, the long-row LayerNorm(32));
+  // the consumer that is the first -- in this graph the only -- writer of such an activation's gradient (the next block's fused
+  // input-gradient epilogue, the closing LayerNorm's backward) then takes a bf16 buffer (tagged in half_) and rounds each value
+  // once, where it stores it.  G / Gw refuse such a buffer: nothing accumulates into it.
+  std::unordered_set<const float*> g16_ok;
+  bool grad16_env = getenv("STY_NO_GRAD16") == nullptr && getenv("STY_NO_CNX_GX") == nullptr;
+  bool grad16_on() const { return grad16_env && act16_on(); }
+  // the gradient buffer of `act` for a consumer that can read a two-byte one
+  float* G16(const float* act, size_t n) {
+    auto it = gmap.find(act);
+    if (it != gmap.end() && is16(it->second)) return it->second;
+    return G(act, n);
+  }
   // gradient buffer of an activation (zero-filled on first request)
   // Deferred LeakyReLU gates (style encoder): `ungated` holds activations a whose gradient buffer still lacks the factor
   // lrelu'(a) -- the input-gradient conv of a LeakyReLU-prologue conv wrote its raw output there (conv2d_bwd).  The next
@@ -275,6 +290,10 @@ struct Trainer {
   float* G(const float* act, size_t n, bool raw = false) {  // raw: the caller deals with a deferred gate itself
     if (!raw && !ungated.empty()) gate_flush(act);
     auto it = gmap.find(act);
+    if (it != gmap.end() && is16(it->second)) {
+      set_error("a two-byte gradient buffer reached a consumer without a two-byte form");
+      rc = STY_ESTATE;
+    }
     if (it != gmap.end()) return side_cow(act, it->second, n);
     float* g = take<float>(n);
     if (live()) {
@@ -289,6 +308,10 @@ struct Trainer {
   float* Gw(const float* act, size_t n, int& acc) {
     if (!ungated.empty()) gate_flush(act);
     auto it = gmap.find(act);
+    if (it != gmap.end() && is16(it->second)) {
+      set_error("a two-byte gradient buffer reached a second writer");
+      rc = STY_ESTATE;
+    }
     if (it != gmap.end()) {
       acc = 1;
       return side_cow(act, it->second, n);
@@ -573,17 +596,28 @@ struct Trainer {
     const float* gbl = fc ? gbp(*fc) : nullptr;
     float* dgl = fc ? dgbp(*fc) : nullptr;
     if (live()) chk(launch_chan_layernorm(x, y, B, C, Tt, eps, fc ? 1 : 0, w, bvec, gbl, relu, omask, st));
+    const bool ln32 = grad16_on() && chan_ln32_eligible(B, C, Tt, relu);
+    if (ln32) g16_ok.insert(y);
     tape.push_back([=]() {
-      float* gY = G(y, (size_t)B * C * Tt);
-      int acc = 1;
-      float* gX = Gw(x, (size_t)B * C * Tt, acc);
+      const size_t nel = (size_t)B * C * Tt;
+      float* gY = ln32 ? G16(y, nel) : G(y, nel);
+      int acc = 1, h16 = is16(gY) ? 2 : 0;
+      float* gX;
+      if (ln32 && g16_ok.count(x) && !gmap.count(x)) {  // the closing LayerNorm of a two-byte chain: first and only writer
+        gX = take_act(nel, true);
+        gmap[x] = gX;
+        acc = 0;
+        h16 |= 4;
+      } else {
+        gX = Gw(x, nel, acc);
+      }
       const size_t mark = ws.off;
       float* mu = take<float>((size_t)B * Tt);
       float* r = take<float>((size_t)B * Tt);
       float* dw = fc ? nullptr : PG(w, C);
       float* db = fc ? nullptr : PG(bvec, C);
       if (live())
-        chk(launch_chan_ln_bwd(x, gY, y, B, C, Tt, eps, fc ? 1 : 0, w, gbl, relu, omask, gX, acc, mu, r, dgl, dw, db, st));
+        chk(launch_chan_ln_bwd(x, gY, y, B, C, Tt, eps, fc ? 1 : 0, w, gbl, relu, omask, gX, acc, mu, r, dgl, dw, db, st, h16));
       ws.off = mark;
     });
     return y;
@@ -715,6 +749,7 @@ struct Trainer {
       chk(launch_grn_finalize(part, nt, c.grn_gamma, B, 128, scale, st));
       chk(launch_convnext32(a, B, 2, st));
     }
+    if (lean && grad16_on()) g16_ok.insert(y);  // the lean backward reads gY as bf16 when its consumer wrote it so
     const float* gbl = gbp(c.norm);
     float* dgl = dgbp(c.norm);
     {
@@ -725,7 +760,8 @@ struct Trainer {
       wg_need(p2n);
     }
     tape.push_back([=]() {
-      float* gY = G(y, n32);
+      float* gY = lean ? G16(y, n32) : G(y, n32);
+      const bool gy16 = is16(gY);
       const bool side = side_ready();
       // y = ... + x: the output gradient becomes (or is added to) the input's gradient.  With the weight gradients on
       // the side stream gY stays read-only: the input gradient goes to a buffer of its own (gX = gY + dwconv^T(gU),
@@ -736,9 +772,18 @@ struct Trainer {
       // itself, out of place, on overlapping tiles (convnext_bwd.hip) -- no dwconv7_bwd_dx pass over gU, gY and gX
       const bool fuse_gx = !gmap.count(x) && Tt % 4 == 0 && getenv("STY_NO_CNX_GX") == nullptr;
       const bool xn16 = lean && getenv("STY_NO_CNX_XN16") == nullptr;  // xn (an MFMA operand of dW1 only) as bf16
+      // two-byte gX: x's producer reads it as bf16 (g16_ok) and this is its first writer; two-byte gU: its one reader then is
+      // the depthwise weight-gradient kernel
+      const bool gx16 = fuse_gx && lean && grad16_on() && g16_ok.count(x) != 0;
+      const bool gu16 = fuse_gx && lean && grad16_on();
+      if (gy16 && !fuse_gx) {
+        set_error("convnext32: a two-byte output gradient needs the fused input-gradient path");
+        rc = STY_ESTATE;
+        return;
+      }
       if (!gmap.count(x)) {
         if (side || fuse_gx) {
-          gX = take<float>(n32);
+          gX = take_act(n32, gx16);
           gmap[x] = gX;
           gx_src = gY;
         } else {
@@ -759,7 +804,7 @@ struct Trainer {
       float* ds_p = (side || deferring()) && lean ? take<float>((size_t)B * 128) : nullptr;
       float* coef_p = (side || deferring()) && lean ? take<float>((size_t)B * 128) : nullptr;
       float* xn_p = side ? take<float>(xn16 ? n32 / 2 : n32) : nullptr;
-      float* gu_p = side ? take<float>(n32) : nullptr;
+      float* gu_p = side ? take<float>(gu16 ? n32 / 2 : n32) : nullptr;
       float* dsc_p = side ? take<float>(dwconv_bwd_scratch_floats(B, 32, Tt, 7)) : nullptr;
       const size_t mark = ws.off;
       double* pds = take<double>((size_t)B * 128 * nt_b);
@@ -769,7 +814,7 @@ struct Trainer {
       float* hs = lean ? nullptr : (side ? hs_p : take<float>(n128));
       float* gh0 = side ? gh0_p : take<float>(lean ? n128 / 2 : n128);
       float* xn = side ? xn_p : take<float>(xn16 ? n32 / 2 : n32);
-      float* gu = side ? gu_p : take<float>(n32);
+      float* gu = side ? gu_p : take<float>(gu16 ? n32 / 2 : n32);
       Cnx32BwdArgs a;
       a.x = x;
       a.gy = gY;
@@ -793,6 +838,9 @@ struct Trainer {
       a.ntiles = nt_b;
       a.gx = fuse_gx ? gX : nullptr;
       a.xn16 = xn16;
+      a.gy16 = gy16;
+      a.gx16 = gx16;
+      a.gu16 = gu16;
       a.bf16 = m->topts.compute_bf16;
       a.wfrag = wfrag;
       // bf16 mode: h s and gH0 leave the kernel as bf16 and feed wgrad_cnx_kernel (T % 8: its 8-sample groups)
@@ -817,7 +865,7 @@ struct Trainer {
         float* pM = take<float>((size_t)B * SB * (4096 + 32));
         a.lean = 1;
         if (live()) {
-          chk(launch_wgrad_cnx(1, h16, gY, B, Tt, pM, 1, st, 1));
+          chk(launch_wgrad_cnx(1, h16, gY, B, Tt, pM, 1, st, 1, gy16));
           chk(launch_cnx_m_finish(pM, B, SB, c.w2_raw, scale, ds, frozen ? nullptr : gw2, frozen ? nullptr : gb2, st));
           chk(launch_grn_bwd(part, nt, c.grn_gamma, ds, B, 128, coef, PG(c.grn_gamma, 128), st));
           chk(launch_convnext32_bwd(a, B, 2, st));
@@ -861,7 +909,7 @@ struct Trainer {
             chk(launch_conv1d_wgrad(f2, gY, nullptr, 1.0f, gw2, p2, gb2, nullptr, s2));
             chk(launch_conv1d_wgrad(f1, gh0, nullptr, 1.0f, gw1, p1, gb1, nullptr, s2));
           }
-          chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, s2));
+          chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, s2, nullptr, 0, gu16));
         });
         // input gradient of the depthwise conv on the main stream (unless the fused kernel wrote it)
         if (live() && !fuse_gx) chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, nullptr, nullptr, nullptr, st, gx_src));
@@ -879,7 +927,7 @@ struct Trainer {
         }
         // depthwise conv backward from gU; note gX may alias gY, which every kernel above has finished reading
         if (fuse_gx)
-          chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, st));
+          chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, nullptr, 0, gdw, gdb, dsc, st, nullptr, 0, gu16));
         else
           chk(launch_dwconv_bwd(x, gu, dww, B, 32, Tt, 7, 3, gX, 1, gdw, gdb, dsc, st));
       }
@@ -2156,6 +2204,7 @@ struct Trainer {
     tw_g.clear();
     nograd.clear();
     half_.clear();
+    g16_ok.clear();
     adain_of.clear();
     scratch_param_n = 1 << 20;
     scratch_param = take<float>(scratch_param_n);
@@ -2650,10 +2699,20 @@ int trainer_block_fwd_bwd(Trainer* t, int kind, const void* blk, int B, int C, i
   t->side_begin();
   t->d_style_out = d_style;
   t->fc_bwd_done = false;
-  float* gO = t->G(out, n);
-  if (t->live() && gy) {
-    hipError_t e = hipMemcpyAsync(gO, gy, n * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) t->rc = hip_fail(e, "block seed copy");
+  // STY_BLOCK_G16=1 (test aid): the block sits inside a two-byte gradient chain -- its output gradient arrives as bf16 (gy
+  // rounded here) and its input's producer takes a bf16 gradient back (converted to fp32 for the caller below)
+  const bool g16 = kind == 0 && getenv("STY_BLOCK_G16") != nullptr && t->grad16_on() && t->g16_ok.count(out) != 0;
+  if (g16) {
+    float* gO16 = t->take_act(n, true);
+    t->gmap[out] = gO16;
+    t->g16_ok.insert(xin);
+    if (t->live() && gy) t->chk(launch_cast_f32_to_16(gy, n, gO16, st));
+  } else {
+    float* gO = t->G(out, n);
+    if (t->live() && gy) {
+      hipError_t e = hipMemcpyAsync(gO, gy, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) t->rc = hip_fail(e, "block seed copy");
+    }
   }
   for (auto it = t->tape.rbegin(); it != t->tape.rend(); ++it) {
     (*it)();
@@ -2662,9 +2721,13 @@ int trainer_block_fwd_bwd(Trainer* t, int kind, const void* blk, int B, int C, i
   t->side_join();
   if (t->rc == STY_OK) t->style_fc_backward();
   if (t->live() && gx) {
-    float* g = t->G(xin, n);
-    hipError_t e = hipMemcpyAsync(gx, g, n * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) t->rc = hip_fail(e, "block input-gradient copy");
+    float* g = g16 ? t->G16(xin, n) : t->G(xin, n);
+    if (t->is16(g)) {
+      t->chk(launch_cast_16_to_f32(g, n, gx, st));
+    } else {
+      hipError_t e = hipMemcpyAsync(gx, g, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) t->rc = hip_fail(e, "block input-gradient copy");
+    }
   }
   if (need) {
     *need = align_up(t->peak, 256) + (64 << 20);

@@ -1134,7 +1134,8 @@ namespace sty {
 // 2 x 128 + 4 x 32 bytes per position instead of 4 x 160 (wgrad_k1_kernel<4,1|1,4>: 2.9-3.4 TB/s on 0.8 GB).
 // T % 8 == 0 (the caller checks): an 8-sample group is inside the row or past its end, never across.
 // =====================================================================================================================
-// N16 (round 5, with !XWIDE): the narrow tensor (xn of the lean ConvNeXt32 backward) is bf16 too -- 16-byte loads straight to LDS
+// N16 (round 5): the narrow tensor (xn of the lean ConvNeXt32 backward; gY of a two-byte gradient chain) is bf16 too -- 16-byte
+// loads straight to LDS
 template <bool XWIDE, bool N16 = false>  // XWIDE: x is the bf16 [B][128][T] tensor and G the fp32 [B][32][T] one; else the other way round
 // SB > 0: per-utterance mode -- workgroup z handles utterance z / SB only (chunks z % SB, z % SB + SB, ...), so that the SB
 // partial planes of an utterance sum to ITS 128 x 32 product (the lean ConvNeXt32 backward needs M_b = gY_b h_b^T per b).
@@ -1198,7 +1199,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      if (XWIDE && want_bias)
+      if constexpr (N16) {
+        if (XWIDE && want_bias) {  // (the bf16 gradient's own values: what the GEMM sums)
+          const uint4 u = __builtin_bit_cast(uint4, nh[m]);
+          bsum[m] += ((sty_bf_lo(u.x) + sty_bf_hi(u.x)) + (sty_bf_lo(u.y) + sty_bf_hi(u.y))) +
+                     ((sty_bf_lo(u.z) + sty_bf_hi(u.z)) + (sty_bf_lo(u.w) + sty_bf_hi(u.w)));
+        }
+      } else if (XWIDE && want_bias)
         bsum[m] += ((nv[m][0] + nv[m][1]) + (nv[m][2] + nv[m][3])) + ((nv[m][4] + nv[m][5]) + (nv[m][6] + nv[m][7]));
       if constexpr (N16)
         *reinterpret_cast<float4*>(ns_ + (r0 + 16 * m) * WB_PITCH + g8) = nh[m];
@@ -1267,10 +1274,6 @@ int wgrad_cnx_per_b(int B, int T) {  // planes per utterance in the per-utteranc
 }
 int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, int T, float* partial, int want_bias,
                      hipStream_t st, int per_b, int narrow16) {
-  if (narrow16 && x_wide) {
-    set_error("wgrad_cnx: a two-byte narrow tensor only in the dW1 form (x narrow)");
-    return STY_EINVAL;
-  }
   if (T % 8) {
     set_error("wgrad_cnx: T %% 8 != 0");
     return STY_EINVAL;
@@ -1280,7 +1283,10 @@ int launch_wgrad_cnx(int x_wide, const void* wide, const float* narrow, int B, i
   const size_t lds = (size_t)160 * WB_PITCH * sizeof(__bf16);
   ProfScope prof(x_wide ? "wgrad_cnx_kernel<true>" : "wgrad_cnx_kernel<false>", 2.0 * 128 * 32 * (double)B * T,
                  (double)B * T * (128 * 2 + 32 * (narrow16 ? 2 : 4)), st);
-  if (x_wide)
+  if (x_wide && narrow16)
+    hipLaunchKernelGGL((wgrad_cnx_kernel<true, true>), dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide),
+                       narrow, B, T, nsplit, cpb, partial, want_bias, SB);
+  else if (x_wide)
     hipLaunchKernelGGL(wgrad_cnx_kernel<true>, dim3(1, 1, nsplit), dim3(256), lds, st, static_cast<const __bf16*>(wide), narrow, B,
                        T, nsplit, cpb, partial, want_bias, SB);
   else if (narrow16)

@@ -441,7 +441,10 @@ def test_c3_backward_full_size_under_a_well_conditioned_loss():
     lines = [f"c3 predictor backward under d<audio, sign(audio)/N>, B = {B}, T = {w['T']}, L = {w['L']}: HIP vs the fp32 oracle's autograd"]
     bad = []
     for mode, tol_e, tol_c in (("fp32", 3e-2, 1e-3), ("bf16", 0.25, 3e-2)):
-        tol_n = 1.0 if mode == "fp32" else 5e-2
+        # (bf16 norm floor 1e-1, as GATE16_FLOOR of the step test: for the text encoder's FFN weights the yardstick itself -- the
+        # bf16-rule oracle on 8 utterances -- read 4.95e-2 with one rounding rule and 2.10e-2 with the next (round 5, two-byte
+        # chain gradients), the product 7.0e-2 and 5.9e-2: a floor of 5e-2 under 2 x a yardstick that moves by 2.4x is a coin)
+        tol_n = 1.0 if mode == "fp32" else 1e-1
         m = S.SpeechPredictor()
         m.load_state_dict({k: v.detach() for k, v in P.items()}, strict=False)
         m = m.to(DEV).enable_training().set_train_opts(compute_bf16=(mode == "bf16"))
