@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int t = t0 + tw + n * 32 + l31;
-      hoff[n] = t < T ? (4 * hi * T + t) * 2 : 0x7FFFFF00;  // columns past the end: outside the descriptor, dropped
+      // paired dword stores (as the lean backward's gH0): the even lane of a pair stores (row r: columns t, t + 1), the odd lane
+      // (row r + 1: columns t - 1, t); T is even here (keep_h: the lean backward's T % 8 == 0), a pair is inside the row or past it
+      hoff[n] = t < T ? (4 * hi * T + ((l31 & 1) ? T + t - 1 : t)) * 2 : 0x7FFFFF00;  // past the end: outside the descriptor, dropped
     }
   }
   f32x16 acc2[2];
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
     // rare one with it (the kernel had 221 basic blocks, a diamond per element; pass 1 1.14 -> 1.08 ms per step, pass 2 unchanged)
     auto elem_loop = [&](auto slow_c) {
       const bool SLOWP = slow_c;
+      float ve[2] = {0.f, 0.f};
   #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -198,9 +201,15 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
           if (PASS2) {
             if constexpr (BF) {
               if (keep_h) {  // h (before the GRN scale) as bf16 for the backward's M = gY h^T (wave-uniform branch)
-                const bf16x8 pk = sty_pack_bf16(v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
-                const int srow = (j * 32 + (r & 3) + 8 * (r >> 2)) * T * 2;  // wave-uniform part of the row offset
-                __builtin_amdgcn_raw_buffer_store_b16((short)(__builtin_bit_cast(uint4, pk).x & 0xffffu), r_h16, hoff[n], srow, 0);
+                if ((r & 1) == 0) {
+                  ve[n] = v;
+                } else {
+                  const bool oddl = l31 & 1;
+                  const float got = sty_pair_swap(oddl ? ve[n] : v);
+                  const unsigned two = oddl ? sty_pack2_bf16(got, v) : sty_pack2_bf16(ve[n], got);
+                  const int srow = (j * 32 + ((r - 1) & 3) + 8 * ((r - 1) >> 2)) * T * 2;  // wave-uniform part of the row offset
+                  __builtin_amdgcn_raw_buffer_store_b32(two, r_h16, hoff[n], srow, 0);
+                }
               }
             }
             h[n][r] = v * sc;
@@ -277,6 +286,10 @@ __global__ __launch_bounds__(256, 2) void convnext32_kernel(Cnx32Args a) {
 int convnext32_ntiles(int T) { return cdiv(T, CNX_TT); }
 
 int launch_convnext32(const Cnx32Args& a, int B, int pass, hipStream_t st) {
+  if (a.h16 && a.T % 2) {
+    set_error("convnext32: h16 (the bf16 copy of h for the lean backward) needs an even T: it is stored in column pairs");
+    return STY_EINVAL;
+  }
   dim3 grid(a.ntiles, B);
   // per position: dw 2*7*32, pw1 2*32*128, pw2 2*128*32 (pass 2 only); x read once (+ once more as residual in
   // pass 2, an L2 hit counted as HBM here), y written once
