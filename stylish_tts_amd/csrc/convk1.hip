@@ -237,8 +237,11 @@ bool convk1_eligible(const ConvArgs& a) {
   if (a.T % 4 || a.w.CinP % G_KC || a.w.CinP < 64 || a.w.CoutP < 64) return false;
   // one buffer descriptor over the whole tensor, 31-bit byte offsets
   if ((size_t)a.B * a.w.CinP * a.T * 4 >= (size_t)1 << 31 || (size_t)a.B * a.w.CoutP * a.T * 4 >= (size_t)1 << 31) return false;
+  // Threshold: 24 tiles (round 5; 256 before).  Below a chip's worth of tiles the kernel still wins on the latency chains: c5-bf16
+  // (100-tile pointwise convs of the stage-A ConvNeXt blocks) 5.59 -> 5.03 ms, the c3 step (the text encoder's 25-tile q / k / v / o
+  // convs) 46.59 -> 46.32 ms; 96 and 48 help c5 alike and c3 less (profiles/r05_ab_env.txt block 15).
   const char* mt = getenv("STY_CONVK1_MIN_TILES");  // read per call: the parity tests lower it for small shapes
-  return (long)cdiv(a.B * a.T, 128) * cdiv(a.w.CoutP, 128) >= (mt ? atoi(mt) : 256);
+  return (long)cdiv(a.B * a.T, 128) * cdiv(a.w.CoutP, 128) >= (mt ? atoi(mt) : 24);
 }
 
 template <int PRO>
