@@ -760,7 +760,11 @@ bool convp16_eligible(const ConvArgs& a) {
   if (q_lds_bytes(a) > 160 * 1024) return false;
   const int co = 64 * q_mtw(a);
   const char* mt = getenv("STY_CONVP16_MIN_TILES");  // read per call: the parity tests lower it for small shapes
-  const int min_tiles = mt ? atoi(mt) : 256;  // one tile per CU at least (c3: 88.3 ms at 512, 87.2 at 256, 87.4 at 128)
+  // (round 2, c3: 88.3 ms at 512 tiles, 87.2 at 256, 87.4 at 128.)  Round 5: 48 -- the text encoder's k = 5 / k = 3 convs with 64 or
+  // 128 tiles of one utterance each leave the tiled kernel: 46.86 ms at 256, 46.45 at 128, 46.25 at 64, 46.42 at 32
+  // (profiles/r05_ab_env.txt block 16; 48 and not 32: no faster, and see DESIGN.md section 7 item 10 on what the full-size bf16
+  // gradient gate read at 32)
+  const int min_tiles = mt ? atoi(mt) : 48;
   return (long)cdiv(a.T, Q_TT) * a.B * cdiv(a.w.CoutP, co) >= min_tiles;
 }
 

@@ -1851,7 +1851,8 @@ def test_persistent_conv32_vs_torch(shape, compute, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(2, 37, 80, 5, 2, 203), (3, 128, 130, 1, 1, 64), (2, 512, 64, 3, 1, 37), (2, 96, 200, 3, 1, 300),
-                                   (2, 64, 96, 3, 1, 1000), (3, 130, 33, 5, 1, 257), (48, 240, 80, 3, 1, 1500)])
+                                   (2, 64, 96, 3, 1, 1000), (3, 130, 33, 5, 1, 257), (48, 240, 80, 3, 1, 1500),
+                                   (32, 128, 512, 3, 1, 100), (32, 512, 128, 3, 1, 100), (32, 128, 128, 5, 1, 100)])
 def test_persistent_conv16_vs_torch(shape, monkeypatch):
     """convp16_kernel (bf16 compute mode, Cin >= 64: producer / consumer waves over 32-channel chunks, bf16 LDS tiles)
     through the unit entry points: forward and input gradient vs float64 on the same bf16-rounded operands.  Small shapes
