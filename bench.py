@@ -119,6 +119,20 @@ def build_model(device):
     return m.to(device), se.to(device), P
 
 
+def _inst_ok(family, rocprof_name):
+    """convp16_kernel<MTW, PRO, RELU, FLAT, X16> has two kinds of instantiation that the library reports as two families: the
+    padded-flat 2-D convs of the style encoder (FLAT = true: `convp16_kernel<2,true>`) and the 1-D convs of the decoder / text
+    encoder (FLAT = false: `convp16_kernel<2,true,1d>`); everything else: any instantiation of the family."""
+    import re
+    if not family.startswith("convp16_kernel<"):
+        return True
+    m = re.search(r"convp16_kernel<([^>]*)>", re.sub(r"\s+", "", rocprof_name))
+    if not m:
+        return True
+    args = m.group(1).split(",")
+    return len(args) < 4 or (args[3] == "false") == family.rstrip(">").endswith(",1d")
+
+
 def pmc_traffic(family, workload):
     """HBM bytes per launch of a kernel from the committed PMC passes of this same command (tools/profile_round.sh ->
     profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  Counters cannot be
@@ -128,6 +142,7 @@ def pmc_traffic(family, workload):
     key = re.sub(r"\s+", "", family)
     base, _, targs = key.partition("<")
     first = targs.split(",")[0].rstrip(">")
+    key = key.replace(",1d>", ">")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
@@ -141,7 +156,7 @@ def pmc_traffic(family, workload):
             if key in kk:
                 return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(f, ROOT)
             m = re.search(r"(?:sty::)?" + re.escape(base) + r"<([^,>]+)", kk)
-            if m and m.group(1) == first:
+            if m and m.group(1) == first and _inst_ok(family, kk):
                 tot += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
                 n += v["launches"]
         if n:
@@ -171,7 +186,7 @@ def rocprof_avg_us(family, workload):
                 continue
             kk = re.sub(r"\s+", "", parts[4])
             m = re.search(r"(?:sty::)?" + re.escape(base) + (r"<([^,>]+)" if targs else r"\b"), kk)
-            if m and (not targs or m.group(1) == first):
+            if m and (not targs or m.group(1) == first) and _inst_ok(family, kk):
                 tot += float(parts[1])
                 n += int(parts[0])
         if n:

@@ -792,7 +792,9 @@ static int launch_q(const ConvArgs& a, hipStream_t st) {
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
   char fam[48];
-  snprintf(fam, sizeof(fam), "convp16_kernel<%d,true>", MTW);
+  // two families, as the two kinds of instantiation are two kernels: the padded-flat 2-D convs (FLAT: the style encoder) and
+  // the 1-D convs (decoder, text encoder: launches of 50-500 tiles since round 5)
+  snprintf(fam, sizeof(fam), a.flatW ? "convp16_kernel<%d,true>" : "convp16_kernel<%d,true,1d>", MTW);
   ProfScope prof(fam, flops, bytes, st, detail);
   const char* de = getenv("STY_Q_DBG");  // timing experiments only (wrong results): 1 no input loads, 2 no weight path,
                                          // 4 no input commit, 8 no drain, 16 no MFMA loop, 32 no accumulator spill
