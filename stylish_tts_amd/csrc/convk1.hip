@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned g_pk(float a, float b) {
   return __builtin_bit_cast(unsigned, r);
 }
 
+// RELU: the output stage's activation -- 0 none, 1 ReLU, 2 Snake (ConvArgs::act_alpha), 3 exact GELU
 template <int PRO, int RELU>
 __global__ __launch_bounds__(256, 2) void convk1_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles, int per_xcd) {
   extern __shared__ __attribute__((aligned(16))) __bf16 g_lds[];  // [2][G_KC][G_PITCH]
@@ -207,12 +208,19 @@ __global__ __launch_bounds__(256, 2) void convk1_kernel(ConvArgs a, int tiles_pe
         const float4 sv = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * c4);
         const float bi = a.w.bias ? a.w.bias[co] : 0.f;
         float v[4] = {sv.x + bi, sv.y + bi, sv.z + bi, sv.w + bi};
+        float al = 1.f, ral = 1.f;
+        if (RELU == 2) {  // Snake epilogue (inference: pwconv1 of the generic ConvNeXt blocks), per-channel alpha
+          al = a.act_alpha[co];
+          ral = 1.0f / al;
+        }
         float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.residual) res = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rres, yo, 0, 0));
         const float rr[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (RELU == 1) v[e] = fmaxf(v[e], 0.f);
+          if (RELU == 2) v[e] = sty_snake(v[e], al, ral);
+          if (RELU == 3) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));  // exact GELU
           v[e] *= a.out_scale;
           if (a.out_mask && !post) v[e] *= om[e];
           v[e] += rr[e];
@@ -232,7 +240,7 @@ int convp16_frags(const ConvArgs& a, hipStream_t st, const void** out);  // conv
 bool convk1_eligible(const ConvArgs& a) {
   if (!a.bf16 || getenv("STY_NO_CONVK1")) return false;  // (read per call: the parity tests toggle it)
   if (a.w.K != 1 || a.flatW || a.nsrc != 1 || a.in_shuffle > 1 || a.shuffle != 1 || a.ln_out || a.Tin || a.y_split) return false;
-  if (!(a.act == ACT_NONE || a.act == ACT_RELU)) return false;
+  if (!(a.act == ACT_NONE || a.act == ACT_RELU || (a.act == ACT_SNAKE && a.act_alpha) || a.act == ACT_GELU)) return false;
   if (!(a.pro == PRO_NONE || a.pro == PRO_MASK || a.pro == PRO_SCALE)) return false;
   if (a.T % 4 || a.w.CinP % G_KC || a.w.CinP < 64 || a.w.CoutP < 64) return false;
   // one buffer descriptor over the whole tensor, 31-bit byte offsets
@@ -248,6 +256,10 @@ template <int PRO>
 static void g_launch(const ConvArgs& a, dim3 grid, size_t lds, int tpr, int ncot, int ntiles, int per, hipStream_t st) {
   if (a.act == ACT_RELU)
     hipLaunchKernelGGL((convk1_kernel<PRO, 1>), grid, dim3(256), lds, st, a, tpr, ncot, ntiles, per);
+  else if (a.act == ACT_SNAKE)
+    hipLaunchKernelGGL((convk1_kernel<PRO, 2>), grid, dim3(256), lds, st, a, tpr, ncot, ntiles, per);
+  else if (a.act == ACT_GELU)
+    hipLaunchKernelGGL((convk1_kernel<PRO, 3>), grid, dim3(256), lds, st, a, tpr, ncot, ntiles, per);
   else
     hipLaunchKernelGGL((convk1_kernel<PRO, 0>), grid, dim3(256), lds, st, a, tpr, ncot, ntiles, per);
 }

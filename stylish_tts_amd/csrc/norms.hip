@@ -275,39 +275,69 @@ int launch_chan_layernorm(const float* x, float* y, int B, int C, int T, float e
 }
 
 // ---- depthwise conv k (zero 'same' padding) fused with AdaLN over channels (conv_next.py:82-84) ----
-// block = 64 time columns x all C channels; u tile in LDS, stats per column, normalised write-out.
+// block = TT time columns x all C channels; u tile in LDS, stats per column, normalised write-out.
+// KT > 0: the tap count at compile time (7: every ConvNeXt block of the path).  Round 5: with a run-time K the tap loop was one
+// load -> wait -> fma per tap and channel -- 224 exposed load latencies per thread, 59 us per launch on c5's 6 MB tensors at
+// under one workgroup per CU; unrolled, a channel's taps are in flight together and two channels overlap.  The column
+// statistics are summed by all 256 threads (per-group partials of the mean, then of the centred squares: still two passes)
+// instead of by TT threads walking all C channels twice.
+template <int KT>
 __global__ __launch_bounds__(256) void dwconv_adaln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int C, int T, int K,
                                                            float eps, const float* __restrict__ gb,
                                                            float* __restrict__ y, int TT) {
-  extern __shared__ __attribute__((aligned(16))) float u[];  // [C][TT] then stats [2][TT]
+  extern __shared__ __attribute__((aligned(16))) float u[];  // [C][TT], stats [2][TT], group partials [256]
   float* smean = u + (size_t)C * TT;
   float* srstd = smean + TT;
+  float* part = srstd + TT;
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
   const int pad = K / 2;
   const int tid = threadIdx.x;
   const int lane = tid % TT, grp = tid / TT, ngrp = 256 / TT;
   const int t = t0 + lane;
+  float psum = 0.f;
   for (int c = grp; c < C; c += ngrp) {
     const float* p = x + ((size_t)b * C + c) * T;
     float acc = bias[c];
-    for (int k = 0; k < K; ++k) {
-      const int tt = t - pad + k;
-      if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+    if constexpr (KT > 0) {
+      float xv[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int tt = t - KT / 2 + k;
+        xv[k] = (tt >= 0 && tt < T) ? p[tt] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KT; ++k) acc = fmaf(w[c * KT + k], xv[k], acc);
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const int tt = t - pad + k;
+        if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+      }
     }
     u[c * TT + lane] = acc;
+    psum += acc;
   }
+  part[tid] = psum;
   __syncthreads();
   if (tid < TT) {
     float mean = 0.f;
-    for (int c = 0; c < C; ++c) mean += u[c * TT + tid];
-    mean /= (float)C;
-    float var = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float d = u[c * TT + tid] - mean;
-      var += d * d;
+    for (int g = 0; g < ngrp; ++g) mean += part[g * TT + tid];
+    smean[tid] = mean / (float)C;
+  }
+  __syncthreads();
+  {
+    const float mean = smean[lane];
+    float pv = 0.f;
+    for (int c = grp; c < C; c += ngrp) {
+      const float d = u[c * TT + lane] - mean;
+      pv = fmaf(d, d, pv);
     }
-    smean[tid] = mean;
+    part[tid] = pv;
+  }
+  __syncthreads();
+  if (tid < TT) {
+    float var = 0.f;
+    for (int g = 0; g < ngrp; ++g) var += part[g * TT + tid];
     srstd[tid] = 1.0f / sqrtf(var / (float)C + eps);
   }
   __syncthreads();
@@ -323,8 +353,11 @@ __global__ __launch_bounds__(256) void dwconv_adaln_kernel(const float* __restri
 int launch_dwconv_adaln(const float* x, const float* w, const float* bias, int B, int C, int T, int K, float eps,
                         const float* gb, float* y, hipStream_t st) {
   const int TT = C > 128 ? 32 : 64;
-  const size_t lds = ((size_t)C * TT + 2 * TT) * sizeof(float);
-  hipLaunchKernelGGL(dwconv_adaln_kernel, dim3(cdiv(T, TT), B), dim3(256), lds, st, x, w, bias, C, T, K, eps, gb, y, TT);
+  const size_t lds = ((size_t)C * TT + 2 * TT + 256) * sizeof(float);
+  if (K == 7)
+    hipLaunchKernelGGL(dwconv_adaln_kernel<7>, dim3(cdiv(T, TT), B), dim3(256), lds, st, x, w, bias, C, T, K, eps, gb, y, TT);
+  else
+    hipLaunchKernelGGL(dwconv_adaln_kernel<0>, dim3(cdiv(T, TT), B), dim3(256), lds, st, x, w, bias, C, T, K, eps, gb, y, TT);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
