@@ -897,12 +897,23 @@ struct Run {
     float* ph_alt = ws.take<float>((size_t)B * 32 * Tu);
     float* real = ws.take<float>((size_t)B * 32 * Tu);
     float* imag = ws.take<float>((size_t)B * 32 * Tu);
+    // The final LayerNorms in front of the k = 21 head convs: fused into the tiled kernel's prologue (rounds 1-4) where the
+    // persistent 32-channel kernel does not take the conv; where it does (round 5), a LayerNorm pass + the persistent kernel are
+    // faster than the fused tiled launch (c5-bf16: 121 us against ~35 + 40; the real / imag pair shares one pass)
+    ConvArgs head_probe = base(v.amp_output_conv, trunk, Tu, logamp);
+    const bool head32p = takes32p(head_probe) && getenv("STY_NO_HEAD32P") == nullptr;
+    float* lnbuf = head32p ? ws.take<float>((size_t)B * 32 * Tu) : nullptr;
     if (live()) {
       ConvArgs a = base(v.amp_output_conv, trunk, Tu, logamp);
-      a.pro = PRO_LN_AFFINE;
-      a.palpha = v.amp_fln_w;
-      a.pbeta = v.amp_fln_b;
-      a.ln_eps = 1e-6f;
+      if (head32p) {
+        chk(launch_chan_layernorm(trunk, lnbuf, B, 32, Tu, 1e-6f, 0, v.amp_fln_w, v.amp_fln_b, nullptr, 0, nullptr, st));
+        a.x[0] = lnbuf;
+      } else {
+        a.pro = PRO_LN_AFFINE;
+        a.palpha = v.amp_fln_w;
+        a.pbeta = v.amp_fln_b;
+        a.ln_eps = 1e-6f;
+      }
       conv(a);
       tap(io.tap_logamp, logamp, (size_t)B * 32 * Tu);
       ConvArgs p = base(v.phase_input_conv, trunk, Tu, ph);
@@ -924,10 +935,15 @@ struct Run {
     }
     if (live()) {
       ConvArgs r = base(v.real_conv, ph, Tu, real);
-      r.pro = PRO_LN_AFFINE;
-      r.palpha = v.phase_fln_w;
-      r.pbeta = v.phase_fln_b;
-      r.ln_eps = 1e-6f;
+      if (head32p) {
+        chk(launch_chan_layernorm(ph, lnbuf, B, 32, Tu, 1e-6f, 0, v.phase_fln_w, v.phase_fln_b, nullptr, 0, nullptr, st));
+        r.x[0] = lnbuf;
+      } else {
+        r.pro = PRO_LN_AFFINE;
+        r.palpha = v.phase_fln_w;
+        r.pbeta = v.phase_fln_b;
+        r.ln_eps = 1e-6f;
+      }
       conv(r);
       r.w = v.imag_conv;
       r.y = imag;
