@@ -1001,8 +1001,78 @@ __global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __re
   }
   y[((size_t)b * C + c) * T + t] = acc;
 }
+// Four consecutive outputs per thread, the K + 3 inputs they need read once into registers, taps unrolled (K <= MAXK)
+template <int MAXK>
+__global__ __launch_bounds__(256) void dwconv_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int C, int T, int K, int pad,
+                                                          float* __restrict__ y) {
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4, c = blockIdx.y, b = blockIdx.z;
+  if (t0 >= T) return;
+  const float* p = x + ((size_t)b * C + c) * T;
+  float wk[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) wk[k] = k < K ? w[c * K + k] : 0.f;
+  float g[MAXK + 3];
+#pragma unroll
+  for (int j = 0; j < MAXK + 3; ++j) {
+    const int tt = t0 - pad + j;
+    g[j] = (tt >= 0 && tt < T && j < K + 3) ? p[tt] : 0.f;
+  }
+  const float b0 = bias ? bias[c] : 0.f;
+  float acc[4] = {b0, b0, b0, b0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) acc[e] = fmaf(wk[k], g[e + k], acc[e]);  // x[t0 + e - pad + k]
+  const size_t o = ((size_t)b * C + c) * T + t0;
+  if (t0 + 3 < T && (o & 3) == 0) {
+    *reinterpret_cast<float4*>(y + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+    for (int e = 0; e < 4 && t0 + e < T; ++e) y[o + e] = acc[e];
+  }
+}
+// K = 7, pad = 3, T % 4 == 0 (the depthwise convs of the generic ConvNeXt blocks in the training graph): four outputs per thread
+// from three aligned 16-byte loads, threads over the flattened (row, group) list -- the forward twin of dwconv7_bwd_dx_kernel
+// below.  The one-output-per-thread kernel above walks its taps one exposed load at a time: 45 us per launch on c3's 17 MB tensors.
+__global__ __launch_bounds__(256) void dwconv7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int C, int T4, unsigned ngroups,
+                                                          float* __restrict__ y) {
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= ngroups) return;
+  const unsigned row = idx / (unsigned)T4;
+  const int q = (int)(idx - row * (unsigned)T4), c = (int)(row % (unsigned)C);
+  const float4* p4 = reinterpret_cast<const float4*>(x) + (size_t)row * T4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 a = q > 0 ? p4[q - 1] : z, b = p4[q], d = q + 1 < T4 ? p4[q + 1] : z;
+  const float g[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};  // x[4 q - 4 + j]
+  float wk[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) wk[k] = w[c * 7 + k];
+  const float b0 = bias ? bias[c] : 0.f;
+  float acc[4] = {b0, b0, b0, b0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[e] = fmaf(wk[k], g[e + 1 + k], acc[e]);  // x[t0 + e - 3 + k], taps in the order of the kernel above
+  reinterpret_cast<float4*>(y)[idx] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
 int launch_dwconv_fwd(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad, float* y,
                       hipStream_t st) {
+  const size_t ng = (size_t)B * C * (T / 4);
+  if (K == 7 && pad == 3 && T % 4 == 0 && ((((size_t)x | (size_t)y) & 15) == 0) && ng < ((size_t)1 << 31) &&
+      getenv("STY_NO_DWCONV7_FWD") == nullptr) {
+    hipLaunchKernelGGL(dwconv7_fwd_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, x, w, bias, C, T / 4, (unsigned)ng, y);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
+  if (K <= 31 && getenv("STY_NO_DWCONV7_FWD") == nullptr) {  // any other K (the conformer's k = 31): four outputs per thread, taps unrolled
+    if (K <= 7)
+      hipLaunchKernelGGL(dwconv_fwd4_kernel<7>, dim3(cdiv(T, 1024), C, B), dim3(256), 0, st, x, w, bias, C, T, K, pad, y);
+    else
+      hipLaunchKernelGGL(dwconv_fwd4_kernel<31>, dim3(cdiv(T, 1024), C, B), dim3(256), 0, st, x, w, bias, C, T, K, pad, y);
+    STY_LAUNCH_CHECK();
+    return STY_OK;
+  }
   hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, st, x, w, bias, C, T, K, pad, y);
   STY_LAUNCH_CHECK();
   return STY_OK;
