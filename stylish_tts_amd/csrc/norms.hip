@@ -376,9 +376,20 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(const float* __res
   const float* p = x + ((size_t)b * C + c) * T;
   const int pad = K / 2;
   float acc = bias[c];
-  for (int k = 0; k < K; ++k) {
-    const int tt = t - pad + k;
-    if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+  if (K == 31) {  // (the conformer's kernel size: taps unrolled, the 31 loads of an output in flight together)
+    float xv[31];
+#pragma unroll
+    for (int k = 0; k < 31; ++k) {
+      const int tt = t - 15 + k;
+      xv[k] = (tt >= 0 && tt < T) ? p[tt] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 31; ++k) acc = fmaf(w[c * 31 + k], xv[k], acc);
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const int tt = t - pad + k;
+      if (tt >= 0 && tt < T) acc = fmaf(w[c * K + k], p[tt], acc);
+    }
   }
   float v = (acc - bn_rm[c]) / sqrtf(bn_rv[c] + bn_eps) * bn_w[c] + bn_b[c];
   v = v * (1.0f / (1.0f + expf(-v)));
