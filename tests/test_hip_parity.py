@@ -1955,15 +1955,18 @@ def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monke
     gs = torch.randn(3, 64, generator=torch.Generator().manual_seed(10))
     out = {}
     for mode in ("tiled", "persistent"):
-        for k in ("STY_NO_CONVP16", "STY_NO_CONV32P", "STY_NO_WGRADB", "STY_CONVP16_MIN_TILES", "STY_CONV32P_MIN_TILES"):
+        for k in ("STY_NO_CONVP16", "STY_NO_CONV32P", "STY_NO_WGRADB", "STY_NO_CONVK1", "STY_CONVP16_MIN_TILES",
+                  "STY_CONV32P_MIN_TILES", "STY_CONVK1_MIN_TILES"):
             monkeypatch.delenv(k, raising=False)
         if mode == "tiled":
             monkeypatch.setenv("STY_NO_CONVP16", "1")
             monkeypatch.setenv("STY_NO_CONV32P", "1")
             monkeypatch.setenv("STY_NO_WGRADB", "1")
+            monkeypatch.setenv("STY_NO_CONVK1", "1")
         else:
             monkeypatch.setenv("STY_CONVP16_MIN_TILES", "1")
             monkeypatch.setenv("STY_CONV32P_MIN_TILES", "1")
+            monkeypatch.setenv("STY_CONVK1_MIN_TILES", "1")  # (round 5: the K = 1 GEMM kernel from 24 tiles; here every eligible launch)
         se = S.MelStyleEncoder()
         se.load_state_dict(fill_state_dict(style_encoder_manifest(), 0))
         se = se.to(DEV).enable_training().set_train_opts(compute_bf16=True)
@@ -1984,6 +1987,7 @@ def test_persistent_kernels_match_the_tiled_kernel_in_the_bf16_graphs(env, monke
         has = (any(n.startswith("convp16") for n in names), any(n.startswith("conv32p") for n in names),
                any(n.startswith("wgradb") for n in names))
         assert has == ((True, True, True) if mode == "persistent" else (False, False, False)), names
+        assert mode == "persistent" or not any(n.startswith("convk1") for n in names), names
         out[mode] = dict(style=style.cpu(), audio=audio.cpu(), d_style=d_style.cpu(),
                          gse=torch.cat([p.grad.flatten().cpu() for p in se.parameters()]),
                          gsp=torch.cat([p.grad.flatten().cpu() for p in sp.parameters()]))
