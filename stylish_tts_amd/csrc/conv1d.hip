@@ -467,8 +467,13 @@ static int launch_conv1d_dispatch(const ConvArgs& a, hipStream_t st) {
   // Tile choice: the biggest output tile that still gives the chip >= ~2 workgroups per CU; the 256-channel stage
   // runs at T <= 800 frames, where 128x128 tiles would launch ~100 workgroups on 256 CUs.
   const long tiles128 = (long)cdiv(a.T, 128) * (a.w.CoutP / 128) * a.B;
-  static const long t128_min = getenv("STY_T128_TILES") ? atol(getenv("STY_T128_TILES")) : 512;
-  static const long t64_min = getenv("STY_T64_TILES") ? atol(getenv("STY_T64_TILES")) : 512;
+  // (round 5, bf16 mode: 256 -- what is left on this kernel there are a dozen launches of 300-600 tiles, the pixel-shuffle
+  //  up-convs and their input gradients, and they run faster on the larger tiles: c3 45.48 -> 45.19 ms, c5-bf16 4.42 -> 4.35;
+  //  fp32 (c2): neutral in the step, +0.5 ms in the serial step: stays at 512.  profiles/r05_ab_env.txt block 20)
+  static const long t128_env = getenv("STY_T128_TILES") ? atol(getenv("STY_T128_TILES")) : 0;
+  static const long t64_env = getenv("STY_T64_TILES") ? atol(getenv("STY_T64_TILES")) : 0;
+  const long t128_min = t128_env ? t128_env : (a.bf16 ? 256 : 512);
+  const long t64_min = t64_env ? t64_env : (a.bf16 ? 256 : 512);
   static const long t32_min = getenv("STY_T32_TILES") ? atol(getenv("STY_T32_TILES")) : 512;
   if (a.act == ACT_GLU) {
     if (a.w.CoutP % 128 == 0 && tiles128 >= t128_min) return launch_cfg<2, 2, 2, 2>(a, st);
