@@ -622,6 +622,7 @@ struct FragBatch {  // the device-side job table of one arena, rebuilt when its 
   int nblk = 0;
 };
 static std::unordered_map<const void*, FragBatch> g_batches;
+static std::unordered_map<const void*, const void*> g_arenas;  // [lo, hi) of every model arena seen by convp16_repack_range
 
 static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
   const size_t bytes = (size_t)a.w.K * a.w.CinP * a.w.CoutP * 2;
@@ -652,6 +653,16 @@ static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
     hipLaunchKernelGGL(frag_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.w.wp, a.w.K, a.w.CinP, a.w.CoutP,
                        static_cast<bf16x8*>(wf));
     STY_LAUNCH_CHECK();
+    // Packed weights inside a MODEL's arena (one that convp16_repack_range has been called with): valid from here until they change --
+    // every change of them is followed by the model's prepare step, which re-makes every existing buffer of the arena.  Without
+    // this the inference plan, whose prepare runs once, re-packed every weight at every launch (c5-bf16: 20 launches per forward).
+    // Weights in caller-owned memory (unit entry points, discriminators) may change at any time: re-packed at every launch.
+    std::lock_guard<std::mutex> lock(g_frag_mu);
+    bool in_arena = false;
+    for (const auto& ar : g_arenas)
+      if ((const void*)a.w.wp >= ar.first && (const void*)a.w.wp < ar.second) in_arena = true;
+    auto it = g_frags.find(a.w.wp);
+    if (in_arena && it != g_frags.end() && it->second.wf == wf) it->second.batched = true;
   }
   *out = wf;
   return STY_OK;
@@ -669,6 +680,7 @@ void convp16_forget_range(const void* lo, const void* hi) {
       ++it;
     }
   }
+  g_arenas.erase(lo);
   auto b = g_batches.find(lo);
   if (b != g_batches.end()) {
     if (b->second.jobs) (void)hipFree(b->second.jobs);
@@ -680,6 +692,7 @@ void convp16_forget_range(const void* lo, const void* hi) {
 // Re-make every fragment buffer whose packed weights lie in [lo, hi) (a model's arena), on `st`, in one launch.
 int convp16_repack_range(const void* lo, const void* hi, hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_frag_mu);
+  g_arenas[lo] = hi;
   std::vector<const float*> keys;
   for (auto& kv : g_frags)
     if ((const void*)kv.first >= lo && (const void*)kv.first < hi && kv.second.wf) keys.push_back(kv.first);

@@ -755,6 +755,48 @@ def test_vocoder_bf16_inference_on_the_small_launch_kernels(env, monkeypatch):
     assert d <= 1.5e-2
 
 
+def test_bf16_weight_fragments_follow_a_weight_update_in_inference(env, monkeypatch):
+    """The bf16 A-fragment buffers of the persistent / GEMM kernels are made once per weight and kept until the model's
+    prepare step re-makes them (convp16.hip, q_frags; round 5: in inference too, where every launch re-packed its weight
+    before).  A weight update through load_state_dict on the SAME model object must reach the next forward: its audio has to
+    equal, bit for bit, that of a fresh model built from the updated weights -- with the kernels forced onto the test's small
+    launches."""
+    import stylish_tts_amd as S
+    for k in ("STY_CONVP16_MIN_TILES", "STY_CONVK1_MIN_TILES", "STY_CONV32P_MIN_TILES"):
+        monkeypatch.setenv(k, "1")
+    cs, want = env["cs"], env["want"]
+    P = {k: v.clone() for k, v in env["P"].items()}
+
+    def run(m):
+        with torch.no_grad():
+            a = m.vocoder_forward(mel=dev(want["decoder_out"]), style=dev(cs["style"]), pitch=dev(cs["pitch"]),
+                                  voiced=dev(env["voiced"]), noise=dev(cs["noise"]), prior_override=dev(want["prior"])).audio
+        torch.cuda.synchronize()
+        return a.cpu()
+
+    m = S.SpeechPredictor()
+    m.load_state_dict(P, strict=False)
+    m = m.to(DEV).set_train_opts(compute_bf16=True)
+    a0 = run(m)
+    assert torch.equal(a0, run(m))  # (second forward: every fragment buffer comes from the cache)
+    P2 = {k: v.clone() for k, v in P.items()}
+    g = torch.Generator().manual_seed(3)
+    changed = 0
+    for k in P2:
+        if k.startswith("generator.") and k.endswith(".weight") and P2[k].dim() == 3 and P2[k].shape[1] >= 64:
+            P2[k] = P2[k] * (1.0 + 0.05 * torch.randn(P2[k].shape, generator=g))
+            changed += 1
+    assert changed >= 4
+    m.load_state_dict(P2, strict=False)
+    a1 = run(m)
+    m2 = S.SpeechPredictor()
+    m2.load_state_dict(P2, strict=False)
+    m2 = m2.to(DEV).set_train_opts(compute_bf16=True)
+    a2 = run(m2)
+    assert not torch.equal(a1, a0)
+    assert torch.equal(a1, a2), (a1 - a2).abs().max().item()
+
+
 def test_speech_predictor_end_to_end_vs_oracle_and_golden(env):
     from safetensors.torch import load_file
     m, cs, want, ali = env["m"], env["cs"], env["want"], env["ali"]
