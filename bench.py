@@ -119,44 +119,94 @@ def build_model(device):
     return m.to(device), se.to(device), P
 
 
-def _inst_ok(family, rocprof_name):
-    """convp16_kernel<MTW, PRO, RELU, FLAT, X16> has two kinds of instantiation that the library reports as two families: the
-    padded-flat 2-D convs of the style encoder (FLAT = true: `convp16_kernel<2,true>`) and the 1-D convs of the decoder / text
-    encoder (FLAT = false: `convp16_kernel<2,true,1d>`); everything else: any instantiation of the family."""
+def norm_kernel_name(name):
+    """A kernel's name reduced to what identifies the instantiation: no return type, no `sty::` / anonymous namespace, no
+    argument list, no blanks -- the form in which the library's `sty_prof_row.inst`, the rows of a committed
+    `profiles/*_kernel_stats.txt` and the keys of `profiles/*_pmc_traffic.json` are compared.  Mangled names
+    (`_ZN3sty...`, as the tracer leaves a few of them) are demangled first when c++filt is there."""
     import re
-    if not family.startswith("convp16_kernel<"):
-        return True
-    m = re.search(r"convp16_kernel<([^>]*)>", re.sub(r"\s+", "", rocprof_name))
-    if not m:
-        return True
-    args = m.group(1).split(",")
-    return len(args) < 4 or (args[3] == "false") == family.rstrip(">").endswith(",1d")
+    n = name.strip()
+    if n.startswith("_Z"):
+        try:
+            import subprocess
+            n = subprocess.run(["c++filt", n], stdout=subprocess.PIPE, timeout=10).stdout.decode().strip() or n
+        except Exception:
+            pass
+    trunc = n.endswith("...")  # tools/rocpd_summary.py of rounds 1-5 cut names at 107 characters
+    if trunc:
+        n = n[:-3]
+    n = re.sub(r"^void\s+", "", n)
+    n = n.replace("(anonymous namespace)::", "").replace("sty::", "")
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    n = re.sub(r"\s+", "", n[:cut])
+    return n, trunc and cut == len(n)
 
 
-def pmc_traffic(family, workload):
-    """HBM bytes per launch of a kernel from the committed PMC passes of this same command (tools/profile_round.sh ->
-    profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  Counters cannot be
-    read from inside the process, so this is the recorded figure of the SAME workload, or None when there is none."""
+def _same_kernel(inst, other):
+    """`inst`: an instantiation name from the library; `other`: a name from a profile file (possibly cut short)."""
+    a, _ = norm_kernel_name(inst)
+    b, cut = norm_kernel_name(other)
+    return a == b or (cut and len(b) > 20 and a.startswith(b))
+
+
+def _profile_files(workload, suffix):
     import glob
-    import re
-    key = re.sub(r"\s+", "", family)
-    base, _, targs = key.partition("<")
-    first = targs.split(",")[0].rstrip(">")
-    key = key.replace(",1d>", ">")
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_traffic.json")), reverse=True):
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_{suffix}")), reverse=True)
+
+
+def rocprof_rows(workload):
+    """(rows, source) of the newest committed rocprofv3 --kernel-trace --stats summary of this same command
+    (profiles/*_<workload>_kernel_stats.txt, tools/profile_round.sh): rows = [(calls, total_us, name)] in the file's order,
+    i.e. largest total first."""
+    for f in _profile_files(workload, "kernel_stats.txt"):
+        rows = []
+        try:
+            for ln in open(f).read().splitlines():
+                parts = ln.split(None, 4)
+                if len(parts) == 5 and parts[0].isdigit():
+                    rows.append((int(parts[0]), float(parts[1]), parts[4]))
+        except Exception:
+            continue
+        if rows:
+            return rows, os.path.relpath(f, ROOT)
+    return [], None
+
+
+def rocprof_avg_us(insts, workload):
+    """Average launch duration (us) of the instantiation(s) `insts` in the committed rocprofv3 summary of this same command --
+    the figure `roofline.avg_launch_us` (HIP events, live) has to agree with."""
+    rows, src = rocprof_rows(workload)
+    tot = n = 0.0
+    for calls, total, name in rows:
+        if any(_same_kernel(i, name) for i in insts):
+            tot += total
+            n += calls
+    return (tot / n, src) if n else (None, src)
+
+
+def pmc_traffic(insts, workload):
+    """HBM bytes per launch of a kernel from the committed PMC passes of this same command (tools/profile_round.sh ->
+    profiles/*_pmc_traffic.json; FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes).
+    Counters cannot be read from inside the process, so this is the recorded figure of the SAME workload, launch-weighted over
+    `insts`; None when there is no such file."""
+    for f in _profile_files(workload, "pmc_traffic.json"):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        # exact instantiation first; otherwise every instantiation of the family (the library's family names carry the
-        # tile parameter and the bf16 marker only, rocprofv3's carry every template argument): launch-weighted mean
         tot = n = 0.0
         for k, v in d.items():
-            kk = re.sub(r"\s+", "", k)
-            if key in kk:
-                return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(f, ROOT)
-            m = re.search(r"(?:sty::)?" + re.escape(base) + r"<([^,>]+)", kk)
-            if m and m.group(1) == first and _inst_ok(family, kk):
+            if k.startswith("_") or not isinstance(v, dict) or "launches" not in v:
+                continue
+            if any(_same_kernel(i, k) for i in insts):
                 tot += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
                 n += v["launches"]
         if n:
@@ -164,34 +214,22 @@ def pmc_traffic(family, workload):
     return None, None
 
 
-def rocprof_avg_us(family, workload):
-    """Average launch duration (us) of a kernel family in the committed rocprofv3 --kernel-trace --stats summary of this
-    same command (profiles/*_<workload>_kernel_stats.txt, tools/profile_round.sh), launch-weighted over the family's
-    instantiations -- the figure `roofline.avg_launch_us` (HIP events, live) has to agree with in order of magnitude; the
-    event time is taken on a chip the kernel shares with three other streams and includes queueing behind them."""
-    import glob
-    import re
-    key = re.sub(r"\s+", "", family)
-    base, _, targs = key.partition("<")
-    first = targs.split(",")[0].rstrip(">")
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_kernel_stats.txt")), reverse=True):
-        tot = n = 0.0
-        try:
-            lines = open(f).read().splitlines()
-        except Exception:
-            continue
-        for ln in lines:
-            parts = ln.split(None, 4)
-            if len(parts) < 5 or not parts[0].isdigit():
-                continue
-            kk = re.sub(r"\s+", "", parts[4])
-            m = re.search(r"(?:sty::)?" + re.escape(base) + (r"<([^,>]+)" if targs else r"\b"), kk)
-            if m and (not targs or m.group(1) == first) and _inst_ok(family, kk):
-                tot += float(parts[1])
-                n += int(parts[0])
-        if n:
-            return tot / n, os.path.relpath(f, ROOT)
-    return None, None
+def pick_dominant(rows, workload):
+    """Which kernel the `roofline` object is about -- decided the same way on every box: the top row of the committed
+    rocprofv3 summary of this command (profiles/*_<workload>_kernel_stats.txt) if the library still has that instantiation
+    (`rows` = this run's warm-up table, one row per (family, instantiation)); otherwise -- a library newer than its profiles --
+    the instantiation with the largest summed time in `rows`.  Returns (family, inst, how)."""
+    rows = [r for r in rows if r["launches"]]
+    if not rows:
+        return None, None, None
+    prows, src = rocprof_rows(workload)
+    for calls, total, name in prows[:1]:
+        for r in rows:
+            if r["inst"] and _same_kernel(r["inst"], name):
+                return r["name"], r["inst"], f"top row of {src}"
+    r = max(rows, key=lambda r: r["ms"])
+    return r["name"], r["inst"], ("largest summed event time of the warm-up step (no committed profile names a kernel of this "
+                                  "library as its top row)")
 
 
 def _usable_cpus():
@@ -417,8 +455,9 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     out = step(warmup)
     barrier()
     lib.sty_prof_enable(0)
-    warm_prof = L.prof_report(2048)
-    dom_name = max(warm_prof, key=lambda r: r["ms"])["name"] if warm_prof else None
+    warm_raw = L.prof_report(4096, by_inst=True)   # one row per (family, instantiation)
+    warm_prof = L.group_families(warm_raw)
+    dom_name, dom_inst, dom_how = pick_dominant(warm_raw, name)
     if dom_name:
         lib.sty_prof_only(dom_name.split(" ")[0].encode())  # STY_PROF_SHAPES appends the shape to the family name
         lib.sty_prof_enable(1)
@@ -434,12 +473,12 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     dt = time.perf_counter() - t0
     lib.sty_prof_enable(0)
     lib.sty_prof_only(None)
-    prof = L.prof_report(2048) if rank == 0 else []
+    prof = L.prof_report(4096, by_inst=True) if rank == 0 else []
     assert bool(torch.isfinite(out).all())
     # After the timed region (training workloads, rank 0's view): the same step with the library's side streams off, all
     # families timed -- the dominant kernel's duration free of the stretch from sharing the chip with the
     # weight-gradient / style-encoder streams.  Reported beside `roofline`, never instead of it.
-    serial_prof = []
+    serial_prof, serial_raw = [], []
     if trainer is not None and serial_pass:  # every rank: the steps contain the gradient all-reduce
         lib.sty_set_single_stream(1)
         trainer.single_stream = True
@@ -450,7 +489,8 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
             step(warmup + steps + 2 + i)
         torch.cuda.synchronize()
         lib.sty_prof_enable(0)
-        serial_prof = L.prof_report(2048)
+        serial_raw = L.prof_report(4096, by_inst=True)
+        serial_prof = L.group_families(serial_raw)
         ts = time.perf_counter()  # and the single-stream step itself, without the per-launch events
         for i in range(2):
             step(warmup + steps + 4 + i)
@@ -507,17 +547,23 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                 rec["hbm_counter_source"] = os.path.relpath(f, ROOT)
                 break
     if prof:
-        dom = max(prof, key=lambda r: r["ms"])
-        traffic, traffic_src = pmc_traffic(dom["name"], name)
+        # the timed region timed ONE family (sty_prof_only); the roofline is about ONE instantiation of it -- the one
+        # pick_dominant named, the same on every box
+        cand = [r for r in prof if r["inst"] == dom_inst] or [max(prof, key=lambda r: r["ms"])]
+        dom = cand[0]
+        insts = [dom["inst"]] if dom["inst"] else []
+        traffic, traffic_src = pmc_traffic(insts, name)
+        rp_us, rp_src = rocprof_avg_us(insts, name)
         per = dom["ms"] / dom["launches"] * 1e-3
         tf = dom["flops"] / dom["launches"] / per / 1e12
         gbs = dom["bytes"] / dom["launches"] / per / 1e9
-        # a kernel of the bf16 compute mode (",true>" instantiation) is priced against the bf16 MFMA peak; the roof
+        # a kernel of the bf16 compute mode (",true>" family) is priced against the bf16 MFMA peak; the roof
         # quoted as `bound` is the one the kernel sits closer to (both fractions are in the record)
-        peak = PEAK_BF16_TFLOPS if dom["name"].endswith("true>") else PEAK_FP32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if dom["name"].split(" ")[0].endswith("true>") or ",true," in dom["name"] else PEAK_FP32_TFLOPS
         f_mfma, f_hbm = tf / peak, gbs / PEAK_HBM_GBS
         hbm_bound = f_hbm > f_mfma
-        rec["roofline"] = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma",
+        rec["roofline"] = {"kernel": dom["inst"] or dom["name"], "family": dom["name"], "chosen_by": dom_how,
+                           "bound": "hbm" if hbm_bound else "mfma",
                            "achieved": gbs if hbm_bound else tf, "peak": PEAK_HBM_GBS if hbm_bound else peak,
                            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": f_hbm if hbm_bound else f_mfma,
                            "traffic": traffic, "traffic_source": traffic_src,
@@ -527,12 +573,11 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                                                "chip with up to three other streams, so this includes queueing behind them; "
                                                "rocprof_avg_launch_us is the committed rocprofv3 --kernel-trace --stats average "
                                                "of the same command, single_stream.avg_launch_us the kernel alone on the chip",
-                           "rocprof_avg_launch_us": rocprof_avg_us(dom["name"], name)[0],
-                           "rocprof_source": rocprof_avg_us(dom["name"], name)[1],
+                           "rocprof_avg_launch_us": rp_us, "rocprof_source": rp_src,
                            "mfma_TFLOPs": tf, "mfma_peak": peak, "mfma_frac": f_mfma,
                            "hbm_GBps_algorithmic": gbs, "hbm_frac": f_hbm,
                            "share_of_step_time": dom["ms"] / (1e3 * dt)}
-        sp = [r for r in serial_prof if r["name"] == dom["name"]]
+        sp = [r for r in serial_raw if r["name"] == dom["name"] and r["inst"] == dom["inst"]]
         if sp:
             per1 = sp[0]["ms"] / sp[0]["launches"] * 1e-3
             tf1 = sp[0]["flops"] / sp[0]["launches"] / per1 / 1e12
@@ -576,7 +621,7 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
             "GBps": sbytes / step_s / 1e9, "hbm_peak": PEAK_HBM_GBS, "hbm_frac": sbytes / step_s / 1e9 / PEAK_HBM_GBS,
             "launches_instrumented": sum(r["launches"] for r in warm_prof) // nprof}
         rec["kernels_source"] = "HIP events over one untimed step after the warm-up; roofline: over the timed region"
-        rec["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / nprof,
+        rec["kernels"] = [{"name": r["name"], "insts": r.get("insts"), "launches": r["launches"], "ms_per_step": r["ms"] / nprof,
                            "TFLOPs": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0.0,
                            "GBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0.0}
                           for r in sorted(warm_prof, key=lambda r: -r["ms"])]
@@ -603,7 +648,7 @@ def _r(x, sig=5):
     return x
 
 
-_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+_ROOF_KEYS = ("kernel", "family", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "rocprof_source",
               "algorithmic_bytes_per_launch", "avg_launch_us", "rocprof_avg_launch_us", "launches", "mfma_frac", "hbm_frac",
               "share_of_step_time")
 
@@ -647,7 +692,8 @@ def format_line(rec, detail_path=None):
         for name, r in rec["extra"].items():
             rf = r.get("roofline") or {}
             e = {"ms_per_step": r.get("ms_per_step"), "value": r.get("value"),
-                 "roofline": {k: rf[k] for k in ("kernel", "bound", "frac", "achieved", "unit", "traffic") if k in rf}}
+                 "roofline": {k: rf[k] for k in ("kernel", "bound", "frac", "achieved", "unit", "traffic", "avg_launch_us",
+                                                   "rocprof_avg_launch_us") if k in rf}}
             for k in ("hbm_counter_GBps", "hbm_counter_source"):
                 if k in r:
                     e[k] = r[k]

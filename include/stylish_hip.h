@@ -451,7 +451,9 @@ int sty_acoustic_gan_loss_fwd_bwd(int B, int N, const float *audio_gt, const flo
  * rows; it returns the number of families.  flops/bytes are ALGORITHMIC counts computed from the launch shapes
  * (DESIGN.md section "roofline accounting"), not counter readings.                                       */
 typedef struct {
-  char name[48];
+  char name[48];   /* family: the launch site's label (kernel name, tile parameter, bf16 marker) */
+  char inst[144];  /* the instantiation that ran, as rocprofv3 --kernel-trace prints it minus "void sty::" and the argument
+                      list, e.g. "convp16_kernel<2, 0, 0, true, true>" (one row per (family, inst) pair) */
   uint64_t launches;
   double ms;    /* summed launch durations */
   double flops; /* summed algorithmic flops */

@@ -140,10 +140,12 @@ def grn_scale(h, gamma, eps=1e-6):
 #   * the input gradient of a conv whose input is such a tensor (d loss / d prologue(x), before the prologue's derivative):
 #     `_BfConv1d(..., round_gx=True)`.
 # Gradient accumulators stay fp32 in the product, so nothing else is rounded on the way back -- except on the 32-channel
-# ConvNeXt chain of the vocoder's phase path (round 5, `round_grad`): under autocast that residual stream and its gradient
-# are bf16 tensors (conv_next.py:80-93); the product keeps the chain's GRADIENTS as two-byte tensors where its fused lean
-# backward applies (C == 32, T % 8 == 0): d loss / d x of every block input between the chain's two LayerNorms and
-# d loss / d (depthwise-conv output) of every such block are each rounded once, where they are stored.
+# ConvNeXt chain of the vocoder's phase path (`round_grad`): where the product's fused lean backward applies (C == 32,
+# T % 8 == 0) d loss / d (depthwise-conv output) of every block is a two-byte tensor, rounded once where it is stored -- under
+# autocast the depthwise conv's output and its gradient are bf16 tensors.  The residual stream itself and its gradient are
+# fp32 in the reference (an fp32 LayerNorm output plus fp32 residual adds: conv_next.py:80-93, generator.py:771-775) and, since
+# round 6, in the product's default; with STY_GRAD16_STREAM=1 (`grad16_stream()`) the product also stores d loss / d x of every
+# block input between the chain's two LayerNorms as two-byte tensors -- a deliberate deviation, stated here with the same switch.
 _DENSE = {"bf16": False, "store16": False}
 
 
@@ -232,6 +234,13 @@ class _RoundGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return bf(g)
+
+
+def grad16_stream():
+    """the product's STY_GRAD16_STREAM=1 opt-in (two-byte gradient of the 32-channel ConvNeXt chain's residual stream: coarser
+    than the reference, off by default): the oracle's storage rule follows the same switch"""
+    import os
+    return os.environ.get("STY_GRAD16_STREAM", "0") not in ("", "0")
 
 
 def round_grad(t, on=True):

@@ -81,9 +81,12 @@ def generator(P, p, mel, style, pitch, voiced, noise, want=None, prior=None):
     ph = F.conv1d(ph, P[p + ".phase_input_conv.weight"], P[p + ".phase_input_conv.bias"], padding=10)
     ph = B.chan_layer_norm(ph, P[p + ".phase_norm.weight"], P[p + ".phase_norm.bias"], 1e-6)
     i = 0
-    # (storage rule: between the two LayerNorms the gradient of every block input / output is a two-byte tensor in the product --
-    #  where its long-row LayerNorm(32) kernel applies: B T >= 65536)
-    g16 = ph.shape[0] * ph.shape[2] >= 65536
+    # (storage rule: the gradient of the depthwise convs' outputs is a two-byte tensor in the product (round_grad inside
+    #  convnext_block), as under autocast.  The residual stream's own gradient is fp32 in the reference (fp32 LayerNorm output,
+    #  fp32 residual adds: conv_next.py:80-93, generator.py:771-775) and in the product's default; STY_GRAD16_STREAM=1 is the
+    #  product's opt-in that keeps it as a two-byte tensor too -- where its long-row LayerNorm(32) kernel applies: B T >= 65536 --
+    #  and then the oracle rounds at the same points.)
+    g16 = B.grad16_stream() and ph.shape[0] * ph.shape[2] >= 65536
     while (f"{p}.phase_convnext.{i}.dwconv.weight") in P:
         ph = B.convnext_block(P, f"{p}.phase_convnext.{i}", ph, style, want, grad16=g16)
         i += 1

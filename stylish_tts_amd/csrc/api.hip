@@ -3,6 +3,11 @@
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
+#include <cxxabi.h>
+
+#include <map>
+#include <string>
 
 #include "model.h"
 
@@ -27,7 +32,9 @@ struct ProfEntry {
   std::string family;
   double flops, bytes;
   hipEvent_t a, b;
+  const void* fn = nullptr;  // host-side handle of the kernel launched inside the scope (the last one, if several)
 };
+thread_local const void* g_last_kernel = nullptr;
 static bool g_single_stream = false;  // sty_set_single_stream
 bool single_stream_mode() { return g_single_stream; }
 static bool g_prof_on = false;
@@ -58,7 +65,43 @@ ProfScope::ProfScope(const char* family, double flops, double bytes, hipStream_t
   g_prof.push_back(e);
 }
 ProfScope::~ProfScope() {
-  if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+  if (slot >= 0) {
+    (void)hipEventRecord(g_prof[slot].b, st);
+    g_prof[slot].fn = g_last_kernel;
+  }
+}
+// "void sty::convp16_kernel<2, 0, 0, true, true>(sty::ConvArgs, int, int, int, int)" -> "convp16_kernel<2, 0, 0, true, true>":
+// the kernel's name as rocprofv3 --kernel-trace prints it, minus return type, namespaces and the argument list
+static std::string kernel_inst_name(const void* fn, hipStream_t st) {
+  static std::map<const void*, std::string> cache;
+  if (!fn) return "";
+  auto it = cache.find(fn);
+  if (it != cache.end()) return it->second;
+  std::string out;
+  const char* mangled = hipKernelNameRefByPtr(fn, st);
+  if (mangled) {
+    int status = 0;
+    char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    std::string d = (status == 0 && dem) ? dem : mangled;
+    free(dem);
+    int depth = 0;  // cut the argument list: the first '(' outside template brackets ("(anonymous namespace)" starts inside "sty::")
+    size_t cut = d.size();
+    for (size_t i = 0; i < d.size(); ++i) {
+      if (d[i] == '<') ++depth;
+      if (d[i] == '>') --depth;
+      if (d[i] == '(' && depth == 0 && d.compare(i, 21, "(anonymous namespace)") != 0) {
+        cut = i;
+        break;
+      }
+    }
+    d = d.substr(0, cut);
+    if (d.compare(0, 5, "void ") == 0) d = d.substr(5);
+    for (const char* ns : {"sty::(anonymous namespace)::", "sty::"})
+      if (d.compare(0, strlen(ns), ns) == 0) d = d.substr(strlen(ns));
+    out = d;
+  }
+  cache[fn] = out;
+  return out;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1399,19 +1442,23 @@ int sty_prof_only(const char* family) {
 }
 int sty_prof_report(sty_prof_row* rows, int cap) {
   STY_HIP(hipDeviceSynchronize());
+  // one row per (family, instantiation): the family is the launch site's label (tile parameter + bf16 marker), the instantiation
+  // the kernel's own name as the tracer prints it
   std::vector<sty_prof_row> agg;
   for (ProfEntry& e : g_prof) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) ms = 0.f;
     g_evpool.push_back(e.a);
     g_evpool.push_back(e.b);
+    const std::string inst = kernel_inst_name(e.fn, nullptr);
     sty_prof_row* r = nullptr;
     for (auto& x : agg)
-      if (!strncmp(x.name, e.family.c_str(), sizeof(x.name) - 1)) r = &x;
+      if (!strncmp(x.name, e.family.c_str(), sizeof(x.name) - 1) && !strncmp(x.inst, inst.c_str(), sizeof(x.inst) - 1)) r = &x;
     if (!r) {
       sty_prof_row n;
       memset(&n, 0, sizeof(n));
       strncpy(n.name, e.family.c_str(), sizeof(n.name) - 1);
+      strncpy(n.inst, inst.c_str(), sizeof(n.inst) - 1);
       agg.push_back(n);
       r = &agg.back();
     }

@@ -612,6 +612,10 @@ struct FragEntry {
   size_t bytes = 0;
   int K = 0, CinP = 0, CoutP = 0;
   bool batched = false;  // re-made by convp16_repack_range since the weights last changed: launches skip the re-pack
+  // batched set by a per-launch pack (q_frags, in-arena weights of an inference plan): the pack ran on `pack_stream`; a later
+  // launch on ANOTHER stream waits for `ready` first (a launch on the same stream is ordered behind the pack by the stream)
+  hipEvent_t ready = nullptr;
+  hipStream_t pack_stream = nullptr;
 };
 static std::mutex g_frag_mu;
 static std::unordered_map<const float*, FragEntry> g_frags;
@@ -647,6 +651,7 @@ static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
     }
     wf = e.wf;
     fresh = e.batched;
+    if (fresh && e.ready && e.pack_stream != st) STY_HIP(hipStreamWaitEvent(st, e.ready, 0));
   }
   if (!fresh) {
     const int n = (int)(bytes / 16);
@@ -662,7 +667,14 @@ static int q_frags(const ConvArgs& a, hipStream_t st, const void** out) {
     for (const auto& ar : g_arenas)
       if ((const void*)a.w.wp >= ar.first && (const void*)a.w.wp < ar.second) in_arena = true;
     auto it = g_frags.find(a.w.wp);
-    if (in_arena && it != g_frags.end() && it->second.wf == wf) it->second.batched = true;
+    if (in_arena && it != g_frags.end() && it->second.wf == wf) {
+      FragEntry& e = it->second;
+      if (!e.ready && hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess) e.ready = nullptr;
+      if (e.ready && hipEventRecord(e.ready, st) == hipSuccess) {  // (no event: stay un-batched, i.e. re-pack at every launch)
+        e.pack_stream = st;
+        e.batched = true;
+      }
+    }
   }
   *out = wf;
   return STY_OK;
@@ -675,6 +687,7 @@ void convp16_forget_range(const void* lo, const void* hi) {
   for (auto it = g_frags.begin(); it != g_frags.end();) {
     if ((const void*)it->first >= lo && (const void*)it->first < hi) {
       if (it->second.wf) (void)hipFree(it->second.wf);
+      if (it->second.ready) (void)hipEventDestroy(it->second.ready);
       it = g_frags.erase(it);
     } else {
       ++it;
@@ -729,7 +742,15 @@ int convp16_repack_range(const void* lo, const void* hi, hipStream_t st) {
   }
   hipLaunchKernelGGL(frag_pack_multi_kernel, dim3(b.nblk), dim3(256), 0, st, b.jobs, b.blk);
   STY_LAUNCH_CHECK();
-  for (const float* k : keys) g_frags[k].batched = true;
+  for (const float* k : keys) {
+    FragEntry& e = g_frags[k];
+    e.batched = true;
+    e.pack_stream = nullptr;  // ordered by the model's prepare event, not by the per-launch one
+    if (e.ready) {
+      (void)hipEventDestroy(e.ready);
+      e.ready = nullptr;
+    }
+  }
   return STY_OK;
 }
 
@@ -834,6 +855,7 @@ static int launch_q_pro(const ConvArgs& a, hipStream_t st) {
 int convp16_frags(const ConvArgs& a, hipStream_t st, const void** out) { return q_frags(a, st, out); }  // (convk1.hip)
 
 int launch_convp16(const ConvArgs& a0, hipStream_t st) {
+  if (a0.x16 && getenv("STY_NO_CONVP16_X16") == nullptr && convq_eligible(a0)) return launch_convq(a0, st);  // round 6: convq.hip
   ConvArgs a = a0;
   int rc = q_frags(a0, st, &a.w.wf);
   if (rc) return rc;

@@ -19,6 +19,21 @@ int hip_fail(hipError_t e, const char* what);
 
 #define STY_LAUNCH_CHECK() STY_HIP(hipGetLastError())
 
+// Every launch of the library goes through hipLaunchKernelGGL; this form also notes WHICH instantiation was launched (the
+// host-side handle of the kernel), so that the in-situ timer can report the exact kernel name rocprofv3 prints for the same
+// launch (sty_prof_row::inst) instead of a family label somebody has to map by hand.
+extern thread_local const void* g_last_kernel;
+template <class R, class... A>
+inline const void* kernel_handle(R (*f)(A...)) {  // a kernel's name decays to this; a function-pointer variable passes through
+  return reinterpret_cast<const void*>(f);
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)        \
+  do {                                                                                             \
+    sty::g_last_kernel = sty::kernel_handle(kernelName);                                           \
+    (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);           \
+  } while (0)
+
 // in-situ timing of kernel families (api.hip); no-ops unless sty_prof_enable(1)
 struct ProfScope {
   int slot = -1;
@@ -222,6 +237,9 @@ int launch_stem2d(const ConvArgs& a, hipStream_t st);
 bool convk1_eligible(const ConvArgs& a);  // convk1.hip: K = 1 as a plain GEMM (transposing LDS reads)
 int launch_convk1(const ConvArgs& a, hipStream_t st);
 bool convp16_eligible(const ConvArgs& a);
+// convq.hip: the same job on bf16 operand twins (ConvArgs::x16), K = 1 / 3: 96 x 256 tiles, wide loads, register transposes
+bool convq_eligible(const ConvArgs& a);
+int launch_convq(const ConvArgs& a, hipStream_t st);
 int convp16_repack_range(const void* lo, const void* hi, hipStream_t st);
 void convp16_forget_range(const void* lo, const void* hi);  // before the arena is freed or re-laid out  // bf16 weight fragments of a model's packed weights, one launch
 int launch_convp16(const ConvArgs& a, hipStream_t st);

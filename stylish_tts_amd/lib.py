@@ -164,18 +164,33 @@ SYMBOLS = {
 
 
 class ProfRow(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("ms", C.c_double), ("flops", C.c_double),
-                ("bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("inst", C.c_char * 144), ("launches", C.c_uint64), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-def prof_report(cap=64):
-    """Drain the in-situ kernel timers: list of dicts (name, launches, ms, flops, bytes)."""
+def prof_report(cap=64, by_inst=False):
+    """Drain the in-situ kernel timers: list of dicts (name, launches, ms, flops, bytes, insts).  The library keeps one row per
+    (family, instantiation); by default they are summed per family with `insts` = {instantiation: launches}; by_inst=True
+    returns the library's rows as they are (with `inst`)."""
+    cap = max(cap, 4096)  # rows are per (family, instantiation) before they are grouped
     rows = (ProfRow * cap)()
     n = LIB.sty_prof_report(C.cast(rows, C.c_void_p), cap)
     if n < 0:
         check(n)
-    return [dict(name=r.name.decode(), launches=int(r.launches), ms=r.ms, flops=r.flops, bytes=r.bytes)
-            for r in rows[:min(n, cap)]]
+    raw = [dict(name=r.name.decode(), inst=r.inst.decode(), launches=int(r.launches), ms=r.ms, flops=r.flops, bytes=r.bytes)
+           for r in rows[:min(n, cap)]]
+    return raw if by_inst else group_families(raw)
+
+
+def group_families(raw):
+    fam = {}
+    for r in raw:
+        f = fam.setdefault(r["name"], dict(name=r["name"], launches=0, ms=0.0, flops=0.0, bytes=0.0, insts={}))
+        for k in ("launches", "ms", "flops", "bytes"):
+            f[k] += r[k]
+        if r["inst"]:
+            f["insts"][r["inst"]] = f["insts"].get(r["inst"], 0) + r["launches"]
+    return list(fam.values())
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int)  # sty_grad_hook(user, segment)
 

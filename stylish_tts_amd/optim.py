@@ -111,27 +111,18 @@ class FlatAdamW:
         if len(groups) != 1 or len(groups[0]["params"]) != len(self._all):
             raise L.StyError(f"optimizer state: expected one param_group over {len(self._all)} parameters, got "
                              f"{[len(g['params']) for g in groups]}")
-        g = groups[0]
-        lr = g["lr"]
-        self.lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
-        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]
-        if "initial_lr" in g:
-            il = g["initial_lr"]
-            self.initial_lr = float(il.item()) if torch.is_tensor(il) else float(il)
-        for m, v in zip(self.m, self.v):
-            m.zero_()
-            v.zero_()
+        # ---- validate everything BEFORE touching lr / betas / the moment buckets: a refused file leaves the optimizer as it was
         steps = set()
+        entries = []
         for i, st in sd.get("state", {}).items():
             i = int(i)
             if i not in slots:
                 raise L.StyError(f"optimizer state: parameter {i} has state but is never stepped here")
             b, off, n, shape = slots[i]
-            if tuple(st["exp_avg"].shape) != shape:
+            if tuple(st["exp_avg"].shape) != shape or tuple(st["exp_avg_sq"].shape) != shape:
                 raise L.StyError(f"optimizer state: parameter {i} is {shape} here, {tuple(st['exp_avg'].shape)} in the file")
-            self.m[b][off:off + n].copy_(st["exp_avg"].reshape(-1))
-            self.v[b][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))
+            entries.append((b, off, n, st))
         if len(steps) > 1:
             # one bias-correction counter per bucket kernel.  torch.optim.AdamW keeps one per parameter, and under the
             # reference's DDP(find_unused_parameters=True) a parameter that had no gradient on some steps is behind the
@@ -145,6 +136,20 @@ class FlatAdamW:
             import warnings
             warnings.warn(f"optimizer state: parameters at different step counts {sorted(steps)}; continuing at "
                           f"{max(steps)}", stacklevel=2)
+        # ---- apply
+        g = groups[0]
+        lr = g["lr"]
+        self.lr = float(lr.item()) if torch.is_tensor(lr) else float(lr)
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]
+        if "initial_lr" in g:
+            il = g["initial_lr"]
+            self.initial_lr = float(il.item()) if torch.is_tensor(il) else float(il)
+        for m, v in zip(self.m, self.v):
+            m.zero_()
+            v.zero_()
+        for b, off, n, st in entries:
+            self.m[b][off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[b][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
         self.t = max(steps) if steps else 0
 
 

@@ -265,7 +265,8 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
     `trainer` (an AcousticTrainer): rank 0's BatchNorm / spectral-norm buffers are broadcast first (sync_buffers), the
     state a multi-rank run lets drift between checkpoints.
 
-    Multi-rank runs: EVERY rank must call this (it holds two collectives: the buffer broadcast and a closing barrier);
+    Multi-rank runs: EVERY rank must call this (it holds two collectives: the buffer broadcast and a closing one-int
+    broadcast of rank 0's success flag, which is also the barrier nobody returns before);
     only rank 0 touches the file system.  Do not wrap the call in `if rank == 0:` -- the other ranks would leave rank 0
     waiting in the broadcast.
 
@@ -280,8 +281,11 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
     if trainer is not None:
         trainer.sync_buffers()
     # I/O part, rank 0 only (the reference saves from the main process: train/train.py:453-469 under
-    # accelerator.is_main_process); each file is written beside its final name and moved over it (os.replace), so that a
-    # reader never sees a half-written file.  Parameters and optimizer state are identical on every rank (all-reduced
+    # accelerator.is_main_process).  ALL files are first written beside their final names; only when every one of them is on
+    # disk are they moved into place (os.replace, one after the other), and a completion marker (`COMPLETE_MARKER`: the list
+    # of files of THIS save) is written last.  A failure while writing leaves the directory as it was; a crash between the
+    # moves leaves a directory without a marker that matches its files, which load_checkpoint refuses (a mix of new model
+    # files and old optimizer files must not load silently).  Parameters and optimizer state are identical on every rank (all-reduced
     # gradients, the same AdamW), the tracked discriminator losses are the rank mean: rank 0's copy is THE state.
     # A failure of rank 0's I/O (disk full, permissions) must not leave the other ranks in the closing collective for good:
     # the error is caught, every rank learns of it through a one-int broadcast, temp files are removed, and ALL ranks raise.
@@ -295,7 +299,7 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
             tmp = osp.join(path, f".{name}.tmp{os.getpid()}")
             tmps.append(tmp)
             torch.save(obj, tmp)
-            os.replace(tmp, osp.join(path, name))
+            staged.append((tmp, osp.join(path, name), name))
 
         for name, m in models.items():
             write({k: v.detach().cpu() for k, v in m.state_dict().items()}, model_file(name))
@@ -313,7 +317,24 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
         for name, obj in (("manifest", manifest), ("normalization", normalization)):
             if obj is not None:
                 write(obj.state_dict(), f"custom_checkpoint_{CUSTOM_ORDER.index(name)}.pkl")
+        # every file of this save exists: invalidate the old marker, move the files into place, write the new marker
+        marker = osp.join(path, COMPLETE_MARKER)
+        if osp.exists(marker):
+            os.unlink(marker)
+        import json as _json
+        import hashlib as _hl
+        sums = {}
+        for tmp, final, name in staged:
+            with open(tmp, "rb") as fh:
+                sums[name] = _hl.sha1(fh.read()).hexdigest()
+            os.replace(tmp, final)
+        mt = marker + f".tmp{os.getpid()}"
+        tmps.append(mt)
+        with open(mt, "w") as fh:
+            _json.dump({"files": sums}, fh)
+        os.replace(mt, marker)
 
+    staged = []
     err = None
     if not multi or dist.get_rank() == 0:
         try:
@@ -326,8 +347,11 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
                 except OSError:
                     pass
     if multi:
-        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32,
-                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        # (NCCL needs a device tensor: the trainer's device if there is one, else this process's current device)
+        dev = "cpu"
+        if dist.get_backend() == "nccl":
+            dev = getattr(trainer, "device", None) or torch.device("cuda", torch.cuda.current_device())
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
         dist.broadcast(flag, 0)  # also the closing barrier: nobody returns before rank 0 has finished writing
         if err is None and int(flag.item()):
             err = L.StyError(f"save_checkpoint: rank 0 failed to write {path}")
@@ -336,25 +360,64 @@ def save_checkpoint(path, models, manifest=None, normalization=None, optimizers=
     return path
 
 
+COMPLETE_MARKER = "stylish_tts_amd.complete.json"  # written LAST by save_checkpoint: {"files": {name: sha1}} of that save
+
+
+def _check_complete(path, names):
+    """A directory this package wrote carries a completion marker listing the files of its last save with their checksums.  If
+    the marker is there, every file we are about to load that the marker lists must still be the file of that save (an
+    interrupted later save moved some files and not others); a directory without a marker (one the reference wrote) loads as is."""
+    import hashlib
+    import json
+    f = osp.join(path, COMPLETE_MARKER)
+    if not osp.exists(f):
+        if any(n.startswith(".") and ".tmp" in n for n in os.listdir(path)):
+            raise L.StyError(f"{path}: temporary files of an unfinished save_checkpoint and no completion marker")
+        return
+    listed = json.load(open(f))["files"]
+    for n in names:
+        p = osp.join(path, n)
+        if n in listed and osp.exists(p):
+            with open(p, "rb") as fh:
+                if hashlib.sha1(fh.read()).hexdigest() != listed[n]:
+                    raise L.StyError(f"{p} is not the file the last complete save_checkpoint wrote (interrupted save?)")
+
+
 def load_checkpoint(path, models, manifest=None, normalization=None, strict=True, optimizers=None, disc_helpers=None,
-                    trainer=None):
+                    trainer=None, allow_mixed_steps=False):
     """Load what save_checkpoint / the reference's accelerator.save_state wrote for the models (and optimizers / loss
     helpers) given.  A missing optimizer file is an error when an optimizer was asked for: resuming with zero moments is
     a different training run.  `trainer` is accepted so that `load_checkpoint(path, **trainer.checkpoint_state())` mirrors
-    the save call (nothing of it is needed: load_state_dict on the shells already invalidates the packed weights)."""
+    the save call (nothing of it is needed: load_state_dict on the shells already invalidates the packed weights).
+    allow_mixed_steps: passed to FlatAdamW.load_state_dict -- an early reference checkpoint written under
+    DDP(find_unused_parameters=True) holds per-parameter step counts that differ."""
     del trainer
+    # everything is READ and checked before anything is applied: a refused file (missing, torn save, optimizer state that does
+    # not fit, mixed step counts without allow_mixed_steps) leaves models and optimizers as they were
+    _check_complete(path, [model_file(n) for n in models] + [optimizer_file(n) for n in (optimizers or {})])
+    msd, osd = {}, {}
     for name, m in models.items():
         f = osp.join(path, model_file(name))
         if not osp.exists(f):
             raise L.StyError(f"{f} not found ({name} is model {MODEL_ORDER.index(name)} of the reference's build_model order)")
         sd = torch.load(f, map_location="cpu", weights_only=True)
-        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}  # a DDP-wrapped save
-        m.load_state_dict(sd, strict=strict)
+        msd[name] = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}  # a DDP-wrapped save
     for name, o in (optimizers or {}).items():
         f = osp.join(path, optimizer_file(name))
         if not osp.exists(f):
             raise L.StyError(f"{f} not found (optimizer of {name}); pass optimizers=None for a weights-only load")
-        o.load_state_dict(torch.load(f, map_location="cpu", weights_only=True))
+        osd[name] = torch.load(f, map_location="cpu", weights_only=True)
+    applied = []
+    try:
+        for name, o in (optimizers or {}).items():  # (validates before it mutates; optimizers first: they are the picky ones)
+            applied.append((o, o.state_dict()))
+            o.load_state_dict(osd[name], allow_mixed_steps=allow_mixed_steps)
+    except Exception:
+        for o, old_sd in applied[:-1]:  # the one that raised is untouched; put back the ones loaded before it
+            o.load_state_dict(old_sd, allow_mixed_steps=True)
+        raise
+    for name, m in models.items():
+        m.load_state_dict(msd[name], strict=strict)
     if disc_helpers:
         f = osp.join(path, f"custom_checkpoint_{CUSTOM_ORDER.index('discriminator_loss')}.pkl")
         if osp.exists(f):

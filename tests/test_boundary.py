@@ -179,3 +179,83 @@ def test_bench_line_fits_the_drivers_record():
         assert "kernels" not in back and "single_stream_kernels" not in back
         for e in back.get("extra", {}).values():
             assert set(e) <= {"ms_per_step", "value", "roofline", "hbm_counter_GBps", "hbm_counter_source"}
+
+
+def test_bench_roofline_joins_the_committed_profiles_by_instantiation():
+    """Round 5's driver line carried `rocprof_avg_launch_us: null` / `traffic: null`: the join from the library's family label
+    to rocprofv3's instantiation name compared template arguments as strings ("true" vs "0").  The library now reports the
+    instantiation itself (`sty_prof_row.inst`); this test joins such names to the committed round-5 files: non-null, the
+    figures of the file's own rows, and the roofline's kernel is the file's top row whatever the warm-up table's order is."""
+    import bench
+    inst = "convp16_kernel<2, 0, 0, true, true>"
+    us, src = bench.rocprof_avg_us([inst], "c3")
+    assert src and src.endswith("_c3_kernel_stats.txt")
+    rows, _ = bench.rocprof_rows("c3")
+    assert rows
+    top = rows[0]
+    if bench._same_kernel(inst, top[2]):  # (true of round 5's file; a later round's top row may be another kernel)
+        assert us is not None and abs(us - top[1] / top[0]) < 1e-6
+    tr, tsrc = bench.pmc_traffic([inst], "c3")
+    if us is not None:
+        assert tr is not None and tr > 0 and tsrc.endswith("_c3_pmc_traffic.json")
+    # names the tracer prints for kernels in an anonymous namespace, with an argument list, cut short by the old summary tool
+    assert bench._same_kernel("attn16_bwd_kv_kernel",
+                              "sty::(anonymous namespace)::attn16_bwd_kv_kernel(sty::AttnArgs, float const*, unsigned long, float const*, ...")
+    assert bench._same_kernel("convk1_kernel<0, 0>", "void sty::convk1_kernel<0, 0>(sty::ConvArgs, int, int, int, int)")
+    assert not bench._same_kernel("convk1_kernel<0, 0>", "void sty::convk1_kernel<6, 0>(sty::ConvArgs, int, int, int, int)")
+    assert not bench._same_kernel("convp16_kernel<2, 0, 0, true, true>", "void sty::convp16_kernel<2, 0, 0, false, false>(sty::ConvArgs, int, int, int, int)")
+    # the dominant kernel = the committed summary's top row, found among this run's (family, instantiation) rows
+    tname = bench.norm_kernel_name(top[2])[0]
+    fake = [dict(name="other_kernel", inst="other_kernel<1>", launches=10, ms=99.0, flops=0.0, bytes=0.0),
+            dict(name="family_of_top", inst=top[2], launches=22, ms=5.0, flops=1.0, bytes=1.0)]
+    fam, ins, how = bench.pick_dominant(fake, "c3")
+    assert fam == "family_of_top" and bench.norm_kernel_name(ins)[0] == tname and "top row" in how
+    # a library whose kernels the committed profile does not know: the largest of the warm-up table, and it says so
+    fam, ins, how = bench.pick_dominant(fake[:1], "c3")
+    assert fam == "other_kernel" and "largest" in how
+    # every workload with a committed summary joins its own top row (c5: the tolerance-meeting vocoder figure)
+    for wl in ("c5", "c5-bf16", "c2"):
+        rws, _ = bench.rocprof_rows(wl)
+        assert rws, wl
+        u, _ = bench.rocprof_avg_us([rws[0][2]], wl)
+        t, _ = bench.pmc_traffic([rws[0][2]], wl)
+        assert u is not None and t is not None, wl
+
+
+def _default_config_yaml(dataset_path, **plan):
+    """A config.yml with the reference's sections and field names (config/config.yml), assembled the way _default_model_yaml
+    assembles model.yml; `plan` overrides training_plan entries."""
+    tp = {s: dict(epochs=1, probe_batch_max=2, lr=1e-4) for s in ("alignment", "acoustic", "textual", "style", "joint", "duration")}
+    for k, v in plan.items():
+        tp[k].update(v)
+    d = dict(training=dict(log_interval=1, save_interval=1000, val_interval=1000, device="cuda", mixed_precision="no",
+                           vram_reserve=200, data_workers=0),
+             training_plan=tp,
+             dataset=dict(path=str(dataset_path), train_data="training-list.txt", val_data="validation-list.txt",
+                          wav_path="wav-dir", pitch_path="pitch.safetensors", alignment_path="alignment.safetensors",
+                          alignment_model_path="alignment_model.safetensors"),
+             validation=dict(sample_count=2),
+             loss_weight=dict(mel=5, generator=1, slm=0.2, pitch=8, energy=8, duration=8, duration_ce=8, style=1, mag=1,
+                              phase=8, voiced=1, multi_phase=8, confidence=1, align_loss=1, discriminator=1))
+    return yaml.safe_dump(d)
+
+
+def test_train_entry_point_refuses_to_run_without_a_device(tmp_path):
+    """`train(config_path, model_config_path, out, stage, checkpoint, reset_stage)` (train/cli.py:283-304) exists and fails
+    loudly where it cannot run: no HIP device here, and there is no CPU training path to fall back on; an unknown stage and
+    a missing dataset are named."""
+    from stylish_tts_amd import train as T
+    from stylish_tts_amd.lib import StyError
+    cfg, mdl = tmp_path / "config.yml", tmp_path / "model.yml"
+    cfg.write_text(_default_config_yaml(tmp_path / "nowhere"))
+    mdl.write_text(_default_model_yaml())
+    with pytest.raises(StyError, match="not a valid stage"):
+        T.train(str(cfg), str(mdl), str(tmp_path / "out"), "alignment")
+    if not torch.cuda.is_available():
+        with pytest.raises(StyError, match="no HIP device"):
+            T.train(str(cfg), str(mdl), str(tmp_path / "out"), "acoustic")
+    with pytest.raises(StyError, match="model config path is required"):
+        T.train(str(cfg), "", str(tmp_path / "out"), "acoustic")
+    assert T.NEXT_STAGE == {"acoustic": "textual", "textual": "duration", "duration": None}
+    with pytest.raises(SystemExit):
+        T.main(["--help"])

@@ -130,7 +130,9 @@ def test_save_checkpoint_is_collective_and_only_rank0_writes(tmp_path):
         assert p.exitcode == 0
     for rank, wrote_before, files, w00, buf in res:
         assert not wrote_before
-        assert files == sorted(["pytorch_model_3.bin", "custom_checkpoint_2.pkl", "custom_checkpoint_3.pkl"]), files
+        # (round 6: + the completion marker, written last -- load_checkpoint refuses a directory whose files do not match it)
+        assert files == sorted(["pytorch_model_3.bin", "custom_checkpoint_2.pkl", "custom_checkpoint_3.pkl",
+                                "stylish_tts_amd.complete.json"]), files
         assert w00 == 1.0          # rank 0's parameters, also as seen from rank 1
         assert buf == [0.0] * 4    # rank 0's buffer after sync_buffers
 

@@ -254,7 +254,7 @@ def test_c3_train_step_full_size_vs_oracle():
       d(HIP bf16, f64)  <=  1.5 x d(bf16-operand oracle, f64) -- the oracle under oracle.blocks.bf16_operands() (the SAME rounding
                             rule, storage rounding points included), measured on the first chunk of 8 utterances (both sides
                             differentiate the same function: the chunk's share of the step's loss with the step's detached
-                            normalisers), floors 1e-1 / 1e-2 / 5 %, caps 0.9 / 0.45 / 25 %.
+                            normalisers), floors 1e-1 / 1e-2 / 10 %, caps 0.5 / 0.1 / 25 % (GATE16_FLOOR / GATE16_CAP above).
     The per-tensor table goes to gpurun_out/c3_parity_table.txt (committed as profiles/r05_c3_parity_table.txt).
     fp32 forward gates: audio MSE 1e-8 / mel-L1 1e-3, mel loss 1e-4, multi-phase loss 1e-3; bf16: losses 1e-3, waveform
     error 2e-2 of the signal power, mel-L1 3e-2."""

@@ -463,6 +463,7 @@ def test_convnext32_two_byte_gradients_vs_float64_oracle_with_the_same_rounding_
         y64 = blocks.round_grad(blocks.convnext_block(P64, prefix, x64, s64, grad16=True))
         (y64 * gy.double()).sum().backward()
     monkeypatch.setenv("STY_BLOCK_G16", "1")
+    monkeypatch.setenv("STY_GRAD16_STREAM", "1")  # (round 6: the stream's two-byte gradient is opt-in; gU alone is the default)
     gxs = {}
     for g16 in (True, False):
         if g16:
@@ -1802,7 +1803,11 @@ def test_dense_conv1d_vs_torch(shape, compute):
 
 
 @pytest.mark.parametrize("shape", [(3, 128, 130, 1, 1, 64), (2, 512, 64, 3, 1, 38), (2, 96, 200, 3, 1, 300), (2, 64, 96, 3, 1, 1000),
-                                   (3, 130, 33, 5, 1, 258), (48, 240, 80, 3, 1, 1500), (2, 64, 64, 3, 1, 1001)])
+                                   (3, 130, 33, 5, 1, 258), (48, 240, 80, 3, 1, 1500), (2, 64, 64, 3, 1, 1001),
+                                   # round 6, convq_kernel (K = 1 / 3, T % 4 == 0): tile edges (T = 256 k +- 4), Cout 80 / 160 / 384
+                                   # on 96-cout tiles, channel counts that are no multiple of 8 / 32, one tile, many chunks
+                                   (2, 160, 160, 3, 1, 2620), (3, 130, 84, 3, 1, 252), (2, 72, 384, 3, 1, 260), (1, 64, 80, 1, 1, 516),
+                                   (2, 1152, 96, 3, 1, 256), (5, 80, 97, 1, 1, 1028)])
 def test_persistent_conv16_on_bf16_operand_twins_vs_torch(shape, monkeypatch):
     """convp16_kernel reading its input as a bf16 operand twin (ConvArgs::x16: two-byte loads, no conversion, no prologue)
     and writing the twin of its OUTPUT from the output stage (ConvArgs::y16, here LeakyReLU(0.2)(y) rounded to bf16): forward
@@ -1814,6 +1819,7 @@ def test_persistent_conv16_on_bf16_operand_twins_vs_torch(shape, monkeypatch):
     from stylish_tts_amd import lib as L
     lib = L.load()
     monkeypatch.setenv("STY_CONVP16_MIN_TILES", "1")
+    monkeypatch.setenv("STY_CONVQ_MIN_TILES", "1")  # (the twin path's kernel since round 6 where K = 1 / 3 and T % 4 == 0)
     B, Ci, Co, K, d, T = shape
     g = torch.Generator().manual_seed(sum(shape))
     x, w, b = torch.randn(B, Ci, T, generator=g), torch.randn(Co, Ci, K, generator=g) / (Ci * K) ** 0.5, torch.randn(Co, generator=g)
@@ -1846,7 +1852,9 @@ def test_persistent_conv16_on_bf16_operand_twins_vs_torch(shape, monkeypatch):
         finally:
             lib.sty_prof_enable(0)
         rows = L.prof_report(256)
-        assert sum(r["launches"] for r in rows if r["name"].startswith("convp16_kernel")) >= 2, rows
+        assert sum(r["launches"] for r in rows if r["name"].startswith(("convp16_kernel", "convq_kernel"))) >= 2, rows
+        if mode == 2 and K in (1, 3) and T % 4 == 0:
+            assert sum(r["launches"] for r in rows if r["name"].startswith("convq_kernel")) >= 2, rows
         out[mode] = (y.cpu(), dx.cpu())
         if mode == 2:  # the output twin: [B][Ci][T] bf16 of the input, then [B][Co][T] bf16 of lrelu(y)
             base = (ws.data_ptr() + need.value + 255) // 256 * 256 - ws.data_ptr()
@@ -2337,6 +2345,66 @@ def test_training_from_sample_dataset_files(tmp_path, env):
         seen += kw["audio_gt"].shape[0]
     torch.cuda.synchronize()
     assert seen == len(lines)
+
+
+def test_train_entry_point_runs_c1_from_the_yaml_files(tmp_path):
+    """BASELINE.json configs[0] (c1): "sample_dataset single-speaker, batch=2 ... via config/config.yml" as a CONFIG, not a test
+    body: config.yml + model.yml (the reference's sections and field names) -> stylish_tts_amd.train.train(...) -> three
+    train_acoustic steps at batch 2 (adversarial terms on, as the reference's stage has them) -> accelerate-layout
+    checkpoint_final with manifest / normalization; then the same command with --checkpoint resumes (optimizer step counts
+    continue), and the NEXT stage (textual, stage_type.py:394) starts from the acoustic checkpoint with the speech predictor
+    frozen; a duration step closes the chain."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_sample_dataset import make
+    from stylish_tts_amd import stage_io as IO
+    from stylish_tts_amd import train as T
+    from tests.test_boundary import _default_config_yaml, _default_model_yaml
+    root = tmp_path / "data"
+    make(str(root), 8, 11)
+    cfg, mdl, out = tmp_path / "config.yml", tmp_path / "model.yml", tmp_path / "out"
+    cfg.write_text(_default_config_yaml(root, acoustic=dict(epochs=3)))
+    mdl.write_text(_default_model_yaml())
+    import json
+    logs = []
+    ctx = T.train(str(cfg), str(mdl), str(out), "acoustic", max_steps=3, log=logs.append)
+    torch.cuda.synchronize()
+    assert ctx.manifest.current_total_step == 3 and ctx.manifest.stage == "acoustic"
+    assert ctx.normalization.frames > 0  # computed from the train split, written beside the stage and the dataset
+    final = os.path.join(str(out), "acoustic", "checkpoint_final")
+    for k in ("speech_predictor", "speech_style_encoder", "mrd0", "mrd1", "mrd2", "disc"):
+        assert os.path.exists(os.path.join(final, IO.model_file(k))), k
+        assert os.path.exists(os.path.join(final, IO.optimizer_file(k))), k
+    assert os.path.exists(os.path.join(final, IO.COMPLETE_MARKER))
+    assert os.path.exists(os.path.join(str(out), "acoustic", "config.yml"))
+    assert json.load(open(os.path.join(str(out), "acoustic", "acoustic_batch_sizes.json")))  # every bin at probe_batch_max = 2
+    assert any("acoustic epoch" in ln for ln in logs)
+    w_before = ctx.models["speech_predictor"].state_dict()["decoder.asr_res.0.weight"].clone() if \
+        "decoder.asr_res.0.weight" in ctx.models["speech_predictor"].state_dict() else None
+    t_before = ctx.stage.trainer.opt["speech_predictor"].t
+    assert t_before == 3
+    del ctx
+    # resume in the same stage
+    ctx = T.train(str(cfg), str(mdl), str(out), "acoustic", checkpoint=final, max_steps=1, log=logs.append)
+    assert ctx.manifest.current_total_step == 4 and ctx.stage.trainer.opt["speech_predictor"].t == 4
+    if w_before is not None:
+        assert ctx.models["speech_predictor"].state_dict()["decoder.asr_res.0.weight"].shape == w_before.shape
+    del ctx
+    # the next stage from the acoustic checkpoint: trained models are new, the frozen speech predictor comes from the file
+    sp_file = torch.load(os.path.join(final, IO.model_file("speech_predictor")), weights_only=True)
+    ctx = T.train(str(cfg), str(mdl), str(out), "textual", checkpoint=final, max_steps=1, log=logs.append)
+    torch.cuda.synchronize()
+    assert ctx.manifest.stage == "textual" and ctx.manifest.current_step == 1
+    k0 = next(k for k, v in sp_file.items() if v.is_floating_point() and v.ndim > 1)
+    got = ctx.models["speech_predictor"].state_dict()[k0].cpu()
+    # (resumed one more step above: the file holds the state after step 4)
+    sp4 = torch.load(os.path.join(final, IO.model_file("speech_predictor")), weights_only=True)[k0]
+    assert torch.equal(got, sp4)
+    assert os.path.exists(os.path.join(str(out), "textual", "checkpoint_final", IO.model_file("pitch_energy_predictor")))
+    del ctx
+    ctx = T.train(str(cfg), str(mdl), str(out), "duration", max_steps=1, log=logs.append)
+    torch.cuda.synchronize()
+    assert os.path.exists(os.path.join(str(out), "duration", "checkpoint_final", IO.model_file("duration_predictor")))
+    assert any("duration epoch" in ln for ln in logs)
 
 
 def _free_port():

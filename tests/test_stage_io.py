@@ -201,6 +201,61 @@ def test_checkpoint_optimizer_and_discriminator_loss_files_are_accelerates(tmp_p
     assert dl.discriminators["mrd1"].last_loss == 0.77 and dl.discriminators["pitch_disc"].last_loss == 0.5
 
 
+def test_refused_checkpoints_leave_the_state_untouched(tmp_path):
+    """Round-5 advisor items: (1) a file with mixed per-parameter step counts (an early reference checkpoint under
+    DDP(find_unused_parameters=True)) is refused BEFORE lr / betas / moments are overwritten and loads through
+    load_checkpoint(allow_mixed_steps=True); (2) a save that died between its os.replace calls -- new model file, old optimizer
+    file -- is refused by load_checkpoint instead of loading the mix; a failed write leaves the directory as it was."""
+    from stylish_tts_amd import stage_io as IO
+    from stylish_tts_amd.optim import FlatAdamW
+    torch.manual_seed(5)
+    net = torch.nn.Linear(3, 2)
+    ref = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4, betas=(0.85, 0.99), eps=1e-9)
+    net(torch.randn(4, 3)).sum().backward()
+    ref.step()
+    net.bias.grad = None  # the bias lags from here on
+    net(torch.randn(4, 3)).sum().backward()
+    net.bias.grad = None
+    ref.step()
+    sd = ref.state_dict()
+    assert sorted(int(float(v["step"])) for v in sd["state"].values()) == [1, 2]
+    d = str(tmp_path / "ck")
+    os.makedirs(d)
+    torch.save(net.state_dict(), os.path.join(d, IO.model_file("speech_predictor")))
+    torch.save(sd, os.path.join(d, IO.optimizer_file("speech_predictor")))
+    mine = torch.nn.Linear(3, 2)
+    w0 = mine.weight.detach().clone()
+    opt = FlatAdamW(list(mine.named_parameters()), lr=7e-4)
+    opt.t = 3
+    opt.m[0].fill_(0.25)
+    with pytest.raises(Exception, match="different step counts"):
+        IO.load_checkpoint(d, {"speech_predictor": mine}, optimizers={"speech_predictor": opt})
+    assert opt.lr == 7e-4 and opt.t == 3 and bool((opt.m[0] == 0.25).all()) and torch.equal(mine.weight, w0)
+    with pytest.warns(UserWarning, match="different step counts"):
+        IO.load_checkpoint(d, {"speech_predictor": mine}, optimizers={"speech_predictor": opt}, allow_mixed_steps=True)
+    assert opt.t == 2 and opt.lr == 2e-4 and torch.equal(mine.weight, net.weight)
+    # (2) a complete save, then a torn one
+    d2 = str(tmp_path / "ck2")
+    IO.save_checkpoint(d2, {"speech_predictor": mine}, optimizers={"speech_predictor": opt})
+    assert os.path.exists(os.path.join(d2, IO.COMPLETE_MARKER))
+    IO.load_checkpoint(d2, {"speech_predictor": mine}, optimizers={"speech_predictor": opt})
+    torch.save({k: v + 1 for k, v in mine.state_dict().items()}, os.path.join(d2, IO.model_file("speech_predictor")))  # moved in, then the crash
+    with pytest.raises(Exception, match="interrupted save"):
+        IO.load_checkpoint(d2, {"speech_predictor": mine}, optimizers={"speech_predictor": opt})
+    # a write that fails (the optimizer cannot be serialised) leaves every file of the previous save in place and no temp files
+    d3 = str(tmp_path / "ck3")
+    IO.save_checkpoint(d3, {"speech_predictor": mine}, optimizers={"speech_predictor": opt})
+    before = {n: open(os.path.join(d3, n), "rb").read() for n in os.listdir(d3)}
+
+    class Broken:
+        def state_dict(self):
+            raise RuntimeError("disk full")
+
+    with pytest.raises(RuntimeError, match="disk full"):
+        IO.save_checkpoint(d3, {"speech_predictor": net}, optimizers={"speech_predictor": Broken()})
+    assert {n: open(os.path.join(d3, n), "rb").read() for n in os.listdir(d3)} == before
+
+
 def test_normalization_priority_and_json_layout(tmp_path, monkeypatch):
     from stylish_tts_amd import stage_io as IO
     from stylish_tts_amd.config import Section

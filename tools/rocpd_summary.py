@@ -14,8 +14,8 @@ def main(path):
     print(f"# total kernel time {tot / 1e3:.3f} ms over {sum(r[1] for r in rows)} dispatches (durations in us)")
     print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'pct':>6}  name")
     for name, calls, total, avg, pct in rows:
-        short = name if len(name) < 110 else name[:107] + "..."
-        print(f"{calls:7d} {total:12.1f} {avg:10.2f} {pct:6.2f}  {short}")
+        # the whole name: bench.py joins its roofline to these rows by instantiation (rounds 1-5 cut names at 107 characters)
+        print(f"{calls:7d} {total:12.1f} {avg:10.2f} {pct:6.2f}  {name}")
 
 
 if __name__ == "__main__":
