@@ -461,6 +461,10 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
     if dom_name:
         lib.sty_prof_only(dom_name.split(" ")[0].encode())  # STY_PROF_SHAPES appends the shape to the family name
         lib.sty_prof_enable(1)
+    if trainer is not None:  # how long each step's AdamW stands still for the gradient exchange (events around GradBuckets.finish)
+        for o in trainer.opt.values():
+            o.grads.exposed = []
+            o.grads.measure_exposed = True
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -499,6 +503,28 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
         lib.sty_set_single_stream(0)
         trainer.single_stream = False
     barrier()
+    exposed_ms = 0.0
+    if trainer is not None:
+        for o in trainer.opt.values():
+            o.grads.measure_exposed = False
+            exposed_ms += o.grads.exposed_ms()
+    rank_view = None
+    if world > 1 or D.collectives_on():
+        # every rank's own step time and exposed exchange time (the driver's first 8-GPU run should say WHICH rank is the
+        # straggler and whether the wire or the host is what it waits for)
+        mine = torch.tensor([1e3 * dt / steps, exposed_ms / steps, 1e3 * host_dt / steps], dtype=torch.float64, device=device)
+        if world > 1:
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        rank_view = {"per_rank_ms": [float(t[0]) for t in allr], "allreduce_exposed_ms": [float(t[1]) for t in allr],
+                     "host_issue_ms": [float(t[2]) for t in allr],
+                     "exchange": ("library communicator (sty_comm_*: ncclReduceScatter + ncclAllGather on the library's stream)"
+                                  if D.native_comm() is not None else "torch.distributed all_reduce"),
+                     "env": {k: v for k, v in os.environ.items()
+                             if k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "STY_NO_NATIVE_COMM")
+                             or k.startswith(("NCCL_", "RCCL_"))}}
     dt = D.max_over_ranks(dt, device)
     if synth is not None:
         T = out.shape[-1] // 300  # frames the duration predictor asked for (same inputs every step)
@@ -530,6 +556,8 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                    "x_realtime": frames / dt / 80.0},
         "host_issue_ms_per_step": 1e3 * host_dt / steps,
     }
+    if rank_view:
+        rec["rank_view"] = rank_view
     if phases:
         rec["phases_ms"] = phases
     if w["what"] == "vocoder":
@@ -685,7 +713,10 @@ def format_line(rec, detail_path=None):
         rk = dict(rec["ranks"])
         r1 = rk.get("rccl_world1")
         if isinstance(r1, dict) and "error" not in r1:
-            rk["rccl_world1"] = {k: r1[k] for k in ("ms_per_step", "vs_no_process_group", "GPU_MAX_HW_QUEUES") if k in r1}
+            rk["rccl_world1"] = {k: r1[k] for k in ("ms_per_step", "vs_no_process_group", "GPU_MAX_HW_QUEUES", "allreduce_exposed_ms",
+                                                    "exchange") if k in r1}
+        if isinstance(rk.get("exchange"), str):
+            rk["exchange"] = rk["exchange"].split(" (")[0]
         line["ranks"] = rk
     if rec.get("extra"):
         line["extra"] = {}
@@ -815,6 +846,7 @@ def main():
     backend = torch.distributed.get_backend() if world > 1 else None
     if world > 1:
         torch.distributed.barrier()
+        D.destroy_native_comm()
         torch.distributed.destroy_process_group()
     rccl1 = None
     if world == 1 and args.workload == "c3" and not args.no_extra and not share and not args.rccl1:
@@ -840,6 +872,8 @@ def main():
                              "(bench.py --rccl1 in a child process)",
                      "ms_per_step": r["ms_per_step"], "vs_no_process_group": r["ms_per_step"] / rec["ms_per_step"],
                      "host_issue_ms_per_step": r["host_issue_ms_per_step"], "backend": "nccl (RCCL)",
+                     "allreduce_exposed_ms": (r.get("ranks") or {}).get("allreduce_exposed_ms"),
+                     "exchange": (r.get("ranks") or {}).get("exchange"),
                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
         except Exception as e:  # never fail the bench line on this
             rccl1 = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -849,6 +883,7 @@ def main():
     rec["ranks"] = {"world_size": world, "launcher": "torch.distributed.run, one process per GPU" if world > 1 else "single process",
                     "backend": (backend + (" (RCCL)" if not share else " (share-device test aid)")) if world > 1 else None,
                     "devices": 1 if share else world}
+    rec["ranks"].update(rec.pop("rank_view", None) or {})
     if rccl1 is not None:
         rec["ranks"]["rccl_world1"] = rccl1
     if extras:

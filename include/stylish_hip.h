@@ -445,6 +445,24 @@ int sty_acoustic_gan_loss_fwd_bwd(int B, int N, const float *audio_gt, const flo
                                   float *d_audio_pred, void *workspace, size_t ws_bytes, void *gan_workspace,
                                   size_t gan_ws_bytes, int compute_bf16, void *stream);
 
+/* ---- gradient exchange of the data-parallel step ---------------------------------------------
+ * Replaces what the reference gets from accelerate's per-module DDP wrappers (train/train_context.py:94-104,
+ * train/train.py:208-211: bucketed gradient all-reduce over NCCL): one communicator per process (one process per GPU) over
+ * RCCL, on a HIP stream the LIBRARY owns.  The rank that calls sty_comm_unique_id hands the 128 bytes to the others by any
+ * side channel (stylish_tts_amd/dist.py: one broadcast through torch.distributed), every rank then calls sty_comm_init
+ * (collective: it returns when all `world` ranks have called it).  stream_priority: < 0 lowest, 0 default, > 0 highest.
+ * sty_comm_allreduce_bucket(buf, n): buf[0..n) := sum over ranks, in place, asynchronously on the communicator's stream, ordered
+ * BEHIND everything `producer_stream` holds at the time of the call; as ncclReduceScatter + ncclAllGather when n is a multiple
+ * of 4 * world, ncclAllReduce otherwise.  sty_comm_wait makes `consumer_stream` wait for every bucket handed over so far (no
+ * host synchronisation).  RCCL is resolved with dlopen at the first call (STY_RCCL_LIB overrides the name).               */
+typedef struct sty_comm sty_comm;
+int sty_comm_unique_id(void *id128);
+int sty_comm_init(const void *id128, int rank, int world, int stream_priority, sty_comm **out);
+int sty_comm_allreduce_bucket(sty_comm *c, float *buf, size_t n, void *producer_stream);
+int sty_comm_wait(sty_comm *c, void *consumer_stream);
+int sty_comm_stats(sty_comm *c, uint64_t *buckets, uint64_t *reduce_scatter_all_gather, double *bytes);
+int sty_comm_destroy(sty_comm *c);
+
 /* ---- in-situ kernel timing (used by bench.py for the roofline object) --------------------------------
  * When enabled, every launch of the instrumented kernel families is bracketed by HIP events on the launch
  * stream.  sty_prof_report synchronises the device, sums the event times per family and writes up to `cap`

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstylish_hip.so")
 SOURCES = ["api.hip", "conv1d.hip", "convnext.hip", "norms.hip", "attn.hip", "source.hip", "misc.hip", "conv2d.hip",
-           "frontend.hip", "bwd.hip", "wgrad.hip", "attn_bwd.hip", "train.hip", "optim.hip", "convnext_bwd.hip", "predictors.hip", "conv32p.hip", "convp16.hip", "wgradb.hip", "disc.hip", "cfdisc.hip", "convk1.hip", "attn16.hip", "convq.hip"]
+           "frontend.hip", "bwd.hip", "wgrad.hip", "attn_bwd.hip", "train.hip", "optim.hip", "convnext_bwd.hip", "predictors.hip", "conv32p.hip", "convp16.hip", "wgradb.hip", "disc.hip", "cfdisc.hip", "convk1.hip", "attn16.hip", "convq.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -847,6 +847,9 @@ struct Run {
       at.H = 8;
       at.scale = 1.0f / sqrtf((float)(inner / 8));
       at.lengths = nullptr;
+      at.bf16 = m->topts.compute_bf16;  // (round 6) bf16 mode: the conformer's attention on the bf16 matrix cores in the inference
+                                        // plan as well (attn16.hip, as the training graph since round 4; c5-bf16: 242 us per forward
+                                        // on the fp32 kernel)
       chk(launch_attention(at, B, inner / 8, st));
       ConvArgs ao = base(c.to_out, o, T, x2);
       ao.residual = xff1;

@@ -27,8 +27,12 @@
 //   * weights: the bf16 A fragments of convp16.hip (frag_pack_kernel), one 16-byte load + one lane-linear ds_write_b128;
 //   * the SAME reduction order as convp16_kernel (chunk, tap, 16-channel half), so results are bit-identical to it: the
 //     operand-twin tests compare the two kernels bit for bit;
-//   * epilogue straight from the accumulators (a register's 32 lanes are 32 consecutive columns = one 128-byte run per
-//     row): bias, ReLU, scale, masks, residual -- q_drain's operation order -- fp32 store + the bf16 twin of the output.
+//   * loads run TWO chunks ahead of their commit in two register sets, every path issuing the same number of them (exact
+//     s_waitcnt, as in convp16.hip);
+//   * epilogue: a row block's accumulators (lane = column) pass through a 32 x 64 LDS stage of the wave's own and leave as
+//     rows -- 16-byte stores of y, 8-byte stores of its bf16 twin (first version: 96 dword + 96 two-byte stores per lane
+//     straight from the accumulators -- a third of the kernel's time on the Cout = 80 layers); bias, ReLU, scale, masks,
+//     residual in q_drain's operation order.
 #include <stdlib.h>
 
 #include "sty_common.h"
@@ -44,8 +48,12 @@ constexpr int CQ_XB = CQ_LW * 64;  // bytes per X buffer
 
 __device__ __forceinline__ int cq_xaddr(int L, int g) { return L * 64 + ((g ^ ((L >> 2) & 3)) << 4); }
 
-template <int MB, int K, int RELU>
+// DBG (STY_CQ_DBG=mask, timing experiments only -- wrong results): 1 no tile loads, 2 no weight loads, 4 no commits (LDS writes),
+// 8 no fragment reads + MFMAs, 16 no epilogue, 32 fragment reads but no MFMAs
+// (compile-time: a run-time switch around the MFMAs makes the allocator keep two copies of the accumulators)
+template <int MB, int K, int RELU, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per_row, int ncot, int ntiles, int per_xcd) {
+  constexpr int dbg = DBG;
   extern __shared__ __attribute__((aligned(16))) unsigned char cq_lds[];
   constexpr int J = 2 * K;             // k-steps of 16 channels per chunk
   constexpr int NFR = J * MB;          // A fragments per chunk
@@ -87,44 +95,69 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
   int ci = 8 * g, kh = 0;      // position of the NEXT chunk to load: source row of the thread's first row, image-row tap
   int hci = hch, hkh = 0;
   int achunk = 0;              // ... and its chunk number (fragment address)
-  struct Set {
+  struct XSet {
     unsigned x[8][2];          // eight rows x (two dwords = four samples)
-    unsigned h;                // the halo element (low half)
-    uint4 av[NFW];             // weight fragments
+    unsigned short h;          // the halo element (kept as loaded: a zero-extension here is scheduled into the MFMA loop, behind
+                               // a vmcnt(0) for the loads that were only just issued)
     int pos0;                  // source position of staged column j = 0 for the thread's row group
-  } S;
-  int faoff[NFW], fdst[NFW];   // per-wave fragment constants: byte offset within a chunk's fragments, LDS byte offset
-#pragma unroll
-  for (int i = 0; i < NFW; ++i) {
-    const int f = wave + 4 * i;
-    const bool ok = f < NFR;
-    const int j = f / MB, m = f - j * MB;
-    faoff[i] = ok ? ((j * NMB + cot * MB + m) * 64 + lane) * 16 : 0x7FFFFF00;
-    fdst[i] = ok ? (f * 64 + lane) * 16 : -1;
-  }
+  };
+  struct ASet {
+    uint4 av[NFW];             // weight fragments: fragment f = wave + 4 i of the chunk
+  };
+  // fragment f of a chunk: (k-step j = f / MB, row block m = f % MB); wave-uniform, so its address is scalar + lane * 16
+  const int lane16 = lane * 16;
+  const int adst0 = wave * 1024 + lane16;  // LDS byte offset of fragment f = wave (+ 4096 i)
+  int xchunk = 0;                          // chunk number of the next X request
   const int hL = 256 + hc;
   const int haddr = cq_xaddr(hL, hch >> 3) + (hch & 7) * 2;
 
-  auto issue = [&]() {
+  // Loads of a chunk: ALWAYS the same vector-memory instructions (8 + 1 for the tile, NFW for the weights), also for chunk numbers
+  // past the last one (their offsets lie outside the descriptors and return zero): with the same count on every path the
+  // compiler's s_waitcnt in front of a commit is vmcnt(loads issued after the awaited ones) instead of vmcnt(0) (convp16.hip).
+  int fso[NFW];    // scalar part of fragment f = wave + 4 i's address within a chunk (k-step j = f / MB, row block m = f % MB)
+  bool fok[NFW];
+#pragma unroll
+  for (int i = 0; i < NFW; ++i) {
+    const int f = wave + 4 * i;
+    const int j = f / MB, m = f - j * MB;
+    fso[i] = (j * NMB + cot * MB + m) * 1024;
+    fok[i] = f < NFR;
+  }
+  auto issue_a = [&](ASet& A) {
+    const bool live = achunk < nch && !(dbg & 2);
+    const int cbase = live ? achunk * (J * NMB * 1024) : 0;
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) {
+      // out of range through the VECTOR offset (the hardware range-checks that one, not the scalar offset)
+      const int vo = (int(live) & int(fok[i])) ? lane16 : 0x7FFFFF00;
+      A.av[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo, cbase + fso[i], 0));
+    }
+    ++achunk;
+  };
+  auto issue_x = [&](XSet& S) {
+    const bool live = xchunk < nch && !(dbg & 1);
     const int pos0 = t0 - a.pad + (flat ? (kh - a.hpad) * a.flatW : 0);
     S.pos0 = pos0;
     const int e = pos0 - (pos0 & 1) + 4 * q;  // even: dword-aligned loads (T is even)
+    // e == -2: samples (-2, -1, 0, 1) -- the load would start in front of the slab (row 0) or in the previous row, and a load
+    // that is partly outside the descriptor returns zeros as a whole: load (0, 1, 2, 3) instead, commit moves them up
+    const int el = e == -2 ? 0 : e;
     // (a negative offset is a huge unsigned one: outside the descriptor, returns zero -- the padding in front of the slab)
-    const int v0 = (ci * T + e) * 2;
+    const int v0 = (ci * T + el) * 2;
     const bool rows_in = ci + 8 <= crow;  // (wave-uniform; 1-D convs with Cin % 8 != 0 or CinP > Cin: rows past the slab read zero)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrs, (rows_in || ci + r < crow) ? v0 + r * T * 2 : 0x7FFFFF00, 0, 0);
+      // (bitwise, not short-circuit: a select, not a branch with the load in both arms)
+      const int ok = int(live) & (int(rows_in) | int(ci + r < crow));
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrs, ok ? v0 + r * T * 2 : 0x7FFFFF00, 0, 0);
       S.x[r][0] = v[0];
       S.x[r][1] = v[1];
     }
     const int hp = t0 - a.pad + (flat ? (hkh - a.hpad) * a.flatW : 0) + 255 + hc;
-    S.h = __builtin_amdgcn_raw_buffer_load_b16(xrs, (hp >= 0 && hp < T && hci < crow) ? (hci * T + hp) * 2 : 0x7FFFFF00, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NFW; ++i)
-      S.av[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, faoff[i], achunk * (J * NMB * 1024), 0));
+    const int hok = int(live) & int(hp >= 0) & int(hp < T) & int(hci < crow);
+    S.h = __builtin_amdgcn_raw_buffer_load_b16(xrs, hok ? (hci * T + hp) * 2 : 0x7FFFFF00, 0, 0);
     // next chunk
-    ++achunk;
+    ++xchunk;
     ci += 32;
     hci += 32;
     if (flat) {
@@ -138,13 +171,15 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
       }
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](XSet& S, const ASet& A, int buf) {
+    if constexpr ((dbg & 4) != 0) return;
     unsigned char* xb = xbuf + buf * CQ_XB;
     unsigned char* ab = abuf + buf * ABYTES;
     const int pos0 = S.pos0, d = pos0 & 1;
     // zero padding: positions outside [0, T) of the row.  Wave-uniform fast path: the whole staged range lies inside.
     if (!(pos0 - 1 >= 0 && pos0 + 263 < T)) {
       const int e = pos0 - d + 4 * q;
+      const bool up = e == -2;  // (see issue_x)
       unsigned mk[2];
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
@@ -153,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
+        S.x[r][1] = (up ? S.x[r][0] : S.x[r][1]) & mk[1];
         S.x[r][0] &= mk[0];
-        S.x[r][1] &= mk[1];
       }
     }
     // 2 x 2 transposes: (row r: samples s, s + 1), (row r + 1: samples s, s + 1) -> (sample s: rows r, r + 1), (sample s + 1: ...)
@@ -170,10 +205,11 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
       const int L = 4 * q - d + i + 1;
       *reinterpret_cast<uint4*>(xb + cq_xaddr(L, g)) = v;
     }
-    *reinterpret_cast<unsigned short*>(xb + haddr) = (unsigned short)S.h;
+    *reinterpret_cast<unsigned short*>(xb + haddr) = S.h;
 #pragma unroll
     for (int i = 0; i < NFW; ++i)
-      if (fdst[i] >= 0) *reinterpret_cast<uint4*>(ab + fdst[i]) = S.av[i];
+      if (4 * i + 3 < NFR || wave + 4 * i < NFR) *reinterpret_cast<uint4*>(ab + adst0 + 4096 * i) = A.av[i];  // (the first
+      // term is a compile-time constant: only the last fragment of a wave depends on the wave number)
   };
 
   // ---- consumer constants: byte offset of this lane's B fragment for (tap k, half s) relative to the wave's first column ----
@@ -192,14 +228,8 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  issue();
-  commit(0);
-  if (nch > 1) issue();
-  __syncthreads();
-  for (int c = 0; c < nch; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nch) commit(buf ^ 1);
-    if (c + 2 < nch) issue();
+  auto compute = [&](int buf) {
+    if constexpr ((dbg & 8) != 0) return;
     const unsigned char* xw = xbuf + buf * CQ_XB + wave * (64 * 64);
     const bf16x8* aw = reinterpret_cast<const bf16x8*>(abuf + buf * ABYTES) + lane;
     bf16x8 A0[MB], B0[2], A1[MB], B1[2];
@@ -209,6 +239,10 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
     _Pragma("unroll") for (int n = 0; n < 2; ++n) BV[n] = *reinterpret_cast<const bf16x8*>(xw + n * 2048 + boff[j]); \
   }
 #define CQ_MM(AV, BV)                                   \
+  if constexpr ((dbg & 32) != 0) {                        \
+    _Pragma("unroll") for (int m = 0; m < MB; ++m)        \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n][0] += (float)AV[m][0] + (float)BV[n][0]; \
+  } else                                                  \
   _Pragma("unroll") for (int m = 0; m < MB; ++m)        \
   _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = \
       __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV[m], BV[n], acc[m][n], 0, 0, 0);
@@ -222,10 +256,53 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
     }
 #undef CQ_LD
 #undef CQ_MM
+  };
+
+  // Loads run TWO chunks ahead of their commit in two register sets (a chunk's MFMAs are ~1 150 cycles, an L2 round trip ~2 000,
+  // an HBM one ~5 000).  Chunk c + 1 is committed to LDS buffer (c + 1) & 1 at the top of iteration c: every wave has finished
+  // reading that buffer at the barrier that ended iteration c - 1; chunk c + 3 is then requested into the set it leaves.  The
+  // wait in front of a commit is vmcnt(loads of the other set).
+  // ONE loop exit: with a `break` between the two halves the 96 accumulators reach the epilogue from two places and the
+  // allocator keeps two copies of them (256 registers + 64 spilled instead of 192).
+  XSet X0, X1;
+  ASet A0s, A1s;
+  issue_x(X0);      // chunk 0
+  issue_a(A0s);
+  issue_x(X1);      // chunk 1
+  issue_a(A1s);
+  commit(X0, A0s, 0);
+  issue_x(X0);      // chunk 2
+  issue_a(A0s);
+  __syncthreads();
+  for (int c = 0; c < nch; c += 2) {
+    commit(X1, A1s, 1);  // chunk c + 1
+    issue_x(X1);         // chunk c + 3
+    issue_a(A1s);
+    compute(0);
+    __syncthreads();
+    // (commit and requests of the second half are unconditional -- past the last chunk they move zeros: a path without them
+    // would make the compiler count fewer loads in flight at the loop head and turn the partial waits above into vmcnt(0))
+    commit(X0, A0s, 0);  // chunk c + 2
+    issue_x(X0);         // chunk c + 4
+    issue_a(A0s);
+    if (c + 1 < nch) compute(1);
     __syncthreads();
   }
 
-  // ---- epilogue: q_drain's arithmetic, from the accumulators ----
+  // ---- epilogue: q_drain's arithmetic.  A row block's accumulators (lane = column) go through a 32 x 64 stage of this wave's
+  // own (the X / A rings are free behind the last barrier) and leave as rows: 16-byte stores, 8-byte stores of the bf16 twin ----
+  if constexpr ((dbg & 16) != 0) {
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[m][n][r];
+    if (sum == 12345.f) a.y[0] = 1.f;
+    return;
+  }
+  float* const stg = reinterpret_cast<float*>(cq_lds + wave * (32 * 68 * 4));
   const __amdgpu_buffer_rsrc_t yrs =
       __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * Cout * T, 0, Cout * T * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -233,45 +310,67 @@ __global__ __launch_bounds__(256, 2) void convq_kernel(ConvArgs a, int tiles_per
   const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
       a.y16 ? a.y16 + (size_t)b * Cout * T : reinterpret_cast<__bf16*>(a.y), 0, a.y16 ? Cout * T * 2 : 0, 0x00020000);
   const bool post = a.out_mask && a.out_mask_post;
+  const bool pre = a.out_mask && !a.out_mask_post;
   const float pre_scale = a.out_scale;
+  const int rr4 = lane >> 4, c4 = lane & 15;
+  const int t = t0 + wave * 64 + 4 * c4;  // T % 4 == 0: a lane's four columns are inside the row together or not at all
+  const bool tin = t < T;
+  float om[4] = {1.f, 1.f, 1.f, 1.f};
+  if (a.out_mask && tin) {
+    const float4 o4 = *reinterpret_cast<const float4*>(a.out_mask + (size_t)b * T + t);
+    om[0] = o4.x;
+    om[1] = o4.y;
+    om[2] = o4.z;
+    om[3] = o4.w;
+  }
+  const bool lrelu16 = a.y16_act == PRO_LRELU;
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int t = t0 + wave * 64 + n * 32 + l31;
-    const bool tin = t < T;
-    const float om = (a.out_mask && tin) ? a.out_mask[(size_t)b * T + t] : 1.f;
+  for (int m = 0; m < MB; ++m) {
+    const int cob = cot * MB * 32 + m * 32;
+    if (cob >= Cout) break;  // (wave-uniform: a row block past the last cout)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const int co0 = cot * MB * 32 + m * 32 + 4 * hi;  // + (r & 3) + 8 (r >> 2)
-      if (co0 - 4 * hi >= Cout) continue;               // (wave-uniform: a row block past the last cout)
-      float res[16];
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) res[r] = 0.f;
-      if (a.residual) {
+      for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * hi) * 68 + n * 32 + l31] = acc[m][n][r];
+    __builtin_amdgcn_wave_barrier();  // (the LDS queue of a wave is in order; this only keeps the compiler from moving the reads up)
+    __builtin_amdgcn_sched_barrier(0);
+    // (rolled, two rows per trip: fully unrolled the scheduler hoists the 24 residual loads and stage reads of a tile to the top --
+    // 190 registers of temporaries -- and the allocator then spills inside the MAIN loop)
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + rr4, co = cob + row;
+      const float4 sv = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * c4);
+      const float bi = bias_lds[m * 32 + row];
+      // (rows co >= Cout lie outside the descriptors: loads return zero, stores are dropped)
+      const int off = tin ? (co * T + t) : 0x1FFFFFC0;
+      float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.residual) res = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, off * 4, 0, 0));
+      float v[4] = {sv.x + bi, sv.y + bi, sv.z + bi, sv.w + bi};
+      const float rs4[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + (r & 3) + 8 * (r >> 2);
-          res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, tin ? (co * T + t) * 4 : 0x7FFFFF00, 0, 0));
-        }
+      for (int e = 0; e < 4; ++e) {
+        if (RELU == 1) v[e] = fmaxf(v[e], 0.f);
+        v[e] *= pre_scale;
+        if (pre) v[e] *= om[e];
+        v[e] += rs4[e];  // (also without a residual, as q_drain does: -0 + 0 = +0)
+        if (post) v[e] *= om[e];
       }
+      const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+      __builtin_amdgcn_raw_buffer_store_b128(
+          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o4), yrs, off * 4, 0, 0);
+      if (a.y16) {
+        float u[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
-        const int co = co0 + (r & 3) + 8 * (r >> 2);
-        float v = acc[m][n][r] + bias_lds[row];
-        if (RELU == 1) v = fmaxf(v, 0.f);
-        v *= pre_scale;
-        if (a.out_mask && !post) v *= om;
-        v += res[r];  // (also without a residual, as q_drain does: -0 + 0 = +0)
-        if (post) v *= om;
-        // (rows co >= Cout lie outside the descriptor: the store is dropped)
-        const int off = tin ? (co * T + t) : 0x1FFFFFC0;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off * 4, 0, 0);
-        if (a.y16) {
-          const float u = (a.y16_act == PRO_LRELU && v < 0.f) ? 0.2f * v : v;
-          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)u), trs, off * 2, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) u[e] = (lrelu16 && v[e] < 0.f) ? 0.2f * v[e] : v[e];
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 dd;
+        dd[0] = sty_pack2_bf16(u[0], u[1]);
+        dd[1] = sty_pack2_bf16(u[2], u[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(dd, trs, off * 2, 0, 0);
       }
     }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -288,6 +387,9 @@ bool convq_eligible(const ConvArgs& a) {
   if (a.T % 4) return false;  // dword-aligned row starts for the 8-byte loads (and the callers' 16-byte neighbours)
   if (a.flatW && (a.Cin2d < 32 || a.Cin2d % 8)) return false;  // a thread's 8 rows share one image-row tap
   if ((long)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T >= (1l << 30)) return false;  // 31-bit byte offsets within a slab
+  // 256-column tiles per row: a row of 520 columns would run three tiles for the work of two (the 1-D convs of the decoder stay
+  // on convp16_kernel's 128-column tiles); STY_CONVQ_MIN_TILES set: the parity tests run every shape
+  if (!getenv("STY_CONVQ_MIN_TILES") && (double)a.T < 0.85 * CQ_TT * cdiv(a.T, CQ_TT)) return false;
   const char* mt = getenv("STY_CONVQ_MIN_TILES");
   const int min_tiles = mt ? atoi(mt) : 48;
   return (long)cdiv(a.T, CQ_TT) * a.B * cdiv(a.w.CoutP, 96) >= min_tiles;
@@ -299,7 +401,7 @@ static int launch_cq(const ConvArgs& a, hipStream_t st) {
   const size_t lds = cq_lds_bytes(MB, K);
   static bool raised = false;
   if (!raised) {
-    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<MB, K, RELU>),
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<MB, K, RELU, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised = true;
   }
@@ -314,7 +416,23 @@ static int launch_cq(const ConvArgs& a, hipStream_t st) {
   char detail[40];
   snprintf(detail, sizeof(detail), "ci%d co%d k%d T%d W%d", a.w.Cin, a.w.Cout, a.w.K, a.T, a.flatW);
   ProfScope prof(a.flatW ? "convq_kernel<3,true>" : "convq_kernel<3,true,1d>", flops, bytes, st, detail);
-  hipLaunchKernelGGL((convq_kernel<MB, K, RELU>), dim3(8 * per_xcd), dim3(256), lds, st, a, tiles_per_row, ncot, ntiles, per_xcd);
+  const char* de = getenv("STY_CQ_DBG");
+  const int dm = de ? atoi(de) : 0;
+  bool done = false;
+  if constexpr (K == 3 && RELU == 0) {  // the phase switches exist for this instantiation only
+#define CQ_DBG_CASE(M)                                                                                                     \
+  if (dm == (M)) {                                                                                                         \
+    STY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<MB, K, RELU, (M)>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                  \
+    hipLaunchKernelGGL((convq_kernel<MB, K, RELU, (M)>), dim3(8 * per_xcd), dim3(256), lds, st, a, tiles_per_row, ncot, ntiles, \
+                       per_xcd);                                                                                           \
+    done = true;                                                                                                           \
+  }
+    CQ_DBG_CASE(3) CQ_DBG_CASE(4) CQ_DBG_CASE(7) CQ_DBG_CASE(8) CQ_DBG_CASE(16) CQ_DBG_CASE(24) CQ_DBG_CASE(32) CQ_DBG_CASE(48)
+#undef CQ_DBG_CASE
+  }
+  if (!done)
+    hipLaunchKernelGGL((convq_kernel<MB, K, RELU, 0>), dim3(8 * per_xcd), dim3(256), lds, st, a, tiles_per_row, ncot, ntiles, per_xcd);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }

@@ -31,8 +31,49 @@ def collectives_on():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective())
 
 
+_COMM = None  # the library's communicator of this process (sty_comm, csrc/comm.hip), or None: torch.distributed does the exchange
+
+
+def native_comm():
+    """The sty_comm handle when the gradient exchange runs under the library (backend nccl = RCCL, one process per GPU), else
+    None (gloo: the CPU tests and the shared-device test aid; STY_NO_NATIVE_COMM=1: torch.distributed's all_reduce as in
+    rounds 1-5)."""
+    return _COMM
+
+
+def _init_native_comm(rank, world):
+    """sty_comm_unique_id on rank 0 -> one broadcast of its 128 bytes through the process group -> sty_comm_init on every rank
+    (a collective).  The communicator's stream is the library's own, at the lowest priority: the exchange fills gaps, the step's
+    chains keep the right of way."""
+    global _COMM
+    import ctypes as C
+    from . import lib as L
+    lib = L.load()
+    idb = (C.c_char * 128)()
+    if rank == 0:
+        L.check(lib.sty_comm_unique_id(C.cast(idb, C.c_void_p)))
+    t = torch.frombuffer(bytearray(bytes(idb)), dtype=torch.uint8).clone().cuda()
+    if world > 1:
+        dist.broadcast(t, 0)
+    raw = bytes(t.cpu().numpy().tobytes())
+    buf = (C.c_char * 128).from_buffer_copy(raw)
+    h = C.c_void_p()
+    L.check(lib.sty_comm_init(C.cast(buf, C.c_void_p), rank, world, -1, C.byref(h)))
+    _COMM = h
+
+
+def destroy_native_comm():
+    global _COMM
+    if _COMM is not None:
+        from . import lib as L
+        L.load().sty_comm_destroy(_COMM)
+        _COMM = None
+
+
 def init(backend=None):
-    """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+    """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*); with the nccl
+    backend (RCCL) also the library's own communicator, which then carries the gradient buckets (`native_comm`).  Call
+    torch.cuda.set_device first."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if (world > 1 or force_collective()) and not dist.is_initialized():
@@ -40,6 +81,8 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl" and _COMM is None and os.environ.get("STY_NO_NATIVE_COMM") != "1":
+            _init_native_comm(rank, world)
     return rank, world
 
 
@@ -74,6 +117,7 @@ class GradBuckets:
         named = [(n, p) for n, p in named if p.requires_grad]
         self.params = [p for _, p in named]
         self.buckets = []       # list of (flat tensor, [(param, offset, numel)])
+        self._full = []         # the buckets with their exchange padding (see _close)
         self.bucket_group = []  # segment of each bucket
         cur, cur_n, cur_g = [], 0, None
         for name, p in reversed(named):
@@ -88,12 +132,21 @@ class GradBuckets:
         if cur:
             self._close(cur, cur_n, cur_g)
         self._work = []
+        self._native_pending = False
         self.collectives = 0  # all-reduces started since construction (tests: the forced world-1 path really ran them)
+        self.native_collectives = 0  # ... of them through sty_comm_allreduce_bucket
+        self.exposed = []     # (event, event) pairs around the waits of finish() when `measure_exposed` is set
+        self.measure_exposed = False
 
     def _close(self, items, n, group=0):
         p0 = items[0][0]
-        flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
-        self.buckets.append((flat, items))
+        # the exchanged length: a multiple of 4 x world floats, so that the library can run the sum as reduce-scatter +
+        # all-gather on whole 16-byte pieces; the tail stays zero on every rank (flat = the first n elements)
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        q = 4 * world
+        full = torch.zeros((n + q - 1) // q * q, dtype=p0.dtype, device=p0.device)
+        self.buckets.append((full[:n], items))
+        self._full.append(full)
         self.bucket_group.append(group)
 
     def attach(self):
@@ -108,7 +161,17 @@ class GradBuckets:
     def reduce_bucket(self, i):
         """Start the all-reduce of bucket i (call once its last gradient has been written)."""
         if collectives_on():
-            self._work.append(dist.all_reduce(self.buckets[i][0], op=dist.ReduceOp.SUM, async_op=True))
+            flat = self.buckets[i][0]
+            if _COMM is not None and flat.is_cuda and flat.dtype == torch.float32:
+                import ctypes as C
+                from . import lib as L
+                full = self._full[i]
+                st = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+                L.check(L.load().sty_comm_allreduce_bucket(_COMM, C.c_void_p(full.data_ptr()), full.numel(), st))
+                self._native_pending = True
+                self.native_collectives += 1
+            else:
+                self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
             self.collectives += 1
 
     def reduce_all(self):
@@ -127,10 +190,33 @@ class GradBuckets:
         """Wait for the outstanding collectives.  average=True turns the sums into means with one pass over the buckets;
         the trainer passes False and folds 1 / world_size into the AdamW kernel instead (sty_adamw_step grad_scale)."""
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        timed = self.measure_exposed and (self._work or self._native_pending) and torch.cuda.is_available()
+        if timed:  # how long the consumer's stream stands still for the exchange: an event on either side of the wait
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._work:
             w.wait()
         self._work = []
+        if self._native_pending:
+            import ctypes as C
+            from . import lib as L
+            dev = self.buckets[0][0].device
+            L.check(L.load().sty_comm_wait(_COMM, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            self._native_pending = False
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.exposed.append((e0, e1))
         if world > 1 and average:
             for flat, _ in self.buckets:
                 flat.div_(world)
         return world
+
+    def exposed_ms(self):
+        """sum of the recorded waits (synchronises); clears the record"""
+        if not self.exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.exposed)
+        self.exposed = []
+        return ms

@@ -156,6 +156,12 @@ SYMBOLS = {
     "sty_acoustic_gan_workspace_bytes": (C.c_int, [_I, _I, _I, _SZP]),
     "sty_acoustic_gan_loss_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_float, _P, _I, _P,
                                                 _P, _P, _P, C.c_size_t, _P, C.c_size_t, _I, _P]),
+    "sty_comm_unique_id": (C.c_int, [_P]),
+    "sty_comm_init": (C.c_int, [_P, _I, _I, _I, C.POINTER(C.c_void_p)]),
+    "sty_comm_allreduce_bucket": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "sty_comm_wait": (C.c_int, [_P, _P]),
+    "sty_comm_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "sty_comm_destroy": (C.c_int, [_P]),
     "sty_prof_enable": (C.c_int, [_I]),
     "sty_prof_only": (C.c_int, [C.c_char_p]),
     "sty_set_single_stream": (C.c_int, [_I]),

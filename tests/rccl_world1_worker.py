@@ -26,10 +26,13 @@ def main(out_path, mode):
     from stylish_tts_amd.synthetic_weights import fill_state_dict
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    if mode == "rccl":
+    if mode in ("rccl", "rccl-torch"):
         assert D.force_collective()
         rank, world = D.init("nccl")
         assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and world == 1
+        # "rccl": the buckets go through the LIBRARY's communicator (sty_comm_*: ncclReduceScatter + ncclAllGather on a stream
+        # the library owns); "rccl-torch" (STY_NO_NATIVE_COMM=1): torch.distributed's all_reduce, as in rounds 1-5
+        assert (D.native_comm() is not None) == (mode == "rccl")
     else:
         assert not D.force_collective()
     sp = S.SpeechPredictor()
@@ -67,11 +70,21 @@ def main(out_path, mode):
     assert bool(torch.isfinite(params).all()) and bool(torch.isfinite(last).all())
     assert not torch.equal(params, before), "parameters did not move"
     n_coll_b = sum(o.grads.collectives for o in tr.opt.values()) - n_coll
+    native = sum(o.grads.native_collectives for o in tr.opt.values())
+    stats = None
+    if D.native_comm() is not None:
+        import ctypes as C
+        from stylish_tts_amd import lib as L
+        nb, nrs, by = C.c_uint64(), C.c_uint64(), C.c_double()
+        L.check(L.load().sty_comm_stats(D.native_comm(), C.byref(nb), C.byref(nrs), C.byref(by)))
+        stats = (int(nb.value), int(nrs.value), float(by.value))
     torch.save({"grads": grads, "losses": torch.stack(losses), "collectives": n_coll, "collectives_b": n_coll_b,
-                "nbuckets": nbuckets, "last": last, "moved": float((params - before).abs().max())}, out_path)
+                "nbuckets": nbuckets, "last": last, "moved": float((params - before).abs().max()), "native": native,
+                "comm_stats": stats}, out_path)
     print(f"[{mode}] 2 + 3 trainer steps, {n_coll} + {n_coll_b} all-reduces started over {nbuckets} buckets, "
           f"losses {losses[-1].tolist()} / {last.tolist()}")
-    if mode == "rccl":
+    if mode != "plain":
+        D.destroy_native_comm()
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

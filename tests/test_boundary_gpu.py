@@ -258,10 +258,13 @@ def test_rccl_world1_step_equals_the_step_without_a_process_group(tmp_path):
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = {}
-    for mode in ("plain", "rccl"):
+    for mode in ("plain", "rccl", "rccl-torch"):
         env = dict(base)
-        if mode == "rccl":
+        env.pop("STY_NO_NATIVE_COMM", None)
+        if mode != "plain":
             env["STY_DIST_FORCE_COLLECTIVE"] = "1"
+            if mode == "rccl-torch":
+                env["STY_NO_NATIVE_COMM"] = "1"
         else:
             env.pop("STY_DIST_FORCE_COLLECTIVE", None)
         out = str(tmp_path / f"{mode}.pt")
@@ -269,8 +272,14 @@ def test_rccl_world1_step_equals_the_step_without_a_process_group(tmp_path):
         assert r.returncode == 0, (mode, r.stdout[-1500:], r.stderr[-3000:])
         print("\n  " + r.stdout.strip().splitlines()[-1])
         outs[mode] = torch.load(out)
-    a, b = outs["plain"], outs["rccl"]
+    a, b, c = outs["plain"], outs["rccl"], outs["rccl-torch"]
     assert a["collectives"] == 0 and a["collectives_b"] == 0
+    # round 6: the exchange runs under the library (sty_comm_allreduce_bucket on the library's stream, reduce-scatter + all-gather);
+    # every collective of the rccl run went that way, none of the rccl-torch run did, and both give the plain run's numbers
+    assert b["native"] == b["collectives"] + b["collectives_b"] > 0 and c["native"] == 0 and c["collectives"] == b["collectives"]
+    assert b["comm_stats"][0] == b["native"] and b["comm_stats"][1] == b["native"], b["comm_stats"]
+    assert torch.allclose(a["losses"], c["losses"], rtol=1e-6, atol=0)
+    assert ((a["grads"] - c["grads"]).norm() / a["grads"].norm()).item() <= 1e-6
     # every bucket that can carry a gradient went through RCCL in every step (one bucket holds the never-stepped l_linear)
     assert b["collectives"] >= 2 * (b["nbuckets"] - 1) > 0 and b["collectives_b"] >= 3 * (b["nbuckets"] - 1), \
         (b["collectives"], b["collectives_b"], b["nbuckets"])
