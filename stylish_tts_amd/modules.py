@@ -915,9 +915,9 @@ class PitchStyleEncoder(_HipModule):
 
 
 class DurationProcessor(torch.nn.Module):
-    """train/utils.py:656-803: class distribution -> expected duration -> soft alignment.  Host-side glue on device
-    tensors (a softmax over 16 classes and the same closed form sty_alignment_fwd evaluates); one .item() sync for
-    the frame count, as in the reference (utils.py:759)."""
+    """train/utils.py:656-803: class distribution -> expected duration -> soft alignment, on the HIP entry points the training
+    stages use (sty_prediction_to_duration, sty_alignment_fwd; rounds 1-5 ran the same closed forms as ATen glue on a [B, L, T]
+    tensor); one .item() sync for the frame count, as in the reference (utils.py:759)."""
     TABLE = (1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 18, 22, 27, 32, 38, 46)
 
     def __init__(self, class_count=16, max_dur=50):
@@ -926,22 +926,13 @@ class DurationProcessor(torch.nn.Module):
         self.register_buffer("class_to_dur_table", torch.tensor(self.TABLE, dtype=torch.float32))
 
     def prediction_to_duration(self, pred, text_length):
-        conf = torch.softmax(pred, dim=-1)
-        soft = (conf * self.class_to_dur_table.to(pred.device)).sum(dim=-1) / (conf.sum(dim=-1) + 1e-9)
-        mask = torch.arange(pred.shape[1], device=pred.device)[None, :] < text_length.to(pred.device)[:, None]
-        return soft * mask
+        from .duration import prediction_to_duration
+        return prediction_to_duration(pred, text_length)
 
     def duration_to_alignment(self, duration, multiplier=1):
+        from .acoustic import duration_to_alignment
         total = int(duration.sum(dim=1).round().max().long().item()) * multiplier
-        duration = duration * multiplier
-        upper = torch.cumsum(duration, dim=1)
-        lower = upper - duration
-        mean = ((lower + upper) / 2).unsqueeze(2)
-        seq = torch.arange(round(total), device=duration.device).view(1, 1, -1)
-        x = seq - mean
-        al = 1 - (x * 2 / (duration.unsqueeze(2) + 6)) ** 2
-        m = (seq > (lower - 3).unsqueeze(2)) * (seq < (upper + 3).unsqueeze(2))
-        return torch.softmax(torch.clamp(al * m, min=0.0), dim=1)
+        return duration_to_alignment(duration * multiplier, total)
 
     def forward(self, pred, text_length, multiplier=1):
         return self.duration_to_alignment(self.prediction_to_duration(pred, text_length), multiplier)

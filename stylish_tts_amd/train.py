@@ -300,6 +300,29 @@ def train(config_path, model_config_path, out, stage, checkpoint="", reset_stage
     return train_model(config, model_config, out, stage, checkpoint, reset_stage, config_path, model_config_path, **kw)
 
 
+def convert(config_path, model_config_path, out, checkpoint, device=None, log=_log):
+    """train/cli.py `convert` / train/train.py:266-275 for this path: the three inference models from a checkpoint directory ->
+    stylish_tts_amd.export.convert (torch.export program with the weights; ONNX when the `onnx` package exists)."""
+    from . import stage_io as IO
+    from .export import convert as _convert
+    del config_path  # (the reference's command takes it for the dataset paths of its metadata; nothing of it is needed here)
+    model_config = get_model_config(model_config_path)
+    check_supported(model_config)
+    if not torch.cuda.is_available():
+        raise L.StyError("no HIP device: the exported graph's models live on the device")
+    device = torch.device(device or "cuda:0")
+    torch.cuda.set_device(device)
+
+    class _Ctx(TrainContext):  # only the model registry of the context
+        def __init__(self):
+            self.model_config, self.device, self.models = model_config, device, {}
+
+    ctx = _Ctx()
+    models = {k: ctx.model(k) for k in ("speech_predictor", "pitch_energy_predictor", "duration_predictor")}
+    IO.load_checkpoint(checkpoint, models)
+    return _convert(model_config, out, models, device, log=log)
+
+
 def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser(prog="python -m stylish_tts_amd.train", description=__doc__.split("\n\n")[0])
@@ -310,7 +333,11 @@ def main(argv=None):
     ap.add_argument("--checkpoint", default="")
     ap.add_argument("--reset-stage", dest="reset_stage", action="store_true")
     ap.add_argument("--max-steps", type=int, default=None)
+    ap.add_argument("--convert", action="store_true", help="export the inference graph of --checkpoint instead of training")
     a = ap.parse_args(argv)
+    if a.convert:
+        convert(a.config_path, a.model_config_path, a.out, a.checkpoint)
+        return
     train(a.config_path, a.model_config_path, a.out, a.stage, a.checkpoint, a.reset_stage, max_steps=a.max_steps)
 
 

@@ -259,3 +259,38 @@ def test_train_entry_point_refuses_to_run_without_a_device(tmp_path):
     assert T.NEXT_STAGE == {"acoustic": "textual", "textual": "duration", "duration": None}
     with pytest.raises(SystemExit):
         T.main(["--help"])
+
+
+def _export_models(mc):
+    import stylish_tts_amd as S
+    return {"speech_predictor": S.SpeechPredictor(mc),
+            "duration_predictor": S.DurationPredictor(style_dim=mc.style_dim, inter_dim=mc.inter_dim, text_config=mc.text_encoder,
+                                                      duration_config=mc.duration_predictor),
+            "pitch_energy_predictor": S.PitchEnergyPredictor(style_dim=mc.style_dim, inter_dim=mc.pitch_energy_predictor.inter_dim,
+                                                             text_config=mc.text_encoder, duration_config=mc.duration_predictor,
+                                                             pitch_energy_config=mc.pitch_energy_predictor)}
+
+
+def test_export_graph_traces_through_torch_export(tmp_path):
+    """The first half of the reference's `convert` (train/convert_to_onnx.py:69-85: torch.export.export of ExportModel with a
+    dynamic token axis) on the HIP-backed graph: the library calls are torch custom ops with fake kernels, so the trace needs no
+    device.  The program holds the four calls in export_model.py's order, EVERY state tensor of the three models as a lifted
+    input (the program carries the weights), a dynamic token axis and a data-dependent frame count; it survives
+    torch.export.save / load.  (Running it is a -m gpu test: tests/test_hip_parity.py.)"""
+    from stylish_tts_amd import export as X
+    from stylish_tts_amd.config import load_model_config_yaml
+    mc = load_model_config_yaml(_default_model_yaml())
+    models = _export_models(mc)
+    ep, inputs = X.export_program(mc, models, "cpu")
+    calls = [str(n.target) for n in ep.graph_module.graph.nodes if n.op == "call_function" and "stylish_tts_amd" in str(n.target)]
+    assert calls == ["stylish_tts_amd.duration_predictor.default", "stylish_tts_amd.duration_to_alignment.default",
+                     "stylish_tts_amd.pitch_energy_predictor.default", "stylish_tts_amd.speech_predictor.default"], calls
+    assert len(ep.state_dict) == sum(len(m.state_dict()) for m in models.values())
+    syms = {str(k): v for k, v in ep.range_constraints.items()}
+    assert any(k.startswith("u") for k in syms) and any(k.startswith("s") for k in syms), syms  # frames (unbacked), tokens
+    f = str(tmp_path / "stylish.pt2")
+    torch.export.save(ep, f)
+    back = torch.export.load(f)
+    assert len(back.state_dict) == len(ep.state_dict)
+    k0 = "speech_predictor.text_encoder.emb.weight" if "speech_predictor.text_encoder.emb.weight" in ep.state_dict else next(iter(ep.state_dict))
+    assert torch.equal(back.state_dict[k0], ep.state_dict[k0])

@@ -2407,6 +2407,43 @@ def test_train_entry_point_runs_c1_from_the_yaml_files(tmp_path):
     assert any("duration epoch" in ln for ln in logs)
 
 
+def test_exported_program_runs_the_hip_graph(tmp_path):
+    """`convert` (train/convert_to_onnx.py:23-108), the torch.export half, on the device: the ExportedProgram of
+    stylish_tts_amd.export.ExportGraph (four custom ops = the four library calls of export_model.py:7-63) gives the audio of
+    stylish_tts_amd.ExportModel bit for bit; saved, loaded and run with the op registry EMPTY (as in a fresh process: the ops
+    rebuild their shells from the weights and the model config the program carries) it still does, also for a token string of
+    another length (the dynamic axis) -- and `convert` says plainly that the ONNX half needs a package this image lacks."""
+    import stylish_tts_amd as S
+    from stylish_tts_amd import export as X
+    from stylish_tts_amd.config import load_model_config_yaml
+    from stylish_tts_amd.manifest import (duration_predictor_manifest, pitch_energy_predictor_manifest,
+                                          speech_predictor_manifest)
+    from stylish_tts_amd.synthetic_weights import fill_state_dict
+    from tests.test_boundary import _default_model_yaml, _export_models
+    mc = load_model_config_yaml(_default_model_yaml())
+    models = _export_models(mc)
+    models["speech_predictor"].load_state_dict(fill_state_dict(speech_predictor_manifest(), 0), strict=False)
+    models["duration_predictor"].load_state_dict(fill_state_dict(duration_predictor_manifest(), 3))
+    models["pitch_energy_predictor"].load_state_dict(fill_state_dict(pitch_energy_predictor_manifest(), 4))
+    models = {k: m.to(DEV) for k, m in models.items()}
+    logs = []
+    out = X.convert(mc, str(tmp_path), models, DEV, log=logs.append)
+    assert os.path.exists(out["program"]) and out["onnx"] is None and any("onnx" in ln for ln in logs)
+    ref_model = S.ExportModel(**models)
+    g = torch.Generator().manual_seed(5)
+    for Lt in (96, 41):
+        texts = torch.randint(1, 178, (1, Lt), generator=g).to(DEV)
+        tl = torch.tensor([Lt], device=DEV)
+        styles = [torch.rand(1, 64, generator=g).to(DEV) for _ in range(3)]
+        want = ref_model(texts, tl, *styles, seed=0)
+        X._REG.clear()  # a fresh process has no live shells: the ops rebuild them from what the program carries
+        ep = torch.export.load(out["program"])
+        got = ep.module()(texts, tl, *styles)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and got.numel() % 300 == 0 and bool(torch.isfinite(got).all())
+        assert torch.equal(got, want), (Lt, (got - want).abs().max().item())
+
+
 def _free_port():
     """a TCP port nobody listens on right now (a fixed number collides with a rendezvous socket still lingering from an
     earlier two-rank test of the same session)"""

@@ -3,7 +3,7 @@
 #   kernel-trace summaries (rocprofv3 --kernel-trace --stats) of the default bench command (c3) and of c5 / c2,
 #   HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes) of the default bench command and of c5,
 #   the per-stream picture of one c3 step, bench JSON lines of every workload.
-tag=${1:-r05}
+tag=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 rm -rf $O; mkdir -p $O
@@ -72,6 +72,10 @@ bash tools/probes/fft_variants.sh > $O/${tag}_fft_variants.txt 2>&1
 # matrix-pipe utilisation counters (SQ_VALU_MFMA_BUSY_CYCLES) of the serialised c3 step -> gpurun_out/pmc_mfma/${tag}_c3_pmc_mfma.txt
 bash tools/pmc_mfma.sh $tag; cp $R/gpurun_out/pmc_mfma/${tag}_c3_pmc_mfma.txt $O/ 2>/dev/null
 python tools/convp16_bench.py 10 2>/dev/null | grep conv > $O/${tag}_convp16_microbench.txt
+# round 6: the twin-operand conv against convp16_kernel<.., X16> (A/B, bit-equality), its phases, the per-shape table of the serial step
+python tools/convq_bench.py 10 > $O/${tag}_convq_microbench.txt 2>/dev/null
+python tools/convq_phases.py 10 > $O/${tag}_convq_phases.txt 2>/dev/null
+bash tools/shapes_c3.sh $tag > /dev/null 2>&1; cp $R/gpurun_out/shapes_$tag.txt $O/${tag}_c3_shapes.txt 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/overlap_probe.hip -o /tmp/overlap_probe 2>/dev/null && /tmp/overlap_probe > $O/${tag}_overlap_probe.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/buffer_offset_probe.hip -o /tmp/buffer_offset_probe 2>/dev/null && /tmp/buffer_offset_probe > $O/${tag}_buffer_offset_probe.txt
 rm -rf $O/c3_trace $O/c5_trace $O/c2_trace $O/c5b_trace $O/c3_fetch/*/*agent_info.csv $O/c5_fetch/*/*agent_info.csv
