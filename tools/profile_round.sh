@@ -41,8 +41,10 @@ python tools/stream_busy.py $O/c3_trace/*/*_results.db 6 > $O/${tag}_c3_streams.
 # where the main stream waits inside one timed step (the last steps of a bench run are its single-stream extras: skip 6)
 python tools/step_gaps.py $O/c3_trace/*/*_results.db 6 150 > $O/${tag}_c3_gaps.txt
 python tools/step_gaps.py $O/c2_trace/*/*_results.db 6 150 > $O/${tag}_c2_gaps.txt
-# the traffic files have to be where bench.py looks for them before the bench lines are taken
+# the traffic files AND the kernel tables have to be where bench.py looks for them before the bench lines are taken (round 6:
+# the roofline's kernel is the top row of the committed table of the same command)
 cp $O/${tag}_c3_pmc_traffic.json $O/${tag}_c5_pmc_traffic.json $R/profiles/
+cp $O/${tag}_c3_kernel_stats.txt $O/${tag}_c5_kernel_stats.txt $O/${tag}_c2_kernel_stats.txt $O/${tag}_c5-bf16_kernel_stats.txt $R/profiles/
 python bench.py > $O/${tag}_bench_default.json 2> $O/bench_default.err
 python bench.py --workload c5-bf16 --steps 50 --warmup 10 --no-cpu-baseline --no-extra > $O/${tag}_bench_c5_bf16.json 2>/dev/null
 python bench.py --workload c2-fwd --no-cpu-baseline --no-extra > $O/${tag}_bench_c2_fwd.json 2>/dev/null
