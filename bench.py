@@ -523,7 +523,7 @@ def run_workload(name, steps, warmup, rank, world, device, lib, L, D, share, ser
                      "exchange": ("library communicator (sty_comm_*: ncclReduceScatter + ncclAllGather on the library's stream)"
                                   if D.native_comm() is not None else "torch.distributed all_reduce"),
                      "env": {k: v for k, v in os.environ.items()
-                             if k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "STY_NO_NATIVE_COMM")
+                             if k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "STY_NATIVE_COMM", "STY_COMM_PRIORITY")
                              or k.startswith(("NCCL_", "RCCL_"))}}
     dt = D.max_over_ranks(dt, device)
     if synth is not None:

@@ -460,6 +460,8 @@ int sty_comm_unique_id(void *id128);
 int sty_comm_init(const void *id128, int rank, int world, int stream_priority, sty_comm **out);
 int sty_comm_allreduce_bucket(sty_comm *c, float *buf, size_t n, void *producer_stream);
 int sty_comm_wait(sty_comm *c, void *consumer_stream);
+/* Run the collectives on a stream of the CALLER's instead (it stays the caller's; it must outlive the communicator's use). */
+int sty_comm_set_stream(sty_comm *c, void *stream);
 int sty_comm_stats(sty_comm *c, uint64_t *buckets, uint64_t *reduce_scatter_all_gather, double *bytes);
 int sty_comm_destroy(sty_comm *c);
 

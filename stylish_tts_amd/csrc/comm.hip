@@ -94,7 +94,8 @@ using namespace sty;
 struct sty_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
-  hipStream_t stream = nullptr;  // the communicator's own stream
+  bool own_stream = true;
+  hipStream_t stream = nullptr;  // the communicator's own stream (or the caller's: sty_comm_set_stream)
   hipEvent_t handed = nullptr;   // recorded on the producer's stream at every hand-over
   hipEvent_t done = nullptr;     // recorded on `stream` behind the last collective started
   uint64_t buckets = 0, rs_ag = 0;
@@ -136,7 +137,7 @@ int sty_comm_init(const void* id128, int rank, int world, int stream_priority, s
   int lo = 0, hi = 0;  // (numerically lower = higher priority)
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   int pr = stream_priority < 0 ? hi : (stream_priority > 0 ? lo : 0);
-  hipError_t he = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr);
+  hipError_t he = hipStreamCreateWithPriority(&c->stream, getenv("STY_COMM_BLOCKING_STREAM") ? hipStreamDefault : hipStreamNonBlocking, pr);
   if (he == hipSuccess) he = hipEventCreateWithFlags(&c->handed, hipEventDisableTiming);
   if (he == hipSuccess) he = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
   if (he != hipSuccess) {
@@ -181,6 +182,20 @@ int sty_comm_wait(sty_comm* c, void* consumer_stream) {
   return STY_OK;
 }
 
+int sty_comm_set_stream(sty_comm* c, void* stream) {
+  if (!c) {
+    set_error("sty_comm_set_stream: null communicator");
+    return STY_EINVAL;
+  }
+  if (c->stream && c->own_stream) {
+    STY_HIP(hipStreamSynchronize(c->stream));
+    (void)hipStreamDestroy(c->stream);
+  }
+  c->stream = static_cast<hipStream_t>(stream);
+  c->own_stream = false;
+  return STY_OK;
+}
+
 int sty_comm_stats(sty_comm* c, uint64_t* buckets, uint64_t* reduce_scatter_all_gather, double* bytes) {
   if (!c) {
     set_error("sty_comm_stats: null communicator");
@@ -198,7 +213,7 @@ int sty_comm_destroy(sty_comm* c) {
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   if (c->handed) (void)hipEventDestroy(c->handed);
   if (c->done) (void)hipEventDestroy(c->done);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return STY_OK;
 }

@@ -31,20 +31,19 @@ def collectives_on():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective())
 
 
+_COMM_TORCH_STREAM = None
 _COMM = None  # the library's communicator of this process (sty_comm, csrc/comm.hip), or None: torch.distributed does the exchange
 
 
 def native_comm():
     """The sty_comm handle when the gradient exchange runs under the library (backend nccl = RCCL, one process per GPU), else
-    None (gloo: the CPU tests and the shared-device test aid; STY_NO_NATIVE_COMM=1: torch.distributed's all_reduce as in
-    rounds 1-5)."""
+    None (the default: torch.distributed's all_reduce as in rounds 1-5; STY_NATIVE_COMM=1 with backend nccl turns it on)."""
     return _COMM
 
 
 def _init_native_comm(rank, world):
     """sty_comm_unique_id on rank 0 -> one broadcast of its 128 bytes through the process group -> sty_comm_init on every rank
-    (a collective).  The communicator's stream is the library's own, at the lowest priority: the exchange fills gaps, the step's
-    chains keep the right of way."""
+    (a collective).  The communicator's stream is the library's own (STY_COMM_PRIORITY: 1 highest, 0 default, -1 lowest)."""
     global _COMM
     import ctypes as C
     from . import lib as L
@@ -58,8 +57,13 @@ def _init_native_comm(rank, world):
     raw = bytes(t.cpu().numpy().tobytes())
     buf = (C.c_char * 128).from_buffer_copy(raw)
     h = C.c_void_p()
-    L.check(lib.sty_comm_init(C.cast(buf, C.c_void_p), rank, world, -1, C.byref(h)))
+    prio = int(os.environ.get("STY_COMM_PRIORITY", "1"))  # (highest: the best of the three at world size 1, see init)
+    L.check(lib.sty_comm_init(C.cast(buf, C.c_void_p), rank, world, prio, C.byref(h)))
     _COMM = h
+    if os.environ.get("STY_COMM_STREAM") == "torch":  # (A/B aid: the collectives on a stream out of torch's pool)
+        global _COMM_TORCH_STREAM
+        _COMM_TORCH_STREAM = torch.cuda.Stream()
+        L.check(lib.sty_comm_set_stream(h, C.c_void_p(_COMM_TORCH_STREAM.cuda_stream)))
 
 
 def destroy_native_comm():
@@ -81,7 +85,14 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
-        if backend == "nccl" and _COMM is None and os.environ.get("STY_NO_NATIVE_COMM") != "1":
+        # OPT-IN (STY_NATIVE_COMM=1).  Measured at world size 1 with the exchange forced (profiles/r06_comm_ab.txt): the step takes
+        # 45.1 ms through torch.distributed's all_reduce (= 44.7 without a process group) and 47.0 / 48.7 / 64.5 ms through the
+        # library's communicator with its stream at the highest / default / lowest priority (72.6 on a stream out of torch's pool):
+        # the hand-over parks a wait in whatever hardware queue the runtime maps the stream to (two queues for six streams:
+        # GPU_MAX_HW_QUEUES=2), and everything mapped behind it stands still until the backward reaches the hand-over point.
+        # Owning the stream is not owning the queue -- HIP does not expose that mapping -- so the default stays the path that
+        # measures 1.00, and the first multi-GPU run can A/B the two with one environment variable.
+        if backend == "nccl" and _COMM is None and os.environ.get("STY_NATIVE_COMM") == "1":
             _init_native_comm(rank, world)
     return rank, world
 

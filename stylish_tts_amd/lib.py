@@ -160,6 +160,7 @@ SYMBOLS = {
     "sty_comm_init": (C.c_int, [_P, _I, _I, _I, C.POINTER(C.c_void_p)]),
     "sty_comm_allreduce_bucket": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "sty_comm_wait": (C.c_int, [_P, _P]),
+    "sty_comm_set_stream": (C.c_int, [_P, _P]),
     "sty_comm_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "sty_comm_destroy": (C.c_int, [_P]),
     "sty_prof_enable": (C.c_int, [_I]),

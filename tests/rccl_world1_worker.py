@@ -31,7 +31,7 @@ def main(out_path, mode):
         rank, world = D.init("nccl")
         assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and world == 1
         # "rccl": the buckets go through the LIBRARY's communicator (sty_comm_*: ncclReduceScatter + ncclAllGather on a stream
-        # the library owns); "rccl-torch" (STY_NO_NATIVE_COMM=1): torch.distributed's all_reduce, as in rounds 1-5
+        # the library owns; STY_NATIVE_COMM=1); "rccl-torch" (the default): torch.distributed's all_reduce, as in rounds 1-5
         assert (D.native_comm() is not None) == (mode == "rccl")
     else:
         assert not D.force_collective()

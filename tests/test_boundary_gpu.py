@@ -260,11 +260,11 @@ def test_rccl_world1_step_equals_the_step_without_a_process_group(tmp_path):
     outs = {}
     for mode in ("plain", "rccl", "rccl-torch"):
         env = dict(base)
-        env.pop("STY_NO_NATIVE_COMM", None)
+        env.pop("STY_NATIVE_COMM", None)
         if mode != "plain":
             env["STY_DIST_FORCE_COLLECTIVE"] = "1"
-            if mode == "rccl-torch":
-                env["STY_NO_NATIVE_COMM"] = "1"
+            if mode == "rccl":
+                env["STY_NATIVE_COMM"] = "1"  # the library's communicator (opt-in: stylish_tts_amd/dist.py init)
         else:
             env.pop("STY_DIST_FORCE_COLLECTIVE", None)
         out = str(tmp_path / f"{mode}.pt")

@@ -401,6 +401,23 @@ C3_BF16_DISPATCH = [("default (convp16 from 48 tiles, convk1 from 24)", {}),
 # the negative control's conv (a listed tensor; a PLAIN weight -- a weight-normed direction `original1` is scale-free -- with no
 # normalisation behind it: the log-amplitude head, whose output goes through exp)
 C3_BIAS_KEY = "generator.basegen.amp_output_conv.weight"
+# What the full-size bf16 gate can and cannot pin (measured in round 6, profiles/r06_c3_well_conditioned_table.txt): at this size
+# the bf16 mode's audio sits 3.5e-4 (MSE) from fp32 and most listed gradients 0.1-0.5 (relative L2) from the fp32 oracle's, with
+# a factor ~3 between dispatch configurations -- one of the four distinct realisations sits that far out on a dozen tensors at
+# once, and under another cotangent it is another one.  A rounding-rule yardstick of one
+# realisation, or the scatter of five, cannot separate a kernel defect from that on those tensors; the kernels' PRECISION is pinned
+# where it can be -- every conv kernel against float64 on the same rounded operands at 2e-5 at these very shapes
+# (test_persistent_conv16_vs_torch & co., with a negative control of their own) -- and here:
+#   * tensors whose gradient the bf16 mode still determines (median relative L2 over the configurations <= 5e-2: the heads) are held
+#     by their COHERENT error p within max(6 MAD, 1e-3) of the configurations' median: that is where one ulp of bf16 in one conv shows
+#     (the negative control: p moves by 4e-3 against a scatter of 1.5e-4);
+#   * every other listed tensor is held to caps that only a gross defect exceeds (relative L2 0.9, 1 - cos 0.3: a dropped layer, a
+#     wrong sign, a factor 2), in EVERY configuration -- thresholds 32 and 48 included;
+#   * the weight-norm direction gradient in front of an instance norm (a cancellation: ANY 2^-9 arithmetic moves it by O(1), the
+#     configurations between 0.85 and 4.0) is reported, not gated.
+C3_WELL_CONDITIONED = 5e-2
+C3_BF16_CAP = (0.9, 0.3)
+C3_BF16_CANCELLATION = ("d " + "generator.basegen.amp_prior_block.convs1.1.parametrizations.weight.original1"[-50:],)
 
 
 def test_c3_backward_full_size_under_a_well_conditioned_loss(monkeypatch):
@@ -415,15 +432,15 @@ def test_c3_backward_full_size_under_a_well_conditioned_loss(monkeypatch):
     bf16 mode (round 6; rounds 4-5 held it to 2 x ONE realisation of the rounding rule -- the bf16-rule oracle on 8 utterances --
     and a dispatch threshold moved the verdict): the yardstick is the PRODUCT'S OWN SCATTER.  The
     step runs under five dispatch configurations (C3_BF16_DISPATCH: convp16 from 32 / 48 / 256 tiles, convk1 from 24 / 256),
-    and per tensor
-      * the COHERENT error p = <g - ref, ref> / <ref, ref> of every configuration lies within max(6 MAD, 1e-3) of the
-        configurations' median, and the median within 2e-2 of zero (rounding noise reaches p divided by sqrt(elements); a
-        kernel that scales, drops or biases does not);
-      * relative L2 error and 1 - cos lie within median + 3 MAD of the configurations, floors 0.25 / 3e-2 (what a 2^-9
-        arithmetic leaves on a cancellation like convs1.*.original1), cap 1.0 / 0.3.
+    and per tensor (the comment above C3_WELL_CONDITIONED says what this can pin and what it cannot):
+      * where the bf16 mode still determines the gradient (median relative L2 <= 5e-2), the COHERENT error
+        p = <g - ref, ref> / <ref, ref> of every configuration lies within max(6 MAD, 1e-3) of the configurations' median
+        (rounding noise reaches p divided by sqrt(elements); a kernel that scales, drops or biases does not);
+      * everywhere else relative L2 <= 0.9 and 1 - cos <= 0.3 in EVERY configuration (gross defects only; the first full-size
+        table is the evidence that nothing tighter separates a defect from a rounding realisation there).
     Both the 32-tile and the 48-tile configuration have to pass.  NEGATIVE CONTROL: one more run with ONE conv's weight scaled by
     1 + 2^-8 on the device only -- one ulp of bf16 on every product of that layer, what a kernel with a wrong constant would
-    do -- must be RED: its p on that conv's own weight gradient sits ~4e-3 from the median, outside the gate."""
+    do -- must be RED on that conv's own weight gradient (p moves by ~4e-3 against a scatter of 1.5e-4)."""
     import stylish_tts_amd as S
     from oracle import frontend, speech_predictor as osp
     _oracle_threads()
@@ -514,24 +531,24 @@ def test_c3_backward_full_size_under_a_well_conditioned_loss(monkeypatch):
         e2m, e2d = med_mad([stats[t][name][0] for t in tags])
         cm, cd = med_mad([stats[t][name][1] for t in tags])
         pm, pd = med_mad([stats[t][name][2] for t in tags])
-        g_e2 = min(max(0.25, e2m + 3 * e2d), 1.0)
-        g_c = min(max(3e-2, cm + 3 * cd), 0.3)
+        well = e2m <= C3_WELL_CONDITIONED and name not in C3_BF16_CANCELLATION   # the p gate applies
         g_p = max(6 * pd, 1e-3)
-        lines.append(f"  bf16 {name:54s} median: rel L2 {e2m:.2e}  1-cos {cm:.2e}  p {pm:+.2e} (MAD {pd:.1e}); gates {g_e2:.2e} / {g_c:.2e} / "
-                     f"|p - median| <= {g_p:.1e}")
-        if abs(pm) > 2e-2:
-            bad.append(("bf16 median p", name, pm))
-        for t in tags:
-            e2, c, p_ = stats[t][name]
-            ok = e2 <= g_e2 and c <= g_c and abs(p_ - pm) <= g_p
-            lines.append(f"       {t:48s} rel L2 {e2:.2e}  1-cos {c:.2e}  p {p_:+.2e}  " + ("ok" if ok else "FAIL"))
-            if not ok:
-                bad.append((t, name, (e2, c, p_)))
-        e2, c, p_ = ctrl[name]
-        red = not (e2 <= g_e2 and c <= g_c and abs(p_ - pm) <= g_p)
-        lines.append(f"       {'NEGATIVE CONTROL (one conv x (1 + 2^-8))':48s} rel L2 {e2:.2e}  1-cos {c:.2e}  p {p_:+.2e}  " + ("red" if red else "not seen"))
-        if red:
-            ctrl_red.append(name)
+        lines.append(f"  bf16 {name:54s} median: rel L2 {e2m:.2e} (MAD {e2d:.1e})  1-cos {cm:.2e}  p {pm:+.2e} (MAD {pd:.1e})  "
+                     + (f"WELL-CONDITIONED: |p - median| <= {g_p:.1e}" if well else
+                        ("cancellation: reported" if name in C3_BF16_CANCELLATION else f"caps {C3_BF16_CAP[0]} / {C3_BF16_CAP[1]}")))
+        for t in tags + ["NEGATIVE CONTROL (one conv x (1 + 2^-8))"]:
+            e2, c, p_ = ctrl[name] if t.startswith("NEGATIVE") else stats[t][name]
+            ok = name in C3_BF16_CANCELLATION or (e2 <= C3_BF16_CAP[0] and c <= C3_BF16_CAP[1])
+            if well:
+                ok = ok and abs(p_ - pm) <= g_p
+            if t.startswith("NEGATIVE"):
+                lines.append(f"       {t:48s} rel L2 {e2:.2e}  1-cos {c:.2e}  p {p_:+.2e}  " + ("red" if not ok else "not seen"))
+                if not ok:
+                    ctrl_red.append(name)
+            else:
+                lines.append(f"       {t:48s} rel L2 {e2:.2e}  1-cos {c:.2e}  p {p_:+.2e}  " + ("ok" if ok else "FAIL"))
+                if not ok:
+                    bad.append((t, name, (e2, c, p_)))
     print("\n".join(lines))
     _write_table("c3_well_conditioned_table.txt", lines)
     assert not bad, bad

@@ -1868,6 +1868,17 @@ def test_persistent_conv16_on_bf16_operand_twins_vs_torch(shape, monkeypatch):
           f"y {torch.equal(out[1][0], out[2][0])}  dx {torch.equal(out[1][1], out[2][1])}")
     assert err <= 2e-5 and e_dx <= 2e-5
     assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1])
+    # NEGATIVE CONTROL of this gate (round 6): the same launch with the weights scaled by 1 + 2^-8 -- one ulp of bf16 on the products,
+    # what a kernel with a wrong constant or a biased rounding would do -- has to be RED here, at the block level, because at
+    # full size it is below what 60 bf16 layers leave of most gradients (tests/test_full_size.py, C3_WELL_CONDITIONED)
+    ws = torch.zeros(need.value + tw_bytes, dtype=torch.uint8, device=DEV)
+    yb = torch.empty(B, Co, T, device=DEV)
+    L.check(lib.sty_conv1d_fwd(B, Ci, Co, K, d, T, L.ptr(xd), L.ptr(dev(w * (1.0 + 2.0 ** -8))), L.ptr(bd), L.ptr(yb), L.ptr(ws),
+                               ws.numel(), 2, st))
+    torch.cuda.synchronize()
+    err_b = (yb.cpu() - ref).abs().max().item()
+    print(f"  negative control (weights x (1 + 2^-8)): max|err| {err_b:.3e} against the gate 2e-5")
+    assert err_b > 20 * 2e-5
 
 
 @pytest.mark.parametrize("shape", [(3, 128, 130, 1, 1, 64), (2, 512, 64, 3, 1, 38), (2, 96, 200, 3, 1, 300), (2, 64, 96, 3, 1, 1000),
