@@ -386,7 +386,8 @@ bool convq_eligible(const ConvArgs& a) {
   if (a.w.CinP < 2 * CI_CHUNK) return false;
   if (a.T % 4) return false;  // dword-aligned row starts for the 8-byte loads (and the callers' 16-byte neighbours)
   if (a.flatW && (a.Cin2d < 32 || a.Cin2d % 8)) return false;  // a thread's 8 rows share one image-row tap
-  if ((long)a.B * (a.flatW ? a.Cin2d : a.w.Cin) * a.T >= (1l << 30)) return false;  // 31-bit byte offsets within a slab
+  // 31-bit byte offsets within a batch slab: the input twin (2 bytes), the output and the residual (4 bytes)
+  if ((long)(a.flatW ? a.Cin2d : a.w.Cin) * a.T >= (1l << 29) || (long)a.w.Cout * a.T >= (1l << 28)) return false;
   // 256-column tiles per row: a row of 520 columns would run three tiles for the work of two (the 1-D convs of the decoder stay
   // on convp16_kernel's 128-column tiles); STY_CONVQ_MIN_TILES set: the parity tests run every shape
   if (!getenv("STY_CONVQ_MIN_TILES") && (double)a.T < 0.85 * CQ_TT * cdiv(a.T, CQ_TT)) return false;
