@@ -26,6 +26,9 @@ from . import lib as L
 from .config import check_supported, load_config_yaml, load_model_config_yaml
 
 NEXT_STAGE = {"acoustic": "textual", "textual": "duration", "duration": None}  # stage_type.py:394,472,637
+# the model keys of build_model (models/models.py:69-83) this path owns (not: text_aligner)
+MODEL_KEYS = ("speech_predictor", "speech_style_encoder", "duration_style_encoder", "pe_style_encoder", "duration_predictor",
+              "pitch_energy_predictor", "mrd0", "mrd1", "mrd2", "disc", "pitch_disc", "dur_disc")
 
 
 def _log(msg):
@@ -70,15 +73,24 @@ class _Stage:
                 self.batch_sizes.save_batch_sizes()
         self.trainer = ctx.make_trainer(name, self.lr)
 
-    def checkpoint_state(self):
+    def checkpoint_state(self, trained_only=False):
+        """models / optimizers / loss helpers for stage_io.  trained_only=False (saving): EVERY model this run holds goes into the
+        directory, also the ones this stage does not train (the reference's accelerator.save_state writes all thirteen models
+        every time, train/train.py:453-469), so that the last stage's checkpoint is what `convert` and the next resume need."""
         t = self.trainer
         if hasattr(t, "checkpoint_state"):
-            return t.checkpoint_state()
-        if self.name == "textual":
-            return dict(models={"pitch_energy_predictor": t.pep, "pe_style_encoder": t.pse, "pitch_disc": t.pitch_disc},
-                        optimizers=dict(t.opt), disc_helpers={"pitch_disc": t.disc_helper})
-        return dict(models={"duration_predictor": t.dp, "duration_style_encoder": t.se, "dur_disc": t.dur_disc},
-                    optimizers=dict(t.opt), disc_helpers={"dur_disc": t.disc_helper})
+            st = t.checkpoint_state()
+        elif self.name == "textual":
+            st = dict(models={"pitch_energy_predictor": t.pep, "pe_style_encoder": t.pse, "pitch_disc": t.pitch_disc},
+                      optimizers=dict(t.opt), disc_helpers={"pitch_disc": t.disc_helper})
+        else:
+            st = dict(models={"duration_predictor": t.dp, "duration_style_encoder": t.se, "dur_disc": t.dur_disc},
+                      optimizers=dict(t.opt), disc_helpers={"dur_disc": t.disc_helper})
+        if not trained_only:
+            st = dict(st, models=dict(st["models"]))
+            for k, m in self.ctx.models.items():
+                st["models"].setdefault(k, m)
+        return st
 
     def step(self, batch, seed):
         from .data import to_step_inputs
@@ -211,14 +223,15 @@ def train_model(config, model_config, out_dir, stage, checkpoint="", reset_stage
     ctx.stage = enter(stage)
     fast_forward = 0
     if checkpoint:  # train/train.py:240-259
-        state = ctx.stage.checkpoint_state()
+        state = ctx.stage.checkpoint_state(trained_only=True)
         have = {k: m for k, m in state["models"].items() if osp.exists(osp.join(checkpoint, IO.model_file(k)))}
         opts = {k: o for k, o in state["optimizers"].items() if k in have and osp.exists(osp.join(checkpoint, IO.optimizer_file(k)))}
         IO.load_checkpoint(checkpoint, have, optimizers=opts, disc_helpers=state.get("disc_helpers"), allow_mixed_steps=True)
-        # frozen models of later stages (the speech predictor inside train_textual) come from the same directory
-        for k, m in ctx.models.items():
+        # every other model of this path that the directory holds comes along (weights only): the frozen speech predictor of
+        # train_textual, and the earlier stages' models, so that this run's checkpoints stay complete
+        for k in MODEL_KEYS:
             if k not in have and osp.exists(osp.join(checkpoint, IO.model_file(k))):
-                IO.load_checkpoint(checkpoint, {k: m})
+                IO.load_checkpoint(checkpoint, {k: ctx.model(k)})
         if ctx.manifest.stage == stage and not reset_stage:
             fast_forward = ctx.manifest.current_step
         else:

@@ -2412,10 +2412,20 @@ def test_train_entry_point_runs_c1_from_the_yaml_files(tmp_path):
     assert torch.equal(got, sp4)
     assert os.path.exists(os.path.join(str(out), "textual", "checkpoint_final", IO.model_file("pitch_energy_predictor")))
     del ctx
-    ctx = T.train(str(cfg), str(mdl), str(out), "duration", max_steps=1, log=logs.append)
+    tfinal = os.path.join(str(out), "textual", "checkpoint_final")
+    assert os.path.exists(os.path.join(tfinal, IO.model_file("speech_predictor")))  # (every model the run holds is saved)
+    ctx = T.train(str(cfg), str(mdl), str(out), "duration", checkpoint=tfinal, max_steps=1, log=logs.append)
     torch.cuda.synchronize()
-    assert os.path.exists(os.path.join(str(out), "duration", "checkpoint_final", IO.model_file("duration_predictor")))
+    dfinal = os.path.join(str(out), "duration", "checkpoint_final")
+    for k in ("duration_predictor", "pitch_energy_predictor", "speech_predictor"):  # the chain's last checkpoint is complete
+        assert os.path.exists(os.path.join(dfinal, IO.model_file(k))), k
     assert any("duration epoch" in ln for ln in logs)
+    del ctx
+    # ... which is what `convert` takes (train/cli.py convert): checkpoint -> the exported text -> audio program
+    res = T.convert(str(cfg), str(mdl), str(tmp_path / "export"), dfinal, log=logs.append)
+    assert os.path.exists(res["program"]) and res["onnx"] is None
+    ep = torch.export.load(res["program"])
+    assert torch.equal(ep.state_dict["speech_predictor." + k0].cpu(), sp4)
 
 
 def test_exported_program_runs_the_hip_graph(tmp_path):
