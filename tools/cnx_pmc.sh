@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 wl=${1:-cnx}
 export PMC_FILTER="convnext32 wgrad_cnx conv32p pro_bwd wgradp32 dwconv"
-[ $wl = se ] && export PMC_FILTER="convp16 wgradb16 wgradb_ dwconv2d avgpool stem pool_fc twin_cast"
+[ $wl = se ] && export PMC_FILTER="convq convp16 wgradb16 wgradb_ dwconv2d avgpool stem pool_fc twin_cast"
 out=$R/gpurun_out/cnx_pmc
 rm -rf $out; mkdir -p $out
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS"; do
