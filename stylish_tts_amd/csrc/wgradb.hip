@@ -649,6 +649,14 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     if (ch + nsplit < total) load_chunk(cb, cc_);
     const __bf16* xr = xs + (wi * 32 * FI + l31) * PITCH + 8 * hi;
     const __bf16* gr = gs + (wo * 32 * FO + l31) * PITCH + 8 * hi + (KN > 1 ? 8 : 0);
+    // The four samples below a window come through a pointer the compiler cannot relate to `gr`: left to itself it fuses the
+    // 8-byte and the 16-byte load of a window into one 24-byte access and legalises that as three ds_read2_b32, whose
+    // dword-granular lanes collide on the 68- / 36-dword row pitch (4.6 - 8 bank-conflict cycles per LDS instruction measured,
+    // profiles/r06_se_pmc_sq_counters.txt); as one ds_read_b128 + one ds_read_b64 the window costs the two-way conflict of
+    // the b64 only.
+    typedef unsigned wb_u32x2 __attribute__((ext_vector_type(2)));
+    const __attribute__((address_space(3))) wb_u32x2* gl = (const __attribute__((address_space(3))) wb_u32x2*)(gr - 4);
+    asm("" : "+v"(gl));
 #pragma unroll
     for (int s8 = 0; s8 < TW / 16; ++s8) {
       bf16x8 bp[FI];
@@ -660,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
         const uint4 a = *reinterpret_cast<const uint4*>(q);
         unsigned win[6] = {0u, 0u, a.x, a.y, a.z, a.w};  // samples p - 4 .. p + 7 of the row as pairs
         if constexpr (KN > 1) {
-          const uint2 lo = *reinterpret_cast<const uint2*>(q - 4);
+          const wb_u32x2 lo = *(gl + (fo * 32 * PITCH + 16 * s8) / 4);
           win[0] = lo.x;
           win[1] = lo.y;
         }
