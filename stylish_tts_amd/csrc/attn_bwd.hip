@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnArgs a, const 
 template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
                                                             float* __restrict__ dQ, size_t dqbs, float* __restrict__ dK,
-                                                            size_t dkbs, float* __restrict__ dV, size_t dvbs) {
+                                                            size_t dkbs, float* __restrict__ dV, size_t dvbs, int overwrite) {
+  // overwrite: bit 0 / 1 / 2 -- dQ / dK / dV is this kernel's to WRITE (its first writer: no zero-fill was issued); a workgroup
+  // covers all DH x T elements of its (batch, head) slab, so every element of the tensor is written
   constexpr int TP = 129;
   __shared__ float qs[DH * TP], ks[DH * TP], vs[DH * TP], gs[DH * TP];
   __shared__ float lse_s[128], del_s[128], pm_s[128], pl_s[128];
@@ -449,7 +451,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnArgs a, const f
       __syncthreads();
       if (half == 0 && live) {
         float* dq = dQ + (size_t)b * dqbs + ho;
-        dq[(size_t)d * T + r] += (acc[d] + pm_s[r]) * a.scale;
+        const float val = (acc[d] + pm_s[r]) * a.scale;
+        dq[(size_t)d * T + r] = (overwrite & 1) ? val : dq[(size_t)d * T + r] + val;
       }
     }
   }
@@ -497,8 +500,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnArgs a, const f
       }
       __syncthreads();
       if (half == 0 && live) {
-        dk[(size_t)d * T + r] += ak[d] + pm_s[r];
-        dv[(size_t)d * T + r] += av[d] + pl_s[r];
+        const float vk = ak[d] + pm_s[r], vv_ = av[d] + pl_s[r];
+        dk[(size_t)d * T + r] = (overwrite & 2) ? vk : dk[(size_t)d * T + r] + vk;
+        dv[(size_t)d * T + r] = (overwrite & 4) ? vv_ : dv[(size_t)d * T + r] + vv_;
       }
     }
   }
@@ -506,9 +510,24 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnArgs a, const f
 
 size_t attention_bwd_ws_floats(int B, int H, int T) { return (size_t)2 * B * H * T; }
 
-// gradients are ACCUMULATED into dQ / dK / dV
+static bool attn_bwd_small_path(const AttnArgs& a, int DH) {
+  static const bool no_small = getenv("STY_NO_ATTN_BWD_SMALL") != nullptr;
+  if (attention16_eligible(a, DH) && a.lse) return false;
+  if (DH == 64 && a.lse && !a.lengths && a.drop_p <= 0.f) return false;
+  return DH == 16 && a.T <= 128 && !no_small;
+}
+// true: launch_attention_bwd can take `overwrite` bits for this problem (the one-workgroup-per-(batch, head) kernel writes every
+// element of dQ / dK / dV exactly once) -- the caller may then hand it buffers nobody zero-filled
+bool attention_bwd_can_overwrite(const AttnArgs& a, int DH) { return attn_bwd_small_path(a, DH); }
+
+// gradients are ACCUMULATED into dQ / dK / dV, except where `overwrite` (bit 0 / 1 / 2: dQ / dK / dV; only with
+// attention_bwd_can_overwrite) says the tensor is this call's to write
 int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* dK, float* dV, size_t dqbs, size_t dkbs,
-                         size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st) {
+                         size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st, int overwrite) {
+  if (overwrite && !attn_bwd_small_path(a, DH)) {
+    set_error("attention_bwd: overwrite requested on a path that accumulates");
+    return STY_EINVAL;
+  }
   if (attention16_eligible(a, DH) && a.lse)
     return launch_attention16_bwd(a, dO, dQ, dK, dV, dqbs, dkbs, dvbs, dobs, B, ws, st);
   float* lse = ws;
@@ -523,14 +542,13 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
     return STY_OK;
   }
   const bool drop = a.drop_p > 0.f;
-  static const bool no_small = getenv("STY_NO_ATTN_BWD_SMALL") != nullptr;
-  if (DH == 16 && a.T <= 128 && !no_small) {  // the text encoder: one workgroup per (batch, head), everything in LDS
+  if (attn_bwd_small_path(a, DH)) {  // the text encoder: one workgroup per (batch, head), everything in LDS
     if (drop)
       hipLaunchKernelGGL((attn_bwd_small_kernel<16, true>), dim3(a.H, B), dim3(256), 0, st, a, dO, dobs, dQ, dqbs, dK, dkbs, dV,
-                         dvbs);
+                         dvbs, overwrite);
     else
       hipLaunchKernelGGL((attn_bwd_small_kernel<16, false>), dim3(a.H, B), dim3(256), 0, st, a, dO, dobs, dQ, dqbs, dK, dkbs,
-                         dV, dvbs);
+                         dV, dvbs, overwrite);
     STY_LAUNCH_CHECK();
     return STY_OK;
   }

@@ -106,6 +106,38 @@ __device__ __forceinline__ void sty_st4_any(void* p, size_t i4, float4 v, bool h
 #endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// Which chunks of a split reduction workgroup `split` of `nsplit` takes.  Until the end of round 6 every weight-gradient kernel
+// took split, split + nsplit, ... (mode 0): one front moving through memory, but neighbouring chunks of a row run on different
+// XCDs (workgroups go round-robin over the eight), and what two neighbours share -- the cache lines their boundary cuts (rows of
+// the 75T-rate bf16 tensors are 64-byte, not 128-byte aligned), the (K - 1) dilation halo of the x operand, the row-shifted reads
+// of a 2-D conv -- is fetched into two L2s: wgradp32_kernel fetched 1.8x (k = 11) / 2.8x (k = 21) its algorithmic bytes, wgrad_cnx
+// 1.5-1.7x (profiles/r06_c3_pmc_traffic.json).  Mode 1: a CONSECUTIVE range [first, end) per workgroup (returns the stride, 1).
+// Mode 2: the strided front, with the workgroups of one XCD (blockIdx % 8) on neighbouring chunks -- eight fronts, one per L2.
+// Measured per kernel, alone on the chip (tools/ab_serial.sh; modes 1 / 2 / 0) and on the block workload of tools/cnx_traffic.sh:
+// wgradb16_kernel<3,128,..> 273 / 317 / 316 us, wgradb_kernel<3,3,..> 48.8 / 50.7 / 50.9; wgradp32_kernel<3,..> 144 / 141 / 142 us and
+// 68 / 65 / 119 MB fetched; wgrad_cnx_kernel<false,..> 143 / 128 / 132 us and 134 / 101 / 144 MB; stem_wgrad_kernel 198 / 188 / 185,
+// conv1d_wgrad_kernel<6> 243 / 240 / 235 (mode 1 turns a streaming kernel's one front into 1 024 scattered streams).  Each kernel
+// names its mode where it calls this.  The partial planes of a workgroup, and with them the last bits of the sums, depend on it.
+#ifdef __HIPCC__
+// mode 0: strided; 1: consecutive ranges; 2: strided, with the workgroups of one XCD (blockIdx % 8) on consecutive chunks -- eight
+// fronts, one per L2, and a chunk's neighbours in the same L2 at about the same time
+__device__ __forceinline__ int wg_chunks(int mode, int split, int nsplit, int total, int& first, int& end) {
+  if (mode == 1) {
+    first = (int)(((long long)split * total) / nsplit);
+    end = (int)(((long long)(split + 1) * total) / nsplit);
+    return 1;
+  }
+  end = total;
+  if (mode == 2) {
+    const int k = split & 7, q = nsplit >> 3, r = nsplit & 7;
+    first = k * q + (k < r ? k : r) + (split >> 3);
+  } else {
+    first = split;
+  }
+  return nsplit;
+}
+#endif
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------

@@ -1208,12 +1208,19 @@ struct Trainer {
     if (live()) chk(launch_attention(at, B, Hd / heads, st));
     tape.push_back([=]() {
       float* gO = G(o, n);
-      float* gQ = G(q, n);
-      float* gK = G(k, n);
-      float* gV = G(v, n);
+      // q / k / v of the text encoder feed nothing but this attention: where the backward kernel writes every element (the
+      // one-workgroup-per-(batch, head) kernel), their gradient buffers are taken without the zero-fill (three launches per
+      // layer less on the chain that ends the step)
+      int aq = 1, ak = 1, av = 1;
+      const bool ow = attention_bwd_can_overwrite(at, Hd / heads);
+      float* gQ = ow ? Gw(q, n, aq) : G(q, n);
+      float* gK = ow ? Gw(k, n, ak) : G(k, n);
+      float* gV = ow ? Gw(v, n, av) : G(v, n);
       const size_t mark = ws.off;
       float* w2 = take<float>(attention_bwd_ws_floats(B, heads, L));
-      if (live()) chk(launch_attention_bwd(at, gO, gQ, gK, gV, at.qbs, at.kbs, at.vbs, at.obs, B, Hd / heads, w2, st));
+      if (live())
+        chk(launch_attention_bwd(at, gO, gQ, gK, gV, at.qbs, at.kbs, at.vbs, at.obs, B, Hd / heads, w2, st,
+                                 (aq ? 0 : 1) | (ak ? 0 : 2) | (av ? 0 : 4)));
       ws.off = mark;
     });
     return o;

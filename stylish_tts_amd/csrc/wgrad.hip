@@ -15,6 +15,10 @@
 
 #include "conv_stage.h"
 
+#ifndef WG_MODE
+#define WG_MODE 0  // chunk order (sty_common.h: wg_chunks)
+#endif
+
 namespace sty {
 
 constexpr int WG_TW = 128;      // time samples per chunk
@@ -76,9 +80,10 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(ConvArgs ax, ConvArgs
   // fused bias gradient (KT <= 3 staging keeps the G rows in registers): ci-tile-0 workgroups sum them over time
   const bool do_bias = want_bias && blockIdx.x == 0 && KT >= 1 && KT <= 3;
   float bsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-  const int total = ax.B * chunks_per_b;
+  int first_, end_;  // this workgroup's chunks [first_, end_), stride stride_ (sty_common.h: wg_chunks)
+  const int stride_ = wg_chunks(WG_MODE, split, nsplit, ax.B * chunks_per_b, first_, end_);
   constexpr int MAXJ = (WG_TW + 128 + 1 + 63) / 64;
-  for (int ch = split; ch < total; ch += nsplit) {
+  for (int ch = first_; ch < end_; ch += stride_) {
     const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW, h = 0;
     const int xmode = stage_mode(ax), gmode = stage_mode(ag);
     const float* xb = stage_base(ax, b);
@@ -311,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
     offg[i] = co < Cg ? co * T * 4 : 0x7fffff00;
   }
   float vx[16][3], vg[16][2], mk[2];
-  const int total = ax.B * chunks_per_b;
+  int first_, end_;  // this workgroup's chunks [first_, end_), stride stride_ (sty_common.h: wg_chunks)
+  const int stride_ = wg_chunks(WG_MODE, split, nsplit, ax.B * chunks_per_b, first_, end_);
   auto load_chunk = [&](int ch) {
     const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -341,8 +347,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
       mk[q] = t < T ? (ag.pro == PRO_MASK ? ag.mask[(size_t)b * T + t] : 1.f) : 0.f;
     }
   };
-  if (split < total) load_chunk(split);
-  for (int ch = split; ch < total; ch += nsplit) {
+  if (first_ < end_) load_chunk(first_);
+  for (int ch = first_; ch < end_; ch += stride_) {
     const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * WG_TW;
     __syncthreads();  // the previous chunk's MFMAs are done with the tiles
     switch (ax.pro) {
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad64_kernel(ConvArgs ax, Con
       }
     }
     __syncthreads();
-    if (ch + nsplit < total) load_chunk(ch + nsplit);  // in flight during the MFMAs below
+    if (ch + stride_ < end_) load_chunk(ch + stride_);  // in flight during the MFMAs below
     if constexpr (BF) {
       bf16x8 ap[WG_TW / 16];
       const float* gr = gs + (wo * 32 + l31) * LWg + 8 * hi;
@@ -517,7 +523,8 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
   float bsum[TO / 4];
 #pragma unroll
   for (int i = 0; i < TO / 4; ++i) bsum[i] = 0.f;
-  const int total = ax.B * chunks_per_b;
+  int first_, end_;  // this workgroup's chunks [first_, end_), stride stride_ (sty_common.h: wg_chunks)
+  const int stride_ = wg_chunks(WG_MODE, split, nsplit, ax.B * chunks_per_b, first_, end_);
   // Software pipeline over the chunk list: the global loads of chunk i+1 are issued right after chunk i's tiles are in
   // LDS, so their latency overlaps chunk i's LDS reads + MFMAs (which wait on lgkmcnt only).  Without it every chunk
   // paid load latency -> LDS store -> barrier -> MFMA back to back: 21-31 TFLOP/s at config c3 in either compute mode.
@@ -566,8 +573,8 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     if (ag.pro == PRO_MASK) mk = t0 + lane < T ? ag.mask[(size_t)b * T + t0 + lane] : 0.f;
     if (ax.pro == PRO_MASK) mkx = t0 + lane < T ? ax.mask[(size_t)b * T + t0 + lane] : 0.f;
   };
-  if (split < total) load_chunk(split);
-  for (int ch = split; ch < total; ch += nsplit) {
+  if (first_ < end_) load_chunk(first_);
+  for (int ch = first_; ch < end_; ch += stride_) {
     const int b = ch / chunks_per_b, t0 = (ch % chunks_per_b) * W1_TW;
     if (do_bias) {  // generic path: rows past Cout / columns past T load 0; plain path: mk is 0 past T, rows are checked
 #pragma unroll
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(ConvArgs ax, ConvArgs ag,
     }
     w1_store<PRO_MASK, TO>(ag, gs, co0, b, t0, wave, lane, vg, mk);
     __syncthreads();
-    if (ch + nsplit < total) load_chunk(ch + nsplit);
+    if (ch + stride_ < end_) load_chunk(ch + stride_);
     if constexpr (BF) {
       const float* gr = gs + (wo * MO * 32 + l31) * LW + 8 * hi;
       const float* xr = xs + (wi * MI * 32 + l31) * LW + 8 * hi;
@@ -955,7 +962,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co0 = blockIdx.x * STEM_CO, split = blockIdx.y;
   const int cpb = (n / 4 + 255) / 256;  // chunks of 1024 positions per image
-  const int total = B * cpb;
+  int first_, end_;  // this workgroup's chunks [first_, end_), stride stride_ (sty_common.h: wg_chunks)
+  const int stride_ = wg_chunks(WG_MODE, split, nsplit, B * cpb, first_, end_);
   float acc[STEM_CO][9], bs[STEM_CO];
 #pragma unroll
   for (int i = 0; i < STEM_CO; ++i) {
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[i][t] = 0.f;
   }
-  for (int ch = split; ch < total; ch += nsplit) {
+  for (int ch = first_; ch < end_; ch += stride_) {
     const int b = ch / cpb, p = ((ch - b * cpb) * 256 + tid) * 4;
     if (p >= n) continue;
     float4 gv[STEM_CO];

@@ -22,6 +22,17 @@
 
 namespace sty {
 
+// chunk order per kernel (sty_common.h: wg_chunks has the measurements): the tiled kernels take consecutive ranges, the two
+// streaming ones keep the strided front but with an XCD's workgroups on neighbouring chunks
+#ifndef WB_MODE
+#define WB_MODE 1   // wgradb_kernel, wgradb16_kernel
+#endif
+#ifndef WP32_MODE
+#define WP32_MODE 2  // wgradp32_kernel: 144 (1) / 141 (2) / 142 us (0) alone on the chip; 68 / 65 / 119 MB fetched on the block workload
+#endif
+#ifndef CNX_MODE
+#define CNX_MODE 2   // wgrad_cnx_kernel: 143 (1) / 128 (2) / 132 us (0); 134 / 101 / 144 MB
+#endif
 constexpr int WB_PITCH = 136;  // bf16 elements between LDS rows
 constexpr int WB_TW_MASKED = 64;
 constexpr int WB_OOB = 0x7fffff00;
@@ -193,9 +204,10 @@ __global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(C
   }
   float xm[PRO == PRO_MASK ? NI : 1][8];
   float gm[GMASK ? GK : 1][GW];
-  const int total = ax.B * chunks_per_b;
+  int first_, total;  // this workgroup's chunks [first_, total), stride stride_ (sty_common.h: wg_chunks)
+  const int stride_ = wg_chunks(WB_MODE, split, nsplit, ax.B * chunks_per_b, first_, total);
   // chunk position (batch row, chunk in the row), advanced incrementally: no division in the loop
-  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+  int cb = first_ / chunks_per_b, cc_ = first_ - cb * chunks_per_b;
 
   auto load_chunk = [&](int b, int c) {
     const int t0 = c * TW;
@@ -248,16 +260,16 @@ __global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(C
     }
   };
   auto advance = [&](int& b, int& c) {
-    c += nsplit;
+    c += stride_;
     while (c >= chunks_per_b) {
       c -= chunks_per_b;
       ++b;
     }
   };
 
-  int ch = split;
+  int ch = first_;
   if (ch < total) load_chunk(cb, cc_);
-  for (; ch < total; ch += nsplit) {
+  for (; ch < total; ch += stride_) {
     const int t0 = cc_ * TW;
     __syncthreads();  // the previous chunk's MFMAs are done with the tiles
     // ---- registers -> bf16 tiles ----
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(256, (KN > 3 && !WIN ? 1 : 2)) void wgradb_kernel(C
     }
     __syncthreads();
     advance(cb, cc_);
-    if (ch + nsplit < total) load_chunk(cb, cc_);  // in flight during the MFMAs below
+    if (ch + stride_ < total) load_chunk(cb, cc_);  // in flight during the MFMAs below
     // ---- MFMAs: A = G_k rows (co), B = x rows (ci), contraction over the 128 samples of the chunk ----
     const __bf16* xr = xs + (wi * 32 * F + l31) * PITCH + 8 * hi;
     const __bf16* gr = gs + (wo * 32 * F + l31) * PITCH + 8 * hi;
@@ -552,8 +564,9 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
   }
   constexpr int GN = 4;  // dwords of a thread's eight G samples
   unsigned xw[NIX][5], gw[NIG][GN], gh[NIG][2];  // gh: the four samples below the chunk (threads of the first group only)
-  const int total = ax.B * chunks_per_b;
-  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+  int first_, total;  // this workgroup's chunks [first_, total), stride stride_ (sty_common.h: wg_chunks)
+  const int stride_ = wg_chunks(WB_MODE, split, nsplit, ax.B * chunks_per_b, first_, total);
+  int cb = first_ / chunks_per_b, cc_ = first_ - cb * chunks_per_b;
 
   auto load_chunk = [&](int b, int c) {
     const int t0 = c * TW;
@@ -606,16 +619,16 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     }
   };
   auto advance = [&](int& b, int& c) {
-    c += nsplit;
+    c += stride_;
     while (c >= chunks_per_b) {
       c -= chunks_per_b;
       ++b;
     }
   };
 
-  int ch = split;
+  int ch = first_;
   if (ch < total) load_chunk(cb, cc_);
-  for (; ch < total; ch += nsplit) {
+  for (; ch < total; ch += stride_) {
     const int t0 = cc_ * TW;
     __syncthreads();
 #pragma unroll
@@ -646,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void wgradb16_kernel(ConvArgs ax, int nspli
     }
     __syncthreads();
     advance(cb, cc_);
-    if (ch + nsplit < total) load_chunk(cb, cc_);
+    if (ch + stride_ < total) load_chunk(cb, cc_);
     const __bf16* xr = xs + (wi * 32 * FI + l31) * PITCH + 8 * hi;
     const __bf16* gr = gs + (wo * 32 * FO + l31) * PITCH + 8 * hi + (KN > 1 ? 8 : 0);
     // The four samples below a window come through a pointer the compiler cannot relate to `gr`: left to itself it fuses the
@@ -862,8 +875,9 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
   }
   float xv[8], gv[2][16], pa = 1.f, ps = 0.f, xm[8], gm[16], bsum[2] = {0.f, 0.f};
   unsigned xraw[5] = {0u, 0u, 0u, 0u, 0u};  // bf16 source tensor: the dwords of the group, unpacked when it is staged
-  const int total = ax.B * chunks_per_b;
-  int cb = split / chunks_per_b, cc_ = split - cb * chunks_per_b;
+  int first_, total;  // this workgroup's chunks [first_, total), stride stride_ (sty_common.h: wg_chunks)
+  const int stride_ = wg_chunks(WP32_MODE, split, nsplit, ax.B * chunks_per_b, first_, total);
+  int cb = first_ / chunks_per_b, cc_ = first_ - cb * chunks_per_b;
   auto load_chunk = [&](int b, int c) {
     const int t0 = c * WP_TW;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -908,15 +922,15 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
     }
   };
   auto advance = [&](int& b, int& c) {
-    c += nsplit;
+    c += stride_;
     while (c >= chunks_per_b) {
       c -= chunks_per_b;
       ++b;
     }
   };
-  int ch = split;
+  int ch = first_;
   if (ch < total) load_chunk(cb, cc_);
-  for (; ch < total; ch += nsplit) {
+  for (; ch < total; ch += stride_) {
     const int t0 = cc_ * WP_TW;
     __syncthreads();
     {  // x
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void wgradp32_kernel(ConvArgs ax, ConvArgs 
     }
     __syncthreads();
     advance(cb, cc_);
-    if (ch + nsplit < total) load_chunk(cb, cc_);
+    if (ch + stride_ < total) load_chunk(cb, cc_);
     // ---- MFMAs: this wave's taps ----
     if constexpr (!BF) {
       const float* xrf = xsf + l31 * PXF + hi;
@@ -1168,8 +1182,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
   float4 wv[8];     // wide: 8 rows x 8 bf16
   float nv[2][8];   // narrow: 2 rows x 8 fp32
   float4 nh[2];     // (N16: 2 rows x 8 bf16)
-  const int total = SB ? chunks_per_b : B * chunks_per_b, step = SB ? SB : nsplit;
-  int cb = SB ? split / SB : split / chunks_per_b, cc_ = SB ? split - cb * SB : split - cb * chunks_per_b;
+  // (per-utterance mode: workgroup j = split % SB of utterance split / SB takes range j of SB of that utterance's chunks)
+  int first_, total;
+  const int step = SB ? wg_chunks(0, split % SB, SB, chunks_per_b, first_, total) : wg_chunks(CNX_MODE, split, nsplit, B * chunks_per_b, first_, total);
+  int cb = SB ? split / SB : first_ / chunks_per_b, cc_ = SB ? first_ : first_ - cb * chunks_per_b;
   auto load_chunk = [&](int b, int c) {
     const int t = c * TW + g8;
     const bool in = t < T;
@@ -1197,7 +1213,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_cnx_kernel(const __bf16* __restr
       ++b;
     }
   };
-  int ch = SB ? cc_ : split;
+  int ch = first_;
   if (ch < total) load_chunk(cb, cc_);
   for (; ch < total; ch += step) {
     __syncthreads();
