@@ -164,8 +164,8 @@ int sty_block_train_workspace_bytes(sty_model *m, const char *kind, const char *
 int sty_block_fwd_bwd(sty_model *m, const char *kind, const char *prefix, int B, int C, int T, const float *x,
                       const float *style, const float *gy, float *y, float *gx, float *d_style, void *workspace,
                       size_t ws_bytes, void *stream);
-/* Softmax attention (text_encoder.py:234-280 with `lengths`, conformer.py:85-91 without) forward + backward on separate
- * q, k, v [B, 8*DH, T] (DH = 16 or 64): d_o -> dq, dk, dv.                                                    */
+/* Softmax attention (text_encoder.py:234-280 with `lengths`, conformer.py:85-91 without, prosody_encoder.py:23-40: 2 heads of
+ * 160 / 96 with `lengths`) forward + backward on separate q, k, v [B, H*DH, T] (DH = 16, 64, 96 or 160): d_o -> dq, dk, dv.  */
 int sty_attention_workspace_bytes(int B, int H, int T, size_t *bytes);
 int sty_attention_fwd_bwd(int B, int H, int DH, int T, const float *q, const float *k, const float *v,
                           const int64_t *lengths, const float *d_o, float *o, float *dq, float *dk, float *dv,

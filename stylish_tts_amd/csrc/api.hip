@@ -2521,7 +2521,8 @@ int sty_block_fwd_bwd(sty_model* m, const char* kind, const char* prefix, int B,
 }
 
 // softmax attention forward + backward on separate q / k / v [B][H*DH][T] (DH = 16: the text encoder's VALU backward with
-// an optional length mask; DH = 64: the conformer's MFMA backward)
+// an optional length mask; DH = 64 / 96 / 160: the fp32 matrix-core backward -- the conformer's 8 x 64, the prosody encoder's
+// 2 x 160 / 2 x 96 with the length mask)
 int sty_attention_workspace_bytes(int B, int H, int T, size_t* bytes) {
   if (!bytes || B <= 0 || H <= 0 || T <= 0) {
     set_error("sty_attention_workspace_bytes: bad argument");
@@ -2535,8 +2536,9 @@ int sty_attention_fwd_bwd(int B, int H, int DH, int T, const float* q, const flo
                           void* workspace, size_t ws_bytes, void* stream) {
   size_t need = 0;
   if (sty_attention_workspace_bytes(B, H, T, &need)) return STY_EINVAL;
-  if (!q || !k || !v || !d_o || !o || !dq || !dk || !dv || !workspace || ws_bytes < need || (DH != 16 && DH != 64) || H != 8) {
-    set_error("sty_attention_fwd_bwd: bad argument (H = 8, DH = 16 or 64, workspace >= %zu bytes)", need);
+  if (!q || !k || !v || !d_o || !o || !dq || !dk || !dv || !workspace || ws_bytes < need ||
+      (DH != 16 && DH != 64 && DH != 96 && DH != 160)) {
+    set_error("sty_attention_fwd_bwd: bad argument (DH = 16, 64, 96 or 160, workspace >= %zu bytes)", need);
     return STY_EINVAL;
   }
   hipStream_t st = S(stream);

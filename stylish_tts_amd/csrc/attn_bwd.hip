@@ -200,7 +200,7 @@ __global__ void attn_delta_kernel(const float* __restrict__ o, size_t obs, const
 
 __device__ __forceinline__ int frag_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
@@ -217,6 +217,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnArgs a, const
   const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
   const float* Lb = lse + ((size_t)b * a.H + h) * T;
   const float* Db = delta + ((size_t)b * a.H + h) * T;
+  // length mask (additive -1e4 where the query or the key is padding: text_encoder.py:256-258, as the forward kernel and the
+  // VALU kernels above) and dropout of the probabilities (the forward's hash of (b, h, i, j)): round 6, with DH = 96 / 160 --
+  // the prosody encoder's 2 x 160 heads at T = 520 ran on the VALU kernels: 5.6 ms per layer, 17 of a `train_textual` step's 101 ms
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  const bool kpad = a.lengths && j >= len;
+  const float inv_keep = DROP ? 1.0f / (1.0f - a.drop_p) : 1.f;
+  const unsigned rowbase = (unsigned)(b * a.H + h) * (unsigned)T;
   float kreg[DH / 2], vreg[DH / 2];
 #pragma unroll
   for (int c2 = 0; c2 < DH / 2; ++c2) {
@@ -252,9 +259,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnArgs a, const
     for (int r = 0; r < 16; ++r) {
       const int ii = frag_row(r, hi);
       const bool ok = i0 + ii < T && j < T;
-      const float p = ok ? expf(s[r] * a.scale - lse_s[ii]) : 0.f;
-      s[r] = p;
-      dp[r] = p * (dp[r] - del_s[ii]);
+      float sv = s[r] * a.scale;
+      if (a.lengths && (kpad || i0 + ii >= len)) sv += -1e4f;
+      const float p = ok ? expf(sv - lse_s[ii]) : 0.f;
+      float mf = 1.f;
+      if constexpr (DROP)
+        mf = sty_hash_u(a.drop_seed, a.drop_site, (rowbase + (unsigned)(i0 + ii)) * (unsigned)T + (unsigned)j) >= a.drop_p ? inv_keep : 0.f;
+      s[r] = p * mf;
+      dp[r] = p * (dp[r] * mf - del_s[ii]);
     }
 #pragma unroll
     for (int n = 0; n < NB; ++n)
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(AttnArgs a, const
   }
 }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnArgs a, const float* __restrict__ dO, size_t dobs,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
@@ -295,6 +307,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnArgs a, const 
   const float* gb = dO + (size_t)b * dobs + (size_t)h * DH * T;
   const float L = i < T ? lse[((size_t)b * a.H + h) * T + i] : 0.f;
   const float dl = i < T ? delta[((size_t)b * a.H + h) * T + i] : 0.f;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  const bool qpad = a.lengths && i >= len;
+  const float inv_keep = DROP ? 1.0f / (1.0f - a.drop_p) : 1.f;
+  const unsigned rowi = ((unsigned)(b * a.H + h) * (unsigned)T + (unsigned)i) * (unsigned)T;
   float qreg[DH / 2], greg[DH / 2];
 #pragma unroll
   for (int c2 = 0; c2 < DH / 2; ++c2) {
@@ -324,9 +340,14 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(AttnArgs a, const 
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool ok = j0 + frag_row(r, hi) < T && i < T;
-      const float p = ok ? expf(s[r] * a.scale - L) : 0.f;
-      dp[r] = p * (dp[r] - dl);
+      const int jx = j0 + frag_row(r, hi);
+      const bool ok = jx < T && i < T;
+      float sv = s[r] * a.scale;
+      if (a.lengths && (qpad || jx >= len)) sv += -1e4f;
+      const float p = ok ? expf(sv - L) : 0.f;
+      float mf = 1.f;
+      if constexpr (DROP) mf = sty_hash_u(a.drop_seed, a.drop_site, rowi + (unsigned)jx) >= a.drop_p ? inv_keep : 0.f;
+      dp[r] = p * (dp[r] * mf - dl);
     }
 #pragma unroll
     for (int n = 0; n < NB; ++n)
@@ -510,10 +531,16 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnArgs a, const f
 
 size_t attention_bwd_ws_floats(int B, int H, int T) { return (size_t)2 * B * H * T; }
 
+// the fp32 matrix-core backward: head dims that are multiples of 32, the forward's row log-sum-exp kept (AttnArgs::lse)
+bool attention_bwd_mfma_dh(int DH) {
+  static const bool off = getenv("STY_NO_ATTN_BWD_MFMA") != nullptr;
+  return !off && (DH == 64 || DH == 96 || DH == 160);
+}
+static bool attn_bwd_mfma_path(const AttnArgs& a, int DH) { return a.lse && attention_bwd_mfma_dh(DH); }
 static bool attn_bwd_small_path(const AttnArgs& a, int DH) {
   static const bool no_small = getenv("STY_NO_ATTN_BWD_SMALL") != nullptr;
   if (attention16_eligible(a, DH) && a.lse) return false;
-  if (DH == 64 && a.lse && !a.lengths && a.drop_p <= 0.f) return false;
+  if (attn_bwd_mfma_path(a, DH)) return false;
   return DH == 16 && a.T <= 128 && !no_small;
 }
 // true: launch_attention_bwd can take `overwrite` bits for this problem (the one-workgroup-per-(batch, head) kernel writes every
@@ -532,12 +559,28 @@ int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* d
     return launch_attention16_bwd(a, dO, dQ, dK, dV, dqbs, dkbs, dvbs, dobs, B, ws, st);
   float* lse = ws;
   float* delta = ws + (size_t)B * a.H * a.T;
-  if (DH == 64 && a.lse && !a.lengths && a.drop_p <= 0.f) {  // matrix-core path; lse kept by the forward kernel
+  if (attn_bwd_mfma_path(a, DH)) {  // matrix-core path; lse kept by the forward kernel
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a.T, 256), a.H, B), dim3(256), 0, st, a.o, a.obs, dO, dobs, a.H, DH,
                        a.T, delta);
     dim3 g2(cdiv(a.T, 128), a.H, B);
-    hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel<64>, g2, dim3(256), 0, st, a, dO, dobs, a.lse, delta, dK, dkbs, dV, dvbs);
-    hipLaunchKernelGGL(attn_bwd_q_mfma_kernel<64>, g2, dim3(256), 0, st, a, dO, dobs, a.lse, delta, dQ, dqbs);
+#define STY_ABWD_MFMA(DHV, DR)                                                                                                      \
+  hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<DHV, DR>), g2, dim3(256), 0, st, a, dO, dobs, a.lse, delta, dK, dkbs, dV, dvbs);       \
+  hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<DHV, DR>), g2, dim3(256), 0, st, a, dO, dobs, a.lse, delta, dQ, dqbs)
+    const bool dr = a.drop_p > 0.f;
+    if (DH == 64 && !dr) {
+      STY_ABWD_MFMA(64, false);
+    } else if (DH == 64) {
+      STY_ABWD_MFMA(64, true);
+    } else if (DH == 96 && !dr) {
+      STY_ABWD_MFMA(96, false);
+    } else if (DH == 96) {
+      STY_ABWD_MFMA(96, true);
+    } else if (!dr) {
+      STY_ABWD_MFMA(160, false);
+    } else {
+      STY_ABWD_MFMA(160, true);
+    }
+#undef STY_ABWD_MFMA
     STY_LAUNCH_CHECK();
     return STY_OK;
   }

@@ -589,9 +589,53 @@ __global__ void pd_gz_kernel(const float* __restrict__ gs, const float* __restri
   }
   gz[o] = v * (a[o] > 0.f ? 1.f : SD_SLOPE);
 }
-// acc[c*K + k] += sum_{b,t} a[b][c][t + k - pad] gs[b][t];  acc[64*K] += sum gs   (one thread per entry; doubles)
-__global__ void pd_score_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ gs, int B, int T, int K,
-                                      double* __restrict__ acc) {
+// acc[c*K + k] += sum_{b,t} a[b][c][t + k - pad] gs[b][t];  acc[64*K] += sum gs   (doubles)
+// One workgroup per input channel c (all K taps) and one more for the bias: a thread walks the flattened (b, t) axis with
+// stride 256 and keeps the K tap sums of its positions; the 256 partial sums of a tap are added in a fixed order (a tree over
+// thread indices), so the result does not depend on scheduling.  (Until the end of round 6: one THREAD per entry looping over
+// all B x T positions -- 2.0 ms per launch at c3, ten launches per `train_textual` step: 20 of its 101 ms.)
+template <int KT>
+__global__ __launch_bounds__(256) void pd_score_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ gs, int B, int T,
+                                                            double* __restrict__ acc) {
+  __shared__ double red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int pad = KT / 2, n = B * T;
+  double s[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) s[k] = 0.0;
+  if (c == PD_C) {  // bias: sum of gs
+    for (int j = tid; j < n; j += 256) s[0] += (double)gs[j];
+  } else {
+    for (int j = tid; j < n; j += 256) {
+      const int b = j / T, t = j - b * T;
+      const float* row = a + ((size_t)b * PD_C + c) * T;
+      const double g = (double)gs[j];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int ts = t + k - pad;
+        if (ts >= 0 && ts < T) s[k] += (double)row[ts] * g;
+      }
+    }
+  }
+  const int nk = c == PD_C ? 1 : KT;
+  for (int k = 0; k < nk; ++k) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+      if (q == k) v = s[q];  // (compile-time indices only: s stays in registers)
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) acc[(c == PD_C ? PD_C * KT : c * KT) + k] += red[0];
+    __syncthreads();
+  }
+}
+// any other tap count: one thread per entry (the first form)
+__global__ void pd_score_wgrad_generic_kernel(const float* __restrict__ a, const float* __restrict__ gs, int B, int T, int K,
+                                              double* __restrict__ acc) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i > PD_C * K) return;
   const int pad = K / 2;
@@ -610,6 +654,14 @@ __global__ void pd_score_wgrad_kernel(const float* __restrict__ a, const float* 
     }
   }
   acc[i] += s;
+}
+static void launch_pd_score_wgrad(const float* a, const float* gs, int B, int T, int K, double* acc, hipStream_t st) {
+  if (K == 21)
+    hipLaunchKernelGGL(pd_score_wgrad_kernel<21>, dim3(PD_C + 1), dim3(256), 0, st, a, gs, B, T, acc);
+  else if (K == 5)
+    hipLaunchKernelGGL(pd_score_wgrad_kernel<5>, dim3(PD_C + 1), dim3(256), 0, st, a, gs, B, T, acc);
+  else
+    hipLaunchKernelGGL(pd_score_wgrad_generic_kernel, dim3(cdiv(PD_C * K + 1, 64)), dim3(64), 0, st, a, gs, B, T, K, acc);
 }
 
 struct PdRun : DiscBase {
@@ -687,7 +739,7 @@ struct PdRun : DiscBase {
       const ConvArgs f = conv_args(i, i == 0 ? ac.x : ac.a[i - 1], nullptr);
       if (gwp) {
         if (live())
-          hipLaunchKernelGGL(pd_score_wgrad_kernel, dim3(cdiv(PD_C * K + 1, 64)), dim3(64), 0, st, ac.a[i], gs[i], B, T, K, sacc[i]);
+          launch_pd_score_wgrad(ac.a[i], gs[i], B, T, K, sacc[i], st);
         float* partial = take<float>(wgrad_partial_floats(f.w, B, T));
         bool done = false;
         if (live()) chk(launch_conv1d_wgrad(f, gz, nullptr, 1.f, gwp[i], partial, gbp[i], &done, st));

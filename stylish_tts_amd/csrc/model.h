@@ -333,6 +333,7 @@ int launch_unpack_grad(const float* gwp, const float* g, const float* v, int Cou
 int launch_attention_bwd(const AttnArgs& a, const float* dO, float* dQ, float* dK, float* dV, size_t dqbs, size_t dkbs,
                          size_t dvbs, size_t dobs, int B, int DH, float* ws, hipStream_t st, int overwrite = 0);
 bool attention_bwd_can_overwrite(const AttnArgs& a, int DH);
+bool attention_bwd_mfma_dh(int DH);
 size_t attention_bwd_ws_floats(int B, int H, int T);
 int launch_rope_signed(float* q, float* k, int B, int H, int DH, int L, int d, const float* theta4, float sgn,
                        hipStream_t st);

@@ -1205,6 +1205,8 @@ struct Trainer {
       at.drop_seed = m->topts.dropout_seed;
       at.drop_site = drop_site++;
     }
+    // head dims the matrix-core backward takes (the prosody encoder's 2 x 160): the forward keeps its row log-sum-exp
+    if (attention_bwd_mfma_dh(Hd / heads)) at.lse = take<float>((size_t)B * heads * L);
     if (live()) chk(launch_attention(at, B, Hd / heads, st));
     tape.push_back([=]() {
       float* gO = G(o, n);

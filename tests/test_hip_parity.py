@@ -548,13 +548,15 @@ def test_convnext32_backward_with_the_input_gradient_fused_equals_the_separate_k
     rep.done()
 
 
-@pytest.mark.parametrize("DH,T,masked", [(16, 40, True), (16, 100, True), (64, 160, False), (64, 520, False)])
+@pytest.mark.parametrize("DH,T,masked", [(16, 40, True), (16, 100, True), (64, 160, False), (64, 520, False),
+                                         (160, 200, True), (160, 520, True), (96, 77, True), (64, 160, True)])
 def test_attention_backward_vs_float64(DH, T, masked):
-    """sty_attention_fwd_bwd: the text encoder's masked attention (DH = 16, VALU backward kernels attn_bwd_{a,b,c}) and
-    the conformer's (DH = 64, MFMA backward attn_bwd_{kv,q}_mfma) vs float64 softmax attention: o, dq, dk, dv."""
+    """sty_attention_fwd_bwd: the text encoder's masked attention (DH = 16, VALU backward kernels attn_bwd_{a,b,c}), the
+    conformer's (DH = 64, MFMA backward attn_bwd_{kv,q}_mfma) and the prosody encoder's (2 heads x 160 / 96 with the length
+    mask, the same MFMA backward since round 6) vs float64 softmax attention: o, dq, dk, dv."""
     from stylish_tts_amd import lib as L
     lib = L.load()
-    B, H = 3, 8
+    B, H = 3, (8 if DH <= 64 else 2)
     g = torch.Generator().manual_seed(DH + T)
     q, k, v, do = (torch.randn(B, H * DH, T, generator=g) for _ in range(4))
     lengths = torch.tensor([T, max(1, T - 7), max(1, T // 2)]) if masked else None
