@@ -265,6 +265,10 @@ int launch_chan_layernorm(const float* x, float* y, int B, int C, int T, float e
     STY_LN_CASE(16)
     STY_LN_CASE(32)
     STY_LN_CASE(64)
+    STY_LN_CASE(80)   // 320: the prosody encoder's 256 + 64 channels (it fell to the one-thread-per-column kernel below: 164 us per
+                      // launch at B = 8, T = 182 -- 24 workgroups of one wave walking 320 rows three times -- 7 % of a `tts` forward)
+    STY_LN_CASE(96)
+    STY_LN_CASE(128)
     default:
       hipLaunchKernelGGL(chan_layernorm_kernel, grid, dim3(64), 0, st, x, y, C, T, eps, ada, w, bvec, gb, relu,
                          out_mask);
