@@ -23,7 +23,11 @@ namespace {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int A16_PK = 72;  // halfs per row of a "row" tile (64 d + 8): 144-byte pitch
-constexpr int A16_PV = 40;  // halfs per row of a "col" tile (32 positions + 8): 80-byte pitch
+#ifndef A16_PV_HALFS
+#define A16_PV_HALFS 36
+#endif
+constexpr int A16_PV = A16_PV_HALFS;  // halfs per row of a "col" tile (32 positions + 4): 72-byte pitch = 18 dwords -- the 32 rows of a half-wave's
+                                       // ds_read_b64 fall on 32 distinct bank pairs (80 bytes = 20 dwords: rows d and d + 16 collided)
 
 __device__ __forceinline__ int a16_frag_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 __device__ __forceinline__ bf16x8 a16_pack(const f32x16& v, int s) {
