@@ -560,20 +560,27 @@ __global__ void pd_add_kernel(const float* __restrict__ src, size_t n, float* __
   if (i < n) dst[i] += src[i];
 }
 // score conv 64 -> 1, k taps: s[b][t] = bias + sum_ci sum_k w[ci][k] a[b][ci][t + k - pad]
-__global__ void pd_score_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bs, int T,
-                                int K, float* __restrict__ s) {
-  const int t = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
-  if (t >= T) return;
+// 64 time columns per workgroup, four waves: wave w sums channels 16 w .. 16 w + 15, the four partial sums are added in a fixed
+// order (round 6: one wave walking all 64 x K products took 157 us per launch at c3 -- 288 single-wave workgroups)
+__global__ __launch_bounds__(256) void pd_score_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                      const float* __restrict__ bs, int T, int K, float* __restrict__ s) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane, b = blockIdx.y;
   const int pad = K / 2;
-  float acc = bs[0];
-  for (int ci = 0; ci < PD_C; ++ci) {
-    const float* row = a + ((size_t)b * PD_C + ci) * T;
-    for (int k = 0; k < K; ++k) {
-      const int ts = t + k - pad;
-      if (ts >= 0 && ts < T) acc = fmaf(w[ci * K + k], row[ts], acc);
+  float acc = 0.f;
+  if (t < T) {
+    for (int ci = 16 * wave; ci < 16 * wave + 16; ++ci) {
+      const float* row = a + ((size_t)b * PD_C + ci) * T;
+      for (int k = 0; k < K; ++k) {
+        const int ts = t + k - pad;
+        if (ts >= 0 && ts < T) acc = fmaf(w[ci * K + k], row[ts], acc);
+      }
     }
   }
-  s[(size_t)b * T + t] = acc;
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && t < T) s[(size_t)b * T + t] = bs[0] + ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 // gz = (score-conv backward of gs + dnext) * LeakyReLU'(a)
 __global__ void pd_gz_kernel(const float* __restrict__ gs, const float* __restrict__ w, const float* __restrict__ a,
@@ -600,13 +607,16 @@ __global__ __launch_bounds__(256) void pd_score_wgrad_kernel(const float* __rest
   __shared__ double red[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   const int pad = KT / 2, n = B * T;
+  // blockIdx.y: one of gridDim.y slices of the (b, t) axis (65 workgroups alone leave three quarters of the chip idle: 174 us per
+  // launch at c3); the slices meet in the double-precision accumulator through atomics -- their order moves the 17th digit
+  const int j0 = (int)(((long long)blockIdx.y * n) / gridDim.y), j1 = (int)(((long long)(blockIdx.y + 1) * n) / gridDim.y);
   double s[KT];
 #pragma unroll
   for (int k = 0; k < KT; ++k) s[k] = 0.0;
   if (c == PD_C) {  // bias: sum of gs
-    for (int j = tid; j < n; j += 256) s[0] += (double)gs[j];
+    for (int j = j0 + tid; j < j1; j += 256) s[0] += (double)gs[j];
   } else {
-    for (int j = tid; j < n; j += 256) {
+    for (int j = j0 + tid; j < j1; j += 256) {
       const int b = j / T, t = j - b * T;
       const float* row = a + ((size_t)b * PD_C + c) * T;
       const double g = (double)gs[j];
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(256) void pd_score_wgrad_kernel(const float* __rest
       if (tid < o) red[tid] += red[tid + o];
       __syncthreads();
     }
-    if (tid == 0) acc[(c == PD_C ? PD_C * KT : c * KT) + k] += red[0];
+    if (tid == 0) atomicAdd(&acc[(c == PD_C ? PD_C * KT : c * KT) + k], red[0]);
     __syncthreads();
   }
 }
@@ -657,9 +667,9 @@ __global__ void pd_score_wgrad_generic_kernel(const float* __restrict__ a, const
 }
 static void launch_pd_score_wgrad(const float* a, const float* gs, int B, int T, int K, double* acc, hipStream_t st) {
   if (K == 21)
-    hipLaunchKernelGGL(pd_score_wgrad_kernel<21>, dim3(PD_C + 1), dim3(256), 0, st, a, gs, B, T, acc);
+    hipLaunchKernelGGL(pd_score_wgrad_kernel<21>, dim3(PD_C + 1, 8), dim3(256), 0, st, a, gs, B, T, acc);
   else if (K == 5)
-    hipLaunchKernelGGL(pd_score_wgrad_kernel<5>, dim3(PD_C + 1), dim3(256), 0, st, a, gs, B, T, acc);
+    hipLaunchKernelGGL(pd_score_wgrad_kernel<5>, dim3(PD_C + 1, 8), dim3(256), 0, st, a, gs, B, T, acc);
   else
     hipLaunchKernelGGL(pd_score_wgrad_generic_kernel, dim3(cdiv(PD_C * K + 1, 64)), dim3(64), 0, st, a, gs, B, T, K, acc);
 }
@@ -726,7 +736,7 @@ struct PdRun : DiscBase {
       if (!live()) continue;
       chk(launch_conv1d(conv_args(i, i == 0 ? x : ac.a[i - 1], ac.a[i]), st));
       hipLaunchKernelGGL(sd_post_kernel, dim3(cdiv(T, 256), PD_C, B), dim3(256), 0, st, ac.a[i], T, T, (float*)nullptr);
-      hipLaunchKernelGGL(pd_score_kernel, dim3(cdiv(T, 64), B), dim3(64), 0, st, ac.a[i], sw[i], sw[i] + PD_C * K, T, K, ac.s[i]);
+      hipLaunchKernelGGL(pd_score_kernel, dim3(cdiv(T, 64), B), dim3(256), 0, st, ac.a[i], sw[i], sw[i] + PD_C * K, T, K, ac.s[i]);
     }
   }
   void backward(const Acts& ac, float* const gs[5], float* const gwp[5], float* const gbp[5], double* const sacc[5], float* dx) {
