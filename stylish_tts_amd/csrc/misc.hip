@@ -1,4 +1,6 @@
 // Small data-movement / glue kernels of the text-encoder and decoder paths.
+#include <stdlib.h>
+
 #include "sty_common.h"
 
 namespace sty {
@@ -49,9 +51,70 @@ __global__ __launch_bounds__(256) void bmm_ct_kernel(const float* __restrict__ e
   for (int l = 0; l < L; ++l) acc = fmaf(es[cw * L + l], a[(size_t)l * T], acc);
   y[((size_t)b * C + c0 + cw) * T + t] = acc;
 }
+// The same product on the fp32 matrix cores (round 6; L % 4 == 0 and T % 4 == 0: 16-byte aligned rows): a workgroup owns 32
+// channels x 128 frames, wave w the frames 32 w .. 32 w + 31; the reduction over tokens runs in chunks of 32 staged through LDS
+// (A = the enc tile, rows c; B = the alignment tile, columns t), the next chunk's five float4 per thread requested ahead.
+// With a 0 / 1 alignment every output has one non-zero product: the result equals the fmaf chain's bit for bit.
+__global__ __launch_bounds__(256) void bmm_ct_mfma_kernel(const float* __restrict__ enc, const float* __restrict__ ali, int C, int L,
+                                                         int T, float* __restrict__ y) {
+  constexpr int PE = 33, PA = 160;  // (PA = 32 mod 64: the two k rows a wave reads in one ds_read fall on different bank halves)
+  __shared__ __attribute__((aligned(16))) float es[32 * PE];
+  __shared__ __attribute__((aligned(16))) float as[32 * PA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int t0 = blockIdx.x * 128, c0 = blockIdx.y * 32, b = blockIdx.z;
+  const float* eb = enc + ((size_t)b * C + c0) * L;
+  const float* ab = ali + (size_t)b * L * T + t0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 nx[5];
+  auto fetch = [&](int l0) {
+    {  // enc tile: 32 rows x 32 tokens = 256 float4
+      const int r = tid >> 3, ll = l0 + (tid & 7) * 4;
+      nx[0] = (c0 + r < C && ll < L) ? *reinterpret_cast<const float4*>(eb + (size_t)r * L + ll) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // alignment tile: 32 tokens x 128 frames = 1 024 float4
+      const int e = tid + 256 * i, r = e >> 5, tt = (e & 31) * 4;
+      nx[1 + i] = (l0 + r < L && t0 + tt < T) ? *reinterpret_cast<const float4*>(ab + (size_t)(l0 + r) * T + tt)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(0);
+  for (int l0 = 0; l0 < L; l0 += 32) {
+    __syncthreads();
+    {
+      float* d = es + (tid >> 3) * PE + (tid & 7) * 4;
+      d[0] = nx[0].x, d[1] = nx[0].y, d[2] = nx[0].z, d[3] = nx[0].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      *reinterpret_cast<float4*>(as + (e >> 5) * PA + (e & 31) * 4) = nx[1 + i];
+    }
+    __syncthreads();
+    if (l0 + 32 < L) fetch(l0 + 32);
+    const float* ea = es + l31 * PE + hi;
+    const float* aa = as + hi * PA + wave * 32 + l31;
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[k], aa[k * PA], acc, 0, 0, 0);
+  }
+  const int t = t0 + wave * 32 + l31;
+  if (t < T) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (c < C) y[((size_t)b * C + c) * T + t] = acc[r];
+    }
+  }
+}
 int launch_bmm_ct(const float* enc, const float* ali, int B, int C, int L, int T, float* y, hipStream_t st) {
-  hipLaunchKernelGGL(bmm_ct_kernel, dim3(cdiv(T, 64), cdiv(C, 4), B), dim3(256), 4 * L * sizeof(float), st, enc, ali,
-                     C, L, T, y);
+  static const bool no_mfma = getenv("STY_NO_BMM_MFMA") != nullptr;
+  if (!no_mfma && L % 4 == 0 && T % 4 == 0)
+    hipLaunchKernelGGL(bmm_ct_mfma_kernel, dim3(cdiv(T, 128), cdiv(C, 32), B), dim3(256), 0, st, enc, ali, C, L, T, y);
+  else
+    hipLaunchKernelGGL(bmm_ct_kernel, dim3(cdiv(T, 64), cdiv(C, 4), B), dim3(256), 4 * L * sizeof(float), st, enc, ali,
+                       C, L, T, y);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
@@ -202,8 +265,83 @@ __global__ __launch_bounds__(64) void bmm_ct_bwd_kernel(const float* __restrict_
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) denc[((size_t)b * C + c) * L + l] += acc;
 }
+// The same contraction on the fp32 matrix cores (round 6): denc[b][c][l] += sum_t g[b][c][t] ali[b][l][t] is a [32 c] x [128 l]
+// x [T] GEMM per workgroup -- A = a g tile (rows c, reduction t), B = the alignment tile (columns l), both staged through LDS in
+// 64-frame chunks with coalesced loads, one 32 x 32 accumulator per wave (wave w: tokens 32 w .. 32 w + 31).  The one-wave-per-
+// output kernel above launches L x C x B = 1.6 M single-wave workgroups at c3 (224 us on the chain in front of the text
+// encoder's backward, 312 us twice per `train_textual` step).  v_mfma_f32_32x32x2_f32: fp32 products and sums, as the fmaf chain.
+constexpr int BMM_TT = 64, BMM_P = BMM_TT + 1;
+__global__ __launch_bounds__(256) void bmm_ct_bwd_mfma_kernel(const float* __restrict__ g, const float* __restrict__ ali, int C,
+                                                             int L, int T, float* __restrict__ denc) {
+  __shared__ float gs[32 * BMM_P], as[128 * BMM_P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int c0 = blockIdx.x * 32, b = blockIdx.y;
+  const float* gb = g + ((size_t)b * C + c0) * T;
+  const float* ab = ali + (size_t)b * L * T;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // a chunk = 160 rows (32 of g, 128 of the alignment) x 64 frames = 2 560 float4: ten per thread, requested one chunk ahead
+  // (T % 4 == 0: rows are 16-byte aligned and a float4 is inside the row or past its end; otherwise element loads)
+  const bool v4 = (T & 3) == 0;
+  float4 nx[10];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int e = tid + 256 * i, r = e >> 4, tt = (e & 15) * 4, t = t0 + tt;
+      const bool isg = r < 32;
+      const int row = isg ? r : r - 32;
+      const bool ok = isg ? (c0 + row < C) : (row < L);
+      const float* src = (isg ? gb : ab) + (size_t)row * T + t;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok && t < T) {
+        if (v4) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (t + 1 < T) v.y = src[1];
+          if (t + 2 < T) v.z = src[2];
+          if (t + 3 < T) v.w = src[3];
+        }
+      }
+      nx[i] = v;
+    }
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < T; t0 += BMM_TT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int e = tid + 256 * i, r = e >> 4, tt = (e & 15) * 4;
+      float* dst = (r < 32 ? gs + r * BMM_P : as + (r - 32) * BMM_P) + tt;
+      dst[0] = nx[i].x;
+      dst[1] = nx[i].y;
+      dst[2] = nx[i].z;
+      dst[3] = nx[i].w;
+    }
+    __syncthreads();
+    if (t0 + BMM_TT < T) fetch(t0 + BMM_TT);
+    const float* ga = gs + l31 * BMM_P + hi;
+    const float* aa = as + (wave * 32 + l31) * BMM_P + hi;
+#pragma unroll 8
+    for (int k = 0; k < BMM_TT; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[k], aa[k], acc, 0, 0, 0);
+  }
+  // accumulator: rows (c) in registers, columns (l) across lanes
+  const int l = wave * 32 + l31;
+  if (l < L) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (c < C) denc[((size_t)b * C + c) * L + l] += acc[r];
+    }
+  }
+}
 int launch_bmm_ct_bwd(const float* g, const float* ali, int B, int C, int L, int T, float* denc, hipStream_t st) {
-  hipLaunchKernelGGL(bmm_ct_bwd_kernel, dim3(L, C, B), dim3(64), 0, st, g, ali, C, L, T, denc);
+  static const bool no_mfma = getenv("STY_NO_BMM_MFMA") != nullptr;
+  if (L <= 128 && !no_mfma)
+    hipLaunchKernelGGL(bmm_ct_bwd_mfma_kernel, dim3(cdiv(C, 32), B), dim3(256), 0, st, g, ali, C, L, T, denc);
+  else
+    hipLaunchKernelGGL(bmm_ct_bwd_kernel, dim3(L, C, B), dim3(64), 0, st, g, ali, C, L, T, denc);
   STY_LAUNCH_CHECK();
   return STY_OK;
 }
