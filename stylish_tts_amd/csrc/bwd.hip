@@ -1508,7 +1508,10 @@ __global__ __launch_bounds__(256) void style_fc_bwd_kernel(const StyleFcBwdDesc*
                                                            float* __restrict__ dstyle) {
   const StyleFcBwdDesc d = descs[blockIdx.x];
   const float* dgb = dgb_base + d.off * B;
-  const int tid = blockIdx.y * 256 + threadIdx.x, nthr = SFC_SLICES * 256;
+  // blockIdx.z: a group of utterances for the d style part (round 6: the widest layer's 2 048 rows were 32 rounds of eight loads
+  // for each of a wave's eight utterances -- 217 us in front of d loss / d style; with four groups a wave has two); the two
+  // parameter loops spread over all workgroups of the layer
+  const int tid = (blockIdx.z * SFC_SLICES + blockIdx.y) * 256 + threadIdx.x, nthr = gridDim.z * SFC_SLICES * 256;
   // parameter grads: thread per (j, k)
   for (int i = tid; i < d.n * style_dim; i += nthr) {
     const int j = i / style_dim, k = i % style_dim;
@@ -1526,7 +1529,7 @@ __global__ __launch_bounds__(256) void style_fc_bwd_kernel(const StyleFcBwdDesc*
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // (four independent chains, eight loads in flight: the one-chain form was 2 048 dependent load -> fma steps on the
     // widest layer, 0.27 ms alone, and this kernel is the last thing in front of d loss / d style)
-    for (int b = wave; b < B; b += 4) {
+    for (int b = wave + 4 * blockIdx.z; b < B; b += 4 * gridDim.z) {
       float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
       if (lane < style_dim) {
         const float* gr = dgb + (size_t)b * d.n;
@@ -1560,7 +1563,7 @@ int launch_style_fc_bwd(const void* descs_dev, int nlayers, int B, int style_dim
     set_error("style_fc_bwd: style_dim %d > 64", style_dim);
     return STY_EINVAL;
   }
-  hipLaunchKernelGGL(style_fc_bwd_kernel, dim3(nlayers, SFC_SLICES), dim3(256), 0, st, (const StyleFcBwdDesc*)descs_dev, style_dim,
+  hipLaunchKernelGGL(style_fc_bwd_kernel, dim3(nlayers, SFC_SLICES, 4), dim3(256), 0, st, (const StyleFcBwdDesc*)descs_dev, style_dim,
                      style, dgb_base, B, dstyle);
   STY_LAUNCH_CHECK();
   return STY_OK;
